@@ -1,0 +1,177 @@
+/*
+ * u3d.h — C-ABI of the MI355X-native (gfx950) 3D U-Net forward/backward hot path.
+ *
+ * This is the drop-in boundary of SURVEY.md §8(b).  The reference (wolny/pytorch-3dunet 1.9.6) has
+ * NO FFI of its own: its hot path bottoms out in torch.nn modules that dispatch into ATen.  Every
+ * entry point below therefore cites the reference call site (file:line under /root/reference) whose
+ * ATen operator it replaces.  A maintainer of the reference binds these with ctypes (see
+ * INTEGRATION.md for the stub); our host-side mirror is pytorch-3dunet_amd/pytorch3dunet_amd.
+ *
+ * Conventions
+ *   - plain C, POD arguments only: raw device pointers, ints, a hipStream_t passed as void*.
+ *   - every function returns 0 on success or a negative U3D_E* code; the message is available from
+ *     u3d_last_error() (thread-local).  Nothing throws or aborts across the ABI.
+ *   - kernels are enqueued asynchronously on `stream`; the library never synchronises, never
+ *     allocates or frees user-visible memory and keeps no pointer beyond a call.
+ *   - re-entrant and thread-safe (autograd worker threads, nn.DataParallel replica threads).
+ *   - all activations are fp32, channels-last "NDHWC": elem(n,z,y,x,c) = ((n*D+z)*H+y)*W+x)*C + c.
+ *     (For in_channels == out_channels == 1 this is byte-identical to the reference's NCDHW.)
+ *   - N*D*H*W must be < 2^31.
+ */
+#ifndef U3D_H
+#define U3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define U3D_VERSION 100 /* 0.1.0 */
+
+#define U3D_OK 0
+#define U3D_EINVAL (-1)  /* bad shape / argument */
+#define U3D_EHIP (-2)    /* a HIP runtime call failed */
+#define U3D_EARCH (-3)   /* device is not gfx950 */
+#define U3D_EWORKSPACE (-4) /* workspace too small */
+
+typedef void* u3d_stream_t; /* hipStream_t */
+
+/* A (possibly virtual) activation tensor read by the conv / stats / GN-backward kernels.
+ *
+ * Channels [0,C0) come from p0 at full resolution (N,D,H,W,C0).  Channels [C0,C0+C1) come from p1, a
+ * LOW-resolution tensor (N,D1,H1,W1,C1) read through nearest-neighbour index maps — this is the
+ * never-materialised `torch.cat((encoder_features, F.interpolate(x, size, mode="nearest")), dim=1)` of
+ * buildingblocks.py:491 + :614 (skip channels first).  zmap/ymap/xmap are device int32 tables of length
+ * D/H/W giving the source index (host computes them with PyTorch's float32 formula
+ * min(floor(dst * (in/out)), in-1)).  C1 == 0 => plain tensor.
+ *
+ * affine, if non-NULL, is the fused GroupNorm apply of buildingblocks.py:75 in 'gcr' order: a device
+ * table [N][C0+C1][2] of (a,b) with value = x*a + b, produced by u3d_gn_finalize.  Zero padding of the
+ * convolution is applied AFTER the affine (padded taps contribute exactly 0), matching
+ * nn.Conv3d(padding=1) applied to the GroupNorm output. */
+typedef struct {
+    const float* p0;
+    const float* p1;
+    const int32_t* zmap;
+    const int32_t* ymap;
+    const int32_t* xmap;
+    const float* affine;
+    int32_t C0, C1;
+    int32_t D1, H1, W1;
+} u3d_src_t;
+
+/* ---- library ------------------------------------------------------------------------------- */
+int u3d_version(void);
+const char* u3d_last_error(void);
+/* 0 if `device` is a gfx950 part, U3D_EARCH otherwise. */
+int u3d_check_device(int device);
+
+/* ---- weight packing -------------------------------------------------------------------------
+ * Reference weights stay nn.Parameters in (Cout,Cin,3,3,3) layout (checkpoint compatibility,
+ * utils.py:36-65).  The MFMA kernels read a packed image [chunk][tap][s][ntile][lane][4]:
+ *   mode 0 (forward):  B[k=(tap,c)][n=cout]      = w[cout][c][tap]
+ *   mode 1 (dgrad):    B[k=(tap,cout)][n=c]      = w[cout][c][26-tap]   (flipped taps, swapped roles)
+ * u3d_packed_weight_floats gives the size of the image in floats for (Cin,Cout,mode). */
+size_t u3d_packed_weight_floats(int Cin, int Cout, int mode);
+int u3d_pack_weights(int device, u3d_stream_t stream, const float* w, int Cout, int Cin, int mode, float* packed);
+
+/* ---- Conv3d 3x3x3, stride 1, pad 1, bias=False ------------------------------------------------
+ * Replaces nn.Conv3d(in,out,3,padding=1,bias=False) (buildingblocks.py:56) forward, and — called with
+ * mode-1 packed weights on dy — its data gradient (autograd of trainer.py:245).  Implicit GEMM on
+ * v_mfma_f32_32x32x2_f32: M = 256-voxel tile (4x8x8), N = 32/64 output channels, K = 27*Cin, input halo
+ * tile staged through LDS with the GroupNorm affine fused into the load.
+ *
+ *   out        (N,D,H,W,Cout) fp32
+ *   relu       apply max(v,0) in the epilogue (nn.ReLU, buildingblocks.py:47)
+ *   out_stats  optional device double[N][Cout][2]: += per-(n,channel) sum and sum of squares of the
+ *              written outputs (feeds the next GroupNorm without re-reading the activation)
+ *   gx/gstats  optional (dgrad use): gx is the layer's forward input (pre-GroupNorm, virtual concat
+ *              allowed; its affine field is ignored); gstats double[N][Cout][2] += (sum dg, sum dg*x) —
+ *              the two reductions GroupNorm backward needs.
+ */
+int u3d_conv3d(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w, float* out,
+               int N, int D, int H, int W, int Cout, int relu, double* out_stats, const u3d_src_t* gx,
+               double* gstats);
+
+/* Weight gradient of the same convolution: dw[cout][cin][tap] = sum_{n,v} dz[n,v,cout] * g[n,v+tap,cin]
+ * with g = src (GroupNorm affine fused on load, zero padded).  Split-K over voxel tiles with a
+ * deterministic two-pass reduction.  workspace must hold u3d_wgrad_workspace_floats() floats.
+ * dw is written (not accumulated) in the reference layout (Cout,Cin,3,3,3). */
+size_t u3d_wgrad_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
+int u3d_conv3d_wgrad(int device, u3d_stream_t stream, const u3d_src_t* src, const float* dz, float* dw, int N,
+                     int D, int H, int W, int Cout, float* workspace, size_t workspace_floats);
+
+/* Straightforward one-thread-per-output direct convolution (same semantics as u3d_conv3d with the
+ * reference (Cout,Cin,27) weights, no packing).  Test/debug aid used to cross-check the MFMA kernel
+ * on the device at sizes where the CPU oracle is slow.  flip=1 computes the data gradient. */
+int u3d_conv3d_naive(int device, u3d_stream_t stream, const u3d_src_t* src, const float* w, float* out, int N,
+                     int D, int H, int W, int Cin, int Cout, int relu, int flip);
+
+/* ---- GroupNorm (nn.GroupNorm(G,C,eps=1e-5), buildingblocks.py:62-75) -------------------------
+ * Statistics are per-(n,channel) sums accumulated in double (order-insensitive to < 1 ulp of fp32):
+ *   u3d_chan_stats   stats[N][C][2] += (sum x, sum x^2) over all voxels of a (virtual) tensor
+ *   u3d_gn_finalize  per (n,group) mean / biased var from up to two stat blocks (channels [0,C0) from
+ *                    stats0 scaled by scale0, [C0,C0+C1) from stats1 scaled by scale1 — scale = 8 reuses
+ *                    the low-res producer's sums for an exact 2x nearest upsampling), `count` voxels.
+ *                    Writes affine[N][C][2] = (rstd*gamma, beta - mean*rstd*gamma) and mean_rstd[N][G][2].
+ */
+int u3d_chan_stats(int device, u3d_stream_t stream, const u3d_src_t* src, int N, int D, int H, int W,
+                   double* stats);
+int u3d_gn_finalize(int device, u3d_stream_t stream, const double* stats0, int C0, double scale0,
+                    const double* stats1, int C1, double scale1, int N, int G, double count, const float* gamma,
+                    const float* beta, float eps, float* affine, float* mean_rstd);
+
+/* GroupNorm backward, reduction part.  gstats[N][C][2] = (sum dg, sum dg*x) from u3d_conv3d.
+ * Writes dgamma[C], dbeta[C] (summed over n) and the coefficient table coef[N][3][C] = (p,q,r) such that
+ *   dx = p*dg + q*x + r        (the whole of GroupNorm backward is this per-(n,channel) affine map). */
+int u3d_gn_bwd_finalize(int device, u3d_stream_t stream, const double* gstats, const float* mean_rstd,
+                        const float* gamma, int N, int C, int G, double count, float* dgamma, float* dbeta,
+                        float* coef);
+
+/* GroupNorm backward, elementwise part (+ fused ReLU backward of the producer, buildingblocks.py:47):
+ *   out[n,v,c] = (p*dg[n,v,coff+c] + q*x[n,v,c] + r) * (relu_mask ? x>0 : 1),   c in [0,Cx)
+ * dg has Cdg channels (Cdg > Cx for the skip half of a concat), x/out have Cx channels. */
+int u3d_gn_bwd_apply(int device, u3d_stream_t stream, const float* dg, int Cdg, int coff, const float* x, int Cx,
+                     const float* coef, int Ctot, int64_t voxels_per_n, int N, int relu_mask, float* out);
+
+/* Same for the upsampled half of a concat: the backward of F.interpolate(nearest) (buildingblocks.py:614)
+ * is a sum over the children of each low-res voxel, fused with the affine map and the ReLU mask of the
+ * low-res producer:  out[n,v1,c] = (p*sum_children dg[.,coff+c] + cnt*(q*x1 + r)) * (x1>0).
+ * zlo/ylo/xlo are device int32 tables of length D1+1/H1+1/W1+1: children of v1 are [lo[i], lo[i+1]). */
+int u3d_gn_bwd_apply_up(int device, u3d_stream_t stream, const float* dg, int Cdg, int coff, const float* x1,
+                        int C1, const float* coef, int Ctot, int N, int D, int H, int W, int D1, int H1, int W1,
+                        const int32_t* zlo, const int32_t* ylo, const int32_t* xlo, int relu_mask, float* out);
+
+/* ---- MaxPool3d(kernel_size=2) (buildingblocks.py:356): stride 2, floor ------------------------
+ * fwd: out (N,D/2,H/2,W/2,C), argmax byte per output element (first max in z,y,x scan order, as ATen),
+ *      optional out_stats as in u3d_conv3d.
+ * bwd_merge: the gradient of the encoder feature e that feeds BOTH the pool and a skip connection:
+ *      dz_e = (skip_grad + scatter(dpool)) * (e>0), with dpool = p*dg + q*pooled + r (GroupNorm backward
+ *      of the pooled tensor fused, coef may be NULL => dpool = dg).  skip_grad may be NULL. */
+int u3d_maxpool2_fwd(int device, u3d_stream_t stream, const float* x, int N, int D, int H, int W, int C,
+                     float* out, uint8_t* argmax, double* out_stats);
+int u3d_maxpool2_bwd_merge(int device, u3d_stream_t stream, const float* dg, const float* pooled,
+                           const uint8_t* argmax, const float* coef, const float* skip_grad, const float* e,
+                           int N, int D, int H, int W, int C, int relu_mask, float* out);
+
+/* ---- final 1x1x1 conv with bias + Sigmoid/Softmax (model.py:88-101,141-147) -------------------
+ * x (N,V,Cin) NDHWC; w (Cout,Cin), b (Cout).  logits/probs are written in the reference's NCDHW
+ * layout (N,Cout,V).  act: 0 none, 1 sigmoid, 2 softmax over channels.  Cout <= 16.
+ * bwd: dlogits (N,Cout,V) -> dx (N,V,Cin) masked by (x>0) when relu_mask (x is a post-ReLU conv output);
+ *      acc double[Cout*Cin + Cout] += (dw, db)  (convert with u3d_cvt_f64_f32). */
+int u3d_conv1x1_head_fwd(int device, u3d_stream_t stream, const float* x, const float* w, const float* b, int N,
+                         int64_t V, int Cin, int Cout, int act, float* logits, float* probs);
+int u3d_conv1x1_head_bwd(int device, u3d_stream_t stream, const float* dlogits, const float* x, const float* w,
+                         int N, int64_t V, int Cin, int Cout, int relu_mask, float* dx, double* acc);
+int u3d_cvt_f64_f32(int device, u3d_stream_t stream, const double* src, float* dst, int64_t n);
+
+/* ---- layout: NCDHW <-> NDHWC for multi-channel model inputs ------------------------------------ */
+int u3d_ncdhw_to_ndhwc(int device, u3d_stream_t stream, const float* src, float* dst, int N, int C, int64_t V);
+int u3d_ndhwc_to_ncdhw(int device, u3d_stream_t stream, const float* src, float* dst, int N, int C, int64_t V);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* U3D_H */

@@ -1,0 +1,103 @@
+// u3d_common.h — shared device helpers for the gfx950 3D U-Net kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "u3d.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+int u3d_set_err(int code, const char* fmt, ...);
+int u3d_enter(int device);  // hipSetDevice guard; returns 0 or error
+
+#define U3D_HIP(call)                                                                       \
+    do {                                                                                    \
+        hipError_t _e = (call);                                                             \
+        if (_e != hipSuccess)                                                               \
+            return u3d_set_err(U3D_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, \
+                               __LINE__);                                                   \
+    } while (0)
+
+#define U3D_REQUIRE(cond, ...)                              \
+    do {                                                    \
+        if (!(cond)) return u3d_set_err(U3D_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+#define U3D_LAUNCH_CHECK() U3D_HIP(hipGetLastError())
+
+// ---- (virtual) source tensor access ------------------------------------------------------------
+// voxel indices of (n,z,y,x) in the full-res source and (through the nearest maps) in the low-res one
+__device__ __forceinline__ void u3d_vox_index(const u3d_src_t& s, int n, int z, int y, int x, int D, int H, int W,
+                                              int& v0, int& v1) {
+    v0 = ((n * D + z) * H + y) * W + x;
+    if (s.C1 > 0) {
+        const int z1 = s.zmap[z], y1 = s.ymap[y], x1 = s.xmap[x];
+        v1 = ((n * s.D1 + z1) * s.H1 + y1) * s.W1 + x1;
+    } else {
+        v1 = 0;
+    }
+}
+
+__device__ __forceinline__ float u3d_load_elem(const u3d_src_t& s, int v0, int v1, int c) {
+    if (c < s.C0) return s.p0[(size_t)v0 * s.C0 + c];
+    if (c < s.C0 + s.C1) return s.p1[(size_t)v1 * s.C1 + (c - s.C0)];
+    return 0.f;
+}
+
+// 4 consecutive channels starting at cq (cq % 4 == 0).  vec: C0 % 4 == 0 && C1 % 4 == 0 and 16-B aligned bases.
+__device__ __forceinline__ f32x4 u3d_load_quad(const u3d_src_t& s, int v0, int v1, int cq, bool vec) {
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+    if (vec) {
+        if (cq < s.C0)
+            r = *reinterpret_cast<const f32x4*>(s.p0 + (size_t)v0 * s.C0 + cq);
+        else if (cq < s.C0 + s.C1)
+            r = *reinterpret_cast<const f32x4*>(s.p1 + (size_t)v1 * s.C1 + (cq - s.C0));
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = u3d_load_elem(s, v0, v1, cq + e);
+    }
+    return r;
+}
+
+// GroupNorm affine (a,b) for 4 consecutive channels of sample n; table [N][Ctot][2].
+__device__ __forceinline__ void u3d_load_affine(const float* aff, int n, int Ctot, int cq, bool vec, f32x4& a,
+                                                f32x4& b) {
+    a = f32x4{0.f, 0.f, 0.f, 0.f};
+    b = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (aff == nullptr) {
+        a = f32x4{1.f, 1.f, 1.f, 1.f};
+        return;
+    }
+    const float* p = aff + ((size_t)n * Ctot + cq) * 2;
+    if (vec) {
+        if (cq < Ctot) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(p);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(p + 4);
+            a = f32x4{lo[0], lo[2], hi[0], hi[2]};
+            b = f32x4{lo[1], lo[3], hi[1], hi[3]};
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (cq + e < Ctot) {
+                a[e] = p[2 * e];
+                b[e] = p[2 * e + 1];
+            }
+    }
+}
+
+__device__ __forceinline__ void u3d_atomic_add_f64(double* p, double v) {
+    // hardware global_atomic_add_f64 on coarse-grained (hipMalloc / torch caching allocator) memory
+    unsafeAtomicAdd(p, v);
+}
+
+// Bijective XCD-aware remap (cdna_hip_programming.md T1): block b runs on XCD b % 8; give every XCD a
+// contiguous run of logical ids so neighbouring tiles (shared halos / shared weights) hit one L2.
+__device__ __forceinline__ int u3d_xcd_remap(int b, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}

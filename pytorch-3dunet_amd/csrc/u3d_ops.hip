@@ -1,0 +1,681 @@
+// u3d_ops.hip — the bandwidth-bound kernels around the convolutions: GroupNorm statistics / finalize /
+// backward, MaxPool3d(2) forward + fused backward merge, the 1x1x1 head with Sigmoid/Softmax, layout
+// transposes.  Reference call sites: buildingblocks.py:47 (ReLU), :62-75 (GroupNorm), :356 (MaxPool3d),
+// :491 (cat), :614 (nearest interpolate), model.py:88-101,141-147 (final conv + activation).
+#include "u3d_common.h"
+
+#include <string.h>
+
+// ---- library plumbing ----------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+int u3d_set_err(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int u3d_enter(int device) {
+    int cur = -1;
+    hipError_t e = hipGetDevice(&cur);
+    if (e != hipSuccess) return u3d_set_err(U3D_EHIP, "hipGetDevice failed: %s", hipGetErrorString(e));
+    if (device >= 0 && cur != device) {
+        e = hipSetDevice(device);
+        if (e != hipSuccess) return u3d_set_err(U3D_EHIP, "hipSetDevice(%d) failed: %s", device, hipGetErrorString(e));
+    }
+    return 0;
+}
+
+extern "C" int u3d_version(void) { return U3D_VERSION; }
+extern "C" const char* u3d_last_error(void) { return g_err; }
+
+extern "C" int u3d_check_device(int device) {
+    hipDeviceProp_t prop;
+    U3D_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return u3d_set_err(U3D_EARCH, "device %d is %s, this library is built for gfx950 only", device, prop.gcnArchName);
+    return 0;
+}
+
+static inline long long cdivll(long long a, long long b) { return (a + b - 1) / b; }
+__device__ __forceinline__ long long cdivll_dev(long long a, long long b) { return (a + b - 1) / b; }
+static inline int grid_for(long long total, int cap = 8192) {
+    long long b = cdivll(total, 256);
+    if (b < 1) b = 1;
+    return (int)(b > cap ? cap : b);
+}
+
+static bool src_vec_ok(const u3d_src_t* s) {
+    if (s->C0 % 4 != 0 || s->C1 % 4 != 0) return false;
+    if (((uintptr_t)s->p0 & 15) != 0) return false;
+    if (s->C1 > 0 && ((uintptr_t)s->p1 & 15) != 0) return false;
+    return true;
+}
+
+// =================================================================================================
+// per-(n,channel) sum / sum of squares of a (virtual) tensor.  grid (blocks_per_n, N), 256 threads:
+// thread -> (row = t / Q, quad = t % Q), Q = ceil(C/4); rows stride the block's voxel range.
+__global__ __launch_bounds__(256) void chan_stats_kernel(const u3d_src_t src, int D, int H, int W, int Q, int rows,
+                                                         int vec, double* __restrict__ stats) {
+    extern __shared__ float red[];  // [rows][Q][8]
+    const int t = threadIdx.x;
+    const int n = blockIdx.y;
+    const int Ctot = src.C0 + src.C1;
+    const long long V = (long long)D * H * W;
+    const long long per = cdivll_dev(V, gridDim.x);
+    const long long vbeg = (long long)blockIdx.x * per;
+    const long long vend = min(V, vbeg + per);
+    const int row = t / Q, qd = t - row * Q;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (row < rows) {
+        for (long long v = vbeg + row; v < vend; v += rows) {
+            int v0 = (int)((long long)n * V + v), v1 = 0;
+            if (src.C1 > 0) {
+                const int x = (int)(v % W);
+                const long long r = v / W;
+                const int y = (int)(r % H);
+                const int z = (int)(r / H);
+                u3d_vox_index(src, n, z, y, x, D, H, W, v0, v1);
+            }
+            const f32x4 q = u3d_load_quad(src, v0, v1, 4 * qd, vec != 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s1[e] += q[e];
+                s2[e] += q[e] * q[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[(row * Q + qd) * 8 + e] = s1[e];
+            red[(row * Q + qd) * 8 + 4 + e] = s2[e];
+        }
+    }
+    __syncthreads();
+    // one channel per thread (strided when C > 256), sum over rows
+    for (int c = t; c < Ctot; c += 256) {
+        const int qd2 = c >> 2, e = c & 3;
+        float a = 0.f, b = 0.f;
+        for (int r = 0; r < rows; ++r) {
+            a += red[(r * Q + qd2) * 8 + e];
+            b += red[(r * Q + qd2) * 8 + 4 + e];
+        }
+        u3d_atomic_add_f64(&stats[((size_t)n * Ctot + c) * 2 + 0], (double)a);
+        u3d_atomic_add_f64(&stats[((size_t)n * Ctot + c) * 2 + 1], (double)b);
+    }
+}
+
+extern "C" int u3d_chan_stats(int device, u3d_stream_t stream, const u3d_src_t* src, int N, int D, int H, int W,
+                              double* stats) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(src && src->p0 && stats && N > 0 && D > 0 && H > 0 && W > 0, "u3d_chan_stats: bad argument");
+    const int Ctot = src->C0 + src->C1;
+    const int Q = (Ctot + 3) / 4;
+    U3D_REQUIRE(Q <= 256, "u3d_chan_stats: at most 1024 channels supported");
+    const int rows = 256 / Q;
+    const long long V = (long long)D * H * W;
+    // ~512 voxels per thread-row, at least 1 block, at most 2048 blocks per sample
+    long long bpn = cdivll(V, (long long)rows * 512);
+    if (bpn < 1) bpn = 1;
+    if (bpn > 2048) bpn = 2048;
+    const size_t shmem = (size_t)rows * Q * 8 * sizeof(float);
+    hipLaunchKernelGGL(chan_stats_kernel, dim3((unsigned)bpn, (unsigned)N), dim3(256), shmem, (hipStream_t)stream,
+                       *src, D, H, W, Q, rows, src_vec_ok(src) ? 1 : 0, stats);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// =================================================================================================
+// GroupNorm finalize: (n,group) mean / rstd from channel sums, then the per-channel affine table.
+__global__ void gn_finalize_kernel(const double* __restrict__ st0, int C0, double sc0, const double* __restrict__ st1,
+                                   int C1, double sc1, int N, int G, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float* __restrict__ affine,
+                                   float* __restrict__ mean_rstd) {
+    const int C = C0 + C1;
+    const int cpg = C / G;
+    for (int pair = blockIdx.x * blockDim.x + threadIdx.x; pair < N * G; pair += gridDim.x * blockDim.x) {
+        const int n = pair / G, g = pair - n * G;
+        double s = 0.0, ss = 0.0;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            if (c < C0) {
+                s += sc0 * st0[((size_t)n * C0 + c) * 2];
+                ss += sc0 * st0[((size_t)n * C0 + c) * 2 + 1];
+            } else {
+                s += sc1 * st1[((size_t)n * C1 + (c - C0)) * 2];
+                ss += sc1 * st1[((size_t)n * C1 + (c - C0)) * 2 + 1];
+            }
+        }
+        const double m = count * cpg;
+        const double mean = s / m;
+        double var = ss / m - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        mean_rstd[(size_t)pair * 2] = (float)mean;
+        mean_rstd[(size_t)pair * 2 + 1] = (float)rstd;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            const double a = rstd * (double)gamma[c];
+            affine[((size_t)n * C + c) * 2] = (float)a;
+            affine[((size_t)n * C + c) * 2 + 1] = (float)((double)beta[c] - mean * a);
+        }
+    }
+}
+
+extern "C" int u3d_gn_finalize(int device, u3d_stream_t stream, const double* stats0, int C0, double scale0,
+                               const double* stats1, int C1, double scale1, int N, int G, double count,
+                               const float* gamma, const float* beta, float eps, float* affine, float* mean_rstd) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(stats0 && C0 > 0 && C1 >= 0 && (C1 == 0 || stats1) && N > 0 && G > 0 && gamma && beta && affine &&
+                    mean_rstd && count > 0,
+                "u3d_gn_finalize: bad argument");
+    U3D_REQUIRE((C0 + C1) % G == 0, "u3d_gn_finalize: channels %d not divisible by groups %d", C0 + C1, G);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(grid_for((long long)N * G, 64)), dim3(64), 0, (hipStream_t)stream,
+                       stats0, C0, scale0, stats1, C1, scale1, N, G, count, gamma, beta, eps, affine, mean_rstd);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// GroupNorm backward reductions -> dgamma, dbeta, coefficient table coef[N][3][C] (p,q,r).
+// One block; phase 1 over (n,g), phase 2 over channels.
+__global__ void gn_bwd_finalize_kernel(const double* __restrict__ gs, const float* __restrict__ mean_rstd,
+                                       const float* __restrict__ gamma, int N, int C, int G, double count,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ coef) {
+    const int cpg = C / G;
+    const double m = count * cpg;
+    for (int pair = threadIdx.x; pair < N * G; pair += blockDim.x) {
+        const int n = pair / G, g = pair - n * G;
+        const double mean = (double)mean_rstd[(size_t)pair * 2], rstd = (double)mean_rstd[(size_t)pair * 2 + 1];
+        double A = 0.0, B = 0.0;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            const double S1 = gs[((size_t)n * C + c) * 2], S2 = gs[((size_t)n * C + c) * 2 + 1];
+            const double gm = (double)gamma[c];
+            A += gm * S1;
+            B += gm * rstd * (S2 - mean * S1);
+        }
+        const double q = -rstd * rstd * B / m;
+        const double r = -rstd * A / m + rstd * rstd * mean * B / m;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            coef[((size_t)n * 3 + 0) * C + c] = (float)(rstd * (double)gamma[c]);
+            coef[((size_t)n * 3 + 1) * C + c] = (float)q;
+            coef[((size_t)n * 3 + 2) * C + c] = (float)r;
+        }
+    }
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cpg;
+        double dg = 0.0, db = 0.0;
+        for (int n = 0; n < N; ++n) {
+            const double mean = (double)mean_rstd[((size_t)n * G + g) * 2], rstd = (double)mean_rstd[((size_t)n * G + g) * 2 + 1];
+            const double S1 = gs[((size_t)n * C + c) * 2], S2 = gs[((size_t)n * C + c) * 2 + 1];
+            dg += rstd * (S2 - mean * S1);
+            db += S1;
+        }
+        dgamma[c] = (float)dg;
+        dbeta[c] = (float)db;
+    }
+}
+
+extern "C" int u3d_gn_bwd_finalize(int device, u3d_stream_t stream, const double* gstats, const float* mean_rstd,
+                                   const float* gamma, int N, int C, int G, double count, float* dgamma,
+                                   float* dbeta, float* coef) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(gstats && mean_rstd && gamma && dgamma && dbeta && coef && N > 0 && C > 0 && G > 0 && C % G == 0,
+                "u3d_gn_bwd_finalize: bad argument");
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, gstats, mean_rstd, gamma,
+                       N, C, G, count, dgamma, dbeta, coef);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// out = (p*dg[coff+c] + q*x + r) * mask
+template <bool VEC>
+__global__ void gn_bwd_apply_kernel(const float* __restrict__ dg, int Cdg, int coff, const float* __restrict__ x,
+                                    int Cx, const float* __restrict__ coef, int Ctot, long long Vn, int N,
+                                    int relu_mask, float* __restrict__ out) {
+    if (VEC) {
+        const int Q = Cx >> 2;
+        const long long total = (long long)N * Vn * Q;
+        for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+             idx += (long long)gridDim.x * blockDim.x) {
+            const int qd = (int)(idx % Q);
+            const long long v = idx / Q;  // n*Vn + voxel
+            const int n = (int)(v / Vn);
+            const int c = 4 * qd;
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dg + (size_t)v * Cdg + coff + c);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)v * Cx + c);
+            const f32x4 p = *reinterpret_cast<const f32x4*>(coef + ((size_t)n * 3 + 0) * Ctot + coff + c);
+            const f32x4 q = *reinterpret_cast<const f32x4*>(coef + ((size_t)n * 3 + 1) * Ctot + coff + c);
+            const f32x4 r = *reinterpret_cast<const f32x4*>(coef + ((size_t)n * 3 + 2) * Ctot + coff + c);
+            f32x4 o = p * d + q * xv + r;
+            if (relu_mask) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = xv[e] > 0.f ? o[e] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(out + (size_t)v * Cx + c) = o;
+        }
+    } else {
+        const long long total = (long long)N * Vn * Cx;
+        for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+             idx += (long long)gridDim.x * blockDim.x) {
+            const int c = (int)(idx % Cx);
+            const long long v = idx / Cx;
+            const int n = (int)(v / Vn);
+            const float d = dg[(size_t)v * Cdg + coff + c];
+            const float xv = x[idx];
+            float o = coef[((size_t)n * 3 + 0) * Ctot + coff + c] * d + coef[((size_t)n * 3 + 1) * Ctot + coff + c] * xv +
+                      coef[((size_t)n * 3 + 2) * Ctot + coff + c];
+            if (relu_mask && !(xv > 0.f)) o = 0.f;
+            out[idx] = o;
+        }
+    }
+}
+
+extern "C" int u3d_gn_bwd_apply(int device, u3d_stream_t stream, const float* dg, int Cdg, int coff, const float* x,
+                                int Cx, const float* coef, int Ctot, int64_t voxels_per_n, int N, int relu_mask,
+                                float* out) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(dg && x && coef && out && Cdg > 0 && Cx > 0 && coff >= 0 && coff + Cx <= Cdg && Ctot >= coff + Cx &&
+                    voxels_per_n > 0 && N > 0,
+                "u3d_gn_bwd_apply: bad argument");
+    const bool vec = (Cdg % 4 == 0) && (Cx % 4 == 0) && (coff % 4 == 0) && (Ctot % 4 == 0) &&
+                     (((uintptr_t)dg | (uintptr_t)x | (uintptr_t)coef | (uintptr_t)out) & 15) == 0;
+    if (vec) {
+        const long long total = (long long)N * voxels_per_n * (Cx / 4);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream,
+                           dg, Cdg, coff, x, Cx, coef, Ctot, (long long)voxels_per_n, N, relu_mask, out);
+    } else {
+        const long long total = (long long)N * voxels_per_n * Cx;
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(grid_for(total, 16384)), dim3(256), 0,
+                           (hipStream_t)stream, dg, Cdg, coff, x, Cx, coef, Ctot, (long long)voxels_per_n, N,
+                           relu_mask, out);
+    }
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// upsampled half of a concat: sum over the children of each low-res voxel
+__global__ void gn_bwd_apply_up_kernel(const float* __restrict__ dg, int Cdg, int coff, const float* __restrict__ x1,
+                                       int C1, const float* __restrict__ coef, int Ctot, int N, int D, int H, int W,
+                                       int D1, int H1, int W1, const int* __restrict__ zlo,
+                                       const int* __restrict__ ylo, const int* __restrict__ xlo, int relu_mask,
+                                       float* __restrict__ out) {
+    const long long total = (long long)N * D1 * H1 * W1 * C1;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C1);
+        long long v = idx / C1;
+        const int xx = (int)(v % W1);
+        v /= W1;
+        const int yy = (int)(v % H1);
+        v /= H1;
+        const int zz = (int)(v % D1);
+        const int n = (int)(v / D1);
+        float sum = 0.f;
+        int cnt = 0;
+        for (int z = zlo[zz]; z < zlo[zz + 1]; ++z)
+            for (int y = ylo[yy]; y < ylo[yy + 1]; ++y)
+                for (int x = xlo[xx]; x < xlo[xx + 1]; ++x) {
+                    sum += dg[((size_t)((n * D + z) * H + y) * W + x) * Cdg + coff + c];
+                    ++cnt;
+                }
+        const float xv = x1[idx];
+        const float p = coef[((size_t)n * 3 + 0) * Ctot + coff + c], q = coef[((size_t)n * 3 + 1) * Ctot + coff + c],
+                    r = coef[((size_t)n * 3 + 2) * Ctot + coff + c];
+        float o = p * sum + (float)cnt * (q * xv + r);
+        if (relu_mask && !(xv > 0.f)) o = 0.f;
+        out[idx] = o;
+    }
+}
+
+extern "C" int u3d_gn_bwd_apply_up(int device, u3d_stream_t stream, const float* dg, int Cdg, int coff,
+                                   const float* x1, int C1, const float* coef, int Ctot, int N, int D, int H, int W,
+                                   int D1, int H1, int W1, const int32_t* zlo, const int32_t* ylo,
+                                   const int32_t* xlo, int relu_mask, float* out) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(dg && x1 && coef && out && zlo && ylo && xlo && C1 > 0 && coff >= 0 && coff + C1 <= Cdg &&
+                    Ctot >= coff + C1 && N > 0,
+                "u3d_gn_bwd_apply_up: bad argument");
+    const long long total = (long long)N * D1 * H1 * W1 * C1;
+    hipLaunchKernelGGL(gn_bwd_apply_up_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, dg,
+                       Cdg, coff, x1, C1, coef, Ctot, N, D, H, W, D1, H1, W1, zlo, ylo, xlo, relu_mask, out);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// =================================================================================================
+// MaxPool3d(2): stride 2, floor.  One thread per (n, out voxel, channel).
+__global__ void maxpool2_fwd_kernel(const float* __restrict__ x, int N, int D, int H, int W, int C,
+                                    float* __restrict__ out, uint8_t* __restrict__ argmax) {
+    const int D2 = D >> 1, H2 = H >> 1, W2 = W >> 1;
+    const long long total = (long long)N * D2 * H2 * W2 * C;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        long long v = idx / C;
+        const int xo = (int)(v % W2);
+        v /= W2;
+        const int yo = (int)(v % H2);
+        v /= H2;
+        const int zo = (int)(v % D2);
+        const int n = (int)(v / D2);
+        float best = -INFINITY;
+        int bi = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int z = 2 * zo + (k >> 2), y = 2 * yo + ((k >> 1) & 1), xx = 2 * xo + (k & 1);
+            const float val = x[((size_t)((n * D + z) * H + y) * W + xx) * C + c];
+            if (val > best || val != val) {  // first max in scan order; NaN propagates (ATen max_pool3d)
+                best = val;
+                bi = k;
+            }
+        }
+        out[idx] = best;
+        argmax[idx] = (uint8_t)bi;
+    }
+}
+
+extern "C" int u3d_maxpool2_fwd(int device, u3d_stream_t stream, const float* x, int N, int D, int H, int W, int C,
+                                float* out, uint8_t* argmax, double* out_stats) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(x && out && argmax && N > 0 && D >= 2 && H >= 2 && W >= 2 && C > 0, "u3d_maxpool2_fwd: bad argument");
+    const long long total = (long long)N * (D / 2) * (H / 2) * (W / 2) * C;
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, x, N, D,
+                       H, W, C, out, argmax);
+    U3D_LAUNCH_CHECK();
+    if (out_stats) {
+        u3d_src_t s = {};
+        s.p0 = out;
+        s.C0 = C;
+        return u3d_chan_stats(device, stream, &s, N, D / 2, H / 2, W / 2, out_stats);
+    }
+    return 0;
+}
+
+// dz_e = (skip_grad + scatter(dpool)) * (e > 0); one thread per (n, window, channel), windows cover ceil dims
+__global__ void maxpool2_bwd_merge_kernel(const float* __restrict__ dg, const float* __restrict__ pooled,
+                                          const uint8_t* __restrict__ argmax, const float* __restrict__ coef,
+                                          const float* __restrict__ skip, const float* __restrict__ e, int N, int D,
+                                          int H, int W, int C, int relu_mask, float* __restrict__ out) {
+    const int D2 = D >> 1, H2 = H >> 1, W2 = W >> 1;
+    const int Dc = (D + 1) >> 1, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1;
+    const long long total = (long long)N * Dc * Hc * Wc * C;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        long long v = idx / C;
+        const int xo = (int)(v % Wc);
+        v /= Wc;
+        const int yo = (int)(v % Hc);
+        v /= Hc;
+        const int zo = (int)(v % Dc);
+        const int n = (int)(v / Dc);
+        const bool pv = zo < D2 && yo < H2 && xo < W2;
+        float dp = 0.f;
+        int am = -1;
+        if (pv) {
+            const size_t pi = ((size_t)((n * D2 + zo) * H2 + yo) * W2 + xo) * C + c;
+            dp = dg[pi];
+            if (coef) dp = coef[((size_t)n * 3 + 0) * C + c] * dp + coef[((size_t)n * 3 + 1) * C + c] * pooled[pi] +
+                           coef[((size_t)n * 3 + 2) * C + c];
+            am = argmax[pi];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int z = 2 * zo + (k >> 2), y = 2 * yo + ((k >> 1) & 1), xx = 2 * xo + (k & 1);
+            if (z < D && y < H && xx < W) {
+                const size_t ei = ((size_t)((n * D + z) * H + y) * W + xx) * C + c;
+                float g = skip ? skip[ei] : 0.f;
+                if (k == am) g += dp;
+                if (relu_mask && !(e[ei] > 0.f)) g = 0.f;
+                out[ei] = g;
+            }
+        }
+    }
+}
+
+extern "C" int u3d_maxpool2_bwd_merge(int device, u3d_stream_t stream, const float* dg, const float* pooled,
+                                      const uint8_t* argmax, const float* coef, const float* skip_grad,
+                                      const float* e, int N, int D, int H, int W, int C, int relu_mask, float* out) {
+    if (int er = u3d_enter(device)) return er;
+    U3D_REQUIRE(dg && argmax && out && (coef == nullptr || pooled) && (!relu_mask || e) && N > 0 && C > 0,
+                "u3d_maxpool2_bwd_merge: bad argument");
+    const long long total = (long long)N * ((D + 1) / 2) * ((H + 1) / 2) * ((W + 1) / 2) * C;
+    hipLaunchKernelGGL(maxpool2_bwd_merge_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, dg,
+                       pooled, argmax, coef, skip_grad, e, N, D, H, W, C, relu_mask, out);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// =================================================================================================
+// head: 1x1x1 conv + bias + activation; x NDHWC (N,V,Cin) -> logits/probs NCDHW (N,Cout,V)
+constexpr int HEAD_MAXCO = 16;
+constexpr int HEAD_MAXCI = 256;
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ b, int N, long long V, int Cin,
+                                                       int Cout, int act, float* __restrict__ logits,
+                                                       float* __restrict__ probs) {
+    __shared__ float ws[HEAD_MAXCO * HEAD_MAXCI + HEAD_MAXCO];
+    for (int i = threadIdx.x; i < Cout * Cin; i += blockDim.x) ws[i] = w[i];
+    for (int i = threadIdx.x; i < Cout; i += blockDim.x) ws[HEAD_MAXCO * HEAD_MAXCI + i] = b[i];
+    __syncthreads();
+    const long long total = (long long)N * V;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(idx / V);
+        const long long v = idx - (long long)n * V;
+        float acc[HEAD_MAXCO];
+#pragma unroll
+        for (int o = 0; o < HEAD_MAXCO; ++o) acc[o] = o < Cout ? ws[HEAD_MAXCO * HEAD_MAXCI + o] : 0.f;
+        const float* xr = x + (size_t)idx * Cin;
+        for (int c = 0; c < Cin; ++c) {
+            const float xv = xr[c];
+#pragma unroll
+            for (int o = 0; o < HEAD_MAXCO; ++o)
+                if (o < Cout) acc[o] = fmaf(xv, ws[o * Cin + c], acc[o]);
+        }
+        float mx = -INFINITY, den = 0.f;
+        if (act == 2) {
+#pragma unroll
+            for (int o = 0; o < HEAD_MAXCO; ++o)
+                if (o < Cout) mx = fmaxf(mx, acc[o]);
+#pragma unroll
+            for (int o = 0; o < HEAD_MAXCO; ++o)
+                if (o < Cout) den += expf(acc[o] - mx);
+        }
+#pragma unroll
+        for (int o = 0; o < HEAD_MAXCO; ++o) {
+            if (o < Cout) {
+                const size_t oi = ((size_t)n * Cout + o) * V + v;
+                logits[oi] = acc[o];
+                if (probs) {
+                    float pr = acc[o];
+                    if (act == 1) pr = 1.f / (1.f + expf(-acc[o]));
+                    if (act == 2) pr = expf(acc[o] - mx) / den;
+                    probs[oi] = pr;
+                }
+            }
+        }
+    }
+}
+
+extern "C" int u3d_conv1x1_head_fwd(int device, u3d_stream_t stream, const float* x, const float* w, const float* b,
+                                    int N, int64_t V, int Cin, int Cout, int act, float* logits, float* probs) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(x && w && b && logits && N > 0 && V > 0, "u3d_conv1x1_head_fwd: bad argument");
+    U3D_REQUIRE(Cout >= 1 && Cout <= HEAD_MAXCO && Cin >= 1 && Cin <= HEAD_MAXCI,
+                "u3d_conv1x1_head_fwd: supports Cout<=%d, Cin<=%d (got %d,%d)", HEAD_MAXCO, HEAD_MAXCI, Cout, Cin);
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(grid_for((long long)N * V, 4096)), dim3(256), 0, (hipStream_t)stream, x,
+                       w, b, N, (long long)V, Cin, Cout, act, logits, probs);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// dx[n,v,c] = sum_o dlogits[n,o,v] * w[o,c]  (masked by x>0)
+__global__ __launch_bounds__(256) void head_bwd_dx_kernel(const float* __restrict__ dl, const float* __restrict__ x,
+                                                          const float* __restrict__ w, int N, long long V, int Cin,
+                                                          int Cout, int relu_mask, float* __restrict__ dx) {
+    __shared__ float ws[HEAD_MAXCO * HEAD_MAXCI];
+    for (int i = threadIdx.x; i < Cout * Cin; i += blockDim.x) ws[i] = w[i];
+    __syncthreads();
+    // thread -> (voxel, channel) with channel fastest: coalesced dx/x, broadcast dlogits
+    const long long total = (long long)N * V * Cin;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % Cin);
+        const long long nv = idx / Cin;
+        const int n = (int)(nv / V);
+        const long long v = nv - (long long)n * V;
+        float s = 0.f;
+        for (int o = 0; o < Cout; ++o) s = fmaf(dl[((size_t)n * Cout + o) * V + v], ws[o * Cin + c], s);
+        if (relu_mask && !(x[idx] > 0.f)) s = 0.f;
+        dx[idx] = s;
+    }
+}
+
+// acc[o*Cin + c] += sum_v dl[o,v] * x[v,c];  acc[Cout*Cin + o] += sum_v dl[o,v]
+__global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* __restrict__ dl, const float* __restrict__ x,
+                                                          int N, long long V, int Cin, int Cout,
+                                                          double* __restrict__ acc) {
+    extern __shared__ float red[];  // [rows][Cin][HEAD_MAXCO+... ] reduced via atomics in LDS instead
+    const int t = threadIdx.x;
+    const int rows = 256 / Cin;
+    const int row = t / Cin, c = t - row * Cin;
+    float a[HEAD_MAXCO];
+    float bsum[HEAD_MAXCO];
+#pragma unroll
+    for (int o = 0; o < HEAD_MAXCO; ++o) {
+        a[o] = 0.f;
+        bsum[o] = 0.f;
+    }
+    const long long total = (long long)N * V;
+    const long long per = (total + gridDim.x - 1) / gridDim.x;
+    const long long beg = (long long)blockIdx.x * per, end = min(total, beg + per);
+    if (row < rows) {
+        for (long long nv = beg + row; nv < end; nv += rows) {
+            const int n = (int)(nv / V);
+            const long long v = nv - (long long)n * V;
+            const float xv = x[(size_t)nv * Cin + c];
+#pragma unroll
+            for (int o = 0; o < HEAD_MAXCO; ++o) {
+                if (o < Cout) {
+                    const float d = dl[((size_t)n * Cout + o) * V + v];
+                    a[o] = fmaf(d, xv, a[o]);
+                    if (c == 0) bsum[o] += d;
+                }
+            }
+        }
+    }
+    // reduce rows through LDS: red[o][c] accumulations
+    for (int i = t; i < (Cout + 1) * Cin; i += 256) red[i] = 0.f;
+    __syncthreads();
+    if (row < rows) {
+#pragma unroll
+        for (int o = 0; o < HEAD_MAXCO; ++o) {
+            if (o < Cout) {
+                atomicAdd(&red[o * Cin + c], a[o]);
+                if (c == 0) atomicAdd(&red[Cout * Cin + o], bsum[o]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < Cout * Cin; i += 256) u3d_atomic_add_f64(&acc[i], (double)red[i]);
+    for (int i = t; i < Cout; i += 256) u3d_atomic_add_f64(&acc[Cout * Cin + i], (double)red[Cout * Cin + i]);
+}
+
+extern "C" int u3d_conv1x1_head_bwd(int device, u3d_stream_t stream, const float* dlogits, const float* x,
+                                    const float* w, int N, int64_t V, int Cin, int Cout, int relu_mask, float* dx,
+                                    double* acc) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(dlogits && x && w && N > 0 && V > 0, "u3d_conv1x1_head_bwd: bad argument");
+    U3D_REQUIRE(Cout >= 1 && Cout <= HEAD_MAXCO && Cin >= 1 && Cin <= HEAD_MAXCI,
+                "u3d_conv1x1_head_bwd: supports Cout<=%d, Cin<=%d (got %d,%d)", HEAD_MAXCO, HEAD_MAXCI, Cout, Cin);
+    if (dx) {
+        hipLaunchKernelGGL(head_bwd_dx_kernel, dim3(grid_for((long long)N * V * Cin, 16384)), dim3(256), 0,
+                           (hipStream_t)stream, dlogits, x, w, N, (long long)V, Cin, Cout, relu_mask, dx);
+        U3D_LAUNCH_CHECK();
+    }
+    if (acc) {
+        long long blocks = cdivll((long long)N * V, 4096);
+        if (blocks > 1024) blocks = 1024;
+        if (blocks < 1) blocks = 1;
+        const size_t shmem = (size_t)(Cout + 1) * Cin * sizeof(float);
+        hipLaunchKernelGGL(head_bwd_dw_kernel, dim3((unsigned)blocks), dim3(256), shmem, (hipStream_t)stream, dlogits,
+                           x, N, (long long)V, Cin, Cout, acc);
+        U3D_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+__global__ void cvt_f64_f32_kernel(const double* __restrict__ s, float* __restrict__ d, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        d[i] = (float)s[i];
+}
+
+extern "C" int u3d_cvt_f64_f32(int device, u3d_stream_t stream, const double* src, float* dst, int64_t n) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(src && dst && n > 0, "u3d_cvt_f64_f32: bad argument");
+    hipLaunchKernelGGL(cvt_f64_f32_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                       (long long)n);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// =================================================================================================
+// layout transposes through a 32x32 LDS tile: src (N, R, S) -> dst (N, S, R)
+__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, long long R, long long S) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const long long r0 = (long long)blockIdx.y * 32, s0 = (long long)blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const float* sp = src + (size_t)n * R * S;
+    float* dp = dst + (size_t)n * R * S;
+    for (int k = ty; k < 32; k += 8)
+        if (r0 + k < R && s0 + tx < S) tile[k][tx] = sp[(size_t)(r0 + k) * S + s0 + tx];
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8)
+        if (s0 + k < S && r0 + tx < R) dp[(size_t)(s0 + k) * R + r0 + tx] = tile[tx][k];
+}
+
+static int launch_transpose(u3d_stream_t stream, const float* src, float* dst, int N, long long R, long long S) {
+    const long long gx = cdivll(S, 32), gy = cdivll(R, 32);
+    // grid.y is limited to 65535: the long (voxel) dimension must be S
+    U3D_REQUIRE(gy <= 65535, "transpose: row dimension too large");
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)N), dim3(256), 0,
+                       (hipStream_t)stream, src, dst, R, S);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int u3d_ncdhw_to_ndhwc(int device, u3d_stream_t stream, const float* src, float* dst, int N, int C,
+                                  int64_t V) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(src && dst && N > 0 && C > 0 && V > 0, "u3d_ncdhw_to_ndhwc: bad argument");
+    return launch_transpose(stream, src, dst, N, C, V);  // (N,C,V) -> (N,V,C)
+}
+
+// (N,V,C) -> (N,C,V): rows = V can exceed 65535*32, so run the transposed problem with swapped roles
+__global__ void transpose_vc_kernel(const float* __restrict__ src, float* __restrict__ dst, long long V, int C) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const long long v0 = (long long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* sp = src + (size_t)n * V * C;
+    float* dp = dst + (size_t)n * V * C;
+    for (int k = ty; k < 32; k += 8)
+        if (v0 + k < V && c0 + tx < C) tile[k][tx] = sp[(size_t)(v0 + k) * C + c0 + tx];
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8)
+        if (c0 + k < C && v0 + tx < V) dp[(size_t)(c0 + k) * V + v0 + tx] = tile[tx][k];
+}
+
+extern "C" int u3d_ndhwc_to_ncdhw(int device, u3d_stream_t stream, const float* src, float* dst, int N, int C,
+                                  int64_t V) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(src && dst && N > 0 && C > 0 && V > 0, "u3d_ndhwc_to_ncdhw: bad argument");
+    hipLaunchKernelGGL(transpose_vc_kernel, dim3((unsigned)cdivll(V, 32), (unsigned)cdivll(C, 32), (unsigned)N),
+                       dim3(256), 0, (hipStream_t)stream, src, dst, (long long)V, C);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,147 @@
+"""ctypes binding of the C-ABI in include/u3d.h (libu3d_hip.so, gfx950 HIP kernels).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libu3d_hip.so")
+
+U3D_OK = 0
+
+
+class U3DSrc(ctypes.Structure):
+    """mirror of u3d_src_t (include/u3d.h)"""
+
+    _fields_ = [
+        ("p0", c_void_p),
+        ("p1", c_void_p),
+        ("zmap", c_void_p),
+        ("ymap", c_void_p),
+        ("xmap", c_void_p),
+        ("affine", c_void_p),
+        ("C0", c_int32),
+        ("C1", c_int32),
+        ("D1", c_int32),
+        ("H1", c_int32),
+        ("W1", c_int32),
+    ]
+
+
+_PROTOS = {
+    # name: (restype, argtypes)
+    "u3d_version": (c_int, []),
+    "u3d_last_error": (c_char_p, []),
+    "u3d_check_device": (c_int, [c_int]),
+    "u3d_packed_weight_floats": (c_size_t, [c_int, c_int, c_int]),
+    "u3d_pack_weights": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "u3d_conv3d": (
+        c_int,
+        [c_int, c_void_p, POINTER(U3DSrc), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+         POINTER(U3DSrc), c_void_p],
+    ),
+    "u3d_wgrad_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "u3d_conv3d_wgrad": (
+        c_int,
+        [c_int, c_void_p, POINTER(U3DSrc), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t],
+    ),
+    "u3d_conv3d_naive": (
+        c_int,
+        [c_int, c_void_p, POINTER(U3DSrc), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
+    ),
+    "u3d_chan_stats": (c_int, [c_int, c_void_p, POINTER(U3DSrc), c_int, c_int, c_int, c_int, c_void_p]),
+    "u3d_gn_finalize": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_int, c_double, c_void_p, c_int, c_double, c_int, c_int, c_double, c_void_p,
+         c_void_p, c_float, c_void_p, c_void_p],
+    ),
+    "u3d_gn_bwd_finalize": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p],
+    ),
+    "u3d_gn_bwd_apply": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p],
+    ),
+    "u3d_gn_bwd_apply_up": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+         c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    ),
+    "u3d_maxpool2_fwd": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "u3d_maxpool2_bwd_merge": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+         c_int, c_void_p],
+    ),
+    "u3d_conv1x1_head_fwd": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p],
+    ),
+    "u3d_conv1x1_head_bwd": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p],
+    ),
+    "u3d_cvt_f64_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64]),
+    "u3d_ncdhw_to_ndhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64]),
+    "u3d_ndhwc_to_ncdhw": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64]),
+}
+
+EXPORTED_SYMBOLS = tuple(_PROTOS.keys())
+
+_lib = None
+_lock = threading.Lock()
+launch_count = 0  # number of native calls issued (tests assert the HIP path really ran)
+
+
+class U3DError(RuntimeError):
+    pass
+
+
+def lib_available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def get_lib():
+    """Load libu3d_hip.so (once).  Raises U3DError if it has not been built — there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise U3DError(
+                f"native library {LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). The MI355X path has no CPU/PyTorch fallback."
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if lib.u3d_version() < 100:
+            raise U3DError("libu3d_hip.so is older than the Python host code")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != U3D_OK:
+        msg = get_lib().u3d_last_error()
+        raise U3DError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
+
+
+def call(name: str, *args) -> None:
+    """Call an int-returning entry point and raise on error."""
+    global launch_count
+    fn = getattr(get_lib(), name)
+    launch_count += 1
+    rc = fn(*args)
+    if rc != U3D_OK:
+        check(rc, name)

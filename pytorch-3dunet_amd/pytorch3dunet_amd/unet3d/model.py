@@ -1,0 +1,158 @@
+"""Drop-in model API of the reference's pytorch3dunet/unet3d/model.py (get_model :361, UNet3D :152,
+ResidualUNet3D :193, ResidualUNetSE3D :237, UNet2D :281, ResidualUNet2D :321, is_model_2d :366) whose
+forward/backward on an MI355X runs as hand-written gfx950 HIP kernels.
+
+Contract kept:
+  * constructor keyword arguments and defaults, extra keys swallowed by **kwargs (model.py:159-174),
+  * forward(x, return_logits=False) -> probs | (probs, logits); regression models return (x, x) (model.py:103-149),
+  * parameter names / shapes of state_dict() — checkpoints of the reference load with strict=True,
+  * class lookup by name through get_model / get_class (utils.py:331-338), isinstance(model, UNet2D) for 2-D.
+
+Dispatch: tensors on a gfx950 device -> native executor (pytorch3dunet_amd/engine.py), which raises if
+libu3d_hip.so is missing (no silent fallback).  CPU tensors (`device: cpu`) run the torch.nn modules the tree is
+made of.  Model variants the executor does not cover yet (residual / SE blocks, 2-D, non-'gcr' orders) run the
+same module tree through stock PyTorch-ROCm operators after a one-time warning; set U3D_STRICT=1 to make that an
+error instead.
+"""
+import os
+import warnings
+
+import torch
+from torch import nn
+
+from .buildingblocks import DoubleConv, ResNetBlock, ResNetBlockSE, create_decoders, create_encoders
+from .utils import get_class, number_of_features_per_level
+
+_THIS_MODULE = __name__
+
+
+class AbstractUNet(nn.Module):
+    """Encoder-decoder skeleton shared by all variants (reference model.py:7-149)."""
+
+    def __init__(self, in_channels, out_channels, final_sigmoid, basic_module, f_maps=64, layer_order="gcr",
+                 num_groups=8, num_levels=4, is_segmentation=True, conv_kernel_size=3, pool_kernel_size=2,
+                 conv_padding=1, conv_upscale=2, upsample="default", dropout_prob=0.1, is3d=True):
+        super().__init__()
+        if isinstance(f_maps, int):
+            f_maps = number_of_features_per_level(f_maps, num_levels=num_levels)
+        assert isinstance(f_maps, (list, tuple))
+        assert len(f_maps) > 1, "Required at least 2 levels in the U-Net"
+        if "g" in layer_order:
+            assert num_groups is not None, "num_groups must be specified if GroupNorm is used"
+
+        self.encoders = create_encoders(in_channels, f_maps, basic_module, conv_kernel_size, conv_padding, conv_upscale,
+                                        dropout_prob, layer_order, num_groups, pool_kernel_size, is3d)
+        self.decoders = create_decoders(f_maps, basic_module, conv_kernel_size, conv_padding, layer_order, num_groups,
+                                        upsample, dropout_prob, is3d)
+        # 1x1(x1) convolution down to the number of labels
+        self.final_conv = (nn.Conv3d if is3d else nn.Conv2d)(f_maps[0], out_channels, 1)
+        if is_segmentation:
+            self.final_activation = nn.Sigmoid() if final_sigmoid else nn.Softmax(dim=1)
+        else:
+            self.final_activation = None
+
+        # ---- native-path eligibility (everything the gfx950 executor implements today)
+        reasons = []
+        if not is3d:
+            reasons.append("2-D model")
+        if basic_module is not DoubleConv:
+            reasons.append(f"basic_module {basic_module.__name__}")
+        if layer_order != "gcr":
+            reasons.append(f"layer_order '{layer_order}'")
+        if conv_kernel_size != 3 or conv_padding != 1:
+            reasons.append("conv kernel/padding other than 3/1")
+        if pool_kernel_size != 2:
+            reasons.append("pool_kernel_size != 2")
+        if upsample not in ("default", "nearest"):
+            reasons.append(f"upsample '{upsample}'")
+        if out_channels > 16 or f_maps[0] > 256:
+            reasons.append("head wider than 16 outputs / 256 inputs")
+        self._native_blockers = reasons
+        self._engine = None
+        self._warned = False
+
+    # ------------------------------------------------------------------------------------------------
+    @property
+    def native_supported(self):
+        return not self._native_blockers
+
+    def _get_engine(self):
+        if self._engine is None:
+            from ..engine import UNet3DEngine
+
+            object.__setattr__(self, "_engine", UNet3DEngine(self))
+        return self._engine
+
+    def forward(self, x, return_logits=False):
+        """(N,C,D,H,W) -> probabilities, or (probabilities, logits) when return_logits (model.py:103-121)."""
+        output, logits = self._forward_logits(x)
+        if return_logits:
+            return output, logits
+        return output
+
+    def _forward_logits(self, x):
+        if x.is_cuda:
+            if self.native_supported and x.dtype == torch.float32 and x.dim() == 5:
+                from ..engine import run_model
+
+                return run_model(self._get_engine(), x)
+            why = ", ".join(self._native_blockers) or f"input dtype/rank {x.dtype}/{x.dim()}"
+            if os.environ.get("U3D_STRICT", "0") == "1":
+                raise NotImplementedError(f"u3d: no native gfx950 path for this configuration ({why})")
+            if not self._warned:
+                warnings.warn(f"u3d: {type(self).__name__} ({why}) is not covered by the native gfx950 executor yet; "
+                              "running the module tree through stock PyTorch-ROCm operators", stacklevel=3)
+                self._warned = True
+        return self._forward_modules(x)
+
+    def _forward_modules(self, x):
+        """Plain torch.nn execution of the module tree (CPU tensors; uncovered variants)."""
+        features = []
+        for encoder in self.encoders:
+            x = encoder(x)
+            features.insert(0, x)
+        # the deepest encoder output is the decoder input, not a skip
+        for decoder, skip in zip(self.decoders, features[1:]):
+            x = decoder(skip, x)
+        x = self.final_conv(x)
+        if self.final_activation is not None:
+            return self.final_activation(x), x
+        return x, x
+
+
+def _variant(name, basic_module, default_levels, is3d, doc):
+    """The five public classes differ only in (basic_module, default num_levels, is3d): build them from one
+    template so their signatures stay identical to the reference's (model.py:152-358)."""
+
+    def __init__(self, in_channels, out_channels, final_sigmoid=True, f_maps=64, layer_order="gcr", num_groups=8,
+                 num_levels=default_levels, is_segmentation=True, conv_padding=1, conv_upscale=2, upsample="default",
+                 dropout_prob=0.1, **kwargs):
+        AbstractUNet.__init__(self, in_channels=in_channels, out_channels=out_channels, final_sigmoid=final_sigmoid,
+                              basic_module=basic_module, f_maps=f_maps, layer_order=layer_order, num_groups=num_groups,
+                              num_levels=num_levels, is_segmentation=is_segmentation, conv_padding=conv_padding,
+                              conv_upscale=conv_upscale, upsample=upsample, dropout_prob=dropout_prob, is3d=is3d)
+
+    return type(name, (AbstractUNet,), {"__init__": __init__, "__doc__": doc, "__module__": _THIS_MODULE})
+
+
+UNet3D = _variant("UNet3D", DoubleConv, 4, True,
+                  "3D U-Net (DoubleConv blocks, nearest-neighbour upsampling + concat) — reference model.py:152-190.")
+ResidualUNet3D = _variant("ResidualUNet3D", ResNetBlock, 5, True,
+                          "Residual 3D U-Net (ResNetBlock, transposed-conv upsampling + sum) — reference model.py:193-234.")
+ResidualUNetSE3D = _variant("ResidualUNetSE3D", ResNetBlockSE, 5, True,
+                            "Residual 3D U-Net with squeeze-and-excitation blocks — reference model.py:237-278.")
+UNet2D = _variant("UNet2D", DoubleConv, 4, False, "2D U-Net — reference model.py:281-318.")
+ResidualUNet2D = _variant("ResidualUNet2D", ResNetBlock, 5, False, "Residual 2D U-Net — reference model.py:321-358.")
+
+
+def get_model(model_config):
+    """Instantiate the class named by model_config['name'] with the whole dict as kwargs (model.py:361-363)."""
+    model_class = get_class(model_config["name"], modules=[_THIS_MODULE])
+    return model_class(**model_config)
+
+
+def is_model_2d(model):
+    """True for UNet2D (also when wrapped in nn.DataParallel) — model.py:366-369."""
+    if isinstance(model, nn.DataParallel):
+        model = model.module
+    return isinstance(model, UNet2D)
