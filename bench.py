@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""bench.py — volumetric patches/sec (fwd+bwd) of the MI355X-native 3D U-Net hot path.
+
+Workload (BASELINE.json configs[1]/[2]): UNet3D in=1,out=1,f_maps=32,'gcr',num_groups=8, per-GPU batch
+2x1x64x128x128 fp32, BCEDiceLoss on the logits, synthetic N(0,1) patches / Bernoulli(0.5) targets, random-init
+weights.  A "step" = forward + loss + backward (+ gradient all-reduce when N>1) + Adam update, inputs resident in
+HBM.  One process per GPU (torch.distributed over RCCL); weak scaling: the per-GPU batch is fixed.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus 8 --steps 20 --warmup 3
+
+Rank 0 prints ONE JSON line (contract in the task description) extended with
+  "roofline":     fp32-MFMA roofline of the dominant kernel family, timed with HIP events on the launching stream
+  "cpu_baseline": the CPU oracle (port of the reference path on ATen CPU operators) timed on this box's host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "pytorch-3dunet_amd"), os.path.join(ROOT, "oracle"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
+PATCH = (64, 128, 128)
+PER_GPU_BATCH = 2
+MODEL_CFG = dict(in_channels=1, out_channels=1, f_maps=32, layer_order="gcr", num_groups=8, final_sigmoid=True)
+
+
+def conv_flops_per_patch(model):
+    """2*Cin*Cout*27*D*H*W per 3^3 conv at its resolution (473.822 GFLOP fwd per patch)."""
+    total = 0.0
+    d, h, w = PATCH
+    dims = []
+    for i, enc in enumerate(model.encoders):
+        if i > 0:
+            d, h, w = d // 2, h // 2, w // 2
+        dims.append((d, h, w))
+        for sc in (enc.basic_module.SingleConv1, enc.basic_module.SingleConv2):
+            total += 2.0 * sc.conv.in_channels * sc.conv.out_channels * 27 * d * h * w
+    for j, dec in enumerate(model.decoders):
+        d, h, w = dims[len(dims) - 2 - j]
+        for sc in (dec.basic_module.SingleConv1, dec.basic_module.SingleConv2):
+            total += 2.0 * sc.conv.in_channels * sc.conv.out_channels * 27 * d * h * w
+    return total
+
+
+def bce_dice(logits, target):
+    """BCEDiceLoss of the reference (losses.py:187-201) on device tensors (stock elementwise/reduction ops; the
+    fused loss kernel is SURVEY.md §8f row 1)."""
+    bce = torch.nn.functional.binary_cross_entropy_with_logits(logits, target)
+    p = torch.sigmoid(logits)
+    c = logits.shape[1]
+    pf = p.transpose(0, 1).reshape(c, -1)
+    tf = target.transpose(0, 1).reshape(c, -1)
+    dice = 2 * (pf * tf).sum(-1) / ((pf * pf).sum(-1) + (tf * tf).sum(-1)).clamp(min=1e-6)
+    return bce + (1.0 - dice.mean())
+
+
+def cpu_baseline(sample_iters=3):
+    """The CPU oracle (oracle/unet3d_oracle.py = the reference's module graph on ATen CPU operators) on a bounded
+    sample of the same workload: batch 1 of the same patch, 1 warm-up + `sample_iters` timed fwd+bwd."""
+    import unet3d_oracle as orc
+    from pytorch3dunet_amd.unet3d.model import UNet3D
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = UNet3D(**MODEL_CFG)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    x = torch.randn(1, 1, *PATCH)
+    target = (torch.rand(1, 1, *PATCH) > 0.5).float()
+    orc.forward_backward(sd, x, target, MODEL_CFG["num_groups"])  # warm-up
+    times = []
+    for _ in range(sample_iters):
+        t0 = time.perf_counter()
+        orc.forward_backward(sd, x, target, MODEL_CFG["num_groups"])
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(1.0 / med, 4), "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"batch 1x1x{PATCH[0]}x{PATCH[1]}x{PATCH[2]} fwd+bwd, 1 warm-up + {sample_iters} timed iterations "
+                      f"(median {med:.3f} s), torch {torch.__version__} CPU operators"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the HIP-event per-kernel timing")
+    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="per-GPU batch (default = BASELINE config 2)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    from pytorch3dunet_amd import _native as nat
+    from pytorch3dunet_amd import parallel
+    from pytorch3dunet_amd.unet3d.model import UNet3D
+
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    nat.call("u3d_check_device", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    torch.manual_seed(0)  # identical initial weights on every rank (also broadcast below)
+    model = UNet3D(**MODEL_CFG).to(dev).train()
+    if world > 1:
+        parallel.attach(model)
+    opt = torch.optim.Adam(model.parameters(), lr=2e-4, weight_decay=1e-5)  # 3DUnet_confocal_boundary/train_config.yml
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)  # per-rank synthetic shard
+    B = args.batch
+    x = torch.randn((B, 1, *PATCH), device=dev, generator=g)
+    target = (torch.rand((B, 1, *PATCH), device=dev, generator=g) > 0.5).float()
+
+    def step():
+        probs, logits = model(x, return_logits=True)
+        loss = bce_dice(logits, target)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    prof = None
+    if not args.no_roofline and rank == 0:
+        prof = nat.EventProfiler()
+        nat.profiler = prof
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    nat.profiler = None
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+    final_loss = loss.item()
+
+    if rank == 0:
+        patches = world * B * args.steps
+        value = patches / elapsed
+        f_fwd = conv_flops_per_patch(model)
+        out = {
+            "metric": "volumetric patches/sec (fwd+bwd), UNet3D f_maps=32 patch 64x128x128",
+            "value": round(value, 3),
+            "unit": "patches/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * elapsed / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"UNet3D in=1 out=1 f_maps=32 gcr num_groups=8, per-GPU batch {B}x1x64x128x128 fp32, "
+                                   "BCEDiceLoss, fwd+loss+bwd+Adam step, random-init weights",
+                       "global_batch": world * B, "parallelism": f"dp{world}",
+                       "conv_gflop_per_patch_fwd": round(f_fwd / 1e9, 3),
+                       "achieved_conv_tflops_whole_step": round(value / world * 3 * f_fwd / 1e12, 2),
+                       "final_loss": round(final_loss, 5)},
+        }
+        if prof is not None:
+            summ = prof.summary()
+            fams = {k: v for k, v in summ.items() if v["flops"] > 0}
+            dom = max(fams, key=lambda k: fams[k]["ms"])
+            d = fams[dom]
+            achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            out["roofline"] = {
+                "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "launches": d["calls"], "avg_launch_ms": round(d["ms"] / d["calls"], 4),
+                "gflop_per_launch": round(d["flops"] / d["calls"] / 1e9, 3),
+                "families": {k: {"calls": v["calls"], "ms_per_step": round(v["ms"] / args.steps, 3),
+                                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None}
+                             for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])},
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

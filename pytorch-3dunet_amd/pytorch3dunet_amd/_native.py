@@ -137,11 +137,42 @@ def check(rc: int, what: str = "") -> None:
         raise U3DError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
 
 
-def call(name: str, *args) -> None:
+class EventProfiler:
+    """Per-entry-point device time from HIP events recorded on the launching stream (bench.py's roofline leg).
+    Usage: nat.profiler = EventProfiler(); ...run...; torch.cuda.synchronize(); prof.summary()."""
+
+    def __init__(self):
+        self.records = []  # (name, flops, start_event, end_event)
+
+    def wrap(self, name, fn, args, flops):
+        import torch
+
+        st = torch.cuda.Event(enable_timing=True)
+        en = torch.cuda.Event(enable_timing=True)
+        st.record()
+        rc = fn(*args)
+        en.record()
+        self.records.append((name, flops, st, en))
+        return rc
+
+    def summary(self):
+        out = {}
+        for name, flops, st, en in self.records:
+            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "flops": 0.0})
+            d["calls"] += 1
+            d["ms"] += st.elapsed_time(en)
+            d["flops"] += flops
+        return out
+
+
+profiler = None
+
+
+def call(name: str, *args, flops: float = 0.0) -> None:
     """Call an int-returning entry point and raise on error."""
     global launch_count
     fn = getattr(get_lib(), name)
     launch_count += 1
-    rc = fn(*args)
+    rc = fn(*args) if profiler is None else profiler.wrap(name, fn, args, flops)
     if rc != U3D_OK:
         check(rc, name)

@@ -222,7 +222,7 @@ class UNet3DEngine:
         ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
         s = src.struct(affine)
         nat.call("u3d_conv3d", dev.index, _stream(dev), ctypes.byref(s), _p(wp), _p(y), N, D, H, W, Cout, 1, _p(ystats),
-                 None, None)
+                 None, None, flops=54.0 * Ctot * Cout * N * D * H * W)
         if tape is not None:
             tape.convs.append(
                 ConvRec(name, src, affine, mean_rstd, y, gn.weight, conv.weight, G, self._pindex[id(gn.weight)],
@@ -345,15 +345,16 @@ class UNet3DEngine:
             Nn, Dd, Hh, Ww = src.N, src.D, src.H, src.W
             Cout = rec.y.shape[-1]
             s_aff = src.struct(rec.affine)
+            flops = 54.0 * src.C * Cout * Nn * Dd * Hh * Ww
             nat.call("u3d_conv3d_wgrad", dev.index, _stream(dev), ctypes.byref(s_aff), _p(dz_), _p(gview(rec.idx_w)), Nn, Dd, Hh,
-                     Ww, Cout, _p(ws), ws.numel())
+                     Ww, Cout, _p(ws), ws.numel(), flops=flops)
             wpd = self._packed(rec.conv_w, 1, dev)
             dg = torch.empty((Nn, Dd, Hh, Ww, src.C), dtype=_F32, device=dev)
             gst = pool.take(Nn * src.C * 2)
             s_dz = VSrc(dz_).struct()
             s_x = src.struct()
             nat.call("u3d_conv3d", dev.index, _stream(dev), ctypes.byref(s_dz), _p(wpd), _p(dg), Nn, Dd, Hh, Ww, src.C, 0, None,
-                     ctypes.byref(s_x), _p(gst))
+                     ctypes.byref(s_x), _p(gst), flops=flops)
             coef = torch.empty((Nn, 3, src.C), dtype=_F32, device=dev)
             nat.call("u3d_gn_bwd_finalize", dev.index, _stream(dev), _p(gst), _p(rec.mean_rstd), _p(rec.gn_w.detach()), Nn, src.C,
                      rec.G, float(Dd * Hh * Ww), _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef))

@@ -1,0 +1,102 @@
+"""Generate the golden vectors in tests/golden/*.npz from the LIVE reference (wolny/pytorch-3dunet 1.9.6 imported
+from /root/reference through oracle/ref_import.py) — run in the build container only:
+
+    python tests/golden/make_golden.py
+
+Each fixture stores the synthetic input, the full state_dict, the reference's (probs, logits), the loss value and
+every parameter gradient after loss.backward() on the CPU path (fp32, torch 2.10.0+rocm7.0 CPU operators).
+`big` fixtures store seeds + strided samples instead of full tensors (the state_dict is re-created by seeding;
+the generator asserts that our module tree reproduces the reference's seeded initialisation bit-for-bit)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "pytorch-3dunet_amd"))
+
+from ref_import import import_reference  # noqa: E402
+
+CASES = {
+    # name: (model config, input shape, loss, full?)
+    "g1_unet3d_small": (dict(name="UNet3D", in_channels=1, out_channels=1, f_maps=[8, 16, 32], num_groups=4,
+                             final_sigmoid=True), (1, 1, 16, 24, 24), "bce_dice", True),
+    "g2_unet3d_multi_odd": (dict(name="UNet3D", in_channels=2, out_channels=3, f_maps=[8, 16], num_groups=2,
+                                 final_sigmoid=False), (2, 2, 9, 13, 11), "probs_sum", True),
+    "g3_unet3d_regression": (dict(name="UNet3D", in_channels=3, out_channels=2, f_maps=[8, 16, 32], num_groups=8,
+                                  is_segmentation=False), (1, 3, 12, 20, 17), "mse", True),
+    "g4_unet3d_f16_cfg1": (dict(name="UNet3D", in_channels=1, out_channels=1, f_maps=16, num_groups=8,
+                                final_sigmoid=True), (1, 1, 32, 64, 64), "bce_dice", False),
+}
+SAMPLE = 97  # stride of the samples kept for `big` fixtures
+
+
+def loss_fn(ref_losses, name, probs, logits, target):
+    if name == "bce_dice":
+        return ref_losses.BCEDiceLoss()(logits, target)  # losses.py:187-201, the loss of BASELINE config 2
+    if name == "mse":
+        return torch.nn.functional.mse_loss(logits, target)
+    if name == "probs_sum":
+        return (probs * target).sum() + 0.5 * (logits * logits).mean()
+    raise ValueError(name)
+
+
+def main():
+    import importlib
+
+    ref_model = import_reference()
+    ref_losses = importlib.import_module("pytorch3dunet.unet3d.losses")
+    from pytorch3dunet_amd.unet3d import model as mine
+
+    torch.set_num_threads(8)
+    for seed, (name, (cfg, shape, loss_name, full)) in enumerate(CASES.items()):
+        torch.manual_seed(100 + seed)
+        model = ref_model.get_model(dict(cfg))
+        torch.manual_seed(100 + seed)
+        ours = mine.get_model(dict(cfg))
+        same_init = all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), ours.state_dict().values()))
+        assert same_init, "seeded initialisation differs from the reference"
+        # perturb GroupNorm affine params away from (1,0) so their gradients/paths are exercised
+        g = torch.Generator().manual_seed(200 + seed)
+        with torch.no_grad():
+            for k, p in model.named_parameters():
+                if "groupnorm" in k:
+                    p.add_(0.2 * torch.randn(p.shape, generator=g))
+        model.train()
+        x = torch.randn(shape, generator=g)
+        n_out = cfg["out_channels"]
+        tshape = (shape[0], n_out) + shape[2:]
+        target = (torch.rand(tshape, generator=g) > 0.5).float()
+        probs, logits = model(x, return_logits=True)
+        loss = loss_fn(ref_losses, loss_name, probs, logits, target)
+        model.zero_grad()
+        loss.backward()
+        out = {"cfg": np.array(repr(cfg)), "loss_name": np.array(loss_name), "seed": np.array(100 + seed),
+               "pert_seed": np.array(200 + seed), "x_shape": np.array(shape), "loss": loss.detach().numpy(),
+               "full": np.array(full)}
+        if full:
+            out["x"] = x.numpy()
+            out["target"] = target.numpy()
+            out["probs"] = probs.detach().numpy()
+            out["logits"] = logits.detach().numpy()
+            for k, p in model.named_parameters():
+                out["sd/" + k] = p.detach().numpy()
+                out["grad/" + k] = p.grad.numpy()
+        else:
+            out["probs_s"] = probs.detach().flatten()[::SAMPLE].numpy()
+            out["logits_s"] = logits.detach().flatten()[::SAMPLE].numpy()
+            out["logits_absmax"] = logits.detach().abs().max().numpy()
+            for k, p in model.named_parameters():
+                out["grad_s/" + k] = p.grad.flatten()[::SAMPLE].numpy()
+                out["grad_norm/" + k] = p.grad.norm().numpy()
+                out["grad_absmax/" + k] = p.grad.abs().max().numpy()
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: loss={loss.item():.6f} -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,153 @@
+"""CPU: the drop-in boundary — API surface, state_dict compatibility, error behaviour, and that
+the C-ABI library loads and exports every symbol include/u3d.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import Golden, ROOT
+from pytorch3dunet_amd import _native as nat
+from pytorch3dunet_amd.unet3d import buildingblocks as bb
+from pytorch3dunet_amd.unet3d import model as M
+from pytorch3dunet_amd.unet3d.utils import get_class, number_of_features_per_level
+from ref_import import import_reference, reference_available
+
+ALL_CFGS = [
+    dict(name="UNet3D", in_channels=1, out_channels=1, f_maps=16),
+    dict(name="UNet3D", in_channels=3, out_channels=2, f_maps=[16, 32, 64], num_groups=4, final_sigmoid=False),
+    dict(name="ResidualUNet3D", in_channels=1, out_channels=1, f_maps=16),
+    dict(name="ResidualUNetSE3D", in_channels=1, out_channels=1, f_maps=16, num_levels=3),
+    dict(name="UNet2D", in_channels=1, out_channels=1, f_maps=16),
+    dict(name="ResidualUNet2D", in_channels=1, out_channels=1, f_maps=16, num_levels=3),
+]
+
+
+def test_header_symbols_exported():
+    """every function declared in include/u3d.h is exported by libu3d_hip.so and bound in _native.py"""
+    hdr = open(os.path.join(ROOT, "include", "u3d.h")).read()
+    declared = set(re.findall(r"\b(u3d_[a-z0-9_]+)\s*\(", hdr)) - {"u3d_stream_t", "u3d_src_t"}
+    assert declared, "no declarations parsed"
+    assert declared == set(nat.EXPORTED_SYMBOLS)
+    if not nat.lib_available():
+        pytest.fail(f"{nat.LIB_PATH} missing: run __graft_entry__.build()")
+    lib = ctypes.CDLL(nat.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert nat.get_lib().u3d_version() == 100
+
+
+def test_host_only_entry_points():
+    lib = nat.get_lib()
+    # packed image: ceil(K/16) chunks x 54 steps x ceil(N/32) n-tiles x 256 floats
+    assert lib.u3d_packed_weight_floats(96, 32, 0) == 6 * 54 * 1 * 256
+    assert lib.u3d_packed_weight_floats(96, 32, 1) == 2 * 54 * 3 * 256
+    assert lib.u3d_packed_weight_floats(1, 16, 0) == 1 * 54 * 1 * 256
+    ws = lib.u3d_wgrad_workspace_floats(1, 64, 128, 128, 96, 32)
+    assert ws % (27 * 1024) == 0 and 0 < ws < (1 << 28)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(nat, "_lib", None)
+    monkeypatch.setattr(nat, "LIB_PATH", "/nonexistent/libu3d_hip.so")
+    with pytest.raises(nat.U3DError):
+        nat.get_lib()
+
+
+def test_struct_layout_matches_header():
+    # 6 pointers + 5 int32, padded to pointer alignment
+    assert ctypes.sizeof(nat.U3DSrc) == 72
+    assert nat.U3DSrc.C0.offset == 48 and nat.U3DSrc.W1.offset == 64
+
+
+def test_get_model_and_class_lookup():
+    m = M.get_model(dict(name="UNet3D", in_channels=1, out_channels=1, f_maps=16, some_unknown_key=3))
+    assert isinstance(m, M.UNet3D) and m.native_supported
+    with pytest.raises(RuntimeError):
+        get_class("NoSuchNet", [M.__name__])
+    assert number_of_features_per_level(32, 4) == [32, 64, 128, 256]
+    assert M.is_model_2d(M.UNet2D(1, 1, f_maps=16)) and not M.is_model_2d(M.UNet3D(1, 1, f_maps=16))
+    assert M.is_model_2d(torch.nn.DataParallel(M.UNet2D(1, 1, f_maps=16)))
+
+
+def test_constructor_validation():
+    with pytest.raises(ValueError):
+        bb.create_conv(4, 8, 3, "gcx", 8, 1, 0.1, True)
+    with pytest.raises(AssertionError):
+        bb.create_conv(4, 8, 3, "gr", 8, 1, 0.1, True)  # no conv
+    with pytest.raises(AssertionError):
+        bb.create_conv(4, 8, 3, "rcg", 8, 1, 0.1, True)  # non-linearity first
+    with pytest.raises(AssertionError):
+        bb.create_conv(12, 8, 3, "gcr", 8, 1, 0.1, True)  # 12 % 8 != 0
+    with pytest.raises(AssertionError):
+        M.UNet3D(1, 1, f_maps=[16])
+    # fewer channels than groups -> one group (buildingblocks.py:69-70)
+    layers = dict(bb.create_conv(1, 16, 3, "gcr", 8, 1, 0.1, True))
+    assert layers["groupnorm"].num_groups == 1 and layers["conv"].bias is None
+    assert dict(bb.create_conv(4, 8, 3, "cr", 8, 1, 0.1, True))["conv"].bias is not None
+
+
+def test_encoder_decoder_widths_unet3d_f32():
+    m = M.UNet3D(1, 1, f_maps=32)
+    w = [(tuple(sc.conv.weight.shape[:2])) for e in m.encoders for sc in (e.basic_module.SingleConv1, e.basic_module.SingleConv2)]
+    assert w == [(16, 1), (32, 16), (32, 32), (64, 32), (64, 64), (128, 64), (128, 128), (256, 128)]
+    w = [(tuple(sc.conv.weight.shape[:2])) for d in m.decoders for sc in (d.basic_module.SingleConv1, d.basic_module.SingleConv2)]
+    assert w == [(128, 384), (128, 128), (64, 192), (64, 64), (32, 96), (32, 32)]
+    assert sum(p.numel() for p in m.parameters()) == 4081267
+
+
+@pytest.mark.parametrize("name", ["g1_unet3d_small", "g2_unet3d_multi_odd", "g3_unet3d_regression"])
+def test_golden_state_dict_loads_strict_and_cpu_forward_matches(name):
+    g = Golden(name)
+    model = g.build_model()
+    x, _ = g.inputs()
+    model.train()
+    probs, logits = model(x, return_logits=True)  # CPU tensors -> torch.nn module tree
+    assert torch.allclose(logits, g.tensor("logits"), atol=1e-5, rtol=1e-5)
+    assert torch.allclose(probs, g.tensor("probs"), atol=1e-6, rtol=1e-5)
+    single = model(x)
+    assert torch.equal(single, probs)
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference only exists in the build container")
+@pytest.mark.parametrize("cfg", ALL_CFGS, ids=lambda c: c["name"] + str(c["in_channels"]))
+def test_state_dict_keys_shapes_match_reference(cfg):
+    ref = import_reference()
+    torch.manual_seed(0)
+    r = ref.get_model(dict(cfg))
+    torch.manual_seed(0)
+    m = M.get_model(dict(cfg))
+    rs, ms = r.state_dict(), m.state_dict()
+    assert list(rs.keys()) == list(ms.keys())
+    for k in rs:
+        assert rs[k].shape == ms[k].shape
+        assert torch.equal(rs[k], ms[k]), f"seeded init differs at {k}"
+    m.load_state_dict(rs, strict=True)
+
+
+def test_reference_property_tests_on_cpu():
+    """the reference's own tests for this path (tests/test_models.py:8-69) are range checks on odd-sized inputs"""
+    for cls, shape in [(M.UNet3D, (1, 1, 33, 65, 65)), (M.ResidualUNet3D, (1, 1, 17, 33, 33)), (M.UNet2D, (1, 1, 65, 65))]:
+        model = cls(1, 1, f_maps=16, final_sigmoid=True).eval()
+        with torch.no_grad():
+            y = model(torch.rand(shape))
+        assert torch.all(0 <= y) and torch.all(y <= 1)
+    for out_c in (64, 32):
+        blk = bb.ResNetBlock(33, out_c, is3d=False, order="cgr").eval()
+        with torch.no_grad():
+            assert torch.all(blk(torch.rand(1, 33, 65, 65)) >= 0)
+
+
+def test_nearest_maps_match_interpolate():
+    from pytorch3dunet_amd.engine import nearest_map_host
+
+    for n_in, n_out in [(8, 16), (16, 33), (5, 9), (7, 7), (10, 21), (1, 3)]:
+        m = nearest_map_host(n_in, n_out)
+        src = torch.arange(n_in, dtype=torch.float32).view(1, 1, n_in, 1, 1).expand(1, 1, n_in, 2, 2)
+        up = torch.nn.functional.interpolate(src, size=(n_out, 2, 2), mode="nearest")[0, 0, :, 0, 0]
+        assert torch.equal(m.float(), up)
+        lo = torch.searchsorted(m.long(), torch.arange(n_in + 1))
+        assert lo[0] == 0 and lo[-1] == n_out
+        for i in range(n_in):  # children ranges partition the output
+            assert torch.all(m[lo[i]:lo[i + 1]] == i)

@@ -1,0 +1,328 @@
+"""-m gpu: every HIP kernel of the hot path, called through the C-ABI, against the CPU oracle
+(torch-functional restatement, oracle/unet3d_oracle.py) on the same seeded inputs.  Tolerance: 1e-3 relative to
+the tensor's max-abs (BASELINE.json north_star: "within 1e-3 rel fp32"); most kernels are held to 2e-5."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+def _mods():
+    import gpu_utils as U
+    from pytorch3dunet_amd import _native as nat
+    from pytorch3dunet_amd.engine import VSrc, _p, _stream
+
+    return U, nat, VSrc, _p, _stream
+
+
+def test_device_is_gfx950_and_native_lib_loaded():
+    U, nat, *_ = _mods()
+    nat.call("u3d_check_device", 0)
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+CONV_CASES = [
+    # N, Cin, Cout, D, H, W, affine, relu
+    (1, 16, 32, 8, 16, 16, False, 0),
+    (1, 16, 32, 8, 16, 16, True, 1),
+    (2, 32, 32, 4, 8, 8, True, 1),
+    (1, 1, 16, 8, 16, 16, True, 1),       # first layer: C=1, scalar load path, Cout < 32
+    (1, 3, 8, 5, 9, 7, True, 0),          # odd dims, odd channels
+    (2, 32, 64, 9, 13, 11, True, 1),      # odd dims, partial tiles, 2 n-tiles
+    (1, 96, 32, 8, 16, 16, True, 1),      # 6 chunks (dec2.conv1 channel shape)
+    (1, 64, 128, 4, 8, 8, False, 0),      # 4 n-tiles
+    (1, 20, 24, 6, 10, 9, True, 1),       # channel padding inside a chunk (vec path, C%4==0 but C%16!=0)
+]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,D,H,W,affine,relu", CONV_CASES)
+def test_conv3d_fwd(N, Cin, Cout, D, H, W, affine, relu):
+    U, nat, VSrc, _p, _stream = _mods()
+    torch.manual_seed(Cin * 131 + Cout)
+    x = torch.randn(N, Cin, D, H, W)
+    w = torch.randn(Cout, Cin, 3, 3, 3) / (27 * Cin) ** 0.5
+    aff = None
+    g = x
+    if affine:
+        ab = torch.randn(N, Cin, 2)
+        aff = ab.contiguous().to(U.DEV)
+        g = x * ab[:, :, 0].view(N, Cin, 1, 1, 1) + ab[:, :, 1].view(N, Cin, 1, 1, 1)
+    ref = F.conv3d(g, w, None, padding=1)
+    if relu:
+        ref = F.relu(ref)
+    src = VSrc(U.ndhwc(x))
+    st = torch.zeros((N, Cout, 2), dtype=torch.float64, device=U.DEV)
+    y = U.conv3d(src, w, Cout, relu=relu, affine=aff, out_stats=st)
+    got = U.ncdhw(y)
+    assert U.relerr(got, ref) < TOL
+    # fused epilogue statistics = per-(n,channel) sum / sum of squares of the written output
+    s_ref = torch.stack([ref.double().sum(dim=(2, 3, 4)), (ref.double() ** 2).sum(dim=(2, 3, 4))], dim=-1)
+    assert U.relerr(st.cpu(), s_ref) < 1e-5
+    # cross-check the naive device kernel (used for the full-size checks)
+    yn = U.conv3d_naive(src, w, Cout, relu=relu, affine=aff)
+    assert U.relerr(U.ncdhw(yn), ref) < TOL
+
+
+def test_conv3d_fwd_nt2_many_tiles():
+    """>= 512 tiles with 64 output channels selects the BN=64 (NT=2) kernel"""
+    U, nat, VSrc, _p, _stream = _mods()
+    torch.manual_seed(5)
+    N, Cin, Cout, D, H, W = 1, 32, 64, 32, 64, 64
+    x = torch.randn(N, Cin, D, H, W)
+    w = torch.randn(Cout, Cin, 3, 3, 3) / (27 * Cin) ** 0.5
+    ref = F.relu(F.conv3d(x, w, None, padding=1))
+    y = U.conv3d(VSrc(U.ndhwc(x)), w, Cout, relu=1)
+    assert U.relerr(U.ncdhw(y), ref) < TOL
+
+
+@pytest.mark.parametrize("size", [(8, 16, 16), (9, 13, 11)])
+def test_conv3d_virtual_concat_upsample(size):
+    """skip (full-res) ++ nearest-upsampled low-res tensor, never materialised (buildingblocks.py:491,:614)"""
+    U, nat, VSrc, _p, _stream = _mods()
+    torch.manual_seed(11)
+    N, C0, C1, Cout = 2, 8, 16, 32
+    D, H, W = size
+    D1, H1, W1 = D // 2, H // 2, W // 2
+    skip = torch.randn(N, C0, D, H, W)
+    low = torch.randn(N, C1, D1, H1, W1)
+    cat = torch.cat((skip, F.interpolate(low, size=size, mode="nearest")), dim=1)
+    w = torch.randn(Cout, C0 + C1, 3, 3, 3) / (27 * (C0 + C1)) ** 0.5
+    ab = torch.randn(N, C0 + C1, 2)
+    g = cat * ab[:, :, 0].view(N, -1, 1, 1, 1) + ab[:, :, 1].view(N, -1, 1, 1, 1)
+    ref = F.relu(F.conv3d(g, w, None, padding=1))
+    src = VSrc(U.ndhwc(skip), U.ndhwc(low))
+    y = U.conv3d(src, w, Cout, relu=1, affine=ab.contiguous().to(U.DEV))
+    assert U.relerr(U.ncdhw(y), ref) < TOL
+    # channel statistics of the virtual tensor
+    st = U.chan_stats(src)
+    s_ref = torch.stack([cat.double().sum(dim=(2, 3, 4)), (cat.double() ** 2).sum(dim=(2, 3, 4))], dim=-1)
+    assert U.relerr(st.cpu(), s_ref) < 1e-5
+    # weight gradient through the same virtual source
+    dz = torch.randn(N, Cout, D, H, W)
+    gl = g.clone().requires_grad_(False)
+    wl = w.clone().requires_grad_(True)
+    F.conv3d(gl, wl, None, padding=1).backward(dz)
+    dw = U.wgrad(src, U.ndhwc(dz), Cout, affine=ab.contiguous().to(U.DEV))
+    assert U.relerr(dw.cpu(), wl.grad) < 1e-4
+
+
+DGRAD_CASES = [(1, 16, 32, 8, 16, 16), (2, 32, 64, 9, 13, 11), (1, 1, 16, 8, 16, 16), (1, 96, 32, 4, 8, 8), (1, 3, 8, 5, 9, 7)]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,D,H,W", DGRAD_CASES)
+def test_conv3d_dgrad_and_groupnorm_reductions(N, Cin, Cout, D, H, W):
+    """data gradient = the same kernel on dz with mode-1 packed weights; its epilogue accumulates
+    (sum dg, sum dg*x) — the two reductions GroupNorm backward needs"""
+    U, nat, VSrc, _p, _stream = _mods()
+    torch.manual_seed(Cin + 7 * Cout)
+    x = torch.randn(N, Cin, D, H, W)
+    w = torch.randn(Cout, Cin, 3, 3, 3) / (27 * Cin) ** 0.5
+    dz = torch.randn(N, Cout, D, H, W)
+    xl = x.clone().requires_grad_(True)
+    F.conv3d(xl, w, None, padding=1).backward(dz)
+    ref = xl.grad
+    gst = torch.zeros((N, Cin, 2), dtype=torch.float64, device=U.DEV)
+    dg = U.conv3d(VSrc(U.ndhwc(dz)), w, Cin, relu=0, mode=1, gx=VSrc(U.ndhwc(x)), gstats=gst)
+    assert U.relerr(U.ncdhw(dg), ref) < TOL
+    s_ref = torch.stack([ref.double().sum(dim=(2, 3, 4)), (ref.double() * x.double()).sum(dim=(2, 3, 4))], dim=-1)
+    assert U.relerr(gst.cpu(), s_ref) < 1e-5
+    dn = U.conv3d_naive(VSrc(U.ndhwc(dz)), w, Cin, flip=1)
+    assert U.relerr(U.ncdhw(dn), ref) < TOL
+
+
+WGRAD_CASES = [(1, 16, 32, 8, 16, 16, False), (2, 32, 64, 9, 13, 11, True), (1, 1, 16, 8, 16, 16, True),
+               (1, 96, 32, 4, 8, 8, True), (1, 3, 8, 5, 9, 7, True), (1, 64, 128, 4, 8, 8, False),
+               (1, 32, 32, 16, 32, 32, True)]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,D,H,W,affine", WGRAD_CASES)
+def test_conv3d_wgrad(N, Cin, Cout, D, H, W, affine):
+    U, nat, VSrc, _p, _stream = _mods()
+    torch.manual_seed(Cin * 3 + Cout)
+    x = torch.randn(N, Cin, D, H, W)
+    dz = torch.randn(N, Cout, D, H, W)
+    aff, g = None, x
+    if affine:
+        ab = torch.randn(N, Cin, 2)
+        aff = ab.contiguous().to(U.DEV)
+        g = x * ab[:, :, 0].view(N, Cin, 1, 1, 1) + ab[:, :, 1].view(N, Cin, 1, 1, 1)
+    wl = torch.zeros(Cout, Cin, 3, 3, 3, requires_grad=True)
+    F.conv3d(g, wl, None, padding=1).backward(dz)
+    dw = U.wgrad(VSrc(U.ndhwc(x)), U.ndhwc(dz), Cout, affine=aff)
+    assert U.relerr(dw.cpu(), wl.grad) < 1e-4
+
+
+@pytest.mark.parametrize("N,C,G,size", [(2, 16, 8, (6, 10, 9)), (1, 1, 1, (8, 16, 16)), (2, 96, 8, (4, 8, 8)), (1, 384, 8, (2, 4, 4)), (2, 6, 1, (5, 7, 3))])
+def test_groupnorm_forward_stats_and_affine(N, C, G, size):
+    U, nat, VSrc, _p, _stream = _mods()
+    torch.manual_seed(C)
+    x = torch.randn(N, C, *size) * 1.7 + 0.6
+    gamma, beta = torch.randn(C), torch.randn(C)
+    src = VSrc(U.ndhwc(x))
+    st = U.chan_stats(src)
+    V = size[0] * size[1] * size[2]
+    aff, mr = U.gn_finalize(st, C, 1.0, None, 0, 0.0, N, G, V, gamma.to(U.DEV), beta.to(U.DEV))
+    ref = F.group_norm(x, G, gamma, beta, 1e-5)
+    a = aff.cpu()
+    got = x * a[:, :, 0].view(N, C, 1, 1, 1) + a[:, :, 1].view(N, C, 1, 1, 1)
+    assert U.relerr(got, ref) < TOL
+    xg = x.view(N, G, -1).double()
+    assert U.relerr(mr.cpu()[:, :, 0], xg.mean(-1)) < 1e-5
+    assert U.relerr(mr.cpu()[:, :, 1], 1.0 / torch.sqrt(xg.var(-1, unbiased=False) + 1e-5)) < 1e-5
+
+
+@pytest.mark.parametrize("N,C,G,size,relu", [(2, 16, 8, (6, 10, 9), 1), (1, 4, 1, (8, 8, 8), 0), (2, 96, 8, (4, 8, 8), 1), (1, 6, 2, (3, 5, 7), 1)])
+def test_groupnorm_backward(N, C, G, size, relu):
+    """dx = p*dg + q*x + r with the finalize kernel's coefficients == autograd of F.group_norm (+ReLU of the producer)"""
+    U, nat, VSrc, _p, _stream = _mods()
+    torch.manual_seed(C + 1)
+    pre = torch.randn(N, C, *size)
+    x = F.relu(pre) if relu else pre
+    gamma, beta = torch.randn(C), torch.randn(C)
+    dg = torch.randn(N, C, *size)
+    pl = pre.clone().requires_grad_(True)
+    gl = gamma.clone().requires_grad_(True)
+    bl = beta.clone().requires_grad_(True)
+    xin = F.relu(pl) if relu else pl
+    F.group_norm(xin, G, gl, bl, 1e-5).backward(dg)
+    V = size[0] * size[1] * size[2]
+    # forward stats on device
+    src = VSrc(U.ndhwc(x))
+    st = U.chan_stats(src)
+    aff, mr = U.gn_finalize(st, C, 1.0, None, 0, 0.0, N, G, V, gamma.to(U.DEV), beta.to(U.DEV))
+    gst = torch.stack([dg.double().sum(dim=(2, 3, 4)), (dg.double() * x.double()).sum(dim=(2, 3, 4))], dim=-1).contiguous().to(U.DEV)
+    dgam = torch.empty(C, device=U.DEV)
+    dbet = torch.empty(C, device=U.DEV)
+    coef = torch.empty((N, 3, C), device=U.DEV)
+    nat.call("u3d_gn_bwd_finalize", 0, _stream(U.DEV), _p(gst), _p(mr), _p(gamma.to(U.DEV)), N, C, G, float(V), _p(dgam), _p(dbet), _p(coef))
+    assert U.relerr(dgam.cpu(), gl.grad) < 1e-4
+    assert U.relerr(dbet.cpu(), bl.grad) < 1e-4
+    xd, dgd = U.ndhwc(x), U.ndhwc(dg)
+    out = torch.empty_like(xd)
+    nat.call("u3d_gn_bwd_apply", 0, _stream(U.DEV), _p(dgd), C, 0, _p(xd), C, _p(coef), C, V, N, relu, _p(out))
+    assert U.relerr(U.ncdhw(out), pl.grad) < 1e-4
+
+
+@pytest.mark.parametrize("size", [(8, 12, 16), (9, 13, 11)])
+def test_groupnorm_backward_concat_split(size):
+    """GroupNorm backward over the virtual concat: skip half (plain affine map) + upsampled half (children sum)"""
+    U, nat, VSrc, _p, _stream = _mods()
+    torch.manual_seed(3)
+    N, C0, C1, G = 2, 8, 16, 4
+    D, H, W = size
+    D1, H1, W1 = D // 2, H // 2, W // 2
+    skip = torch.randn(N, C0, D, H, W, requires_grad=True)
+    lowpre = torch.randn(N, C1, D1, H1, W1, requires_grad=True)
+    low = F.relu(lowpre)
+    gamma, beta = torch.randn(C0 + C1), torch.randn(C0 + C1)
+    cat = torch.cat((skip, F.interpolate(low, size=size, mode="nearest")), dim=1)
+    dg = torch.randn(N, C0 + C1, D, H, W)
+    F.group_norm(cat, G, gamma, beta, 1e-5).backward(dg)
+    V = D * H * W
+    src = VSrc(U.ndhwc(skip.detach()), U.ndhwc(low.detach()))
+    st = U.chan_stats(src)
+    C = C0 + C1
+    aff, mr = U.gn_finalize(st, C, 1.0, None, 0, 0.0, N, G, V, gamma.to(U.DEV), beta.to(U.DEV))
+    catd = cat.detach()
+    gst = torch.stack([dg.double().sum(dim=(2, 3, 4)), (dg.double() * catd.double()).sum(dim=(2, 3, 4))], dim=-1).contiguous().to(U.DEV)
+    dgam, dbet = torch.empty(C, device=U.DEV), torch.empty(C, device=U.DEV)
+    coef = torch.empty((N, 3, C), device=U.DEV)
+    nat.call("u3d_gn_bwd_finalize", 0, _stream(U.DEV), _p(gst), _p(mr), _p(gamma.to(U.DEV)), N, C, G, float(V), _p(dgam), _p(dbet), _p(coef))
+    dgd = U.ndhwc(dg)
+    sg = torch.empty((N, D, H, W, C0), device=U.DEV)
+    nat.call("u3d_gn_bwd_apply", 0, _stream(U.DEV), _p(dgd), C, 0, _p(src.t0), C0, _p(coef), C, V, N, 0, _p(sg))
+    assert U.relerr(U.ncdhw(sg), skip.grad) < 1e-4
+    dzl = torch.empty_like(src.t1)
+    lz, ly, lx = src.los
+    nat.call("u3d_gn_bwd_apply_up", 0, _stream(U.DEV), _p(dgd), C, C0, _p(src.t1), C1, _p(coef), C, N, D, H, W, D1, H1, W1,
+             _p(lz), _p(ly), _p(lx), 1, _p(dzl))
+    assert U.relerr(U.ncdhw(dzl), lowpre.grad) < 1e-4
+
+
+@pytest.mark.parametrize("N,C,size", [(2, 8, (8, 12, 16)), (1, 5, (9, 13, 11)), (1, 32, (4, 6, 2))])
+def test_maxpool_forward_backward_merge(N, C, size):
+    U, nat, VSrc, _p, _stream = _mods()
+    torch.manual_seed(C)
+    D, H, W = size
+    pre = torch.randn(N, C, D, H, W, requires_grad=True)
+    e = F.relu(pre)  # post-ReLU: exact-zero ties exercise the first-max rule
+    pooled = F.max_pool3d(e, 2)
+    dpool = torch.randn_like(pooled)
+    skipg = torch.randn(N, C, D, H, W)
+    (pooled * dpool).sum().backward(retain_graph=True)
+    (e * skipg).sum().backward()
+    ed = U.ndhwc(e.detach())
+    D2, H2, W2 = D // 2, H // 2, W // 2
+    out = torch.empty((N, D2, H2, W2, C), device=U.DEV)
+    am = torch.empty(out.shape, dtype=torch.uint8, device=U.DEV)
+    st = torch.zeros((N, C, 2), dtype=torch.float64, device=U.DEV)
+    nat.call("u3d_maxpool2_fwd", 0, _stream(U.DEV), _p(ed), N, D, H, W, C, _p(out), _p(am), _p(st))
+    assert torch.equal(U.ncdhw(out), pooled.detach())
+    pd = pooled.detach().double()
+    assert U.relerr(st.cpu(), torch.stack([pd.sum(dim=(2, 3, 4)), (pd ** 2).sum(dim=(2, 3, 4))], dim=-1)) < 1e-6
+    res = torch.empty_like(ed)
+    nat.call("u3d_maxpool2_bwd_merge", 0, _stream(U.DEV), _p(U.ndhwc(dpool)), None, _p(am), None, _p(U.ndhwc(skipg)), _p(ed),
+             N, D, H, W, C, 1, _p(res))
+    assert U.relerr(U.ncdhw(res), pre.grad) < 1e-6
+
+
+@pytest.mark.parametrize("N,Cin,Cout,act", [(2, 32, 1, 1), (1, 8, 3, 2), (1, 16, 2, 0)])
+def test_head_forward_backward(N, Cin, Cout, act):
+    U, nat, VSrc, _p, _stream = _mods()
+    torch.manual_seed(Cin + Cout)
+    D, H, W = 5, 6, 7
+    V = D * H * W
+    pre = torch.randn(N, Cin, D, H, W, requires_grad=True)
+    x = F.relu(pre)
+    w = torch.randn(Cout, Cin, 1, 1, 1, requires_grad=True)
+    b = torch.randn(Cout, requires_grad=True)
+    logits = F.conv3d(x, w, b)
+    probs = torch.sigmoid(logits) if act == 1 else (torch.softmax(logits, 1) if act == 2 else logits)
+    dl = torch.randn_like(logits)
+    logits.backward(dl)
+    xd = U.ndhwc(x.detach())
+    lg = torch.empty((N, Cout, D, H, W), device=U.DEV)
+    pr = torch.empty_like(lg)
+    nat.call("u3d_conv1x1_head_fwd", 0, _stream(U.DEV), _p(xd), _p(w.detach().to(U.DEV)), _p(b.detach().to(U.DEV)), N, V, Cin,
+             Cout, act, _p(lg), _p(pr) if act else None)
+    assert U.relerr(lg.cpu(), logits.detach()) < TOL
+    if act:
+        assert U.relerr(pr.cpu(), probs.detach()) < TOL
+    dx = torch.empty_like(xd)
+    acc = torch.zeros(Cout * Cin + Cout, dtype=torch.float64, device=U.DEV)
+    nat.call("u3d_conv1x1_head_bwd", 0, _stream(U.DEV), _p(dl.to(U.DEV)), _p(xd), _p(w.detach().to(U.DEV)), N, V, Cin, Cout, 1,
+             _p(dx), _p(acc))
+    assert U.relerr(U.ncdhw(dx), pre.grad) < TOL
+    f32 = torch.empty(Cout * Cin + Cout, device=U.DEV)
+    nat.call("u3d_cvt_f64_f32", 0, _stream(U.DEV), _p(acc), _p(f32), acc.numel())
+    assert U.relerr(f32[: Cout * Cin].cpu().view(Cout, Cin), w.grad.view(Cout, Cin)) < 1e-5
+    assert U.relerr(f32[Cout * Cin:].cpu(), b.grad) < 1e-5
+
+
+def test_layout_transposes_roundtrip():
+    U, nat, VSrc, _p, _stream = _mods()
+    x = torch.randn(2, 5, 7, 9, 11)
+    xd = x.to(U.DEV)
+    V = 7 * 9 * 11
+    y = torch.empty((2, 7, 9, 11, 5), device=U.DEV)
+    nat.call("u3d_ncdhw_to_ndhwc", 0, _stream(U.DEV), _p(xd), _p(y), 2, 5, V)
+    assert torch.equal(y.cpu(), x.permute(0, 2, 3, 4, 1).contiguous())
+    z = torch.empty_like(xd)
+    nat.call("u3d_ndhwc_to_ncdhw", 0, _stream(U.DEV), _p(y), _p(z), 2, 5, V)
+    assert torch.equal(z.cpu(), x)
+
+
+def test_error_convention():
+    """bad arguments come back as a negative code + message, never an abort (include/u3d.h conventions)"""
+    U, nat, VSrc, _p, _stream = _mods()
+    lib = nat.get_lib()
+    rc = lib.u3d_pack_weights(0, None, None, 4, 4, 0, None)
+    assert rc == -1 and b"u3d_pack_weights" in lib.u3d_last_error()
+    x = torch.zeros((1, 2, 2, 2, 4), device=U.DEV)
+    with pytest.raises(nat.U3DError):
+        nat.call("u3d_gn_finalize", 0, _stream(U.DEV), _p(x), 5, 1.0, None, 0, 0.0, 1, 2, 8.0, _p(x), _p(x), 1e-5, _p(x), _p(x))

@@ -1,0 +1,175 @@
+"""-m gpu: the whole hot path (model forward + backward through the fused executor) against the golden vectors
+of the live reference, against the CPU oracle on extra configurations, and — at BASELINE.json's full sizes — through
+size-independent properties."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import Golden, GOLDEN_NAMES, loss_by_name
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-3  # BASELINE.json north_star: within 1e-3 rel fp32 of the reference CPU path
+
+
+def _run_native(model, x, target, loss_name):
+    from pytorch3dunet_amd import _native as nat
+
+    dev = torch.device("cuda", 0)
+    model = model.to(dev).train()
+    before = nat.launch_count
+    probs, logits = model(x.to(dev), return_logits=True)
+    loss = loss_by_name(loss_name, probs, logits, target.to(dev))
+    model.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert nat.launch_count > before, "native HIP path did not run"
+    grads = {k: p.grad.detach().cpu() for k, p in model.named_parameters()}
+    return probs.detach().cpu(), logits.detach().cpu(), loss.item(), grads
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_model_matches_reference_golden(name):
+    import unet3d_oracle as orc
+
+    g = Golden(name)
+    model = g.build_model()
+    x, target = g.inputs()
+    probs, logits, loss, grads = _run_native(model, x, target, g.loss_name)
+    assert abs(loss - g.loss) <= REL * max(1.0, abs(g.loss))
+    if g.full:
+        assert orc.rel_err(logits, g.tensor("logits")) < REL
+        assert orc.rel_err(probs, g.tensor("probs")) < REL
+        worst = 0.0
+        for k, rg in g.group("grad/").items():
+            e = orc.rel_err(grads[k], rg)
+            worst = max(worst, e)
+            assert e < REL, f"{k}: {e}"
+        print(f"{name}: logits rel {orc.rel_err(logits, g.tensor('logits')):.2e}, worst grad rel {worst:.2e}")
+    else:
+        s = 97
+        assert (logits.flatten()[::s] - g.tensor("logits_s")).abs().max().item() < REL * float(g.z["logits_absmax"])
+        for k, rs in g.group("grad_s/").items():
+            am = float(g.z["grad_absmax/" + k])
+            assert (grads[k].flatten()[::s] - rs).abs().max().item() < REL * am, k
+            n_ref = float(g.z["grad_norm/" + k])
+            assert abs(grads[k].norm().item() - n_ref) < REL * n_ref + 1e-12, k
+
+
+@pytest.mark.parametrize("cfg,shape,loss_name", [
+    (dict(in_channels=1, out_channels=1, f_maps=32, num_groups=8), (2, 1, 16, 32, 32), "bce_dice"),  # cfg2 model, small patch, batch 2
+    (dict(in_channels=1, out_channels=1, f_maps=16, num_groups=8), (1, 1, 33, 65, 65), "bce_dice"),  # the reference's odd test shape
+    (dict(in_channels=3, out_channels=2, f_maps=[16, 32, 64, 128], num_groups=4, final_sigmoid=False), (1, 3, 16, 24, 40), "probs_sum"),
+])
+def test_model_matches_cpu_oracle(cfg, shape, loss_name):
+    import unet3d_oracle as orc
+    from pytorch3dunet_amd.unet3d.model import UNet3D
+
+    torch.manual_seed(1234)
+    model = UNet3D(**cfg)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if "groupnorm" in k:
+                p.add_(0.2 * torch.randn_like(p))
+    x = torch.randn(shape)
+    target = (torch.rand((shape[0], cfg["out_channels"]) + shape[2:]) > 0.5).float()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    p_ref, l_ref, loss_ref, g_ref = orc.forward_backward(sd, x, target, cfg["num_groups"], cfg.get("final_sigmoid", True), True, loss_name)
+    probs, logits, loss, grads = _run_native(model, x, target, loss_name)
+    assert orc.rel_err(logits, l_ref) < REL
+    assert orc.rel_err(probs, p_ref) < REL
+    assert abs(loss - loss_ref.item()) < REL * max(1.0, abs(loss_ref.item()))
+    for k in g_ref:
+        assert orc.rel_err(grads[k], g_ref[k]) < REL, k
+
+
+def test_inference_no_grad_and_eval_matches_train_forward():
+    from pytorch3dunet_amd.unet3d.model import UNet3D
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    model = UNet3D(1, 1, f_maps=16).to(dev)
+    x = torch.rand(1, 1, 33, 65, 65, device=dev)  # tests/test_models.py:17-24 of the reference
+    model.eval()
+    with torch.no_grad():
+        y = model(x)
+    assert y.shape == x.shape and torch.all(0 <= y) and torch.all(y <= 1)
+    model.train()
+    y2, logits = model(x, return_logits=True)
+    assert torch.allclose(y, y2.detach(), atol=1e-6)
+    assert torch.allclose(torch.sigmoid(logits.detach()), y, atol=1e-6)
+
+
+def test_input_gradient():
+    import unet3d_oracle as orc
+    from pytorch3dunet_amd.unet3d.model import UNet3D
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(2)
+    model = UNet3D(2, 1, f_maps=[8, 16], num_groups=2)
+    x = torch.randn(1, 2, 8, 8, 8)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    xl = x.clone().requires_grad_(True)
+    _, lr = orc.unet3d_forward(sd, xl, 2)
+    (lr * lr).mean().backward()
+    model = model.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    _, lg = model(xd, return_logits=True)
+    (lg * lg).mean().backward()
+    assert orc.rel_err(xd.grad.cpu(), xl.grad) < REL
+
+
+def test_full_size_cfg2_properties():
+    """BASELINE.json config 2 at full size (f_maps=32, 2x1x64x128x128): runs, finite, probabilities in [0,1],
+    run-to-run reproducible; the dominant conv layer shape (96->32 @ 64x128x128) agrees with the naive device
+    kernel; the conv is linear in its input (size-independent properties, no CPU oracle at this size)."""
+    import gpu_utils as U
+    from pytorch3dunet_amd.engine import VSrc
+    from pytorch3dunet_amd.unet3d.model import UNet3D
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    model = UNet3D(1, 1, f_maps=32).to(dev).train()
+    x = torch.randn(2, 1, 64, 128, 128, device=dev)
+    target = (torch.rand_like(x) > 0.5).float()
+    outs = []
+    for _ in range(2):
+        probs, logits = model(x, return_logits=True)
+        loss = loss_by_name("bce_dice", probs, logits, target)
+        model.zero_grad()
+        loss.backward()
+        outs.append((logits.detach().clone(), torch.cat([p.grad.flatten() for p in model.parameters()]).clone()))
+        assert torch.isfinite(logits).all() and torch.all(0 <= probs) and torch.all(probs <= 1)
+    assert torch.isfinite(outs[0][1]).all()
+    assert U.relerr(outs[1][0], outs[0][0]) < 1e-6 and U.relerr(outs[1][1], outs[0][1]) < 1e-5
+    del outs
+    # dominant layer shape vs naive kernel
+    torch.manual_seed(1)
+    a = torch.randn(1, 64, 128, 128, 96, device=dev)
+    w = torch.randn(32, 96, 3, 3, 3) / (27 * 96) ** 0.5
+    src = VSrc(a)
+    y = U.conv3d(src, w, 32, relu=0)
+    yn = U.conv3d_naive(src, w, 32)
+    assert U.relerr(y, yn) < 2e-5
+    y2 = U.conv3d(VSrc(a * 2.0), w, 32, relu=0)
+    assert U.relerr(y2, 2.0 * y) < 1e-6
+    dz = torch.randn(1, 64, 128, 128, 32, device=dev)
+    dw = U.wgrad(src, dz, 32)
+    # <dw, w> == <dz, conv(a, w)>  (adjoint identity ties wgrad to the forward kernel at full size)
+    lhs = (dw.double().cpu() * w.double()).sum().item()
+    rhs = (dz.double() * y.double()).sum().item()
+    assert abs(lhs - rhs) < 1e-4 * max(abs(lhs), abs(rhs), 1.0)
+    # <dgrad(dz), a> == <dz, conv(a, w)>
+    dg = U.conv3d(VSrc(dz), w, 96, relu=0, mode=1)
+    lhs2 = (dg.double() * a.double()).sum().item()
+    assert abs(lhs2 - rhs) < 1e-4 * max(abs(lhs2), abs(rhs), 1.0)
+
+
+def test_uncovered_variant_strict_mode(monkeypatch):
+    from pytorch3dunet_amd.unet3d.model import ResidualUNet3D
+
+    dev = torch.device("cuda", 0)
+    model = ResidualUNet3D(1, 1, f_maps=16, num_levels=3).to(dev).eval()
+    monkeypatch.setenv("U3D_STRICT", "1")
+    with pytest.raises(NotImplementedError):
+        model(torch.rand(1, 1, 8, 16, 16, device=dev))

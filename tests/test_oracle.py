@@ -1,0 +1,124 @@
+"""CPU: pin the oracle (oracle/unet3d_oracle.py, oracle/ref_ops.c) against the golden vectors generated from the
+live reference, and against the live reference itself when /root/reference is present."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import c_ops
+import unet3d_oracle as orc
+from conftest import Golden, GOLDEN_NAMES
+from ref_import import import_reference, reference_available
+
+TOL = 2e-5  # the oracle and the reference run the same ATen CPU operators; only reduction-order noise remains
+
+
+def _check_against_golden(g: Golden):
+    model = g.build_model()
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    x, target = g.inputs()
+    probs, logits, loss, grads = orc.forward_backward(sd, x, target, num_groups=g.cfg.get("num_groups", 8),
+                                                      final_sigmoid=g.cfg.get("final_sigmoid", True),
+                                                      is_segmentation=g.cfg.get("is_segmentation", True),
+                                                      loss=g.loss_name)
+    assert abs(loss.item() - g.loss) <= 1e-5 * max(1.0, abs(g.loss))
+    if g.full:
+        assert orc.rel_err(logits, g.tensor("logits")) < TOL
+        assert orc.rel_err(probs, g.tensor("probs")) < TOL
+        ref_grads = g.group("grad/")
+        assert set(ref_grads) == set(grads)
+        for k, rg in ref_grads.items():
+            assert orc.rel_err(grads[k], rg) < 5e-4, k
+    else:
+        s = 97
+        assert (logits.flatten()[::s] - g.tensor("logits_s")).abs().max().item() < TOL * float(g.z["logits_absmax"])
+        for k, rs in g.group("grad_s/").items():
+            am = float(g.z["grad_absmax/" + k])
+            assert (grads[k].flatten()[::s] - rs).abs().max().item() < 5e-4 * am, k
+            assert abs(grads[k].norm().item() - float(g.z["grad_norm/" + k])) < 5e-4 * float(g.z["grad_norm/" + k]) + 1e-12
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_oracle_matches_golden(name):
+    _check_against_golden(Golden(name))
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference only exists in the build container")
+@pytest.mark.parametrize("cfg,shape", [
+    (dict(name="UNet3D", in_channels=1, out_channels=1, f_maps=16, num_groups=8), (1, 1, 17, 33, 33)),
+    (dict(name="UNet3D", in_channels=3, out_channels=2, f_maps=[8, 16, 32], num_groups=4, final_sigmoid=False), (2, 3, 8, 16, 12)),
+])
+def test_oracle_matches_live_reference(cfg, shape):
+    ref = import_reference()
+    torch.manual_seed(7)
+    model = ref.get_model(dict(cfg))
+    x = torch.randn(shape)
+    probs_r, logits_r = model(x, return_logits=True)
+    target = (torch.rand(logits_r.shape) > 0.5).float()
+    loss_r = orc.bce_dice_loss(logits_r, target)
+    model.zero_grad()
+    loss_r.backward()
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    probs, logits, loss, grads = orc.forward_backward(sd, x, target, cfg["num_groups"], cfg.get("final_sigmoid", True))
+    assert torch.equal(logits, logits_r.detach()) or orc.rel_err(logits, logits_r.detach()) < 1e-6
+    assert orc.rel_err(probs, probs_r.detach()) < 1e-6
+    for k, p in model.named_parameters():
+        assert orc.rel_err(grads[k], p.grad) < 1e-5, k
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference only exists in the build container")
+def test_bce_dice_restatement_matches_reference_loss():
+    import importlib
+
+    import_reference()
+    ref_losses = importlib.import_module("pytorch3dunet.unet3d.losses")
+    torch.manual_seed(3)
+    logits = torch.randn(2, 3, 5, 6, 7)
+    target = (torch.rand_like(logits) > 0.5).float()
+    assert abs(ref_losses.BCEDiceLoss()(logits, target).item() - orc.bce_dice_loss(logits, target).item()) < 1e-6
+
+
+# ---- plain-C operator restatement vs the torch-functional one ----------------------------------------
+def test_c_conv3d_fwd_dgrad_wgrad():
+    torch.manual_seed(0)
+    x = torch.randn(2, 3, 5, 6, 7, requires_grad=True)
+    w = torch.randn(4, 3, 3, 3, 3, requires_grad=True)
+    y = F.conv3d(x, w, None, padding=1)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    assert np.abs(c_ops.conv3d_fwd(x.detach().numpy(), w.detach().numpy()) - y.detach().numpy()).max() < 1e-4
+    assert np.abs(c_ops.conv3d_dgrad(dy.numpy(), w.detach().numpy()) - x.grad.numpy()).max() < 1e-4
+    assert np.abs(c_ops.conv3d_wgrad(x.detach().numpy(), dy.numpy()) - w.grad.numpy()).max() < 2e-4
+
+
+@pytest.mark.parametrize("C,G", [(8, 4), (6, 1), (16, 8)])
+def test_c_groupnorm(C, G):
+    torch.manual_seed(1)
+    x = (torch.randn(2, C, 4, 5, 6) * 2 + 0.5).requires_grad_(True)
+    gamma = torch.randn(C, requires_grad=True)
+    beta = torch.randn(C, requires_grad=True)
+    y = F.group_norm(x, G, gamma, beta, 1e-5)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    yc, mean, rstd = c_ops.groupnorm_fwd(x.detach().numpy(), gamma.detach().numpy(), beta.detach().numpy(), G)
+    assert np.abs(yc - y.detach().numpy()).max() < 1e-5
+    dx, dg, db = c_ops.groupnorm_bwd(dy.numpy(), x.detach().numpy(), mean, rstd, gamma.detach().numpy(), G)
+    assert np.abs(dx - x.grad.numpy()).max() < 1e-5
+    assert np.abs(dg - gamma.grad.numpy()).max() < 1e-4
+    assert np.abs(db - beta.grad.numpy()).max() < 1e-4
+
+
+def test_c_maxpool_and_nearest():
+    torch.manual_seed(2)
+    x = torch.relu(torch.randn(1, 3, 7, 9, 5))  # ReLU output: many exact-zero ties
+    y, idx = F.max_pool3d(x, 2, return_indices=True)
+    yc, ic = c_ops.maxpool2_fwd(x.numpy())
+    assert np.array_equal(yc, y.numpy())
+    # our argmax byte k = dz*4+dy*2+dx must address the same element as ATen's flat index
+    D, H, W = x.shape[2:]
+    zo, yo, xo = np.meshgrid(np.arange(D // 2), np.arange(H // 2), np.arange(W // 2), indexing="ij")
+    flat = ((2 * zo + (ic >> 2)) * H + 2 * yo + ((ic >> 1) & 1)) * W + 2 * xo + (ic & 1)
+    assert np.array_equal(flat, idx.numpy())
+    for size in [(14, 18, 10), (15, 19, 11), (7, 9, 5)]:
+        up = F.interpolate(x, size=size, mode="nearest")
+        assert np.array_equal(c_ops.upsample_nearest(x.numpy(), size), up.numpy())
