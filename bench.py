@@ -70,7 +70,10 @@ def cpu_baseline(sample_iters=3):
     import unet3d_oracle as orc
     from pytorch3dunet_amd.unet3d.model import UNet3D
 
-    cores = os.cpu_count() or 1
+    # thread count: tools/cpu_thread_scan.py on the MI355X box (256 logical cores) gives 8:0.352 s, 16:0.266 s,
+    # 32:0.356 s, 64:0.620 s, 128:1.014 s, 256:34.7 s per iteration on a 1x1x32x64x64 patch -> 16 threads is the
+    # fastest ATen/oneDNN configuration; the default (all 256) would understate the CPU path 100x.
+    cores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     model = UNet3D(**MODEL_CFG)

@@ -120,6 +120,11 @@ def get_lib():
                 f"native library {LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). The MI355X path has no CPU/PyTorch fallback."
             )
+        # torch bundles its own HIP runtime (torch/lib/libamdhip64.so): it must be in the process BEFORE this
+        # library is loaded so that both share ONE runtime (streams, allocations); loading ours first would pull
+        # in /opt/rocm's copy as a second, unusable runtime.
+        import torch  # noqa: F401
+
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing

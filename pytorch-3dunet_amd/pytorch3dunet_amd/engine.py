@@ -154,6 +154,7 @@ class UNet3DEngine:
         self.model = model
         self._pack_cache: dict = {}
         self.grad_sync = None  # set by parallel.GradSync (RCCL all-reduce overlapped with the encoder backward)
+        self.debug = None  # dict -> backward stores clones of per-layer dz / dg (tools/gpu_layer_diag.py)
         self.fused_stats = True
         self.params = list(model.parameters())
         self._pindex = {id(p): i for i, p in enumerate(self.params)}
@@ -297,6 +298,8 @@ class UNet3DEngine:
                  Cf, Co, act, _p(logits), _p(probs))
         if tape is not None:
             tape.head_x = cur
+            if self.debug is not None:
+                self.debug["tape"] = tape
         return logits, probs, tape
 
     # -- backward -----------------------------------------------------------------------------------
@@ -344,6 +347,8 @@ class UNet3DEngine:
             src = rec.src
             Nn, Dd, Hh, Ww = src.N, src.D, src.H, src.W
             Cout = rec.y.shape[-1]
+            if self.debug is not None:
+                self.debug[rec.name + ".dz"] = dz_.clone()
             s_aff = src.struct(rec.affine)
             flops = 54.0 * src.C * Cout * Nn * Dd * Hh * Ww
             nat.call("u3d_conv3d_wgrad", dev.index, _stream(dev), ctypes.byref(s_aff), _p(dz_), _p(gview(rec.idx_w)), Nn, Dd, Hh,
@@ -355,6 +360,8 @@ class UNet3DEngine:
             s_x = src.struct()
             nat.call("u3d_conv3d", dev.index, _stream(dev), ctypes.byref(s_dz), _p(wpd), _p(dg), Nn, Dd, Hh, Ww, src.C, 0, None,
                      ctypes.byref(s_x), _p(gst), flops=flops)
+            if self.debug is not None:
+                self.debug[rec.name + ".dg"] = dg.clone()
             coef = torch.empty((Nn, 3, src.C), dtype=_F32, device=dev)
             nat.call("u3d_gn_bwd_finalize", dev.index, _stream(dev), _p(gst), _p(rec.mean_rstd), _p(rec.gn_w.detach()), Nn, src.C,
                      rec.G, float(Dd * Hh * Ww), _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef))
@@ -437,7 +444,8 @@ class _UNet3DFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, engine: UNet3DEngine, x: torch.Tensor, *params):
-        save = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        # grad mode is always off inside Function.forward: needs_input_grad tells whether a backward can follow
+        save = any(ctx.needs_input_grad)
         logits, probs, tape = engine.forward(x, save)
         ctx.engine = engine
         ctx.tape = tape

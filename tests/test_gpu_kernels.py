@@ -199,7 +199,8 @@ def test_groupnorm_backward(N, C, G, size, relu):
     dgam = torch.empty(C, device=U.DEV)
     dbet = torch.empty(C, device=U.DEV)
     coef = torch.empty((N, 3, C), device=U.DEV)
-    nat.call("u3d_gn_bwd_finalize", 0, _stream(U.DEV), _p(gst), _p(mr), _p(gamma.to(U.DEV)), N, C, G, float(V), _p(dgam), _p(dbet), _p(coef))
+    gamma_d = gamma.to(U.DEV)
+    nat.call("u3d_gn_bwd_finalize", 0, _stream(U.DEV), _p(gst), _p(mr), _p(gamma_d), N, C, G, float(V), _p(dgam), _p(dbet), _p(coef))
     assert U.relerr(dgam.cpu(), gl.grad) < 1e-4
     assert U.relerr(dbet.cpu(), bl.grad) < 1e-4
     xd, dgd = U.ndhwc(x), U.ndhwc(dg)
@@ -232,7 +233,8 @@ def test_groupnorm_backward_concat_split(size):
     gst = torch.stack([dg.double().sum(dim=(2, 3, 4)), (dg.double() * catd.double()).sum(dim=(2, 3, 4))], dim=-1).contiguous().to(U.DEV)
     dgam, dbet = torch.empty(C, device=U.DEV), torch.empty(C, device=U.DEV)
     coef = torch.empty((N, 3, C), device=U.DEV)
-    nat.call("u3d_gn_bwd_finalize", 0, _stream(U.DEV), _p(gst), _p(mr), _p(gamma.to(U.DEV)), N, C, G, float(V), _p(dgam), _p(dbet), _p(coef))
+    gamma_d = gamma.to(U.DEV)
+    nat.call("u3d_gn_bwd_finalize", 0, _stream(U.DEV), _p(gst), _p(mr), _p(gamma_d), N, C, G, float(V), _p(dgam), _p(dbet), _p(coef))
     dgd = U.ndhwc(dg)
     sg = torch.empty((N, D, H, W, C0), device=U.DEV)
     nat.call("u3d_gn_bwd_apply", 0, _stream(U.DEV), _p(dgd), C, 0, _p(src.t0), C0, _p(coef), C, V, N, 0, _p(sg))
@@ -266,7 +268,8 @@ def test_maxpool_forward_backward_merge(N, C, size):
     pd = pooled.detach().double()
     assert U.relerr(st.cpu(), torch.stack([pd.sum(dim=(2, 3, 4)), (pd ** 2).sum(dim=(2, 3, 4))], dim=-1)) < 1e-6
     res = torch.empty_like(ed)
-    nat.call("u3d_maxpool2_bwd_merge", 0, _stream(U.DEV), _p(U.ndhwc(dpool)), None, _p(am), None, _p(U.ndhwc(skipg)), _p(ed),
+    dpool_d, skipg_d = U.ndhwc(dpool), U.ndhwc(skipg)  # keep device tensors alive across the async launch
+    nat.call("u3d_maxpool2_bwd_merge", 0, _stream(U.DEV), _p(dpool_d), None, _p(am), None, _p(skipg_d), _p(ed),
              N, D, H, W, C, 1, _p(res))
     assert U.relerr(U.ncdhw(res), pre.grad) < 1e-6
 
@@ -286,16 +289,17 @@ def test_head_forward_backward(N, Cin, Cout, act):
     dl = torch.randn_like(logits)
     logits.backward(dl)
     xd = U.ndhwc(x.detach())
+    wd, bd, dld = w.detach().to(U.DEV), b.detach().to(U.DEV), dl.to(U.DEV)  # keep alive across the async launches
     lg = torch.empty((N, Cout, D, H, W), device=U.DEV)
     pr = torch.empty_like(lg)
-    nat.call("u3d_conv1x1_head_fwd", 0, _stream(U.DEV), _p(xd), _p(w.detach().to(U.DEV)), _p(b.detach().to(U.DEV)), N, V, Cin,
+    nat.call("u3d_conv1x1_head_fwd", 0, _stream(U.DEV), _p(xd), _p(wd), _p(bd), N, V, Cin,
              Cout, act, _p(lg), _p(pr) if act else None)
     assert U.relerr(lg.cpu(), logits.detach()) < TOL
     if act:
         assert U.relerr(pr.cpu(), probs.detach()) < TOL
     dx = torch.empty_like(xd)
     acc = torch.zeros(Cout * Cin + Cout, dtype=torch.float64, device=U.DEV)
-    nat.call("u3d_conv1x1_head_bwd", 0, _stream(U.DEV), _p(dl.to(U.DEV)), _p(xd), _p(w.detach().to(U.DEV)), N, V, Cin, Cout, 1,
+    nat.call("u3d_conv1x1_head_bwd", 0, _stream(U.DEV), _p(dld), _p(xd), _p(wd), N, V, Cin, Cout, 1,
              _p(dx), _p(acc))
     assert U.relerr(U.ncdhw(dx), pre.grad) < TOL
     f32 = torch.empty(Cout * Cin + Cout, device=U.DEV)
