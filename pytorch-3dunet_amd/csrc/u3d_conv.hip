@@ -479,23 +479,40 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const WgradParams 
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int S, int nchunks,
-                                    int nkb, int Cin, int Cout) {
-    // thread -> (c, tap, k) with k fastest (coalesced partial reads)
+// deterministic second pass of the split-K: block = 64 outputs x 4 split-groups, fixed summation order
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                           int S, int nchunks, int nkb, int Cin, int Cout) {
+    __shared__ float red[4][64];
     const long long total = (long long)Cin * 27 * Cout;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const int k = (int)(idx % Cout);
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long long idx = (long long)blockIdx.x * 64 + lane;  // (c, tap, k) with k fastest: coalesced partial reads
+    float sum = 0.f;
+    int k = 0, tap = 0, c = 0;
+    if (idx < total) {
+        k = (int)(idx % Cout);
         const long long r = idx / Cout;
-        const int tap = (int)(r % 27);
-        const int c = (int)(r / 27);
+        tap = (int)(r % 27);
+        c = (int)(r / 27);
         const int chunk = c >> 5, kb = k >> 5;
         const size_t off = ((size_t)(chunk * nkb + kb) * 27 + tap) * 1024 + (c & 31) * 32 + (k & 31);
         const size_t sstride = (size_t)nchunks * nkb * 27 * 1024;
-        float sum = 0.f;
-        for (int s = 0; s < S; ++s) sum += partial[s * sstride + off];
-        dw[((size_t)k * Cin + c) * 27 + tap] = sum;
+        const int per = (S + 3) / 4;
+        const int s0 = grp * per, s1 = min(S, s0 + per);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int s = s0;
+        for (; s + 3 < s1; s += 4) {
+            a0 += partial[(size_t)s * sstride + off];
+            a1 += partial[(size_t)(s + 1) * sstride + off];
+            a2 += partial[(size_t)(s + 2) * sstride + off];
+            a3 += partial[(size_t)(s + 3) * sstride + off];
+        }
+        for (; s < s1; ++s) a0 += partial[(size_t)s * sstride + off];
+        sum = (a0 + a1) + (a2 + a3);
     }
+    red[grp][lane] = sum;
+    __syncthreads();
+    if (grp == 0 && idx < total)
+        dw[((size_t)k * Cin + c) * 27 + tap] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // =================================================================================================
@@ -712,7 +729,7 @@ extern "C" int u3d_conv3d_wgrad(int device, u3d_stream_t stream, const u3d_src_t
                            (hipStream_t)stream, p);
     U3D_LAUNCH_CHECK();
     const long long total = (long long)Cin * 27 * Cout;
-    const int rblocks = (int)((total + 255) / 256);
+    const int rblocks = (int)((total + 63) / 64);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, (hipStream_t)stream, workspace, dw, p.S,
                        p.nchunks, p.nkb, Cin, Cout);
     U3D_LAUNCH_CHECK();

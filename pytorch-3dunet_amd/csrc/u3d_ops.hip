@@ -115,10 +115,12 @@ extern "C" int u3d_chan_stats(int device, u3d_stream_t stream, const u3d_src_t* 
     U3D_REQUIRE(Q <= 256, "u3d_chan_stats: at most 1024 channels supported");
     const int rows = 256 / Q;
     const long long V = (long long)D * H * W;
-    // ~512 voxels per thread-row, at least 1 block, at most 2048 blocks per sample
-    long long bpn = cdivll(V, (long long)rows * 512);
+    // >= ~2048 blocks in total when the tensor is large enough (>= 16 voxels per thread-row), <= 4096 per sample
+    long long bpn = cdivll(V, (long long)rows * 16);
+    const long long want = cdivll(2048, N);
+    if (bpn > want) bpn = want;
     if (bpn < 1) bpn = 1;
-    if (bpn > 2048) bpn = 2048;
+    if (bpn > 4096) bpn = 4096;
     const size_t shmem = (size_t)rows * Q * 8 * sizeof(float);
     hipLaunchKernelGGL(chan_stats_kernel, dim3((unsigned)bpn, (unsigned)N), dim3(256), shmem, (hipStream_t)stream,
                        *src, D, H, W, Q, rows, src_vec_ok(src) ? 1 : 0, stats);
@@ -499,14 +501,84 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     }
 }
 
+// Vectorised variant: G = Cin/4 lanes (power of two, <= 64) share one voxel, each loads one float4 of the row
+// (fully coalesced 16 B/lane), partial dot products are combined with a butterfly shuffle.
+template <int G>
+__global__ __launch_bounds__(256) void head_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ b, int N, long long V, int Cin,
+                                                           int Cout, int act, float* __restrict__ logits,
+                                                           float* __restrict__ probs) {
+    const int t = threadIdx.x;
+    const int sub = t & (G - 1);
+    const long long total = (long long)N * V;
+    const long long vpb = 256 / G;
+    for (long long idx = (long long)blockIdx.x * vpb + t / G; idx < total; idx += (long long)gridDim.x * vpb) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)idx * Cin + 4 * sub);
+        float acc[HEAD_MAXCO];
+#pragma unroll
+        for (int o = 0; o < HEAD_MAXCO; ++o) {
+            acc[o] = 0.f;
+            if (o < Cout) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (size_t)o * Cin + 4 * sub);
+                float p = xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+#pragma unroll
+                for (int m = G >> 1; m > 0; m >>= 1) p += __shfl_xor(p, m);
+                acc[o] = p + b[o];
+            }
+        }
+        if (sub == 0) {
+            const int n = (int)(idx / V);
+            const long long v = idx - (long long)n * V;
+            float mx = -INFINITY, den = 0.f;
+            if (act == 2) {
+#pragma unroll
+                for (int o = 0; o < HEAD_MAXCO; ++o)
+                    if (o < Cout) mx = fmaxf(mx, acc[o]);
+#pragma unroll
+                for (int o = 0; o < HEAD_MAXCO; ++o)
+                    if (o < Cout) den += expf(acc[o] - mx);
+            }
+#pragma unroll
+            for (int o = 0; o < HEAD_MAXCO; ++o) {
+                if (o < Cout) {
+                    const size_t oi = ((size_t)n * Cout + o) * V + v;
+                    logits[oi] = acc[o];
+                    if (probs) {
+                        float pr = acc[o];
+                        if (act == 1) pr = 1.f / (1.f + expf(-acc[o]));
+                        if (act == 2) pr = expf(acc[o] - mx) / den;
+                        probs[oi] = pr;
+                    }
+                }
+            }
+        }
+    }
+}
+
 extern "C" int u3d_conv1x1_head_fwd(int device, u3d_stream_t stream, const float* x, const float* w, const float* b,
                                     int N, int64_t V, int Cin, int Cout, int act, float* logits, float* probs) {
     if (int e = u3d_enter(device)) return e;
     U3D_REQUIRE(x && w && b && logits && N > 0 && V > 0, "u3d_conv1x1_head_fwd: bad argument");
     U3D_REQUIRE(Cout >= 1 && Cout <= HEAD_MAXCO && Cin >= 1 && Cin <= HEAD_MAXCI,
                 "u3d_conv1x1_head_fwd: supports Cout<=%d, Cin<=%d (got %d,%d)", HEAD_MAXCO, HEAD_MAXCI, Cout, Cin);
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(grid_for((long long)N * V, 4096)), dim3(256), 0, (hipStream_t)stream, x,
-                       w, b, N, (long long)V, Cin, Cout, act, logits, probs);
+    const int G = Cin / 4;
+    const bool vec = (Cin % 4 == 0) && (G & (G - 1)) == 0 && G >= 1 && G <= 64 && (((uintptr_t)x | (uintptr_t)w) & 15) == 0;
+    hipStream_t st = (hipStream_t)stream;
+    const long long tot = (long long)N * V;
+#define U3D_HEAD_FWD(GG)                                                                                            \
+    hipLaunchKernelGGL(head_fwd_vec_kernel<GG>, dim3(grid_for(tot * GG, 8192)), dim3(256), 0, st, x, w, b, N,       \
+                       (long long)V, Cin, Cout, act, logits, probs)
+    if (vec && G == 1) U3D_HEAD_FWD(1);
+    else if (vec && G == 2) U3D_HEAD_FWD(2);
+    else if (vec && G == 4) U3D_HEAD_FWD(4);
+    else if (vec && G == 8) U3D_HEAD_FWD(8);
+    else if (vec && G == 16) U3D_HEAD_FWD(16);
+    else if (vec && G == 32) U3D_HEAD_FWD(32);
+    else if (vec && G == 64) U3D_HEAD_FWD(64);
+    else
+        hipLaunchKernelGGL(head_fwd_kernel, dim3(grid_for(tot, 4096)), dim3(256), 0, st, x, w, b, N, (long long)V, Cin,
+                           Cout, act, logits, probs);
+#undef U3D_HEAD_FWD
     U3D_LAUNCH_CHECK();
     return 0;
 }
@@ -583,6 +655,68 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* __restric
     for (int i = t; i < Cout; i += 256) u3d_atomic_add_f64(&acc[Cout * Cin + i], (double)red[Cout * Cin + i]);
 }
 
+// Fused vectorised backward: thread -> (voxel, channel quad) with a FIXED quad per thread (grid stride is a
+// multiple of Q), so dw partials stay in registers; x is read once for both dx (ReLU mask) and dw.
+__global__ __launch_bounds__(256) void head_bwd_vec_kernel(const float* __restrict__ dl, const float* __restrict__ x,
+                                                           const float* __restrict__ w, int N, long long V, int Cin,
+                                                           int Cout, int relu_mask, float* __restrict__ dx,
+                                                           double* __restrict__ acc) {
+    extern __shared__ float red[];  // [(Cout+1)][Cin]
+    const int t = threadIdx.x;
+    const int Q = Cin >> 2;
+    const int rows = 256 / Q;  // voxels per block iteration
+    const int q = t % Q, row = t / Q;
+    f32x4 wv[HEAD_MAXCO];
+    f32x4 aw[HEAD_MAXCO];
+    float ab[HEAD_MAXCO];
+#pragma unroll
+    for (int o = 0; o < HEAD_MAXCO; ++o) {
+        wv[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+        aw[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ab[o] = 0.f;
+        if (o < Cout) wv[o] = *reinterpret_cast<const f32x4*>(w + (size_t)o * Cin + 4 * q);
+    }
+    const long long total = (long long)N * V;
+    if (row < rows) {
+        for (long long nv = (long long)blockIdx.x * rows + row; nv < total; nv += (long long)gridDim.x * rows) {
+            const int n = (int)(nv / V);
+            const long long v = nv - (long long)n * V;
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)nv * Cin + 4 * q);
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int o = 0; o < HEAD_MAXCO; ++o) {
+                if (o < Cout) {
+                    const float d = dl[((size_t)n * Cout + o) * V + v];
+                    s += d * wv[o];
+                    aw[o] += d * xv;
+                    if (q == 0) ab[o] += d;
+                }
+            }
+            if (relu_mask) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[e] = xv[e] > 0.f ? s[e] : 0.f;
+            }
+            if (dx) *reinterpret_cast<f32x4*>(dx + (size_t)nv * Cin + 4 * q) = s;
+        }
+    }
+    if (acc == nullptr) return;
+    for (int i = t; i < (Cout + 1) * Cin; i += 256) red[i] = 0.f;
+    __syncthreads();
+    if (row < rows) {
+#pragma unroll
+        for (int o = 0; o < HEAD_MAXCO; ++o) {
+            if (o < Cout) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(&red[o * Cin + 4 * q + e], aw[o][e]);
+                if (q == 0) atomicAdd(&red[Cout * Cin + o], ab[o]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < Cout * Cin; i += 256) u3d_atomic_add_f64(&acc[i], (double)red[i]);
+    for (int i = t; i < Cout; i += 256) u3d_atomic_add_f64(&acc[Cout * Cin + i], (double)red[Cout * Cin + i]);
+}
+
 extern "C" int u3d_conv1x1_head_bwd(int device, u3d_stream_t stream, const float* dlogits, const float* x,
                                     const float* w, int N, int64_t V, int Cin, int Cout, int relu_mask, float* dx,
                                     double* acc) {
@@ -590,6 +724,18 @@ extern "C" int u3d_conv1x1_head_bwd(int device, u3d_stream_t stream, const float
     U3D_REQUIRE(dlogits && x && w && N > 0 && V > 0, "u3d_conv1x1_head_bwd: bad argument");
     U3D_REQUIRE(Cout >= 1 && Cout <= HEAD_MAXCO && Cin >= 1 && Cin <= HEAD_MAXCI,
                 "u3d_conv1x1_head_bwd: supports Cout<=%d, Cin<=%d (got %d,%d)", HEAD_MAXCO, HEAD_MAXCI, Cout, Cin);
+    const bool vec = (Cin % 4 == 0) && Cin <= 1024 && Cout <= 4 &&
+                     (((uintptr_t)x | (uintptr_t)w | (uintptr_t)dx) & 15) == 0;
+    if (vec) {
+        const int rows = 256 / (Cin / 4);
+        long long blocks = cdivll((long long)N * V, (long long)rows * 64);
+        if (blocks > 2048) blocks = 2048;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(head_bwd_vec_kernel, dim3((unsigned)blocks), dim3(256), (size_t)(Cout + 1) * Cin * sizeof(float),
+                           (hipStream_t)stream, dlogits, x, w, N, (long long)V, Cin, Cout, relu_mask, dx, acc);
+        U3D_LAUNCH_CHECK();
+        return 0;
+    }
     if (dx) {
         hipLaunchKernelGGL(head_bwd_dx_kernel, dim3(grid_for((long long)N * V * Cin, 16384)), dim3(256), 0,
                            (hipStream_t)stream, dlogits, x, w, N, (long long)V, Cin, Cout, relu_mask, dx);

@@ -50,6 +50,16 @@ _PROTOS = {
         c_int,
         [c_int, c_void_p, POINTER(U3DSrc), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t],
     ),
+    "u3d_conv3d_small_cin_fwd": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
+    ),
+    "u3d_small_cin_bwd_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "u3d_conv3d_small_cin_bwd": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+         c_int, c_void_p, c_size_t],
+    ),
     "u3d_conv3d_naive": (
         c_int,
         [c_int, c_void_p, POINTER(U3DSrc), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int],

@@ -120,6 +120,7 @@ class ConvRec:
     idx_gw: int = -1  # indices into the flat parameter list
     idx_gb: int = -1
     idx_w: int = -1
+    small: bool = False  # ran through the small-Cin (first layer) kernels
 
 
 @dataclass
@@ -156,6 +157,7 @@ class UNet3DEngine:
         self.grad_sync = None  # set by parallel.GradSync (RCCL all-reduce overlapped with the encoder backward)
         self.debug = None  # dict -> backward stores clones of per-layer dz / dg (tools/gpu_layer_diag.py)
         self.fused_stats = True
+        self.small_cin = True  # dedicated kernels for the in_channels<=4 first layer
         self.params = list(model.parameters())
         self._pindex = {id(p): i for i, p in enumerate(self.params)}
         # static layer table
@@ -218,16 +220,23 @@ class UNet3DEngine:
         mean_rstd = torch.empty((N, G, 2), dtype=_F32, device=dev)
         nat.call("u3d_gn_finalize", dev.index, _stream(dev), _p(st0), C0, sc0, _p(st1), C1, sc1, N, G,
                  float(D * H * W), _p(gn.weight.detach()), _p(gn.bias.detach()), float(gn.eps), _p(affine), _p(mean_rstd))
-        wp = self._packed(conv.weight, 0, dev)
         y = torch.empty((N, D, H, W, Cout), dtype=_F32, device=dev)
-        ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
-        s = src.struct(affine)
-        nat.call("u3d_conv3d", dev.index, _stream(dev), ctypes.byref(s), _p(wp), _p(y), N, D, H, W, Cout, 1, _p(ystats),
-                 None, None, flops=54.0 * Ctot * Cout * N * D * H * W)
+        small = self.small_cin and src.t1 is None and Ctot <= 4 and Cout <= 32
+        if small:
+            # first layer of the network: K = 27*Cin is too small for the MFMA tiling (csrc/u3d_smallc.hip)
+            ystats = None
+            nat.call("u3d_conv3d_small_cin_fwd", dev.index, _stream(dev), _p(src.t0), _p(affine), _p(conv.weight.detach()),
+                     _p(y), N, D, H, W, Ctot, Cout, 1, flops=54.0 * Ctot * Cout * N * D * H * W)
+        else:
+            wp = self._packed(conv.weight, 0, dev)
+            ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
+            s = src.struct(affine)
+            nat.call("u3d_conv3d", dev.index, _stream(dev), ctypes.byref(s), _p(wp), _p(y), N, D, H, W, Cout, 1, _p(ystats),
+                     None, None, flops=54.0 * Ctot * Cout * N * D * H * W)
         if tape is not None:
             tape.convs.append(
                 ConvRec(name, src, affine, mean_rstd, y, gn.weight, conv.weight, G, self._pindex[id(gn.weight)],
-                        self._pindex[id(gn.bias)], self._pindex[id(conv.weight)])
+                        self._pindex[id(gn.bias)], self._pindex[id(conv.weight)], small)
             )
         return y, ystats
 
@@ -327,6 +336,10 @@ class UNet3DEngine:
         for r in tape.convs:
             ws_floats = max(ws_floats, lib.u3d_wgrad_workspace_floats(r.src.N, r.src.D, r.src.H, r.src.W, r.src.C,
                                                                       r.y.shape[-1]))
+        r0 = tape.convs[0]
+        if r0.small:
+            ws_floats = max(ws_floats, lib.u3d_small_cin_bwd_workspace_floats(r0.src.N, r0.src.D, r0.src.H, r0.src.W,
+                                                                              r0.src.C, r0.y.shape[-1]))
         ws = torch.empty(ws_floats, dtype=_F32, device=dev)
 
         # ---- head backward: dz of the last decoder conv (ReLU mask fused)
@@ -342,13 +355,23 @@ class UNet3DEngine:
         n_dec = len(self.dec)
         skip_grad = {}  # encoder level -> gradient arriving through the skip connection (pre-mask)
 
-        def conv_bwd(rec: ConvRec, dz_):
+        def conv_bwd(rec: ConvRec, dz_, need_dg=True):
             """wgrad + dgrad + GroupNorm-backward reductions of one SingleConv; returns (dg, coef)"""
             src = rec.src
             Nn, Dd, Hh, Ww = src.N, src.D, src.H, src.W
             Cout = rec.y.shape[-1]
             if self.debug is not None:
                 self.debug[rec.name + ".dz"] = dz_.clone()
+            if rec.small and not need_dg:
+                # one pass gives dw and the GroupNorm-backward sums; no data gradient needed (csrc/u3d_smallc.hip)
+                gst = pool.take(Nn * src.C * 2)
+                nat.call("u3d_conv3d_small_cin_bwd", dev.index, _stream(dev), _p(src.t0), _p(rec.affine), _p(dz_),
+                         _p(rec.conv_w.detach()), _p(gview(rec.idx_w)), _p(gst), Nn, Dd, Hh, Ww, src.C, Cout, _p(ws), ws.numel(),
+                         flops=2 * 54.0 * src.C * Cout * Nn * Dd * Hh * Ww)
+                coef = torch.empty((Nn, 3, src.C), dtype=_F32, device=dev)
+                nat.call("u3d_gn_bwd_finalize", dev.index, _stream(dev), _p(gst), _p(rec.mean_rstd), _p(rec.gn_w.detach()), Nn,
+                         src.C, rec.G, float(Dd * Hh * Ww), _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef))
+                return None, coef
             s_aff = src.struct(rec.affine)
             flops = 54.0 * src.C * Cout * Nn * Dd * Hh * Ww
             nat.call("u3d_conv3d_wgrad", dev.index, _stream(dev), ctypes.byref(s_aff), _p(dz_), _p(gview(rec.idx_w)), Nn, Dd, Hh,
@@ -413,7 +436,7 @@ class UNet3DEngine:
             dg2, coef2 = conv_bwd(r2, dz)
             dz1 = plain_apply(dg2, coef2, r2.src.t0, 1)
             del dg2
-            dg1, coef1 = conv_bwd(r1, dz1)
+            dg1, coef1 = conv_bwd(r1, dz1, need_dg=(i > 0 or need_input_grad))
             if i > 0:
                 pooled, argmax, e_in = tape.pools[i - 1]
                 Ne, De, He, We, Ce = e_in.shape

@@ -330,3 +330,35 @@ def test_error_convention():
     x = torch.zeros((1, 2, 2, 2, 4), device=U.DEV)
     with pytest.raises(nat.U3DError):
         nat.call("u3d_gn_finalize", 0, _stream(U.DEV), _p(x), 5, 1.0, None, 0, 0.0, 1, 2, 8.0, _p(x), _p(x), 1e-5, _p(x), _p(x))
+
+
+@pytest.mark.parametrize("N,Cin,Cout,D,H,W", [(2, 1, 16, 8, 16, 16), (1, 3, 8, 5, 9, 7), (1, 2, 32, 9, 13, 11), (1, 4, 12, 4, 8, 8), (1, 1, 6, 6, 7, 5)])
+def test_small_cin_first_layer_kernels(N, Cin, Cout, D, H, W):
+    """dedicated first-layer kernels: forward == conv3d(GN-affine(x)); backward yields dw and the GroupNorm
+    reductions (sum dg, sum dg*x) WITHOUT computing dg — compare with autograd of the conv"""
+    U, nat, VSrc, _p, _stream = _mods()
+    torch.manual_seed(Cin * 17 + Cout)
+    x = torch.randn(N, Cin, D, H, W)
+    w = torch.randn(Cout, Cin, 3, 3, 3) / (27 * Cin) ** 0.5
+    ab = torch.randn(N, Cin, 2)
+    xl = x.clone().requires_grad_(True)
+    wl = w.clone().requires_grad_(True)
+    g = xl * ab[:, :, 0].view(N, Cin, 1, 1, 1) + ab[:, :, 1].view(N, Cin, 1, 1, 1)
+    g.retain_grad()
+    z = F.conv3d(g, wl, None, padding=1)
+    dz = torch.randn_like(z)
+    z.backward(dz)
+    xd, abd, wd, dzd = U.ndhwc(x), ab.contiguous().to(U.DEV), w.contiguous().to(U.DEV), U.ndhwc(dz)
+    y = torch.empty((N, D, H, W, Cout), device=U.DEV)
+    nat.call("u3d_conv3d_small_cin_fwd", 0, _stream(U.DEV), _p(xd), _p(abd), _p(wd), _p(y), N, D, H, W, Cin, Cout, 1)
+    assert U.relerr(U.ncdhw(y), F.relu(z.detach())) < TOL
+    n = nat.get_lib().u3d_small_cin_bwd_workspace_floats(N, D, H, W, Cin, Cout)
+    ws = torch.empty(n, device=U.DEV)
+    dw = torch.empty((Cout, Cin, 3, 3, 3), device=U.DEV)
+    gst = torch.zeros((N, Cin, 2), dtype=torch.float64, device=U.DEV)
+    nat.call("u3d_conv3d_small_cin_bwd", 0, _stream(U.DEV), _p(xd), _p(abd), _p(dzd), _p(wd), _p(dw), _p(gst), N, D, H, W, Cin,
+             Cout, _p(ws), n)
+    assert U.relerr(dw.cpu(), wl.grad) < 1e-4
+    dg = g.grad.double()
+    s_ref = torch.stack([dg.sum(dim=(2, 3, 4)), (dg * x.double()).sum(dim=(2, 3, 4))], dim=-1)
+    assert U.relerr(gst.cpu(), s_ref) < 1e-4
