@@ -119,6 +119,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     nat.call("u3d_check_device", local_rank)
+    for kv in os.environ.get("U3D_TUNE", "").split(","):  # e.g. U3D_TUNE=0:0 switches the start-phase stagger off
+        if ":" in kv:
+            nat.call("u3d_set_tuning", int(kv.split(":")[0]), int(kv.split(":")[1]))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)

@@ -67,6 +67,9 @@ int u3d_version(void);
 const char* u3d_last_error(void);
 /* 0 if `device` is a gfx950 part, U3D_EARCH otherwise. */
 int u3d_check_device(int device);
+/* Process-wide performance knobs for A/B measurements (never change results).
+ * key 0: de-synchronised block start phases in the conv kernels (default 1). */
+int u3d_set_tuning(int key, int value);
 
 /* ---- weight packing -------------------------------------------------------------------------
  * Reference weights stay nn.Parameters in (Cout,Cin,3,3,3) layout (checkpoint compatibility,

@@ -14,6 +14,9 @@
 // contiguous per wave-load, L1/L2 resident), software-prefetched two k-steps ahead.
 #include "u3d_common.h"
 
+// run-time tuning knobs (u3d_set_tuning): [0] stagger on/off
+int g_u3d_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [1] = ablation mask for timing experiments (wrong results!)
+
 namespace cv {
 constexpr int TZ = 4, TY = 8, TX = 8;
 constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
@@ -38,9 +41,12 @@ struct ConvParams {
     int nchunks, ncb, ntot;
     int tz, ty, tx;
     int relu, vec, has_gx;
+    int stagger;  // shader cycles of one phase step (0 = off)
 };
 
-template <int NT, bool VEC>
+// ABL: timing-only ablation mask (tools/conv_microbench.py): 1 no B loads in the k-loop, 2 no A LDS reads in the
+// k-loop, 4 no re-staging after the first chunk, 8 no epilogue.  ABL != 0 produces wrong results by design.
+template <int NT, bool VEC, int ABL = 0>
 __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvParams p) {
     using namespace cv;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -60,6 +66,19 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvParams p) {
     const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
     const int D = p.D, H = p.H, W = p.W;
     const int Ctot = p.src.C0 + p.src.C1;
+
+    // ---- de-synchronise the first wave of workgroups.  All resident blocks are dispatched together and do
+    //      identical work, so left alone they run in lockstep: every chunk they all stage their halo tiles at the
+    //      same moment (a tens-of-MB burst with every MFMA pipe idle) and then all compute with memory idle.  A
+    //      hashed start phase makes one block's staging overlap its co-residents' MFMA phase; blocks dispatched
+    //      later inherit the spread.
+    if (p.stagger > 0 && blockIdx.x < 256u * 4u) {
+        const unsigned hsh = (blockIdx.x * 2654435761u) >> 30;  // 0..3
+        if (hsh) {
+            const long long until = clock64() + (long long)hsh * p.stagger;
+            while (clock64() < until) __builtin_amdgcn_s_sleep(64);
+        }
+    }
 
     // ---- per-thread staging descriptors (constant across chunks)
     int ldsoff[NIT], gv0[NIT], gv1[NIT];
@@ -105,7 +124,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvParams p) {
         // ---- stage the halo tile of this 16-channel chunk: global -> regs -> (affine) -> LDS.
         //      Fast path is branch-free: every load is issued unconditionally from a clamped (always valid)
         //      address so the 10 loads of a thread are in flight together; validity is applied by select.
-        {
+        if (!(ABL & 4) || ch == 0) {
             const int cq = ch * CC + 4 * q;
             f32x4 v[NIT];
             f32x4 ga = {1.f, 1.f, 1.f, 1.f}, gb = {0.f, 0.f, 0.f, 0.f};
@@ -157,9 +176,20 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvParams p) {
         for (int st = 0; st < NSTEP; ++st) {
             if (st + 2 < NSTEP) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bq[(st + 2) % 3][nt] = wq[(size_t)(st + 2) * wstep + nt * 64];
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (ABL & 1) {
+                        bq[(st + 2) % 3][nt] = bq[st % 3][nt];
+                        asm volatile("" : "+v"(bq[(st + 2) % 3][nt]));
+                    } else {
+                        bq[(st + 2) % 3][nt] = wq[(size_t)(st + 2) * wstep + nt * 64];
+                    }
+                }
             }
-            if (st + 1 < NSTEP) {
+            if ((ABL & 2) && st + 1 < NSTEP) {
+                aq[(st + 1) & 1][0] = aq[st & 1][0];
+                aq[(st + 1) & 1][1] = aq[st & 1][1];
+                asm volatile("" : "+v"(aq[(st + 1) & 1][0]), "+v"(aq[(st + 1) & 1][1]));
+            } else if (st + 1 < NSTEP) {
                 const int tap = (st + 1) >> 1, s1_ = (st + 1) & 1;
                 const int aoff = (tap / 9) * PS + ((tap / 3) % 3) * RS + (tap % 3) * CS + 8 * s1_;
                 aq[(st + 1) & 1][0] = *reinterpret_cast<const f32x4*>(&lds[abase + aoff]);
@@ -181,6 +211,18 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvParams p) {
 
     // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5);
     //      M-tile row -> (y = row>>3, x = row&7)  =>  reg r of lane (m,h): y = r>>2, x = (r&3) + 4h.
+    if (ABL & 8) {
+        // keep the accumulators alive without storing them
+        float keep = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) keep += acc[mt][nt][r];
+        if (keep == 123.456f) p.out[0] = keep;
+        return;
+    }
     const int z = z0 + w;
     float s1[NT], s2[NT];
 #pragma unroll
@@ -291,6 +333,7 @@ struct WgradParams {
     int nchunks, nkb, S;
     int tz, ty, tx, ntiles, tps;
     int vec, dzvec;
+    int stagger;
 };
 
 template <bool VEC>
@@ -309,6 +352,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const WgradParams 
     const int s = logical / (p.nkb * p.nchunks);
     const int D = p.D, H = p.H, W = p.W;
     const int Ctot = p.src.C0 + p.src.C1;
+
+    // start-phase offset against lockstep staging (see conv3d_mfma_kernel)
+    if (p.stagger > 0) {
+        const unsigned hsh = (blockIdx.x * 2654435761u) >> 31;  // 0..1: two blocks per CU
+        if (hsh) {
+            const long long until = clock64() + (long long)p.stagger;
+            while (clock64() < until) __builtin_amdgcn_s_sleep(64);
+        }
+    }
 
     int toff[7];
 #pragma unroll
@@ -600,6 +652,12 @@ static int check_src(const u3d_src_t* s, const char* what) {
     return 0;
 }
 
+extern "C" int u3d_set_tuning(int key, int value) {
+    if (key < 0 || key >= 8) return u3d_set_err(U3D_EINVAL, "u3d_set_tuning: key out of range");
+    g_u3d_tune[key] = value;
+    return 0;
+}
+
 extern "C" size_t u3d_packed_weight_floats(int Cin, int Cout, int mode) {
     const int K = mode == 0 ? Cin : Cout, Nn = mode == 0 ? Cout : Cin;
     return (size_t)cdiv(K, 16) * cv::NSTEP * cdiv(Nn, 32) * 256;
@@ -650,12 +708,15 @@ extern "C" int u3d_conv3d(int device, u3d_stream_t stream, const u3d_src_t* src,
     p.tz = cdiv(D, cv::TZ), p.ty = cdiv(H, cv::TY), p.tx = cdiv(W, cv::TX);
     p.relu = relu;
     p.vec = src_vec_ok(src) ? 1 : 0;
+    p.stagger = 0;
     const long long ntiles = (long long)N * p.tz * p.ty * p.tx;
     // BN = 64 halves the A-tile restaging; use it when there are enough blocks to fill 256 CUs anyway
     const bool nt2 = (p.ntot % 2 == 0) && (ntiles * (p.ntot / 2) >= 512);
     p.ncb = nt2 ? p.ntot / 2 : p.ntot;
     const long long nblk = ntiles * p.ncb;
     U3D_REQUIRE(nblk < (1ll << 31), "u3d_conv3d: grid too large");
+    // quarter of a chunk period when the CU is full: one wave's MFMA time per chunk = 54 steps * 8*NT MFMAs * 64 cycles
+    if (g_u3d_tune[0] && nblk >= 512 && p.nchunks >= 1) p.stagger = 54 * 8 * (nt2 ? 2 : 1) * 64;
     const size_t shmem = cv::LDS_FLOATS * sizeof(float);
     const bool vec = p.vec != 0;
     const dim3 grid((unsigned)nblk), block(256);
@@ -664,6 +725,18 @@ extern "C" int u3d_conv3d(int device, u3d_stream_t stream, const u3d_src_t* src,
         hipLaunchKernelGGL((conv3d_mfma_kernel<2, true>), grid, block, shmem, st, p);
     else if (nt2)
         hipLaunchKernelGGL((conv3d_mfma_kernel<2, false>), grid, block, shmem, st, p);
+    else if (vec && g_u3d_tune[1] == 1)
+        hipLaunchKernelGGL((conv3d_mfma_kernel<1, true, 1>), grid, block, shmem, st, p);
+    else if (vec && g_u3d_tune[1] == 2)
+        hipLaunchKernelGGL((conv3d_mfma_kernel<1, true, 2>), grid, block, shmem, st, p);
+    else if (vec && g_u3d_tune[1] == 4)
+        hipLaunchKernelGGL((conv3d_mfma_kernel<1, true, 4>), grid, block, shmem, st, p);
+    else if (vec && g_u3d_tune[1] == 8)
+        hipLaunchKernelGGL((conv3d_mfma_kernel<1, true, 8>), grid, block, shmem, st, p);
+    else if (vec && g_u3d_tune[1] == 7)
+        hipLaunchKernelGGL((conv3d_mfma_kernel<1, true, 7>), grid, block, shmem, st, p);
+    else if (vec && g_u3d_tune[1] == 15)
+        hipLaunchKernelGGL((conv3d_mfma_kernel<1, true, 15>), grid, block, shmem, st, p);
     else if (vec)
         hipLaunchKernelGGL((conv3d_mfma_kernel<1, true>), grid, block, shmem, st, p);
     else
@@ -719,6 +792,8 @@ extern "C" int u3d_conv3d_wgrad(int device, u3d_stream_t stream, const u3d_src_t
     p.N = N, p.D = D, p.H = H, p.W = W, p.Cout = Cout;
     p.vec = src_vec_ok(src) ? 1 : 0;
     p.dzvec = (Cout % 4 == 0 && ((uintptr_t)dz & 15) == 0) ? 1 : 0;
+    // half a tile period: one wave's MFMA time per tile = 64 voxel pairs * 7 taps * 64 cycles
+    p.stagger = (g_u3d_tune[0] && p.tps >= 2) ? 64 * 7 * 64 : 0;
     if (int e = wgrad_set_lds_once(device)) return e;
     const int nblk = p.S * p.nchunks * p.nkb;
     if (p.vec && p.dzvec)

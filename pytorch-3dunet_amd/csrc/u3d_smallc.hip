@@ -143,7 +143,7 @@ template <int KH>  // output channels per thread: k = kq + 16*a, a < KH  (KH = 1
 __global__ __launch_bounds__(256) void conv3d_small_bwd_kernel(const SmallBwdParams p) {
     using namespace sc;
     __shared__ float xs[HV * (MAXC + 1)];  // [hv][Cin+1]: raw x, then the in-bounds indicator
-    __shared__ float dzs[256 * 32];        // [voxel][k] (Cout <= 32)
+    __shared__ float dzs[256 * 16 * KH];   // [voxel][k] (k < 16*KH)
     const int t = threadIdx.x;
     const int n = blockIdx.y;
     const int kq = t & 15, tg = t >> 4;
@@ -175,19 +175,21 @@ __global__ __launch_bounds__(256) void conv3d_small_bwd_kernel(const SmallBwdPar
             for (int c = 0; c < Cin; ++c) xs[i * C1 + c] = in ? src[c] : 0.f;
             xs[i * C1 + Cin] = in ? 1.f : 0.f;
         }
-        for (int i = t; i < 256 * 32; i += 256) {
-            const int k = i & 31, v = i >> 5;
+        constexpr int KW = 16 * KH;
+        for (int i = t; i < 256 * KW; i += 256) {
+            const int k = i % KW, v = i / KW;
             const int z = z0 + (v >> 6), y = y0 + ((v >> 3) & 7), x = x0 + (v & 7);
             float val = 0.f;
             if (k < Cout && z < D && y < H && x < W) val = p.dz[((size_t)((n * D + z) * H + y) * W + x) * Cout + k];
             dzs[i] = val;
         }
         __syncthreads();
+#pragma unroll 8
         for (int v = 0; v < 256; ++v) {
             const int hb = (v >> 6) * (HY * HX) + ((v >> 3) & 7) * HX + (v & 7);
             float d[KH];
 #pragma unroll
-            for (int a = 0; a < KH; ++a) d[a] = dzs[v * 32 + kq + 16 * a];
+            for (int a = 0; a < KH; ++a) d[a] = dzs[v * KW + kq + 16 * a];
             const float* x0p = &xs[(hb + off0) * C1];
             const float* x1p = &xs[(hb + off1) * C1];
 #pragma unroll
@@ -219,58 +221,67 @@ __global__ __launch_bounds__(256) void conv3d_small_bwd_kernel(const SmallBwdPar
     }
 }
 
-// finalize: one block.  thread -> (k, tap); reduces the B partials per sample in a fixed order, forms dw and the
-// GroupNorm-backward sums (S1,S2) per (n, c).
-__global__ __launch_bounds__(1024) void conv3d_small_bwd_finalize_kernel(const float* __restrict__ partial,
-                                                                         const float* __restrict__ affine,
-                                                                         const float* __restrict__ w, int N, int B,
-                                                                         int Cin, int Cout, float* __restrict__ dw,
-                                                                         double* __restrict__ gstats) {
-    __shared__ double s1s[sc::MAXC], s2s[sc::MAXC];
+// finalize: grid = ceil(Cout*27 / 64) blocks of 256 threads = 64 (k,tap) lanes x 4 partial-groups.  Fixed summation
+// order; forms dw (summed over n in-thread) and adds the GroupNorm-backward sums (S1,S2) per (n, c).
+__global__ __launch_bounds__(256) void conv3d_small_bwd_finalize_kernel(const float* __restrict__ partial,
+                                                                        const float* __restrict__ affine,
+                                                                        const float* __restrict__ w, int N, int B,
+                                                                        int Cin, int Cout, float* __restrict__ dw,
+                                                                        double* __restrict__ gstats) {
+    __shared__ float red[4][64][sc::MAXC + 1];
     const int C1 = Cin + 1;
     const int nkt = Cout * 27;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int kt = blockIdx.x * 64 + lane;
+    const bool valid = kt < nkt;
+    const int k = valid ? kt / 27 : 0, tap = valid ? kt % 27 : 0;
     double dwacc[sc::MAXC];
     for (int c = 0; c < sc::MAXC; ++c) dwacc[c] = 0.0;
     for (int n = 0; n < N; ++n) {
-        if (threadIdx.x < sc::MAXC) {
-            s1s[threadIdx.x] = 0.0;
-            s2s[threadIdx.x] = 0.0;
-        }
-        __syncthreads();
-        for (int kt = threadIdx.x; kt < nkt; kt += blockDim.x) {  // at most one iteration when nkt <= 1024
-            double X[sc::MAXC + 1];
-            for (int c = 0; c <= sc::MAXC; ++c) X[c] = 0.0;
-            for (int b = 0; b < B; ++b) {
+        float acc[sc::MAXC + 1];
+        for (int c = 0; c <= sc::MAXC; ++c) acc[c] = 0.f;
+        if (valid) {
+            for (int b = grp; b < B; b += 4) {
                 const float* src = partial + ((size_t)n * B + b) * ((size_t)nkt * C1) + (size_t)kt * C1;
-                for (int c = 0; c < C1; ++c) X[c] += (double)src[c];
+                for (int c = 0; c < C1; ++c) acc[c] += src[c];
             }
-            const int k = kt / 27, tap = kt % 27;
+        }
+        for (int c = 0; c < C1; ++c) red[grp][lane][c] = acc[c];
+        __syncthreads();
+        if (grp == 0) {  // wave 0: lanes = 64 (k,tap) pairs
+            double X[sc::MAXC + 1];
+            for (int c = 0; c < C1; ++c)
+                X[c] = ((double)red[0][lane][c] + (double)red[1][lane][c]) + ((double)red[2][lane][c] + (double)red[3][lane][c]);
             const double T = X[Cin];
             for (int c = 0; c < Cin; ++c) {
-                const double a = affine ? (double)affine[((size_t)n * Cin + c) * 2] : 1.0;
-                const double bb = affine ? (double)affine[((size_t)n * Cin + c) * 2 + 1] : 0.0;
-                dwacc[c] += a * X[c] + bb * T;
-                const double wv = (double)w[((size_t)k * Cin + c) * 27 + tap];
-                atomicAdd(&s1s[c], wv * T);
-                atomicAdd(&s2s[c], wv * X[c]);
+                double s1 = 0.0, s2 = 0.0;
+                if (valid) {
+                    const double a = affine ? (double)affine[((size_t)n * Cin + c) * 2] : 1.0;
+                    const double bb = affine ? (double)affine[((size_t)n * Cin + c) * 2 + 1] : 0.0;
+                    dwacc[c] += a * X[c] + bb * T;
+                    const double wv = (double)w[((size_t)k * Cin + c) * 27 + tap];
+                    s1 = wv * T;
+                    s2 = wv * X[c];
+                }
+                for (int m = 32; m > 0; m >>= 1) {
+                    s1 += __shfl_xor(s1, m);
+                    s2 += __shfl_xor(s2, m);
+                }
+                if (lane == 0 && gstats) {
+                    u3d_atomic_add_f64(&gstats[((size_t)n * Cin + c) * 2], s1);
+                    u3d_atomic_add_f64(&gstats[((size_t)n * Cin + c) * 2 + 1], s2);
+                }
             }
         }
         __syncthreads();
-        if (gstats && threadIdx.x < Cin) {
-            gstats[((size_t)n * Cin + threadIdx.x) * 2] += s1s[threadIdx.x];
-            gstats[((size_t)n * Cin + threadIdx.x) * 2 + 1] += s2s[threadIdx.x];
-        }
-        __syncthreads();
     }
-    for (int kt = threadIdx.x; kt < nkt; kt += blockDim.x) {
-        const int k = kt / 27, tap = kt % 27;
+    if (grp == 0 && valid)
         for (int c = 0; c < Cin; ++c) dw[((size_t)k * Cin + c) * 27 + tap] = (float)dwacc[c];
-    }
 }
 
 static int small_bwd_blocks(int N, int D, int H, int W) {
     const long long ntiles = (long long)((D + 3) / 4) * ((H + 7) / 8) * ((W + 7) / 8);
-    long long B = 256 / (N > 0 ? N : 1);  // ~one block per CU in total; each walks its share of tiles
+    long long B = 1024 / (N > 0 ? N : 1);  // ~4 blocks per CU in total (latency hiding); each walks its share of tiles
     if (B < 1) B = 1;
     if (B > ntiles) B = ntiles;
     return (int)B;
@@ -300,8 +311,8 @@ extern "C" int u3d_conv3d_small_cin_bwd(int device, u3d_stream_t stream, const f
     else
         hipLaunchKernelGGL(conv3d_small_bwd_kernel<2>, dim3((unsigned)p.B, (unsigned)N), dim3(256), 0, (hipStream_t)stream, p);
     U3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(conv3d_small_bwd_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, workspace, affine, w,
-                       N, p.B, Cin, Cout, dw, gstats);
+    hipLaunchKernelGGL(conv3d_small_bwd_finalize_kernel, dim3((Cout * 27 + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                       workspace, affine, w, N, p.B, Cin, Cout, dw, gstats);
     U3D_LAUNCH_CHECK();
     return 0;
 }
