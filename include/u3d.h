@@ -68,8 +68,12 @@ const char* u3d_last_error(void);
 /* 0 if `device` is a gfx950 part, U3D_EARCH otherwise. */
 int u3d_check_device(int device);
 /* Process-wide performance knobs for A/B measurements (never change results).
- * key 0: de-synchronised block start phases in the conv kernels (default 1). */
+ * key 0: forced N-tiles per block of u3d_conv3d (1,2,3; 0 = automatic); key 1: wgrad split override. */
 int u3d_set_tuning(int key, int value);
+/* Developer aid (tools/wave_timeline.py): while a device buffer is registered, u3d_conv3d launches an instrumented
+ * twin of the kernel in which every wave records 24 int64 (block, HW_ID, XCC_ID, shader-clock stamps at entry /
+ * first tile staged / end of each chunk's k-loop / epilogue start / exit).  NULL switches it off (default). */
+int u3d_set_profile_buffer(void* device_buffer, size_t bytes);
 
 /* ---- weight packing -------------------------------------------------------------------------
  * Reference weights stay nn.Parameters in (Cout,Cin,3,3,3) layout (checkpoint compatibility,

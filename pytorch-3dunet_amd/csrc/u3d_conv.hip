@@ -14,8 +14,9 @@
 // contiguous per wave-load, L1/L2 resident), software-prefetched two k-steps ahead.
 #include "u3d_common.h"
 
-// run-time tuning knobs (u3d_set_tuning): [0] stagger on/off
-int g_u3d_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [1] = ablation mask for timing experiments (wrong results!)
+// run-time tuning knobs (u3d_set_tuning), for A/B measurements only — results never change:
+//   [0] forced N-tiles per block of u3d_conv3d (1,2,3; 0 = automatic)   [1] wgrad split override (0 = automatic)
+int g_u3d_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 namespace cv {
 constexpr int TZ = 4, TY = 8, TX = 8;
@@ -28,6 +29,7 @@ constexpr int LDS_FLOATS = HZ * PS + 4;           // 9840 floats + one dummy flo
 constexpr int NITEMS = HZ * HY * HX * (CC / 4);   // 2400 float4 items per chunk
 constexpr int NIT = (NITEMS + 255) / 256;         // 10
 constexpr int NSTEP = 27 * (CC / 8);              // 54 k-steps of 8 channels per chunk
+constexpr int PF_EVERY = 5;                       // one halo prefetch load every 5 k-steps (10 loads in steps 0..45)
 }  // namespace cv
 
 struct ConvParams {
@@ -40,18 +42,49 @@ struct ConvParams {
     int N, D, H, W, Cout;
     int nchunks, ncb, ntot;
     int tz, ty, tx;
-    int relu, vec, has_gx;
-    int stagger;  // shader cycles of one phase step (0 = off)
+    int relu, vec, has_gx, ovec;
+    long long* dbg;  // optional per-wave timeline records (u3d_set_profile_buffer), 16 int64 per wave
 };
 
-// ABL: timing-only ablation mask (tools/conv_microbench.py): 1 no B loads in the k-loop, 2 no A LDS reads in the
-// k-loop, 4 no re-staging after the first chunk, 8 no epilogue.  ABL != 0 produces wrong results by design.
-template <int NT, bool VEC, int ABL = 0>
-__global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvParams p) {
+// timeline record of one wave (DBG kernels only), 24 int64: [0] block, [1] HW_ID, [2] XCC_ID, [3] t_entry,
+// [5] t_epilogue_start, [6] t_exit, [7] nchunks, [8+2c] / [9+2c] start / end of the k-loop of chunk c < 8
+#define U3D_DBG_STAMP(slot)                                                   \
+    do {                                                                      \
+        if constexpr (DBG) {                                                  \
+            if (l == 0) dbgw[slot] = (long long)__builtin_readcyclecounter(); \
+        }                                                                     \
+    } while (0)
+
+// Software pipeline (VEC path).  The k-loop of chunk c is 54 steps x 8*NT MFMAs = 27648*NT MFMA-pipe cycles per
+// wave.  While it runs, the wave (1) streams the B fragments of the global step two ahead (the packed weight image
+// is one contiguous stream over (chunk, step), so the ring never restarts at a chunk boundary) and (2) issues the
+// 10 halo loads of chunk c+1 into registers, one every 5 steps, so that neither the HBM/L2 latency nor the burst of
+// every resident block re-staging at once is exposed: between chunks only [barrier, affine + 10 ds_write_b128,
+// barrier] remains.  vmcnt retires in order, hence the interleaving: a prefetch load is always older than a B load
+// that is needed two steps later, never younger than one needed now.
+template <int NT, bool VEC, bool DBG = false>
+__global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3d_mfma_kernel(const ConvParams p) {
     using namespace cv;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int t = threadIdx.x;
     const int l = t & 63, w = t >> 6, m = l & 31, h = l >> 5;
+    // Waves in their prologue / restaging / epilogue issue VALU, LDS and memory instructions; co-resident waves in
+    // their k-loop always have an MFMA pending and, being older, win the issue arbitration every cycle: measured with
+    // the timeline twin, prologue + epilogue took 7-10x their stand-alone time (26 % of a wave's life).  Priority
+    // outranks age: run the non-MFMA phases at priority 3 and the k-loop at 0 (an MFMA needs one issue slot per 64
+    // cycles, so the k-loop waves lose nothing).
+    __builtin_amdgcn_s_setprio(3);
+    long long* dbgw = nullptr;
+    if constexpr (DBG) {
+        dbgw = p.dbg + ((size_t)blockIdx.x * 4 + w) * 24;
+        if (l == 0) {
+            dbgw[0] = blockIdx.x;
+            dbgw[1] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
+            dbgw[2] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+            dbgw[7] = p.nchunks;
+        }
+    }
+    U3D_DBG_STAMP(3);
 
     // ---- block -> (tile, cout block) with XCD-contiguous ordering
     const int logical = u3d_xcd_remap(blockIdx.x, gridDim.x);
@@ -66,19 +99,6 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvParams p) {
     const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
     const int D = p.D, H = p.H, W = p.W;
     const int Ctot = p.src.C0 + p.src.C1;
-
-    // ---- de-synchronise the first wave of workgroups.  All resident blocks are dispatched together and do
-    //      identical work, so left alone they run in lockstep: every chunk they all stage their halo tiles at the
-    //      same moment (a tens-of-MB burst with every MFMA pipe idle) and then all compute with memory idle.  A
-    //      hashed start phase makes one block's staging overlap its co-residents' MFMA phase; blocks dispatched
-    //      later inherit the spread.
-    if (p.stagger > 0 && blockIdx.x < 256u * 4u) {
-        const unsigned hsh = (blockIdx.x * 2654435761u) >> 30;  // 0..3
-        if (hsh) {
-            const long long until = clock64() + (long long)hsh * p.stagger;
-            while (clock64() < until) __builtin_amdgcn_s_sleep(64);
-        }
-    }
 
     // ---- per-thread staging descriptors (constant across chunks)
     int ldsoff[NIT], gv0[NIT], gv1[NIT];
@@ -111,85 +131,106 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvParams p) {
     // A-fragment base: lane (m,h) -> voxel (zl = w, yl = (m>>3) [+4 for mt=1], xl = m&7), channels 4h..4h+3
     const int abase = w * PS + (m >> 3) * RS + (m & 7) * CS + 4 * h;
 
-    for (int ch = 0; ch < p.nchunks; ++ch) {
-        // weights of the first two k-steps: issued with the staging loads so their latency is shared
-        const f32x4* wq = reinterpret_cast<const f32x4*>(p.wp) + ((size_t)ch * NSTEP * p.ntot + cb * NT) * 64 + l;
-        const size_t wstep = (size_t)p.ntot * 64;
-        f32x4 bq[3][NT];
+    // B stream: packed f32x4 index ((g*ntot + ntile)*64 + lane) for the global step g = chunk*54 + step
+    const f32x4* wq = reinterpret_cast<const f32x4*>(p.wp) + (size_t)cb * NT * 64 + l;
+    const int wstep = p.ntot * 64;
+    const int glast = p.nchunks * NSTEP - 1;
+    f32x4 bq[3][NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            bq[0][nt] = wq[nt * 64];
-            bq[1][nt] = wq[wstep + nt * 64];
+    for (int nt = 0; nt < NT; ++nt) {
+        bq[0][nt] = wq[nt * 64];
+        bq[1][nt] = wq[(size_t)wstep + nt * 64];
+    }
+
+    // per-chunk source selection of this thread's channel quad
+    struct ChunkSrc {
+        const float* base;
+        int Cs;
+        bool cok, from0;
+        f32x4 ga, gb;
+    };
+    auto chunk_src = [&](int ch, bool live) {
+        ChunkSrc c;
+        const int cq = ch * CC + 4 * q;
+        c.cok = live && cq < Ctot;
+        c.from0 = cq < p.src.C0;
+        c.base = !c.cok ? p.src.p0 : (c.from0 ? p.src.p0 + cq : p.src.p1 + (cq - p.src.C0));
+        c.Cs = (c.from0 || !c.cok) ? p.src.C0 : p.src.C1;
+        c.ga = f32x4{1.f, 1.f, 1.f, 1.f};
+        c.gb = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.src.affine) {
+            const float* ap = p.src.affine + ((size_t)n * Ctot + (c.cok ? cq : 0)) * 2;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(ap);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(ap + 4);
+            c.ga = f32x4{lo[0], lo[2], hi[0], hi[2]};
+            c.gb = f32x4{lo[1], lo[3], hi[1], hi[3]};
         }
-        // ---- stage the halo tile of this 16-channel chunk: global -> regs -> (affine) -> LDS.
-        //      Fast path is branch-free: every load is issued unconditionally from a clamped (always valid)
-        //      address so the 10 loads of a thread are in flight together; validity is applied by select.
-        if (!(ABL & 4) || ch == 0) {
+        return c;
+    };
+    // branch-free halo load: always a valid address (clamped), validity is applied by select at the LDS write
+    auto halo_load = [&](const ChunkSrc& c, int it) {
+        const bool ok = c.cok && gv0[it] >= 0;
+        const int idx = ok ? (c.from0 ? gv0[it] : gv1[it]) : 0;
+        return *reinterpret_cast<const f32x4*>(c.base + (size_t)idx * c.Cs);
+    };
+    auto halo_store = [&](const ChunkSrc& c, int it, f32x4 raw) {
+        const bool ok = c.cok && gv0[it] >= 0;
+        f32x4 val = raw * c.ga + c.gb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[e] = ok ? val[e] : 0.f;  // padding stays exactly 0
+        *reinterpret_cast<f32x4*>(&lds[ldsoff[it]]) = val;
+    };
+
+    // ---- prologue: stage chunk 0
+    if constexpr (VEC) {
+        const ChunkSrc c0 = chunk_src(0, true);
+        f32x4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) v[it] = halo_load(c0, it);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) halo_store(c0, it, v[it]);
+    }
+
+    for (int ch = 0; ch < p.nchunks; ++ch) {
+        const bool has_next = ch + 1 < p.nchunks;
+        ChunkSrc cn;
+        f32x4 v[NIT];
+        if constexpr (VEC) {
+            cn = chunk_src(ch + 1, has_next);
+        } else {
+            // scalar-load path (channel counts that are not multiples of 4): synchronous staging
             const int cq = ch * CC + 4 * q;
-            f32x4 v[NIT];
-            f32x4 ga = {1.f, 1.f, 1.f, 1.f}, gb = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (VEC) {
-                const bool cok = cq < Ctot;
-                const bool from0 = cq < p.src.C0;
-                const float* base = !cok ? p.src.p0 : (from0 ? p.src.p0 + cq : p.src.p1 + (cq - p.src.C0));
-                const int Cs = (from0 || !cok) ? p.src.C0 : p.src.C1;
-                if (p.src.affine) {
-                    const float* ap = p.src.affine + ((size_t)n * Ctot + (cok ? cq : 0)) * 2;
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(ap);
-                    const f32x4 hi = *reinterpret_cast<const f32x4*>(ap + 4);
-                    ga = f32x4{lo[0], lo[2], hi[0], hi[2]};
-                    gb = f32x4{lo[1], lo[3], hi[1], hi[3]};
-                }
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const bool ok = cok && gv0[it] >= 0;
-                    const int idx = ok ? (from0 ? gv0[it] : gv1[it]) : 0;
-                    v[it] = *reinterpret_cast<const f32x4*>(base + (size_t)idx * Cs);
-                }
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const bool ok = cok && gv0[it] >= 0;
-                    f32x4 val = v[it] * ga + gb;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) val[e] = ok ? val[e] : 0.f;  // padding stays exactly 0
-                    *reinterpret_cast<f32x4*>(&lds[ldsoff[it]]) = val;
-                }
-            } else {
-                u3d_load_affine(p.src.affine, n, Ctot, cq, false, ga, gb);
+            f32x4 ga, gb;
+            u3d_load_affine(p.src.affine, n, Ctot, cq, false, ga, gb);
 #pragma unroll 1
-                for (int it = 0; it < NIT; ++it) {
-                    f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                    if (gv0[it] >= 0) val = u3d_load_quad(p.src, gv0[it], gv1[it], cq, false) * ga + gb;
-                    *reinterpret_cast<f32x4*>(&lds[ldsoff[it]]) = val;
-                }
+            for (int it = 0; it < NIT; ++it) {
+                f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                if (gv0[it] >= 0) val = u3d_load_quad(p.src, gv0[it], gv1[it], cq, false) * ga + gb;
+                *reinterpret_cast<f32x4*>(&lds[ldsoff[it]]) = val;
             }
         }
         __syncthreads();
+        __builtin_amdgcn_s_setprio(0);
+        if (ch < 8) U3D_DBG_STAMP(8 + 2 * ch);
 
-        // ---- 54 k-steps (27 taps x 2 channel-octets): 8*NT MFMAs each.  Software pipeline pinned with
-        //      sched_barrier: B (weights, global/L1) is fetched two steps ahead, A (LDS) one step ahead; the
-        //      compiler inserts the matching counted vmcnt/lgkmcnt waits.
+        // ---- 54 k-steps (27 taps x 2 channel-octets): 8*NT MFMAs each, pinned with sched_barrier; the compiler
+        //      inserts the matching counted vmcnt/lgkmcnt waits (the loop is fully unrolled).
         f32x4 aq[2][2];
         aq[0][0] = *reinterpret_cast<const f32x4*>(&lds[abase]);
         aq[0][1] = *reinterpret_cast<const f32x4*>(&lds[abase + 4 * RS]);
+        const int g0 = ch * NSTEP;
 #pragma unroll
         for (int st = 0; st < NSTEP; ++st) {
-            if (st + 2 < NSTEP) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    if (ABL & 1) {
-                        bq[(st + 2) % 3][nt] = bq[st % 3][nt];
-                        asm volatile("" : "+v"(bq[(st + 2) % 3][nt]));
-                    } else {
-                        bq[(st + 2) % 3][nt] = wq[(size_t)(st + 2) * wstep + nt * 64];
-                    }
-                }
+            if constexpr (VEC) {
+                if (st % PF_EVERY == 0 && st / PF_EVERY < NIT) v[st / PF_EVERY] = halo_load(cn, st / PF_EVERY);
             }
-            if ((ABL & 2) && st + 1 < NSTEP) {
-                aq[(st + 1) & 1][0] = aq[st & 1][0];
-                aq[(st + 1) & 1][1] = aq[st & 1][1];
-                asm volatile("" : "+v"(aq[(st + 1) & 1][0]), "+v"(aq[(st + 1) & 1][1]));
-            } else if (st + 1 < NSTEP) {
+            {
+                const int g2 = min(g0 + st + 2, glast);
+                const f32x4* wsrc = wq + (size_t)g2 * wstep;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bq[(st + 2) % 3][nt] = wsrc[nt * 64];
+            }
+            if (st + 1 < NSTEP) {
                 const int tap = (st + 1) >> 1, s1_ = (st + 1) & 1;
                 const int aoff = (tap / 9) * PS + ((tap / 3) % 3) * RS + (tap % 3) * CS + 8 * s1_;
                 aq[(st + 1) & 1][0] = *reinterpret_cast<const f32x4*>(&lds[abase + aoff]);
@@ -206,88 +247,156 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvParams p) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (ch < 8) U3D_DBG_STAMP(9 + 2 * ch);
+        __builtin_amdgcn_s_setprio(3);
         __syncthreads();
+        if constexpr (VEC) {
+            if (has_next) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) halo_store(cn, it, v[it]);
+            }
+        }
     }
 
     // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5);
     //      M-tile row -> (y = row>>3, x = row&7)  =>  reg r of lane (m,h): y = r>>2, x = (r&3) + 4h.
-    if (ABL & 8) {
-        // keep the accumulators alive without storing them
-        float keep = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) keep += acc[mt][nt][r];
-        if (keep == 123.456f) p.out[0] = keep;
-        return;
-    }
+    U3D_DBG_STAMP(5);
     const int z = z0 + w;
-    float s1[NT], s2[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        s1[nt] = 0.f;
-        s2[nt] = 0.f;
-    }
     const bool want_stats = p.out_stats != nullptr;
     const bool want_g = p.gstats != nullptr;
-    // dgrad epilogue: x of the layer input at (voxel, cout); per-lane source select is fixed per nt
-    const float* xb[NT];
-    int xcs[NT];
-    bool xfrom0[NT];
+    float* red = lds + 4 * 2048;  // [4 waves][NT][32][2] partial statistics, behind the 4 transposition regions
+    if (p.ovec) {
+        // ---- wide epilogue: each wave transposes its 64-voxel x 32-channel tile through a private 8 KiB LDS region
+        //      so that a lane owns 4 consecutive channels of one voxel: 16-byte stores (8 voxels x 128 B = 1 KiB
+        //      contiguous per instruction when Cout == 32) and 16-byte loads of x for the GroupNorm-backward sums,
+        //      instead of 32 four-byte stores (+32 four-byte loads) per N-tile.
+        float* tr = lds + w * 2048;        // [voxel = yl*8 + xl][32]
+        const int cq = l & 7, vl = l >> 3;  // read phase: channel quad, x within the row
+        f32x4 q1[NT], q2[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int co = (cb * NT + nt) * 32 + m;
-        const bool cok = co < p.Cout;
-        xfrom0[nt] = co < p.gx.C0 || !cok;
-        xb[nt] = !cok ? p.gx.p0 : (xfrom0[nt] ? p.gx.p0 + co : p.gx.p1 + (co - p.gx.C0));
-        xcs[nt] = xfrom0[nt] ? p.gx.C0 : p.gx.C1;
-    }
+        for (int nt = 0; nt < NT; ++nt) {
+            q1[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            q2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int y = y0 + mt * 4 + (r >> 2);
-            const int x = x0 + (r & 3) + 4 * h;
-            const bool vok = z < D && y < H && x < W;
-            int v0 = 0, v1 = 0;
+                for (int r = 0; r < 16; ++r) {
+                    float val = acc[mt][nt][r];
+                    if (p.relu) val = fmaxf(val, 0.f);
+                    tr[((4 * mt + (r >> 2)) * 8 + (r & 3) + 4 * h) * 32 + m] = val;
+                }
+            const int co = (cb * NT + nt) * 32 + 4 * cq;
+            const bool cok = co < p.Cout;
+            const int x = x0 + vl;
+            f32x4 xv[8];
             if (want_g) {
-                // clamped coordinates: always a valid address, masked below
-                u3d_vox_index(p.gx, n, min(z, D - 1), min(y, H - 1), min(x, W - 1), D, H, W, v0, v1);
+                const bool xfrom0 = co < p.gx.C0 || !cok;
+                const float* xb = !cok ? p.gx.p0 : (xfrom0 ? p.gx.p0 + co : p.gx.p1 + (co - p.gx.C0));
+                const int xcs = xfrom0 ? p.gx.C0 : p.gx.C1;
+#pragma unroll
+                for (int st = 0; st < 8; ++st) {
+                    int v0, v1;  // clamped coordinates: always a valid address, masked below
+                    u3d_vox_index(p.gx, n, min(z, D - 1), min(y0 + st, H - 1), min(x, W - 1), D, H, W, v0, v1);
+                    xv[st] = *reinterpret_cast<const f32x4*>(xb + (size_t)(xfrom0 ? v0 : v1) * xcs);
+                }
             }
-            const size_t vidx = (size_t)((n * D + z) * H + y) * W + x;
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                const int y = y0 + st;
+                const bool ok = cok && z < D && y < H && x < W;
+                f32x4 val = *reinterpret_cast<const f32x4*>(&tr[(st * 8 + vl) * 32 + 4 * cq]);
+                const size_t vidx = (size_t)((n * D + z) * H + y) * W + x;
+                if (ok) *reinterpret_cast<f32x4*>(p.out + vidx * p.Cout + co) = val;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) val[e] = ok ? val[e] : 0.f;
+                q1[nt] += val;
+                q2[nt] += want_g ? val * xv[st] : val * val;
+            }
+        }
+        if (want_stats || want_g) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int co = (cb * NT + nt) * 32 + m;
-                const bool ok = vok && co < p.Cout;
-                float val = acc[mt][nt][r];
-                if (p.relu) val = fmaxf(val, 0.f);
-                if (ok) p.out[vidx * p.Cout + co] = val;
-                const float vv = ok ? val : 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a = q1[nt][e], b = q2[nt][e];
+#pragma unroll
+                    for (int mask = 8; mask < 64; mask <<= 1) {
+                        a += __shfl_xor(a, mask);
+                        b += __shfl_xor(b, mask);
+                    }
+                    if (l < 8) {
+                        red[((w * NT + nt) * 32 + 4 * cq + e) * 2 + 0] = a;
+                        red[((w * NT + nt) * 32 + 4 * cq + e) * 2 + 1] = b;
+                    }
+                }
+            }
+        }
+    } else {
+        float s1[NT], s2[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            s1[nt] = 0.f;
+            s2[nt] = 0.f;
+        }
+        // dgrad epilogue: x of the layer input at (voxel, cout); per-lane source select is fixed per nt
+        const float* xb[NT];
+        int xcs[NT];
+        bool xfrom0[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = (cb * NT + nt) * 32 + m;
+            const bool cok = co < p.Cout;
+            xfrom0[nt] = co < p.gx.C0 || !cok;
+            xb[nt] = !cok ? p.gx.p0 : (xfrom0[nt] ? p.gx.p0 + co : p.gx.p1 + (co - p.gx.C0));
+            xcs[nt] = xfrom0[nt] ? p.gx.C0 : p.gx.C1;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int y = y0 + mt * 4 + (r >> 2);
+                const int x = x0 + (r & 3) + 4 * h;
+                const bool vok = z < D && y < H && x < W;
+                int v0 = 0, v1 = 0;
                 if (want_g) {
-                    const float xv = xb[nt][(size_t)(xfrom0[nt] ? v0 : v1) * xcs[nt]];
-                    s1[nt] += vv;
-                    s2[nt] += vv * xv;
-                } else {
-                    s1[nt] += vv;
-                    s2[nt] += vv * vv;
+                    // clamped coordinates: always a valid address, masked below
+                    u3d_vox_index(p.gx, n, min(z, D - 1), min(y, H - 1), min(x, W - 1), D, H, W, v0, v1);
+                }
+                const size_t vidx = (size_t)((n * D + z) * H + y) * W + x;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int co = (cb * NT + nt) * 32 + m;
+                    const bool ok = vok && co < p.Cout;
+                    float val = acc[mt][nt][r];
+                    if (p.relu) val = fmaxf(val, 0.f);
+                    if (ok) p.out[vidx * p.Cout + co] = val;
+                    const float vv = ok ? val : 0.f;
+                    if (want_g) {
+                        const float xv = xb[nt][(size_t)(xfrom0[nt] ? v0 : v1) * xcs[nt]];
+                        s1[nt] += vv;
+                        s2[nt] += vv * xv;
+                    } else {
+                        s1[nt] += vv;
+                        s2[nt] += vv * vv;
+                    }
+                }
+            }
+        }
+        if (want_stats || want_g) {
+            // reduce over the two half-waves (same cout)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                s1[nt] += __shfl_xor(s1[nt], 32);
+                s2[nt] += __shfl_xor(s2[nt], 32);
+                if (h == 0) {
+                    red[((w * NT + nt) * 32 + m) * 2 + 0] = s1[nt];
+                    red[((w * NT + nt) * 32 + m) * 2 + 1] = s2[nt];
                 }
             }
         }
     }
     if (want_stats || want_g) {
-        // reduce over the two half-waves (same cout), then over the 4 waves through LDS, then one f64 atomic
-        float* red = lds;  // [4][NT][32][2]
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            s1[nt] += __shfl_xor(s1[nt], 32);
-            s2[nt] += __shfl_xor(s2[nt], 32);
-            if (h == 0) {
-                red[((w * NT + nt) * 32 + m) * 2 + 0] = s1[nt];
-                red[((w * NT + nt) * 32 + m) * 2 + 1] = s2[nt];
-            }
-        }
+        // over the 4 waves through LDS, then one f64 atomic per (n, channel) and block
         __syncthreads();
         if (t < NT * 32) {
             const int nt = t >> 5, mm = t & 31;
@@ -305,6 +414,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvParams p) {
             }
         }
     }
+    U3D_DBG_STAMP(6);
 }
 
 // =================================================================================================
@@ -319,10 +429,14 @@ constexpr int CSg = 32, RSg = HX * CSg, PSg = HY * RSg;  // 32, 320, 3200
 constexpr int G_FLOATS = HZ * PSg;                       // 12800
 constexpr int TV = TZ * TY * TX;                         // 128 voxels
 constexpr int DZ_FLOATS = TV * 32;                       // 4096
-constexpr int LDS_FLOATS = G_FLOATS + DZ_FLOATS;         // 16896 floats = 67584 B
+constexpr int DUMMY_OFF = G_FLOATS + DZ_FLOATS;          // one float4 slot that swallows the tail staging items
+constexpr int BUF_FLOATS = G_FLOATS + DZ_FLOATS + 4;     // 16900 floats = 67600 B per staging buffer
+constexpr int LDS_FLOATS = 2 * BUF_FLOATS;               // double buffered: 135200 B -> one 8-wave block per CU
+constexpr int NTHR = 512;
 constexpr int NITEMS_G = HZ * HY * HX * (CC / 4);        // 3200
-constexpr int NIT_G = (NITEMS_G + 255) / 256;            // 13
-constexpr int NIT_DZ = TV * 8 / 256;                     // 4
+constexpr int NIT_G = (NITEMS_G + NTHR - 1) / NTHR;      // 7
+constexpr int NIT_DZ = TV * 8 / NTHR;                    // 2
+constexpr int MAX_MAP_INTS = 4096;                       // LDS copy of the nearest-upsample index maps (D + H + W)
 }  // namespace wg
 
 struct WgradParams {
@@ -333,18 +447,25 @@ struct WgradParams {
     int nchunks, nkb, S;
     int tz, ty, tx, ntiles, tps;
     int vec, dzvec;
-    int stagger;
 };
 
+// One block = 8 waves (512 threads) per CU: wave w owns the 7 taps {tg, tg+4, ..} (tg = w & 3) on voxel half
+// hf = w >> 2 (z-plane hf of the 2x8x8 tile), i.e. the block carries TWO independent 27-tap accumulator sets that
+// are written out as two split-K partials.  LDS holds two staging buffers: while the 224 MFMAs per wave of tile i
+// run on buffer b, the 7 + 2 staging loads of tile i+1 are issued (one every two voxel-pair groups) and written to
+// buffer b^1 later in the same loop with the GroupNorm affine applied — one barrier per tile, nothing else exposed.
+// The nearest-upsample index maps of a virtual source are copied to LDS once per block so that the prefetch
+// address arithmetic never waits on a dependent global load inside the MFMA stream.
 template <bool VEC>
-__global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const WgradParams p) {
+__global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams p) {
     using namespace wg;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* gl = lds;
-    float* dzl = lds + G_FLOATS;
+    int* zmapl = reinterpret_cast<int*>(lds + 2 * BUF_FLOATS);  // [D | H | W] (virtual source only)
+    __builtin_amdgcn_s_setprio(3);  // non-MFMA phases outrank co-resident k-loops (see conv3d_mfma_kernel)
     const int t = threadIdx.x;
     const int l = t & 63, i = l & 31, h = l >> 5;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int tg = w & 3, hf = w >> 2;
 
     const int logical = u3d_xcd_remap(blockIdx.x, gridDim.x);
     const int kb = logical % p.nkb;
@@ -352,180 +473,235 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const WgradParams 
     const int s = logical / (p.nkb * p.nchunks);
     const int D = p.D, H = p.H, W = p.W;
     const int Ctot = p.src.C0 + p.src.C1;
-
-    // start-phase offset against lockstep staging (see conv3d_mfma_kernel)
-    if (p.stagger > 0) {
-        const unsigned hsh = (blockIdx.x * 2654435761u) >> 31;  // 0..1: two blocks per CU
-        if (hsh) {
-            const long long until = clock64() + (long long)p.stagger;
-            while (clock64() < until) __builtin_amdgcn_s_sleep(64);
-        }
+    int* ymapl = zmapl + D;
+    int* xmapl = ymapl + H;
+    if (p.src.C1 > 0) {
+        for (int k = t; k < D; k += NTHR) zmapl[k] = p.src.zmap[k];
+        for (int k = t; k < H; k += NTHR) ymapl[k] = p.src.ymap[k];
+        for (int k = t; k < W; k += NTHR) xmapl[k] = p.src.xmap[k];
+        __syncthreads();
     }
 
-    int toff[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        const int tap = w + 4 * k;
-        toff[k] = tap < 27 ? (tap / 9) * PSg + ((tap / 3) % 3) * RSg + (tap % 3) * CSg : 0;
-    }
     f32x16 acc[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
 
-    // staging descriptors: g halo items (voxel = item>>3, quad = t&7), packed halo coords
-    const int q = t & 7;
-    int gpk[NIT_G], goff[NIT_G];
-#pragma unroll
-    for (int it = 0; it < NIT_G; ++it) {
-        const int item = t + 256 * it;
-        const int vox = item >> 3;
-        const bool in = item < NITEMS_G;
+    // this thread's channel quad of g (fixed per block) and of dz
+    const int q = t & 7, tv = t >> 3;  // tv in [0,64)
+    const int cq = chunk * CC + 4 * q;
+    const int co = kb * 32 + 4 * q;
+    const bool cok = cq < Ctot, from0 = cq < p.src.C0, dcok = co < p.Cout;
+    const float* gbase = !cok ? p.src.p0 : (from0 ? p.src.p0 + cq : p.src.p1 + (cq - p.src.C0));
+    const int Cs = (from0 || !cok) ? p.src.C0 : p.src.C1;
+    const float* dzbase = p.dz + (dcok ? co : 0);
+
+    struct TileC {
+        int n, z0, y0, x0;
+    };
+    auto tile_coords = [&](int tile) {
+        TileC c;
+        c.x0 = (tile % p.tx) * TX;
+        tile /= p.tx;
+        c.y0 = (tile % p.ty) * TY;
+        tile /= p.ty;
+        c.z0 = (tile % p.tz) * TZ;
+        c.n = tile / p.tz;
+        return c;
+    };
+    // g halo item `it` of a tile: LDS offset, validity and (clamped, always valid) global voxel index
+    auto g_item = [&](const TileC& c, int it, int& off, bool& ok, int& idx) {
+        const int vox = tv + 64 * it;
         const int hz = vox / (HY * HX);
         const int rem = vox - hz * (HY * HX);
         const int hy = rem / HX;
         const int hx = rem - hy * HX;
-        gpk[it] = in ? (hz | (hy << 8) | (hx << 16)) : (int)0x80000000;
-        goff[it] = hz * PSg + hy * RSg + hx * CSg + 4 * q;
-    }
-
-    const int tile_end = min(p.ntiles, (s + 1) * p.tps);
-    for (int tile = s * p.tps; tile < tile_end; ++tile) {
-        int tt = tile;
-        const int txi = tt % p.tx;
-        tt /= p.tx;
-        const int tyi = tt % p.ty;
-        tt /= p.ty;
-        const int tzi = tt % p.tz;
-        const int n = tt / p.tz;
-        const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
-
-        // ---- stage g (GroupNorm-affine input, zero padded) and dz; fast path is branch-free (clamped
-        //      addresses + select) so all loads of a thread are in flight together
-        {
-            const int cq = chunk * CC + 4 * q;
-            const int co = kb * 32 + 4 * q;
-            if constexpr (VEC) {
-                const bool cok = cq < Ctot;
-                const bool from0 = cq < p.src.C0;
-                const float* base = !cok ? p.src.p0 : (from0 ? p.src.p0 + cq : p.src.p1 + (cq - p.src.C0));
-                const int Cs = (from0 || !cok) ? p.src.C0 : p.src.C1;
-                f32x4 ga = {1.f, 1.f, 1.f, 1.f}, gb = {0.f, 0.f, 0.f, 0.f};
-                if (p.src.affine) {
-                    const float* ap = p.src.affine + ((size_t)n * Ctot + (cok ? cq : 0)) * 2;
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(ap);
-                    const f32x4 hi = *reinterpret_cast<const f32x4*>(ap + 4);
-                    ga = f32x4{lo[0], lo[2], hi[0], hi[2]};
-                    gb = f32x4{lo[1], lo[3], hi[1], hi[3]};
-                }
-                // dz first (4 loads), then g in two batches of 7/6 to bound live registers
-                f32x4 dv[NIT_DZ];
-                const bool dcok = co < p.Cout;
-#pragma unroll
-                for (int it = 0; it < NIT_DZ; ++it) {
-                    const int vox = (t >> 3) + 32 * it;
-                    const int z = z0 + (vox >> 6), y = y0 + ((vox >> 3) & 7), x = x0 + (vox & 7);
-                    const bool ok = dcok && z < D && y < H && x < W;
-                    const int vi = ok ? ((n * D + z) * H + y) * W + x : 0;
-                    dv[it] = *reinterpret_cast<const f32x4*>(p.dz + (size_t)vi * p.Cout + (dcok ? co : 0));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) dv[it][e] = ok ? dv[it][e] : 0.f;
-                }
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    constexpr int HB = (NIT_G + 1) / 2;  // 7
-                    f32x4 v[HB];
-                    bool ok[HB];
-#pragma unroll
-                    for (int k = 0; k < HB; ++k) {
-                        const int it = half * HB + k;
-                        if (it < NIT_G) {
-                            const int gz = z0 - 1 + (gpk[it] & 0xff), gy = y0 - 1 + ((gpk[it] >> 8) & 0xff),
-                                      gxx = x0 - 1 + ((gpk[it] >> 16) & 0xff);
-                            ok[k] = cok && gpk[it] >= 0 && gz >= 0 && gz < D && gy >= 0 && gy < H && gxx >= 0 && gxx < W;
-                            int v0, v1;
-                            u3d_vox_index(p.src, n, min(max(gz, 0), D - 1), min(max(gy, 0), H - 1),
-                                          min(max(gxx, 0), W - 1), D, H, W, v0, v1);
-                            const int idx = ok[k] ? (from0 ? v0 : v1) : 0;
-                            v[k] = *reinterpret_cast<const f32x4*>(base + (size_t)idx * Cs);
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < HB; ++k) {
-                        const int it = half * HB + k;
-                        if (it < NIT_G) {
-                            f32x4 val = v[k] * ga + gb;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) val[e] = ok[k] ? val[e] : 0.f;
-                            if (gpk[it] >= 0) *reinterpret_cast<f32x4*>(&gl[goff[it]]) = val;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int it = 0; it < NIT_DZ; ++it)
-                    *reinterpret_cast<f32x4*>(&dzl[((t >> 3) + 32 * it) * 32 + 4 * q]) = dv[it];
-            } else {
-                f32x4 ga, gb;
-                u3d_load_affine(p.src.affine, n, Ctot, cq, false, ga, gb);
-#pragma unroll 1
-                for (int it = 0; it < NIT_G; ++it) {
-                    if (gpk[it] < 0) continue;
-                    const int gz = z0 - 1 + (gpk[it] & 0xff), gy = y0 - 1 + ((gpk[it] >> 8) & 0xff),
-                              gxx = x0 - 1 + ((gpk[it] >> 16) & 0xff);
-                    f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                    if (gz >= 0 && gz < D && gy >= 0 && gy < H && gxx >= 0 && gxx < W) {
-                        int v0, v1;
-                        u3d_vox_index(p.src, n, gz, gy, gxx, D, H, W, v0, v1);
-                        val = u3d_load_quad(p.src, v0, v1, cq, false) * ga + gb;
-                    }
-                    *reinterpret_cast<f32x4*>(&gl[goff[it]]) = val;
-                }
-#pragma unroll 1
-                for (int it = 0; it < NIT_DZ; ++it) {
-                    const int vox = (t >> 3) + 32 * it;
-                    const int z = z0 + (vox >> 6), y = y0 + ((vox >> 3) & 7), x = x0 + (vox & 7);
-                    f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                    if (z < D && y < H && x < W) {
-                        const float* sp = p.dz + ((size_t)((n * D + z) * H + y) * W + x) * p.Cout + co;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (co + e < p.Cout) val[e] = sp[e];
-                    }
-                    *reinterpret_cast<f32x4*>(&dzl[vox * 32 + 4 * q]) = val;
-                }
-            }
+        off = vox < HZ * HY * HX ? hz * PSg + hy * RSg + hx * CSg + 4 * q : DUMMY_OFF;  // tail items -> dummy slot
+        const int gz = c.z0 - 1 + hz, gy = c.y0 - 1 + hy, gxx = c.x0 - 1 + hx;
+        ok = cok && vox < HZ * HY * HX && gz >= 0 && gz < D && gy >= 0 && gy < H && gxx >= 0 && gxx < W;
+        const int zc = min(max(gz, 0), D - 1), yc = min(max(gy, 0), H - 1), xc = min(max(gxx, 0), W - 1);
+        idx = ((c.n * D + zc) * H + yc) * W + xc;
+        if (p.src.C1 > 0) {  // uniform branch; the select below is per lane (a chunk may straddle C0)
+            const int idx1 = ((c.n * p.src.D1 + zmapl[zc]) * p.src.H1 + ymapl[yc]) * p.src.W1 + xmapl[xc];
+            idx = from0 ? idx : idx1;
         }
-        __syncthreads();
-
-        // ---- 64 voxel pairs x 7 taps.  A[i=c][k=h] = g[voxel 2t+h shifted by tap][c], B[k=h][j] = dz[voxel][j]
-        const int abase = i + h * CSg;
-#pragma unroll 2
-        for (int row = 0; row < 16; ++row) {
-            const int rowbase = (row >> 3) * PSg + (row & 7) * RSg + abase;
-#pragma unroll
-            for (int tq = 0; tq < 4; ++tq) {
-                const float b = dzl[(row * 8 + 2 * tq + h) * 32 + i];
-#pragma unroll
-                for (int k = 0; k < 7; ++k) {
-                    const float a = gl[rowbase + 2 * tq * CSg + toff[k]];
-                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[k], 0, 0, 0);
-                }
-            }
+        idx = ok ? idx : 0;
+    };
+    auto dz_item = [&](const TileC& c, int it, bool& ok, int& idx) {
+        const int vox = tv + 64 * it;
+        const int z = c.z0 + (vox >> 6), y = c.y0 + ((vox >> 3) & 7), x = c.x0 + (vox & 7);
+        ok = dcok && z < D && y < H && x < W;
+        idx = ok ? ((c.n * D + z) * H + y) * W + x : 0;
+    };
+    auto load_affine = [&](int n, f32x4& ga, f32x4& gb) {
+        ga = f32x4{1.f, 1.f, 1.f, 1.f};
+        gb = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.src.affine) {
+            const float* ap = p.src.affine + ((size_t)n * Ctot + (cok ? cq : 0)) * 2;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(ap);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(ap + 4);
+            ga = f32x4{lo[0], lo[2], hi[0], hi[2]};
+            gb = f32x4{lo[1], lo[3], hi[1], hi[3]};
         }
-        __syncthreads();
-    }
+    };
+    auto pf_load = [&](const TileC& c, int k) {  // k < NIT_G: g item, else dz item
+        bool ok;
+        int idx, off;
+        if (k < NIT_G) {
+            g_item(c, k, off, ok, idx);
+            return *reinterpret_cast<const f32x4*>(gbase + (size_t)idx * Cs);
+        }
+        dz_item(c, k - NIT_G, ok, idx);
+        return *reinterpret_cast<const f32x4*>(dzbase + (size_t)idx * p.Cout);
+    };
+    auto pf_store = [&](float* buf, const TileC& c, int k, f32x4 raw, const f32x4& ga, const f32x4& gb) {
+        bool ok;
+        int idx, off;
+        if (k < NIT_G) {
+            g_item(c, k, off, ok, idx);
+            f32x4 val = raw * ga + gb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) val[e] = ok ? val[e] : 0.f;  // zero padding AFTER the affine
+            *reinterpret_cast<f32x4*>(&buf[off]) = val;
+        } else {
+            dz_item(c, k - NIT_G, ok, idx);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) raw[e] = ok ? raw[e] : 0.f;
+            *reinterpret_cast<f32x4*>(&buf[G_FLOATS + (tv + 64 * (k - NIT_G)) * 32 + 4 * q]) = raw;
+        }
+    };
+    // scalar-load staging (channel counts that are not multiples of 4): synchronous
+    auto stage_scalar = [&](float* buf, const TileC& c) {
+        f32x4 ga, gb;
+        u3d_load_affine(p.src.affine, c.n, Ctot, cq, false, ga, gb);
+#pragma unroll 1
+        for (int it = 0; it < NIT_G; ++it) {
+            const int vox = tv + 64 * it;
+            if (vox >= HZ * HY * HX) continue;
+            const int hz = vox / (HY * HX), rem = vox - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+            const int gz = c.z0 - 1 + hz, gy = c.y0 - 1 + hy, gxx = c.x0 - 1 + hx;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (gz >= 0 && gz < D && gy >= 0 && gy < H && gxx >= 0 && gxx < W) {
+                int v0, v1;
+                u3d_vox_index(p.src, c.n, gz, gy, gxx, D, H, W, v0, v1);
+                val = u3d_load_quad(p.src, v0, v1, cq, false) * ga + gb;
+            }
+            *reinterpret_cast<f32x4*>(&buf[hz * PSg + hy * RSg + hx * CSg + 4 * q]) = val;
+        }
+#pragma unroll 1
+        for (int it = 0; it < NIT_DZ; ++it) {
+            const int vox = tv + 64 * it;
+            const int z = c.z0 + (vox >> 6), y = c.y0 + ((vox >> 3) & 7), x = c.x0 + (vox & 7);
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (z < D && y < H && x < W) {
+                const float* sp = p.dz + ((size_t)((c.n * D + z) * H + y) * W + x) * p.Cout + co;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (co + e < p.Cout) val[e] = sp[e];
+            }
+            *reinterpret_cast<f32x4*>(&buf[G_FLOATS + vox * 32 + 4 * q]) = val;
+        }
+    };
 
-    // ---- partial[s][chunk][kb][tap][c][k]; D rows = c, cols = k
-    float* dst = p.partial + ((size_t)((s * p.nchunks + chunk) * p.nkb + kb) * 27) * 1024;
+    constexpr int NPF = NIT_G + NIT_DZ;  // 9 prefetch loads per thread and tile
+    constexpr int ST0 = 20;              // first voxel-pair group that writes a prefetched item to the other buffer
+    static_assert(2 * (NPF - 1) < ST0 && ST0 + NPF <= 32, "prefetch schedule must fit the 32 groups of a tile");
+    const int tile_begin = s * p.tps, tile_end = min(p.ntiles, (s + 1) * p.tps);
+
+    // ---- prologue: stage the first tile into buffer 0
+    if (tile_begin < tile_end) {
+        const TileC c = tile_coords(tile_begin);
+        if constexpr (VEC) {
+            f32x4 ga, gb;
+            load_affine(c.n, ga, gb);
+            f32x4 v[NPF];
+#pragma unroll
+            for (int k = 0; k < NPF; ++k) v[k] = pf_load(c, k);
+#pragma unroll
+            for (int k = 0; k < NPF; ++k) pf_store(lds, c, k, v[k], ga, gb);
+        } else {
+            stage_scalar(lds, c);
+        }
+    }
+    __syncthreads();
+
+    // A-operand bases: lane (i = channel, h = voxel parity) + the wave's z-plane + its 7 tap offsets
+    int abase[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
-        const int tap = w + 4 * k;
-        if (tap < 27) {
+        const int tap = tg + 4 * k;
+        const int toff = tap < 27 ? (tap / 9) * PSg + ((tap / 3) % 3) * RSg + (tap % 3) * CSg : 0;
+        abase[k] = i + h * CSg + hf * PSg + toff;
+    }
+    int bbase = G_FLOATS + (hf * 64 + h) * 32 + i;
+    int cur = 0;  // buffer holding the current tile
+    __builtin_amdgcn_s_setprio(0);
+
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        const bool has_next = tile + 1 < tile_end;
+        const TileC cn = tile_coords(has_next ? tile + 1 : tile);
+        float* nbuf = lds + (cur ^ 1) * BUF_FLOATS;
+        f32x4 v[NPF];
+        f32x4 gan, gbn;
+        if constexpr (VEC) {
+            load_affine(cn.n, gan, gbn);
+        }
+        const float* gl = lds + cur * BUF_FLOATS;
+
+        // ---- 32 voxel-pair groups x 7 taps.  A[i=c][k=h] = g[voxel 2t+h shifted by tap][c], B[k=h][j] = dz[voxel][j]
+        float aop[2][7], bop[2];
+        bop[0] = gl[bbase];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = (r & 3) + 8 * (r >> 2) + 4 * h;
-                dst[((size_t)tap * 32 + c) * 32 + i] = acc[k][r];
+        for (int k = 0; k < 7; ++k) aop[0][k] = gl[abase[k]];
+#pragma unroll
+        for (int g = 0; g < 32; ++g) {
+            if constexpr (VEC) {
+                if (g % 2 == 0 && g / 2 < NPF) v[g / 2] = pf_load(cn, g / 2);
+                // (after the last tile this re-stages it into the idle buffer: harmless and branch-free)
+                if (g >= ST0 && g - ST0 < NPF) pf_store(nbuf, cn, g - ST0, v[g - ST0], gan, gbn);
+            }
+            if (g + 1 < 32) {
+                const int row = (g + 1) >> 2, tq = (g + 1) & 3;
+                const int goff = row * RSg + 2 * tq * CSg;
+                bop[(g + 1) & 1] = gl[bbase + (row * 8 + 2 * tq) * 32];
+#pragma unroll
+                for (int k = 0; k < 7; ++k) aop[(g + 1) & 1][k] = gl[abase[k] + goff];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[g & 1][k], bop[g & 1], acc[k], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (!VEC) {
+            if (has_next) stage_scalar(nbuf, cn);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    __builtin_amdgcn_s_setprio(3);
+    // ---- fold the two voxel halves (fixed order: hf 0 + hf 1) through LDS, then
+    //      partial[s][chunk][kb][tap][c][k]; D rows = c, cols = k
+    float* red = lds;  // [tg][k][r][lane]: 4 * 7 * 16 * 64 floats = 112 KiB of the (now idle) staging buffers
+    if (hf == 1) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((tg * 7 + k) * 16 + r) * 64 + l] = acc[k][r];
+    }
+    __syncthreads();
+    if (hf == 0) {
+        float* dst = p.partial + ((size_t)((s * p.nchunks + chunk) * p.nkb + kb) * 27) * 1024;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int tap = tg + 4 * k;
+            if (tap < 27) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    dst[((size_t)tap * 32 + c) * 32 + i] = acc[k][r] + red[((tg * 7 + k) * 16 + r) * 64 + l];
+                }
             }
         }
     }
@@ -652,6 +828,15 @@ static int check_src(const u3d_src_t* s, const char* what) {
     return 0;
 }
 
+static long long* g_u3d_prof_buf = nullptr;
+static size_t g_u3d_prof_records = 0;
+
+extern "C" int u3d_set_profile_buffer(void* device_buffer, size_t bytes) {
+    g_u3d_prof_buf = static_cast<long long*>(device_buffer);
+    g_u3d_prof_records = device_buffer ? bytes / (24 * sizeof(long long)) : 0;
+    return 0;
+}
+
 extern "C" int u3d_set_tuning(int key, int value) {
     if (key < 0 || key >= 8) return u3d_set_err(U3D_EINVAL, "u3d_set_tuning: key out of range");
     g_u3d_tune[key] = value;
@@ -708,39 +893,40 @@ extern "C" int u3d_conv3d(int device, u3d_stream_t stream, const u3d_src_t* src,
     p.tz = cdiv(D, cv::TZ), p.ty = cdiv(H, cv::TY), p.tx = cdiv(W, cv::TX);
     p.relu = relu;
     p.vec = src_vec_ok(src) ? 1 : 0;
-    p.stagger = 0;
+    // wide (16-byte) epilogue: whole channel quads, aligned output and (for dgrad) an x source readable in quads
+    p.ovec = (Cout % 4 == 0 && ((uintptr_t)out & 15) == 0 && (!gx || src_vec_ok(gx))) ? 1 : 0;
     const long long ntiles = (long long)N * p.tz * p.ty * p.tx;
-    // BN = 64 halves the A-tile restaging; use it when there are enough blocks to fill 256 CUs anyway
-    const bool nt2 = (p.ntot % 2 == 0) && (ntiles * (p.ntot / 2) >= 512);
-    p.ncb = nt2 ? p.ntot / 2 : p.ntot;
+    // N-tiles per block: BN = 32*NT output channels share one staged A tile.  Larger NT = fewer re-stagings of the
+    // same halo tile and fewer LDS reads per MFMA, at the price of registers (NT=1: 3 blocks/CU, NT>=2: 2 blocks/CU);
+    // take the largest NT in {3,2} that divides the N-tile count and still leaves >= 2 blocks per CU.
+    int nt = 1;
+    if (p.ntot % 3 == 0 && ntiles * (p.ntot / 3) >= 512) nt = 3;
+    else if (p.ntot % 2 == 0 && ntiles * (p.ntot / 2) >= 512) nt = 2;
+    if (g_u3d_tune[0] >= 1 && g_u3d_tune[0] <= 3 && p.ntot % g_u3d_tune[0] == 0) nt = g_u3d_tune[0];
+    p.ncb = p.ntot / nt;
     const long long nblk = ntiles * p.ncb;
     U3D_REQUIRE(nblk < (1ll << 31), "u3d_conv3d: grid too large");
-    // quarter of a chunk period when the CU is full: one wave's MFMA time per chunk = 54 steps * 8*NT MFMAs * 64 cycles
-    if (g_u3d_tune[0] && nblk >= 512 && p.nchunks >= 1) p.stagger = 54 * 8 * (nt2 ? 2 : 1) * 64;
     const size_t shmem = cv::LDS_FLOATS * sizeof(float);
     const bool vec = p.vec != 0;
     const dim3 grid((unsigned)nblk), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (nt2 && vec)
-        hipLaunchKernelGGL((conv3d_mfma_kernel<2, true>), grid, block, shmem, st, p);
-    else if (nt2)
-        hipLaunchKernelGGL((conv3d_mfma_kernel<2, false>), grid, block, shmem, st, p);
-    else if (vec && g_u3d_tune[1] == 1)
-        hipLaunchKernelGGL((conv3d_mfma_kernel<1, true, 1>), grid, block, shmem, st, p);
-    else if (vec && g_u3d_tune[1] == 2)
-        hipLaunchKernelGGL((conv3d_mfma_kernel<1, true, 2>), grid, block, shmem, st, p);
-    else if (vec && g_u3d_tune[1] == 4)
-        hipLaunchKernelGGL((conv3d_mfma_kernel<1, true, 4>), grid, block, shmem, st, p);
-    else if (vec && g_u3d_tune[1] == 8)
-        hipLaunchKernelGGL((conv3d_mfma_kernel<1, true, 8>), grid, block, shmem, st, p);
-    else if (vec && g_u3d_tune[1] == 7)
-        hipLaunchKernelGGL((conv3d_mfma_kernel<1, true, 7>), grid, block, shmem, st, p);
-    else if (vec && g_u3d_tune[1] == 15)
-        hipLaunchKernelGGL((conv3d_mfma_kernel<1, true, 15>), grid, block, shmem, st, p);
-    else if (vec)
-        hipLaunchKernelGGL((conv3d_mfma_kernel<1, true>), grid, block, shmem, st, p);
+    p.dbg = (vec && g_u3d_prof_buf && (size_t)nblk * 4 <= g_u3d_prof_records) ? g_u3d_prof_buf : nullptr;
+#define U3D_CONV_LAUNCH(NT_)                                                                     \
+    do {                                                                                         \
+        if (p.dbg)                                                                               \
+            hipLaunchKernelGGL((conv3d_mfma_kernel<NT_, true, true>), grid, block, shmem, st, p); \
+        else if (vec)                                                                            \
+            hipLaunchKernelGGL((conv3d_mfma_kernel<NT_, true>), grid, block, shmem, st, p);      \
+        else                                                                                     \
+            hipLaunchKernelGGL((conv3d_mfma_kernel<NT_, false>), grid, block, shmem, st, p);     \
+    } while (0)
+    if (nt == 3)
+        U3D_CONV_LAUNCH(3);
+    else if (nt == 2)
+        U3D_CONV_LAUNCH(2);
     else
-        hipLaunchKernelGGL((conv3d_mfma_kernel<1, false>), grid, block, shmem, st, p);
+        U3D_CONV_LAUNCH(1);
+#undef U3D_CONV_LAUNCH
     U3D_LAUNCH_CHECK();
     return 0;
 }
@@ -750,10 +936,25 @@ static void wgrad_plan(int N, int D, int H, int W, int Cin, int Cout, WgradParam
     p.nkb = cdiv(Cout, 32);
     p.tz = cdiv(D, wg::TZ), p.ty = cdiv(H, wg::TY), p.tx = cdiv(W, wg::TX);
     p.ntiles = N * p.tz * p.ty * p.tx;
-    int S = 512 / (p.nchunks * p.nkb);
-    if (S < 1) S = 1;
-    if (S > p.ntiles) S = p.ntiles;
-    p.tps = cdiv(p.ntiles, S);
+    // One 8-wave block per CU (135 KB of LDS): pick the split count S whose grid S*pairs fills whole rounds of the
+    // 256 CUs best.  cost = rounds * (tiles per split + ~2 tiles of prologue / partial-sum write per block).
+    const int pairs = p.nchunks * p.nkb;
+    long long best_cost = -1;
+    int best_S = 1;
+    for (int rounds = 1; rounds <= 8; ++rounds) {
+        int S = (rounds * 256) / pairs;
+        if (S < 1) S = 1;
+        if (S > p.ntiles) S = p.ntiles;
+        const int tps = cdiv(p.ntiles, S);
+        S = cdiv(p.ntiles, tps);
+        const long long cost = (long long)cdiv(S * pairs, 256) * (tps + 2);
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best_S = S;
+        }
+    }
+    if (g_u3d_tune[1] > 0) best_S = g_u3d_tune[1] > p.ntiles ? p.ntiles : g_u3d_tune[1];
+    p.tps = cdiv(p.ntiles, best_S);
     p.S = cdiv(p.ntiles, p.tps);
 }
 
@@ -767,9 +968,9 @@ static int wgrad_set_lds_once(int device) {
     static bool done[64] = {false};
     if (device >= 0 && device < 64 && done[device]) return 0;
     U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wgrad_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, wg::LDS_FLOATS * sizeof(float)));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (wg::LDS_FLOATS + wg::MAX_MAP_INTS) * sizeof(float)));
     U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wgrad_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, wg::LDS_FLOATS * sizeof(float)));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (wg::LDS_FLOATS + wg::MAX_MAP_INTS) * sizeof(float)));
     if (device >= 0 && device < 64) done[device] = true;
     return 0;
 }
@@ -792,16 +993,14 @@ extern "C" int u3d_conv3d_wgrad(int device, u3d_stream_t stream, const u3d_src_t
     p.N = N, p.D = D, p.H = H, p.W = W, p.Cout = Cout;
     p.vec = src_vec_ok(src) ? 1 : 0;
     p.dzvec = (Cout % 4 == 0 && ((uintptr_t)dz & 15) == 0) ? 1 : 0;
-    // half a tile period: one wave's MFMA time per tile = 64 voxel pairs * 7 taps * 64 cycles
-    p.stagger = (g_u3d_tune[0] && p.tps >= 2) ? 64 * 7 * 64 : 0;
     if (int e = wgrad_set_lds_once(device)) return e;
     const int nblk = p.S * p.nchunks * p.nkb;
+    U3D_REQUIRE(D + H + W <= wg::MAX_MAP_INTS, "u3d_conv3d_wgrad: D+H+W must be <= %d", wg::MAX_MAP_INTS);
+    const size_t shmem = (wg::LDS_FLOATS + (size_t)(D + H + W)) * sizeof(float);
     if (p.vec && p.dzvec)
-        hipLaunchKernelGGL(conv3d_wgrad_kernel<true>, dim3(nblk), dim3(256), wg::LDS_FLOATS * sizeof(float),
-                           (hipStream_t)stream, p);
+        hipLaunchKernelGGL(conv3d_wgrad_kernel<true>, dim3(nblk), dim3(wg::NTHR), shmem, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL(conv3d_wgrad_kernel<false>, dim3(nblk), dim3(256), wg::LDS_FLOATS * sizeof(float),
-                           (hipStream_t)stream, p);
+        hipLaunchKernelGGL(conv3d_wgrad_kernel<false>, dim3(nblk), dim3(wg::NTHR), shmem, (hipStream_t)stream, p);
     U3D_LAUNCH_CHECK();
     const long long total = (long long)Cin * 27 * Cout;
     const int rblocks = (int)((total + 63) / 64);

@@ -39,6 +39,7 @@ _PROTOS = {
     "u3d_last_error": (c_char_p, []),
     "u3d_check_device": (c_int, [c_int]),
     "u3d_set_tuning": (c_int, [c_int, c_int]),
+    "u3d_set_profile_buffer": (c_int, [c_void_p, c_size_t]),
     "u3d_packed_weight_floats": (c_size_t, [c_int, c_int, c_int]),
     "u3d_pack_weights": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "u3d_conv3d": (

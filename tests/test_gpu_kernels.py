@@ -80,6 +80,67 @@ def test_conv3d_fwd_nt2_many_tiles():
     assert U.relerr(U.ncdhw(y), ref) < TOL
 
 
+def test_conv3d_fwd_nt3_many_tiles():
+    """96 output channels (3 N-tiles) with >= 512 tiles selects the BN=96 (NT=3) kernel — the dgrad shape of the
+    96->32 decoder conv"""
+    U, nat, VSrc, _p, _stream = _mods()
+    torch.manual_seed(6)
+    N, Cin, Cout, D, H, W = 1, 32, 96, 32, 64, 64
+    x = torch.randn(N, Cin, D, H, W)
+    w = torch.randn(Cout, Cin, 3, 3, 3) / (27 * Cin) ** 0.5
+    ref = F.conv3d(x, w, None, padding=1)
+    st = torch.zeros((N, Cout, 2), dtype=torch.float64, device=U.DEV)
+    y = U.conv3d(VSrc(U.ndhwc(x)), w, Cout, relu=0, out_stats=st)
+    assert U.relerr(U.ncdhw(y), ref) < TOL
+    s_ref = torch.stack([ref.double().sum(dim=(2, 3, 4)), (ref.double() ** 2).sum(dim=(2, 3, 4))], dim=-1)
+    assert U.relerr(st.cpu(), s_ref) < 1e-5
+
+
+@pytest.mark.parametrize("forced_nt", [1, 2, 3])
+def test_conv3d_forced_ntile_variants_agree(forced_nt):
+    """u3d_set_tuning(0, NT) forces the N-tiles-per-block variant; every variant gives the same result on a
+    6-chunk virtual-concat source (the prefetch pipeline crosses the skip -> upsampled source switch)"""
+    U, nat, VSrc, _p, _stream = _mods()
+    torch.manual_seed(12)
+    N, C0, C1, Cout = 1, 32, 64, 192
+    D, H, W = 8, 16, 16
+    skip = torch.randn(N, C0, D, H, W)
+    low = torch.randn(N, C1, D // 2, H // 2, W // 2)
+    cat = torch.cat((skip, F.interpolate(low, size=(D, H, W), mode="nearest")), dim=1)
+    w = torch.randn(Cout, C0 + C1, 3, 3, 3) / (27 * (C0 + C1)) ** 0.5
+    ab = torch.randn(N, C0 + C1, 2)
+    g = cat * ab[:, :, 0].view(N, -1, 1, 1, 1) + ab[:, :, 1].view(N, -1, 1, 1, 1)
+    ref = F.relu(F.conv3d(g, w, None, padding=1))
+    src = VSrc(U.ndhwc(skip), U.ndhwc(low))
+    nat.call("u3d_set_tuning", 0, forced_nt)
+    try:
+        y = U.conv3d(src, w, Cout, relu=1, affine=ab.contiguous().to(U.DEV))
+    finally:
+        nat.call("u3d_set_tuning", 0, 0)
+    assert U.relerr(U.ncdhw(y), ref) < TOL
+
+
+@pytest.mark.parametrize("split", [1, 3, 16])
+def test_conv3d_wgrad_split_override_crosses_samples(split):
+    """u3d_set_tuning(1, S) forces the split-K count: S=3 over 16 tiles makes a block walk 6 tiles across the
+    sample boundary (per-tile GroupNorm affine reload, double-buffered staging), S=16 is one tile per block"""
+    U, nat, VSrc, _p, _stream = _mods()
+    torch.manual_seed(13)
+    N, Cin, Cout, D, H, W = 2, 32, 32, 4, 16, 16
+    x = torch.randn(N, Cin, D, H, W)
+    dz = torch.randn(N, Cout, D, H, W)
+    ab = torch.randn(N, Cin, 2)
+    g = x * ab[:, :, 0].view(N, Cin, 1, 1, 1) + ab[:, :, 1].view(N, Cin, 1, 1, 1)
+    wl = torch.zeros(Cout, Cin, 3, 3, 3, requires_grad=True)
+    F.conv3d(g, wl, None, padding=1).backward(dz)
+    nat.call("u3d_set_tuning", 1, split)
+    try:
+        dw = U.wgrad(VSrc(U.ndhwc(x)), U.ndhwc(dz), Cout, affine=ab.contiguous().to(U.DEV))
+    finally:
+        nat.call("u3d_set_tuning", 1, 0)
+    assert U.relerr(dw.cpu(), wl.grad) < 1e-4
+
+
 @pytest.mark.parametrize("size", [(8, 16, 16), (9, 13, 11)])
 def test_conv3d_virtual_concat_upsample(size):
     """skip (full-res) ++ nearest-upsampled low-res tensor, never materialised (buildingblocks.py:491,:614)"""
