@@ -12,10 +12,13 @@
 // reads (tools/lds_bank_model.py).  An MFMA M-tile is 4(y) x 8(x) voxels at one z; wave w owns z = z0+w and
 // both y-halves (MT = 2).  B fragments (weights) are read straight from the packed global image (1 KiB
 // contiguous per wave-load, L1/L2 resident), software-prefetched two k-steps ahead.
+#include <type_traits>
+
 #include "u3d_common.h"
 
 // run-time tuning knobs (u3d_set_tuning), for A/B measurements only — results never change:
 //   [0] forced N-tiles per block of u3d_conv3d (1,2,3; 0 = automatic)   [1] wgrad split override (0 = automatic)
+//   [2] ablation mask of the instrumented conv twin (timing experiments, wrong results)
 int g_u3d_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 namespace cv {
@@ -25,11 +28,16 @@ constexpr int CC = 16;             // input channels per chunk
 constexpr int CS = 16;             // voxel stride (floats)
 constexpr int RS = HX * CS + 4;    // row stride 164 (bank-conflict-free, see header)
 constexpr int PS = HY * RS;        // plane stride 1640
-constexpr int LDS_FLOATS = HZ * PS + 4;           // 9840 floats + one dummy float4 slot = 39376 B
+constexpr int TILE_FLOATS = HZ * PS + 4;          // 9840 floats + one dummy float4 slot = 39376 B per staging buffer
+constexpr int CNT_OFF = 2 * TILE_FLOATS;          // 16 ints: [0,1] full[buf], [2,3] freed[buf], [4] statistics arrivals
+constexpr int RED_OFF = CNT_OFF + 16;             // [4 waves][NT <= 3][32][2] partial statistics
+constexpr int LDS_FLOATS = RED_OFF + 4 * 3 * 32 * 2;  // 20472 floats = 81888 B -> two blocks per CU
 constexpr int NITEMS = HZ * HY * HX * (CC / 4);   // 2400 float4 items per chunk
 constexpr int NIT = (NITEMS + 255) / 256;         // 10
 constexpr int NSTEP = 27 * (CC / 8);              // 54 k-steps of 8 channels per chunk
-constexpr int PF_EVERY = 5;                       // one halo prefetch load every 5 k-steps (10 loads in steps 0..45)
+constexpr int ST0 = 30;                           // k-step of the first halo store into the other buffer
+constexpr int PACK_PAD = 5;                       // zero k-steps appended to the packed weight image (B prefetch overrun)
+static_assert(2 * (NIT - 1) < ST0 - 8 && ST0 + NIT <= NSTEP, "prefetch schedule must fit the k-loop");
 }  // namespace cv
 
 struct ConvParams {
@@ -43,7 +51,7 @@ struct ConvParams {
     int nchunks, ncb, ntot;
     int tz, ty, tx;
     int relu, vec, has_gx, ovec;
-    long long* dbg;  // optional per-wave timeline records (u3d_set_profile_buffer), 16 int64 per wave
+    long long* dbg;  // optional per-wave timeline records (u3d_set_profile_buffer), 24 int64 per wave
 };
 
 // timeline record of one wave (DBG kernels only), 24 int64: [0] block, [1] HW_ID, [2] XCC_ID, [3] t_entry,
@@ -55,24 +63,44 @@ struct ConvParams {
         }                                                                     \
     } while (0)
 
-// Software pipeline (VEC path).  The k-loop of chunk c is 54 steps x 8*NT MFMAs = 27648*NT MFMA-pipe cycles per
-// wave.  While it runs, the wave (1) streams the B fragments of the global step two ahead (the packed weight image
-// is one contiguous stream over (chunk, step), so the ring never restarts at a chunk boundary) and (2) issues the
-// 10 halo loads of chunk c+1 into registers, one every 5 steps, so that neither the HBM/L2 latency nor the burst of
-// every resident block re-staging at once is exposed: between chunks only [barrier, affine + 10 ds_write_b128,
-// barrier] remains.  vmcnt retires in order, hence the interleaving: a prefetch load is always older than a B load
-// that is needed two steps later, never younger than one needed now.
-template <int NT, bool VEC, bool DBG = false>
-__global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3d_mfma_kernel(const ConvParams p) {
+// ---- intra-block flags in LDS (no rendezvous): the LDS unit executes a wave's DS instructions in order, so a
+// counter increment issued after a wave's tile stores is observed only after those stores; the compiler is held to
+// program order by the asm memory clobbers.  No fences: a workgroup-scope fence would drain vmcnt, i.e. stall on
+// the in-flight weight / halo prefetch loads.
+__device__ __forceinline__ void u3d_flag_signal(int* c, int lane) {
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void u3d_flag_wait(int* c, int target) {
+    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(2);
+    asm volatile("" ::: "memory");
+}
+
+// Asynchronous software pipeline.  A block = 4 waves on the 4 SIMDs of a CU sharing a 4x8x8 output tile; its 6x10x10
+// halo tile of the current 16-channel chunk lives in one of TWO LDS buffers.  During the 54 k-steps of chunk c a wave
+//   steps 0,2,..,18   issues its 10 halo loads of chunk c+1 into registers (branch-free, clamped addresses),
+//   every step        streams the B fragments (packed weights, one contiguous image over (chunk, step)) two steps ahead
+//                     and reads the A fragments of the next step from LDS,
+//   steps 30..39      applies the GroupNorm affine and writes one halo item per step into the OTHER buffer,
+//   step 39           signals full[other]; at the end of the k-loop it signals freed[current].
+// Waves never meet at a barrier inside the chunk loop: a wave enters chunk c+1 as soon as all four have signalled
+// full, and overwrites a buffer only after all four signalled freed.  The four waves of a block share their SIMDs
+// with waves of another block in arbitrary phases and therefore progress at different speeds; with rendezvous
+// barriers that skew cost ~10 k cycles per chunk (measured with the timeline twin), with flags it is absorbed as
+// long as a wave is not more than ~half a chunk ahead of the slowest.
+// ABL (instrumented twin only, u3d_set_tuning key 2): timing-only ablation mask — 1 no halo prefetch/restaging,
+// 2 no B loads in the k-loop, 4 no A reads in the k-loop.  ABL != 0 produces wrong results by design.
+template <int NT, bool VEC, bool DBG = false, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvParams p) {
     using namespace cv;
+    constexpr int RB = NT == 1 ? 6 : 3;  // B ring depth: fragments are fetched RB-1 k-steps ahead (54 % RB == 0)
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    int* cnt = reinterpret_cast<int*>(lds + CNT_OFF);
     const int t = threadIdx.x;
     const int l = t & 63, w = t >> 6, m = l & 31, h = l >> 5;
-    // Waves in their prologue / restaging / epilogue issue VALU, LDS and memory instructions; co-resident waves in
-    // their k-loop always have an MFMA pending and, being older, win the issue arbitration every cycle: measured with
-    // the timeline twin, prologue + epilogue took 7-10x their stand-alone time (26 % of a wave's life).  Priority
-    // outranks age: run the non-MFMA phases at priority 3 and the k-loop at 0 (an MFMA needs one issue slot per 64
-    // cycles, so the k-loop waves lose nothing).
+    // Non-MFMA phases (prologue, epilogue) run at priority 3: co-resident waves in their k-loop always have an MFMA
+    // pending and, being older, would otherwise win the issue arbitration every cycle.
     __builtin_amdgcn_s_setprio(3);
     long long* dbgw = nullptr;
     if constexpr (DBG) {
@@ -85,6 +113,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3d_mfma_kernel(const
         }
     }
     U3D_DBG_STAMP(3);
+    if (t < 16) cnt[t] = 0;
+    __syncthreads();  // the only rendezvous of the kernel
 
     // ---- block -> (tile, cout block) with XCD-contiguous ordering
     const int logical = u3d_xcd_remap(blockIdx.x, gridDim.x);
@@ -131,16 +161,17 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3d_mfma_kernel(const
     // A-fragment base: lane (m,h) -> voxel (zl = w, yl = (m>>3) [+4 for mt=1], xl = m&7), channels 4h..4h+3
     const int abase = w * PS + (m >> 3) * RS + (m & 7) * CS + 4 * h;
 
-    // B stream: packed f32x4 index ((g*ntot + ntile)*64 + lane) for the global step g = chunk*54 + step
+    // B stream: packed f32x4 index ((g*ntot + ntile)*64 + lane) for the global step g = chunk*54 + step; the image
+    // carries PACK_PAD zero steps past the end, so the (RB-1)-steps-ahead fetch needs no clamp.  vmcnt retires in
+    // order: a B fragment can only be consumed once every OLDER load has landed, including a halo prefetch load
+    // (HBM latency), hence the depth: RB-1 steps x 512*NT MFMA cycles must cover an HBM miss.
     const f32x4* wq = reinterpret_cast<const f32x4*>(p.wp) + (size_t)cb * NT * 64 + l;
     const int wstep = p.ntot * 64;
-    const int glast = p.nchunks * NSTEP - 1;
-    f32x4 bq[3][NT];
+    f32x4 bq[RB][NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        bq[0][nt] = wq[nt * 64];
-        bq[1][nt] = wq[(size_t)wstep + nt * 64];
-    }
+    for (int k = 0; k < RB - 1; ++k)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bq[k][nt] = wq[(size_t)k * wstep + nt * 64];
 
     // per-chunk source selection of this thread's channel quad
     struct ChunkSrc {
@@ -173,90 +204,120 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3d_mfma_kernel(const
         const int idx = ok ? (c.from0 ? gv0[it] : gv1[it]) : 0;
         return *reinterpret_cast<const f32x4*>(c.base + (size_t)idx * c.Cs);
     };
-    auto halo_store = [&](const ChunkSrc& c, int it, f32x4 raw) {
+    auto halo_store = [&](float* buf, const ChunkSrc& c, int it, f32x4 raw) {
         const bool ok = c.cok && gv0[it] >= 0;
         f32x4 val = raw * c.ga + c.gb;
 #pragma unroll
         for (int e = 0; e < 4; ++e) val[e] = ok ? val[e] : 0.f;  // padding stays exactly 0
-        *reinterpret_cast<f32x4*>(&lds[ldsoff[it]]) = val;
+        *reinterpret_cast<f32x4*>(&buf[ldsoff[it]]) = val;
+    };
+    // scalar-load staging of one chunk (channel counts that are not multiples of 4)
+    auto stage_scalar = [&](float* buf, int ch) {
+        const int cq = ch * CC + 4 * q;
+        f32x4 ga, gb;
+        u3d_load_affine(p.src.affine, n, Ctot, cq, false, ga, gb);
+#pragma unroll 1
+        for (int it = 0; it < NIT; ++it) {
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (gv0[it] >= 0) val = u3d_load_quad(p.src, gv0[it], gv1[it], cq, false) * ga + gb;
+            *reinterpret_cast<f32x4*>(&buf[ldsoff[it]]) = val;
+        }
     };
 
-    // ---- prologue: stage chunk 0
+    // ---- prologue: stage chunk 0 into buffer 0
     if constexpr (VEC) {
         const ChunkSrc c0 = chunk_src(0, true);
         f32x4 v[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) v[it] = halo_load(c0, it);
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) halo_store(c0, it, v[it]);
+        for (int it = 0; it < NIT; ++it) halo_store(lds, c0, it, v[it]);
+    } else {
+        stage_scalar(lds, 0);
     }
+    u3d_flag_signal(&cnt[0], l);
 
     for (int ch = 0; ch < p.nchunks; ++ch) {
         const bool has_next = ch + 1 < p.nchunks;
+        const int b = ch & 1;
+        const float* cur = lds + b * TILE_FLOATS;
+        float* nxt = lds + (b ^ 1) * TILE_FLOATS;
         ChunkSrc cn;
         f32x4 v[NIT];
-        if constexpr (VEC) {
-            cn = chunk_src(ch + 1, has_next);
-        } else {
-            // scalar-load path (channel counts that are not multiples of 4): synchronous staging
-            const int cq = ch * CC + 4 * q;
-            f32x4 ga, gb;
-            u3d_load_affine(p.src.affine, n, Ctot, cq, false, ga, gb);
-#pragma unroll 1
-            for (int it = 0; it < NIT; ++it) {
-                f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                if (gv0[it] >= 0) val = u3d_load_quad(p.src, gv0[it], gv1[it], cq, false) * ga + gb;
-                *reinterpret_cast<f32x4*>(&lds[ldsoff[it]]) = val;
-            }
-        }
-        __syncthreads();
+        if constexpr (VEC) cn = chunk_src(ch + 1, has_next);
+        u3d_flag_wait(&cnt[b], 4 * (ch / 2 + 1));  // all four waves have staged chunk ch
         __builtin_amdgcn_s_setprio(0);
         if (ch < 8) U3D_DBG_STAMP(8 + 2 * ch);
 
-        // ---- 54 k-steps (27 taps x 2 channel-octets): 8*NT MFMAs each, pinned with sched_barrier; the compiler
+        // ---- 54 k-steps (27 taps x 2 channel-octets), 8*NT MFMAs each, in two halves so that the non-MFMA
+        //      instructions in front of each half issue while the previous MFMA still occupies the pipe; the compiler
         //      inserts the matching counted vmcnt/lgkmcnt waits (the loop is fully unrolled).
         f32x4 aq[2][2];
-        aq[0][0] = *reinterpret_cast<const f32x4*>(&lds[abase]);
-        aq[0][1] = *reinterpret_cast<const f32x4*>(&lds[abase + 4 * RS]);
-        const int g0 = ch * NSTEP;
+        aq[0][0] = *reinterpret_cast<const f32x4*>(&cur[abase]);
+        aq[0][1] = *reinterpret_cast<const f32x4*>(&cur[abase + 4 * RS]);
+        const f32x4* wch = wq + (size_t)(ch * NSTEP + RB - 1) * wstep;
 #pragma unroll
         for (int st = 0; st < NSTEP; ++st) {
-            if constexpr (VEC) {
-                if (st % PF_EVERY == 0 && st / PF_EVERY < NIT) v[st / PF_EVERY] = halo_load(cn, st / PF_EVERY);
+            if constexpr (VEC && !(ABL & 1)) {
+                if (st % 2 == 0 && st / 2 < NIT) v[st / 2] = halo_load(cn, st / 2);
             }
-            {
-                const int g2 = min(g0 + st + 2, glast);
-                const f32x4* wsrc = wq + (size_t)g2 * wstep;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bq[(st + 2) % 3][nt] = wsrc[nt * 64];
-            }
-            if (st + 1 < NSTEP) {
-                const int tap = (st + 1) >> 1, s1_ = (st + 1) & 1;
-                const int aoff = (tap / 9) * PS + ((tap / 3) % 3) * RS + (tap % 3) * CS + 8 * s1_;
-                aq[(st + 1) & 1][0] = *reinterpret_cast<const f32x4*>(&lds[abase + aoff]);
-                aq[(st + 1) & 1][1] = *reinterpret_cast<const f32x4*>(&lds[abase + 4 * RS + aoff]);
+            for (int nt = 0; nt < NT; ++nt) {
+                if constexpr (ABL & 2) {
+                    bq[(st + RB - 1) % RB][nt] = bq[st % RB][nt];
+                    asm volatile("" : "+v"(bq[(st + RB - 1) % RB][nt]));
+                } else {
+                    bq[(st + RB - 1) % RB][nt] = wch[(size_t)st * wstep + nt * 64];
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 2; ++j) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st & 1][0][j], bq[st % 3][nt][j], acc[0][nt], 0, 0, 0);
-                    acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st & 1][1][j], bq[st % 3][nt][j], acc[1][nt], 0, 0, 0);
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st & 1][0][j], bq[st % RB][nt][j], acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st & 1][1][j], bq[st % RB][nt][j], acc[1][nt], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if ((ABL & 4) && st + 1 < NSTEP) {
+                aq[(st + 1) & 1][0] = aq[st & 1][0];
+                aq[(st + 1) & 1][1] = aq[st & 1][1];
+                asm volatile("" : "+v"(aq[(st + 1) & 1][0]), "+v"(aq[(st + 1) & 1][1]));
+            } else if (st + 1 < NSTEP) {
+                const int tap = (st + 1) >> 1, s1_ = (st + 1) & 1;
+                const int aoff = (tap / 9) * PS + ((tap / 3) % 3) * RS + (tap % 3) * CS + 8 * s1_;
+                aq[(st + 1) & 1][0] = *reinterpret_cast<const f32x4*>(&cur[abase + aoff]);
+                aq[(st + 1) & 1][1] = *reinterpret_cast<const f32x4*>(&cur[abase + 4 * RS + aoff]);
+            }
+            if (st >= ST0 && st < ST0 + NIT && has_next && !(ABL & 1)) {
+                // the other buffer is free once all four waves have finished the k-loop of chunk ch-1
+                if (st == ST0) u3d_flag_wait(&cnt[2 + (b ^ 1)], 4 * ((ch + 1) / 2));
+                if constexpr (VEC) {
+                    halo_store(nxt, cn, st - ST0, v[st - ST0]);
+                } else {
+                    if (st == ST0) stage_scalar(nxt, ch + 1);
+                }
+                if (st == ST0 + NIT - 1) u3d_flag_signal(&cnt[b ^ 1], l);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 2; j < 4; ++j) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st & 1][0][j], bq[st % RB][nt][j], acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st & 1][1][j], bq[st % RB][nt][j], acc[1][nt], 0, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (ch < 8) U3D_DBG_STAMP(9 + 2 * ch);
-        __builtin_amdgcn_s_setprio(3);
-        __syncthreads();
-        if constexpr (VEC) {
-            if (has_next) {
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) halo_store(cn, it, v[it]);
-            }
+        if constexpr ((ABL & 1) != 0) {
+            if (has_next) u3d_flag_signal(&cnt[b ^ 1], l);
         }
+        u3d_flag_signal(&cnt[2 + b], l);  // this wave no longer reads buffer b
     }
+    __builtin_amdgcn_s_setprio(3);
 
     // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5);
     //      M-tile row -> (y = row>>3, x = row&7)  =>  reg r of lane (m,h): y = r>>2, x = (r&3) + 4h.
@@ -264,53 +325,73 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3d_mfma_kernel(const
     const int z = z0 + w;
     const bool want_stats = p.out_stats != nullptr;
     const bool want_g = p.gstats != nullptr;
-    float* red = lds + 4 * 2048;  // [4 waves][NT][32][2] partial statistics, behind the 4 transposition regions
+    float* red = lds + RED_OFF;  // [4 waves][NT][32][2] partial statistics
     if (p.ovec) {
-        // ---- wide epilogue: each wave transposes its 64-voxel x 32-channel tile through a private 8 KiB LDS region
-        //      so that a lane owns 4 consecutive channels of one voxel: 16-byte stores (8 voxels x 128 B = 1 KiB
-        //      contiguous per instruction when Cout == 32) and 16-byte loads of x for the GroupNorm-backward sums,
-        //      instead of 32 four-byte stores (+32 four-byte loads) per N-tile.
-        float* tr = lds + w * 2048;        // [voxel = yl*8 + xl][32]
-        const int cq = l & 7, vl = l >> 3;  // read phase: channel quad, x within the row
+        // ---- wide epilogue.  In the MFMA C layout lane (m, h) holds channel m of 16 voxels; the 4 rows r&3 of a
+        //      register quad are the voxels x = (r&3) + 4h of one y.  A 4x4 transpose inside every lane quad (two DPP
+        //      butterfly stages, no LDS) leaves lane j of quad k with the 4 consecutive channels 4k..4k+3 of voxel
+        //      x = j + 4h: 16-byte stores (8 voxels x 128 B = 1 KiB contiguous per instruction when Cout == 32) and
+        //      16-byte loads of x for the GroupNorm-backward sums instead of 4-byte ones.
+        const int cq = (l >> 2) & 7, vl = (l & 3) + 4 * h;  // after the transpose: channel quad, x within the row
+        const bool odd = (l & 1) != 0, hi = (l & 2) != 0;
+        auto xlane = [](float v, auto ctrl) {
+            return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, true));
+        };
+        using X1 = std::integral_constant<int, 0xB1>;  // quad_perm [1,0,3,2]: value of lane ^ 1
+        using X2 = std::integral_constant<int, 0x4E>;  // quad_perm [2,3,0,1]: value of lane ^ 2
         f32x4 q1[NT], q2[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             q1[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
             q2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 tq[8];  // row st = 4*mt + bi: the lane's channel quad at voxel (y0 + st, x0 + vl)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float val = acc[mt][nt][r];
-                    if (p.relu) val = fmaxf(val, 0.f);
-                    tr[((4 * mt + (r >> 2)) * 8 + (r & 3) + 4 * h) * 32 + m] = val;
+                for (int bi = 0; bi < 4; ++bi) {
+                    float a0 = acc[mt][nt][4 * bi + 0], a1 = acc[mt][nt][4 * bi + 1];
+                    float a2 = acc[mt][nt][4 * bi + 2], a3 = acc[mt][nt][4 * bi + 3];
+                    if (p.relu) {
+                        a0 = fmaxf(a0, 0.f);
+                        a1 = fmaxf(a1, 0.f);
+                        a2 = fmaxf(a2, 0.f);
+                        a3 = fmaxf(a3, 0.f);
+                    }
+                    const float t0 = xlane(a1, X1{}), t1 = xlane(a0, X1{}), t2 = xlane(a3, X1{}), t3 = xlane(a2, X1{});
+                    const float c0 = odd ? t0 : a0, c1 = odd ? a1 : t1, c2 = odd ? t2 : a2, c3 = odd ? a3 : t3;
+                    const float u0 = xlane(c2, X2{}), u2 = xlane(c0, X2{}), u1 = xlane(c3, X2{}), u3 = xlane(c1, X2{});
+                    tq[4 * mt + bi] = f32x4{hi ? u0 : c0, hi ? u1 : c1, hi ? c2 : u2, hi ? c3 : u3};
                 }
             const int co = (cb * NT + nt) * 32 + 4 * cq;
             const bool cok = co < p.Cout;
             const int x = x0 + vl;
-            f32x4 xv[8];
-            if (want_g) {
-                const bool xfrom0 = co < p.gx.C0 || !cok;
-                const float* xb = !cok ? p.gx.p0 : (xfrom0 ? p.gx.p0 + co : p.gx.p1 + (co - p.gx.C0));
-                const int xcs = xfrom0 ? p.gx.C0 : p.gx.C1;
+            const bool xfrom0 = co < p.gx.C0 || !cok;
+            const float* xb = !cok ? p.gx.p0 : (xfrom0 ? p.gx.p0 + co : p.gx.p1 + (co - p.gx.C0));
+            const int xcs = xfrom0 ? p.gx.C0 : p.gx.C1;
 #pragma unroll
-                for (int st = 0; st < 8; ++st) {
-                    int v0, v1;  // clamped coordinates: always a valid address, masked below
-                    u3d_vox_index(p.gx, n, min(z, D - 1), min(y0 + st, H - 1), min(x, W - 1), D, H, W, v0, v1);
-                    xv[st] = *reinterpret_cast<const f32x4*>(xb + (size_t)(xfrom0 ? v0 : v1) * xcs);
+            for (int half = 0; half < 2; ++half) {  // two batches of 4 rows bound the live registers
+                f32x4 xv[4];
+                if (want_g) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        int v0, v1;  // clamped coordinates: always a valid address, masked below
+                        u3d_vox_index(p.gx, n, min(z, D - 1), min(y0 + 4 * half + k, H - 1), min(x, W - 1), D, H, W, v0, v1);
+                        xv[k] = *reinterpret_cast<const f32x4*>(xb + (size_t)(xfrom0 ? v0 : v1) * xcs);
+                    }
                 }
-            }
 #pragma unroll
-            for (int st = 0; st < 8; ++st) {
-                const int y = y0 + st;
-                const bool ok = cok && z < D && y < H && x < W;
-                f32x4 val = *reinterpret_cast<const f32x4*>(&tr[(st * 8 + vl) * 32 + 4 * cq]);
-                const size_t vidx = (size_t)((n * D + z) * H + y) * W + x;
-                if (ok) *reinterpret_cast<f32x4*>(p.out + vidx * p.Cout + co) = val;
+                for (int k = 0; k < 4; ++k) {
+                    const int st = 4 * half + k;
+                    const int y = y0 + st;
+                    const bool ok = cok && z < D && y < H && x < W;
+                    f32x4 val = tq[st];
+                    const size_t vidx = (size_t)((n * D + z) * H + y) * W + x;
+                    if (ok) *reinterpret_cast<f32x4*>(p.out + vidx * p.Cout + co) = val;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) val[e] = ok ? val[e] : 0.f;
-                q1[nt] += val;
-                q2[nt] += want_g ? val * xv[st] : val * val;
+                    for (int e = 0; e < 4; ++e) val[e] = ok ? val[e] : 0.f;
+                    q1[nt] += val;
+                    q2[nt] += want_g ? val * xv[k] : val * val;
+                }
             }
         }
         if (want_stats || want_g) {
@@ -320,11 +401,11 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3d_mfma_kernel(const
                 for (int e = 0; e < 4; ++e) {
                     float a = q1[nt][e], b = q2[nt][e];
 #pragma unroll
-                    for (int mask = 8; mask < 64; mask <<= 1) {
+                    for (int mask : {1, 2, 32}) {  // lanes of one channel quad: x = (l&3) + 4*(l>>5)
                         a += __shfl_xor(a, mask);
                         b += __shfl_xor(b, mask);
                     }
-                    if (l < 8) {
+                    if ((l & 35) == 0) {
                         red[((w * NT + nt) * 32 + 4 * cq + e) * 2 + 0] = a;
                         red[((w * NT + nt) * 32 + 4 * cq + e) * 2 + 1] = b;
                     }
@@ -396,21 +477,28 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3d_mfma_kernel(const
         }
     }
     if (want_stats || want_g) {
-        // over the 4 waves through LDS, then one f64 atomic per (n, channel) and block
-        __syncthreads();
-        if (t < NT * 32) {
-            const int nt = t >> 5, mm = t & 31;
-            float a = 0.f, b = 0.f;
+        // over the 4 waves through LDS: the LAST wave to arrive adds the four partials (fixed order) and issues one
+        // f64 atomic per (n, channel) and block — nobody waits
+        int arrived = 0;
+        asm volatile("" ::: "memory");
+        if (l == 0) arrived = __hip_atomic_fetch_add(&cnt[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        arrived = __builtin_amdgcn_readfirstlane(arrived);
+        asm volatile("" ::: "memory");
+        if (arrived == 3) {
+            for (int k = l; k < NT * 32; k += 64) {
+                const int nt = k >> 5, mm = k & 31;
+                float a = 0.f, b = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < 4; ++ww) {
-                a += red[((ww * NT + nt) * 32 + mm) * 2 + 0];
-                b += red[((ww * NT + nt) * 32 + mm) * 2 + 1];
-            }
-            const int co = (cb * NT + nt) * 32 + mm;
-            if (co < p.Cout) {
-                double* dst = (want_stats ? p.out_stats : p.gstats) + ((size_t)n * p.Cout + co) * 2;
-                u3d_atomic_add_f64(dst, (double)a);
-                u3d_atomic_add_f64(dst + 1, (double)b);
+                for (int ww = 0; ww < 4; ++ww) {
+                    a += red[((ww * NT + nt) * 32 + mm) * 2 + 0];
+                    b += red[((ww * NT + nt) * 32 + mm) * 2 + 1];
+                }
+                const int co = (cb * NT + nt) * 32 + mm;
+                if (co < p.Cout) {
+                    double* dst = (want_stats ? p.out_stats : p.gstats) + ((size_t)n * p.Cout + co) * 2;
+                    u3d_atomic_add_f64(dst, (double)a);
+                    u3d_atomic_add_f64(dst + 1, (double)b);
+                }
             }
         }
     }
@@ -748,7 +836,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //   k-channel  c  = ch*16 + 8*(st&1) + 4*(lane>>5) + j,  tap = st>>1,  n-channel = ntg*32 + (lane&31)
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin,
                                     int mode, int nchunks, int ntot) {
-    const long long total = (long long)nchunks * cv::NSTEP * ntot * 256;
+    const long long total = ((long long)nchunks * cv::NSTEP + cv::PACK_PAD) * ntot * 256;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         const int j = (int)(idx & 3);
@@ -762,7 +850,9 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
         const int tap = st >> 1;
         const int nc = ntg * 32 + (lane & 31);
         float v = 0.f;
-        if (mode == 0) {
+        if (ch >= nchunks) {
+            // the trailing zero steps
+        } else if (mode == 0) {
             if (kc < Cin && nc < Cout) v = w[((size_t)nc * Cin + kc) * 27 + tap];
         } else {
             // dgrad: contraction over original cout (kc), output = original cin (nc), flipped taps
@@ -845,7 +935,7 @@ extern "C" int u3d_set_tuning(int key, int value) {
 
 extern "C" size_t u3d_packed_weight_floats(int Cin, int Cout, int mode) {
     const int K = mode == 0 ? Cin : Cout, Nn = mode == 0 ? Cout : Cin;
-    return (size_t)cdiv(K, 16) * cv::NSTEP * cdiv(Nn, 32) * 256;
+    return ((size_t)cdiv(K, 16) * cv::NSTEP + cv::PACK_PAD) * cdiv(Nn, 32) * 256;  // + zero steps (prefetch overrun)
 }
 
 extern "C" int u3d_pack_weights(int device, u3d_stream_t stream, const float* w, int Cout, int Cin, int mode,
@@ -854,11 +944,43 @@ extern "C" int u3d_pack_weights(int device, u3d_stream_t stream, const float* w,
     U3D_REQUIRE(w && packed && Cout > 0 && Cin > 0 && (mode == 0 || mode == 1), "u3d_pack_weights: bad argument");
     const int K = mode == 0 ? Cin : Cout, Nn = mode == 0 ? Cout : Cin;
     const int nchunks = cdiv(K, 16), ntot = cdiv(Nn, 32);
-    const long long total = (long long)nchunks * cv::NSTEP * ntot * 256;
+    const long long total = ((long long)nchunks * cv::NSTEP + cv::PACK_PAD) * ntot * 256;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin,
                        mode, nchunks, ntot);
     U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int NT>
+static int conv_set_lds_nt() {
+    const int bytes = cv::LDS_FLOATS * sizeof(float);
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_kernel<NT, true, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_kernel<NT, false, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_kernel<NT, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (NT == 1) {
+        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_kernel<1, true, true, 1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_kernel<1, true, true, 2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_kernel<1, true, true, 3>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_kernel<1, true, true, 7>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    }
+    return 0;
+}
+
+static int conv_set_lds_once(int device) {
+    static bool done[64] = {false};
+    if (device >= 0 && device < 64 && done[device]) return 0;
+    if (int e = conv_set_lds_nt<1>()) return e;
+    if (int e = conv_set_lds_nt<2>()) return e;
+    if (int e = conv_set_lds_nt<3>()) return e;
+    if (device >= 0 && device < 64) done[device] = true;
     return 0;
 }
 
@@ -907,13 +1029,22 @@ extern "C" int u3d_conv3d(int device, u3d_stream_t stream, const u3d_src_t* src,
     const long long nblk = ntiles * p.ncb;
     U3D_REQUIRE(nblk < (1ll << 31), "u3d_conv3d: grid too large");
     const size_t shmem = cv::LDS_FLOATS * sizeof(float);
+    if (int e = conv_set_lds_once(device)) return e;
     const bool vec = p.vec != 0;
     const dim3 grid((unsigned)nblk), block(256);
     hipStream_t st = (hipStream_t)stream;
     p.dbg = (vec && g_u3d_prof_buf && (size_t)nblk * 4 <= g_u3d_prof_records) ? g_u3d_prof_buf : nullptr;
 #define U3D_CONV_LAUNCH(NT_)                                                                     \
     do {                                                                                         \
-        if (p.dbg)                                                                               \
+        if (p.dbg && NT_ == 1 && g_u3d_tune[2] == 1)                                             \
+            hipLaunchKernelGGL((conv3d_mfma_kernel<1, true, true, 1>), grid, block, shmem, st, p); \
+        else if (p.dbg && NT_ == 1 && g_u3d_tune[2] == 2)                                        \
+            hipLaunchKernelGGL((conv3d_mfma_kernel<1, true, true, 2>), grid, block, shmem, st, p); \
+        else if (p.dbg && NT_ == 1 && g_u3d_tune[2] == 3)                                        \
+            hipLaunchKernelGGL((conv3d_mfma_kernel<1, true, true, 3>), grid, block, shmem, st, p); \
+        else if (p.dbg && NT_ == 1 && g_u3d_tune[2] == 7)                                        \
+            hipLaunchKernelGGL((conv3d_mfma_kernel<1, true, true, 7>), grid, block, shmem, st, p); \
+        else if (p.dbg)                                                                          \
             hipLaunchKernelGGL((conv3d_mfma_kernel<NT_, true, true>), grid, block, shmem, st, p); \
         else if (vec)                                                                            \
             hipLaunchKernelGGL((conv3d_mfma_kernel<NT_, true>), grid, block, shmem, st, p);      \

@@ -22,7 +22,7 @@ dev = U.DEV
 N, D0, H0, W0 = 2, 64, 128, 128
 
 
-def run(name, dgrad, forced_nt=0, dims=None):
+def run(name, dgrad, forced_nt=0, dims=None, abl=0):
     (_, C0, C1, Cout, lvl) = next(x for x in LAYERS if x[0] == name)
     global N
     D, H, W = D0 >> lvl, H0 >> lvl, W0 >> lvl
@@ -59,12 +59,14 @@ def run(name, dgrad, forced_nt=0, dims=None):
     nrec = 4 * 65536
     buf = torch.zeros((nrec, 24), dtype=torch.int64, device=dev)
     nat.call("u3d_set_profile_buffer", _p(buf), buf.numel() * 8)
+    nat.call("u3d_set_tuning", 2, abl)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     fn()
     e1.record()
     torch.cuda.synchronize()
     nat.call("u3d_set_profile_buffer", None, 0)
+    nat.call("u3d_set_tuning", 2, 0)
     nat.call("u3d_set_tuning", 0, 0)
     ms = e0.elapsed_time(e1)
     r = buf.cpu()
@@ -74,7 +76,7 @@ def run(name, dgrad, forced_nt=0, dims=None):
     entry, staged, epi, exit_ = r[:, 3], r[:, 8], r[:, 5], r[:, 6]
     span_all = (exit_.max() - entry.min()).item()
     flops = 54.0 * kin * kout * N * D * H * W
-    print(f"== {name}{':dgrad' if dgrad else ''} {kin}->{kout} @{D}x{H}x{W}: {ms:.3f} ms, {flops / ms / 1e9:.1f} TF; {nw} waves, "
+    print(f"== {name}{':dgrad' if dgrad else ''}{' abl=%d' % abl if abl else ''} {kin}->{kout} @{D}x{H}x{W}: {ms:.3f} ms, {flops / ms / 1e9:.1f} TF; {nw} waves, "
           f"{nch} chunks; counter span {span_all} ticks = {span_all / ms / 1e6:.3f} GHz-equivalent")
     # MFMA cycles per wave: total MFMAs (incl. padded lanes) = nchunks*54*8*NT ; infer NT from grid
     ntot = (kout + 31) // 32
@@ -128,10 +130,12 @@ if __name__ == "__main__":
         parts = spec.split(":")
         name = parts[0]
         dgrad = "dgrad" in parts[1:]
-        nt, dims = 0, None
+        nt, dims, abl = 0, None, 0
         for q in parts[1:]:
             if q.startswith("nt"):
                 nt = int(q[2:])
             if q.startswith("dims"):
                 dims = tuple(int(v) for v in q[4:].split("x"))
-        run(name, dgrad, nt, dims)
+            if q.startswith("abl"):
+                abl = int(q[3:])
+        run(name, dgrad, nt, dims, abl)
