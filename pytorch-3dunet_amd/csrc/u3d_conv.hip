@@ -544,7 +544,13 @@ struct WgradParams {
 // buffer b^1 later in the same loop with the GroupNorm affine applied — one barrier per tile, nothing else exposed.
 // The nearest-upsample index maps of a virtual source are copied to LDS once per block so that the prefetch
 // address arithmetic never waits on a dependent global load inside the MFMA stream.
-template <bool VEC>
+//
+// f32 MFMA executes on the SIMD's FMA lanes: every VALU instruction any co-resident wave issues costs ~5 cycles of
+// MFMA time (tools/mfma_mix.hip; SALU, s_waitcnt and LDS reads are free).  REG (every tile fully inside the volume,
+// plain or exact-2x source) therefore replaces the per-item index arithmetic (~40 VALU per staged item and tile) by
+// per-thread constants computed once per block: index = tile base + rel[item], validity = one bit of a mask built
+// from six per-face item masks and uniform tile-position tests.
+template <bool VEC, bool REG = false>
 __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams p) {
     using namespace wg;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -585,8 +591,55 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
     const int Cs = (from0 || !cok) ? p.src.C0 : p.src.C1;
     const float* dzbase = p.dz + (dcok ? co : 0);
 
+    // REG: per-thread constants of the 7 + 2 staged items
+    constexpr int NPFC = NIT_G + NIT_DZ;
+    int rel[NPFC], loff[NPFC];
+    unsigned fz0 = 0, fz1 = 0, fy0 = 0, fy1 = 0, fx0 = 0, fx1 = 0, fdead = 0;
+    if constexpr (REG) {
+#pragma unroll
+        for (int it = 0; it < NIT_G; ++it) {
+            const int vox = tv + 64 * it;
+            const int hz = vox / (HY * HX);
+            const int rem = vox - hz * (HY * HX);
+            const int hy = rem / HX;
+            const int hx = rem - hy * HX;
+            const bool in = vox < HZ * HY * HX;
+            // exact 2x: tile origins are even, so ((z0 - 1 + hz) >> 1) = z0/2 + ((hz - 1) >> 1)
+            rel[it] = from0 ? ((hz - 1) * H + (hy - 1)) * W + (hx - 1)
+                            : (((hz - 1) >> 1) * p.src.H1 + ((hy - 1) >> 1)) * p.src.W1 + ((hx - 1) >> 1);
+            loff[it] = in ? hz * PSg + hy * RSg + hx * CSg + 4 * q : DUMMY_OFF;
+            fz0 |= (in && hz == 0 ? 1u : 0u) << it;
+            fz1 |= (in && hz == HZ - 1 ? 1u : 0u) << it;
+            fy0 |= (in && hy == 0 ? 1u : 0u) << it;
+            fy1 |= (in && hy == HY - 1 ? 1u : 0u) << it;
+            fx0 |= (in && hx == 0 ? 1u : 0u) << it;
+            fx1 |= (in && hx == HX - 1 ? 1u : 0u) << it;
+            fdead |= (in && cok ? 0u : 1u) << it;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT_DZ; ++it) {
+            const int vox = tv + 64 * it;
+            rel[NIT_G + it] = ((vox >> 6) * H + ((vox >> 3) & 7)) * W + (vox & 7);
+            loff[NIT_G + it] = G_FLOATS + vox * 32 + 4 * q;
+        }
+        fdead |= (dcok ? 0u : 3u) << NIT_G;
+    }
+    // invalid-item mask of a (fully inside) tile: uniform face tests select the per-thread face masks
+    auto tile_invalid = [&](int z0, int y0, int x0) {
+        unsigned inv = fdead;
+        inv |= z0 == 0 ? fz0 : 0u;
+        inv |= z0 + TZ == D ? fz1 : 0u;
+        inv |= y0 == 0 ? fy0 : 0u;
+        inv |= y0 + TY == H ? fy1 : 0u;
+        inv |= x0 == 0 ? fx0 : 0u;
+        inv |= x0 + TX == W ? fx1 : 0u;
+        return inv;
+    };
+
     struct TileC {
         int n, z0, y0, x0;
+        int base, dzb;  // REG: voxel index of the tile origin in the g source of this thread / in dz
+        unsigned inv;   // REG: invalid-item bits
     };
     auto tile_coords = [&](int tile) {
         TileC c;
@@ -596,6 +649,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
         tile /= p.ty;
         c.z0 = (tile % p.tz) * TZ;
         c.n = tile / p.tz;
+        c.base = c.dzb = 0;
+        c.inv = 0;
+        if constexpr (REG) {
+            c.dzb = ((c.n * D + c.z0) * H + c.y0) * W + c.x0;
+            const int b1 = ((c.n * p.src.D1 + (c.z0 >> 1)) * p.src.H1 + (c.y0 >> 1)) * p.src.W1 + (c.x0 >> 1);
+            c.base = from0 ? c.dzb : b1;
+            c.inv = tile_invalid(c.z0, c.y0, c.x0);
+        }
         return c;
     };
     // g halo item `it` of a tile: LDS offset, validity and (clamped, always valid) global voxel index
@@ -636,6 +697,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
     auto pf_load = [&](const TileC& c, int k) {  // k < NIT_G: g item, else dz item
         bool ok;
         int idx, off;
+        if constexpr (REG) {
+            ok = ((c.inv >> k) & 1u) == 0;
+            if (k < NIT_G) return *reinterpret_cast<const f32x4*>(gbase + (size_t)(ok ? c.base + rel[k] : 0) * Cs);
+            return *reinterpret_cast<const f32x4*>(dzbase + (size_t)(ok ? c.dzb + rel[k] : 0) * p.Cout);
+        }
         if (k < NIT_G) {
             g_item(c, k, off, ok, idx);
             return *reinterpret_cast<const f32x4*>(gbase + (size_t)idx * Cs);
@@ -646,6 +712,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
     auto pf_store = [&](float* buf, const TileC& c, int k, f32x4 raw, const f32x4& ga, const f32x4& gb) {
         bool ok;
         int idx, off;
+        if constexpr (REG) {
+            ok = ((c.inv >> k) & 1u) == 0;
+            f32x4 val = k < NIT_G ? raw * ga + gb : raw;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) val[e] = ok ? val[e] : 0.f;  // zero padding AFTER the affine
+            *reinterpret_cast<f32x4*>(&buf[loff[k]]) = val;
+            return;
+        }
         if (k < NIT_G) {
             g_item(c, k, off, ok, idx);
             f32x4 val = raw * ga + gb;
@@ -1098,6 +1172,8 @@ extern "C" size_t u3d_wgrad_workspace_floats(int N, int D, int H, int W, int Cin
 static int wgrad_set_lds_once(int device) {
     static bool done[64] = {false};
     if (device >= 0 && device < 64 && done[device]) return 0;
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wgrad_kernel<true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (wg::LDS_FLOATS + wg::MAX_MAP_INTS) * sizeof(float)));
     U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wgrad_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (wg::LDS_FLOATS + wg::MAX_MAP_INTS) * sizeof(float)));
     U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wgrad_kernel<false>),
@@ -1128,7 +1204,12 @@ extern "C" int u3d_conv3d_wgrad(int device, u3d_stream_t stream, const u3d_src_t
     const int nblk = p.S * p.nchunks * p.nkb;
     U3D_REQUIRE(D + H + W <= wg::MAX_MAP_INTS, "u3d_conv3d_wgrad: D+H+W must be <= %d", wg::MAX_MAP_INTS);
     const size_t shmem = (wg::LDS_FLOATS + (size_t)(D + H + W)) * sizeof(float);
-    if (p.vec && p.dzvec)
+    // every tile fully inside the volume and no table look-ups -> constant-offset staging (REG)
+    const bool reg = D % wg::TZ == 0 && H % wg::TY == 0 && W % wg::TX == 0 &&
+                     (src->C1 == 0 || (D == 2 * src->D1 && H == 2 * src->H1 && W == 2 * src->W1));
+    if (p.vec && p.dzvec && reg)
+        hipLaunchKernelGGL((conv3d_wgrad_kernel<true, true>), dim3(nblk), dim3(wg::NTHR), shmem, (hipStream_t)stream, p);
+    else if (p.vec && p.dzvec)
         hipLaunchKernelGGL(conv3d_wgrad_kernel<true>, dim3(nblk), dim3(wg::NTHR), shmem, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(conv3d_wgrad_kernel<false>, dim3(nblk), dim3(wg::NTHR), shmem, (hipStream_t)stream, p);
