@@ -41,6 +41,18 @@ __device__ __forceinline__ void u3d_vox_index(const u3d_src_t& s, int n, int z, 
     }
 }
 
+// same, with the index tables bypassed for an exact 2x nearest upsampling (D == 2*D1, H == 2*H1, W == 2*W1), where
+// PyTorch's float32 formula min(floor(dst * 0.5f), in-1) is i >> 1 for every i: no dependent loads
+__device__ __forceinline__ void u3d_vox_index_x(const u3d_src_t& s, bool exact2x, int n, int z, int y, int x, int D, int H,
+                                                int W, int& v0, int& v1) {
+    v0 = ((n * D + z) * H + y) * W + x;
+    v1 = 0;
+    if (s.C1 > 0) {
+        const int z1 = exact2x ? z >> 1 : s.zmap[z], y1 = exact2x ? y >> 1 : s.ymap[y], x1 = exact2x ? x >> 1 : s.xmap[x];
+        v1 = ((n * s.D1 + z1) * s.H1 + y1) * s.W1 + x1;
+    }
+}
+
 __device__ __forceinline__ float u3d_load_elem(const u3d_src_t& s, int v0, int v1, int c) {
     if (c < s.C0) return s.p0[(size_t)v0 * s.C0 + c];
     if (c < s.C0 + s.C1) return s.p1[(size_t)v1 * s.C1 + (c - s.C0)];

@@ -19,6 +19,7 @@
 // run-time tuning knobs (u3d_set_tuning), for A/B measurements only — results never change:
 //   [0] forced N-tiles per block of u3d_conv3d (1,2,3; 0 = automatic)   [1] wgrad split override (0 = automatic)
 //   [2] ablation mask of the instrumented conv twin (timing experiments, wrong results)
+//   [3] 1 = never use the persistent fast variant of u3d_conv3d (A/B against the generic kernel)
 int g_u3d_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 namespace cv {
@@ -36,6 +37,7 @@ constexpr int NITEMS = HZ * HY * HX * (CC / 4);   // 2400 float4 items per chunk
 constexpr int NIT = (NITEMS + 255) / 256;         // 10
 constexpr int NSTEP = 27 * (CC / 8);              // 54 k-steps of 8 channels per chunk
 constexpr int ST0 = 30;                           // k-step of the first halo store into the other buffer
+constexpr int ISTORE = 5;                         // persistent variant: tap row (of 9) whose k-steps store the halo
 constexpr int PACK_PAD = 5;                       // zero k-steps appended to the packed weight image (B prefetch overrun)
 static_assert(2 * (NIT - 1) < ST0 - 8 && ST0 + NIT <= NSTEP, "prefetch schedule must fit the k-loop");
 }  // namespace cv
@@ -51,6 +53,8 @@ struct ConvParams {
     int nchunks, ncb, ntot;
     int tz, ty, tx;
     int relu, vec, has_gx, ovec;
+    int total;   // REG kernel: work items = tiles * ncb
+    int gx_x2;   // REG kernel: gx's low-res half is an exact 2x upsampling (index = i >> 1, no table)
     long long* dbg;  // optional per-wave timeline records (u3d_set_profile_buffer), 24 int64 per wave
 };
 
@@ -501,6 +505,428 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvParams p)
                 }
             }
         }
+    }
+    U3D_DBG_STAMP(6);
+}
+
+// =================================================================================================
+// The fast variant of the same convolution: PERSISTENT blocks and a VALU diet.
+//
+// f32 MFMA executes on the SIMD's FMA lanes: tools/mfma_mix.hip measures ~5 cycles of lost MFMA time per VALU
+// instruction that ANY co-resident wave issues (SALU, s_waitcnt and LDS reads are free).  With the timeline twin the
+// model "64 cycles per MFMA + 5 per VALU instruction" reproduces the measured pipe utilisation of the generic kernel
+// (87 % on the 6-chunk 96->32 layer, 80 % on the 2-chunk 32->32 layer, 69 % on the 1-chunk 16->32 layer): what is
+// lost is the prologue (index arithmetic of 10 staging items, ~800 VALU), the epilogue and the per-item arithmetic
+// of the staging, not memory latency.  This kernel therefore
+//   * is launched as 2 blocks per CU that walk the work items slot, slot + grid, ...: (tile, 16-channel chunk) is one
+//     flat sequence of chunks alternating between the two LDS buffers, the next tile's first chunk is staged under
+//     the current tile's last k-loop and the prologue is paid once per block instead of once per tile;
+//   * requires every tile to lie fully inside the volume (D % 4 == H % 8 == W % 8 == 0) and a plain or exact-2x
+//     virtual source, so that the global index of a staging item is (uniform tile base) + (per-thread constant) and
+//     its validity one bit of a mask assembled from six per-face item masks by uniform tests: ~7 VALU per item and
+//     chunk instead of ~45 per item and tile, and no masking at all on the 2/3 of the tiles that touch no face;
+//   * keeps the B stream on a scalar base pointer (no VALU in the 54 k-steps);
+//   * needs no LDS in the epilogue (DPP transposition), accumulates the GroupNorm statistics per wave in LDS
+//     (ds_add_f32) and flushes them with f64 atomics when the block's sample changes.
+// Everything else (flags instead of barriers, halo prefetch schedule, fragment layouts) is the generic kernel's.
+template <int NT, bool VIRT, bool DBG = false>
+__global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParams p) {
+    using namespace cv;
+    constexpr int RB = NT == 1 ? 6 : 3;  // B ring depth (54 % RB == 0, 6 % RB == 0)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int* cnt = reinterpret_cast<int*>(lds + CNT_OFF);
+    float* red = lds + RED_OFF;  // [2 sample parities][NT*32][2] block-level partial statistics
+    const int t = threadIdx.x;
+    const int l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), m = l & 31, h = l >> 5;
+    __builtin_amdgcn_s_setprio(3);
+    long long* dbgw = nullptr;
+    if constexpr (DBG) {
+        dbgw = p.dbg + ((size_t)blockIdx.x * 4 + w) * 24;
+        if (l == 0) {
+            dbgw[0] = blockIdx.x;
+            dbgw[1] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
+            dbgw[2] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+            dbgw[7] = p.nchunks;
+        }
+    }
+    U3D_DBG_STAMP(3);
+    if (t < 16) cnt[t] = 0;
+    for (int k = t; k < 4 * 3 * 32 * 2; k += 256) red[k] = 0.f;
+    __syncthreads();  // the only rendezvous of the kernel
+
+    const int D = p.D, H = p.H, W = p.W;
+    const int Ctot = p.src.C0 + p.src.C1;
+    const int G = gridDim.x;
+    const int D1 = p.src.D1, H1 = p.src.H1, W1 = p.src.W1;
+
+    // ---- work item -> (tile, cout block); slot s of the grid runs on XCD s % 8 (observed, speed only): within one
+    //      round of G items every XCD gets a contiguous run of logical ids, so neighbouring tiles share an L2
+    struct Item {
+        int cb, n, z0, y0, x0;
+        int base0, base1;  // voxel index of the halo origin (z0-1, y0-1, x0-1) in the full-res / low-res source
+        unsigned inv;      // per-thread bit mask of staging items that are zero padding (or dead)
+        bool border;       // uniform: the tile touches a face of the volume
+    };
+    const int q = t & 3, tv = t >> 2;
+    int rel0[NIT], rel1[VIRT ? NIT : 1], loff[NIT];
+    unsigned fz0 = 0, fz1 = 0, fy0 = 0, fy1 = 0, fx0 = 0, fx1 = 0, fdead = 0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int vox = tv + 64 * it;
+        const bool in = vox < HZ * HY * HX;
+        const int hz = vox / (HY * HX);
+        const int rem = vox - hz * (HY * HX);
+        const int hy = rem / HX;
+        const int hx = rem - hy * HX;
+        // dead tail items (the 10th round covers 2560 > 2400 items) read the halo origin and write the dummy slot
+        rel0[it] = in ? (hz * H + hy) * W + hx : 0;
+        // exact 2x, tile origins even: ((z0 - 1 + hz) >> 1) = z0/2 + ((hz - 1) >> 1), relative to the low-res origin
+        if constexpr (VIRT) rel1[it] = in ? (((hz - 1) >> 1) * H1 + ((hy - 1) >> 1)) * W1 + ((hx - 1) >> 1) : 0;
+        loff[it] = in ? hz * PS + hy * RS + hx * CS + 4 * q : HZ * PS;  // tail items -> dummy slot
+        fz0 |= (in && hz == 0 ? 1u : 0u) << it;
+        fz1 |= (in && hz == HZ - 1 ? 1u : 0u) << it;
+        fy0 |= (in && hy == 0 ? 1u : 0u) << it;
+        fy1 |= (in && hy == HY - 1 ? 1u : 0u) << it;
+        fx0 |= (in && hx == 0 ? 1u : 0u) << it;
+        fx1 |= (in && hx == HX - 1 ? 1u : 0u) << it;
+        fdead |= (in ? 0u : 1u) << it;
+    }
+    auto item_of = [&](int wi) {
+        Item c;
+        c.cb = wi % p.ncb;
+        int tile = wi / p.ncb;
+        c.x0 = (tile % p.tx) * TX;
+        tile /= p.tx;
+        c.y0 = (tile % p.ty) * TY;
+        tile /= p.ty;
+        c.z0 = (tile % p.tz) * TZ;
+        c.n = tile / p.tz;
+        c.base0 = ((c.n * D + c.z0 - 1) * H + c.y0 - 1) * W + c.x0 - 1;
+        c.base1 = VIRT ? ((c.n * D1 + (c.z0 >> 1)) * H1 + (c.y0 >> 1)) * W1 + (c.x0 >> 1) : 0;
+        const bool bz0 = c.z0 == 0, bz1 = c.z0 + TZ == D, by0 = c.y0 == 0, by1 = c.y0 + TY == H, bx0 = c.x0 == 0,
+                   bx1 = c.x0 + TX == W;
+        c.border = bz0 || bz1 || by0 || by1 || bx0 || bx1;
+        c.inv = fdead | (bz0 ? fz0 : 0u) | (bz1 ? fz1 : 0u) | (by0 ? fy0 : 0u) | (by1 ? fy1 : 0u) | (bx0 ? fx0 : 0u) |
+                (bx1 ? fx1 : 0u);
+        return c;
+    };
+    int wi = u3d_xcd_remap(blockIdx.x, G);
+    Item T = item_of(wi);
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    // A-fragment base: lane (m,h) -> voxel (zl = w, yl = (m>>3) [+4 for mt=1], xl = m&7), channels 4h..4h+3
+    const int abase = w * PS + (m >> 3) * RS + (m & 7) * CS + 4 * h;
+
+    // B stream: uniform base pointer of the block's channel block + the lane's 16-byte slot (no VALU per step)
+    const f32x4* wimg = reinterpret_cast<const f32x4*>(p.wp);
+    const f32x4* wq = wimg + (size_t)T.cb * NT * 64;
+    const int wstep = p.ntot * 64;
+    f32x4 bq[RB][NT];
+#pragma unroll
+    for (int k = 0; k < RB - 1; ++k)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bq[k][nt] = wq[(size_t)k * wstep + nt * 64 + l];
+
+    // per-chunk source selection of this thread's channel quad
+    struct ChunkSrc {
+        const float* base;
+        int Cs;
+        bool cok, from0;
+        f32x4 ga, gb;
+    };
+    auto chunk_src = [&](int ch, int n, bool live) {
+        ChunkSrc c;
+        const int cq = ch * CC + 4 * q;
+        c.cok = live && cq < Ctot;
+        c.from0 = !VIRT || cq < p.src.C0;
+        c.base = !c.cok ? p.src.p0 : (c.from0 ? p.src.p0 + cq : p.src.p1 + (cq - p.src.C0));
+        c.Cs = (c.from0 || !c.cok) ? p.src.C0 : p.src.C1;
+        c.ga = f32x4{1.f, 1.f, 1.f, 1.f};
+        c.gb = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.src.affine) {
+            const float* ap = p.src.affine + ((size_t)n * Ctot + (c.cok ? cq : 0)) * 2;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(ap);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(ap + 4);
+            c.ga = f32x4{lo[0], lo[2], hi[0], hi[2]};
+            c.gb = f32x4{lo[1], lo[3], hi[1], hi[3]};
+        }
+        return c;
+    };
+    // `masked`: the staged tile has padding items (border tile) or this thread's channel quad is dead
+    auto halo_load = [&](const ChunkSrc& c, const Item& S, int it, bool masked) {
+        int idx = c.from0 ? S.base0 + rel0[it] : S.base1 + rel1[VIRT ? it : 0];
+        if (masked) idx = (c.cok && ((S.inv >> it) & 1u) == 0) ? idx : 0;
+        return *reinterpret_cast<const f32x4*>(c.base + (size_t)idx * c.Cs);
+    };
+    auto halo_store = [&](float* buf, const ChunkSrc& c, const Item& S, int it, f32x4 raw, bool masked) {
+        f32x4 val = raw * c.ga + c.gb;
+        if (masked) {
+            const bool ok = c.cok && ((S.inv >> it) & 1u) == 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) val[e] = ok ? val[e] : 0.f;  // padding stays exactly 0
+        }
+        *reinterpret_cast<f32x4*>(&buf[loff[it]]) = val;
+    };
+    // GroupNorm statistics: the four waves add their 64-voxel sums of every tile into ONE block-level LDS row per
+    // sample parity (ds_add_f32); when a wave has finished the block's last tile of a sample it arrives on that
+    // parity's counter and the LAST of the four flushes the row with f64 atomics and clears it — 64*NT global atomics
+    // per block and sample instead of per wave and tile (same-address f64 atomics retire at ~24 ns each: 2048 waves
+    // flushing at once cost 100 us on the 32^3-tile layers).  A wave is never more than one tile ahead of the slowest,
+    // so two rows suffice.
+    const bool want_stats = p.out_stats != nullptr;
+    const bool want_g = p.gstats != nullptr;
+    auto flush_stats = [&](int n, int cb) {
+        if (!(want_stats || want_g)) return;
+        const int par = n & 1;
+        int arrived = 0;
+        asm volatile("" ::: "memory");
+        if (l == 0) arrived = __hip_atomic_fetch_add(&cnt[5 + par], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        arrived = __builtin_amdgcn_readfirstlane(arrived);
+        asm volatile("" ::: "memory");
+        if ((arrived & 3) != 3) return;
+        for (int k = l; k < NT * 32; k += 64) {
+            float* r = &red[(par * NT * 32 + k) * 2];
+            const float a = r[0], b = r[1];
+            r[0] = 0.f;
+            r[1] = 0.f;
+            const int co = cb * NT * 32 + k;
+            if (co < p.Cout) {
+                double* dst = (want_stats ? p.out_stats : p.gstats) + ((size_t)n * p.Cout + co) * 2;
+                u3d_atomic_add_f64(dst, (double)a);
+                u3d_atomic_add_f64(dst + 1, (double)b);
+            }
+        }
+        asm volatile("" ::: "memory");
+    };
+    const bool dead_quads = (Ctot % CC) != 0;  // uniform: some thread quads lie beyond the last channel
+
+    // ---- prologue: stage chunk 0 of the first tile into buffer 0
+    {
+        const ChunkSrc c0 = chunk_src(0, T.n, true);
+        const bool masked = T.border || dead_quads || fdead != 0;
+        f32x4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) v[it] = halo_load(c0, T, it, true);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) halo_store(lds, c0, T, it, v[it], true);
+        (void)masked;
+    }
+    u3d_flag_signal(&cnt[0], l);
+
+    int gch = 0;     // chunks done by this wave over all tiles: buffer parity and flag targets
+    int ntiles = 0;  // tiles done (timeline record)
+    while (true) {
+        const int nwi = wi + G;
+        const bool has_next_tile = nwi < p.total;
+        const Item TN = item_of(has_next_tile ? nwi : wi);
+        const f32x4* wqn = wimg + (size_t)TN.cb * NT * 64;
+
+        for (int ch = 0; ch < p.nchunks; ++ch, ++gch) {
+            const bool last = ch + 1 == p.nchunks;
+            const bool has_next = !last || has_next_tile;
+            const int b = gch & 1;
+            const float* cur = lds + b * TILE_FLOATS;
+            float* nxt = lds + (b ^ 1) * TILE_FLOATS;
+            // the chunk staged during this k-loop: the next chunk of this tile, or chunk 0 of the next tile
+            const int nch_ = last ? 0 : ch + 1;
+            const Item S = last ? TN : T;
+            const ChunkSrc cn = chunk_src(nch_, S.n, has_next);
+            // uniform: does any lane have to mask an item of the staged chunk?  (the tail items of the 10th round are
+            // dead in 3 of 4 waves only; they go to the dummy slot and need no masking)
+            const bool masked = S.border || !has_next || (dead_quads && nch_ + 1 == p.nchunks);
+            f32x4 v[NIT];
+            u3d_flag_wait(&cnt[b], 4 * (gch / 2 + 1));  // all four waves have staged this chunk
+            __builtin_amdgcn_s_setprio(0);
+            if (ntiles == 0 && ch < 8) U3D_DBG_STAMP(8 + 2 * ch);
+
+            // ---- 54 k-steps as 9 tap rows x 6 steps (3 taps x 2 channel-octets) of 8*NT MFMAs; tap row 0 carries
+            //      the 10 halo loads of the next chunk, tap row ISTORE their LDS stores
+            f32x4 aq[2][2];
+            aq[0][0] = *reinterpret_cast<const f32x4*>(&cur[abase]);
+            aq[0][1] = *reinterpret_cast<const f32x4*>(&cur[abase + 4 * RS]);
+            const f32x4* wrow = wq + (size_t)(ch * NSTEP + RB - 1) * wstep;  // B fragments of step (row, 0) + RB-1
+#pragma unroll 1
+            for (int row = 0; row < 9; ++row) {
+                const int rz = row / 3, ry = row - 3 * rz;
+                const float* arow = cur + abase + rz * PS + ry * RS;
+                const int nrow = row + 1;
+                const float* anext = cur + abase + (nrow / 3) * PS + (nrow % 3) * RS;
+                const bool do_load = row == 0, do_store = row == ISTORE && has_next;
+                if (do_store) u3d_flag_wait(&cnt[2 + (b ^ 1)], 4 * ((gch + 1) / 2));  // other buffer free
+#pragma unroll
+                for (int s6 = 0; s6 < 6; ++s6) {
+                    if (do_load && s6 < NIT / 2) {
+                        if (masked) {
+                            v[2 * s6] = halo_load(cn, S, 2 * s6, true);
+                            v[2 * s6 + 1] = halo_load(cn, S, 2 * s6 + 1, true);
+                        } else {
+                            v[2 * s6] = halo_load(cn, S, 2 * s6, false);
+                            v[2 * s6 + 1] = halo_load(cn, S, 2 * s6 + 1, false);
+                        }
+                    }
+                    {
+                        // B fragments of step + RB-1; past the end of a tile's image continue with the next tile's
+                        const f32x4* wsrc = wrow + (size_t)s6 * wstep;
+                        if (s6 + RB - 1 >= 6 && row == 8 && last) wsrc = wqn + (size_t)(s6 + RB - 1 - 6) * wstep;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) bq[(s6 + RB - 1) % RB][nt] = wsrc[nt * 64 + l];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s6 & 1][0][j], bq[s6 % RB][nt][j], acc[0][nt], 0, 0, 0);
+                            acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s6 & 1][1][j], bq[s6 % RB][nt][j], acc[1][nt], 0, 0, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s6 < 5) {
+                        const int aoff = ((s6 + 1) >> 1) * CS + 8 * ((s6 + 1) & 1);
+                        aq[(s6 + 1) & 1][0] = *reinterpret_cast<const f32x4*>(&arow[aoff]);
+                        aq[(s6 + 1) & 1][1] = *reinterpret_cast<const f32x4*>(&arow[4 * RS + aoff]);
+                    } else if (row < 8) {
+                        aq[0][0] = *reinterpret_cast<const f32x4*>(&anext[0]);
+                        aq[0][1] = *reinterpret_cast<const f32x4*>(&anext[4 * RS]);
+                    }
+                    if (do_store && s6 < NIT / 2) {
+                        if (masked) {
+                            halo_store(nxt, cn, S, 2 * s6, v[2 * s6], true);
+                            halo_store(nxt, cn, S, 2 * s6 + 1, v[2 * s6 + 1], true);
+                        } else {
+                            halo_store(nxt, cn, S, 2 * s6, v[2 * s6], false);
+                            halo_store(nxt, cn, S, 2 * s6 + 1, v[2 * s6 + 1], false);
+                        }
+                        if (s6 == NIT / 2 - 1) u3d_flag_signal(&cnt[b ^ 1], l);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 2; j < 4; ++j) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s6 & 1][0][j], bq[s6 % RB][nt][j], acc[0][nt], 0, 0, 0);
+                            acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s6 & 1][1][j], bq[s6 % RB][nt][j], acc[1][nt], 0, 0, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                wrow += (size_t)6 * wstep;
+            }
+            if (ntiles == 0 && ch < 8) U3D_DBG_STAMP(9 + 2 * ch);
+            u3d_flag_signal(&cnt[2 + b], l);  // this wave no longer reads buffer b
+        }
+        __builtin_amdgcn_s_setprio(3);
+
+        // ---- epilogue of tile T (fully inside the volume: no voxel masks).  C/D layout of 32x32 MFMA: col = lane&31
+        //      (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5); M-tile row -> (y = row>>3, x = row&7).  A 4x4 transpose
+        //      inside every lane quad (two DPP butterfly stages) leaves lane j of quad k with the 4 consecutive
+        //      channels 4k..4k+3 of voxel x = j + 4h: 16-byte stores and 16-byte loads of x for the GroupNorm sums.
+        if (ntiles == 0) U3D_DBG_STAMP(5);
+        {
+            const int n = T.n, cb = T.cb;
+            const int z = T.z0 + w;
+            const int cq = (l >> 2) & 7, vl = (l & 3) + 4 * h;
+            const bool odd = (l & 1) != 0, hi = (l & 2) != 0;
+            auto xlane = [](float v, auto ctrl) {
+                return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, true));
+            };
+            using X1 = std::integral_constant<int, 0xB1>;  // quad_perm [1,0,3,2]: value of lane ^ 1
+            using X2 = std::integral_constant<int, 0x4E>;  // quad_perm [2,3,0,1]: value of lane ^ 2
+            const int vrow = ((n * D + z) * H + T.y0) * W + T.x0 + vl;  // voxel of row 0; row st adds st * W
+            // low-res (exact 2x) voxel of row 0 of gx's upsampled half; row st is (st >> 1) low-res rows further
+            const int xrow = ((n * p.gx.D1 + (z >> 1)) * p.gx.H1 + (T.y0 >> 1)) * p.gx.W1 + ((T.x0 + vl) >> 1);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 q1 = {0.f, 0.f, 0.f, 0.f}, q2 = {0.f, 0.f, 0.f, 0.f};
+                f32x4 tq[8];  // row st = 4*mt + bi: the lane's channel quad at voxel (y0 + st, x0 + vl)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int bi = 0; bi < 4; ++bi) {
+                        float a0 = acc[mt][nt][4 * bi + 0], a1 = acc[mt][nt][4 * bi + 1];
+                        float a2 = acc[mt][nt][4 * bi + 2], a3 = acc[mt][nt][4 * bi + 3];
+                        if (p.relu) {
+                            a0 = fmaxf(a0, 0.f);
+                            a1 = fmaxf(a1, 0.f);
+                            a2 = fmaxf(a2, 0.f);
+                            a3 = fmaxf(a3, 0.f);
+                        }
+                        const float t0 = xlane(a1, X1{}), t1 = xlane(a0, X1{}), t2 = xlane(a3, X1{}), t3 = xlane(a2, X1{});
+                        const float c0 = odd ? t0 : a0, c1 = odd ? a1 : t1, c2 = odd ? t2 : a2, c3 = odd ? a3 : t3;
+                        const float u0 = xlane(c2, X2{}), u2 = xlane(c0, X2{}), u1 = xlane(c3, X2{}), u3 = xlane(c1, X2{});
+                        tq[4 * mt + bi] = f32x4{hi ? u0 : c0, hi ? u1 : c1, hi ? c2 : u2, hi ? c3 : u3};
+                    }
+                const int co = (cb * NT + nt) * 32 + 4 * cq;
+                const bool cok = co < p.Cout;
+                float* orow = p.out + (size_t)vrow * p.Cout + co;
+                const bool xfrom0 = co < p.gx.C0 || !cok;
+                const float* xb = !cok ? p.gx.p0 : (xfrom0 ? p.gx.p0 + co : p.gx.p1 + (co - p.gx.C0));
+                const int xcs = xfrom0 ? p.gx.C0 : p.gx.C1;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {  // two batches of 4 rows bound the live registers
+                    f32x4 xv[4];
+                    if (want_g) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int st = 4 * half + k;
+                            const int xi = xfrom0 ? vrow + st * W : xrow + (st >> 1) * p.gx.W1;
+                            xv[k] = *reinterpret_cast<const f32x4*>(xb + (size_t)xi * xcs);
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int st = 4 * half + k;
+                        f32x4 val = tq[st];
+                        if (cok) *reinterpret_cast<f32x4*>(orow + (size_t)st * W * p.Cout) = val;
+                        if (p.Cout % 32 != 0) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) val[e] = cok ? val[e] : 0.f;
+                        }
+                        q1 += val;
+                        q2 += want_g ? val * xv[k] : val * val;
+                    }
+                }
+                if (want_stats || want_g) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float a = q1[e], b2 = q2[e];
+#pragma unroll
+                        for (int mask : {1, 2, 32}) {  // lanes of one channel quad: x = (l&3) + 4*(l>>5)
+                            a += __shfl_xor(a, mask);
+                            b2 += __shfl_xor(b2, mask);
+                        }
+                        if ((l & 35) == 0) {
+                            float* r = &red[(((n & 1) * NT + nt) * 32 + 4 * cq + e) * 2];
+                            __hip_atomic_fetch_add(r, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(r + 1, b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                }
+            }
+        }
+        ++ntiles;
+        // statistics are per (sample, channel): flush this wave's LDS row when the sample or the channel block changes
+        if (!has_next_tile || TN.n != T.n || TN.cb != T.cb) flush_stats(T.n, T.cb);
+        if (!has_next_tile) break;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+        wi = nwi;
+        T = TN;
+        wq = wqn;
+    }
+    if constexpr (DBG) {
+        if (l == 0) dbgw[4] = ntiles;
     }
     U3D_DBG_STAMP(6);
 }
@@ -1026,9 +1452,31 @@ extern "C" int u3d_pack_weights(int device, u3d_stream_t stream, const float* w,
     return 0;
 }
 
+static int device_cu_count(int device, int* out) {
+    static int cached[64] = {0};
+    if (device >= 0 && device < 64 && cached[device] > 0) {
+        *out = cached[device];
+        return 0;
+    }
+    int n = 0;
+    U3D_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device));
+    if (n <= 0) n = 256;
+    if (device >= 0 && device < 64) cached[device] = n;
+    *out = n;
+    return 0;
+}
+
 template <int NT>
 static int conv_set_lds_nt() {
     const int bytes = cv::LDS_FLOATS * sizeof(float);
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<NT, false, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<NT, true, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<NT, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<NT, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_kernel<NT, true, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_kernel<NT, false, false>),
@@ -1104,9 +1552,49 @@ extern "C" int u3d_conv3d(int device, u3d_stream_t stream, const u3d_src_t* src,
     U3D_REQUIRE(nblk < (1ll << 31), "u3d_conv3d: grid too large");
     const size_t shmem = cv::LDS_FLOATS * sizeof(float);
     if (int e = conv_set_lds_once(device)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    // ---- fast variant: persistent blocks, constant-offset staging (every tile fully inside, no table look-ups)
+    auto plain_or_x2 = [&](const u3d_src_t& s_) {
+        return s_.C1 == 0 || (D == 2 * s_.D1 && H == 2 * s_.H1 && W == 2 * s_.W1);
+    };
+    const bool reg = p.vec && p.ovec && D % cv::TZ == 0 && H % cv::TY == 0 && W % cv::TX == 0 && plain_or_x2(p.src) &&
+                     (!gx || plain_or_x2(p.gx)) && g_u3d_tune[3] == 0;
+    if (reg) {
+        p.total = (int)nblk;
+        p.gx_x2 = (gx && p.gx.C1 > 0) ? 1 : 0;
+        int ncu = 0;
+        if (int e = device_cu_count(device, &ncu)) return e;
+        long long slots = 2ll * ncu;  // two blocks per CU (LDS)
+        if (slots >= nblk)
+            slots = nblk;
+        else if (slots > p.ncb)
+            slots -= slots % p.ncb;  // a block stays on one channel block: one statistics flush per sample
+        const dim3 rgrid((unsigned)slots), rblock(256);
+        const bool virt = p.src.C1 > 0;
+        p.dbg = (g_u3d_prof_buf && (size_t)slots * 4 <= g_u3d_prof_records) ? g_u3d_prof_buf : nullptr;
+#define U3D_REG_LAUNCH(NT_)                                                                                \
+    do {                                                                                                   \
+        if (p.dbg && virt)                                                                                 \
+            hipLaunchKernelGGL((conv3d_mfma_reg_kernel<NT_, true, true>), rgrid, rblock, shmem, st, p);    \
+        else if (p.dbg)                                                                                    \
+            hipLaunchKernelGGL((conv3d_mfma_reg_kernel<NT_, false, true>), rgrid, rblock, shmem, st, p);   \
+        else if (virt)                                                                                     \
+            hipLaunchKernelGGL((conv3d_mfma_reg_kernel<NT_, true, false>), rgrid, rblock, shmem, st, p);   \
+        else                                                                                               \
+            hipLaunchKernelGGL((conv3d_mfma_reg_kernel<NT_, false, false>), rgrid, rblock, shmem, st, p);  \
+    } while (0)
+        if (nt == 3)
+            U3D_REG_LAUNCH(3);
+        else if (nt == 2)
+            U3D_REG_LAUNCH(2);
+        else
+            U3D_REG_LAUNCH(1);
+#undef U3D_REG_LAUNCH
+        U3D_LAUNCH_CHECK();
+        return 0;
+    }
     const bool vec = p.vec != 0;
     const dim3 grid((unsigned)nblk), block(256);
-    hipStream_t st = (hipStream_t)stream;
     p.dbg = (vec && g_u3d_prof_buf && (size_t)nblk * 4 <= g_u3d_prof_records) ? g_u3d_prof_buf : nullptr;
 #define U3D_CONV_LAUNCH(NT_)                                                                     \
     do {                                                                                         \

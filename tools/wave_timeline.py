@@ -84,7 +84,9 @@ def run(name, dgrad, forced_nt=0, dims=None, abl=0):
     if ncb_hint := 0:
         pass
     nblk = nw // 4
-    ncb = nblk // ntiles
+    done = r[:, 4].double().clamp(min=1)  # tiles walked by each wave (persistent kernel), 1 for the generic kernel
+    items = int(done.sum().item()) // 4
+    ncb = max(1, items // ntiles)
     NT = ntot // ncb
     mfma_cyc = nch * 54 * 8 * NT * 64
     life = (exit_ - entry).double()
@@ -97,7 +99,7 @@ def run(name, dgrad, forced_nt=0, dims=None, abl=0):
             gaps.append((r[:, 8 + 2 * c] - r[:, 7 + 2 * c]).double())
     # gap between chunks = (start of next k-loop) - (end of this) is folded into next chunk's duration here; report
     # chunk durations instead
-    print(f"   NT={NT} blocks={nblk}  ideal MFMA cycles/wave {mfma_cyc}  | mean lifetime {life.mean():.0f} "
+    print(f"   NT={NT} blocks={nblk} tiles/block {done.mean():.1f}  ideal MFMA cycles/wave/tile {mfma_cyc}  | mean lifetime {life.mean():.0f} "
           f"(prologue {pro.mean():.0f} = {100 * pro.mean() / life.mean():.1f}%, epilogue {ep.mean():.0f} = "
           f"{100 * ep.mean() / life.mean():.1f}%)")
     print("   k-loop durations (mean ticks): " + " ".join(f"{k.mean():.0f}" for k in kl) +
@@ -111,7 +113,7 @@ def run(name, dgrad, forced_nt=0, dims=None, abl=0):
     for k, idx in groups.items():
         idx_t = torch.tensor(idx)
         s0, s1 = entry[idx_t].min().item(), exit_[idx_t].max().item()
-        utils.append(len(idx) * mfma_cyc / (s1 - s0))
+        utils.append(done[idx_t].sum().item() * mfma_cyc / (s1 - s0))
         conc.append(life[idx_t].sum().item() / (s1 - s0))
     ut = torch.tensor(utils)
     print(f"   SIMDs seen {len(groups)}; waves/SIMD {nw / len(groups):.1f}; MFMA-pipe utilisation per SIMD (ticks basis): "
