@@ -93,6 +93,24 @@ def cpu_baseline(sample_iters=3):
                       f"(median {med:.3f} s), torch {torch.__version__} CPU operators"}
 
 
+def pmc_traffic(family):
+    """HBM bytes per launch of a kernel family from the newest committed PMC summary (profiles/*_pmc_traffic.json,
+    written by tools/prof_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this
+    very command; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  PMC counters cannot be read from inside the timed
+    process, hence the file; None if absent."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as fh:
+            fam = json.load(fh)["families"][family]
+        return round(fam["bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,9 +217,11 @@ def main():
             dom = max(fams, key=lambda k: fams[k]["ms"])
             d = fams[dom]
             achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            traffic, traffic_src = pmc_traffic(dom)
             out["roofline"] = {
                 "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,
                 "launches": d["calls"], "avg_launch_ms": round(d["ms"] / d["calls"], 4),
                 "gflop_per_launch": round(d["flops"] / d["calls"] / 1e9, 3),
                 "families": {k: {"calls": v["calls"], "ms_per_step": round(v["ms"] / args.steps, 3),

@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvParams p)
 //     chunk instead of ~45 per item and tile, and no masking at all on the 2/3 of the tiles that touch no face;
 //   * keeps the B stream on a scalar base pointer (no VALU in the 54 k-steps);
 //   * needs no LDS in the epilogue (DPP transposition), accumulates the GroupNorm statistics per wave in LDS
-//     (ds_add_f32) and flushes them with f64 atomics when the block's sample changes.
+//     (ds_add_f64) and flushes them with f64 atomics when the block's sample changes.
 // Everything else (flags instead of barriers, halo prefetch schedule, fragment layouts) is the generic kernel's.
 template <int NT, bool VIRT, bool DBG = false>
 __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParams p) {
@@ -535,7 +535,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
     constexpr int RB = NT == 1 ? 6 : 3;  // B ring depth (54 % RB == 0, 6 % RB == 0)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int* cnt = reinterpret_cast<int*>(lds + CNT_OFF);
-    float* red = lds + RED_OFF;  // [2 sample parities][NT*32][2] block-level partial statistics
+    // [2 sample parities][NT*32][2] block-level partial statistics, accumulated in f64 (ds_add_f64): the arrival order
+    // of the waves then perturbs the sums below 1e-15 relative, i.e. results are run-to-run reproducible
+    double* red = reinterpret_cast<double*>(lds + RED_OFF);
+    static_assert((RED_OFF * 4) % 8 == 0 && 2 * 3 * 32 * 2 * 8 <= 4 * 3 * 32 * 2 * 4, "f64 statistics rows must fit");
     const int t = threadIdx.x;
     const int l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), m = l & 31, h = l >> 5;
     __builtin_amdgcn_s_setprio(3);
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
     }
     U3D_DBG_STAMP(3);
     if (t < 16) cnt[t] = 0;
-    for (int k = t; k < 4 * 3 * 32 * 2; k += 256) red[k] = 0.f;
+    for (int k = t; k < 2 * 3 * 32 * 2; k += 256) red[k] = 0.0;
     __syncthreads();  // the only rendezvous of the kernel
 
     const int D = p.D, H = p.H, W = p.W;
@@ -675,7 +678,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
         *reinterpret_cast<f32x4*>(&buf[loff[it]]) = val;
     };
     // GroupNorm statistics: the four waves add their 64-voxel sums of every tile into ONE block-level LDS row per
-    // sample parity (ds_add_f32); when a wave has finished the block's last tile of a sample it arrives on that
+    // sample parity (ds_add_f64); when a wave has finished the block's last tile of a sample it arrives on that
     // parity's counter and the LAST of the four flushes the row with f64 atomics and clears it — 64*NT global atomics
     // per block and sample instead of per wave and tile (same-address f64 atomics retire at ~24 ns each: 2048 waves
     // flushing at once cost 100 us on the 32^3-tile layers).  A wave is never more than one tile ahead of the slowest,
@@ -692,15 +695,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
         asm volatile("" ::: "memory");
         if ((arrived & 3) != 3) return;
         for (int k = l; k < NT * 32; k += 64) {
-            float* r = &red[(par * NT * 32 + k) * 2];
-            const float a = r[0], b = r[1];
-            r[0] = 0.f;
-            r[1] = 0.f;
+            double* r = &red[(par * NT * 32 + k) * 2];
+            const double a = r[0], b = r[1];
+            r[0] = 0.0;
+            r[1] = 0.0;
             const int co = cb * NT * 32 + k;
             if (co < p.Cout) {
                 double* dst = (want_stats ? p.out_stats : p.gstats) + ((size_t)n * p.Cout + co) * 2;
-                u3d_atomic_add_f64(dst, (double)a);
-                u3d_atomic_add_f64(dst + 1, (double)b);
+                u3d_atomic_add_f64(dst, a);
+                u3d_atomic_add_f64(dst + 1, b);
             }
         }
         asm volatile("" ::: "memory");
@@ -903,9 +906,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                             b2 += __shfl_xor(b2, mask);
                         }
                         if ((l & 35) == 0) {
-                            float* r = &red[(((n & 1) * NT + nt) * 32 + 4 * cq + e) * 2];
-                            __hip_atomic_fetch_add(r, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            __hip_atomic_fetch_add(r + 1, b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            double* r = &red[(((n & 1) * NT + nt) * 32 + 4 * cq + e) * 2];
+                            __hip_atomic_fetch_add(r, (double)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(r + 1, (double)b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                     }
                 }

@@ -151,3 +151,19 @@ def test_nearest_maps_match_interpolate():
         assert lo[0] == 0 and lo[-1] == n_out
         for i in range(n_in):  # children ranges partition the output
             assert torch.all(m[lo[i]:lo[i + 1]] == i)
+
+
+def test_product_never_imports_oracle():
+    """the shipped package (pytorch-3dunet_amd/) must not import, load or mention anything under oracle/ — the oracle
+    is the checker, never part of the product path"""
+    pkg = os.path.join(ROOT, "pytorch-3dunet_amd")
+    bad = []
+    for dirpath, _dirs, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith((".py", ".hip", ".h", ".cpp")):
+                continue
+            src = open(os.path.join(dirpath, f), errors="ignore").read()
+            for needle in ("unet3d_oracle", "ref_ops", "ref_import", "oracle/", "libref_ops", "c_ops"):
+                if needle in src:
+                    bad.append((os.path.join(dirpath, f), needle))
+    assert not bad, bad
