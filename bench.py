@@ -52,18 +52,6 @@ def conv_flops_per_patch(model):
     return total
 
 
-def bce_dice(logits, target):
-    """BCEDiceLoss of the reference (losses.py:187-201) on device tensors (stock elementwise/reduction ops; the
-    fused loss kernel is SURVEY.md §8f row 1)."""
-    bce = torch.nn.functional.binary_cross_entropy_with_logits(logits, target)
-    p = torch.sigmoid(logits)
-    c = logits.shape[1]
-    pf = p.transpose(0, 1).reshape(c, -1)
-    tf = target.transpose(0, 1).reshape(c, -1)
-    dice = 2 * (pf * tf).sum(-1) / ((pf * pf).sum(-1) + (tf * tf).sum(-1)).clamp(min=1e-6)
-    return bce + (1.0 - dice.mean())
-
-
 def cpu_baseline(sample_iters=3):
     """The CPU oracle (oracle/unet3d_oracle.py = the reference's module graph on ATen CPU operators) on a bounded
     sample of the same workload: batch 1 of the same patch, 1 warm-up + `sample_iters` timed fwd+bwd."""
@@ -154,9 +142,13 @@ def main():
     x = torch.randn((B, 1, *PATCH), device=dev, generator=g)
     target = (torch.rand((B, 1, *PATCH), device=dev, generator=g) > 0.5).float()
 
+    from pytorch3dunet_amd.unet3d.losses import BCEDiceLoss
+
+    criterion = BCEDiceLoss()  # fused HIP kernels on the logits (u3d_bce_dice_fwd/_bwd)
+
     def step():
         probs, logits = model(x, return_logits=True)
-        loss = bce_dice(logits, target)
+        loss = criterion(logits, target)
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()

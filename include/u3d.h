@@ -187,6 +187,20 @@ int u3d_conv1x1_head_bwd(int device, u3d_stream_t stream, const float* dlogits, 
                          int N, int64_t V, int Cin, int Cout, int relu_mask, float* dx, double* acc);
 int u3d_cvt_f64_f32(int device, u3d_stream_t stream, const double* src, float* dst, int64_t n);
 
+/* ---- BCEDiceLoss / DiceLoss / BCEWithLogitsLoss on the logits (losses.py:187-201, :84-127, :11-37) ------------
+ * loss = w_bce * mean(BCE-with-logits) + w_dice * (1 - mean_c dice_c),
+ * dice_c = 2 * weight_c * sum(p*t) / clamp(sum(p^2) + sum(t^2), eps), p = sigmoid(logits), sums over (N, V) per channel.
+ * BCEDiceLoss(alpha) = (w_bce 1, w_dice alpha); DiceLoss() = (0, 1); nn.BCEWithLogitsLoss() = (1, 0).
+ * logits / target: (N, C, V) contiguous fp32 (the reference's NCDHW).  weight: optional device float[C] (DiceLoss's
+ * per-class weight) or NULL.
+ * fwd : sums double[1 + 3C] (scratch, zeroed by the call), loss float[1], coef float[2C + 1] (saved for backward)
+ * bwd : dlogits = grad_out[0] * dloss/dlogits; grad_out is a DEVICE scalar (NULL = 1) — no host synchronisation. */
+int u3d_bce_dice_fwd(int device, u3d_stream_t stream, const float* logits, const float* target, const float* weight,
+                     int N, int C, int64_t V, float w_bce, float w_dice, float eps, double* sums, float* loss,
+                     float* coef);
+int u3d_bce_dice_bwd(int device, u3d_stream_t stream, const float* logits, const float* target, const float* coef,
+                     const float* grad_out, int N, int C, int64_t V, float* dlogits);
+
 /* ---- layout: NCDHW <-> NDHWC for multi-channel model inputs ------------------------------------ */
 int u3d_ncdhw_to_ndhwc(int device, u3d_stream_t stream, const float* src, float* dst, int N, int C, int64_t V);
 int u3d_ndhwc_to_ncdhw(int device, u3d_stream_t stream, const float* src, float* dst, int N, int C, int64_t V);

@@ -979,9 +979,14 @@ struct WgradParams {
 // plain or exact-2x source) therefore replaces the per-item index arithmetic (~40 VALU per staged item and tile) by
 // per-thread constants computed once per block: index = tile base + rel[item], validity = one bit of a mask built
 // from six per-face item masks and uniform tile-position tests.
-template <bool VEC, bool REG = false>
+//
+// PAIR (Cin <= 16: the single input chunk fills only half of the 32 MFMA rows): rows 0-15 carry the 16 channels at
+// tap 2q, rows 16-31 the same channels at tap 2q+1 — one MFMA serves two taps, 14 tap pairs instead of 27 taps
+// (wave w owns pairs {w&3, +4, ..}: 4 accumulators instead of 7).
+template <bool VEC, bool REG = false, bool PAIR = false>
 __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams p) {
     using namespace wg;
+    constexpr int NA = PAIR ? 4 : 7;  // accumulators (taps / tap pairs) per wave
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int* zmapl = reinterpret_cast<int*>(lds + 2 * BUF_FLOATS);  // [D | H | W] (virtual source only)
     __builtin_amdgcn_s_setprio(3);  // non-MFMA phases outrank co-resident k-loops (see conv3d_mfma_kernel)
@@ -1005,9 +1010,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
         __syncthreads();
     }
 
-    f32x16 acc[7];
+    f32x16 acc[NA];
 #pragma unroll
-    for (int k = 0; k < 7; ++k)
+    for (int k = 0; k < NA; ++k)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
 
@@ -1218,12 +1223,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
     __syncthreads();
 
     // A-operand bases: lane (i = channel, h = voxel parity) + the wave's z-plane + its 7 tap offsets
-    int abase[7];
+    int abase[NA];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        const int tap = tg + 4 * k;
+    for (int k = 0; k < NA; ++k) {
+        const int tap = PAIR ? 2 * (tg + 4 * k) + (i >> 4) : tg + 4 * k;
         const int toff = tap < 27 ? (tap / 9) * PSg + ((tap / 3) % 3) * RSg + (tap % 3) * CSg : 0;
-        abase[k] = i + h * CSg + hf * PSg + toff;
+        abase[k] = (PAIR ? (i & 15) : i) + h * CSg + hf * PSg + toff;
     }
     int bbase = G_FLOATS + (hf * 64 + h) * 32 + i;
     int cur = 0;  // buffer holding the current tile
@@ -1241,10 +1246,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
         const float* gl = lds + cur * BUF_FLOATS;
 
         // ---- 32 voxel-pair groups x 7 taps.  A[i=c][k=h] = g[voxel 2t+h shifted by tap][c], B[k=h][j] = dz[voxel][j]
-        float aop[2][7], bop[2];
+        float aop[2][NA], bop[2];
         bop[0] = gl[bbase];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) aop[0][k] = gl[abase[k]];
+        for (int k = 0; k < NA; ++k) aop[0][k] = gl[abase[k]];
 #pragma unroll
         for (int g = 0; g < 32; ++g) {
             if constexpr (VEC) {
@@ -1257,11 +1262,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
                 const int goff = row * RSg + 2 * tq * CSg;
                 bop[(g + 1) & 1] = gl[bbase + (row * 8 + 2 * tq) * 32];
 #pragma unroll
-                for (int k = 0; k < 7; ++k) aop[(g + 1) & 1][k] = gl[abase[k] + goff];
+                for (int k = 0; k < NA; ++k) aop[(g + 1) & 1][k] = gl[abase[k] + goff];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int k = 0; k < 7; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[g & 1][k], bop[g & 1], acc[k], 0, 0, 0);
+            for (int k = 0; k < NA; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[g & 1][k], bop[g & 1], acc[k], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (!VEC) {
@@ -1277,7 +1282,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
     float* red = lds;  // [tg][k][r][lane]: 4 * 7 * 16 * 64 floats = 112 KiB of the (now idle) staging buffers
     if (hf == 1) {
 #pragma unroll
-        for (int k = 0; k < 7; ++k)
+        for (int k = 0; k < NA; ++k)
 #pragma unroll
             for (int r = 0; r < 16; ++r) red[((tg * 7 + k) * 16 + r) * 64 + l] = acc[k][r];
     }
@@ -1285,14 +1290,13 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
     if (hf == 0) {
         float* dst = p.partial + ((size_t)((s * p.nchunks + chunk) * p.nkb + kb) * 27) * 1024;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            const int tap = tg + 4 * k;
-            if (tap < 27) {
+        for (int k = 0; k < NA; ++k) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int c = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    dst[((size_t)tap * 32 + c) * 32 + i] = acc[k][r] + red[((tg * 7 + k) * 16 + r) * 64 + l];
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;  // D row of this register
+                const int tap = PAIR ? 2 * (tg + 4 * k) + (row >> 4) : tg + 4 * k;
+                const int c = PAIR ? (row & 15) : row;
+                if (tap < 27) dst[((size_t)tap * 32 + c) * 32 + i] = acc[k][r] + red[((tg * 7 + k) * 16 + r) * 64 + l];
             }
         }
     }
@@ -1665,6 +1669,8 @@ static int wgrad_set_lds_once(int device) {
     if (device >= 0 && device < 64 && done[device]) return 0;
     U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wgrad_kernel<true, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (wg::LDS_FLOATS + wg::MAX_MAP_INTS) * sizeof(float)));
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wgrad_kernel<true, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (wg::LDS_FLOATS + wg::MAX_MAP_INTS) * sizeof(float)));
     U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wgrad_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (wg::LDS_FLOATS + wg::MAX_MAP_INTS) * sizeof(float)));
     U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wgrad_kernel<false>),
@@ -1698,7 +1704,9 @@ extern "C" int u3d_conv3d_wgrad(int device, u3d_stream_t stream, const u3d_src_t
     // every tile fully inside the volume and no table look-ups -> constant-offset staging (REG)
     const bool reg = D % wg::TZ == 0 && H % wg::TY == 0 && W % wg::TX == 0 &&
                      (src->C1 == 0 || (D == 2 * src->D1 && H == 2 * src->H1 && W == 2 * src->W1));
-    if (p.vec && p.dzvec && reg)
+    if (p.vec && p.dzvec && reg && Cin <= 16)
+        hipLaunchKernelGGL((conv3d_wgrad_kernel<true, true, true>), dim3(nblk), dim3(wg::NTHR), shmem, (hipStream_t)stream, p);
+    else if (p.vec && p.dzvec && reg)
         hipLaunchKernelGGL((conv3d_wgrad_kernel<true, true>), dim3(nblk), dim3(wg::NTHR), shmem, (hipStream_t)stream, p);
     else if (p.vec && p.dzvec)
         hipLaunchKernelGGL(conv3d_wgrad_kernel<true>, dim3(nblk), dim3(wg::NTHR), shmem, (hipStream_t)stream, p);

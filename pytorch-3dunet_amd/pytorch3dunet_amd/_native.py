@@ -99,6 +99,12 @@ _PROTOS = {
         c_int,
         [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p],
     ),
+    "u3d_bce_dice_fwd": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_float, c_float, c_float, c_void_p, c_void_p,
+         c_void_p],
+    ),
+    "u3d_bce_dice_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "u3d_cvt_f64_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64]),
     "u3d_ncdhw_to_ndhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64]),
     "u3d_ndhwc_to_ncdhw": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64]),

@@ -112,5 +112,49 @@ def main():
         print(f"{name}: loss={loss.item():.6f} -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def make_loss_golden():
+    """l1_losses.npz: values and dlogits of the reference's BCEDiceLoss / DiceLoss / BCEWithLogitsLoss
+    (pytorch3dunet/unet3d/losses.py) on small seeded (logits, target) pairs, incl. the clamp(min=eps) corner."""
+    import importlib
+
+    import_reference()
+    L = importlib.import_module("pytorch3dunet.unet3d.losses")
+    g = torch.Generator().manual_seed(4242)
+    out = {}
+    cases = {
+        "a": (2.0 * torch.randn((2, 3, 5, 6, 7), generator=g), None),
+        "b": (3.0 * torch.randn((1, 1, 9, 13, 11), generator=g), None),
+        "c": (torch.randn((3, 2, 4, 4, 8), generator=g), None),
+        # channel 1 has an empty target and p ~ 0: sum(p^2)+sum(t^2) < 1e-6 -> the clamped branch of the Dice
+        "z": (torch.cat([torch.randn((1, 1, 4, 4, 4), generator=g), torch.full((1, 1, 4, 4, 4), -12.0)], dim=1), "zero1"),
+    }
+    crits = {
+        "bcedice": lambda: L.BCEDiceLoss(),
+        "bcedice_a05": lambda: L.BCEDiceLoss(alpha=0.5),
+        "dice": lambda: L.DiceLoss(),
+        "bce": lambda: torch.nn.BCEWithLogitsLoss(),
+    }
+    for cname, (logits, special) in cases.items():
+        target = (torch.rand(logits.shape, generator=g) > 0.5).float()
+        if special == "zero1":
+            target[:, 1] = 0.0
+        out[f"{cname}/logits"] = logits.numpy()
+        out[f"{cname}/target"] = target.numpy()
+        items = dict(crits)
+        if logits.shape[1] == 3:
+            items["dice_w"] = lambda: L.DiceLoss(weight=torch.tensor([0.2, 0.3, 0.5]))
+        for lname, mk in items.items():
+            x = logits.clone().requires_grad_(True)
+            val = mk()(x, target)
+            (1.7 * val).backward()  # non-unit upstream gradient
+            out[f"{cname}/{lname}/loss"] = val.detach().numpy()
+            out[f"{cname}/{lname}/dlogits"] = x.grad.numpy()
+    path = os.path.join(HERE, "l1_losses.npz")
+    np.savez_compressed(path, **out)
+    print(f"l1_losses: {len(out)} arrays -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 if __name__ == "__main__":
-    main()
+    if "--losses-only" not in sys.argv:
+        main()
+    make_loss_golden()

@@ -198,7 +198,9 @@ def test_conv3d_dgrad_and_groupnorm_reductions(N, Cin, Cout, D, H, W):
 
 WGRAD_CASES = [(1, 16, 32, 8, 16, 16, False), (2, 32, 64, 9, 13, 11, True), (1, 1, 16, 8, 16, 16, True),
                (1, 96, 32, 4, 8, 8, True), (1, 3, 8, 5, 9, 7, True), (1, 64, 128, 4, 8, 8, False),
-               (1, 32, 32, 16, 32, 32, True)]
+               (1, 32, 32, 16, 32, 32, True),
+               # Cin <= 16 with aligned dims: the tap-pairing variant (two taps per MFMA)
+               (2, 16, 32, 8, 16, 16, True), (1, 8, 16, 4, 8, 16, True), (1, 12, 20, 4, 8, 8, True), (2, 4, 8, 2, 8, 8, False)]
 
 
 @pytest.mark.parametrize("N,Cin,Cout,D,H,W,affine", WGRAD_CASES)
