@@ -102,6 +102,12 @@ int u3d_conv3d(int device, u3d_stream_t stream, const u3d_src_t* src, const floa
                int N, int D, int H, int W, int Cout, int relu, double* out_stats, const u3d_src_t* gx,
                double* gstats);
 
+/* The same convolution with a residual added before the ReLU: out = [relu](conv(src) + residual) — the tail of
+ * ResNetBlock.forward (buildingblocks.py:277-288: conv3 without non-linearity, `out += residual`, non-linearity).
+ * residual: (N,D,H,W,Cout) fp32. */
+int u3d_conv3d_residual(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w, float* out,
+                        int N, int D, int H, int W, int Cout, int relu, double* out_stats, const float* residual);
+
 /* Weight gradient of the same convolution: dw[cout][cin][tap] = sum_{n,v} dz[n,v,cout] * g[n,v+tap,cin]
  * with g = src (GroupNorm affine fused on load, zero padded).  Split-K over voxel tiles with a
  * deterministic two-pass reduction.  workspace must hold u3d_wgrad_workspace_floats() floats.
@@ -156,6 +162,13 @@ int u3d_gn_bwd_finalize(int device, u3d_stream_t stream, const double* gstats, c
 int u3d_gn_bwd_apply(int device, u3d_stream_t stream, const float* dg, int Cdg, int coff, const float* x, int Cx,
                      const float* coef, int Ctot, int64_t voxels_per_n, int N, int relu_mask, float* out);
 
+/* Same with an extra gradient term added BEFORE the mask: out = (p*dg + q*x + r + add) * mask.  ResNetBlock
+ * (buildingblocks.py:277-288): the block input `residual` receives the GroupNorm-backward of conv2 plus the gradient
+ * that flows through `out += residual`. */
+int u3d_gn_bwd_apply_add(int device, u3d_stream_t stream, const float* dg, int Cdg, int coff, const float* x, int Cx,
+                         const float* coef, int Ctot, int64_t voxels_per_n, int N, int relu_mask, const float* add,
+                         float* out);
+
 /* Same for the upsampled half of a concat: the backward of F.interpolate(nearest) (buildingblocks.py:614)
  * is a sum over the children of each low-res voxel, fused with the affine map and the ReLU mask of the
  * low-res producer:  out[n,v1,c] = (p*sum_children dg[.,coff+c] + cnt*(q*x1 + r)) * (x1>0).
@@ -186,6 +199,30 @@ int u3d_conv1x1_head_fwd(int device, u3d_stream_t stream, const float* x, const 
 int u3d_conv1x1_head_bwd(int device, u3d_stream_t stream, const float* dlogits, const float* x, const float* w,
                          int N, int64_t V, int Cin, int Cout, int relu_mask, float* dx, double* acc);
 int u3d_cvt_f64_f32(int device, u3d_stream_t stream, const double* src, float* dst, int64_t n);
+
+/* ---- residual variants (ResidualUNet3D / ResidualUNetSE3D, model.py:193-278) -------------------------------------
+ * 1x1x1 convolution WITH bias (ResNetBlock.conv1, buildingblocks.py:248-255).  x (N,V,Cin), w (Cout,Cin), y (N,V,Cout),
+ * all NDHWC; out_stats as in u3d_conv3d (feeds conv2's GroupNorm).
+ * bwd: dx (nullable) = dy * w; acc double[Cout*Cin + Cout] += (dw, db) — zeroed scratch, convert with u3d_cvt_f64_f32. */
+int u3d_conv1x1_fwd(int device, u3d_stream_t stream, const float* x, const float* w, const float* bias, float* y, int N,
+                    int64_t V, int Cin, int Cout, double* out_stats);
+int u3d_conv1x1_bwd(int device, u3d_stream_t stream, const float* dy, const float* x, const float* w, int N, int64_t V,
+                    int Cin, int Cout, float* dx, double* acc);
+/* nn.ConvTranspose3d(Cin, Cout, kernel_size=3, stride=2, padding=1, bias=False) (buildingblocks.py:653-662):
+ * x (N,D1,H1,W1,Cin) -> t (N,2D1-1,2H1-1,2W1-1,Cout); w in the reference layout (Cin,Cout,3,3,3).
+ * bwd: dx (nullable) = stride-2 convolution of dt, masked by x > 0 when relu_mask; acc double[Cin*Cout*27] += dw. */
+int u3d_convtr3d_fwd(int device, u3d_stream_t stream, const float* x, const float* w, float* t, int N, int D1, int H1,
+                     int W1, int Cin, int Cout);
+int u3d_convtr3d_bwd(int device, u3d_stream_t stream, const float* dt, const float* x, const float* w, int N, int D1,
+                     int H1, int W1, int Cin, int Cout, int relu_mask, float* dx, double* acc);
+/* F.interpolate(t, size=skip.shape[2:]) (nearest, buildingblocks.py:650-651) + summation joining (:493):
+ * out = skip + t[zmap[z], ymap[y], xmap[x]], out_stats as in u3d_conv3d.  bwd: dt[s] = sum of dj over the voxels mapped to
+ * s (lo tables of length Dt+1 / Ht+1 / Wt+1: children of s are [lo[s], lo[s+1])); the skip's gradient is dj itself. */
+int u3d_nearest_add_fwd(int device, u3d_stream_t stream, const float* skip, const float* t, const int32_t* zmap,
+                        const int32_t* ymap, const int32_t* xmap, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C,
+                        float* out, double* out_stats);
+int u3d_nearest_sum_bwd(int device, u3d_stream_t stream, const float* dj, const int32_t* zlo, const int32_t* ylo,
+                        const int32_t* xlo, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C, float* dt);
 
 /* ---- BCEDiceLoss / DiceLoss / BCEWithLogitsLoss on the logits (losses.py:187-201, :84-127, :11-37) ------------
  * loss = w_bce * mean(BCE-with-logits) + w_dice * (1 - mean_c dice_c),

@@ -49,6 +49,7 @@ struct ConvParams {
     float* out;
     double* out_stats;
     double* gstats;
+    const float* res;  // optional residual (N,D,H,W,Cout) added before the ReLU (ResNetBlock, buildingblocks.py:285)
     int N, D, H, W, Cout;
     int nchunks, ncb, ntot;
     int tz, ty, tx;
@@ -353,14 +354,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvParams p)
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int bi = 0; bi < 4; ++bi) {
-                    float a0 = acc[mt][nt][4 * bi + 0], a1 = acc[mt][nt][4 * bi + 1];
-                    float a2 = acc[mt][nt][4 * bi + 2], a3 = acc[mt][nt][4 * bi + 3];
-                    if (p.relu) {
-                        a0 = fmaxf(a0, 0.f);
-                        a1 = fmaxf(a1, 0.f);
-                        a2 = fmaxf(a2, 0.f);
-                        a3 = fmaxf(a3, 0.f);
-                    }
+                    const float a0 = acc[mt][nt][4 * bi + 0], a1 = acc[mt][nt][4 * bi + 1];
+                    const float a2 = acc[mt][nt][4 * bi + 2], a3 = acc[mt][nt][4 * bi + 3];
                     const float t0 = xlane(a1, X1{}), t1 = xlane(a0, X1{}), t2 = xlane(a3, X1{}), t3 = xlane(a2, X1{});
                     const float c0 = odd ? t0 : a0, c1 = odd ? a1 : t1, c2 = odd ? t2 : a2, c3 = odd ? a3 : t3;
                     const float u0 = xlane(c2, X2{}), u2 = xlane(c0, X2{}), u1 = xlane(c3, X2{}), u3 = xlane(c1, X2{});
@@ -390,6 +385,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvParams p)
                     const bool ok = cok && z < D && y < H && x < W;
                     f32x4 val = tq[st];
                     const size_t vidx = (size_t)((n * D + z) * H + y) * W + x;
+                    if (p.res && ok) val += *reinterpret_cast<const f32x4*>(p.res + vidx * p.Cout + co);
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
+                    }
                     if (ok) *reinterpret_cast<f32x4*>(p.out + vidx * p.Cout + co) = val;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) val[e] = ok ? val[e] : 0.f;
@@ -453,6 +453,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvParams p)
                     const int co = (cb * NT + nt) * 32 + m;
                     const bool ok = vok && co < p.Cout;
                     float val = acc[mt][nt][r];
+                    if (p.res && ok) val += p.res[vidx * p.Cout + co];
                     if (p.relu) val = fmaxf(val, 0.f);
                     if (ok) p.out[vidx * p.Cout + co] = val;
                     const float vv = ok ? val : 0.f;
@@ -853,14 +854,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int bi = 0; bi < 4; ++bi) {
-                        float a0 = acc[mt][nt][4 * bi + 0], a1 = acc[mt][nt][4 * bi + 1];
-                        float a2 = acc[mt][nt][4 * bi + 2], a3 = acc[mt][nt][4 * bi + 3];
-                        if (p.relu) {
-                            a0 = fmaxf(a0, 0.f);
-                            a1 = fmaxf(a1, 0.f);
-                            a2 = fmaxf(a2, 0.f);
-                            a3 = fmaxf(a3, 0.f);
-                        }
+                        const float a0 = acc[mt][nt][4 * bi + 0], a1 = acc[mt][nt][4 * bi + 1];
+                        const float a2 = acc[mt][nt][4 * bi + 2], a3 = acc[mt][nt][4 * bi + 3];
                         const float t0 = xlane(a1, X1{}), t1 = xlane(a0, X1{}), t2 = xlane(a3, X1{}), t3 = xlane(a2, X1{});
                         const float c0 = odd ? t0 : a0, c1 = odd ? a1 : t1, c2 = odd ? t2 : a2, c3 = odd ? a3 : t3;
                         const float u0 = xlane(c2, X2{}), u2 = xlane(c0, X2{}), u1 = xlane(c3, X2{}), u3 = xlane(c1, X2{});
@@ -882,11 +877,20 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                             const int xi = xfrom0 ? vrow + st * W : xrow + (st >> 1) * p.gx.W1;
                             xv[k] = *reinterpret_cast<const f32x4*>(xb + (size_t)xi * xcs);
                         }
+                    } else if (p.res) {  // residual rows (same voxels / channels as the output rows)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            xv[k] = *reinterpret_cast<const f32x4*>(p.res + (size_t)(vrow + (4 * half + k) * W) * p.Cout + (cok ? co : 0));
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int st = 4 * half + k;
                         f32x4 val = tq[st];
+                        if (p.res) val += xv[k];
+                        if (p.relu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
+                        }
                         if (cok) *reinterpret_cast<f32x4*>(orow + (size_t)st * W * p.Cout) = val;
                         if (p.Cout % 32 != 0) {
 #pragma unroll
@@ -1513,9 +1517,26 @@ static int conv_set_lds_once(int device) {
     return 0;
 }
 
+static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w, float* out, int N,
+                       int D, int H, int W, int Cout, int relu, double* out_stats, const u3d_src_t* gx, double* gstats,
+                       const float* residual);
+
 extern "C" int u3d_conv3d(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w, float* out,
                           int N, int D, int H, int W, int Cout, int relu, double* out_stats, const u3d_src_t* gx,
                           double* gstats) {
+    return conv3d_impl(device, stream, src, packed_w, out, N, D, H, W, Cout, relu, out_stats, gx, gstats, nullptr);
+}
+
+extern "C" int u3d_conv3d_residual(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w,
+                                   float* out, int N, int D, int H, int W, int Cout, int relu, double* out_stats,
+                                   const float* residual) {
+    if (residual == nullptr) return u3d_set_err(U3D_EINVAL, "u3d_conv3d_residual: residual is NULL");
+    return conv3d_impl(device, stream, src, packed_w, out, N, D, H, W, Cout, relu, out_stats, nullptr, nullptr, residual);
+}
+
+static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w, float* out, int N,
+                       int D, int H, int W, int Cout, int relu, double* out_stats, const u3d_src_t* gx, double* gstats,
+                       const float* residual) {
     if (int e = u3d_enter(device)) return e;
     if (int e = check_src(src, "u3d_conv3d")) return e;
     U3D_REQUIRE(packed_w && out && N > 0 && D > 0 && H > 0 && W > 0 && Cout > 0, "u3d_conv3d: bad argument");
@@ -1537,6 +1558,7 @@ extern "C" int u3d_conv3d(int device, u3d_stream_t stream, const u3d_src_t* src,
     p.out = out;
     p.out_stats = out_stats;
     p.gstats = gstats;
+    p.res = residual;
     p.N = N, p.D = D, p.H = H, p.W = W, p.Cout = Cout;
     const int Cin = src->C0 + src->C1;
     p.nchunks = cdiv(Cin, 16);
@@ -1545,7 +1567,8 @@ extern "C" int u3d_conv3d(int device, u3d_stream_t stream, const u3d_src_t* src,
     p.relu = relu;
     p.vec = src_vec_ok(src) ? 1 : 0;
     // wide (16-byte) epilogue: whole channel quads, aligned output and (for dgrad) an x source readable in quads
-    p.ovec = (Cout % 4 == 0 && ((uintptr_t)out & 15) == 0 && (!gx || src_vec_ok(gx))) ? 1 : 0;
+    p.ovec = (Cout % 4 == 0 && ((uintptr_t)out & 15) == 0 && (!gx || src_vec_ok(gx)) &&
+              (!residual || ((uintptr_t)residual & 15) == 0)) ? 1 : 0;
     const long long ntiles = (long long)N * p.tz * p.ty * p.tx;
     // N-tiles per block: BN = 32*NT output channels share one staged A tile.  Larger NT = fewer re-stagings of the
     // same halo tile and fewer LDS reads per MFMA, at the price of registers (NT=1: 3 blocks/CU, NT>=2: 2 blocks/CU);

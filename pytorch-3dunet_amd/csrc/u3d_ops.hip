@@ -233,7 +233,7 @@ extern "C" int u3d_gn_bwd_finalize(int device, u3d_stream_t stream, const double
 template <bool VEC>
 __global__ void gn_bwd_apply_kernel(const float* __restrict__ dg, int Cdg, int coff, const float* __restrict__ x,
                                     int Cx, const float* __restrict__ coef, int Ctot, long long Vn, int N,
-                                    int relu_mask, float* __restrict__ out) {
+                                    int relu_mask, const float* __restrict__ add, float* __restrict__ out) {
     if (VEC) {
         const int Q = Cx >> 2;
         const long long total = (long long)N * Vn * Q;
@@ -249,6 +249,7 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ dg, int Cdg, int c
             const f32x4 q = *reinterpret_cast<const f32x4*>(coef + ((size_t)n * 3 + 1) * Ctot + coff + c);
             const f32x4 r = *reinterpret_cast<const f32x4*>(coef + ((size_t)n * 3 + 2) * Ctot + coff + c);
             f32x4 o = p * d + q * xv + r;
+            if (add) o += *reinterpret_cast<const f32x4*>(add + (size_t)v * Cx + c);
             if (relu_mask) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = xv[e] > 0.f ? o[e] : 0.f;
@@ -266,30 +267,48 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ dg, int Cdg, int c
             const float xv = x[idx];
             float o = coef[((size_t)n * 3 + 0) * Ctot + coff + c] * d + coef[((size_t)n * 3 + 1) * Ctot + coff + c] * xv +
                       coef[((size_t)n * 3 + 2) * Ctot + coff + c];
+            if (add) o += add[idx];
             if (relu_mask && !(xv > 0.f)) o = 0.f;
             out[idx] = o;
         }
     }
 }
 
+static int gn_bwd_apply_impl(int device, u3d_stream_t stream, const float* dg, int Cdg, int coff, const float* x, int Cx,
+                             const float* coef, int Ctot, int64_t voxels_per_n, int N, int relu_mask, const float* add,
+                             float* out);
+
 extern "C" int u3d_gn_bwd_apply(int device, u3d_stream_t stream, const float* dg, int Cdg, int coff, const float* x,
                                 int Cx, const float* coef, int Ctot, int64_t voxels_per_n, int N, int relu_mask,
                                 float* out) {
+    return gn_bwd_apply_impl(device, stream, dg, Cdg, coff, x, Cx, coef, Ctot, voxels_per_n, N, relu_mask, nullptr, out);
+}
+
+extern "C" int u3d_gn_bwd_apply_add(int device, u3d_stream_t stream, const float* dg, int Cdg, int coff, const float* x,
+                                    int Cx, const float* coef, int Ctot, int64_t voxels_per_n, int N, int relu_mask,
+                                    const float* add, float* out) {
+    if (add == nullptr) return u3d_set_err(U3D_EINVAL, "u3d_gn_bwd_apply_add: add is NULL");
+    return gn_bwd_apply_impl(device, stream, dg, Cdg, coff, x, Cx, coef, Ctot, voxels_per_n, N, relu_mask, add, out);
+}
+
+static int gn_bwd_apply_impl(int device, u3d_stream_t stream, const float* dg, int Cdg, int coff, const float* x, int Cx,
+                             const float* coef, int Ctot, int64_t voxels_per_n, int N, int relu_mask, const float* add,
+                             float* out) {
     if (int e = u3d_enter(device)) return e;
     U3D_REQUIRE(dg && x && coef && out && Cdg > 0 && Cx > 0 && coff >= 0 && coff + Cx <= Cdg && Ctot >= coff + Cx &&
                     voxels_per_n > 0 && N > 0,
                 "u3d_gn_bwd_apply: bad argument");
     const bool vec = (Cdg % 4 == 0) && (Cx % 4 == 0) && (coff % 4 == 0) && (Ctot % 4 == 0) &&
-                     (((uintptr_t)dg | (uintptr_t)x | (uintptr_t)coef | (uintptr_t)out) & 15) == 0;
+                     (((uintptr_t)dg | (uintptr_t)x | (uintptr_t)coef | (uintptr_t)out | (uintptr_t)add) & 15) == 0;
     if (vec) {
         const long long total = (long long)N * voxels_per_n * (Cx / 4);
         hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream,
-                           dg, Cdg, coff, x, Cx, coef, Ctot, (long long)voxels_per_n, N, relu_mask, out);
+                           dg, Cdg, coff, x, Cx, coef, Ctot, (long long)voxels_per_n, N, relu_mask, add, out);
     } else {
         const long long total = (long long)N * voxels_per_n * Cx;
         hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(grid_for(total, 16384)), dim3(256), 0,
                            (hipStream_t)stream, dg, Cdg, coff, x, Cx, coef, Ctot, (long long)voxels_per_n, N,
-                           relu_mask, out);
+                           relu_mask, add, out);
     }
     U3D_LAUNCH_CHECK();
     return 0;

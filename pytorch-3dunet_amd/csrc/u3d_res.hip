@@ -1,0 +1,536 @@
+// u3d_res.hip — the operators the residual U-Net variants add around the 3x3x3 convolutions
+// (ResidualUNet3D / ResidualUNetSE3D):
+//   * 1x1x1 convolution WITH bias that widens the block input (ResNetBlock.conv1, buildingblocks.py:248-255) fwd / bwd
+//   * ConvTranspose3d(k=3, stride=2, padding=1, bias=False) (TransposeConvUpsampling, buildingblocks.py:617-664) fwd / bwd
+//   * nearest resize of its (2n-1) output to the skip's size + summation joining (:650-651, :493) fwd / bwd
+// These are <7 % of the model's FLOPs (8.4 + 212 of 3675 GFLOP at BASELINE config 4).  They run as ONE generic
+// register-tiled "gather GEMM" on the FP32 vector units (64 rows x 64 outputs per block, 4x4 per thread, K-chunks of 16
+// through LDS): rows are output voxels on a regular sub-grid, each tap reads the input voxel row*stride + offset (zero
+// outside the tensor).  ConvTranspose3d is 8 such GEMMs, one per output parity class: an even output coordinate 2j
+// receives only tap 1 of input j, an odd one 2j+1 taps 0 and 2 of inputs j+1 and j — 1/2/4/8 taps per class, no
+// multiplications by the inserted zeros.  (An MFMA version of the 8 parity classes is the next step for this file.)
+#include "u3d_common.h"
+
+namespace gc {
+constexpr int TM = 64, TN = 64, TK = 16, LD = 68;  // LD: padded LDS row (keeps 16-byte alignment of the quads)
+}
+
+struct GConvParams {
+    const float* x;     // (N, Di, Hi, Wi, Ci)
+    const float* w;     // element (tap, in-channel i, out-channel j) at w[woff[tap] + i*wsi + j*wsj]
+    const float* bias;  // [Cj] or null
+    const float* mask;  // output-shaped or null: out = mask > 0 ? out : 0   (ReLU backward of the producer)
+    float* out;         // (N, Do, Ho, Wo, Cj)
+    double* stats;      // [N][Cj][2] += (sum, sum of squares) of the written values, or null
+    int N, Di, Hi, Wi, Ci, Do, Ho, Wo, Cj;
+    int Rz, Ry, Rx;        // row grid; output coordinate = r * os + oo, input coordinate of tap t = r * is + t?[t]
+    int osz, osy, osx, ooz, ooy, oox;
+    int isz, isy, isx;
+    int ntaps;
+    signed char tz[27], ty[27], tx[27];
+    int woff[27];
+    long long wsi, wsj;
+    int avec, ovec;
+};
+
+__global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
+    using namespace gc;
+    __shared__ __attribute__((aligned(16))) float As[TK][LD];  // [k][row]
+    __shared__ __attribute__((aligned(16))) float Bs[TK][LD];  // [k][out channel]
+    __shared__ float red[16][TN];
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    const int n = blockIdx.z, j0 = blockIdx.y * TN;
+    const long long R = (long long)p.Rz * p.Ry * p.Rx;
+    const int la = t >> 2, lq = t & 3;   // A-load role: row, channel quad of the 16-channel chunk
+    const int bci = t >> 4, bjq = t & 15;  // B-load role: chunk channel, out-channel quad
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long long tile = blockIdx.x; tile * TM < R; tile += gridDim.x) {
+        const long long ra = tile * TM + la;
+        const bool rok = ra < R;
+        int rz = 0, ry = 0, rx = 0;
+        if (rok) {
+            rx = (int)(ra % p.Rx);
+            const long long q = ra / p.Rx;
+            ry = (int)(q % p.Ry);
+            rz = (int)(q / p.Ry);
+        }
+        float acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+        for (int tap = 0; tap < p.ntaps; ++tap) {
+            const int iz = rz * p.isz + p.tz[tap], iy = ry * p.isy + p.ty[tap], ix = rx * p.isx + p.tx[tap];
+            const bool inb = rok && iz >= 0 && iz < p.Di && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+            const float* xrow = p.x + (inb ? ((size_t)((n * p.Di + iz) * p.Hi + iy) * p.Wi + ix) * p.Ci : 0);
+            const float* wt = p.w + p.woff[tap];
+            for (int c0 = 0; c0 < p.Ci; c0 += TK) {
+                f32x4 av = {0.f, 0.f, 0.f, 0.f};
+                const int ca = c0 + 4 * lq;
+                if (inb) {
+                    if (p.avec && ca + 3 < p.Ci) {
+                        av = *reinterpret_cast<const f32x4*>(xrow + ca);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (ca + e < p.Ci) av[e] = xrow[ca + e];
+                    }
+                }
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                const int cb = c0 + bci;
+                if (cb < p.Ci) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int j = j0 + 4 * bjq + e;
+                        if (j < p.Cj) bv[e] = wt[(size_t)cb * p.wsi + (size_t)j * p.wsj];
+                    }
+                }
+                __syncthreads();  // the previous chunk's reads are done
+#pragma unroll
+                for (int e = 0; e < 4; ++e) As[4 * lq + e][la] = av[e];
+                *reinterpret_cast<f32x4*>(&Bs[bci][4 * bjq]) = bv;
+                __syncthreads();
+#pragma unroll
+                for (int kk = 0; kk < TK; ++kk) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(&As[kk][4 * ty]);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[kk][4 * tx]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][e] = fmaf(a[i], b[e], acc[i][e]);
+                }
+            }
+        }
+        // ---- epilogue: rows tile*TM + 4*ty + i, out channels j0 + 4*tx + e
+        const int jb = j0 + 4 * tx;
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (jb + e < p.Cj) bias[e] = p.bias[jb + e];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long r = tile * TM + 4 * ty + i;
+            if (r >= R || jb >= p.Cj) continue;
+            const int ox = (int)(r % p.Rx) * p.osx + p.oox;
+            const long long q = r / p.Rx;
+            const int oy = (int)(q % p.Ry) * p.osy + p.ooy;
+            const int oz = (int)(q / p.Ry) * p.osz + p.ooz;
+            const size_t o = ((size_t)((n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.Cj + jb;
+            f32x4 val;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) val[e] = acc[i][e] + bias[e];
+            if (p.ovec && jb + 3 < p.Cj) {
+                if (p.mask) {
+                    const f32x4 m = *reinterpret_cast<const f32x4*>(p.mask + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] = m[e] > 0.f ? val[e] : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(p.out + o) = val;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (jb + e < p.Cj) {
+                        if (p.mask && !(p.mask[o + e] > 0.f)) val[e] = 0.f;
+                        p.out[o + e] = val[e];
+                    } else {
+                        val[e] = 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s1[e] += val[e];
+                s2[e] += val[e] * val[e];
+            }
+        }
+    }
+    if (p.stats) {
+        // over the 16 row groups (ty) of a column through LDS, fixed order; one f64 atomic per (n, channel) and block
+        for (int pass = 0; pass < 2; ++pass) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[ty][4 * tx + e] = pass == 0 ? s1[e] : s2[e];
+            __syncthreads();
+            if (t < TN) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) s += (double)red[k][t];
+                const int j = j0 + t;
+                if (j < p.Cj) u3d_atomic_add_f64(&p.stats[((size_t)n * p.Cj + j) * 2 + pass], s);
+            }
+        }
+    }
+}
+
+// ---- weight-gradient twin: acc[tap*dst_t + a*dst_a + b*dst_b] += sum_rows X[row, a] * Y[ycoord(row, tap), b]
+struct GWgradParams {
+    const float* X;  // (N, Rz, Ry, Rx, Ca)
+    const float* Y;  // (N, Dy, Hy, Wy, Cb); coordinate of tap t = r * ys + t?[t], zero outside
+    double* acc;
+    double* bias_acc;  // optional [Cb] += sum_rows Y[row, b] (tap 0 only)
+    int N, Ca, Cb;
+    int Rz, Ry, Rx, Dy, Hy, Wy, ysz, ysy, ysx;
+    int ntaps;
+    signed char tz[27], ty[27], tx[27];
+    long long dst_t, dst_a, dst_b;
+    int atiles, btiles;
+    long long rows_per_split;
+    int xvec, yvec;
+};
+
+__global__ __launch_bounds__(256) void gwgrad_kernel(const GWgradParams p) {
+    using namespace gc;
+    __shared__ __attribute__((aligned(16))) float Xs[TK][LD];
+    __shared__ __attribute__((aligned(16))) float Ys[TK][LD];
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    const int a0 = (blockIdx.x % p.atiles) * TM, b0 = (blockIdx.x / p.atiles) * TN;
+    const int tap = blockIdx.y;
+    const long long R = (long long)p.Rz * p.Ry * p.Rx, total = (long long)p.N * R;
+    const long long r_begin = (long long)blockIdx.z * p.rows_per_split;
+    const long long r_end = r_begin + p.rows_per_split < total ? r_begin + p.rows_per_split : total;
+    const int lr = t >> 4, lqd = t & 15;  // load role: row of the 16-row chunk, channel quad
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool want_bias = p.bias_acc != nullptr && tap == 0 && a0 == 0;
+    for (long long rc = r_begin; rc < r_end; rc += TK) {
+        const long long row = rc + lr;
+        f32x4 xv = {0.f, 0.f, 0.f, 0.f}, yv = {0.f, 0.f, 0.f, 0.f};
+        if (row < r_end) {
+            const int n = (int)(row / R);
+            const long long r = row - (long long)n * R;
+            const int rx = (int)(r % p.Rx);
+            const long long q = r / p.Rx;
+            const int ry = (int)(q % p.Ry), rz = (int)(q / p.Ry);
+            const int ca = a0 + 4 * lqd;
+            const float* xr = p.X + (size_t)row * p.Ca;
+            if (p.xvec && ca + 3 < p.Ca) {
+                xv = *reinterpret_cast<const f32x4*>(xr + ca);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (ca + e < p.Ca) xv[e] = xr[ca + e];
+            }
+            const int yz = rz * p.ysz + p.tz[tap], yy = ry * p.ysy + p.ty[tap], yx = rx * p.ysx + p.tx[tap];
+            if (yz >= 0 && yz < p.Dy && yy >= 0 && yy < p.Hy && yx >= 0 && yx < p.Wy) {
+                const float* yr = p.Y + ((size_t)((n * p.Dy + yz) * p.Hy + yy) * p.Wy + yx) * p.Cb;
+                const int cb = b0 + 4 * lqd;
+                if (p.yvec && cb + 3 < p.Cb) {
+                    yv = *reinterpret_cast<const f32x4*>(yr + cb);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (cb + e < p.Cb) yv[e] = yr[cb + e];
+                }
+            }
+        }
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(&Xs[lr][4 * lqd]) = xv;
+        *reinterpret_cast<f32x4*>(&Ys[lr][4 * lqd]) = yv;
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < TK; ++kk) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&Xs[kk][4 * ty]);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(&Ys[kk][4 * tx]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][e] = fmaf(a[i], b[e], acc[i][e]);
+            if (want_bias && ty == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bsum[e] += b[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int a = a0 + 4 * ty + i;
+        if (a >= p.Ca) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int b = b0 + 4 * tx + e;
+            if (b < p.Cb) u3d_atomic_add_f64(&p.acc[(size_t)tap * p.dst_t + (size_t)a * p.dst_a + (size_t)b * p.dst_b], (double)acc[i][e]);
+        }
+    }
+    if (want_bias && ty == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int b = b0 + 4 * tx + e;
+            if (b < p.Cb) u3d_atomic_add_f64(&p.bias_acc[b], (double)bsum[e]);
+        }
+    }
+}
+
+// ---- nearest resize + summation joining: out = skip + t[map(voxel)]  (+ per-(n,channel) statistics of out) ----------
+__global__ __launch_bounds__(256) void nearest_add_kernel(const float* __restrict__ skip, const float* __restrict__ tt,
+                                                          const int* __restrict__ zmap, const int* __restrict__ ymap,
+                                                          const int* __restrict__ xmap, int D, int H, int W, int Dt, int Ht,
+                                                          int Wt, int C, int Q, int vecw, float* __restrict__ out,
+                                                          double* __restrict__ stats) {
+    // thread -> (row = t / Q, unit = t % Q); a unit is vecw (4 or 1) channels; rows stride the block's voxel range
+    extern __shared__ double sred[];  // [Q*vecw][2]
+    const int n = blockIdx.y;
+    const int t = threadIdx.x;
+    const int rows = 256 / Q;
+    const int unit = t % Q, row = t / Q;
+    const bool active = row < rows;
+    for (int k = t; k < 2 * Q * vecw; k += 256) sred[k] = 0.0;
+    __syncthreads();
+    const long long V = (long long)D * H * W;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        for (long long v = (long long)blockIdx.x * rows + row; v < V; v += (long long)gridDim.x * rows) {
+            const int x = (int)(v % W);
+            const long long q = v / W;
+            const int y = (int)(q % H), z = (int)(q / H);
+            const size_t o = ((size_t)n * V + v) * C + (size_t)unit * vecw;
+            const size_t ti = ((size_t)((n * Dt + zmap[z]) * Ht + ymap[y]) * Wt + xmap[x]) * C + (size_t)unit * vecw;
+            if (vecw == 4) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(skip + o);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(tt + ti);
+                const f32x4 r = a + b;
+                *reinterpret_cast<f32x4*>(out + o) = r;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s1[e] += r[e];
+                    s2[e] += r[e] * r[e];
+                }
+            } else {
+                const float r = skip[o] + tt[ti];
+                out[o] = r;
+                s1[0] += r;
+                s2[0] += r * r;
+            }
+        }
+    }
+    if (stats) {
+        if (active) {
+            for (int e = 0; e < vecw; ++e) {
+                __hip_atomic_fetch_add(&sred[(unit * vecw + e) * 2], (double)s1[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&sred[(unit * vecw + e) * 2 + 1], (double)s2[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __syncthreads();
+        for (int k = t; k < 2 * C; k += 256) u3d_atomic_add_f64(&stats[(size_t)n * C * 2 + k], sred[k]);
+    }
+}
+
+// dt[s] = sum of dj over the children of s (voxels o with map(o) == s): lo tables of length Dt+1 / Ht+1 / Wt+1
+__global__ void nearest_sum_kernel(const float* __restrict__ dj, const int* __restrict__ zlo, const int* __restrict__ ylo,
+                                   const int* __restrict__ xlo, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C,
+                                   float* __restrict__ dt) {
+    const long long total = (long long)N * Dt * Ht * Wt * C;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        long long v = idx / C;
+        const int xx = (int)(v % Wt);
+        v /= Wt;
+        const int yy = (int)(v % Ht);
+        v /= Ht;
+        const int zz = (int)(v % Dt);
+        const int n = (int)(v / Dt);
+        float sum = 0.f;
+        for (int z = zlo[zz]; z < zlo[zz + 1]; ++z)
+            for (int y = ylo[yy]; y < ylo[yy + 1]; ++y)
+                for (int x = xlo[xx]; x < xlo[xx + 1]; ++x) sum += dj[((size_t)((n * D + z) * H + y) * W + x) * C + c];
+        dt[idx] = sum;
+    }
+}
+
+// =====================================================================================================================
+static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+static int launch_gconv(GConvParams& p, hipStream_t st) {
+    const long long R = (long long)p.Rz * p.Ry * p.Rx;
+    if (R <= 0) return 0;
+    long long tiles = (R + gc::TM - 1) / gc::TM;
+    const int jt = (p.Cj + gc::TN - 1) / gc::TN;
+    // persistent over row tiles when statistics are accumulated (few atomics); otherwise one tile per block
+    long long gx = tiles;
+    const long long cap = p.stats ? (2048 / ((long long)jt * p.N) > 1 ? 2048 / ((long long)jt * p.N) : 1) : 65535 * 16;
+    if (gx > cap) gx = cap;
+    if (gx > 2147483647ll) gx = 2147483647ll;
+    p.avec = (p.Ci % 4 == 0 && al16(p.x)) ? 1 : 0;
+    p.ovec = (p.Cj % 4 == 0 && al16(p.out) && (!p.mask || al16(p.mask))) ? 1 : 0;
+    hipLaunchKernelGGL(gconv_kernel, dim3((unsigned)gx, (unsigned)jt, (unsigned)p.N), dim3(256), 0, st, p);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+static int launch_gwgrad(GWgradParams& p, hipStream_t st) {
+    const long long total = (long long)p.N * p.Rz * p.Ry * p.Rx;
+    if (total <= 0) return 0;
+    p.atiles = (p.Ca + gc::TM - 1) / gc::TM;
+    p.btiles = (p.Cb + gc::TN - 1) / gc::TN;
+    const long long blocks = (long long)p.atiles * p.btiles * p.ntaps;
+    long long S = 2048 / blocks;  // ~8 blocks per CU in total
+    if (S < 1) S = 1;
+    const long long maxS = (total + 255) / 256;  // at least 256 rows per split
+    if (S > maxS) S = maxS;
+    if (S > 65535) S = 65535;
+    long long rps = (total + S - 1) / S;
+    rps = (rps + gc::TK - 1) / gc::TK * gc::TK;
+    S = (total + rps - 1) / rps;
+    p.rows_per_split = rps;
+    p.xvec = (p.Ca % 4 == 0 && al16(p.X)) ? 1 : 0;
+    p.yvec = (p.Cb % 4 == 0 && al16(p.Y)) ? 1 : 0;
+    hipLaunchKernelGGL(gwgrad_kernel, dim3((unsigned)(p.atiles * p.btiles), (unsigned)p.ntaps, (unsigned)S), dim3(256), 0, st, p);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- 1x1x1 convolution with bias --------------------------------------------------------------------------------------
+extern "C" int u3d_conv1x1_fwd(int device, u3d_stream_t stream, const float* x, const float* w, const float* bias, float* y,
+                               int N, int64_t V, int Cin, int Cout, double* out_stats) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(x && w && y && N > 0 && V > 0 && Cin > 0 && Cout > 0, "u3d_conv1x1_fwd: bad argument");
+    U3D_REQUIRE(V < (1ll << 31) && (long long)N * V < (1ll << 31), "u3d_conv1x1_fwd: N*V must be < 2^31");
+    GConvParams p{};
+    p.x = x, p.w = w, p.bias = bias, p.mask = nullptr, p.out = y, p.stats = out_stats;
+    p.N = N, p.Di = 1, p.Hi = 1, p.Wi = (int)V, p.Ci = Cin, p.Do = 1, p.Ho = 1, p.Wo = (int)V, p.Cj = Cout;
+    p.Rz = 1, p.Ry = 1, p.Rx = (int)V;
+    p.osz = p.osy = p.osx = 1, p.ooz = p.ooy = p.oox = 0, p.isz = p.isy = p.isx = 1;
+    p.ntaps = 1, p.tz[0] = p.ty[0] = p.tx[0] = 0;
+    p.woff[0] = 0, p.wsi = 1, p.wsj = Cin;  // w[cout][cin]
+    return launch_gconv(p, (hipStream_t)stream);
+}
+
+extern "C" int u3d_conv1x1_bwd(int device, u3d_stream_t stream, const float* dy, const float* x, const float* w, int N,
+                               int64_t V, int Cin, int Cout, float* dx, double* acc) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(dy && x && w && acc && N > 0 && V > 0 && Cin > 0 && Cout > 0, "u3d_conv1x1_bwd: bad argument");
+    U3D_REQUIRE(V < (1ll << 31) && (long long)N * V < (1ll << 31), "u3d_conv1x1_bwd: N*V must be < 2^31");
+    hipStream_t st = (hipStream_t)stream;
+    if (dx) {  // dx[v, c] = sum_k dy[v, k] * w[k][c]
+        GConvParams p{};
+        p.x = dy, p.w = w, p.bias = nullptr, p.mask = nullptr, p.out = dx, p.stats = nullptr;
+        p.N = N, p.Di = 1, p.Hi = 1, p.Wi = (int)V, p.Ci = Cout, p.Do = 1, p.Ho = 1, p.Wo = (int)V, p.Cj = Cin;
+        p.Rz = 1, p.Ry = 1, p.Rx = (int)V;
+        p.osz = p.osy = p.osx = 1, p.ooz = p.ooy = p.oox = 0, p.isz = p.isy = p.isx = 1;
+        p.ntaps = 1, p.tz[0] = p.ty[0] = p.tx[0] = 0;
+        p.woff[0] = 0, p.wsi = Cin, p.wsj = 1;
+        if (int e = launch_gconv(p, st)) return e;
+    }
+    // dw[k][c] = sum_v dy[v,k] * x[v,c] -> acc[k*Cin + c];  db[k] = sum_v dy[v,k] -> acc[Cout*Cin + k]
+    GWgradParams g{};
+    g.X = x, g.Y = dy, g.acc = acc, g.bias_acc = acc + (size_t)Cout * Cin;
+    g.N = N, g.Ca = Cin, g.Cb = Cout;
+    g.Rz = 1, g.Ry = 1, g.Rx = (int)V, g.Dy = 1, g.Hy = 1, g.Wy = (int)V, g.ysz = g.ysy = g.ysx = 1;
+    g.ntaps = 1, g.tz[0] = g.ty[0] = g.tx[0] = 0;
+    g.dst_t = 0, g.dst_a = 1, g.dst_b = Cin;
+    return launch_gwgrad(g, st);
+}
+
+// ---- ConvTranspose3d(k=3, stride=2, padding=1, bias=False): (N,D1,H1,W1,Cin) -> (N,2D1-1,2H1-1,2W1-1,Cout) ------------
+// weight layout of nn.ConvTranspose3d: (Cin, Cout, 3, 3, 3); output coordinate s = 2i - 1 + t per dimension, so an even
+// s = 2j takes (input j, tap 1) and an odd s = 2j+1 takes (input j+1, tap 0) and (input j, tap 2).
+static int parity_taps(int pz, int py, int px, signed char* tz, signed char* ty, signed char* tx, int* woff) {
+    static const int offs[2][2] = {{0, 0}, {1, 0}}, taps[2][2] = {{1, 1}, {0, 2}};
+    int n = 0;
+    for (int a = 0; a <= pz; ++a)
+        for (int b = 0; b <= py; ++b)
+            for (int c = 0; c <= px; ++c) {
+                tz[n] = (signed char)offs[pz][a], ty[n] = (signed char)offs[py][b], tx[n] = (signed char)offs[px][c];
+                woff[n] = (taps[pz][a] * 3 + taps[py][b]) * 3 + taps[px][c];
+                ++n;
+            }
+    return n;
+}
+
+extern "C" int u3d_convtr3d_fwd(int device, u3d_stream_t stream, const float* x, const float* w, float* t, int N, int D1,
+                                int H1, int W1, int Cin, int Cout) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(x && w && t && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && Cin > 0 && Cout > 0, "u3d_convtr3d_fwd: bad argument");
+    const int Dt = 2 * D1 - 1, Ht = 2 * H1 - 1, Wt = 2 * W1 - 1;
+    U3D_REQUIRE((long long)N * Dt * Ht * Wt < (1ll << 31), "u3d_convtr3d_fwd: output voxel count must be < 2^31");
+    hipStream_t st = (hipStream_t)stream;
+    for (int cls = 0; cls < 8; ++cls) {  // one gather GEMM per output parity class
+        const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+        GConvParams p{};
+        p.x = x, p.w = w, p.bias = nullptr, p.mask = nullptr, p.out = t, p.stats = nullptr;
+        p.N = N, p.Di = D1, p.Hi = H1, p.Wi = W1, p.Ci = Cin, p.Do = Dt, p.Ho = Ht, p.Wo = Wt, p.Cj = Cout;
+        p.Rz = D1 - pz, p.Ry = H1 - py, p.Rx = W1 - px;  // s = 2j + p <= 2n - 2
+        if (p.Rz <= 0 || p.Ry <= 0 || p.Rx <= 0) continue;
+        p.osz = p.osy = p.osx = 2, p.ooz = pz, p.ooy = py, p.oox = px, p.isz = p.isy = p.isx = 1;
+        p.ntaps = parity_taps(pz, py, px, p.tz, p.ty, p.tx, p.woff);
+        p.wsi = (long long)Cout * 27, p.wsj = 27;  // element (ci, co, tap) at w[(ci*Cout + co)*27 + tap]
+        if (int e = launch_gconv(p, st)) return e;
+    }
+    return 0;
+}
+
+// dt: gradient w.r.t. the transposed conv's output (N,2D1-1,2H1-1,2W1-1,Cout).
+//   dx[i, ci]      = sum_{t, co} dt[2i - 1 + t, co] * w[ci, co, t]      (a stride-2 3x3x3 convolution of dt), masked by
+//                    x > 0 when relu_mask (x is the post-ReLU output of the block that produced it)
+//   acc[(ci*Cout + co)*27 + t] += sum_i x[i, ci] * dt[2i - 1 + t, co]   (zeroed double scratch; u3d_cvt_f64_f32)
+extern "C" int u3d_convtr3d_bwd(int device, u3d_stream_t stream, const float* dt, const float* x, const float* w, int N,
+                                int D1, int H1, int W1, int Cin, int Cout, int relu_mask, float* dx, double* acc) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(dt && x && w && acc && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && Cin > 0 && Cout > 0, "u3d_convtr3d_bwd: bad argument");
+    const int Dt = 2 * D1 - 1, Ht = 2 * H1 - 1, Wt = 2 * W1 - 1;
+    U3D_REQUIRE((long long)N * Dt * Ht * Wt < (1ll << 31), "u3d_convtr3d_bwd: output voxel count must be < 2^31");
+    hipStream_t st = (hipStream_t)stream;
+    if (dx) {
+        GConvParams p{};
+        p.x = dt, p.w = w, p.bias = nullptr, p.mask = relu_mask ? x : nullptr, p.out = dx, p.stats = nullptr;
+        p.N = N, p.Di = Dt, p.Hi = Ht, p.Wi = Wt, p.Ci = Cout, p.Do = D1, p.Ho = H1, p.Wo = W1, p.Cj = Cin;
+        p.Rz = D1, p.Ry = H1, p.Rx = W1;
+        p.osz = p.osy = p.osx = 1, p.ooz = p.ooy = p.oox = 0, p.isz = p.isy = p.isx = 2;
+        p.ntaps = 27;
+        for (int tp = 0; tp < 27; ++tp) {
+            p.tz[tp] = (signed char)(tp / 9 - 1), p.ty[tp] = (signed char)((tp / 3) % 3 - 1), p.tx[tp] = (signed char)(tp % 3 - 1);
+            p.woff[tp] = tp;
+        }
+        p.wsi = 27, p.wsj = (long long)Cout * 27;  // (tap, in = co, out = ci) at w[(ci*Cout + co)*27 + tap]
+        if (int e = launch_gconv(p, st)) return e;
+    }
+    GWgradParams g{};
+    g.X = x, g.Y = dt, g.acc = acc, g.bias_acc = nullptr;
+    g.N = N, g.Ca = Cin, g.Cb = Cout;
+    g.Rz = D1, g.Ry = H1, g.Rx = W1, g.Dy = Dt, g.Hy = Ht, g.Wy = Wt, g.ysz = g.ysy = g.ysx = 2;
+    g.ntaps = 27;
+    for (int tp = 0; tp < 27; ++tp)
+        g.tz[tp] = (signed char)(tp / 9 - 1), g.ty[tp] = (signed char)((tp / 3) % 3 - 1), g.tx[tp] = (signed char)(tp % 3 - 1);
+    g.dst_t = 1, g.dst_a = (long long)Cout * 27, g.dst_b = 27;
+    return launch_gwgrad(g, st);
+}
+
+// ---- nearest resize to the skip's size + summation joining (buildingblocks.py:650-651 + :493) ---------------------------
+extern "C" int u3d_nearest_add_fwd(int device, u3d_stream_t stream, const float* skip, const float* t, const int32_t* zmap,
+                                   const int32_t* ymap, const int32_t* xmap, int N, int D, int H, int W, int Dt, int Ht,
+                                   int Wt, int C, float* out, double* out_stats) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(skip && t && zmap && ymap && xmap && out && N > 0 && D > 0 && H > 0 && W > 0 && Dt > 0 && Ht > 0 && Wt > 0 &&
+                    C > 0 && C <= 1024,
+                "u3d_nearest_add_fwd: bad argument (C <= 1024)");
+    const int vecw = (C % 4 == 0 && al16(skip) && al16(t) && al16(out)) ? 4 : 1;
+    int Q = C / vecw;
+    U3D_REQUIRE(Q <= 256, "u3d_nearest_add_fwd: more than 256 channel units per voxel (C %% 4 != 0 with C > 256)");
+    const int rows = 256 / Q;
+    const long long V = (long long)D * H * W;
+    long long bx = (V + rows - 1) / rows;
+    const long long cap = 2048 / N > 1 ? 2048 / N : 1;
+    if (bx > cap) bx = cap;
+    hipLaunchKernelGGL(nearest_add_kernel, dim3((unsigned)bx, (unsigned)N), dim3(256), sizeof(double) * 2 * (size_t)C,
+                       (hipStream_t)stream, skip, t, zmap, ymap, xmap, D, H, W, Dt, Ht, Wt, C, Q, vecw, out, out_stats);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int u3d_nearest_sum_bwd(int device, u3d_stream_t stream, const float* dj, const int32_t* zlo, const int32_t* ylo,
+                                   const int32_t* xlo, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C, float* dt) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(dj && zlo && ylo && xlo && dt && N > 0 && C > 0, "u3d_nearest_sum_bwd: bad argument");
+    const long long total = (long long)N * Dt * Ht * Wt * C;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(nearest_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dj, zlo, ylo, xlo, N, D, H,
+                       W, Dt, Ht, Wt, C, dt);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}

@@ -129,8 +129,11 @@ extern "C" int u3d_conv3d_small_cin_fwd(int device, u3d_stream_t stream, const f
 
 // -------------------------------------------------------------------------------------------------------------
 // backward: partial[n][b][(k*27 + tap)*(Cin+1) + c]  (c == Cin is the T slot).  grid (B, N); a block walks tiles
-// b, b+B, ... of sample n.  256 threads = 16 k-lanes x 16 tap-groups; thread (kq, tg) owns taps {tg, tg+16} and output
-// channels {kq, kq+16}.
+// b, b+B, ... of sample n.  The contraction  P[k][(tap,c)] = sum_u dz[u,k] * xs[u + tap][c]  (xs = raw x with an
+// in-bounds indicator as channel Cin, zero outside the volume) is a GEMM with M = Cout, N = 27*(Cin+1), K = voxels: it
+// runs on v_mfma_f32_16x16x4_f32 (A[i = k][kk = voxel] straight from global dz, B[kk = voxel][j = column] from the LDS
+// halo tile).  Wave w owns z-plane w of the 4x8x8 tile = 16 k-steps of 4 consecutive x; the four waves' sums are folded in a
+// fixed order at the end of the block, the finalize kernel adds the blocks' partials in a fixed order.
 struct SmallBwdParams {
     const float* x;   // raw input (N,D,H,W,Cin)
     const float* dz;  // (N,D,H,W,Cout)
@@ -139,25 +142,33 @@ struct SmallBwdParams {
     int tz, ty, tx, B;
 };
 
-template <int KH>  // output channels per thread: k = kq + 16*a, a < KH  (KH = 1 for Cout <= 16)
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+
+template <int CIN, int RT>  // RT = row tiles of 16 output channels (Cout <= 16*RT)
 __global__ __launch_bounds__(256) void conv3d_small_bwd_kernel(const SmallBwdParams p) {
     using namespace sc;
-    __shared__ float xs[HV * (MAXC + 1)];  // [hv][Cin+1]: raw x, then the in-bounds indicator
-    __shared__ float dzs[256 * 16 * KH];   // [voxel][k] (k < 16*KH)
-    const int t = threadIdx.x;
+    constexpr int C1 = CIN + 1;
+    constexpr int NCOL = 27 * C1;
+    constexpr int NCT = (NCOL + 15) / 16;
+    __shared__ float xs[HV * C1];  // [hv][CIN+1]: raw x, then the in-bounds indicator
+    const int t = threadIdx.x, l = t & 63, w = t >> 6;
     const int n = blockIdx.y;
-    const int kq = t & 15, tg = t >> 4;
-    const int Cin = p.Cin, C1 = p.Cin + 1, Cout = p.Cout, D = p.D, H = p.H, W = p.W;
-    float acc[KH][2][MAXC + 1];  // [k half][tap slot][c]
+    const int j = l & 15, kk = l >> 4;
+    const int Cout = p.Cout, D = p.D, H = p.H, W = p.W;
+    int boff[NCT];
 #pragma unroll
-    for (int a = 0; a < KH; ++a)
+    for (int ct = 0; ct < NCT; ++ct) {
+        const int col = ct * 16 + j;
+        const int tap = col / C1, c = col - tap * C1;
+        const int off = (tap / 9) * (HY * HX) + ((tap / 3) % 3) * HX + tap % 3;
+        boff[ct] = col < NCOL ? off * C1 + c : 0;  // dead columns read column 0; never written out
+    }
+    const int bbase = (w * (HY * HX) + kk) * C1;
+    f32x4s acc[RT][NCT];
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int c = 0; c <= MAXC; ++c) acc[a][b][c] = 0.f;
-    const int tap0 = tg, tap1 = tg + 16;  // tap1 valid if < 27
-    const int off0 = (tap0 / 9) * (HY * HX) + ((tap0 / 3) % 3) * HX + tap0 % 3;
-    const int off1 = tap1 < 27 ? (tap1 / 9) * (HY * HX) + ((tap1 / 3) % 3) * HX + tap1 % 3 : 0;
+        for (int ct = 0; ct < NCT; ++ct) acc[rt][ct] = f32x4s{0.f, 0.f, 0.f, 0.f};
     const int ntiles = p.tz * p.ty * p.tx;
     for (int tile = blockIdx.x; tile < ntiles; tile += p.B) {
         int tt = tile;
@@ -166,59 +177,83 @@ __global__ __launch_bounds__(256) void conv3d_small_bwd_kernel(const SmallBwdPar
         const int tyi = tt % p.ty;
         const int tzi = tt / p.ty;
         const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
-        __syncthreads();
+        // A operands of the whole tile: dz[voxel(step, kk)][k = j + 16*rt], zero outside the volume / beyond Cout
+        float a[RT][16];
+        {
+            const int z = z0 + w;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int y = y0 + (s >> 1), x = x0 + (s & 1) * 4 + kk;
+                const bool vin = z < D && y < H && x < W;
+                const size_t vox = (size_t)((n * D + (vin ? z : 0)) * H + (vin ? y : 0)) * W + (vin ? x : 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const int k = j + 16 * rt;
+                    const float v = p.dz[vox * Cout + (k < Cout ? k : 0)];
+                    a[rt][s] = (vin && k < Cout) ? v : 0.f;
+                }
+            }
+        }
+        __syncthreads();  // previous tile's B reads are done
         for (int i = t; i < HV; i += 256) {
             const int hz = i / (HY * HX), rem = i - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
             const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
             const bool in = gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            const float* src = p.x + ((size_t)((n * D + (in ? gz : 0)) * H + (in ? gy : 0)) * W + (in ? gx : 0)) * Cin;
-            for (int c = 0; c < Cin; ++c) xs[i * C1 + c] = in ? src[c] : 0.f;
-            xs[i * C1 + Cin] = in ? 1.f : 0.f;
-        }
-        constexpr int KW = 16 * KH;
-        for (int i = t; i < 256 * KW; i += 256) {
-            const int k = i % KW, v = i / KW;
-            const int z = z0 + (v >> 6), y = y0 + ((v >> 3) & 7), x = x0 + (v & 7);
-            float val = 0.f;
-            if (k < Cout && z < D && y < H && x < W) val = p.dz[((size_t)((n * D + z) * H + y) * W + x) * Cout + k];
-            dzs[i] = val;
+            const float* src = p.x + ((size_t)((n * D + (in ? gz : 0)) * H + (in ? gy : 0)) * W + (in ? gx : 0)) * CIN;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) xs[i * C1 + c] = in ? src[c] : 0.f;
+            xs[i * C1 + CIN] = in ? 1.f : 0.f;
         }
         __syncthreads();
-#pragma unroll 8
-        for (int v = 0; v < 256; ++v) {
-            const int hb = (v >> 6) * (HY * HX) + ((v >> 3) & 7) * HX + (v & 7);
-            float d[KH];
 #pragma unroll
-            for (int a = 0; a < KH; ++a) d[a] = dzs[v * KW + kq + 16 * a];
-            const float* x0p = &xs[(hb + off0) * C1];
-            const float* x1p = &xs[(hb + off1) * C1];
+        for (int s = 0; s < 16; ++s) {
+            const int so = ((s >> 1) * HX + (s & 1) * 4) * C1;
+            float b[NCT];
 #pragma unroll
-            for (int c = 0; c <= MAXC; ++c) {
-                if (c < C1) {
-                    const float xa = x0p[c], xb = x1p[c];
+            for (int ct = 0; ct < NCT; ++ct) b[ct] = xs[bbase + so + boff[ct]];
 #pragma unroll
-                    for (int a = 0; a < KH; ++a) {
-                        acc[a][0][c] = fmaf(d[a], xa, acc[a][0][c]);
-                        acc[a][1][c] = fmaf(d[a], xb, acc[a][1][c]);
-                    }
-                }
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][s], b[ct], acc[rt][ct], 0, 0, 0);
+        }
+    }
+    // fold the four z-plane partials (fixed order 0+1+2+3) through LDS, then write the block's partial.
+    // D layout of 16x16x4: col = lane & 15, row = 4*(lane >> 4) + reg
+    __shared__ float red[RT * NCT * 4 * 64];
+    for (int src = 1; src < 4; ++src) {
+        __syncthreads();
+        if (w == src) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[((rt * NCT + ct) * 4 + r) * 64 + l] = acc[rt][ct][r];
+        }
+        __syncthreads();
+        if (w == 0) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[rt][ct][r] += red[((rt * NCT + ct) * 4 + r) * 64 + l];
+        }
+    }
+    if (w != 0) return;
+    float* dst = p.partial + (size_t)(n * p.B + blockIdx.x) * ((size_t)Cout * NCOL);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const int col = ct * 16 + j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = rt * 16 + 4 * kk + r;
+                if (k < Cout && col < NCOL) dst[(size_t)k * NCOL + col] = acc[rt][ct][r];
             }
         }
-    }
-    float* dst = p.partial + ((size_t)n * p.B + blockIdx.x) * ((size_t)Cout * 27 * C1);
-#pragma unroll
-    for (int a = 0; a < KH; ++a) {
-        const int k = kq + 16 * a;
-        if (k >= Cout) continue;
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int tap = b == 0 ? tap0 : tap1;
-            if (tap >= 27) continue;
-#pragma unroll
-            for (int c = 0; c <= MAXC; ++c)
-                if (c < C1) dst[((size_t)k * 27 + tap) * C1 + c] = acc[a][b][c];
-        }
-    }
 }
 
 // finalize: grid = ceil(Cout*27 / 64) blocks of 256 threads = 64 (k,tap) lanes x 4 partial-groups.  Fixed summation
@@ -306,10 +341,24 @@ extern "C" int u3d_conv3d_small_cin_bwd(int device, u3d_stream_t stream, const f
     const size_t need = (size_t)N * p.B * Cout * 27 * (Cin + 1);
     if (workspace_floats < need)
         return u3d_set_err(U3D_EWORKSPACE, "u3d_conv3d_small_cin_bwd: workspace %zu < %zu floats", workspace_floats, need);
-    if (Cout <= 16)
-        hipLaunchKernelGGL(conv3d_small_bwd_kernel<1>, dim3((unsigned)p.B, (unsigned)N), dim3(256), 0, (hipStream_t)stream, p);
+    const dim3 grid((unsigned)p.B, (unsigned)N), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define U3D_SMALL_BWD(CIN_)                                                                   \
+    do {                                                                                      \
+        if (Cout <= 16)                                                                       \
+            hipLaunchKernelGGL((conv3d_small_bwd_kernel<CIN_, 1>), grid, block, 0, st, p);    \
+        else                                                                                  \
+            hipLaunchKernelGGL((conv3d_small_bwd_kernel<CIN_, 2>), grid, block, 0, st, p);    \
+    } while (0)
+    if (Cin == 1)
+        U3D_SMALL_BWD(1);
+    else if (Cin == 2)
+        U3D_SMALL_BWD(2);
+    else if (Cin == 3)
+        U3D_SMALL_BWD(3);
     else
-        hipLaunchKernelGGL(conv3d_small_bwd_kernel<2>, dim3((unsigned)p.B, (unsigned)N), dim3(256), 0, (hipStream_t)stream, p);
+        U3D_SMALL_BWD(4);
+#undef U3D_SMALL_BWD
     U3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(conv3d_small_bwd_finalize_kernel, dim3((Cout * 27 + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                        workspace, affine, w, N, p.B, Cin, Cout, dw, gstats);

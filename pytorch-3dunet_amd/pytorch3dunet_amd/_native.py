@@ -99,6 +99,31 @@ _PROTOS = {
         c_int,
         [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p],
     ),
+    "u3d_conv3d_residual": (
+        c_int,
+        [c_int, c_void_p, POINTER(U3DSrc), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    ),
+    "u3d_gn_bwd_apply_add": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p],
+    ),
+    "u3d_conv1x1_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
+    "u3d_conv1x1_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "u3d_convtr3d_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "u3d_convtr3d_bwd": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    ),
+    "u3d_nearest_add_fwd": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+         c_int, c_void_p, c_void_p],
+    ),
+    "u3d_nearest_sum_bwd": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+         c_void_p],
+    ),
     "u3d_bce_dice_fwd": (
         c_int,
         [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_float, c_float, c_float, c_void_p, c_void_p,

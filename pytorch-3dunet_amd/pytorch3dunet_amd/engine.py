@@ -130,6 +130,8 @@ class Tape:
     head_x: Optional[torch.Tensor] = None
     dims: tuple = ()
     x0: Optional[torch.Tensor] = None
+    blocks: list = field(default_factory=list)  # residual executor: ResRec per block (encoders, then decoders)
+    ups: list = field(default_factory=list)     # residual executor: UpRec per decoder
 
 
 class _StatPool:
@@ -146,6 +148,18 @@ class _StatPool:
         return s
 
 
+class _BwdCtx:
+    """per-backward scratch shared by the helper methods: zeroed double pool, wgrad workspace, flat gradient buffer"""
+
+    def __init__(self, dev, pool, ws, flat, engine):
+        self.dev, self.pool, self.ws, self.flat = dev, pool, ws, flat
+        self._e = engine
+
+    def gview(self, idx):
+        e = self._e
+        return self.flat[e.poffs[idx] : e.poffs[idx] + e.params[idx].numel()]
+
+
 class UNet3DEngine:
     """Executes the forward / backward of a UNet3D-family model natively.  Built once per model by
     `pytorch3dunet_amd.unet3d.model.AbstractUNet`; holds no tensors between calls except caches keyed on
@@ -160,15 +174,7 @@ class UNet3DEngine:
         self.small_cin = True  # dedicated kernels for the in_channels<=4 first layer
         self.params = list(model.parameters())
         self._pindex = {id(p): i for i, p in enumerate(self.params)}
-        # static layer table
-        self.enc = []
-        for enc in model.encoders:
-            bm = enc.basic_module
-            self.enc.append((enc.pooling is not None, bm.SingleConv1, bm.SingleConv2))
-        self.dec = []
-        for dec in model.decoders:
-            bm = dec.basic_module
-            self.dec.append((bm.SingleConv1, bm.SingleConv2))
+        self._build_layer_table(model)
         # split point of the flat gradient buffer: encoders first (module order), then decoders + head
         n_enc = sum(p.numel() for p in model.encoders.parameters())
         self.n_enc_params = n_enc
@@ -178,6 +184,16 @@ class UNet3DEngine:
             offs.append(o)
             o += p.numel()
         self.poffs = offs
+
+    def _build_layer_table(self, model):
+        self.enc = []
+        for enc in model.encoders:
+            bm = enc.basic_module
+            self.enc.append((enc.pooling is not None, bm.SingleConv1, bm.SingleConv2))
+        self.dec = []
+        for dec in model.decoders:
+            bm = dec.basic_module
+            self.dec.append((bm.SingleConv1, bm.SingleConv2))
 
     # -- helpers ------------------------------------------------------------------------------------
     def _packed(self, w: torch.Tensor, mode: int, dev) -> torch.Tensor:
@@ -209,7 +225,10 @@ class UNet3DEngine:
         nat.call("u3d_chan_stats", dev.index, _stream(dev), ctypes.byref(s), src.N, src.D, src.H, src.W, _p(st))
         return st, src.C, 1.0, None, 0, 0.0
 
-    def _single_conv_fwd(self, sc, name, src: VSrc, st_in, pool: _StatPool, tape: Optional[Tape], want_stats=True):
+    def _single_conv_fwd(self, sc, name, src: VSrc, st_in, pool: _StatPool, tape: Optional[Tape], want_stats=True,
+                         residual: Optional[torch.Tensor] = None):
+        """GroupNorm -> Conv3d -> ReLU of one SingleConv; with `residual`: ReLU(conv(GN(x)) + residual), the tail of
+        ResNetBlock.forward (buildingblocks.py:277-288)."""
         dev = src.t0.device
         gn, conv = sc.groupnorm, sc.conv
         N, D, H, W = src.N, src.D, src.H, src.W
@@ -221,7 +240,7 @@ class UNet3DEngine:
         nat.call("u3d_gn_finalize", dev.index, _stream(dev), _p(st0), C0, sc0, _p(st1), C1, sc1, N, G,
                  float(D * H * W), _p(gn.weight.detach()), _p(gn.bias.detach()), float(gn.eps), _p(affine), _p(mean_rstd))
         y = torch.empty((N, D, H, W, Cout), dtype=_F32, device=dev)
-        small = self.small_cin and src.t1 is None and Ctot <= 4 and Cout <= 32
+        small = self.small_cin and src.t1 is None and Ctot <= 4 and Cout <= 32 and residual is None
         if small:
             # first layer of the network: K = 27*Cin is too small for the MFMA tiling (csrc/u3d_smallc.hip)
             ystats = None
@@ -231,14 +250,81 @@ class UNet3DEngine:
             wp = self._packed(conv.weight, 0, dev)
             ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
             s = src.struct(affine)
-            nat.call("u3d_conv3d", dev.index, _stream(dev), ctypes.byref(s), _p(wp), _p(y), N, D, H, W, Cout, 1, _p(ystats),
-                     None, None, flops=54.0 * Ctot * Cout * N * D * H * W)
+            if residual is not None:
+                nat.call("u3d_conv3d_residual", dev.index, _stream(dev), ctypes.byref(s), _p(wp), _p(y), N, D, H, W, Cout, 1,
+                         _p(ystats), _p(residual), flops=54.0 * Ctot * Cout * N * D * H * W)
+            else:
+                nat.call("u3d_conv3d", dev.index, _stream(dev), ctypes.byref(s), _p(wp), _p(y), N, D, H, W, Cout, 1,
+                         _p(ystats), None, None, flops=54.0 * Ctot * Cout * N * D * H * W)
         if tape is not None:
             tape.convs.append(
                 ConvRec(name, src, affine, mean_rstd, y, gn.weight, conv.weight, G, self._pindex[id(gn.weight)],
                         self._pindex[id(gn.bias)], self._pindex[id(conv.weight)], small)
             )
         return y, ystats
+
+    # -- backward building blocks (shared by the DoubleConv and the residual executors) -----------------------
+    def _conv_bwd(self, cx, rec: ConvRec, dz_, need_dg=True):
+        """wgrad + dgrad + GroupNorm-backward reductions of one SingleConv; returns (dg, coef)"""
+        dev, pool, ws, gview = cx.dev, cx.pool, cx.ws, cx.gview
+        src = rec.src
+        Nn, Dd, Hh, Ww = src.N, src.D, src.H, src.W
+        Cout = rec.y.shape[-1]
+        if self.debug is not None:
+            self.debug[rec.name + ".dz"] = dz_.clone()
+        if rec.small and not need_dg:
+            # one pass gives dw and the GroupNorm-backward sums; no data gradient needed (csrc/u3d_smallc.hip)
+            gst = pool.take(Nn * src.C * 2)
+            nat.call("u3d_conv3d_small_cin_bwd", dev.index, _stream(dev), _p(src.t0), _p(rec.affine), _p(dz_),
+                     _p(rec.conv_w.detach()), _p(gview(rec.idx_w)), _p(gst), Nn, Dd, Hh, Ww, src.C, Cout, _p(ws), ws.numel(),
+                     flops=2 * 54.0 * src.C * Cout * Nn * Dd * Hh * Ww)
+            coef = torch.empty((Nn, 3, src.C), dtype=_F32, device=dev)
+            nat.call("u3d_gn_bwd_finalize", dev.index, _stream(dev), _p(gst), _p(rec.mean_rstd), _p(rec.gn_w.detach()), Nn,
+                     src.C, rec.G, float(Dd * Hh * Ww), _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef))
+            return None, coef
+        s_aff = src.struct(rec.affine)
+        flops = 54.0 * src.C * Cout * Nn * Dd * Hh * Ww
+        nat.call("u3d_conv3d_wgrad", dev.index, _stream(dev), ctypes.byref(s_aff), _p(dz_), _p(gview(rec.idx_w)), Nn, Dd, Hh,
+                 Ww, Cout, _p(ws), ws.numel(), flops=flops)
+        wpd = self._packed(rec.conv_w, 1, dev)
+        dg = torch.empty((Nn, Dd, Hh, Ww, src.C), dtype=_F32, device=dev)
+        gst = pool.take(Nn * src.C * 2)
+        s_dz = VSrc(dz_).struct()
+        s_x = src.struct()
+        nat.call("u3d_conv3d", dev.index, _stream(dev), ctypes.byref(s_dz), _p(wpd), _p(dg), Nn, Dd, Hh, Ww, src.C, 0, None,
+                 ctypes.byref(s_x), _p(gst), flops=flops)
+        if self.debug is not None:
+            self.debug[rec.name + ".dg"] = dg.clone()
+        coef = torch.empty((Nn, 3, src.C), dtype=_F32, device=dev)
+        nat.call("u3d_gn_bwd_finalize", dev.index, _stream(dev), _p(gst), _p(rec.mean_rstd), _p(rec.gn_w.detach()), Nn, src.C,
+                 rec.G, float(Dd * Hh * Ww), _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef))
+        return dg, coef
+
+    def _plain_apply(self, cx, dg, coef, x, relu_mask, add=None):
+        """GroupNorm backward, elementwise part: (p*dg + q*x + r [+ add]) * (relu_mask ? x > 0 : 1)"""
+        dev = cx.dev
+        out = torch.empty_like(x)
+        Nn = x.shape[0]
+        C = x.shape[-1]
+        if add is None:
+            nat.call("u3d_gn_bwd_apply", dev.index, _stream(dev), _p(dg), C, 0, _p(x), C, _p(coef), C, x.numel() // (Nn * C), Nn,
+                     relu_mask, _p(out))
+        else:
+            nat.call("u3d_gn_bwd_apply_add", dev.index, _stream(dev), _p(dg), C, 0, _p(x), C, _p(coef), C,
+                     x.numel() // (Nn * C), Nn, relu_mask, _p(add), _p(out))
+        return out
+
+    def _wgrad_workspace(self, tape, dev):
+        lib = nat.get_lib()
+        ws_floats = 0
+        for r in tape.convs:
+            ws_floats = max(ws_floats, lib.u3d_wgrad_workspace_floats(r.src.N, r.src.D, r.src.H, r.src.W, r.src.C,
+                                                                      r.y.shape[-1]))
+        r0 = tape.convs[0]
+        if r0.small:
+            ws_floats = max(ws_floats, lib.u3d_small_cin_bwd_workspace_floats(r0.src.N, r0.src.D, r0.src.H, r0.src.W,
+                                                                              r0.src.C, r0.y.shape[-1]))
+        return torch.empty(max(ws_floats, 4), dtype=_F32, device=dev)
 
     # -- forward ------------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, save: bool):
@@ -330,17 +416,7 @@ class UNet3DEngine:
         Co, Cf = fc.out_channels, fc.in_channels
         tot = Co * Cf + Co + sum(N * r.src.C * 2 for r in tape.convs)
         pool = _StatPool(dev, tot)
-        # wgrad workspace: max over layers
-        lib = nat.get_lib()
-        ws_floats = 0
-        for r in tape.convs:
-            ws_floats = max(ws_floats, lib.u3d_wgrad_workspace_floats(r.src.N, r.src.D, r.src.H, r.src.W, r.src.C,
-                                                                      r.y.shape[-1]))
-        r0 = tape.convs[0]
-        if r0.small:
-            ws_floats = max(ws_floats, lib.u3d_small_cin_bwd_workspace_floats(r0.src.N, r0.src.D, r0.src.H, r0.src.W,
-                                                                              r0.src.C, r0.y.shape[-1]))
-        ws = torch.empty(ws_floats, dtype=_F32, device=dev)
+        ws = self._wgrad_workspace(tape, dev)
 
         # ---- head backward: dz of the last decoder conv (ReLU mask fused)
         hacc = pool.take(Co * Cf + Co)
@@ -355,48 +431,13 @@ class UNet3DEngine:
         n_dec = len(self.dec)
         skip_grad = {}  # encoder level -> gradient arriving through the skip connection (pre-mask)
 
+        cx = _BwdCtx(dev, pool, ws, flat, self)
+
         def conv_bwd(rec: ConvRec, dz_, need_dg=True):
-            """wgrad + dgrad + GroupNorm-backward reductions of one SingleConv; returns (dg, coef)"""
-            src = rec.src
-            Nn, Dd, Hh, Ww = src.N, src.D, src.H, src.W
-            Cout = rec.y.shape[-1]
-            if self.debug is not None:
-                self.debug[rec.name + ".dz"] = dz_.clone()
-            if rec.small and not need_dg:
-                # one pass gives dw and the GroupNorm-backward sums; no data gradient needed (csrc/u3d_smallc.hip)
-                gst = pool.take(Nn * src.C * 2)
-                nat.call("u3d_conv3d_small_cin_bwd", dev.index, _stream(dev), _p(src.t0), _p(rec.affine), _p(dz_),
-                         _p(rec.conv_w.detach()), _p(gview(rec.idx_w)), _p(gst), Nn, Dd, Hh, Ww, src.C, Cout, _p(ws), ws.numel(),
-                         flops=2 * 54.0 * src.C * Cout * Nn * Dd * Hh * Ww)
-                coef = torch.empty((Nn, 3, src.C), dtype=_F32, device=dev)
-                nat.call("u3d_gn_bwd_finalize", dev.index, _stream(dev), _p(gst), _p(rec.mean_rstd), _p(rec.gn_w.detach()), Nn,
-                         src.C, rec.G, float(Dd * Hh * Ww), _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef))
-                return None, coef
-            s_aff = src.struct(rec.affine)
-            flops = 54.0 * src.C * Cout * Nn * Dd * Hh * Ww
-            nat.call("u3d_conv3d_wgrad", dev.index, _stream(dev), ctypes.byref(s_aff), _p(dz_), _p(gview(rec.idx_w)), Nn, Dd, Hh,
-                     Ww, Cout, _p(ws), ws.numel(), flops=flops)
-            wpd = self._packed(rec.conv_w, 1, dev)
-            dg = torch.empty((Nn, Dd, Hh, Ww, src.C), dtype=_F32, device=dev)
-            gst = pool.take(Nn * src.C * 2)
-            s_dz = VSrc(dz_).struct()
-            s_x = src.struct()
-            nat.call("u3d_conv3d", dev.index, _stream(dev), ctypes.byref(s_dz), _p(wpd), _p(dg), Nn, Dd, Hh, Ww, src.C, 0, None,
-                     ctypes.byref(s_x), _p(gst), flops=flops)
-            if self.debug is not None:
-                self.debug[rec.name + ".dg"] = dg.clone()
-            coef = torch.empty((Nn, 3, src.C), dtype=_F32, device=dev)
-            nat.call("u3d_gn_bwd_finalize", dev.index, _stream(dev), _p(gst), _p(rec.mean_rstd), _p(rec.gn_w.detach()), Nn, src.C,
-                     rec.G, float(Dd * Hh * Ww), _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef))
-            return dg, coef
+            return self._conv_bwd(cx, rec, dz_, need_dg)
 
         def plain_apply(dg, coef, x, relu_mask):
-            out = torch.empty_like(x)
-            Nn = x.shape[0]
-            C = x.shape[-1]
-            nat.call("u3d_gn_bwd_apply", dev.index, _stream(dev), _p(dg), C, 0, _p(x), C, _p(coef), C, x.numel() // (Nn * C), Nn,
-                     relu_mask, _p(out))
-            return out
+            return self._plain_apply(cx, dg, coef, x, relu_mask)
 
         recs = tape.convs  # order: enc0.c1, enc0.c2, enc1.c1, ..., dec0.c1, dec0.c2, ...
         enc_recs = [(recs[2 * i], recs[2 * i + 1]) for i in range(n_levels)]
@@ -456,6 +497,248 @@ class UNet3DEngine:
         if dx0 is not None:
             if Cin == 1:
                 dx = dx0.view(N, 1, D, H, W)
+            else:
+                dx = torch.empty((N, Cin, D, H, W), dtype=_F32, device=dev)
+                nat.call("u3d_ndhwc_to_ncdhw", dev.index, _stream(dev), _p(dx0), _p(dx), N, Cin, V)
+        return flat, dx
+
+
+@dataclass
+class ResRec:
+    """what one ResNetBlock (buildingblocks.py:230-288, order 'gcr') saves for backward"""
+
+    name: str
+    x_in: torch.Tensor           # block input (pooled tensor / network input / joined decoder tensor)
+    r: torch.Tensor              # `residual` = conv1(x_in) (or x_in itself for nn.Identity)
+    rec2: ConvRec                # conv2: GroupNorm -> conv -> ReLU on r
+    rec3: ConvRec                # conv3: GroupNorm -> conv on conv2's output; rec3.y = ReLU(conv3 + r) = block output
+    conv1: Optional[torch.nn.Module]  # the 1x1x1 conv with bias, None for nn.Identity
+
+
+@dataclass
+class UpRec:
+    """TransposeConvUpsampling + summation joining of one decoder (buildingblocks.py:617-664, :493)"""
+
+    x_low: torch.Tensor
+    weight: torch.Tensor  # (Cin, Cout, 3, 3, 3)
+    los: tuple            # children tables of the nearest resize (2n-1 -> skip size)
+    tdims: tuple          # (Dt, Ht, Wt)
+
+
+class ResUNetEngine(UNet3DEngine):
+    """Native executor of ResidualUNet3D (model.py:193-234): ResNetBlock encoders (max-pool down), decoders that upsample
+    with ConvTranspose3d(k3,s2,p1) -> nearest resize -> sum with the skip, then a ResNetBlock; same head.
+
+    The 3x3x3 convolutions (94 % of the FLOPs at BASELINE config 4) run on the same MFMA kernels as UNet3D, with the
+    block's `out += residual; ReLU` fused into conv3's epilogue (u3d_conv3d_residual); GroupNorm statistics of the
+    residual come out of the 1x1x1 conv's / the joining kernel's epilogue.  The 1x1x1 convolutions and the transposed
+    convolution run on the FP32 vector units (csrc/u3d_res.hip)."""
+
+    def _build_layer_table(self, model):
+        self.enc = [(e.pooling is not None, e.basic_module) for e in model.encoders]
+        self.dec = [(d.upsampling.upsample.conv_transposed, d.basic_module) for d in model.decoders]
+
+    # -- forward ------------------------------------------------------------------------------------
+    def _block_fwd(self, bm, name, x_in, x_st, pool, tape, dev):
+        N, D, H, W, Cin = x_in.shape
+        Cout = bm.conv2.conv.in_channels
+        conv1 = None if isinstance(bm.conv1, torch.nn.Identity) else bm.conv1
+        if conv1 is None:
+            r, r_st = x_in, x_st
+            if r_st is None:
+                r_st = pool.take(N * Cout * 2)
+                sx = VSrc(r).struct()
+                nat.call("u3d_chan_stats", dev.index, _stream(dev), ctypes.byref(sx), N, D, H, W, _p(r_st))
+        else:
+            r = torch.empty((N, D, H, W, Cout), dtype=_F32, device=dev)
+            r_st = pool.take(N * Cout * 2)
+            w1 = conv1.weight.detach().view(Cout, Cin)
+            nat.call("u3d_conv1x1_fwd", dev.index, _stream(dev), _p(x_in), _p(w1), _p(conv1.bias.detach()), _p(r), N, D * H * W,
+                     Cin, Cout, _p(r_st), flops=2.0 * Cin * Cout * N * D * H * W)
+        n0 = len(tape.convs) if tape is not None else 0
+        src2 = VSrc(r)
+        out2, st2 = self._single_conv_fwd(bm.conv2, name + ".c2", src2, (r_st, Cout, 1.0, None, 0, 0.0), pool, tape)
+        src3 = VSrc(out2)
+        y, _ = self._single_conv_fwd(bm.conv3, name + ".c3", src3, (st2, Cout, 1.0, None, 0, 0.0), pool, tape,
+                                     want_stats=False, residual=r)
+        if tape is not None:
+            tape.blocks.append(ResRec(name, x_in, r, tape.convs[n0], tape.convs[n0 + 1], conv1))
+        return y
+
+    def forward(self, x: torch.Tensor, save: bool):
+        m = self.model
+        dev = x.device
+        N, Cin, D, H, W = x.shape
+        x = x.contiguous()
+        if Cin == 1:
+            x0 = x.view(N, D, H, W, 1)
+        else:
+            x0 = torch.empty((N, D, H, W, Cin), dtype=_F32, device=dev)
+            nat.call("u3d_ncdhw_to_ndhwc", dev.index, _stream(dev), _p(x), _p(x0), N, Cin, D * H * W)
+        tape = Tape() if save else None
+        if tape is not None:
+            tape.x0 = x0
+            tape.dims = (N, Cin, D, H, W)
+            tape.blocks = []
+            tape.ups = []
+        widths = [bm.conv2.conv.in_channels for _, bm in self.enc]
+        pool = _StatPool(dev, 16 * N * sum(widths) * 2 + 64)
+
+        feats = []
+        cur = x0
+        for i, (has_pool, bm) in enumerate(self.enc):
+            if has_pool:
+                Np, Dp, Hp, Wp, Cp = cur.shape
+                pooled = torch.empty((Np, Dp // 2, Hp // 2, Wp // 2, Cp), dtype=_F32, device=dev)
+                argmax = torch.empty(pooled.shape, dtype=torch.uint8, device=dev)
+                nat.call("u3d_maxpool2_fwd", dev.index, _stream(dev), _p(cur), Np, Dp, Hp, Wp, Cp, _p(pooled), _p(argmax),
+                         None)
+                if tape is not None:
+                    tape.pools.append((pooled, argmax, cur))
+                cur = pooled
+            cur = self._block_fwd(bm, f"enc{i}", cur, None, pool, tape, dev)
+            feats.append(cur)
+
+        skips = feats[:-1][::-1]
+        for j, ((ct, bm), sk) in enumerate(zip(self.dec, skips)):
+            Nl, D1, H1, W1, Cl = cur.shape
+            _, Ds, Hs, Ws, Cs = sk.shape
+            Dt, Ht, Wt = 2 * D1 - 1, 2 * H1 - 1, 2 * W1 - 1
+            t = torch.empty((Nl, Dt, Ht, Wt, Cs), dtype=_F32, device=dev)
+            nat.call("u3d_convtr3d_fwd", dev.index, _stream(dev), _p(cur), _p(ct.weight.detach()), _p(t), Nl, D1, H1, W1, Cl, Cs,
+                     flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
+            (mz, lz), (my, ly), (mx, lx) = _maps(dev, Dt, Ds), _maps(dev, Ht, Hs), _maps(dev, Wt, Ws)
+            joined = torch.empty_like(sk)
+            j_st = pool.take(Nl * Cs * 2)
+            nat.call("u3d_nearest_add_fwd", dev.index, _stream(dev), _p(sk), _p(t), _p(mz), _p(my), _p(mx), Nl, Ds, Hs, Ws, Dt, Ht,
+                     Wt, Cs, _p(joined), _p(j_st))
+            del t
+            if tape is not None:
+                tape.ups.append(UpRec(cur, ct.weight, (lz, ly, lx), (Dt, Ht, Wt)))
+            cur = self._block_fwd(bm, f"dec{j}", joined, j_st, pool, tape, dev)
+
+        fc = m.final_conv
+        Co, Cf = fc.out_channels, fc.in_channels
+        V = D * H * W
+        logits = torch.empty((N, Co, D, H, W), dtype=_F32, device=dev)
+        act = 0
+        probs = None
+        if m.final_activation is not None:
+            act = 1 if isinstance(m.final_activation, torch.nn.Sigmoid) else 2
+            probs = torch.empty_like(logits)
+        nat.call("u3d_conv1x1_head_fwd", dev.index, _stream(dev), _p(cur), _p(fc.weight.detach()), _p(fc.bias.detach()), N, V,
+                 Cf, Co, act, _p(logits), _p(probs))
+        if tape is not None:
+            tape.head_x = cur
+            if self.debug is not None:
+                self.debug["tape"] = tape
+        return logits, probs, tape
+
+    # -- backward -----------------------------------------------------------------------------------
+    def _block_bwd(self, cx, rec: ResRec, m_):
+        """m_ = dL/d(block output) already masked by (output > 0).  Returns dL/d(residual r)."""
+        dg3, coef3 = self._conv_bwd(cx, rec.rec3, m_)
+        dz2 = self._plain_apply(cx, dg3, coef3, rec.rec3.src.t0, 1)  # conv2's output is post-ReLU
+        del dg3
+        dg2, coef2 = self._conv_bwd(cx, rec.rec2, dz2)
+        del dz2
+        # r feeds conv2's GroupNorm AND the `out += residual` shortcut; r itself is linear (no ReLU mask)
+        return self._plain_apply(cx, dg2, coef2, rec.r, 0, add=m_)
+
+    def backward(self, tape: Tape, dlogits: torch.Tensor, need_input_grad: bool):
+        m = self.model
+        dev = dlogits.device
+        N, Cin, D, H, W = tape.dims
+        V = D * H * W
+        dlogits = dlogits.contiguous()
+        flat = torch.empty(self.n_params, dtype=_F32, device=dev)
+        fc = m.final_conv
+        Co, Cf = fc.out_channels, fc.in_channels
+        tot = Co * Cf + Co + sum(N * r.src.C * 2 for r in tape.convs)
+        for b in tape.blocks:
+            if b.conv1 is not None:
+                tot += b.conv1.weight.numel() + b.conv1.bias.numel()
+        for u in tape.ups:
+            tot += u.weight.numel()
+        pool = _StatPool(dev, tot)
+        ws = self._wgrad_workspace(tape, dev)
+        cx = _BwdCtx(dev, pool, ws, flat, self)
+        gview = cx.gview
+
+        hacc = pool.take(Co * Cf + Co)
+        dz = torch.empty_like(tape.head_x)
+        nat.call("u3d_conv1x1_head_bwd", dev.index, _stream(dev), _p(dlogits), _p(tape.head_x), _p(fc.weight.detach()), N, V,
+                 Cf, Co, 1, _p(dz), _p(hacc))
+        iw, ib = self._pindex[id(fc.weight)], self._pindex[id(fc.bias)]
+        assert self.poffs[ib] == self.poffs[iw] + Co * Cf
+        nat.call("u3d_cvt_f64_f32", dev.index, _stream(dev), _p(hacc), _p(gview(iw)), Co * Cf + Co)
+
+        n_levels, n_dec = len(self.enc), len(self.dec)
+        enc_blocks, dec_blocks = tape.blocks[:n_levels], tape.blocks[n_levels:]
+        skip_grad = {}
+
+        for j in range(n_dec - 1, -1, -1):
+            rec, up = dec_blocks[j], tape.ups[j]
+            dj = self._block_bwd(cx, rec, dz)  # gradient of the joined tensor (conv1 is nn.Identity in decoders)
+            assert rec.conv1 is None
+            skip_grad[n_levels - 2 - j] = dj   # summation joining: the skip receives dj as is
+            xl = up.x_low
+            Nl, D1, H1, W1, Cl = xl.shape
+            _, Ds, Hs, Ws, Cs = dj.shape
+            Dt, Ht, Wt = up.tdims
+            dt = torch.empty((Nl, Dt, Ht, Wt, Cs), dtype=_F32, device=dev)
+            lz, ly, lx = up.los
+            nat.call("u3d_nearest_sum_bwd", dev.index, _stream(dev), _p(dj), _p(lz), _p(ly), _p(lx), Nl, Ds, Hs, Ws, Dt, Ht, Wt,
+                     Cs, _p(dt))
+            acc = pool.take(up.weight.numel())
+            dxl = torch.empty_like(xl)
+            nat.call("u3d_convtr3d_bwd", dev.index, _stream(dev), _p(dt), _p(xl), _p(up.weight.detach()), Nl, D1, H1, W1, Cl, Cs,
+                     1, _p(dxl), _p(acc), flops=4.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
+            nat.call("u3d_cvt_f64_f32", dev.index, _stream(dev), _p(acc), _p(gview(self._pindex[id(up.weight)])),
+                     up.weight.numel())
+            del dt
+            dz = dxl  # masked by (x_low > 0): x_low is the post-ReLU output of the block below
+
+        if self.grad_sync is not None:
+            self.grad_sync.launch(flat[self.n_enc_params :])
+
+        dx0 = None
+        for i in range(n_levels - 1, -1, -1):
+            rec = enc_blocks[i]
+            dr = self._block_bwd(cx, rec, dz)
+            need_dx = i > 0 or need_input_grad
+            if rec.conv1 is not None:
+                c1 = rec.conv1
+                Cout_, Cin_ = c1.weight.shape[0], c1.weight.shape[1]
+                xin = rec.x_in
+                acc = pool.take(Cout_ * Cin_ + Cout_)
+                dxin = torch.empty_like(xin) if need_dx else None
+                nat.call("u3d_conv1x1_bwd", dev.index, _stream(dev), _p(dr), _p(xin), _p(c1.weight.detach().view(Cout_, Cin_)),
+                         xin.shape[0], xin.numel() // (xin.shape[0] * Cin_), Cin_, Cout_, _p(dxin), _p(acc),
+                         flops=(4.0 if need_dx else 2.0) * Cin_ * Cout_ * (xin.numel() // Cin_))
+                jw, jb = self._pindex[id(c1.weight)], self._pindex[id(c1.bias)]
+                assert self.poffs[jb] == self.poffs[jw] + Cout_ * Cin_
+                nat.call("u3d_cvt_f64_f32", dev.index, _stream(dev), _p(acc), _p(gview(jw)), Cout_ * Cin_ + Cout_)
+            else:
+                dxin = dr
+            if i > 0:
+                pooled, argmax, e_in = tape.pools[i - 1]
+                Ne, De, He, We, Ce = e_in.shape
+                out = torch.empty_like(e_in)
+                nat.call("u3d_maxpool2_bwd_merge", dev.index, _stream(dev), _p(dxin), _p(pooled), _p(argmax), None,
+                         _p(skip_grad.get(i - 1)), _p(e_in), Ne, De, He, We, Ce, 1, _p(out))
+                dz = out
+            elif need_input_grad:
+                dx0 = dxin
+
+        if self.grad_sync is not None:
+            self.grad_sync.launch(flat[: self.n_enc_params])
+            self.grad_sync.finish()
+
+        dx = None
+        if dx0 is not None:
+            if Cin == 1:
+                dx = dx0.reshape(N, 1, D, H, W)
             else:
                 dx = torch.empty((N, Cin, D, H, W), dtype=_F32, device=dev)
                 nat.call("u3d_ndhwc_to_ncdhw", dev.index, _stream(dev), _p(dx0), _p(dx), N, Cin, V)

@@ -55,7 +55,7 @@ class AbstractUNet(nn.Module):
         reasons = []
         if not is3d:
             reasons.append("2-D model")
-        if basic_module is not DoubleConv:
+        if basic_module not in (DoubleConv, ResNetBlock):
             reasons.append(f"basic_module {basic_module.__name__}")
         if layer_order != "gcr":
             reasons.append(f"layer_order '{layer_order}'")
@@ -63,11 +63,14 @@ class AbstractUNet(nn.Module):
             reasons.append("conv kernel/padding other than 3/1")
         if pool_kernel_size != 2:
             reasons.append("pool_kernel_size != 2")
-        if upsample not in ("default", "nearest"):
+        if basic_module is DoubleConv and upsample not in ("default", "nearest"):
             reasons.append(f"upsample '{upsample}'")
+        if basic_module is ResNetBlock and upsample not in ("default", "deconv"):
+            reasons.append(f"upsample '{upsample}' with residual blocks")
         if out_channels > 16 or f_maps[0] > 256:
             reasons.append("head wider than 16 outputs / 256 inputs")
         self._native_blockers = reasons
+        self._residual = basic_module is ResNetBlock
         self._engine = None
         self._warned = False
 
@@ -78,9 +81,9 @@ class AbstractUNet(nn.Module):
 
     def _get_engine(self):
         if self._engine is None:
-            from ..engine import UNet3DEngine
+            from ..engine import ResUNetEngine, UNet3DEngine
 
-            object.__setattr__(self, "_engine", UNet3DEngine(self))
+            object.__setattr__(self, "_engine", (ResUNetEngine if self._residual else UNet3DEngine)(self))
         return self._engine
 
     def forward(self, x, return_logits=False):

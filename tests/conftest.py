@@ -79,7 +79,8 @@ class Golden:
         return model
 
 
-GOLDEN_NAMES = ["g1_unet3d_small", "g2_unet3d_multi_odd", "g3_unet3d_regression", "g4_unet3d_f16_cfg1"]
+GOLDEN_NAMES = ["g1_unet3d_small", "g2_unet3d_multi_odd", "g3_unet3d_regression", "g4_unet3d_f16_cfg1",
+                "g5_resunet3d_small", "g6_resunet3d_multi_odd"]
 
 
 @pytest.fixture(params=GOLDEN_NAMES)

@@ -30,6 +30,10 @@ CASES = {
                                   is_segmentation=False), (1, 3, 12, 20, 17), "mse", True),
     "g4_unet3d_f16_cfg1": (dict(name="UNet3D", in_channels=1, out_channels=1, f_maps=16, num_groups=8,
                                 final_sigmoid=True), (1, 1, 32, 64, 64), "bce_dice", False),
+    "g5_resunet3d_small": (dict(name="ResidualUNet3D", in_channels=1, out_channels=1, f_maps=[8, 16, 32], num_groups=4,
+                                final_sigmoid=True), (1, 1, 16, 24, 24), "bce_dice", True),
+    "g6_resunet3d_multi_odd": (dict(name="ResidualUNet3D", in_channels=2, out_channels=3, f_maps=[8, 16, 24], num_groups=2,
+                                    final_sigmoid=False), (2, 2, 9, 13, 11), "probs_sum", True),
 }
 SAMPLE = 97  # stride of the samples kept for `big` fixtures
 
@@ -52,7 +56,10 @@ def main():
     from pytorch3dunet_amd.unet3d import model as mine
 
     torch.set_num_threads(8)
-    for seed, (name, (cfg, shape, loss_name, full)) in enumerate(CASES.items()):
+    only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--only=")]
+    for seed, (name, (cfg, shape, loss_name, full)) in enumerate(CASES.items()):  # seed = position: append only
+        if only and name not in only[0]:
+            continue
         torch.manual_seed(100 + seed)
         model = ref_model.get_model(dict(cfg))
         torch.manual_seed(100 + seed)
@@ -157,4 +164,5 @@ def make_loss_golden():
 if __name__ == "__main__":
     if "--losses-only" not in sys.argv:
         main()
-    make_loss_golden()
+    if not any(a.startswith("--only=") for a in sys.argv):
+        make_loss_golden()

@@ -1,0 +1,145 @@
+"""-m gpu: the operators the residual variants add (csrc/u3d_res.hip + the residual conv epilogue), each through the
+C-ABI against torch CPU operators — the ATen call sites of buildingblocks.py:248-255 (1x1x1 conv + bias), :277-288
+(out += residual; ReLU), :653-662 (ConvTranspose3d k3 s2 p1), :650-651 + :493 (nearest resize + sum joining)."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def _mods():
+    import gpu_utils as U
+    from pytorch3dunet_amd import _native as nat
+    from pytorch3dunet_amd.engine import VSrc, _maps, _p, _stream
+
+    return U, nat, VSrc, _maps, _p, _stream
+
+
+@pytest.mark.parametrize("N,Cin,Cout,size", [(2, 1, 16, (4, 6, 5)), (1, 32, 64, (8, 8, 8)), (2, 3, 7, (3, 5, 4)),
+                                             (1, 64, 128, (4, 8, 16)), (1, 130, 70, (2, 3, 5))])
+def test_conv1x1_forward_backward(N, Cin, Cout, size):
+    U, nat, VSrc, _maps, _p, _stream = _mods()
+    torch.manual_seed(Cin + Cout)
+    x = torch.randn(N, Cin, *size, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 1, 1, 1) / Cin ** 0.5).requires_grad_(True)
+    b = torch.randn(Cout, requires_grad=True)
+    y = F.conv3d(x, w, b)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    V = size[0] * size[1] * size[2]
+    xd, wd, bd = U.ndhwc(x.detach()), w.detach().reshape(Cout, Cin).contiguous().to(U.DEV), b.detach().to(U.DEV)
+    yd = torch.empty((N, *size, Cout), device=U.DEV)
+    st = torch.zeros((N, Cout, 2), dtype=torch.float64, device=U.DEV)
+    nat.call("u3d_conv1x1_fwd", 0, _stream(U.DEV), _p(xd), _p(wd), _p(bd), _p(yd), N, V, Cin, Cout, _p(st))
+    assert U.relerr(U.ncdhw(yd), y.detach()) < TOL
+    yy = y.detach().double()
+    s_ref = torch.stack([yy.sum(dim=(2, 3, 4)), (yy * yy).sum(dim=(2, 3, 4))], dim=-1)
+    assert U.relerr(st.cpu(), s_ref) < 1e-5
+    dyd = U.ndhwc(dy)
+    dx = torch.empty_like(xd)
+    acc = torch.zeros(Cout * Cin + Cout, dtype=torch.float64, device=U.DEV)
+    nat.call("u3d_conv1x1_bwd", 0, _stream(U.DEV), _p(dyd), _p(xd), _p(wd), N, V, Cin, Cout, _p(dx), _p(acc))
+    assert U.relerr(U.ncdhw(dx), x.grad) < TOL
+    assert U.relerr(acc[: Cout * Cin].cpu().float().view(Cout, Cin), w.grad.view(Cout, Cin)) < 1e-4
+    assert U.relerr(acc[Cout * Cin:].cpu().float(), b.grad) < 1e-4
+
+
+@pytest.mark.parametrize("N,Cin,Cout,size", [(1, 8, 4, (3, 4, 5)), (2, 32, 16, (4, 4, 4)), (1, 6, 3, (1, 2, 3)),
+                                             (1, 64, 32, (5, 10, 10)), (1, 16, 16, (2, 1, 7))])
+@pytest.mark.parametrize("relu_mask", [0, 1])
+def test_convtranspose3d_forward_backward(N, Cin, Cout, size, relu_mask):
+    U, nat, VSrc, _maps, _p, _stream = _mods()
+    torch.manual_seed(Cin * 5 + Cout)
+    x = torch.randn(N, Cin, *size)
+    if relu_mask:
+        x = F.relu(x)
+    x.requires_grad_(True)
+    w = (torch.randn(Cin, Cout, 3, 3, 3) / (Cin * 3.4) ** 0.5).requires_grad_(True)
+    t = F.conv_transpose3d(x, w, None, stride=2, padding=1)
+    D1, H1, W1 = size
+    assert tuple(t.shape[2:]) == (2 * D1 - 1, 2 * H1 - 1, 2 * W1 - 1)
+    dt = torch.randn_like(t)
+    t.backward(dt)
+    xd, wd = U.ndhwc(x.detach()), w.detach().contiguous().to(U.DEV)
+    td = torch.empty((N, 2 * D1 - 1, 2 * H1 - 1, 2 * W1 - 1, Cout), device=U.DEV)
+    nat.call("u3d_convtr3d_fwd", 0, _stream(U.DEV), _p(xd), _p(wd), _p(td), N, D1, H1, W1, Cin, Cout)
+    assert U.relerr(U.ncdhw(td), t.detach()) < TOL
+    dtd = U.ndhwc(dt)
+    dx = torch.empty_like(xd)
+    acc = torch.zeros(Cin * Cout * 27, dtype=torch.float64, device=U.DEV)
+    nat.call("u3d_convtr3d_bwd", 0, _stream(U.DEV), _p(dtd), _p(xd), _p(wd), N, D1, H1, W1, Cin, Cout, relu_mask, _p(dx),
+             _p(acc))
+    ref_dx = x.grad * (x.detach() > 0) if relu_mask else x.grad
+    assert U.relerr(U.ncdhw(dx), ref_dx) < TOL
+    assert U.relerr(acc.cpu().float().view(Cin, Cout, 3, 3, 3), w.grad) < 1e-4
+
+
+@pytest.mark.parametrize("N,C,lo,hi", [(2, 8, (3, 4, 5), (6, 8, 10)), (1, 6, (5, 10, 10), (10, 20, 20)), (1, 3, (2, 3, 4), (5, 7, 9)),
+                                       (2, 64, (2, 2, 2), (4, 4, 4)), (1, 5, (1, 2, 2), (3, 5, 4))])
+def test_nearest_add_and_sum(N, C, lo, hi):
+    """t has the transposed conv's (2n-1) size; F.interpolate(t, size=skip) then skip + t (buildingblocks.py:650-651,:493)"""
+    U, nat, VSrc, _maps, _p, _stream = _mods()
+    torch.manual_seed(C)
+    Dt, Ht, Wt = (2 * v - 1 for v in lo)
+    t = torch.randn(N, C, Dt, Ht, Wt, requires_grad=True)
+    skip = torch.randn(N, C, *hi, requires_grad=True)
+    j = skip + F.interpolate(t, size=hi)
+    dj = torch.randn_like(j)
+    j.backward(dj)
+    maps, los = zip(*(_maps(U.DEV, a, b) for a, b in zip((Dt, Ht, Wt), hi)))
+    td, sd = U.ndhwc(t.detach()), U.ndhwc(skip.detach())
+    out = torch.empty_like(sd)
+    st = torch.zeros((N, C, 2), dtype=torch.float64, device=U.DEV)
+    nat.call("u3d_nearest_add_fwd", 0, _stream(U.DEV), _p(sd), _p(td), _p(maps[0]), _p(maps[1]), _p(maps[2]), N, *hi, Dt, Ht, Wt,
+             C, _p(out), _p(st))
+    assert U.relerr(U.ncdhw(out), j.detach()) < 1e-6
+    jj = j.detach().double()
+    assert U.relerr(st.cpu(), torch.stack([jj.sum(dim=(2, 3, 4)), (jj * jj).sum(dim=(2, 3, 4))], dim=-1)) < 1e-5
+    djd = U.ndhwc(dj)
+    dtd = torch.empty_like(td)
+    nat.call("u3d_nearest_sum_bwd", 0, _stream(U.DEV), _p(djd), _p(los[0]), _p(los[1]), _p(los[2]), N, *hi, Dt, Ht, Wt, C, _p(dtd))
+    assert U.relerr(U.ncdhw(dtd), t.grad) < 1e-5
+
+
+@pytest.mark.parametrize("N,Cin,Cout,size", [(1, 16, 32, (8, 16, 16)), (2, 32, 32, (4, 8, 8)), (1, 8, 12, (5, 9, 7)),
+                                             (1, 64, 96, (4, 8, 16)), (1, 6, 5, (3, 4, 5))])
+def test_conv3d_residual_epilogue(N, Cin, Cout, size):
+    """out = relu(conv(GN-affine(x)) + residual): aligned sizes take the persistent kernel, ragged ones the generic"""
+    U, nat, VSrc, _maps, _p, _stream = _mods()
+    torch.manual_seed(Cin + 7 * Cout)
+    x = torch.randn(N, Cin, *size)
+    w = torch.randn(Cout, Cin, 3, 3, 3) / (27 * Cin) ** 0.5
+    ab = torch.randn(N, Cin, 2)
+    res = torch.randn(N, Cout, *size)
+    g = x * ab[:, :, 0].view(N, Cin, 1, 1, 1) + ab[:, :, 1].view(N, Cin, 1, 1, 1)
+    ref = F.relu(F.conv3d(g, w, None, padding=1) + res)
+    src = VSrc(U.ndhwc(x))
+    aff = ab.contiguous().to(U.DEV)  # must outlive the call: the struct holds a raw pointer
+    s = src.struct(aff)
+    wp = U.pack(w, 0)
+    resd = U.ndhwc(res)
+    y = torch.empty((N, *size, Cout), device=U.DEV)
+    st = torch.zeros((N, Cout, 2), dtype=torch.float64, device=U.DEV)
+    nat.call("u3d_conv3d_residual", 0, _stream(U.DEV), ctypes.byref(s), _p(wp), _p(y), N, *size, Cout, 1, _p(st), _p(resd))
+    assert U.relerr(U.ncdhw(y), ref) < TOL
+    rr = ref.double()
+    assert U.relerr(st.cpu(), torch.stack([rr.sum(dim=(2, 3, 4)), (rr * rr).sum(dim=(2, 3, 4))], dim=-1)) < 1e-5
+
+
+def test_gn_bwd_apply_add():
+    U, nat, VSrc, _maps, _p, _stream = _mods()
+    torch.manual_seed(2)
+    N, C, V = 2, 12, 77
+    dg, x, add = (torch.randn(N, V, C, device=U.DEV) for _ in range(3))
+    coef = torch.randn(N, 3, C, device=U.DEV)
+    out = torch.empty_like(x)
+    for relu in (0, 1):
+        nat.call("u3d_gn_bwd_apply_add", 0, _stream(U.DEV), _p(dg), C, 0, _p(x), C, _p(coef), C, V, N, relu, _p(add), _p(out))
+        ref = coef[:, 0:1] * dg + coef[:, 1:2] * x + coef[:, 2:3] + add
+        if relu:
+            ref = ref * (x > 0)
+        assert U.relerr(out, ref) < 1e-6
