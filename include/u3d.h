@@ -224,6 +224,29 @@ int u3d_nearest_add_fwd(int device, u3d_stream_t stream, const float* skip, cons
 int u3d_nearest_sum_bwd(int device, u3d_stream_t stream, const float* dj, const int32_t* zlo, const int32_t* ylo,
                         const int32_t* xlo, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C, float* dt);
 
+/* ---- squeeze-and-excitation gates of ResNetBlockSE (se.py:18-114, buildingblocks.py:291-307) ------------------------
+ * y: a block output (N,V,C) NDHWC, post-ReLU; C % 4 == 0, C <= 1024.  mode 0 scSE (max of both gates), 1 cSE, 2 sSE.
+ *   gate_fwd : s[N][C] = channel means from conv3's fused statistics (ystats double[N][C][2], count = V),
+ *              h[N][Cr] = relu(fc1 s + b1), gc[N][C] = sigmoid(fc2 h + b2)        (w1 (Cr,C), w2 (C,Cr) as nn.Linear)
+ *   apply_fwd: a[N*V] = sigmoid(<ws, y[v,:]> + bs) (saved for backward), out = y * {max(gc,a) | gc | a}
+ *   bwd_reduce: from dout (gradient of out): dls[N*V] = d logit_s, acc_gc double[N][C] += d gc, acc_ws double[C+1] +=
+ *              (d ws, d bs) — zeroed scratch
+ *   gate_bwd : FC backward -> ds[N][C] (gradient reaching y through the channel mean, already / V) and the parameter
+ *              gradients dw1,db1,dw2,db2 (written); dz2 [N][C], dz1 [N][Cr] are scratch
+ *   bwd_apply: m = (dout*gate + dls[v]*ws[c] + ds[n,c]) * (relu_mask ? y > 0 : 1) = gradient of the block's pre-ReLU sum */
+int u3d_se_gate_fwd(int device, u3d_stream_t stream, const double* ystats, double count, const float* w1, const float* b1,
+                    const float* w2, const float* b2, int N, int C, int Cr, float* s, float* h, float* gc);
+int u3d_se_apply_fwd(int device, u3d_stream_t stream, const float* y, const float* gc, const float* ws, const float* bs, int N,
+                     int64_t V, int C, int mode, float* out, float* a);
+int u3d_se_bwd_reduce(int device, u3d_stream_t stream, const float* dout, const float* y, const float* gc, const float* a,
+                      const float* ws, int N, int64_t V, int C, int mode, float* dls, double* acc_gc, double* acc_ws);
+int u3d_se_gate_bwd(int device, u3d_stream_t stream, const double* acc_gc, const float* gc, const float* h, const float* s,
+                    const float* w1, const float* w2, int N, int C, int Cr, double count, float* dz2, float* dz1, float* ds,
+                    float* dw1, float* db1, float* dw2, float* db2);
+int u3d_se_bwd_apply(int device, u3d_stream_t stream, const float* dout, const float* y, const float* gc, const float* a,
+                     const float* ws, const float* dls, const float* ds, int N, int64_t V, int C, int mode, int relu_mask,
+                     float* out);
+
 /* ---- BCEDiceLoss / DiceLoss / BCEWithLogitsLoss on the logits (losses.py:187-201, :84-127, :11-37) ------------
  * loss = w_bce * mean(BCE-with-logits) + w_dice * (1 - mean_c dice_c),
  * dice_c = 2 * weight_c * sum(p*t) / clamp(sum(p^2) + sum(t^2), eps), p = sigmoid(logits), sums over (N, V) per channel.

@@ -124,6 +124,28 @@ _PROTOS = {
         [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
          c_void_p],
     ),
+    "u3d_se_gate_fwd": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+         c_void_p],
+    ),
+    "u3d_se_apply_fwd": (
+        c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "u3d_se_bwd_reduce": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p,
+         c_void_p],
+    ),
+    "u3d_se_gate_bwd": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_void_p,
+         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "u3d_se_bwd_apply": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int,
+         c_int, c_void_p],
+    ),
     "u3d_bce_dice_fwd": (
         c_int,
         [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_float, c_float, c_float, c_void_p, c_void_p,

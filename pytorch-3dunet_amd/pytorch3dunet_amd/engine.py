@@ -513,6 +513,7 @@ class ResRec:
     rec2: ConvRec                # conv2: GroupNorm -> conv -> ReLU on r
     rec3: ConvRec                # conv3: GroupNorm -> conv on conv2's output; rec3.y = ReLU(conv3 + r) = block output
     conv1: Optional[torch.nn.Module]  # the 1x1x1 conv with bias, None for nn.Identity
+    se: Optional[dict] = None    # ResNetBlockSE: gate tensors saved by _se_fwd (the block output is se["out"])
 
 
 @dataclass
@@ -559,11 +560,82 @@ class ResUNetEngine(UNet3DEngine):
         src2 = VSrc(r)
         out2, st2 = self._single_conv_fwd(bm.conv2, name + ".c2", src2, (r_st, Cout, 1.0, None, 0, 0.0), pool, tape)
         src3 = VSrc(out2)
-        y, _ = self._single_conv_fwd(bm.conv3, name + ".c3", src3, (st2, Cout, 1.0, None, 0, 0.0), pool, tape,
-                                     want_stats=False, residual=r)
+        se_mod = getattr(bm, "se_module", None)
+        y, y_st = self._single_conv_fwd(bm.conv3, name + ".c3", src3, (st2, Cout, 1.0, None, 0, 0.0), pool, tape,
+                                        want_stats=se_mod is not None, residual=r)
+        se = None
+        out = y
+        if se_mod is not None:
+            se = self._se_fwd(se_mod, y, y_st, dev)
+            out = se["out"]
         if tape is not None:
-            tape.blocks.append(ResRec(name, x_in, r, tape.convs[n0], tape.convs[n0 + 1], conv1))
-        return y
+            tape.blocks.append(ResRec(name, x_in, r, tape.convs[n0], tape.convs[n0 + 1], conv1, se))
+        return out
+
+    @staticmethod
+    def _se_parts(se_mod):
+        """(mode, cSE-or-None, sSE-or-None): 0 scSE, 1 cSE, 2 sSE (buildingblocks.py:298-307)"""
+        if hasattr(se_mod, "cSE"):
+            return 0, se_mod.cSE, se_mod.sSE
+        if hasattr(se_mod, "fc1"):
+            return 1, se_mod, None
+        return 2, None, se_mod
+
+    def _se_fwd(self, se_mod, y, y_st, dev):
+        """squeeze-and-excitation gate on a block output (se.py:18-114): out = y * max(gc[n,c], a[n,v])"""
+        N, D, H, W, C = y.shape
+        V = D * H * W
+        mode, cse, sse = self._se_parts(se_mod)
+        st = {"mode": mode, "y": y, "cse": cse, "sse": sse, "gc": None, "a": None}
+        if cse is not None:
+            Cr = cse.fc1.out_features
+            st["s"] = torch.empty((N, C), dtype=_F32, device=dev)
+            st["h"] = torch.empty((N, Cr), dtype=_F32, device=dev)
+            st["gc"] = torch.empty((N, C), dtype=_F32, device=dev)
+            nat.call("u3d_se_gate_fwd", dev.index, _stream(dev), _p(y_st), float(V), _p(cse.fc1.weight.detach()),
+                     _p(cse.fc1.bias.detach()), _p(cse.fc2.weight.detach()), _p(cse.fc2.bias.detach()), N, C, Cr, _p(st["s"]),
+                     _p(st["h"]), _p(st["gc"]))
+        ws = bs = None
+        if sse is not None:
+            ws, bs = sse.conv.weight.detach().view(C), sse.conv.bias.detach()
+            st["a"] = torch.empty((N * V,), dtype=_F32, device=dev)
+        out = torch.empty_like(y)
+        nat.call("u3d_se_apply_fwd", dev.index, _stream(dev), _p(y), _p(st["gc"]), _p(ws), _p(bs), N, V, C, mode, _p(out),
+                 _p(st["a"]))
+        st["out"] = out
+        return st
+
+    def _se_bwd(self, cx, se, dout):
+        """gradient of the block's pre-ReLU sum from the gradient of the gated output (masked by y > 0)"""
+        dev, pool, gview = cx.dev, cx.pool, cx.gview
+        y = se["y"]
+        N, D, H, W, C = y.shape
+        V = D * H * W
+        mode, cse, sse = se["mode"], se["cse"], se["sse"]
+        acc_gc = pool.take(N * C) if cse is not None else None
+        acc_ws = pool.take(C + 1) if sse is not None else None
+        dls = torch.empty((N * V,), dtype=_F32, device=dev) if sse is not None else None
+        ws = sse.conv.weight.detach().view(C) if sse is not None else None
+        nat.call("u3d_se_bwd_reduce", dev.index, _stream(dev), _p(dout), _p(y), _p(se["gc"]), _p(se["a"]), _p(ws), N, V, C, mode,
+                 _p(dls), _p(acc_gc), _p(acc_ws))
+        ds = None
+        if cse is not None:
+            Cr = cse.fc1.out_features
+            dz2 = torch.empty((N, C), dtype=_F32, device=dev)
+            dz1 = torch.empty((N, Cr), dtype=_F32, device=dev)
+            ds = torch.empty((N, C), dtype=_F32, device=dev)
+            ix = [self._pindex[id(p)] for p in (cse.fc1.weight, cse.fc1.bias, cse.fc2.weight, cse.fc2.bias)]
+            nat.call("u3d_se_gate_bwd", dev.index, _stream(dev), _p(acc_gc), _p(se["gc"]), _p(se["h"]), _p(se["s"]),
+                     _p(cse.fc1.weight.detach()), _p(cse.fc2.weight.detach()), N, C, Cr, float(V), _p(dz2), _p(dz1), _p(ds),
+                     _p(gview(ix[0])), _p(gview(ix[1])), _p(gview(ix[2])), _p(gview(ix[3])))
+        if sse is not None:
+            jw, jb = self._pindex[id(sse.conv.weight)], self._pindex[id(sse.conv.bias)]
+            assert self.poffs[jb] == self.poffs[jw] + C
+            nat.call("u3d_cvt_f64_f32", dev.index, _stream(dev), _p(acc_ws), _p(gview(jw)), C + 1)
+        m_ = torch.empty_like(y)
+        nat.call("u3d_se_bwd_apply", dev.index, _stream(dev), _p(dout), _p(y), _p(se["gc"]), _p(se["a"]), _p(ws), _p(dls), _p(ds),
+                 N, V, C, mode, 1, _p(m_))
+        return m_
 
     def forward(self, x: torch.Tensor, save: bool):
         m = self.model
@@ -637,6 +709,8 @@ class ResUNetEngine(UNet3DEngine):
     # -- backward -----------------------------------------------------------------------------------
     def _block_bwd(self, cx, rec: ResRec, m_):
         """m_ = dL/d(block output) already masked by (output > 0).  Returns dL/d(residual r)."""
+        if rec.se is not None:
+            m_ = self._se_bwd(cx, rec.se, m_)
         dg3, coef3 = self._conv_bwd(cx, rec.rec3, m_)
         dz2 = self._plain_apply(cx, dg3, coef3, rec.rec3.src.t0, 1)  # conv2's output is post-ReLU
         del dg3
@@ -660,6 +734,9 @@ class ResUNetEngine(UNet3DEngine):
                 tot += b.conv1.weight.numel() + b.conv1.bias.numel()
         for u in tape.ups:
             tot += u.weight.numel()
+        for b in tape.blocks:
+            if b.se is not None:
+                tot += (N + 1) * b.se["y"].shape[-1] + 1
         pool = _StatPool(dev, tot)
         ws = self._wgrad_workspace(tape, dev)
         cx = _BwdCtx(dev, pool, ws, flat, self)

@@ -10,7 +10,7 @@ Contract kept:
 
 Dispatch: tensors on a gfx950 device -> native executor (pytorch3dunet_amd/engine.py), which raises if
 libu3d_hip.so is missing (no silent fallback).  CPU tensors (`device: cpu`) run the torch.nn modules the tree is
-made of.  Model variants the executor does not cover yet (residual / SE blocks, 2-D, non-'gcr' orders) run the
+made of.  Model variants the executor does not cover yet (2-D, non-'gcr' orders, other upsampling modes) run the
 same module tree through stock PyTorch-ROCm operators after a one-time warning; set U3D_STRICT=1 to make that an
 error instead.
 """
@@ -55,8 +55,10 @@ class AbstractUNet(nn.Module):
         reasons = []
         if not is3d:
             reasons.append("2-D model")
-        if basic_module not in (DoubleConv, ResNetBlock):
+        if basic_module not in (DoubleConv, ResNetBlock, ResNetBlockSE):
             reasons.append(f"basic_module {basic_module.__name__}")
+        if basic_module is ResNetBlockSE and (any(f % 4 for f in f_maps) or max(f_maps) > 1024):
+            reasons.append("SE gates need channel counts that are multiples of 4 and <= 1024")
         if layer_order != "gcr":
             reasons.append(f"layer_order '{layer_order}'")
         if conv_kernel_size != 3 or conv_padding != 1:
@@ -65,12 +67,12 @@ class AbstractUNet(nn.Module):
             reasons.append("pool_kernel_size != 2")
         if basic_module is DoubleConv and upsample not in ("default", "nearest"):
             reasons.append(f"upsample '{upsample}'")
-        if basic_module is ResNetBlock and upsample not in ("default", "deconv"):
+        if basic_module in (ResNetBlock, ResNetBlockSE) and upsample not in ("default", "deconv"):
             reasons.append(f"upsample '{upsample}' with residual blocks")
         if out_channels > 16 or f_maps[0] > 256:
             reasons.append("head wider than 16 outputs / 256 inputs")
         self._native_blockers = reasons
-        self._residual = basic_module is ResNetBlock
+        self._residual = basic_module in (ResNetBlock, ResNetBlockSE)
         self._engine = None
         self._warned = False
 

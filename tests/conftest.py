@@ -80,7 +80,7 @@ class Golden:
 
 
 GOLDEN_NAMES = ["g1_unet3d_small", "g2_unet3d_multi_odd", "g3_unet3d_regression", "g4_unet3d_f16_cfg1",
-                "g5_resunet3d_small", "g6_resunet3d_multi_odd"]
+                "g5_resunet3d_small", "g6_resunet3d_multi_odd", "g7_resunetse3d_small", "g8_resunetse3d_multi_odd"]
 
 
 @pytest.fixture(params=GOLDEN_NAMES)

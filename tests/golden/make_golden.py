@@ -34,6 +34,10 @@ CASES = {
                                 final_sigmoid=True), (1, 1, 16, 24, 24), "bce_dice", True),
     "g6_resunet3d_multi_odd": (dict(name="ResidualUNet3D", in_channels=2, out_channels=3, f_maps=[8, 16, 24], num_groups=2,
                                     final_sigmoid=False), (2, 2, 9, 13, 11), "probs_sum", True),
+    "g7_resunetse3d_small": (dict(name="ResidualUNetSE3D", in_channels=1, out_channels=1, f_maps=[8, 16, 32], num_groups=4,
+                                  final_sigmoid=True), (1, 1, 16, 24, 24), "bce_dice", True),
+    "g8_resunetse3d_multi_odd": (dict(name="ResidualUNetSE3D", in_channels=3, out_channels=2, f_maps=[8, 16], num_groups=2,
+                                      final_sigmoid=False), (2, 3, 9, 13, 11), "probs_sum", True),
 }
 SAMPLE = 97  # stride of the samples kept for `big` fixtures
 

@@ -132,6 +132,8 @@ def test_model_matches_cpu_oracle(cfg, shape, loss_name):
     (dict(name="ResidualUNet3D", in_channels=2, out_channels=3, f_maps=[8, 16, 24], num_groups=4, final_sigmoid=False), (2, 2, 9, 13, 11), "probs_sum"),
     (dict(name="ResidualUNet3D", in_channels=1, out_channels=1, f_maps=32, num_levels=3, num_groups=8), (1, 1, 8, 32, 40), "bce_dice"),
     (dict(name="ResidualUNet3D", in_channels=1, out_channels=2, f_maps=[16, 32, 64], num_groups=8, final_sigmoid=False), (1, 1, 17, 33, 35), "probs_sum"),
+    (dict(name="ResidualUNetSE3D", in_channels=1, out_channels=1, f_maps=16, num_levels=3, num_groups=8), (1, 1, 16, 32, 32), "bce_dice"),
+    (dict(name="ResidualUNetSE3D", in_channels=3, out_channels=2, f_maps=[8, 24, 40], num_groups=4, final_sigmoid=False), (2, 3, 9, 13, 11), "probs_sum"),
 ])
 def test_gradients_match_decision_consistent_fp64_oracle(cfg, shape, loss_name):
     """The tight gradient check: the float64 oracle with OUR ReLU masks and max-pool arg-maxes imposed
@@ -254,10 +256,10 @@ def test_full_size_cfg2_properties():
 
 
 def test_uncovered_variant_strict_mode(monkeypatch):
-    from pytorch3dunet_amd.unet3d.model import ResidualUNetSE3D
+    from pytorch3dunet_amd.unet3d.model import UNet3D
 
     dev = torch.device("cuda", 0)
-    model = ResidualUNetSE3D(1, 1, f_maps=16, num_levels=3).to(dev).eval()
+    model = UNet3D(1, 1, f_maps=16, num_levels=3, layer_order="gcl").to(dev).eval()  # LeakyReLU order: not native
     monkeypatch.setenv("U3D_STRICT", "1")
     with pytest.raises(NotImplementedError):
         model(torch.rand(1, 1, 8, 16, 16, device=dev))

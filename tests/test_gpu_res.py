@@ -143,3 +143,58 @@ def test_gn_bwd_apply_add():
         if relu:
             ref = ref * (x > 0)
         assert U.relerr(out, ref) < 1e-6
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("N,C,size", [(2, 16, (4, 6, 5)), (1, 96, (3, 4, 4)), (1, 8, (2, 3, 3)), (2, 256, (2, 2, 3)), (1, 1024, (1, 2, 2))])
+def test_se_gates_forward_backward(mode, N, C, size):
+    """scSE / cSE / sSE (se.py:18-114) on a post-ReLU tensor: forward and every gradient against the torch modules"""
+    U, nat, VSrc, _maps, _p, _stream = _mods()
+    from pytorch3dunet_amd.unet3d.se import ChannelSELayer3D, ChannelSpatialSELayer3D, SpatialSELayer3D
+
+    torch.manual_seed(C + mode)
+    mod = [ChannelSpatialSELayer3D(C, 1), ChannelSELayer3D(C, 1), SpatialSELayer3D(C)][mode]
+    cse = mod.cSE if mode == 0 else (mod if mode == 1 else None)
+    sse = mod.sSE if mode == 0 else (mod if mode == 2 else None)
+    pre = torch.randn(N, C, *size, requires_grad=True)
+    y = F.relu(pre)
+    out = mod(y)
+    dout = torch.randn_like(out)
+    out.backward(dout)
+    V = size[0] * size[1] * size[2]
+    yd = U.ndhwc(y.detach())
+    yy = y.detach().double()
+    st = torch.stack([yy.sum(dim=(2, 3, 4)), (yy * yy).sum(dim=(2, 3, 4))], dim=-1).contiguous().to(U.DEV)
+    dev_ = lambda t: t.detach().contiguous().to(U.DEV)  # noqa: E731
+    gc = s = h = a = ws = bs = None
+    if cse is not None:
+        w1, b1, w2, b2 = dev_(cse.fc1.weight), dev_(cse.fc1.bias), dev_(cse.fc2.weight), dev_(cse.fc2.bias)
+        s, h, gc = (torch.empty((N, C), device=U.DEV) for _ in range(3))
+        nat.call("u3d_se_gate_fwd", 0, _stream(U.DEV), _p(st), float(V), _p(w1), _p(b1), _p(w2), _p(b2), N, C, C, _p(s), _p(h), _p(gc))
+    if sse is not None:
+        ws, bs = dev_(sse.conv.weight.view(C)), dev_(sse.conv.bias)
+        a = torch.empty(N * V, device=U.DEV)
+    od = torch.empty_like(yd)
+    nat.call("u3d_se_apply_fwd", 0, _stream(U.DEV), _p(yd), _p(gc), _p(ws), _p(bs), N, V, C, mode, _p(od), _p(a))
+    assert U.relerr(U.ncdhw(od), out.detach()) < TOL
+    # backward
+    dd = U.ndhwc(dout)
+    acc_gc = torch.zeros(N * C, dtype=torch.float64, device=U.DEV) if cse is not None else None
+    acc_ws = torch.zeros(C + 1, dtype=torch.float64, device=U.DEV) if sse is not None else None
+    dls = torch.empty(N * V, device=U.DEV) if sse is not None else None
+    nat.call("u3d_se_bwd_reduce", 0, _stream(U.DEV), _p(dd), _p(yd), _p(gc), _p(a), _p(ws), N, V, C, mode, _p(dls), _p(acc_gc), _p(acc_ws))
+    ds = None
+    if cse is not None:
+        dz2, dz1, ds = (torch.empty((N, C), device=U.DEV) for _ in range(3))
+        dw1, dw2 = torch.empty((C, C), device=U.DEV), torch.empty((C, C), device=U.DEV)
+        db1, db2 = torch.empty(C, device=U.DEV), torch.empty(C, device=U.DEV)
+        nat.call("u3d_se_gate_bwd", 0, _stream(U.DEV), _p(acc_gc), _p(gc), _p(h), _p(s), _p(w1), _p(w2), N, C, C, float(V), _p(dz2),
+                 _p(dz1), _p(ds), _p(dw1), _p(db1), _p(dw2), _p(db2))
+        for got, ref in ((dw1, cse.fc1.weight.grad), (db1, cse.fc1.bias.grad), (dw2, cse.fc2.weight.grad), (db2, cse.fc2.bias.grad)):
+            assert U.relerr(got, ref) < 1e-4
+    if sse is not None:
+        assert U.relerr(acc_ws[:C].cpu().float(), sse.conv.weight.grad.view(C)) < 1e-4
+        assert U.relerr(acc_ws[C:].cpu().float(), sse.conv.bias.grad) < 1e-4
+    md = torch.empty_like(yd)
+    nat.call("u3d_se_bwd_apply", 0, _stream(U.DEV), _p(dd), _p(yd), _p(gc), _p(a), _p(ws), _p(dls), _p(ds), N, V, C, mode, 1, _p(md))
+    assert U.relerr(U.ncdhw(md), pre.grad) < 1e-4
