@@ -21,36 +21,35 @@ __device__ __forceinline__ float sigmoidf_(float x) {
     return x >= 0.f ? r : e * r;
 }
 
-// ---- channel gate: grid N, 256 threads (4 waves; a wave owns rows w, w+4, ...; lanes stride the row: coalesced) --------
-__global__ __launch_bounds__(256) void se_gate_fwd_kernel(const double* __restrict__ ystats, double count,
-                                                          const float* __restrict__ w1, const float* __restrict__ b1,
-                                                          const float* __restrict__ w2, const float* __restrict__ b2, int C,
-                                                          int Cr, float* __restrict__ s_out, float* __restrict__ h_out,
-                                                          float* __restrict__ gc) {
-    __shared__ float ss[1024], sh[1024];
-    const int n = blockIdx.x, t = threadIdx.x, l = t & 63, w = t >> 6;
-    for (int c = t; c < C; c += 256) {
-        const float m = (float)(ystats[((size_t)n * C + c) * 2] / count);  // AdaptiveAvgPool3d(1), se.py:40
-        ss[c] = m;
-        s_out[(size_t)n * C + c] = m;
-    }
-    __syncthreads();
-    for (int j = w; j < Cr; j += 4) {
-        float p = 0.f;
-        for (int c = l; c < C; c += 64) p += w1[(size_t)j * C + c] * ss[c];
-        for (int m = 32; m > 0; m >>= 1) p += __shfl_xor(p, m);
-        if (l == 0) {
-            const float hv = fmaxf(p + b1[j], 0.f);
-            sh[j] = hv;
-            h_out[(size_t)n * Cr + j] = hv;
+// ---- channel gate, two launches of the same row kernel: out[n][r] = act(b[r] + <w[r,:], in[n,:]>).  grid (ceil(R/16), N),
+//      256 threads = 4 waves x 4 rows each; lanes stride the row (coalesced), butterfly reduction.
+//      stage 0: in = channel means from the fused statistics (also written to s_out), act = ReLU   (fc1, se.py:43-46)
+//      stage 1: in = h, act = sigmoid                                                             (fc2, se.py:47)
+__global__ __launch_bounds__(256) void se_fc_rows_kernel(const double* __restrict__ ystats, double count,
+                                                         const float* __restrict__ in, const float* __restrict__ w,
+                                                         const float* __restrict__ b, int K, int R, int stage,
+                                                         float* __restrict__ s_out, float* __restrict__ out) {
+    __shared__ float sv[1024];
+    const int n = blockIdx.y, t = threadIdx.x, l = t & 63, wv = t >> 6;
+    for (int c = t; c < K; c += 256) {
+        float m;
+        if (stage == 0) {
+            m = (float)(ystats[((size_t)n * K + c) * 2] / count);  // AdaptiveAvgPool3d(1), se.py:40
+            if (blockIdx.x == 0) s_out[(size_t)n * K + c] = m;
+        } else {
+            m = in[(size_t)n * K + c];
         }
+        sv[c] = m;
     }
     __syncthreads();
-    for (int c = w; c < C; c += 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = blockIdx.x * 16 + wv * 4 + i;
+        if (r >= R) break;
         float p = 0.f;
-        for (int j = l; j < Cr; j += 64) p += w2[(size_t)c * Cr + j] * sh[j];
+        for (int c = l; c < K; c += 64) p += w[(size_t)r * K + c] * sv[c];
         for (int m = 32; m > 0; m >>= 1) p += __shfl_xor(p, m);
-        if (l == 0) gc[(size_t)n * C + c] = sigmoidf_(p + b2[c]);
+        if (l == 0) out[(size_t)n * R + r] = stage == 0 ? fmaxf(p + b[r], 0.f) : sigmoidf_(p + b[r]);
     }
 }
 
@@ -317,7 +316,10 @@ extern "C" int u3d_se_gate_fwd(int device, u3d_stream_t stream, const double* ys
     if (int e = u3d_enter(device)) return e;
     U3D_REQUIRE(ystats && w1 && b1 && w2 && b2 && s && h && gc && N > 0 && C > 0 && C <= 1024 && Cr > 0 && Cr <= 1024 && count > 0,
                 "u3d_se_gate_fwd: bad argument (C, Cr <= 1024)");
-    hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, ystats, count, w1, b1, w2, b2, C, Cr, s, h, gc);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(se_fc_rows_kernel, dim3((Cr + 15) / 16, N), dim3(256), 0, st, ystats, count, nullptr, w1, b1, C, Cr, 0, s, h);
+    U3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(se_fc_rows_kernel, dim3((C + 15) / 16, N), dim3(256), 0, st, nullptr, count, h, w2, b2, Cr, C, 1, nullptr, gc);
     U3D_LAUNCH_CHECK();
     return 0;
 }
