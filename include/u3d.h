@@ -210,11 +210,14 @@ int u3d_conv1x1_bwd(int device, u3d_stream_t stream, const float* dy, const floa
                     int Cin, int Cout, float* dx, double* acc);
 /* nn.ConvTranspose3d(Cin, Cout, kernel_size=3, stride=2, padding=1, bias=False) (buildingblocks.py:653-662):
  * x (N,D1,H1,W1,Cin) -> t (N,2D1-1,2H1-1,2W1-1,Cout); w in the reference layout (Cin,Cout,3,3,3).
- * bwd: dx (nullable) = stride-2 convolution of dt, masked by x > 0 when relu_mask; acc double[Cin*Cout*27] += dw. */
+ * bwd: dx (nullable) = stride-2 convolution of dt, masked by x > 0 when relu_mask; acc double[Cin*Cout*27] += dw.
+ * packed / packed_t (optional, may be NULL): u3d_pack_convtr_weights images of w — mode 0 [tap][Cin][Cout] for the forward,
+ * mode 1 [tap][Cout][Cin] for the data gradient (27*Cin*Cout floats each) — that make the weight-tile loads coalesced. */
+int u3d_pack_convtr_weights(int device, u3d_stream_t stream, const float* w, int Cin, int Cout, int mode, float* packed);
 int u3d_convtr3d_fwd(int device, u3d_stream_t stream, const float* x, const float* w, float* t, int N, int D1, int H1,
-                     int W1, int Cin, int Cout);
+                     int W1, int Cin, int Cout, const float* packed);
 int u3d_convtr3d_bwd(int device, u3d_stream_t stream, const float* dt, const float* x, const float* w, int N, int D1,
-                     int H1, int W1, int Cin, int Cout, int relu_mask, float* dx, double* acc);
+                     int H1, int W1, int Cin, int Cout, int relu_mask, float* dx, double* acc, const float* packed_t);
 /* F.interpolate(t, size=skip.shape[2:]) (nearest, buildingblocks.py:650-651) + summation joining (:493):
  * out = skip + t[zmap[z], ymap[y], xmap[x]], out_stats as in u3d_conv3d.  bwd: dt[s] = sum of dj over the voxels mapped to
  * s (lo tables of length Dt+1 / Ht+1 / Wt+1: children of s are [lo[s], lo[s+1])); the skip's gradient is dj itself. */

@@ -30,20 +30,30 @@ struct GConvParams {
     signed char tz[27], ty[27], tx[27];
     int woff[27];
     long long wsi, wsj;
-    int avec, ovec;
+    int avec, ovec, bvec;
 };
 
+// MFMA version (v_mfma_f32_32x32x2_f32): a block = 4 waves owns a 64-row x 64-column tile, wave w the 32x32 quadrant
+// (w >> 1, w & 1).  The (tap, 16-channel chunk) steps run as ONE flat software pipeline: the A rows (gathered, zero
+// outside the tensor) and the B slice of step s+1 are loaded into registers before the 8 MFMAs of step s are issued from
+// the LDS buffer s & 1, then stored to buffer (s+1) & 1 — one barrier per step.
 __global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
     using namespace gc;
-    __shared__ __attribute__((aligned(16))) float As[TK][LD];  // [k][row]
-    __shared__ __attribute__((aligned(16))) float Bs[TK][LD];  // [k][out channel]
-    __shared__ float red[16][TN];
-    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    __shared__ __attribute__((aligned(16))) float As[2][TK][LD];  // [buffer][k][row]
+    __shared__ __attribute__((aligned(16))) float Bs[2][TK][LD];  // [buffer][k][out channel]
+    __shared__ int orow[TM];                                      // output voxel index of each tile row, -1 = no row
+    __shared__ double sred[TN][2];
+    const int t = threadIdx.x, l = t & 63, w = t >> 6;
+    const int wr = w >> 1, wc = w & 1, lm = l & 31, lh = l >> 5;
     const int n = blockIdx.z, j0 = blockIdx.y * TN;
     const long long R = (long long)p.Rz * p.Ry * p.Rx;
-    const int la = t >> 2, lq = t & 3;   // A-load role: row, channel quad of the 16-channel chunk
+    const int la = t >> 2, lq = t & 3;     // A-load role: row, channel quad of the 16-channel chunk
     const int bci = t >> 4, bjq = t & 15;  // B-load role: chunk channel, out-channel quad
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int nchunk = (p.Ci + TK - 1) / TK, nsteps = p.ntaps * nchunk;
+    const bool bvec = p.wsj == 1 && p.bvec;
+    const int col = j0 + 32 * wc + lm;  // this lane's output channel
+    float s1 = 0.f, s2 = 0.f;
+    if (t < TN) sred[t][0] = sred[t][1] = 0.0;
     for (long long tile = blockIdx.x; tile * TM < R; tile += gridDim.x) {
         const long long ra = tile * TM + la;
         const bool rok = ra < R;
@@ -54,112 +64,89 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
             ry = (int)(q % p.Ry);
             rz = (int)(q / p.Ry);
         }
-        float acc[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
-        for (int tap = 0; tap < p.ntaps; ++tap) {
+        __syncthreads();  // the previous tile's epilogue has read orow; its last MFMAs have read the LDS buffers
+        if (lq == 0)
+            orow[la] = rok ? ((n * p.Do + rz * p.osz + p.ooz) * p.Ho + ry * p.osy + p.ooy) * p.Wo + rx * p.osx + p.oox : -1;
+        auto load_step = [&](int s_, f32x4& av, f32x4& bv) {
+            const int tap = s_ / nchunk, c0 = (s_ - tap * nchunk) * TK;
+            av = f32x4{0.f, 0.f, 0.f, 0.f};
+            bv = f32x4{0.f, 0.f, 0.f, 0.f};
             const int iz = rz * p.isz + p.tz[tap], iy = ry * p.isy + p.ty[tap], ix = rx * p.isx + p.tx[tap];
             const bool inb = rok && iz >= 0 && iz < p.Di && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-            const float* xrow = p.x + (inb ? ((size_t)((n * p.Di + iz) * p.Hi + iy) * p.Wi + ix) * p.Ci : 0);
-            const float* wt = p.w + p.woff[tap];
-            for (int c0 = 0; c0 < p.Ci; c0 += TK) {
-                f32x4 av = {0.f, 0.f, 0.f, 0.f};
-                const int ca = c0 + 4 * lq;
-                if (inb) {
-                    if (p.avec && ca + 3 < p.Ci) {
-                        av = *reinterpret_cast<const f32x4*>(xrow + ca);
-                    } else {
+            const int ca = c0 + 4 * lq;
+            if (inb) {
+                const float* xrow = p.x + ((size_t)((n * p.Di + iz) * p.Hi + iy) * p.Wi + ix) * p.Ci;
+                if (p.avec && ca + 3 < p.Ci) {
+                    av = *reinterpret_cast<const f32x4*>(xrow + ca);
+                } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (ca + e < p.Ci) av[e] = xrow[ca + e];
-                    }
-                }
-                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                const int cb = c0 + bci;
-                if (cb < p.Ci) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int j = j0 + 4 * bjq + e;
-                        if (j < p.Cj) bv[e] = wt[(size_t)cb * p.wsi + (size_t)j * p.wsj];
-                    }
-                }
-                __syncthreads();  // the previous chunk's reads are done
-#pragma unroll
-                for (int e = 0; e < 4; ++e) As[4 * lq + e][la] = av[e];
-                *reinterpret_cast<f32x4*>(&Bs[bci][4 * bjq]) = bv;
-                __syncthreads();
-#pragma unroll
-                for (int kk = 0; kk < TK; ++kk) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(&As[kk][4 * ty]);
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[kk][4 * tx]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[i][e] = fmaf(a[i], b[e], acc[i][e]);
+                    for (int e = 0; e < 4; ++e)
+                        if (ca + e < p.Ci) av[e] = xrow[ca + e];
                 }
             }
+            const int cb = c0 + bci, jb_ = j0 + 4 * bjq;
+            if (cb < p.Ci) {
+                const float* wt = p.w + p.woff[tap] + (size_t)cb * p.wsi;
+                if (bvec && jb_ + 3 < p.Cj) {
+                    bv = *reinterpret_cast<const f32x4*>(wt + jb_);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (jb_ + e < p.Cj) bv[e] = wt[(size_t)(jb_ + e) * p.wsj];
+                }
+            }
+        };
+        auto store_step = [&](int buf, const f32x4& av, const f32x4& bv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) As[buf][4 * lq + e][la] = av[e];
+            *reinterpret_cast<f32x4*>(&Bs[buf][bci][4 * bjq]) = bv;
+        };
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        f32x4 av, bv;
+        load_step(0, av, bv);
+        store_step(0, av, bv);
+        __syncthreads();
+        for (int s_ = 0; s_ < nsteps; ++s_) {
+            const int buf = s_ & 1;
+            const bool more = s_ + 1 < nsteps;
+            if (more) load_step(s_ + 1, av, bv);
+#pragma unroll
+            for (int kk = 0; kk < TK; kk += 2) {
+                const float a = As[buf][kk + lh][32 * wr + lm];
+                const float b = Bs[buf][kk + lh][32 * wc + lm];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+            if (more) store_step(buf ^ 1, av, bv);
+            __syncthreads();
         }
-        // ---- epilogue: rows tile*TM + 4*ty + i, out channels j0 + 4*tx + e
-        const int jb = j0 + 4 * tx;
-        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) {
+        // ---- epilogue.  C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+        const bool cok = col < p.Cj;
+        const float bias = (p.bias && cok) ? p.bias[col] : 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (jb + e < p.Cj) bias[e] = p.bias[jb + e];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long long r = tile * TM + 4 * ty + i;
-            if (r >= R || jb >= p.Cj) continue;
-            const int ox = (int)(r % p.Rx) * p.osx + p.oox;
-            const long long q = r / p.Rx;
-            const int oy = (int)(q % p.Ry) * p.osy + p.ooy;
-            const int oz = (int)(q / p.Ry) * p.osz + p.ooz;
-            const size_t o = ((size_t)((n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.Cj + jb;
-            f32x4 val;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) val[e] = acc[i][e] + bias[e];
-            if (p.ovec && jb + 3 < p.Cj) {
-                if (p.mask) {
-                    const f32x4 m = *reinterpret_cast<const f32x4*>(p.mask + o);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) val[e] = m[e] > 0.f ? val[e] : 0.f;
-                }
-                *reinterpret_cast<f32x4*>(p.out + o) = val;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (jb + e < p.Cj) {
-                        if (p.mask && !(p.mask[o + e] > 0.f)) val[e] = 0.f;
-                        p.out[o + e] = val[e];
-                    } else {
-                        val[e] = 0.f;
-                    }
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s1[e] += val[e];
-                s2[e] += val[e] * val[e];
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * wr + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int ov = orow[row];
+            if (ov < 0 || !cok) continue;
+            const size_t o = (size_t)ov * p.Cj + col;
+            float val = acc[r] + bias;
+            if (p.mask && !(p.mask[o] > 0.f)) val = 0.f;
+            p.out[o] = val;
+            s1 += val;
+            s2 += val * val;
         }
     }
     if (p.stats) {
-        // over the 16 row groups (ty) of a column through LDS, fixed order; one f64 atomic per (n, channel) and block
-        for (int pass = 0; pass < 2; ++pass) {
-            __syncthreads();
-#pragma unroll
-            for (int e = 0; e < 4; ++e) red[ty][4 * tx + e] = pass == 0 ? s1[e] : s2[e];
-            __syncthreads();
-            if (t < TN) {
-                double s = 0.0;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) s += (double)red[k][t];
-                const int j = j0 + t;
-                if (j < p.Cj) u3d_atomic_add_f64(&p.stats[((size_t)n * p.Cj + j) * 2 + pass], s);
-            }
+        __syncthreads();
+        if (col < p.Cj) {
+            __hip_atomic_fetch_add(&sred[32 * wc + lm][0], (double)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&sred[32 * wc + lm][1], (double)s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+        if (t < TN && j0 + t < p.Cj) {
+            u3d_atomic_add_f64(&p.stats[((size_t)n * p.Cj + j0 + t) * 2], sred[t][0]);
+            u3d_atomic_add_f64(&p.stats[((size_t)n * p.Cj + j0 + t) * 2 + 1], sred[t][1]);
         }
     }
 }
@@ -181,87 +168,90 @@ struct GWgradParams {
 };
 
 __global__ __launch_bounds__(256) void gwgrad_kernel(const GWgradParams p) {
+    // same MFMA scheme: D[a][b] += X^T Y over 16-row chunks; wave w owns the 32x32 quadrant (w >> 1, w & 1) of the 64x64 tile;
+    // register-prefetched double buffering, one barrier per chunk
     using namespace gc;
-    __shared__ __attribute__((aligned(16))) float Xs[TK][LD];
-    __shared__ __attribute__((aligned(16))) float Ys[TK][LD];
-    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    __shared__ __attribute__((aligned(16))) float Xs[2][TK][LD];
+    __shared__ __attribute__((aligned(16))) float Ys[2][TK][LD];
+    const int t = threadIdx.x, l = t & 63, w = t >> 6;
+    const int wr = w >> 1, wc = w & 1, lm = l & 31, lh = l >> 5;
     const int a0 = (blockIdx.x % p.atiles) * TM, b0 = (blockIdx.x / p.atiles) * TN;
     const int tap = blockIdx.y;
     const long long R = (long long)p.Rz * p.Ry * p.Rx, total = (long long)p.N * R;
     const long long r_begin = (long long)blockIdx.z * p.rows_per_split;
     const long long r_end = r_begin + p.rows_per_split < total ? r_begin + p.rows_per_split : total;
     const int lr = t >> 4, lqd = t & 15;  // load role: row of the 16-row chunk, channel quad
-    float acc[4][4];
+    f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool want_bias = p.bias_acc != nullptr && tap == 0 && a0 == 0;
-    for (long long rc = r_begin; rc < r_end; rc += TK) {
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bsum = 0.f;
+    const bool want_bias = p.bias_acc != nullptr && tap == 0 && a0 == 0 && wr == 0;
+    auto load_chunk = [&](long long rc, f32x4& xv, f32x4& yv) {
+        xv = f32x4{0.f, 0.f, 0.f, 0.f};
+        yv = f32x4{0.f, 0.f, 0.f, 0.f};
         const long long row = rc + lr;
-        f32x4 xv = {0.f, 0.f, 0.f, 0.f}, yv = {0.f, 0.f, 0.f, 0.f};
-        if (row < r_end) {
-            const int n = (int)(row / R);
-            const long long r = row - (long long)n * R;
-            const int rx = (int)(r % p.Rx);
-            const long long q = r / p.Rx;
-            const int ry = (int)(q % p.Ry), rz = (int)(q / p.Ry);
-            const int ca = a0 + 4 * lqd;
-            const float* xr = p.X + (size_t)row * p.Ca;
-            if (p.xvec && ca + 3 < p.Ca) {
-                xv = *reinterpret_cast<const f32x4*>(xr + ca);
+        if (row >= r_end) return;
+        const int n = (int)(row / R);
+        const long long r = row - (long long)n * R;
+        const int rx = (int)(r % p.Rx);
+        const long long q = r / p.Rx;
+        const int ry = (int)(q % p.Ry), rz = (int)(q / p.Ry);
+        const int ca = a0 + 4 * lqd;
+        const float* xr = p.X + (size_t)row * p.Ca;
+        if (p.xvec && ca + 3 < p.Ca) {
+            xv = *reinterpret_cast<const f32x4*>(xr + ca);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (ca + e < p.Ca) xv[e] = xr[ca + e];
+        }
+        const int yz = rz * p.ysz + p.tz[tap], yy = ry * p.ysy + p.ty[tap], yx = rx * p.ysx + p.tx[tap];
+        if (yz >= 0 && yz < p.Dy && yy >= 0 && yy < p.Hy && yx >= 0 && yx < p.Wy) {
+            const float* yr = p.Y + ((size_t)((n * p.Dy + yz) * p.Hy + yy) * p.Wy + yx) * p.Cb;
+            const int cb = b0 + 4 * lqd;
+            if (p.yvec && cb + 3 < p.Cb) {
+                yv = *reinterpret_cast<const f32x4*>(yr + cb);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (ca + e < p.Ca) xv[e] = xr[ca + e];
+                    if (cb + e < p.Cb) yv[e] = yr[cb + e];
             }
-            const int yz = rz * p.ysz + p.tz[tap], yy = ry * p.ysy + p.ty[tap], yx = rx * p.ysx + p.tx[tap];
-            if (yz >= 0 && yz < p.Dy && yy >= 0 && yy < p.Hy && yx >= 0 && yx < p.Wy) {
-                const float* yr = p.Y + ((size_t)((n * p.Dy + yz) * p.Hy + yy) * p.Wy + yx) * p.Cb;
-                const int cb = b0 + 4 * lqd;
-                if (p.yvec && cb + 3 < p.Cb) {
-                    yv = *reinterpret_cast<const f32x4*>(yr + cb);
-                } else {
+        }
+    };
+    f32x4 xv, yv;
+    if (r_begin < r_end) {
+        load_chunk(r_begin, xv, yv);
+        *reinterpret_cast<f32x4*>(&Xs[0][lr][4 * lqd]) = xv;
+        *reinterpret_cast<f32x4*>(&Ys[0][lr][4 * lqd]) = yv;
+    }
+    __syncthreads();
+    int buf = 0;
+    for (long long rc = r_begin; rc < r_end; rc += TK, buf ^= 1) {
+        const bool more = rc + TK < r_end;
+        if (more) load_chunk(rc + TK, xv, yv);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (cb + e < p.Cb) yv[e] = yr[cb + e];
-                }
-            }
+        for (int kk = 0; kk < TK; kk += 2) {
+            const float a = Xs[buf][kk + lh][32 * wr + lm];
+            const float b = Ys[buf][kk + lh][32 * wc + lm];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            if (want_bias) bsum += b;
+        }
+        if (more) {
+            *reinterpret_cast<f32x4*>(&Xs[buf ^ 1][lr][4 * lqd]) = xv;
+            *reinterpret_cast<f32x4*>(&Ys[buf ^ 1][lr][4 * lqd]) = yv;
         }
         __syncthreads();
-        *reinterpret_cast<f32x4*>(&Xs[lr][4 * lqd]) = xv;
-        *reinterpret_cast<f32x4*>(&Ys[lr][4 * lqd]) = yv;
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < TK; ++kk) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(&Xs[kk][4 * ty]);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(&Ys[kk][4 * tx]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[i][e] = fmaf(a[i], b[e], acc[i][e]);
-            if (want_bias && ty == 0) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bsum[e] += b[e];
-            }
-        }
     }
+    const int b = b0 + 32 * wc + lm;
+    if (b < p.Cb) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int a = a0 + 4 * ty + i;
-        if (a >= p.Ca) continue;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int b = b0 + 4 * tx + e;
-            if (b < p.Cb) u3d_atomic_add_f64(&p.acc[(size_t)tap * p.dst_t + (size_t)a * p.dst_a + (size_t)b * p.dst_b], (double)acc[i][e]);
+        for (int r = 0; r < 16; ++r) {
+            const int a = a0 + 32 * wr + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (a < p.Ca) u3d_atomic_add_f64(&p.acc[(size_t)tap * p.dst_t + (size_t)a * p.dst_a + (size_t)b * p.dst_b], (double)acc[r]);
         }
-    }
-    if (want_bias && ty == 0) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int b = b0 + 4 * tx + e;
-            if (b < p.Cb) u3d_atomic_add_f64(&p.bias_acc[b], (double)bsum[e]);
+        if (want_bias) {
+            bsum += __shfl_xor(bsum, 32);  // the two k-halves of the wave hold alternate rows
+            if (lh == 0) u3d_atomic_add_f64(&p.bias_acc[b], (double)bsum);
         }
     }
 }
@@ -357,6 +347,9 @@ static int launch_gconv(GConvParams& p, hipStream_t st) {
     if (gx > 2147483647ll) gx = 2147483647ll;
     p.avec = (p.Ci % 4 == 0 && al16(p.x)) ? 1 : 0;
     p.ovec = (p.Cj % 4 == 0 && al16(p.out) && (!p.mask || al16(p.mask))) ? 1 : 0;
+    p.bvec = (p.wsj == 1 && p.Cj % 4 == 0 && p.wsi % 4 == 0 && al16(p.w)) ? 1 : 0;
+    for (int k = 0; k < p.ntaps; ++k)
+        if (p.woff[k] % 4 != 0) p.bvec = 0;
     hipLaunchKernelGGL(gconv_kernel, dim3((unsigned)gx, (unsigned)jt, (unsigned)p.N), dim3(256), 0, st, p);
     U3D_LAUNCH_CHECK();
     return 0;
@@ -442,8 +435,34 @@ static int parity_taps(int pz, int py, int px, signed char* tz, signed char* ty,
     return n;
 }
 
+// packed image of the transposed-conv weights for coalesced B-tile loads:
+//   mode 0 (forward):   out[tap][ci][co] = w[ci][co][tap]        mode 1 (data gradient): out[tap][co][ci] = w[ci][co][tap]
+__global__ void pack_convtr_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin, int Cout, int mode) {
+    const long long total = (long long)27 * Cin * Cout;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int inner = mode == 0 ? Cout : Cin, outer = mode == 0 ? Cin : Cout;
+        const int j = (int)(i % inner);
+        const long long q = i / inner;
+        const int k = (int)(q % outer), tap = (int)(q / outer);
+        const int ci = mode == 0 ? k : j, co = mode == 0 ? j : k;
+        out[i] = w[((size_t)ci * Cout + co) * 27 + tap];
+    }
+}
+
+extern "C" int u3d_pack_convtr_weights(int device, u3d_stream_t stream, const float* w, int Cin, int Cout, int mode,
+                                       float* packed) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(w && packed && Cin > 0 && Cout > 0 && (mode == 0 || mode == 1), "u3d_pack_convtr_weights: bad argument");
+    const long long total = (long long)27 * Cin * Cout;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pack_convtr_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cin, Cout, mode);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int u3d_convtr3d_fwd(int device, u3d_stream_t stream, const float* x, const float* w, float* t, int N, int D1,
-                                int H1, int W1, int Cin, int Cout) {
+                                int H1, int W1, int Cin, int Cout, const float* packed) {
     if (int e = u3d_enter(device)) return e;
     U3D_REQUIRE(x && w && t && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && Cin > 0 && Cout > 0, "u3d_convtr3d_fwd: bad argument");
     const int Dt = 2 * D1 - 1, Ht = 2 * H1 - 1, Wt = 2 * W1 - 1;
@@ -459,6 +478,10 @@ extern "C" int u3d_convtr3d_fwd(int device, u3d_stream_t stream, const float* x,
         p.osz = p.osy = p.osx = 2, p.ooz = pz, p.ooy = py, p.oox = px, p.isz = p.isy = p.isx = 1;
         p.ntaps = parity_taps(pz, py, px, p.tz, p.ty, p.tx, p.woff);
         p.wsi = (long long)Cout * 27, p.wsj = 27;  // element (ci, co, tap) at w[(ci*Cout + co)*27 + tap]
+        if (packed) {                               // packed[tap][ci][co]
+            p.w = packed, p.wsi = Cout, p.wsj = 1;
+            for (int k = 0; k < p.ntaps; ++k) p.woff[k] *= Cin * Cout;
+        }
         if (int e = launch_gconv(p, st)) return e;
     }
     return 0;
@@ -469,7 +492,8 @@ extern "C" int u3d_convtr3d_fwd(int device, u3d_stream_t stream, const float* x,
 //                    x > 0 when relu_mask (x is the post-ReLU output of the block that produced it)
 //   acc[(ci*Cout + co)*27 + t] += sum_i x[i, ci] * dt[2i - 1 + t, co]   (zeroed double scratch; u3d_cvt_f64_f32)
 extern "C" int u3d_convtr3d_bwd(int device, u3d_stream_t stream, const float* dt, const float* x, const float* w, int N,
-                                int D1, int H1, int W1, int Cin, int Cout, int relu_mask, float* dx, double* acc) {
+                                int D1, int H1, int W1, int Cin, int Cout, int relu_mask, float* dx, double* acc,
+                                const float* packed_t) {
     if (int e = u3d_enter(device)) return e;
     U3D_REQUIRE(dt && x && w && acc && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && Cin > 0 && Cout > 0, "u3d_convtr3d_bwd: bad argument");
     const int Dt = 2 * D1 - 1, Ht = 2 * H1 - 1, Wt = 2 * W1 - 1;
@@ -487,6 +511,10 @@ extern "C" int u3d_convtr3d_bwd(int device, u3d_stream_t stream, const float* dt
             p.woff[tp] = tp;
         }
         p.wsi = 27, p.wsj = (long long)Cout * 27;  // (tap, in = co, out = ci) at w[(ci*Cout + co)*27 + tap]
+        if (packed_t) {                              // packed_t[tap][co][ci]
+            p.w = packed_t, p.wsi = Cin, p.wsj = 1;
+            for (int tp = 0; tp < 27; ++tp) p.woff[tp] = tp * Cin * Cout;
+        }
         if (int e = launch_gconv(p, st)) return e;
     }
     GWgradParams g{};

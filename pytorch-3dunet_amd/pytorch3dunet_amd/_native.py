@@ -109,10 +109,12 @@ _PROTOS = {
     ),
     "u3d_conv1x1_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
     "u3d_conv1x1_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p]),
-    "u3d_convtr3d_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "u3d_pack_convtr_weights": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "u3d_convtr3d_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "u3d_convtr3d_bwd": (
         c_int,
-        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+         c_void_p],
     ),
     "u3d_nearest_add_fwd": (
         c_int,

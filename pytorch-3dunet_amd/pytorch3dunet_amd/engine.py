@@ -539,6 +539,19 @@ class ResUNetEngine(UNet3DEngine):
         self.enc = [(e.pooling is not None, e.basic_module) for e in model.encoders]
         self.dec = [(d.upsampling.upsample.conv_transposed, d.basic_module) for d in model.decoders]
 
+    def _packed_convtr(self, w: torch.Tensor, mode: int, dev) -> torch.Tensor:
+        """[tap][Cin][Cout] (mode 0) / [tap][Cout][Cin] (mode 1) image of a ConvTranspose3d weight, cached per version"""
+        key = (id(w), 10 + mode)
+        ver = (w._version, w.data_ptr())
+        hit = self._pack_cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        Cin, Cout = w.shape[0], w.shape[1]
+        out = torch.empty(27 * Cin * Cout, dtype=_F32, device=dev)
+        nat.call("u3d_pack_convtr_weights", dev.index, _stream(dev), _p(w.detach()), Cin, Cout, mode, _p(out))
+        self._pack_cache[key] = (ver, out)
+        return out
+
     # -- forward ------------------------------------------------------------------------------------
     def _block_fwd(self, bm, name, x_in, x_st, pool, tape, dev):
         N, D, H, W, Cin = x_in.shape
@@ -678,7 +691,7 @@ class ResUNetEngine(UNet3DEngine):
             Dt, Ht, Wt = 2 * D1 - 1, 2 * H1 - 1, 2 * W1 - 1
             t = torch.empty((Nl, Dt, Ht, Wt, Cs), dtype=_F32, device=dev)
             nat.call("u3d_convtr3d_fwd", dev.index, _stream(dev), _p(cur), _p(ct.weight.detach()), _p(t), Nl, D1, H1, W1, Cl, Cs,
-                     flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
+                     _p(self._packed_convtr(ct.weight, 0, dev)), flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
             (mz, lz), (my, ly), (mx, lx) = _maps(dev, Dt, Ds), _maps(dev, Ht, Hs), _maps(dev, Wt, Ws)
             joined = torch.empty_like(sk)
             j_st = pool.take(Nl * Cs * 2)
@@ -770,7 +783,7 @@ class ResUNetEngine(UNet3DEngine):
             acc = pool.take(up.weight.numel())
             dxl = torch.empty_like(xl)
             nat.call("u3d_convtr3d_bwd", dev.index, _stream(dev), _p(dt), _p(xl), _p(up.weight.detach()), Nl, D1, H1, W1, Cl, Cs,
-                     1, _p(dxl), _p(acc), flops=4.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
+                     1, _p(dxl), _p(acc), _p(self._packed_convtr(up.weight, 1, dev)), flops=4.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
             nat.call("u3d_cvt_f64_f32", dev.index, _stream(dev), _p(acc), _p(gview(self._pindex[id(up.weight)])),
                      up.weight.numel())
             del dt

@@ -66,15 +66,26 @@ def test_convtranspose3d_forward_backward(N, Cin, Cout, size, relu_mask):
     t.backward(dt)
     xd, wd = U.ndhwc(x.detach()), w.detach().contiguous().to(U.DEV)
     td = torch.empty((N, 2 * D1 - 1, 2 * H1 - 1, 2 * W1 - 1, Cout), device=U.DEV)
-    nat.call("u3d_convtr3d_fwd", 0, _stream(U.DEV), _p(xd), _p(wd), _p(td), N, D1, H1, W1, Cin, Cout)
+    nat.call("u3d_convtr3d_fwd", 0, _stream(U.DEV), _p(xd), _p(wd), _p(td), N, D1, H1, W1, Cin, Cout, None)
     assert U.relerr(U.ncdhw(td), t.detach()) < TOL
+    pk0, pk1 = torch.empty(27 * Cin * Cout, device=U.DEV), torch.empty(27 * Cin * Cout, device=U.DEV)
+    nat.call("u3d_pack_convtr_weights", 0, _stream(U.DEV), _p(wd), Cin, Cout, 0, _p(pk0))
+    nat.call("u3d_pack_convtr_weights", 0, _stream(U.DEV), _p(wd), Cin, Cout, 1, _p(pk1))
+    td2 = torch.empty_like(td)
+    nat.call("u3d_convtr3d_fwd", 0, _stream(U.DEV), _p(xd), _p(wd), _p(td2), N, D1, H1, W1, Cin, Cout, _p(pk0))
+    assert U.relerr(U.ncdhw(td2), t.detach()) < TOL
     dtd = U.ndhwc(dt)
     dx = torch.empty_like(xd)
     acc = torch.zeros(Cin * Cout * 27, dtype=torch.float64, device=U.DEV)
     nat.call("u3d_convtr3d_bwd", 0, _stream(U.DEV), _p(dtd), _p(xd), _p(wd), N, D1, H1, W1, Cin, Cout, relu_mask, _p(dx),
-             _p(acc))
+             _p(acc), None)
     ref_dx = x.grad * (x.detach() > 0) if relu_mask else x.grad
     assert U.relerr(U.ncdhw(dx), ref_dx) < TOL
+    dx2 = torch.empty_like(xd)
+    acc2 = torch.zeros_like(acc)
+    nat.call("u3d_convtr3d_bwd", 0, _stream(U.DEV), _p(dtd), _p(xd), _p(wd), N, D1, H1, W1, Cin, Cout, relu_mask, _p(dx2),
+             _p(acc2), _p(pk1))
+    assert U.relerr(U.ncdhw(dx2), ref_dx) < TOL
     assert U.relerr(acc.cpu().float().view(Cin, Cout, 3, 3, 3), w.grad) < 1e-4
 
 
