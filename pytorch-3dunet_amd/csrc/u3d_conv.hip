@@ -20,6 +20,7 @@
 //   [0] forced N-tiles per block of u3d_conv3d (1,2,3; 0 = automatic)   [1] wgrad split override (0 = automatic)
 //   [2] ablation mask of the instrumented conv twin (timing experiments, wrong results)
 //   [3] 1 = never use the persistent fast variant of u3d_conv3d (A/B against the generic kernel)
+//   [4] 1 = never use the paired-y variant for <= 16 output channels
 int g_u3d_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 namespace cv {
@@ -36,6 +37,7 @@ constexpr int LDS_FLOATS = RED_OFF + 4 * 3 * 32 * 2;  // 20472 floats = 81888 B 
 constexpr int NITEMS = HZ * HY * HX * (CC / 4);   // 2400 float4 items per chunk
 constexpr int NIT = (NITEMS + 255) / 256;         // 10
 constexpr int NSTEP = 27 * (CC / 8);              // 54 k-steps of 8 channels per chunk
+constexpr int NSTEP_PAIRY = 36 * (CC / 8);        // 72 k-steps: 3 x 4 x 3 tap window of the paired-y variant
 constexpr int ST0 = 30;                           // k-step of the first halo store into the other buffer
 constexpr int ISTORE = 5;                         // persistent variant: tap row (of 9) whose k-steps store the halo
 constexpr int PACK_PAD = 5;                       // zero k-steps appended to the packed weight image (B prefetch overrun)
@@ -530,10 +532,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvParams p)
 //   * needs no LDS in the epilogue (DPP transposition), accumulates the GroupNorm statistics per wave in LDS
 //     (ds_add_f64) and flushes them with f64 atomics when the block's sample changes.
 // Everything else (flags instead of barriers, halo prefetch schedule, fragment layouts) is the generic kernel's.
-template <int NT, bool VIRT, bool DBG = false>
+//
+// PAIRY (Cout <= 16, NT = 1): half of a 32-column N-tile would be padding.  Columns 16-31 instead compute the SAME 16
+// output channels for the voxel one row further in y: out[y+1] = sum_t x[y + (t_y+1)] w[t], i.e. the shared A row of
+// voxel y serves both outputs when the tap window is 3 x 4 x 3 (36 taps, the weights of the second half shifted by one
+// in y, zero where that leaves the 3^3 kernel).  A wave then needs only the even rows y = 0,2,4,6 of its z-plane (ONE
+// M-tile): 72 k-steps x 4 MFMAs per chunk instead of 54 x 8 — 2/3 of the padded work.
+template <int NT, bool VIRT, bool DBG = false, bool PAIRY = false>
 __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParams p) {
     using namespace cv;
-    constexpr int RB = NT == 1 ? 6 : 3;  // B ring depth (54 % RB == 0, 6 % RB == 0)
+    static_assert(!PAIRY || NT == 1, "the paired-y variant has a single N-tile");
+    constexpr int RB = NT == 1 ? 6 : 3;  // B ring depth (54 % RB == 0, 72 % RB == 0, 6 % RB == 0)
+    constexpr int MT = PAIRY ? 1 : 2;    // M-tiles (4 y-rows x 8 x) per wave
+    constexpr int RY = PAIRY ? 4 : 3;    // taps along y
+    constexpr int NROWS = 3 * RY;        // tap rows (z, y) of 3 x-taps x 2 channel octets = 6 k-steps each
+    constexpr int NSTEPL = NROWS * 6;    // k-steps per chunk
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int* cnt = reinterpret_cast<int*>(lds + CNT_OFF);
     // [2 sample parities][NT*32][2] block-level partial statistics, accumulated in f64 (ds_add_f64): the arrival order
@@ -617,16 +630,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
     int wi = u3d_xcd_remap(blockIdx.x, G);
     Item T = item_of(wi);
 
-    f32x16 acc[2][NT];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    // A-fragment base: lane (m,h) -> voxel (zl = w, yl = (m>>3) [+4 for mt=1], xl = m&7), channels 4h..4h+3
-    const int abase = w * PS + (m >> 3) * RS + (m & 7) * CS + 4 * h;
+    // A-fragment base: lane (m,h) -> voxel (zl = w, yl = (m>>3) [+4 for mt=1], xl = m&7), channels 4h..4h+3;
+    // PAIRY: yl = 2*(m>>3) (even rows only)
+    const int abase = w * PS + (m >> 3) * (PAIRY ? 2 : 1) * RS + (m & 7) * CS + 4 * h;
 
     // B stream: uniform base pointer of the block's channel block + the lane's 16-byte slot (no VALU per step)
     const f32x4* wimg = reinterpret_cast<const f32x4*>(p.wp);
@@ -752,16 +766,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
 
             // ---- 54 k-steps as 9 tap rows x 6 steps (3 taps x 2 channel-octets) of 8*NT MFMAs; tap row 0 carries
             //      the 10 halo loads of the next chunk, tap row ISTORE their LDS stores
-            f32x4 aq[2][2];
-            aq[0][0] = *reinterpret_cast<const f32x4*>(&cur[abase]);
-            aq[0][1] = *reinterpret_cast<const f32x4*>(&cur[abase + 4 * RS]);
-            const f32x4* wrow = wq + (size_t)(ch * NSTEP + RB - 1) * wstep;  // B fragments of step (row, 0) + RB-1
+            f32x4 aq[2][MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) aq[0][mt] = *reinterpret_cast<const f32x4*>(&cur[abase + 4 * mt * RS]);
+            const f32x4* wrow = wq + (size_t)(ch * NSTEPL + RB - 1) * wstep;  // B fragments of step (row, 0) + RB-1
 #pragma unroll 1
-            for (int row = 0; row < 9; ++row) {
-                const int rz = row / 3, ry = row - 3 * rz;
+            for (int row = 0; row < NROWS; ++row) {
+                const int rz = row / RY, ry = row - RY * rz;
                 const float* arow = cur + abase + rz * PS + ry * RS;
                 const int nrow = row + 1;
-                const float* anext = cur + abase + (nrow / 3) * PS + (nrow % 3) * RS;
+                const float* anext = cur + abase + (nrow / RY) * PS + (nrow % RY) * RS;
                 const bool do_load = row == 0, do_store = row == ISTORE && has_next;
                 if (do_store) u3d_flag_wait(&cnt[2 + (b ^ 1)], 4 * ((gch + 1) / 2));  // other buffer free
 #pragma unroll
@@ -778,7 +792,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                     {
                         // B fragments of step + RB-1; past the end of a tile's image continue with the next tile's
                         const f32x4* wsrc = wrow + (size_t)s6 * wstep;
-                        if (s6 + RB - 1 >= 6 && row == 8 && last) wsrc = wqn + (size_t)(s6 + RB - 1 - 6) * wstep;
+                        if (s6 + RB - 1 >= 6 && row == NROWS - 1 && last) wsrc = wqn + (size_t)(s6 + RB - 1 - 6) * wstep;
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) bq[(s6 + RB - 1) % RB][nt] = wsrc[nt * 64 + l];
                     }
@@ -787,18 +801,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                     for (int j = 0; j < 2; ++j) {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
-                            acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s6 & 1][0][j], bq[s6 % RB][nt][j], acc[0][nt], 0, 0, 0);
-                            acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s6 & 1][1][j], bq[s6 % RB][nt][j], acc[1][nt], 0, 0, 0);
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s6 & 1][mt][j], bq[s6 % RB][nt][j], acc[mt][nt], 0, 0, 0);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (s6 < 5) {
                         const int aoff = ((s6 + 1) >> 1) * CS + 8 * ((s6 + 1) & 1);
-                        aq[(s6 + 1) & 1][0] = *reinterpret_cast<const f32x4*>(&arow[aoff]);
-                        aq[(s6 + 1) & 1][1] = *reinterpret_cast<const f32x4*>(&arow[4 * RS + aoff]);
-                    } else if (row < 8) {
-                        aq[0][0] = *reinterpret_cast<const f32x4*>(&anext[0]);
-                        aq[0][1] = *reinterpret_cast<const f32x4*>(&anext[4 * RS]);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) aq[(s6 + 1) & 1][mt] = *reinterpret_cast<const f32x4*>(&arow[4 * mt * RS + aoff]);
+                    } else if (row < NROWS - 1) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) aq[0][mt] = *reinterpret_cast<const f32x4*>(&anext[4 * mt * RS]);
                     }
                     if (do_store && s6 < NIT / 2) {
                         if (masked) {
@@ -815,8 +830,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                     for (int j = 2; j < 4; ++j) {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
-                            acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s6 & 1][0][j], bq[s6 % RB][nt][j], acc[0][nt], 0, 0, 0);
-                            acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s6 & 1][1][j], bq[s6 % RB][nt][j], acc[1][nt], 0, 0, 0);
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s6 & 1][mt][j], bq[s6 % RB][nt][j], acc[mt][nt], 0, 0, 0);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -849,9 +865,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 f32x4 q1 = {0.f, 0.f, 0.f, 0.f}, q2 = {0.f, 0.f, 0.f, 0.f};
-                f32x4 tq[8];  // row st = 4*mt + bi: the lane's channel quad at voxel (y0 + st, x0 + vl)
+                f32x4 tq[4 * MT];  // row st = 4*mt + bi: the lane's channel quad at voxel (y0 + yoff(st), x0 + vl)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int bi = 0; bi < 4; ++bi) {
                         const float a0 = acc[mt][nt][4 * bi + 0], a1 = acc[mt][nt][4 * bi + 1];
@@ -861,26 +877,29 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                         const float u0 = xlane(c2, X2{}), u2 = xlane(c0, X2{}), u1 = xlane(c3, X2{}), u3 = xlane(c1, X2{});
                         tq[4 * mt + bi] = f32x4{hi ? u0 : c0, hi ? u1 : c1, hi ? c2 : u2, hi ? c3 : u3};
                     }
-                const int co = (cb * NT + nt) * 32 + 4 * cq;
+                // PAIRY: column quad cq = (second-row flag, channel quad): columns 16-31 are the voxels one row below
+                const int ysh = PAIRY ? (cq >> 2) : 0;
+                const int co = PAIRY ? 4 * (cq & 3) : (cb * NT + nt) * 32 + 4 * cq;
+                auto yoff = [&](int st) { return PAIRY ? 2 * st + ysh : st; };
                 const bool cok = co < p.Cout;
                 float* orow = p.out + (size_t)vrow * p.Cout + co;
                 const bool xfrom0 = co < p.gx.C0 || !cok;
                 const float* xb = !cok ? p.gx.p0 : (xfrom0 ? p.gx.p0 + co : p.gx.p1 + (co - p.gx.C0));
                 const int xcs = xfrom0 ? p.gx.C0 : p.gx.C1;
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {  // two batches of 4 rows bound the live registers
+                for (int half = 0; half < MT; ++half) {  // batches of 4 rows bound the live registers
                     f32x4 xv[4];
                     if (want_g) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            const int st = 4 * half + k;
-                            const int xi = xfrom0 ? vrow + st * W : xrow + (st >> 1) * p.gx.W1;
+                            const int yo = yoff(4 * half + k);
+                            const int xi = xfrom0 ? vrow + yo * W : xrow + (yo >> 1) * p.gx.W1;
                             xv[k] = *reinterpret_cast<const f32x4*>(xb + (size_t)xi * xcs);
                         }
                     } else if (p.res) {  // residual rows (same voxels / channels as the output rows)
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            xv[k] = *reinterpret_cast<const f32x4*>(p.res + (size_t)(vrow + (4 * half + k) * W) * p.Cout + (cok ? co : 0));
+                            xv[k] = *reinterpret_cast<const f32x4*>(p.res + (size_t)(vrow + yoff(4 * half + k) * W) * p.Cout + (cok ? co : 0));
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -891,7 +910,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
 #pragma unroll
                             for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
                         }
-                        if (cok) *reinterpret_cast<f32x4*>(orow + (size_t)st * W * p.Cout) = val;
+                        if (cok) *reinterpret_cast<f32x4*>(orow + (size_t)yoff(st) * W * p.Cout) = val;
                         if (p.Cout % 32 != 0) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) val[e] = cok ? val[e] : 0.f;
@@ -909,8 +928,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                             a += __shfl_xor(a, mask);
                             b2 += __shfl_xor(b2, mask);
                         }
-                        if ((l & 35) == 0) {
-                            double* r = &red[(((n & 1) * NT + nt) * 32 + 4 * cq + e) * 2];
+                        if constexpr (PAIRY) {  // the two y-rows of a channel quad sit 16 lanes apart
+                            a += __shfl_xor(a, 16);
+                            b2 += __shfl_xor(b2, 16);
+                        }
+                        if ((l & (PAIRY ? 51 : 35)) == 0) {
+                            double* r = &red[(((n & 1) * NT + nt) * 32 + co - (PAIRY ? 0 : (cb * NT + nt) * 32) + e) * 2];
                             __hip_atomic_fetch_add(r, (double)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             __hip_atomic_fetch_add(r + 1, (double)b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
@@ -923,7 +946,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
         if (!has_next_tile || TN.n != T.n || TN.cb != T.cb) flush_stats(T.n, T.cb);
         if (!has_next_tile) break;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -1348,21 +1371,36 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin,
                                     int mode, int nchunks, int ntot) {
     const long long total = ((long long)nchunks * cv::NSTEP + cv::PACK_PAD) * ntot * 256;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+    // narrow outputs (<= 16 channels) get a second image for the paired-y kernel variant: 72 k-steps per chunk over the
+    // 3 x 4 x 3 tap window, columns 16-31 = the same channels with the kernel shifted by one row in y
+    const int Nn = mode == 0 ? Cout : Cin;
+    const long long total2 = Nn <= 16 ? ((long long)nchunks * cv::NSTEP_PAIRY + cv::PACK_PAD) * 256 : 0;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total + total2;
          idx += (long long)gridDim.x * blockDim.x) {
-        const int j = (int)(idx & 3);
-        const int lane = (int)((idx >> 2) & 63);
-        long long r = idx >> 8;
-        const int ntg = (int)(r % ntot);
-        r /= ntot;
-        const int st = (int)(r % cv::NSTEP);
-        const int ch = (int)(r / cv::NSTEP);
+        const bool pair = idx >= total;
+        const long long id = pair ? idx - total : idx;
+        const int j = (int)(id & 3);
+        const int lane = (int)((id >> 2) & 63);
+        long long r = id >> 8;
+        const int nstep = pair ? cv::NSTEP_PAIRY : cv::NSTEP;
+        const int ntg = pair ? 0 : (int)(r % ntot);
+        if (!pair) r /= ntot;
+        const int st = (int)(r % nstep);
+        const int ch = (int)(r / nstep);
         const int kc = ch * 16 + 8 * (st & 1) + 4 * (lane >> 5) + j;
-        const int tap = st >> 1;
-        const int nc = ntg * 32 + (lane & 31);
+        int tap = st >> 1;
+        int nc = ntg * 32 + (lane & 31);
+        bool tap_ok = true;
+        if (pair) {
+            const int tz = tap / 12, ty4 = (tap / 3) % 4, tx = tap % 3;
+            const int ty = ty4 - ((lane & 31) >> 4);  // second half: kernel shifted by one row
+            tap_ok = ty >= 0 && ty <= 2;
+            tap = (tz * 3 + ty) * 3 + tx;
+            nc = lane & 15;
+        }
         float v = 0.f;
-        if (ch >= nchunks) {
-            // the trailing zero steps
+        if (ch >= nchunks || !tap_ok) {
+            // the trailing zero steps / taps outside the 3^3 kernel
         } else if (mode == 0) {
             if (kc < Cin && nc < Cout) v = w[((size_t)nc * Cin + kc) * 27 + tap];
         } else {
@@ -1446,7 +1484,9 @@ extern "C" int u3d_set_tuning(int key, int value) {
 
 extern "C" size_t u3d_packed_weight_floats(int Cin, int Cout, int mode) {
     const int K = mode == 0 ? Cin : Cout, Nn = mode == 0 ? Cout : Cin;
-    return ((size_t)cdiv(K, 16) * cv::NSTEP + cv::PACK_PAD) * cdiv(Nn, 32) * 256;  // + zero steps (prefetch overrun)
+    size_t n = ((size_t)cdiv(K, 16) * cv::NSTEP + cv::PACK_PAD) * cdiv(Nn, 32) * 256;  // + zero steps (prefetch overrun)
+    if (Nn <= 16) n += ((size_t)cdiv(K, 16) * cv::NSTEP_PAIRY + cv::PACK_PAD) * 256;   // + the paired-y image
+    return n;
 }
 
 extern "C" int u3d_pack_weights(int device, u3d_stream_t stream, const float* w, int Cout, int Cin, int mode,
@@ -1455,7 +1495,8 @@ extern "C" int u3d_pack_weights(int device, u3d_stream_t stream, const float* w,
     U3D_REQUIRE(w && packed && Cout > 0 && Cin > 0 && (mode == 0 || mode == 1), "u3d_pack_weights: bad argument");
     const int K = mode == 0 ? Cin : Cout, Nn = mode == 0 ? Cout : Cin;
     const int nchunks = cdiv(K, 16), ntot = cdiv(Nn, 32);
-    const long long total = ((long long)nchunks * cv::NSTEP + cv::PACK_PAD) * ntot * 256;
+    long long total = ((long long)nchunks * cv::NSTEP + cv::PACK_PAD) * ntot * 256;
+    if (Nn <= 16) total += ((long long)nchunks * cv::NSTEP_PAIRY + cv::PACK_PAD) * 256;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin,
                        mode, nchunks, ntot);
@@ -1488,6 +1529,12 @@ static int conv_set_lds_nt() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<NT, true, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (NT == 1) {
+        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<1, false, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<1, true, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    }
     U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_kernel<NT, true, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_kernel<NT, false, false>),
@@ -1602,6 +1649,16 @@ static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, co
         const dim3 rgrid((unsigned)slots), rblock(256);
         const bool virt = p.src.C1 > 0;
         p.dbg = (g_u3d_prof_buf && (size_t)slots * 4 <= g_u3d_prof_records) ? g_u3d_prof_buf : nullptr;
+        if (Cout <= 16 && nt == 1 && p.ntot == 1 && !p.dbg && g_u3d_tune[4] == 0) {
+            // paired-y variant on the second packed image (u3d_pack_weights appends it for <= 16 output channels)
+            p.wp = packed_w + ((size_t)p.nchunks * cv::NSTEP + cv::PACK_PAD) * 256;
+            if (virt)
+                hipLaunchKernelGGL((conv3d_mfma_reg_kernel<1, true, false, true>), rgrid, rblock, shmem, st, p);
+            else
+                hipLaunchKernelGGL((conv3d_mfma_reg_kernel<1, false, false, true>), rgrid, rblock, shmem, st, p);
+            U3D_LAUNCH_CHECK();
+            return 0;
+        }
 #define U3D_REG_LAUNCH(NT_)                                                                                \
     do {                                                                                                   \
         if (p.dbg && virt)                                                                                 \

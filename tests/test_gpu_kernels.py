@@ -37,6 +37,9 @@ CONV_CASES = [
     (1, 96, 32, 8, 16, 16, True, 1),      # 6 chunks (dec2.conv1 channel shape)
     (1, 64, 128, 4, 8, 8, False, 0),      # 4 n-tiles
     (1, 20, 24, 6, 10, 9, True, 1),       # channel padding inside a chunk (vec path, C%4==0 but C%16!=0)
+    (2, 32, 16, 8, 16, 16, True, 1),      # <= 16 output channels, aligned dims: paired-y variant
+    (1, 16, 8, 4, 8, 8, True, 0),
+    (1, 48, 12, 4, 16, 8, False, 1),
 ]
 
 
@@ -172,7 +175,9 @@ def test_conv3d_virtual_concat_upsample(size):
     assert U.relerr(dw.cpu(), wl.grad) < 1e-4
 
 
-DGRAD_CASES = [(1, 16, 32, 8, 16, 16), (2, 32, 64, 9, 13, 11), (1, 1, 16, 8, 16, 16), (1, 96, 32, 4, 8, 8), (1, 3, 8, 5, 9, 7)]
+DGRAD_CASES = [(1, 16, 32, 8, 16, 16), (2, 32, 64, 9, 13, 11), (1, 1, 16, 8, 16, 16), (1, 96, 32, 4, 8, 8), (1, 3, 8, 5, 9, 7),
+               # <= 16 output channels of the data gradient, aligned dims: the paired-y variant (several tiles / samples)
+               (2, 16, 32, 8, 16, 32), (1, 8, 16, 4, 8, 8), (1, 12, 24, 8, 24, 16)]
 
 
 @pytest.mark.parametrize("N,Cin,Cout,D,H,W", DGRAD_CASES)
