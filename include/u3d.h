@@ -188,6 +188,14 @@ int u3d_maxpool2_fwd(int device, u3d_stream_t stream, const float* x, int N, int
 int u3d_maxpool2_bwd_merge(int device, u3d_stream_t stream, const float* dg, const float* pooled,
                            const uint8_t* argmax, const float* coef, const float* skip_grad, const float* e,
                            int N, int D, int H, int W, int C, int relu_mask, float* out);
+/* Same with the skip gradient computed on the fly as the GroupNorm backward of the decoder's first conv restricted to the
+ * skip channels (the first C of Cdg channels of skip_dg, coefficient table skip_coef[N][3][Ctot]):
+ *      skip_grad = ps*skip_dg[v, c] + qs*e[v, c] + rs
+ * — the skip half of `torch.cat` backward + GroupNorm backward never makes a round trip through HBM. */
+int u3d_maxpool2_bwd_merge_gn(int device, u3d_stream_t stream, const float* dg, const float* pooled,
+                              const uint8_t* argmax, const float* coef, const float* skip_dg, int Cdg,
+                              const float* skip_coef, int Ctot, const float* e, int N, int D, int H, int W, int C,
+                              int relu_mask, float* out);
 
 /* ---- final 1x1x1 conv with bias + Sigmoid/Softmax (model.py:88-101,141-147) -------------------
  * x (N,V,Cin) NDHWC; w (Cout,Cin), b (Cout).  logits/probs are written in the reference's NCDHW

@@ -412,18 +412,25 @@ extern "C" int u3d_maxpool2_fwd(int device, u3d_stream_t stream, const float* x,
     return 0;
 }
 
-// dz_e = (skip_grad + scatter(dpool)) * (e > 0); one thread per (n, window, channel), windows cover ceil dims
+// dz_e = (skip_grad + scatter(dpool)) * (e > 0); one thread per (n, 2x2x2 window, channel unit), windows cover ceil dims.
+// A unit is VW (4 or 1) channels.  The skip gradient is either absent, a plain tensor (sdg with Csdg channels per voxel),
+// or — fused — the GroupNorm backward of the decoder's first conv restricted to the skip channels:
+//     skip = ps*sdg[v, c] + qs*e[v, c] + rs      (scoef[N][3][Cstot], skip channels first => no channel offset)
+// which removes one full write + read of the skip gradient per decoder level.
+template <int VW>
 __global__ void maxpool2_bwd_merge_kernel(const float* __restrict__ dg, const float* __restrict__ pooled,
                                           const uint8_t* __restrict__ argmax, const float* __restrict__ coef,
-                                          const float* __restrict__ skip, const float* __restrict__ e, int N, int D,
-                                          int H, int W, int C, int relu_mask, float* __restrict__ out) {
+                                          const float* __restrict__ sdg, int Csdg, const float* __restrict__ scoef,
+                                          int Cstot, const float* __restrict__ e, int N, int D, int H, int W, int C,
+                                          int relu_mask, float* __restrict__ out) {
     const int D2 = D >> 1, H2 = H >> 1, W2 = W >> 1;
     const int Dc = (D + 1) >> 1, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1;
-    const long long total = (long long)N * Dc * Hc * Wc * C;
+    const int Q = C / VW;
+    const long long total = (long long)N * Dc * Hc * Wc * Q;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C);
-        long long v = idx / C;
+        const int c = (int)(idx % Q) * VW;
+        long long v = idx / Q;
         const int xo = (int)(v % Wc);
         v /= Wc;
         const int yo = (int)(v % Hc);
@@ -431,40 +438,96 @@ __global__ void maxpool2_bwd_merge_kernel(const float* __restrict__ dg, const fl
         const int zo = (int)(v % Dc);
         const int n = (int)(v / Dc);
         const bool pv = zo < D2 && yo < H2 && xo < W2;
-        float dp = 0.f;
-        int am = -1;
+        float dp[VW], ps[VW], qs[VW], rs[VW];
+        int am[VW];
+#pragma unroll
+        for (int k = 0; k < VW; ++k) {
+            dp[k] = 0.f;
+            am[k] = -1;
+            ps[k] = 1.f, qs[k] = 0.f, rs[k] = 0.f;
+            if (scoef) {
+                ps[k] = scoef[((size_t)n * 3 + 0) * Cstot + c + k];
+                qs[k] = scoef[((size_t)n * 3 + 1) * Cstot + c + k];
+                rs[k] = scoef[((size_t)n * 3 + 2) * Cstot + c + k];
+            }
+        }
         if (pv) {
             const size_t pi = ((size_t)((n * D2 + zo) * H2 + yo) * W2 + xo) * C + c;
-            dp = dg[pi];
-            if (coef) dp = coef[((size_t)n * 3 + 0) * C + c] * dp + coef[((size_t)n * 3 + 1) * C + c] * pooled[pi] +
-                           coef[((size_t)n * 3 + 2) * C + c];
-            am = argmax[pi];
+#pragma unroll
+            for (int k = 0; k < VW; ++k) {
+                dp[k] = dg[pi + k];
+                if (coef)
+                    dp[k] = coef[((size_t)n * 3 + 0) * C + c + k] * dp[k] + coef[((size_t)n * 3 + 1) * C + c + k] * pooled[pi + k] +
+                            coef[((size_t)n * 3 + 2) * C + c + k];
+                am[k] = argmax[pi + k];
+            }
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int z = 2 * zo + (k >> 2), y = 2 * yo + ((k >> 1) & 1), xx = 2 * xo + (k & 1);
+        for (int j = 0; j < 8; ++j) {
+            const int z = 2 * zo + (j >> 2), y = 2 * yo + ((j >> 1) & 1), xx = 2 * xo + (j & 1);
             if (z < D && y < H && xx < W) {
-                const size_t ei = ((size_t)((n * D + z) * H + y) * W + xx) * C + c;
-                float g = skip ? skip[ei] : 0.f;
-                if (k == am) g += dp;
-                if (relu_mask && !(e[ei] > 0.f)) g = 0.f;
-                out[ei] = g;
+                const size_t vi = (size_t)((n * D + z) * H + y) * W + xx;
+                const size_t ei = vi * C + c;
+                float ev[VW], sv[VW], o[VW];
+                if (VW == 4) {
+                    const f32x4 t = (relu_mask || scoef) ? *reinterpret_cast<const f32x4*>(e + ei) : f32x4{1.f, 1.f, 1.f, 1.f};
+                    const f32x4 u = sdg ? *reinterpret_cast<const f32x4*>(sdg + vi * Csdg + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ev[k] = t[k], sv[k] = u[k];
+                } else {
+                    ev[0] = (relu_mask || scoef) ? e[ei] : 1.f;
+                    sv[0] = sdg ? sdg[vi * Csdg + c] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < VW; ++k) {
+                    float g = sdg ? (scoef ? ps[k] * sv[k] + qs[k] * ev[k] + rs[k] : sv[k]) : 0.f;
+                    if (j == am[k]) g += dp[k];
+                    if (relu_mask && !(ev[k] > 0.f)) g = 0.f;
+                    o[k] = g;
+                }
+                if (VW == 4)
+                    *reinterpret_cast<f32x4*>(out + ei) = f32x4{o[0], o[1], o[2], o[3]};
+                else
+                    out[ei] = o[0];
             }
         }
     }
 }
 
+static int maxpool2_bwd_merge_impl(int device, u3d_stream_t stream, const float* dg, const float* pooled,
+                                   const uint8_t* argmax, const float* coef, const float* sdg, int Csdg, const float* scoef,
+                                   int Cstot, const float* e, int N, int D, int H, int W, int C, int relu_mask, float* out) {
+    if (int er = u3d_enter(device)) return er;
+    U3D_REQUIRE(dg && argmax && out && (coef == nullptr || pooled) && (!(relu_mask || scoef) || e) && N > 0 && C > 0 &&
+                    (!sdg || Csdg >= C) && (!scoef || (sdg && Cstot >= C)),
+                "u3d_maxpool2_bwd_merge: bad argument");
+    const bool vec = C % 4 == 0 && (!sdg || Csdg % 4 == 0) &&
+                     (((uintptr_t)e | (uintptr_t)sdg | (uintptr_t)out) & 15) == 0;
+    const long long total = (long long)N * ((D + 1) / 2) * ((H + 1) / 2) * ((W + 1) / 2) * (vec ? C / 4 : C);
+    if (vec)
+        hipLaunchKernelGGL(maxpool2_bwd_merge_kernel<4>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, dg,
+                           pooled, argmax, coef, sdg, Csdg, scoef, Cstot, e, N, D, H, W, C, relu_mask, out);
+    else
+        hipLaunchKernelGGL(maxpool2_bwd_merge_kernel<1>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, dg,
+                           pooled, argmax, coef, sdg, Csdg, scoef, Cstot, e, N, D, H, W, C, relu_mask, out);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int u3d_maxpool2_bwd_merge(int device, u3d_stream_t stream, const float* dg, const float* pooled,
                                       const uint8_t* argmax, const float* coef, const float* skip_grad,
                                       const float* e, int N, int D, int H, int W, int C, int relu_mask, float* out) {
-    if (int er = u3d_enter(device)) return er;
-    U3D_REQUIRE(dg && argmax && out && (coef == nullptr || pooled) && (!relu_mask || e) && N > 0 && C > 0,
-                "u3d_maxpool2_bwd_merge: bad argument");
-    const long long total = (long long)N * ((D + 1) / 2) * ((H + 1) / 2) * ((W + 1) / 2) * C;
-    hipLaunchKernelGGL(maxpool2_bwd_merge_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, dg,
-                       pooled, argmax, coef, skip_grad, e, N, D, H, W, C, relu_mask, out);
-    U3D_LAUNCH_CHECK();
-    return 0;
+    return maxpool2_bwd_merge_impl(device, stream, dg, pooled, argmax, coef, skip_grad, C, nullptr, 0, e, N, D, H, W, C,
+                                   relu_mask, out);
+}
+
+extern "C" int u3d_maxpool2_bwd_merge_gn(int device, u3d_stream_t stream, const float* dg, const float* pooled,
+                                         const uint8_t* argmax, const float* coef, const float* skip_dg, int Cdg,
+                                         const float* skip_coef, int Ctot, const float* e, int N, int D, int H, int W, int C,
+                                         int relu_mask, float* out) {
+    if (!skip_dg || !skip_coef) return u3d_set_err(U3D_EINVAL, "u3d_maxpool2_bwd_merge_gn: skip_dg / skip_coef are NULL");
+    return maxpool2_bwd_merge_impl(device, stream, dg, pooled, argmax, coef, skip_dg, Cdg, skip_coef, Ctot, e, N, D, H, W, C,
+                                   relu_mask, out);
 }
 
 // =================================================================================================

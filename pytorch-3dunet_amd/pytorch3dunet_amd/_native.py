@@ -91,6 +91,11 @@ _PROTOS = {
         [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
          c_int, c_void_p],
     ),
+    "u3d_maxpool2_bwd_merge_gn": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
+         c_int, c_int, c_int, c_int, c_void_p],
+    ),
     "u3d_conv1x1_head_fwd": (
         c_int,
         [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p],

@@ -452,12 +452,10 @@ class UNet3DEngine:
             dg1, coef1 = conv_bwd(r1, dz1)
             src = r1.src
             C0, C1, Ct = src.C0, src.C1, src.C
-            # skip half -> gradient of the encoder feature (mask applied later, merged with the pool path)
+            # skip half -> gradient of the encoder feature: its GroupNorm backward (p*dg + q*e + r on the first C0 channels)
+            # is evaluated inside the max-pool merge kernel of that encoder level, never written to HBM
             lvl = n_levels - 2 - j
-            sg = torch.empty_like(src.t0)
-            nat.call("u3d_gn_bwd_apply", dev.index, _stream(dev), _p(dg1), Ct, 0, _p(src.t0), C0, _p(coef1), Ct,
-                     src.D * src.H * src.W, src.N, 0, _p(sg))
-            skip_grad[lvl] = sg
+            skip_grad[lvl] = (dg1, Ct, coef1)
             # upsampled half -> low-res producer (previous decoder's conv2 or the deepest encoder), ReLU mask fused
             dzl = torch.empty_like(src.t1)
             lz, ly, lx = src.los
@@ -482,8 +480,15 @@ class UNet3DEngine:
                 pooled, argmax, e_in = tape.pools[i - 1]
                 Ne, De, He, We, Ce = e_in.shape
                 out = torch.empty_like(e_in)
-                nat.call("u3d_maxpool2_bwd_merge", dev.index, _stream(dev), _p(dg1), _p(pooled), _p(argmax), _p(coef1),
-                         _p(skip_grad.get(i - 1)), _p(e_in), Ne, De, He, We, Ce, 1, _p(out))
+                sk = skip_grad.pop(i - 1, None)
+                if sk is None:
+                    nat.call("u3d_maxpool2_bwd_merge", dev.index, _stream(dev), _p(dg1), _p(pooled), _p(argmax), _p(coef1), None,
+                             _p(e_in), Ne, De, He, We, Ce, 1, _p(out))
+                else:
+                    sdg, sCt, scoef = sk
+                    nat.call("u3d_maxpool2_bwd_merge_gn", dev.index, _stream(dev), _p(dg1), _p(pooled), _p(argmax), _p(coef1),
+                             _p(sdg), sCt, _p(scoef), sCt, _p(e_in), Ne, De, He, We, Ce, 1, _p(out))
+                    del sk, sdg, scoef
                 dz = out
             elif need_input_grad:
                 dx0 = plain_apply(dg1, coef1, tape.x0, 0)
