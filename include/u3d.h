@@ -83,6 +83,17 @@ int u3d_set_profile_buffer(void* device_buffer, size_t bytes);
  * u3d_packed_weight_floats gives the size of the image in floats for (Cin,Cout,mode). */
 size_t u3d_packed_weight_floats(int Cin, int Cout, int mode);
 int u3d_pack_weights(int device, u3d_stream_t stream, const float* w, int Cout, int Cin, int mode, float* packed);
+/* All layers of a model in ONE launch (weights change every optimizer step: 2 x 13 pack launches per step otherwise).
+ * descs: DEVICE array of n descriptors sorted by `first` = cumulative float offset of the layer's image(s) within the
+ * concatenation (first of descriptor 0 is 0); total_floats = sum of u3d_packed_weight_floats over the descriptors. */
+typedef struct {
+    const float* w; /* (Cout,Cin,3,3,3) */
+    float* packed;  /* u3d_packed_weight_floats(Cin, Cout, mode) floats */
+    int64_t first;
+    int32_t Cout, Cin, mode, pad_;
+} u3d_pack_desc_t;
+int u3d_pack_weights_batch(int device, u3d_stream_t stream, const u3d_pack_desc_t* descs_device, int n,
+                           int64_t total_floats);
 
 /* ---- Conv3d 3x3x3, stride 1, pad 1, bias=False ------------------------------------------------
  * Replaces nn.Conv3d(in,out,3,padding=1,bias=False) (buildingblocks.py:56) forward, and — called with

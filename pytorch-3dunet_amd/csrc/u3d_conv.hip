@@ -1368,46 +1368,74 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // =================================================================================================
 // weight packing: packed f32x4 index (((ch*54 + st)*ntot + ntg)*64 + lane), element j:
 //   k-channel  c  = ch*16 + 8*(st&1) + 4*(lane>>5) + j,  tap = st>>1,  n-channel = ntg*32 + (lane&31)
-__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin,
-                                    int mode, int nchunks, int ntot) {
+// one element of the packed image(s) of one layer: `idx` counts through the normal image, then (<= 16 output channels) the
+// paired-y image
+__device__ __forceinline__ float pack_elem(const float* __restrict__ w, int Cout, int Cin, int mode, int nchunks, int ntot,
+                                           long long idx) {
     const long long total = ((long long)nchunks * cv::NSTEP + cv::PACK_PAD) * ntot * 256;
     // narrow outputs (<= 16 channels) get a second image for the paired-y kernel variant: 72 k-steps per chunk over the
     // 3 x 4 x 3 tap window, columns 16-31 = the same channels with the kernel shifted by one row in y
-    const int Nn = mode == 0 ? Cout : Cin;
-    const long long total2 = Nn <= 16 ? ((long long)nchunks * cv::NSTEP_PAIRY + cv::PACK_PAD) * 256 : 0;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total + total2;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const bool pair = idx >= total;
-        const long long id = pair ? idx - total : idx;
-        const int j = (int)(id & 3);
-        const int lane = (int)((id >> 2) & 63);
-        long long r = id >> 8;
-        const int nstep = pair ? cv::NSTEP_PAIRY : cv::NSTEP;
-        const int ntg = pair ? 0 : (int)(r % ntot);
-        if (!pair) r /= ntot;
-        const int st = (int)(r % nstep);
-        const int ch = (int)(r / nstep);
-        const int kc = ch * 16 + 8 * (st & 1) + 4 * (lane >> 5) + j;
-        int tap = st >> 1;
-        int nc = ntg * 32 + (lane & 31);
-        bool tap_ok = true;
-        if (pair) {
-            const int tz = tap / 12, ty4 = (tap / 3) % 4, tx = tap % 3;
-            const int ty = ty4 - ((lane & 31) >> 4);  // second half: kernel shifted by one row
-            tap_ok = ty >= 0 && ty <= 2;
-            tap = (tz * 3 + ty) * 3 + tx;
-            nc = lane & 15;
+    const bool pair = idx >= total;
+    const long long id = pair ? idx - total : idx;
+    const int j = (int)(id & 3);
+    const int lane = (int)((id >> 2) & 63);
+    long long r = id >> 8;
+    const int nstep = pair ? cv::NSTEP_PAIRY : cv::NSTEP;
+    const int ntg = pair ? 0 : (int)(r % ntot);
+    if (!pair) r /= ntot;
+    const int st = (int)(r % nstep);
+    const int ch = (int)(r / nstep);
+    const int kc = ch * 16 + 8 * (st & 1) + 4 * (lane >> 5) + j;
+    int tap = st >> 1;
+    int nc = ntg * 32 + (lane & 31);
+    bool tap_ok = true;
+    if (pair) {
+        const int tz = tap / 12, ty4 = (tap / 3) % 4, tx = tap % 3;
+        const int ty = ty4 - ((lane & 31) >> 4);  // second half: kernel shifted by one row
+        tap_ok = ty >= 0 && ty <= 2;
+        tap = (tz * 3 + ty) * 3 + tx;
+        nc = lane & 15;
+    }
+    float v = 0.f;
+    if (ch >= nchunks || !tap_ok) {
+        // the trailing zero steps / taps outside the 3^3 kernel
+    } else if (mode == 0) {
+        if (kc < Cin && nc < Cout) v = w[((size_t)nc * Cin + kc) * 27 + tap];
+    } else {
+        // dgrad: contraction over original cout (kc), output = original cin (nc), flipped taps
+        if (kc < Cout && nc < Cin) v = w[((size_t)kc * Cin + nc) * 27 + (26 - tap)];
+    }
+    return v;
+}
+
+static long long pack_total_floats(int Cin, int Cout, int mode, int* nchunks_out, int* ntot_out) {
+    const int K = mode == 0 ? Cin : Cout, Nn = mode == 0 ? Cout : Cin;
+    const int nchunks = (K + 15) / 16, ntot = (Nn + 31) / 32;
+    long long total = ((long long)nchunks * cv::NSTEP + cv::PACK_PAD) * ntot * 256;
+    if (Nn <= 16) total += ((long long)nchunks * cv::NSTEP_PAIRY + cv::PACK_PAD) * 256;
+    if (nchunks_out) *nchunks_out = nchunks;
+    if (ntot_out) *ntot_out = ntot;
+    return total;
+}
+
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin,
+                                    int mode, int nchunks, int ntot, long long total) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x)
+        out[idx] = pack_elem(w, Cout, Cin, mode, nchunks, ntot, idx);
+}
+
+// all layers of a model in ONE launch: descs (device memory) hold cumulative element offsets in `first`
+__global__ void pack_weights_batch_kernel(const u3d_pack_desc_t* __restrict__ descs, int n, long long total) {
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = n - 1;  // last descriptor with first <= g
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (descs[mid].first <= g) lo = mid; else hi = mid - 1;
         }
-        float v = 0.f;
-        if (ch >= nchunks || !tap_ok) {
-            // the trailing zero steps / taps outside the 3^3 kernel
-        } else if (mode == 0) {
-            if (kc < Cin && nc < Cout) v = w[((size_t)nc * Cin + kc) * 27 + tap];
-        } else {
-            // dgrad: contraction over original cout (kc), output = original cin (nc), flipped taps
-            if (kc < Cout && nc < Cin) v = w[((size_t)kc * Cin + nc) * 27 + (26 - tap)];
-        }
-        out[idx] = v;
+        const u3d_pack_desc_t d = descs[lo];
+        const int K = d.mode == 0 ? d.Cin : d.Cout, Nn = d.mode == 0 ? d.Cout : d.Cin;
+        d.packed[g - d.first] = pack_elem(d.w, d.Cout, d.Cin, d.mode, (K + 15) / 16, (Nn + 31) / 32, g - d.first);
     }
 }
 
@@ -1483,23 +1511,30 @@ extern "C" int u3d_set_tuning(int key, int value) {
 }
 
 extern "C" size_t u3d_packed_weight_floats(int Cin, int Cout, int mode) {
-    const int K = mode == 0 ? Cin : Cout, Nn = mode == 0 ? Cout : Cin;
-    size_t n = ((size_t)cdiv(K, 16) * cv::NSTEP + cv::PACK_PAD) * cdiv(Nn, 32) * 256;  // + zero steps (prefetch overrun)
-    if (Nn <= 16) n += ((size_t)cdiv(K, 16) * cv::NSTEP_PAIRY + cv::PACK_PAD) * 256;   // + the paired-y image
-    return n;
+    return (size_t)pack_total_floats(Cin, Cout, mode, nullptr, nullptr);  // incl. zero steps (prefetch overrun) and pair image
 }
 
 extern "C" int u3d_pack_weights(int device, u3d_stream_t stream, const float* w, int Cout, int Cin, int mode,
                                 float* packed) {
     if (int e = u3d_enter(device)) return e;
     U3D_REQUIRE(w && packed && Cout > 0 && Cin > 0 && (mode == 0 || mode == 1), "u3d_pack_weights: bad argument");
-    const int K = mode == 0 ? Cin : Cout, Nn = mode == 0 ? Cout : Cin;
-    const int nchunks = cdiv(K, 16), ntot = cdiv(Nn, 32);
-    long long total = ((long long)nchunks * cv::NSTEP + cv::PACK_PAD) * ntot * 256;
-    if (Nn <= 16) total += ((long long)nchunks * cv::NSTEP_PAIRY + cv::PACK_PAD) * 256;
+    int nchunks = 0, ntot = 0;
+    const long long total = pack_total_floats(Cin, Cout, mode, &nchunks, &ntot);
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin,
-                       mode, nchunks, ntot);
+                       mode, nchunks, ntot, total);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int u3d_pack_weights_batch(int device, u3d_stream_t stream, const u3d_pack_desc_t* descs_device, int n,
+                                      int64_t total_floats) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(descs_device && n > 0 && total_floats > 0, "u3d_pack_weights_batch: bad argument");
+    long long blocks = (total_floats + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pack_weights_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, descs_device, n,
+                       (long long)total_floats);
     U3D_LAUNCH_CHECK();
     return 0;
 }

@@ -314,37 +314,52 @@ static int gn_bwd_apply_impl(int device, u3d_stream_t stream, const float* dg, i
     return 0;
 }
 
-// upsampled half of a concat: sum over the children of each low-res voxel
+// upsampled half of a concat: sum over the children of each low-res voxel; a thread owns VW (4 or 1) channels
+template <int VW>
 __global__ void gn_bwd_apply_up_kernel(const float* __restrict__ dg, int Cdg, int coff, const float* __restrict__ x1,
                                        int C1, const float* __restrict__ coef, int Ctot, int N, int D, int H, int W,
                                        int D1, int H1, int W1, const int* __restrict__ zlo,
                                        const int* __restrict__ ylo, const int* __restrict__ xlo, int relu_mask,
                                        float* __restrict__ out) {
-    const long long total = (long long)N * D1 * H1 * W1 * C1;
+    const int Q = C1 / VW;
+    const long long total = (long long)N * D1 * H1 * W1 * Q;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C1);
-        long long v = idx / C1;
+        const int c = (int)(idx % Q) * VW;
+        long long v = idx / Q;
         const int xx = (int)(v % W1);
         v /= W1;
         const int yy = (int)(v % H1);
         v /= H1;
         const int zz = (int)(v % D1);
         const int n = (int)(v / D1);
-        float sum = 0.f;
+        float sum[VW];
+#pragma unroll
+        for (int k = 0; k < VW; ++k) sum[k] = 0.f;
         int cnt = 0;
         for (int z = zlo[zz]; z < zlo[zz + 1]; ++z)
             for (int y = ylo[yy]; y < ylo[yy + 1]; ++y)
                 for (int x = xlo[xx]; x < xlo[xx + 1]; ++x) {
-                    sum += dg[((size_t)((n * D + z) * H + y) * W + x) * Cdg + coff + c];
+                    const float* src = dg + ((size_t)((n * D + z) * H + y) * W + x) * Cdg + coff + c;
+                    if (VW == 4) {
+                        const f32x4 t = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) sum[k] += t[k];
+                    } else {
+                        sum[0] += src[0];
+                    }
                     ++cnt;
                 }
-        const float xv = x1[idx];
-        const float p = coef[((size_t)n * 3 + 0) * Ctot + coff + c], q = coef[((size_t)n * 3 + 1) * Ctot + coff + c],
-                    r = coef[((size_t)n * 3 + 2) * Ctot + coff + c];
-        float o = p * sum + (float)cnt * (q * xv + r);
-        if (relu_mask && !(xv > 0.f)) o = 0.f;
-        out[idx] = o;
+        const size_t oi = (size_t)(idx / Q) * C1 + c;
+#pragma unroll
+        for (int k = 0; k < VW; ++k) {
+            const float xv = x1[oi + k];
+            const float p = coef[((size_t)n * 3 + 0) * Ctot + coff + c + k], q = coef[((size_t)n * 3 + 1) * Ctot + coff + c + k],
+                        r = coef[((size_t)n * 3 + 2) * Ctot + coff + c + k];
+            float o = p * sum[k] + (float)cnt * (q * xv + r);
+            if (relu_mask && !(xv > 0.f)) o = 0.f;
+            out[oi + k] = o;
+        }
     }
 }
 
@@ -356,9 +371,14 @@ extern "C" int u3d_gn_bwd_apply_up(int device, u3d_stream_t stream, const float*
     U3D_REQUIRE(dg && x1 && coef && out && zlo && ylo && xlo && C1 > 0 && coff >= 0 && coff + C1 <= Cdg &&
                     Ctot >= coff + C1 && N > 0,
                 "u3d_gn_bwd_apply_up: bad argument");
-    const long long total = (long long)N * D1 * H1 * W1 * C1;
-    hipLaunchKernelGGL(gn_bwd_apply_up_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, dg,
-                       Cdg, coff, x1, C1, coef, Ctot, N, D, H, W, D1, H1, W1, zlo, ylo, xlo, relu_mask, out);
+    const bool vec = C1 % 4 == 0 && Cdg % 4 == 0 && coff % 4 == 0 && ((uintptr_t)dg & 15) == 0;
+    const long long total = (long long)N * D1 * H1 * W1 * (vec ? C1 / 4 : C1);
+    if (vec)
+        hipLaunchKernelGGL(gn_bwd_apply_up_kernel<4>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, dg,
+                           Cdg, coff, x1, C1, coef, Ctot, N, D, H, W, D1, H1, W1, zlo, ylo, xlo, relu_mask, out);
+    else
+        hipLaunchKernelGGL(gn_bwd_apply_up_kernel<1>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, dg,
+                           Cdg, coff, x1, C1, coef, Ctot, N, D, H, W, D1, H1, W1, zlo, ylo, xlo, relu_mask, out);
     U3D_LAUNCH_CHECK();
     return 0;
 }

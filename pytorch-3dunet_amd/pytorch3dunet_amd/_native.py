@@ -33,6 +33,13 @@ class U3DSrc(ctypes.Structure):
     ]
 
 
+class U3DPackDesc(ctypes.Structure):
+    """mirror of u3d_pack_desc_t (include/u3d.h)"""
+
+    _fields_ = [("w", c_void_p), ("packed", c_void_p), ("first", c_int64), ("Cout", c_int32), ("Cin", c_int32),
+                ("mode", c_int32), ("pad_", c_int32)]
+
+
 _PROTOS = {
     # name: (restype, argtypes)
     "u3d_version": (c_int, []),
@@ -42,6 +49,7 @@ _PROTOS = {
     "u3d_set_profile_buffer": (c_int, [c_void_p, c_size_t]),
     "u3d_packed_weight_floats": (c_size_t, [c_int, c_int, c_int]),
     "u3d_pack_weights": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "u3d_pack_weights_batch": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int64]),
     "u3d_conv3d": (
         c_int,
         [c_int, c_void_p, POINTER(U3DSrc), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,

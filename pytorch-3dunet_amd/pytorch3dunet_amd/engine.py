@@ -196,6 +196,59 @@ class UNet3DEngine:
             self.dec.append((bm.SingleConv1, bm.SingleConv2))
 
     # -- helpers ------------------------------------------------------------------------------------
+    def _conv_weights(self):
+        """every 3x3x3 conv weight the MFMA kernels read through a packed image"""
+        out = []
+        for mod in self.model.modules():
+            if isinstance(mod, torch.nn.Conv3d) and mod.kernel_size == (3, 3, 3):
+                out.append(mod.weight)
+        return out
+
+    def _repack_all(self, dev, modes):
+        """(Re)pack the images of ALL conv weights whose parameter changed since the last pack — one launch for the whole
+        model (u3d_pack_weights_batch) instead of one per layer and mode.  The packed buffers and the device descriptor
+        table are allocated once and reused (stable pointers)."""
+        ws = getattr(self, "_cw", None)
+        if ws is None:
+            ws = self._cw = self._conv_weights()
+        stale = []
+        for w in ws:
+            if self.small_cin and w.shape[1] <= 4 and w.shape[0] <= 32:
+                continue  # first layer: dedicated kernels read the reference layout
+            for mode in modes:
+                hit = self._pack_cache.get((id(w), mode))
+                if hit is None or hit[0] != (w._version, w.data_ptr()):
+                    stale.append((w, mode))
+        if not stale:
+            return
+        lib = nat.get_lib()
+        key = tuple((id(w), mode, w.data_ptr()) for w, mode in stale)
+        tab = getattr(self, "_pack_tables", None)
+        if tab is None:
+            tab = self._pack_tables = {}
+        ent = tab.get(key)
+        if ent is None:
+            descs = (nat.U3DPackDesc * len(stale))()
+            bufs, first = [], 0
+            for i, (w, mode) in enumerate(stale):
+                Cout, Cin = w.shape[0], w.shape[1]
+                n = lib.u3d_packed_weight_floats(Cin, Cout, mode)
+                hit = self._pack_cache.get((id(w), mode))
+                buf = hit[1] if hit is not None and hit[1].numel() == n and hit[1].device == dev else torch.empty(
+                    n, dtype=_F32, device=dev)
+                bufs.append(buf)
+                descs[i].w, descs[i].packed, descs[i].first = w.data_ptr(), buf.data_ptr(), first
+                descs[i].Cout, descs[i].Cin, descs[i].mode = Cout, Cin, mode
+                first += n
+            host = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8)
+            ent = (host.to(dev), bufs, first)
+            tab.clear()  # one live table per (set of stale weights): parameters are re-packed together every step
+            tab[key] = ent
+        table, bufs, total = ent
+        nat.call("u3d_pack_weights_batch", dev.index, _stream(dev), _p(table), len(stale), total)
+        for (w, mode), buf in zip(stale, bufs):
+            self._pack_cache[(id(w), mode)] = ((w._version, w.data_ptr()), buf)
+
     def _packed(self, w: torch.Tensor, mode: int, dev) -> torch.Tensor:
         key = (id(w), mode)
         ver = (w._version, w.data_ptr())
@@ -343,6 +396,7 @@ class UNet3DEngine:
         if tape is not None:
             tape.x0 = x0
             tape.dims = (N, Cin, D, H, W)
+        self._repack_all(dev, (0, 1) if save else (0,))
         # stat doubles: every conv output + every GN input computed standalone; generous upper bound
         tot = 0
         for _, c1, c2 in self.enc:
@@ -671,6 +725,7 @@ class ResUNetEngine(UNet3DEngine):
             tape.dims = (N, Cin, D, H, W)
             tape.blocks = []
             tape.ups = []
+        self._repack_all(dev, (0, 1) if save else (0,))
         widths = [bm.conv2.conv.in_channels for _, bm in self.enc]
         pool = _StatPool(dev, 16 * N * sum(widths) * 2 + 64)
 
