@@ -21,6 +21,7 @@
 //   [2] ablation mask of the instrumented conv twin (timing experiments, wrong results)
 //   [3] 1 = never use the persistent fast variant of u3d_conv3d (A/B against the generic kernel)
 //   [4] 1 = never use the paired-y variant for <= 16 output channels
+//   [5] start-phase stagger of the persistent kernel in units of 1024 cycles (0 = off)
 int g_u3d_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 namespace cv {
@@ -58,6 +59,7 @@ struct ConvParams {
     int relu, vec, has_gx, ovec;
     int total;   // REG kernel: work items = tiles * ncb
     int gx_x2;   // REG kernel: gx's low-res half is an exact 2x upsampling (index = i >> 1, no table)
+    int stagger; // REG kernel: start delay of the second half of the grid, in units of 1024 cycles
     long long* dbg;  // optional per-wave timeline records (u3d_set_profile_buffer), 24 int64 per wave
 };
 
@@ -737,6 +739,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
         (void)masked;
     }
     u3d_flag_signal(&cnt[0], l);
+
+    // Phase-stagger experiment (u3d_set_tuning key 5, default off).  Blocks b and b + G/2 share a CU (observed with the
+    // timeline twin: every SIMD holds one wave of each, starting within ~40 cycles of each other) and, doing identical work,
+    // run their k-loops AND their epilogues at the same time.  Delaying the second half of the grid once would interleave
+    // the phases — measured: no gain (see host side).
+    if (p.stagger > 0 && (int)blockIdx.x >= (G + 1) / 2) {
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+    }
 
     int gch = 0;     // chunks done by this wave over all tiles: buffer parity and flag targets
     int ntiles = 0;  // tiles done (timeline record)
@@ -1674,6 +1684,9 @@ static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, co
     if (reg) {
         p.total = (int)nblk;
         p.gx_x2 = (gx && p.gx.C1 > 0) ? 1 : 0;
+        // experiment knob, default off: a sweep of 8..64 k cycles changed no layer by more than noise (profiles/r01q) — a
+        // wave that is alone on its SIMD does not run at twice the shared rate, so interleaving the epilogues buys nothing
+        p.stagger = g_u3d_tune[5] > 0 ? g_u3d_tune[5] : 0;
         int ncu = 0;
         if (int e = device_cu_count(device, &ncu)) return e;
         long long slots = 2ll * ncu;  // two blocks per CU (LDS)

@@ -46,18 +46,24 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--only", default="fwd,dgrad,wgrad")
     ap.add_argument("--patch", default="64,128,128")
+    ap.add_argument("--layers", default="", help="comma-separated layer names (default: all)")
     args = ap.parse_args()
     only = args.only.split(",")
     N = args.batch
     D0, H0, W0 = (int(v) for v in args.patch.split(","))
     tot = {k: [0.0, 0.0] for k in only}
     lib = nat.get_lib()
+    for kv in os.environ.get("U3D_TUNE", "").split(","):  # e.g. U3D_TUNE=5:24 (start-phase stagger of 24k cycles)
+        if ":" in kv:
+            nat.call("u3d_set_tuning", int(kv.split(":")[0]), int(kv.split(":")[1]))
     # warm the clocks
     a = torch.randn(4096, 4096, device=dev)
     for _ in range(20):
         a @ a
     torch.cuda.synchronize()
     for name, C0, C1, Cout, lvl in LAYERS:
+        if args.layers and name not in args.layers.split(","):
+            continue
         D, H, W = D0 >> lvl, H0 >> lvl, W0 >> lvl
         Cin = C0 + C1
         t0 = torch.randn(N, D, H, W, C0, device=dev)

@@ -115,6 +115,15 @@ def run(name, dgrad, forced_nt=0, dims=None, abl=0):
         s0, s1 = entry[idx_t].min().item(), exit_[idx_t].max().item()
         utils.append(done[idx_t].sum().item() * mfma_cyc / (s1 - s0))
         conc.append(life[idx_t].sum().item() / (s1 - s0))
+    # which blocks share a SIMD?  (the dispatcher's placement decides who must be staggered against whom)
+    pairs = defaultdict(int)
+    for k, idx in list(groups.items()):
+        blks = sorted(set(int(r[i, 0]) for i in idx))
+        if len(blks) == 2:
+            pairs[blks[1] - blks[0]] += 1
+    top = sorted(pairs.items(), key=lambda kv: -kv[1])[:6]
+    print(f"   co-resident block-id differences (count of SIMDs): {top}; first-k-loop start spread per SIMD pair (ticks): "
+          f"{torch.tensor([abs(int(staged[i[0]]) - int(staged[i[-1]])) for i in groups.values() if len(i) >= 2]).double().mean():.0f}")
     ut = torch.tensor(utils)
     print(f"   SIMDs seen {len(groups)}; waves/SIMD {nw / len(groups):.1f}; MFMA-pipe utilisation per SIMD (ticks basis): "
           f"mean {ut.mean():.3f} min {ut.min():.3f} max {ut.max():.3f}; mean concurrent waves/SIMD {sum(conc) / len(conc):.2f}")
