@@ -22,6 +22,7 @@
 //   [3] 1 = never use the persistent fast variant of u3d_conv3d (A/B against the generic kernel)
 //   [4] 1 = never use the paired-y variant for <= 16 output channels
 //   [5] start-phase stagger of the persistent kernel in units of 1024 cycles (0 = off)
+//   [6] 1 = one persistent block per CU instead of two (occupancy experiment)
 int g_u3d_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 namespace cv {
@@ -1689,7 +1690,7 @@ static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, co
         p.stagger = g_u3d_tune[5] > 0 ? g_u3d_tune[5] : 0;
         int ncu = 0;
         if (int e = device_cu_count(device, &ncu)) return e;
-        long long slots = 2ll * ncu;  // two blocks per CU (LDS)
+        long long slots = (g_u3d_tune[6] == 1 ? 1ll : 2ll) * ncu;  // two blocks per CU (LDS); key 6 = 1: one (experiment)
         if (slots >= nblk)
             slots = nblk;
         else if (slots > p.ncb)
