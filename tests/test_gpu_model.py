@@ -263,3 +263,60 @@ def test_uncovered_variant_strict_mode(monkeypatch):
     monkeypatch.setenv("U3D_STRICT", "1")
     with pytest.raises(NotImplementedError):
         model(torch.rand(1, 1, 8, 16, 16, device=dev))
+
+
+@pytest.mark.parametrize("name,levels,shape", [("UNet3D", 4, (1, 1, 8, 8, 8)), ("UNet3D", 3, (3, 1, 4, 12, 20)),
+                                               ("ResidualUNet3D", 3, (1, 1, 4, 4, 4)), ("ResidualUNetSE3D", 3, (2, 1, 6, 10, 14))])
+def test_edge_shapes_minimum_size_and_odd_batch(name, levels, shape):
+    """smallest legal inputs (one voxel at the deepest level), batch 3, sizes that are not multiples of the pooling
+    factor: forward + every gradient against the CPU oracle"""
+    import unet3d_oracle as orc
+
+    torch.manual_seed(11)
+    model = _make(dict(name=name, in_channels=1, out_channels=1, f_maps=8, num_levels=levels, num_groups=4))
+    x = torch.randn(shape)
+    target = (torch.rand(shape) > 0.5).float()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    p_ref, l_ref, loss_ref, g_ref, ref_err = orc.forward_backward_with_truth(sd, x, target, 4, True, True, "bce_dice")
+    probs, logits, loss, grads = _run_native(model, x, target, "bce_dice")
+    assert orc.rel_err(logits, l_ref) < REL and orc.rel_err(probs, p_ref) < REL
+    keys = list(g_ref)
+    ours = torch.cat([grads[k].flatten().double() for k in keys])
+    ref = torch.cat([g_ref[k].flatten().double() for k in keys])
+    assert ((ours - ref).norm() / ref.norm()).item() < 2e-2  # tiny tensors: a single ReLU flip is a percent-level event
+    assert torch.isfinite(ours).all()
+
+
+def test_non_contiguous_and_strided_inputs():
+    """the boundary accepts what nn.Module.forward accepts: a permuted / sliced (non-contiguous) input tensor"""
+    from pytorch3dunet_amd.unet3d.model import UNet3D
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(5)
+    model = UNet3D(2, 1, f_maps=[8, 16], num_groups=4).to(dev).eval()
+    base = torch.randn(1, 8, 16, 16, 2, device=dev)
+    xnc = base.permute(0, 4, 1, 2, 3)  # (N,C,D,H,W) view of an NDHWC buffer
+    assert not xnc.is_contiguous()
+    with torch.no_grad():
+        y1 = model(xnc)
+        y2 = model(xnc.contiguous())
+        big = torch.randn(1, 2, 10, 20, 20, device=dev)
+        y3 = model(big[:, :, 1:9, 2:18, 2:18])
+        y4 = model(big[:, :, 1:9, 2:18, 2:18].contiguous())
+    assert torch.equal(y1, y2) and torch.equal(y3, y4)
+
+
+def test_eval_no_grad_on_residual_variants_saves_no_tape():
+    from pytorch3dunet_amd.unet3d.model import ResidualUNetSE3D
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(6)
+    model = ResidualUNetSE3D(1, 2, f_maps=[8, 16], num_groups=4, final_sigmoid=False).to(dev).eval()
+    x = torch.randn(2, 1, 8, 16, 16, device=dev)
+    with torch.no_grad():
+        y = model(x)
+    assert y.shape == (2, 2, 8, 16, 16) and torch.allclose(y.sum(dim=1), torch.ones_like(y[:, 0]), atol=1e-5)
+    assert not y.requires_grad
+    model.train()
+    y2, logits = model(x, return_logits=True)
+    assert torch.allclose(y2.detach(), y, atol=1e-6) and logits.requires_grad
