@@ -916,7 +916,9 @@ class _UNet3DFunction(torch.autograd.Function):
     def backward(ctx, *grads):
         engine, tape = ctx.engine, ctx.tape
         if tape is None:
-            raise RuntimeError("u3d: backward called but forward ran without grad mode")
+            raise RuntimeError("u3d: no activation tape for this backward — either the forward ran without grad mode, or "
+                               "backward was already called once (the tape is released after the first backward; "
+                               "re-run the forward instead of retain_graph=True)")
         dlogits = grads[0]
         if ctx.has_probs and len(grads) > 1 and grads[1] is not None:
             # gradient flowing through the probabilities (rare: the reference's trainer takes the loss on logits,
