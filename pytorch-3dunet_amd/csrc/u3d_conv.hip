@@ -183,12 +183,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvParams p)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bq[k][nt] = wq[(size_t)k * wstep + nt * 64];
 
-    // per-chunk source selection of this thread's channel quad
+    // per-chunk source selection of this thread's channel quad.  The GroupNorm affine rows are NOT loaded here: a load
+    // at the head of a chunk is waited for at once (s_waitcnt vmcnt(0), a full memory round trip per chunk) — see the
+    // persistent kernel; load_affine_rows is called a few k-steps before the first halo store instead.
     struct ChunkSrc {
         const float* base;
         int Cs;
         bool cok, from0;
-        f32x4 ga, gb;
+        const float* ap;  // this thread's rows of the affine table (nullptr: identity)
+        f32x4 lo, hi;     // raw rows (a0,b0,a1,b1), (a2,b2,a3,b3)
     };
     auto chunk_src = [&](int ch, bool live) {
         ChunkSrc c;
@@ -197,16 +200,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvParams p)
         c.from0 = cq < p.src.C0;
         c.base = !c.cok ? p.src.p0 : (c.from0 ? p.src.p0 + cq : p.src.p1 + (cq - p.src.C0));
         c.Cs = (c.from0 || !c.cok) ? p.src.C0 : p.src.C1;
-        c.ga = f32x4{1.f, 1.f, 1.f, 1.f};
-        c.gb = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.src.affine) {
-            const float* ap = p.src.affine + ((size_t)n * Ctot + (c.cok ? cq : 0)) * 2;
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(ap);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(ap + 4);
-            c.ga = f32x4{lo[0], lo[2], hi[0], hi[2]};
-            c.gb = f32x4{lo[1], lo[3], hi[1], hi[3]};
-        }
+        c.ap = p.src.affine ? p.src.affine + ((size_t)n * Ctot + (c.cok ? cq : 0)) * 2 : nullptr;
+        c.lo = f32x4{1.f, 0.f, 1.f, 0.f};
+        c.hi = f32x4{1.f, 0.f, 1.f, 0.f};
         return c;
+    };
+    auto load_affine_rows = [&](ChunkSrc& c) {
+        if (c.ap) {
+            c.lo = *reinterpret_cast<const f32x4*>(c.ap);
+            c.hi = *reinterpret_cast<const f32x4*>(c.ap + 4);
+        }
     };
     // branch-free halo load: always a valid address (clamped), validity is applied by select at the LDS write
     auto halo_load = [&](const ChunkSrc& c, int it) {
@@ -216,7 +219,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvParams p)
     };
     auto halo_store = [&](float* buf, const ChunkSrc& c, int it, f32x4 raw) {
         const bool ok = c.cok && gv0[it] >= 0;
-        f32x4 val = raw * c.ga + c.gb;
+        f32x4 val = {fmaf(raw[0], c.lo[0], c.lo[1]), fmaf(raw[1], c.lo[2], c.lo[3]), fmaf(raw[2], c.hi[0], c.hi[1]),
+                     fmaf(raw[3], c.hi[2], c.hi[3])};
 #pragma unroll
         for (int e = 0; e < 4; ++e) val[e] = ok ? val[e] : 0.f;  // padding stays exactly 0
         *reinterpret_cast<f32x4*>(&buf[ldsoff[it]]) = val;
@@ -236,7 +240,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvParams p)
 
     // ---- prologue: stage chunk 0 into buffer 0
     if constexpr (VEC) {
-        const ChunkSrc c0 = chunk_src(0, true);
+        ChunkSrc c0 = chunk_src(0, true);
+        load_affine_rows(c0);
         f32x4 v[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) v[it] = halo_load(c0, it);
@@ -270,6 +275,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvParams p)
         for (int st = 0; st < NSTEP; ++st) {
             if constexpr (VEC && !(ABL & 1)) {
                 if (st % 2 == 0 && st / 2 < NIT) v[st / 2] = halo_load(cn, st / 2);
+                if (st == ST0 - 6) load_affine_rows(cn);  // 6 k-steps ahead of the first halo store
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -660,8 +666,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
         const float* base;
         int Cs;
         bool cok, from0;
-        f32x4 ga, gb;
+        const float* ap;  // this thread's rows of the GroupNorm affine table (nullptr: identity)
+        f32x4 lo, hi;     // the raw rows (a0,b0,a1,b1), (a2,b2,a3,b3)
     };
+    // chunk_src does NOT load the GroupNorm affine: a load placed at the head of a chunk makes the compiler wait for it
+    // (s_waitcnt vmcnt(0): ALL outstanding loads, a full memory round trip of 3-4 k cycles per chunk, measured as the
+    // "restage gap" of the timeline twin) because the (a,b) de-interleave uses it at once.  The affine rows are loaded
+    // one tap row before the halo stores that need them (load_affine_rows in the k-loop).
     auto chunk_src = [&](int ch, int n, bool live) {
         ChunkSrc c;
         const int cq = ch * CC + 4 * q;
@@ -669,16 +680,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
         c.from0 = !VIRT || cq < p.src.C0;
         c.base = !c.cok ? p.src.p0 : (c.from0 ? p.src.p0 + cq : p.src.p1 + (cq - p.src.C0));
         c.Cs = (c.from0 || !c.cok) ? p.src.C0 : p.src.C1;
-        c.ga = f32x4{1.f, 1.f, 1.f, 1.f};
-        c.gb = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.src.affine) {
-            const float* ap = p.src.affine + ((size_t)n * Ctot + (c.cok ? cq : 0)) * 2;
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(ap);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(ap + 4);
-            c.ga = f32x4{lo[0], lo[2], hi[0], hi[2]};
-            c.gb = f32x4{lo[1], lo[3], hi[1], hi[3]};
-        }
+        c.ap = p.src.affine ? p.src.affine + ((size_t)n * Ctot + (c.cok ? cq : 0)) * 2 : nullptr;
+        c.lo = f32x4{1.f, 0.f, 1.f, 0.f};  // (a,b) pairs of channels 0,1 / 2,3 of the quad: identity
+        c.hi = f32x4{1.f, 0.f, 1.f, 0.f};
         return c;
+    };
+    auto load_affine_rows = [&](ChunkSrc& c) {  // raw rows only: their first USE is a tap row later (halo_store)
+        if (c.ap) {
+            c.lo = *reinterpret_cast<const f32x4*>(c.ap);
+            c.hi = *reinterpret_cast<const f32x4*>(c.ap + 4);
+        }
     };
     // `masked`: the staged tile has padding items (border tile) or this thread's channel quad is dead
     auto halo_load = [&](const ChunkSrc& c, const Item& S, int it, bool masked) {
@@ -687,7 +698,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
         return *reinterpret_cast<const f32x4*>(c.base + (size_t)idx * c.Cs);
     };
     auto halo_store = [&](float* buf, const ChunkSrc& c, const Item& S, int it, f32x4 raw, bool masked) {
-        f32x4 val = raw * c.ga + c.gb;
+        f32x4 val = {fmaf(raw[0], c.lo[0], c.lo[1]), fmaf(raw[1], c.lo[2], c.lo[3]), fmaf(raw[2], c.hi[0], c.hi[1]),
+                     fmaf(raw[3], c.hi[2], c.hi[3])};
         if (masked) {
             const bool ok = c.cok && ((S.inv >> it) & 1u) == 0;
 #pragma unroll
@@ -730,7 +742,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
 
     // ---- prologue: stage chunk 0 of the first tile into buffer 0
     {
-        const ChunkSrc c0 = chunk_src(0, T.n, true);
+        ChunkSrc c0 = chunk_src(0, T.n, true);
+        load_affine_rows(c0);
         const bool masked = T.border || dead_quads || fdead != 0;
         f32x4 v[NIT];
 #pragma unroll
@@ -766,7 +779,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
             // the chunk staged during this k-loop: the next chunk of this tile, or chunk 0 of the next tile
             const int nch_ = last ? 0 : ch + 1;
             const Item S = last ? TN : T;
-            const ChunkSrc cn = chunk_src(nch_, S.n, has_next);
+            ChunkSrc cn = chunk_src(nch_, S.n, has_next);
             // uniform: does any lane have to mask an item of the staged chunk?  (the tail items of the 10th round are
             // dead in 3 of 4 waves only; they go to the dummy slot and need no masking)
             const bool masked = S.border || !has_next || (dead_quads && nch_ + 1 == p.nchunks);
@@ -788,6 +801,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                 const int nrow = row + 1;
                 const float* anext = cur + abase + (nrow / RY) * PS + (nrow % RY) * RS;
                 const bool do_load = row == 0, do_store = row == ISTORE && has_next;
+                if (row == ISTORE - 1) load_affine_rows(cn);  // a whole tap row (6 k-steps) ahead of its first use
                 if (do_store) u3d_flag_wait(&cnt[2 + (b ^ 1)], 4 * ((gch + 1) / 2));  // other buffer free
 #pragma unroll
                 for (int s6 = 0; s6 < 6; ++s6) {
@@ -1272,14 +1286,21 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
     int cur = 0;  // buffer holding the current tile
     __builtin_amdgcn_s_setprio(0);
 
+    // GroupNorm affine of this block's channel quad: depends on the sample only.  Re-loading it at the head of every
+    // tile costs a full memory round trip per tile (the compiler waits for ALL outstanding loads before the (a,b)
+    // de-interleave): keep it in registers and reload on a sample change (a uniform, rare branch).
+    f32x4 gan = {1.f, 1.f, 1.f, 1.f}, gbn = {0.f, 0.f, 0.f, 0.f};
+    int n_aff = -1;
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         const bool has_next = tile + 1 < tile_end;
         const TileC cn = tile_coords(has_next ? tile + 1 : tile);
         float* nbuf = lds + (cur ^ 1) * BUF_FLOATS;
         f32x4 v[NPF];
-        f32x4 gan, gbn;
         if constexpr (VEC) {
-            load_affine(cn.n, gan, gbn);
+            if (cn.n != n_aff) {
+                load_affine(cn.n, gan, gbn);
+                n_aff = cn.n;
+            }
         }
         const float* gl = lds + cur * BUF_FLOATS;
 
