@@ -793,31 +793,45 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
             f32x4 aq[2][MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) aq[0][mt] = *reinterpret_cast<const f32x4*>(&cur[abase + 4 * mt * RS]);
-            const f32x4* wrow = wq + (size_t)(ch * NSTEPL + RB - 1) * wstep;  // B fragments of step (row, 0) + RB-1
-#pragma unroll 1
-            for (int row = 0; row < NROWS; ++row) {
+            const f32x4* wch0 = wq + (size_t)(ch * NSTEPL + RB - 1) * wstep;  // B fragments of step (row 0, 0) + RB-1
+            // One tap row = 6 k-steps.  The rows differ in what rides along with the MFMAs (halo loads in row 0, the affine
+            // rows in row ISTORE-1, the halo stores in row ISTORE, the switch to the next tile's weight image in the last
+            // row); each kind is its own compile-time specialisation, so that the plain rows — 5 of 9 — carry nothing but
+            // the B load, two A reads and 8*NT MFMAs per step.  (With every condition evaluated at run time in one loop body
+            // the ~30 scalar instructions and 3 branches between two MFMA groups did not fit under one 64-cycle MFMA: a wave
+            // alone on its SIMD ran its k-loop at 81 % of the pipe, tools/wave_timeline.py with U3D_TUNE=6:1.)
+            enum { ROW_PLAIN = 0, ROW_LOAD = 1, ROW_AFFINE = 2, ROW_STORE = 3, ROW_LAST = 4 };
+            auto row_body = [&](auto kind_c, int row) __attribute__((always_inline)) {
+                constexpr int KIND = decltype(kind_c)::value;
                 const int rz = row / RY, ry = row - RY * rz;
                 const float* arow = cur + abase + rz * PS + ry * RS;
                 const int nrow = row + 1;
                 const float* anext = cur + abase + (nrow / RY) * PS + (nrow % RY) * RS;
-                const bool do_load = row == 0, do_store = row == ISTORE && has_next;
-                if (row == ISTORE - 1) load_affine_rows(cn);  // a whole tap row (6 k-steps) ahead of its first use
-                if (do_store) u3d_flag_wait(&cnt[2 + (b ^ 1)], 4 * ((gch + 1) / 2));  // other buffer free
+                const bool do_store = KIND == ROW_STORE && has_next;
+                if constexpr (KIND == ROW_AFFINE) load_affine_rows(cn);  // a whole tap row ahead of its first use
+                if constexpr (KIND == ROW_STORE) {
+                    if (do_store) u3d_flag_wait(&cnt[2 + (b ^ 1)], 4 * ((gch + 1) / 2));  // other buffer free
+                }
 #pragma unroll
                 for (int s6 = 0; s6 < 6; ++s6) {
-                    if (do_load && s6 < NIT / 2) {
-                        if (masked) {
-                            v[2 * s6] = halo_load(cn, S, 2 * s6, true);
-                            v[2 * s6 + 1] = halo_load(cn, S, 2 * s6 + 1, true);
-                        } else {
-                            v[2 * s6] = halo_load(cn, S, 2 * s6, false);
-                            v[2 * s6 + 1] = halo_load(cn, S, 2 * s6 + 1, false);
+                    if constexpr (KIND == ROW_LOAD) {
+                        if (s6 < NIT / 2) {
+                            if (masked) {
+                                v[2 * s6] = halo_load(cn, S, 2 * s6, true);
+                                v[2 * s6 + 1] = halo_load(cn, S, 2 * s6 + 1, true);
+                            } else {
+                                v[2 * s6] = halo_load(cn, S, 2 * s6, false);
+                                v[2 * s6 + 1] = halo_load(cn, S, 2 * s6 + 1, false);
+                            }
                         }
                     }
                     {
-                        // B fragments of step + RB-1; past the end of a tile's image continue with the next tile's
-                        const f32x4* wsrc = wrow + (size_t)s6 * wstep;
-                        if (s6 + RB - 1 >= 6 && row == NROWS - 1 && last) wsrc = wqn + (size_t)(s6 + RB - 1 - 6) * wstep;
+                        // B fragments of step + RB-1; past the end of a tile's image continue with the next tile's.
+                        // (recomputed from uniform scalars, not carried as a mutated pointer: keeps the address in SGPRs)
+                        const f32x4* wsrc = wch0 + (size_t)(row * 6 + s6) * wstep;
+                        if constexpr (KIND == ROW_LAST) {
+                            if (s6 + RB - 1 >= 6 && last) wsrc = wqn + (size_t)(s6 + RB - 1 - 6) * wstep;
+                        }
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) bq[(s6 + RB - 1) % RB][nt] = wsrc[nt * 64 + l];
                     }
@@ -836,19 +850,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                         const int aoff = ((s6 + 1) >> 1) * CS + 8 * ((s6 + 1) & 1);
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) aq[(s6 + 1) & 1][mt] = *reinterpret_cast<const f32x4*>(&arow[4 * mt * RS + aoff]);
-                    } else if (row < NROWS - 1) {
+                    } else if constexpr (KIND != ROW_LAST) {
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) aq[0][mt] = *reinterpret_cast<const f32x4*>(&anext[4 * mt * RS]);
                     }
-                    if (do_store && s6 < NIT / 2) {
-                        if (masked) {
-                            halo_store(nxt, cn, S, 2 * s6, v[2 * s6], true);
-                            halo_store(nxt, cn, S, 2 * s6 + 1, v[2 * s6 + 1], true);
-                        } else {
-                            halo_store(nxt, cn, S, 2 * s6, v[2 * s6], false);
-                            halo_store(nxt, cn, S, 2 * s6 + 1, v[2 * s6 + 1], false);
+                    if constexpr (KIND == ROW_STORE) {
+                        if (do_store && s6 < NIT / 2) {
+                            if (masked) {
+                                halo_store(nxt, cn, S, 2 * s6, v[2 * s6], true);
+                                halo_store(nxt, cn, S, 2 * s6 + 1, v[2 * s6 + 1], true);
+                            } else {
+                                halo_store(nxt, cn, S, 2 * s6, v[2 * s6], false);
+                                halo_store(nxt, cn, S, 2 * s6 + 1, v[2 * s6 + 1], false);
+                            }
+                            if (s6 == NIT / 2 - 1) u3d_flag_signal(&cnt[b ^ 1], l);
                         }
-                        if (s6 == NIT / 2 - 1) u3d_flag_signal(&cnt[b ^ 1], l);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -862,8 +878,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                wrow += (size_t)6 * wstep;
-            }
+            };
+            static_assert(ISTORE - 1 > 1 && ISTORE + 1 < NROWS - 1, "row kinds must not collide");
+            row_body(std::integral_constant<int, ROW_LOAD>{}, 0);
+#pragma unroll 1
+            for (int row = 1; row < ISTORE - 1; ++row) row_body(std::integral_constant<int, ROW_PLAIN>{}, row);
+            row_body(std::integral_constant<int, ROW_AFFINE>{}, ISTORE - 1);
+            row_body(std::integral_constant<int, ROW_STORE>{}, ISTORE);
+#pragma unroll 1
+            for (int row = ISTORE + 1; row < NROWS - 1; ++row) row_body(std::integral_constant<int, ROW_PLAIN>{}, row);
+            row_body(std::integral_constant<int, ROW_LAST>{}, NROWS - 1);
             if (ntiles == 0 && ch < 8) U3D_DBG_STAMP(9 + 2 * ch);
             u3d_flag_signal(&cnt[2 + b], l);  // this wave no longer reads buffer b
         }

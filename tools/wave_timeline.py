@@ -20,6 +20,9 @@ from layer_bench import LAYERS  # noqa: E402
 
 dev = U.DEV
 N, D0, H0, W0 = 2, 64, 128, 128
+for _kv in os.environ.get("U3D_TUNE", "").split(","):  # e.g. U3D_TUNE=6:1 = one block per CU
+    if ":" in _kv:
+        nat.call("u3d_set_tuning", int(_kv.split(":")[0]), int(_kv.split(":")[1]))
 
 
 def run(name, dgrad, forced_nt=0, dims=None, abl=0):
