@@ -556,6 +556,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
     constexpr int RY = PAIRY ? 4 : 3;    // taps along y
     constexpr int NROWS = 3 * RY;        // tap rows (z, y) of 3 x-taps x 2 channel octets = 6 k-steps each
     constexpr int NSTEPL = NROWS * 6;    // k-steps per chunk
+    constexpr int DBG_TILE = 1;          // timeline twin: which tile of a block is stamped (1 = steady state, not the cold first)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int* cnt = reinterpret_cast<int*>(lds + CNT_OFF);
     // [2 sample parities][NT*32][2] block-level partial statistics, accumulated in f64 (ds_add_f64): the arrival order
@@ -764,6 +765,29 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
 
     int gch = 0;     // chunks done by this wave over all tiles: buffer parity and flag targets
     int ntiles = 0;  // tiles done (timeline record)
+    // Statistics of the written values.  After the epilogue's transposition lane (l&3, l>>5) of a channel quad holds one of
+    // its 8 x-positions: the 4 lanes of a quad are summed with two DPP steps (no LDS round trips as __shfl_xor would
+    // take), the two half-waves (and, PAIRY, the two y-row column groups) each add their sum to the block's f64 LDS row.
+    // NT = 1 carries the per-lane sums in registers across the tiles of one (sample, channel block) and reduces only when
+    // that changes: the per-tile epilogue is then transposition + stores only.
+    constexpr bool CARRY = NT == 1;
+    f32x4 sq1 = {0.f, 0.f, 0.f, 0.f}, sq2 = {0.f, 0.f, 0.f, 0.f};
+    auto quad_sum = [](float v) {
+        v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));  // lane ^ 1
+        v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));  // lane ^ 2
+        return v;
+    };
+    auto stat_reduce = [&](const f32x4& a1, const f32x4& a2, int n_, int nt_, int c0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = quad_sum(a1[e]), b2 = quad_sum(a2[e]);
+            if ((l & 3) == 0) {
+                double* r = &red[(((n_ & 1) * NT + nt_) * 32 + c0 + e) * 2];
+                __hip_atomic_fetch_add(r, (double)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(r + 1, (double)b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    };
     while (true) {
         const int nwi = wi + G;
         const bool has_next_tile = nwi < p.total;
@@ -786,7 +810,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
             f32x4 v[NIT];
             u3d_flag_wait(&cnt[b], 4 * (gch / 2 + 1));  // all four waves have staged this chunk
             __builtin_amdgcn_s_setprio(0);
-            if (ntiles == 0 && ch < 8) U3D_DBG_STAMP(8 + 2 * ch);
+            if (ntiles == DBG_TILE && ch < 8) U3D_DBG_STAMP(8 + 2 * ch);
 
             // ---- 54 k-steps as 9 tap rows x 6 steps (3 taps x 2 channel-octets) of 8*NT MFMAs; tap row 0 carries
             //      the 10 halo loads of the next chunk, tap row ISTORE their LDS stores
@@ -888,7 +912,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
 #pragma unroll 1
             for (int row = ISTORE + 1; row < NROWS - 1; ++row) row_body(std::integral_constant<int, ROW_PLAIN>{}, row);
             row_body(std::integral_constant<int, ROW_LAST>{}, NROWS - 1);
-            if (ntiles == 0 && ch < 8) U3D_DBG_STAMP(9 + 2 * ch);
+            if (ntiles == DBG_TILE && ch < 8) U3D_DBG_STAMP(9 + 2 * ch);
             u3d_flag_signal(&cnt[2 + b], l);  // this wave no longer reads buffer b
         }
         __builtin_amdgcn_s_setprio(3);
@@ -897,7 +921,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
         //      (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5); M-tile row -> (y = row>>3, x = row&7).  A 4x4 transpose
         //      inside every lane quad (two DPP butterfly stages) leaves lane j of quad k with the 4 consecutive
         //      channels 4k..4k+3 of voxel x = j + 4h: 16-byte stores and 16-byte loads of x for the GroupNorm sums.
-        if (ntiles == 0) U3D_DBG_STAMP(5);
+        if (ntiles == DBG_TILE) U3D_DBG_STAMP(5);
         {
             const int n = T.n, cb = T.cb;
             const int z = T.z0 + w;
@@ -969,30 +993,28 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                     }
                 }
                 if (want_stats || want_g) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float a = q1[e], b2 = q2[e];
-#pragma unroll
-                        for (int mask : {1, 2, 32}) {  // lanes of one channel quad: x = (l&3) + 4*(l>>5)
-                            a += __shfl_xor(a, mask);
-                            b2 += __shfl_xor(b2, mask);
-                        }
-                        if constexpr (PAIRY) {  // the two y-rows of a channel quad sit 16 lanes apart
-                            a += __shfl_xor(a, 16);
-                            b2 += __shfl_xor(b2, 16);
-                        }
-                        if ((l & (PAIRY ? 51 : 35)) == 0) {
-                            double* r = &red[(((n & 1) * NT + nt) * 32 + co - (PAIRY ? 0 : (cb * NT + nt) * 32) + e) * 2];
-                            __hip_atomic_fetch_add(r, (double)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            __hip_atomic_fetch_add(r + 1, (double)b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
+                    if constexpr (CARRY) {  // NT = 1: keep per-lane running sums across the tiles, reduce at the flush
+                        sq1 += q1;
+                        sq2 += q2;
+                    } else {
+                        stat_reduce(q1, q2, n, nt, co - (PAIRY ? 0 : (cb * NT + nt) * 32));
                     }
                 }
             }
         }
         ++ntiles;
         // statistics are per (sample, channel): flush this wave's LDS row when the sample or the channel block changes
-        if (!has_next_tile || TN.n != T.n || TN.cb != T.cb) flush_stats(T.n, T.cb);
+        if (!has_next_tile || TN.n != T.n || TN.cb != T.cb) {
+            if constexpr (CARRY) {
+                if (want_stats || want_g) {
+                    const int cq_ = (l >> 2) & 7;
+                    stat_reduce(sq1, sq2, T.n, 0, PAIRY ? 4 * (cq_ & 3) : 4 * cq_);
+                    sq1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    sq2 = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            flush_stats(T.n, T.cb);
+        }
         if (!has_next_tile) break;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
