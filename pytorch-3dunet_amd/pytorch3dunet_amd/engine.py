@@ -148,16 +148,46 @@ class _StatPool:
         return s
 
 
+_SIDE_STREAMS: dict = {}
+
+
 class _BwdCtx:
-    """per-backward scratch shared by the helper methods: zeroed double pool, wgrad workspace, flat gradient buffer"""
+    """per-backward scratch shared by the helper methods: zeroed double pool, wgrad workspace, flat gradient buffer, and the
+    side stream on which the weight gradients of SMALL layers run concurrently with their data gradients"""
+
+    # layers with at most this many voxels (N*D*H*W) cannot fill 256 CUs with one kernel (<= 128 tiles of 4x8x8): their
+    # weight gradient — independent of the data gradient, both only read dz — is issued on a second HIP stream
+    SIDE_MAX_VOXELS = 2 * 16 * 32 * 32
 
     def __init__(self, dev, pool, ws, flat, engine):
         self.dev, self.pool, self.ws, self.flat = dev, pool, ws, flat
         self._e = engine
+        self.side = None
+        self.ws_side = None
+        self.side_used = False
 
     def gview(self, idx):
         e = self._e
         return self.flat[e.poffs[idx] : e.poffs[idx] + e.params[idx].numel()]
+
+    def side_stream(self, ws_floats):
+        if self.side is None:
+            key = (self.dev.type, self.dev.index)
+            st = _SIDE_STREAMS.get(key)
+            if st is None:
+                st = _SIDE_STREAMS[key] = torch.cuda.Stream(self.dev)
+            self.side = st
+        if self.ws_side is None or self.ws_side.numel() < ws_floats:
+            if self.ws_side is not None:
+                self.join()  # the old workspace may still be in use on the side stream
+            self.ws_side = torch.empty(max(int(ws_floats), 4), dtype=_F32, device=self.dev)
+        return self.side
+
+    def join(self):
+        """make the caller's stream wait for every weight gradient issued on the side stream"""
+        if self.side_used:
+            torch.cuda.current_stream(self.dev).wait_stream(self.side)
+            self.side_used = False
 
 
 class UNet3DEngine:
@@ -172,6 +202,7 @@ class UNet3DEngine:
         self.debug = None  # dict -> backward stores clones of per-layer dz / dg (tools/gpu_layer_diag.py)
         self.fused_stats = True
         self.small_cin = True  # dedicated kernels for the in_channels<=4 first layer
+        self.overlap_small_wgrad = True  # weight gradients of small layers on a second HIP stream (see _BwdCtx)
         self.params = list(model.parameters())
         self._pindex = {id(p): i for i, p in enumerate(self.params)}
         self._build_layer_table(model)
@@ -337,8 +368,20 @@ class UNet3DEngine:
             return None, coef
         s_aff = src.struct(rec.affine)
         flops = 54.0 * src.C * Cout * Nn * Dd * Hh * Ww
-        nat.call("u3d_conv3d_wgrad", dev.index, _stream(dev), ctypes.byref(s_aff), _p(dz_), _p(gview(rec.idx_w)), Nn, Dd, Hh,
-                 Ww, Cout, _p(ws), ws.numel(), flops=flops)
+        if self.overlap_small_wgrad and Nn * Dd * Hh * Ww <= cx.SIDE_MAX_VOXELS and self.debug is None:
+            # small layer: neither kernel fills the chip on its own -> weight gradient on the side stream, data gradient
+            # (below) on the caller's stream; joined before anything consumes the flat gradient buffer
+            need = nat.get_lib().u3d_wgrad_workspace_floats(Nn, Dd, Hh, Ww, src.C, Cout)
+            side = cx.side_stream(need)
+            side.wait_stream(torch.cuda.current_stream(dev))  # dz_ (and the flat buffer) are ready
+            with torch.cuda.stream(side):
+                nat.call("u3d_conv3d_wgrad", dev.index, _stream(dev), ctypes.byref(s_aff), _p(dz_), _p(gview(rec.idx_w)), Nn,
+                         Dd, Hh, Ww, Cout, _p(cx.ws_side), cx.ws_side.numel(), flops=flops)
+            dz_.record_stream(side)  # dz_ is released on the main stream while the side stream may still read it
+            cx.side_used = True
+        else:
+            nat.call("u3d_conv3d_wgrad", dev.index, _stream(dev), ctypes.byref(s_aff), _p(dz_), _p(gview(rec.idx_w)), Nn, Dd,
+                     Hh, Ww, Cout, _p(ws), ws.numel(), flops=flops)
         wpd = self._packed(rec.conv_w, 1, dev)
         dg = torch.empty((Nn, Dd, Hh, Ww, src.C), dtype=_F32, device=dev)
         gst = pool.take(Nn * src.C * 2)
@@ -520,6 +563,7 @@ class UNet3DEngine:
 
         # decoder + head gradients are final: start their all-reduce now, overlapped with the encoder backward
         if self.grad_sync is not None:
+            cx.join()
             self.grad_sync.launch(flat[self.n_enc_params :])
 
         # ---- encoders, deepest to first
@@ -548,6 +592,7 @@ class UNet3DEngine:
                 dx0 = plain_apply(dg1, coef1, tape.x0, 0)
             del dg1
 
+        cx.join()
         if self.grad_sync is not None:
             self.grad_sync.launch(flat[: self.n_enc_params])
             self.grad_sync.finish()
@@ -850,6 +895,7 @@ class ResUNetEngine(UNet3DEngine):
             dz = dxl  # masked by (x_low > 0): x_low is the post-ReLU output of the block below
 
         if self.grad_sync is not None:
+            cx.join()
             self.grad_sync.launch(flat[self.n_enc_params :])
 
         dx0 = None
@@ -881,6 +927,7 @@ class ResUNetEngine(UNet3DEngine):
             elif need_input_grad:
                 dx0 = dxin
 
+        cx.join()
         if self.grad_sync is not None:
             self.grad_sync.launch(flat[: self.n_enc_params])
             self.grad_sync.finish()
