@@ -18,6 +18,7 @@ torch.distributed only.
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -155,9 +156,12 @@ class _BwdCtx:
     """per-backward scratch shared by the helper methods: zeroed double pool, wgrad workspace, flat gradient buffer, and the
     side stream on which the weight gradients of SMALL layers run concurrently with their data gradients"""
 
-    # layers with at most this many voxels (N*D*H*W) cannot fill 256 CUs with one kernel (<= 128 tiles of 4x8x8): their
-    # weight gradient — independent of the data gradient, both only read dz — is issued on a second HIP stream
-    SIDE_MAX_VOXELS = 2 * 16 * 32 * 32
+    # Layers with at most this many voxels (N*D*H*W) issue their weight gradient — independent of the data gradient, both
+    # only read dz — on a second HIP stream.  Measured on the bench workload (profiles/r01v_side_stream_sweep.txt): 0 (off)
+    # 80.1 patches/s, 32 k voxels (the levels that cannot fill 256 CUs) 80.0, every layer 82.0 (+2.4 %: tails of one
+    # kernel filled by the other).  Default OFF: concurrent kernels make every per-kernel duration (HIP events, rocprofv3)
+    # read longer, which would blur the roofline evidence for +2.4 %; export U3D_SIDE_VOXELS=4000000 to trade that.
+    SIDE_MAX_VOXELS = int(os.environ.get("U3D_SIDE_VOXELS", 0))
 
     def __init__(self, dev, pool, ws, flat, engine):
         self.dev, self.pool, self.ws, self.flat = dev, pool, ws, flat
