@@ -618,16 +618,52 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
         fx1 |= (in && hx == HX - 1 ? 1u : 0u) << it;
         fdead |= (in ? 0u : 1u) << it;
     }
-    auto item_of = [&](int wi) {
-        Item c;
-        c.cb = wi % p.ncb;
-        int tile = wi / p.ncb;
-        c.x0 = (tile % p.tx) * TX;
+    // Work items are walked with stride G.  Decoding an item index costs five integer divisions (VALU sequences — and a
+    // VALU instruction of a wave whose SIMD partner is in its k-loop waits ~45 cycles for an MFMA boundary, measured with
+    // the timeline twin: tile-switch code that takes 2.5 k cycles alone takes 10 k beside a busy partner).  So the index
+    // is decoded ONCE (mixed-radix digits cb, x, y, z, n) and then advanced digit-wise by the digits of G with carries:
+    // scalar adds / compares only.
+    struct Digits {
+        int cb, xi, yi, zi, n;
+    };
+    auto decode = [&](int idx) {
+        Digits d;
+        d.cb = idx % p.ncb;
+        int tile = idx / p.ncb;
+        d.xi = tile % p.tx;
         tile /= p.tx;
-        c.y0 = (tile % p.ty) * TY;
+        d.yi = tile % p.ty;
         tile /= p.ty;
-        c.z0 = (tile % p.tz) * TZ;
-        c.n = tile / p.tz;
+        d.zi = tile % p.tz;
+        d.n = tile / p.tz;
+        return d;
+    };
+    const Digits dG = decode(G);
+    auto advance = [&](const Digits& a) {  // a + G in the mixed radix (ncb, tx, ty, tz, unbounded)
+        Digits r;
+        int c;
+        r.cb = a.cb + dG.cb;
+        c = r.cb >= p.ncb ? 1 : 0;
+        r.cb -= c ? p.ncb : 0;
+        r.xi = a.xi + dG.xi + c;
+        c = r.xi >= p.tx ? 1 : 0;
+        r.xi -= c ? p.tx : 0;
+        r.yi = a.yi + dG.yi + c;
+        c = r.yi >= p.ty ? 1 : 0;
+        r.yi -= c ? p.ty : 0;
+        r.zi = a.zi + dG.zi + c;
+        c = r.zi >= p.tz ? 1 : 0;
+        r.zi -= c ? p.tz : 0;
+        r.n = a.n + dG.n + c;
+        return r;
+    };
+    auto item_of = [&](const Digits& d) {
+        Item c;
+        c.cb = d.cb;
+        c.x0 = d.xi * TX;
+        c.y0 = d.yi * TY;
+        c.z0 = d.zi * TZ;
+        c.n = d.n;
         c.base0 = ((c.n * D + c.z0 - 1) * H + c.y0 - 1) * W + c.x0 - 1;
         c.base1 = VIRT ? ((c.n * D1 + (c.z0 >> 1)) * H1 + (c.y0 >> 1)) * W1 + (c.x0 >> 1) : 0;
         const bool bz0 = c.z0 == 0, bz1 = c.z0 + TZ == D, by0 = c.y0 == 0, by1 = c.y0 + TY == H, bx0 = c.x0 == 0,
@@ -638,15 +674,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
         return c;
     };
     int wi = u3d_xcd_remap(blockIdx.x, G);
-    Item T = item_of(wi);
+    Digits dT = decode(wi);
+    Item T = item_of(dT);
 
+    // NT <= 2: the accumulators are written first by the C = 0 MFMAs of every tile's first k-step (ROW_LOAD_FIRST); NT = 3
+    // keeps explicit zeroing (the extra row variant costs it registers it does not have: +90 B of spills, -3 %)
+    constexpr bool ZEROC = NT < 3;
     f32x16 acc[MT][NT];
+    if constexpr (!ZEROC) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    }
 
     // A-fragment base: lane (m,h) -> voxel (zl = w, yl = (m>>3) [+4 for mt=1], xl = m&7), channels 4h..4h+3;
     // PAIRY: yl = 2*(m>>3) (even rows only)
@@ -791,7 +833,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
     while (true) {
         const int nwi = wi + G;
         const bool has_next_tile = nwi < p.total;
-        const Item TN = item_of(has_next_tile ? nwi : wi);
+        const Digits dTN = has_next_tile ? advance(dT) : dT;
+        const Item TN = item_of(dTN);
         const f32x4* wqn = wimg + (size_t)TN.cb * NT * 64;
 
         for (int ch = 0; ch < p.nchunks; ++ch, ++gch) {
@@ -810,7 +853,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
             f32x4 v[NIT];
             u3d_flag_wait(&cnt[b], 4 * (gch / 2 + 1));  // all four waves have staged this chunk
             __builtin_amdgcn_s_setprio(0);
-            if (ntiles == DBG_TILE && ch < 8) U3D_DBG_STAMP(8 + 2 * ch);
+            if (ntiles == DBG_TILE && ch < 7) U3D_DBG_STAMP(8 + 2 * ch);
+            if (ntiles == DBG_TILE + 1 && ch == 0) U3D_DBG_STAMP(23);  // first k-loop of the following tile starts
 
             // ---- 54 k-steps as 9 tap rows x 6 steps (3 taps x 2 channel-octets) of 8*NT MFMAs; tap row 0 carries
             //      the 10 halo loads of the next chunk, tap row ISTORE their LDS stores
@@ -824,7 +868,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
             // the B load, two A reads and 8*NT MFMAs per step.  (With every condition evaluated at run time in one loop body
             // the ~30 scalar instructions and 3 branches between two MFMA groups did not fit under one 64-cycle MFMA: a wave
             // alone on its SIMD ran its k-loop at 81 % of the pipe, tools/wave_timeline.py with U3D_TUNE=6:1.)
-            enum { ROW_PLAIN = 0, ROW_LOAD = 1, ROW_AFFINE = 2, ROW_STORE = 3, ROW_LAST = 4 };
+            // ROW_LOAD_FIRST: row 0 of a tile's first chunk — its very first MFMA per accumulator takes C = 0 (inline constant),
+            // which replaces 32*NT v_mov of accumulator zeroing per tile
+            enum { ROW_PLAIN = 0, ROW_LOAD = 1, ROW_AFFINE = 2, ROW_STORE = 3, ROW_LAST = 4, ROW_LOAD_FIRST = 5 };
             auto row_body = [&](auto kind_c, int row) __attribute__((always_inline)) {
                 constexpr int KIND = decltype(kind_c)::value;
                 const int rz = row / RY, ry = row - RY * rz;
@@ -838,7 +884,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                 }
 #pragma unroll
                 for (int s6 = 0; s6 < 6; ++s6) {
-                    if constexpr (KIND == ROW_LOAD) {
+                    if constexpr (KIND == ROW_LOAD || KIND == ROW_LOAD_FIRST) {
                         if (s6 < NIT / 2) {
                             if (masked) {
                                 v[2 * s6] = halo_load(cn, S, 2 * s6, true);
@@ -865,8 +911,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-                            for (int mt = 0; mt < MT; ++mt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s6 & 1][mt][j], bq[s6 % RB][nt][j], acc[mt][nt], 0, 0, 0);
+                            for (int mt = 0; mt < MT; ++mt) {
+                                if (KIND == ROW_LOAD_FIRST && s6 == 0 && j == 0) {
+                                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[0][mt][0], bq[0][nt][0], zero, 0, 0, 0);
+                                } else {
+                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s6 & 1][mt][j], bq[s6 % RB][nt][j], acc[mt][nt], 0, 0, 0);
+                                }
+                            }
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -904,7 +956,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                 }
             };
             static_assert(ISTORE - 1 > 1 && ISTORE + 1 < NROWS - 1, "row kinds must not collide");
-            row_body(std::integral_constant<int, ROW_LOAD>{}, 0);
+            if (ZEROC && ch == 0)
+                row_body(std::integral_constant<int, ROW_LOAD_FIRST>{}, 0);
+            else
+                row_body(std::integral_constant<int, ROW_LOAD>{}, 0);
 #pragma unroll 1
             for (int row = 1; row < ISTORE - 1; ++row) row_body(std::integral_constant<int, ROW_PLAIN>{}, row);
             row_body(std::integral_constant<int, ROW_AFFINE>{}, ISTORE - 1);
@@ -912,7 +967,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
 #pragma unroll 1
             for (int row = ISTORE + 1; row < NROWS - 1; ++row) row_body(std::integral_constant<int, ROW_PLAIN>{}, row);
             row_body(std::integral_constant<int, ROW_LAST>{}, NROWS - 1);
-            if (ntiles == DBG_TILE && ch < 8) U3D_DBG_STAMP(9 + 2 * ch);
+            if (ntiles == DBG_TILE && ch < 7) U3D_DBG_STAMP(9 + 2 * ch);
             u3d_flag_signal(&cnt[2 + b], l);  // this wave no longer reads buffer b
         }
         __builtin_amdgcn_s_setprio(3);
@@ -1002,6 +1057,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                 }
             }
         }
+        if (ntiles == DBG_TILE) U3D_DBG_STAMP(22);  // epilogue of the stamped tile done
         ++ntiles;
         // statistics are per (sample, channel): flush this wave's LDS row when the sample or the channel block changes
         if (!has_next_tile || TN.n != T.n || TN.cb != T.cb) {
@@ -1016,13 +1072,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
             flush_stats(T.n, T.cb);
         }
         if (!has_next_tile) break;
+        if constexpr (!ZEROC) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+        }
         wi = nwi;
+        dT = dTN;
         T = TN;
         wq = wqn;
     }

@@ -96,7 +96,12 @@ def run(name, dgrad, forced_nt=0, dims=None, abl=0):
     pro = (staged - entry).double()
     ep = (exit_ - epi).double()
     kl, gaps = [], []
-    for c in range(min(nch, 8)):
+    if (r[:, 22] != 0).all() and (r[:, 23] != 0).all():
+        e_dur = (r[:, 22] - r[:, 5]).double()
+        e_gap = (r[:, 23] - r[:, 22]).double()
+        print(f"   epilogue of the stamped tile: {e_dur.mean():.0f} ticks (min {e_dur.min():.0f} max {e_dur.max():.0f}); from its end to the "
+              f"next tile's first k-loop: {e_gap.mean():.0f}")
+    for c in range(min(nch, 7)):
         kl.append((r[:, 9 + 2 * c] - r[:, 8 + 2 * c]).double())
         if c > 0:
             gaps.append((r[:, 8 + 2 * c] - r[:, 7 + 2 * c]).double())
