@@ -1234,14 +1234,42 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
         int base, dzb;  // REG: voxel index of the tile origin in the g source of this thread / in dz
         unsigned inv;   // REG: invalid-item bits
     };
-    auto tile_coords = [&](int tile) {
-        TileC c;
-        c.x0 = (tile % p.tx) * TX;
+    // Tiles are walked consecutively: the index is decoded once (three integer divisions) and then advanced digit-wise with
+    // carries — scalar adds / compares only.  (A VALU instruction issued while the SIMD's other wave is in its MFMA stream
+    // waits ~45 cycles for an MFMA boundary: 100 VALU of divisions per 14 k-cycle tile were a double-digit percentage.)
+    struct TileIdx {
+        int xi, yi, zi, n;
+    };
+    auto tile_decode = [&](int tile) {
+        TileIdx d;
+        d.xi = tile % p.tx;
         tile /= p.tx;
-        c.y0 = (tile % p.ty) * TY;
+        d.yi = tile % p.ty;
         tile /= p.ty;
-        c.z0 = (tile % p.tz) * TZ;
-        c.n = tile / p.tz;
+        d.zi = tile % p.tz;
+        d.n = tile / p.tz;
+        return d;
+    };
+    auto tile_next = [&](const TileIdx& a) {
+        TileIdx r = a;
+        r.xi += 1;
+        int c = r.xi >= p.tx ? 1 : 0;
+        r.xi = c ? 0 : r.xi;
+        r.yi += c;
+        c = r.yi >= p.ty ? 1 : 0;
+        r.yi = c ? 0 : r.yi;
+        r.zi += c;
+        c = r.zi >= p.tz ? 1 : 0;
+        r.zi = c ? 0 : r.zi;
+        r.n += c;
+        return r;
+    };
+    auto tile_coords = [&](const TileIdx& d) {
+        TileC c;
+        c.x0 = d.xi * TX;
+        c.y0 = d.yi * TY;
+        c.z0 = d.zi * TZ;
+        c.n = d.n;
         c.base = c.dzb = 0;
         c.inv = 0;
         if constexpr (REG) {
@@ -1365,8 +1393,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
     const int tile_begin = s * p.tps, tile_end = min(p.ntiles, (s + 1) * p.tps);
 
     // ---- prologue: stage the first tile into buffer 0
+    TileIdx tix = tile_decode(tile_begin);
     if (tile_begin < tile_end) {
-        const TileC c = tile_coords(tile_begin);
+        const TileC c = tile_coords(tix);
         if constexpr (VEC) {
             f32x4 ga, gb;
             load_affine(c.n, ga, gb);
@@ -1400,7 +1429,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
     int n_aff = -1;
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         const bool has_next = tile + 1 < tile_end;
-        const TileC cn = tile_coords(has_next ? tile + 1 : tile);
+        if (has_next) tix = tile_next(tix);
+        const TileC cn = tile_coords(tix);
         float* nbuf = lds + (cur ^ 1) * BUF_FLOATS;
         f32x4 v[NPF];
         if constexpr (VEC) {
