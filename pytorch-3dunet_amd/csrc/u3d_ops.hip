@@ -130,36 +130,52 @@ extern "C" int u3d_chan_stats(int device, u3d_stream_t stream, const u3d_src_t* 
 
 // =================================================================================================
 // GroupNorm finalize: (n,group) mean / rstd from channel sums, then the per-channel affine table.
-__global__ void gn_finalize_kernel(const double* __restrict__ st0, int C0, double sc0, const double* __restrict__ st1,
-                                   int C1, double sc1, int N, int G, double count, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float eps, float* __restrict__ affine,
-                                   float* __restrict__ mean_rstd) {
-    const int C = C0 + C1;
-    const int cpg = C / G;
-    for (int pair = blockIdx.x * blockDim.x + threadIdx.x; pair < N * G; pair += gridDim.x * blockDim.x) {
-        const int n = pair / G, g = pair - n * G;
+// One block per sample: threads = channels (coalesced loads of the per-channel sums into LDS), then one thread per group
+// reduces its channels from LDS, then threads = channels again for the affine table.  (The first version ran one thread per
+// (n, group) with a serial loop of dependent global loads: ~9 us per launch, 28 launches per step.)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ st0, int C0, double sc0,
+                                                          const double* __restrict__ st1, int C1, double sc1, int N, int G,
+                                                          double count, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          float* __restrict__ affine, float* __restrict__ mean_rstd) {
+    extern __shared__ double sh[];  // [C][2] channel sums, then [G][2] mean / rstd
+    const int C = C0 + C1, cpg = C / G, n = blockIdx.x, t = threadIdx.x;
+    double* gmr = sh + 2 * (size_t)C;
+    for (int c = t; c < C; c += blockDim.x) {
+        double s, ss;
+        if (c < C0) {
+            s = sc0 * st0[((size_t)n * C0 + c) * 2];
+            ss = sc0 * st0[((size_t)n * C0 + c) * 2 + 1];
+        } else {
+            s = sc1 * st1[((size_t)n * C1 + (c - C0)) * 2];
+            ss = sc1 * st1[((size_t)n * C1 + (c - C0)) * 2 + 1];
+        }
+        sh[2 * c] = s;
+        sh[2 * c + 1] = ss;
+    }
+    __syncthreads();
+    for (int g = t; g < G; g += blockDim.x) {
         double s = 0.0, ss = 0.0;
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-            if (c < C0) {
-                s += sc0 * st0[((size_t)n * C0 + c) * 2];
-                ss += sc0 * st0[((size_t)n * C0 + c) * 2 + 1];
-            } else {
-                s += sc1 * st1[((size_t)n * C1 + (c - C0)) * 2];
-                ss += sc1 * st1[((size_t)n * C1 + (c - C0)) * 2 + 1];
-            }
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {  // fixed order
+            s += sh[2 * c];
+            ss += sh[2 * c + 1];
         }
         const double m = count * cpg;
         const double mean = s / m;
         double var = ss / m - mean * mean;
         if (var < 0.0) var = 0.0;
         const double rstd = 1.0 / sqrt(var + (double)eps);
-        mean_rstd[(size_t)pair * 2] = (float)mean;
-        mean_rstd[(size_t)pair * 2 + 1] = (float)rstd;
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-            const double a = rstd * (double)gamma[c];
-            affine[((size_t)n * C + c) * 2] = (float)a;
-            affine[((size_t)n * C + c) * 2 + 1] = (float)((double)beta[c] - mean * a);
-        }
+        gmr[2 * g] = mean;
+        gmr[2 * g + 1] = rstd;
+        mean_rstd[((size_t)n * G + g) * 2] = (float)mean;
+        mean_rstd[((size_t)n * G + g) * 2 + 1] = (float)rstd;
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += blockDim.x) {
+        const int g = c / cpg;
+        const double a = gmr[2 * g + 1] * (double)gamma[c];
+        affine[((size_t)n * C + c) * 2] = (float)a;
+        affine[((size_t)n * C + c) * 2 + 1] = (float)((double)beta[c] - gmr[2 * g] * a);
     }
 }
 
@@ -171,7 +187,9 @@ extern "C" int u3d_gn_finalize(int device, u3d_stream_t stream, const double* st
                     mean_rstd && count > 0,
                 "u3d_gn_finalize: bad argument");
     U3D_REQUIRE((C0 + C1) % G == 0, "u3d_gn_finalize: channels %d not divisible by groups %d", C0 + C1, G);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(grid_for((long long)N * G, 64)), dim3(64), 0, (hipStream_t)stream,
+    const int C = C0 + C1;
+    U3D_REQUIRE(C <= 4096, "u3d_gn_finalize: more than 4096 channels");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), sizeof(double) * 2 * ((size_t)C + G), (hipStream_t)stream,
                        stats0, C0, scale0, stats1, C1, scale1, N, G, count, gamma, beta, eps, affine, mean_rstd);
     U3D_LAUNCH_CHECK();
     return 0;
@@ -179,10 +197,19 @@ extern "C" int u3d_gn_finalize(int device, u3d_stream_t stream, const double* st
 
 // GroupNorm backward reductions -> dgamma, dbeta, coefficient table coef[N][3][C] (p,q,r).
 // One block; phase 1 over (n,g), phase 2 over channels.
-__global__ void gn_bwd_finalize_kernel(const double* __restrict__ gs, const float* __restrict__ mean_rstd,
-                                       const float* __restrict__ gamma, int N, int C, int G, double count,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ coef) {
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __restrict__ gs, const float* __restrict__ mean_rstd,
+                                                              const float* __restrict__ gamma, int N, int C, int G,
+                                                              double count, int staged, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ coef) {
+    // `staged`: the N*C*2 sums are first copied to LDS with coalesced loads (threads = elements) so that the per-group
+    // loops below read LDS instead of issuing a serial chain of global loads
+    extern __shared__ double shb[];
+    const double* src = gs;
+    if (staged) {
+        for (int i = threadIdx.x; i < N * C * 2; i += blockDim.x) shb[i] = gs[i];
+        __syncthreads();
+        src = shb;
+    }
     const int cpg = C / G;
     const double m = count * cpg;
     for (int pair = threadIdx.x; pair < N * G; pair += blockDim.x) {
@@ -190,7 +217,7 @@ __global__ void gn_bwd_finalize_kernel(const double* __restrict__ gs, const floa
         const double mean = (double)mean_rstd[(size_t)pair * 2], rstd = (double)mean_rstd[(size_t)pair * 2 + 1];
         double A = 0.0, B = 0.0;
         for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-            const double S1 = gs[((size_t)n * C + c) * 2], S2 = gs[((size_t)n * C + c) * 2 + 1];
+            const double S1 = src[((size_t)n * C + c) * 2], S2 = src[((size_t)n * C + c) * 2 + 1];
             const double gm = (double)gamma[c];
             A += gm * S1;
             B += gm * rstd * (S2 - mean * S1);
@@ -208,7 +235,7 @@ __global__ void gn_bwd_finalize_kernel(const double* __restrict__ gs, const floa
         double dg = 0.0, db = 0.0;
         for (int n = 0; n < N; ++n) {
             const double mean = (double)mean_rstd[((size_t)n * G + g) * 2], rstd = (double)mean_rstd[((size_t)n * G + g) * 2 + 1];
-            const double S1 = gs[((size_t)n * C + c) * 2], S2 = gs[((size_t)n * C + c) * 2 + 1];
+            const double S1 = src[((size_t)n * C + c) * 2], S2 = src[((size_t)n * C + c) * 2 + 1];
             dg += rstd * (S2 - mean * S1);
             db += S1;
         }
@@ -223,8 +250,10 @@ extern "C" int u3d_gn_bwd_finalize(int device, u3d_stream_t stream, const double
     if (int e = u3d_enter(device)) return e;
     U3D_REQUIRE(gstats && mean_rstd && gamma && dgamma && dbeta && coef && N > 0 && C > 0 && G > 0 && C % G == 0,
                 "u3d_gn_bwd_finalize: bad argument");
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, gstats, mean_rstd, gamma,
-                       N, C, G, count, dgamma, dbeta, coef);
+    const size_t bytes = sizeof(double) * 2 * (size_t)N * C;
+    const int staged = bytes <= 48 * 1024 ? 1 : 0;
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(256), staged ? bytes : 0, (hipStream_t)stream, gstats, mean_rstd,
+                       gamma, N, C, G, count, staged, dgamma, dbeta, coef);
     U3D_LAUNCH_CHECK();
     return 0;
 }
