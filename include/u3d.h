@@ -130,11 +130,11 @@ int u3d_conv3d_wgrad(int device, u3d_stream_t stream, const u3d_src_t* src, cons
 /* The network's first convolution (in_channels 1..4 behind a one-group GroupNorm): K = 27*Cin is too small for
  * the MFMA tiling, so it has bandwidth-shaped kernels of its own (same semantics as u3d_conv3d / u3d_conv3d_wgrad;
  * x is a plain (N,D,H,W,Cin) tensor, w the reference (Cout,Cin,3,3,3) weights, Cin <= 4, Cout <= 32).
- *   _fwd : out = [relu](conv3d(x*a+b zero-padded, w))
+ *   _fwd : out = [relu](conv3d(x*a+b zero-padded, w)); out_stats (optional) as in u3d_conv3d
  *   _bwd : ONE pass over (dz, x) yields dw AND the GroupNorm-backward sums gstats[N][Cin][2] += (sum dg, sum dg*x)
  *          without computing the data gradient dg (see csrc/u3d_smallc.hip for the identity). */
 int u3d_conv3d_small_cin_fwd(int device, u3d_stream_t stream, const float* x, const float* affine, const float* w,
-                             float* out, int N, int D, int H, int W, int Cin, int Cout, int relu);
+                             float* out, int N, int D, int H, int W, int Cin, int Cout, int relu, double* out_stats);
 size_t u3d_small_cin_bwd_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
 int u3d_conv3d_small_cin_bwd(int device, u3d_stream_t stream, const float* x, const float* affine, const float* dz,
                              const float* w, float* dw, double* gstats, int N, int D, int H, int W, int Cin, int Cout,

@@ -23,24 +23,22 @@ struct SmallFwdParams {
     const float* affine;  // [N][Cin][2] or null
     const float* w;       // (Cout,Cin,27) reference layout
     float* out;           // (N,D,H,W,Cout)
+    double* out_stats;    // optional [N][Cout][2] += (sum, sum of squares) of the written values
     int N, D, H, W, Cin, Cout, relu;
-    int tz, ty, tx;
+    int tz, ty, tx, B;
 };
 
+// grid (B, N): a block walks tiles b, b+B, ... of sample n (weights staged in LDS once per block; the statistics of the
+// written values — the next GroupNorm's input — are carried in registers over all its tiles and leave the block as ONE
+// f64 atomic per channel, so the 16-channel output is not re-read by a separate statistics pass)
 template <int COUTP>
 __global__ __launch_bounds__(256) void conv3d_small_fwd_kernel(const SmallFwdParams p) {
     using namespace sc;
     __shared__ __attribute__((aligned(16))) float xs[HV * MAXC];
     __shared__ __attribute__((aligned(16))) float ws[27 * MAXC * COUTP];
+    __shared__ double sred[COUTP][2];
     const int t = threadIdx.x;
-    int tile = blockIdx.x;
-    const int txi = tile % p.tx;
-    tile /= p.tx;
-    const int tyi = tile % p.ty;
-    tile /= p.ty;
-    const int tzi = tile % p.tz;
-    const int n = tile / p.tz;
-    const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
+    const int n = blockIdx.y;
     const int Cin = p.Cin, D = p.D, H = p.H, W = p.W;
     // weights -> LDS as [tap][c][k] (k padded to COUTP with zeros)
     for (int i = t; i < 27 * Cin * COUTP; i += 256) {
@@ -49,80 +47,118 @@ __global__ __launch_bounds__(256) void conv3d_small_fwd_kernel(const SmallFwdPar
         const int c = r % Cin, tap = r / Cin;
         ws[i] = k < p.Cout ? p.w[((size_t)k * Cin + c) * 27 + tap] : 0.f;
     }
-    // halo tile with the GroupNorm affine applied, zero padded
-    for (int i = t; i < HV * Cin; i += 256) {
-        const int c = i % Cin;
-        const int hv = i / Cin;
-        const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
-        const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-        float v = 0.f;
-        if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            v = p.x[((size_t)((n * D + gz) * H + gy) * W + gx) * Cin + c];
-            if (p.affine) v = v * p.affine[((size_t)n * Cin + c) * 2] + p.affine[((size_t)n * Cin + c) * 2 + 1];
-        }
-        xs[hv * Cin + c] = v;
-    }
-    __syncthreads();
+    if (t < COUTP) sred[t][0] = sred[t][1] = 0.0;
+    float s1[COUTP], s2[COUTP];
+#pragma unroll
+    for (int k = 0; k < COUTP; ++k) s1[k] = s2[k] = 0.f;
     const int zl = t >> 6, yl = (t >> 3) & 7, xl = t & 7;
-    float acc[COUTP];
-#pragma unroll
-    for (int k = 0; k < COUTP; ++k) acc[k] = 0.f;
-    for (int tap = 0; tap < 27; ++tap) {
-        const int hv = (zl + tap / 9) * (HY * HX) + (yl + (tap / 3) % 3) * HX + xl + tap % 3;
-        for (int c = 0; c < Cin; ++c) {
-            const float xv = xs[hv * Cin + c];
-            const f32x4* wr = reinterpret_cast<const f32x4*>(&ws[(tap * Cin + c) * COUTP]);
-#pragma unroll
-            for (int k4 = 0; k4 < COUTP / 4; ++k4) {
-                const f32x4 wv = wr[k4];  // broadcast read
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[4 * k4 + e] = fmaf(xv, wv[e], acc[4 * k4 + e]);
+    const int ntiles = p.tz * p.ty * p.tx;
+    for (int tile = blockIdx.x; tile < ntiles; tile += p.B) {
+        int tt = tile;
+        const int txi = tt % p.tx;
+        tt /= p.tx;
+        const int tyi = tt % p.ty;
+        const int tzi = tt / p.ty;
+        const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
+        __syncthreads();  // the previous tile's reads of xs are done (and ws / sred are initialised)
+        // halo tile with the GroupNorm affine applied, zero padded
+        for (int i = t; i < HV * Cin; i += 256) {
+            const int c = i % Cin;
+            const int hv = i / Cin;
+            const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+            const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            float v = 0.f;
+            if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                v = p.x[((size_t)((n * D + gz) * H + gy) * W + gx) * Cin + c];
+                if (p.affine) v = v * p.affine[((size_t)n * Cin + c) * 2] + p.affine[((size_t)n * Cin + c) * 2 + 1];
             }
+            xs[hv * Cin + c] = v;
         }
-    }
-    const int z = z0 + zl, y = y0 + yl, x = x0 + xl;
-    if (z < D && y < H && x < W) {
-        float* o = p.out + ((size_t)((n * D + z) * H + y) * W + x) * p.Cout;
-        if (p.Cout % 4 == 0) {
+        __syncthreads();
+        float acc[COUTP];
 #pragma unroll
-            for (int k4 = 0; k4 < COUTP / 4; ++k4) {
-                if (4 * k4 < p.Cout) {
-                    f32x4 v = {acc[4 * k4], acc[4 * k4 + 1], acc[4 * k4 + 2], acc[4 * k4 + 3]};
-                    if (p.relu) {
+        for (int k = 0; k < COUTP; ++k) acc[k] = 0.f;
+        for (int tap = 0; tap < 27; ++tap) {
+            const int hv = (zl + tap / 9) * (HY * HX) + (yl + (tap / 3) % 3) * HX + xl + tap % 3;
+            for (int c = 0; c < Cin; ++c) {
+                const float xv = xs[hv * Cin + c];
+                const f32x4* wr = reinterpret_cast<const f32x4*>(&ws[(tap * Cin + c) * COUTP]);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    *reinterpret_cast<f32x4*>(o + 4 * k4) = v;
+                for (int k4 = 0; k4 < COUTP / 4; ++k4) {
+                    const f32x4 wv = wr[k4];  // broadcast read
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[4 * k4 + e] = fmaf(xv, wv[e], acc[4 * k4 + e]);
                 }
             }
-        } else {
+        }
+        const int z = z0 + zl, y = y0 + yl, x = x0 + xl;
+        if (z < D && y < H && x < W) {
+            float* o = p.out + ((size_t)((n * D + z) * H + y) * W + x) * p.Cout;
 #pragma unroll
-            for (int k = 0; k < COUTP; ++k)
-                if (k < p.Cout) o[k] = p.relu ? fmaxf(acc[k], 0.f) : acc[k];
+            for (int k = 0; k < COUTP; ++k) {
+                if (p.relu) acc[k] = fmaxf(acc[k], 0.f);
+                s1[k] += acc[k];  // padded channels (k >= Cout) are exactly 0
+                s2[k] += acc[k] * acc[k];
+            }
+            if (p.Cout % 4 == 0) {
+#pragma unroll
+                for (int k4 = 0; k4 < COUTP / 4; ++k4)
+                    if (4 * k4 < p.Cout)
+                        *reinterpret_cast<f32x4*>(o + 4 * k4) = f32x4{acc[4 * k4], acc[4 * k4 + 1], acc[4 * k4 + 2], acc[4 * k4 + 3]};
+            } else {
+#pragma unroll
+                for (int k = 0; k < COUTP; ++k)
+                    if (k < p.Cout) o[k] = acc[k];
+            }
+        }
+    }
+    if (p.out_stats) {
+        // wave butterflies, then the four waves through LDS (f64), one global f64 atomic per channel and block
+#pragma unroll
+        for (int k = 0; k < COUTP; ++k) {
+            float a = s1[k], b2 = s2[k];
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) {
+                a += __shfl_xor(a, m);
+                b2 += __shfl_xor(b2, m);
+            }
+            if ((t & 63) == 0) {
+                __hip_atomic_fetch_add(&sred[k][0], (double)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&sred[k][1], (double)b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __syncthreads();
+        if (t < p.Cout) {
+            u3d_atomic_add_f64(&p.out_stats[((size_t)n * p.Cout + t) * 2], sred[t][0]);
+            u3d_atomic_add_f64(&p.out_stats[((size_t)n * p.Cout + t) * 2 + 1], sred[t][1]);
         }
     }
 }
 
 extern "C" int u3d_conv3d_small_cin_fwd(int device, u3d_stream_t stream, const float* x, const float* affine,
                                         const float* w, float* out, int N, int D, int H, int W, int Cin, int Cout,
-                                        int relu) {
+                                        int relu, double* out_stats) {
     if (int e = u3d_enter(device)) return e;
     U3D_REQUIRE(x && w && out && N > 0 && D > 0 && H > 0 && W > 0, "u3d_conv3d_small_cin_fwd: bad argument");
     U3D_REQUIRE(Cin >= 1 && Cin <= sc::MAXC && Cout >= 1 && Cout <= 32,
                 "u3d_conv3d_small_cin_fwd: needs Cin<=4, Cout<=32 (got %d,%d)", Cin, Cout);
     SmallFwdParams p;
-    p.x = x, p.affine = affine, p.w = w, p.out = out;
+    p.x = x, p.affine = affine, p.w = w, p.out = out, p.out_stats = out_stats;
     p.N = N, p.D = D, p.H = H, p.W = W, p.Cin = Cin, p.Cout = Cout, p.relu = relu;
     p.tz = (D + sc::TZ - 1) / sc::TZ, p.ty = (H + sc::TY - 1) / sc::TY, p.tx = (W + sc::TX - 1) / sc::TX;
-    const long long nblk = (long long)N * p.tz * p.ty * p.tx;
-    U3D_REQUIRE(nblk < (1ll << 31), "u3d_conv3d_small_cin_fwd: grid too large");
+    const long long ntiles = (long long)p.tz * p.ty * p.tx;
+    long long B = 2048 / N;  // ~8 blocks per CU in total
+    if (B < 1) B = 1;
+    if (B > ntiles) B = ntiles;
+    p.B = (int)B;
     hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)B, (unsigned)N);
     if (Cout <= 8)
-        hipLaunchKernelGGL(conv3d_small_fwd_kernel<8>, dim3((unsigned)nblk), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(conv3d_small_fwd_kernel<8>, grid, dim3(256), 0, st, p);
     else if (Cout <= 16)
-        hipLaunchKernelGGL(conv3d_small_fwd_kernel<16>, dim3((unsigned)nblk), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(conv3d_small_fwd_kernel<16>, grid, dim3(256), 0, st, p);
     else
-        hipLaunchKernelGGL(conv3d_small_fwd_kernel<32>, dim3((unsigned)nblk), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(conv3d_small_fwd_kernel<32>, grid, dim3(256), 0, st, p);
     U3D_LAUNCH_CHECK();
     return 0;
 }

@@ -62,7 +62,7 @@ _PROTOS = {
     ),
     "u3d_conv3d_small_cin_fwd": (
         c_int,
-        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
+        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     ),
     "u3d_small_cin_bwd_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "u3d_conv3d_small_cin_bwd": (

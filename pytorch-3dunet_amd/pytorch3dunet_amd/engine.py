@@ -331,9 +331,9 @@ class UNet3DEngine:
         small = self.small_cin and src.t1 is None and Ctot <= 4 and Cout <= 32 and residual is None
         if small:
             # first layer of the network: K = 27*Cin is too small for the MFMA tiling (csrc/u3d_smallc.hip)
-            ystats = None
+            ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
             nat.call("u3d_conv3d_small_cin_fwd", dev.index, _stream(dev), _p(src.t0), _p(affine), _p(conv.weight.detach()),
-                     _p(y), N, D, H, W, Ctot, Cout, 1, flops=54.0 * Ctot * Cout * N * D * H * W)
+                     _p(y), N, D, H, W, Ctot, Cout, 1, _p(ystats), flops=54.0 * Ctot * Cout * N * D * H * W)
         else:
             wp = self._packed(conv.weight, 0, dev)
             ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None

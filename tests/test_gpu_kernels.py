@@ -418,8 +418,11 @@ def test_small_cin_first_layer_kernels(N, Cin, Cout, D, H, W):
     z.backward(dz)
     xd, abd, wd, dzd = U.ndhwc(x), ab.contiguous().to(U.DEV), w.contiguous().to(U.DEV), U.ndhwc(dz)
     y = torch.empty((N, D, H, W, Cout), device=U.DEV)
-    nat.call("u3d_conv3d_small_cin_fwd", 0, _stream(U.DEV), _p(xd), _p(abd), _p(wd), _p(y), N, D, H, W, Cin, Cout, 1)
+    yst = torch.zeros((N, Cout, 2), dtype=torch.float64, device=U.DEV)
+    nat.call("u3d_conv3d_small_cin_fwd", 0, _stream(U.DEV), _p(xd), _p(abd), _p(wd), _p(y), N, D, H, W, Cin, Cout, 1, _p(yst))
     assert U.relerr(U.ncdhw(y), F.relu(z.detach())) < TOL
+    yr = F.relu(z.detach()).double()
+    assert U.relerr(yst.cpu(), torch.stack([yr.sum(dim=(2, 3, 4)), (yr * yr).sum(dim=(2, 3, 4))], dim=-1)) < 1e-5
     n = nat.get_lib().u3d_small_cin_bwd_workspace_floats(N, D, H, W, Cin, Cout)
     ws = torch.empty(n, device=U.DEV)
     dw = torch.empty((Cout, Cin, 3, 3, 3), device=U.DEV)
