@@ -547,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvParams p)
 // voxel y serves both outputs when the tap window is 3 x 4 x 3 (36 taps, the weights of the second half shifted by one
 // in y, zero where that leaves the 3^3 kernel).  A wave then needs only the even rows y = 0,2,4,6 of its z-plane (ONE
 // M-tile): 72 k-steps x 4 MFMAs per chunk instead of 54 x 8 — 2/3 of the padded work.
-template <int NT, bool VIRT, bool DBG = false, bool PAIRY = false>
+template <int NT, bool VIRT, bool DBG = false, bool PAIRY = false, bool AFF = true>
 __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParams p) {
     using namespace cv;
     static_assert(!PAIRY || NT == 1, "the paired-y variant has a single N-tile");
@@ -729,9 +729,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
         return c;
     };
     auto load_affine_rows = [&](ChunkSrc& c) {  // raw rows only: their first USE is a tap row later (halo_store)
-        if (c.ap) {
-            c.lo = *reinterpret_cast<const f32x4*>(c.ap);
-            c.hi = *reinterpret_cast<const f32x4*>(c.ap + 4);
+        if constexpr (AFF) {
+            if (c.ap) {
+                c.lo = *reinterpret_cast<const f32x4*>(c.ap);
+                c.hi = *reinterpret_cast<const f32x4*>(c.ap + 4);
+            }
         }
     };
     // `masked`: the staged tile has padding items (border tile) or this thread's channel quad is dead
@@ -741,8 +743,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
         return *reinterpret_cast<const f32x4*>(c.base + (size_t)idx * c.Cs);
     };
     auto halo_store = [&](float* buf, const ChunkSrc& c, const Item& S, int it, f32x4 raw, bool masked) {
-        f32x4 val = {fmaf(raw[0], c.lo[0], c.lo[1]), fmaf(raw[1], c.lo[2], c.lo[3]), fmaf(raw[2], c.hi[0], c.hi[1]),
-                     fmaf(raw[3], c.hi[2], c.hi[3])};
+        f32x4 val = raw;  // AFF=false (source without a GroupNorm affine, i.e. every dgrad launch): no per-element FMA
+        if constexpr (AFF)
+            val = f32x4{fmaf(raw[0], c.lo[0], c.lo[1]), fmaf(raw[1], c.lo[2], c.lo[3]), fmaf(raw[2], c.hi[0], c.hi[1]),
+                        fmaf(raw[3], c.hi[2], c.hi[3])};
         if (masked) {
             const bool ok = c.cok && ((S.inv >> it) & 1u) == 0;
 #pragma unroll
@@ -1733,7 +1737,11 @@ static int conv_set_lds_nt() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<NT, true, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<NT, false, false, false, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     if (NT == 1) {
+        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<1, false, false, true, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<1, false, false, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<1, true, false, true>),
@@ -1855,12 +1863,17 @@ static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, co
             slots -= slots % p.ncb;  // a block stays on one channel block: one statistics flush per sample
         const dim3 rgrid((unsigned)slots), rblock(256);
         const bool virt = p.src.C1 > 0;
+        // a source without a GroupNorm affine (every dgrad launch: dz is plain) runs the variant compiled without the
+        // per-element FMA of the halo stores (key 7 = 1 turns it off for A/B runs)
+        const bool noaff = p.src.affine == nullptr && g_u3d_tune[7] == 0;
         p.dbg = (g_u3d_prof_buf && (size_t)slots * 4 <= g_u3d_prof_records) ? g_u3d_prof_buf : nullptr;
         if (Cout <= 16 && nt == 1 && p.ntot == 1 && !p.dbg && g_u3d_tune[4] == 0) {
             // paired-y variant on the second packed image (u3d_pack_weights appends it for <= 16 output channels)
             p.wp = packed_w + ((size_t)p.nchunks * cv::NSTEP + cv::PACK_PAD) * 256;
             if (virt)
                 hipLaunchKernelGGL((conv3d_mfma_reg_kernel<1, true, false, true>), rgrid, rblock, shmem, st, p);
+            else if (noaff)
+                hipLaunchKernelGGL((conv3d_mfma_reg_kernel<1, false, false, true, false>), rgrid, rblock, shmem, st, p);
             else
                 hipLaunchKernelGGL((conv3d_mfma_reg_kernel<1, false, false, true>), rgrid, rblock, shmem, st, p);
             U3D_LAUNCH_CHECK();
@@ -1874,6 +1887,9 @@ static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, co
             hipLaunchKernelGGL((conv3d_mfma_reg_kernel<NT_, false, true>), rgrid, rblock, shmem, st, p);   \
         else if (virt)                                                                                     \
             hipLaunchKernelGGL((conv3d_mfma_reg_kernel<NT_, true, false>), rgrid, rblock, shmem, st, p);   \
+        else if (noaff)                                                                                    \
+            hipLaunchKernelGGL((conv3d_mfma_reg_kernel<NT_, false, false, false, false>), rgrid, rblock,   \
+                               shmem, st, p);                                                              \
         else                                                                                               \
             hipLaunchKernelGGL((conv3d_mfma_reg_kernel<NT_, false, false>), rgrid, rblock, shmem, st, p);  \
     } while (0)
