@@ -119,6 +119,18 @@ int u3d_conv3d(int device, u3d_stream_t stream, const u3d_src_t* src, const floa
 int u3d_conv3d_residual(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w, float* out,
                         int N, int D, int H, int W, int Cout, int relu, double* out_stats, const float* residual);
 
+/* The general entry point: u3d_conv3d / u3d_conv3d_residual plus an optional scratch buffer.  At the bottom of the U
+ * (few 4x8x8 tiles, many channels: 16 tiles x 4 channel blocks for 128 channels at 8x16x16) one block per (tile,
+ * channel block) leaves most of the 256 CUs idle; given a workspace of u3d_conv3d_workspace_floats() floats the
+ * reduction over input channels is split over several blocks whose partial sums are added in a fixed order by a second
+ * kernel that also applies the epilogue (residual, ReLU, statistics) — same results contract as u3d_conv3d.
+ * u3d_conv3d_workspace_floats() returns 0 for shapes that never split; workspace may be NULL (no split).
+ * residual and gx/gstats are mutually exclusive. */
+long long u3d_conv3d_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
+int u3d_conv3d_ex(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w, float* out, int N,
+                  int D, int H, int W, int Cout, int relu, double* out_stats, const u3d_src_t* gx, double* gstats,
+                  const float* residual, float* workspace, long long workspace_floats);
+
 /* Weight gradient of the same convolution: dw[cout][cin][tap] = sum_{n,v} dz[n,v,cout] * g[n,v+tap,cin]
  * with g = src (GroupNorm affine fused on load, zero padded).  Split-K over voxel tiles with a
  * deterministic two-pass reduction.  workspace must hold u3d_wgrad_workspace_floats() floats.

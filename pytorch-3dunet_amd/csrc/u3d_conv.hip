@@ -61,6 +61,8 @@ struct ConvParams {
     int total;   // REG kernel: work items = tiles * ncb
     int gx_x2;   // REG kernel: gx's low-res half is an exact 2x upsampling (index = i >> 1, no table)
     int stagger; // REG kernel: start delay of the second half of the grid, in units of 1024 cycles
+    int ksplit, cps;        // generic kernel, split-K: the chunk range is cut into ksplit runs of cps chunks, one per block,
+    long long part_stride;  // each run writing its partial sums to out + run * part_stride (summed by splitk_reduce_kernel)
     long long* dbg;  // optional per-wave timeline records (u3d_set_profile_buffer), 24 int64 per wave
 };
 
@@ -127,7 +129,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvParams p)
     __syncthreads();  // the only rendezvous of the kernel
 
     // ---- block -> (tile, cout block) with XCD-contiguous ordering
-    const int logical = u3d_xcd_remap(blockIdx.x, gridDim.x);
+    int logical = u3d_xcd_remap(blockIdx.x, gridDim.x);
+    int ch0 = 0, nch = p.nchunks;  // this block's chunk run (split-K: one of ksplit runs)
+    float* const outp = p.out + (size_t)(p.ksplit > 1 ? logical % p.ksplit : 0) * p.part_stride;
+    if (p.ksplit > 1) {
+        ch0 = (logical % p.ksplit) * p.cps;
+        nch = min(p.cps, p.nchunks - ch0);
+        logical /= p.ksplit;
+    }
     const int cb = logical % p.ncb;
     int tile = logical / p.ncb;
     const int txi = tile % p.tx;
@@ -175,8 +184,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvParams p)
     // carries PACK_PAD zero steps past the end, so the (RB-1)-steps-ahead fetch needs no clamp.  vmcnt retires in
     // order: a B fragment can only be consumed once every OLDER load has landed, including a halo prefetch load
     // (HBM latency), hence the depth: RB-1 steps x 512*NT MFMA cycles must cover an HBM miss.
-    const f32x4* wq = reinterpret_cast<const f32x4*>(p.wp) + (size_t)cb * NT * 64 + l;
     const int wstep = p.ntot * 64;
+    const f32x4* wq = reinterpret_cast<const f32x4*>(p.wp) + (size_t)cb * NT * 64 + l + (size_t)ch0 * NSTEP * wstep;
     f32x4 bq[RB][NT];
 #pragma unroll
     for (int k = 0; k < RB - 1; ++k)
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvParams p)
 
     // ---- prologue: stage chunk 0 into buffer 0
     if constexpr (VEC) {
-        ChunkSrc c0 = chunk_src(0, true);
+        ChunkSrc c0 = chunk_src(ch0, true);
         load_affine_rows(c0);
         f32x4 v[NIT];
 #pragma unroll
@@ -248,18 +257,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvParams p)
 #pragma unroll
         for (int it = 0; it < NIT; ++it) halo_store(lds, c0, it, v[it]);
     } else {
-        stage_scalar(lds, 0);
+        stage_scalar(lds, ch0);
     }
     u3d_flag_signal(&cnt[0], l);
 
-    for (int ch = 0; ch < p.nchunks; ++ch) {
-        const bool has_next = ch + 1 < p.nchunks;
+    for (int ch = 0; ch < nch; ++ch) {  // ch counts within the block's run; the source chunk is ch0 + ch
+        const bool has_next = ch + 1 < nch;
         const int b = ch & 1;
         const float* cur = lds + b * TILE_FLOATS;
         float* nxt = lds + (b ^ 1) * TILE_FLOATS;
         ChunkSrc cn;
         f32x4 v[NIT];
-        if constexpr (VEC) cn = chunk_src(ch + 1, has_next);
+        if constexpr (VEC) cn = chunk_src(ch0 + ch + 1, has_next);
         u3d_flag_wait(&cnt[b], 4 * (ch / 2 + 1));  // all four waves have staged chunk ch
         __builtin_amdgcn_s_setprio(0);
         if (ch < 8) U3D_DBG_STAMP(8 + 2 * ch);
@@ -312,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvParams p)
                 if constexpr (VEC) {
                     halo_store(nxt, cn, st - ST0, v[st - ST0]);
                 } else {
-                    if (st == ST0) stage_scalar(nxt, ch + 1);
+                    if (st == ST0) stage_scalar(nxt, ch0 + ch + 1);
                 }
                 if (st == ST0 + NIT - 1) u3d_flag_signal(&cnt[b ^ 1], l);
             }
@@ -401,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvParams p)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
                     }
-                    if (ok) *reinterpret_cast<f32x4*>(p.out + vidx * p.Cout + co) = val;
+                    if (ok) *reinterpret_cast<f32x4*>(outp + vidx * p.Cout + co) = val;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) val[e] = ok ? val[e] : 0.f;
                     q1[nt] += val;
@@ -466,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvParams p)
                     float val = acc[mt][nt][r];
                     if (p.res && ok) val += p.res[vidx * p.Cout + co];
                     if (p.relu) val = fmaxf(val, 0.f);
-                    if (ok) p.out[vidx * p.Cout + co] = val;
+                    if (ok) outp[vidx * p.Cout + co] = val;
                     const float vv = ok ? val : 0.f;
                     if (want_g) {
                         const float xv = xb[nt][(size_t)(xfrom0[nt] ? v0 : v1) * xcs[nt]];
@@ -519,6 +528,64 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvParams p)
         }
     }
     U3D_DBG_STAMP(6);
+}
+
+// ---- split-K: small volumes with many channels (the bottom of the U: 16 tiles x 4 channel blocks on 256 CUs) do not
+// fill the chip with one block per (tile, channel block).  The generic kernel then runs ksplit blocks per item, each
+// over a run of input-channel chunks, writing plain partial sums; this kernel adds the runs in a fixed order and applies
+// the whole epilogue (residual, ReLU, GroupNorm statistics / GroupNorm-backward sums) — the result does not depend on
+// which block finished first.
+struct SplitKParams {
+    const float* part;
+    long long stride;
+    float* out;
+    const float* res;
+    double* stats;
+    u3d_src_t gx;
+    int ksplit, relu, want_g, V, D, H, W, C;
+};
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const SplitKParams p) {
+    __shared__ double red[256 * 4 * 2];  // [C/4 quads <= 256][4][2]
+    const int Q = p.C >> 2, per = blockDim.x / Q;
+    const int t = threadIdx.x, cq = t % Q, vl = t / Q, n = blockIdx.y;
+    for (int k = t; k < Q * 8; k += blockDim.x) red[k] = 0.0;
+    __syncthreads();
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    const bool xfrom0 = 4 * cq < p.gx.C0;
+    for (int v = blockIdx.x * per + vl; v < p.V; v += gridDim.x * per) {
+        const size_t off = ((size_t)n * p.V + v) * p.C + 4 * cq;
+        f32x4 a = *reinterpret_cast<const f32x4*>(p.part + off);
+        for (int k = 1; k < p.ksplit; ++k) a += *reinterpret_cast<const f32x4*>(p.part + (size_t)k * p.stride + off);
+        if (p.res) a += *reinterpret_cast<const f32x4*>(p.res + off);
+        if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = fmaxf(a[e], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(p.out + off) = a;
+        if (p.stats) {
+            s1 += a;
+            if (p.want_g) {
+                const int x = v % p.W, y = (v / p.W) % p.H, z = v / (p.W * p.H);
+                int v0, v1;
+                u3d_vox_index(p.gx, n, z, y, x, p.D, p.H, p.W, v0, v1);
+                const f32x4 xv = xfrom0 ? *reinterpret_cast<const f32x4*>(p.gx.p0 + (size_t)v0 * p.gx.C0 + 4 * cq)
+                                        : *reinterpret_cast<const f32x4*>(p.gx.p1 + (size_t)v1 * p.gx.C1 + (4 * cq - p.gx.C0));
+                s2 += a * xv;
+            } else {
+                s2 += a * a;
+            }
+        }
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            __hip_atomic_fetch_add(&red[(cq * 4 + e) * 2], (double)s1[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&red[(cq * 4 + e) * 2 + 1], (double)s2[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+        for (int k = t; k < p.C * 2; k += blockDim.x) u3d_atomic_add_f64(&p.stats[(size_t)n * p.C * 2 + k], red[k]);
+    }
 }
 
 // =================================================================================================
@@ -1778,12 +1845,33 @@ static int conv_set_lds_once(int device) {
 
 static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w, float* out, int N,
                        int D, int H, int W, int Cout, int relu, double* out_stats, const u3d_src_t* gx, double* gstats,
-                       const float* residual);
+                       const float* residual, float* ws = nullptr, long long ws_floats = 0);
 
 extern "C" int u3d_conv3d(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w, float* out,
                           int N, int D, int H, int W, int Cout, int relu, double* out_stats, const u3d_src_t* gx,
                           double* gstats) {
     return conv3d_impl(device, stream, src, packed_w, out, N, D, H, W, Cout, relu, out_stats, gx, gstats, nullptr);
+}
+
+// split-K (see splitk_reduce_kernel): used when one block per (tile, 32-channel block) leaves most CUs idle
+constexpr int SPLITK_MAX = 16;
+static bool splitk_shape(int N, int D, int H, int W, int Cin, int Cout) {
+    const long long items = (long long)N * cdiv(D, cv::TZ) * cdiv(H, cv::TY) * cdiv(W, cv::TX) * cdiv(Cout, 32);
+    return Cin > 16 && Cout % 4 == 0 && Cout <= 1024 && items < 256;
+}
+
+extern "C" long long u3d_conv3d_workspace_floats(int N, int D, int H, int W, int Cin, int Cout) {
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || !splitk_shape(N, D, H, W, Cin, Cout)) return 0;
+    const int ks = cdiv(Cin, 16) < SPLITK_MAX ? cdiv(Cin, 16) : SPLITK_MAX;
+    return (long long)ks * N * D * H * W * Cout;
+}
+
+extern "C" int u3d_conv3d_ex(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w, float* out,
+                             int N, int D, int H, int W, int Cout, int relu, double* out_stats, const u3d_src_t* gx,
+                             double* gstats, const float* residual, float* workspace, long long workspace_floats) {
+    U3D_REQUIRE(!(residual && gx), "u3d_conv3d_ex: residual and gx are mutually exclusive");
+    return conv3d_impl(device, stream, src, packed_w, out, N, D, H, W, Cout, relu, out_stats, gx, gstats, residual,
+                       workspace, workspace_floats);
 }
 
 extern "C" int u3d_conv3d_residual(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w,
@@ -1795,7 +1883,7 @@ extern "C" int u3d_conv3d_residual(int device, u3d_stream_t stream, const u3d_sr
 
 static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w, float* out, int N,
                        int D, int H, int W, int Cout, int relu, double* out_stats, const u3d_src_t* gx, double* gstats,
-                       const float* residual) {
+                       const float* residual, float* ws, long long ws_floats) {
     if (int e = u3d_enter(device)) return e;
     if (int e = check_src(src, "u3d_conv3d")) return e;
     U3D_REQUIRE(packed_w && out && N > 0 && D > 0 && H > 0 && W > 0 && Cout > 0, "u3d_conv3d: bad argument");
@@ -1842,6 +1930,44 @@ static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, co
     const size_t shmem = cv::LDS_FLOATS * sizeof(float);
     if (int e = conv_set_lds_once(device)) return e;
     hipStream_t st = (hipStream_t)stream;
+    p.ksplit = 1, p.cps = p.nchunks, p.part_stride = 0;
+    // ---- split-K on small volumes: ksplit blocks per (tile, 32-channel block), partial sums in the caller's workspace,
+    //      summed in a fixed order by splitk_reduce_kernel together with the epilogue (key 7 = 2 turns it off)
+    if (ws && p.vec && p.ovec && ((uintptr_t)ws & 15) == 0 && splitk_shape(N, D, H, W, Cin, Cout) && g_u3d_tune[7] != 2) {
+        int ncu = 0;
+        if (int e = device_cu_count(device, &ncu)) return e;
+        const long long items = ntiles * p.ntot, out_elems = (long long)N * D * H * W * Cout;
+        long long ks = (2ll * ncu) / items;
+        if (ks > p.nchunks) ks = p.nchunks;
+        if (ks > SPLITK_MAX) ks = SPLITK_MAX;
+        if (ks >= 2) {
+            p.cps = cdiv(p.nchunks, (int)ks);
+            p.ksplit = cdiv(p.nchunks, p.cps);
+        }
+        if (p.ksplit >= 2 && (long long)p.ksplit * out_elems <= ws_floats) {
+            p.ncb = p.ntot;  // NT = 1: most blocks
+            p.part_stride = out_elems;
+            p.out = ws;
+            p.out_stats = nullptr, p.gstats = nullptr, p.res = nullptr, p.relu = 0, p.has_gx = 0, p.dbg = nullptr;
+            const dim3 kgrid((unsigned)(items * p.ksplit)), kblock(256);
+            hipLaunchKernelGGL((conv3d_mfma_kernel<1, true>), kgrid, kblock, shmem, st, p);
+            U3D_LAUNCH_CHECK();
+            SplitKParams r;
+            r.part = ws, r.stride = out_elems, r.out = out, r.res = residual;
+            r.stats = out_stats ? out_stats : gstats;
+            r.gx = gx ? *gx : *src;
+            r.ksplit = p.ksplit, r.relu = relu, r.want_g = gstats != nullptr;
+            r.V = D * H * W, r.D = D, r.H = H, r.W = W, r.C = Cout;
+            const int Q = Cout / 4, per = 256 / Q;
+            int gxb = cdiv(r.V, per * 4);  // >= 4 voxels per thread
+            const int cap = 256 / N > 1 ? 256 / N : 1;
+            if (gxb > cap) gxb = cap;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)gxb, (unsigned)N), dim3((unsigned)(Q * per)), 0, st, r);
+            U3D_LAUNCH_CHECK();
+            return 0;
+        }
+        p.ksplit = 1, p.cps = p.nchunks;
+    }
     // ---- fast variant: persistent blocks, constant-offset staging (every tile fully inside, no table look-ups)
     auto plain_or_x2 = [&](const u3d_src_t& s_) {
         return s_.C1 == 0 || (D == 2 * s_.D1 && H == 2 * s_.H1 && W == 2 * s_.W1);

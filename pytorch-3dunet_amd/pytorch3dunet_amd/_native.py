@@ -112,6 +112,12 @@ _PROTOS = {
         c_int,
         [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p],
     ),
+    "u3d_conv3d_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "u3d_conv3d_ex": (
+        c_int,
+        [c_int, c_void_p, POINTER(U3DSrc), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+         POINTER(U3DSrc), c_void_p, c_void_p, c_void_p, c_int64],
+    ),
     "u3d_conv3d_residual": (
         c_int,
         [c_int, c_void_p, POINTER(U3DSrc), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],

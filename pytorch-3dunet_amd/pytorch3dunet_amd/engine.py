@@ -338,12 +338,11 @@ class UNet3DEngine:
             wp = self._packed(conv.weight, 0, dev)
             ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
             s = src.struct(affine)
-            if residual is not None:
-                nat.call("u3d_conv3d_residual", dev.index, _stream(dev), ctypes.byref(s), _p(wp), _p(y), N, D, H, W, Cout, 1,
-                         _p(ystats), _p(residual), flops=54.0 * Ctot * Cout * N * D * H * W)
-            else:
-                nat.call("u3d_conv3d", dev.index, _stream(dev), ctypes.byref(s), _p(wp), _p(y), N, D, H, W, Cout, 1,
-                         _p(ystats), None, None, flops=54.0 * Ctot * Cout * N * D * H * W)
+            # bottom-of-the-U shapes split the channel reduction over blocks through a scratch buffer (0 floats otherwise)
+            need = nat.get_lib().u3d_conv3d_workspace_floats(N, D, H, W, Ctot, Cout)
+            kws = torch.empty(need, dtype=_F32, device=dev) if need > 0 else None
+            nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s), _p(wp), _p(y), N, D, H, W, Cout, 1,
+                     _p(ystats), None, None, _p(residual), _p(kws), need, flops=54.0 * Ctot * Cout * N * D * H * W)
         if tape is not None:
             tape.convs.append(
                 ConvRec(name, src, affine, mean_rstd, y, gn.weight, conv.weight, G, self._pindex[id(gn.weight)],
@@ -391,8 +390,8 @@ class UNet3DEngine:
         gst = pool.take(Nn * src.C * 2)
         s_dz = VSrc(dz_).struct()
         s_x = src.struct()
-        nat.call("u3d_conv3d", dev.index, _stream(dev), ctypes.byref(s_dz), _p(wpd), _p(dg), Nn, Dd, Hh, Ww, src.C, 0, None,
-                 ctypes.byref(s_x), _p(gst), flops=flops)
+        nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s_dz), _p(wpd), _p(dg), Nn, Dd, Hh, Ww, src.C, 0, None,
+                 ctypes.byref(s_x), _p(gst), None, _p(ws), ws.numel(), flops=flops)
         if self.debug is not None:
             self.debug[rec.name + ".dg"] = dg.clone()
         coef = torch.empty((Nn, 3, src.C), dtype=_F32, device=dev)
@@ -420,6 +419,9 @@ class UNet3DEngine:
         for r in tape.convs:
             ws_floats = max(ws_floats, lib.u3d_wgrad_workspace_floats(r.src.N, r.src.D, r.src.H, r.src.W, r.src.C,
                                                                       r.y.shape[-1]))
+            if not r.small:  # split-K scratch of the data gradient (Cin and Cout swap roles)
+                ws_floats = max(ws_floats, lib.u3d_conv3d_workspace_floats(r.src.N, r.src.D, r.src.H, r.src.W, r.y.shape[-1],
+                                                                           r.src.C))
         r0 = tape.convs[0]
         if r0.small:
             ws_floats = max(ws_floats, lib.u3d_small_cin_bwd_workspace_floats(r0.src.N, r0.src.D, r0.src.H, r0.src.W,

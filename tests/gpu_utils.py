@@ -36,6 +36,20 @@ def conv3d(src: VSrc, w, Cout, relu=0, affine=None, mode=0, out_stats=None, gx: 
     return y
 
 
+def conv3d_ex(src: VSrc, w, Cout, relu=0, affine=None, mode=0, out_stats=None, gx: VSrc = None, gstats=None, residual=None,
+              use_ws=True):
+    """u3d_conv3d_ex with the scratch buffer the library asks for (split-K on small volumes); returns (y, ws_floats)"""
+    wp = pack(w, mode)
+    y = torch.empty((src.N, src.D, src.H, src.W, Cout), dtype=torch.float32, device=DEV)
+    s = src.struct(affine)
+    gs = gx.struct() if gx is not None else None
+    need = nat.get_lib().u3d_conv3d_workspace_floats(src.N, src.D, src.H, src.W, src.C, Cout) if use_ws else 0
+    ws = torch.empty(need, dtype=torch.float32, device=DEV) if need > 0 else None
+    nat.call("u3d_conv3d_ex", 0, _stream(DEV), ctypes.byref(s), _p(wp), _p(y), src.N, src.D, src.H, src.W, Cout, relu,
+             _p(out_stats), ctypes.byref(gs) if gs is not None else None, _p(gstats), _p(residual), _p(ws), need)
+    return y, need
+
+
 def conv3d_naive(src: VSrc, w, Cout, relu=0, affine=None, flip=0):
     y = torch.empty((src.N, src.D, src.H, src.W, Cout), dtype=torch.float32, device=DEV)
     s = src.struct(affine)

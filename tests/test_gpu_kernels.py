@@ -175,6 +175,68 @@ def test_conv3d_virtual_concat_upsample(size):
     assert U.relerr(dw.cpu(), wl.grad) < 1e-4
 
 
+SPLITK_CASES = [
+    # N, C0, C1 (nearest-upsampled half of a virtual concat), Cout, D, H, W, residual
+    (2, 128, 0, 128, 8, 16, 16, False),   # the bench workload's bottom level: 16 tiles x 4 channel blocks, 8 chunks
+    (1, 64, 0, 256, 4, 8, 16, True),      # residual + ReLU in the reduce kernel
+    (1, 40, 0, 36, 5, 9, 7, False),       # ragged tiles, 3 chunks with a partial last one, Cout not a multiple of 32
+    (1, 32, 64, 32, 4, 8, 8, False),      # virtual concat source
+    (2, 272, 0, 64, 4, 8, 8, False),      # 17 chunks > 16 splits: uneven runs
+]
+
+
+@pytest.mark.parametrize("N,C0,C1,Cout,D,H,W,res", SPLITK_CASES)
+def test_conv3d_splitk_small_volumes(N, C0, C1, Cout, D, H, W, res):
+    """u3d_conv3d_ex on bottom-of-the-U shapes: the channel reduction is split over blocks and summed by a second
+    kernel that owns the epilogue — same outputs and statistics as the one-kernel path and as torch"""
+    U, nat, VSrc, _p, _stream = _mods()
+    torch.manual_seed(C0 + 3 * Cout + D)
+    Cin = C0 + C1
+    x0 = torch.randn(N, C0, D, H, W)
+    x1 = torch.randn(N, C1, D // 2, H // 2, W // 2) if C1 else None
+    x = x0 if x1 is None else torch.cat((x0, F.interpolate(x1, size=(D, H, W), mode="nearest")), dim=1)
+    w = torch.randn(Cout, Cin, 3, 3, 3) / (27 * Cin) ** 0.5
+    ab = torch.randn(N, Cin, 2)
+    g = x * ab[:, :, 0].view(N, Cin, 1, 1, 1) + ab[:, :, 1].view(N, Cin, 1, 1, 1)
+    r = torch.randn(N, Cout, D, H, W) if res else None
+    ref = F.conv3d(g, w, None, padding=1)
+    ref = F.relu(ref + r) if res else F.relu(ref)
+    src = VSrc(U.ndhwc(x0), U.ndhwc(x1) if x1 is not None else None)
+    aff = ab.contiguous().to(U.DEV)
+    rd = U.ndhwc(r) if res else None
+    st = torch.zeros((N, Cout, 2), dtype=torch.float64, device=U.DEV)
+    y, need = U.conv3d_ex(src, w, Cout, relu=1, affine=aff, out_stats=st, residual=rd)
+    assert need > 0, "shape is expected to take the split-K path"
+    assert U.relerr(U.ncdhw(y), ref) < TOL
+    s_ref = torch.stack([ref.double().sum(dim=(2, 3, 4)), (ref.double() ** 2).sum(dim=(2, 3, 4))], dim=-1)
+    assert U.relerr(st.cpu(), s_ref) < 1e-5
+    # against the one-kernel path (no workspace): identical decisions, sums differ only by fp32 association
+    st1 = torch.zeros_like(st)
+    y1, _ = U.conv3d_ex(src, w, Cout, relu=1, affine=aff, out_stats=st1, residual=rd, use_ws=False)
+    assert U.relerr(y, y1) < 1e-5
+    # run-to-run reproducible: the runs are added in a fixed order
+    y2, _ = U.conv3d_ex(src, w, Cout, relu=1, affine=aff, out_stats=torch.zeros_like(st), residual=rd)
+    assert torch.equal(y, y2)
+    # data gradient through the same path, with the GroupNorm-backward sums against a (virtual) gx
+    dz = torch.randn(N, Cout, D, H, W)
+    xl = x.clone().requires_grad_(True)
+    F.conv3d(xl, w, None, padding=1).backward(dz)
+    gst = torch.zeros((N, Cin, 2), dtype=torch.float64, device=U.DEV)
+    dg, need_d = U.conv3d_ex(VSrc(U.ndhwc(dz)), w, Cin, relu=0, mode=1, gx=src, gstats=gst)
+    assert U.relerr(U.ncdhw(dg), xl.grad) < TOL
+    sg = torch.stack([xl.grad.double().sum(dim=(2, 3, 4)), (xl.grad.double() * x.double()).sum(dim=(2, 3, 4))], dim=-1)
+    assert U.relerr(gst.cpu(), sg) < 1e-5
+
+
+def test_conv3d_ex_without_workspace_and_large_volumes_do_not_split():
+    U, nat, VSrc, _p, _stream = _mods()
+    lib = nat.get_lib()
+    assert lib.u3d_conv3d_workspace_floats(2, 64, 128, 128, 32, 32) == 0
+    assert lib.u3d_conv3d_workspace_floats(2, 8, 16, 16, 16, 128) == 0       # a single chunk: nothing to split
+    assert lib.u3d_conv3d_workspace_floats(2, 8, 16, 16, 128, 128) == 8 * 2 * 8 * 16 * 16 * 128
+    assert lib.u3d_conv3d_workspace_floats(0, 8, 16, 16, 128, 128) == 0
+
+
 DGRAD_CASES = [(1, 16, 32, 8, 16, 16), (2, 32, 64, 9, 13, 11), (1, 1, 16, 8, 16, 16), (1, 96, 32, 4, 8, 8), (1, 3, 8, 5, 9, 7),
                # <= 16 output channels of the data gradient, aligned dims: the paired-y variant (several tiles / samples)
                (2, 16, 32, 8, 16, 32), (1, 8, 16, 4, 8, 8), (1, 12, 24, 8, 24, 16)]

@@ -78,8 +78,10 @@ def main():
             y = torch.empty((N, D, H, W, Cout), device=dev)
             st = torch.zeros((N, Cout, 2), dtype=torch.float64, device=dev)
             s = src.struct(aff)
-            ms = timeit(lambda: nat.call("u3d_conv3d", 0, _stream(dev), ctypes.byref(s), _p(wp), _p(y), N, D, H, W, Cout, 1,
-                                         _p(st), None, None), args.iters)
+            kn = lib.u3d_conv3d_workspace_floats(N, D, H, W, Cin, Cout)
+            kws = torch.empty(kn, device=dev) if kn else None
+            ms = timeit(lambda: nat.call("u3d_conv3d_ex", 0, _stream(dev), ctypes.byref(s), _p(wp), _p(y), N, D, H, W, Cout, 1,
+                                         _p(st), None, None, None, _p(kws), kn), args.iters)
             line += f"fwd {ms:7.3f} ms {flops / ms / 1e9:6.1f} TF | "
             tot["fwd"][0] += ms
             tot["fwd"][1] += flops
@@ -90,8 +92,10 @@ def main():
             gst = torch.zeros((N, Cin, 2), dtype=torch.float64, device=dev)
             s_dz = VSrc(dz).struct()
             s_x = src.struct()
-            ms = timeit(lambda: nat.call("u3d_conv3d", 0, _stream(dev), ctypes.byref(s_dz), _p(wpd), _p(dg), N, D, H, W, Cin, 0,
-                                         None, ctypes.byref(s_x), _p(gst)), args.iters)
+            kn = lib.u3d_conv3d_workspace_floats(N, D, H, W, Cout, Cin)
+            kws = torch.empty(kn, device=dev) if kn else None
+            ms = timeit(lambda: nat.call("u3d_conv3d_ex", 0, _stream(dev), ctypes.byref(s_dz), _p(wpd), _p(dg), N, D, H, W, Cin, 0,
+                                         None, ctypes.byref(s_x), _p(gst), None, _p(kws), kn), args.iters)
             line += f"dgrad {ms:7.3f} ms {flops / ms / 1e9:6.1f} TF | "
             tot["dgrad"][0] += ms
             tot["dgrad"][1] += flops
