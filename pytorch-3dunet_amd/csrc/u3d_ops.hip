@@ -788,6 +788,7 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* __restric
 
 // Fused vectorised backward: thread -> (voxel, channel quad) with a FIXED quad per thread (grid stride is a
 // multiple of Q), so dw partials stay in registers; x is read once for both dx (ReLU mask) and dw.
+constexpr int HEAD_VEC_MAXCO = 4;  // the vector kernels keep per-output partials in registers
 __global__ __launch_bounds__(256) void head_bwd_vec_kernel(const float* __restrict__ dl, const float* __restrict__ x,
                                                            const float* __restrict__ w, int N, long long V, int Cin,
                                                            int Cout, int relu_mask, float* __restrict__ dx,
@@ -797,37 +798,57 @@ __global__ __launch_bounds__(256) void head_bwd_vec_kernel(const float* __restri
     const int Q = Cin >> 2;
     const int rows = 256 / Q;  // voxels per block iteration
     const int q = t % Q, row = t / Q;
-    f32x4 wv[HEAD_MAXCO];
-    f32x4 aw[HEAD_MAXCO];
-    float ab[HEAD_MAXCO];
+    f32x4 wv[HEAD_VEC_MAXCO];
+    f32x4 aw[HEAD_VEC_MAXCO];
+    float ab[HEAD_VEC_MAXCO];
 #pragma unroll
-    for (int o = 0; o < HEAD_MAXCO; ++o) {
+    for (int o = 0; o < HEAD_VEC_MAXCO; ++o) {
         wv[o] = f32x4{0.f, 0.f, 0.f, 0.f};
         aw[o] = f32x4{0.f, 0.f, 0.f, 0.f};
         ab[o] = 0.f;
         if (o < Cout) wv[o] = *reinterpret_cast<const f32x4*>(w + (size_t)o * Cin + 4 * q);
     }
-    const long long total = (long long)N * V;
     if (row < rows) {
-        for (long long nv = (long long)blockIdx.x * rows + row; nv < total; nv += (long long)gridDim.x * rows) {
-            const int n = (int)(nv / V);
-            const long long v = nv - (long long)n * V;
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)nv * Cin + 4 * q);
-            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        // per sample, two voxels per iteration (both loads in flight before the first use); no 64-bit division
+        const long long stride = (long long)gridDim.x * rows;
+        for (int n = 0; n < N; ++n) {
+            const float* xn = x + (size_t)n * V * Cin + 4 * q;
+            const float* dn = dl + (size_t)n * Cout * V;
+            float* dxn = dx ? dx + (size_t)n * V * Cin + 4 * q : nullptr;
+            for (long long v = (long long)blockIdx.x * rows + row; v < V; v += 2 * stride) {
+                const long long v2 = v + stride;
+                const bool two = v2 < V;
+                const long long vb = two ? v2 : v;
+                const f32x4 xa = *reinterpret_cast<const f32x4*>(xn + (size_t)v * Cin);
+                const f32x4 xb = *reinterpret_cast<const f32x4*>(xn + (size_t)vb * Cin);
+                float da[HEAD_VEC_MAXCO], db[HEAD_VEC_MAXCO];
 #pragma unroll
-            for (int o = 0; o < HEAD_MAXCO; ++o) {
-                if (o < Cout) {
-                    const float d = dl[((size_t)n * Cout + o) * V + v];
-                    s += d * wv[o];
-                    aw[o] += d * xv;
-                    if (q == 0) ab[o] += d;
+                for (int o = 0; o < HEAD_VEC_MAXCO; ++o) {
+                    da[o] = o < Cout ? dn[(size_t)o * V + v] : 0.f;
+                    db[o] = (o < Cout && two) ? dn[(size_t)o * V + vb] : 0.f;
+                }
+                f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int o = 0; o < HEAD_VEC_MAXCO; ++o) {
+                    if (o < Cout) {
+                        sa += da[o] * wv[o];
+                        sb += db[o] * wv[o];
+                        aw[o] += da[o] * xa + db[o] * xb;
+                        if (q == 0) ab[o] += da[o] + db[o];
+                    }
+                }
+                if (relu_mask) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        sa[e] = xa[e] > 0.f ? sa[e] : 0.f;
+                        sb[e] = xb[e] > 0.f ? sb[e] : 0.f;
+                    }
+                }
+                if (dxn) {
+                    *reinterpret_cast<f32x4*>(dxn + (size_t)v * Cin) = sa;
+                    if (two) *reinterpret_cast<f32x4*>(dxn + (size_t)vb * Cin) = sb;
                 }
             }
-            if (relu_mask) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) s[e] = xv[e] > 0.f ? s[e] : 0.f;
-            }
-            if (dx) *reinterpret_cast<f32x4*>(dx + (size_t)nv * Cin + 4 * q) = s;
         }
     }
     if (acc == nullptr) return;
@@ -835,7 +856,7 @@ __global__ __launch_bounds__(256) void head_bwd_vec_kernel(const float* __restri
     __syncthreads();
     if (row < rows) {
 #pragma unroll
-        for (int o = 0; o < HEAD_MAXCO; ++o) {
+        for (int o = 0; o < HEAD_VEC_MAXCO; ++o) {
             if (o < Cout) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) atomicAdd(&red[o * Cin + 4 * q + e], aw[o][e]);
@@ -855,11 +876,11 @@ extern "C" int u3d_conv1x1_head_bwd(int device, u3d_stream_t stream, const float
     U3D_REQUIRE(dlogits && x && w && N > 0 && V > 0, "u3d_conv1x1_head_bwd: bad argument");
     U3D_REQUIRE(Cout >= 1 && Cout <= HEAD_MAXCO && Cin >= 1 && Cin <= HEAD_MAXCI,
                 "u3d_conv1x1_head_bwd: supports Cout<=%d, Cin<=%d (got %d,%d)", HEAD_MAXCO, HEAD_MAXCI, Cout, Cin);
-    const bool vec = (Cin % 4 == 0) && Cin <= 1024 && Cout <= 4 &&
+    const bool vec = (Cin % 4 == 0) && Cin <= 1024 && Cout <= HEAD_VEC_MAXCO &&
                      (((uintptr_t)x | (uintptr_t)w | (uintptr_t)dx) & 15) == 0;
     if (vec) {
         const int rows = 256 / (Cin / 4);
-        long long blocks = cdivll((long long)N * V, (long long)rows * 64);
+        long long blocks = cdivll((long long)V, (long long)rows * 32);
         if (blocks > 2048) blocks = 2048;
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(head_bwd_vec_kernel, dim3((unsigned)blocks), dim3(256), (size_t)(Cout + 1) * Cin * sizeof(float),

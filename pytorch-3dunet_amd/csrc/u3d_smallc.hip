@@ -292,14 +292,17 @@ __global__ __launch_bounds__(256) void conv3d_small_bwd_kernel(const SmallBwdPar
         }
 }
 
-// finalize: grid = ceil(Cout*27 / 64) blocks of 256 threads = 64 (k,tap) lanes x 4 partial-groups.  Fixed summation
-// order; forms dw (summed over n in-thread) and adds the GroupNorm-backward sums (S1,S2) per (n, c).
-__global__ __launch_bounds__(256) void conv3d_small_bwd_finalize_kernel(const float* __restrict__ partial,
-                                                                        const float* __restrict__ affine,
-                                                                        const float* __restrict__ w, int N, int B,
-                                                                        int Cin, int Cout, float* __restrict__ dw,
-                                                                        double* __restrict__ gstats) {
-    __shared__ float red[4][64][sc::MAXC + 1];
+// finalize: grid = ceil(Cout*27 / 64) blocks of 1024 threads = 64 (k,tap) lanes x 16 partial-groups; every thread keeps
+// four independent loads in flight (the pass is latency-bound: a few MB through 7 blocks).  Fixed summation order;
+// forms dw (summed over n in-thread) and adds the GroupNorm-backward sums (S1,S2) per (n, c).
+constexpr int FIN_GROUPS = 16, FIN_UNROLL = 4;
+__global__ __launch_bounds__(64 * FIN_GROUPS) void conv3d_small_bwd_finalize_kernel(const float* __restrict__ partial,
+                                                                                   const float* __restrict__ affine,
+                                                                                   const float* __restrict__ w, int N,
+                                                                                   int B, int Cin, int Cout,
+                                                                                   float* __restrict__ dw,
+                                                                                   double* __restrict__ gstats) {
+    __shared__ float red[FIN_GROUPS][64][sc::MAXC + 1];
     const int C1 = Cin + 1;
     const int nkt = Cout * 27;
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -310,19 +313,36 @@ __global__ __launch_bounds__(256) void conv3d_small_bwd_finalize_kernel(const fl
     for (int c = 0; c < sc::MAXC; ++c) dwacc[c] = 0.0;
     for (int n = 0; n < N; ++n) {
         float acc[sc::MAXC + 1];
+#pragma unroll
         for (int c = 0; c <= sc::MAXC; ++c) acc[c] = 0.f;
         if (valid) {
-            for (int b = grp; b < B; b += 4) {
-                const float* src = partial + ((size_t)n * B + b) * ((size_t)nkt * C1) + (size_t)kt * C1;
-                for (int c = 0; c < C1; ++c) acc[c] += src[c];
+            const float* base = partial + (size_t)n * B * ((size_t)nkt * C1) + (size_t)kt * C1;
+            for (int b = grp; b < B; b += FIN_GROUPS * FIN_UNROLL) {
+                float tmp[FIN_UNROLL][sc::MAXC + 1];
+#pragma unroll
+                for (int u = 0; u < FIN_UNROLL; ++u) {
+                    const int bb = b + u * FIN_GROUPS;
+                    const float* src = base + (size_t)(bb < B ? bb : b) * ((size_t)nkt * C1);
+#pragma unroll
+                    for (int c = 0; c <= sc::MAXC; ++c) tmp[u][c] = (c < C1 && bb < B) ? src[c] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < FIN_UNROLL; ++u)
+#pragma unroll
+                    for (int c = 0; c <= sc::MAXC; ++c) acc[c] += tmp[u][c];
             }
         }
-        for (int c = 0; c < C1; ++c) red[grp][lane][c] = acc[c];
+#pragma unroll
+        for (int c = 0; c <= sc::MAXC; ++c)
+            if (c < C1) red[grp][lane][c] = acc[c];
         __syncthreads();
         if (grp == 0) {  // wave 0: lanes = 64 (k,tap) pairs
             double X[sc::MAXC + 1];
-            for (int c = 0; c < C1; ++c)
-                X[c] = ((double)red[0][lane][c] + (double)red[1][lane][c]) + ((double)red[2][lane][c] + (double)red[3][lane][c]);
+            for (int c = 0; c < C1; ++c) {
+                double sum = 0.0;
+                for (int g = 0; g < FIN_GROUPS; ++g) sum += (double)red[g][lane][c];
+                X[c] = sum;
+            }
             const double T = X[Cin];
             for (int c = 0; c < Cin; ++c) {
                 double s1 = 0.0, s2 = 0.0;
@@ -396,7 +416,7 @@ extern "C" int u3d_conv3d_small_cin_bwd(int device, u3d_stream_t stream, const f
         U3D_SMALL_BWD(4);
 #undef U3D_SMALL_BWD
     U3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(conv3d_small_bwd_finalize_kernel, dim3((Cout * 27 + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(conv3d_small_bwd_finalize_kernel, dim3((Cout * 27 + 63) / 64), dim3(64 * FIN_GROUPS), 0, (hipStream_t)stream,
                        workspace, affine, w, N, p.B, Cin, Cout, dw, gstats);
     U3D_LAUNCH_CHECK();
     return 0;
