@@ -86,11 +86,14 @@ int u3d_pack_weights(int device, u3d_stream_t stream, const float* w, int Cout, 
 /* All layers of a model in ONE launch (weights change every optimizer step: 2 x 13 pack launches per step otherwise).
  * descs: DEVICE array of n descriptors sorted by `first` = cumulative float offset of the layer's image(s) within the
  * concatenation (first of descriptor 0 is 0); total_floats = sum of u3d_packed_weight_floats over the descriptors. */
+/* A descriptor may also pack a CHANNEL SLICE of a weight: w points at input channel c_off of the parent
+ * (parent + c_off*27), Cin is the slice width and cin_stride the parent's channel count (0 = Cin, a whole weight).
+ * mode 2 packs the slice's sub-pixel image (u3d_subpixel_packed_floats(Cin, Cout) floats, see u3d_subpixel_conv_fwd). */
 typedef struct {
-    const float* w; /* (Cout,Cin,3,3,3) */
+    const float* w; /* (Cout,Cin,3,3,3), or a channel slice of it */
     float* packed;  /* u3d_packed_weight_floats(Cin, Cout, mode) floats */
     int64_t first;
-    int32_t Cout, Cin, mode, pad_;
+    int32_t Cout, Cin, mode, cin_stride;
 } u3d_pack_desc_t;
 int u3d_pack_weights_batch(int device, u3d_stream_t stream, const u3d_pack_desc_t* descs_device, int n,
                            int64_t total_floats);
@@ -130,6 +133,24 @@ long long u3d_conv3d_workspace_floats(int N, int D, int H, int W, int Cin, int C
 int u3d_conv3d_ex(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w, float* out, int N,
                   int D, int H, int W, int Cout, int relu, double* out_stats, const u3d_src_t* gx, double* gstats,
                   const float* residual, float* workspace, long long workspace_floats);
+
+/* ---- 3x3x3 convolution over a nearest-2x-upsampled tensor, without the upsampled work ------------------------
+ * The upsampled half of cat(skip, F.interpolate(low, nearest)) (buildingblocks.py:491,:614) feeding the decoder's first
+ * Conv3d (buildingblocks.py:56): for an output voxel of parity p the three taps per dimension read only two low-res
+ * voxels, so each of the 8 parity classes is a 2x2x2 convolution over the low-res grid with pre-summed weights — 8/27 of
+ * the multiply-adds (csrc/u3d_subpix.hip).  Requires an exact 2x upsampling (output dims 2*D1, 2*H1, 2*W1), C1 % 4 ==
+ * Cout % 4 == 0.
+ *   u3d_pack_subpixel_weights: w is the full (Cout, Cin_total, 3,3,3) weight, channels [c_off, c_off + C1) are packed.
+ *   u3d_subpixel_conv_fwd: low (N,D1,H1,W1,C1); affine optional GroupNorm (a,b) rows of those channels, sample n at
+ *     affine + n * affine_sample_stride (floats) — a slice of the layer's [N][Ctot][2] table works in place;
+ *     out (N,2*D1,2*H1,2*W1,Cout) receives the plain partial sums (no ReLU / statistics): add the skip half with
+ *     u3d_conv3d_residual(skip, weights of the first C0 channels, residual = out). */
+long long u3d_subpixel_packed_floats(int C1, int Cout);
+int u3d_pack_subpixel_weights(int device, u3d_stream_t stream, const float* w, int Cout, int Cin_total, int c_off, int C1,
+                              float* packed);
+int u3d_subpixel_conv_fwd(int device, u3d_stream_t stream, const float* low, const float* affine,
+                          long long affine_sample_stride, const float* packed, float* out, int N, int D1, int H1, int W1,
+                          int C1, int Cout);
 
 /* Weight gradient of the same convolution: dw[cout][cin][tap] = sum_{n,v} dz[n,v,cout] * g[n,v+tap,cin]
  * with g = src (GroupNorm affine fused on load, zero padded).  Split-K over voxel tiles with a

@@ -15,6 +15,7 @@
 #include <type_traits>
 
 #include "u3d_common.h"
+#include "u3d_subpix.h"
 
 // run-time tuning knobs (u3d_set_tuning), for A/B measurements only — results never change:
 //   [0] forced N-tiles per block of u3d_conv3d (1,2,3; 0 = automatic)   [1] wgrad split override (0 = automatic)
@@ -1610,8 +1611,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //   k-channel  c  = ch*16 + 8*(st&1) + 4*(lane>>5) + j,  tap = st>>1,  n-channel = ntg*32 + (lane&31)
 // one element of the packed image(s) of one layer: `idx` counts through the normal image, then (<= 16 output channels) the
 // paired-y image
-__device__ __forceinline__ float pack_elem(const float* __restrict__ w, int Cout, int Cin, int mode, int nchunks, int ntot,
-                                           long long idx) {
+// cstride: channels per output-channel row of `w` (Cin, or the parent's channel count when w points into a channel slice)
+__device__ __forceinline__ float pack_elem(const float* __restrict__ w, int Cout, int Cin, int cstride, int mode, int nchunks,
+                                           int ntot, long long idx) {
     const long long total = ((long long)nchunks * cv::NSTEP + cv::PACK_PAD) * ntot * 256;
     // narrow outputs (<= 16 channels) get a second image for the paired-y kernel variant: 72 k-steps per chunk over the
     // 3 x 4 x 3 tap window, columns 16-31 = the same channels with the kernel shifted by one row in y
@@ -1640,10 +1642,10 @@ __device__ __forceinline__ float pack_elem(const float* __restrict__ w, int Cout
     if (ch >= nchunks || !tap_ok) {
         // the trailing zero steps / taps outside the 3^3 kernel
     } else if (mode == 0) {
-        if (kc < Cin && nc < Cout) v = w[((size_t)nc * Cin + kc) * 27 + tap];
+        if (kc < Cin && nc < Cout) v = w[((size_t)nc * cstride + kc) * 27 + tap];
     } else {
         // dgrad: contraction over original cout (kc), output = original cin (nc), flipped taps
-        if (kc < Cout && nc < Cin) v = w[((size_t)kc * Cin + nc) * 27 + (26 - tap)];
+        if (kc < Cout && nc < Cin) v = w[((size_t)kc * cstride + nc) * 27 + (26 - tap)];
     }
     return v;
 }
@@ -1662,7 +1664,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
                                     int mode, int nchunks, int ntot, long long total) {
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x)
-        out[idx] = pack_elem(w, Cout, Cin, mode, nchunks, ntot, idx);
+        out[idx] = pack_elem(w, Cout, Cin, Cin, mode, nchunks, ntot, idx);
 }
 
 // all layers of a model in ONE launch: descs (device memory) hold cumulative element offsets in `first`
@@ -1674,8 +1676,13 @@ __global__ void pack_weights_batch_kernel(const u3d_pack_desc_t* __restrict__ de
             if (descs[mid].first <= g) lo = mid; else hi = mid - 1;
         }
         const u3d_pack_desc_t d = descs[lo];
+        const int cstride = d.cin_stride > 0 ? d.cin_stride : d.Cin;
+        if (d.mode == 2) {  // sub-pixel image of the channel slice [w, w + Cin) (csrc/u3d_subpix.h)
+            d.packed[g - d.first] = sp::pack_elem(d.w, d.Cout, cstride, d.Cin, (d.Cin + 15) / 16, (d.Cout + 31) / 32, g - d.first);
+            continue;
+        }
         const int K = d.mode == 0 ? d.Cin : d.Cout, Nn = d.mode == 0 ? d.Cout : d.Cin;
-        d.packed[g - d.first] = pack_elem(d.w, d.Cout, d.Cin, d.mode, (K + 15) / 16, (Nn + 31) / 32, g - d.first);
+        d.packed[g - d.first] = pack_elem(d.w, d.Cout, d.Cin, cstride, d.mode, (K + 15) / 16, (Nn + 31) / 32, g - d.first);
     }
 }
 

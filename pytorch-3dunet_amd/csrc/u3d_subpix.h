@@ -1,0 +1,93 @@
+// u3d_subpix.h — tiling constants and the packed-weight layout of the sub-pixel convolution (csrc/u3d_subpix.hip); shared with
+// the batch weight packer in u3d_conv.hip.
+#pragma once
+#include <type_traits>
+
+#include "u3d_common.h"
+
+namespace sp {
+constexpr int TZ = 4, TY = 4, TX = 8;
+constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+constexpr int CC = 16, CS = 16;
+constexpr int RS = HX * CS + 4;   // 164: the conflict-free row stride of u3d_conv.hip
+constexpr int PS = HY * RS;       // 984
+constexpr int TILE_FLOATS = HZ * PS + 4;
+constexpr int NITEMS = HZ * HY * HX * (CC / 4);  // 1440 float4 items per chunk
+constexpr int NIT = (NITEMS + 255) / 256;        // 6
+constexpr int NSTEP = 54;
+constexpr int NFRAG = 128;   // B fragments per chunk = sum over steps of the classes using the step's offset
+constexpr int RING = 8;      // B ring slots; fragments are fetched RING-1 ahead (NFRAG % RING == 0)
+constexpr int PACK_PAD = 8;  // zero fragments appended to the packed image (fetch overrun)
+constexpr int ST0 = 30;      // k-step of the first halo store into the other buffer
+
+__host__ __device__ constexpr int ncls1(int h) { return h == 1 ? 2 : 1; }
+__host__ __device__ constexpr int cls1(int h, int i) { return h == 0 ? 0 : (h == 2 ? 1 : i); }
+__host__ __device__ constexpr int ncls(int tap) { return ncls1(tap / 9) * ncls1((tap / 3) % 3) * ncls1(tap % 3); }
+// i-th class (pz*4 + py*2 + px) using halo offset `tap`
+__host__ __device__ constexpr int cls(int tap, int i) {
+    const int ny = ncls1((tap / 3) % 3), nx = ncls1(tap % 3);
+    const int ix = i % nx, iy = (i / nx) % ny, iz = i / (nx * ny);
+    return cls1(tap / 9, iz) * 4 + cls1((tap / 3) % 3, iy) * 2 + cls1(tap % 3, ix);
+}
+__host__ __device__ constexpr int prefix(int st) {  // fragments of a chunk before k-step st
+    int s = 0;
+    for (int k = 0; k < st; ++k) s += ncls(k >> 1);
+    return s;
+}
+static_assert(prefix(NSTEP) == NFRAG, "fragment count");
+
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// ---- weight packing: f32x4 index (((ch*128 + f)*ncb + cb)*64 + lane), element j; fragment f = (k-step st, i-th class of
+// the step's halo offset); k-channel = ch*16 + 8*(st&1) + 4*(lane>>5) + j, n-channel = cb*32 + (lane&31); the value is the
+// SUM of the original taps of that class which read this low-res voxel.  `w` points at the first packed input channel of
+// the (Cout, cstride, 3,3,3) weight.
+__host__ __device__ inline long long packed_floats(int C1, int Cout) {
+    return ((long long)((C1 + 15) / 16) * NFRAG + PACK_PAD) * ((Cout + 31) / 32) * 256;
+}
+
+__device__ __forceinline__ float pack_elem(const float* __restrict__ w, int Cout, int cstride, int C1, int nchunks, int ncb,
+                                           long long idx) {
+    const int j = (int)(idx & 3);
+    const int lane = (int)((idx >> 2) & 63);
+    long long r = idx >> 8;
+    const int cb = (int)(r % ncb);
+    r /= ncb;
+    const int f = (int)(r % NFRAG);
+    const int ch = (int)(r / NFRAG);
+    if (ch >= nchunks) return 0.f;  // the trailing zero fragments
+    int st = 0, pre = 0;
+    while (pre + ncls(st >> 1) <= f) {
+        pre += ncls(st >> 1);
+        ++st;
+    }
+    const int tap = st >> 1, ci = cls(tap, f - pre);
+    const int kc = ch * 16 + 8 * (st & 1) + 4 * (lane >> 5) + j;
+    const int nc = cb * 32 + (lane & 31);
+    if (kc >= C1 || nc >= Cout) return 0.f;
+    const int hh[3] = {tap / 9, (tap / 3) % 3, tap % 3};
+    const int pp[3] = {ci >> 2, (ci >> 1) & 1, ci & 1};
+    int lo[3], num[3];  // original taps t in [lo, lo+num) of parity p read halo offset h
+    for (int d = 0; d < 3; ++d) {
+        if (pp[d] == 0) {
+            lo[d] = hh[d] == 0 ? 0 : 1;
+            num[d] = hh[d] == 0 ? 1 : 2;
+        } else {
+            lo[d] = hh[d] == 1 ? 0 : 2;
+            num[d] = hh[d] == 1 ? 2 : 1;
+        }
+    }
+    const float* wr = w + ((size_t)nc * cstride + kc) * 27;
+    float v = 0.f;
+    for (int a = 0; a < num[0]; ++a)
+        for (int b = 0; b < num[1]; ++b)
+            for (int c = 0; c < num[2]; ++c) v += wr[((lo[0] + a) * 3 + lo[1] + b) * 3 + lo[2] + c];
+    return v;
+}
+}  // namespace sp

@@ -1,0 +1,285 @@
+// u3d_subpix.hip — 3x3x3 convolution over a NEAREST-2x-UPSAMPLED tensor without the upsampled work.
+//
+// The decoder's first SingleConv convolves cat(skip, interpolate(low, nearest)) (buildingblocks.py:491,:614,:56).  For the
+// upsampled half, full-res input voxel v reads low-res voxel v >> 1, so for an output voxel 2j + p (p = parity, per
+// dimension) the three taps t = 0,1,2 at full-res positions 2j + p + t - 1 hit only TWO low-res voxels:
+//      p = 0:  t=0 -> j-1,  t=1,2 -> j          p = 1:  t=0,1 -> j,  t=2 -> j+1
+// Taps that hit the same low-res voxel are added up ONCE in the weights (pack kernel), so each of the 8 output parity
+// classes is a 2x2x2 convolution over the low-res grid: 8 instead of 27 multiply-adds per (voxel, cin, cout) — 0.296 of
+// the FLOPs, same result up to fp32 association.  Zero padding carries over: full-res positions outside the volume
+// map exactly to low-res positions outside the low-res volume.
+//
+// Kernel (implicit GEMM on v_mfma_f32_32x32x2_f32, same pipeline as conv3d_mfma_kernel in u3d_conv.hip): a block of 4 waves
+// owns a 4x4x8 LOW-RES tile (wave w: the 4(y) x 8(x) voxels at z0 + w) x 32 output channels and keeps the accumulators
+// of ALL EIGHT parity classes (8 x 16 registers): the 6x6x10 low-res halo tile of a 16-channel chunk is staged once (two
+// LDS buffers, LDS flags instead of barriers, GroupNorm affine fused) and serves every class.  The k-loop walks the 27
+// halo offsets x 2 channel octets; at offset h only the classes that use it issue MFMAs (1, 2, 4 or 8 of them: per
+// dimension offset 0 belongs to parity 0, offset 2 to parity 1, offset 1 to both), each with its own combined-weight
+// fragment: 512 MFMAs and 54 A-fragment reads per chunk and wave.  The B fragments form one flat stream of 128 per
+// chunk, fetched 7 fragments (1800 MFMA cycles) ahead through an 8-slot register ring.
+//
+// Output: plain partial sums at full resolution (no ReLU, no statistics) — the caller adds the skip half with
+// u3d_conv3d_residual, whose epilogue applies ReLU and the GroupNorm statistics to the sum.
+#include "u3d_subpix.h"
+
+
+struct SubpixParams {
+    const float* low;     // (N, D1, H1, W1, C1)
+    const float* affine;  // optional GroupNorm (a,b) rows of the C1 channels: affine[n * aff_nstride + 2*c]
+    long long aff_nstride;
+    const float* wp;
+    float* out;           // (N, 2*D1, 2*H1, 2*W1, Cout)
+    int N, D1, H1, W1, C1, Cout;
+    int tz, ty, tx, nchunks, ncb;
+};
+
+__device__ __forceinline__ void sp_flag_signal(int* c, int lane) {
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void sp_flag_wait(int* c, int target) {
+    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(2);
+    asm volatile("" ::: "memory");
+}
+
+__global__ __launch_bounds__(256, 2) void subpixel_fwd_kernel(const SubpixParams p) {
+    using namespace sp;
+    __shared__ __attribute__((aligned(16))) float lds[2 * TILE_FLOATS];
+    __shared__ int cnt[16];  // [0,1] full[buf], [2,3] freed[buf]
+    const int t = threadIdx.x;
+    const int l = t & 63, w = t >> 6, m = l & 31, h = l >> 5;
+    __builtin_amdgcn_s_setprio(3);
+    if (t < 16) cnt[t] = 0;
+    __syncthreads();  // the only rendezvous of the kernel
+
+    const int logical = u3d_xcd_remap(blockIdx.x, gridDim.x);
+    const int cb = logical % p.ncb;
+    int tile = logical / p.ncb;
+    const int txi = tile % p.tx;
+    tile /= p.tx;
+    const int tyi = tile % p.ty;
+    tile /= p.ty;
+    const int tzi = tile % p.tz;
+    const int n = tile / p.tz;
+    const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
+    const int D1 = p.D1, H1 = p.H1, W1 = p.W1, C1 = p.C1;
+
+    // ---- per-thread staging descriptors (constant across chunks)
+    int ldsoff[NIT], gv[NIT];
+    const int q = t & 3;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int item = t + 256 * it;
+        const int vox = item >> 2;
+        const bool in = item < NITEMS;
+        const int hz = vox / (HY * HX);
+        const int rem = vox - hz * (HY * HX);
+        const int hy = rem / HX;
+        const int hx = rem - hy * HX;
+        ldsoff[it] = in ? hz * PS + hy * RS + hx * CS + 4 * q : HZ * PS;  // tail items -> dummy slot
+        const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool ok = in && gz >= 0 && gz < D1 && gy >= 0 && gy < H1 && gx >= 0 && gx < W1;
+        gv[it] = ok ? ((n * D1 + gz) * H1 + gy) * W1 + gx : -1;
+    }
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+    // A-fragment base: lane (m,h) -> low-res voxel (zl = w, yl = m>>3, xl = m&7), channels 4h..4h+3 of an octet
+    const int abase = w * PS + (m >> 3) * RS + (m & 7) * CS + 4 * h;
+    const int wstep = p.ncb * 64;
+    const f32x4* wq = reinterpret_cast<const f32x4*>(p.wp) + (size_t)cb * 64;  // uniform base; lanes add l
+    f32x4 bq[RING];
+#pragma unroll
+    for (int k = 0; k < RING - 1; ++k) bq[k] = wq[(size_t)k * wstep + l];
+
+    struct ChunkSrc {
+        const float* base;
+        bool cok;
+        const float* ap;
+        f32x4 lo, hi;  // raw affine rows (a0,b0,a1,b1), (a2,b2,a3,b3)
+    };
+    auto chunk_src = [&](int ch, bool live) {
+        ChunkSrc c;
+        const int cq = ch * CC + 4 * q;
+        c.cok = live && cq < C1;
+        c.base = c.cok ? p.low + cq : p.low;
+        c.ap = p.affine ? p.affine + (size_t)n * p.aff_nstride + (size_t)(c.cok ? cq : 0) * 2 : nullptr;
+        c.lo = f32x4{1.f, 0.f, 1.f, 0.f};
+        c.hi = f32x4{1.f, 0.f, 1.f, 0.f};
+        return c;
+    };
+    auto load_affine_rows = [&](ChunkSrc& c) {
+        if (c.ap) {
+            c.lo = *reinterpret_cast<const f32x4*>(c.ap);
+            c.hi = *reinterpret_cast<const f32x4*>(c.ap + 4);
+        }
+    };
+    auto halo_load = [&](const ChunkSrc& c, int it) {  // branch-free: clamped address, validity applied at the store
+        const int idx = (c.cok && gv[it] >= 0) ? gv[it] : 0;
+        return *reinterpret_cast<const f32x4*>(c.base + (size_t)idx * C1);
+    };
+    auto halo_store = [&](float* buf, const ChunkSrc& c, int it, f32x4 raw) {
+        const bool ok = c.cok && gv[it] >= 0;
+        f32x4 val = {fmaf(raw[0], c.lo[0], c.lo[1]), fmaf(raw[1], c.lo[2], c.lo[3]), fmaf(raw[2], c.hi[0], c.hi[1]),
+                     fmaf(raw[3], c.hi[2], c.hi[3])};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[e] = ok ? val[e] : 0.f;  // padding stays exactly 0
+        *reinterpret_cast<f32x4*>(&buf[ldsoff[it]]) = val;
+    };
+
+    // ---- prologue: stage chunk 0 into buffer 0
+    {
+        ChunkSrc c0 = chunk_src(0, true);
+        load_affine_rows(c0);
+        f32x4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) v[it] = halo_load(c0, it);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) halo_store(lds, c0, it, v[it]);
+    }
+    sp_flag_signal(&cnt[0], l);
+
+    for (int ch = 0; ch < p.nchunks; ++ch) {
+        const bool has_next = ch + 1 < p.nchunks;
+        const int b = ch & 1;
+        const float* cur = lds + b * TILE_FLOATS;
+        float* nxt = lds + (b ^ 1) * TILE_FLOATS;
+        ChunkSrc cn = chunk_src(ch + 1, has_next);
+        f32x4 v[NIT];
+        sp_flag_wait(&cnt[b], 4 * (ch / 2 + 1));  // all four waves have staged chunk ch
+        __builtin_amdgcn_s_setprio(0);
+
+        f32x4 aq[2];
+        aq[0] = *reinterpret_cast<const f32x4*>(&cur[abase]);
+        const f32x4* wch = wq + ((size_t)ch * NFRAG + RING - 1) * wstep;  // fragment (chunk, f) + RING-1
+        static_for<0, NSTEP>([&](auto ic) {
+            constexpr int st = decltype(ic)::value;
+            constexpr int tap = st >> 1;
+            constexpr int NC = ncls(tap);
+            constexpr int pre = prefix(st);
+            if constexpr (st % 2 == 0 && st / 2 < NIT) v[st / 2] = halo_load(cn, st / 2);
+            if constexpr (st == ST0 - 6) load_affine_rows(cn);
+            static_for<0, NC>([&](auto ii) {
+                constexpr int i = decltype(ii)::value;
+                constexpr int f = pre + i;
+                constexpr int ci = cls(tap, i);
+                bq[(f + RING - 1) % RING] = wch[(size_t)f * wstep + l];
+                __builtin_amdgcn_sched_barrier(0);
+                acc[ci] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st & 1][0], bq[f % RING][0], acc[ci], 0, 0, 0);
+                acc[ci] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st & 1][1], bq[f % RING][1], acc[ci], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (i == 0) {
+                    // the non-MFMA work of the step issues while the MFMA pipe is busy with the two above
+                    if constexpr (st + 1 < NSTEP) {
+                        constexpr int tap1 = (st + 1) >> 1, s1 = (st + 1) & 1;
+                        constexpr int aoff = (tap1 / 9) * PS + ((tap1 / 3) % 3) * RS + (tap1 % 3) * CS + 8 * s1;
+                        aq[(st + 1) & 1] = *reinterpret_cast<const f32x4*>(&cur[abase + aoff]);
+                    }
+                    if constexpr (st >= ST0 && st < ST0 + NIT) {
+                        if (has_next) {
+                            // the other buffer is free once all four waves have finished the k-loop of chunk ch-1
+                            if constexpr (st == ST0) sp_flag_wait(&cnt[2 + (b ^ 1)], 4 * ((ch + 1) / 2));
+                            halo_store(nxt, cn, st - ST0, v[st - ST0]);
+                            if constexpr (st == ST0 + NIT - 1) sp_flag_signal(&cnt[b ^ 1], l);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                acc[ci] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st & 1][2], bq[f % RING][2], acc[ci], 0, 0, 0);
+                acc[ci] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st & 1][3], bq[f % RING][3], acc[ci], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        sp_flag_signal(&cnt[2 + b], l);  // this wave no longer reads buffer b
+    }
+    __builtin_amdgcn_s_setprio(3);
+
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5); M-tile
+    //      row -> (y = row>>3, x = row&7).  A 4x4 transpose inside every lane quad (two DPP stages) leaves lane j of
+    //      quad k with the 4 consecutive channels 4k..4k+3 of voxel x = j + 4h: 16-byte stores.
+    const int cq = (l >> 2) & 7, vl = (l & 3) + 4 * h;
+    const bool odd = (l & 1) != 0, hi2 = (l & 2) != 0;
+    auto xlane = [](float v, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    using X1 = std::integral_constant<int, 0xB1>;  // quad_perm [1,0,3,2]: value of lane ^ 1
+    using X2 = std::integral_constant<int, 0x4E>;  // quad_perm [2,3,0,1]: value of lane ^ 2
+    const int co = cb * 32 + 4 * cq;
+    const bool cok = co < p.Cout;
+    const int z = z0 + w, x = x0 + vl;
+    const int D = 2 * D1, H = 2 * H1, W = 2 * W1;
+    static_for<0, 8>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        constexpr int pz = c >> 2, py = (c >> 1) & 1, px = c & 1;
+#pragma unroll
+        for (int bi = 0; bi < 4; ++bi) {
+            const float a0 = acc[c][4 * bi + 0], a1 = acc[c][4 * bi + 1], a2 = acc[c][4 * bi + 2], a3 = acc[c][4 * bi + 3];
+            const float t0 = xlane(a1, X1{}), t1 = xlane(a0, X1{}), t2 = xlane(a3, X1{}), t3 = xlane(a2, X1{});
+            const float c0 = odd ? t0 : a0, c1 = odd ? a1 : t1, c2 = odd ? t2 : a2, c3 = odd ? a3 : t3;
+            const float u0 = xlane(c2, X2{}), u2 = xlane(c0, X2{}), u1 = xlane(c3, X2{}), u3 = xlane(c1, X2{});
+            const f32x4 val = {hi2 ? u0 : c0, hi2 ? u1 : c1, hi2 ? c2 : u2, hi2 ? c3 : u3};
+            const int y = y0 + bi;
+            if (cok && z < D1 && y < H1 && x < W1) {
+                const size_t vidx = ((size_t)(n * D + 2 * z + pz) * H + 2 * y + py) * W + 2 * x + px;
+                *reinterpret_cast<f32x4*>(p.out + vidx * p.Cout + co) = val;
+            }
+        }
+    });
+}
+
+__global__ void pack_subpixel_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int cstride, int C1,
+                                     int nchunks, int ncb, long long total) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x)
+        out[idx] = sp::pack_elem(w, Cout, cstride, C1, nchunks, ncb, idx);
+}
+
+static inline int sp_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+extern "C" long long u3d_subpixel_packed_floats(int C1, int Cout) {
+    if (C1 <= 0 || Cout <= 0) return 0;
+    return sp::packed_floats(C1, Cout);
+}
+
+extern "C" int u3d_pack_subpixel_weights(int device, u3d_stream_t stream, const float* w, int Cout, int Cin_total,
+                                         int c_off, int C1, float* packed) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(w && packed && Cout > 0 && C1 > 0 && c_off >= 0 && c_off + C1 <= Cin_total,
+                "u3d_pack_subpixel_weights: bad argument");
+    const long long total = u3d_subpixel_packed_floats(C1, Cout);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_subpixel_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w + (size_t)c_off * 27,
+                       packed, Cout, Cin_total, C1, sp_cdiv(C1, 16), sp_cdiv(Cout, 32), total);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int u3d_subpixel_conv_fwd(int device, u3d_stream_t stream, const float* low, const float* affine,
+                                     long long affine_sample_stride, const float* packed, float* out, int N, int D1,
+                                     int H1, int W1, int C1, int Cout) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(low && packed && out && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && C1 > 0 && Cout > 0,
+                "u3d_subpixel_conv_fwd: bad argument");
+    U3D_REQUIRE(C1 % 4 == 0 && Cout % 4 == 0, "u3d_subpixel_conv_fwd: C1 and Cout must be multiples of 4 (got %d,%d)", C1,
+                Cout);
+    U3D_REQUIRE((((uintptr_t)low | (uintptr_t)packed | (uintptr_t)out | (uintptr_t)affine) & 15) == 0 &&
+                    (affine == nullptr || affine_sample_stride % 4 == 0),
+                "u3d_subpixel_conv_fwd: pointers must be 16-byte aligned");
+    U3D_REQUIRE((long long)N * D1 * H1 * W1 * 8 < (1ll << 31), "u3d_subpixel_conv_fwd: volume too large");
+    SubpixParams p;
+    p.low = low, p.affine = affine, p.aff_nstride = affine_sample_stride, p.wp = packed, p.out = out;
+    p.N = N, p.D1 = D1, p.H1 = H1, p.W1 = W1, p.C1 = C1, p.Cout = Cout;
+    p.tz = sp_cdiv(D1, sp::TZ), p.ty = sp_cdiv(H1, sp::TY), p.tx = sp_cdiv(W1, sp::TX);
+    p.nchunks = sp_cdiv(C1, 16), p.ncb = sp_cdiv(Cout, 32);
+    const long long nblk = (long long)N * p.tz * p.ty * p.tx * p.ncb;
+    U3D_REQUIRE(nblk < (1ll << 31), "u3d_subpixel_conv_fwd: grid too large");
+    hipLaunchKernelGGL(subpixel_fwd_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}

@@ -37,7 +37,7 @@ class U3DPackDesc(ctypes.Structure):
     """mirror of u3d_pack_desc_t (include/u3d.h)"""
 
     _fields_ = [("w", c_void_p), ("packed", c_void_p), ("first", c_int64), ("Cout", c_int32), ("Cin", c_int32),
-                ("mode", c_int32), ("pad_", c_int32)]
+                ("mode", c_int32), ("cin_stride", c_int32)]
 
 
 _PROTOS = {
@@ -111,6 +111,12 @@ _PROTOS = {
     "u3d_conv1x1_head_bwd": (
         c_int,
         [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p],
+    ),
+    "u3d_subpixel_packed_floats": (c_int64, [c_int, c_int]),
+    "u3d_pack_subpixel_weights": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "u3d_subpixel_conv_fwd": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int],
     ),
     "u3d_conv3d_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "u3d_conv3d_ex": (

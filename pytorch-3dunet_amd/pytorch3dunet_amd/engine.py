@@ -207,6 +207,9 @@ class UNet3DEngine:
         self.fused_stats = True
         self.small_cin = True  # dedicated kernels for the in_channels<=4 first layer
         self.overlap_small_wgrad = True  # weight gradients of small layers on a second HIP stream (see _BwdCtx)
+        # decoder first convs over an exact-2x upsampling: sub-pixel convolution of the upsampled half (csrc/u3d_subpix.hip)
+        self.subpixel = os.environ.get("U3D_SUBPIXEL", "1") != "0"
+        self._sub: dict = {}  # id(conv weight) -> (C0, C1) of the layers taking that path in the current forward
         self.params = list(model.parameters())
         self._pindex = {id(p): i for i, p in enumerate(self.params)}
         self._build_layer_table(model)
@@ -239,6 +242,20 @@ class UNet3DEngine:
                 out.append(mod.weight)
         return out
 
+    # pack modes: 0 forward, 1 data gradient (u3d_pack_weights); 10 = forward image of the first C0 input channels, 12 =
+    # sub-pixel image of the remaining C1 (layers in self._sub, which then need no mode-0 image)
+    def _pack_shape(self, w, mode):
+        """(w pointer, Cin, C-ABI mode, cin_stride, floats) of one packed image"""
+        lib = nat.get_lib()
+        Cout, Cin = w.shape[0], w.shape[1]
+        if mode == 10:
+            C0 = self._sub[id(w)][0]
+            return w.data_ptr(), C0, 0, Cin, lib.u3d_packed_weight_floats(C0, Cout, 0)
+        if mode == 12:
+            C0, C1 = self._sub[id(w)]
+            return w.data_ptr() + C0 * 27 * 4, C1, 2, Cin, lib.u3d_subpixel_packed_floats(C1, Cout)
+        return w.data_ptr(), Cin, mode, 0, lib.u3d_packed_weight_floats(Cin, Cout, mode)
+
     def _repack_all(self, dev, modes):
         """(Re)pack the images of ALL conv weights whose parameter changed since the last pack — one launch for the whole
         model (u3d_pack_weights_batch) instead of one per layer and mode.  The packed buffers and the device descriptor
@@ -250,7 +267,10 @@ class UNet3DEngine:
         for w in ws:
             if self.small_cin and w.shape[1] <= 4 and w.shape[0] <= 32:
                 continue  # first layer: dedicated kernels read the reference layout
-            for mode in modes:
+            wmodes = modes
+            if id(w) in self._sub:
+                wmodes = tuple(mm for mm in modes if mm != 0) + ((10, 12) if 0 in modes else ())
+            for mode in wmodes:
                 hit = self._pack_cache.get((id(w), mode))
                 if hit is None or hit[0] != (w._version, w.data_ptr()):
                     stale.append((w, mode))
@@ -266,14 +286,13 @@ class UNet3DEngine:
             descs = (nat.U3DPackDesc * len(stale))()
             bufs, first = [], 0
             for i, (w, mode) in enumerate(stale):
-                Cout, Cin = w.shape[0], w.shape[1]
-                n = lib.u3d_packed_weight_floats(Cin, Cout, mode)
+                wptr, Cin, cmode, cstride, n = self._pack_shape(w, mode)
                 hit = self._pack_cache.get((id(w), mode))
                 buf = hit[1] if hit is not None and hit[1].numel() == n and hit[1].device == dev else torch.empty(
                     n, dtype=_F32, device=dev)
                 bufs.append(buf)
-                descs[i].w, descs[i].packed, descs[i].first = w.data_ptr(), buf.data_ptr(), first
-                descs[i].Cout, descs[i].Cin, descs[i].mode = Cout, Cin, mode
+                descs[i].w, descs[i].packed, descs[i].first = wptr, buf.data_ptr(), first
+                descs[i].Cout, descs[i].Cin, descs[i].mode, descs[i].cin_stride = w.shape[0], Cin, cmode, cstride
                 first += n
             host = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8)
             ent = (host.to(dev), bufs, first)
@@ -295,6 +314,27 @@ class UNet3DEngine:
         out = torch.empty(n, dtype=_F32, device=dev)
         nat.call("u3d_pack_weights", dev.index, _stream(dev), _p(w.detach()), Cout, Cin, mode, _p(out))
         self._pack_cache[key] = (ver, out)
+        return out
+
+    def _subpixel_layers(self, size):
+        """decoder first convs whose low-res input is upsampled by exactly 2 in every dimension at this input size"""
+        if not self.subpixel:
+            return {}
+        dims = [tuple(size)]
+        for has_pool, _, _ in self.enc:
+            if has_pool:
+                dims.append(tuple(d // 2 for d in dims[-1]))
+        out = {}
+        L = len(self.enc)
+        for j, (c1, _) in enumerate(self.dec):
+            skip_lvl, low_lvl = L - 2 - j, L - 1 - j
+            if skip_lvl < 0 or low_lvl >= len(dims):
+                continue
+            C0 = self.enc[skip_lvl][2].conv.out_channels
+            C1 = c1.conv.in_channels - C0
+            if (all(a == 2 * b for a, b in zip(dims[skip_lvl], dims[low_lvl])) and C0 > 0 and C1 > 0 and C0 % 4 == 0
+                    and C1 % 4 == 0 and c1.conv.out_channels % 4 == 0):
+                out[id(c1.conv.weight)] = (C0, C1)
         return out
 
     def _stats_of(self, src: VSrc, st0, st1, pool: _StatPool, dev):
@@ -334,6 +374,21 @@ class UNet3DEngine:
             ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
             nat.call("u3d_conv3d_small_cin_fwd", dev.index, _stream(dev), _p(src.t0), _p(affine), _p(conv.weight.detach()),
                      _p(y), N, D, H, W, Ctot, Cout, 1, _p(ystats), flops=54.0 * Ctot * Cout * N * D * H * W)
+        elif src.t1 is not None and residual is None and id(conv.weight) in self._sub:
+            # cat(skip, nearest2x(low)): the upsampled half as 8 parity-class 2x2x2 convolutions over the low-res tensor
+            # (8/27 of the multiply-adds), then the skip half, whose epilogue adds the partial sums before ReLU / statistics
+            C0, C1 = self._sub[id(conv.weight)]
+            ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
+            part = torch.empty((N, D, H, W, Cout), dtype=_F32, device=dev)
+            D1, H1, W1 = D // 2, H // 2, W // 2
+            nat.call("u3d_subpixel_conv_fwd", dev.index, _stream(dev), _p(src.t1), _p(affine.view(-1)[2 * C0:]), Ctot * 2,
+                     _p(self._pack_cache[(id(conv.weight), 12)][1]), _p(part), N, D1, H1, W1, C1, Cout,
+                     flops=128.0 * C1 * Cout * N * D1 * H1 * W1)
+            a0 = affine[:, :C0].contiguous()
+            s0 = VSrc(src.t0).struct(a0)
+            nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s0), _p(self._pack_cache[(id(conv.weight), 10)][1]),
+                     _p(y), N, D, H, W, Cout, 1, _p(ystats), None, None, _p(part), None, 0,
+                     flops=54.0 * C0 * Cout * N * D * H * W)
         else:
             wp = self._packed(conv.weight, 0, dev)
             ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
@@ -445,6 +500,7 @@ class UNet3DEngine:
         if tape is not None:
             tape.x0 = x0
             tape.dims = (N, Cin, D, H, W)
+        self._sub = self._subpixel_layers((D, H, W))
         self._repack_all(dev, (0, 1) if save else (0,))
         # stat doubles: every conv output + every GN input computed standalone; generous upper bound
         tot = 0

@@ -237,6 +237,53 @@ def test_conv3d_ex_without_workspace_and_large_volumes_do_not_split():
     assert lib.u3d_conv3d_workspace_floats(0, 8, 16, 16, 128, 128) == 0
 
 
+SUBPIX_CASES = [
+    # N, C0 (skip), C1 (upsampled), Cout, D1, H1, W1, affine
+    (2, 32, 64, 32, 4, 8, 8, True),     # the bench workload's dec2.c1 channel split on a small volume
+    (1, 16, 24, 64, 4, 4, 8, True),     # partial last chunk (24 = 16 + 8), two output blocks
+    (1, 8, 16, 20, 3, 5, 6, False),     # ragged low-res tiles, Cout not a multiple of 32, no affine
+    (1, 4, 48, 32, 2, 4, 16, True),     # three chunks
+]
+
+
+@pytest.mark.parametrize("N,C0,C1,Cout,D1,H1,W1,affine", SUBPIX_CASES)
+def test_subpixel_conv_of_upsampled_half(N, C0, C1, Cout, D1, H1, W1, affine):
+    """conv3d(cat(skip, nearest2x(low))) = conv3d(skip, w[:, :C0]) + [8 parity-class 2x2x2 convolutions of low with
+    pre-summed taps]; the second term comes from u3d_subpixel_conv_fwd, the sum from u3d_conv3d_residual's epilogue"""
+    U, nat, VSrc, _p, _stream = _mods()
+    torch.manual_seed(C1 + 5 * Cout + D1)
+    D, H, W = 2 * D1, 2 * H1, 2 * W1
+    Ctot = C0 + C1
+    skip = torch.randn(N, C0, D, H, W)
+    low = torch.randn(N, C1, D1, H1, W1)
+    w = torch.randn(Cout, Ctot, 3, 3, 3) / (27 * Ctot) ** 0.5
+    ab = torch.randn(N, Ctot, 2) if affine else torch.stack([torch.ones(N, Ctot), torch.zeros(N, Ctot)], dim=-1)
+    cat = torch.cat((skip, F.interpolate(low, size=(D, H, W), mode="nearest")), dim=1)
+    g = cat * ab[:, :, 0].view(N, Ctot, 1, 1, 1) + ab[:, :, 1].view(N, Ctot, 1, 1, 1)
+    ref_up = F.conv3d(g[:, C0:], w[:, C0:].contiguous(), None, padding=1)
+    ref = F.relu(F.conv3d(g, w, None, padding=1))
+    lib = nat.get_lib()
+    wd = w.contiguous().to(U.DEV)
+    abd = ab.contiguous().to(U.DEV)
+    npk = lib.u3d_subpixel_packed_floats(C1, Cout)
+    pk = torch.empty(npk, dtype=torch.float32, device=U.DEV)
+    nat.call("u3d_pack_subpixel_weights", 0, _stream(U.DEV), _p(wd), Cout, Ctot, C0, C1, _p(pk))
+    lowd = U.ndhwc(low)
+    part = torch.full((N, D, H, W, Cout), float("nan"), dtype=torch.float32, device=U.DEV)  # every element must be written
+    aff_sub = abd.view(-1)[2 * C0:] if affine else None   # rows C0.. of sample 0; sample stride stays Ctot*2
+    nat.call("u3d_subpixel_conv_fwd", 0, _stream(U.DEV), _p(lowd), _p(aff_sub), Ctot * 2, _p(pk), _p(part), N, D1, H1, W1, C1,
+             Cout)
+    assert U.relerr(U.ncdhw(part), ref_up) < TOL
+    # skip half + residual epilogue = the whole layer
+    w0 = w[:, :C0].contiguous()
+    a0 = abd[:, :C0].contiguous() if affine else None
+    st = torch.zeros((N, Cout, 2), dtype=torch.float64, device=U.DEV)
+    y, _ = U.conv3d_ex(VSrc(U.ndhwc(skip)), w0, Cout, relu=1, affine=a0, out_stats=st, residual=part, use_ws=False)
+    assert U.relerr(U.ncdhw(y), ref) < TOL
+    s_ref = torch.stack([ref.double().sum(dim=(2, 3, 4)), (ref.double() ** 2).sum(dim=(2, 3, 4))], dim=-1)
+    assert U.relerr(st.cpu(), s_ref) < 1e-5
+
+
 DGRAD_CASES = [(1, 16, 32, 8, 16, 16), (2, 32, 64, 9, 13, 11), (1, 1, 16, 8, 16, 16), (1, 96, 32, 4, 8, 8), (1, 3, 8, 5, 9, 7),
                # <= 16 output channels of the data gradient, aligned dims: the paired-y variant (several tiles / samples)
                (2, 16, 32, 8, 16, 32), (1, 8, 16, 4, 8, 8), (1, 12, 24, 8, 24, 16)]

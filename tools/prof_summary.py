@@ -54,6 +54,7 @@ def pmc(d):
 FAMILIES = {  # C-ABI entry point -> substrings of the kernels it launches
     "u3d_conv3d": ("conv3d_mfma_reg_kernel", "conv3d_mfma_kernel", "splitk_reduce_kernel"),
     "u3d_conv3d_wgrad": ("conv3d_wgrad_kernel", "wgrad_reduce_kernel"),
+    "u3d_subpixel_conv_fwd": ("subpixel_fwd_kernel",),
 }
 
 
