@@ -88,7 +88,8 @@ int u3d_pack_weights(int device, u3d_stream_t stream, const float* w, int Cout, 
  * concatenation (first of descriptor 0 is 0); total_floats = sum of u3d_packed_weight_floats over the descriptors. */
 /* A descriptor may also pack a CHANNEL SLICE of a weight: w points at input channel c_off of the parent
  * (parent + c_off*27), Cin is the slice width and cin_stride the parent's channel count (0 = Cin, a whole weight).
- * mode 2 packs the slice's sub-pixel image (u3d_subpixel_packed_floats(Cin, Cout) floats, see u3d_subpixel_conv_fwd). */
+ * mode 2 packs the slice's sub-pixel image (u3d_subpixel_packed_floats(Cin, Cout) floats, see u3d_subpixel_conv_fwd),
+ * mode 3 its data-gradient image (u3d_subpixel_dgrad_packed_floats(Cout, Cin) floats). */
 typedef struct {
     const float* w; /* (Cout,Cin,3,3,3), or a channel slice of it */
     float* packed;  /* u3d_packed_weight_floats(Cin, Cout, mode) floats */
@@ -145,7 +146,17 @@ int u3d_conv3d_ex(int device, u3d_stream_t stream, const u3d_src_t* src, const f
  *     affine + n * affine_sample_stride (floats) — a slice of the layer's [N][Ctot][2] table works in place;
  *     out (N,2*D1,2*H1,2*W1,Cout) receives the plain partial sums (no ReLU / statistics): add the skip half with
  *     u3d_conv3d_residual(skip, weights of the first C0 channels, residual = out). */
+/*   u3d_subpixel_conv_dgrad: the data gradient with respect to the LOW-RES tensor, i.e. the reference's conv data gradient
+ *     summed over the 8 children of every low-res voxel (the backward of F.interpolate(nearest)) in one pass: a 4x4x4-tap,
+ *     stride-2 gather of dz with pre-summed taps.  dz (N,2*D1,2*H1,2*W1,Cout); dlow (N,D1,H1,W1,C1); optional gstats
+ *     double[N][C1][2] += (sum dlow, sum dlow * x_low) — the GroupNorm-backward sums of those channels (equal to the
+ *     full-resolution sums).  Packed image: u3d_pack_subpixel_dgrad_weights (batch descriptor mode 3). */
 long long u3d_subpixel_packed_floats(int C1, int Cout);
+long long u3d_subpixel_dgrad_packed_floats(int Cout, int C1);
+int u3d_pack_subpixel_dgrad_weights(int device, u3d_stream_t stream, const float* w, int Cout, int Cin_total, int c_off,
+                                    int C1, float* packed);
+int u3d_subpixel_conv_dgrad(int device, u3d_stream_t stream, const float* dz, const float* packed, const float* x_low,
+                            float* dlow, double* gstats, int N, int D1, int H1, int W1, int C1, int Cout);
 int u3d_pack_subpixel_weights(int device, u3d_stream_t stream, const float* w, int Cout, int Cin_total, int c_off, int C1,
                               float* packed);
 int u3d_subpixel_conv_fwd(int device, u3d_stream_t stream, const float* low, const float* affine,

@@ -1681,6 +1681,10 @@ __global__ void pack_weights_batch_kernel(const u3d_pack_desc_t* __restrict__ de
             d.packed[g - d.first] = sp::pack_elem(d.w, d.Cout, cstride, d.Cin, (d.Cin + 15) / 16, (d.Cout + 31) / 32, g - d.first);
             continue;
         }
+        if (d.mode == 3) {  // its data-gradient image (contraction over the layer's output channels)
+            d.packed[g - d.first] = spd::pack_elem(d.w, d.Cout, cstride, d.Cin, (d.Cout + 15) / 16, (d.Cin + 31) / 32, g - d.first);
+            continue;
+        }
         const int K = d.mode == 0 ? d.Cin : d.Cout, Nn = d.mode == 0 ? d.Cout : d.Cin;
         d.packed[g - d.first] = pack_elem(d.w, d.Cout, d.Cin, cstride, d.mode, (K + 15) / 16, (Nn + 31) / 32, g - d.first);
     }

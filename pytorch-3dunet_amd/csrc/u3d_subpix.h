@@ -91,3 +91,53 @@ __device__ __forceinline__ float pack_elem(const float* __restrict__ w, int Cout
     return v;
 }
 }  // namespace sp
+
+// ---- data gradient of the same operator with respect to the LOW-RES tensor (csrc/u3d_subpix.hip, subpixel_dgrad_kernel):
+//   dlow[i][c] = sum_{d in {-1,0,1,2}^3} sum_k dz[2i + d][k] * Wd[d][k][c],
+// Wd[d] = the sum of the original taps t with (v + t - 1) >> 1 == i for v = 2i + d: per dimension d=-1 -> {2}, d=0 -> {1,2},
+// d=1 -> {0,1}, d=2 -> {0}.  64 taps at stride 2 instead of 8 x 27.
+namespace spd {
+constexpr int TZ = 2, TY = 4, TX = 8;                          // low-res output tile of a block
+constexpr int RZ = 2 * TZ + 2, RY = 2 * TY + 2, RX = 2 * TX + 2;  // full-res dz region 6 x 10 x 18
+constexpr int ROW = 2 * (RX / 2) * 16 + 4;                     // 292: [x parity][9][16 ch] + pad; ROW/4 = 1 (mod 4): conflict-free
+constexpr int REGION_FLOATS = RZ * RY * ROW;                   // [rz][y parity][5][ROW] = 17520 floats (70 KB)
+constexpr int NITEMS = RZ * RY * RX * 4;                       // 4320 float4 items per 16-channel chunk
+constexpr int NIT = (NITEMS + 255) / 256;                      // 17
+constexpr int NFRAG = 128;                                     // 64 taps x 2 channel octets
+constexpr int RING = 8, PACK_PAD = 8;
+
+__host__ __device__ inline long long packed_floats(int K, int C1) {
+    return ((long long)((K + 15) / 16) * NFRAG + PACK_PAD) * ((C1 + 31) / 32) * 256;
+}
+
+// f32x4 index (((ch*128 + f)*ntot + ntg)*64 + lane), element j; f = tap*2 + octet, tap = (dz+1)*16 + (dy+1)*4 + (dx+1);
+// k (dz channel) = ch*16 + 8*octet + 4*(lane>>5) + j, n (low-res channel) = ntg*32 + (lane&31).  `w` points at the first
+// upsampled input channel of the (K, cstride, 3,3,3) weight.
+__device__ __forceinline__ float pack_elem(const float* __restrict__ w, int K, int cstride, int C1, int nchunks, int ntot,
+                                           long long idx) {
+    const int j = (int)(idx & 3);
+    const int lane = (int)((idx >> 2) & 63);
+    long long r = idx >> 8;
+    const int ntg = (int)(r % ntot);
+    r /= ntot;
+    const int f = (int)(r % NFRAG);
+    const int ch = (int)(r / NFRAG);
+    if (ch >= nchunks) return 0.f;
+    const int tap = f >> 1;
+    const int kc = ch * 16 + 8 * (f & 1) + 4 * (lane >> 5) + j;
+    const int nc = ntg * 32 + (lane & 31);
+    if (kc >= K || nc >= C1) return 0.f;
+    const int di[3] = {tap >> 4, (tap >> 2) & 3, tap & 3};
+    int lo[3], num[3];
+    for (int d = 0; d < 3; ++d) {
+        lo[d] = di[d] == 0 ? 2 : (di[d] == 1 ? 1 : 0);
+        num[d] = (di[d] == 1 || di[d] == 2) ? 2 : 1;
+    }
+    const float* wr = w + ((size_t)kc * cstride + nc) * 27;
+    float v = 0.f;
+    for (int a = 0; a < num[0]; ++a)
+        for (int b = 0; b < num[1]; ++b)
+            for (int c = 0; c < num[2]; ++c) v += wr[((lo[0] + a) * 3 + lo[1] + b) * 3 + lo[2] + c];
+    return v;
+}
+}  // namespace spd

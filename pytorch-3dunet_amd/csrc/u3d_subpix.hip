@@ -232,6 +232,197 @@ __global__ __launch_bounds__(256, 2) void subpixel_fwd_kernel(const SubpixParams
     });
 }
 
+// =================================================================================================================
+// Data gradient with respect to the low-res tensor.  Block = 4 waves on a 2x4x8 low-res tile x 64 low-res channels: wave
+// w owns z-plane (w & 1) and the 32-channel half (w >> 1).  The 6x10x18 full-res dz region of a 16-channel chunk lives
+// in ONE LDS buffer (70 KB, two blocks per CU) laid out [z][y parity][y/2][x parity][x/2][16]: for a fixed tap the 32
+// voxels 2i + d of an M-tile then sit at unit stride in y/2 and x/2, so the A-fragment reads are the same conflict-free
+// pattern as in the forward kernels.  The next chunk's 17 items per thread are fetched into registers during the 128
+// fragment steps (4 MFMAs each) of the current chunk and written to LDS between two k-loops, after all four waves have
+// signalled that they are done reading.  Epilogue: transposed 16-byte stores of dlow and the two GroupNorm-backward sums
+// (sum dlow, sum dlow * x_low — equal to the full-resolution sums of the reference's formulation).
+struct SubpixDgradParams {
+    const float* dz;    // (N, 2*D1, 2*H1, 2*W1, K)
+    const float* wp;
+    const float* xlow;  // (N, D1, H1, W1, C1): forward input of the upsampled half (for the sums), may be null
+    float* out;         // (N, D1, H1, W1, C1)
+    double* gstats;     // [N][C1][2] += (sum dlow, sum dlow*x), may be null
+    int N, D1, H1, W1, C1, K;
+    int tz, ty, tx, nchunks, ncb, ntot;
+};
+
+__global__ __launch_bounds__(256, 2) void subpixel_dgrad_kernel(const SubpixDgradParams p) {
+    using namespace spd;
+    using sp::static_for;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // REGION_FLOATS + 4 (dummy slot) + red[4][32][2] + cnt[16]
+    float* red = lds + REGION_FLOATS + 4;
+    int* cnt = reinterpret_cast<int*>(red + 4 * 32 * 2);
+    const int t = threadIdx.x;
+    const int l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), m = l & 31, h = l >> 5;
+    const int zi = w & 1, ni = w >> 1;
+    __builtin_amdgcn_s_setprio(3);
+    if (t < 16) cnt[t] = 0;
+    __syncthreads();
+
+    const int logical = u3d_xcd_remap(blockIdx.x, gridDim.x);
+    const int cb = logical % p.ncb;
+    int tile = logical / p.ncb;
+    const int txi = tile % p.tx;
+    tile /= p.tx;
+    const int tyi = tile % p.ty;
+    tile /= p.ty;
+    const int tzi = tile % p.tz;
+    const int n = tile / p.tz;
+    const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
+    const int D1 = p.D1, H1 = p.H1, W1 = p.W1, K = p.K;
+    const int D = 2 * D1, H = 2 * H1, W = 2 * W1;
+
+    int ldsoff[NIT], gv[NIT];
+    const int q = t & 3;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int item = t + 256 * it;
+        const int vox = item >> 2;
+        const bool in = item < NITEMS;
+        const int rz = vox / (RY * RX);
+        const int rem = vox - rz * (RY * RX);
+        const int ry = rem / RX;
+        const int rx = rem - ry * RX;
+        ldsoff[it] = in ? ((rz * 2 + (ry & 1)) * (RY / 2) + (ry >> 1)) * ROW + ((rx & 1) * (RX / 2) + (rx >> 1)) * 16 + 4 * q
+                        : REGION_FLOATS;
+        const int gz = 2 * z0 - 1 + rz, gy = 2 * y0 - 1 + ry, gx = 2 * x0 - 1 + rx;
+        const bool ok = in && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        gv[it] = ok ? ((n * D + gz) * H + gy) * W + gx : -1;
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    // lane (m,h) -> low-res voxel (zl = zi, yl = m>>3, xl = m&7); tap d adds a compile-time offset
+    const int abase = zi * (2 * RY) * ROW + (m >> 3) * ROW + (m & 7) * 16 + 4 * h;
+    const int ntg = cb * 2 + ni;
+    const int wstep = p.ntot * 64;
+    const f32x4* wq = reinterpret_cast<const f32x4*>(p.wp) + (size_t)ntg * 64;  // wave-uniform base; lanes add l
+    f32x4 bq[RING];
+#pragma unroll
+    for (int k = 0; k < RING - 1; ++k) bq[k] = wq[(size_t)k * wstep + l];
+
+    auto halo_load = [&](int ch, bool live, int it) {
+        const int cq = ch * 16 + 4 * q;
+        const bool ok = live && cq < K && gv[it] >= 0;
+        return *reinterpret_cast<const f32x4*>(p.dz + (size_t)(ok ? gv[it] : 0) * K + (ok ? cq : 0));
+    };
+    auto halo_store = [&](int ch, int it, f32x4 raw) {
+        const bool ok = ch * 16 + 4 * q < K && gv[it] >= 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) raw[e] = ok ? raw[e] : 0.f;  // outside the volume / beyond the last channel: 0
+        *reinterpret_cast<f32x4*>(&lds[ldsoff[it]]) = raw;
+    };
+    auto aoff = [](int f) constexpr {
+        const int tap = f >> 1, s = f & 1;
+        const int dz = tap >> 4, dy = (tap >> 2) & 3, dx = tap & 3;  // d + 1
+        return ((dz * 2 + (dy & 1)) * (RY / 2) + (dy >> 1)) * ROW + ((dx & 1) * (RX / 2) + (dx >> 1)) * 16 + 8 * s;
+    };
+
+    {
+        f32x4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) v[it] = halo_load(0, true, it);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) halo_store(0, it, v[it]);
+    }
+    sp_flag_signal(&cnt[0], l);
+
+    for (int ch = 0; ch < p.nchunks; ++ch) {
+        const bool has_next = ch + 1 < p.nchunks;
+        f32x4 v[NIT];
+        sp_flag_wait(&cnt[0], 4 * (ch + 1));  // all four waves have staged chunk ch
+        __builtin_amdgcn_s_setprio(0);
+        f32x4 aq[2];
+        aq[0] = *reinterpret_cast<const f32x4*>(&lds[abase + aoff(0)]);
+        const f32x4* wch = wq + ((size_t)ch * NFRAG + RING - 1) * wstep;
+        static_for<0, NFRAG>([&](auto ic) {
+            constexpr int f = decltype(ic)::value;
+            if constexpr (f % 4 == 0 && f / 4 < NIT) v[f / 4] = halo_load(ch + 1, has_next, f / 4);
+            bq[(f + RING - 1) % RING] = wch[(size_t)f * wstep + l];
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[f & 1][0], bq[f % RING][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[f & 1][1], bq[f % RING][1], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (f + 1 < NFRAG) aq[(f + 1) & 1] = *reinterpret_cast<const f32x4*>(&lds[abase + aoff(f + 1)]);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[f & 1][2], bq[f % RING][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[f & 1][3], bq[f % RING][3], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        sp_flag_signal(&cnt[1], l);  // this wave no longer reads the buffer
+        if (has_next) {
+            __builtin_amdgcn_s_setprio(3);
+            sp_flag_wait(&cnt[1], 4 * (ch + 1));
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) halo_store(ch + 1, it, v[it]);
+            sp_flag_signal(&cnt[0], l);
+        }
+    }
+    __builtin_amdgcn_s_setprio(3);
+
+    // ---- epilogue (C/D layout and the in-register 4x4 transpose as in the forward kernel)
+    const int cq = (l >> 2) & 7, vl = (l & 3) + 4 * h;
+    const bool odd = (l & 1) != 0, hi2 = (l & 2) != 0;
+    auto xlane = [](float v_, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v_), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    using X1 = std::integral_constant<int, 0xB1>;
+    using X2 = std::integral_constant<int, 0x4E>;
+    const int co = ntg * 32 + 4 * cq;
+    const bool cok = co < p.C1;
+    const int z = z0 + zi, x = x0 + vl;
+    const bool want = p.gstats != nullptr;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi) {
+        const float a0 = acc[4 * bi + 0], a1 = acc[4 * bi + 1], a2 = acc[4 * bi + 2], a3 = acc[4 * bi + 3];
+        const float t0 = xlane(a1, X1{}), t1 = xlane(a0, X1{}), t2 = xlane(a3, X1{}), t3 = xlane(a2, X1{});
+        const float c0 = odd ? t0 : a0, c1 = odd ? a1 : t1, c2 = odd ? t2 : a2, c3 = odd ? a3 : t3;
+        const float u0 = xlane(c2, X2{}), u2 = xlane(c0, X2{}), u1 = xlane(c3, X2{}), u3 = xlane(c1, X2{});
+        const f32x4 val = {hi2 ? u0 : c0, hi2 ? u1 : c1, hi2 ? c2 : u2, hi2 ? c3 : u3};
+        const int y = y0 + bi;
+        if (cok && z < D1 && y < H1 && x < W1) {
+            const size_t off = ((size_t)((n * D1 + z) * H1 + y) * W1 + x) * p.C1 + co;
+            *reinterpret_cast<f32x4*>(p.out + off) = val;
+            if (want) {
+                s1 += val;
+                s2 += val * *reinterpret_cast<const f32x4*>(p.xlow + off);
+            }
+        }
+    }
+    if (want) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = s1[e], b = s2[e];
+#pragma unroll
+            for (int mask : {1, 2, 32}) {  // lanes of one channel quad: x = (l&3) + 4*(l>>5)
+                a += __shfl_xor(a, mask);
+                b += __shfl_xor(b, mask);
+            }
+            if ((l & 35) == 0) {
+                red[(w * 32 + 4 * cq + e) * 2 + 0] = a;
+                red[(w * 32 + 4 * cq + e) * 2 + 1] = b;
+            }
+        }
+        __syncthreads();
+        if (t < 128) {  // (channel half, channel, which sum): the two z-planes in a fixed order, one f64 atomic each
+            const int nh = t >> 6, c = (t >> 1) & 31, j = t & 1;
+            const int cc = (cb * 2 + nh) * 32 + c;
+            if (cc < p.C1) {
+                const float sum = red[((nh * 2 + 0) * 32 + c) * 2 + j] + red[((nh * 2 + 1) * 32 + c) * 2 + j];
+                u3d_atomic_add_f64(&p.gstats[((size_t)n * p.C1 + cc) * 2 + j], (double)sum);
+            }
+        }
+    }
+}
+
 __global__ void pack_subpixel_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int cstride, int C1,
                                      int nchunks, int ncb, long long total) {
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -280,6 +471,63 @@ extern "C" int u3d_subpixel_conv_fwd(int device, u3d_stream_t stream, const floa
     const long long nblk = (long long)N * p.tz * p.ty * p.tx * p.ncb;
     U3D_REQUIRE(nblk < (1ll << 31), "u3d_subpixel_conv_fwd: grid too large");
     hipLaunchKernelGGL(subpixel_fwd_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void pack_subpixel_dgrad_kernel(const float* __restrict__ w, float* __restrict__ out, int K, int cstride, int C1,
+                                           int nchunks, int ntot, long long total) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x)
+        out[idx] = spd::pack_elem(w, K, cstride, C1, nchunks, ntot, idx);
+}
+
+extern "C" long long u3d_subpixel_dgrad_packed_floats(int Cout, int C1) {
+    if (C1 <= 0 || Cout <= 0) return 0;
+    return spd::packed_floats(Cout, C1);
+}
+
+extern "C" int u3d_pack_subpixel_dgrad_weights(int device, u3d_stream_t stream, const float* w, int Cout, int Cin_total,
+                                               int c_off, int C1, float* packed) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(w && packed && Cout > 0 && C1 > 0 && c_off >= 0 && c_off + C1 <= Cin_total,
+                "u3d_pack_subpixel_dgrad_weights: bad argument");
+    const long long total = spd::packed_floats(Cout, C1);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_subpixel_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       w + (size_t)c_off * 27, packed, Cout, Cin_total, C1, sp_cdiv(Cout, 16), sp_cdiv(C1, 32), total);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int u3d_subpixel_conv_dgrad(int device, u3d_stream_t stream, const float* dz, const float* packed,
+                                       const float* x_low, float* dlow, double* gstats, int N, int D1, int H1, int W1, int C1,
+                                       int Cout) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(dz && packed && dlow && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && C1 > 0 && Cout > 0,
+                "u3d_subpixel_conv_dgrad: bad argument");
+    U3D_REQUIRE((gstats == nullptr) || x_low != nullptr, "u3d_subpixel_conv_dgrad: gstats needs x_low");
+    U3D_REQUIRE(C1 % 4 == 0 && Cout % 4 == 0, "u3d_subpixel_conv_dgrad: C1 and Cout must be multiples of 4 (got %d,%d)", C1,
+                Cout);
+    U3D_REQUIRE((((uintptr_t)dz | (uintptr_t)packed | (uintptr_t)dlow | (uintptr_t)x_low) & 15) == 0,
+                "u3d_subpixel_conv_dgrad: pointers must be 16-byte aligned");
+    U3D_REQUIRE((long long)N * D1 * H1 * W1 * 8 < (1ll << 31), "u3d_subpixel_conv_dgrad: volume too large");
+    SubpixDgradParams p;
+    p.dz = dz, p.wp = packed, p.xlow = x_low, p.out = dlow, p.gstats = gstats;
+    p.N = N, p.D1 = D1, p.H1 = H1, p.W1 = W1, p.C1 = C1, p.K = Cout;
+    p.tz = sp_cdiv(D1, spd::TZ), p.ty = sp_cdiv(H1, spd::TY), p.tx = sp_cdiv(W1, spd::TX);
+    p.nchunks = sp_cdiv(Cout, 16), p.ntot = sp_cdiv(C1, 32), p.ncb = sp_cdiv(p.ntot, 2);
+    const long long nblk = (long long)N * p.tz * p.ty * p.tx * p.ncb;
+    U3D_REQUIRE(nblk < (1ll << 31), "u3d_subpixel_conv_dgrad: grid too large");
+    const size_t shmem = (spd::REGION_FLOATS + 4 + 4 * 32 * 2 + 16) * sizeof(float);
+    static bool attr_done[64] = {false};
+    if (device < 0 || device >= 64 || !attr_done[device]) {
+        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(subpixel_dgrad_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        if (device >= 0 && device < 64) attr_done[device] = true;
+    }
+    hipLaunchKernelGGL(subpixel_dgrad_kernel, dim3((unsigned)nblk), dim3(256), shmem, (hipStream_t)stream, p);
     U3D_LAUNCH_CHECK();
     return 0;
 }

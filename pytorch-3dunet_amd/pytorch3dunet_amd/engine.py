@@ -122,6 +122,7 @@ class ConvRec:
     idx_gb: int = -1
     idx_w: int = -1
     small: bool = False  # ran through the small-Cin (first layer) kernels
+    sub: Optional[tuple] = None  # (C0, C1): the upsampled half ran as a sub-pixel convolution (csrc/u3d_subpix.hip)
 
 
 @dataclass
@@ -242,18 +243,20 @@ class UNet3DEngine:
                 out.append(mod.weight)
         return out
 
-    # pack modes: 0 forward, 1 data gradient (u3d_pack_weights); 10 = forward image of the first C0 input channels, 12 =
-    # sub-pixel image of the remaining C1 (layers in self._sub, which then need no mode-0 image)
+    # pack modes: 0 forward, 1 data gradient (u3d_pack_weights).  Layers in self._sub (sub-pixel path) use instead: 10 / 11 =
+    # forward / data-gradient image of the first C0 input channels, 12 / 13 = sub-pixel forward / data-gradient image of the
+    # remaining C1 — and no mode-0 / mode-1 image.
     def _pack_shape(self, w, mode):
         """(w pointer, Cin, C-ABI mode, cin_stride, floats) of one packed image"""
         lib = nat.get_lib()
         Cout, Cin = w.shape[0], w.shape[1]
-        if mode == 10:
-            C0 = self._sub[id(w)][0]
-            return w.data_ptr(), C0, 0, Cin, lib.u3d_packed_weight_floats(C0, Cout, 0)
-        if mode == 12:
+        if mode >= 10:
             C0, C1 = self._sub[id(w)]
-            return w.data_ptr() + C0 * 27 * 4, C1, 2, Cin, lib.u3d_subpixel_packed_floats(C1, Cout)
+            if mode in (10, 11):
+                return w.data_ptr(), C0, mode - 10, Cin, lib.u3d_packed_weight_floats(C0, Cout, mode - 10)
+            if mode == 12:
+                return w.data_ptr() + C0 * 27 * 4, C1, 2, Cin, lib.u3d_subpixel_packed_floats(C1, Cout)
+            return w.data_ptr() + C0 * 27 * 4, C1, 3, Cin, lib.u3d_subpixel_dgrad_packed_floats(Cout, C1)
         return w.data_ptr(), Cin, mode, 0, lib.u3d_packed_weight_floats(Cin, Cout, mode)
 
     def _repack_all(self, dev, modes):
@@ -269,7 +272,7 @@ class UNet3DEngine:
                 continue  # first layer: dedicated kernels read the reference layout
             wmodes = modes
             if id(w) in self._sub:
-                wmodes = tuple(mm for mm in modes if mm != 0) + ((10, 12) if 0 in modes else ())
+                wmodes = tuple(mm + 10 for mm in modes) + tuple(mm + 12 for mm in modes)
             for mode in wmodes:
                 hit = self._pack_cache.get((id(w), mode))
                 if hit is None or hit[0] != (w._version, w.data_ptr()):
@@ -303,6 +306,23 @@ class UNet3DEngine:
         for (w, mode), buf in zip(stale, bufs):
             self._pack_cache[(id(w), mode)] = ((w._version, w.data_ptr()), buf)
 
+    def _packed_sub(self, rec: ConvRec, mode: int, dev) -> torch.Tensor:
+        """packed image of a sub-pixel layer (modes 10..13); normally current from the forward's batch pack"""
+        w = rec.conv_w
+        hit = self._pack_cache.get((id(w), mode))
+        if hit is None or hit[0] != (w._version, w.data_ptr()) or self._sub.get(id(w)) != rec.sub:
+            self._sub[id(w)] = rec.sub  # e.g. a forward at another input size ran in between
+            wptr, Cin, cmode, cstride, n = self._pack_shape(w, mode)
+            buf = torch.empty(n, dtype=_F32, device=dev)
+            desc = (nat.U3DPackDesc * 1)()
+            desc[0].w, desc[0].packed, desc[0].first = wptr, buf.data_ptr(), 0
+            desc[0].Cout, desc[0].Cin, desc[0].mode, desc[0].cin_stride = w.shape[0], Cin, cmode, cstride
+            table = torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8).to(dev)
+            nat.call("u3d_pack_weights_batch", dev.index, _stream(dev), _p(table), 1, n)
+            hit = ((w._version, w.data_ptr()), buf)
+            self._pack_cache[(id(w), mode)] = hit
+        return hit[1]
+
     def _packed(self, w: torch.Tensor, mode: int, dev) -> torch.Tensor:
         key = (id(w), mode)
         ver = (w._version, w.data_ptr())
@@ -315,6 +335,13 @@ class UNet3DEngine:
         nat.call("u3d_pack_weights", dev.index, _stream(dev), _p(w.detach()), Cout, Cin, mode, _p(out))
         self._pack_cache[key] = (ver, out)
         return out
+
+    def _up_scale(self, dev):
+        """(1, 8, 8) on the (p, q, r) rows of a GroupNorm-backward coefficient table: a low-res voxel stands for 8 children"""
+        t = getattr(self, "_up_scale_t", None)
+        if t is None or t.device != dev:
+            t = self._up_scale_t = torch.tensor([1.0, 8.0, 8.0], dtype=_F32, device=dev).view(1, 3, 1)
+        return t
 
     def _subpixel_layers(self, size):
         """decoder first convs whose low-res input is upsampled by exactly 2 in every dimension at this input size"""
@@ -401,7 +428,8 @@ class UNet3DEngine:
         if tape is not None:
             tape.convs.append(
                 ConvRec(name, src, affine, mean_rstd, y, gn.weight, conv.weight, G, self._pindex[id(gn.weight)],
-                        self._pindex[id(gn.bias)], self._pindex[id(conv.weight)], small)
+                        self._pindex[id(gn.bias)], self._pindex[id(conv.weight)], small,
+                        self._sub.get(id(conv.weight)) if (src.t1 is not None and residual is None) else None)
             )
         return y, ystats
 
@@ -440,14 +468,31 @@ class UNet3DEngine:
         else:
             nat.call("u3d_conv3d_wgrad", dev.index, _stream(dev), ctypes.byref(s_aff), _p(dz_), _p(gview(rec.idx_w)), Nn, Dd,
                      Hh, Ww, Cout, _p(ws), ws.numel(), flops=flops)
-        wpd = self._packed(rec.conv_w, 1, dev)
-        dg = torch.empty((Nn, Dd, Hh, Ww, src.C), dtype=_F32, device=dev)
-        gst = pool.take(Nn * src.C * 2)
         s_dz = VSrc(dz_).struct()
-        s_x = src.struct()
-        nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s_dz), _p(wpd), _p(dg), Nn, Dd, Hh, Ww, src.C, 0, None,
-                 ctypes.byref(s_x), _p(gst), None, _p(ws), ws.numel(), flops=flops)
-        if self.debug is not None:
+        if rec.sub is not None:
+            # skip half at full resolution; upsampled half directly at LOW resolution (the children sum of the nearest
+            # upsampling is folded into the 4x4x4-tap stride-2 gather).  dg = (dg_skip, dlow)
+            C0, C1 = rec.sub
+            dg0 = torch.empty((Nn, Dd, Hh, Ww, C0), dtype=_F32, device=dev)
+            dlow = torch.empty_like(src.t1)
+            gst0, gst1 = pool.take(Nn * C0 * 2), pool.take(Nn * C1 * 2)
+            s_x0 = VSrc(src.t0).struct()
+            nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s_dz), _p(self._packed_sub(rec, 11, dev)), _p(dg0),
+                     Nn, Dd, Hh, Ww, C0, 0, None, ctypes.byref(s_x0), _p(gst0), None, _p(ws), ws.numel(),
+                     flops=54.0 * C0 * Cout * Nn * Dd * Hh * Ww)
+            nat.call("u3d_subpixel_conv_dgrad", dev.index, _stream(dev), _p(dz_), _p(self._packed_sub(rec, 13, dev)), _p(src.t1),
+                     _p(dlow), _p(gst1), Nn, src.D1, src.H1, src.W1, C1, Cout,
+                     flops=128.0 * C1 * Cout * Nn * src.D1 * src.H1 * src.W1)
+            gst = torch.cat((gst0.view(Nn, C0, 2), gst1.view(Nn, C1, 2)), dim=1)
+            dg = (dg0, dlow)
+        else:
+            wpd = self._packed(rec.conv_w, 1, dev)
+            dg = torch.empty((Nn, Dd, Hh, Ww, src.C), dtype=_F32, device=dev)
+            gst = pool.take(Nn * src.C * 2)
+            s_x = src.struct()
+            nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s_dz), _p(wpd), _p(dg), Nn, Dd, Hh, Ww, src.C, 0, None,
+                     ctypes.byref(s_x), _p(gst), None, _p(ws), ws.numel(), flops=flops)
+        if self.debug is not None and rec.sub is None:
             self.debug[rec.name + ".dg"] = dg.clone()
         coef = torch.empty((Nn, 3, src.C), dtype=_F32, device=dev)
         nat.call("u3d_gn_bwd_finalize", dev.index, _stream(dev), _p(gst), _p(rec.mean_rstd), _p(rec.gn_w.detach()), Nn, src.C,
@@ -476,7 +521,7 @@ class UNet3DEngine:
                                                                       r.y.shape[-1]))
             if not r.small:  # split-K scratch of the data gradient (Cin and Cout swap roles)
                 ws_floats = max(ws_floats, lib.u3d_conv3d_workspace_floats(r.src.N, r.src.D, r.src.H, r.src.W, r.y.shape[-1],
-                                                                           r.src.C))
+                                                                           r.sub[0] if r.sub is not None else r.src.C))
         r0 = tape.convs[0]
         if r0.small:
             ws_floats = max(ws_floats, lib.u3d_small_cin_bwd_workspace_floats(r0.src.N, r0.src.D, r0.src.H, r0.src.W,
@@ -614,12 +659,21 @@ class UNet3DEngine:
             # skip half -> gradient of the encoder feature: its GroupNorm backward (p*dg + q*e + r on the first C0 channels)
             # is evaluated inside the max-pool merge kernel of that encoder level, never written to HBM
             lvl = n_levels - 2 - j
-            skip_grad[lvl] = (dg1, Ct, coef1)
-            # upsampled half -> low-res producer (previous decoder's conv2 or the deepest encoder), ReLU mask fused
             dzl = torch.empty_like(src.t1)
-            lz, ly, lx = src.los
-            nat.call("u3d_gn_bwd_apply_up", dev.index, _stream(dev), _p(dg1), Ct, C0, _p(src.t1), C1, _p(coef1), Ct, src.N, src.D,
-                     src.H, src.W, src.D1, src.H1, src.W1, _p(lz), _p(ly), _p(lx), 1, _p(dzl))
+            if r1.sub is not None:
+                dg0, dlow = dg1
+                skip_grad[lvl] = (dg0, C0, coef1, Ct)
+                # dlow already holds the children sums: (p*dlow + 8*(q*x + r)) * (x > 0) on the low-res producer
+                coef_up = coef1[:, :, C0:] * self._up_scale(dev)
+                nat.call("u3d_gn_bwd_apply", dev.index, _stream(dev), _p(dlow), C1, 0, _p(src.t1), C1, _p(coef_up), C1,
+                         src.D1 * src.H1 * src.W1, src.N, 1, _p(dzl))
+                del dg0, dlow
+            else:
+                skip_grad[lvl] = (dg1, Ct, coef1, Ct)
+                # upsampled half -> low-res producer (previous decoder's conv2 or the deepest encoder), ReLU mask fused
+                lz, ly, lx = src.los
+                nat.call("u3d_gn_bwd_apply_up", dev.index, _stream(dev), _p(dg1), Ct, C0, _p(src.t1), C1, _p(coef1), Ct, src.N,
+                         src.D, src.H, src.W, src.D1, src.H1, src.W1, _p(lz), _p(ly), _p(lx), 1, _p(dzl))
             del dg1
             dz = dzl
 
@@ -645,9 +699,9 @@ class UNet3DEngine:
                     nat.call("u3d_maxpool2_bwd_merge", dev.index, _stream(dev), _p(dg1), _p(pooled), _p(argmax), _p(coef1), None,
                              _p(e_in), Ne, De, He, We, Ce, 1, _p(out))
                 else:
-                    sdg, sCt, scoef = sk
+                    sdg, sCdg, scoef, sCt = sk
                     nat.call("u3d_maxpool2_bwd_merge_gn", dev.index, _stream(dev), _p(dg1), _p(pooled), _p(argmax), _p(coef1),
-                             _p(sdg), sCt, _p(scoef), sCt, _p(e_in), Ne, De, He, We, Ce, 1, _p(out))
+                             _p(sdg), sCdg, _p(scoef), sCt, _p(e_in), Ne, De, He, We, Ce, 1, _p(out))
                     del sk, sdg, scoef
                 dz = out
             elif need_input_grad:

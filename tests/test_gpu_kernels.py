@@ -284,6 +284,36 @@ def test_subpixel_conv_of_upsampled_half(N, C0, C1, Cout, D1, H1, W1, affine):
     assert U.relerr(st.cpu(), s_ref) < 1e-5
 
 
+@pytest.mark.parametrize("N,C1,Cout,D1,H1,W1", [(2, 64, 32, 4, 8, 8), (1, 128, 64, 2, 4, 8), (1, 24, 20, 3, 5, 6),
+                                                 (1, 96, 48, 2, 4, 16)])
+def test_subpixel_conv_dgrad_to_low_res(N, C1, Cout, D1, H1, W1):
+    """d/d(low) of conv3d(nearest2x(low), w) in one pass over dz (4x4x4 taps at stride 2 with pre-summed weights) =
+    the reference's conv data gradient followed by the sum over the children of every low-res voxel"""
+    U, nat, VSrc, _p, _stream = _mods()
+    torch.manual_seed(C1 + 3 * Cout + W1)
+    D, H, W = 2 * D1, 2 * H1, 2 * W1
+    C0 = 8
+    Ctot = C0 + C1
+    w = torch.randn(Cout, Ctot, 3, 3, 3) / (27 * Ctot) ** 0.5
+    low = torch.randn(N, C1, D1, H1, W1)
+    dz = torch.randn(N, Cout, D, H, W)
+    gl = low.clone().requires_grad_(True)
+    F.conv3d(F.interpolate(gl, size=(D, H, W), mode="nearest"), w[:, C0:].contiguous(), None, padding=1).backward(dz)
+    ref = gl.grad
+    lib = nat.get_lib()
+    wd = w.contiguous().to(U.DEV)
+    pk = torch.empty(lib.u3d_subpixel_dgrad_packed_floats(Cout, C1), dtype=torch.float32, device=U.DEV)
+    nat.call("u3d_pack_subpixel_dgrad_weights", 0, _stream(U.DEV), _p(wd), Cout, Ctot, C0, C1, _p(pk))
+    lowd = U.ndhwc(low)
+    out = torch.full((N, D1, H1, W1, C1), float("nan"), dtype=torch.float32, device=U.DEV)
+    gst = torch.zeros((N, C1, 2), dtype=torch.float64, device=U.DEV)
+    nat.call("u3d_subpixel_conv_dgrad", 0, _stream(U.DEV), _p(U.ndhwc(dz)), _p(pk), _p(lowd), _p(out), _p(gst), N, D1, H1, W1, C1,
+             Cout)
+    assert U.relerr(U.ncdhw(out), ref) < TOL
+    s_ref = torch.stack([ref.double().sum(dim=(2, 3, 4)), (ref.double() * low.double()).sum(dim=(2, 3, 4))], dim=-1)
+    assert U.relerr(gst.cpu(), s_ref) < 1e-5
+
+
 DGRAD_CASES = [(1, 16, 32, 8, 16, 16), (2, 32, 64, 9, 13, 11), (1, 1, 16, 8, 16, 16), (1, 96, 32, 4, 8, 8), (1, 3, 8, 5, 9, 7),
                # <= 16 output channels of the data gradient, aligned dims: the paired-y variant (several tiles / samples)
                (2, 16, 32, 8, 16, 32), (1, 8, 16, 4, 8, 8), (1, 12, 24, 8, 24, 16)]

@@ -63,6 +63,16 @@ def main():
         s0 = VSrc(t0).struct(a0)
         ms_b2 = timeit(lambda: nat.call("u3d_conv3d_ex", 0, _stream(dev), ctypes.byref(s0), _p(w0), _p(y), N, D, H, W, Cout, 1,
                                         _p(st), None, None, _p(part), None, 0), args.iters)
+        # (c) data gradient of the upsampled half at low resolution vs the full virtual data gradient
+        dz = torch.randn(N, D, H, W, Cout, device=dev)
+        pkd = torch.empty(lib.u3d_subpixel_dgrad_packed_floats(Cout, C1), device=dev)
+        nat.call("u3d_pack_subpixel_dgrad_weights", 0, _stream(dev), _p(w), Cout, Cin, C0, C1, _p(pkd))
+        dlow = torch.empty((N, D1, H1, W1, C1), device=dev)
+        gst = torch.zeros((N, C1, 2), dtype=torch.float64, device=dev)
+        ms_c = timeit(lambda: nat.call("u3d_subpixel_conv_dgrad", 0, _stream(dev), _p(dz), _p(pkd), _p(t1), _p(dlow), _p(gst), N, D1,
+                                       H1, W1, C1, Cout), args.iters)
+        f_dg = 2.0 * 64 * C1 * Cout * N * D1 * H1 * W1
+        print(f"{name} dgrad(low) {ms_c:.3f} ms ({f_dg / ms_c / 1e9:.1f} TF executed)", flush=True)
         err = ((y - ya).abs().max() / ya.abs().max()).item()
         f_sub = 2.0 * 64 * C1 * Cout * N * D1 * H1 * W1  # executed: 8 classes x 8 taps per low-res voxel
         print(f"{name} {C0}+{C1}->{Cout}: one kernel {ms_a:.3f} ms ({flops / ms_a / 1e9:.1f} TF algorithmic) | subpixel {ms_b1:.3f} ms "
