@@ -171,6 +171,22 @@ size_t u3d_wgrad_workspace_floats(int N, int D, int H, int W, int Cin, int Cout)
 int u3d_conv3d_wgrad(int device, u3d_stream_t stream, const u3d_src_t* src, const float* dz, float* dw, int N,
                      int D, int H, int W, int Cout, float* workspace, size_t workspace_floats);
 
+/* Same, writing the gradient of a CHANNEL SLICE of a wider weight: dw points at the slice's first input channel inside the
+ * (Cout, dw_cin_stride, 3,3,3) gradient; src holds only the slice's channels. */
+int u3d_conv3d_wgrad_strided(int device, u3d_stream_t stream, const u3d_src_t* src, const float* dz, float* dw,
+                             int dw_cin_stride, int N, int D, int H, int W, int Cout, float* workspace,
+                             size_t workspace_floats);
+
+/* Weight gradient of the upsampled half of a decoder's first convolution (see u3d_subpixel_conv_fwd): the 64 matrices
+ * sum_j g_low[j + p - 1 + e] (x) dz[2j + p] (8 parity classes p x 8 tap halves e) over the low-res grid — 8/27 of the
+ * multiply-adds of the reference formulation — folded into the 27 taps by a fixed-order reduce.  dw points at the first
+ * upsampled input channel inside the (Cout, dw_cin_stride, 3,3,3) gradient.  low (N,D1,H1,W1,C1) with the optional
+ * GroupNorm affine slice (as u3d_subpixel_conv_fwd); dz (N,2*D1,2*H1,2*W1,Cout). */
+long long u3d_subpixel_wgrad_workspace_floats(int N, int D1, int H1, int W1, int C1, int Cout);
+int u3d_subpixel_conv_wgrad(int device, u3d_stream_t stream, const float* low, const float* affine,
+                            long long affine_sample_stride, const float* dz, float* dw, int dw_cin_stride, int N, int D1,
+                            int H1, int W1, int C1, int Cout, float* workspace, long long workspace_floats);
+
 /* The network's first convolution (in_channels 1..4 behind a one-group GroupNorm): K = 27*Cin is too small for
  * the MFMA tiling, so it has bandwidth-shaped kernels of its own (same semantics as u3d_conv3d / u3d_conv3d_wgrad;
  * x is a plain (N,D,H,W,Cin) tensor, w the reference (Cout,Cin,3,3,3) weights, Cin <= 4, Cout <= 32).

@@ -1572,7 +1572,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
 
 // deterministic second pass of the split-K: block = 64 outputs x 4 split-groups, fixed summation order
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                                           int S, int nchunks, int nkb, int Cin, int Cout) {
+                                                           int S, int nchunks, int nkb, int Cin, int Cout, int cstride) {
     __shared__ float red[4][64];
     const long long total = (long long)Cin * 27 * Cout;
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -1603,7 +1603,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     red[grp][lane] = sum;
     __syncthreads();
     if (grp == 0 && idx < total)
-        dw[((size_t)k * Cin + c) * 27 + tap] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        dw[((size_t)k * cstride + c) * 27 + tap] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // =================================================================================================
@@ -2119,8 +2119,23 @@ static int wgrad_set_lds_once(int device) {
     return 0;
 }
 
+static int conv3d_wgrad_impl(int device, u3d_stream_t stream, const u3d_src_t* src, const float* dz, float* dw, int cstride,
+                             int N, int D, int H, int W, int Cout, float* workspace, size_t workspace_floats);
+
 extern "C" int u3d_conv3d_wgrad(int device, u3d_stream_t stream, const u3d_src_t* src, const float* dz, float* dw,
                                 int N, int D, int H, int W, int Cout, float* workspace, size_t workspace_floats) {
+    return conv3d_wgrad_impl(device, stream, src, dz, dw, 0, N, D, H, W, Cout, workspace, workspace_floats);
+}
+
+extern "C" int u3d_conv3d_wgrad_strided(int device, u3d_stream_t stream, const u3d_src_t* src, const float* dz, float* dw,
+                                        int dw_cin_stride, int N, int D, int H, int W, int Cout, float* workspace,
+                                        size_t workspace_floats) {
+    U3D_REQUIRE(src && dw_cin_stride >= src->C0 + src->C1, "u3d_conv3d_wgrad_strided: dw_cin_stride < channels of src");
+    return conv3d_wgrad_impl(device, stream, src, dz, dw, dw_cin_stride, N, D, H, W, Cout, workspace, workspace_floats);
+}
+
+static int conv3d_wgrad_impl(int device, u3d_stream_t stream, const u3d_src_t* src, const float* dz, float* dw, int cstride,
+                             int N, int D, int H, int W, int Cout, float* workspace, size_t workspace_floats) {
     if (int e = u3d_enter(device)) return e;
     if (int e = check_src(src, "u3d_conv3d_wgrad")) return e;
     U3D_REQUIRE(dz && dw && workspace && N > 0 && D > 0 && H > 0 && W > 0 && Cout > 0, "u3d_conv3d_wgrad: bad argument");
@@ -2156,7 +2171,7 @@ extern "C" int u3d_conv3d_wgrad(int device, u3d_stream_t stream, const u3d_src_t
     const long long total = (long long)Cin * 27 * Cout;
     const int rblocks = (int)((total + 63) / 64);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, (hipStream_t)stream, workspace, dw, p.S,
-                       p.nchunks, p.nkb, Cin, Cout);
+                       p.nchunks, p.nkb, Cin, Cout, cstride > 0 ? cstride : Cin);
     U3D_LAUNCH_CHECK();
     return 0;
 }

@@ -423,6 +423,235 @@ __global__ __launch_bounds__(256, 2) void subpixel_dgrad_kernel(const SubpixDgra
     }
 }
 
+// =================================================================================================================
+// Weight gradient of the upsampled half.  With v = 2j + p (parity class p) reading low-res voxel j + p - 1 + e, e in {0,1}
+// per dimension:   dWc[p][e][c][k] = sum_j g_low[j + p - 1 + e][c] * dz[2j + p][k]      (64 matrices (p, e))
+// and the reference's dw[k][c][t] = sum_p dWc[p][e(p,t)]  (p=0: t=0 -> e=0, t=1,2 -> e=1;  p=1: t=0,1 -> e=0, t=2 -> e=1), 8 of
+// the 64 per tap — formed by the reduce kernel, which also sums the split-K partials in a fixed order.
+//
+// Block = 8 waves = the 8 parity classes on a 2x4x8 low-res tile x 32 low-res channels x 32 dz channels.  A dz voxel
+// belongs to exactly one class, so the B operand (dz[2j+p][k], one float per lane) never goes through LDS: every wave
+// fetches its own 32 voxel pairs of the NEXT tile straight into registers while it computes the current one.  The A operand
+// (g_low shifted by the tap, GroupNorm affine fused) is read from a double-buffered 4x6x10 halo tile in LDS like in
+// conv3d_wgrad_kernel.  Per tile and wave: 32 voxel-pair groups x 8 taps = 256 MFMAs, one barrier.
+namespace spw {
+constexpr int TZ = 2, TY = 4, TX = 8;
+constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;   // 4 x 6 x 10 low-res halo tile
+constexpr int CS = 32, RS = HX * CS, PS = HY * RS;      // [hz][hy][hx][32 channels]
+constexpr int G_FLOATS = HZ * PS;                       // 7680 floats = 30 KB per buffer
+constexpr int NTHR = 512;
+constexpr int NITEMS = HZ * HY * HX * 8;                // 1920 float4 items
+constexpr int NIT = (NITEMS + NTHR - 1) / NTHR;         // 4
+constexpr int NGRP = TZ * TY * TX / 2;                  // 32 voxel pairs
+}  // namespace spw
+
+struct SubpixWgradParams {
+    const float* low;     // (N, D1, H1, W1, C1)
+    const float* affine;  // optional, sample stride aff_nstride floats
+    long long aff_nstride;
+    const float* dz;      // (N, 2*D1, 2*H1, 2*W1, K)
+    float* partial;       // [S][nchunks][nkb][64 (p, e)][32 c][32 k]
+    int N, D1, H1, W1, C1, K;
+    int nchunks, nkb, S, tz, ty, tx, ntiles, tps;
+};
+
+__global__ __launch_bounds__(512, 2) void subpixel_wgrad_kernel(const SubpixWgradParams p) {
+    using namespace spw;
+    using sp::static_for;
+    __shared__ __attribute__((aligned(16))) float lds[2 * G_FLOATS + 4];  // two halo buffers + a dummy float4 slot
+    __builtin_amdgcn_s_setprio(3);
+    const int t = threadIdx.x;
+    const int l = t & 63, i = l & 31, h = l >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int pz = w >> 2, py = (w >> 1) & 1, px = w & 1;
+
+    const int logical = u3d_xcd_remap(blockIdx.x, gridDim.x);
+    const int kb = logical % p.nkb;
+    const int chunk = (logical / p.nkb) % p.nchunks;
+    const int s = logical / (p.nkb * p.nchunks);
+    const int D1 = p.D1, H1 = p.H1, W1 = p.W1, C1 = p.C1, K = p.K;
+    const int H = 2 * H1, W = 2 * W1;
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+    // ---- staging of the g halo tile: this thread's items (halo voxel, channel quad), constant across tiles
+    const int q = t & 7;
+    const int cq = chunk * 32 + 4 * q;
+    const bool cok = cq < C1;
+    int ihv[NIT], loff[NIT];  // halo coordinates packed as hz | hy << 8 | hx << 16 (hz = 100: tail item, never inside)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int vox = (t >> 3) + 64 * it;
+        const bool in = vox < HZ * HY * HX;
+        const int hz = vox / (HY * HX);
+        const int rem = vox - hz * (HY * HX);
+        const int hy = rem / HX;
+        const int hx = rem - hy * HX;
+        loff[it] = in ? vox * CS + 4 * q : 2 * G_FLOATS;  // tail items -> dummy slot
+        ihv[it] = (in ? hz : 100) | (hy << 8) | (hx << 16);
+    }
+    struct Tile {
+        int n, z0, y0, x0;
+    };
+    auto tile_of = [&](int tile) {
+        Tile c;
+        c.x0 = (tile % p.tx) * TX;
+        tile /= p.tx;
+        c.y0 = (tile % p.ty) * TY;
+        tile /= p.ty;
+        c.z0 = (tile % p.tz) * TZ;
+        c.n = tile / p.tz;
+        return c;
+    };
+    auto g_load = [&](const Tile& c, int it) {
+        const int gz = c.z0 - 1 + (ihv[it] & 255), gy = c.y0 - 1 + ((ihv[it] >> 8) & 255), gx = c.x0 - 1 + (ihv[it] >> 16);
+        const bool ok = cok & ((unsigned)gz < (unsigned)D1) & ((unsigned)gy < (unsigned)H1) & ((unsigned)gx < (unsigned)W1);
+        const int idx = ok ? ((c.n * D1 + gz) * H1 + gy) * W1 + gx : 0;
+        return *reinterpret_cast<const f32x4*>(p.low + (size_t)idx * C1 + (cok ? cq : 0));
+    };
+    auto g_store = [&](float* buf, const Tile& c, int it, f32x4 raw, const f32x4& ga, const f32x4& gb) {
+        const int gz = c.z0 - 1 + (ihv[it] & 255), gy = c.y0 - 1 + ((ihv[it] >> 8) & 255), gx = c.x0 - 1 + (ihv[it] >> 16);
+        const bool ok = cok & ((unsigned)gz < (unsigned)D1) & ((unsigned)gy < (unsigned)H1) & ((unsigned)gx < (unsigned)W1);
+        f32x4 val = raw * ga + gb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[e] = ok ? val[e] : 0.f;
+        *reinterpret_cast<f32x4*>(&buf[loff[it]]) = val;
+    };
+    auto load_affine = [&](int n, f32x4& ga, f32x4& gb) {
+        ga = f32x4{1.f, 1.f, 1.f, 1.f};
+        gb = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.affine && cok) {
+            const float* ap = p.affine + (size_t)n * p.aff_nstride + (size_t)cq * 2;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(ap), hi = *reinterpret_cast<const f32x4*>(ap + 4);
+            ga = f32x4{lo[0], lo[2], hi[0], hi[2]};
+            gb = f32x4{lo[1], lo[3], hi[1], hi[3]};
+        }
+    };
+    // ---- B operand: lane (i = dz channel, h = voxel of the pair) of group g reads dz[2(j) + p][kb*32 + i] of its own class
+    const int kch = kb * 32 + i;
+    const bool kok = kch < K;
+    auto b_load = [&](const Tile& c, int g) {
+        const int zl = g >> 4, yl = (g >> 2) & 3, xl = 2 * (g & 3) + h;
+        const bool ok = kok & (c.z0 + zl < D1) & (c.y0 + yl < H1) & (c.x0 + xl < W1);
+        const int vz = 2 * (c.z0 + zl) + pz, vy = 2 * (c.y0 + yl) + py, vx = 2 * (c.x0 + xl) + px;
+        int vi = ok ? ((c.n * 2 * D1 + vz) * H + vy) * W + vx : 0;
+        asm volatile("" : "+v"(vi));  // opaque: an unconditional load from a clamped address, no exec-masked branch
+        const float v = p.dz[(size_t)vi * K + (kok ? kch : 0)];
+        return ok ? v : 0.f;
+    };
+
+    const int tile_begin = s * p.tps, tile_end = min(p.ntiles, (s + 1) * p.tps);
+    float bcur[NGRP];
+    f32x4 gan, gbn;
+    int n_aff = -1;
+    if (tile_begin < tile_end) {
+        const Tile c = tile_of(tile_begin);
+        load_affine(c.n, gan, gbn);
+        n_aff = c.n;
+        f32x4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) v[it] = g_load(c, it);
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g) bcur[g] = b_load(c, g);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) g_store(lds, c, it, v[it], gan, gbn);
+    }
+    __syncthreads();
+
+    // A base: lane (i = channel, h = voxel of the pair) + the class offset p; tap e and group add compile-time offsets
+    const int ab0 = (pz * HY + py) * RS + px * CS + h * CS + i;
+    auto toff = [](int k) constexpr { return ((k >> 2) * HY + ((k >> 1) & 1)) * RS + (k & 1) * CS; };
+    int cur = 0;
+    __builtin_amdgcn_s_setprio(0);
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        const bool has_next = tile + 1 < tile_end;
+        const Tile cn = tile_of(has_next ? tile + 1 : tile);
+        float* nbuf = lds + (cur ^ 1) * G_FLOATS;
+        const float* gl = lds + cur * G_FLOATS;
+        if (cn.n != n_aff) {
+            load_affine(cn.n, gan, gbn);
+            n_aff = cn.n;
+        }
+        f32x4 v[NIT];
+        float aop[2][8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) aop[0][k] = gl[ab0 + toff(k)];
+        static_for<0, NGRP>([&](auto gg) {
+            constexpr int g = decltype(gg)::value;
+            if constexpr (g % 2 == 0 && g / 2 < NIT) v[g / 2] = g_load(cn, g / 2);
+            if constexpr (g >= 20 && g - 20 < NIT) g_store(nbuf, cn, g - 20, v[g - 20], gan, gbn);
+            if constexpr (g + 1 < NGRP) {
+                constexpr int g1 = g + 1;
+                constexpr int goff = ((g1 >> 4) * HY + ((g1 >> 2) & 3)) * RS + 2 * (g1 & 3) * CS;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) aop[g1 & 1][k] = gl[ab0 + toff(k) + goff];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[g & 1][k], bcur[g], acc[k], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            bcur[g] = b_load(cn, g);  // the same pair of the NEXT tile: in flight for a whole tile before its use
+        });
+        __syncthreads();
+        cur ^= 1;
+    }
+    __builtin_amdgcn_s_setprio(3);
+    // partial[s][chunk][kb][w*8 + e][c][k]: D rows = c, cols = k
+    float* dst = p.partial + ((size_t)((s * p.nchunks + chunk) * p.nkb + kb) * 64 + w * 8) * 1024;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            dst[((size_t)k * 32 + row) * 32 + i] = acc[k][r];
+        }
+}
+
+// fixed-order sum over the splits and over the 8 (class, tap-half) matrices that make up one original tap; writes
+// dw[k][c_off + c][t] of the (K, cstride, 3,3,3) weight gradient
+__global__ __launch_bounds__(256) void subpixel_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                                    int S, int nchunks, int nkb, int C1, int K,
+                                                                    int cstride) {
+    __shared__ float red[4][64];
+    const long long total = (long long)C1 * 27 * K;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long long idx = (long long)blockIdx.x * 64 + lane;  // (c, tap, k), k fastest
+    float sum = 0.f;
+    int k = 0, tap = 0, c = 0;
+    if (idx < total) {
+        k = (int)(idx % K);
+        const long long r = idx / K;
+        tap = (int)(r % 27);
+        c = (int)(r / 27);
+        const int t3[3] = {tap / 9, (tap / 3) % 3, tap % 3};
+        const size_t base = ((size_t)((c >> 5) * nkb + (k >> 5)) * 64) * 1024 + (c & 31) * 32 + (k & 31);
+        const size_t sstride = (size_t)nchunks * nkb * 64 * 1024;
+        const int per = (S + 3) / 4;
+        const int s0 = grp * per, s1 = min(S, s0 + per);
+        for (int s = s0; s < s1; ++s) {
+            float a = 0.f;
+            for (int pc = 0; pc < 8; ++pc) {  // parity class (pz, py, px) and the tap half e it pairs with this tap
+                int e = 0;
+                for (int d = 0; d < 3; ++d) {
+                    const int pd = (pc >> (2 - d)) & 1;
+                    const int ed = pd == 0 ? (t3[d] == 0 ? 0 : 1) : (t3[d] == 2 ? 1 : 0);
+                    e = e * 2 + ed;
+                }
+                a += partial[(size_t)s * sstride + base + (size_t)(pc * 8 + e) * 1024];
+            }
+            sum += a;
+        }
+    }
+    red[grp][lane] = sum;
+    __syncthreads();
+    if (grp == 0 && idx < total)
+        dw[((size_t)k * cstride + c) * 27 + tap] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
 __global__ void pack_subpixel_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int cstride, int C1,
                                      int nchunks, int ncb, long long total) {
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -528,6 +757,63 @@ extern "C" int u3d_subpixel_conv_dgrad(int device, u3d_stream_t stream, const fl
         if (device >= 0 && device < 64) attr_done[device] = true;
     }
     hipLaunchKernelGGL(subpixel_dgrad_kernel, dim3((unsigned)nblk), dim3(256), shmem, (hipStream_t)stream, p);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+static void subpixel_wgrad_plan(int N, int D1, int H1, int W1, int C1, int K, SubpixWgradParams& p) {
+    p.nchunks = sp_cdiv(C1, 32), p.nkb = sp_cdiv(K, 32);
+    p.tz = sp_cdiv(D1, spw::TZ), p.ty = sp_cdiv(H1, spw::TY), p.tx = sp_cdiv(W1, spw::TX);
+    p.ntiles = N * p.tz * p.ty * p.tx;
+    // one 8-wave block per CU: the split count whose grid fills whole rounds of 256 CUs best (as u3d_conv3d_wgrad)
+    const int pairs = p.nchunks * p.nkb;
+    long long best = -1;
+    int best_S = 1;
+    for (int rounds = 1; rounds <= 8; ++rounds) {
+        int S = (rounds * 256) / pairs;
+        if (S < 1) S = 1;
+        if (S > p.ntiles) S = p.ntiles;
+        const int tps = sp_cdiv(p.ntiles, S);
+        S = sp_cdiv(p.ntiles, tps);
+        const long long cost = (long long)sp_cdiv(S * pairs, 256) * (tps + 2);
+        if (best < 0 || cost < best) best = cost, best_S = S;
+    }
+    p.tps = sp_cdiv(p.ntiles, best_S);
+    p.S = sp_cdiv(p.ntiles, p.tps);
+}
+
+extern "C" long long u3d_subpixel_wgrad_workspace_floats(int N, int D1, int H1, int W1, int C1, int Cout) {
+    if (N <= 0 || D1 <= 0 || H1 <= 0 || W1 <= 0 || C1 <= 0 || Cout <= 0) return 0;
+    SubpixWgradParams p;
+    subpixel_wgrad_plan(N, D1, H1, W1, C1, Cout, p);
+    return (long long)p.S * p.nchunks * p.nkb * 64 * 1024;
+}
+
+extern "C" int u3d_subpixel_conv_wgrad(int device, u3d_stream_t stream, const float* low, const float* affine,
+                                       long long affine_sample_stride, const float* dz, float* dw, int dw_cin_stride, int N,
+                                       int D1, int H1, int W1, int C1, int Cout, float* workspace,
+                                       long long workspace_floats) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(low && dz && dw && workspace && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && C1 > 0 && Cout > 0 &&
+                    dw_cin_stride >= C1,
+                "u3d_subpixel_conv_wgrad: bad argument");
+    U3D_REQUIRE(C1 % 4 == 0, "u3d_subpixel_conv_wgrad: C1 must be a multiple of 4 (got %d)", C1);
+    U3D_REQUIRE((((uintptr_t)low | (uintptr_t)affine) & 15) == 0 && (affine == nullptr || affine_sample_stride % 4 == 0),
+                "u3d_subpixel_conv_wgrad: low / affine must be 16-byte aligned");
+    U3D_REQUIRE((long long)N * D1 * H1 * W1 * 8 < (1ll << 31), "u3d_subpixel_conv_wgrad: volume too large");
+    SubpixWgradParams p;
+    subpixel_wgrad_plan(N, D1, H1, W1, C1, Cout, p);
+    const long long need = (long long)p.S * p.nchunks * p.nkb * 64 * 1024;
+    if (workspace_floats < need)
+        return u3d_set_err(U3D_EWORKSPACE, "u3d_subpixel_conv_wgrad: workspace %lld < %lld floats", workspace_floats, need);
+    p.low = low, p.affine = affine, p.aff_nstride = affine_sample_stride, p.dz = dz, p.partial = workspace;
+    p.N = N, p.D1 = D1, p.H1 = H1, p.W1 = W1, p.C1 = C1, p.K = Cout;
+    hipLaunchKernelGGL(subpixel_wgrad_kernel, dim3((unsigned)(p.S * p.nchunks * p.nkb)), dim3(spw::NTHR), 0,
+                       (hipStream_t)stream, p);
+    U3D_LAUNCH_CHECK();
+    const long long total = (long long)C1 * 27 * Cout;
+    hipLaunchKernelGGL(subpixel_wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
+                       workspace, dw, p.S, p.nchunks, p.nkb, C1, Cout, dw_cin_stride);
     U3D_LAUNCH_CHECK();
     return 0;
 }

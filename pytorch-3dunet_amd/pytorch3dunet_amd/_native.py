@@ -112,6 +112,16 @@ _PROTOS = {
         c_int,
         [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p],
     ),
+    "u3d_conv3d_wgrad_strided": (
+        c_int,
+        [c_int, c_void_p, POINTER(U3DSrc), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t],
+    ),
+    "u3d_subpixel_wgrad_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "u3d_subpixel_conv_wgrad": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+         c_void_p, c_int64],
+    ),
     "u3d_subpixel_packed_floats": (c_int64, [c_int, c_int]),
     "u3d_subpixel_dgrad_packed_floats": (c_int64, [c_int, c_int]),
     "u3d_pack_subpixel_dgrad_weights": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

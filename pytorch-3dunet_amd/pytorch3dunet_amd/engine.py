@@ -454,7 +454,20 @@ class UNet3DEngine:
             return None, coef
         s_aff = src.struct(rec.affine)
         flops = 54.0 * src.C * Cout * Nn * Dd * Hh * Ww
-        if self.overlap_small_wgrad and Nn * Dd * Hh * Ww <= cx.SIDE_MAX_VOXELS and self.debug is None:
+        if rec.sub is not None:
+            # weight gradient in two channel slices of the same (Cout, Ctot, 27) buffer: upsampled channels from the 64
+            # (parity class, tap half) matrices over the low-res grid, skip channels from the standard kernel
+            C0, C1 = rec.sub
+            Ct = src.C
+            dwv = gview(rec.idx_w)
+            nat.call("u3d_subpixel_conv_wgrad", dev.index, _stream(dev), _p(src.t1), _p(rec.affine.view(-1)[2 * C0:]), Ct * 2,
+                     _p(dz_), _p(dwv[C0 * 27:]), Ct, Nn, src.D1, src.H1, src.W1, C1, Cout, _p(ws), ws.numel(),
+                     flops=128.0 * C1 * Cout * Nn * src.D1 * src.H1 * src.W1)
+            a0 = rec.affine[:, :C0].contiguous()
+            s0 = VSrc(src.t0).struct(a0)
+            nat.call("u3d_conv3d_wgrad_strided", dev.index, _stream(dev), ctypes.byref(s0), _p(dz_), _p(dwv), Ct, Nn, Dd, Hh, Ww,
+                     Cout, _p(ws), ws.numel(), flops=54.0 * C0 * Cout * Nn * Dd * Hh * Ww)
+        elif self.overlap_small_wgrad and Nn * Dd * Hh * Ww <= cx.SIDE_MAX_VOXELS and self.debug is None:
             # small layer: neither kernel fills the chip on its own -> weight gradient on the side stream, data gradient
             # (below) on the caller's stream; joined before anything consumes the flat gradient buffer
             need = nat.get_lib().u3d_wgrad_workspace_floats(Nn, Dd, Hh, Ww, src.C, Cout)
@@ -517,8 +530,12 @@ class UNet3DEngine:
         lib = nat.get_lib()
         ws_floats = 0
         for r in tape.convs:
-            ws_floats = max(ws_floats, lib.u3d_wgrad_workspace_floats(r.src.N, r.src.D, r.src.H, r.src.W, r.src.C,
-                                                                      r.y.shape[-1]))
+            Nn, Co = r.src.N, r.y.shape[-1]
+            if r.sub is not None:  # skip slice + sub-pixel slice
+                ws_floats = max(ws_floats, lib.u3d_wgrad_workspace_floats(Nn, r.src.D, r.src.H, r.src.W, r.sub[0], Co),
+                                lib.u3d_subpixel_wgrad_workspace_floats(Nn, r.src.D1, r.src.H1, r.src.W1, r.sub[1], Co))
+            else:
+                ws_floats = max(ws_floats, lib.u3d_wgrad_workspace_floats(Nn, r.src.D, r.src.H, r.src.W, r.src.C, Co))
             if not r.small:  # split-K scratch of the data gradient (Cin and Cout swap roles)
                 ws_floats = max(ws_floats, lib.u3d_conv3d_workspace_floats(r.src.N, r.src.D, r.src.H, r.src.W, r.y.shape[-1],
                                                                            r.sub[0] if r.sub is not None else r.src.C))

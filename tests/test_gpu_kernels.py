@@ -314,6 +314,43 @@ def test_subpixel_conv_dgrad_to_low_res(N, C1, Cout, D1, H1, W1):
     assert U.relerr(gst.cpu(), s_ref) < 1e-5
 
 
+@pytest.mark.parametrize("N,C0,C1,Cout,D1,H1,W1,affine", [(2, 32, 64, 32, 4, 8, 8, True), (1, 16, 40, 48, 2, 4, 8, True),
+                                                           (1, 8, 24, 20, 3, 5, 6, False), (2, 4, 32, 32, 2, 4, 16, True)])
+def test_subpixel_conv_wgrad_and_strided_skip_half(N, C0, C1, Cout, D1, H1, W1, affine):
+    """weight gradient of conv3d(cat(skip, nearest2x(low))): upsampled channels from the 64 (class, tap-half) matrices over
+    the low-res grid (u3d_subpixel_conv_wgrad), skip channels from u3d_conv3d_wgrad_strided — both write their channel slice
+    of ONE (Cout, C0+C1, 3,3,3) gradient"""
+    U, nat, VSrc, _p, _stream = _mods()
+    torch.manual_seed(C1 + 7 * Cout + H1)
+    D, H, W = 2 * D1, 2 * H1, 2 * W1
+    Ctot = C0 + C1
+    skip = torch.randn(N, C0, D, H, W)
+    low = torch.randn(N, C1, D1, H1, W1)
+    dz = torch.randn(N, Cout, D, H, W)
+    ab = torch.randn(N, Ctot, 2) if affine else torch.stack([torch.ones(N, Ctot), torch.zeros(N, Ctot)], dim=-1)
+    cat = torch.cat((skip, F.interpolate(low, size=(D, H, W), mode="nearest")), dim=1)
+    g = cat * ab[:, :, 0].view(N, Ctot, 1, 1, 1) + ab[:, :, 1].view(N, Ctot, 1, 1, 1)
+    wl = torch.zeros(Cout, Ctot, 3, 3, 3, requires_grad=True)
+    F.conv3d(g, wl, None, padding=1).backward(dz)
+    ref = wl.grad
+    lib = nat.get_lib()
+    abd = ab.contiguous().to(U.DEV)
+    dzd = U.ndhwc(dz)
+    dw = torch.full((Cout, Ctot, 3, 3, 3), float("nan"), dtype=torch.float32, device=U.DEV)
+    nws = max(lib.u3d_subpixel_wgrad_workspace_floats(N, D1, H1, W1, C1, Cout), lib.u3d_wgrad_workspace_floats(N, D, H, W, C0, Cout))
+    ws = torch.empty(nws, dtype=torch.float32, device=U.DEV)
+    aff_sub = abd.view(-1)[2 * C0:] if affine else None
+    nat.call("u3d_subpixel_conv_wgrad", 0, _stream(U.DEV), _p(U.ndhwc(low)), _p(aff_sub), Ctot * 2, _p(dzd), _p(dw.view(-1)[C0 * 27:]),
+             Ctot, N, D1, H1, W1, C1, Cout, _p(ws), nws)
+    a0 = abd[:, :C0].contiguous() if affine else None
+    s0 = VSrc(U.ndhwc(skip)).struct(a0)
+    nat.call("u3d_conv3d_wgrad_strided", 0, _stream(U.DEV), ctypes.byref(s0), _p(dzd), _p(dw), Ctot, N, D, H, W, Cout, _p(ws), nws)
+    got = dw.cpu()
+    assert torch.isfinite(got).all()
+    assert U.relerr(got[:, C0:], ref[:, C0:]) < 1e-4
+    assert U.relerr(got[:, :C0], ref[:, :C0]) < 1e-4
+
+
 DGRAD_CASES = [(1, 16, 32, 8, 16, 16), (2, 32, 64, 9, 13, 11), (1, 1, 16, 8, 16, 16), (1, 96, 32, 4, 8, 8), (1, 3, 8, 5, 9, 7),
                # <= 16 output channels of the data gradient, aligned dims: the paired-y variant (several tiles / samples)
                (2, 16, 32, 8, 16, 32), (1, 8, 16, 4, 8, 8), (1, 12, 24, 8, 24, 16)]

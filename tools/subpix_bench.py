@@ -73,6 +73,20 @@ def main():
                                        H1, W1, C1, Cout), args.iters)
         f_dg = 2.0 * 64 * C1 * Cout * N * D1 * H1 * W1
         print(f"{name} dgrad(low) {ms_c:.3f} ms ({f_dg / ms_c / 1e9:.1f} TF executed)", flush=True)
+        # (d) weight gradient: full virtual source vs skip slice + sub-pixel slice
+        nws = max(lib.u3d_wgrad_workspace_floats(N, D, H, W, Cin, Cout), lib.u3d_subpixel_wgrad_workspace_floats(N, D1, H1, W1, C1, Cout))
+        ws = torch.empty(nws, device=dev)
+        dw = torch.empty((Cout, Cin, 3, 3, 3), device=dev)
+        ms_w = timeit(lambda: nat.call("u3d_conv3d_wgrad", 0, _stream(dev), ctypes.byref(s), _p(dz), _p(dw), N, D, H, W, Cout, _p(ws),
+                                       nws), args.iters)
+        dw_ref = dw.clone()
+        ms_w1 = timeit(lambda: nat.call("u3d_subpixel_conv_wgrad", 0, _stream(dev), _p(t1), _p(aff_sub), Cin * 2, _p(dz),
+                                        _p(dw.view(-1)[C0 * 27:]), Cin, N, D1, H1, W1, C1, Cout, _p(ws), nws), args.iters)
+        ms_w0 = timeit(lambda: nat.call("u3d_conv3d_wgrad_strided", 0, _stream(dev), ctypes.byref(s0), _p(dz), _p(dw), Cin, N, D, H, W,
+                                        Cout, _p(ws), nws), args.iters)
+        werr = ((dw - dw_ref).abs().max() / dw_ref.abs().max()).item()
+        print(f"{name} wgrad: one kernel {ms_w:.3f} ms | subpixel {ms_w1:.3f} ms ({f_dg / ms_w1 / 1e9:.1f} TF executed) + skip slice "
+              f"{ms_w0:.3f} ms = {ms_w1 + ms_w0:.3f} ms, max rel diff {werr:.2e}", flush=True)
         err = ((y - ya).abs().max() / ya.abs().max()).item()
         f_sub = 2.0 * 64 * C1 * Cout * N * D1 * H1 * W1  # executed: 8 classes x 8 taps per low-res voxel
         print(f"{name} {C0}+{C1}->{Cout}: one kernel {ms_a:.3f} ms ({flops / ms_a / 1e9:.1f} TF algorithmic) | subpixel {ms_b1:.3f} ms "
