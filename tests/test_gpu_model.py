@@ -320,3 +320,36 @@ def test_eval_no_grad_on_residual_variants_saves_no_tape():
     model.train()
     y2, logits = model(x, return_logits=True)
     assert torch.allclose(y2.detach(), y, atol=1e-6) and logits.requires_grad
+
+
+def test_subpixel_decoder_path_agrees_with_virtual_concat_path():
+    """The decoder first convs run the upsampled half as sub-pixel convolutions over the low-res tensor (8/27 of the
+    multiply-adds, csrc/u3d_subpix.hip) whenever the upsampling is an exact 2x; with the path switched off the same layers
+    run the one-kernel virtual-concat convolution.  Same loss, same parameter gradients (fp32 association only), and the
+    path really is taken / not taken."""
+    from pytorch3dunet_amd import _native as nat
+
+    cfg = dict(in_channels=1, out_channels=2, f_maps=16, layer_order="gcr", num_groups=4, final_sigmoid=True, num_levels=3)
+    torch.manual_seed(5)
+    model = _make(cfg)
+    x = torch.randn(2, 1, 16, 24, 32)
+    target = (torch.rand(2, 2, 16, 24, 32) > 0.5).float()
+    engine = model.to(torch.device("cuda", 0))._get_engine()
+    res = {}
+    for on in (True, False):
+        engine.subpixel = on
+        prof = nat.EventProfiler()
+        nat.profiler = prof
+        try:
+            res[on] = _run_native(model, x, target, "bce_dice")
+        finally:
+            nat.profiler = None
+        names = set(prof.summary())
+        assert ("u3d_subpixel_conv_fwd" in names) == on and ("u3d_subpixel_conv_wgrad" in names) == on
+    engine.subpixel = True
+    (p1, l1, loss1, g1), (p0, l0, loss0, g0) = res[True], res[False]
+    assert abs(loss1 - loss0) < 1e-5 * max(1.0, abs(loss0))
+    assert (l1 - l0).abs().max().item() < 1e-4 * l0.abs().max().item()
+    for k in g0:
+        scale = g0[k].abs().max().item() + 1e-12
+        assert (g1[k] - g0[k]).abs().max().item() < 2e-4 * scale, k

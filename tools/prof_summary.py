@@ -43,7 +43,7 @@ def pmc(d):
                 ndisp[k].add((f, row.get("Dispatch_Id") or row.get("dispatch_id")))
     print(f"# rocprofv3 --pmc summary ({d}); counter sums over all dispatches of a kernel\n")
     for k in sorted(agg, key=lambda k: -agg[k].get("SQ_WAVE_CYCLES", agg[k].get("GRBM_GUI_ACTIVE", 0))):
-        if not any(s in k for s in ("conv3d", "wgrad", "head_", "chan_stats", "gn_", "maxpool")):
+        if not any(s in k for s in ("conv3d", "wgrad", "subpixel", "head_", "chan_stats", "gn_", "maxpool")):
             continue
         print(f"## `{k[:100]}`  ({len(ndisp[k])} dispatch records)")
         for c, v in sorted(agg[k].items()):

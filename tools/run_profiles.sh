@@ -1,0 +1,22 @@
+#!/bin/bash
+# The measurement set committed under profiles/: bench line, rocprofv3 kernel stats, HBM traffic (separate --pmc passes) and
+# SQ counters of the same command.  Run from the repo root on the GPU box:  bash tools/run_profiles.sh <tag>
+set -u
+tag=${1:-rXX}
+out=gpurun_out/$tag
+mkdir -p $out
+export TMPDIR=/tmp
+B="python bench.py --no-cpu-baseline --no-roofline"
+python bench.py > $out/bench.json.log 2> $out/bench.err
+timeout 300 rocprofv3 --kernel-trace --stats -d $out/stats -- $B --steps 3 --warmup 3 > $out/stats.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- $B --steps 2 --warmup 1 > $out/fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- $B --steps 2 --warmup 1 > $out/write.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE \
+    --output-format csv -d $out/sq -- $B --steps 2 --warmup 1 > $out/sq.log 2>&1
+db=$(find $out/stats -name "*.db" | head -1)
+python tools/prof_summary.py stats "$db" 6 > $out/${tag}_bench_kernel_stats.md
+python tools/prof_summary.py traffic $out/fetch $out/write 3 > $out/${tag}_pmc_traffic.json
+python tools/prof_summary.py pmc $out/sq > $out/${tag}_pmc_sq.md
+cp $out/bench.json.log $out/${tag}_bench.json.log
+rm -rf $out/stats $out/fetch $out/write $out/sq
+tail -1 $out/bench.json.log | cut -c1-400
