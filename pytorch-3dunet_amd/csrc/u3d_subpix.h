@@ -44,6 +44,26 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// fragment f of a chunk -> (k-step, index of the class within the step), as a compile-time table
+struct FragTab {
+    unsigned char st[NFRAG], i[NFRAG];
+};
+constexpr FragTab make_frag_tab() {
+    FragTab t{};
+    int f = 0;
+    for (int st = 0; st < NSTEP; ++st)
+        for (int i = 0; i < ncls(st >> 1); ++i) {
+            t.st[f] = (unsigned char)st;
+            t.i[f] = (unsigned char)i;
+            ++f;
+        }
+    return t;
+}
+__device__ __forceinline__ const FragTab& frag_tab() {
+    static constexpr FragTab tab = make_frag_tab();
+    return tab;
+}
+
 // ---- weight packing: f32x4 index (((ch*128 + f)*ncb + cb)*64 + lane), element j; fragment f = (k-step st, i-th class of
 // the step's halo offset); k-channel = ch*16 + 8*(st&1) + 4*(lane>>5) + j, n-channel = cb*32 + (lane&31); the value is the
 // SUM of the original taps of that class which read this low-res voxel.  `w` points at the first packed input channel of
@@ -62,12 +82,9 @@ __device__ __forceinline__ float pack_elem(const float* __restrict__ w, int Cout
     const int f = (int)(r % NFRAG);
     const int ch = (int)(r / NFRAG);
     if (ch >= nchunks) return 0.f;  // the trailing zero fragments
-    int st = 0, pre = 0;
-    while (pre + ncls(st >> 1) <= f) {
-        pre += ncls(st >> 1);
-        ++st;
-    }
-    const int tap = st >> 1, ci = cls(tap, f - pre);
+    const FragTab& ft = frag_tab();
+    const int st = ft.st[f];
+    const int tap = st >> 1, ci = cls(tap, ft.i[f]);
     const int kc = ch * 16 + 8 * (st & 1) + 4 * (lane >> 5) + j;
     const int nc = cb * 32 + (lane & 31);
     if (kc >= C1 || nc >= Cout) return 0.f;
