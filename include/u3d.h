@@ -295,6 +295,13 @@ int u3d_conv1x1_bwd(int device, u3d_stream_t stream, const float* dy, const floa
 int u3d_pack_convtr_weights(int device, u3d_stream_t stream, const float* w, int Cin, int Cout, int mode, float* packed);
 int u3d_convtr3d_fwd(int device, u3d_stream_t stream, const float* x, const float* w, float* t, int N, int D1, int H1,
                      int W1, int Cin, int Cout, const float* packed);
+/* The same forward on the sub-pixel MFMA kernel (csrc/u3d_subpix.hip): the 8 output parity classes (1/2/4/8 single taps each)
+ * are accumulated from ONE staged input halo tile.  Cin % 4 == Cout % 4 == 0; packed = u3d_pack_convtr3d_subpixel image
+ * (u3d_convtr3d_subpixel_packed_floats floats). */
+long long u3d_convtr3d_subpixel_packed_floats(int Cin, int Cout);
+int u3d_pack_convtr3d_subpixel(int device, u3d_stream_t stream, const float* w, int Cin, int Cout, float* packed);
+int u3d_convtr3d_fwd_subpixel(int device, u3d_stream_t stream, const float* x, const float* packed, float* t, int N, int D1,
+                              int H1, int W1, int Cin, int Cout);
 int u3d_convtr3d_bwd(int device, u3d_stream_t stream, const float* dt, const float* x, const float* w, int N, int D1,
                      int H1, int W1, int Cin, int Cout, int relu_mask, float* dx, double* acc, const float* packed_t);
 /* F.interpolate(t, size=skip.shape[2:]) (nearest, buildingblocks.py:650-651) + summation joining (:493):

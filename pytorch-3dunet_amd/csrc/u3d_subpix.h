@@ -15,26 +15,64 @@ constexpr int TILE_FLOATS = HZ * PS + 4;
 constexpr int NITEMS = HZ * HY * HX * (CC / 4);  // 1440 float4 items per chunk
 constexpr int NIT = (NITEMS + 255) / 256;        // 6
 constexpr int NSTEP = 54;
-constexpr int NFRAG = 128;   // B fragments per chunk = sum over steps of the classes using the step's offset
-constexpr int RING = 8;      // B ring slots; fragments are fetched RING-1 ahead (NFRAG % RING == 0)
-constexpr int PACK_PAD = 8;  // zero fragments appended to the packed image (fetch overrun)
-constexpr int ST0 = 30;      // k-step of the first halo store into the other buffer
+constexpr int PACK_PAD = 9;  // zero fragments appended to the packed image (fetch overrun, >= RING)
 
-__host__ __device__ constexpr int ncls1(int h) { return h == 1 ? 2 : 1; }
-__host__ __device__ constexpr int cls1(int h, int i) { return h == 0 ? 0 : (h == 2 ? 1 : i); }
-__host__ __device__ constexpr int ncls(int tap) { return ncls1(tap / 9) * ncls1((tap / 3) % 3) * ncls1(tap % 3); }
-// i-th class (pz*4 + py*2 + px) using halo offset `tap`
-__host__ __device__ constexpr int cls(int tap, int i) {
-    const int ny = ncls1((tap / 3) % 3), nx = ncls1(tap % 3);
-    const int ix = i % nx, iy = (i / nx) % ny, iz = i / (nx * ny);
-    return cls1(tap / 9, iz) * 4 + cls1((tap / 3) % 3, iy) * 2 + cls1(tap % 3, ix);
-}
-__host__ __device__ constexpr int prefix(int st) {  // fragments of a chunk before k-step st
-    int s = 0;
-    for (int k = 0; k < st; ++k) s += ncls(k >> 1);
-    return s;
-}
-static_assert(prefix(NSTEP) == NFRAG, "fragment count");
+// Which output parity classes use which halo offset h (0,1,2 = low-res offset -1,0,+1), per dimension.
+//   Nearest2x: conv3x3x3 over a nearest-2x-upsampled tensor — parity 0 reads offsets {-1,0}, parity 1 reads {0,+1}.
+//   Deconv3s2: ConvTranspose3d(k=3, stride=2, padding=1) (buildingblocks.py:653-662) — output 2j reads input j (tap 1),
+//              output 2j+1 reads inputs j (tap 2) and j+1 (tap 0); offset -1 is never used.
+struct Nearest2x {
+    static constexpr int RING = 8;  // B ring slots; fragments are fetched RING-1 ahead (NFRAG % RING == 0)
+    __host__ __device__ static constexpr int ncls1(int h) { return h == 1 ? 2 : 1; }
+    __host__ __device__ static constexpr int cls1(int h, int i) { return h == 0 ? 0 : (h == 2 ? 1 : i); }
+};
+struct Deconv3s2 {
+    static constexpr int RING = 9;
+    __host__ __device__ static constexpr int ncls1(int h) { return h == 0 ? 0 : (h == 1 ? 2 : 1); }
+    __host__ __device__ static constexpr int cls1(int h, int i) { return h == 1 ? i : 1; }
+};
+template <class S>
+struct Sch {
+    __host__ __device__ static constexpr int ncls(int tap) {
+        return S::ncls1(tap / 9) * S::ncls1((tap / 3) % 3) * S::ncls1(tap % 3);
+    }
+    // i-th class (pz*4 + py*2 + px) using halo offset `tap`
+    __host__ __device__ static constexpr int cls(int tap, int i) {
+        const int ny = S::ncls1((tap / 3) % 3), nx = S::ncls1(tap % 3);
+        const int ix = i % nx, iy = (i / nx) % ny, iz = i / (nx * ny);
+        return S::cls1(tap / 9, iz) * 4 + S::cls1((tap / 3) % 3, iy) * 2 + S::cls1(tap % 3, ix);
+    }
+    __host__ __device__ static constexpr int prefix(int st) {  // fragments of a chunk before k-step st
+        int s = 0;
+        for (int k = 0; k < st; ++k) s += ncls(k >> 1);
+        return s;
+    }
+    __host__ __device__ static constexpr int nact() {  // k-steps with at least one class
+        int n = 0;
+        for (int st = 0; st < NSTEP; ++st) n += ncls(st >> 1) > 0 ? 1 : 0;
+        return n;
+    }
+    __host__ __device__ static constexpr int act(int k) {  // the k-th such step
+        int n = 0;
+        for (int st = 0; st < NSTEP; ++st)
+            if (ncls(st >> 1) > 0) {
+                if (n == k) return st;
+                ++n;
+            }
+        return NSTEP;
+    }
+};
+template <class S>
+constexpr int NFRAG_OF = Sch<S>::prefix(NSTEP);  // B fragments per chunk
+template <class S>
+constexpr int NACT_OF = Sch<S>::nact();
+constexpr int NFRAG = NFRAG_OF<Nearest2x>;  // 128
+constexpr int RING = Nearest2x::RING;
+static_assert(NFRAG == 128 && NFRAG % RING == 0, "fragment count");
+static_assert(NFRAG_OF<Deconv3s2> == 54 && NFRAG_OF<Deconv3s2> % Deconv3s2::RING == 0 && NACT_OF<Deconv3s2> == 16, "deconv scheme");
+__host__ __device__ constexpr int ncls(int tap) { return Sch<Nearest2x>::ncls(tap); }
+__host__ __device__ constexpr int cls(int tap, int i) { return Sch<Nearest2x>::cls(tap, i); }
+__host__ __device__ constexpr int prefix(int st) { return Sch<Nearest2x>::prefix(st); }
 
 template <int B, int E, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -45,22 +83,29 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // fragment f of a chunk -> (k-step, index of the class within the step), as a compile-time table
-struct FragTab {
-    unsigned char st[NFRAG], i[NFRAG];
+template <class S>
+struct FragTabT {
+    unsigned char st[NFRAG_OF<S>], i[NFRAG_OF<S>];
 };
-constexpr FragTab make_frag_tab() {
-    FragTab t{};
+template <class S>
+constexpr FragTabT<S> make_frag_tab() {
+    FragTabT<S> t{};
     int f = 0;
     for (int st = 0; st < NSTEP; ++st)
-        for (int i = 0; i < ncls(st >> 1); ++i) {
+        for (int i = 0; i < Sch<S>::ncls(st >> 1); ++i) {
             t.st[f] = (unsigned char)st;
             t.i[f] = (unsigned char)i;
             ++f;
         }
     return t;
 }
+using FragTab = FragTabT<Nearest2x>;
 __device__ __forceinline__ const FragTab& frag_tab() {
-    static constexpr FragTab tab = make_frag_tab();
+    static constexpr FragTab tab = make_frag_tab<Nearest2x>();
+    return tab;
+}
+__device__ __forceinline__ const FragTabT<Deconv3s2>& frag_tab_deconv() {
+    static constexpr FragTabT<Deconv3s2> tab = make_frag_tab<Deconv3s2>();
     return tab;
 }
 
@@ -106,6 +151,35 @@ __device__ __forceinline__ float pack_elem(const float* __restrict__ w, int Cout
         for (int b = 0; b < num[1]; ++b)
             for (int c = 0; c < num[2]; ++c) v += wr[((lo[0] + a) * 3 + lo[1] + b) * 3 + lo[2] + c];
     return v;
+}
+
+// ConvTranspose3d(k=3, s=2, p=1) weight (Cin, Cout, 3,3,3) in the same fragment layout (54 fragments per chunk): every (class,
+// offset) pair is a single tap — per dimension (parity 0, offset 0) -> tap 1, (1, 0) -> tap 2, (1, +1) -> tap 0.
+__host__ __device__ inline long long packed_floats_deconv(int Cin, int Cout) {
+    return ((long long)((Cin + 15) / 16) * NFRAG_OF<Deconv3s2> + PACK_PAD) * ((Cout + 31) / 32) * 256;
+}
+__device__ __forceinline__ float pack_elem_deconv(const float* __restrict__ w, int Cin, int Cout, int nchunks, int ncb,
+                                                  long long idx) {
+    constexpr int NF = NFRAG_OF<Deconv3s2>;
+    const int j = (int)(idx & 3);
+    const int lane = (int)((idx >> 2) & 63);
+    long long r = idx >> 8;
+    const int cb = (int)(r % ncb);
+    r /= ncb;
+    const int f = (int)(r % NF);
+    const int ch = (int)(r / NF);
+    if (ch >= nchunks) return 0.f;
+    const FragTabT<Deconv3s2>& ft = frag_tab_deconv();
+    const int st = ft.st[f];
+    const int tap = st >> 1, ci = Sch<Deconv3s2>::cls(tap, ft.i[f]);
+    const int kc = ch * 16 + 8 * (st & 1) + 4 * (lane >> 5) + j;
+    const int nc = cb * 32 + (lane & 31);
+    if (kc >= Cin || nc >= Cout) return 0.f;
+    const int hh[3] = {tap / 9, (tap / 3) % 3, tap % 3};
+    const int pp[3] = {ci >> 2, (ci >> 1) & 1, ci & 1};
+    int t3[3];
+    for (int d = 0; d < 3; ++d) t3[d] = pp[d] == 0 ? 1 : (hh[d] == 1 ? 2 : 0);
+    return w[((size_t)kc * Cout + nc) * 27 + (t3[0] * 3 + t3[1]) * 3 + t3[2]];
 }
 }  // namespace sp
 

@@ -28,8 +28,8 @@ struct SubpixParams {
     const float* affine;  // optional GroupNorm (a,b) rows of the C1 channels: affine[n * aff_nstride + 2*c]
     long long aff_nstride;
     const float* wp;
-    float* out;           // (N, 2*D1, 2*H1, 2*W1, Cout)
-    int N, D1, H1, W1, C1, Cout;
+    float* out;           // (N, Do, Ho, Wo, Cout): 2*D1.. (nearest upsampling) or 2*D1-1.. (transposed convolution)
+    int N, D1, H1, W1, C1, Cout, Do, Ho, Wo;
     int tz, ty, tx, nchunks, ncb;
 };
 
@@ -43,8 +43,16 @@ __device__ __forceinline__ void sp_flag_wait(int* c, int target) {
     asm volatile("" ::: "memory");
 }
 
+template <class S>
 __global__ __launch_bounds__(256, 2) void subpixel_fwd_kernel(const SubpixParams p) {
     using namespace sp;
+    using SC = Sch<S>;
+    constexpr int NFRAG = NFRAG_OF<S>, RING = S::RING, NACT = NACT_OF<S>;
+    // prefetch schedule in units of ACTIVE k-steps: halo loads early, halo stores late, affine rows a few steps before
+    constexpr int LE = NACT >= 2 * NIT + 8 ? 2 : 1;
+    constexpr int KS0 = NACT >= 40 ? 30 : NACT - NIT - 1;
+    constexpr int KA = KS0 >= 6 ? KS0 - 6 : 0;
+    static_assert(LE * (NIT - 1) < KS0 && KS0 + NIT <= NACT, "prefetch schedule must fit the k-loop");
     __shared__ __attribute__((aligned(16))) float lds[2 * TILE_FLOATS];
     __shared__ int cnt[16];  // [0,1] full[buf], [2,3] freed[buf]
     const int t = threadIdx.x;
@@ -155,43 +163,49 @@ __global__ __launch_bounds__(256, 2) void subpixel_fwd_kernel(const SubpixParams
         __builtin_amdgcn_s_setprio(0);
 
         f32x4 aq[2];
-        aq[0] = *reinterpret_cast<const f32x4*>(&cur[abase]);
+        {
+            constexpr int st0 = SC::act(0);
+            constexpr int aoff0 = ((st0 >> 1) / 9) * PS + (((st0 >> 1) / 3) % 3) * RS + ((st0 >> 1) % 3) * CS + 8 * (st0 & 1);
+            aq[0] = *reinterpret_cast<const f32x4*>(&cur[abase + aoff0]);
+        }
         const f32x4* wch = wq + ((size_t)ch * NFRAG + RING - 1) * wstep;  // fragment (chunk, f) + RING-1
-        static_for<0, NSTEP>([&](auto ic) {
-            constexpr int st = decltype(ic)::value;
+        static_for<0, NACT>([&](auto ic) {
+            constexpr int k = decltype(ic)::value;
+            constexpr int st = SC::act(k);
             constexpr int tap = st >> 1;
-            constexpr int NC = ncls(tap);
-            constexpr int pre = prefix(st);
-            if constexpr (st % 2 == 0 && st / 2 < NIT) v[st / 2] = halo_load(cn, st / 2);
-            if constexpr (st == ST0 - 6) load_affine_rows(cn);
+            constexpr int NC = SC::ncls(tap);
+            constexpr int pre = SC::prefix(st);
+            if constexpr (k % LE == 0 && k / LE < NIT) v[k / LE] = halo_load(cn, k / LE);
+            if constexpr (k == KA) load_affine_rows(cn);
             static_for<0, NC>([&](auto ii) {
                 constexpr int i = decltype(ii)::value;
                 constexpr int f = pre + i;
-                constexpr int ci = cls(tap, i);
+                constexpr int ci = SC::cls(tap, i);
                 bq[(f + RING - 1) % RING] = wch[(size_t)f * wstep + l];
                 __builtin_amdgcn_sched_barrier(0);
-                acc[ci] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st & 1][0], bq[f % RING][0], acc[ci], 0, 0, 0);
-                acc[ci] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st & 1][1], bq[f % RING][1], acc[ci], 0, 0, 0);
+                acc[ci] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[k & 1][0], bq[f % RING][0], acc[ci], 0, 0, 0);
+                acc[ci] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[k & 1][1], bq[f % RING][1], acc[ci], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (i == 0) {
                     // the non-MFMA work of the step issues while the MFMA pipe is busy with the two above
-                    if constexpr (st + 1 < NSTEP) {
-                        constexpr int tap1 = (st + 1) >> 1, s1 = (st + 1) & 1;
+                    if constexpr (k + 1 < NACT) {
+                        constexpr int st1 = SC::act(k + 1);
+                        constexpr int tap1 = st1 >> 1, s1 = st1 & 1;
                         constexpr int aoff = (tap1 / 9) * PS + ((tap1 / 3) % 3) * RS + (tap1 % 3) * CS + 8 * s1;
-                        aq[(st + 1) & 1] = *reinterpret_cast<const f32x4*>(&cur[abase + aoff]);
+                        aq[(k + 1) & 1] = *reinterpret_cast<const f32x4*>(&cur[abase + aoff]);
                     }
-                    if constexpr (st >= ST0 && st < ST0 + NIT) {
+                    if constexpr (k >= KS0 && k < KS0 + NIT) {
                         if (has_next) {
                             // the other buffer is free once all four waves have finished the k-loop of chunk ch-1
-                            if constexpr (st == ST0) sp_flag_wait(&cnt[2 + (b ^ 1)], 4 * ((ch + 1) / 2));
-                            halo_store(nxt, cn, st - ST0, v[st - ST0]);
-                            if constexpr (st == ST0 + NIT - 1) sp_flag_signal(&cnt[b ^ 1], l);
+                            if constexpr (k == KS0) sp_flag_wait(&cnt[2 + (b ^ 1)], 4 * ((ch + 1) / 2));
+                            halo_store(nxt, cn, k - KS0, v[k - KS0]);
+                            if constexpr (k == KS0 + NIT - 1) sp_flag_signal(&cnt[b ^ 1], l);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                acc[ci] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st & 1][2], bq[f % RING][2], acc[ci], 0, 0, 0);
-                acc[ci] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[st & 1][3], bq[f % RING][3], acc[ci], 0, 0, 0);
+                acc[ci] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[k & 1][2], bq[f % RING][2], acc[ci], 0, 0, 0);
+                acc[ci] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[k & 1][3], bq[f % RING][3], acc[ci], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
@@ -212,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void subpixel_fwd_kernel(const SubpixParams
     const int co = cb * 32 + 4 * cq;
     const bool cok = co < p.Cout;
     const int z = z0 + w, x = x0 + vl;
-    const int D = 2 * D1, H = 2 * H1, W = 2 * W1;
+    const int D = p.Do, H = p.Ho, W = p.Wo;
     static_for<0, 8>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
         constexpr int pz = c >> 2, py = (c >> 1) & 1, px = c & 1;
@@ -224,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void subpixel_fwd_kernel(const SubpixParams
             const float u0 = xlane(c2, X2{}), u2 = xlane(c0, X2{}), u1 = xlane(c3, X2{}), u3 = xlane(c1, X2{});
             const f32x4 val = {hi2 ? u0 : c0, hi2 ? u1 : c1, hi2 ? c2 : u2, hi2 ? c3 : u3};
             const int y = y0 + bi;
-            if (cok && z < D1 && y < H1 && x < W1) {
+            if (cok && 2 * z + pz < D && 2 * y + py < H && 2 * x + px < W) {
                 const size_t vidx = ((size_t)(n * D + 2 * z + pz) * H + 2 * y + py) * W + 2 * x + px;
                 *reinterpret_cast<f32x4*>(p.out + vidx * p.Cout + co) = val;
             }
@@ -695,11 +709,61 @@ extern "C" int u3d_subpixel_conv_fwd(int device, u3d_stream_t stream, const floa
     SubpixParams p;
     p.low = low, p.affine = affine, p.aff_nstride = affine_sample_stride, p.wp = packed, p.out = out;
     p.N = N, p.D1 = D1, p.H1 = H1, p.W1 = W1, p.C1 = C1, p.Cout = Cout;
+    p.Do = 2 * D1, p.Ho = 2 * H1, p.Wo = 2 * W1;
     p.tz = sp_cdiv(D1, sp::TZ), p.ty = sp_cdiv(H1, sp::TY), p.tx = sp_cdiv(W1, sp::TX);
     p.nchunks = sp_cdiv(C1, 16), p.ncb = sp_cdiv(Cout, 32);
     const long long nblk = (long long)N * p.tz * p.ty * p.tx * p.ncb;
     U3D_REQUIRE(nblk < (1ll << 31), "u3d_subpixel_conv_fwd: grid too large");
-    hipLaunchKernelGGL(subpixel_fwd_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(subpixel_fwd_kernel<sp::Nearest2x>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- ConvTranspose3d(k=3, stride=2, padding=1, bias=False) forward on the same kernel (scheme Deconv3s2): 8 parity classes
+// with 1/2/4/8 single taps each — exactly 27*Cin*Cout multiply-adds per input voxel, no zero-stuffed work.
+__global__ void pack_deconv_subpixel_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin, int Cout, int nchunks,
+                                            int ncb, long long total) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x)
+        out[idx] = sp::pack_elem_deconv(w, Cin, Cout, nchunks, ncb, idx);
+}
+
+extern "C" long long u3d_convtr3d_subpixel_packed_floats(int Cin, int Cout) {
+    if (Cin <= 0 || Cout <= 0) return 0;
+    return sp::packed_floats_deconv(Cin, Cout);
+}
+
+extern "C" int u3d_pack_convtr3d_subpixel(int device, u3d_stream_t stream, const float* w, int Cin, int Cout, float* packed) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(w && packed && Cin > 0 && Cout > 0, "u3d_pack_convtr3d_subpixel: bad argument");
+    const long long total = sp::packed_floats_deconv(Cin, Cout);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_deconv_subpixel_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cin,
+                       Cout, sp_cdiv(Cin, 16), sp_cdiv(Cout, 32), total);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int u3d_convtr3d_fwd_subpixel(int device, u3d_stream_t stream, const float* x, const float* packed, float* t, int N,
+                                         int D1, int H1, int W1, int Cin, int Cout) {
+    if (int e = u3d_enter(device)) return e;
+    U3D_REQUIRE(x && packed && t && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && Cin > 0 && Cout > 0,
+                "u3d_convtr3d_fwd_subpixel: bad argument");
+    U3D_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "u3d_convtr3d_fwd_subpixel: Cin and Cout must be multiples of 4 (got %d,%d)",
+                Cin, Cout);
+    U3D_REQUIRE((((uintptr_t)x | (uintptr_t)packed | (uintptr_t)t) & 15) == 0,
+                "u3d_convtr3d_fwd_subpixel: pointers must be 16-byte aligned");
+    U3D_REQUIRE((long long)N * D1 * H1 * W1 * 8 < (1ll << 31), "u3d_convtr3d_fwd_subpixel: volume too large");
+    SubpixParams p;
+    p.low = x, p.affine = nullptr, p.aff_nstride = 0, p.wp = packed, p.out = t;
+    p.N = N, p.D1 = D1, p.H1 = H1, p.W1 = W1, p.C1 = Cin, p.Cout = Cout;
+    p.Do = 2 * D1 - 1, p.Ho = 2 * H1 - 1, p.Wo = 2 * W1 - 1;
+    p.tz = sp_cdiv(D1, sp::TZ), p.ty = sp_cdiv(H1, sp::TY), p.tx = sp_cdiv(W1, sp::TX);
+    p.nchunks = sp_cdiv(Cin, 16), p.ncb = sp_cdiv(Cout, 32);
+    const long long nblk = (long long)N * p.tz * p.ty * p.tx * p.ncb;
+    U3D_REQUIRE(nblk < (1ll << 31), "u3d_convtr3d_fwd_subpixel: grid too large");
+    hipLaunchKernelGGL(subpixel_fwd_kernel<sp::Deconv3s2>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
     U3D_LAUNCH_CHECK();
     return 0;
 }

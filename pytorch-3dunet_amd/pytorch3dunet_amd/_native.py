@@ -122,6 +122,11 @@ _PROTOS = {
         [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
          c_void_p, c_int64],
     ),
+    "u3d_convtr3d_subpixel_packed_floats": (c_int64, [c_int, c_int]),
+    "u3d_pack_convtr3d_subpixel": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "u3d_convtr3d_fwd_subpixel": (
+        c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int],
+    ),
     "u3d_subpixel_packed_floats": (c_int64, [c_int, c_int]),
     "u3d_subpixel_dgrad_packed_floats": (c_int64, [c_int, c_int]),
     "u3d_pack_subpixel_dgrad_weights": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -784,8 +784,12 @@ class ResUNetEngine(UNet3DEngine):
         if hit is not None and hit[0] == ver:
             return hit[1]
         Cin, Cout = w.shape[0], w.shape[1]
-        out = torch.empty(27 * Cin * Cout, dtype=_F32, device=dev)
-        nat.call("u3d_pack_convtr_weights", dev.index, _stream(dev), _p(w.detach()), Cin, Cout, mode, _p(out))
+        if mode == 2:  # fragment image of the sub-pixel forward kernel
+            out = torch.empty(nat.get_lib().u3d_convtr3d_subpixel_packed_floats(Cin, Cout), dtype=_F32, device=dev)
+            nat.call("u3d_pack_convtr3d_subpixel", dev.index, _stream(dev), _p(w.detach()), Cin, Cout, _p(out))
+        else:
+            out = torch.empty(27 * Cin * Cout, dtype=_F32, device=dev)
+            nat.call("u3d_pack_convtr_weights", dev.index, _stream(dev), _p(w.detach()), Cin, Cout, mode, _p(out))
         self._pack_cache[key] = (ver, out)
         return out
 
@@ -928,8 +932,13 @@ class ResUNetEngine(UNet3DEngine):
             _, Ds, Hs, Ws, Cs = sk.shape
             Dt, Ht, Wt = 2 * D1 - 1, 2 * H1 - 1, 2 * W1 - 1
             t = torch.empty((Nl, Dt, Ht, Wt, Cs), dtype=_F32, device=dev)
-            nat.call("u3d_convtr3d_fwd", dev.index, _stream(dev), _p(cur), _p(ct.weight.detach()), _p(t), Nl, D1, H1, W1, Cl, Cs,
-                     _p(self._packed_convtr(ct.weight, 0, dev)), flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
+            if self.subpixel and Cl % 4 == 0 and Cs % 4 == 0:
+                # 8 output parity classes accumulated from one staged input halo tile (csrc/u3d_subpix.hip, scheme Deconv3s2)
+                nat.call("u3d_convtr3d_fwd_subpixel", dev.index, _stream(dev), _p(cur), _p(self._packed_convtr(ct.weight, 2, dev)),
+                         _p(t), Nl, D1, H1, W1, Cl, Cs, flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
+            else:
+                nat.call("u3d_convtr3d_fwd", dev.index, _stream(dev), _p(cur), _p(ct.weight.detach()), _p(t), Nl, D1, H1, W1, Cl,
+                         Cs, _p(self._packed_convtr(ct.weight, 0, dev)), flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
             (mz, lz), (my, ly), (mx, lx) = _maps(dev, Dt, Ds), _maps(dev, Ht, Hs), _maps(dev, Wt, Ws)
             joined = torch.empty_like(sk)
             j_st = pool.take(Nl * Cs * 2)

@@ -74,6 +74,13 @@ def test_convtranspose3d_forward_backward(N, Cin, Cout, size, relu_mask):
     td2 = torch.empty_like(td)
     nat.call("u3d_convtr3d_fwd", 0, _stream(U.DEV), _p(xd), _p(wd), _p(td2), N, D1, H1, W1, Cin, Cout, _p(pk0))
     assert U.relerr(U.ncdhw(td2), t.detach()) < TOL
+    if Cin % 4 == 0 and Cout % 4 == 0:
+        # the sub-pixel MFMA forward: all 8 output parity classes from one staged input halo tile
+        pk2 = torch.empty(nat.get_lib().u3d_convtr3d_subpixel_packed_floats(Cin, Cout), device=U.DEV)
+        nat.call("u3d_pack_convtr3d_subpixel", 0, _stream(U.DEV), _p(wd), Cin, Cout, _p(pk2))
+        td3 = torch.full_like(td, float("nan"))
+        nat.call("u3d_convtr3d_fwd_subpixel", 0, _stream(U.DEV), _p(xd), _p(pk2), _p(td3), N, D1, H1, W1, Cin, Cout)
+        assert U.relerr(U.ncdhw(td3), t.detach()) < TOL
     dtd = U.ndhwc(dt)
     dx = torch.empty_like(xd)
     acc = torch.zeros(Cin * Cout * 27, dtype=torch.float64, device=U.DEV)
