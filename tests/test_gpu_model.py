@@ -350,6 +350,9 @@ def test_subpixel_decoder_path_agrees_with_virtual_concat_path():
     (p1, l1, loss1, g1), (p0, l0, loss0, g0) = res[True], res[False]
     assert abs(loss1 - loss0) < 1e-5 * max(1.0, abs(loss0))
     assert (l1 - l0).abs().max().item() < 1e-4 * l0.abs().max().item()
+    gmax = max(v.abs().max().item() for v in g0.values())
     for k in g0:
-        scale = g0[k].abs().max().item() + 1e-12
+        # relative to the tensor's own scale, with a floor for gradients that are pure cancellation noise (the first GroupNorm's
+        # gamma over a single normalised channel is ~1e-8)
+        scale = max(g0[k].abs().max().item(), 1e-3 * gmax)
         assert (g1[k] - g0[k]).abs().max().item() < 2e-4 * scale, k
