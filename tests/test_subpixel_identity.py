@@ -30,3 +30,24 @@ def test_presummed_kernels_preserve_the_tap_mass():
     assert len(ks) == 8
     for k in ks.values():
         assert k.sum().item() == 27.0
+
+
+def test_engine_selects_subpixel_layers_only_for_exact_2x_levels():
+    """host logic (no GPU): which decoder first convs take the sub-pixel path depends on the input size — every level
+    whose skip is exactly twice the low-res tensor, with channel counts divisible by 4"""
+    from pytorch3dunet_amd.engine import UNet3DEngine
+    from pytorch3dunet_amd.unet3d.model import UNet3D
+
+    model = UNet3D(in_channels=1, out_channels=1, f_maps=32, layer_order="gcr", num_groups=8, final_sigmoid=True)
+    eng = UNet3DEngine(model)
+    sub = eng._subpixel_layers((64, 128, 128))
+    w = {id(d.basic_module.SingleConv1.conv.weight): d.basic_module.SingleConv1.conv.weight for d in model.decoders}
+    assert set(sub) == set(w)
+    assert sorted(sub.values()) == [(32, 64), (64, 128), (128, 256)]  # (skip channels, upsampled channels)
+    # 20 -> 10 -> 5 -> 2: the deepest level is not an exact 2x (5 != 2*2), the other two are
+    sub = eng._subpixel_layers((20, 40, 40))
+    assert sorted(sub.values()) == [(32, 64), (64, 128)]
+    # odd input: no level qualifies
+    assert eng._subpixel_layers((9, 13, 11)) == {}
+    eng.subpixel = False
+    assert eng._subpixel_layers((64, 128, 128)) == {}
