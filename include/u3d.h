@@ -159,9 +159,12 @@ int u3d_subpixel_conv_dgrad(int device, u3d_stream_t stream, const float* dz, co
                             float* dlow, double* gstats, int N, int D1, int H1, int W1, int C1, int Cout);
 int u3d_pack_subpixel_weights(int device, u3d_stream_t stream, const float* w, int Cout, int Cin_total, int c_off, int C1,
                               float* packed);
+/*   workspace (optional, u3d_subpixel_fwd_workspace_floats() floats, 0 for shapes that never split): on small grids the
+ *     channel reduction is split over several blocks whose partial sums are added in a fixed order. */
+long long u3d_subpixel_fwd_workspace_floats(int N, int D1, int H1, int W1, int C1, int Cout);
 int u3d_subpixel_conv_fwd(int device, u3d_stream_t stream, const float* low, const float* affine,
                           long long affine_sample_stride, const float* packed, float* out, int N, int D1, int H1, int W1,
-                          int C1, int Cout);
+                          int C1, int Cout, float* workspace, long long workspace_floats);
 
 /* Weight gradient of the same convolution: dw[cout][cin][tap] = sum_{n,v} dz[n,v,cout] * g[n,v+tap,cin]
  * with g = src (GroupNorm affine fused on load, zero padded).  Split-K over voxel tiles with a

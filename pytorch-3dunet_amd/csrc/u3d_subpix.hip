@@ -31,6 +31,8 @@ struct SubpixParams {
     float* out;           // (N, Do, Ho, Wo, Cout): 2*D1.. (nearest upsampling) or 2*D1-1.. (transposed convolution)
     int N, D1, H1, W1, C1, Cout, Do, Ho, Wo;
     int tz, ty, tx, nchunks, ncb;
+    int ksplit, cps;        // split-K on small grids: ksplit blocks per (tile, channel block), each over a run of cps chunks,
+    long long part_stride;  // writing its partial sums to out + run * part_stride (summed by sum_partials_kernel)
 };
 
 __device__ __forceinline__ void sp_flag_signal(int* c, int lane) {
@@ -61,7 +63,14 @@ __global__ __launch_bounds__(256, 2) void subpixel_fwd_kernel(const SubpixParams
     if (t < 16) cnt[t] = 0;
     __syncthreads();  // the only rendezvous of the kernel
 
-    const int logical = u3d_xcd_remap(blockIdx.x, gridDim.x);
+    int logical = u3d_xcd_remap(blockIdx.x, gridDim.x);
+    int ch0 = 0, nch = p.nchunks;  // this block's run of chunks
+    float* const outp = p.out + (size_t)(p.ksplit > 1 ? logical % p.ksplit : 0) * p.part_stride;
+    if (p.ksplit > 1) {
+        ch0 = (logical % p.ksplit) * p.cps;
+        nch = min(p.cps, p.nchunks - ch0);
+        logical /= p.ksplit;
+    }
     const int cb = logical % p.ncb;
     int tile = logical / p.ncb;
     const int txi = tile % p.tx;
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void subpixel_fwd_kernel(const SubpixParams
     // A-fragment base: lane (m,h) -> low-res voxel (zl = w, yl = m>>3, xl = m&7), channels 4h..4h+3 of an octet
     const int abase = w * PS + (m >> 3) * RS + (m & 7) * CS + 4 * h;
     const int wstep = p.ncb * 64;
-    const f32x4* wq = reinterpret_cast<const f32x4*>(p.wp) + (size_t)cb * 64;  // uniform base; lanes add l
+    const f32x4* wq = reinterpret_cast<const f32x4*>(p.wp) + (size_t)cb * 64 + (size_t)ch0 * NFRAG * wstep;  // uniform
     f32x4 bq[RING];
 #pragma unroll
     for (int k = 0; k < RING - 1; ++k) bq[k] = wq[(size_t)k * wstep + l];
@@ -142,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void subpixel_fwd_kernel(const SubpixParams
 
     // ---- prologue: stage chunk 0 into buffer 0
     {
-        ChunkSrc c0 = chunk_src(0, true);
+        ChunkSrc c0 = chunk_src(ch0, true);
         load_affine_rows(c0);
         f32x4 v[NIT];
 #pragma unroll
@@ -152,12 +161,12 @@ __global__ __launch_bounds__(256, 2) void subpixel_fwd_kernel(const SubpixParams
     }
     sp_flag_signal(&cnt[0], l);
 
-    for (int ch = 0; ch < p.nchunks; ++ch) {
-        const bool has_next = ch + 1 < p.nchunks;
+    for (int ch = 0; ch < nch; ++ch) {  // ch counts within the block's run; the source chunk is ch0 + ch
+        const bool has_next = ch + 1 < nch;
         const int b = ch & 1;
         const float* cur = lds + b * TILE_FLOATS;
         float* nxt = lds + (b ^ 1) * TILE_FLOATS;
-        ChunkSrc cn = chunk_src(ch + 1, has_next);
+        ChunkSrc cn = chunk_src(ch0 + ch + 1, has_next);
         f32x4 v[NIT];
         sp_flag_wait(&cnt[b], 4 * (ch / 2 + 1));  // all four waves have staged chunk ch
         __builtin_amdgcn_s_setprio(0);
@@ -227,6 +236,26 @@ __global__ __launch_bounds__(256, 2) void subpixel_fwd_kernel(const SubpixParams
     const bool cok = co < p.Cout;
     const int z = z0 + w, x = x0 + vl;
     const int D = p.Do, H = p.Ho, W = p.Wo;
+    // Fast path (tile and channel block fully inside): store the accumulators in their native layout — lane (m, h) holds
+    // output channel m of voxel x = (r&3) + 4h, so one 4-byte store per register writes two full 128-byte channel rows.  The
+    // address is a UNIFORM base (scalar arithmetic) plus a per-lane constant: no VALU at all, against 4 VALU per value for
+    // the in-register transposition below (a VALU instruction issued beside another wave's MFMA stream waits ~45 cycles).
+    const bool full = 2 * (z0 + TZ) - 1 < D && 2 * (y0 + TY) - 1 < H && 2 * (x0 + TX) - 1 < W && cb * 32 + 32 <= p.Cout;
+    if (full) {
+        const int wz = __builtin_amdgcn_readfirstlane(z);
+        const int lane_off = 8 * h * p.Cout + m;  // x = x0 + (r&3) + 4h  ->  full-res 2x: 8h voxels further
+        static_for<0, 8>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int pz = c >> 2, py = (c >> 1) & 1, px = c & 1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const size_t vu = ((size_t)(n * D + 2 * wz + pz) * H + 2 * (y0 + (r >> 2)) + py) * W + 2 * (x0 + (r & 3)) + px;
+                float* ob = outp + vu * p.Cout + cb * 32;
+                ob[lane_off] = acc[c][r];
+            }
+        });
+        return;
+    }
     static_for<0, 8>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
         constexpr int pz = c >> 2, py = (c >> 1) & 1, px = c & 1;
@@ -240,10 +269,20 @@ __global__ __launch_bounds__(256, 2) void subpixel_fwd_kernel(const SubpixParams
             const int y = y0 + bi;
             if (cok && 2 * z + pz < D && 2 * y + py < H && 2 * x + px < W) {
                 const size_t vidx = ((size_t)(n * D + 2 * z + pz) * H + 2 * y + py) * W + 2 * x + px;
-                *reinterpret_cast<f32x4*>(p.out + vidx * p.Cout + co) = val;
+                *reinterpret_cast<f32x4*>(outp + vidx * p.Cout + co) = val;
             }
         }
     });
+}
+
+// out = sum of the split-K runs, in a fixed order
+__global__ void sum_partials_kernel(const float* __restrict__ part, long long stride, int ks, float* __restrict__ out,
+                                    long long n4) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        f32x4 a = reinterpret_cast<const f32x4*>(part)[i];
+        for (int k = 1; k < ks; ++k) a += reinterpret_cast<const f32x4*>(part + (size_t)k * stride)[i];
+        reinterpret_cast<f32x4*>(out)[i] = a;
+    }
 }
 
 // =================================================================================================================
@@ -694,9 +733,29 @@ extern "C" int u3d_pack_subpixel_weights(int device, u3d_stream_t stream, const 
     return 0;
 }
 
+static void subpixel_fwd_split(long long items, int nchunks, int* ksplit, int* cps) {
+    // fewer than one block per CU: split the channel reduction until there are ~2 blocks per CU (256 CUs)
+    *ksplit = 1, *cps = nchunks;
+    if (items >= 256 || nchunks < 2) return;
+    long long ks = 512 / items;
+    if (ks > nchunks) ks = nchunks;
+    if (ks > 8) ks = 8;
+    if (ks < 2) return;
+    *cps = sp_cdiv(nchunks, (int)ks);
+    *ksplit = sp_cdiv(nchunks, *cps);
+}
+
+extern "C" long long u3d_subpixel_fwd_workspace_floats(int N, int D1, int H1, int W1, int C1, int Cout) {
+    if (N <= 0 || D1 <= 0 || H1 <= 0 || W1 <= 0 || C1 <= 0 || Cout <= 0) return 0;
+    const long long items = (long long)N * sp_cdiv(D1, sp::TZ) * sp_cdiv(H1, sp::TY) * sp_cdiv(W1, sp::TX) * sp_cdiv(Cout, 32);
+    int ks, cps;
+    subpixel_fwd_split(items, sp_cdiv(C1, 16), &ks, &cps);
+    return ks > 1 ? (long long)ks * N * D1 * H1 * W1 * 8 * Cout : 0;
+}
+
 extern "C" int u3d_subpixel_conv_fwd(int device, u3d_stream_t stream, const float* low, const float* affine,
                                      long long affine_sample_stride, const float* packed, float* out, int N, int D1,
-                                     int H1, int W1, int C1, int Cout) {
+                                     int H1, int W1, int C1, int Cout, float* workspace, long long workspace_floats) {
     if (int e = u3d_enter(device)) return e;
     U3D_REQUIRE(low && packed && out && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && C1 > 0 && Cout > 0,
                 "u3d_subpixel_conv_fwd: bad argument");
@@ -712,10 +771,25 @@ extern "C" int u3d_subpixel_conv_fwd(int device, u3d_stream_t stream, const floa
     p.Do = 2 * D1, p.Ho = 2 * H1, p.Wo = 2 * W1;
     p.tz = sp_cdiv(D1, sp::TZ), p.ty = sp_cdiv(H1, sp::TY), p.tx = sp_cdiv(W1, sp::TX);
     p.nchunks = sp_cdiv(C1, 16), p.ncb = sp_cdiv(Cout, 32);
-    const long long nblk = (long long)N * p.tz * p.ty * p.tx * p.ncb;
+    long long nblk = (long long)N * p.tz * p.ty * p.tx * p.ncb;
     U3D_REQUIRE(nblk < (1ll << 31), "u3d_subpixel_conv_fwd: grid too large");
+    const long long out_elems = (long long)N * D1 * H1 * W1 * 8 * Cout;
+    subpixel_fwd_split(nblk, p.nchunks, &p.ksplit, &p.cps);
+    if (p.ksplit > 1 && workspace && ((uintptr_t)workspace & 15) == 0 && (long long)p.ksplit * out_elems <= workspace_floats) {
+        p.out = workspace, p.part_stride = out_elems;
+        nblk *= p.ksplit;
+    } else {
+        p.ksplit = 1, p.cps = p.nchunks, p.part_stride = 0;
+    }
     hipLaunchKernelGGL(subpixel_fwd_kernel<sp::Nearest2x>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
     U3D_LAUNCH_CHECK();
+    if (p.ksplit > 1) {
+        long long blocks = (out_elems / 4 + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, workspace, out_elems,
+                           p.ksplit, out, out_elems / 4);
+        U3D_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -761,6 +835,7 @@ extern "C" int u3d_convtr3d_fwd_subpixel(int device, u3d_stream_t stream, const 
     p.Do = 2 * D1 - 1, p.Ho = 2 * H1 - 1, p.Wo = 2 * W1 - 1;
     p.tz = sp_cdiv(D1, sp::TZ), p.ty = sp_cdiv(H1, sp::TY), p.tx = sp_cdiv(W1, sp::TX);
     p.nchunks = sp_cdiv(Cin, 16), p.ncb = sp_cdiv(Cout, 32);
+    p.ksplit = 1, p.cps = p.nchunks, p.part_stride = 0;
     const long long nblk = (long long)N * p.tz * p.ty * p.tx * p.ncb;
     U3D_REQUIRE(nblk < (1ll << 31), "u3d_convtr3d_fwd_subpixel: grid too large");
     hipLaunchKernelGGL(subpixel_fwd_kernel<sp::Deconv3s2>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);

@@ -408,8 +408,10 @@ class UNet3DEngine:
             ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
             part = torch.empty((N, D, H, W, Cout), dtype=_F32, device=dev)
             D1, H1, W1 = D // 2, H // 2, W // 2
+            need = nat.get_lib().u3d_subpixel_fwd_workspace_floats(N, D1, H1, W1, C1, Cout)  # split-K scratch, small levels only
+            kws = torch.empty(need, dtype=_F32, device=dev) if need > 0 else None
             nat.call("u3d_subpixel_conv_fwd", dev.index, _stream(dev), _p(src.t1), _p(affine.view(-1)[2 * C0:]), Ctot * 2,
-                     _p(self._pack_cache[(id(conv.weight), 12)][1]), _p(part), N, D1, H1, W1, C1, Cout,
+                     _p(self._pack_cache[(id(conv.weight), 12)][1]), _p(part), N, D1, H1, W1, C1, Cout, _p(kws), need,
                      flops=128.0 * C1 * Cout * N * D1 * H1 * W1)
             a0 = affine[:, :C0].contiguous()
             s0 = VSrc(src.t0).struct(a0)

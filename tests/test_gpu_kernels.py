@@ -272,8 +272,18 @@ def test_subpixel_conv_of_upsampled_half(N, C0, C1, Cout, D1, H1, W1, affine):
     part = torch.full((N, D, H, W, Cout), float("nan"), dtype=torch.float32, device=U.DEV)  # every element must be written
     aff_sub = abd.view(-1)[2 * C0:] if affine else None   # rows C0.. of sample 0; sample stride stays Ctot*2
     nat.call("u3d_subpixel_conv_fwd", 0, _stream(U.DEV), _p(lowd), _p(aff_sub), Ctot * 2, _p(pk), _p(part), N, D1, H1, W1, C1,
-             Cout)
+             Cout, None, 0)
     assert U.relerr(U.ncdhw(part), ref_up) < TOL
+    # with the scratch buffer these small grids split the channel reduction over blocks (fixed-order sum of the runs)
+    need = lib.u3d_subpixel_fwd_workspace_floats(N, D1, H1, W1, C1, Cout)
+    assert (need > 0) == (C1 > 16)
+    if need:
+        ws = torch.empty(need, dtype=torch.float32, device=U.DEV)
+        part2 = torch.full_like(part, float("nan"))
+        nat.call("u3d_subpixel_conv_fwd", 0, _stream(U.DEV), _p(lowd), _p(aff_sub), Ctot * 2, _p(pk), _p(part2), N, D1, H1, W1, C1,
+                 Cout, _p(ws), need)
+        assert U.relerr(U.ncdhw(part2), ref_up) < TOL
+        assert U.relerr(part2, part) < 1e-5
     # skip half + residual epilogue = the whole layer
     w0 = w[:, :C0].contiguous()
     a0 = abd[:, :C0].contiguous() if affine else None

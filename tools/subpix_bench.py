@@ -56,8 +56,10 @@ def main():
         nat.call("u3d_pack_subpixel_weights", 0, _stream(dev), _p(w), Cout, Cin, C0, C1, _p(pk))
         part = torch.empty((N, D, H, W, Cout), device=dev)
         aff_sub = aff.view(-1)[2 * C0:]
+        kn = lib.u3d_subpixel_fwd_workspace_floats(N, D1, H1, W1, C1, Cout)
+        kws = torch.empty(kn, device=dev) if kn else None
         ms_b1 = timeit(lambda: nat.call("u3d_subpixel_conv_fwd", 0, _stream(dev), _p(t1), _p(aff_sub), Cin * 2, _p(pk), _p(part),
-                                        N, D1, H1, W1, C1, Cout), args.iters)
+                                        N, D1, H1, W1, C1, Cout, _p(kws), kn), args.iters)
         w0 = U.pack(w[:, :C0].contiguous(), 0)
         a0 = aff[:, :C0].contiguous()
         s0 = VSrc(t0).struct(a0)
