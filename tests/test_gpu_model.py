@@ -68,6 +68,9 @@ def test_model_matches_reference_golden(name):
     (dict(in_channels=1, out_channels=1, f_maps=32, num_groups=8), (2, 1, 16, 32, 32), "bce_dice"),  # cfg2 model, small patch, batch 2
     (dict(in_channels=1, out_channels=1, f_maps=16, num_groups=8), (1, 1, 33, 65, 65), "bce_dice"),  # the reference's odd test shape
     (dict(in_channels=3, out_channels=2, f_maps=[16, 32, 64, 128], num_groups=4, final_sigmoid=False), (1, 3, 16, 24, 40), "probs_sum"),
+    # 12x20x24 -> 6x10x12 -> 3x5x6 -> 1x2x3: the two upper decoder levels are exact 2x (sub-pixel kernels), the deepest one is
+    # not (virtual-concat kernel with index maps) — both paths in one network, ragged tiles everywhere
+    (dict(in_channels=2, out_channels=1, f_maps=8, num_groups=4), (2, 2, 12, 20, 24), "bce_dice"),
     # residual variant: aligned sizes (persistent conv kernels) and the reference's odd test shape
     (dict(name="ResidualUNet3D", in_channels=1, out_channels=1, f_maps=16, num_levels=4, num_groups=8), (1, 1, 16, 32, 32), "bce_dice"),
     (dict(name="ResidualUNet3D", in_channels=1, out_channels=2, f_maps=[16, 32, 64], num_groups=8, final_sigmoid=False), (1, 1, 17, 33, 35), "probs_sum"),
