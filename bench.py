@@ -128,14 +128,17 @@ def main():
     for kv in os.environ.get("U3D_TUNE", "").split(","):  # e.g. U3D_TUNE=0:0 switches the start-phase stagger off
         if ":" in kv:
             nat.call("u3d_set_tuning", int(kv.split(":")[0]), int(kv.split(":")[1]))
-    if world > 1:
+    # launched through torch.distributed.run (RANK set) the RCCL path runs even with ONE rank: same hooks, same
+    # collectives, so the N>1 code path is exercised on a single-GPU box (`--nproc-per-node 1`)
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     torch.manual_seed(0)  # identical initial weights on every rank (also broadcast below)
     model = UNet3D(**MODEL_CFG).to(dev).train()
-    if world > 1:
-        parallel.attach(model)
+    sync = parallel.attach(model, force_single=True) if use_dist else None
     opt = torch.optim.Adam(model.parameters(), lr=2e-4, weight_decay=1e-5)  # 3DUnet_confocal_boundary/train_config.yml
     g = torch.Generator(device=dev).manual_seed(1000 + rank)  # per-rank synthetic shard
     B = args.batch
@@ -158,7 +161,7 @@ def main():
         step()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -175,7 +178,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     nat.profiler = None
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
@@ -198,6 +201,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            # what torch.distributed actually saw: ranks, backend, gradient collectives issued per step by the engine hooks
+            "ranks_seen": ({"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                            "allreduce_per_step": sync.launched // (args.steps + args.warmup)} if use_dist
+                           else {"world_size": 1, "backend": None, "allreduce_per_step": 0}),
             "config": {"workload": f"UNet3D in=1 out=1 f_maps=32 gcr num_groups=8, per-GPU batch {B}x1x64x128x128 fp32, "
                                    "BCEDiceLoss, fwd+loss+bwd+Adam step, random-init weights",
                        "global_batch": world * B, "parallelism": f"dp{world}",
@@ -209,7 +216,7 @@ def main():
         }
         if prof is not None:
             summ = prof.summary()
-            if world == 1:  # (with N > 1 a step contains a collective: rank 0 must not run extra ones alone)
+            if not use_dist:  # (a distributed step contains a collective: rank 0 must not run extra ones alone)
                 full = nat.EventProfiler()  # untimed: the complete per-entry-point table
                 nat.profiler = full
                 for _ in range(3):
@@ -246,7 +253,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

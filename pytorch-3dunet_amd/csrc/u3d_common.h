@@ -11,7 +11,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 int u3d_set_err(int code, const char* fmt, ...);
-int u3d_enter(int device);  // hipSetDevice guard; returns 0 or error
+// Every entry point runs with `device` current and RESTORES the caller's current device on return: the library never
+// changes the calling thread's HIP device behind PyTorch (autograd worker threads, nn.DataParallel replica threads).
+struct u3d_device_guard {
+    int prev = -1;
+    bool switched = false;
+    int enter(int device);
+    ~u3d_device_guard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+#define U3D_ENTER(device)           \
+    u3d_device_guard _u3d_guard;    \
+    if (int _e = _u3d_guard.enter(device)) return _e
 
 #define U3D_HIP(call)                                                                       \
     do {                                                                                    \

@@ -1767,7 +1767,7 @@ extern "C" size_t u3d_packed_weight_floats(int Cin, int Cout, int mode) {
 
 extern "C" int u3d_pack_weights(int device, u3d_stream_t stream, const float* w, int Cout, int Cin, int mode,
                                 float* packed) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(w && packed && Cout > 0 && Cin > 0 && (mode == 0 || mode == 1), "u3d_pack_weights: bad argument");
     int nchunks = 0, ntot = 0;
     const long long total = pack_total_floats(Cin, Cout, mode, &nchunks, &ntot);
@@ -1780,7 +1780,7 @@ extern "C" int u3d_pack_weights(int device, u3d_stream_t stream, const float* w,
 
 extern "C" int u3d_pack_weights_batch(int device, u3d_stream_t stream, const u3d_pack_desc_t* descs_device, int n,
                                       int64_t total_floats) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(descs_device && n > 0 && total_floats > 0, "u3d_pack_weights_batch: bad argument");
     long long blocks = (total_floats + 255) / 256;
     if (blocks > 8192) blocks = 8192;
@@ -1895,7 +1895,7 @@ extern "C" int u3d_conv3d_residual(int device, u3d_stream_t stream, const u3d_sr
 static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w, float* out, int N,
                        int D, int H, int W, int Cout, int relu, double* out_stats, const u3d_src_t* gx, double* gstats,
                        const float* residual, float* ws, long long ws_floats) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     if (int e = check_src(src, "u3d_conv3d")) return e;
     U3D_REQUIRE(packed_w && out && N > 0 && D > 0 && H > 0 && W > 0 && Cout > 0, "u3d_conv3d: bad argument");
     U3D_REQUIRE((long long)N * D * H * W < (1ll << 31), "u3d_conv3d: N*D*H*W must be < 2^31");
@@ -2136,7 +2136,7 @@ extern "C" int u3d_conv3d_wgrad_strided(int device, u3d_stream_t stream, const u
 
 static int conv3d_wgrad_impl(int device, u3d_stream_t stream, const u3d_src_t* src, const float* dz, float* dw, int cstride,
                              int N, int D, int H, int W, int Cout, float* workspace, size_t workspace_floats) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     if (int e = check_src(src, "u3d_conv3d_wgrad")) return e;
     U3D_REQUIRE(dz && dw && workspace && N > 0 && D > 0 && H > 0 && W > 0 && Cout > 0, "u3d_conv3d_wgrad: bad argument");
     U3D_REQUIRE((long long)N * D * H * W < (1ll << 31), "u3d_conv3d_wgrad: N*D*H*W must be < 2^31");
@@ -2178,7 +2178,7 @@ static int conv3d_wgrad_impl(int device, u3d_stream_t stream, const u3d_src_t* s
 
 extern "C" int u3d_conv3d_naive(int device, u3d_stream_t stream, const u3d_src_t* src, const float* w, float* out,
                                 int N, int D, int H, int W, int Cin, int Cout, int relu, int flip) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     if (int e = check_src(src, "u3d_conv3d_naive")) return e;
     U3D_REQUIRE(w && out && Cin == src->C0 + src->C1, "u3d_conv3d_naive: bad argument");
     const long long total = (long long)N * D * H * W * Cout;

@@ -141,7 +141,7 @@ inline dim3 loss_grid(int rows, long long V) {
 extern "C" int u3d_bce_dice_fwd(int device, u3d_stream_t stream, const float* logits, const float* target,
                                 const float* weight, int N, int C, int64_t V, float w_bce, float w_dice, float eps,
                                 double* sums, float* loss, float* coef) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(logits && target && sums && loss && coef && N > 0 && C > 0 && V > 0, "u3d_bce_dice_fwd: bad argument");
     U3D_REQUIRE((long long)N * C < 65536, "u3d_bce_dice_fwd: N*C must be < 65536");
     hipStream_t st = (hipStream_t)stream;
@@ -157,7 +157,7 @@ extern "C" int u3d_bce_dice_fwd(int device, u3d_stream_t stream, const float* lo
 
 extern "C" int u3d_bce_dice_bwd(int device, u3d_stream_t stream, const float* logits, const float* target,
                                 const float* coef, const float* grad_out, int N, int C, int64_t V, float* dlogits) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(logits && target && coef && dlogits && N > 0 && C > 0 && V > 0, "u3d_bce_dice_bwd: bad argument");
     U3D_REQUIRE((long long)N * C < 65536, "u3d_bce_dice_bwd: N*C must be < 65536");
     const int vec = rows_vec_ok(logits, target, dlogits, V) ? 1 : 0;

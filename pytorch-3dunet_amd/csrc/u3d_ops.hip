@@ -17,13 +17,13 @@ int u3d_set_err(int code, const char* fmt, ...) {
     return code;
 }
 
-int u3d_enter(int device) {
-    int cur = -1;
-    hipError_t e = hipGetDevice(&cur);
+int u3d_device_guard::enter(int device) {
+    hipError_t e = hipGetDevice(&prev);
     if (e != hipSuccess) return u3d_set_err(U3D_EHIP, "hipGetDevice failed: %s", hipGetErrorString(e));
-    if (device >= 0 && cur != device) {
+    if (device >= 0 && prev != device) {
         e = hipSetDevice(device);
         if (e != hipSuccess) return u3d_set_err(U3D_EHIP, "hipSetDevice(%d) failed: %s", device, hipGetErrorString(e));
+        switched = true;
     }
     return 0;
 }
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const u3d_src_t src, in
 
 extern "C" int u3d_chan_stats(int device, u3d_stream_t stream, const u3d_src_t* src, int N, int D, int H, int W,
                               double* stats) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(src && src->p0 && stats && N > 0 && D > 0 && H > 0 && W > 0, "u3d_chan_stats: bad argument");
     const int Ctot = src->C0 + src->C1;
     const int Q = (Ctot + 3) / 4;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
 extern "C" int u3d_gn_finalize(int device, u3d_stream_t stream, const double* stats0, int C0, double scale0,
                                const double* stats1, int C1, double scale1, int N, int G, double count,
                                const float* gamma, const float* beta, float eps, float* affine, float* mean_rstd) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(stats0 && C0 > 0 && C1 >= 0 && (C1 == 0 || stats1) && N > 0 && G > 0 && gamma && beta && affine &&
                     mean_rstd && count > 0,
                 "u3d_gn_finalize: bad argument");
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __re
 extern "C" int u3d_gn_bwd_finalize(int device, u3d_stream_t stream, const double* gstats, const float* mean_rstd,
                                    const float* gamma, int N, int C, int G, double count, float* dgamma,
                                    float* dbeta, float* coef) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(gstats && mean_rstd && gamma && dgamma && dbeta && coef && N > 0 && C > 0 && G > 0 && C % G == 0,
                 "u3d_gn_bwd_finalize: bad argument");
     const size_t bytes = sizeof(double) * 2 * (size_t)N * C;
@@ -323,7 +323,7 @@ extern "C" int u3d_gn_bwd_apply_add(int device, u3d_stream_t stream, const float
 static int gn_bwd_apply_impl(int device, u3d_stream_t stream, const float* dg, int Cdg, int coff, const float* x, int Cx,
                              const float* coef, int Ctot, int64_t voxels_per_n, int N, int relu_mask, const float* add,
                              float* out) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(dg && x && coef && out && Cdg > 0 && Cx > 0 && coff >= 0 && coff + Cx <= Cdg && Ctot >= coff + Cx &&
                     voxels_per_n > 0 && N > 0,
                 "u3d_gn_bwd_apply: bad argument");
@@ -396,7 +396,7 @@ extern "C" int u3d_gn_bwd_apply_up(int device, u3d_stream_t stream, const float*
                                    const float* x1, int C1, const float* coef, int Ctot, int N, int D, int H, int W,
                                    int D1, int H1, int W1, const int32_t* zlo, const int32_t* ylo,
                                    const int32_t* xlo, int relu_mask, float* out) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(dg && x1 && coef && out && zlo && ylo && xlo && C1 > 0 && coff >= 0 && coff + C1 <= Cdg &&
                     Ctot >= coff + C1 && N > 0,
                 "u3d_gn_bwd_apply_up: bad argument");
@@ -446,7 +446,7 @@ __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, int N, int D, i
 
 extern "C" int u3d_maxpool2_fwd(int device, u3d_stream_t stream, const float* x, int N, int D, int H, int W, int C,
                                 float* out, uint8_t* argmax, double* out_stats) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(x && out && argmax && N > 0 && D >= 2 && H >= 2 && W >= 2 && C > 0, "u3d_maxpool2_fwd: bad argument");
     const long long total = (long long)N * (D / 2) * (H / 2) * (W / 2) * C;
     hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, x, N, D,
@@ -546,7 +546,7 @@ __global__ void maxpool2_bwd_merge_kernel(const float* __restrict__ dg, const fl
 static int maxpool2_bwd_merge_impl(int device, u3d_stream_t stream, const float* dg, const float* pooled,
                                    const uint8_t* argmax, const float* coef, const float* sdg, int Csdg, const float* scoef,
                                    int Cstot, const float* e, int N, int D, int H, int W, int C, int relu_mask, float* out) {
-    if (int er = u3d_enter(device)) return er;
+    U3D_ENTER(device);
     U3D_REQUIRE(dg && argmax && out && (coef == nullptr || pooled) && (!(relu_mask || scoef) || e) && N > 0 && C > 0 &&
                     (!sdg || Csdg >= C) && (!scoef || (sdg && Cstot >= C)),
                 "u3d_maxpool2_bwd_merge: bad argument");
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(256) void head_fwd_vec_kernel(const float* __restri
 
 extern "C" int u3d_conv1x1_head_fwd(int device, u3d_stream_t stream, const float* x, const float* w, const float* b,
                                     int N, int64_t V, int Cin, int Cout, int act, float* logits, float* probs) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(x && w && b && logits && N > 0 && V > 0, "u3d_conv1x1_head_fwd: bad argument");
     U3D_REQUIRE(Cout >= 1 && Cout <= HEAD_MAXCO && Cin >= 1 && Cin <= HEAD_MAXCI,
                 "u3d_conv1x1_head_fwd: supports Cout<=%d, Cin<=%d (got %d,%d)", HEAD_MAXCO, HEAD_MAXCI, Cout, Cin);
@@ -872,7 +872,7 @@ __global__ __launch_bounds__(256) void head_bwd_vec_kernel(const float* __restri
 extern "C" int u3d_conv1x1_head_bwd(int device, u3d_stream_t stream, const float* dlogits, const float* x,
                                     const float* w, int N, int64_t V, int Cin, int Cout, int relu_mask, float* dx,
                                     double* acc) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(dlogits && x && w && N > 0 && V > 0, "u3d_conv1x1_head_bwd: bad argument");
     U3D_REQUIRE(Cout >= 1 && Cout <= HEAD_MAXCO && Cin >= 1 && Cin <= HEAD_MAXCI,
                 "u3d_conv1x1_head_bwd: supports Cout<=%d, Cin<=%d (got %d,%d)", HEAD_MAXCO, HEAD_MAXCI, Cout, Cin);
@@ -911,7 +911,7 @@ __global__ void cvt_f64_f32_kernel(const double* __restrict__ s, float* __restri
 }
 
 extern "C" int u3d_cvt_f64_f32(int device, u3d_stream_t stream, const double* src, float* dst, int64_t n) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(src && dst && n > 0, "u3d_cvt_f64_f32: bad argument");
     hipLaunchKernelGGL(cvt_f64_f32_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, src, dst,
                        (long long)n);
@@ -947,7 +947,7 @@ static int launch_transpose(u3d_stream_t stream, const float* src, float* dst, i
 
 extern "C" int u3d_ncdhw_to_ndhwc(int device, u3d_stream_t stream, const float* src, float* dst, int N, int C,
                                   int64_t V) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(src && dst && N > 0 && C > 0 && V > 0, "u3d_ncdhw_to_ndhwc: bad argument");
     return launch_transpose(stream, src, dst, N, C, V);  // (N,C,V) -> (N,V,C)
 }
@@ -970,7 +970,7 @@ __global__ void transpose_vc_kernel(const float* __restrict__ src, float* __rest
 
 extern "C" int u3d_ndhwc_to_ncdhw(int device, u3d_stream_t stream, const float* src, float* dst, int N, int C,
                                   int64_t V) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(src && dst && N > 0 && C > 0 && V > 0, "u3d_ndhwc_to_ncdhw: bad argument");
     hipLaunchKernelGGL(transpose_vc_kernel, dim3((unsigned)cdivll(V, 32), (unsigned)cdivll(C, 32), (unsigned)N),
                        dim3(256), 0, (hipStream_t)stream, src, dst, (long long)V, C);

@@ -380,7 +380,7 @@ static int launch_gwgrad(GWgradParams& p, hipStream_t st) {
 // ---- 1x1x1 convolution with bias --------------------------------------------------------------------------------------
 extern "C" int u3d_conv1x1_fwd(int device, u3d_stream_t stream, const float* x, const float* w, const float* bias, float* y,
                                int N, int64_t V, int Cin, int Cout, double* out_stats) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(x && w && y && N > 0 && V > 0 && Cin > 0 && Cout > 0, "u3d_conv1x1_fwd: bad argument");
     U3D_REQUIRE(V < (1ll << 31) && (long long)N * V < (1ll << 31), "u3d_conv1x1_fwd: N*V must be < 2^31");
     GConvParams p{};
@@ -395,7 +395,7 @@ extern "C" int u3d_conv1x1_fwd(int device, u3d_stream_t stream, const float* x, 
 
 extern "C" int u3d_conv1x1_bwd(int device, u3d_stream_t stream, const float* dy, const float* x, const float* w, int N,
                                int64_t V, int Cin, int Cout, float* dx, double* acc) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(dy && x && w && acc && N > 0 && V > 0 && Cin > 0 && Cout > 0, "u3d_conv1x1_bwd: bad argument");
     U3D_REQUIRE(V < (1ll << 31) && (long long)N * V < (1ll << 31), "u3d_conv1x1_bwd: N*V must be < 2^31");
     hipStream_t st = (hipStream_t)stream;
@@ -451,7 +451,7 @@ __global__ void pack_convtr_kernel(const float* __restrict__ w, float* __restric
 
 extern "C" int u3d_pack_convtr_weights(int device, u3d_stream_t stream, const float* w, int Cin, int Cout, int mode,
                                        float* packed) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(w && packed && Cin > 0 && Cout > 0 && (mode == 0 || mode == 1), "u3d_pack_convtr_weights: bad argument");
     const long long total = (long long)27 * Cin * Cout;
     long long blocks = (total + 255) / 256;
@@ -463,7 +463,7 @@ extern "C" int u3d_pack_convtr_weights(int device, u3d_stream_t stream, const fl
 
 extern "C" int u3d_convtr3d_fwd(int device, u3d_stream_t stream, const float* x, const float* w, float* t, int N, int D1,
                                 int H1, int W1, int Cin, int Cout, const float* packed) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(x && w && t && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && Cin > 0 && Cout > 0, "u3d_convtr3d_fwd: bad argument");
     const int Dt = 2 * D1 - 1, Ht = 2 * H1 - 1, Wt = 2 * W1 - 1;
     U3D_REQUIRE((long long)N * Dt * Ht * Wt < (1ll << 31), "u3d_convtr3d_fwd: output voxel count must be < 2^31");
@@ -494,7 +494,7 @@ extern "C" int u3d_convtr3d_fwd(int device, u3d_stream_t stream, const float* x,
 extern "C" int u3d_convtr3d_bwd(int device, u3d_stream_t stream, const float* dt, const float* x, const float* w, int N,
                                 int D1, int H1, int W1, int Cin, int Cout, int relu_mask, float* dx, double* acc,
                                 const float* packed_t) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(dt && x && w && acc && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && Cin > 0 && Cout > 0, "u3d_convtr3d_bwd: bad argument");
     const int Dt = 2 * D1 - 1, Ht = 2 * H1 - 1, Wt = 2 * W1 - 1;
     U3D_REQUIRE((long long)N * Dt * Ht * Wt < (1ll << 31), "u3d_convtr3d_bwd: output voxel count must be < 2^31");
@@ -532,7 +532,7 @@ extern "C" int u3d_convtr3d_bwd(int device, u3d_stream_t stream, const float* dt
 extern "C" int u3d_nearest_add_fwd(int device, u3d_stream_t stream, const float* skip, const float* t, const int32_t* zmap,
                                    const int32_t* ymap, const int32_t* xmap, int N, int D, int H, int W, int Dt, int Ht,
                                    int Wt, int C, float* out, double* out_stats) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(skip && t && zmap && ymap && xmap && out && N > 0 && D > 0 && H > 0 && W > 0 && Dt > 0 && Ht > 0 && Wt > 0 &&
                     C > 0 && C <= 1024,
                 "u3d_nearest_add_fwd: bad argument (C <= 1024)");
@@ -552,7 +552,7 @@ extern "C" int u3d_nearest_add_fwd(int device, u3d_stream_t stream, const float*
 
 extern "C" int u3d_nearest_sum_bwd(int device, u3d_stream_t stream, const float* dj, const int32_t* zlo, const int32_t* ylo,
                                    const int32_t* xlo, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C, float* dt) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(dj && zlo && ylo && xlo && dt && N > 0 && C > 0, "u3d_nearest_sum_bwd: bad argument");
     const long long total = (long long)N * Dt * Ht * Wt * C;
     long long blocks = (total + 255) / 256;

@@ -313,7 +313,7 @@ static int se_check(int N, int64_t V, int C, int mode, const char* what) {
 extern "C" int u3d_se_gate_fwd(int device, u3d_stream_t stream, const double* ystats, double count, const float* w1,
                                const float* b1, const float* w2, const float* b2, int N, int C, int Cr, float* s, float* h,
                                float* gc) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(ystats && w1 && b1 && w2 && b2 && s && h && gc && N > 0 && C > 0 && C <= 1024 && Cr > 0 && Cr <= 1024 && count > 0,
                 "u3d_se_gate_fwd: bad argument (C, Cr <= 1024)");
     hipStream_t st = (hipStream_t)stream;
@@ -326,7 +326,7 @@ extern "C" int u3d_se_gate_fwd(int device, u3d_stream_t stream, const double* ys
 
 extern "C" int u3d_se_apply_fwd(int device, u3d_stream_t stream, const float* y, const float* gc, const float* ws,
                                 const float* bs, int N, int64_t V, int C, int mode, float* out, float* a) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     if (int e = se_check(N, V, C, mode, "u3d_se_apply_fwd")) return e;
     U3D_REQUIRE(y && out && (mode == 2 || gc) && (mode == 1 || (ws && bs)), "u3d_se_apply_fwd: missing gate inputs");
     const int lpv = lanes_per_voxel(C / 4);
@@ -342,7 +342,7 @@ extern "C" int u3d_se_apply_fwd(int device, u3d_stream_t stream, const float* y,
 extern "C" int u3d_se_bwd_reduce(int device, u3d_stream_t stream, const float* dout, const float* y, const float* gc,
                                  const float* a, const float* ws, int N, int64_t V, int C, int mode, float* dls, double* acc_gc,
                                  double* acc_ws) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     if (int e = se_check(N, V, C, mode, "u3d_se_bwd_reduce")) return e;
     U3D_REQUIRE(dout && y && (mode == 2 || (gc && acc_gc)) && (mode == 1 || (a && ws && dls && acc_ws)),
                 "u3d_se_bwd_reduce: missing argument");
@@ -360,7 +360,7 @@ extern "C" int u3d_se_bwd_reduce(int device, u3d_stream_t stream, const float* d
 extern "C" int u3d_se_gate_bwd(int device, u3d_stream_t stream, const double* acc_gc, const float* gc, const float* h,
                                const float* s, const float* w1, const float* w2, int N, int C, int Cr, double count, float* dz2,
                                float* dz1, float* ds, float* dw1, float* db1, float* dw2, float* db2) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(acc_gc && gc && h && s && w1 && w2 && dz2 && dz1 && ds && dw1 && db1 && dw2 && db2 && N > 0 && C > 0 && C <= 1024 &&
                     Cr > 0 && Cr <= 1024 && count > 0,
                 "u3d_se_gate_bwd: bad argument");
@@ -378,7 +378,7 @@ extern "C" int u3d_se_gate_bwd(int device, u3d_stream_t stream, const double* ac
 extern "C" int u3d_se_bwd_apply(int device, u3d_stream_t stream, const float* dout, const float* y, const float* gc,
                                 const float* a, const float* ws, const float* dls, const float* ds, int N, int64_t V, int C,
                                 int mode, int relu_mask, float* out) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     if (int e = se_check(N, V, C, mode, "u3d_se_bwd_apply")) return e;
     U3D_REQUIRE(dout && y && out && (mode == 2 || (gc && ds)) && (mode == 1 || (a && ws && dls)), "u3d_se_bwd_apply: missing argument");
     const long long total = (long long)N * V * (C / 4);

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void conv3d_small_fwd_kernel(const SmallFwdPar
 extern "C" int u3d_conv3d_small_cin_fwd(int device, u3d_stream_t stream, const float* x, const float* affine,
                                         const float* w, float* out, int N, int D, int H, int W, int Cin, int Cout,
                                         int relu, double* out_stats) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(x && w && out && N > 0 && D > 0 && H > 0 && W > 0, "u3d_conv3d_small_cin_fwd: bad argument");
     U3D_REQUIRE(Cin >= 1 && Cin <= sc::MAXC && Cout >= 1 && Cout <= 32,
                 "u3d_conv3d_small_cin_fwd: needs Cin<=4, Cout<=32 (got %d,%d)", Cin, Cout);
@@ -385,7 +385,7 @@ extern "C" size_t u3d_small_cin_bwd_workspace_floats(int N, int D, int H, int W,
 extern "C" int u3d_conv3d_small_cin_bwd(int device, u3d_stream_t stream, const float* x, const float* affine,
                                         const float* dz, const float* w, float* dw, double* gstats, int N, int D,
                                         int H, int W, int Cin, int Cout, float* workspace, size_t workspace_floats) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(x && dz && w && dw && workspace && N > 0 && D > 0 && H > 0 && W > 0, "u3d_conv3d_small_cin_bwd: bad argument");
     U3D_REQUIRE(Cin >= 1 && Cin <= sc::MAXC && Cout >= 1 && Cout <= 32 && Cout * 27 <= 1024,
                 "u3d_conv3d_small_cin_bwd: needs Cin<=4, Cout<=32 (got %d,%d)", Cin, Cout);

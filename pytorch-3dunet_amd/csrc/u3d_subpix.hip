@@ -721,7 +721,7 @@ extern "C" long long u3d_subpixel_packed_floats(int C1, int Cout) {
 
 extern "C" int u3d_pack_subpixel_weights(int device, u3d_stream_t stream, const float* w, int Cout, int Cin_total,
                                          int c_off, int C1, float* packed) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(w && packed && Cout > 0 && C1 > 0 && c_off >= 0 && c_off + C1 <= Cin_total,
                 "u3d_pack_subpixel_weights: bad argument");
     const long long total = u3d_subpixel_packed_floats(C1, Cout);
@@ -756,7 +756,7 @@ extern "C" long long u3d_subpixel_fwd_workspace_floats(int N, int D1, int H1, in
 extern "C" int u3d_subpixel_conv_fwd(int device, u3d_stream_t stream, const float* low, const float* affine,
                                      long long affine_sample_stride, const float* packed, float* out, int N, int D1,
                                      int H1, int W1, int C1, int Cout, float* workspace, long long workspace_floats) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(low && packed && out && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && C1 > 0 && Cout > 0,
                 "u3d_subpixel_conv_fwd: bad argument");
     U3D_REQUIRE(C1 % 4 == 0 && Cout % 4 == 0, "u3d_subpixel_conv_fwd: C1 and Cout must be multiples of 4 (got %d,%d)", C1,
@@ -808,7 +808,7 @@ extern "C" long long u3d_convtr3d_subpixel_packed_floats(int Cin, int Cout) {
 }
 
 extern "C" int u3d_pack_convtr3d_subpixel(int device, u3d_stream_t stream, const float* w, int Cin, int Cout, float* packed) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(w && packed && Cin > 0 && Cout > 0, "u3d_pack_convtr3d_subpixel: bad argument");
     const long long total = sp::packed_floats_deconv(Cin, Cout);
     long long blocks = (total + 255) / 256;
@@ -821,7 +821,7 @@ extern "C" int u3d_pack_convtr3d_subpixel(int device, u3d_stream_t stream, const
 
 extern "C" int u3d_convtr3d_fwd_subpixel(int device, u3d_stream_t stream, const float* x, const float* packed, float* t, int N,
                                          int D1, int H1, int W1, int Cin, int Cout) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(x && packed && t && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && Cin > 0 && Cout > 0,
                 "u3d_convtr3d_fwd_subpixel: bad argument");
     U3D_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "u3d_convtr3d_fwd_subpixel: Cin and Cout must be multiples of 4 (got %d,%d)",
@@ -857,7 +857,7 @@ extern "C" long long u3d_subpixel_dgrad_packed_floats(int Cout, int C1) {
 
 extern "C" int u3d_pack_subpixel_dgrad_weights(int device, u3d_stream_t stream, const float* w, int Cout, int Cin_total,
                                                int c_off, int C1, float* packed) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(w && packed && Cout > 0 && C1 > 0 && c_off >= 0 && c_off + C1 <= Cin_total,
                 "u3d_pack_subpixel_dgrad_weights: bad argument");
     const long long total = spd::packed_floats(Cout, C1);
@@ -872,7 +872,7 @@ extern "C" int u3d_pack_subpixel_dgrad_weights(int device, u3d_stream_t stream, 
 extern "C" int u3d_subpixel_conv_dgrad(int device, u3d_stream_t stream, const float* dz, const float* packed,
                                        const float* x_low, float* dlow, double* gstats, int N, int D1, int H1, int W1, int C1,
                                        int Cout) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(dz && packed && dlow && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && C1 > 0 && Cout > 0,
                 "u3d_subpixel_conv_dgrad: bad argument");
     U3D_REQUIRE((gstats == nullptr) || x_low != nullptr, "u3d_subpixel_conv_dgrad: gstats needs x_low");
@@ -932,7 +932,7 @@ extern "C" int u3d_subpixel_conv_wgrad(int device, u3d_stream_t stream, const fl
                                        long long affine_sample_stride, const float* dz, float* dw, int dw_cin_stride, int N,
                                        int D1, int H1, int W1, int C1, int Cout, float* workspace,
                                        long long workspace_floats) {
-    if (int e = u3d_enter(device)) return e;
+    U3D_ENTER(device);
     U3D_REQUIRE(low && dz && dw && workspace && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && C1 > 0 && Cout > 0 &&
                     dw_cin_stride >= C1,
                 "u3d_subpixel_conv_wgrad: bad argument");

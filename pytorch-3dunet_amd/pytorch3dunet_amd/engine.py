@@ -17,8 +17,11 @@ torch.distributed only.
 """
 from __future__ import annotations
 
+import copy
 import ctypes
+import dataclasses
 import os
+import threading
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -62,6 +65,70 @@ def _maps(dev: torch.device, n_in: int, n_out: int):
         hit = (m.to(dev), lo.to(dev))
         _MAP_CACHE[key] = hit
     return hit
+
+
+def module_params(module) -> list:
+    """`list(module.parameters())` that also works on an nn.DataParallel replica: replicate() empties `_parameters` and keeps
+    the broadcast copies (non-leaf tensors that require grad) as plain attributes + `_former_parameters`, in the same
+    registration order (torch/nn/parallel/replicate.py).  Same module pre-order as nn.Module.parameters()."""
+    out, seen = [], set()
+    for mod in module.modules():
+        src = mod._parameters if mod._parameters else getattr(mod, "_former_parameters", None) or {}
+        for p in src.values():
+            if p is not None and id(p) not in seen:
+                seen.add(id(p))
+                out.append(p)
+    return out
+
+
+class _Ref:
+    """placeholder of a tensor inside a stashed tape: index into ctx.saved_tensors, or into engine.params"""
+
+    __slots__ = ("i", "param")
+
+    def __init__(self, i, param):
+        self.i, self.param = i, param
+
+
+def _walk(obj, fn):
+    """rebuild the tape's object graph (dataclasses, VSrc, lists/tuples/dicts) with every leaf mapped through fn;
+    nn.Modules, numbers and strings stay as they are"""
+    if isinstance(obj, (torch.Tensor, _Ref)):
+        return fn(obj)
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_walk(o, fn) for o in obj)
+    if isinstance(obj, dict):
+        return {k: _walk(v, fn) for k, v in obj.items()}
+    if dataclasses.is_dataclass(obj) or isinstance(obj, VSrc):
+        new = copy.copy(obj)
+        for k, v in vars(obj).items():
+            setattr(new, k, _walk(v, fn))
+        return new
+    return obj
+
+
+def stash_tape(tape, pindex):
+    """(skeleton, tensors): the tape with every activation replaced by a placeholder, and the activations as a flat list
+    for ctx.save_for_backward — autograd then owns their lifetime exactly as it does for stock modules: released after
+    backward unless retain_graph=True, 'backward through the graph a second time' raised by autograd itself, in-place
+    modification detected by the version counters.  Parameters are referenced by position, not saved."""
+    bag, slot = [], {}
+
+    def put(t):
+        pi = pindex.get(id(t))
+        if pi is not None:
+            return _Ref(pi, True)
+        i = slot.get(id(t))
+        if i is None:
+            i = slot[id(t)] = len(bag)
+            bag.append(t)
+        return _Ref(i, False)
+
+    return _walk(tape, put), bag
+
+
+def unstash_tape(skel, saved, params):
+    return _walk(skel, lambda r: params[r.i] if r.param else saved[r.i])
 
 
 class VSrc:
@@ -210,12 +277,17 @@ class UNet3DEngine:
         self.overlap_small_wgrad = True  # weight gradients of small layers on a second HIP stream (see _BwdCtx)
         # decoder first convs over an exact-2x upsampling: sub-pixel convolution of the upsampled half (csrc/u3d_subpix.hip)
         self.subpixel = os.environ.get("U3D_SUBPIXEL", "1") != "0"
-        self._sub: dict = {}  # id(conv weight) -> (C0, C1) of the layers taking that path in the current forward
-        self.params = list(model.parameters())
+        # id(conv weight) -> (C0, C1) of every decoder first conv (static); WHICH of them take the sub-pixel path depends on
+        # the input size and is per-call state (`sub` argument / ConvRec.sub), never stored on the engine: forwards at
+        # different sizes, other threads and nn.DataParallel replicas must not see each other's choice
+        self._sub_pairs: dict = {}
+        self._lock = threading.RLock()  # host-side enqueue of one forward / backward at a time per engine
+        self.params = module_params(model)
+        self._pids = [id(p) for p in self.params]
         self._pindex = {id(p): i for i, p in enumerate(self.params)}
         self._build_layer_table(model)
         # split point of the flat gradient buffer: encoders first (module order), then decoders + head
-        n_enc = sum(p.numel() for p in model.encoders.parameters())
+        n_enc = sum(p.numel() for p in module_params(model.encoders))
         self.n_enc_params = n_enc
         self.n_params = sum(p.numel() for p in self.params)
         offs, o = [], 0
@@ -251,7 +323,7 @@ class UNet3DEngine:
         lib = nat.get_lib()
         Cout, Cin = w.shape[0], w.shape[1]
         if mode >= 10:
-            C0, C1 = self._sub[id(w)]
+            C0, C1 = self._sub_pairs[id(w)]
             if mode in (10, 11):
                 return w.data_ptr(), C0, mode - 10, Cin, lib.u3d_packed_weight_floats(C0, Cout, mode - 10)
             if mode == 12:
@@ -259,7 +331,7 @@ class UNet3DEngine:
             return w.data_ptr() + C0 * 27 * 4, C1, 3, Cin, lib.u3d_subpixel_dgrad_packed_floats(Cout, C1)
         return w.data_ptr(), Cin, mode, 0, lib.u3d_packed_weight_floats(Cin, Cout, mode)
 
-    def _repack_all(self, dev, modes):
+    def _repack_all(self, dev, modes, sub=()):
         """(Re)pack the images of ALL conv weights whose parameter changed since the last pack — one launch for the whole
         model (u3d_pack_weights_batch) instead of one per layer and mode.  The packed buffers and the device descriptor
         table are allocated once and reused (stable pointers)."""
@@ -271,7 +343,7 @@ class UNet3DEngine:
             if self.small_cin and w.shape[1] <= 4 and w.shape[0] <= 32:
                 continue  # first layer: dedicated kernels read the reference layout
             wmodes = modes
-            if id(w) in self._sub:
+            if id(w) in sub:
                 wmodes = tuple(mm + 10 for mm in modes) + tuple(mm + 12 for mm in modes)
             for mode in wmodes:
                 hit = self._pack_cache.get((id(w), mode))
@@ -310,8 +382,7 @@ class UNet3DEngine:
         """packed image of a sub-pixel layer (modes 10..13); normally current from the forward's batch pack"""
         w = rec.conv_w
         hit = self._pack_cache.get((id(w), mode))
-        if hit is None or hit[0] != (w._version, w.data_ptr()) or self._sub.get(id(w)) != rec.sub:
-            self._sub[id(w)] = rec.sub  # e.g. a forward at another input size ran in between
+        if hit is None or hit[0] != (w._version, w.data_ptr()):  # e.g. a no-grad forward packed only the forward images
             wptr, Cin, cmode, cstride, n = self._pack_shape(w, mode)
             buf = torch.empty(n, dtype=_F32, device=dev)
             desc = (nat.U3DPackDesc * 1)()
@@ -344,7 +415,8 @@ class UNet3DEngine:
         return t
 
     def _subpixel_layers(self, size):
-        """decoder first convs whose low-res input is upsampled by exactly 2 in every dimension at this input size"""
+        """decoder first convs whose low-res input is upsampled by exactly 2 in every dimension at this input size:
+        {id(weight): (C0, C1)} — per-call state, handed down as the `sub` argument"""
         if not self.subpixel:
             return {}
         dims = [tuple(size)]
@@ -362,6 +434,7 @@ class UNet3DEngine:
             if (all(a == 2 * b for a, b in zip(dims[skip_lvl], dims[low_lvl])) and C0 > 0 and C1 > 0 and C0 % 4 == 0
                     and C1 % 4 == 0 and c1.conv.out_channels % 4 == 0):
                 out[id(c1.conv.weight)] = (C0, C1)
+        self._sub_pairs.update(out)
         return out
 
     def _stats_of(self, src: VSrc, st0, st1, pool: _StatPool, dev):
@@ -381,7 +454,7 @@ class UNet3DEngine:
         return st, src.C, 1.0, None, 0, 0.0
 
     def _single_conv_fwd(self, sc, name, src: VSrc, st_in, pool: _StatPool, tape: Optional[Tape], want_stats=True,
-                         residual: Optional[torch.Tensor] = None):
+                         residual: Optional[torch.Tensor] = None, sub=()):
         """GroupNorm -> Conv3d -> ReLU of one SingleConv; with `residual`: ReLU(conv(GN(x)) + residual), the tail of
         ResNetBlock.forward (buildingblocks.py:277-288)."""
         dev = src.t0.device
@@ -401,10 +474,10 @@ class UNet3DEngine:
             ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
             nat.call("u3d_conv3d_small_cin_fwd", dev.index, _stream(dev), _p(src.t0), _p(affine), _p(conv.weight.detach()),
                      _p(y), N, D, H, W, Ctot, Cout, 1, _p(ystats), flops=54.0 * Ctot * Cout * N * D * H * W)
-        elif src.t1 is not None and residual is None and id(conv.weight) in self._sub:
+        elif src.t1 is not None and residual is None and id(conv.weight) in sub:
             # cat(skip, nearest2x(low)): the upsampled half as 8 parity-class 2x2x2 convolutions over the low-res tensor
             # (8/27 of the multiply-adds), then the skip half, whose epilogue adds the partial sums before ReLU / statistics
-            C0, C1 = self._sub[id(conv.weight)]
+            C0, C1 = sub[id(conv.weight)]
             ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
             part = torch.empty((N, D, H, W, Cout), dtype=_F32, device=dev)
             D1, H1, W1 = D // 2, H // 2, W // 2
@@ -431,7 +504,7 @@ class UNet3DEngine:
             tape.convs.append(
                 ConvRec(name, src, affine, mean_rstd, y, gn.weight, conv.weight, G, self._pindex[id(gn.weight)],
                         self._pindex[id(gn.bias)], self._pindex[id(conv.weight)], small,
-                        self._sub.get(id(conv.weight)) if (src.t1 is not None and residual is None) else None)
+                        sub.get(id(conv.weight)) if (sub and src.t1 is not None and residual is None) else None)
             )
         return y, ystats
 
@@ -564,8 +637,8 @@ class UNet3DEngine:
         if tape is not None:
             tape.x0 = x0
             tape.dims = (N, Cin, D, H, W)
-        self._sub = self._subpixel_layers((D, H, W))
-        self._repack_all(dev, (0, 1) if save else (0,))
+        sub = self._subpixel_layers((D, H, W))
+        self._repack_all(dev, (0, 1) if save else (0,), sub)
         # stat doubles: every conv output + every GN input computed standalone; generous upper bound
         tot = 0
         for _, c1, c2 in self.enc:
@@ -597,7 +670,8 @@ class UNet3DEngine:
         skips = feats[:-1][::-1]  # model.py:126-133
         for j, ((c1, c2), (sk, sk_st)) in enumerate(zip(self.dec, skips)):
             src = VSrc(sk, cur)  # skip channels first (buildingblocks.py:491)
-            y1, s1 = self._single_conv_fwd(c1, f"dec{j}.c1", src, self._stats_of(src, sk_st, cur_st, pool, dev), pool, tape)
+            y1, s1 = self._single_conv_fwd(c1, f"dec{j}.c1", src, self._stats_of(src, sk_st, cur_st, pool, dev), pool, tape,
+                                           sub=sub)
             src2 = VSrc(y1)
             y2, s2 = self._single_conv_fwd(c2, f"dec{j}.c2", src2, self._stats_of(src2, s1, None, pool, dev), pool, tape)
             cur, cur_st = y2, s2
@@ -1093,28 +1167,34 @@ class _UNet3DFunction(torch.autograd.Function):
     def forward(ctx, engine: UNet3DEngine, x: torch.Tensor, *params):
         # grad mode is always off inside Function.forward: needs_input_grad tells whether a backward can follow
         save = any(ctx.needs_input_grad)
-        logits, probs, tape = engine.forward(x, save)
+        with engine._lock:
+            logits, probs, tape = engine.forward(x, save)
         ctx.engine = engine
-        ctx.tape = tape
         ctx.has_probs = probs is not None
         ctx.x_requires_grad = x.requires_grad
-        if probs is not None:
+        ctx.skel = None
+        if tape is not None:
+            ctx.skel, bag = stash_tape(tape, engine._pindex)
+            ctx.save_for_backward(*([probs] if probs is not None else []), *bag)
+        elif probs is not None:
             ctx.save_for_backward(probs)
+        if probs is not None:
             return logits, probs
         return (logits,)
 
     @staticmethod
     def backward(ctx, *grads):
-        engine, tape = ctx.engine, ctx.tape
-        if tape is None:
-            raise RuntimeError("u3d: no activation tape for this backward — either the forward ran without grad mode, or "
-                               "backward was already called once (the tape is released after the first backward; "
-                               "re-run the forward instead of retain_graph=True)")
+        engine = ctx.engine
+        if ctx.skel is None:
+            raise RuntimeError("u3d: no activation tape for this backward (the forward ran without any input requiring grad)")
+        # a second backward without retain_graph=True raises autograd's own "backward through the graph a second time" here
+        saved = ctx.saved_tensors
+        probs = saved[0] if ctx.has_probs else None
+        tape = unstash_tape(ctx.skel, saved[1:] if ctx.has_probs else saved, engine.params)
         dlogits = grads[0]
         if ctx.has_probs and len(grads) > 1 and grads[1] is not None:
             # gradient flowing through the probabilities (rare: the reference's trainer takes the loss on logits,
             # trainer.py:362-365): fold it into dlogits.  Tiny (N,Cout,D,H,W) tensors.
-            (probs,) = ctx.saved_tensors
             gp = grads[1]
             if isinstance(engine.model.final_activation, torch.nn.Sigmoid):
                 extra = gp * probs * (1 - probs)
@@ -1122,17 +1202,29 @@ class _UNet3DFunction(torch.autograd.Function):
                 extra = probs * (gp - (gp * probs).sum(dim=1, keepdim=True))
             dlogits = extra if dlogits is None else dlogits + extra
         if dlogits is None:
-            dlogits = torch.zeros_like(ctx.saved_tensors[0]) if ctx.has_probs else None
-        flat, dx = engine.backward(tape, dlogits, ctx.x_requires_grad)
-        ctx.tape = None
+            dlogits = torch.zeros_like(probs)
+        with engine._lock:
+            flat, dx = engine.backward(tape, dlogits, ctx.x_requires_grad)
+        del tape, saved
         out = [None, dx]
         for p, off in zip(engine.params, engine.poffs):
             out.append(flat[off : off + p.numel()].view(p.shape) if p.requires_grad else None)
         return tuple(out)
 
 
+def check_placement(engine: UNet3DEngine, x: torch.Tensor):
+    """The kernels read raw pointers: every parameter must be fp32 and live on the input's device (stock modules raise
+    ATen's device/dtype mismatch errors in the same situations, e.g. model.half() or a model left on another GPU)."""
+    for p in engine.params:
+        if p.device != x.device or p.dtype != torch.float32:
+            raise RuntimeError(f"u3d: parameter of shape {tuple(p.shape)} is {p.dtype} on {p.device}, the input is "
+                               f"{x.dtype} on {x.device} — the native gfx950 path needs fp32 parameters on the input's "
+                               "device (one process per GPU: pytorch3dunet_amd.parallel.attach; or model.to(x.device))")
+
+
 def run_model(engine: UNet3DEngine, x: torch.Tensor):
     """(probs_or_logits, logits) exactly like AbstractUNet._forward_logits (model.py:123-149)."""
+    check_placement(engine, x)
     outs = _UNet3DFunction.apply(engine, x, *engine.params)
     if len(outs) == 2:
         logits, probs = outs

@@ -14,6 +14,7 @@ link).
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -23,17 +24,22 @@ import torch.distributed as dist
 class GradSync:
     """Asynchronous bucketed gradient averaging for `UNet3DEngine` (attach with `attach`)."""
 
-    def __init__(self, process_group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, process_group: Optional[dist.ProcessGroup] = None, force_single: Optional[bool] = None):
         self.group = process_group
         self.world = dist.get_world_size(process_group)
+        # a 1-rank group normally skips the collective; U3D_SYNC_SINGLE=1 (or force_single=True) issues it anyway so that
+        # the engine -> RCCL hook placement can be executed and checked on a single-GPU box (tests/test_gpu_parallel.py)
+        self.force_single = os.environ.get("U3D_SYNC_SINGLE", "0") == "1" if force_single is None else bool(force_single)
+        self.launched = 0  # collectives issued (tests)
         self._pending: List = []
         backend = dist.get_backend(process_group)
         self._avg_op = dist.ReduceOp.AVG if backend == "nccl" else None  # gloo has no AVG
 
     def launch(self, bucket: torch.Tensor) -> None:
         """Start averaging `bucket` (a contiguous slice of the flat gradient buffer) across ranks."""
-        if self.world == 1 or bucket.numel() == 0:
+        if (self.world == 1 and not self.force_single) or bucket.numel() == 0:
             return
+        self.launched += 1
         if self._avg_op is not None:
             work = dist.all_reduce(bucket, op=self._avg_op, group=self.group, async_op=True)
         else:
@@ -56,7 +62,7 @@ def broadcast_parameters(model: torch.nn.Module, src: int = 0, process_group=Non
             dist.broadcast(t, src=src, group=process_group)
 
 
-def attach(model: torch.nn.Module, process_group=None, broadcast: bool = True) -> GradSync:
+def attach(model: torch.nn.Module, process_group=None, broadcast: bool = True, force_single: Optional[bool] = None) -> GradSync:
     """Enable data-parallel training of a natively supported model: after this, `loss.backward()` leaves
     rank-averaged gradients in `.grad` exactly like torch DDP would, with the exchange overlapped as described."""
     if not dist.is_initialized():
@@ -66,7 +72,7 @@ def attach(model: torch.nn.Module, process_group=None, broadcast: bool = True) -
                                   "variants in torch.nn.parallel.DistributedDataParallel")
     if broadcast:
         broadcast_parameters(model, 0, process_group)
-    sync = GradSync(process_group)
+    sync = GradSync(process_group, force_single)
     model._get_engine().grad_sync = sync
     return sync
 

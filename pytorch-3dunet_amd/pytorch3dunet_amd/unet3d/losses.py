@@ -15,6 +15,7 @@ import ctypes
 
 import torch
 from torch import nn
+from torch.nn import L1Loss, MSELoss, SmoothL1Loss  # noqa: F401  (names the reference's module exposes, losses.py:4)
 from torch.nn import functional as F
 
 
@@ -191,6 +192,60 @@ class SkipLastTargetChannelWrapper(nn.Module):
         return self.loss(input, target)
 
 
+class GeneralizedDiceLoss(_AbstractDiceLoss):
+    """Generalized Dice (arXiv:1707.03237), reference losses.py:148-184: every label's overlap and volume are weighted
+    by 1 / (label volume)^2; a single-channel input is extended with its complement so that there are two labels.
+    Plain torch reductions over (C, N*D*H*W) — outside the fused kernels (not on the measured path)."""
+
+    def __init__(self, normalization="sigmoid", epsilon=1e-6):
+        super().__init__(weight=None, normalization=normalization)
+        self.epsilon = epsilon
+
+    def dice(self, input, target, weight):
+        assert input.size() == target.size(), "'input' and 'target' must have the same shape"
+        p, t = flatten(input), flatten(target).float()
+        if p.size(0) == 1:
+            p, t = torch.cat((p, 1 - p), dim=0), torch.cat((t, 1 - t), dim=0)
+        vol = t.sum(-1)
+        w = (1 / (vol * vol).clamp(min=self.epsilon)).detach()
+        overlap = ((p * t).sum(-1) * w).sum()
+        total = ((p + t).sum(-1) * w).clamp(min=self.epsilon).sum()
+        return 2 * overlap / total
+
+
+class WeightedCrossEntropyLoss(nn.Module):
+    """Cross entropy with per-class weights (1 - mean softmax mass) / (mean softmax mass) recomputed from every
+    prediction, reference losses.py:204-227."""
+
+    def __init__(self, ignore_index=-1):
+        super().__init__()
+        self.ignore_index = ignore_index
+
+    @staticmethod
+    def _class_weights(input):
+        mass = flatten(F.softmax(input, dim=1))
+        return ((1.0 - mass).sum(-1) / mass.sum(-1)).detach()
+
+    def forward(self, input, target):
+        return F.cross_entropy(input, target, weight=self._class_weights(input), ignore_index=self.ignore_index)
+
+
+class WeightedSmoothL1Loss(nn.SmoothL1Loss):
+    """SmoothL1 whose per-voxel terms are multiplied by `initial_weight` where the TARGET is below (or at/above) a
+    threshold, then averaged — reference losses.py:230-250."""
+
+    def __init__(self, threshold, initial_weight, apply_below_threshold=True):
+        super().__init__(reduction="none")
+        self.threshold = threshold
+        self.apply_below_threshold = apply_below_threshold
+        self.weight = initial_weight
+
+    def forward(self, input, target):
+        per_voxel = super().forward(input, target)
+        picked = (target < self.threshold) if self.apply_below_threshold else (target >= self.threshold)
+        return torch.where(picked, per_voxel * self.weight, per_voxel).mean()
+
+
 def _create_loss(name, loss_config, weight, ignore_index, pos_weight):
     if name == "BCEWithLogitsLoss":
         return BCEWithLogitsLoss(pos_weight=pos_weight)
@@ -206,8 +261,14 @@ def _create_loss(name, loss_config, weight, ignore_index, pos_weight):
         return nn.SmoothL1Loss()
     if name == "L1Loss":
         return nn.L1Loss()
-    raise RuntimeError(f"Unsupported loss function: '{name}' (GeneralizedDiceLoss / WeightedCrossEntropyLoss / "
-                       "WeightedSmoothL1Loss are outside the accelerated path: use the reference's own losses module)")
+    if name == "WeightedCrossEntropyLoss":
+        return WeightedCrossEntropyLoss(ignore_index=-100 if ignore_index is None else ignore_index)
+    if name == "GeneralizedDiceLoss":
+        return GeneralizedDiceLoss(normalization=loss_config.get("normalization", "sigmoid"))
+    if name == "WeightedSmoothL1Loss":
+        return WeightedSmoothL1Loss(threshold=loss_config["threshold"], initial_weight=loss_config["initial_weight"],
+                                    apply_below_threshold=loss_config.get("apply_below_threshold", True))
+    raise RuntimeError(f"Unsupported loss function: '{name}'")
 
 
 def get_loss_criterion(config):

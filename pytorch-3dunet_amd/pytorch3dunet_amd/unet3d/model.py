@@ -67,7 +67,9 @@ class AbstractUNet(nn.Module):
             reasons.append("pool_kernel_size != 2")
         if basic_module is DoubleConv and upsample not in ("default", "nearest"):
             reasons.append(f"upsample '{upsample}'")
-        if basic_module in (ResNetBlock, ResNetBlockSE) and upsample not in ("default", "deconv"):
+        if basic_module in (ResNetBlock, ResNetBlockSE) and upsample != "default":
+            # an EXPLICIT 'deconv' keeps concat joining and a 1x1x1 conv deep->shallow in the block (buildingblocks.py:441-468:
+            # only 'default' selects summation joining + adapted channels), which the residual executor does not implement
             reasons.append(f"upsample '{upsample}' with residual blocks")
         if out_channels > 16 or f_maps[0] > 256:
             reasons.append("head wider than 16 outputs / 256 inputs")
@@ -82,11 +84,22 @@ class AbstractUNet(nn.Module):
         return not self._native_blockers
 
     def _get_engine(self):
-        if self._engine is None:
-            from ..engine import ResUNetEngine, UNet3DEngine
+        """The executor bound to THIS module object and its current parameter tensors.  An nn.DataParallel replica
+        (reference trainer.py:202-205, predict.py:63-66 wrap the model whenever more than one device is visible) is a shallow
+        copy whose __dict__ still points at the original's executor: it gets its own (per replica, per forward — replicas
+        are rebuilt by every DataParallel.forward), built from the replica's broadcast parameter copies, so nothing mutable
+        is shared between replica threads and gradients flow back through the broadcast.  The executor is also rebuilt
+        when parameters were replaced (load_state_dict(assign=True), parametrizations)."""
+        from ..engine import ResUNetEngine, UNet3DEngine, module_params
 
-            object.__setattr__(self, "_engine", (ResUNetEngine if self._residual else UNet3DEngine)(self))
-        return self._engine
+        eng = self.__dict__.get("_engine")
+        if eng is not None and eng.model is self and eng._pids == [id(p) for p in module_params(self)]:
+            return eng
+        new = (ResUNetEngine if self._residual else UNet3DEngine)(self)
+        if eng is not None and eng.model is self:
+            new.grad_sync = eng.grad_sync  # same module, new parameter objects: keep the data-parallel hook
+        object.__setattr__(self, "_engine", new)
+        return new
 
     def forward(self, x, return_logits=False):
         """(N,C,D,H,W) -> probabilities, or (probabilities, logits) when return_logits (model.py:103-121)."""

@@ -26,6 +26,19 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+def diag(**kw):
+    """append one JSON line of observed error figures to gpurun_out/parity_diag.jsonl (evidence for the tolerances
+    written in the tests; gpurun merges gpurun_out/ back)"""
+    import json
+
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "parity_diag.jsonl"), "a") as fh:
+            fh.write(json.dumps(kw) + "\n")
+    except OSError:
+        pass
+
+
 class Golden:
     """One fixture written by tests/golden/make_golden.py from the live reference."""
 
@@ -39,6 +52,7 @@ class Golden:
         self.pert_seed = int(z["pert_seed"])
         self.x_shape = tuple(int(v) for v in z["x_shape"])
         self.loss = float(z["loss"])
+        self.sample = int(z["sample"]) if "sample" in z.files else 97  # stride of the gradient samples of `big` fixtures
         self.z = z
 
     def tensor(self, key):
@@ -80,7 +94,9 @@ class Golden:
 
 
 GOLDEN_NAMES = ["g1_unet3d_small", "g2_unet3d_multi_odd", "g3_unet3d_regression", "g4_unet3d_f16_cfg1",
-                "g5_resunet3d_small", "g6_resunet3d_multi_odd", "g7_resunetse3d_small", "g8_resunetse3d_multi_odd"]
+                "g5_resunet3d_small", "g6_resunet3d_multi_odd", "g7_resunetse3d_small", "g8_resunetse3d_multi_odd",
+                # BASELINE.json configurations at full channel width (sampled fixtures): config 2 itself, config 4's and 5's ladders
+                "g9_unet3d_f32_cfg2", "g10_resunet3d_f64_ladder", "g11_resunetse3d_in3_ladder"]
 
 
 @pytest.fixture(params=GOLDEN_NAMES)

@@ -38,8 +38,19 @@ CASES = {
                                   final_sigmoid=True), (1, 1, 16, 24, 24), "bce_dice", True),
     "g8_resunetse3d_multi_odd": (dict(name="ResidualUNetSE3D", in_channels=3, out_channels=2, f_maps=[8, 16], num_groups=2,
                                       final_sigmoid=False), (2, 3, 9, 13, 11), "probs_sum", True),
+    # ---- BASELINE.json configurations at full channel width (round 2): sampled `big` fixtures
+    # config 2 exactly: UNet3D f_maps=32, per-GPU batch 2x1x64x128x128, BCEDiceLoss
+    "g9_unet3d_f32_cfg2": (dict(name="UNet3D", in_channels=1, out_channels=1, f_maps=32, num_groups=8,
+                                final_sigmoid=True), (2, 1, 64, 128, 128), "bce_dice", False),
+    # config 4's channel ladder 64..1024 over 5 levels (ResidualUNet3D f_maps=64), reduced spatial size
+    "g10_resunet3d_f64_ladder": (dict(name="ResidualUNet3D", in_channels=1, out_channels=1, f_maps=64, num_groups=8,
+                                      final_sigmoid=True), (1, 1, 32, 64, 64), "bce_dice", False),
+    # config 5's ladder: ResidualUNetSE3D, 3 input channels, f_maps=64, 5 levels, non-cubic patch
+    "g11_resunetse3d_in3_ladder": (dict(name="ResidualUNetSE3D", in_channels=3, out_channels=1, f_maps=64, num_groups=8,
+                                        final_sigmoid=True), (1, 3, 16, 32, 48), "bce_dice", False),
 }
 SAMPLE = 97  # stride of the samples kept for `big` fixtures
+SAMPLES = {"g10_resunet3d_f64_ladder": 499, "g11_resunetse3d_in3_ladder": 499}  # >100 M parameters: sparser samples
 
 
 def loss_fn(ref_losses, name, probs, logits, target):
@@ -108,13 +119,22 @@ def main():
                 out["sd/" + k] = p.detach().numpy()
                 out["grad/" + k] = p.grad.numpy()
         else:
+            S = SAMPLES.get(name, SAMPLE)
+            out["sample"] = np.array(S)
             out["probs_s"] = probs.detach().flatten()[::SAMPLE].numpy()
             out["logits_s"] = logits.detach().flatten()[::SAMPLE].numpy()
             out["logits_absmax"] = logits.detach().abs().max().numpy()
-            for k, p in model.named_parameters():
-                out["grad_s/" + k] = p.grad.flatten()[::SAMPLE].numpy()
+            for (k, p), (_, q) in zip(model.named_parameters(), model64.named_parameters()):
+                out["grad_s/" + k] = p.grad.flatten()[::S].numpy()
                 out["grad_norm/" + k] = p.grad.norm().numpy()
                 out["grad_absmax/" + k] = p.grad.abs().max().numpy()
+                if name not in ("g4_unet3d_f16_cfg1",):  # round-2 fixtures also carry the float64 reference's samples
+                    out["grad64_s/" + k] = q.grad.flatten()[::S].numpy()
+            # global relative L2 distance of the reference's fp32 gradient from its own float64 gradient
+            num = sum((p.grad.double() - q.grad).pow(2).sum().item()
+                      for (_, p), (_, q) in zip(model.named_parameters(), model64.named_parameters()))
+            den = sum(q.grad.pow(2).sum().item() for _, q in model64.named_parameters())
+            out["ref_grad_rel_l2"] = np.array((num / den) ** 0.5)
         for k, v in ref_err.items():
             out["ref_err/" + k] = np.array(v)
         out["logits_ref_err"] = np.array((logits.detach().double() - l64.detach()).abs().max().item())

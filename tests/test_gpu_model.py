@@ -5,11 +5,12 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import Golden, GOLDEN_NAMES, loss_by_name
+from conftest import Golden, GOLDEN_NAMES, diag, loss_by_name
 
 pytestmark = pytest.mark.gpu
 
 REL = 1e-3  # BASELINE.json north_star: within 1e-3 rel fp32 of the reference CPU path
+GRAD_FLIP_FACTOR = 4.0  # see test_model_matches_reference_golden (sampled fixtures)
 
 
 def _make(cfg):
@@ -54,14 +55,46 @@ def test_model_matches_reference_golden(name):
             assert orc.grad_within_tolerance(grads[k], rg, float(g.z["ref_err/" + k]), REL), f"{k}: {e}"
         print(f"{name}: logits rel {orc.rel_err(logits, g.tensor('logits')):.2e}, worst grad rel {worst:.2e}")
     else:
-        s = 97
-        assert (logits.flatten()[::s] - g.tensor("logits_s")).abs().max().item() < REL * float(g.z["logits_absmax"])
+        # sampled fixture of a BASELINE-size configuration (g4 = config 1, g9 = config 2 at full size, g10 / g11 = the channel
+        # ladders of configs 4 / 5).  Logits: 1e-3 of the reference's range.  Gradients, per parameter:
+        #   |ours - ref32| <= max(1e-3 * max|ref32|, GRAD_FLIP_FACTOR * ref_err)
+        # ref_err = max|ref32 - ref64| of the reference itself on this very step: its fp32 path takes ReLU / arg-max
+        # decisions at pre-activations within round-off of 0 differently from exact arithmetic, each flip an O(1) local
+        # event.  Ours takes an independent set of such decisions, so |ours - ref32| is the difference of two such error
+        # processes; the observed worst ratio per fixture is written to gpurun_out/parity_diag.jsonl (committed copy:
+        # profiles/r02_parity_diag.jsonl) and GRAD_FLIP_FACTOR is set from it.  The global relative L2 distance from the float64 gradient must not
+        # exceed 2x the reference's own; the decision-consistent test below is the tight (1e-4) gradient gate.
+        s = g.sample
+        assert (logits.flatten()[::97] - g.tensor("logits_s")).abs().max().item() < REL * float(g.z["logits_absmax"])
+        has64 = any(k.startswith("grad64_s/") for k in g.z.files)
+        g64 = g.group("grad64_s/") if has64 else {}
+        worst, num32, num64, den, bad = (0.0, ""), 0.0, 0.0, 0.0, []
         for k, rs in g.group("grad_s/").items():
             am = float(g.z["grad_absmax/" + k])
             re = float(g.z["ref_err/" + k])  # the reference's own fp32-vs-fp64 deviation for this parameter
-            assert (grads[k].flatten()[::s] - rs).abs().max().item() <= max(REL * am, 10 * re), k
+            ours = grads[k].flatten()[::s].double()
+            err = (ours - rs.double()).abs().max().item()
+            ratio = err / max(REL * am, re, 1e-30)
+            if ratio > worst[0]:
+                worst = (ratio, k)
+            if err > max(REL * am, GRAD_FLIP_FACTOR * re):
+                bad.append((k, err, am, re))
             n_ref = float(g.z["grad_norm/" + k])
-            assert abs(grads[k].norm().item() - n_ref) <= max(REL * n_ref, 10 * re * grads[k].numel() ** 0.5) + 1e-12, k
+            if abs(grads[k].norm().item() - n_ref) > max(REL * n_ref, GRAD_FLIP_FACTOR * re * grads[k].numel() ** 0.5) + 1e-12:
+                bad.append((k, "norm", grads[k].norm().item(), n_ref))
+            if has64:
+                num64 += (ours - g64[k]).pow(2).sum().item()
+                num32 += (rs.double() - g64[k]).pow(2).sum().item()
+                den += g64[k].pow(2).sum().item()
+        rec = {"test": "golden_big", "name": name, "worst_ratio_to_max(1e-3*absmax,ref_err)": worst[0], "worst_param": worst[1]}
+        if has64:
+            ours_l2, ref_l2 = (num64 / den) ** 0.5, (num32 / den) ** 0.5
+            rec.update(ours_vs_fp64_rel_l2=ours_l2, ref32_vs_fp64_rel_l2=ref_l2, ref32_vs_fp64_rel_l2_all=float(g.z["ref_grad_rel_l2"]))
+        diag(**rec)
+        print(rec)
+        assert not bad, bad[:5]
+        if has64:
+            assert ours_l2 <= max(REL, 2.0 * ref_l2), (ours_l2, ref_l2)
 
 
 @pytest.mark.parametrize("cfg,shape,loss_name", [
@@ -128,6 +161,7 @@ def test_model_matches_cpu_oracle(cfg, shape, loss_name):
 
 @pytest.mark.parametrize("cfg,shape,loss_name", [
     (dict(in_channels=1, out_channels=1, f_maps=16, num_groups=8), (1, 1, 16, 32, 32), "bce_dice"),
+    (dict(in_channels=1, out_channels=1, f_maps=16, num_groups=8), (1, 1, 32, 64, 64), "bce_dice"),  # BASELINE config 1's shape (= g4)
     (dict(in_channels=1, out_channels=1, f_maps=32, num_groups=8), (2, 1, 16, 32, 32), "bce_dice"),
     (dict(in_channels=1, out_channels=1, f_maps=16, num_groups=8), (1, 1, 33, 65, 65), "bce_dice"),
     (dict(in_channels=2, out_channels=3, f_maps=[8, 16, 32], num_groups=4, final_sigmoid=False), (2, 2, 9, 13, 11), "probs_sum"),
@@ -174,6 +208,86 @@ def test_gradients_match_decision_consistent_fp64_oracle(cfg, shape, loss_name):
             worst = (k, e)
     print(f"decision-consistent fp64 oracle: worst gradient rel err {worst[1]:.2e} ({worst[0]})")
     assert worst[1] < 1e-3, worst
+
+
+# |pre-activation| (relative to the layer's largest pre-activation) below which OUR ReLU mask may differ from the fp32
+# oracle's, and the same for the gap between the two candidates of a max-pool window: k * eps_fp32 with k = 256.  Both
+# implementations carry a forward error of a few 1e-6 of the layer's range (tests above); a mask can only flip where the
+# pre-activation is smaller than that error.  MAX_FLIP_FRACTION bounds how many decisions may differ at all.
+DECISION_TOL = 256 * 1.1920929e-07
+MAX_FLIP_FRACTION = 2e-4
+
+
+@pytest.mark.parametrize("cfg,shape", [
+    (dict(in_channels=1, out_channels=1, f_maps=16, num_groups=8), (1, 1, 32, 64, 64)),   # BASELINE config 1's shape
+    (dict(in_channels=1, out_channels=1, f_maps=32, num_groups=8), (2, 1, 16, 32, 32)),   # config 2's model, small patch
+    (dict(in_channels=1, out_channels=1, f_maps=16, num_groups=8), (1, 1, 33, 65, 65)),   # odd sizes: virtual-concat kernels
+    (dict(in_channels=2, out_channels=3, f_maps=[8, 16, 32], num_groups=4, final_sigmoid=False), (2, 2, 9, 13, 11)),
+    (dict(name="ResidualUNet3D", in_channels=1, out_channels=1, f_maps=16, num_levels=4, num_groups=8), (1, 1, 16, 32, 32)),
+    (dict(name="ResidualUNetSE3D", in_channels=3, out_channels=2, f_maps=[8, 24, 40], num_groups=4, final_sigmoid=False), (2, 3, 9, 13, 11)),
+])
+def test_discrete_decisions_agree_with_fp32_oracle(cfg, shape):
+    """Every ReLU mask and every max-pool arg-max the native path took (they decide which gradient the backward computes)
+    against the fp32 oracle's OWN decisions, layer by layer: they may differ only where the oracle's pre-activation (or the
+    gap between the two window candidates) is at fp32 round-off level, and only for a bounded number of elements.  A wrong
+    mask / arg-max kernel fails here directly (the decision-consistent gradient test imposes OUR decisions on the oracle and
+    would reproduce such an error on both sides)."""
+    import unet3d_oracle as orc
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(777)
+    model = _make(cfg)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if "groupnorm" in k:
+                p.add_(0.2 * torch.randn_like(p))
+    x = torch.randn(shape)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    trace, l_ref = orc.forward_decisions(sd, x, cfg["num_groups"], cfg.get("final_sigmoid", True))
+    model = model.to(dev).train()
+    eng = model._get_engine()
+    eng.debug = {}
+    _, logits = model(x.to(dev), return_logits=True)
+    tape = eng.debug["tape"]
+    eng.debug = None
+    assert orc.rel_err(logits.detach().cpu(), l_ref) < REL
+    ncdhw = lambda t: t.permute(0, 4, 1, 2, 3).contiguous().cpu()  # noqa: E731
+    assert len(tape.convs) == len(trace["pre"]) and len(tape.pools) == len(trace["pool"])
+    worst_rel, flips, total = 0.0, 0, 0
+    for rec, z in zip(tape.convs, trace["pre"]):
+        ours = ncdhw(rec.y > 0)
+        assert ours.shape == z.shape
+        diff = ours != (z > 0)
+        n = int(diff.sum())
+        flips += n
+        total += z.numel()
+        if n:
+            rel = (z[diff].abs().max() / z.abs().max()).item()
+            worst_rel = max(worst_rel, rel)
+            assert rel <= DECISION_TOL, (rec.name, n, rel)
+        assert n <= max(2, MAX_FLIP_FRACTION * z.numel()), (rec.name, n, z.numel())
+    pool_flips, pool_total, worst_gap = 0, 0, 0.0
+    for (pooled, argmax, _), h in zip(tape.pools, trace["pool"]):
+        win = orc.pool_windows(h)                       # (N,C,d,h,w,8), k = dz*4 + dy*2 + dx
+        _, idx = F.max_pool3d(h, 2, return_indices=True)  # ATen's own choice among ties (flat index into D*H*W)
+        Hh, Ww = h.shape[3:]
+        theirs = ((idx // (Hh * Ww)) % 2) * 4 + (((idx // Ww) % Hh) % 2) * 2 + (idx % Ww) % 2
+        ours = ncdhw(argmax).long()
+        assert ours.shape == theirs.shape
+        diff = ours != theirs
+        n = int(diff.sum())
+        pool_flips += n
+        pool_total += theirs.numel()
+        if n:
+            gap = (win.gather(-1, theirs.unsqueeze(-1)) - win.gather(-1, ours.unsqueeze(-1))).squeeze(-1)[diff]
+            rel = (gap.abs().max() / h.abs().max()).item()
+            worst_gap = max(worst_gap, rel)
+            assert rel <= DECISION_TOL, (n, rel)
+        assert n <= max(2, MAX_FLIP_FRACTION * theirs.numel()), (n, theirs.numel())
+    rec = {"test": "decisions", "cfg": str(cfg), "shape": list(shape), "relu_flips": flips, "relu_total": total,
+           "worst_flipped_preact_rel": worst_rel, "pool_flips": pool_flips, "pool_total": pool_total, "worst_pool_gap_rel": worst_gap}
+    diag(**rec)
+    print(rec)
 
 
 def test_inference_no_grad_and_eval_matches_train_forward():

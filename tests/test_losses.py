@@ -104,3 +104,51 @@ def test_fused_bce_dice_vs_cpu_oracle(shape):
     # run-to-run reproducible loss value (f64 accumulation)
     val2 = L.BCEDiceLoss(alpha=0.7)(x.detach(), target.cuda())
     assert abs(val2.item() - val.item()) <= 1e-7 * max(1.0, abs(val.item()))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/pytorch3dunet"), reason="live reference only in the build container")
+def test_remaining_losses_match_live_reference():
+    """GeneralizedDiceLoss / WeightedCrossEntropyLoss / WeightedSmoothL1Loss + get_loss_criterion's name table
+    (reference losses.py:148-184,204-250,274-345): value and dlogits against the imported reference on seeded inputs."""
+    import importlib
+
+    from ref_import import import_reference
+
+    import_reference()
+    R = importlib.import_module("pytorch3dunet.unet3d.losses")
+    g = torch.Generator().manual_seed(77)
+    logits3 = torch.randn((2, 3, 4, 6, 5), generator=g)
+    logits1 = torch.randn((2, 1, 4, 6, 5), generator=g)
+    t3 = (torch.rand(logits3.shape, generator=g) > 0.6).float()
+    t1 = (torch.rand(logits1.shape, generator=g) > 0.6).float()
+    labels = torch.randint(0, 3, (2, 4, 6, 5), generator=g)
+    labels[0, 0, 0, :2] = -1
+    reg_t = torch.randn(logits1.shape, generator=g)
+    cases = [
+        (lambda M: M.GeneralizedDiceLoss(), logits3, t3),
+        (lambda M: M.GeneralizedDiceLoss(), logits1, t1),  # single channel -> complement channel added
+        (lambda M: M.GeneralizedDiceLoss(normalization="softmax"), logits3, t3),
+        (lambda M: M.WeightedCrossEntropyLoss(ignore_index=-1), logits3, labels),
+        (lambda M: M.WeightedSmoothL1Loss(threshold=0.1, initial_weight=3.0), logits1, reg_t),
+        (lambda M: M.WeightedSmoothL1Loss(threshold=0.1, initial_weight=0.25, apply_below_threshold=False), logits1, reg_t),
+    ]
+    for mk, x0, tgt in cases:
+        xa, xb = x0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+        va, vb = mk(L)(xa, tgt), mk(R)(xb, tgt)
+        va.backward()
+        vb.backward()
+        assert abs(va.item() - vb.item()) < 1e-6 * max(1.0, abs(vb.item()))
+        assert (xa.grad - xb.grad).abs().max().item() <= 1e-6 * max(xb.grad.abs().max().item(), 1e-12) + 1e-9
+    names = ["BCEWithLogitsLoss", "BCEDiceLoss", "CrossEntropyLoss", "WeightedCrossEntropyLoss", "GeneralizedDiceLoss",
+             "DiceLoss", "MSELoss", "SmoothL1Loss", "L1Loss"]
+    for n in names:
+        a = L.get_loss_criterion({"device": "cpu", "loss": {"name": n}})
+        b = R.get_loss_criterion({"device": "cpu", "loss": {"name": n}})
+        assert type(a).__name__ == type(b).__name__, n
+    w = L.get_loss_criterion({"device": "cpu", "loss": {"name": "WeightedSmoothL1Loss", "threshold": 0.5, "initial_weight": 2.0,
+                                                         "ignore_index": 7, "skip_last_target": True}})
+    assert type(w).__name__ == "SkipLastTargetChannelWrapper" and type(w.loss).__name__ == "MaskingLossWrapper"
+    for missing in ("compute_per_channel_dice", "flatten", "MaskingLossWrapper", "SkipLastTargetChannelWrapper", "_AbstractDiceLoss"):
+        assert hasattr(L, missing)
+    with pytest.raises(RuntimeError):
+        L.get_loss_criterion({"device": "cpu", "loss": {"name": "NoSuchLoss"}})
