@@ -169,3 +169,87 @@ def test_product_never_imports_oracle():
                 if needle in src:
                     bad.append((os.path.join(dirpath, f), needle))
     assert not bad, bad
+
+
+def _fake_replicate(model):
+    """what torch.nn.parallel.replicate() does to a module tree (replicate.py): every module is shallow-copied with an EMPTY
+    `_parameters`, the broadcast parameter copies (non-leaf tensors) are plain attributes + `_former_parameters`"""
+    from collections import OrderedDict
+
+    mods = list(model.modules())
+    copies = {}
+    for m in mods:
+        r = m._replicate_for_data_parallel()
+        r._former_parameters = OrderedDict()
+        copies[m] = r
+    for m in mods:
+        r = copies[m]
+        for key, child in m._modules.items():
+            if child is not None:
+                setattr(r, key, copies[child])
+        for key, p in m._parameters.items():
+            if p is not None:
+                c = p * 1.0  # non-leaf, requires grad, like Broadcast's outputs
+                setattr(r, key, c)
+                r._former_parameters[key] = c
+    return copies[model]
+
+
+def test_dataparallel_replica_gets_its_own_engine_over_the_broadcast_parameters():
+    """reference trainer.py:202-205 / predict.py:63-66 wrap in nn.DataParallel when several devices are visible"""
+    from pytorch3dunet_amd.engine import module_params
+    from pytorch3dunet_amd.unet3d.model import ResidualUNetSE3D, UNet3D
+
+    for cls in (UNet3D, ResidualUNetSE3D):
+        model = cls(1, 1, f_maps=[8, 16], num_groups=4)
+        assert [id(p) for p in module_params(model)] == [id(p) for p in model.parameters()]
+        eng = model._get_engine()
+        assert model._get_engine() is eng
+        rep = _fake_replicate(model)
+        assert len(list(rep.parameters())) == 0 and rep._engine is eng  # the shallow copy still points at the original's
+        rparams = module_params(rep)
+        assert len(rparams) == len(eng.params) and all(not p.is_leaf and p.requires_grad for p in rparams)
+        assert [tuple(p.shape) for p in rparams] == [tuple(p.shape) for p in eng.params]
+        reng = rep._get_engine()
+        assert reng is not eng and reng.model is rep and model._get_engine() is eng  # nothing shared, original untouched
+        assert [id(p) for p in reng.params] == [id(p) for p in rparams]
+        assert reng.n_enc_params == eng.n_enc_params and reng.poffs == eng.poffs
+        # parameters replaced wholesale -> a new executor; the data-parallel hook survives
+        eng.grad_sync = object()
+        model.load_state_dict({k: v.clone() for k, v in model.state_dict().items()}, assign=True)
+        eng2 = model._get_engine()
+        assert eng2 is not eng and eng2.grad_sync is eng.grad_sync
+
+
+def test_explicit_deconv_on_residual_blocks_is_not_claimed_native():
+    """ResidualUNet3D(upsample='deconv') keeps concat joining + a 1x1x1 conv in the decoder blocks
+    (buildingblocks.py:441-468) — not what the residual executor implements; it must take the module-tree path"""
+    import torch
+
+    from pytorch3dunet_amd.unet3d.model import ResidualUNet3D
+
+    m = ResidualUNet3D(1, 1, f_maps=[8, 16], num_groups=4, upsample="deconv")
+    assert not m.native_supported and m.decoders[0].basic_module.conv1.weight.shape == (8, 16, 1, 1, 1)
+    assert m(torch.randn(1, 1, 4, 8, 8)).shape == (1, 1, 4, 8, 8)
+    assert ResidualUNet3D(1, 1, f_maps=[8, 16], num_groups=4).native_supported
+
+
+def test_tape_stash_roundtrip_keeps_structure_and_references_parameters_by_position():
+    import torch
+
+    from pytorch3dunet_amd.engine import ConvRec, Tape, VSrc, stash_tape, unstash_tape
+    from pytorch3dunet_amd.unet3d.model import UNet3D
+
+    eng = UNet3D(1, 1, f_maps=[8, 16], num_groups=4)._get_engine()
+    a, b = torch.zeros(1, 2, 2, 2, 4), torch.ones(1, 1, 1, 1, 4)
+    t = Tape()
+    t.convs.append(ConvRec("enc0.c1", VSrc(a, b), a, b, a, eng.params[0], eng.params[2], 2, 0, 1, 2))
+    t.pools.append((a, b, a))
+    t.dims = (1, 1, 2, 2, 2)
+    skel, bag = stash_tape(t, eng._pindex)
+    assert all(isinstance(x, torch.Tensor) for x in bag) and not any(x is eng.params[2] for x in bag)
+    assert sum(x is a for x in bag) == 1  # shared tensors are saved once
+    t2 = unstash_tape(skel, bag, eng.params)
+    r = t2.convs[0]
+    assert r.src.t0 is a and r.src.t1 is b and r.conv_w is eng.params[2] and r.gn_w is eng.params[0] and r.name == "enc0.c1"
+    assert r.src.maps[0] is t.convs[0].src.maps[0] and t2.pools[0][1] is b and t2.dims == (1, 1, 2, 2, 2)

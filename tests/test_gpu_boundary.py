@@ -1,0 +1,279 @@
+"""-m gpu: the drop-in boundary under the reference's callers' usage patterns — the training loop of
+UNetTrainer (trainer.py:214-300, 301-349, 351-368, 381-403) restated on the GPU box (the unmodified trainer itself is driven
+in the build container by tests/test_reference_trainer.py), nn.DataParallel as trainer.py:202-205 / predict.py:63-66 wrap
+it, retain_graph / second backward, parameter placement errors, and the 1-rank RCCL gradient path."""
+import copy
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT, diag
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(in_channels=1, out_channels=1, f_maps=[8, 16, 32], num_groups=4, final_sigmoid=True)
+
+
+def _batches(n, seed, shape=(2, 1, 8, 16, 16)):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n):
+        x = torch.randn(shape, generator=g)
+        out.append((x, (x > 0.3).float()))
+    return out
+
+
+def _train_steps(model, opt, crit, batches, dev):
+    losses = []
+    model.train()
+    for x, t in batches:
+        out, logits = model(x.to(dev), return_logits=True)  # trainer.py:362
+        loss = crit(logits, t.to(dev))                        # :365, always on the logits
+        losses.append(loss.item())                            # :241
+        opt.zero_grad()                                       # :244
+        loss.backward()
+        opt.step()
+    return losses
+
+
+def test_training_loop_validate_checkpoint_resume_identical_next_step(tmp_path):
+    """train 3 iterations (Adam over the flat-buffer gradient views) -> validate under no_grad/eval -> save the
+    reference-format checkpoint (utils.py:17-34) -> resume in fresh objects -> the next training step gives the IDENTICAL
+    loss and parameters as continuing in the original objects; and the whole trajectory follows the stock torch.nn module
+    tree (our CPU branch = the reference's semantics) within fp32 round-off."""
+    from pytorch3dunet_amd import _native as nat
+    from pytorch3dunet_amd.unet3d.losses import BCEDiceLoss
+    from pytorch3dunet_amd.unet3d.model import UNet3D
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    cpu_model = UNet3D(**CFG)
+    model = copy.deepcopy(cpu_model).to(dev)
+    crit = BCEDiceLoss()
+    mk_opt = lambda m: torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-5)  # noqa: E731  utils.py:307-309
+    opt, cpu_opt = mk_opt(model), mk_opt(cpu_model)
+    init = [p.detach().clone() for p in cpu_model.parameters()]
+    train, val = _batches(5, 1), _batches(2, 2)
+
+    n0 = nat.launch_count
+    losses = _train_steps(model, opt, crit, train[:3], dev)
+    assert nat.launch_count > n0
+    cpu_losses = _train_steps(cpu_model, cpu_opt, crit, train[:3], torch.device("cpu"))
+    assert max(abs(a - b) for a, b in zip(losses, cpu_losses)) < 2e-4, (losses, cpu_losses)
+    # parameters after 3 Adam steps: Adam normalises every coordinate's step to ~lr, so coordinates whose gradient is pure
+    # round-off noise (e.g. the first GroupNorm's gamma: analytically 0) move by +-lr in an implementation-dependent
+    # direction; compare the update as a whole (relative L2 of the difference of the two updates)
+    num = den = 0.0
+    for (k, p), (_, q), p0 in zip(model.named_parameters(), cpu_model.named_parameters(), init):
+        assert p.grad is not None and p.grad.shape == p.shape, k
+        num += (p.detach().cpu() - q.detach()).double().pow(2).sum().item()
+        den += (q.detach() - p0).double().pow(2).sum().item()
+    upd_rel = (num / den) ** 0.5
+    diag(test="adam_trajectory", losses=losses, cpu_losses=cpu_losses, update_rel_l2=upd_rel)
+    assert upd_rel < 0.1, upd_rel
+
+    # validation (trainer.py:301-349): eval mode + no_grad, loss on logits, probabilities for the metric
+    model.eval()
+    with torch.no_grad():
+        vls = []
+        for x, t in val:
+            out, logits = model(x.to(dev), return_logits=True)
+            assert not logits.requires_grad and float(out.min()) >= 0 and float(out.max()) <= 1
+            vls.append(crit(logits, t.to(dev)).item())
+    model.train()
+
+    # checkpoint in the reference's layout (utils.py:17-34, trainer.py:381-403)
+    path = os.path.join(tmp_path, "last_checkpoint.pytorch")
+    torch.save({"num_epochs": 1, "num_iterations": 3, "model_state_dict": model.state_dict(), "best_eval_score": 0.5,
+                "optimizer_state_dict": opt.state_dict()}, path)
+    state = torch.load(path, map_location="cpu")  # utils.py:59
+    model2 = UNet3D(**CFG).to(dev)
+    opt2 = mk_opt(model2)
+    model2.load_state_dict(state["model_state_dict"])  # strict
+    opt2.load_state_dict(state["optimizer_state_dict"])
+
+    nxt = _train_steps(model, opt, crit, train[3:4], dev)
+    nxt2 = _train_steps(model2, opt2, crit, train[3:4], dev)
+    assert nxt == nxt2, (nxt, nxt2)
+    for (k, p), (_, q) in zip(model.named_parameters(), model2.named_parameters()):
+        assert torch.equal(p, q), k
+    # validation gives the same numbers again in the resumed model before that step? (forward is a pure function of state)
+    model2.eval()
+    with torch.no_grad():
+        _, lg_a = model(val[0][0].to(dev), return_logits=True)
+        _, lg_b = model2(val[0][0].to(dev), return_logits=True)
+    assert torch.equal(lg_a, lg_b)
+
+
+def test_second_backward_with_retain_graph_and_error_without():
+    """The reference's modules support loss.backward(retain_graph=True) followed by another backward; without it autograd
+    raises its own 'backward through the graph a second time'.  The activation tape is owned by autograd
+    (ctx.save_for_backward), so both behaviours are the stock ones."""
+    from pytorch3dunet_amd.unet3d.model import UNet3D
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    model = UNet3D(**CFG).to(dev).train()
+    x = torch.randn(1, 1, 8, 16, 16, device=dev)
+    _, logits = model(x, return_logits=True)
+    loss = (logits * logits).mean()
+    loss.backward(retain_graph=True)
+    g1 = [p.grad.clone() for p in model.parameters()]
+    model.zero_grad()
+    loss.backward()  # second pass over the retained graph: identical gradients
+    for a, p in zip(g1, model.parameters()):
+        assert torch.equal(a, p.grad)
+    with pytest.raises(RuntimeError, match="second time|already been freed"):
+        loss.backward()
+    # two forwards alive at once, at different input sizes, backward in the opposite order (per-call state, no engine globals)
+    xa, xb = torch.randn(1, 1, 8, 16, 16, device=dev), torch.randn(1, 1, 12, 20, 20, device=dev)
+    model.zero_grad()
+    _, la = model(xa, return_logits=True)
+    _, lb = model(xb, return_logits=True)
+    (la * la).mean().backward()
+    ga = [p.grad.clone() for p in model.parameters()]
+    model.zero_grad()
+    (lb * lb).mean().backward()
+    model.zero_grad()
+    _, la2 = model(xa, return_logits=True)
+    (la2 * la2).mean().backward()
+    for a, p in zip(ga, model.parameters()):
+        assert torch.equal(a, p.grad)
+
+
+def test_dataparallel_wrap_trains_and_predicts():
+    """trainer.py:202-205 / predict.py:63-66 wrap the model in nn.DataParallel whenever more than one device is visible.
+    Replicas are shallow copies whose parameters are broadcast NON-LEAF tensors kept as plain attributes: every replica
+    gets its own executor (nothing mutable shared between the replica threads) and gradients flow back through the
+    broadcast.  On this one-GPU box the two replicas both live on device 0 (device_ids=[0, 0]) — same code path: scatter,
+    replicate, one Python thread per replica calling into the C-ABI concurrently, gather."""
+    from pytorch3dunet_amd import _native as nat
+    from pytorch3dunet_amd.unet3d.model import UNet3D, is_model_2d
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(4)
+    model = UNet3D(**CFG).to(dev).train()
+    ref = copy.deepcopy(model)
+    dp = torch.nn.DataParallel(model, device_ids=[0, 0])
+    assert not is_model_2d(dp)
+    x = torch.randn(4, 1, 8, 16, 16, device=dev)
+    t = (x > 0.3).float()
+    n0 = nat.launch_count
+    try:
+        out, logits = dp(x, return_logits=True)
+    except RuntimeError as e:  # pragma: no cover - torch refusing duplicate device ids would be an environment limit
+        if "device" in str(e) and "duplicate" in str(e).lower():
+            pytest.skip(f"this torch build refuses device_ids=[0, 0]: {e}")
+        raise
+    assert nat.launch_count > n0 and logits.shape == x.shape and logits.requires_grad
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, t)
+    loss.backward()
+    # single-model result on the whole batch: the same mean loss -> the same gradients (samples are independent: GroupNorm)
+    out_r, logits_r = ref(x, return_logits=True)
+    torch.nn.functional.binary_cross_entropy_with_logits(logits_r, t).backward()
+    assert (logits - logits_r).abs().max().item() <= 1e-5 * logits_r.abs().max().item()
+    for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None, k
+        scale = max(q.grad.abs().max().item(), 1e-12)
+        assert (p.grad - q.grad).abs().max().item() <= 2e-4 * scale + 1e-9, k
+    # the original model is untouched by the replicas and still runs on its own executor
+    eng = model._get_engine()
+    assert eng.model is model
+    dp.eval()
+    with torch.no_grad():
+        y = dp(x)
+        y1 = model(x)
+    assert torch.allclose(y, y1, atol=1e-6)
+
+
+def test_parameter_placement_and_dtype_errors_are_loud():
+    from pytorch3dunet_amd.unet3d.model import UNet3D
+
+    dev = torch.device("cuda", 0)
+    model = UNet3D(**CFG)  # parameters left on the CPU, CUDA input: stock modules raise a device-mismatch RuntimeError too
+    with pytest.raises(RuntimeError, match="u3d: parameter"):
+        model(torch.randn(1, 1, 8, 16, 16, device=dev))
+    model = model.to(dev).half()
+    with pytest.raises(RuntimeError, match="u3d: parameter"):
+        model(torch.randn(1, 1, 8, 16, 16, device=dev))
+    model = model.float()
+    assert model(torch.randn(1, 1, 8, 16, 16, device=dev)).shape == (1, 1, 8, 16, 16)
+    # parameters replaced wholesale (load_state_dict(assign=True)): the executor follows the new tensors
+    sd = {k: v.detach().clone() * 0.5 for k, v in model.state_dict().items()}
+    x = torch.randn(1, 1, 8, 16, 16, device=dev)
+    y0 = model(x)
+    model.load_state_dict(sd, assign=True)
+    y1 = model(x)
+    fresh = UNet3D(**CFG).to(dev)
+    fresh.load_state_dict(sd)
+    assert torch.equal(y1, fresh(x)) and not torch.equal(y0, y1)
+    # versioned in-place updates (what optimizers and EMA swaps under no_grad do) invalidate the packed weight images
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(2.0)
+    fresh2 = UNet3D(**CFG).to(dev)
+    fresh2.load_state_dict({k: v * 2.0 for k, v in sd.items()})
+    assert torch.equal(model(x), fresh2(x))
+
+
+def _spawn(args, env_extra, timeout=600):
+    env = dict(os.environ, **env_extra)
+    return subprocess.run(args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+
+
+@pytest.mark.timeout(900)
+def test_one_rank_rccl_gradient_path_equals_unsynced_run():
+    """The engine -> RCCL hook placement (decoder+head bucket launched before the encoder backward, encoder bucket after,
+    engine.py backward) executed on a real device with a 1-rank `nccl` group: averaging over one rank is the identity, so the
+    gradients must equal the unsynced run bit for bit, twice in a row; both buckets are really issued."""
+    code = r'''
+import os, sys, json
+sys.path.insert(0, os.path.join(os.getcwd(), "pytorch-3dunet_amd"))
+import torch, torch.distributed as dist
+from pytorch3dunet_amd import parallel
+from pytorch3dunet_amd.unet3d.model import UNet3D, ResidualUNet3D
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+res = {}
+for name, cls in (("unet", UNet3D), ("res", ResidualUNet3D)):
+    torch.manual_seed(0)
+    model = cls(1, 1, f_maps=[8, 16, 32], num_groups=4).to(dev).train()
+    x = torch.randn(2, 1, 8, 16, 16, device=dev)
+    def grads():
+        model.zero_grad()
+        _, lg = model(x, return_logits=True)
+        (lg * lg).mean().backward()
+        torch.cuda.synchronize()
+        return torch.cat([p.grad.flatten() for p in model.parameters()]).clone()
+    g_plain = grads()
+    sync = parallel.attach(model, force_single=True)
+    g1 = grads(); n1 = sync.launched
+    g2 = grads()
+    res[name] = {"equal_plain": bool(torch.equal(g_plain, g1)), "equal_rerun": bool(torch.equal(g1, g2)),
+                 "launched_per_backward": n1, "backend": dist.get_backend(), "world": dist.get_world_size()}
+dist.destroy_process_group()
+print("RESULT " + json.dumps(res))
+'''
+    proc = _spawn([sys.executable, "-c", code], {"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    r = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    for name in ("unet", "res"):
+        assert r[name] == {"equal_plain": True, "equal_rerun": True, "launched_per_backward": 2, "backend": "nccl", "world": 1}, r
+
+
+@pytest.mark.timeout(900)
+def test_bench_under_torch_distributed_run_one_rank():
+    """bench.py's N>1 branch (process group, attach, barrier, max-over-ranks) through the driver's own launcher with one rank"""
+    proc = _spawn([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                   "--master-port", "29543", "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                  {"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    line = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["ranks_seen"] == {"world_size": 1, "backend": "nccl", "allreduce_per_step": 2}, r["ranks_seen"]
+    assert r["n_gpus"] == 1 and r["value"] > 0 and "roofline" in r
