@@ -769,21 +769,24 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* __restric
             }
         }
     }
-    // reduce rows through LDS: red[o][c] accumulations
-    for (int i = t; i < (Cout + 1) * Cin; i += 256) red[i] = 0.f;
-    __syncthreads();
+    // reduce the rows through LDS in a FIXED order (red[row][(Cout+1)*Cin]; no floating-point atomics: the block's
+    // partial is bit-reproducible, the cross-block sum is carried in f64)
+    const int L = (Cout + 1) * Cin;
     if (row < rows) {
 #pragma unroll
         for (int o = 0; o < HEAD_MAXCO; ++o) {
             if (o < Cout) {
-                atomicAdd(&red[o * Cin + c], a[o]);
-                if (c == 0) atomicAdd(&red[Cout * Cin + o], bsum[o]);
+                red[row * L + o * Cin + c] = a[o];
+                if (c == 0) red[row * L + Cout * Cin + o] = bsum[o];
             }
         }
     }
     __syncthreads();
-    for (int i = t; i < Cout * Cin; i += 256) u3d_atomic_add_f64(&acc[i], (double)red[i]);
-    for (int i = t; i < Cout; i += 256) u3d_atomic_add_f64(&acc[Cout * Cin + i], (double)red[Cout * Cin + i]);
+    for (int i = t; i < Cout * Cin + Cout; i += 256) {
+        double sum = 0.0;
+        for (int r = 0; r < rows; ++r) sum += (double)red[r * L + i];
+        u3d_atomic_add_f64(&acc[i], sum);
+    }
 }
 
 // Fused vectorised backward: thread -> (voxel, channel quad) with a FIXED quad per thread (grid stride is a
@@ -852,21 +855,24 @@ __global__ __launch_bounds__(256) void head_bwd_vec_kernel(const float* __restri
         }
     }
     if (acc == nullptr) return;
-    for (int i = t; i < (Cout + 1) * Cin; i += 256) red[i] = 0.f;
-    __syncthreads();
+    // fixed-order reduction of the rows (red[row][(Cout+1)*Cin]), no floating-point atomics inside the block
+    const int L = (Cout + 1) * Cin;
     if (row < rows) {
 #pragma unroll
         for (int o = 0; o < HEAD_VEC_MAXCO; ++o) {
             if (o < Cout) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) atomicAdd(&red[o * Cin + 4 * q + e], aw[o][e]);
-                if (q == 0) atomicAdd(&red[Cout * Cin + o], ab[o]);
+                for (int e = 0; e < 4; ++e) red[row * L + o * Cin + 4 * q + e] = aw[o][e];
+                if (q == 0) red[row * L + Cout * Cin + o] = ab[o];
             }
         }
     }
     __syncthreads();
-    for (int i = t; i < Cout * Cin; i += 256) u3d_atomic_add_f64(&acc[i], (double)red[i]);
-    for (int i = t; i < Cout; i += 256) u3d_atomic_add_f64(&acc[Cout * Cin + i], (double)red[Cout * Cin + i]);
+    for (int i = t; i < Cout * Cin + Cout; i += 256) {
+        double sum = 0.0;
+        for (int r = 0; r < rows; ++r) sum += (double)red[r * L + i];
+        u3d_atomic_add_f64(&acc[i], sum);
+    }
 }
 
 extern "C" int u3d_conv1x1_head_bwd(int device, u3d_stream_t stream, const float* dlogits, const float* x,
@@ -883,7 +889,7 @@ extern "C" int u3d_conv1x1_head_bwd(int device, u3d_stream_t stream, const float
         long long blocks = cdivll((long long)V, (long long)rows * 32);
         if (blocks > 2048) blocks = 2048;
         if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(head_bwd_vec_kernel, dim3((unsigned)blocks), dim3(256), (size_t)(Cout + 1) * Cin * sizeof(float),
+        hipLaunchKernelGGL(head_bwd_vec_kernel, dim3((unsigned)blocks), dim3(256), (size_t)rows * (Cout + 1) * Cin * sizeof(float),
                            (hipStream_t)stream, dlogits, x, w, N, (long long)V, Cin, Cout, relu_mask, dx, acc);
         U3D_LAUNCH_CHECK();
         return 0;
@@ -897,7 +903,7 @@ extern "C" int u3d_conv1x1_head_bwd(int device, u3d_stream_t stream, const float
         long long blocks = cdivll((long long)N * V, 4096);
         if (blocks > 1024) blocks = 1024;
         if (blocks < 1) blocks = 1;
-        const size_t shmem = (size_t)(Cout + 1) * Cin * sizeof(float);
+        const size_t shmem = (size_t)(256 / Cin) * (Cout + 1) * Cin * sizeof(float);
         hipLaunchKernelGGL(head_bwd_dw_kernel, dim3((unsigned)blocks), dim3(256), shmem, (hipStream_t)stream, dlogits,
                            x, N, (long long)V, Cin, Cout, acc);
         U3D_LAUNCH_CHECK();

@@ -73,8 +73,8 @@ def module_params(module) -> list:
     registration order (torch/nn/parallel/replicate.py).  Same module pre-order as nn.Module.parameters()."""
     out, seen = [], set()
     for mod in module.modules():
-        src = mod._parameters if mod._parameters else getattr(mod, "_former_parameters", None) or {}
-        for p in src.values():
+        # a replica's `_parameters` holds only the None entries (e.g. bias=False); the live copies are in `_former_parameters`
+        for p in list(mod._parameters.values()) + list((getattr(mod, "_former_parameters", None) or {}).values()):
             if p is not None and id(p) not in seen:
                 seen.add(id(p))
                 out.append(p)

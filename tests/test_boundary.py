@@ -188,7 +188,9 @@ def _fake_replicate(model):
             if child is not None:
                 setattr(r, key, copies[child])
         for key, p in m._parameters.items():
-            if p is not None:
+            if p is None:
+                r._parameters[key] = None  # e.g. Conv3d(bias=False): the replica's _parameters is NOT empty
+            else:
                 c = p * 1.0  # non-leaf, requires grad, like Broadcast's outputs
                 setattr(r, key, c)
                 r._former_parameters[key] = c

@@ -206,17 +206,18 @@ def test_parameter_placement_and_dtype_errors_are_loud():
     sd = {k: v.detach().clone() * 0.5 for k, v in model.state_dict().items()}
     x = torch.randn(1, 1, 8, 16, 16, device=dev)
     y0 = model(x)
+    sd_copy = {k: v.clone() for k, v in sd.items()}  # assign=True makes the model's Parameters WRAP the tensors of `sd`
     model.load_state_dict(sd, assign=True)
     y1 = model(x)
     fresh = UNet3D(**CFG).to(dev)
-    fresh.load_state_dict(sd)
+    fresh.load_state_dict(sd_copy)
     assert torch.equal(y1, fresh(x)) and not torch.equal(y0, y1)
     # versioned in-place updates (what optimizers and EMA swaps under no_grad do) invalidate the packed weight images
     with torch.no_grad():
         for p in model.parameters():
             p.mul_(2.0)
     fresh2 = UNet3D(**CFG).to(dev)
-    fresh2.load_state_dict({k: v * 2.0 for k, v in sd.items()})
+    fresh2.load_state_dict({k: v * 2.0 for k, v in sd_copy.items()})
     assert torch.equal(model(x), fresh2(x))
 
 

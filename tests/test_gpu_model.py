@@ -61,8 +61,8 @@ def test_model_matches_reference_golden(name):
         # ref_err = max|ref32 - ref64| of the reference itself on this very step: its fp32 path takes ReLU / arg-max
         # decisions at pre-activations within round-off of 0 differently from exact arithmetic, each flip an O(1) local
         # event.  Ours takes an independent set of such decisions, so |ours - ref32| is the difference of two such error
-        # processes; the observed worst ratio per fixture is written to gpurun_out/parity_diag.jsonl (committed copy:
-        # profiles/r02_parity_diag.jsonl) and GRAD_FLIP_FACTOR is set from it.  The global relative L2 distance from the float64 gradient must not
+        # processes.  Measured worst ratio err / max(1e-3*absmax, ref_err) over all parameters (profiles/r02_parity_diag.jsonl):
+        # g4 1.37, g9 (config 2 at full size) 3.67, g10 2.45, g11 1.00 -> GRAD_FLIP_FACTOR = 4 (round 1 used 10).  The global relative L2 distance from the float64 gradient must not
         # exceed 2x the reference's own; the decision-consistent test below is the tight (1e-4) gradient gate.
         s = g.sample
         assert (logits.flatten()[::97] - g.tensor("logits_s")).abs().max().item() < REL * float(g.z["logits_absmax"])
@@ -211,11 +211,13 @@ def test_gradients_match_decision_consistent_fp64_oracle(cfg, shape, loss_name):
 
 
 # |pre-activation| (relative to the layer's largest pre-activation) below which OUR ReLU mask may differ from the fp32
-# oracle's, and the same for the gap between the two candidates of a max-pool window: k * eps_fp32 with k = 256.  Both
-# implementations carry a forward error of a few 1e-6 of the layer's range (tests above); a mask can only flip where the
-# pre-activation is smaller than that error.  MAX_FLIP_FRACTION bounds how many decisions may differ at all.
-DECISION_TOL = 256 * 1.1920929e-07
-MAX_FLIP_FRACTION = 2e-4
+# oracle's, and the same for the gap between the two candidates of a max-pool window: 64 * eps_fp32 = 7.6e-6.  Both
+# implementations carry a forward error of ~1e-6 of a layer's range; a mask can only flip where the pre-activation is
+# smaller than that error.  Measured (profiles/r02_parity_diag.jsonl): 0-5 flips among 0.1-10 M decisions per network, the
+# largest flipped pre-activation 1.9e-6 of its layer's range, no arg-max flip at all -> 4x margin on the level, and at most
+# 1e-5 of a layer's decisions (or 4) may differ.
+DECISION_TOL = 64 * 1.1920929e-07
+MAX_FLIP_FRACTION = 1e-5
 
 
 @pytest.mark.parametrize("cfg,shape", [
@@ -265,7 +267,7 @@ def test_discrete_decisions_agree_with_fp32_oracle(cfg, shape):
             rel = (z[diff].abs().max() / z.abs().max()).item()
             worst_rel = max(worst_rel, rel)
             assert rel <= DECISION_TOL, (rec.name, n, rel)
-        assert n <= max(2, MAX_FLIP_FRACTION * z.numel()), (rec.name, n, z.numel())
+        assert n <= max(4, MAX_FLIP_FRACTION * z.numel()), (rec.name, n, z.numel())
     pool_flips, pool_total, worst_gap = 0, 0, 0.0
     for (pooled, argmax, _), h in zip(tape.pools, trace["pool"]):
         win = orc.pool_windows(h)                       # (N,C,d,h,w,8), k = dz*4 + dy*2 + dx
@@ -283,7 +285,7 @@ def test_discrete_decisions_agree_with_fp32_oracle(cfg, shape):
             rel = (gap.abs().max() / h.abs().max()).item()
             worst_gap = max(worst_gap, rel)
             assert rel <= DECISION_TOL, (n, rel)
-        assert n <= max(2, MAX_FLIP_FRACTION * theirs.numel()), (n, theirs.numel())
+        assert n <= max(4, MAX_FLIP_FRACTION * theirs.numel()), (n, theirs.numel())
     rec = {"test": "decisions", "cfg": str(cfg), "shape": list(shape), "relu_flips": flips, "relu_total": total,
            "worst_flipped_preact_rel": worst_rel, "pool_flips": pool_flips, "pool_total": pool_total, "worst_pool_gap_rel": worst_gap}
     diag(**rec)
