@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define U3D_VERSION 100 /* 0.1.0 */
+#define U3D_VERSION 110 /* 0.1.1: bf16-operand convolutions */
 
 #define U3D_OK 0
 #define U3D_EINVAL (-1)  /* bad shape / argument */
@@ -352,6 +352,34 @@ int u3d_bce_dice_fwd(int device, u3d_stream_t stream, const float* logits, const
                      float* coef);
 int u3d_bce_dice_bwd(int device, u3d_stream_t stream, const float* logits, const float* target, const float* coef,
                      const float* grad_out, int N, int C, int64_t V, float* dlogits);
+
+/* ---- opt-in bf16-operand convolutions (BASELINE config 4: "bf16 compute", fp32 master weights) --------------
+ * The same nn.Conv3d(in,out,3,padding=1,bias=False) (buildingblocks.py:56) and, with mode-1 packed weights on dy, its
+ * data gradient — as u3d_conv3d, but on v_mfma_f32_32x32x16_bf16: operands rounded to bf16 (round-to-nearest-even; the
+ * activations after the fp32 GroupNorm affine, while they are staged into LDS), products accumulated in FP32; inputs,
+ * outputs, statistics and the residual are fp32 tensors.  Single-tensor sources only (no virtual concat); needs
+ * Cin % 16 == 0 and Cout % 32 == 0 (u3d_conv3d_bf16_supported), 16-byte aligned pointers.
+ *   x         (N,D,H,W,Cin) fp32        affine  optional (N,Cin,2) GroupNorm (a,b): conv input = a*x + b, zero padded
+ *   packed_w  image written by u3d_pack_weights_bf16 (u3d_packed_weight_bf16_elems() 2-byte elements)
+ *   out       (N,D,H,W,Cout) fp32 = [relu](conv + residual)
+ *   out_stats optional double[N][Cout][2] += (sum, sum of squares) of the written values
+ *   gx/gstats optional (data-gradient use): gx (N,D,H,W,Cout) fp32 = the forward input of the layer; gstats
+ *             double[N][Cout][2] += (sum dg, sum dg*gx) — what GroupNorm backward needs.  Exclusive with out_stats. */
+int u3d_conv3d_bf16_supported(int Cin, int Cout);
+long long u3d_packed_weight_bf16_elems(int Cin, int Cout, int mode);
+int u3d_pack_weights_bf16(int device, u3d_stream_t stream, const float* w, int Cout, int Cin, int mode, void* packed);
+int u3d_conv3d_bf16(int device, u3d_stream_t stream, const float* x, const float* affine, const void* packed_w, float* out,
+                    int N, int D, int H, int W, int Cin, int Cout, int relu, double* out_stats, const float* gx,
+                    double* gstats, const float* residual);
+
+/* Weight gradient of the same convolution with bf16 operands / FP32 accumulation (autograd of trainer.py:245 for
+ * buildingblocks.py:56): dw (Cout,Cin,3,3,3) fp32, reference layout, = sum over voxels of g(x)[v+tap] (x) dz[v] with
+ * g = a*x + b zero padded.  Needs Cin % 32 == 0, Cout % 64 == 0 and a scratch buffer of
+ * u3d_wgrad_bf16_workspace_floats() floats (split partial sums, reduced in a fixed order: run-to-run identical). */
+int u3d_conv3d_wgrad_bf16_supported(int Cin, int Cout);
+long long u3d_wgrad_bf16_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
+int u3d_conv3d_wgrad_bf16(int device, u3d_stream_t stream, const float* x, const float* affine, const float* dz, float* dw,
+                          int N, int D, int H, int W, int Cin, int Cout, float* workspace, long long workspace_floats);
 
 /* ---- layout: NCDHW <-> NDHWC for multi-channel model inputs ------------------------------------ */
 int u3d_ncdhw_to_ndhwc(int device, u3d_stream_t stream, const float* src, float* dst, int N, int C, int64_t V);

@@ -1,0 +1,545 @@
+// u3d_bf16.hip — opt-in bf16-operand convolutions for BASELINE config 4 (ResidualUNet3D f_maps=64, "bf16 compute, fp32
+// master weights"): the 3x3x3 Conv3d of buildingblocks.py:56 and its data gradient as an implicit GEMM on
+// v_mfma_f32_32x32x16_bf16 — bf16 operands, FP32 accumulation, everything around it (activations in HBM, GroupNorm
+// statistics, residual add, ReLU, parameter gradients) stays fp32.  Operands are converted while staging: activations
+// (GroupNorm affine applied in fp32 first) in the global->LDS pass, weights by u3d_pack_weights_bf16 from the fp32 master
+// copy (round-to-nearest-even, v_cvt_pk_bf16_f32).
+//
+// GEMM view: M = voxels, N = output channels, K = 27 taps x Cin.  Block = 4 waves, output tile (4*ZW) x 8 x 8 voxels x
+// 32*NT channels; wave w owns z-planes [w*ZW, w*ZW+ZW) x two y-halves = 2*ZW M-tiles of 32 voxels (4 y x 8 x), so every
+// A fragment (one ds_read_b128) feeds NT MFMAs and every B fragment (16 B per lane of packed weights, L1/L2 resident)
+// feeds 2*ZW MFMAs: 4*ZW*NT MFMAs of 32 cycles per (tap, 16-channel chunk) against 2*ZW LDS reads and NT global loads.
+// The (TZ+2) x 10 x 10 halo tile of a chunk lives in LDS as two channel-half planes [kh][hz][hy][hx pad 12][8 bf16]:
+// a lane's fragment (8 channels of one voxel) is one 16-byte record and, with M-tile row r -> (y = r & 3, x = r >> 2),
+// the 16 lanes of every ds_read_b128 service group hit 16 distinct 16-byte slots (row stride 12 records: checked by
+// brute force against the lane groups of MI355X_MICROARCH.md §LDS).  Two buffers: chunk c+1 is fetched into registers in
+// three batches under the three z-tap groups of chunk c and written to the other buffer after each group; one barrier
+// per chunk.
+#include "u3d_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int HY = 10, HX = 10, HS = 12;  // halo extent in y / x, padded row stride (records)
+
+struct bf16_conv_params {
+    const float* x;        // (N,D,H,W,C) fp32
+    const float* affine;   // (N,C,2) GroupNorm (a,b) per sample and channel, or null
+    const bf16x8* wpk;     // packed weights [chunk][tap][n-tile][lane][8]
+    float* y;              // (N,D,H,W,K) fp32
+    const float* residual; // (N,D,H,W,K) or null: added before the ReLU
+    const float* gx;       // (N,D,H,W,K) or null: forward input of the layer whose data gradient this is
+    double* out_stats;     // [N][K][2] += (sum y, sum y^2) or null
+    double* gstats;        // [N][K][2] += (sum y, sum y*gx) or null
+    int N, D, H, W, C, K, relu;
+    int tz, ty, tx;        // tiles per dimension
+};
+
+template <int ZW>
+struct tile_geom {
+    static constexpr int TZ = 4 * ZW, HZ = TZ + 2, MT = 2 * ZW;
+    static constexpr int PLANE = HZ * HY * HS * 16 + 64;  // bytes; +64: the two planes' writes land on different banks
+    static constexpr int BUF = 2 * PLANE;
+    static constexpr int ITEMS = HZ * HY * HX * 4;        // (halo voxel, channel quad) float4 items per chunk
+    static constexpr int ITERS = (ITEMS + 255) / 256;
+    static constexpr int PER_PART = (ITERS + 2) / 3;
+};
+
+// one staged item: global float4 (4 channels of one halo voxel) -> affine -> 4 bf16 -> 8 bytes of LDS
+template <int ZW>
+__device__ __forceinline__ void item_coords(int item, int& hz, int& hy, int& hx) {
+    const int hv = item >> 2;
+    hz = hv / (HY * HX);
+    const int rem = hv - hz * (HY * HX);
+    hy = rem / HX;
+    hx = rem - hy * HX;
+}
+
+template <int NT, int ZW>
+__global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_params p) {
+    using G = tile_geom<ZW>;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int nblk = p.K / (32 * NT);
+    const int bid = u3d_xcd_remap(blockIdx.x, gridDim.x);
+    const int nb = bid % nblk;
+    int tile = bid / nblk;
+    const int txi = tile % p.tx;
+    tile /= p.tx;
+    const int tyi = tile % p.ty;
+    tile /= p.ty;
+    const int tzi = tile % p.tz;
+    const int n = tile / p.tz;
+    const int z0 = tzi * G::TZ, y0 = tyi * 8, x0 = txi * 8;
+    const int nch = p.C >> 4;
+    const int ntiles = p.K >> 5;
+    const int q = t & 3;  // this thread's channel quad within a chunk (item & 3 == t & 3 for every item it stages)
+
+    f32x16 acc[G::MT][NT];
+#pragma unroll
+    for (int m = 0; m < G::MT; ++m)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][j][e] = 0.f;
+
+    // A-fragment base of this lane: row r = lane & 31 -> (yy = r & 3, xx = r >> 2), channel half kh = lane >> 5
+    const int r = lane & 31, kh = lane >> 5;
+    const int a_base = kh * G::PLANE + (((w * ZW) * HY + (r & 3)) * HS + (r >> 2)) * 16;
+
+    auto load_item = [&](int c, int it, f32x4& v) {
+        const int item = t + it * 256;
+        v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (item < G::ITEMS) {
+            int hz, hy, hx;
+            item_coords<ZW>(item, hz, hy, hx);
+            const int z = z0 - 1 + hz, y = y0 - 1 + hy, xx = x0 - 1 + hx;
+            if ((unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
+                const size_t vox = (((size_t)n * p.D + z) * p.H + y) * p.W + xx;
+                v = *reinterpret_cast<const f32x4*>(p.x + vox * p.C + (c << 4) + 4 * q);
+            }
+        }
+    };
+    auto store_item = [&](char* buf, int it, const f32x4& v, const f32x4& ga, const f32x4& gb) {
+        const int item = t + it * 256;
+        if (item < G::ITEMS) {
+            int hz, hy, hx;
+            item_coords<ZW>(item, hz, hy, hx);
+            bf16x4 o;
+            const int z = z0 - 1 + hz, y = y0 - 1 + hy, xx = x0 - 1 + hx;
+            if (!((unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)) {
+                // zero padding applies AFTER the GroupNorm affine: Conv3d(padding=1) pads the normalised tensor
+                o = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (__bf16)fmaf(v[e], ga[e], gb[e]);
+            }
+            char* dst = buf + (q >> 1) * G::PLANE + ((hz * HY + hy) * HS + hx) * 16 + (q & 1) * 8;
+            *reinterpret_cast<bf16x4*>(dst) = o;
+        }
+    };
+    auto chunk_affine = [&](int c, f32x4& ga, f32x4& gb) {
+        u3d_load_affine(p.affine, n, p.C, (c << 4) + 4 * q, true, ga, gb);
+    };
+
+    // ---- prologue: chunk 0 into buffer 0
+    {
+        f32x4 ga, gb;
+        chunk_affine(0, ga, gb);
+#pragma unroll 1
+        for (int it = 0; it < G::ITERS; ++it) {
+            f32x4 v;
+            load_item(0, it, v);
+            store_item(lds, it, v, ga, gb);
+        }
+    }
+
+    for (int c = 0; c < nch; ++c) {
+        __syncthreads();  // buffer (c&1) is complete; everyone is done reading buffer ((c+1)&1)
+        const char* cur = lds + (c & 1) * G::BUF;
+        char* nxt = lds + ((c + 1) & 1) * G::BUF;
+        const bool more = c + 1 < nch;
+        f32x4 ga, gb;
+        if (more) chunk_affine(c + 1, ga, gb);
+        const bf16x8* wp = p.wpk + ((size_t)c * 27 * ntiles + (size_t)nb * NT) * 64 + lane;
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {  // part = z tap
+            f32x4 st[G::PER_PART];
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < G::PER_PART; ++i)
+                    if (part * G::PER_PART + i < G::ITERS) load_item(c + 1, part * G::PER_PART + i, st[i]);
+            }
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9) {
+                const int tap = part * 9 + t9, tyy = t9 / 3, txx = t9 % 3;
+                bf16x8 b[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) b[j] = wp[((size_t)tap * ntiles + j) * 64];
+#pragma unroll
+                for (int m = 0; m < G::MT; ++m) {
+                    const int zl = m >> 1, yh = m & 1;
+                    const int off = (((zl + part) * HY + (yh * 4 + tyy)) * HS + txx) * 16;
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(cur + a_base + off);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[j], acc[m][j], 0, 0, 0);
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < G::PER_PART; ++i)
+                    if (part * G::PER_PART + i < G::ITERS) store_item(nxt, part * G::PER_PART + i, st[i], ga, gb);
+            }
+        }
+    }
+
+    // ---- epilogue: residual, ReLU, store, per-(n,channel) statistics.  C/D layout of the 32x32 MFMA: column = lane & 31,
+    // row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5); with row -> (yy = row & 3, xx = row >> 2): yy = e & 3, xx = 2*(e >> 2) + (lane >> 5)
+    const int col = lane & 31, half = lane >> 5;
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
+    const bool want_stats = p.out_stats != nullptr, want_g = p.gstats != nullptr;
+#pragma unroll
+    for (int m = 0; m < G::MT; ++m) {
+        const int z = z0 + w * ZW + (m >> 1);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int y = y0 + (m & 1) * 4 + (e & 3), xx = x0 + 2 * (e >> 2) + half;
+            const bool ok = z < p.D && y < p.H && xx < p.W;
+            if (ok) {
+                const size_t vox = (((size_t)n * p.D + z) * p.H + y) * p.W + xx;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const size_t o = vox * p.K + (size_t)(nb * NT + j) * 32 + col;
+                    float v = acc[m][j][e];
+                    if (p.residual) v += p.residual[o];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    p.y[o] = v;
+                    if (want_stats) {
+                        s1[j] += v;
+                        s2[j] = fmaf(v, v, s2[j]);
+                    } else if (want_g) {
+                        s1[j] += v;
+                        s2[j] = fmaf(v, p.gx[o], s2[j]);
+                    }
+                }
+            }
+        }
+    }
+    if (want_stats || want_g) {
+        // fixed-order block reduction through LDS (the halo buffers are free now), then one f64 atomic per (n, channel)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(lds);  // [8 = wave*2+half][NT*32][2]
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            red[((w * 2 + half) * NT * 32 + j * 32 + col) * 2 + 0] = s1[j];
+            red[((w * 2 + half) * NT * 32 + j * 32 + col) * 2 + 1] = s2[j];
+        }
+        __syncthreads();
+        if (t < NT * 32 * 2) {
+            double sum = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sum += (double)red[i * NT * 32 * 2 + t];
+            double* dst = (want_stats ? p.out_stats : p.gstats) + ((size_t)n * p.K + (size_t)nb * NT * 32) * 2;
+            u3d_atomic_add_f64(dst + t, sum);
+        }
+    }
+}
+
+// fp32 master weights (Cout,Cin,3,3,3) -> bf16 fragment image [chunk][tap][n-tile][lane][8]:
+// mode 0 (forward):       B[k = input channel ][col = output channel] = w[col][k][tap]
+// mode 1 (data gradient): B[k = output channel][col = input channel ] = w[k][col][26 - tap]   (taps flipped, roles swapped)
+// lane l of a fragment holds column (l & 31) of n-tile `nt` and the 8 consecutive k = chunk*16 + 8*(l >> 5) + 0..7.
+__global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int Cout, int Cin, int mode, __bf16* __restrict__ out,
+                                         long long total) {
+    const int Kc = mode == 0 ? Cin : Cout;   // contraction channels
+    const int Nc = mode == 0 ? Cout : Cin;   // produced channels
+    const int ntiles = Nc >> 5;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 7);
+        long long rest = i >> 3;
+        const int l = (int)(rest & 63);
+        rest >>= 6;
+        const int nt = (int)(rest % ntiles);
+        rest /= ntiles;
+        const int tap = (int)(rest % 27);
+        const int c = (int)(rest / 27);
+        const int k = c * 16 + 8 * (l >> 5) + e, col = nt * 32 + (l & 31);
+        float v = 0.f;
+        if (k < Kc && col < Nc) {
+            if (mode == 0)
+                v = w[((size_t)col * Cin + k) * 27 + tap];
+            else
+                v = w[((size_t)k * Cin + col) * 27 + (26 - tap)];
+        }
+        out[i] = (__bf16)v;
+    }
+}
+
+}  // namespace
+
+extern "C" long long u3d_packed_weight_bf16_elems(int Cin, int Cout, int mode) {
+    const int Kc = mode == 0 ? Cin : Cout, Nc = mode == 0 ? Cout : Cin;
+    if (Kc <= 0 || Nc <= 0 || Kc % 16 != 0 || Nc % 32 != 0) return 0;
+    return (long long)(Kc / 16) * 27 * (Nc / 32) * 64 * 8;
+}
+
+extern "C" int u3d_pack_weights_bf16(int device, u3d_stream_t stream, const float* w, int Cout, int Cin, int mode,
+                                     void* packed) {
+    U3D_ENTER(device);
+    const long long total = u3d_packed_weight_bf16_elems(Cin, Cout, mode);
+    U3D_REQUIRE(w && packed && (mode == 0 || mode == 1) && total > 0,
+                "u3d_pack_weights_bf16: needs contraction channels %% 16 == 0 and produced channels %% 32 == 0 (Cin %d, Cout %d)",
+                Cin, Cout);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, mode,
+                       reinterpret_cast<__bf16*>(packed), total);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int u3d_conv3d_bf16_supported(int C, int K) { return (C > 0 && K > 0 && C % 16 == 0 && K % 32 == 0) ? 1 : 0; }
+
+template <int NT, int ZW>
+static int launch_bf16(const bf16_conv_params& p, hipStream_t stream) {
+    using G = tile_geom<ZW>;
+    bf16_conv_params q = p;
+    q.tz = (p.D + G::TZ - 1) / G::TZ;
+    q.ty = (p.H + 7) / 8;
+    q.tx = (p.W + 7) / 8;
+    const long long blocks = (long long)p.N * q.tz * q.ty * q.tx * (p.K / (32 * NT));
+    if (blocks > 0x7fffffffLL) return u3d_set_err(U3D_EINVAL, "u3d_conv3d_bf16: grid too large");
+    const size_t shmem = 2 * (size_t)G::BUF;
+    // (per device, cheap: set on every launch so that every device of a multi-GPU process has it)
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_bf16_kernel<NT, ZW>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL((conv3d_bf16_kernel<NT, ZW>), dim3((unsigned)blocks), dim3(256), shmem, stream, q);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int u3d_conv3d_bf16(int device, u3d_stream_t stream, const float* x, const float* affine, const void* packed_w,
+                               float* out, int N, int D, int H, int W, int C, int K, int relu, double* out_stats,
+                               const float* gx, double* gstats, const float* residual) {
+    U3D_ENTER(device);
+    U3D_REQUIRE(x && packed_w && out && N > 0 && D > 0 && H > 0 && W > 0, "u3d_conv3d_bf16: bad argument");
+    U3D_REQUIRE(u3d_conv3d_bf16_supported(C, K), "u3d_conv3d_bf16: needs Cin %% 16 == 0 and Cout %% 32 == 0 (got %d, %d)", C, K);
+    U3D_REQUIRE(!(out_stats && gstats), "u3d_conv3d_bf16: out_stats and gstats are mutually exclusive");
+    U3D_REQUIRE(!gstats || gx, "u3d_conv3d_bf16: gstats needs gx");
+    U3D_REQUIRE((((uintptr_t)x | (uintptr_t)packed_w | (uintptr_t)affine) & 15) == 0, "u3d_conv3d_bf16: 16-byte alignment");
+    bf16_conv_params p{x, affine, reinterpret_cast<const bf16x8*>(packed_w), out, residual, gx, out_stats, gstats,
+                       N, D, H, W, C, K, relu, 0, 0, 0};
+    // tile height: 8 z-planes per block when that still gives >= 2 blocks per CU, else 4 (more, smaller blocks at the bottom
+    // of the U); 64 output channels per block when possible
+    const bool nt2 = K % 64 == 0;
+    const long long big = (long long)N * ((D + 7) / 8) * ((H + 7) / 8) * ((W + 7) / 8) * (K / (nt2 ? 64 : 32));
+    const bool zw2 = big >= 512 && D >= 8;
+    hipStream_t s = (hipStream_t)stream;
+    if (nt2) return zw2 ? launch_bf16<2, 2>(p, s) : launch_bf16<2, 1>(p, s);
+    return zw2 ? launch_bf16<1, 2>(p, s) : launch_bf16<1, 1>(p, s);
+}
+
+// =====================================================================================================================
+// Weight gradient on v_mfma_f32_32x32x16_bf16:  dw[co][ci][tap] = sum_{n,v} g[n, v + tap - 1, ci] * dz[n, v, co],
+// g = GroupNorm-affine(x) zero padded.  GEMM view: rows = 32 input channels, columns = 32 output channels, K = voxels
+// (16 consecutive x positions per MFMA).  The contraction runs over VOXELS while both tensors are stored channel-
+// contiguous (NDHWC), so each operand fragment (8 voxels of one channel per lane) is a transposed read: the tiles sit in
+// LDS as [voxel][channel] bf16 and fragments are fetched with ds_read_b64_tr_b16, a pure shuffle inside 16-lane groups
+// (out[l][j] = in[16*(l>>4) + 4*j + ((l&15)>>2)][(l&15)&3], tools/tr_probe.hip): source lane s of a group supplies the
+// address of 4 channels of voxel (s >> 2), lane l receives channel (l & 15) of voxels j = 0..3.  The 32 lanes of one LDS
+// cycle cover 4 voxels x 64 bytes = 256 contiguous bytes: conflict-free.
+//
+// Block = 8 waves owns (split s, 32 input channels, 64 output channels): wave w takes output-channel half (w >> 2) and
+// the taps {w&3, (w&3)+4, ...} (7,7,7,6) — 7 accumulators of 16 registers.  Per 2 x 8 x 16 voxel tile the g halo tile
+// (4 x 10 x 18 x 32 ch) and the dz tile (2 halves x 256 x 32 ch) are staged once (fp32 -> affine -> bf16); per 16-voxel
+// row a wave reads its dz fragment once and one g fragment per tap.  Partial sums of the splits are written to a
+// workspace and reduced in a FIXED order by wgrad_bf16_reduce_kernel straight into the reference layout.
+namespace {
+
+constexpr int WG_TZ = 2, WG_TY = 8, WG_TX = 16;
+constexpr int WG_HZ = WG_TZ + 2, WG_HY = WG_TY + 2, WG_HX = WG_TX + 2;
+constexpr int WG_G_BYTES = WG_HZ * WG_HY * WG_HX * 64;       // [hz][hy][hx][32 ci] bf16
+constexpr int WG_DZ_HALF = WG_TZ * WG_TY * WG_TX * 64;       // [z][y][x][32 co] bf16, two halves
+constexpr int WG_LDS = WG_G_BYTES + 2 * WG_DZ_HALF;          // 46080 + 32768 = 78848 bytes
+constexpr int WG_G_ITEMS = WG_HZ * WG_HY * WG_HX * 8;        // (halo voxel, channel quad)
+constexpr int WG_DZ_ITEMS = WG_TZ * WG_TY * WG_TX * 16;      // (voxel, channel quad of 64)
+
+struct bf16_wgrad_params {
+    const float* x;       // (N,D,H,W,C)
+    const float* affine;  // (N,C,2) or null
+    const float* dz;      // (N,D,H,W,K)
+    float* ws;            // [S][P][27][32][64] partial sums
+    int N, D, H, W, C, K;
+    int tz, ty, tx;       // tiles per dimension
+    int tiles;            // N*tz*ty*tx
+    int per_block;        // tiles per split
+    int pco;              // K / 64
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* lds_addr) {
+    // two transposed reads: voxels +0..3 and +4..7 of this lane's 8-voxel half (4 voxels x 64 B apart)
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(uintptr_t)(uint32_t)(uintptr_t)lds_addr);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(uintptr_t)(uint32_t)(uintptr_t)(lds_addr + 4 * 64));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wgrad_params p) {
+    __shared__ __attribute__((aligned(256))) char lds[WG_LDS];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int P = (p.C >> 5) * p.pco;
+    const int pair = blockIdx.x % P, split = blockIdx.x / P;
+    const int cib = pair / p.pco, cob = pair % p.pco;
+    const int c0 = cib * 32, k0 = cob * 64;
+    const int h = w >> 2, wq = w & 3;
+
+    f32x16 acc[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    // fragment addressing (see the header comment): group g4 = lane >> 4 -> channel half (g4 & 1), voxel half kh = g4 >> 1;
+    // as a SOURCE lane, sidx = lane & 15 supplies voxel (sidx >> 2), channel quad (sidx & 3)
+    const int g4 = lane >> 4, sidx = lane & 15;
+    const int lane_off = (8 * (g4 >> 1) + (sidx >> 2)) * 64 + (16 * (g4 & 1) + 4 * (sidx & 3)) * 2;
+    int a_off[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int tap = min(wq + 4 * i, 26);
+        const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
+        a_off[i] = lane_off + ((tz * WG_HY + ty) * WG_HX + tx) * 64;
+    }
+    const int b_off = WG_G_BYTES + h * WG_DZ_HALF + lane_off;
+
+    const int first = split * p.per_block, last = min(p.tiles, first + p.per_block);
+    for (int tile = first; tile < last; ++tile) {
+        int tt = tile;
+        const int txi = tt % p.tx;
+        tt /= p.tx;
+        const int tyi = tt % p.ty;
+        tt /= p.ty;
+        const int tzi = tt % p.tz;
+        const int n = tt / p.tz;
+        const int z0 = tzi * WG_TZ, y0 = tyi * WG_TY, x0 = txi * WG_TX;
+        __syncthreads();  // the previous tile's fragment reads are done
+        // ---- stage the g halo tile: fp32 -> GroupNorm affine -> bf16, zero outside the volume
+        for (int item = t; item < WG_G_ITEMS; item += 512) {
+            const int q = item & 7, hv = item >> 3;
+            const int hz = hv / (WG_HY * WG_HX), rem = hv - hz * (WG_HY * WG_HX);
+            const int hy = rem / WG_HX, hx = rem - hy * WG_HX;
+            const int z = z0 - 1 + hz, y = y0 - 1 + hy, xx = x0 - 1 + hx;
+            bf16x4 o = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+            if ((unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
+                const size_t vox = (((size_t)n * p.D + z) * p.H + y) * p.W + xx;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + vox * p.C + c0 + 4 * q);
+                f32x4 ga, gb;
+                u3d_load_affine(p.affine, n, p.C, c0 + 4 * q, true, ga, gb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (__bf16)fmaf(v[e], ga[e], gb[e]);
+            }
+            *reinterpret_cast<bf16x4*>(lds + hv * 64 + q * 8) = o;
+        }
+        // ---- stage the dz tile (two 32-channel halves)
+        for (int item = t; item < WG_DZ_ITEMS; item += 512) {
+            const int q = item & 15, v = item >> 4;
+            const int zl = v / (WG_TY * WG_TX), rem = v - zl * (WG_TY * WG_TX);
+            const int yl = rem / WG_TX, xl = rem - yl * WG_TX;
+            const int z = z0 + zl, y = y0 + yl, xx = x0 + xl;
+            bf16x4 o = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+            if (z < p.D && y < p.H && xx < p.W) {
+                const size_t vox = (((size_t)n * p.D + z) * p.H + y) * p.W + xx;
+                const f32x4 d = *reinterpret_cast<const f32x4*>(p.dz + vox * p.K + k0 + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (__bf16)d[e];
+            }
+            *reinterpret_cast<bf16x4*>(lds + WG_G_BYTES + (q >> 3) * WG_DZ_HALF + v * 64 + (q & 7) * 8) = o;
+        }
+        __syncthreads();
+        // ---- 16 rows of 16 voxels: one dz fragment per row, one g fragment + MFMA per tap of this wave
+#pragma unroll 2
+        for (int kg = 0; kg < WG_TZ * WG_TY; ++kg) {
+            const int zl = kg / WG_TY, yl = kg % WG_TY;
+            const bf16x8 b = tr_frag(lds + b_off + (zl * WG_TY + yl) * WG_TX * 64);
+            const int row = (zl * WG_HY + yl) * WG_HX * 64;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                if (i < 6 || wq < 3) {
+                    const bf16x8 a = tr_frag(lds + a_off[i] + row);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- partial sums: ws[split][pair][tap][ci 32][co 64]; D layout: column = lane & 31 (co), row = ci
+    float* dst = p.ws + ((size_t)split * P + pair) * 27 * 2048;
+    const int col = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int tap = wq + 4 * i;
+        if (tap < 27) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ci = (e & 3) + 8 * (e >> 2) + 4 * half;
+                dst[(size_t)tap * 2048 + ci * 64 + h * 32 + col] = acc[i][e];
+            }
+        }
+    }
+}
+
+// dw[co][ci][tap] (or a channel slice of it) = sum over splits, fixed order
+__global__ void wgrad_bf16_reduce_kernel(const float* __restrict__ ws, int S, int C, int K, float* __restrict__ dw) {
+    const int pco = K >> 6, P = (C >> 5) * pco;
+    const long long total = (long long)C * K * 27;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        // read-coalesced order: co fastest, then ci, then tap
+        const int co = (int)(i % K);
+        long long r = i / K;
+        const int ci = (int)(r % C);
+        const int tap = (int)(r / C);
+        const int pair = (ci >> 5) * pco + (co >> 6);
+        const size_t off = ((size_t)pair * 27 + tap) * 2048 + (ci & 31) * 64 + (co & 63);
+        double sum = 0.0;
+        for (int s = 0; s < S; ++s) sum += (double)ws[(size_t)s * P * 27 * 2048 + off];
+        dw[((size_t)co * C + ci) * 27 + tap] = (float)sum;
+    }
+}
+
+struct wgrad_plan {
+    int tz, ty, tx, tiles, per_block, S, P;
+};
+wgrad_plan plan_wgrad(int N, int D, int H, int W, int C, int K) {
+    wgrad_plan q;
+    q.tz = (D + WG_TZ - 1) / WG_TZ;
+    q.ty = (H + WG_TY - 1) / WG_TY;
+    q.tx = (W + WG_TX - 1) / WG_TX;
+    q.tiles = N * q.tz * q.ty * q.tx;
+    q.P = (C / 32) * (K / 64);
+    int target = 1024 / q.P;  // ~4 blocks per CU in total, 2 resident
+    if (target < 1) target = 1;
+    q.per_block = (q.tiles + target - 1) / target;
+    if (q.per_block < 1) q.per_block = 1;
+    q.S = (q.tiles + q.per_block - 1) / q.per_block;
+    return q;
+}
+
+}  // namespace
+
+extern "C" int u3d_conv3d_wgrad_bf16_supported(int C, int K) { return (C > 0 && K > 0 && C % 32 == 0 && K % 64 == 0) ? 1 : 0; }
+
+extern "C" long long u3d_wgrad_bf16_workspace_floats(int N, int D, int H, int W, int C, int K) {
+    if (!u3d_conv3d_wgrad_bf16_supported(C, K) || N <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    const wgrad_plan q = plan_wgrad(N, D, H, W, C, K);
+    return (long long)q.S * q.P * 27 * 2048;
+}
+
+extern "C" int u3d_conv3d_wgrad_bf16(int device, u3d_stream_t stream, const float* x, const float* affine, const float* dz,
+                                     float* dw, int N, int D, int H, int W, int C, int K, float* workspace,
+                                     long long workspace_floats) {
+    U3D_ENTER(device);
+    U3D_REQUIRE(x && dz && dw && N > 0 && D > 0 && H > 0 && W > 0, "u3d_conv3d_wgrad_bf16: bad argument");
+    U3D_REQUIRE(u3d_conv3d_wgrad_bf16_supported(C, K), "u3d_conv3d_wgrad_bf16: needs Cin %% 32 == 0 and Cout %% 64 == 0 (got %d, %d)", C, K);
+    U3D_REQUIRE((((uintptr_t)x | (uintptr_t)dz | (uintptr_t)affine) & 15) == 0, "u3d_conv3d_wgrad_bf16: 16-byte alignment");
+    const wgrad_plan q = plan_wgrad(N, D, H, W, C, K);
+    const long long need = (long long)q.S * q.P * 27 * 2048;
+    if (!workspace || workspace_floats < need)
+        return u3d_set_err(U3D_EWORKSPACE, "u3d_conv3d_wgrad_bf16: workspace of %lld floats needed, %lld given", need, workspace_floats);
+    bf16_wgrad_params p{x, affine, dz, workspace, N, D, H, W, C, K, q.tz, q.ty, q.tx, q.tiles, q.per_block, K / 64};
+    hipLaunchKernelGGL(conv3d_wgrad_bf16_kernel, dim3((unsigned)(q.S * q.P)), dim3(512), 0, (hipStream_t)stream, p);
+    U3D_LAUNCH_CHECK();
+    long long rb = ((long long)C * K * 27 + 255) / 256;
+    if (rb > 8192) rb = 8192;
+    hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, (hipStream_t)stream, workspace, q.S, C, K, dw);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}

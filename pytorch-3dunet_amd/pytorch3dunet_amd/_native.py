@@ -202,6 +202,20 @@ _PROTOS = {
          c_void_p],
     ),
     "u3d_bce_dice_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "u3d_conv3d_bf16_supported": (c_int, [c_int, c_int]),
+    "u3d_packed_weight_bf16_elems": (c_int64, [c_int, c_int, c_int]),
+    "u3d_pack_weights_bf16": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "u3d_conv3d_bf16": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+         c_void_p, c_void_p, c_void_p],
+    ),
+    "u3d_conv3d_wgrad_bf16_supported": (c_int, [c_int, c_int]),
+    "u3d_wgrad_bf16_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "u3d_conv3d_wgrad_bf16": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64],
+    ),
     "u3d_cvt_f64_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64]),
     "u3d_ncdhw_to_ndhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64]),
     "u3d_ndhwc_to_ncdhw": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64]),
@@ -245,7 +259,7 @@ def get_lib():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.u3d_version() < 100:
+        if lib.u3d_version() < 110:
             raise U3DError("libu3d_hip.so is older than the Python host code")
         _lib = lib
     return _lib
