@@ -211,7 +211,11 @@ class _StatPool:
         self.off = 0
 
     def take(self, n: int) -> torch.Tensor:
-        assert self.off + n <= self.buf.numel(), "stat pool exhausted"
+        if self.off + n > self.buf.numel():
+            # (recomputed blocks of the activation-checkpointing path are not known when the pool is sized) — a fresh zeroed
+            # chunk; slices handed out earlier keep the old buffer alive
+            self.buf = torch.zeros(max(n, 1 << 16), dtype=torch.float64, device=self.buf.device)
+            self.off = 0
         s = self.buf[self.off : self.off + n]
         self.off += n
         return s
@@ -241,6 +245,13 @@ class _BwdCtx:
     def gview(self, idx):
         e = self._e
         return self.flat[e.poffs[idx] : e.poffs[idx] + e.params[idx].numel()]
+
+    def ensure_ws(self, floats):
+        """the shared scratch buffer, grown on demand (kernels already queued on this stream keep using the old block: the
+        caching allocator only hands it out again to later work of the same stream)"""
+        if self.ws.numel() < floats:
+            self.ws = torch.empty(int(floats), dtype=_F32, device=self.dev)
+        return self.ws
 
     def side_stream(self, ws_floats):
         if self.side is None:
@@ -277,6 +288,12 @@ class UNet3DEngine:
         self.overlap_small_wgrad = True  # weight gradients of small layers on a second HIP stream (see _BwdCtx)
         # decoder first convs over an exact-2x upsampling: sub-pixel convolution of the upsampled half (csrc/u3d_subpix.hip)
         self.subpixel = os.environ.get("U3D_SUBPIXEL", "1") != "0"
+        # opt-in (BASELINE config 4): bf16 MFMA operands with fp32 accumulation for the 3x3x3 convolutions whose channel
+        # counts allow it (csrc/u3d_bf16.hip), fp32 master weights / activations / statistics; and recomputation of the
+        # encoder blocks in backward instead of keeping their intermediates.  Set through the model
+        # (`compute_dtype: bf16`, `checkpoint_encoders: true` in the YAML's model section, or U3D_BF16=1 / U3D_CHECKPOINT=1).
+        self.bf16 = bool(getattr(model, "compute_bf16", False))
+        self.checkpoint_encoders = bool(getattr(model, "checkpoint_encoders", False))
         # id(conv weight) -> (C0, C1) of every decoder first conv (static); WHICH of them take the sub-pixel path depends on
         # the input size and is per-call state (`sub` argument / ConvRec.sub), never stored on the engine: forwards at
         # different sizes, other threads and nn.DataParallel replicas must not see each other's choice
@@ -286,6 +303,7 @@ class UNet3DEngine:
         self._pids = [id(p) for p in self.params]
         self._pindex = {id(p): i for i, p in enumerate(self.params)}
         self._build_layer_table(model)
+        self._virtual_w = self._virtual_weights()
         # split point of the flat gradient buffer: encoders first (module order), then decoders + head
         n_enc = sum(p.numel() for p in module_params(model.encoders))
         self.n_enc_params = n_enc
@@ -295,6 +313,10 @@ class UNet3DEngine:
             offs.append(o)
             o += p.numel()
         self.poffs = offs
+
+    def _virtual_weights(self):
+        """ids of the conv weights whose input is a virtual concat (decoder first convs): fp32 kernels only"""
+        return {id(c1.conv.weight) for c1, _ in self.dec}
 
     def _build_layer_table(self, model):
         self.enc = []
@@ -307,6 +329,26 @@ class UNet3DEngine:
             self.dec.append((bm.SingleConv1, bm.SingleConv2))
 
     # -- helpers ------------------------------------------------------------------------------------
+    def _bf16_layer(self, Cin: int, Cout: int) -> bool:
+        """forward AND data gradient of a (Cin -> Cout) 3x3x3 conv can run on the bf16 kernels (both directions need the
+        contraction channels % 16 and the produced channels % 32)"""
+        return self.bf16 and Cin % 32 == 0 and Cout % 32 == 0
+
+    def _packed_bf16(self, w: torch.Tensor, mode: int, dev) -> torch.Tensor:
+        """bf16 fragment image of an fp32 master weight (u3d_pack_weights_bf16), cached per parameter version"""
+        key = (id(w), 20 + mode)
+        ver = (w._version, w.data_ptr())
+        hit = self._pack_cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        Cout, Cin = w.shape[0], w.shape[1]
+        n = nat.get_lib().u3d_packed_weight_bf16_elems(Cin, Cout, mode)
+        out = hit[1] if hit is not None and hit[1].numel() == n and hit[1].device == dev else torch.empty(
+            n, dtype=torch.bfloat16, device=dev)
+        nat.call("u3d_pack_weights_bf16", dev.index, _stream(dev), _p(w.detach()), Cout, Cin, mode, _p(out))
+        self._pack_cache[key] = (ver, out)
+        return out
+
     def _conv_weights(self):
         """every 3x3x3 conv weight the MFMA kernels read through a packed image"""
         out = []
@@ -342,6 +384,8 @@ class UNet3DEngine:
         for w in ws:
             if self.small_cin and w.shape[1] <= 4 and w.shape[0] <= 32:
                 continue  # first layer: dedicated kernels read the reference layout
+            if self._bf16_layer(w.shape[1], w.shape[0]) and id(w) not in self._virtual_w:
+                continue  # bf16 fragment images are packed on demand (_packed_bf16)
             wmodes = modes
             if id(w) in sub:
                 wmodes = tuple(mm + 10 for mm in modes) + tuple(mm + 12 for mm in modes)
@@ -454,7 +498,7 @@ class UNet3DEngine:
         return st, src.C, 1.0, None, 0, 0.0
 
     def _single_conv_fwd(self, sc, name, src: VSrc, st_in, pool: _StatPool, tape: Optional[Tape], want_stats=True,
-                         residual: Optional[torch.Tensor] = None, sub=()):
+                         residual: Optional[torch.Tensor] = None, sub=(), y_out: Optional[torch.Tensor] = None):
         """GroupNorm -> Conv3d -> ReLU of one SingleConv; with `residual`: ReLU(conv(GN(x)) + residual), the tail of
         ResNetBlock.forward (buildingblocks.py:277-288)."""
         dev = src.t0.device
@@ -467,7 +511,9 @@ class UNet3DEngine:
         mean_rstd = torch.empty((N, G, 2), dtype=_F32, device=dev)
         nat.call("u3d_gn_finalize", dev.index, _stream(dev), _p(st0), C0, sc0, _p(st1), C1, sc1, N, G,
                  float(D * H * W), _p(gn.weight.detach()), _p(gn.bias.detach()), float(gn.eps), _p(affine), _p(mean_rstd))
-        y = torch.empty((N, D, H, W, Cout), dtype=_F32, device=dev)
+        # y_out: recomputation under activation checkpointing rewrites the (still alive) block output in place with the
+        # bit-identical values instead of allocating a second copy
+        y = y_out if y_out is not None else torch.empty((N, D, H, W, Cout), dtype=_F32, device=dev)
         small = self.small_cin and src.t1 is None and Ctot <= 4 and Cout <= 32 and residual is None
         if small:
             # first layer of the network: K = 27*Cin is too small for the MFMA tiling (csrc/u3d_smallc.hip)
@@ -491,6 +537,12 @@ class UNet3DEngine:
             nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s0), _p(self._pack_cache[(id(conv.weight), 10)][1]),
                      _p(y), N, D, H, W, Cout, 1, _p(ystats), None, None, _p(part), None, 0,
                      flops=54.0 * C0 * Cout * N * D * H * W)
+        elif src.t1 is None and self._bf16_layer(Ctot, Cout):
+            # bf16 MFMA operands, fp32 accumulation / epilogue (csrc/u3d_bf16.hip)
+            ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
+            nat.call("u3d_conv3d_bf16", dev.index, _stream(dev), _p(src.t0), _p(affine), _p(self._packed_bf16(conv.weight, 0, dev)),
+                     _p(y), N, D, H, W, Ctot, Cout, 1, _p(ystats), None, None, _p(residual),
+                     flops=54.0 * Ctot * Cout * N * D * H * W)
         else:
             wp = self._packed(conv.weight, 0, dev)
             ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
@@ -529,7 +581,13 @@ class UNet3DEngine:
             return None, coef
         s_aff = src.struct(rec.affine)
         flops = 54.0 * src.C * Cout * Nn * Dd * Hh * Ww
-        if rec.sub is not None:
+        bf16 = src.t1 is None and rec.sub is None and not rec.small and self._bf16_layer(src.C, Cout)
+        if bf16 and Cout % 64 == 0:
+            need = nat.get_lib().u3d_wgrad_bf16_workspace_floats(Nn, Dd, Hh, Ww, src.C, Cout)
+            ws = cx.ensure_ws(need)
+            nat.call("u3d_conv3d_wgrad_bf16", dev.index, _stream(dev), _p(src.t0), _p(rec.affine), _p(dz_), _p(gview(rec.idx_w)),
+                     Nn, Dd, Hh, Ww, src.C, Cout, _p(ws), ws.numel(), flops=flops)
+        elif rec.sub is not None:
             # weight gradient in two channel slices of the same (Cout, Ctot, 27) buffer: upsampled channels from the 64
             # (parity class, tap half) matrices over the low-res grid, skip channels from the standard kernel
             C0, C1 = rec.sub
@@ -573,6 +631,11 @@ class UNet3DEngine:
                      flops=128.0 * C1 * Cout * Nn * src.D1 * src.H1 * src.W1)
             gst = torch.cat((gst0.view(Nn, C0, 2), gst1.view(Nn, C1, 2)), dim=1)
             dg = (dg0, dlow)
+        elif bf16:
+            dg = torch.empty((Nn, Dd, Hh, Ww, src.C), dtype=_F32, device=dev)
+            gst = pool.take(Nn * src.C * 2)
+            nat.call("u3d_conv3d_bf16", dev.index, _stream(dev), _p(dz_), None, _p(self._packed_bf16(rec.conv_w, 1, dev)), _p(dg),
+                     Nn, Dd, Hh, Ww, Cout, src.C, 0, None, _p(src.t0), _p(gst), None, flops=flops)
         else:
             wpd = self._packed(rec.conv_w, 1, dev)
             dg = torch.empty((Nn, Dd, Hh, Ww, src.C), dtype=_F32, device=dev)
@@ -602,9 +665,14 @@ class UNet3DEngine:
         return out
 
     def _wgrad_workspace(self, tape, dev):
+        return torch.empty(max(self._wgrad_workspace_floats(tape.convs), 4), dtype=_F32, device=dev)
+
+    def _wgrad_workspace_floats(self, convs):
+        """scratch floats the fp32 weight-gradient / split-K kernels of these layers need (bf16 layers grow the buffer on
+        demand, _BwdCtx.ensure_ws)"""
         lib = nat.get_lib()
         ws_floats = 0
-        for r in tape.convs:
+        for r in convs:
             Nn, Co = r.src.N, r.y.shape[-1]
             if r.sub is not None:  # skip slice + sub-pixel slice
                 ws_floats = max(ws_floats, lib.u3d_wgrad_workspace_floats(Nn, r.src.D, r.src.H, r.src.W, r.sub[0], Co),
@@ -614,11 +682,11 @@ class UNet3DEngine:
             if not r.small:  # split-K scratch of the data gradient (Cin and Cout swap roles)
                 ws_floats = max(ws_floats, lib.u3d_conv3d_workspace_floats(r.src.N, r.src.D, r.src.H, r.src.W, r.y.shape[-1],
                                                                            r.sub[0] if r.sub is not None else r.src.C))
-        r0 = tape.convs[0]
-        if r0.small:
-            ws_floats = max(ws_floats, lib.u3d_small_cin_bwd_workspace_floats(r0.src.N, r0.src.D, r0.src.H, r0.src.W,
-                                                                              r0.src.C, r0.y.shape[-1]))
-        return torch.empty(max(ws_floats, 4), dtype=_F32, device=dev)
+        for r0 in convs:
+            if r0.small:
+                ws_floats = max(ws_floats, lib.u3d_small_cin_bwd_workspace_floats(r0.src.N, r0.src.D, r0.src.H, r0.src.W,
+                                                                                  r0.src.C, r0.y.shape[-1]))
+        return int(ws_floats)
 
     # -- forward ------------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, save: bool):
@@ -830,6 +898,16 @@ class ResRec:
 
 
 @dataclass
+class CkptRec:
+    """an encoder block under activation checkpointing: only its input is kept, `_block_fwd` is re-run in backward"""
+
+    name: str
+    bm: torch.nn.Module
+    x_in: torch.Tensor
+    out: torch.Tensor  # the block output (alive anyway: skip connection / pool input); rewritten in place by the recomputation
+
+
+@dataclass
 class UpRec:
     """TransposeConvUpsampling + summation joining of one decoder (buildingblocks.py:617-664, :493)"""
 
@@ -847,6 +925,9 @@ class ResUNetEngine(UNet3DEngine):
     block's `out += residual; ReLU` fused into conv3's epilogue (u3d_conv3d_residual); GroupNorm statistics of the
     residual come out of the 1x1x1 conv's / the joining kernel's epilogue.  The 1x1x1 convolutions and the transposed
     convolution run on the FP32 vector units (csrc/u3d_res.hip)."""
+
+    def _virtual_weights(self):
+        return set()  # summation joining: every 3x3x3 conv reads one real tensor
 
     def _build_layer_table(self, model):
         self.enc = [(e.pooling is not None, e.basic_module) for e in model.encoders]
@@ -870,7 +951,7 @@ class ResUNetEngine(UNet3DEngine):
         return out
 
     # -- forward ------------------------------------------------------------------------------------
-    def _block_fwd(self, bm, name, x_in, x_st, pool, tape, dev):
+    def _block_fwd(self, bm, name, x_in, x_st, pool, tape, dev, y_out=None):
         N, D, H, W, Cin = x_in.shape
         Cout = bm.conv2.conv.in_channels
         conv1 = None if isinstance(bm.conv1, torch.nn.Identity) else bm.conv1
@@ -892,7 +973,7 @@ class ResUNetEngine(UNet3DEngine):
         src3 = VSrc(out2)
         se_mod = getattr(bm, "se_module", None)
         y, y_st = self._single_conv_fwd(bm.conv3, name + ".c3", src3, (st2, Cout, 1.0, None, 0, 0.0), pool, tape,
-                                        want_stats=se_mod is not None, residual=r)
+                                        want_stats=se_mod is not None, residual=r, y_out=y_out if se_mod is None else None)
         se = None
         out = y
         if se_mod is not None:
@@ -999,7 +1080,13 @@ class ResUNetEngine(UNet3DEngine):
                 if tape is not None:
                     tape.pools.append((pooled, argmax, cur))
                 cur = pooled
-            cur = self._block_fwd(bm, f"enc{i}", cur, None, pool, tape, dev)
+            if tape is not None and self.checkpoint_encoders:
+                # activation checkpointing of the encoder blocks (BASELINE config 4): keep the block input only
+                x_in = cur
+                cur = self._block_fwd(bm, f"enc{i}", cur, None, pool, None, dev)
+                tape.blocks.append(CkptRec(f"enc{i}", bm, x_in, cur))
+            else:
+                cur = self._block_fwd(bm, f"enc{i}", cur, None, pool, tape, dev)
             feats.append(cur)
 
         skips = feats[:-1][::-1]
@@ -1066,12 +1153,12 @@ class ResUNetEngine(UNet3DEngine):
         Co, Cf = fc.out_channels, fc.in_channels
         tot = Co * Cf + Co + sum(N * r.src.C * 2 for r in tape.convs)
         for b in tape.blocks:
-            if b.conv1 is not None:
+            if isinstance(b, ResRec) and b.conv1 is not None:
                 tot += b.conv1.weight.numel() + b.conv1.bias.numel()
         for u in tape.ups:
             tot += u.weight.numel()
         for b in tape.blocks:
-            if b.se is not None:
+            if isinstance(b, ResRec) and b.se is not None:
                 tot += (N + 1) * b.se["y"].shape[-1] + 1
         pool = _StatPool(dev, tot)
         ws = self._wgrad_workspace(tape, dev)
@@ -1119,6 +1206,14 @@ class ResUNetEngine(UNet3DEngine):
         dx0 = None
         for i in range(n_levels - 1, -1, -1):
             rec = enc_blocks[i]
+            if isinstance(rec, CkptRec):
+                # recompute the block's forward (bit-identical kernels, same inputs) to rebuild what backward needs
+                tmp = Tape()
+                fpool = _StatPool(dev, 16 * rec.x_in.shape[0] * rec.bm.conv2.conv.in_channels * 2 + 64)
+                self._block_fwd(rec.bm, rec.name, rec.x_in, None, fpool, tmp, dev, y_out=rec.out)
+                cx.ensure_ws(self._wgrad_workspace_floats(tmp.convs))
+                rec = tmp.blocks[0]
+                del tmp, fpool
             dr = self._block_bwd(cx, rec, dz)
             need_dx = i > 0 or need_input_grad
             if rec.conv1 is not None:

@@ -31,7 +31,8 @@ class AbstractUNet(nn.Module):
 
     def __init__(self, in_channels, out_channels, final_sigmoid, basic_module, f_maps=64, layer_order="gcr",
                  num_groups=8, num_levels=4, is_segmentation=True, conv_kernel_size=3, pool_kernel_size=2,
-                 conv_padding=1, conv_upscale=2, upsample="default", dropout_prob=0.1, is3d=True):
+                 conv_padding=1, conv_upscale=2, upsample="default", dropout_prob=0.1, is3d=True, compute_dtype=None,
+                 checkpoint_encoders=None):
         super().__init__()
         if isinstance(f_maps, int):
             f_maps = number_of_features_per_level(f_maps, num_levels=num_levels)
@@ -73,6 +74,16 @@ class AbstractUNet(nn.Module):
             reasons.append(f"upsample '{upsample}' with residual blocks")
         if out_channels > 16 or f_maps[0] > 256:
             reasons.append("head wider than 16 outputs / 256 inputs")
+        # opt-in extras of the native executor (extra keys of the YAML's model section are swallowed by the reference's **kwargs):
+        # bf16 MFMA operands with fp32 accumulation / master weights, and recomputation of the encoder blocks in backward
+        if compute_dtype is None:
+            compute_dtype = "bf16" if os.environ.get("U3D_BF16", "0") == "1" else "fp32"
+        if str(compute_dtype).lower() not in ("fp32", "float32", "bf16", "bfloat16"):
+            raise ValueError(f"compute_dtype must be 'fp32' or 'bf16', got {compute_dtype!r}")
+        self.compute_bf16 = str(compute_dtype).lower() in ("bf16", "bfloat16")
+        if checkpoint_encoders is None:
+            checkpoint_encoders = os.environ.get("U3D_CHECKPOINT", "0") == "1"
+        self.checkpoint_encoders = bool(checkpoint_encoders)
         self._native_blockers = reasons
         self._residual = basic_module in (ResNetBlock, ResNetBlockSE)
         self._engine = None
@@ -148,7 +159,8 @@ def _variant(name, basic_module, default_levels, is3d, doc):
         AbstractUNet.__init__(self, in_channels=in_channels, out_channels=out_channels, final_sigmoid=final_sigmoid,
                               basic_module=basic_module, f_maps=f_maps, layer_order=layer_order, num_groups=num_groups,
                               num_levels=num_levels, is_segmentation=is_segmentation, conv_padding=conv_padding,
-                              conv_upscale=conv_upscale, upsample=upsample, dropout_prob=dropout_prob, is3d=is3d)
+                              conv_upscale=conv_upscale, upsample=upsample, dropout_prob=dropout_prob, is3d=is3d,
+                              compute_dtype=kwargs.get("compute_dtype"), checkpoint_encoders=kwargs.get("checkpoint_encoders"))
 
     return type(name, (AbstractUNet,), {"__init__": __init__, "__doc__": doc, "__module__": _THIS_MODULE})
 

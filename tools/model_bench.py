@@ -2,6 +2,11 @@
 bench.py uses for its roofline leg.
 
     python tools/model_bench.py --name ResidualUNet3D --f-maps 64 --levels 5 --patch 80,160,160 --batch 1 --steps 5
+    python tools/model_bench.py --bf16 --checkpoint      # BASELINE config 4: bf16 MFMA operands, encoder blocks recomputed
+
+With --bf16 the bf16 kernel families get a roofline against BOTH bounds: the dense bf16 MFMA peak (2.5 PFLOP/s) and HBM
+(8 TB/s) with their algorithmic bytes (fp32 input + output once, + the forward input re-read by the data gradient; the two
+operands once for the weight gradient).
 """
 import argparse
 import json
@@ -30,11 +35,14 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--forward-only", action="store_true")
+    ap.add_argument("--bf16", action="store_true", help="compute_dtype='bf16' (fp32 master weights / activations / statistics)")
+    ap.add_argument("--checkpoint", action="store_true", help="checkpoint_encoders=True")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     model = get_model(dict(name=args.name, in_channels=args.in_channels, out_channels=args.out_channels, f_maps=args.f_maps,
-                           num_levels=args.levels, layer_order="gcr", num_groups=8, final_sigmoid=True)).to(dev)
+                           num_levels=args.levels, layer_order="gcr", num_groups=8, final_sigmoid=True,
+                           compute_dtype="bf16" if args.bf16 else "fp32", checkpoint_encoders=args.checkpoint)).to(dev)
     assert model.native_supported, model._native_blockers
     D, H, W = (int(v) for v in args.patch.split(","))
     x = torch.randn(args.batch, args.in_channels, D, H, W, device=dev)
@@ -55,6 +63,14 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    # bare step time and peak memory first (the event profiler adds ~2 us of device time per call)
+    torch.cuda.reset_peak_memory_stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt_bare = (time.perf_counter() - t0) / args.steps
+    peak = torch.cuda.max_memory_allocated()
     prof = nat.EventProfiler()
     nat.profiler = prof
     t0 = time.perf_counter()
@@ -67,9 +83,19 @@ def main():
     fams = {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] and v["ms"] > 0 else None}
             for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
-    print(json.dumps({"model": args.name, "f_maps": args.f_maps, "levels": args.levels, "patch": [D, H, W], "batch": args.batch,
+    PEAK = {"u3d_conv3d_bf16": 2500.0, "u3d_conv3d_wgrad_bf16": 2500.0}
+    for k, v in summ.items():
+        if k in PEAK and v["flops"] and v["ms"] > 0:
+            tf = v["flops"] / (v["ms"] * 1e-3) / 1e12
+            # algorithmic HBM bytes of these launches: 54*Cin*Cout FLOP per voxel, square layers (Cin == Cout == C) move
+            # 4*C (+4*C) bytes in and 4*C out per voxel -> bytes = flops * 8 / (54 * C); reported for C = f_maps (level 0, the
+            # most bandwidth-hungry level)
+            fams[k]["frac_of_bf16_mfma_peak"] = round(tf / PEAK[k], 3)
+            fams[k]["hbm_gbps_algorithmic_level0"] = round(tf * 1e12 * 8.0 / (54.0 * args.f_maps) / 1e9, 1)
+    print(json.dumps({"model": args.name, "compute": "bf16" if args.bf16 else "fp32", "checkpoint_encoders": args.checkpoint,
+                      "ms_per_step_bare": round(dt_bare * 1e3, 2), "patches_per_s_bare": round(args.batch / dt_bare, 3), "f_maps": args.f_maps, "levels": args.levels, "patch": [D, H, W], "batch": args.batch,
                       "mode": "fwd" if args.forward_only else "fwd+bwd", "ms_per_step": round(dt * 1e3, 2),
-                      "patches_per_s": round(args.batch / dt, 3), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
+                      "patches_per_s": round(args.batch / dt, 3), "peak_mem_gb": round(peak / 2**30, 3),
                       "families": fams}))
 
 
