@@ -381,6 +381,20 @@ long long u3d_wgrad_bf16_workspace_floats(int N, int D, int H, int W, int Cin, i
 int u3d_conv3d_wgrad_bf16(int device, u3d_stream_t stream, const float* x, const float* affine, const float* dz, float* dw,
                           int N, int D, int H, int W, int Cin, int Cout, float* workspace, long long workspace_floats);
 
+/* ---- layer orders other than 'gcr' (buildingblocks.py:10-96): LeakyReLU / ELU, GroupNorm after the convolution --------
+ * Activation codes: 0 none, 1 nn.ReLU, 2 nn.LeakyReLU(slope) (buildingblocks.py:49: 0.01; ResNetBlock :271: 0.1), 3 nn.ELU
+ * (alpha 1, :51).  The convolutions run with their epilogue ReLU off; these passes supply the rest:
+ *   u3d_act_fwd         out = f(x), n elements (in place allowed)
+ *   u3d_act_bwd         out = g * f'(.) with the derivative expressed through the OUTPUT y of f (in place on g allowed)
+ *   u3d_affine_act_fwd  out[n,v,c] = f(a[n,c]*z[n,v,c] + b[n,c]): nn.GroupNorm apply (+ non-linearity) of a post-norm layer
+ *                       ('cgr' family, GroupNorm on the conv OUTPUT channels, buildingblocks.py:62-66); affine (N,C,2)
+ *   u3d_pair_stats      stats double[N][C][2] += (sum_v a, sum_v a*b): the reductions nn.GroupNorm's backward needs */
+int u3d_act_fwd(int device, u3d_stream_t stream, const float* x, int64_t n, int mode, float slope, float* out);
+int u3d_act_bwd(int device, u3d_stream_t stream, const float* g, const float* y, int64_t n, int mode, float slope, float* out);
+int u3d_affine_act_fwd(int device, u3d_stream_t stream, const float* z, const float* affine, int N, int64_t V, int C, int mode,
+                       float slope, float* out);
+int u3d_pair_stats(int device, u3d_stream_t stream, const float* a, const float* b, int N, int64_t V, int C, double* stats);
+
 /* ---- layout: NCDHW <-> NDHWC for multi-channel model inputs ------------------------------------ */
 int u3d_ncdhw_to_ndhwc(int device, u3d_stream_t stream, const float* src, float* dst, int N, int C, int64_t V);
 int u3d_ndhwc_to_ncdhw(int device, u3d_stream_t stream, const float* src, float* dst, int N, int C, int64_t V);

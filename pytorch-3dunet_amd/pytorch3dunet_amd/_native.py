@@ -216,6 +216,10 @@ _PROTOS = {
         c_int,
         [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64],
     ),
+    "u3d_act_fwd": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
+    "u3d_act_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
+    "u3d_affine_act_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_float, c_void_p]),
+    "u3d_pair_stats": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
     "u3d_cvt_f64_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64]),
     "u3d_ncdhw_to_ndhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64]),
     "u3d_ndhwc_to_ncdhw": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64]),

@@ -173,6 +173,23 @@ class VSrc:
 
 
 # ---------------------------------------------------------------------------------------------------------
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU = 0, 1, 2, 3  # activation codes of include/u3d.h (u3d_act_fwd)
+
+
+def parse_order(order: str):
+    """The layer-order strings (buildingblocks.py:10-96) the executor runs natively -> (post_norm, act, slope), else None.
+    Native: one GroupNorm + Conv3d, the GroupNorm before ('gc…': normalises the conv INPUT) or after the conv ('cg…': the
+    conv OUTPUT), optionally followed by ONE non-linearity at the end: ReLU 'r', LeakyReLU(0.01) 'l', ELU 'e'.  Everything
+    else (no norm -> conv with bias, BatchNorm 'b', dropout 'd'/'D', a non-linearity before the norm) runs the module tree."""
+    if not order or any(ch not in "gcrle" for ch in order) or order.count("c") != 1 or order.count("g") != 1:
+        return None
+    acts = [ch for ch in order if ch in "rle"]
+    if len(acts) > 1 or (acts and order[-1] != acts[0]):
+        return None
+    act = {"r": ACT_RELU, "l": ACT_LEAKY, "e": ACT_ELU}[acts[0]] if acts else ACT_NONE
+    return order.index("g") > order.index("c"), act, (0.01 if act == ACT_LEAKY else 0.0)
+
+
 @dataclass
 class ConvRec:
     """what one SingleConv ('gcr': GroupNorm -> Conv3d -> ReLU, buildingblocks.py:99-135) saves for backward"""
@@ -190,6 +207,8 @@ class ConvRec:
     idx_w: int = -1
     small: bool = False  # ran through the small-Cin (first layer) kernels
     sub: Optional[tuple] = None  # (C0, C1): the upsampled half ran as a sub-pixel convolution (csrc/u3d_subpix.hip)
+    pre_norm: bool = True        # GroupNorm on the conv input ('gc…'); False: `affine` is the identity table
+    post: Optional[tuple] = None  # post-norm order ('cg…'): (z = conv output, its GroupNorm affine table); y = f(a*z + b)
 
 
 @dataclass
@@ -299,6 +318,11 @@ class UNet3DEngine:
         # different sizes, other threads and nn.DataParallel replicas must not see each other's choice
         self._sub_pairs: dict = {}
         self._lock = threading.RLock()  # host-side enqueue of one forward / backward at a time per engine
+        self._const: dict = {}
+        # the model-wide layer order (every SingleConv of a DoubleConv net shares it): non-linearity of the layer outputs
+        spec = parse_order(getattr(model, "layer_order", "gcr")) or (False, ACT_RELU, 0.0)
+        self.post_norm, self.act, self.slope = spec
+        self.mask = 1 if self.act == ACT_RELU else 0  # ReLU backward is a fused mask in the consumer kernels
         self.params = module_params(model)
         self._pids = [id(p) for p in self.params]
         self._pindex = {id(p): i for i, p in enumerate(self.params)}
@@ -324,9 +348,11 @@ class UNet3DEngine:
             bm = enc.basic_module
             self.enc.append((enc.pooling is not None, bm.SingleConv1, bm.SingleConv2))
         self.dec = []
+        self.dec_up = []  # upsample='deconv' (buildingblocks.py:445-451): the decoder's ConvTranspose3d, else None (nearest)
         for dec in model.decoders:
             bm = dec.basic_module
             self.dec.append((bm.SingleConv1, bm.SingleConv2))
+            self.dec_up.append(getattr(getattr(dec.upsampling, "upsample", None), "conv_transposed", None))
 
     # -- helpers ------------------------------------------------------------------------------------
     def _bf16_layer(self, Cin: int, Cout: int) -> bool:
@@ -346,6 +372,23 @@ class UNet3DEngine:
         out = hit[1] if hit is not None and hit[1].numel() == n and hit[1].device == dev else torch.empty(
             n, dtype=torch.bfloat16, device=dev)
         nat.call("u3d_pack_weights_bf16", dev.index, _stream(dev), _p(w.detach()), Cout, Cin, mode, _p(out))
+        self._pack_cache[key] = (ver, out)
+        return out
+
+    def _packed_convtr(self, w: torch.Tensor, mode: int, dev) -> torch.Tensor:
+        """[tap][Cin][Cout] (mode 0) / [tap][Cout][Cin] (mode 1) image of a ConvTranspose3d weight, cached per version"""
+        key = (id(w), 10 + mode)
+        ver = (w._version, w.data_ptr())
+        hit = self._pack_cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        Cin, Cout = w.shape[0], w.shape[1]
+        if mode == 2:  # fragment image of the sub-pixel forward kernel
+            out = torch.empty(nat.get_lib().u3d_convtr3d_subpixel_packed_floats(Cin, Cout), dtype=_F32, device=dev)
+            nat.call("u3d_pack_convtr3d_subpixel", dev.index, _stream(dev), _p(w.detach()), Cin, Cout, _p(out))
+        else:
+            out = torch.empty(27 * Cin * Cout, dtype=_F32, device=dev)
+            nat.call("u3d_pack_convtr_weights", dev.index, _stream(dev), _p(w.detach()), Cin, Cout, mode, _p(out))
         self._pack_cache[key] = (ver, out)
         return out
 
@@ -451,6 +494,28 @@ class UNet3DEngine:
         self._pack_cache[key] = (ver, out)
         return out
 
+    def _identity_affine(self, N, C, dev):
+        """(N,C,2) table a = 1, b = 0: the 'GroupNorm affine' of a conv input that has no GroupNorm (post-norm orders)"""
+        key = ("ida", N, C, str(dev))
+        t = self._const.get(key)
+        if t is None:
+            t = self._const[key] = torch.tensor([1.0, 0.0], dtype=_F32, device=dev).repeat(N, C, 1).contiguous()
+        return t
+
+    def _identity_coef(self, N, C, dev):
+        """(N,3,C) table p = 1, q = 0, r = 0: GroupNorm backward of 'no GroupNorm' (dx = dg)"""
+        key = ("idc", N, C, str(dev))
+        t = self._const.get(key)
+        if t is None:
+            t = self._const[key] = torch.tensor([1.0, 0.0, 0.0], dtype=_F32, device=dev).view(1, 3, 1).repeat(N, 1, C).contiguous()
+        return t
+
+    def _unact(self, dev, g, y):
+        """in place: gradient w.r.t. the activated tensor y -> gradient w.r.t. its pre-activation (LeakyReLU / ELU; ReLU is
+        fused into the producing kernels as a mask, 'no activation' needs nothing)"""
+        if self.act in (ACT_LEAKY, ACT_ELU):
+            nat.call("u3d_act_bwd", dev.index, _stream(dev), _p(g), _p(y), g.numel(), self.act, self.slope, _p(g))
+
     def _up_scale(self, dev):
         """(1, 8, 8) on the (p, q, r) rows of a GroupNorm-backward coefficient table: a low-res voxel stands for 8 children"""
         t = getattr(self, "_up_scale_t", None)
@@ -461,8 +526,8 @@ class UNet3DEngine:
     def _subpixel_layers(self, size):
         """decoder first convs whose low-res input is upsampled by exactly 2 in every dimension at this input size:
         {id(weight): (C0, C1)} — per-call state, handed down as the `sub` argument"""
-        if not self.subpixel:
-            return {}
+        if not self.subpixel or any(ct is not None for ct in self.dec_up):
+            return {}  # (a transposed convolution yields 2n-1 voxels, resized to the skip: never an exact 2x replication)
         dims = [tuple(size)]
         for has_pool, _, _ in self.enc:
             if has_pool:
@@ -498,19 +563,29 @@ class UNet3DEngine:
         return st, src.C, 1.0, None, 0, 0.0
 
     def _single_conv_fwd(self, sc, name, src: VSrc, st_in, pool: _StatPool, tape: Optional[Tape], want_stats=True,
-                         residual: Optional[torch.Tensor] = None, sub=(), y_out: Optional[torch.Tensor] = None):
-        """GroupNorm -> Conv3d -> ReLU of one SingleConv; with `residual`: ReLU(conv(GN(x)) + residual), the tail of
-        ResNetBlock.forward (buildingblocks.py:277-288)."""
+                         residual: Optional[torch.Tensor] = None, sub=(), y_out: Optional[torch.Tensor] = None, act=None):
+        """One SingleConv (buildingblocks.py:99-135) in any native order (parse_order): 'gcr' = GroupNorm -> Conv3d -> ReLU fully
+        fused; other non-linearities / GroupNorm after the conv add one bandwidth pass (csrc/u3d_act.hip).  With `residual`:
+        f(conv(GN(x)) + residual), the tail of ResNetBlock.forward (buildingblocks.py:277-288; `act` = the block's f)."""
         dev = src.t0.device
         gn, conv = sc.groupnorm, sc.conv
         N, D, H, W = src.N, src.D, src.H, src.W
         Ctot, Cout, G = src.C, conv.out_channels, gn.num_groups
-        assert gn.num_channels == Ctot and conv.in_channels == Ctot
-        st0, C0, sc0, st1, C1, sc1 = st_in
-        affine = torch.empty((N, Ctot, 2), dtype=_F32, device=dev)
-        mean_rstd = torch.empty((N, G, 2), dtype=_F32, device=dev)
-        nat.call("u3d_gn_finalize", dev.index, _stream(dev), _p(st0), C0, sc0, _p(st1), C1, sc1, N, G,
-                 float(D * H * W), _p(gn.weight.detach()), _p(gn.bias.detach()), float(gn.eps), _p(affine), _p(mean_rstd))
+        post, act, slope = parse_order(sc.order) if act is None else (False, act[0], act[1])
+        assert conv.in_channels == Ctot and gn.num_channels == (Cout if post else Ctot)
+        assert not (post and residual is not None)
+        relu = 1 if (act == ACT_RELU and not post) else 0
+        # the conv epilogue's statistics describe the conv OUTPUT: they are the next GroupNorm's input only when nothing
+        # else transforms it (ReLU is in the epilogue); a post-norm layer needs them for its own GroupNorm
+        want_stats = post or (want_stats and act in (ACT_NONE, ACT_RELU))
+        if post:
+            affine, mean_rstd = self._identity_affine(N, Ctot, dev), None
+        else:
+            st0, C0, sc0, st1, C1, sc1 = st_in
+            affine = torch.empty((N, Ctot, 2), dtype=_F32, device=dev)
+            mean_rstd = torch.empty((N, G, 2), dtype=_F32, device=dev)
+            nat.call("u3d_gn_finalize", dev.index, _stream(dev), _p(st0), C0, sc0, _p(st1), C1, sc1, N, G,
+                     float(D * H * W), _p(gn.weight.detach()), _p(gn.bias.detach()), float(gn.eps), _p(affine), _p(mean_rstd))
         # y_out: recomputation under activation checkpointing rewrites the (still alive) block output in place with the
         # bit-identical values instead of allocating a second copy
         y = y_out if y_out is not None else torch.empty((N, D, H, W, Cout), dtype=_F32, device=dev)
@@ -519,7 +594,7 @@ class UNet3DEngine:
             # first layer of the network: K = 27*Cin is too small for the MFMA tiling (csrc/u3d_smallc.hip)
             ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
             nat.call("u3d_conv3d_small_cin_fwd", dev.index, _stream(dev), _p(src.t0), _p(affine), _p(conv.weight.detach()),
-                     _p(y), N, D, H, W, Ctot, Cout, 1, _p(ystats), flops=54.0 * Ctot * Cout * N * D * H * W)
+                     _p(y), N, D, H, W, Ctot, Cout, relu, _p(ystats), flops=54.0 * Ctot * Cout * N * D * H * W)
         elif src.t1 is not None and residual is None and id(conv.weight) in sub:
             # cat(skip, nearest2x(low)): the upsampled half as 8 parity-class 2x2x2 convolutions over the low-res tensor
             # (8/27 of the multiply-adds), then the skip half, whose epilogue adds the partial sums before ReLU / statistics
@@ -535,13 +610,13 @@ class UNet3DEngine:
             a0 = affine[:, :C0].contiguous()
             s0 = VSrc(src.t0).struct(a0)
             nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s0), _p(self._pack_cache[(id(conv.weight), 10)][1]),
-                     _p(y), N, D, H, W, Cout, 1, _p(ystats), None, None, _p(part), None, 0,
+                     _p(y), N, D, H, W, Cout, relu, _p(ystats), None, None, _p(part), None, 0,
                      flops=54.0 * C0 * Cout * N * D * H * W)
         elif src.t1 is None and self._bf16_layer(Ctot, Cout):
             # bf16 MFMA operands, fp32 accumulation / epilogue (csrc/u3d_bf16.hip)
             ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
             nat.call("u3d_conv3d_bf16", dev.index, _stream(dev), _p(src.t0), _p(affine), _p(self._packed_bf16(conv.weight, 0, dev)),
-                     _p(y), N, D, H, W, Ctot, Cout, 1, _p(ystats), None, None, _p(residual),
+                     _p(y), N, D, H, W, Ctot, Cout, relu, _p(ystats), None, None, _p(residual),
                      flops=54.0 * Ctot * Cout * N * D * H * W)
         else:
             wp = self._packed(conv.weight, 0, dev)
@@ -550,13 +625,30 @@ class UNet3DEngine:
             # bottom-of-the-U shapes split the channel reduction over blocks through a scratch buffer (0 floats otherwise)
             need = nat.get_lib().u3d_conv3d_workspace_floats(N, D, H, W, Ctot, Cout)
             kws = torch.empty(need, dtype=_F32, device=dev) if need > 0 else None
-            nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s), _p(wp), _p(y), N, D, H, W, Cout, 1,
+            nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s), _p(wp), _p(y), N, D, H, W, Cout, relu,
                      _p(ystats), None, None, _p(residual), _p(kws), need, flops=54.0 * Ctot * Cout * N * D * H * W)
+        post_rec = None
+        if post:
+            # GroupNorm over the conv output z (statistics from the conv epilogue), then the non-linearity: y = f(a*z + b)
+            z, zst = y, ystats
+            if zst is None:
+                zst = self._stats_of(VSrc(z), None, None, pool, dev)[0]
+            aff2 = torch.empty((N, Cout, 2), dtype=_F32, device=dev)
+            mean_rstd = torch.empty((N, G, 2), dtype=_F32, device=dev)
+            nat.call("u3d_gn_finalize", dev.index, _stream(dev), _p(zst), Cout, 1.0, None, 0, 0.0, N, G, float(D * H * W),
+                     _p(gn.weight.detach()), _p(gn.bias.detach()), float(gn.eps), _p(aff2), _p(mean_rstd))
+            y = torch.empty_like(z)
+            nat.call("u3d_affine_act_fwd", dev.index, _stream(dev), _p(z), _p(aff2), N, D * H * W, Cout, act, slope, _p(y))
+            post_rec, ystats = (z, aff2), None
+        elif act in (ACT_LEAKY, ACT_ELU):
+            nat.call("u3d_act_fwd", dev.index, _stream(dev), _p(y), y.numel(), act, slope, _p(y))
+            ystats = None
         if tape is not None:
             tape.convs.append(
                 ConvRec(name, src, affine, mean_rstd, y, gn.weight, conv.weight, G, self._pindex[id(gn.weight)],
                         self._pindex[id(gn.bias)], self._pindex[id(conv.weight)], small,
-                        sub.get(id(conv.weight)) if (sub and src.t1 is not None and residual is None) else None)
+                        sub.get(id(conv.weight)) if (sub and src.t1 is not None and residual is None) else None,
+                        not post, post_rec)
             )
         return y, ystats
 
@@ -567,6 +659,17 @@ class UNet3DEngine:
         src = rec.src
         Nn, Dd, Hh, Ww = src.N, src.D, src.H, src.W
         Cout = rec.y.shape[-1]
+        if rec.post is not None:
+            # post-norm layer: dz_ is the gradient w.r.t. n = a*z + b (the caller removed the non-linearity): GroupNorm backward
+            # over the conv output z first — sums (sum dn, sum dn*z), parameter gradients, dz = p*dn + q*z + r
+            z, _ = rec.post
+            Vz = Dd * Hh * Ww
+            gst2 = pool.take(Nn * Cout * 2)
+            nat.call("u3d_pair_stats", dev.index, _stream(dev), _p(dz_), _p(z), Nn, Vz, Cout, _p(gst2))
+            coef2 = torch.empty((Nn, 3, Cout), dtype=_F32, device=dev)
+            nat.call("u3d_gn_bwd_finalize", dev.index, _stream(dev), _p(gst2), _p(rec.mean_rstd), _p(rec.gn_w.detach()), Nn, Cout,
+                     rec.G, float(Vz), _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef2))
+            dz_ = self._plain_apply(cx, dz_, coef2, z, 0)
         if self.debug is not None:
             self.debug[rec.name + ".dz"] = dz_.clone()
         if rec.small and not need_dg:
@@ -575,6 +678,8 @@ class UNet3DEngine:
             nat.call("u3d_conv3d_small_cin_bwd", dev.index, _stream(dev), _p(src.t0), _p(rec.affine), _p(dz_),
                      _p(rec.conv_w.detach()), _p(gview(rec.idx_w)), _p(gst), Nn, Dd, Hh, Ww, src.C, Cout, _p(ws), ws.numel(),
                      flops=2 * 54.0 * src.C * Cout * Nn * Dd * Hh * Ww)
+            if not rec.pre_norm:
+                return None, self._identity_coef(Nn, src.C, dev)
             coef = torch.empty((Nn, 3, src.C), dtype=_F32, device=dev)
             nat.call("u3d_gn_bwd_finalize", dev.index, _stream(dev), _p(gst), _p(rec.mean_rstd), _p(rec.gn_w.detach()), Nn,
                      src.C, rec.G, float(Dd * Hh * Ww), _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef))
@@ -645,6 +750,8 @@ class UNet3DEngine:
                      ctypes.byref(s_x), _p(gst), None, _p(ws), ws.numel(), flops=flops)
         if self.debug is not None and rec.sub is None:
             self.debug[rec.name + ".dg"] = dg.clone()
+        if not rec.pre_norm:
+            return dg, self._identity_coef(Nn, src.C, dev)  # no GroupNorm on the conv input: dx = dg
         coef = torch.empty((Nn, 3, src.C), dtype=_F32, device=dev)
         nat.call("u3d_gn_bwd_finalize", dev.index, _stream(dev), _p(gst), _p(rec.mean_rstd), _p(rec.gn_w.detach()), Nn, src.C,
                  rec.G, float(Dd * Hh * Ww), _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef))
@@ -722,26 +829,43 @@ class UNet3DEngine:
                 Np, Dp, Hp, Wp, Cp = cur.shape
                 pooled = torch.empty((Np, Dp // 2, Hp // 2, Wp // 2, Cp), dtype=_F32, device=dev)
                 argmax = torch.empty(pooled.shape, dtype=torch.uint8, device=dev)
-                pst = pool.take(Np * Cp * 2)
+                pst = None if self.post_norm else pool.take(Np * Cp * 2)
                 nat.call("u3d_maxpool2_fwd", dev.index, _stream(dev), _p(cur), Np, Dp, Hp, Wp, Cp, _p(pooled), _p(argmax),
                          _p(pst))
                 if tape is not None:
                     tape.pools.append((pooled, argmax, cur))
                 cur, cur_st = pooled, pst
             src = VSrc(cur)
-            y1, s1 = self._single_conv_fwd(c1, f"enc{i}.c1", src, self._stats_of(src, cur_st, None, pool, dev), pool, tape)
+            stats_of = (lambda *a: None) if self.post_norm else self._stats_of  # only a GroupNorm on the conv INPUT needs them
+            y1, s1 = self._single_conv_fwd(c1, f"enc{i}.c1", src, stats_of(src, cur_st, None, pool, dev), pool, tape)
             src2 = VSrc(y1)
-            y2, s2 = self._single_conv_fwd(c2, f"enc{i}.c2", src2, self._stats_of(src2, s1, None, pool, dev), pool, tape)
+            y2, s2 = self._single_conv_fwd(c2, f"enc{i}.c2", src2, stats_of(src2, s1, None, pool, dev), pool, tape)
             feats.append((y2, s2))
             cur, cur_st = y2, s2
 
         skips = feats[:-1][::-1]  # model.py:126-133
         for j, ((c1, c2), (sk, sk_st)) in enumerate(zip(self.dec, skips)):
+            ct = self.dec_up[j]
+            if ct is not None:
+                # upsample='deconv': ConvTranspose3d(k3, s2, p1) -> 2n-1 voxels (buildingblocks.py:617-664); the nearest resize
+                # to the skip's size (:650-651) and the concat are virtual, like the interpolation path
+                Nl, D1, H1, W1, Cl = cur.shape
+                Cs = ct.out_channels
+                t = torch.empty((Nl, 2 * D1 - 1, 2 * H1 - 1, 2 * W1 - 1, Cs), dtype=_F32, device=dev)
+                if self.subpixel and Cl % 4 == 0 and Cs % 4 == 0:
+                    nat.call("u3d_convtr3d_fwd_subpixel", dev.index, _stream(dev), _p(cur), _p(self._packed_convtr(ct.weight, 2, dev)),
+                             _p(t), Nl, D1, H1, W1, Cl, Cs, flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
+                else:
+                    nat.call("u3d_convtr3d_fwd", dev.index, _stream(dev), _p(cur), _p(ct.weight.detach()), _p(t), Nl, D1, H1, W1, Cl,
+                             Cs, _p(self._packed_convtr(ct.weight, 0, dev)), flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
+                if tape is not None:
+                    tape.ups.append(UpRec(cur, ct.weight, None, tuple(t.shape[1:4])))
+                cur, cur_st = t, None
             src = VSrc(sk, cur)  # skip channels first (buildingblocks.py:491)
-            y1, s1 = self._single_conv_fwd(c1, f"dec{j}.c1", src, self._stats_of(src, sk_st, cur_st, pool, dev), pool, tape,
+            y1, s1 = self._single_conv_fwd(c1, f"dec{j}.c1", src, stats_of(src, sk_st, cur_st, pool, dev), pool, tape,
                                            sub=sub)
             src2 = VSrc(y1)
-            y2, s2 = self._single_conv_fwd(c2, f"dec{j}.c2", src2, self._stats_of(src2, s1, None, pool, dev), pool, tape)
+            y2, s2 = self._single_conv_fwd(c2, f"dec{j}.c2", src2, stats_of(src2, s1, None, pool, dev), pool, tape)
             cur, cur_st = y2, s2
 
         # head: 1x1x1 conv + bias + activation (model.py:141-147), NCDHW outputs
@@ -787,13 +911,15 @@ class UNet3DEngine:
         hacc = pool.take(Co * Cf + Co)
         dz = torch.empty_like(tape.head_x)
         nat.call("u3d_conv1x1_head_bwd", dev.index, _stream(dev), _p(dlogits), _p(tape.head_x), _p(fc.weight.detach()), N, V,
-                 Cf, Co, 1, _p(dz), _p(hacc))
+                 Cf, Co, self.mask, _p(dz), _p(hacc))
+        self._unact(dev, dz, tape.head_x)
         iw, ib = self._pindex[id(fc.weight)], self._pindex[id(fc.bias)]
         assert self.poffs[ib] == self.poffs[iw] + Co * Cf
         nat.call("u3d_cvt_f64_f32", dev.index, _stream(dev), _p(hacc), _p(gview(iw)), Co * Cf + Co)
 
         n_levels = len(self.enc)
         n_dec = len(self.dec)
+        mk = self.mask  # 1: the producers' ReLU masks are applied inside the consumer kernels; else _unact afterwards
         skip_grad = {}  # encoder level -> gradient arriving through the skip connection (pre-mask)
 
         cx = _BwdCtx(dev, pool, ws, flat, self)
@@ -812,7 +938,8 @@ class UNet3DEngine:
         for j in range(n_dec - 1, -1, -1):
             r1, r2 = dec_recs[j]
             dg2, coef2 = conv_bwd(r2, dz)
-            dz1 = plain_apply(dg2, coef2, r2.src.t0, 1)  # r2.src.t0 is r1.y (post-ReLU)
+            dz1 = plain_apply(dg2, coef2, r2.src.t0, mk)  # r2.src.t0 is r1.y (post-activation)
+            self._unact(dev, dz1, r2.src.t0)
             del dg2
             dg1, coef1 = conv_bwd(r1, dz1)
             src = r1.src
@@ -827,15 +954,33 @@ class UNet3DEngine:
                 # dlow already holds the children sums: (p*dlow + 8*(q*x + r)) * (x > 0) on the low-res producer
                 coef_up = coef1[:, :, C0:] * self._up_scale(dev)
                 nat.call("u3d_gn_bwd_apply", dev.index, _stream(dev), _p(dlow), C1, 0, _p(src.t1), C1, _p(coef_up), C1,
-                         src.D1 * src.H1 * src.W1, src.N, 1, _p(dzl))
+                         src.D1 * src.H1 * src.W1, src.N, mk, _p(dzl))
                 del dg0, dlow
             else:
                 skip_grad[lvl] = (dg1, Ct, coef1, Ct)
                 # upsampled half -> low-res producer (previous decoder's conv2 or the deepest encoder), ReLU mask fused
                 lz, ly, lx = src.los
                 nat.call("u3d_gn_bwd_apply_up", dev.index, _stream(dev), _p(dg1), Ct, C0, _p(src.t1), C1, _p(coef1), Ct, src.N,
-                         src.D, src.H, src.W, src.D1, src.H1, src.W1, _p(lz), _p(ly), _p(lx), 1, _p(dzl))
+                         src.D, src.H, src.W, src.D1, src.H1, src.W1, _p(lz), _p(ly), _p(lx),
+                         0 if self.dec_up[j] is not None else mk, _p(dzl))
             del dg1
+            if self.dec_up[j] is not None:
+                # dzl is the gradient of the transposed convolution's (linear) output: its two gradients, with the non-linearity
+                # of the tensor it upsampled
+                up = tape.ups[j]
+                xl = up.x_low
+                Nl, D1, H1, W1, Cl = xl.shape
+                Cs = up.weight.shape[1]
+                acc = pool.take(up.weight.numel())
+                dxl = torch.empty_like(xl)
+                nat.call("u3d_convtr3d_bwd", dev.index, _stream(dev), _p(dzl), _p(xl), _p(up.weight.detach()), Nl, D1, H1, W1, Cl, Cs,
+                         mk, _p(dxl), _p(acc), _p(self._packed_convtr(up.weight, 1, dev)), flops=4.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
+                nat.call("u3d_cvt_f64_f32", dev.index, _stream(dev), _p(acc), _p(gview(self._pindex[id(up.weight)])),
+                         up.weight.numel())
+                self._unact(dev, dxl, xl)
+                dzl = dxl
+            else:
+                self._unact(dev, dzl, src.t1)
             dz = dzl
 
         # decoder + head gradients are final: start their all-reduce now, overlapped with the encoder backward
@@ -848,7 +993,8 @@ class UNet3DEngine:
         for i in range(n_levels - 1, -1, -1):
             r1, r2 = enc_recs[i]
             dg2, coef2 = conv_bwd(r2, dz)
-            dz1 = plain_apply(dg2, coef2, r2.src.t0, 1)
+            dz1 = plain_apply(dg2, coef2, r2.src.t0, mk)
+            self._unact(dev, dz1, r2.src.t0)
             del dg2
             dg1, coef1 = conv_bwd(r1, dz1, need_dg=(i > 0 or need_input_grad))
             if i > 0:
@@ -858,12 +1004,13 @@ class UNet3DEngine:
                 sk = skip_grad.pop(i - 1, None)
                 if sk is None:
                     nat.call("u3d_maxpool2_bwd_merge", dev.index, _stream(dev), _p(dg1), _p(pooled), _p(argmax), _p(coef1), None,
-                             _p(e_in), Ne, De, He, We, Ce, 1, _p(out))
+                             _p(e_in), Ne, De, He, We, Ce, mk, _p(out))
                 else:
                     sdg, sCdg, scoef, sCt = sk
                     nat.call("u3d_maxpool2_bwd_merge_gn", dev.index, _stream(dev), _p(dg1), _p(pooled), _p(argmax), _p(coef1),
-                             _p(sdg), sCdg, _p(scoef), sCt, _p(e_in), Ne, De, He, We, Ce, 1, _p(out))
+                             _p(sdg), sCdg, _p(scoef), sCt, _p(e_in), Ne, De, He, We, Ce, mk, _p(out))
                     del sk, sdg, scoef
+                self._unact(dev, out, e_in)
                 dz = out
             elif need_input_grad:
                 dx0 = plain_apply(dg1, coef1, tape.x0, 0)
@@ -933,23 +1080,6 @@ class ResUNetEngine(UNet3DEngine):
         self.enc = [(e.pooling is not None, e.basic_module) for e in model.encoders]
         self.dec = [(d.upsampling.upsample.conv_transposed, d.basic_module) for d in model.decoders]
 
-    def _packed_convtr(self, w: torch.Tensor, mode: int, dev) -> torch.Tensor:
-        """[tap][Cin][Cout] (mode 0) / [tap][Cout][Cin] (mode 1) image of a ConvTranspose3d weight, cached per version"""
-        key = (id(w), 10 + mode)
-        ver = (w._version, w.data_ptr())
-        hit = self._pack_cache.get(key)
-        if hit is not None and hit[0] == ver:
-            return hit[1]
-        Cin, Cout = w.shape[0], w.shape[1]
-        if mode == 2:  # fragment image of the sub-pixel forward kernel
-            out = torch.empty(nat.get_lib().u3d_convtr3d_subpixel_packed_floats(Cin, Cout), dtype=_F32, device=dev)
-            nat.call("u3d_pack_convtr3d_subpixel", dev.index, _stream(dev), _p(w.detach()), Cin, Cout, _p(out))
-        else:
-            out = torch.empty(27 * Cin * Cout, dtype=_F32, device=dev)
-            nat.call("u3d_pack_convtr_weights", dev.index, _stream(dev), _p(w.detach()), Cin, Cout, mode, _p(out))
-        self._pack_cache[key] = (ver, out)
-        return out
-
     # -- forward ------------------------------------------------------------------------------------
     def _block_fwd(self, bm, name, x_in, x_st, pool, tape, dev, y_out=None):
         N, D, H, W, Cin = x_in.shape
@@ -973,7 +1103,8 @@ class ResUNetEngine(UNet3DEngine):
         src3 = VSrc(out2)
         se_mod = getattr(bm, "se_module", None)
         y, y_st = self._single_conv_fwd(bm.conv3, name + ".c3", src3, (st2, Cout, 1.0, None, 0, 0.0), pool, tape,
-                                        want_stats=se_mod is not None, residual=r, y_out=y_out if se_mod is None else None)
+                                        want_stats=se_mod is not None, residual=r, y_out=y_out if se_mod is None else None,
+                                        act=(ACT_RELU, 0.0))
         se = None
         out = y
         if se_mod is not None:

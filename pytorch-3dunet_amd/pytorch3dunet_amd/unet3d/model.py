@@ -60,13 +60,18 @@ class AbstractUNet(nn.Module):
             reasons.append(f"basic_module {basic_module.__name__}")
         if basic_module is ResNetBlockSE and (any(f % 4 for f in f_maps) or max(f_maps) > 1024):
             reasons.append("SE gates need channel counts that are multiples of 4 and <= 1024")
-        if layer_order != "gcr":
-            reasons.append(f"layer_order '{layer_order}'")
+        from ..engine import parse_order
+
+        self.layer_order = layer_order
+        if parse_order(layer_order) is None:
+            reasons.append(f"layer_order '{layer_order}' (native: one GroupNorm before or after the conv + optional final r/l/e)")
+        elif basic_module in (ResNetBlock, ResNetBlockSE) and layer_order != "gcr":
+            reasons.append(f"layer_order '{layer_order}' with residual blocks")
         if conv_kernel_size != 3 or conv_padding != 1:
             reasons.append("conv kernel/padding other than 3/1")
         if pool_kernel_size != 2:
             reasons.append("pool_kernel_size != 2")
-        if basic_module is DoubleConv and upsample not in ("default", "nearest"):
+        if basic_module is DoubleConv and upsample not in ("default", "nearest", "deconv"):
             reasons.append(f"upsample '{upsample}'")
         if basic_module in (ResNetBlock, ResNetBlockSE) and upsample != "default":
             # an EXPLICIT 'deconv' keeps concat joining and a 1x1x1 conv deep->shallow in the block (buildingblocks.py:441-468:

@@ -378,7 +378,7 @@ def test_uncovered_variant_strict_mode(monkeypatch):
     from pytorch3dunet_amd.unet3d.model import UNet3D
 
     dev = torch.device("cuda", 0)
-    model = UNet3D(1, 1, f_maps=16, num_levels=3, layer_order="gcl").to(dev).eval()  # LeakyReLU order: not native
+    model = UNet3D(1, 1, f_maps=16, num_levels=3, layer_order="bcr").to(dev).eval()  # BatchNorm order: not native
     monkeypatch.setenv("U3D_STRICT", "1")
     with pytest.raises(NotImplementedError):
         model(torch.rand(1, 1, 8, 16, 16, device=dev))

@@ -1,0 +1,139 @@
+"""-m gpu: layer orders other than 'gcr' on the native path (buildingblocks.py:10-96): LeakyReLU /
+ELU non-linearities and GroupNorm after the convolution, same MFMA convolutions + the bandwidth passes of csrc/u3d_act.hip,
+against the CPU oracle's ordered restatement (pinned to the live reference by tests/test_oracle.py)."""
+import pytest
+import torch
+
+import gpu_utils as U
+from conftest import diag, loss_by_name
+from pytorch3dunet_amd import _native as nat
+from pytorch3dunet_amd.engine import _p, _stream
+
+pytestmark = pytest.mark.gpu
+REL = 1e-3
+
+
+@pytest.mark.parametrize("mode,slope", [(0, 0.0), (1, 0.0), (2, 0.01), (2, 0.1), (3, 0.0)])
+def test_activation_and_postnorm_kernels(mode, slope):
+    import torch.nn.functional as F
+
+    torch.manual_seed(mode)
+    f = {0: lambda t: t, 1: F.relu, 2: lambda t: F.leaky_relu(t, slope), 3: F.elu}[mode]
+    N, V, C = 2, 777, 24
+    z = torch.randn(N, V, C, requires_grad=True)
+    a, b = torch.randn(N, C), torch.randn(N, C)
+    y = f(z * a.view(N, 1, C) + b.view(N, 1, C))
+    g = torch.randn(N, V, C)
+    zd, gd = z.detach().to(U.DEV), g.to(U.DEV)
+    aff = torch.stack((a, b), dim=-1).contiguous().to(U.DEV)
+    yd = torch.empty_like(zd)
+    nat.call("u3d_affine_act_fwd", 0, _stream(U.DEV), _p(zd), _p(aff), N, V, C, mode, slope, _p(yd))
+    assert torch.allclose(yd.cpu(), y.detach(), atol=1e-6, rtol=1e-6)
+    # act fwd in place + derivative through the output
+    t = torch.randn(N, V, C, requires_grad=True)
+    ft = f(t)
+    ft.backward(g)
+    td = t.detach().to(U.DEV)
+    nat.call("u3d_act_fwd", 0, _stream(U.DEV), _p(td), td.numel(), mode, slope, _p(td))
+    assert torch.allclose(td.cpu(), ft.detach(), atol=1e-6, rtol=1e-6)
+    dn = torch.empty_like(gd)
+    nat.call("u3d_act_bwd", 0, _stream(U.DEV), _p(gd), _p(td), gd.numel(), mode, slope, _p(dn))
+    assert torch.allclose(dn.cpu(), t.grad, atol=1e-6, rtol=1e-5)
+    st = torch.zeros((N, C, 2), dtype=torch.float64, device=U.DEV)
+    nat.call("u3d_pair_stats", 0, _stream(U.DEV), _p(gd), _p(zd), N, V, C, _p(st))
+    assert torch.allclose(st[..., 0].cpu(), g.double().sum(1), rtol=1e-6, atol=1e-4)
+    assert torch.allclose(st[..., 1].cpu(), (g.double() * z.detach().double()).sum(1), rtol=1e-6, atol=1e-4)
+
+
+@pytest.mark.parametrize("order", ["gcl", "gce", "gc", "cgr", "cgl", "cge", "cg"])
+@pytest.mark.parametrize("cfg,shape,loss_name", [
+    (dict(in_channels=1, out_channels=1, f_maps=16, num_levels=3, num_groups=8), (1, 1, 16, 32, 32), "bce_dice"),   # exact 2x: sub-pixel decoders
+    (dict(in_channels=2, out_channels=3, f_maps=[8, 16, 32], num_groups=4, final_sigmoid=False), (2, 2, 9, 13, 11), "probs_sum"),  # ragged
+])
+def test_unet3d_other_layer_orders_native(order, cfg, shape, loss_name, monkeypatch):
+    import unet3d_oracle as orc
+    from pytorch3dunet_amd.unet3d.model import UNet3D
+
+    monkeypatch.setenv("U3D_STRICT", "1")  # no stock-operator fallback allowed
+    torch.manual_seed(31)
+    model = UNet3D(layer_order=order, **cfg)
+    assert model.native_supported
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if "groupnorm" in k:
+                p.add_(0.2 * torch.randn_like(p))
+    x = torch.randn(shape)
+    target = (torch.rand((shape[0], cfg["out_channels"]) + shape[2:]) > 0.5).float()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    G, fs = cfg["num_groups"], cfg.get("final_sigmoid", True)
+    p32, l32, v32, g32 = orc.forward_backward(sd, x, target, G, fs, True, loss_name, order=order)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    _, _, _, g64 = orc.forward_backward(sd64, x.double(), target.double(), G, fs, True, loss_name, order=order)
+    model = model.to(U.DEV).train()
+    n0 = nat.launch_count
+    probs, logits = model(x.to(U.DEV), return_logits=True)
+    loss = loss_by_name(loss_name, probs, logits, target.to(U.DEV))
+    model.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert nat.launch_count > n0
+    assert orc.rel_err(logits.detach().cpu(), l32) < REL and orc.rel_err(probs.detach().cpu(), p32) < REL
+    assert abs(loss.item() - v32.item()) < REL * max(1.0, abs(v32.item()))
+    keys = list(g32)
+    ours = torch.cat([dict(model.named_parameters())[k].grad.detach().cpu().double().flatten() for k in keys])
+    r32 = torch.cat([g32[k].double().flatten() for k in keys])
+    r64 = torch.cat([g64[k].flatten() for k in keys])
+    e_ours = ((ours - r64).norm() / r64.norm()).item()
+    e_ref = ((r32 - r64).norm() / r64.norm()).item()
+    diag(test="orders", order=order, shape=list(shape), ours_vs_fp64=e_ours, ref32_vs_fp64=e_ref)
+    # distance from the exact (float64) gradient: within 1e-3, or no worse than 3x the reference arithmetic's own distance
+    # (kinks of ReLU / LeakyReLU at 0 and max-pool ties make every fp32 implementation differ from exact in isolated voxels)
+    assert e_ours <= max(REL, 3.0 * e_ref), (order, e_ours, e_ref)
+    # the model can be wrapped / evaluated like any other
+    model.eval()
+    with torch.no_grad():
+        y = model(x.to(U.DEV))
+    assert torch.allclose(y, probs.detach(), atol=1e-6)
+
+
+@pytest.mark.parametrize("order", ["gcr", "gce", "cgl"])
+@pytest.mark.parametrize("cfg,shape", [
+    (dict(in_channels=1, out_channels=1, f_maps=16, num_levels=3, num_groups=8), (1, 1, 16, 32, 32)),
+    (dict(in_channels=2, out_channels=2, f_maps=[8, 16, 32], num_groups=4, final_sigmoid=False), (2, 2, 9, 13, 11)),
+])
+def test_unet3d_deconv_upsampling_native(order, cfg, shape, monkeypatch):
+    """upsample='deconv' with DoubleConv blocks (buildingblocks.py:435-464): ConvTranspose3d(k3,s2,p1) -> 2n-1 -> nearest resize
+    -> concat, all native (transposed-convolution kernels + virtual concat)"""
+    import unet3d_oracle as orc
+    from pytorch3dunet_amd.unet3d.model import UNet3D
+
+    monkeypatch.setenv("U3D_STRICT", "1")
+    torch.manual_seed(41)
+    model = UNet3D(layer_order=order, upsample="deconv", **cfg)
+    assert model.native_supported
+    assert any("conv_transposed" in k for k in model.state_dict())
+    x = torch.randn(shape)
+    loss_name = "bce_dice" if cfg.get("final_sigmoid", True) else "probs_sum"
+    target = (torch.rand((shape[0], cfg["out_channels"]) + shape[2:]) > 0.5).float()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    G, fs = cfg["num_groups"], cfg.get("final_sigmoid", True)
+    p32, l32, v32, g32 = orc.forward_backward(sd, x, target, G, fs, True, loss_name, order=order)
+    _, _, _, g64 = orc.forward_backward({k: v.double() for k, v in sd.items()}, x.double(), target.double(), G, fs, True, loss_name,
+                                        order=order)
+    model = model.to(U.DEV).train()
+    probs, logits = model(x.to(U.DEV), return_logits=True)
+    loss = loss_by_name(loss_name, probs, logits, target.to(U.DEV))
+    model.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert orc.rel_err(logits.detach().cpu(), l32) < REL
+    keys = list(g32)
+    ours = torch.cat([dict(model.named_parameters())[k].grad.detach().cpu().double().flatten() for k in keys])
+    r32 = torch.cat([g32[k].double().flatten() for k in keys])
+    r64 = torch.cat([g64[k].flatten() for k in keys])
+    e_ours, e_ref = ((ours - r64).norm() / r64.norm()).item(), ((r32 - r64).norm() / r64.norm()).item()
+    assert e_ours <= max(REL, 3.0 * e_ref), (e_ours, e_ref)
+    for k in keys:
+        if "conv_transposed" in k:
+            g = dict(model.named_parameters())[k].grad.detach().cpu().double()
+            assert ((g - g64[k]).norm() / g64[k].norm()).item() < max(5e-3, 10 * e_ref), k

@@ -158,3 +158,22 @@ def test_decision_consistent_oracle_reproduces_plain_oracle():
     _, logits2, _, grads2 = orc.forward_backward(sd, x.double(), t.double(), G, False, True, "probs_sum")
     assert orc.rel_err(logits, logits2) < 1e-12
     assert max(orc.rel_err(grads[k], grads2[k]) for k in grads) < 1e-10
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference only exists in the build container")
+@pytest.mark.parametrize("order", ["gcl", "gce", "cgr", "cgl", "cge", "cg", "gc"])
+def test_ordered_oracle_matches_live_reference(order):
+    """the layer-order mini language (buildingblocks.py:10-96) restated in single_conv_ordered, against the imported reference"""
+    ref = import_reference()
+    cfg = dict(name="UNet3D", in_channels=2, out_channels=2, f_maps=[8, 16], num_groups=4, layer_order=order, final_sigmoid=False)
+    torch.manual_seed(11)
+    model = ref.get_model(dict(cfg))
+    x = torch.randn(1, 2, 8, 12, 10)
+    target = (torch.rand(1, 2, 8, 12, 10) > 0.5).float()
+    probs_r, logits_r = model(x, return_logits=True)
+    ((probs_r * target).sum() + 0.5 * (logits_r * logits_r).mean()).backward()
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    probs, logits, _, grads = orc.forward_backward(sd, x, target, 4, False, True, "probs_sum", order=order)
+    assert orc.rel_err(logits, logits_r.detach()) < 1e-6 and orc.rel_err(probs, probs_r.detach()) < 1e-6
+    for k, p in model.named_parameters():
+        assert orc.rel_err(grads[k], p.grad) < 2e-5, k
