@@ -371,6 +371,13 @@ int u3d_pack_weights_bf16(int device, u3d_stream_t stream, const float* w, int C
 int u3d_conv3d_bf16(int device, u3d_stream_t stream, const float* x, const float* affine, const void* packed_w, float* out,
                     int N, int D, int H, int W, int Cin, int Cout, int relu, double* out_stats, const float* gx,
                     double* gstats, const float* residual);
+/* ... with an optional scratch buffer of u3d_conv3d_bf16_workspace_floats() floats (0 for shapes that never split): at the
+ * bottom of the U (few tiles, many channels) the reduction over input channels is split over several blocks whose partial sums
+ * are added in a fixed order by a second kernel that owns the epilogue — same results contract. */
+long long u3d_conv3d_bf16_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
+int u3d_conv3d_bf16_ex(int device, u3d_stream_t stream, const float* x, const float* affine, const void* packed_w, float* out,
+                       int N, int D, int H, int W, int Cin, int Cout, int relu, double* out_stats, const float* gx,
+                       double* gstats, const float* residual, float* workspace, long long workspace_floats);
 
 /* Weight gradient of the same convolution with bf16 operands / FP32 accumulation (autograd of trainer.py:245 for
  * buildingblocks.py:56): dw (Cout,Cin,3,3,3) fp32, reference layout, = sum over voxels of g(x)[v+tap] (x) dz[v] with

@@ -35,6 +35,8 @@ struct bf16_conv_params {
     double* gstats;        // [N][K][2] += (sum y, sum y*gx) or null
     int N, D, H, W, C, K, relu;
     int tz, ty, tx;        // tiles per dimension
+    int ksplit;            // > 1: the channel reduction is split over `ksplit` blocks per (tile, channel block); raw partial
+    float* ws;             //      sums go to ws[split][voxel][K] and splitk_bf16_reduce_kernel owns the epilogue
 };
 
 template <int ZW>
@@ -66,6 +68,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
     const int bid = u3d_xcd_remap(blockIdx.x, gridDim.x);
     const int nb = bid % nblk;
     int tile = bid / nblk;
+    const int split = tile % p.ksplit;  // (ksplit == 1: 0)
+    tile /= p.ksplit;
     const int txi = tile % p.tx;
     tile /= p.tx;
     const int tyi = tile % p.ty;
@@ -73,7 +77,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
     const int tzi = tile % p.tz;
     const int n = tile / p.tz;
     const int z0 = tzi * G::TZ, y0 = tyi * 8, x0 = txi * 8;
-    const int nch = p.C >> 4;
+    const int nch_all = p.C >> 4;
+    const int cps = (nch_all + p.ksplit - 1) / p.ksplit;          // chunks per split
+    const int cbeg = split * cps, nch = min(nch_all, cbeg + cps);  // this block's chunk range [cbeg, nch)
     const int ntiles = p.K >> 5;
     const int q = t & 3;  // this thread's channel quad within a chunk (item & 3 == t & 3 for every item it stages)
 
@@ -124,19 +130,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
         u3d_load_affine(p.affine, n, p.C, (c << 4) + 4 * q, true, ga, gb);
     };
 
-    // ---- prologue: chunk 0 into buffer 0
-    {
+    // ---- prologue: the first chunk into its buffer
+    if (cbeg < nch) {
         f32x4 ga, gb;
-        chunk_affine(0, ga, gb);
+        chunk_affine(cbeg, ga, gb);
 #pragma unroll 1
         for (int it = 0; it < G::ITERS; ++it) {
             f32x4 v;
-            load_item(0, it, v);
-            store_item(lds, it, v, ga, gb);
+            load_item(cbeg, it, v);
+            store_item(lds + (cbeg & 1) * G::BUF, it, v, ga, gb);
         }
     }
 
-    for (int c = 0; c < nch; ++c) {
+    for (int c = cbeg; c < nch; ++c) {
         __syncthreads();  // buffer (c&1) is complete; everyone is done reading buffer ((c+1)&1)
         const char* cur = lds + (c & 1) * G::BUF;
         char* nxt = lds + ((c + 1) & 1) * G::BUF;
@@ -179,6 +185,24 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
     // ---- epilogue: residual, ReLU, store, per-(n,channel) statistics.  C/D layout of the 32x32 MFMA: column = lane & 31,
     // row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5); with row -> (yy = row & 3, xx = row >> 2): yy = e & 3, xx = 2*(e >> 2) + (lane >> 5)
     const int col = lane & 31, half = lane >> 5;
+    if (p.ksplit > 1) {
+        // raw partial sums of this chunk range; residual / ReLU / statistics happen in the fixed-order reduction
+        float* wsp = p.ws + (size_t)split * p.N * p.D * p.H * p.W * p.K;
+#pragma unroll
+        for (int m = 0; m < G::MT; ++m) {
+            const int z = z0 + w * ZW + (m >> 1);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int y = y0 + (m & 1) * 4 + (e & 3), xx = x0 + 2 * (e >> 2) + half;
+                if (z < p.D && y < p.H && xx < p.W) {
+                    const size_t vox = (((size_t)n * p.D + z) * p.H + y) * p.W + xx;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) wsp[vox * p.K + (size_t)(nb * NT + j) * 32 + col] = acc[m][j][e];
+                }
+            }
+        }
+        return;
+    }
     float s1[NT], s2[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
@@ -227,6 +251,31 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
             double* dst = (want_stats ? p.out_stats : p.gstats) + ((size_t)n * p.K + (size_t)nb * NT * 32) * 2;
             u3d_atomic_add_f64(dst + t, sum);
         }
+    }
+}
+
+// out = [relu](sum over splits (fixed order) + residual), statistics like the fused epilogue.
+// grid (voxel blocks, ceil(K/256), N); thread = one channel, loops over the block's voxels
+__global__ __launch_bounds__(256) void splitk_bf16_reduce_kernel(const bf16_conv_params p, long long V, int vper) {
+    const int c = blockIdx.y * 256 + threadIdx.x, n = blockIdx.z;
+    if (c >= p.K) return;
+    const long long v0 = (long long)blockIdx.x * vper, v1 = min(V, v0 + vper);
+    const size_t split_stride = (size_t)p.N * V * p.K;
+    float s1 = 0.f, s2 = 0.f;
+    for (long long v = v0; v < v1; ++v) {
+        const size_t o = ((size_t)n * V + v) * p.K + c;
+        float acc = 0.f;
+        for (int s = 0; s < p.ksplit; ++s) acc += p.ws[s * split_stride + o];
+        if (p.residual) acc += p.residual[o];
+        if (p.relu) acc = fmaxf(acc, 0.f);
+        p.y[o] = acc;
+        s1 += acc;
+        s2 = fmaf(acc, p.out_stats ? acc : (p.gstats ? p.gx[o] : 0.f), s2);
+    }
+    double* dst = p.out_stats ? p.out_stats : p.gstats;
+    if (dst) {
+        u3d_atomic_add_f64(dst + ((size_t)n * p.K + c) * 2 + 0, (double)s1);
+        u3d_atomic_add_f64(dst + ((size_t)n * p.K + c) * 2 + 1, (double)s2);
     }
 }
 
@@ -292,7 +341,7 @@ static int launch_bf16(const bf16_conv_params& p, hipStream_t stream) {
     q.tz = (p.D + G::TZ - 1) / G::TZ;
     q.ty = (p.H + 7) / 8;
     q.tx = (p.W + 7) / 8;
-    const long long blocks = (long long)p.N * q.tz * q.ty * q.tx * (p.K / (32 * NT));
+    const long long blocks = (long long)p.N * q.tz * q.ty * q.tx * (p.K / (32 * NT)) * p.ksplit;
     if (blocks > 0x7fffffffLL) return u3d_set_err(U3D_EINVAL, "u3d_conv3d_bf16: grid too large");
     const size_t shmem = 2 * (size_t)G::BUF;
     // (per device, cheap: set on every launch so that every device of a multi-GPU process has it)
@@ -300,12 +349,50 @@ static int launch_bf16(const bf16_conv_params& p, hipStream_t stream) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL((conv3d_bf16_kernel<NT, ZW>), dim3((unsigned)blocks), dim3(256), shmem, stream, q);
     U3D_LAUNCH_CHECK();
+    if (p.ksplit > 1) {
+        const long long V = (long long)p.D * p.H * p.W;
+        int vper = 16;
+        hipLaunchKernelGGL(splitk_bf16_reduce_kernel, dim3((unsigned)((V + vper - 1) / vper), (unsigned)((p.K + 255) / 256), (unsigned)p.N),
+                           dim3(256), 0, stream, q, V, vper);
+        U3D_LAUNCH_CHECK();
+    }
     return 0;
 }
+
+// how many ways the channel reduction is split: only when the natural grid (4-plane tiles) leaves most of the 256 CUs idle
+static int bf16_ksplit(int N, int D, int H, int W, int C, int K) {
+    const bool nt2 = K % 64 == 0;
+    const long long natural = (long long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 7) / 8) * (K / (nt2 ? 64 : 32));
+    const int nch = C / 16;
+    if (natural >= 384 || nch < 4) return 1;
+    long long ks = (1024 + natural - 1) / natural;
+    if (ks > nch / 2) ks = nch / 2;
+    if (ks > 16) ks = 16;
+    return ks < 2 ? 1 : (int)ks;
+}
+
+extern "C" long long u3d_conv3d_bf16_workspace_floats(int N, int D, int H, int W, int C, int K) {
+    if (!u3d_conv3d_bf16_supported(C, K) || N <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    const int ks = bf16_ksplit(N, D, H, W, C, K);
+    return ks > 1 ? (long long)ks * N * D * H * W * K : 0;
+}
+
+extern "C" int u3d_conv3d_bf16_ex(int device, u3d_stream_t stream, const float* x, const float* affine, const void* packed_w,
+                                  float* out, int N, int D, int H, int W, int C, int K, int relu, double* out_stats,
+                                  const float* gx, double* gstats, const float* residual, float* workspace,
+                                  long long workspace_floats);
 
 extern "C" int u3d_conv3d_bf16(int device, u3d_stream_t stream, const float* x, const float* affine, const void* packed_w,
                                float* out, int N, int D, int H, int W, int C, int K, int relu, double* out_stats,
                                const float* gx, double* gstats, const float* residual) {
+    return u3d_conv3d_bf16_ex(device, stream, x, affine, packed_w, out, N, D, H, W, C, K, relu, out_stats, gx, gstats, residual,
+                              nullptr, 0);
+}
+
+extern "C" int u3d_conv3d_bf16_ex(int device, u3d_stream_t stream, const float* x, const float* affine, const void* packed_w,
+                                  float* out, int N, int D, int H, int W, int C, int K, int relu, double* out_stats,
+                                  const float* gx, double* gstats, const float* residual, float* workspace,
+                                  long long workspace_floats) {
     U3D_ENTER(device);
     U3D_REQUIRE(x && packed_w && out && N > 0 && D > 0 && H > 0 && W > 0, "u3d_conv3d_bf16: bad argument");
     U3D_REQUIRE(u3d_conv3d_bf16_supported(C, K), "u3d_conv3d_bf16: needs Cin %% 16 == 0 and Cout %% 32 == 0 (got %d, %d)", C, K);
@@ -313,12 +400,17 @@ extern "C" int u3d_conv3d_bf16(int device, u3d_stream_t stream, const float* x, 
     U3D_REQUIRE(!gstats || gx, "u3d_conv3d_bf16: gstats needs gx");
     U3D_REQUIRE((((uintptr_t)x | (uintptr_t)packed_w | (uintptr_t)affine) & 15) == 0, "u3d_conv3d_bf16: 16-byte alignment");
     bf16_conv_params p{x, affine, reinterpret_cast<const bf16x8*>(packed_w), out, residual, gx, out_stats, gstats,
-                       N, D, H, W, C, K, relu, 0, 0, 0};
+                       N, D, H, W, C, K, relu, 0, 0, 0, 1, nullptr};
+    const int ks = bf16_ksplit(N, D, H, W, C, K);
+    if (ks > 1 && workspace && workspace_floats >= (long long)ks * N * D * H * W * K) {
+        p.ksplit = ks;
+        p.ws = workspace;
+    }
     // tile height: 8 z-planes per block when that still gives >= 2 blocks per CU, else 4 (more, smaller blocks at the bottom
     // of the U); 64 output channels per block when possible
     const bool nt2 = K % 64 == 0;
     const long long big = (long long)N * ((D + 7) / 8) * ((H + 7) / 8) * ((W + 7) / 8) * (K / (nt2 ? 64 : 32));
-    const bool zw2 = big >= 512 && D >= 8;
+    const bool zw2 = big >= 512 && D >= 8 && p.ksplit == 1;
     hipStream_t s = (hipStream_t)stream;
     if (nt2) return zw2 ? launch_bf16<2, 2>(p, s) : launch_bf16<2, 1>(p, s);
     return zw2 ? launch_bf16<1, 2>(p, s) : launch_bf16<1, 1>(p, s);

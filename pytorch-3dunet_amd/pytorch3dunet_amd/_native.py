@@ -210,6 +210,12 @@ _PROTOS = {
         [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
          c_void_p, c_void_p, c_void_p],
     ),
+    "u3d_conv3d_bf16_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "u3d_conv3d_bf16_ex": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+         c_void_p, c_void_p, c_void_p, c_void_p, c_int64],
+    ),
     "u3d_conv3d_wgrad_bf16_supported": (c_int, [c_int, c_int]),
     "u3d_wgrad_bf16_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "u3d_conv3d_wgrad_bf16": (

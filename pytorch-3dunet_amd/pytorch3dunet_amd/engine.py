@@ -615,8 +615,10 @@ class UNet3DEngine:
         elif src.t1 is None and self._bf16_layer(Ctot, Cout):
             # bf16 MFMA operands, fp32 accumulation / epilogue (csrc/u3d_bf16.hip)
             ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
-            nat.call("u3d_conv3d_bf16", dev.index, _stream(dev), _p(src.t0), _p(affine), _p(self._packed_bf16(conv.weight, 0, dev)),
-                     _p(y), N, D, H, W, Ctot, Cout, relu, _p(ystats), None, None, _p(residual),
+            need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(N, D, H, W, Ctot, Cout)  # split-K scratch at the bottom of the U
+            kws = torch.empty(need, dtype=_F32, device=dev) if need > 0 else None
+            nat.call("u3d_conv3d_bf16_ex", dev.index, _stream(dev), _p(src.t0), _p(affine), _p(self._packed_bf16(conv.weight, 0, dev)),
+                     _p(y), N, D, H, W, Ctot, Cout, relu, _p(ystats), None, None, _p(residual), _p(kws), need,
                      flops=54.0 * Ctot * Cout * N * D * H * W)
         else:
             wp = self._packed(conv.weight, 0, dev)
@@ -739,8 +741,10 @@ class UNet3DEngine:
         elif bf16:
             dg = torch.empty((Nn, Dd, Hh, Ww, src.C), dtype=_F32, device=dev)
             gst = pool.take(Nn * src.C * 2)
-            nat.call("u3d_conv3d_bf16", dev.index, _stream(dev), _p(dz_), None, _p(self._packed_bf16(rec.conv_w, 1, dev)), _p(dg),
-                     Nn, Dd, Hh, Ww, Cout, src.C, 0, None, _p(src.t0), _p(gst), None, flops=flops)
+            need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(Nn, Dd, Hh, Ww, Cout, src.C)
+            kws = cx.ensure_ws(need) if need > 0 else None
+            nat.call("u3d_conv3d_bf16_ex", dev.index, _stream(dev), _p(dz_), None, _p(self._packed_bf16(rec.conv_w, 1, dev)), _p(dg),
+                     Nn, Dd, Hh, Ww, Cout, src.C, 0, None, _p(src.t0), _p(gst), None, _p(kws), need, flops=flops)
         else:
             wpd = self._packed(rec.conv_w, 1, dev)
             dg = torch.empty((Nn, Dd, Hh, Ww, src.C), dtype=_F32, device=dev)

@@ -99,6 +99,37 @@ def test_conv3d_bf16_data_gradient_with_groupnorm_sums_and_residual(shape, C, K)
     assert (y.double() - (ref + res.double()).clamp_min(0)).abs().max().item() < 1e-3 * max(scale, 1.0)
 
 
+@pytest.mark.parametrize("shape,C,K", [((1, 5, 10, 10), 256, 128), ((2, 4, 9, 7), 128, 64)])
+def test_conv3d_bf16_split_k_at_the_bottom_of_the_u(shape, C, K):
+    """few tiles, many channels: the channel reduction is split over blocks (workspace) and reduced in a fixed order by the
+    kernel that owns the epilogue — same results as the unsplit launch, run-to-run identical, residual / ReLU / statistics"""
+    N, D, H, W = shape
+    lib = nat.get_lib()
+    need = lib.u3d_conv3d_bf16_workspace_floats(N, D, H, W, C, K)
+    assert need > 0
+    torch.manual_seed(5)
+    x = torch.randn(N, C, D, H, W)
+    w = torch.randn(K, C, 3, 3, 3) / (27 * C) ** 0.5
+    res = torch.randn(N, K, D, H, W)
+    xd, resd, wp = U.ndhwc(x), U.ndhwc(res), pack_bf16(w, 0)
+    ws = torch.empty(need, dtype=torch.float32, device=U.DEV)
+    outs = []
+    for use_ws in (True, True, False):
+        y = torch.empty((N, D, H, W, K), dtype=torch.float32, device=U.DEV)
+        st = torch.zeros((N, K, 2), dtype=torch.float64, device=U.DEV)
+        nat.call("u3d_conv3d_bf16_ex", 0, _stream(U.DEV), _p(xd), None, _p(wp), _p(y), N, D, H, W, C, K, 1, _p(st), None, None,
+                 _p(resd), _p(ws) if use_ws else None, need if use_ws else 0)
+        torch.cuda.synchronize()
+        outs.append((U.ncdhw(y), st.cpu()))
+    ref = (F.conv3d(bf16_round(x).double(), bf16_round(w).double(), None, padding=1) + res.double()).clamp_min(0)
+    scale = ref.abs().max().item()
+    assert torch.equal(outs[0][0], outs[1][0])
+    for y, st in outs:
+        assert (y.double() - ref).abs().max().item() < 1e-3 * scale
+        assert torch.allclose(st[..., 0], y.double().sum(dim=(2, 3, 4)), rtol=1e-5, atol=1e-4)
+        assert torch.allclose(st[..., 1], (y.double() ** 2).sum(dim=(2, 3, 4)), rtol=1e-5, atol=1e-4)
+
+
 def test_conv3d_bf16_rejects_unsupported_channel_counts():
     assert nat.get_lib().u3d_conv3d_bf16_supported(64, 64) == 1
     assert nat.get_lib().u3d_conv3d_bf16_supported(8, 32) == 0 and nat.get_lib().u3d_conv3d_bf16_supported(16, 48) == 0
@@ -219,7 +250,7 @@ def test_model_bf16_against_bf16_operand_oracle_and_fp32_oracle(cfg, shape):
     finally:
         orc.BF16_OPERANDS = False
     logits, loss, grads, names = _step(model, x, target, loss_name)
-    assert "u3d_conv3d_bf16" in names and "u3d_conv3d_wgrad_bf16" in names, names
+    assert "u3d_conv3d_bf16_ex" in names and "u3d_conv3d_wgrad_bf16" in names, names
     keys = list(g32)
     cat = lambda d: torch.cat([d[k].flatten().double() for k in keys])  # noqa: E731
     ours, r16, r32 = cat(grads), cat(g16), cat(g32)

@@ -65,6 +65,8 @@ def main():
             n16 = lib.u3d_packed_weight_bf16_elems(C, C, mode)
             wp16 = torch.empty(n16, dtype=torch.bfloat16, device=dev)
             nat.call("u3d_pack_weights_bf16", 0, _stream(dev), _p(w), C, C, mode, _p(wp16))
+            n16k = lib.u3d_conv3d_bf16_workspace_floats(N, D, H, W, C, C)
+            ws16k = torch.empty(max(n16k, 4), device=dev)
             need = lib.u3d_conv3d_workspace_floats(N, D, H, W, C, C)
             ws = torch.empty(max(need, 4), device=dev)
             s = src.struct(aff if mode == 0 else None)
@@ -72,13 +74,13 @@ def main():
             if mode == 0:
                 f32 = lambda: nat.call("u3d_conv3d_ex", 0, _stream(dev), ctypes.byref(s), _p(wp32), _p(y), N, D, H, W, C, 1,  # noqa: E731
                                        _p(st), None, None, None, _p(ws), need)
-                b16 = lambda: nat.call("u3d_conv3d_bf16", 0, _stream(dev), _p(x), _p(aff), _p(wp16), _p(y), N, D, H, W, C, C, 1,  # noqa: E731
-                                       _p(st), None, None, None)
+                b16 = lambda: nat.call("u3d_conv3d_bf16_ex", 0, _stream(dev), _p(x), _p(aff), _p(wp16), _p(y), N, D, H, W, C, C, 1,  # noqa: E731
+                                       _p(st), None, None, None, _p(ws16k), n16k)
             else:
                 f32 = lambda: nat.call("u3d_conv3d_ex", 0, _stream(dev), ctypes.byref(s), _p(wp32), _p(y), N, D, H, W, C, 0,  # noqa: E731
                                        None, ctypes.byref(gxs), _p(st), None, _p(ws), need)
-                b16 = lambda: nat.call("u3d_conv3d_bf16", 0, _stream(dev), _p(x), None, _p(wp16), _p(y), N, D, H, W, C, C, 0,  # noqa: E731
-                                       None, _p(x), _p(st), None)
+                b16 = lambda: nat.call("u3d_conv3d_bf16_ex", 0, _stream(dev), _p(x), None, _p(wp16), _p(y), N, D, H, W, C, C, 0,  # noqa: E731
+                                       None, _p(x), _p(st), None, _p(ws16k), n16k)
             m32, m16 = timeit(f32, args.iters), timeit(b16, args.iters)
             tot["f32"] += m32
             tot["bf16"] += m16

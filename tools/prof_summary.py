@@ -4,6 +4,9 @@
   python tools/prof_summary.py stats  <results.db>  <steps_in_run>  > profiles/rNN_kernel_stats.md
   python tools/prof_summary.py pmc    <dir with *counter_collection.csv>     > profiles/rNN_pmc.md
   python tools/prof_summary.py traffic <FETCH_SIZE dir> <WRITE_SIZE dir> <steps> > profiles/rNN_pmc_traffic.json
+  python tools/prof_summary.py tables <results.db> <steps_in_run> <SQ counter dir> <bench.json.log> > profiles/rNN_tables.md
+      -> the two tables DESIGN.md quotes, GENERATED: per-family roofline fraction from the rocprofv3 kernel durations (family
+         FLOPs per step taken from the bench line of the same build) and per-kernel MFMA pipe utilisation from the SQ counters
 """
 import csv
 import glob
@@ -94,8 +97,66 @@ def traffic(fetch_dir, write_dir, steps):
     print(json.dumps(res, indent=1))
 
 
+ROOFLINE_FAMILIES = {  # bench.py family (entry points merged when they launch the same kernels) -> kernel-name substrings
+    "u3d_conv3d": (("u3d_conv3d",), ("conv3d_mfma_reg_kernel", "conv3d_mfma_kernel", "splitk_reduce_kernel")),
+    "u3d_conv3d_wgrad (+_strided)": (("u3d_conv3d_wgrad", "u3d_conv3d_wgrad_strided"), ("conv3d_wgrad_kernel", "wgrad_reduce_kernel")),
+    "u3d_subpixel_conv_fwd": (("u3d_subpixel_conv_fwd",), ("subpixel_fwd_kernel", "sum_partials_kernel")),
+    "u3d_subpixel_conv_dgrad": (("u3d_subpixel_conv_dgrad",), ("subpixel_dgrad_kernel",)),
+    "u3d_subpixel_conv_wgrad": (("u3d_subpixel_conv_wgrad",), ("subpixel_wgrad_kernel", "subpixel_wgrad_reduce_kernel")),
+}
+PEAK_F32_MFMA = 157.3
+
+
+def tables(db_path, steps, sq_dir, bench_log):
+    import json
+
+    bench = json.loads([ln for ln in open(bench_log).read().splitlines() if ln.startswith("{")][-1])
+    fam_bench = bench["roofline"]["families"]
+    db = sqlite3.connect(db_path)
+    rows = db.execute("select name, total_calls, total_duration from top_kernels").fetchall()
+    tot = sum(r[2] for r in rows)
+    unit = 1e-6 if tot > 1e8 else 1e-3  # -> ms
+    print(f"# Generated by tools/prof_summary.py tables — do not edit ({os.path.basename(db_path)}; bench line: "
+          f"{bench['value']} {bench['unit']}, {bench['ms_per_step']} ms/step)\n")
+    print("## Per-family fp32-MFMA roofline (FLOPs per step from the bench line's HIP-event table, time from rocprofv3 kernel durations)\n")
+    print("| family | GFLOP/step | rocprofv3 ms/step | TFLOP/s | frac of 157.3 | HIP-event ms/step | HIP-event frac |")
+    print("|---|---|---|---|---|---|---|")
+    all_gf = all_ms = 0.0
+    for fam, (entries, subs) in ROOFLINE_FAMILIES.items():
+        gf = sum(fam_bench[e]["tflops"] * fam_bench[e]["ms_per_step"] for e in entries if e in fam_bench and fam_bench[e]["tflops"])
+        ev_ms = sum(fam_bench[e]["ms_per_step"] for e in entries if e in fam_bench)
+        ms = sum(r[2] for r in rows if any(sub in r[0] for sub in subs)) * unit / steps
+        if gf <= 0 or ms <= 0:
+            continue
+        all_gf += gf
+        all_ms += ms
+        print(f"| `{fam}` | {gf:.1f} | {ms:.3f} | {gf / ms:.1f} | {gf / ms / PEAK_F32_MFMA:.3f} | {ev_ms:.3f} | {gf / ev_ms / PEAK_F32_MFMA:.3f} |")
+    print(f"| all MFMA families | {all_gf:.1f} | {all_ms:.3f} | {all_gf / all_ms:.1f} | {all_gf / all_ms / PEAK_F32_MFMA:.3f} | | |")
+    print(f"\nwhole step (rocprofv3): {tot * unit / steps:.2f} ms of kernels; executed {all_gf / (tot * unit / steps):.1f} TFLOP/s = "
+          f"{all_gf / (tot * unit / steps) / PEAK_F32_MFMA:.3f} of the fp32-MFMA peak\n")
+    # MFMA pipe utilisation from the SQ counters
+    files = glob.glob(os.path.join(sq_dir, "**", "*counter_collection.csv"), recursive=True)
+    agg = defaultdict(lambda: defaultdict(float))
+    for f in files:
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                agg[row.get("Kernel_Name") or row.get("kernel_name")][row.get("Counter_Name") or row.get("counter_name")] += float(
+                    row.get("Counter_Value") or row.get("counter_value") or 0)
+    print("## MFMA pipe utilisation (SQ counters; busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128): per SIMD and active cycle)\n")
+    print("| kernel | MFMA pipe busy | VALU : MFMA instructions | SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES |")
+    print("|---|---|---|---|")
+    for k in sorted(agg, key=lambda k: -agg[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0)):
+        a = agg[k]
+        if a.get("SQ_INSTS_MFMA", 0) <= 0 or a.get("GRBM_GUI_ACTIVE", 0) <= 0:
+            continue
+        print(f"| `{k[:80]}` | {100 * a['SQ_VALU_MFMA_BUSY_CYCLES'] / (a['GRBM_GUI_ACTIVE'] * 128):.1f} % | "
+              f"{a['SQ_INSTS_VALU'] / a['SQ_INSTS_MFMA']:.2f} | {a.get('SQ_WAIT_INST_ANY', 0) / max(a.get('SQ_WAVE_CYCLES', 1), 1):.2f} |")
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "tables":
+        tables(sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5])
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], int(sys.argv[3]))
     elif sys.argv[1] == "traffic":
         traffic(sys.argv[2], sys.argv[3], int(sys.argv[4]))

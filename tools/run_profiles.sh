@@ -17,6 +17,7 @@ db=$(find $out/stats -name "*.db" | head -1)
 python tools/prof_summary.py stats "$db" 6 > $out/${tag}_bench_kernel_stats.md
 python tools/prof_summary.py traffic $out/fetch $out/write 3 > $out/${tag}_pmc_traffic.json
 python tools/prof_summary.py pmc $out/sq > $out/${tag}_pmc_sq.md
+python tools/prof_summary.py tables "$db" 6 $out/sq $out/bench.json.log > $out/${tag}_tables.md
 cp $out/bench.json.log $out/${tag}_bench.json.log
 rm -rf $out/stats $out/fetch $out/write $out/sq
 tail -1 $out/bench.json.log | cut -c1-400
