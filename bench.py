@@ -76,9 +76,19 @@ def cpu_baseline(sample_iters=3):
         times.append(time.perf_counter() - t0)
     times.sort()
     med = times[len(times) // 2]
+    cpu_model = "unknown CPU"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            cpu_model = next(ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name"))
+    except Exception:
+        pass
+    # kind "port": /root/reference does not exist on the GPU box, so what is timed is oracle/unet3d_oracle.py — the reference's
+    # module graph restated on the same ATen CPU operators.  tests/test_oracle.py::test_port_and_live_reference_same_speed times
+    # both side by side in the build container (same numerics to 1e-6, same throughput within noise).
     return {"value": round(1.0 / med, 4), "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"batch 1x1x{PATCH[0]}x{PATCH[1]}x{PATCH[2]} fwd+bwd, 1 warm-up + {sample_iters} timed iterations "
-                      f"(median {med:.3f} s), torch {torch.__version__} CPU operators"}
+            "sample": f"PORT of the reference path (oracle/unet3d_oracle.py, not the reference module tree itself): batch "
+                      f"1x1x{PATCH[0]}x{PATCH[1]}x{PATCH[2]} fwd+bwd, 1 warm-up + {sample_iters} timed iterations (median {med:.3f} s), "
+                      f"torch {torch.__version__} CPU operators, {torch.get_num_threads()} of {os.cpu_count()} logical cores of {cpu_model}"}
 
 
 def pmc_traffic(family):

@@ -177,3 +177,39 @@ def test_ordered_oracle_matches_live_reference(order):
     assert orc.rel_err(logits, logits_r.detach()) < 1e-6 and orc.rel_err(probs, probs_r.detach()) < 1e-6
     for k, p in model.named_parameters():
         assert orc.rel_err(grads[k], p.grad) < 2e-5, k
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference only exists in the build container")
+def test_port_and_live_reference_same_speed():
+    """bench.py's cpu_baseline times the oracle (kind "port": /root/reference does not travel to the GPU box).  Here both run
+    side by side on BASELINE config 1's shape: identical numerics (1e-6) and the same throughput within noise — the port is a
+    faithful stand-in for 'the reference timed on the same box's host cores'."""
+    import time
+
+    ref = import_reference()
+    cfg = dict(name="UNet3D", in_channels=1, out_channels=1, f_maps=16, num_groups=8, final_sigmoid=True)
+    torch.manual_seed(0)
+    model = ref.get_model(dict(cfg)).train()
+    x = torch.randn(1, 1, 32, 64, 64)
+    target = (torch.rand(1, 1, 32, 64, 64) > 0.5).float()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    def step_ref():
+        model.zero_grad()
+        _, logits = model(x, return_logits=True)
+        loss = orc.bce_dice_loss(logits, target)
+        loss.backward()
+        return logits.detach()
+
+    def step_port():
+        return orc.forward_backward(sd, x, target, 8)[1]
+
+    l_ref, l_port = step_ref(), step_port()  # warm-up + numerics
+    assert orc.rel_err(l_port, l_ref) < 1e-6
+    t_ref, t_port = [], []
+    for _ in range(4):  # interleaved, best-of: robust against a noisy shared host
+        t0 = time.perf_counter(); step_ref(); t_ref.append(time.perf_counter() - t0)     # noqa: E702
+        t0 = time.perf_counter(); step_port(); t_port.append(time.perf_counter() - t0)   # noqa: E702
+    ratio = min(t_port) / min(t_ref)
+    print(f"reference {min(t_ref) * 1e3:.1f} ms, port {min(t_port) * 1e3:.1f} ms per fwd+bwd (ratio {ratio:.2f})")
+    assert 0.7 < ratio < 1.4, (t_ref, t_port)
