@@ -46,7 +46,8 @@ struct tile_geom {
     static constexpr int BUF = 2 * PLANE;
     static constexpr int ITEMS = HZ * HY * HX * 4;        // (halo voxel, channel quad) float4 items per chunk
     static constexpr int ITERS = (ITEMS + 255) / 256;
-    static constexpr int PER_PART = (ITERS + 2) / 3;
+    static constexpr int NPARTS = 9;                      // staging parts per chunk = (z tap, y tap) groups of 3 taps
+    static constexpr int PER_PART = (ITERS + NPARTS - 1) / NPARTS;
 };
 
 // one staged item: global float4 (4 channels of one halo voxel) -> affine -> 4 bf16 -> 8 bytes of LDS
@@ -82,14 +83,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
     const int cbeg = split * cps, nch = min(nch_all, cbeg + cps);  // this block's chunk range [cbeg, nch)
     const int ntiles = p.K >> 5;
     const int q = t & 3;  // this thread's channel quad within a chunk (item & 3 == t & 3 for every item it stages)
-
-    f32x16 acc[G::MT][NT];
-#pragma unroll
-    for (int m = 0; m < G::MT; ++m)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[m][j][e] = 0.f;
 
     // A-fragment base of this lane: row r = lane & 31 -> (yy = r & 3, xx = r >> 2), channel half kh = lane >> 5
     const int r = lane & 31, kh = lane >> 5;
@@ -130,18 +123,40 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
         u3d_load_affine(p.affine, n, p.C, (c << 4) + 4 * q, true, ga, gb);
     };
 
-    // ---- prologue: the first chunk into its buffer
+    // ---- prologue: the first chunk into its buffer, 8 loads in flight per thread (the accumulators are not live yet)
     if (cbeg < nch) {
         f32x4 ga, gb;
         chunk_affine(cbeg, ga, gb);
 #pragma unroll 1
-        for (int it = 0; it < G::ITERS; ++it) {
-            f32x4 v;
-            load_item(cbeg, it, v);
-            store_item(lds + (cbeg & 1) * G::BUF, it, v, ga, gb);
+        for (int it0 = 0; it0 < G::ITERS; it0 += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) load_item(cbeg, it0 + i, v[i]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) store_item(lds + (cbeg & 1) * G::BUF, it0 + i, v[i], ga, gb);
         }
     }
+    f32x16 acc[G::MT][NT];
+#pragma unroll
+    for (int m = 0; m < G::MT; ++m)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][j][e] = 0.f;
 
+    // Software pipeline (the compiler's own schedule issues every load right before its use — ~400 cycles of L1/L2 latency and
+    // an LDS round trip exposed per tap): B fragments run two taps ahead in a 3-slot register ring (across chunk boundaries: the
+    // packed image is linear in (chunk, tap)), each A fragment is refilled for the next tap right after its MFMAs, the next
+    // chunk's halo items are fetched at the start of a 3-tap part and written at its end; sched_barriers pin "issue the prefetches, then the 4*ZW*NT MFMAs".
+    bf16x8 bq[3][NT];
+    if (cbeg < nch) {
+        const bf16x8* wp0 = p.wpk + ((size_t)cbeg * 27 * ntiles + (size_t)nb * NT) * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            bq[0][j] = wp0[(size_t)j * 64];
+            bq[1][j] = wp0[((size_t)ntiles + j) * 64];
+        }
+    }
     for (int c = cbeg; c < nch; ++c) {
         __syncthreads();  // buffer (c&1) is complete; everyone is done reading buffer ((c+1)&1)
         const char* cur = lds + (c & 1) * G::BUF;
@@ -150,28 +165,37 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
         f32x4 ga, gb;
         if (more) chunk_affine(c + 1, ga, gb);
         const bf16x8* wp = p.wpk + ((size_t)c * 27 * ntiles + (size_t)nb * NT) * 64 + lane;
+        f32x4 st[G::PER_PART];  // the next chunk's halo items of one part: loaded at the part's start, stored at its end
+        bf16x8 aq[G::MT];  // one set: fragment m is refilled for the next tap right after its MFMAs of this tap
 #pragma unroll
-        for (int part = 0; part < 3; ++part) {  // part = z tap
-            f32x4 st[G::PER_PART];
+        for (int m = 0; m < G::MT; ++m)
+            aq[m] = *reinterpret_cast<const bf16x8*>(cur + a_base + ((((m >> 1)) * HY + ((m & 1) * 4)) * HS) * 16);
+#pragma unroll
+        for (int part = 0; part < G::NPARTS; ++part) {  // part = (z tap, y tap)
             if (more) {
 #pragma unroll
                 for (int i = 0; i < G::PER_PART; ++i)
                     if (part * G::PER_PART + i < G::ITERS) load_item(c + 1, part * G::PER_PART + i, st[i]);
             }
 #pragma unroll
-            for (int t9 = 0; t9 < 9; ++t9) {
-                const int tap = part * 9 + t9, tyy = t9 / 3, txx = t9 % 3;
-                bf16x8 b[NT];
+            for (int t3 = 0; t3 < 3; ++t3) {
+                const int tap = part * 3 + t3;
+                if (tap + 2 < 27 || more) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) b[j] = wp[((size_t)tap * ntiles + j) * 64];
+                    for (int j = 0; j < NT; ++j) bq[(tap + 2) % 3][j] = wp[((size_t)(tap + 2) * ntiles + j) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int nt_ = tap + 1, tzz = nt_ / 9, tyy = (nt_ / 3) % 3, txx = nt_ % 3;
 #pragma unroll
                 for (int m = 0; m < G::MT; ++m) {
-                    const int zl = m >> 1, yh = m & 1;
-                    const int off = (((zl + part) * HY + (yh * 4 + tyy)) * HS + txx) * 16;
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(cur + a_base + off);
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[j], acc[m][j], 0, 0, 0);
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[m], bq[tap % 3][j], acc[m][j], 0, 0, 0);
+                    if (nt_ < 27) {
+                        const int off = ((((m >> 1) + tzz) * HY + ((m & 1) * 4 + tyy)) * HS + txx) * 16;
+                        aq[m] = *reinterpret_cast<const bf16x8*>(cur + a_base + off);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (more) {
@@ -207,20 +231,28 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
 #pragma unroll
     for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
     const bool want_stats = p.out_stats != nullptr, want_g = p.gstats != nullptr;
+    const float* side = p.residual ? p.residual : (want_g ? p.gx : nullptr);  // the one tensor the epilogue reads (exclusive)
 #pragma unroll
     for (int m = 0; m < G::MT; ++m) {
         const int z = z0 + w * ZW + (m >> 1);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int y = y0 + (m & 1) * 4 + (e & 3), xx = x0 + 2 * (e >> 2) + half;
-            const bool ok = z < p.D && y < p.H && xx < p.W;
-            if (ok) {
-                const size_t vox = (((size_t)n * p.D + z) * p.H + y) * p.W + xx;
+        for (int j = 0; j < NT; ++j) {
+            // all 16 side loads of this accumulator tile in flight before the first use
+            f32x16 sv;
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const size_t o = vox * p.K + (size_t)(nb * NT + j) * 32 + col;
+            for (int e = 0; e < 16; ++e) {
+                const int y = y0 + (m & 1) * 4 + (e & 3), xx = x0 + 2 * (e >> 2) + half;
+                sv[e] = 0.f;
+                if (side && z < p.D && y < p.H && xx < p.W)
+                    sv[e] = side[((((size_t)n * p.D + z) * p.H + y) * p.W + xx) * p.K + (size_t)(nb * NT + j) * 32 + col];
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int y = y0 + (m & 1) * 4 + (e & 3), xx = x0 + 2 * (e >> 2) + half;
+                if (z < p.D && y < p.H && xx < p.W) {
+                    const size_t o = ((((size_t)n * p.D + z) * p.H + y) * p.W + xx) * p.K + (size_t)(nb * NT + j) * 32 + col;
                     float v = acc[m][j][e];
-                    if (p.residual) v += p.residual[o];
+                    if (p.residual) v += sv[e];
                     if (p.relu) v = fmaxf(v, 0.f);
                     p.y[o] = v;
                     if (want_stats) {
@@ -228,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
                         s2[j] = fmaf(v, v, s2[j]);
                     } else if (want_g) {
                         s1[j] += v;
-                        s2[j] = fmaf(v, p.gx[o], s2[j]);
+                        s2[j] = fmaf(v, sv[e], s2[j]);
                     }
                 }
             }
@@ -398,6 +430,7 @@ extern "C" int u3d_conv3d_bf16_ex(int device, u3d_stream_t stream, const float* 
     U3D_REQUIRE(u3d_conv3d_bf16_supported(C, K), "u3d_conv3d_bf16: needs Cin %% 16 == 0 and Cout %% 32 == 0 (got %d, %d)", C, K);
     U3D_REQUIRE(!(out_stats && gstats), "u3d_conv3d_bf16: out_stats and gstats are mutually exclusive");
     U3D_REQUIRE(!gstats || gx, "u3d_conv3d_bf16: gstats needs gx");
+    U3D_REQUIRE(!(residual && gstats), "u3d_conv3d_bf16: residual and gx/gstats are mutually exclusive");
     U3D_REQUIRE((((uintptr_t)x | (uintptr_t)packed_w | (uintptr_t)affine) & 15) == 0, "u3d_conv3d_bf16: 16-byte alignment");
     bf16_conv_params p{x, affine, reinterpret_cast<const bf16x8*>(packed_w), out, residual, gx, out_stats, gstats,
                        N, D, H, W, C, K, relu, 0, 0, 0, 1, nullptr};
@@ -466,14 +499,101 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* lds_addr) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+constexpr int WG_G_ITERS = (WG_G_ITEMS + 511) / 512;    // 12 halo items per thread
+constexpr int WG_DZ_ITERS = (WG_DZ_ITEMS + 511) / 512;  // 8 dz items per thread
+constexpr int WG_ITERS = WG_G_ITERS + WG_DZ_ITERS;      // 20 = 4 parts x 5
+constexpr int WG_PARTS = 4, WG_PER_PART = WG_ITERS / WG_PARTS;
+static_assert(WG_PER_PART * WG_PARTS == WG_ITERS, "staging items must split evenly over the parts");
+
+struct wg_tile {
+    int n, z0, y0, x0;
+};
+
+// One block per CU (8 waves, 163 VGPRs): the staging of tile i+1 must overlap the MFMAs of tile i INSIDE the block — two LDS
+// buffers; the next tile's 20 items per thread are fetched in four batches of five at the start of each 4-row part of the
+// current tile and written (affine, bf16) to the other buffer at the part's end; one barrier per tile.
 __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wgrad_params p) {
-    __shared__ __attribute__((aligned(256))) char lds[WG_LDS];
+    extern __shared__ __attribute__((aligned(256))) char lds[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int P = (p.C >> 5) * p.pco;
     const int pair = blockIdx.x % P, split = blockIdx.x / P;
     const int cib = pair / p.pco, cob = pair % p.pco;
     const int c0 = cib * 32, k0 = cob * 64;
     const int h = w >> 2, wq = w & 3;
+
+    auto decode = [&](int tile) {
+        wg_tile r;
+        int tt = tile;
+        r.x0 = (tt % p.tx) * WG_TX;
+        tt /= p.tx;
+        r.y0 = (tt % p.ty) * WG_TY;
+        tt /= p.ty;
+        r.z0 = (tt % p.tz) * WG_TZ;
+        r.n = tt / p.tz;
+        return r;
+    };
+    // staging item `it` of this thread: it < WG_G_ITERS: (halo voxel, quad t & 7) of the g tile, else (voxel, quad t & 15) of dz
+    auto load_item = [&](const wg_tile& tl, int it, f32x4& v) {
+        v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (it < WG_G_ITERS) {
+            const int item = t + it * 512;
+            if (item < WG_G_ITEMS) {
+                const int q = item & 7, hv = item >> 3;
+                const int hz = hv / (WG_HY * WG_HX), rem = hv - hz * (WG_HY * WG_HX);
+                const int hy = rem / WG_HX, hx = rem - hy * WG_HX;
+                const int z = tl.z0 - 1 + hz, y = tl.y0 - 1 + hy, xx = tl.x0 - 1 + hx;
+                if ((unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
+                    v = *reinterpret_cast<const f32x4*>(p.x + ((((size_t)tl.n * p.D + z) * p.H + y) * p.W + xx) * p.C + c0 + 4 * q);
+            }
+        } else {
+            const int item = t + (it - WG_G_ITERS) * 512;
+            const int q = item & 15, vv = item >> 4;
+            const int zl = vv / (WG_TY * WG_TX), rem = vv - zl * (WG_TY * WG_TX);
+            const int yl = rem / WG_TX, xl = rem - yl * WG_TX;
+            const int z = tl.z0 + zl, y = tl.y0 + yl, xx = tl.x0 + xl;
+            if (z < p.D && y < p.H && xx < p.W)
+                v = *reinterpret_cast<const f32x4*>(p.dz + ((((size_t)tl.n * p.D + z) * p.H + y) * p.W + xx) * p.K + k0 + 4 * q);
+        }
+    };
+    auto store_item = [&](char* buf, const wg_tile& tl, int it, const f32x4& v, const f32x4& ga, const f32x4& gb) {
+        bf16x4 o = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+        if (it < WG_G_ITERS) {
+            const int item = t + it * 512;
+            if (item < WG_G_ITEMS) {
+                const int q = item & 7, hv = item >> 3;
+                const int hz = hv / (WG_HY * WG_HX), rem = hv - hz * (WG_HY * WG_HX);
+                const int hy = rem / WG_HX, hx = rem - hy * WG_HX;
+                const int z = tl.z0 - 1 + hz, y = tl.y0 - 1 + hy, xx = tl.x0 - 1 + hx;
+                if ((unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)fmaf(v[e], ga[e], gb[e]);  // zero padding applies AFTER the affine
+                }
+                *reinterpret_cast<bf16x4*>(buf + hv * 64 + q * 8) = o;
+            }
+        } else {
+            const int item = t + (it - WG_G_ITERS) * 512;
+            const int q = item & 15, vv = item >> 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];  // (zero outside the volume: loaded as zero)
+            *reinterpret_cast<bf16x4*>(buf + WG_G_BYTES + (q >> 3) * WG_DZ_HALF + vv * 64 + (q & 7) * 8) = o;
+        }
+    };
+
+    const int first = split * p.per_block, last = min(p.tiles, first + p.per_block);
+    // ---- prologue: the first tile into buffer 0 (the accumulators are not live yet: 10 loads in flight per thread)
+    if (first < last) {
+        const wg_tile tl = decode(first);
+        f32x4 ga, gb;
+        u3d_load_affine(p.affine, tl.n, p.C, c0 + 4 * (t & 7), true, ga, gb);
+#pragma unroll 1
+        for (int it0 = 0; it0 < WG_ITERS; it0 += 10) {
+            f32x4 v[10];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) load_item(tl, it0 + i, v[i]);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) store_item(lds, tl, it0 + i, v[i], ga, gb);
+        }
+    }
 
     f32x16 acc[7];
 #pragma unroll
@@ -494,62 +614,42 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wg
     }
     const int b_off = WG_G_BYTES + h * WG_DZ_HALF + lane_off;
 
-    const int first = split * p.per_block, last = min(p.tiles, first + p.per_block);
     for (int tile = first; tile < last; ++tile) {
-        int tt = tile;
-        const int txi = tt % p.tx;
-        tt /= p.tx;
-        const int tyi = tt % p.ty;
-        tt /= p.ty;
-        const int tzi = tt % p.tz;
-        const int n = tt / p.tz;
-        const int z0 = tzi * WG_TZ, y0 = tyi * WG_TY, x0 = txi * WG_TX;
-        __syncthreads();  // the previous tile's fragment reads are done
-        // ---- stage the g halo tile: fp32 -> GroupNorm affine -> bf16, zero outside the volume
-        for (int item = t; item < WG_G_ITEMS; item += 512) {
-            const int q = item & 7, hv = item >> 3;
-            const int hz = hv / (WG_HY * WG_HX), rem = hv - hz * (WG_HY * WG_HX);
-            const int hy = rem / WG_HX, hx = rem - hy * WG_HX;
-            const int z = z0 - 1 + hz, y = y0 - 1 + hy, xx = x0 - 1 + hx;
-            bf16x4 o = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-            if ((unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
-                const size_t vox = (((size_t)n * p.D + z) * p.H + y) * p.W + xx;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + vox * p.C + c0 + 4 * q);
-                f32x4 ga, gb;
-                u3d_load_affine(p.affine, n, p.C, c0 + 4 * q, true, ga, gb);
+        __syncthreads();  // buffer (tile - first) & 1 is complete; everyone is done reading the other one
+        const char* cur = lds + ((tile - first) & 1) * WG_LDS;
+        char* nxt = lds + ((tile - first + 1) & 1) * WG_LDS;
+        const bool more = tile + 1 < last;
+        const wg_tile tn = decode(more ? tile + 1 : tile);
+        f32x4 ga, gb;
+        if (more) u3d_load_affine(p.affine, tn.n, p.C, c0 + 4 * (t & 7), true, ga, gb);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (__bf16)fmaf(v[e], ga[e], gb[e]);
+        for (int part = 0; part < WG_PARTS; ++part) {
+            f32x4 st[WG_PER_PART];
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < WG_PER_PART; ++i) load_item(tn, part * WG_PER_PART + i, st[i]);
             }
-            *reinterpret_cast<bf16x4*>(lds + hv * 64 + q * 8) = o;
-        }
-        // ---- stage the dz tile (two 32-channel halves)
-        for (int item = t; item < WG_DZ_ITEMS; item += 512) {
-            const int q = item & 15, v = item >> 4;
-            const int zl = v / (WG_TY * WG_TX), rem = v - zl * (WG_TY * WG_TX);
-            const int yl = rem / WG_TX, xl = rem - yl * WG_TX;
-            const int z = z0 + zl, y = y0 + yl, xx = x0 + xl;
-            bf16x4 o = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-            if (z < p.D && y < p.H && xx < p.W) {
-                const size_t vox = (((size_t)n * p.D + z) * p.H + y) * p.W + xx;
-                const f32x4 d = *reinterpret_cast<const f32x4*>(p.dz + vox * p.K + k0 + 4 * q);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- 4 rows of 16 voxels: one dz fragment per row, one g fragment + MFMA per tap of this wave (g fragments one tap ahead)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (__bf16)d[e];
-            }
-            *reinterpret_cast<bf16x4*>(lds + WG_G_BYTES + (q >> 3) * WG_DZ_HALF + v * 64 + (q & 7) * 8) = o;
-        }
-        __syncthreads();
-        // ---- 16 rows of 16 voxels: one dz fragment per row, one g fragment + MFMA per tap of this wave
-#pragma unroll 2
-        for (int kg = 0; kg < WG_TZ * WG_TY; ++kg) {
-            const int zl = kg / WG_TY, yl = kg % WG_TY;
-            const bf16x8 b = tr_frag(lds + b_off + (zl * WG_TY + yl) * WG_TX * 64);
-            const int row = (zl * WG_HY + yl) * WG_HX * 64;
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int kg = part * 4 + r4;
+                const int zl = kg / WG_TY, yl = kg % WG_TY;
+                const int row = (zl * WG_HY + yl) * WG_HX * 64;
+                const bf16x8 b = tr_frag(cur + b_off + (zl * WG_TY + yl) * WG_TX * 64);
+                bf16x8 a = tr_frag(cur + a_off[0] + row);
 #pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                if (i < 6 || wq < 3) {
-                    const bf16x8 a = tr_frag(lds + a_off[i] + row);
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+                for (int i = 0; i < 7; ++i) {
+                    bf16x8 an = a;
+                    if (i + 1 < 7) an = tr_frag(cur + a_off[i + 1] + row);
+                    if (i < 6 || wq < 3) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+                    a = an;
                 }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < WG_PER_PART; ++i) store_item(nxt, tn, part * WG_PER_PART + i, st[i], ga, gb);
             }
         }
     }
@@ -627,7 +727,9 @@ extern "C" int u3d_conv3d_wgrad_bf16(int device, u3d_stream_t stream, const floa
     if (!workspace || workspace_floats < need)
         return u3d_set_err(U3D_EWORKSPACE, "u3d_conv3d_wgrad_bf16: workspace of %lld floats needed, %lld given", need, workspace_floats);
     bf16_wgrad_params p{x, affine, dz, workspace, N, D, H, W, C, K, q.tz, q.ty, q.tx, q.tiles, q.per_block, K / 64};
-    hipLaunchKernelGGL(conv3d_wgrad_bf16_kernel, dim3((unsigned)(q.S * q.P)), dim3(512), 0, (hipStream_t)stream, p);
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * WG_LDS));
+    hipLaunchKernelGGL(conv3d_wgrad_bf16_kernel, dim3((unsigned)(q.S * q.P)), dim3(512), 2 * WG_LDS, (hipStream_t)stream, p);
     U3D_LAUNCH_CHECK();
     long long rb = ((long long)C * K * 27 + 255) / 256;
     if (rb > 8192) rb = 8192;
