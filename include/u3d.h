@@ -388,6 +388,29 @@ long long u3d_wgrad_bf16_workspace_floats(int N, int D, int H, int W, int Cin, i
 int u3d_conv3d_wgrad_bf16(int device, u3d_stream_t stream, const float* x, const float* affine, const float* dz, float* dw,
                           int N, int D, int H, int W, int Cin, int Cout, float* workspace, long long workspace_floats);
 
+/* nn.ConvTranspose3d(in, out, 3, stride=2, padding=1, bias=False) (buildingblocks.py:653-662) and its two gradients on the bf16
+ * MFMA kernels, in SPACE-TO-DEPTH form: the (2n-1)^3 output is stored as T8 (N,D1,H1,W1, 8*Cout) with
+ * T8[i][p*Cout + co] = t[2i + p][co] (p = pz*4 + py*2 + px), which turns all three passes into 2x2x2 convolutions on the low-res
+ * grid (64/27 = 2.4x the minimal multiply-adds).  u3d_nearest_add_fwd_t8 / u3d_nearest_sum_bwd_t8 are u3d_nearest_add_fwd /
+ * _sum_bwd reading / writing that layout (T8 entries outside the (2n-1) grid are written as zero, never read).
+ * Needs Cin % 32 == 0 and Cout % 8 == 0.  packed: u3d_pack_convtr3d_t8 image of w (Cin,Cout,3,3,3), mode 0 forward, 1 data
+ * gradient.  x_mask (optional): dx = x_mask > 0 ? dx : 0 (ReLU mask of the tensor that was upsampled). */
+int u3d_convtr3d_t8_supported(int Cin, int Cout);
+long long u3d_convtr3d_t8_packed_elems(int Cin, int Cout, int mode);
+int u3d_pack_convtr3d_t8(int device, u3d_stream_t stream, const float* w, int Cin, int Cout, int mode, void* packed);
+int u3d_convtr3d_fwd_t8(int device, u3d_stream_t stream, const float* x, const void* packed, float* t8, int N, int D1, int H1,
+                        int W1, int Cin, int Cout);
+int u3d_convtr3d_dgrad_t8(int device, u3d_stream_t stream, const float* dt8, const void* packed, const float* x_mask, float* dx,
+                          int N, int D1, int H1, int W1, int Cin, int Cout);
+long long u3d_convtr3d_wgrad_t8_workspace_floats(int N, int D1, int H1, int W1, int Cin, int Cout);
+int u3d_convtr3d_wgrad_t8(int device, u3d_stream_t stream, const float* x, const float* dt8, float* dw, int N, int D1, int H1,
+                          int W1, int Cin, int Cout, float* workspace, long long workspace_floats);
+int u3d_nearest_add_fwd_t8(int device, u3d_stream_t stream, const float* skip, const float* t8, const int32_t* zmap,
+                           const int32_t* ymap, const int32_t* xmap, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C,
+                           float* out, double* out_stats);
+int u3d_nearest_sum_bwd_t8(int device, u3d_stream_t stream, const float* dj, const int32_t* zlo, const int32_t* ylo,
+                           const int32_t* xlo, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C, float* dt8);
+
 /* ---- layer orders other than 'gcr' (buildingblocks.py:10-96): LeakyReLU / ELU, GroupNorm after the convolution --------
  * Activation codes: 0 none, 1 nn.ReLU, 2 nn.LeakyReLU(slope) (buildingblocks.py:49: 0.01; ResNetBlock :271: 0.1), 3 nn.ELU
  * (alpha 1, :51).  The convolutions run with their epilogue ReLU off; these passes supply the rest:

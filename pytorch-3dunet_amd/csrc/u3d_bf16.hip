@@ -20,9 +20,11 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+extern int g_u3d_tune[8];  // csrc/u3d_conv.hip: run-time A/B knobs (u3d_set_tuning); results never change
+
 namespace {
 
-constexpr int HY = 10, HX = 10, HS = 12;  // halo extent in y / x, padded row stride (records)
+constexpr int HS = 12;  // padded halo row stride (16-byte records): conflict-free ds_read_b128 (see the header), >= 8 + KS - 1
 
 struct bf16_conv_params {
     const float* x;        // (N,D,H,W,C) fp32
@@ -35,34 +37,41 @@ struct bf16_conv_params {
     double* gstats;        // [N][K][2] += (sum y, sum y*gx) or null
     int N, D, H, W, C, K, relu;
     int tz, ty, tx;        // tiles per dimension
+    int off;               // halo origin = tile origin - off: 1 for the 3x3x3 'same' convolution; the 2x2x2 kernels of the
+                           // transposed convolution (§ below) read [i, i+1] (off 0, forward) or [i-1, i] (off 1, data gradient)
+    const float* maskx;    // (N,D,H,W,K) or null: out = maskx > 0 ? out : 0 (ReLU mask of the tensor this gradient flows into)
     int ksplit;            // > 1: the channel reduction is split over `ksplit` blocks per (tile, channel block); raw partial
     float* ws;             //      sums go to ws[split][voxel][K] and splitk_bf16_reduce_kernel owns the epilogue
 };
 
-template <int ZW>
+template <int ZW, int KS>
 struct tile_geom {
-    static constexpr int TZ = 4 * ZW, HZ = TZ + 2, MT = 2 * ZW;
+    static constexpr int TZ = 4 * ZW, HZ = TZ + KS - 1, HY = 8 + KS - 1, HX = 8 + KS - 1, MT = 2 * ZW;
+    static constexpr int NTAPS = KS * KS * KS;
+    static constexpr int RING = KS == 3 ? 3 : 4;          // B-fragment ring: NTAPS % RING == 0 keeps the slots aligned across chunks
     static constexpr int PLANE = HZ * HY * HS * 16 + 64;  // bytes; +64: the two planes' writes land on different banks
     static constexpr int BUF = 2 * PLANE;
     static constexpr int ITEMS = HZ * HY * HX * 4;        // (halo voxel, channel quad) float4 items per chunk
     static constexpr int ITERS = (ITEMS + 255) / 256;
-    static constexpr int NPARTS = 9;                      // staging parts per chunk = (z tap, y tap) groups of 3 taps
+    static constexpr int NPARTS = KS * KS;                // staging parts per chunk = (z tap, y tap) groups of KS taps
     static constexpr int PER_PART = (ITERS + NPARTS - 1) / NPARTS;
 };
 
 // one staged item: global float4 (4 channels of one halo voxel) -> affine -> 4 bf16 -> 8 bytes of LDS
-template <int ZW>
+template <int ZW, int KS>
 __device__ __forceinline__ void item_coords(int item, int& hz, int& hy, int& hx) {
+    using G = tile_geom<ZW, KS>;
     const int hv = item >> 2;
-    hz = hv / (HY * HX);
-    const int rem = hv - hz * (HY * HX);
-    hy = rem / HX;
-    hx = rem - hy * HX;
+    hz = hv / (G::HY * G::HX);
+    const int rem = hv - hz * (G::HY * G::HX);
+    hy = rem / G::HX;
+    hx = rem - hy * G::HX;
 }
 
-template <int NT, int ZW>
+template <int NT, int ZW, int KS>
 __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_params p) {
-    using G = tile_geom<ZW>;
+    using G = tile_geom<ZW, KS>;
+    constexpr int HY = G::HY;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int nblk = p.K / (32 * NT);
@@ -93,8 +102,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
         v = f32x4{0.f, 0.f, 0.f, 0.f};
         if (item < G::ITEMS) {
             int hz, hy, hx;
-            item_coords<ZW>(item, hz, hy, hx);
-            const int z = z0 - 1 + hz, y = y0 - 1 + hy, xx = x0 - 1 + hx;
+            item_coords<ZW, KS>(item, hz, hy, hx);
+            const int z = z0 - p.off + hz, y = y0 - p.off + hy, xx = x0 - p.off + hx;
             if ((unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
                 const size_t vox = (((size_t)n * p.D + z) * p.H + y) * p.W + xx;
                 v = *reinterpret_cast<const f32x4*>(p.x + vox * p.C + (c << 4) + 4 * q);
@@ -105,9 +114,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
         const int item = t + it * 256;
         if (item < G::ITEMS) {
             int hz, hy, hx;
-            item_coords<ZW>(item, hz, hy, hx);
+            item_coords<ZW, KS>(item, hz, hy, hx);
             bf16x4 o;
-            const int z = z0 - 1 + hz, y = y0 - 1 + hy, xx = x0 - 1 + hx;
+            const int z = z0 - p.off + hz, y = y0 - p.off + hy, xx = x0 - p.off + hx;
             if (!((unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)) {
                 // zero padding applies AFTER the GroupNorm affine: Conv3d(padding=1) pads the normalised tensor
                 o = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
@@ -148,9 +157,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
     // an LDS round trip exposed per tap): B fragments run two taps ahead in a 3-slot register ring (across chunk boundaries: the
     // packed image is linear in (chunk, tap)), each A fragment is refilled for the next tap right after its MFMAs, the next
     // chunk's halo items are fetched at the start of a 3-tap part and written at its end; sched_barriers pin "issue the prefetches, then the 4*ZW*NT MFMAs".
-    bf16x8 bq[3][NT];
+    bf16x8 bq[G::RING][NT];
     if (cbeg < nch) {
-        const bf16x8* wp0 = p.wpk + ((size_t)cbeg * 27 * ntiles + (size_t)nb * NT) * 64 + lane;
+        const bf16x8* wp0 = p.wpk + ((size_t)cbeg * G::NTAPS * ntiles + (size_t)nb * NT) * 64 + lane;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             bq[0][j] = wp0[(size_t)j * 64];
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
         const bool more = c + 1 < nch;
         f32x4 ga, gb;
         if (more) chunk_affine(c + 1, ga, gb);
-        const bf16x8* wp = p.wpk + ((size_t)c * 27 * ntiles + (size_t)nb * NT) * 64 + lane;
+        const bf16x8* wp = p.wpk + ((size_t)c * G::NTAPS * ntiles + (size_t)nb * NT) * 64 + lane;
         f32x4 st[G::PER_PART];  // the next chunk's halo items of one part: loaded at the part's start, stored at its end
         bf16x8 aq[G::MT];  // one set: fragment m is refilled for the next tap right after its MFMAs of this tap
 #pragma unroll
@@ -178,20 +187,20 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
                     if (part * G::PER_PART + i < G::ITERS) load_item(c + 1, part * G::PER_PART + i, st[i]);
             }
 #pragma unroll
-            for (int t3 = 0; t3 < 3; ++t3) {
-                const int tap = part * 3 + t3;
-                if (tap + 2 < 27 || more) {
+            for (int t3 = 0; t3 < KS; ++t3) {
+                const int tap = part * KS + t3;
+                if (tap + 2 < G::NTAPS || more) {
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) bq[(tap + 2) % 3][j] = wp[((size_t)(tap + 2) * ntiles + j) * 64];
+                    for (int j = 0; j < NT; ++j) bq[(tap + 2) % G::RING][j] = wp[((size_t)(tap + 2) * ntiles + j) * 64];
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                const int nt_ = tap + 1, tzz = nt_ / 9, tyy = (nt_ / 3) % 3, txx = nt_ % 3;
+                const int nt_ = tap + 1, tzz = nt_ / (KS * KS), tyy = (nt_ / KS) % KS, txx = nt_ % KS;
 #pragma unroll
                 for (int m = 0; m < G::MT; ++m) {
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[m], bq[tap % 3][j], acc[m][j], 0, 0, 0);
-                    if (nt_ < 27) {
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[m], bq[tap % G::RING][j], acc[m][j], 0, 0, 0);
+                    if (nt_ < G::NTAPS) {
                         const int off = ((((m >> 1) + tzz) * HY + ((m & 1) * 4 + tyy)) * HS + txx) * 16;
                         aq[m] = *reinterpret_cast<const bf16x8*>(cur + a_base + off);
                     }
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
 #pragma unroll
     for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
     const bool want_stats = p.out_stats != nullptr, want_g = p.gstats != nullptr;
-    const float* side = p.residual ? p.residual : (want_g ? p.gx : nullptr);  // the one tensor the epilogue reads (exclusive)
+    const float* side = p.residual ? p.residual : (want_g ? p.gx : p.maskx);  // the one tensor the epilogue reads (exclusive)
 #pragma unroll
     for (int m = 0; m < G::MT; ++m) {
         const int z = z0 + w * ZW + (m >> 1);
@@ -253,6 +262,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
                     const size_t o = ((((size_t)n * p.D + z) * p.H + y) * p.W + xx) * p.K + (size_t)(nb * NT + j) * 32 + col;
                     float v = acc[m][j][e];
                     if (p.residual) v += sv[e];
+                    if (p.maskx && !(sv[e] > 0.f)) v = 0.f;
                     if (p.relu) v = fmaxf(v, 0.f);
                     p.y[o] = v;
                     if (want_stats) {
@@ -299,6 +309,7 @@ __global__ __launch_bounds__(256) void splitk_bf16_reduce_kernel(const bf16_conv
         float acc = 0.f;
         for (int s = 0; s < p.ksplit; ++s) acc += p.ws[s * split_stride + o];
         if (p.residual) acc += p.residual[o];
+        if (p.maskx && !(p.maskx[o] > 0.f)) acc = 0.f;
         if (p.relu) acc = fmaxf(acc, 0.f);
         p.y[o] = acc;
         s1 += acc;
@@ -366,9 +377,9 @@ extern "C" int u3d_pack_weights_bf16(int device, u3d_stream_t stream, const floa
 
 extern "C" int u3d_conv3d_bf16_supported(int C, int K) { return (C > 0 && K > 0 && C % 16 == 0 && K % 32 == 0) ? 1 : 0; }
 
-template <int NT, int ZW>
+template <int NT, int ZW, int KS>
 static int launch_bf16(const bf16_conv_params& p, hipStream_t stream) {
-    using G = tile_geom<ZW>;
+    using G = tile_geom<ZW, KS>;
     bf16_conv_params q = p;
     q.tz = (p.D + G::TZ - 1) / G::TZ;
     q.ty = (p.H + 7) / 8;
@@ -377,9 +388,9 @@ static int launch_bf16(const bf16_conv_params& p, hipStream_t stream) {
     if (blocks > 0x7fffffffLL) return u3d_set_err(U3D_EINVAL, "u3d_conv3d_bf16: grid too large");
     const size_t shmem = 2 * (size_t)G::BUF;
     // (per device, cheap: set on every launch so that every device of a multi-GPU process has it)
-    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_bf16_kernel<NT, ZW>),
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_bf16_kernel<NT, ZW, KS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL((conv3d_bf16_kernel<NT, ZW>), dim3((unsigned)blocks), dim3(256), shmem, stream, q);
+    hipLaunchKernelGGL((conv3d_bf16_kernel<NT, ZW, KS>), dim3((unsigned)blocks), dim3(256), shmem, stream, q);
     U3D_LAUNCH_CHECK();
     if (p.ksplit > 1) {
         const long long V = (long long)p.D * p.H * p.W;
@@ -433,7 +444,7 @@ extern "C" int u3d_conv3d_bf16_ex(int device, u3d_stream_t stream, const float* 
     U3D_REQUIRE(!(residual && gstats), "u3d_conv3d_bf16: residual and gx/gstats are mutually exclusive");
     U3D_REQUIRE((((uintptr_t)x | (uintptr_t)packed_w | (uintptr_t)affine) & 15) == 0, "u3d_conv3d_bf16: 16-byte alignment");
     bf16_conv_params p{x, affine, reinterpret_cast<const bf16x8*>(packed_w), out, residual, gx, out_stats, gstats,
-                       N, D, H, W, C, K, relu, 0, 0, 0, 1, nullptr};
+                       N, D, H, W, C, K, relu, 0, 0, 0, 1, nullptr, 1, nullptr};
     const int ks = bf16_ksplit(N, D, H, W, C, K);
     if (ks > 1 && workspace && workspace_floats >= (long long)ks * N * D * H * W * K) {
         p.ksplit = ks;
@@ -443,10 +454,12 @@ extern "C" int u3d_conv3d_bf16_ex(int device, u3d_stream_t stream, const float* 
     // of the U); 64 output channels per block when possible
     const bool nt2 = K % 64 == 0;
     const long long big = (long long)N * ((D + 7) / 8) * ((H + 7) / 8) * ((W + 7) / 8) * (K / (nt2 ? 64 : 32));
-    const bool zw2 = big >= 512 && D >= 8 && p.ksplit == 1;
+    bool zw2 = big >= 512 && D >= 8 && p.ksplit == 1;
+    if (g_u3d_tune[7] == 1) zw2 = false;  // A/B knob (u3d_set_tuning key 7): 1 = 4-plane tiles everywhere, 2 = 8-plane wherever legal
+    if (g_u3d_tune[7] == 2) zw2 = D >= 8 && p.ksplit == 1;
     hipStream_t s = (hipStream_t)stream;
-    if (nt2) return zw2 ? launch_bf16<2, 2>(p, s) : launch_bf16<2, 1>(p, s);
-    return zw2 ? launch_bf16<1, 2>(p, s) : launch_bf16<1, 1>(p, s);
+    if (nt2) return zw2 ? launch_bf16<2, 2, 3>(p, s) : launch_bf16<2, 1, 3>(p, s);
+    return zw2 ? launch_bf16<1, 2, 3>(p, s) : launch_bf16<1, 1, 3>(p, s);
 }
 
 // =====================================================================================================================
@@ -467,19 +480,32 @@ extern "C" int u3d_conv3d_bf16_ex(int device, u3d_stream_t stream, const float* 
 namespace {
 
 constexpr int WG_TZ = 2, WG_TY = 8, WG_TX = 16;
-constexpr int WG_HZ = WG_TZ + 2, WG_HY = WG_TY + 2, WG_HX = WG_TX + 2;
-constexpr int WG_G_BYTES = WG_HZ * WG_HY * WG_HX * 64;       // [hz][hy][hx][32 ci] bf16
 constexpr int WG_DZ_HALF = WG_TZ * WG_TY * WG_TX * 64;       // [z][y][x][32 co] bf16, two halves
-constexpr int WG_LDS = WG_G_BYTES + 2 * WG_DZ_HALF;          // 46080 + 32768 = 78848 bytes
-constexpr int WG_G_ITEMS = WG_HZ * WG_HY * WG_HX * 8;        // (halo voxel, channel quad)
 constexpr int WG_DZ_ITEMS = WG_TZ * WG_TY * WG_TX * 16;      // (voxel, channel quad of 64)
+constexpr int WG_DZ_ITERS = (WG_DZ_ITEMS + 511) / 512;       // 8 dz items per thread
+
+// KS = 3: the 3x3x3 'same' convolution; KS = 2: the 2x2x2 kernels of the transposed convolution in space-to-depth form
+template <int KS>
+struct wg_geom {
+    static constexpr int HZ = WG_TZ + KS - 1, HY = WG_TY + KS - 1, HX = WG_TX + KS - 1;
+    static constexpr int G_BYTES = HZ * HY * HX * 64;         // [hz][hy][hx][32 ci] bf16 (KS 3: 46080)
+    static constexpr int LDS = G_BYTES + 2 * WG_DZ_HALF;      // KS 3: 78848 bytes
+    static constexpr int G_ITEMS = HZ * HY * HX * 8;          // (halo voxel, channel quad)
+    static constexpr int G_ITERS = (G_ITEMS + 511) / 512;
+    static constexpr int PARTS = 4;                            // 4 rows of 16 voxels each
+    static constexpr int ITERS = ((G_ITERS + WG_DZ_ITERS + PARTS - 1) / PARTS) * PARTS;
+    static constexpr int PER_PART = ITERS / PARTS;
+    static constexpr int NTAPS = KS * KS * KS;
+    static constexpr int NTW = (NTAPS + 3) / 4;                // taps (= accumulators) per wave: 7 / 2
+};
 
 struct bf16_wgrad_params {
     const float* x;       // (N,D,H,W,C)
     const float* affine;  // (N,C,2) or null
     const float* dz;      // (N,D,H,W,K)
-    float* ws;            // [S][P][27][32][64] partial sums
+    float* ws;            // [S][P][KS^3][32][64] partial sums
     int N, D, H, W, C, K;
+    int off;              // g halo origin = tile origin - off (1: 3x3x3 'same'; 0: the forward-looking 2x2x2 kernel)
     int tz, ty, tx;       // tiles per dimension
     int tiles;            // N*tz*ty*tx
     int per_block;        // tiles per split
@@ -499,12 +525,6 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* lds_addr) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-constexpr int WG_G_ITERS = (WG_G_ITEMS + 511) / 512;    // 12 halo items per thread
-constexpr int WG_DZ_ITERS = (WG_DZ_ITEMS + 511) / 512;  // 8 dz items per thread
-constexpr int WG_ITERS = WG_G_ITERS + WG_DZ_ITERS;      // 20 = 4 parts x 5
-constexpr int WG_PARTS = 4, WG_PER_PART = WG_ITERS / WG_PARTS;
-static_assert(WG_PER_PART * WG_PARTS == WG_ITERS, "staging items must split evenly over the parts");
-
 struct wg_tile {
     int n, z0, y0, x0;
 };
@@ -512,7 +532,11 @@ struct wg_tile {
 // One block per CU (8 waves, 163 VGPRs): the staging of tile i+1 must overlap the MFMAs of tile i INSIDE the block — two LDS
 // buffers; the next tile's 20 items per thread are fetched in four batches of five at the start of each 4-row part of the
 // current tile and written (affine, bf16) to the other buffer at the part's end; one barrier per tile.
+template <int KS>
 __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wgrad_params p) {
+    using G = wg_geom<KS>;
+    constexpr int WG_HY = G::HY, WG_HX = G::HX, WG_G_BYTES = G::G_BYTES, WG_LDS = G::LDS, WG_G_ITEMS = G::G_ITEMS,
+                  WG_G_ITERS = G::G_ITERS, WG_ITERS = G::ITERS, WG_PARTS = G::PARTS, WG_PER_PART = G::PER_PART, NTW = G::NTW;
     extern __shared__ __attribute__((aligned(256))) char lds[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int P = (p.C >> 5) * p.pco;
@@ -541,11 +565,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wg
                 const int q = item & 7, hv = item >> 3;
                 const int hz = hv / (WG_HY * WG_HX), rem = hv - hz * (WG_HY * WG_HX);
                 const int hy = rem / WG_HX, hx = rem - hy * WG_HX;
-                const int z = tl.z0 - 1 + hz, y = tl.y0 - 1 + hy, xx = tl.x0 - 1 + hx;
+                const int z = tl.z0 - p.off + hz, y = tl.y0 - p.off + hy, xx = tl.x0 - p.off + hx;
                 if ((unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
                     v = *reinterpret_cast<const f32x4*>(p.x + ((((size_t)tl.n * p.D + z) * p.H + y) * p.W + xx) * p.C + c0 + 4 * q);
             }
-        } else {
+        } else if (it < WG_G_ITERS + WG_DZ_ITERS) {
             const int item = t + (it - WG_G_ITERS) * 512;
             const int q = item & 15, vv = item >> 4;
             const int zl = vv / (WG_TY * WG_TX), rem = vv - zl * (WG_TY * WG_TX);
@@ -563,14 +587,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wg
                 const int q = item & 7, hv = item >> 3;
                 const int hz = hv / (WG_HY * WG_HX), rem = hv - hz * (WG_HY * WG_HX);
                 const int hy = rem / WG_HX, hx = rem - hy * WG_HX;
-                const int z = tl.z0 - 1 + hz, y = tl.y0 - 1 + hy, xx = tl.x0 - 1 + hx;
+                const int z = tl.z0 - p.off + hz, y = tl.y0 - p.off + hy, xx = tl.x0 - p.off + hx;
                 if ((unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = (__bf16)fmaf(v[e], ga[e], gb[e]);  // zero padding applies AFTER the affine
                 }
                 *reinterpret_cast<bf16x4*>(buf + hv * 64 + q * 8) = o;
             }
-        } else {
+        } else if (it < WG_G_ITERS + WG_DZ_ITERS) {
             const int item = t + (it - WG_G_ITERS) * 512;
             const int q = item & 15, vv = item >> 4;
 #pragma unroll
@@ -586,18 +610,18 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wg
         f32x4 ga, gb;
         u3d_load_affine(p.affine, tl.n, p.C, c0 + 4 * (t & 7), true, ga, gb);
 #pragma unroll 1
-        for (int it0 = 0; it0 < WG_ITERS; it0 += 10) {
-            f32x4 v[10];
+        for (int it0 = 0; it0 < WG_ITERS; it0 += WG_ITERS / 2) {
+            f32x4 v[WG_ITERS / 2];
 #pragma unroll
-            for (int i = 0; i < 10; ++i) load_item(tl, it0 + i, v[i]);
+            for (int i = 0; i < WG_ITERS / 2; ++i) load_item(tl, it0 + i, v[i]);
 #pragma unroll
-            for (int i = 0; i < 10; ++i) store_item(lds, tl, it0 + i, v[i], ga, gb);
+            for (int i = 0; i < WG_ITERS / 2; ++i) store_item(lds, tl, it0 + i, v[i], ga, gb);
         }
     }
 
-    f32x16 acc[7];
+    f32x16 acc[NTW];
 #pragma unroll
-    for (int i = 0; i < 7; ++i)
+    for (int i = 0; i < NTW; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
@@ -605,11 +629,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wg
     // as a SOURCE lane, sidx = lane & 15 supplies voxel (sidx >> 2), channel quad (sidx & 3)
     const int g4 = lane >> 4, sidx = lane & 15;
     const int lane_off = (8 * (g4 >> 1) + (sidx >> 2)) * 64 + (16 * (g4 & 1) + 4 * (sidx & 3)) * 2;
-    int a_off[7];
+    int a_off[NTW];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        const int tap = min(wq + 4 * i, 26);
-        const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
+    for (int i = 0; i < NTW; ++i) {
+        const int tap = min(wq + 4 * i, G::NTAPS - 1);
+        const int tz = tap / (KS * KS), ty = (tap / KS) % KS, tx = tap % KS;
         a_off[i] = lane_off + ((tz * WG_HY + ty) * WG_HX + tx) * 64;
     }
     const int b_off = WG_G_BYTES + h * WG_DZ_HALF + lane_off;
@@ -639,10 +663,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wg
                 const bf16x8 b = tr_frag(cur + b_off + (zl * WG_TY + yl) * WG_TX * 64);
                 bf16x8 a = tr_frag(cur + a_off[0] + row);
 #pragma unroll
-                for (int i = 0; i < 7; ++i) {
+                for (int i = 0; i < NTW; ++i) {
                     bf16x8 an = a;
-                    if (i + 1 < 7) an = tr_frag(cur + a_off[i + 1] + row);
-                    if (i < 6 || wq < 3) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+                    if (i + 1 < NTW) an = tr_frag(cur + a_off[i + 1] + row);
+                    if (wq + 4 * i < G::NTAPS) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
                     a = an;
                 }
             }
@@ -654,12 +678,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wg
         }
     }
     // ---- partial sums: ws[split][pair][tap][ci 32][co 64]; D layout: column = lane & 31 (co), row = ci
-    float* dst = p.ws + ((size_t)split * P + pair) * 27 * 2048;
+    float* dst = p.ws + ((size_t)split * P + pair) * G::NTAPS * 2048;
     const int col = lane & 31, half = lane >> 5;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
+    for (int i = 0; i < NTW; ++i) {
         const int tap = wq + 4 * i;
-        if (tap < 27) {
+        if (tap < G::NTAPS) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int ci = (e & 3) + 8 * (e >> 2) + 4 * half;
@@ -726,14 +750,171 @@ extern "C" int u3d_conv3d_wgrad_bf16(int device, u3d_stream_t stream, const floa
     const long long need = (long long)q.S * q.P * 27 * 2048;
     if (!workspace || workspace_floats < need)
         return u3d_set_err(U3D_EWORKSPACE, "u3d_conv3d_wgrad_bf16: workspace of %lld floats needed, %lld given", need, workspace_floats);
-    bf16_wgrad_params p{x, affine, dz, workspace, N, D, H, W, C, K, q.tz, q.ty, q.tx, q.tiles, q.per_block, K / 64};
-    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                2 * WG_LDS));
-    hipLaunchKernelGGL(conv3d_wgrad_bf16_kernel, dim3((unsigned)(q.S * q.P)), dim3(512), 2 * WG_LDS, (hipStream_t)stream, p);
+    bf16_wgrad_params p{x, affine, dz, workspace, N, D, H, W, C, K, 1, q.tz, q.ty, q.tx, q.tiles, q.per_block, K / 64};
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_bf16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * wg_geom<3>::LDS));
+    hipLaunchKernelGGL(conv3d_wgrad_bf16_kernel<3>, dim3((unsigned)(q.S * q.P)), dim3(512), 2 * wg_geom<3>::LDS, (hipStream_t)stream, p);
     U3D_LAUNCH_CHECK();
     long long rb = ((long long)C * K * 27 + 255) / 256;
     if (rb > 8192) rb = 8192;
     hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, (hipStream_t)stream, workspace, q.S, C, K, dw);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+
+// =====================================================================================================================
+// ConvTranspose3d(k=3, stride=2, padding=1, bias=False) (buildingblocks.py:653-662) on the bf16 kernels, in SPACE-TO-DEPTH form.
+// t[o] = sum_j sum_s [o = 2j - 1 + s] x[j] w[s]: an output voxel o = 2i + p (parity p per dimension) takes, per dimension,
+//   p = 0: tap s = 1 of input i;          p = 1: tap s = 2 of input i and tap s = 0 of input i + 1.
+// Store the (2n-1)^3 output as T8 (N, D1, H1, W1, 8*Cs) with T8[i][p*Cs + co] = t[2i + p][co] (p = pz*4 + py*2 + px; entries with
+// 2i + p = 2n - 1 do not exist and are never read).  Then
+//   forward        T8 = conv2x2x2(x; taps a in {0,1}^3 read x[i + a])            Cl -> 8*Cs channels
+//   data gradient  dx = conv2x2x2(dT8; taps read dT8[j - a])                     8*Cs -> Cl channels (+ ReLU mask of x)
+//   weight grad    dV[a][ci][p,co] = sum_i x[i + a][ci] dT8[i][p,co]             the 2x2x2 weight gradient
+// with the weight V[a][ci][p*Cs + co] = w[ci][co][s(a,p)] where per dimension s(0,0) = 1, s(0,1) = 2, s(1,1) = 0 and (a,p) = (1,0)
+// is structurally zero: 27 of the 64 (a,p) combinations carry the 27 taps — 64/27 = 2.4x the minimal multiply-adds, on the
+// low-res grid, at bf16 MFMA rates, with the SAME kernels as the 3x3x3 convolutions (template KS = 2).  The nearest resize +
+// join kernels read / write the T8 layout directly (u3d_nearest_add_fwd_t8 / u3d_nearest_sum_bwd_t8, csrc/u3d_res.hip).
+namespace {
+
+__device__ __host__ inline int t8_tap_of(int a, int p) {  // per dimension: the 3-tap index s(a,p), or -1
+    return a == 0 ? (p == 0 ? 1 : 2) : (p == 1 ? 0 : -1);
+}
+
+// mode 0 (forward):       B[k = ci][col = p*Cs + co] for tap a      = w[ci][co][s(a,p)]
+// mode 1 (data gradient): B[k = p*Cs + co][col = ci] for tap tau    = w[ci][co][s(1 - tau, p)]   (tap tau reads dT8[j + tau - 1])
+// w: (Cl, Cs, 3,3,3) fp32, the nn.ConvTranspose3d layout.  Image [chunk][tap 8][n-tile][lane][8] like pack_weights_bf16_kernel.
+__global__ void pack_convtr_t8_kernel(const float* __restrict__ w, int Cl, int Cs, int mode, __bf16* __restrict__ out, long long total) {
+    const int Kc = mode == 0 ? Cl : 8 * Cs, Nc = mode == 0 ? 8 * Cs : Cl;
+    const int ntiles = Nc >> 5;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 7);
+        long long rest = i >> 3;
+        const int l = (int)(rest & 63);
+        rest >>= 6;
+        const int nt = (int)(rest % ntiles);
+        rest /= ntiles;
+        const int tap = (int)(rest & 7);
+        const int c = (int)(rest >> 3);
+        const int k = c * 16 + 8 * (l >> 5) + e, col = nt * 32 + (l & 31);
+        float v = 0.f;
+        if (k < Kc && col < Nc) {
+            const int ci = mode == 0 ? k : col, pc = mode == 0 ? col : k;
+            const int pp = pc / Cs, co = pc - pp * Cs;
+            int sidx = 0;
+            bool ok = true;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {  // d = 0: z (bit 2), 1: y, 2: x
+                const int bit = 2 - d;
+                const int tb = (tap >> bit) & 1, pb = (pp >> bit) & 1;
+                const int sd = t8_tap_of(mode == 0 ? tb : 1 - tb, pb);
+                ok = ok && sd >= 0;
+                sidx = sidx * 3 + (sd < 0 ? 0 : sd);
+            }
+            if (ok) v = w[((size_t)ci * Cs + co) * 27 + sidx];
+        }
+        out[i] = (__bf16)v;
+    }
+}
+
+// dW[ci][co][s] = sum over splits of D[a][ci][p*Cs + co] with (a,p) = the one combination that carries tap s (fixed order)
+__global__ void wgrad_t8_reduce_kernel(const float* __restrict__ ws, int S, int Cl, int Cs, float* __restrict__ dw) {
+    const int Kp = 8 * Cs, pco = Kp >> 6, P = (Cl >> 5) * pco;
+    const long long total = (long long)Cl * Cs * 27;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cs);
+        long long r = i / Cs;
+        const int ci = (int)(r % Cl);
+        const int s = (int)(r / Cl);
+        int tap = 0, pp = 0;
+        const int sd[3] = {s / 9, (s / 3) % 3, s % 3};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int a = sd[d] == 0 ? 1 : 0, pb = sd[d] == 1 ? 0 : 1;  // s = 0 -> (1,1); 1 -> (0,0); 2 -> (0,1)
+            tap = tap * 2 + a;
+            pp = pp * 2 + pb;
+        }
+        const int kp = pp * Cs + co;
+        const int pair = (ci >> 5) * pco + (kp >> 6);
+        const size_t off = ((size_t)pair * 8 + tap) * 2048 + (ci & 31) * 64 + (kp & 63);
+        double sum = 0.0;
+        for (int sp = 0; sp < S; ++sp) sum += (double)ws[(size_t)sp * P * 8 * 2048 + off];
+        dw[((size_t)ci * Cs + co) * 27 + s] = (float)sum;
+    }
+}
+
+int launch_t8_conv(const bf16_conv_params& p0, hipStream_t s) {
+    bf16_conv_params p = p0;
+    const bool nt2 = p.K % 64 == 0;
+    const long long big = (long long)p.N * ((p.D + 7) / 8) * ((p.H + 7) / 8) * ((p.W + 7) / 8) * (p.K / (nt2 ? 64 : 32));
+    const bool zw2 = big >= 512 && p.D >= 8;
+    if (nt2) return zw2 ? launch_bf16<2, 2, 2>(p, s) : launch_bf16<2, 1, 2>(p, s);
+    return zw2 ? launch_bf16<1, 2, 2>(p, s) : launch_bf16<1, 1, 2>(p, s);
+}
+
+}  // namespace
+
+extern "C" int u3d_convtr3d_t8_supported(int Cl, int Cs) { return (Cl > 0 && Cs > 0 && Cl % 32 == 0 && Cs % 8 == 0) ? 1 : 0; }
+
+extern "C" long long u3d_convtr3d_t8_packed_elems(int Cl, int Cs, int mode) {
+    if (!u3d_convtr3d_t8_supported(Cl, Cs)) return 0;
+    const int Kc = mode == 0 ? Cl : 8 * Cs, Nc = mode == 0 ? 8 * Cs : Cl;
+    return (long long)(Kc / 16) * 8 * (Nc / 32) * 64 * 8;
+}
+
+extern "C" int u3d_pack_convtr3d_t8(int device, u3d_stream_t stream, const float* w, int Cl, int Cs, int mode, void* packed) {
+    U3D_ENTER(device);
+    const long long total = u3d_convtr3d_t8_packed_elems(Cl, Cs, mode);
+    U3D_REQUIRE(w && packed && (mode == 0 || mode == 1) && total > 0, "u3d_pack_convtr3d_t8: needs Cin %% 32 == 0, Cout %% 8 == 0 (%d, %d)", Cl, Cs);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_convtr_t8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, Cl, Cs, mode,
+                       reinterpret_cast<__bf16*>(packed), total);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int u3d_convtr3d_fwd_t8(int device, u3d_stream_t stream, const float* x, const void* packed, float* t8, int N, int D1,
+                                   int H1, int W1, int Cl, int Cs) {
+    U3D_ENTER(device);
+    U3D_REQUIRE(x && packed && t8 && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && u3d_convtr3d_t8_supported(Cl, Cs), "u3d_convtr3d_fwd_t8: bad argument");
+    bf16_conv_params p{x, nullptr, reinterpret_cast<const bf16x8*>(packed), t8, nullptr, nullptr, nullptr, nullptr,
+                       N, D1, H1, W1, Cl, 8 * Cs, 0, 0, 0, 0, 0, nullptr, 1, nullptr};
+    return launch_t8_conv(p, (hipStream_t)stream);
+}
+
+extern "C" int u3d_convtr3d_dgrad_t8(int device, u3d_stream_t stream, const float* dt8, const void* packed, const float* x_mask,
+                                     float* dx, int N, int D1, int H1, int W1, int Cl, int Cs) {
+    U3D_ENTER(device);
+    U3D_REQUIRE(dt8 && packed && dx && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && u3d_convtr3d_t8_supported(Cl, Cs), "u3d_convtr3d_dgrad_t8: bad argument");
+    bf16_conv_params p{dt8, nullptr, reinterpret_cast<const bf16x8*>(packed), dx, nullptr, nullptr, nullptr, nullptr,
+                       N, D1, H1, W1, 8 * Cs, Cl, 0, 0, 0, 0, 1, x_mask, 1, nullptr};
+    return launch_t8_conv(p, (hipStream_t)stream);
+}
+
+extern "C" long long u3d_convtr3d_wgrad_t8_workspace_floats(int N, int D1, int H1, int W1, int Cl, int Cs) {
+    if (!u3d_convtr3d_t8_supported(Cl, Cs) || N <= 0 || D1 <= 0 || H1 <= 0 || W1 <= 0) return 0;
+    const wgrad_plan q = plan_wgrad(N, D1, H1, W1, Cl, 8 * Cs);
+    return (long long)q.S * q.P * 8 * 2048;
+}
+
+extern "C" int u3d_convtr3d_wgrad_t8(int device, u3d_stream_t stream, const float* x, const float* dt8, float* dw, int N, int D1,
+                                     int H1, int W1, int Cl, int Cs, float* workspace, long long workspace_floats) {
+    U3D_ENTER(device);
+    U3D_REQUIRE(x && dt8 && dw && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && u3d_convtr3d_t8_supported(Cl, Cs), "u3d_convtr3d_wgrad_t8: bad argument");
+    const wgrad_plan q = plan_wgrad(N, D1, H1, W1, Cl, 8 * Cs);
+    const long long need = (long long)q.S * q.P * 8 * 2048;
+    if (!workspace || workspace_floats < need)
+        return u3d_set_err(U3D_EWORKSPACE, "u3d_convtr3d_wgrad_t8: workspace of %lld floats needed, %lld given", need, workspace_floats);
+    bf16_wgrad_params p{x, nullptr, dt8, workspace, N, D1, H1, W1, Cl, 8 * Cs, 0, q.tz, q.ty, q.tx, q.tiles, q.per_block, 8 * Cs / 64};
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_bf16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * wg_geom<2>::LDS));
+    hipLaunchKernelGGL(conv3d_wgrad_bf16_kernel<2>, dim3((unsigned)(q.S * q.P)), dim3(512), 2 * wg_geom<2>::LDS, (hipStream_t)stream, p);
+    U3D_LAUNCH_CHECK();
+    long long rb = ((long long)Cl * Cs * 27 + 255) / 256;
+    if (rb > 8192) rb = 8192;
+    hipLaunchKernelGGL(wgrad_t8_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, (hipStream_t)stream, workspace, q.S, Cl, Cs, dw);
     U3D_LAUNCH_CHECK();
     return 0;
 }

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void gwgrad_kernel(const GWgradParams p) {
 __global__ __launch_bounds__(256) void nearest_add_kernel(const float* __restrict__ skip, const float* __restrict__ tt,
                                                           const int* __restrict__ zmap, const int* __restrict__ ymap,
                                                           const int* __restrict__ xmap, int D, int H, int W, int Dt, int Ht,
-                                                          int Wt, int C, int Q, int vecw, float* __restrict__ out,
+                                                          int Wt, int C, int Q, int vecw, int t8, float* __restrict__ out,
                                                           double* __restrict__ stats) {
     // thread -> (row = t / Q, unit = t % Q); a unit is vecw (4 or 1) channels; rows stride the block's voxel range
     extern __shared__ double sred[];  // [Q*vecw][2]
@@ -279,7 +279,15 @@ __global__ __launch_bounds__(256) void nearest_add_kernel(const float* __restric
             const long long q = v / W;
             const int y = (int)(q % H), z = (int)(q / H);
             const size_t o = ((size_t)n * V + v) * C + (size_t)unit * vecw;
-            const size_t ti = ((size_t)((n * Dt + zmap[z]) * Ht + ymap[y]) * Wt + xmap[x]) * C + (size_t)unit * vecw;
+            size_t ti;
+            if (t8) {  // space-to-depth layout of the transposed convolution's output (csrc/u3d_bf16.hip): T8[i][parity*C + c]
+                const int zt = zmap[z], yt = ymap[y], xt = xmap[x];
+                const int D1 = (Dt + 1) >> 1, H1 = (Ht + 1) >> 1, W1 = (Wt + 1) >> 1;
+                ti = (((size_t)((n * D1 + (zt >> 1)) * H1 + (yt >> 1)) * W1 + (xt >> 1)) * 8 + ((zt & 1) * 4 + (yt & 1) * 2 + (xt & 1))) * C +
+                     (size_t)unit * vecw;
+            } else {
+                ti = ((size_t)((n * Dt + zmap[z]) * Ht + ymap[y]) * Wt + xmap[x]) * C + (size_t)unit * vecw;
+            }
             if (vecw == 4) {
                 const f32x4 a = *reinterpret_cast<const f32x4*>(skip + o);
                 const f32x4 b = *reinterpret_cast<const f32x4*>(tt + ti);
@@ -313,17 +321,34 @@ __global__ __launch_bounds__(256) void nearest_add_kernel(const float* __restric
 // dt[s] = sum of dj over the children of s (voxels o with map(o) == s): lo tables of length Dt+1 / Ht+1 / Wt+1
 __global__ void nearest_sum_kernel(const float* __restrict__ dj, const int* __restrict__ zlo, const int* __restrict__ ylo,
                                    const int* __restrict__ xlo, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C,
-                                   float* __restrict__ dt) {
-    const long long total = (long long)N * Dt * Ht * Wt * C;
+                                   int t8, float* __restrict__ dt) {
+    const int D1 = (Dt + 1) >> 1, H1 = (Ht + 1) >> 1, W1 = (Wt + 1) >> 1;
+    const long long total = t8 ? (long long)N * D1 * H1 * W1 * 8 * C : (long long)N * Dt * Ht * Wt * C;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(idx % C);
         long long v = idx / C;
-        const int xx = (int)(v % Wt);
-        v /= Wt;
-        const int yy = (int)(v % Ht);
-        v /= Ht;
-        const int zz = (int)(v % Dt);
-        const int n = (int)(v / Dt);
+        int xx, yy, zz, n;
+        if (t8) {  // T8[i][parity*C + c] = dt[2i + parity]; parities that fall outside the (2n-1) grid are written as 0
+            const int par = (int)(v & 7);
+            v >>= 3;
+            xx = 2 * (int)(v % W1) + (par & 1);
+            v /= W1;
+            yy = 2 * (int)(v % H1) + ((par >> 1) & 1);
+            v /= H1;
+            zz = 2 * (int)(v % D1) + (par >> 2);
+            n = (int)(v / D1);
+            if (zz >= Dt || yy >= Ht || xx >= Wt) {
+                dt[idx] = 0.f;
+                continue;
+            }
+        } else {
+            xx = (int)(v % Wt);
+            v /= Wt;
+            yy = (int)(v % Ht);
+            v /= Ht;
+            zz = (int)(v % Dt);
+            n = (int)(v / Dt);
+        }
         float sum = 0.f;
         for (int z = zlo[zz]; z < zlo[zz + 1]; ++z)
             for (int y = ylo[yy]; y < ylo[yy + 1]; ++y)
@@ -529,9 +554,25 @@ extern "C" int u3d_convtr3d_bwd(int device, u3d_stream_t stream, const float* dt
 }
 
 // ---- nearest resize to the skip's size + summation joining (buildingblocks.py:650-651 + :493) ---------------------------
+static int nearest_add_impl(int device, u3d_stream_t stream, const float* skip, const float* t, const int32_t* zmap,
+                            const int32_t* ymap, const int32_t* xmap, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C,
+                            float* out, double* out_stats, int t8);
+
 extern "C" int u3d_nearest_add_fwd(int device, u3d_stream_t stream, const float* skip, const float* t, const int32_t* zmap,
                                    const int32_t* ymap, const int32_t* xmap, int N, int D, int H, int W, int Dt, int Ht,
                                    int Wt, int C, float* out, double* out_stats) {
+    return nearest_add_impl(device, stream, skip, t, zmap, ymap, xmap, N, D, H, W, Dt, Ht, Wt, C, out, out_stats, 0);
+}
+
+extern "C" int u3d_nearest_add_fwd_t8(int device, u3d_stream_t stream, const float* skip, const float* t8, const int32_t* zmap,
+                                      const int32_t* ymap, const int32_t* xmap, int N, int D, int H, int W, int Dt, int Ht,
+                                      int Wt, int C, float* out, double* out_stats) {
+    return nearest_add_impl(device, stream, skip, t8, zmap, ymap, xmap, N, D, H, W, Dt, Ht, Wt, C, out, out_stats, 1);
+}
+
+static int nearest_add_impl(int device, u3d_stream_t stream, const float* skip, const float* t, const int32_t* zmap,
+                            const int32_t* ymap, const int32_t* xmap, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C,
+                            float* out, double* out_stats, int t8) {
     U3D_ENTER(device);
     U3D_REQUIRE(skip && t && zmap && ymap && xmap && out && N > 0 && D > 0 && H > 0 && W > 0 && Dt > 0 && Ht > 0 && Wt > 0 &&
                     C > 0 && C <= 1024,
@@ -545,20 +586,33 @@ extern "C" int u3d_nearest_add_fwd(int device, u3d_stream_t stream, const float*
     const long long cap = 2048 / N > 1 ? 2048 / N : 1;
     if (bx > cap) bx = cap;
     hipLaunchKernelGGL(nearest_add_kernel, dim3((unsigned)bx, (unsigned)N), dim3(256), sizeof(double) * 2 * (size_t)C,
-                       (hipStream_t)stream, skip, t, zmap, ymap, xmap, D, H, W, Dt, Ht, Wt, C, Q, vecw, out, out_stats);
+                       (hipStream_t)stream, skip, t, zmap, ymap, xmap, D, H, W, Dt, Ht, Wt, C, Q, vecw, t8, out, out_stats);
     U3D_LAUNCH_CHECK();
     return 0;
 }
 
+static int nearest_sum_impl(int device, u3d_stream_t stream, const float* dj, const int32_t* zlo, const int32_t* ylo,
+                            const int32_t* xlo, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C, float* dt, int t8);
+
 extern "C" int u3d_nearest_sum_bwd(int device, u3d_stream_t stream, const float* dj, const int32_t* zlo, const int32_t* ylo,
                                    const int32_t* xlo, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C, float* dt) {
+    return nearest_sum_impl(device, stream, dj, zlo, ylo, xlo, N, D, H, W, Dt, Ht, Wt, C, dt, 0);
+}
+
+extern "C" int u3d_nearest_sum_bwd_t8(int device, u3d_stream_t stream, const float* dj, const int32_t* zlo, const int32_t* ylo,
+                                      const int32_t* xlo, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C, float* dt8) {
+    return nearest_sum_impl(device, stream, dj, zlo, ylo, xlo, N, D, H, W, Dt, Ht, Wt, C, dt8, 1);
+}
+
+static int nearest_sum_impl(int device, u3d_stream_t stream, const float* dj, const int32_t* zlo, const int32_t* ylo,
+                            const int32_t* xlo, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C, float* dt, int t8) {
     U3D_ENTER(device);
     U3D_REQUIRE(dj && zlo && ylo && xlo && dt && N > 0 && C > 0, "u3d_nearest_sum_bwd: bad argument");
-    const long long total = (long long)N * Dt * Ht * Wt * C;
+    const long long total = t8 ? (long long)N * ((Dt + 1) / 2) * ((Ht + 1) / 2) * ((Wt + 1) / 2) * 8 * C : (long long)N * Dt * Ht * Wt * C;
     long long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(nearest_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dj, zlo, ylo, xlo, N, D, H,
-                       W, Dt, Ht, Wt, C, dt);
+                       W, Dt, Ht, Wt, C, t8, dt);
     U3D_LAUNCH_CHECK();
     return 0;
 }

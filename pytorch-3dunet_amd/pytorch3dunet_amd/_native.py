@@ -222,6 +222,24 @@ _PROTOS = {
         c_int,
         [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64],
     ),
+    "u3d_convtr3d_t8_supported": (c_int, [c_int, c_int]),
+    "u3d_convtr3d_t8_packed_elems": (c_int64, [c_int, c_int, c_int]),
+    "u3d_pack_convtr3d_t8": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "u3d_convtr3d_fwd_t8": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "u3d_convtr3d_dgrad_t8": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "u3d_convtr3d_wgrad_t8_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "u3d_convtr3d_wgrad_t8": (
+        c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64]),
+    "u3d_nearest_add_fwd_t8": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+         c_int, c_void_p, c_void_p],
+    ),
+    "u3d_nearest_sum_bwd_t8": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+         c_void_p],
+    ),
     "u3d_act_fwd": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "u3d_act_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "u3d_affine_act_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_float, c_void_p]),

@@ -392,6 +392,22 @@ class UNet3DEngine:
         self._pack_cache[key] = (ver, out)
         return out
 
+    def _convtr_t8(self, Cl: int, Cs: int) -> bool:
+        """the transposed convolution and its gradients run in space-to-depth form on the bf16 MFMA kernels"""
+        return self.bf16 and nat.get_lib().u3d_convtr3d_t8_supported(Cl, Cs) == 1
+
+    def _packed_convtr_t8(self, w: torch.Tensor, mode: int, dev) -> torch.Tensor:
+        key = (id(w), 30 + mode)
+        ver = (w._version, w.data_ptr())
+        hit = self._pack_cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        Cl, Cs = w.shape[0], w.shape[1]
+        out = torch.empty(nat.get_lib().u3d_convtr3d_t8_packed_elems(Cl, Cs, mode), dtype=torch.bfloat16, device=dev)
+        nat.call("u3d_pack_convtr3d_t8", dev.index, _stream(dev), _p(w.detach()), Cl, Cs, mode, _p(out))
+        self._pack_cache[key] = (ver, out)
+        return out
+
     def _conv_weights(self):
         """every 3x3x3 conv weight the MFMA kernels read through a packed image"""
         out = []
@@ -778,26 +794,29 @@ class UNet3DEngine:
     def _wgrad_workspace(self, tape, dev):
         return torch.empty(max(self._wgrad_workspace_floats(tape.convs), 4), dtype=_F32, device=dev)
 
-    def _wgrad_workspace_floats(self, convs):
-        """scratch floats the fp32 weight-gradient / split-K kernels of these layers need (bf16 layers grow the buffer on
-        demand, _BwdCtx.ensure_ws)"""
+    def _layer_ws_floats(self, N, D, H, W, Cin, Cout, sub=None, small=False, virtual=False):
+        """scratch floats one 3x3x3 layer's backward needs from the shared buffer, for the kernels it will actually run"""
         lib = nat.get_lib()
-        ws_floats = 0
+        if small:
+            return lib.u3d_small_cin_bwd_workspace_floats(N, D, H, W, Cin, Cout)
+        if sub is not None:  # skip slice (fp32 kernels) + sub-pixel slice
+            return max(lib.u3d_wgrad_workspace_floats(N, D, H, W, sub[0], Cout),
+                       lib.u3d_subpixel_wgrad_workspace_floats(N, D // 2, H // 2, W // 2, sub[1], Cout),
+                       lib.u3d_conv3d_workspace_floats(N, D, H, W, Cout, sub[0]))
+        if not virtual and self._bf16_layer(Cin, Cout):
+            need = lib.u3d_conv3d_bf16_workspace_floats(N, D, H, W, Cout, Cin)  # data gradient: roles swapped
+            wg = lib.u3d_wgrad_bf16_workspace_floats(N, D, H, W, Cin, Cout) if Cout % 64 == 0 else lib.u3d_wgrad_workspace_floats(
+                N, D, H, W, Cin, Cout)
+            return max(need, wg)
+        return max(lib.u3d_wgrad_workspace_floats(N, D, H, W, Cin, Cout), lib.u3d_conv3d_workspace_floats(N, D, H, W, Cout, Cin))
+
+    def _wgrad_workspace_floats(self, convs):
+        """scratch floats the backward kernels of these recorded layers need (one shared buffer, sized once per backward)"""
+        need = 0
         for r in convs:
-            Nn, Co = r.src.N, r.y.shape[-1]
-            if r.sub is not None:  # skip slice + sub-pixel slice
-                ws_floats = max(ws_floats, lib.u3d_wgrad_workspace_floats(Nn, r.src.D, r.src.H, r.src.W, r.sub[0], Co),
-                                lib.u3d_subpixel_wgrad_workspace_floats(Nn, r.src.D1, r.src.H1, r.src.W1, r.sub[1], Co))
-            else:
-                ws_floats = max(ws_floats, lib.u3d_wgrad_workspace_floats(Nn, r.src.D, r.src.H, r.src.W, r.src.C, Co))
-            if not r.small:  # split-K scratch of the data gradient (Cin and Cout swap roles)
-                ws_floats = max(ws_floats, lib.u3d_conv3d_workspace_floats(r.src.N, r.src.D, r.src.H, r.src.W, r.y.shape[-1],
-                                                                           r.sub[0] if r.sub is not None else r.src.C))
-        for r0 in convs:
-            if r0.small:
-                ws_floats = max(ws_floats, lib.u3d_small_cin_bwd_workspace_floats(r0.src.N, r0.src.D, r0.src.H, r0.src.W,
-                                                                                  r0.src.C, r0.y.shape[-1]))
-        return int(ws_floats)
+            need = max(need, self._layer_ws_floats(r.src.N, r.src.D, r.src.H, r.src.W, r.src.C, r.y.shape[-1], r.sub, r.small,
+                                                   r.src.t1 is not None))
+        return int(need)
 
     # -- forward ------------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, save: bool):
@@ -1066,6 +1085,7 @@ class UpRec:
     weight: torch.Tensor  # (Cin, Cout, 3, 3, 3)
     los: tuple            # children tables of the nearest resize (2n-1 -> skip size)
     tdims: tuple          # (Dt, Ht, Wt)
+    t8: bool = False      # ran in space-to-depth form on the bf16 kernels (csrc/u3d_bf16.hip)
 
 
 class ResUNetEngine(UNet3DEngine):
@@ -1229,6 +1249,23 @@ class ResUNetEngine(UNet3DEngine):
             Nl, D1, H1, W1, Cl = cur.shape
             _, Ds, Hs, Ws, Cs = sk.shape
             Dt, Ht, Wt = 2 * D1 - 1, 2 * H1 - 1, 2 * W1 - 1
+            t8 = self._convtr_t8(Cl, Cs)
+            (mz, lz), (my, ly), (mx, lx) = _maps(dev, Dt, Ds), _maps(dev, Ht, Hs), _maps(dev, Wt, Ws)
+            joined = torch.empty_like(sk)
+            j_st = pool.take(Nl * Cs * 2)
+            if t8:
+                # bf16 mode: 2x2x2 convolution on the low-res grid into the space-to-depth layout T8[i][parity*Cs + c] = t[2i + parity];
+                # the resize + join reads that layout directly
+                t = torch.empty((Nl, D1, H1, W1, 8 * Cs), dtype=_F32, device=dev)
+                nat.call("u3d_convtr3d_fwd_t8", dev.index, _stream(dev), _p(cur), _p(self._packed_convtr_t8(ct.weight, 0, dev)), _p(t),
+                         Nl, D1, H1, W1, Cl, Cs, flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
+                nat.call("u3d_nearest_add_fwd_t8", dev.index, _stream(dev), _p(sk), _p(t), _p(mz), _p(my), _p(mx), Nl, Ds, Hs, Ws, Dt,
+                         Ht, Wt, Cs, _p(joined), _p(j_st))
+                del t
+                if tape is not None:
+                    tape.ups.append(UpRec(cur, ct.weight, (lz, ly, lx), (Dt, Ht, Wt), True))
+                cur = self._block_fwd(bm, f"dec{j}", joined, j_st, pool, tape, dev)
+                continue
             t = torch.empty((Nl, Dt, Ht, Wt, Cs), dtype=_F32, device=dev)
             if self.subpixel and Cl % 4 == 0 and Cs % 4 == 0:
                 # 8 output parity classes accumulated from one staged input halo tile (csrc/u3d_subpix.hip, scheme Deconv3s2)
@@ -1237,9 +1274,6 @@ class ResUNetEngine(UNet3DEngine):
             else:
                 nat.call("u3d_convtr3d_fwd", dev.index, _stream(dev), _p(cur), _p(ct.weight.detach()), _p(t), Nl, D1, H1, W1, Cl,
                          Cs, _p(self._packed_convtr(ct.weight, 0, dev)), flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
-            (mz, lz), (my, ly), (mx, lx) = _maps(dev, Dt, Ds), _maps(dev, Ht, Hs), _maps(dev, Wt, Ws)
-            joined = torch.empty_like(sk)
-            j_st = pool.take(Nl * Cs * 2)
             nat.call("u3d_nearest_add_fwd", dev.index, _stream(dev), _p(sk), _p(t), _p(mz), _p(my), _p(mx), Nl, Ds, Hs, Ws, Dt, Ht,
                      Wt, Cs, _p(joined), _p(j_st))
             del t
@@ -1296,7 +1330,13 @@ class ResUNetEngine(UNet3DEngine):
             if isinstance(b, ResRec) and b.se is not None:
                 tot += (N + 1) * b.se["y"].shape[-1] + 1
         pool = _StatPool(dev, tot)
-        ws = self._wgrad_workspace(tape, dev)
+        need = self._wgrad_workspace_floats(tape.convs)
+        for b in tape.blocks:
+            if isinstance(b, CkptRec):  # recomputed in backward: two (C -> C) convolutions at the block's resolution
+                Nb, Db, Hb, Wb, _ = b.x_in.shape
+                Cb = b.bm.conv2.conv.in_channels
+                need = max(need, self._layer_ws_floats(Nb, Db, Hb, Wb, Cb, Cb))
+        ws = torch.empty(max(int(need), 4), dtype=_F32, device=dev)
         cx = _BwdCtx(dev, pool, ws, flat, self)
         gview = cx.gview
 
@@ -1321,8 +1361,22 @@ class ResUNetEngine(UNet3DEngine):
             Nl, D1, H1, W1, Cl = xl.shape
             _, Ds, Hs, Ws, Cs = dj.shape
             Dt, Ht, Wt = up.tdims
-            dt = torch.empty((Nl, Dt, Ht, Wt, Cs), dtype=_F32, device=dev)
             lz, ly, lx = up.los
+            if up.t8:
+                dt8 = torch.empty((Nl, D1, H1, W1, 8 * Cs), dtype=_F32, device=dev)
+                nat.call("u3d_nearest_sum_bwd_t8", dev.index, _stream(dev), _p(dj), _p(lz), _p(ly), _p(lx), Nl, Ds, Hs, Ws, Dt, Ht, Wt,
+                         Cs, _p(dt8))
+                need = nat.get_lib().u3d_convtr3d_wgrad_t8_workspace_floats(Nl, D1, H1, W1, Cl, Cs)
+                wsb = cx.ensure_ws(need)
+                nat.call("u3d_convtr3d_wgrad_t8", dev.index, _stream(dev), _p(xl), _p(dt8), _p(gview(self._pindex[id(up.weight)])),
+                         Nl, D1, H1, W1, Cl, Cs, _p(wsb), wsb.numel(), flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
+                dxl = torch.empty_like(xl)
+                nat.call("u3d_convtr3d_dgrad_t8", dev.index, _stream(dev), _p(dt8), _p(self._packed_convtr_t8(up.weight, 1, dev)),
+                         _p(xl), _p(dxl), Nl, D1, H1, W1, Cl, Cs, flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
+                del dt8
+                dz = dxl  # masked by (x_low > 0)
+                continue
+            dt = torch.empty((Nl, Dt, Ht, Wt, Cs), dtype=_F32, device=dev)
             nat.call("u3d_nearest_sum_bwd", dev.index, _stream(dev), _p(dj), _p(lz), _p(ly), _p(lx), Nl, Ds, Hs, Ws, Dt, Ht, Wt,
                      Cs, _p(dt))
             acc = pool.take(up.weight.numel())

@@ -289,3 +289,103 @@ def test_activation_checkpointing_gives_bitwise_identical_gradients(bf16):
         assert torch.equal(g0[k], g1[k]), k
     print(f"peak step memory: {m0 / 2**20:.1f} MiB without, {m1 / 2**20:.1f} MiB with encoder checkpointing")
     assert m1 < m0
+
+
+# ---- ConvTranspose3d(k3, s2, p1) in space-to-depth form on the bf16 kernels (u3d_convtr3d_*_t8) --------------------------------
+def _t8_to_t(t8, Cs, Dt, Ht, Wt):
+    """(N,D1,H1,W1,8*Cs) device tensor -> (N,Cs,Dt,Ht,Wt) cpu: t[2i + p] = T8[i][p]"""
+    N, D1, H1, W1, _ = t8.shape
+    v = t8.cpu().view(N, D1, H1, W1, 2, 2, 2, Cs).permute(0, 7, 1, 4, 2, 5, 3, 6).reshape(N, Cs, 2 * D1, 2 * H1, 2 * W1)
+    return v[:, :, :Dt, :Ht, :Wt].contiguous()
+
+
+def _t_to_t8(t, D1, H1, W1):
+    """(N,Cs,Dt,Ht,Wt) cpu -> (N,D1,H1,W1,8*Cs) device (entries outside the (2n-1) grid zero)"""
+    N, Cs, Dt, Ht, Wt = t.shape
+    full = torch.zeros(N, Cs, 2 * D1, 2 * H1, 2 * W1)
+    full[:, :, :Dt, :Ht, :Wt] = t
+    v = full.view(N, Cs, D1, 2, H1, 2, W1, 2).permute(0, 2, 4, 6, 3, 5, 7, 1).reshape(N, D1, H1, W1, 8 * Cs)
+    return v.contiguous().to(U.DEV)
+
+
+@pytest.mark.parametrize("shape,Cl,Cs", [((1, 5, 10, 10), 64, 32), ((2, 4, 9, 7), 32, 8), ((1, 16, 24, 40), 32, 16), ((1, 40, 48, 48), 32, 16)])
+def test_convtranspose3d_space_to_depth_bf16(shape, Cl, Cs):
+    """forward, data gradient (with the ReLU mask of x) and weight gradient of nn.ConvTranspose3d(Cl, Cs, 3, stride=2, padding=1,
+    bias=False) against torch with the operands rounded to bf16 the same way"""
+    N, D1, H1, W1 = shape
+    Dt, Ht, Wt = 2 * D1 - 1, 2 * H1 - 1, 2 * W1 - 1
+    lib = nat.get_lib()
+    assert lib.u3d_convtr3d_t8_supported(Cl, Cs) == 1
+    torch.manual_seed(7)
+    x = torch.relu(torch.randn(N, Cl, D1, H1, W1))  # post-ReLU like the real input (exact zeros exercise the mask)
+    w = torch.randn(Cl, Cs, 3, 3, 3) / (27 * Cl / 8) ** 0.5
+    dt = torch.randn(N, Cs, Dt, Ht, Wt)
+    xr = bf16_round(x).double().requires_grad_(True)
+    wr = bf16_round(w).double().requires_grad_(True)
+    t_ref = F.conv_transpose3d(xr, wr, None, stride=2, padding=1)
+    xd, wd = U.ndhwc(x), w.contiguous().to(U.DEV)
+
+    def pack(mode):
+        buf = torch.empty(lib.u3d_convtr3d_t8_packed_elems(Cl, Cs, mode), dtype=torch.bfloat16, device=U.DEV)
+        nat.call("u3d_pack_convtr3d_t8", 0, _stream(U.DEV), _p(wd), Cl, Cs, mode, _p(buf))
+        return buf
+
+    # forward
+    t8 = torch.empty((N, D1, H1, W1, 8 * Cs), dtype=torch.float32, device=U.DEV)
+    pk0 = pack(0)
+    nat.call("u3d_convtr3d_fwd_t8", 0, _stream(U.DEV), _p(xd), _p(pk0), _p(t8), N, D1, H1, W1, Cl, Cs)
+    torch.cuda.synchronize()
+    t = _t8_to_t(t8, Cs, Dt, Ht, Wt)
+    scale = t_ref.abs().max().item()
+    assert (t.double() - t_ref.detach()).abs().max().item() < 1e-3 * scale
+    # gradients: operands (dt, w) and (x, dt) rounded
+    dtr = bf16_round(dt).double()
+    gx, gw = torch.autograd.grad(t_ref, (xr, wr), dtr)
+    dt8 = _t_to_t8(dt, D1, H1, W1)
+    pk1 = pack(1)
+    dx = torch.empty((N, D1, H1, W1, Cl), dtype=torch.float32, device=U.DEV)
+    nat.call("u3d_convtr3d_dgrad_t8", 0, _stream(U.DEV), _p(dt8), _p(pk1), _p(xd), _p(dx), N, D1, H1, W1, Cl, Cs)
+    need = lib.u3d_convtr3d_wgrad_t8_workspace_floats(N, D1, H1, W1, Cl, Cs)
+    ws = torch.empty(need, dtype=torch.float32, device=U.DEV)
+    dw = torch.full((Cl, Cs, 3, 3, 3), float("nan"), dtype=torch.float32, device=U.DEV)
+    nat.call("u3d_convtr3d_wgrad_t8", 0, _stream(U.DEV), _p(xd), _p(dt8), _p(dw), N, D1, H1, W1, Cl, Cs, _p(ws), need)
+    torch.cuda.synchronize()
+    gx_masked = gx * (x > 0)
+    assert (U.ncdhw(dx).double() - gx_masked).abs().max().item() < 1e-3 * gx.abs().max().item()
+    assert torch.isfinite(dw).all()
+    assert (dw.cpu().double() - gw).abs().max().item() < 1e-3 * gw.abs().max().item()
+
+
+def test_nearest_resize_join_on_space_to_depth_layout():
+    """u3d_nearest_add_fwd_t8 / u3d_nearest_sum_bwd_t8 == the plain-layout kernels on the de-interleaved tensor"""
+    from pytorch3dunet_amd.engine import _maps
+
+    torch.manual_seed(8)
+    N, D1, H1, W1, C = 2, 3, 5, 4, 8
+    Dt, Ht, Wt = 2 * D1 - 1, 2 * H1 - 1, 2 * W1 - 1
+    D, H, W = 2 * D1, 2 * H1 + 1, 2 * W1  # skip sizes: even and odd
+    t = torch.randn(N, C, Dt, Ht, Wt)
+    skip = torch.randn(N, C, D, H, W)
+    t8 = _t_to_t8(t, D1, H1, W1)
+    (mz, lz), (my, ly), (mx, lx) = _maps(U.DEV, Dt, D), _maps(U.DEV, Ht, H), _maps(U.DEV, Wt, W)
+    skd, td = U.ndhwc(skip), U.ndhwc(t)
+    outs = []
+    for name, src in (("u3d_nearest_add_fwd", td), ("u3d_nearest_add_fwd_t8", t8)):
+        out = torch.empty_like(skd)
+        st = torch.zeros((N, C, 2), dtype=torch.float64, device=U.DEV)
+        nat.call(name, 0, _stream(U.DEV), _p(skd), _p(src), _p(mz), _p(my), _p(mx), N, D, H, W, Dt, Ht, Wt, C, _p(out), _p(st))
+        outs.append((out, st))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.allclose(outs[0][1], outs[1][1])
+    assert torch.allclose(U.ncdhw(outs[0][0]), skip + F.interpolate(t, size=(D, H, W), mode="nearest"))
+    dj = torch.randn(N, D, H, W, C, device=U.DEV)
+    dt_plain = torch.empty((N, Dt, Ht, Wt, C), dtype=torch.float32, device=U.DEV)
+    dt8 = torch.full((N, D1, H1, W1, 8 * C), float("nan"), dtype=torch.float32, device=U.DEV)
+    nat.call("u3d_nearest_sum_bwd", 0, _stream(U.DEV), _p(dj), _p(lz), _p(ly), _p(lx), N, D, H, W, Dt, Ht, Wt, C, _p(dt_plain))
+    nat.call("u3d_nearest_sum_bwd_t8", 0, _stream(U.DEV), _p(dj), _p(lz), _p(ly), _p(lx), N, D, H, W, Dt, Ht, Wt, C, _p(dt8))
+    torch.cuda.synchronize()
+    assert torch.isfinite(dt8).all()
+    assert torch.equal(_t8_to_t(dt8, C, Dt, Ht, Wt), U.ncdhw(dt_plain))
+    # entries outside the (2n-1) grid are zero
+    full = dt8.cpu().view(N, D1, H1, W1, 2, 2, 2, C)
+    assert float(full[:, -1, :, :, 1].abs().max()) == 0.0 and float(full[:, :, :, -1, :, :, 1].abs().max()) == 0.0

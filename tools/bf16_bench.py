@@ -45,6 +45,9 @@ def main():
     D0, H0, W0 = (int(v) for v in args.patch.split(","))
     N = args.batch
     lib = nat.get_lib()
+    for kv in os.environ.get("U3D_TUNE", "").split(","):
+        if ":" in kv:
+            nat.call("u3d_set_tuning", int(kv.split(":")[0]), int(kv.split(":")[1]))
     a = torch.randn(4096, 4096, device=dev)
     for _ in range(20):
         a @ a
