@@ -693,13 +693,39 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wg
     }
 }
 
-// dw[co][ci][tap] (or a channel slice of it) = sum over splits, fixed order
-__global__ void wgrad_bf16_reduce_kernel(const float* __restrict__ ws, int S, int C, int K, float* __restrict__ dw) {
+// dw[co][ci][tap] = sum over splits, fixed order.  One block per (pair, input channel): the 27 x 64 partial sums of that row are
+// read coalesced over the output channel (256-byte runs), transposed through LDS, and written as 64 runs of 27 consecutive
+// floats (the reference layout has the tap innermost) — a thread-per-element version writes 4 bytes every 27*Cin floats and
+// costs more than the GEMM at 1024 channels.
+__global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __restrict__ ws, int S, int C, int K, float* __restrict__ dw) {
+    __shared__ float tile[64][28];
+    const int pco = K >> 6, P = (C >> 5) * pco;
+    const int pair = blockIdx.x >> 5, cil = blockIdx.x & 31;
+    const int cib = pair / pco, cob = pair - cib * pco;
+    const int t = threadIdx.x;
+    const size_t split_stride = (size_t)P * 27 * 2048;
+    for (int i = t; i < 27 * 64; i += 256) {
+        const int tap = i >> 6, co = i & 63;
+        const size_t off = ((size_t)pair * 27 + tap) * 2048 + cil * 64 + co;
+        double sum = 0.0;
+        for (int s = 0; s < S; ++s) sum += (double)ws[(size_t)s * split_stride + off];
+        tile[co][tap] = (float)sum;
+    }
+    __syncthreads();
+    const int ci = cib * 32 + cil;
+    for (int i = t; i < 27 * 64; i += 256) {
+        const int co = i / 27, tap = i - co * 27;
+        dw[((size_t)(cob * 64 + co) * C + ci) * 27 + tap] = tile[co][tap];
+    }
+}
+
+// few (pair, channel) rows but many splits (64-channel layers at full resolution): one thread per output element instead, so
+// that the sum over hundreds of splits is spread over the whole chip (the scattered 4-byte writes are few there)
+__global__ void wgrad_bf16_reduce_flat_kernel(const float* __restrict__ ws, int S, int C, int K, float* __restrict__ dw) {
     const int pco = K >> 6, P = (C >> 5) * pco;
     const long long total = (long long)C * K * 27;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        // read-coalesced order: co fastest, then ci, then tap
-        const int co = (int)(i % K);
+        const int co = (int)(i % K);  // read-coalesced order: co fastest, then ci, then tap
         long long r = i / K;
         const int ci = (int)(r % C);
         const int tap = (int)(r / C);
@@ -755,9 +781,13 @@ extern "C" int u3d_conv3d_wgrad_bf16(int device, u3d_stream_t stream, const floa
                                 2 * wg_geom<3>::LDS));
     hipLaunchKernelGGL(conv3d_wgrad_bf16_kernel<3>, dim3((unsigned)(q.S * q.P)), dim3(512), 2 * wg_geom<3>::LDS, (hipStream_t)stream, p);
     U3D_LAUNCH_CHECK();
-    long long rb = ((long long)C * K * 27 + 255) / 256;
-    if (rb > 8192) rb = 8192;
-    hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, (hipStream_t)stream, workspace, q.S, C, K, dw);
+    if (q.P * 32 >= 1024) {
+        hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)(q.P * 32)), dim3(256), 0, (hipStream_t)stream, workspace, q.S, C, K, dw);
+    } else {
+        long long rb = ((long long)C * K * 27 + 255) / 256;
+        if (rb > 8192) rb = 8192;
+        hipLaunchKernelGGL(wgrad_bf16_reduce_flat_kernel, dim3((unsigned)rb), dim3(256), 0, (hipStream_t)stream, workspace, q.S, C, K, dw);
+    }
     U3D_LAUNCH_CHECK();
     return 0;
 }
@@ -818,29 +848,40 @@ __global__ void pack_convtr_t8_kernel(const float* __restrict__ w, int Cl, int C
     }
 }
 
-// dW[ci][co][s] = sum over splits of D[a][ci][p*Cs + co] with (a,p) = the one combination that carries tap s (fixed order)
-__global__ void wgrad_t8_reduce_kernel(const float* __restrict__ ws, int S, int Cl, int Cs, float* __restrict__ dw) {
+// dW[ci][co][s] = sum over splits of D[a][ci][p*Cs + co] with (a,p) = the one combination that carries tap s (fixed order).
+// One block per (input channel, run of 64 output channels): reads coalesced over co, writes runs of 27 consecutive floats.
+__global__ __launch_bounds__(256) void wgrad_t8_reduce_kernel(const float* __restrict__ ws, int S, int Cl, int Cs, float* __restrict__ dw) {
+    __shared__ float tile[64][28];
     const int Kp = 8 * Cs, pco = Kp >> 6, P = (Cl >> 5) * pco;
-    const long long total = (long long)Cl * Cs * 27;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int co = (int)(i % Cs);
-        long long r = i / Cs;
-        const int ci = (int)(r % Cl);
-        const int s = (int)(r / Cl);
-        int tap = 0, pp = 0;
-        const int sd[3] = {s / 9, (s / 3) % 3, s % 3};
+    const int cblocks = (Cs + 63) >> 6;
+    const int ci = blockIdx.x / cblocks, co0 = (blockIdx.x - ci * cblocks) * 64;
+    const int t = threadIdx.x;
+    const size_t split_stride = (size_t)P * 8 * 2048;
+    for (int i = t; i < 27 * 64; i += 256) {
+        const int s = i >> 6, col = i & 63, co = co0 + col;
+        float v = 0.f;
+        if (co < Cs) {
+            int tap = 0, pp = 0;
+            const int sd[3] = {s / 9, (s / 3) % 3, s % 3};
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int a = sd[d] == 0 ? 1 : 0, pb = sd[d] == 1 ? 0 : 1;  // s = 0 -> (1,1); 1 -> (0,0); 2 -> (0,1)
-            tap = tap * 2 + a;
-            pp = pp * 2 + pb;
+            for (int d = 0; d < 3; ++d) {
+                const int a = sd[d] == 0 ? 1 : 0, pb = sd[d] == 1 ? 0 : 1;  // s = 0 -> (1,1); 1 -> (0,0); 2 -> (0,1)
+                tap = tap * 2 + a;
+                pp = pp * 2 + pb;
+            }
+            const int kp = pp * Cs + co;
+            const int pair = (ci >> 5) * pco + (kp >> 6);
+            const size_t off = ((size_t)pair * 8 + tap) * 2048 + (ci & 31) * 64 + (kp & 63);
+            double sum = 0.0;
+            for (int sp = 0; sp < S; ++sp) sum += (double)ws[(size_t)sp * split_stride + off];
+            v = (float)sum;
         }
-        const int kp = pp * Cs + co;
-        const int pair = (ci >> 5) * pco + (kp >> 6);
-        const size_t off = ((size_t)pair * 8 + tap) * 2048 + (ci & 31) * 64 + (kp & 63);
-        double sum = 0.0;
-        for (int sp = 0; sp < S; ++sp) sum += (double)ws[(size_t)sp * P * 8 * 2048 + off];
-        dw[((size_t)ci * Cs + co) * 27 + s] = (float)sum;
+        tile[col][s] = v;
+    }
+    __syncthreads();
+    for (int i = t; i < 27 * 64; i += 256) {
+        const int col = i / 27, s = i - col * 27;
+        if (co0 + col < Cs) dw[((size_t)ci * Cs + co0 + col) * 27 + s] = tile[col][s];
     }
 }
 
@@ -912,9 +953,8 @@ extern "C" int u3d_convtr3d_wgrad_t8(int device, u3d_stream_t stream, const floa
                                 2 * wg_geom<2>::LDS));
     hipLaunchKernelGGL(conv3d_wgrad_bf16_kernel<2>, dim3((unsigned)(q.S * q.P)), dim3(512), 2 * wg_geom<2>::LDS, (hipStream_t)stream, p);
     U3D_LAUNCH_CHECK();
-    long long rb = ((long long)Cl * Cs * 27 + 255) / 256;
-    if (rb > 8192) rb = 8192;
-    hipLaunchKernelGGL(wgrad_t8_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, (hipStream_t)stream, workspace, q.S, Cl, Cs, dw);
+    hipLaunchKernelGGL(wgrad_t8_reduce_kernel, dim3((unsigned)(Cl * ((Cs + 63) / 64))), dim3(256), 0, (hipStream_t)stream, workspace,
+                       q.S, Cl, Cs, dw);
     U3D_LAUNCH_CHECK();
     return 0;
 }
