@@ -48,25 +48,21 @@ template <int ZW, int KS>
 struct tile_geom {
     static constexpr int TZ = 4 * ZW, HZ = TZ + KS - 1, HY = 8 + KS - 1, HX = 8 + KS - 1, MT = 2 * ZW;
     static constexpr int NTAPS = KS * KS * KS;
-    static constexpr int RING = KS == 3 ? 3 : 4;          // B-fragment ring: NTAPS % RING == 0 keeps the slots aligned across chunks
-    static constexpr int PLANE = HZ * HY * HS * 16 + 64;  // bytes; +64: the two planes' writes land on different banks
+    // B-fragment ring: NTAPS % RING == 0 keeps the slots aligned across chunks (the packed image is linear in (chunk, tap));
+    // fragments are fetched BDIST taps ahead — a tap is only 4*ZW*NT MFMAs = 128-256 cycles against ~500 cycles of L2 latency for
+    // the first wave that touches a weight fragment.  The image carries BDIST taps of tail padding so that the prefetch never
+    // needs a bounds branch.
+    static constexpr int RING = KS == 3 ? 9 : 8;
+    static constexpr int BDIST = 6;
+    static constexpr int ADIST = 2;                       // A fragments (LDS) two taps ahead, ring of ADIST + 1 sets
+    static constexpr int PLANE = HZ * HY * HS * 16 + 64;  // bytes; +64: the two planes' writes land on different banks; the
+                                                          // pad also serves as the dump slot of items past the tile
     static constexpr int BUF = 2 * PLANE;
     static constexpr int ITEMS = HZ * HY * HX * 4;        // (halo voxel, channel quad) float4 items per chunk
     static constexpr int ITERS = (ITEMS + 255) / 256;
     static constexpr int NPARTS = KS * KS;                // staging parts per chunk = (z tap, y tap) groups of KS taps
     static constexpr int PER_PART = (ITERS + NPARTS - 1) / NPARTS;
 };
-
-// one staged item: global float4 (4 channels of one halo voxel) -> affine -> 4 bf16 -> 8 bytes of LDS
-template <int ZW, int KS>
-__device__ __forceinline__ void item_coords(int item, int& hz, int& hy, int& hx) {
-    using G = tile_geom<ZW, KS>;
-    const int hv = item >> 2;
-    hz = hv / (G::HY * G::HX);
-    const int rem = hv - hz * (G::HY * G::HX);
-    hy = rem / G::HX;
-    hx = rem - hy * G::HX;
-}
 
 template <int NT, int ZW, int KS>
 __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_params p) {
@@ -97,36 +93,44 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
     const int r = lane & 31, kh = lane >> 5;
     const int a_base = kh * G::PLANE + (((w * ZW) * HY + (r & 3)) * HS + (r >> 2)) * 16;
 
-    auto load_item = [&](int c, int it, f32x4& v) {
-        const int item = t + it * 256;
-        v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (item < G::ITEMS) {
-            int hz, hy, hx;
-            item_coords<ZW, KS>(item, hz, hy, hx);
+    // Staging descriptors, computed ONCE per block: per item the element offset from the tile's halo origin, a validity bit and
+    // the LDS byte offset.  The hot loop is then BRANCH-FREE: out-of-volume items load a harmless in-tensor address (the tile's
+    // own first voxel) and are zeroed by a select (zero padding applies AFTER the GroupNorm affine, as Conv3d(padding=1) on the
+    // normalised tensor requires); items past the tile's halo write into the plane's pad bytes.  (Measured before: ~10 VALU
+    // instructions per MFMA and a scalar branch per item and tap; every branch in the unrolled loop cost 1-2 % of the kernel.)
+    int rel[G::ITERS], lo[G::ITERS];
+    unsigned okmask = 0;
+    {
+        const int hv0 = t >> 2;
+        const int bz = hv0 / (G::HY * G::HX), brem = hv0 - bz * (G::HY * G::HX), by = brem / G::HX, bx = brem - by * G::HX;
+        const int rel_safe = ((p.off * p.H + p.off) * p.W + p.off) * p.C;  // the tile's first output voxel: always inside the volume
+#pragma unroll
+        for (int it = 0; it < G::ITERS; ++it) {
+            constexpr int HYX = G::HY * G::HX;
+            const int dz = (64 * it) / HYX, dy = ((64 * it) % HYX) / G::HX, dx = (64 * it) % G::HX;  // compile-time
+            int hx = bx + dx, hy = by + dy, hz = bz + dz;
+            if (hx >= G::HX) hx -= G::HX, hy += 1;
+            if (hy >= G::HY) hy -= G::HY, hz += 1;
             const int z = z0 - p.off + hz, y = y0 - p.off + hy, xx = x0 - p.off + hx;
-            if ((unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
-                const size_t vox = (((size_t)n * p.D + z) * p.H + y) * p.W + xx;
-                v = *reinterpret_cast<const f32x4*>(p.x + vox * p.C + (c << 4) + 4 * q);
-            }
+            const bool ok = hz < G::HZ && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+            rel[it] = ok ? ((hz * p.H + hy) * p.W + hx) * p.C : rel_safe;
+            okmask |= (ok ? 1u : 0u) << it;
+            lo[it] = hz < G::HZ ? (q >> 1) * G::PLANE + ((hz * G::HY + hy) * HS + hx) * 16 + (q & 1) * 8 : G::PLANE - 64 + (t & 7) * 8;
         }
+    }
+    // halo origin of the tile (may lie outside the tensor: only dereferenced through `rel`), this thread's channel quad
+    const float* xo = p.x + ((((long long)n * p.D + (z0 - p.off)) * p.H + (y0 - p.off)) * p.W + (x0 - p.off)) * (long long)p.C + 4 * q;
+    const int rel_dump = ((p.off * p.H + p.off) * p.W + p.off) * p.C;
+    // live = false (the last chunk has nothing to stage): every item re-reads one cached address instead of branching
+    auto load_item = [&](int c, int it, f32x4& v, bool live = true) {
+        v = *reinterpret_cast<const f32x4*>(xo + (live ? rel[it] : rel_dump) + (c << 4));
     };
     auto store_item = [&](char* buf, int it, const f32x4& v, const f32x4& ga, const f32x4& gb) {
-        const int item = t + it * 256;
-        if (item < G::ITEMS) {
-            int hz, hy, hx;
-            item_coords<ZW, KS>(item, hz, hy, hx);
-            bf16x4 o;
-            const int z = z0 - p.off + hz, y = y0 - p.off + hy, xx = x0 - p.off + hx;
-            if (!((unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)) {
-                // zero padding applies AFTER the GroupNorm affine: Conv3d(padding=1) pads the normalised tensor
-                o = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-            } else {
+        bf16x4 o;
+        const bool ok = (okmask >> it) & 1u;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (__bf16)fmaf(v[e], ga[e], gb[e]);
-            }
-            char* dst = buf + (q >> 1) * G::PLANE + ((hz * HY + hy) * HS + hx) * 16 + (q & 1) * 8;
-            *reinterpret_cast<bf16x4*>(dst) = o;
-        }
+        for (int e = 0; e < 4; ++e) o[e] = (__bf16)(ok ? fmaf(v[e], ga[e], gb[e]) : 0.f);
+        *reinterpret_cast<bf16x4*>(buf + lo[it]) = o;
     };
     auto chunk_affine = [&](int c, f32x4& ga, f32x4& gb) {
         u3d_load_affine(p.affine, n, p.C, (c << 4) + 4 * q, true, ga, gb);
@@ -136,13 +140,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
     if (cbeg < nch) {
         f32x4 ga, gb;
         chunk_affine(cbeg, ga, gb);
-#pragma unroll 1
+#pragma unroll
         for (int it0 = 0; it0 < G::ITERS; it0 += 8) {
             f32x4 v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) load_item(cbeg, it0 + i, v[i]);
+            for (int i = 0; i < 8; ++i)
+                if (it0 + i < G::ITERS) load_item(cbeg, it0 + i, v[i]);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) store_item(lds + (cbeg & 1) * G::BUF, it0 + i, v[i], ga, gb);
+            for (int i = 0; i < 8; ++i)
+                if (it0 + i < G::ITERS) store_item(lds + (cbeg & 1) * G::BUF, it0 + i, v[i], ga, gb);
         }
     }
     f32x16 acc[G::MT][NT];
@@ -153,65 +159,65 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[m][j][e] = 0.f;
 
-    // Software pipeline (the compiler's own schedule issues every load right before its use — ~400 cycles of L1/L2 latency and
-    // an LDS round trip exposed per tap): B fragments run two taps ahead in a 3-slot register ring (across chunk boundaries: the
-    // packed image is linear in (chunk, tap)), each A fragment is refilled for the next tap right after its MFMAs, the next
-    // chunk's halo items are fetched at the start of a 3-tap part and written at its end; sched_barriers pin "issue the prefetches, then the 4*ZW*NT MFMAs".
+    // Software pipeline (hipcc's own schedule issues every load right before its use): B fragments BDIST taps ahead in a register
+    // ring that runs across chunk boundaries, A fragments ADIST taps ahead (restarted per chunk: the LDS buffer changes), the next
+    // chunk's halo items fetched at the start of a KS-tap part and written at its end; sched_barriers pin "issue the prefetches,
+    // then the 2*ZW*NT MFMAs of the tap".  The last chunk prefetches a clamped (repeated) chunk instead of branching.
     bf16x8 bq[G::RING][NT];
     if (cbeg < nch) {
-        const bf16x8* wp0 = p.wpk + ((size_t)cbeg * G::NTAPS * ntiles + (size_t)nb * NT) * 64 + lane;
+        const bf16x8* wp0 = p.wpk + ((size_t)cbeg * G::NTAPS * ntiles + (size_t)nb * NT) * 64;  // wave-uniform base + lane
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            bq[0][j] = wp0[(size_t)j * 64];
-            bq[1][j] = wp0[((size_t)ntiles + j) * 64];
-        }
+        for (int d = 0; d < G::BDIST; ++d)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bq[d][j] = wp0[((size_t)d * ntiles + j) * 64 + lane];
     }
     for (int c = cbeg; c < nch; ++c) {
         __syncthreads();  // buffer (c&1) is complete; everyone is done reading buffer ((c+1)&1)
         const char* cur = lds + (c & 1) * G::BUF;
         char* nxt = lds + ((c + 1) & 1) * G::BUF;
         const bool more = c + 1 < nch;
+        const int cn = more ? c + 1 : c;  // the chunk staged under this one (the last chunk stages a dummy: never read)
         f32x4 ga, gb;
-        if (more) chunk_affine(c + 1, ga, gb);
-        const bf16x8* wp = p.wpk + ((size_t)c * G::NTAPS * ntiles + (size_t)nb * NT) * 64 + lane;
-        f32x4 st[G::PER_PART];  // the next chunk's halo items of one part: loaded at the part's start, stored at its end
-        bf16x8 aq[G::MT];  // one set: fragment m is refilled for the next tap right after its MFMAs of this tap
+        chunk_affine(cn, ga, gb);
+        const bf16x8* wp = p.wpk + ((size_t)c * G::NTAPS * ntiles + (size_t)nb * NT) * 64;  // wave-uniform (scalar) base
+        f32x4 st[G::PER_PART];
+        bf16x8 aq[G::ADIST + 1][G::MT];
 #pragma unroll
-        for (int m = 0; m < G::MT; ++m)
-            aq[m] = *reinterpret_cast<const bf16x8*>(cur + a_base + ((((m >> 1)) * HY + ((m & 1) * 4)) * HS) * 16);
+        for (int d = 0; d < G::ADIST; ++d) {
+            const int tzz = d / (KS * KS), tyy = (d / KS) % KS, txx = d % KS;
+#pragma unroll
+            for (int m = 0; m < G::MT; ++m)
+                aq[d][m] = *reinterpret_cast<const bf16x8*>(cur + a_base + ((((m >> 1) + tzz) * HY + ((m & 1) * 4 + tyy)) * HS + txx) * 16);
+        }
 #pragma unroll
         for (int part = 0; part < G::NPARTS; ++part) {  // part = (z tap, y tap)
-            if (more) {
 #pragma unroll
-                for (int i = 0; i < G::PER_PART; ++i)
-                    if (part * G::PER_PART + i < G::ITERS) load_item(c + 1, part * G::PER_PART + i, st[i]);
-            }
+            for (int i = 0; i < G::PER_PART; ++i)
+                if (part * G::PER_PART + i < G::ITERS) load_item(cn, part * G::PER_PART + i, st[i], more);
 #pragma unroll
             for (int t3 = 0; t3 < KS; ++t3) {
                 const int tap = part * KS + t3;
-                if (tap + 2 < G::NTAPS || more) {
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) bq[(tap + 2) % G::RING][j] = wp[((size_t)(tap + 2) * ntiles + j) * 64];
+                for (int j = 0; j < NT; ++j)
+                    bq[(tap + G::BDIST) % G::RING][j] = wp[((size_t)(tap + G::BDIST) * ntiles + j) * 64 + lane];
+                if (tap + G::ADIST < G::NTAPS) {
+                    const int nt_ = tap + G::ADIST, tzz = nt_ / (KS * KS), tyy = (nt_ / KS) % KS, txx = nt_ % KS;
+#pragma unroll
+                    for (int m = 0; m < G::MT; ++m)
+                        aq[nt_ % (G::ADIST + 1)][m] =
+                            *reinterpret_cast<const bf16x8*>(cur + a_base + ((((m >> 1) + tzz) * HY + ((m & 1) * 4 + tyy)) * HS + txx) * 16);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                const int nt_ = tap + 1, tzz = nt_ / (KS * KS), tyy = (nt_ / KS) % KS, txx = nt_ % KS;
 #pragma unroll
-                for (int m = 0; m < G::MT; ++m) {
+                for (int m = 0; m < G::MT; ++m)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[m], bq[tap % G::RING][j], acc[m][j], 0, 0, 0);
-                    if (nt_ < G::NTAPS) {
-                        const int off = ((((m >> 1) + tzz) * HY + ((m & 1) * 4 + tyy)) * HS + txx) * 16;
-                        aq[m] = *reinterpret_cast<const bf16x8*>(cur + a_base + off);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[tap % (G::ADIST + 1)][m], bq[tap % G::RING][j], acc[m][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (more) {
 #pragma unroll
-                for (int i = 0; i < G::PER_PART; ++i)
-                    if (part * G::PER_PART + i < G::ITERS) store_item(nxt, part * G::PER_PART + i, st[i], ga, gb);
-            }
+            for (int i = 0; i < G::PER_PART; ++i)
+                if (part * G::PER_PART + i < G::ITERS) store_item(nxt, part * G::PER_PART + i, st[i], ga, gb);
         }
     }
 
@@ -357,7 +363,7 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int Cout, 
 extern "C" long long u3d_packed_weight_bf16_elems(int Cin, int Cout, int mode) {
     const int Kc = mode == 0 ? Cin : Cout, Nc = mode == 0 ? Cout : Cin;
     if (Kc <= 0 || Nc <= 0 || Kc % 16 != 0 || Nc % 32 != 0) return 0;
-    return (long long)(Kc / 16) * 27 * (Nc / 32) * 64 * 8;
+    return ((long long)(Kc / 16) * 27 + 6) * (Nc / 32) * 64 * 8;  // + BDIST taps of tail padding (prefetched, never used)
 }
 
 extern "C" int u3d_pack_weights_bf16(int device, u3d_stream_t stream, const float* w, int Cout, int Cin, int mode,
@@ -454,9 +460,9 @@ extern "C" int u3d_conv3d_bf16_ex(int device, u3d_stream_t stream, const float* 
     // of the U); 64 output channels per block when possible
     const bool nt2 = K % 64 == 0;
     const long long big = (long long)N * ((D + 7) / 8) * ((H + 7) / 8) * ((W + 7) / 8) * (K / (nt2 ? 64 : 32));
-    bool zw2 = big >= 512 && D >= 8 && p.ksplit == 1;
-    if (g_u3d_tune[7] == 1) zw2 = false;  // A/B knob (u3d_set_tuning key 7): 1 = 4-plane tiles everywhere, 2 = 8-plane wherever legal
-    if (g_u3d_tune[7] == 2) zw2 = D >= 8 && p.ksplit == 1;
+    // 4-plane tiles everywhere: 8-plane tiles (twice the B-fragment reuse) timed the same (profiles/r02i) and have no registers
+    // left for the staging descriptors and the deeper rings; u3d_set_tuning key 7 = 2 selects them for A/B runs
+    const bool zw2 = g_u3d_tune[7] == 2 && big >= 512 && D >= 8 && p.ksplit == 1;
     hipStream_t s = (hipStream_t)stream;
     if (nt2) return zw2 ? launch_bf16<2, 2, 3>(p, s) : launch_bf16<2, 1, 3>(p, s);
     return zw2 ? launch_bf16<1, 2, 3>(p, s) : launch_bf16<1, 1, 3>(p, s);
@@ -888,10 +894,7 @@ __global__ __launch_bounds__(256) void wgrad_t8_reduce_kernel(const float* __res
 int launch_t8_conv(const bf16_conv_params& p0, hipStream_t s) {
     bf16_conv_params p = p0;
     const bool nt2 = p.K % 64 == 0;
-    const long long big = (long long)p.N * ((p.D + 7) / 8) * ((p.H + 7) / 8) * ((p.W + 7) / 8) * (p.K / (nt2 ? 64 : 32));
-    const bool zw2 = big >= 512 && p.D >= 8;
-    if (nt2) return zw2 ? launch_bf16<2, 2, 2>(p, s) : launch_bf16<2, 1, 2>(p, s);
-    return zw2 ? launch_bf16<1, 2, 2>(p, s) : launch_bf16<1, 1, 2>(p, s);
+    return nt2 ? launch_bf16<2, 1, 2>(p, s) : launch_bf16<1, 1, 2>(p, s);
 }
 
 }  // namespace
@@ -901,7 +904,7 @@ extern "C" int u3d_convtr3d_t8_supported(int Cl, int Cs) { return (Cl > 0 && Cs 
 extern "C" long long u3d_convtr3d_t8_packed_elems(int Cl, int Cs, int mode) {
     if (!u3d_convtr3d_t8_supported(Cl, Cs)) return 0;
     const int Kc = mode == 0 ? Cl : 8 * Cs, Nc = mode == 0 ? 8 * Cs : Cl;
-    return (long long)(Kc / 16) * 8 * (Nc / 32) * 64 * 8;
+    return ((long long)(Kc / 16) * 8 + 6) * (Nc / 32) * 64 * 8;  // + BDIST taps of tail padding (prefetched, never used)
 }
 
 extern "C" int u3d_pack_convtr3d_t8(int device, u3d_stream_t stream, const float* w, int Cl, int Cs, int mode, void* packed) {

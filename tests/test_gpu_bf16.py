@@ -277,6 +277,9 @@ def test_activation_checkpointing_gives_bitwise_identical_gradients(bf16):
     for ck in (False, True):
         model, x, target = _prep(cfg, shape, compute_dtype="bf16" if bf16 else "fp32", checkpoint_encoders=ck)
         assert model._get_engine().checkpoint_encoders == ck and model._get_engine().bf16 == bf16
+        import gc
+
+        gc.collect()  # the previous iteration's model / graph (reference cycles) must not be freed INSIDE the measured step
         torch.cuda.synchronize()
         torch.cuda.reset_peak_memory_stats()
         base = torch.cuda.memory_allocated()
