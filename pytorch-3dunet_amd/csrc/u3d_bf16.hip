@@ -16,6 +16,7 @@
 // three batches under the three z-tap groups of chunk c and written to the other buffer after each group; one barrier
 // per chunk.
 #include "u3d_common.h"
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -247,39 +248,49 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
     for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
     const bool want_stats = p.out_stats != nullptr, want_g = p.gstats != nullptr;
     const float* side = p.residual ? p.residual : (want_g ? p.gx : p.maskx);  // the one tensor the epilogue reads (exclusive)
+    // Addressing is hoisted: element e of an accumulator tile sits (e & 3) rows and 2*(e >> 2) voxels from the tile's first
+    // voxel, so one 64-bit base per (m, j) plus sixteen 32-bit offsets replaces a five-term index per element; tiles that lie
+    // wholly inside the volume (all but the ragged rim) skip the per-element bounds tests.
+    const int K = p.K, rowK = p.W * K;
+    const bool full = z0 + G::TZ <= p.D && y0 + 8 <= p.H && x0 + 8 <= p.W;
+    auto emit_tile = [&](auto FULL, int m, int j) {
+        const int z = z0 + w * ZW + (m >> 1), yb = y0 + (m & 1) * 4, xb = x0 + half;
+        const size_t base = ((((size_t)n * p.D + z) * p.H + yb) * p.W + xb) * K + (size_t)(nb * NT + j) * 32 + col;
+        float* yp = p.y + base;
+        const float* sp = side ? side + base : nullptr;
+        auto inside = [&](int e) { return FULL.value || (z < p.D && yb + (e & 3) < p.H && xb + 2 * (e >> 2) < p.W); };
+        f32x16 sv;  // all 16 side loads of this accumulator tile in flight before the first use
 #pragma unroll
-    for (int m = 0; m < G::MT; ++m) {
-        const int z = z0 + w * ZW + (m >> 1);
+        for (int e = 0; e < 16; ++e) {
+            sv[e] = 0.f;
+            if (sp && inside(e)) sv[e] = sp[(e & 3) * rowK + (e >> 2) * 2 * K];
+        }
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            // all 16 side loads of this accumulator tile in flight before the first use
-            f32x16 sv;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int y = y0 + (m & 1) * 4 + (e & 3), xx = x0 + 2 * (e >> 2) + half;
-                sv[e] = 0.f;
-                if (side && z < p.D && y < p.H && xx < p.W)
-                    sv[e] = side[((((size_t)n * p.D + z) * p.H + y) * p.W + xx) * p.K + (size_t)(nb * NT + j) * 32 + col];
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int y = y0 + (m & 1) * 4 + (e & 3), xx = x0 + 2 * (e >> 2) + half;
-                if (z < p.D && y < p.H && xx < p.W) {
-                    const size_t o = ((((size_t)n * p.D + z) * p.H + y) * p.W + xx) * p.K + (size_t)(nb * NT + j) * 32 + col;
-                    float v = acc[m][j][e];
-                    if (p.residual) v += sv[e];
-                    if (p.maskx && !(sv[e] > 0.f)) v = 0.f;
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    p.y[o] = v;
-                    if (want_stats) {
-                        s1[j] += v;
-                        s2[j] = fmaf(v, v, s2[j]);
-                    } else if (want_g) {
-                        s1[j] += v;
-                        s2[j] = fmaf(v, sv[e], s2[j]);
-                    }
+        for (int e = 0; e < 16; ++e) {
+            if (inside(e)) {
+                float v = acc[m][j][e];
+                if (p.residual) v += sv[e];
+                if (p.maskx && !(sv[e] > 0.f)) v = 0.f;
+                if (p.relu) v = fmaxf(v, 0.f);
+                yp[(e & 3) * rowK + (e >> 2) * 2 * K] = v;
+                if (want_stats) {
+                    s1[j] += v;
+                    s2[j] = fmaf(v, v, s2[j]);
+                } else if (want_g) {
+                    s1[j] += v;
+                    s2[j] = fmaf(v, sv[e], s2[j]);
                 }
             }
+        }
+    };
+#pragma unroll
+    for (int m = 0; m < G::MT; ++m) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (full)
+                emit_tile(std::true_type{}, m, j);
+            else
+                emit_tile(std::false_type{}, m, j);
         }
     }
     if (want_stats || want_g) {
