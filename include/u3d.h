@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define U3D_VERSION 110 /* 0.1.1: bf16-operand convolutions */
+#define U3D_VERSION 111 /* bf16-operand convolutions; residual blocks in every native layer order */
 
 #define U3D_OK 0
 #define U3D_EINVAL (-1)  /* bad shape / argument */
@@ -418,11 +418,15 @@ int u3d_nearest_sum_bwd_t8(int device, u3d_stream_t stream, const float* dj, con
  *   u3d_act_bwd         out = g * f'(.) with the derivative expressed through the OUTPUT y of f (in place on g allowed)
  *   u3d_affine_act_fwd  out[n,v,c] = f(a[n,c]*z[n,v,c] + b[n,c]): nn.GroupNorm apply (+ non-linearity) of a post-norm layer
  *                       ('cgr' family, GroupNorm on the conv OUTPUT channels, buildingblocks.py:62-66); affine (N,C,2)
+ *   u3d_affine_add_act_fwd  out = f(a*z + b + add[n,v,c]) (add may be NULL): the tail of ResNetBlock.forward for post-norm
+ *                       orders — conv3's GroupNorm, `out += residual`, non-linearity (buildingblocks.py:277-288)
  *   u3d_pair_stats      stats double[N][C][2] += (sum_v a, sum_v a*b): the reductions nn.GroupNorm's backward needs */
 int u3d_act_fwd(int device, u3d_stream_t stream, const float* x, int64_t n, int mode, float slope, float* out);
 int u3d_act_bwd(int device, u3d_stream_t stream, const float* g, const float* y, int64_t n, int mode, float slope, float* out);
 int u3d_affine_act_fwd(int device, u3d_stream_t stream, const float* z, const float* affine, int N, int64_t V, int C, int mode,
                        float slope, float* out);
+int u3d_affine_add_act_fwd(int device, u3d_stream_t stream, const float* z, const float* affine, const float* add, int N,
+                           int64_t V, int C, int mode, float slope, float* out);
 int u3d_pair_stats(int device, u3d_stream_t stream, const float* a, const float* b, int N, int64_t V, int C, double* stats);
 
 /* ---- layout: NCDHW <-> NDHWC for multi-channel model inputs ------------------------------------ */

@@ -5,6 +5,7 @@
 //   u3d_act_fwd         y = f(x)                               (in place allowed)
 //   u3d_act_bwd         out = g * f'(.) expressed through the OUTPUT y of f (sign(y) = sign(x); ELU': y + 1 for y <= 0)
 //   u3d_affine_act_fwd  y = f(a[n,c] * z + b[n,c])             GroupNorm apply (+ non-linearity) of a post-norm layer
+//   u3d_affine_add_act_fwd  y = f(a*z + b + add)                the same with a ResNetBlock's `out += residual` before f
 //   u3d_pair_stats      stats[n][c] += (sum_v a, sum_v a*b)    the two reductions GroupNorm backward needs
 // Activation codes: 0 none, 1 ReLU, 2 LeakyReLU(slope), 3 ELU(alpha = 1).  All tensors NDHWC fp32.
 #include "u3d_common.h"
@@ -36,14 +37,16 @@ __global__ void act_bwd_kernel(const float* __restrict__ g, const float* __restr
         out[i] = g[i] * act_df(y[i], mode, slope);
 }
 
-__global__ void affine_act_fwd_kernel(const float* __restrict__ z, const float* __restrict__ affine, int N, long long V, int C,
-                                      int mode, float slope, float* __restrict__ out) {
+__global__ void affine_act_fwd_kernel(const float* __restrict__ z, const float* __restrict__ affine, const float* __restrict__ add,
+                                      int N, long long V, int C, int mode, float slope, float* __restrict__ out) {
     const long long total = (long long)N * V * C;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         const int n = (int)(i / ((long long)V * C));
         const float* ab = affine + ((size_t)n * C + c) * 2;
-        out[i] = act_f(fmaf(z[i], ab[0], ab[1]), mode, slope);
+        float v = fmaf(z[i], ab[0], ab[1]);
+        if (add) v += add[i];
+        out[i] = act_f(v, mode, slope);
     }
 }
 
@@ -103,14 +106,19 @@ extern "C" int u3d_act_bwd(int device, u3d_stream_t stream, const float* g, cons
     return 0;
 }
 
-extern "C" int u3d_affine_act_fwd(int device, u3d_stream_t stream, const float* z, const float* affine, int N, int64_t V, int C,
-                                  int mode, float slope, float* out) {
+extern "C" int u3d_affine_add_act_fwd(int device, u3d_stream_t stream, const float* z, const float* affine, const float* add, int N,
+                                      int64_t V, int C, int mode, float slope, float* out) {
     U3D_ENTER(device);
-    U3D_REQUIRE(z && affine && out && N > 0 && V > 0 && C > 0 && mode >= 0 && mode <= 3, "u3d_affine_act_fwd: bad argument");
+    U3D_REQUIRE(z && affine && out && N > 0 && V > 0 && C > 0 && mode >= 0 && mode <= 3, "u3d_affine_add_act_fwd: bad argument");
     hipLaunchKernelGGL(affine_act_fwd_kernel, dim3(blocks_for((long long)N * V * C)), dim3(256), 0, (hipStream_t)stream, z, affine,
-                       N, (long long)V, C, mode, slope, out);
+                       add, N, (long long)V, C, mode, slope, out);
     U3D_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int u3d_affine_act_fwd(int device, u3d_stream_t stream, const float* z, const float* affine, int N, int64_t V, int C,
+                                  int mode, float slope, float* out) {
+    return u3d_affine_add_act_fwd(device, stream, z, affine, nullptr, N, V, C, mode, slope, out);
 }
 
 extern "C" int u3d_pair_stats(int device, u3d_stream_t stream, const float* a, const float* b, int N, int64_t V, int C,

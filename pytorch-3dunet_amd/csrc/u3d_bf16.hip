@@ -65,7 +65,7 @@ struct tile_geom {
     static constexpr int PER_PART = (ITERS + NPARTS - 1) / NPARTS;
 };
 
-template <int NT, int ZW, int KS>
+template <int NT, int ZW, int KS, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_params p) {
     using G = tile_geom<ZW, KS>;
     constexpr int HY = G::HY;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
             for (int j = 0; j < NT; ++j) bq[d][j] = wp0[((size_t)d * ntiles + j) * 64 + lane];
     }
     for (int c = cbeg; c < nch; ++c) {
-        __syncthreads();  // buffer (c&1) is complete; everyone is done reading buffer ((c+1)&1)
+        if constexpr (!(ABL & 8)) __syncthreads();  // buffer (c&1) is complete; everyone is done reading buffer ((c+1)&1)
         const char* cur = lds + (c & 1) * G::BUF;
         char* nxt = lds + ((c + 1) & 1) * G::BUF;
         const bool more = c + 1 < nch;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
         chunk_affine(cn, ga, gb);
         const bf16x8* wp = p.wpk + ((size_t)c * G::NTAPS * ntiles + (size_t)nb * NT) * 64;  // wave-uniform (scalar) base
         f32x4 st[G::PER_PART];
-        bf16x8 aq[G::ADIST + 1][G::MT];
+        bf16x8 aq[G::ADIST + 1][G::MT] = {};
 #pragma unroll
         for (int d = 0; d < G::ADIST; ++d) {
             const int tzz = d / (KS * KS), tyy = (d / KS) % KS, txx = d % KS;
@@ -194,14 +194,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
         for (int part = 0; part < G::NPARTS; ++part) {  // part = (z tap, y tap)
 #pragma unroll
             for (int i = 0; i < G::PER_PART; ++i)
-                if (part * G::PER_PART + i < G::ITERS) load_item(cn, part * G::PER_PART + i, st[i], more);
+                if (!(ABL & 4) && part * G::PER_PART + i < G::ITERS) load_item(cn, part * G::PER_PART + i, st[i], more);
 #pragma unroll
             for (int t3 = 0; t3 < KS; ++t3) {
                 const int tap = part * KS + t3;
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    bq[(tap + G::BDIST) % G::RING][j] = wp[((size_t)(tap + G::BDIST) * ntiles + j) * 64 + lane];
-                if (tap + G::ADIST < G::NTAPS) {
+                    if constexpr (!(ABL & 1)) bq[(tap + G::BDIST) % G::RING][j] = wp[((size_t)(tap + G::BDIST) * ntiles + j) * 64 + lane];
+                if (!(ABL & 2) && tap + G::ADIST < G::NTAPS) {
                     const int nt_ = tap + G::ADIST, tzz = nt_ / (KS * KS), tyy = (nt_ / KS) % KS, txx = nt_ % KS;
 #pragma unroll
                     for (int m = 0; m < G::MT; ++m)
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
             }
 #pragma unroll
             for (int i = 0; i < G::PER_PART; ++i)
-                if (part * G::PER_PART + i < G::ITERS) store_item(nxt, part * G::PER_PART + i, st[i], ga, gb);
+                if (!(ABL & 4) && part * G::PER_PART + i < G::ITERS) store_item(nxt, part * G::PER_PART + i, st[i], ga, gb);
         }
     }
 
@@ -394,7 +394,7 @@ extern "C" int u3d_pack_weights_bf16(int device, u3d_stream_t stream, const floa
 
 extern "C" int u3d_conv3d_bf16_supported(int C, int K) { return (C > 0 && K > 0 && C % 16 == 0 && K % 32 == 0) ? 1 : 0; }
 
-template <int NT, int ZW, int KS>
+template <int NT, int ZW, int KS, int ABL = 0>
 static int launch_bf16(const bf16_conv_params& p, hipStream_t stream) {
     using G = tile_geom<ZW, KS>;
     bf16_conv_params q = p;
@@ -405,9 +405,9 @@ static int launch_bf16(const bf16_conv_params& p, hipStream_t stream) {
     if (blocks > 0x7fffffffLL) return u3d_set_err(U3D_EINVAL, "u3d_conv3d_bf16: grid too large");
     const size_t shmem = 2 * (size_t)G::BUF;
     // (per device, cheap: set on every launch so that every device of a multi-GPU process has it)
-    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_bf16_kernel<NT, ZW, KS>),
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_bf16_kernel<NT, ZW, KS, ABL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL((conv3d_bf16_kernel<NT, ZW, KS>), dim3((unsigned)blocks), dim3(256), shmem, stream, q);
+    hipLaunchKernelGGL((conv3d_bf16_kernel<NT, ZW, KS, ABL>), dim3((unsigned)blocks), dim3(256), shmem, stream, q);
     U3D_LAUNCH_CHECK();
     if (p.ksplit > 1) {
         const long long V = (long long)p.D * p.H * p.W;
@@ -475,6 +475,18 @@ extern "C" int u3d_conv3d_bf16_ex(int device, u3d_stream_t stream, const float* 
     // left for the staging descriptors and the deeper rings; u3d_set_tuning key 7 = 2 selects them for A/B runs
     const bool zw2 = g_u3d_tune[7] == 2 && big >= 512 && D >= 8 && p.ksplit == 1;
     hipStream_t s = (hipStream_t)stream;
+    if (nt2 && g_u3d_tune[6] >= 200) {  // TIMING-ONLY ablations (results are wrong): which loop memory ops cost what
+        switch (g_u3d_tune[6] - 200) {
+            case 1: return launch_bf16<2, 1, 3, 1>(p, s);
+            case 2: return launch_bf16<2, 1, 3, 2>(p, s);
+            case 4: return launch_bf16<2, 1, 3, 4>(p, s);
+            case 8: return launch_bf16<2, 1, 3, 8>(p, s);
+            case 3: return launch_bf16<2, 1, 3, 3>(p, s);
+            case 12: return launch_bf16<2, 1, 3, 12>(p, s);
+            case 7: return launch_bf16<2, 1, 3, 7>(p, s);
+            case 15: return launch_bf16<2, 1, 3, 15>(p, s);
+        }
+    }
     if (nt2) return zw2 ? launch_bf16<2, 2, 3>(p, s) : launch_bf16<2, 1, 3>(p, s);
     return zw2 ? launch_bf16<1, 2, 3>(p, s) : launch_bf16<1, 1, 3>(p, s);
 }

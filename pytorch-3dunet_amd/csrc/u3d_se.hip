@@ -5,8 +5,8 @@
 // ChannelSpatialSELayer3D :96-114 (scSE = elementwise max of the two), attached after the residual block by
 // ResNetBlockSE (buildingblocks.py:291-307, reduction_ratio = 1).
 //
-// The gated tensor y is a block output (post-ReLU, >= 0) and both gates are positive, so
-//     max(y * gc[n,c], y * a[n,v]) = y * max(gc[n,c], a[n,v]).
+// Both gates are positive, so max(y * gc[n,c], y * a[n,v]) = y * max(gc, a) where y >= 0 (always, for ReLU blocks) and
+// y * min(gc, a) where y < 0 (LeakyReLU / ELU blocks).
 // Forward: the channel means come for free from conv3's fused statistics; a tiny kernel runs the two FC layers per sample;
 // ONE bandwidth pass computes the spatial gate (a dot product over the voxel's channels, lanes of a wave share a voxel)
 // and applies max(gc, a).  Backward: one reduction pass (d gc, d ws, d bs, d logit_s per voxel), the FC backward, and one
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void se_apply_fwd_kernel(const float* __restri
                 if (mode != 2) {
                     const f32x4 gv = *reinterpret_cast<const f32x4*>(gc + (size_t)n * C + 4 * q);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) g[e] = mode == 0 ? fmaxf(gv[e], a) : gv[e];
+                    for (int e = 0; e < 4; ++e) g[e] = mode == 0 ? (yv[it][e] >= 0.f ? fmaxf(gv[e], a) : fminf(gv[e], a)) : gv[e];
                 }
                 *reinterpret_cast<f32x4*>(out + (size_t)idx * C + 4 * q) = yv[it] * g;
             }
@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const float* __restr
                         to_g = 0.f, to_a = tv;
                     } else if (mode == 0) {
                         const float g = gq[it][e];
-                        to_g = g > a ? tv : (g == a ? 0.5f * tv : 0.f);
+                        const bool pick_g = yv[it][e] >= 0.f ? g > a : g < a;  // which product is the larger one
+                        to_g = pick_g ? tv : (g == a ? 0.5f * tv : 0.f);
                         to_a = tv - to_g;
                     }
                     dg[it][e] += to_g;
@@ -269,7 +270,7 @@ __global__ void se_bwd_apply_kernel(const float* __restrict__ dout, const float*
             const f32x4 gv = *reinterpret_cast<const f32x4*>(gc + (size_t)n * C + 4 * q);
             dsv = *reinterpret_cast<const f32x4*>(ds + (size_t)n * C + 4 * q);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = mode == 0 ? fmaxf(gv[e], a) : gv[e];
+            for (int e = 0; e < 4; ++e) g[e] = mode == 0 ? (yv[e] >= 0.f ? fmaxf(gv[e], a) : fminf(gv[e], a)) : gv[e];
         }
         if (mode != 1) wv = *reinterpret_cast<const f32x4*>(ws + 4 * q);
         f32x4 o = d * g + wv * dl + dsv;

@@ -587,10 +587,13 @@ class UNet3DEngine:
         gn, conv = sc.groupnorm, sc.conv
         N, D, H, W = src.N, src.D, src.H, src.W
         Ctot, Cout, G = src.C, conv.out_channels, gn.num_groups
-        post, act, slope = parse_order(sc.order) if act is None else (False, act[0], act[1])
+        post, act0, slope0 = parse_order(sc.order)
+        act, slope = (act0, slope0) if act is None else act
         assert conv.in_channels == Ctot and gn.num_channels == (Cout if post else Ctot)
-        assert not (post and residual is not None)
         relu = 1 if (act == ACT_RELU and not post) else 0
+        # `out += residual` follows the block's last GroupNorm: inside the conv epilogue for pre-norm orders, in the
+        # GroupNorm-apply pass for post-norm orders
+        conv_res = None if post else residual
         # the conv epilogue's statistics describe the conv OUTPUT: they are the next GroupNorm's input only when nothing
         # else transforms it (ReLU is in the epilogue); a post-norm layer needs them for its own GroupNorm
         want_stats = post or (want_stats and act in (ACT_NONE, ACT_RELU))
@@ -604,7 +607,7 @@ class UNet3DEngine:
                      float(D * H * W), _p(gn.weight.detach()), _p(gn.bias.detach()), float(gn.eps), _p(affine), _p(mean_rstd))
         # y_out: recomputation under activation checkpointing rewrites the (still alive) block output in place with the
         # bit-identical values instead of allocating a second copy
-        y = y_out if y_out is not None else torch.empty((N, D, H, W, Cout), dtype=_F32, device=dev)
+        y = y_out if (y_out is not None and not post) else torch.empty((N, D, H, W, Cout), dtype=_F32, device=dev)
         small = self.small_cin and src.t1 is None and Ctot <= 4 and Cout <= 32 and residual is None
         if small:
             # first layer of the network: K = 27*Cin is too small for the MFMA tiling (csrc/u3d_smallc.hip)
@@ -634,7 +637,7 @@ class UNet3DEngine:
             need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(N, D, H, W, Ctot, Cout)  # split-K scratch at the bottom of the U
             kws = torch.empty(need, dtype=_F32, device=dev) if need > 0 else None
             nat.call("u3d_conv3d_bf16_ex", dev.index, _stream(dev), _p(src.t0), _p(affine), _p(self._packed_bf16(conv.weight, 0, dev)),
-                     _p(y), N, D, H, W, Ctot, Cout, relu, _p(ystats), None, None, _p(residual), _p(kws), need,
+                     _p(y), N, D, H, W, Ctot, Cout, relu, _p(ystats), None, None, _p(conv_res), _p(kws), need,
                      flops=54.0 * Ctot * Cout * N * D * H * W)
         else:
             wp = self._packed(conv.weight, 0, dev)
@@ -644,7 +647,7 @@ class UNet3DEngine:
             need = nat.get_lib().u3d_conv3d_workspace_floats(N, D, H, W, Ctot, Cout)
             kws = torch.empty(need, dtype=_F32, device=dev) if need > 0 else None
             nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s), _p(wp), _p(y), N, D, H, W, Cout, relu,
-                     _p(ystats), None, None, _p(residual), _p(kws), need, flops=54.0 * Ctot * Cout * N * D * H * W)
+                     _p(ystats), None, None, _p(conv_res), _p(kws), need, flops=54.0 * Ctot * Cout * N * D * H * W)
         post_rec = None
         if post:
             # GroupNorm over the conv output z (statistics from the conv epilogue), then the non-linearity: y = f(a*z + b)
@@ -655,8 +658,9 @@ class UNet3DEngine:
             mean_rstd = torch.empty((N, G, 2), dtype=_F32, device=dev)
             nat.call("u3d_gn_finalize", dev.index, _stream(dev), _p(zst), Cout, 1.0, None, 0, 0.0, N, G, float(D * H * W),
                      _p(gn.weight.detach()), _p(gn.bias.detach()), float(gn.eps), _p(aff2), _p(mean_rstd))
-            y = torch.empty_like(z)
-            nat.call("u3d_affine_act_fwd", dev.index, _stream(dev), _p(z), _p(aff2), N, D * H * W, Cout, act, slope, _p(y))
+            y = y_out if y_out is not None else torch.empty_like(z)
+            nat.call("u3d_affine_add_act_fwd", dev.index, _stream(dev), _p(z), _p(aff2), _p(residual), N, D * H * W, Cout, act,
+                     slope, _p(y))
             post_rec, ystats = (z, aff2), None
         elif act in (ACT_LEAKY, ACT_ELU):
             nat.call("u3d_act_fwd", dev.index, _stream(dev), _p(y), y.numel(), act, slope, _p(y))
@@ -1056,13 +1060,13 @@ class UNet3DEngine:
 
 @dataclass
 class ResRec:
-    """what one ResNetBlock (buildingblocks.py:230-288, order 'gcr') saves for backward"""
+    """what one ResNetBlock (buildingblocks.py:230-288, any native order) saves for backward"""
 
     name: str
     x_in: torch.Tensor           # block input (pooled tensor / network input / joined decoder tensor)
     r: torch.Tensor              # `residual` = conv1(x_in) (or x_in itself for nn.Identity)
-    rec2: ConvRec                # conv2: GroupNorm -> conv -> ReLU on r
-    rec3: ConvRec                # conv3: GroupNorm -> conv on conv2's output; rec3.y = ReLU(conv3 + r) = block output
+    rec2: ConvRec                # conv2: SingleConv(order) on r
+    rec3: ConvRec                # conv3: SingleConv(order without r/l/e) on conv2's output; rec3.y = f(conv3 + r) = block output
     conv1: Optional[torch.nn.Module]  # the 1x1x1 conv with bias, None for nn.Identity
     se: Optional[dict] = None    # ResNetBlockSE: gate tensors saved by _se_fwd (the block output is se["out"])
 
@@ -1097,6 +1101,16 @@ class ResUNetEngine(UNet3DEngine):
     residual come out of the 1x1x1 conv's / the joining kernel's epilogue.  The 1x1x1 convolutions and the transposed
     convolution run on the FP32 vector units (csrc/u3d_res.hip)."""
 
+    def __init__(self, model):
+        super().__init__(model)
+        # two non-linearities per block: conv2's own (from the order string, nn defaults: LeakyReLU 0.01) and the block's final
+        # one after `out += residual` (buildingblocks.py:270-275: LeakyReLU(0.1) if 'l', ELU if 'e', else ReLU).  self.act /
+        # self.slope / self.mask describe the BLOCK outputs (what pooling, joining and the head consume).
+        order = getattr(model, "layer_order", "gcr")
+        self.act2, self.slope2 = self.act, self.slope
+        self.act, self.slope = (ACT_LEAKY, 0.1) if "l" in order else ((ACT_ELU, 0.0) if "e" in order else (ACT_RELU, 0.0))
+        self.mask = 1 if self.act == ACT_RELU else 0
+
     def _virtual_weights(self):
         return set()  # summation joining: every 3x3x3 conv reads one real tensor
 
@@ -1125,13 +1139,17 @@ class ResUNetEngine(UNet3DEngine):
         src2 = VSrc(r)
         out2, st2 = self._single_conv_fwd(bm.conv2, name + ".c2", src2, (r_st, Cout, 1.0, None, 0, 0.0), pool, tape)
         src3 = VSrc(out2)
+        if st2 is None and not self.post_norm:  # conv2's epilogue sums do not describe its (LeakyReLU / ELU) output
+            st2 = self._stats_of(src3, None, None, pool, dev)[0]
         se_mod = getattr(bm, "se_module", None)
         y, y_st = self._single_conv_fwd(bm.conv3, name + ".c3", src3, (st2, Cout, 1.0, None, 0, 0.0), pool, tape,
                                         want_stats=se_mod is not None, residual=r, y_out=y_out if se_mod is None else None,
-                                        act=(ACT_RELU, 0.0))
+                                        act=(self.act, self.slope))
         se = None
         out = y
         if se_mod is not None:
+            if y_st is None:
+                y_st = self._stats_of(VSrc(y), None, None, pool, dev)[0]
             se = self._se_fwd(se_mod, y, y_st, dev)
             out = se["out"]
         if tape is not None:
@@ -1200,7 +1218,7 @@ class ResUNetEngine(UNet3DEngine):
             nat.call("u3d_cvt_f64_f32", dev.index, _stream(dev), _p(acc_ws), _p(gview(jw)), C + 1)
         m_ = torch.empty_like(y)
         nat.call("u3d_se_bwd_apply", dev.index, _stream(dev), _p(dout), _p(y), _p(se["gc"]), _p(se["a"]), _p(ws), _p(dls), _p(ds),
-                 N, V, C, mode, 1, _p(m_))
+                 N, V, C, mode, self.mask, _p(m_))
         return m_
 
     def forward(self, x: torch.Tensor, save: bool):
@@ -1300,11 +1318,17 @@ class ResUNetEngine(UNet3DEngine):
 
     # -- backward -----------------------------------------------------------------------------------
     def _block_bwd(self, cx, rec: ResRec, m_):
-        """m_ = dL/d(block output) already masked by (output > 0).  Returns dL/d(residual r)."""
+        """m_ = dL/d(block output); for ReLU blocks the producers already masked it by (output > 0) (self.mask), other
+        non-linearities are removed here through the block's pre-gate output y = f(sum).  Returns dL/d(residual r)."""
+        dev = cx.dev
         if rec.se is not None:
             m_ = self._se_bwd(cx, rec.se, m_)
+        self._unact(dev, m_, rec.rec3.y)  # -> gradient of (conv3 branch + residual)
         dg3, coef3 = self._conv_bwd(cx, rec.rec3, m_)
-        dz2 = self._plain_apply(cx, dg3, coef3, rec.rec3.src.t0, 1)  # conv2's output is post-ReLU
+        o2 = rec.rec3.src.t0
+        dz2 = self._plain_apply(cx, dg3, coef3, o2, 1 if self.act2 == ACT_RELU else 0)  # through conv2's non-linearity
+        if self.act2 in (ACT_LEAKY, ACT_ELU):
+            nat.call("u3d_act_bwd", dev.index, _stream(dev), _p(dz2), _p(o2), dz2.numel(), self.act2, self.slope2, _p(dz2))
         del dg3
         dg2, coef2 = self._conv_bwd(cx, rec.rec2, dz2)
         del dz2
@@ -1342,8 +1366,9 @@ class ResUNetEngine(UNet3DEngine):
 
         hacc = pool.take(Co * Cf + Co)
         dz = torch.empty_like(tape.head_x)
+        mk = self.mask  # ReLU blocks: the consumers' backward kernels mask by (block output > 0); else _block_bwd removes f
         nat.call("u3d_conv1x1_head_bwd", dev.index, _stream(dev), _p(dlogits), _p(tape.head_x), _p(fc.weight.detach()), N, V,
-                 Cf, Co, 1, _p(dz), _p(hacc))
+                 Cf, Co, mk, _p(dz), _p(hacc))
         iw, ib = self._pindex[id(fc.weight)], self._pindex[id(fc.bias)]
         assert self.poffs[ib] == self.poffs[iw] + Co * Cf
         nat.call("u3d_cvt_f64_f32", dev.index, _stream(dev), _p(hacc), _p(gview(iw)), Co * Cf + Co)
@@ -1372,9 +1397,9 @@ class ResUNetEngine(UNet3DEngine):
                          Nl, D1, H1, W1, Cl, Cs, _p(wsb), wsb.numel(), flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
                 dxl = torch.empty_like(xl)
                 nat.call("u3d_convtr3d_dgrad_t8", dev.index, _stream(dev), _p(dt8), _p(self._packed_convtr_t8(up.weight, 1, dev)),
-                         _p(xl), _p(dxl), Nl, D1, H1, W1, Cl, Cs, flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
+                         _p(xl) if mk else None, _p(dxl), Nl, D1, H1, W1, Cl, Cs, flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
                 del dt8
-                dz = dxl  # masked by (x_low > 0)
+                dz = dxl  # ReLU blocks: masked by (x_low > 0)
                 continue
             dt = torch.empty((Nl, Dt, Ht, Wt, Cs), dtype=_F32, device=dev)
             nat.call("u3d_nearest_sum_bwd", dev.index, _stream(dev), _p(dj), _p(lz), _p(ly), _p(lx), Nl, Ds, Hs, Ws, Dt, Ht, Wt,
@@ -1382,11 +1407,11 @@ class ResUNetEngine(UNet3DEngine):
             acc = pool.take(up.weight.numel())
             dxl = torch.empty_like(xl)
             nat.call("u3d_convtr3d_bwd", dev.index, _stream(dev), _p(dt), _p(xl), _p(up.weight.detach()), Nl, D1, H1, W1, Cl, Cs,
-                     1, _p(dxl), _p(acc), _p(self._packed_convtr(up.weight, 1, dev)), flops=4.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
+                     mk, _p(dxl), _p(acc), _p(self._packed_convtr(up.weight, 1, dev)), flops=4.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
             nat.call("u3d_cvt_f64_f32", dev.index, _stream(dev), _p(acc), _p(gview(self._pindex[id(up.weight)])),
                      up.weight.numel())
             del dt
-            dz = dxl  # masked by (x_low > 0): x_low is the post-ReLU output of the block below
+            dz = dxl  # ReLU blocks: masked by (x_low > 0), x_low being the output of the block below
 
         if self.grad_sync is not None:
             cx.join()
@@ -1424,7 +1449,7 @@ class ResUNetEngine(UNet3DEngine):
                 Ne, De, He, We, Ce = e_in.shape
                 out = torch.empty_like(e_in)
                 nat.call("u3d_maxpool2_bwd_merge", dev.index, _stream(dev), _p(dxin), _p(pooled), _p(argmax), None,
-                         _p(skip_grad.get(i - 1)), _p(e_in), Ne, De, He, We, Ce, 1, _p(out))
+                         _p(skip_grad.get(i - 1)), _p(e_in), Ne, De, He, We, Ce, mk, _p(out))
                 dz = out
             elif need_input_grad:
                 dx0 = dxin

@@ -65,8 +65,6 @@ class AbstractUNet(nn.Module):
         self.layer_order = layer_order
         if parse_order(layer_order) is None:
             reasons.append(f"layer_order '{layer_order}' (native: one GroupNorm before or after the conv + optional final r/l/e)")
-        elif basic_module in (ResNetBlock, ResNetBlockSE) and layer_order != "gcr":
-            reasons.append(f"layer_order '{layer_order}' with residual blocks")
         if conv_kernel_size != 3 or conv_padding != 1:
             reasons.append("conv kernel/padding other than 3/1")
         if pool_kernel_size != 2:

@@ -96,6 +96,88 @@ def test_unet3d_other_layer_orders_native(order, cfg, shape, loss_name, monkeypa
     assert torch.allclose(y, probs.detach(), atol=1e-6)
 
 
+@pytest.mark.parametrize("order", ["cge", "cgr", "gcl", "gce", "cgl", "gc", "cg"])
+@pytest.mark.parametrize("cls,cfg,shape,loss_name", [
+    ("ResidualUNet3D", dict(in_channels=1, out_channels=1, f_maps=[16, 32, 64], num_groups=8), (1, 1, 16, 32, 32), "bce_dice"),
+    ("ResidualUNet3D", dict(in_channels=2, out_channels=3, f_maps=[8, 16, 32], num_groups=4, final_sigmoid=False), (2, 2, 9, 13, 11), "probs_sum"),
+    ("ResidualUNetSE3D", dict(in_channels=2, out_channels=2, f_maps=[8, 16, 32], num_groups=4, final_sigmoid=False), (1, 2, 10, 12, 14), "probs_sum"),
+])
+def test_residual_nets_other_layer_orders_native(order, cls, cfg, shape, loss_name, monkeypatch):
+    """ResNetBlock / ResNetBlockSE in the orders other than 'gcr' (buildingblocks.py:245-275; 'cge' is the class default, the
+    reference's tests/test_models.py:26-44 builds 'cgr' blocks): GroupNorm before or after the convolutions, conv2's own
+    non-linearity (LeakyReLU 0.01) and the block's final one after `out += residual` (LeakyReLU 0.1 / ELU / ReLU)."""
+    import unet3d_oracle as orc
+    from pytorch3dunet_amd.unet3d import model as M
+
+    monkeypatch.setenv("U3D_STRICT", "1")
+    torch.manual_seed(37)
+    model = getattr(M, cls)(layer_order=order, **cfg)
+    assert model.native_supported, model._native_blockers
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if "groupnorm" in k:
+                p.add_(0.2 * torch.randn_like(p))
+    x = torch.randn(shape)
+    target = (torch.rand((shape[0], cfg["out_channels"]) + shape[2:]) > 0.5).float()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    G, fs = cfg["num_groups"], cfg.get("final_sigmoid", True)
+    p32, l32, v32, g32 = orc.forward_backward(sd, x, target, G, fs, True, loss_name, order=order)
+    _, _, _, g64 = orc.forward_backward({k: v.double() for k, v in sd.items()}, x.double(), target.double(), G, fs, True, loss_name,
+                                        order=order)
+    model = model.to(U.DEV).train()
+    n0 = nat.launch_count
+    xd = x.to(U.DEV).requires_grad_(True)
+    probs, logits = model(xd, return_logits=True)
+    loss = loss_by_name(loss_name, probs, logits, target.to(U.DEV))
+    model.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert nat.launch_count > n0
+    assert orc.rel_err(logits.detach().cpu(), l32) < REL and orc.rel_err(probs.detach().cpu(), p32) < REL
+    keys = list(g32)
+    ours = torch.cat([dict(model.named_parameters())[k].grad.detach().cpu().double().flatten() for k in keys])
+    r32 = torch.cat([g32[k].double().flatten() for k in keys])
+    r64 = torch.cat([g64[k].flatten() for k in keys])
+    e_ours, e_ref = ((ours - r64).norm() / r64.norm()).item(), ((r32 - r64).norm() / r64.norm()).item()
+    diag(test="orders_residual", cls=cls, order=order, shape=list(shape), ours_vs_fp64=e_ours, ref32_vs_fp64=e_ref)
+    assert e_ours <= max(REL, 3.0 * e_ref), (order, e_ours, e_ref)
+    # every parameter on its own (a wrong mask / slope in one branch would hide in the global norm)
+    for k in keys:
+        g = dict(model.named_parameters())[k].grad.detach().cpu().double()
+        assert ((g - g64[k]).norm() / g64[k].norm().clamp_min(1e-12)).item() < max(5e-3, 20 * e_ref), k
+    # the input gradient too (first block's conv1 / identity shortcut)
+    xr = x.clone().requires_grad_(True)
+    pr, lr = orc.model_forward({k: v for k, v in sd.items()}, xr, G, fs, True, order=order)
+    loss_by_name(loss_name, pr, lr, target).backward()
+    assert orc.rel_err(xd.grad.cpu(), xr.grad) < 5e-3
+    model.eval()
+    with torch.no_grad():
+        y = model(x.to(U.DEV))
+    assert torch.allclose(y, probs.detach(), atol=1e-6)
+
+
+@pytest.mark.parametrize("order", ["cge", "gcl"])
+def test_residual_orders_with_checkpointing_and_bf16(order, monkeypatch):
+    """the opt-in extras compose with the layer orders: encoder recomputation is bitwise the same as the stored-activation
+    run; bf16 operands stay within the bf16 tolerances of tests/test_gpu_bf16.py"""
+    from pytorch3dunet_amd.unet3d.model import ResidualUNet3D
+
+    monkeypatch.setenv("U3D_STRICT", "1")
+    cfg = dict(in_channels=1, out_channels=1, f_maps=[32, 64, 128], num_groups=8, layer_order=order)
+    x = torch.randn(1, 1, 16, 24, 24, generator=torch.Generator().manual_seed(5)).to(U.DEV)
+    target = (torch.rand(1, 1, 16, 24, 24, generator=torch.Generator().manual_seed(6)) > 0.5).float().to(U.DEV)
+    grads = {}
+    for tag, kw in (("plain", {}), ("ckpt", dict(checkpoint_encoders=True)), ("bf16", dict(compute_dtype="bf16"))):
+        torch.manual_seed(3)
+        model = ResidualUNet3D(**cfg, **kw).to(U.DEV).train()
+        probs, logits = model(x, return_logits=True)
+        loss_by_name("bce_dice", probs, logits, target).backward()
+        grads[tag] = torch.cat([p.grad.flatten() for p in model.parameters()]).double()
+    assert torch.equal(grads["plain"], grads["ckpt"])
+    e = ((grads["bf16"] - grads["plain"]).norm() / grads["plain"].norm()).item()
+    assert e < 0.15, e
+
+
 @pytest.mark.parametrize("order", ["gcr", "gce", "cgl"])
 @pytest.mark.parametrize("cfg,shape", [
     (dict(in_channels=1, out_channels=1, f_maps=16, num_levels=3, num_groups=8), (1, 1, 16, 32, 32)),

@@ -163,10 +163,12 @@ def test_gn_bwd_apply_add():
         assert U.relerr(out, ref) < 1e-6
 
 
+@pytest.mark.parametrize("signed", [False, True])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("N,C,size", [(2, 16, (4, 6, 5)), (1, 96, (3, 4, 4)), (1, 8, (2, 3, 3)), (2, 256, (2, 2, 3)), (1, 1024, (1, 2, 2))])
-def test_se_gates_forward_backward(mode, N, C, size):
-    """scSE / cSE / sSE (se.py:18-114) on a post-ReLU tensor: forward and every gradient against the torch modules"""
+def test_se_gates_forward_backward(mode, N, C, size, signed):
+    """scSE / cSE / sSE (se.py:18-114) on a block output — post-ReLU (>= 0), or signed as after ELU / LeakyReLU blocks, where
+    max(y*gc, y*a) picks the SMALLER gate for y < 0: forward and every gradient against the torch modules"""
     U, nat, VSrc, _maps, _p, _stream = _mods()
     from pytorch3dunet_amd.unet3d.se import ChannelSELayer3D, ChannelSpatialSELayer3D, SpatialSELayer3D
 
@@ -175,7 +177,7 @@ def test_se_gates_forward_backward(mode, N, C, size):
     cse = mod.cSE if mode == 0 else (mod if mode == 1 else None)
     sse = mod.sSE if mode == 0 else (mod if mode == 2 else None)
     pre = torch.randn(N, C, *size, requires_grad=True)
-    y = F.relu(pre)
+    y = F.elu(pre) if signed else F.relu(pre)
     out = mod(y)
     dout = torch.randn_like(out)
     out.backward(dout)
@@ -214,5 +216,8 @@ def test_se_gates_forward_backward(mode, N, C, size):
         assert U.relerr(acc_ws[:C].cpu().float(), sse.conv.weight.grad.view(C)) < 1e-4
         assert U.relerr(acc_ws[C:].cpu().float(), sse.conv.bias.grad) < 1e-4
     md = torch.empty_like(yd)
-    nat.call("u3d_se_bwd_apply", 0, _stream(U.DEV), _p(dd), _p(yd), _p(gc), _p(a), _p(ws), _p(dls), _p(ds), N, V, C, mode, 1, _p(md))
+    nat.call("u3d_se_bwd_apply", 0, _stream(U.DEV), _p(dd), _p(yd), _p(gc), _p(a), _p(ws), _p(dls), _p(ds), N, V, C, mode,
+             0 if signed else 1, _p(md))
+    if signed:  # the block removes its own non-linearity afterwards (engine._block_bwd)
+        nat.call("u3d_act_bwd", 0, _stream(U.DEV), _p(md), _p(yd), md.numel(), 3, 0.0, _p(md))
     assert U.relerr(U.ncdhw(md), pre.grad) < 1e-4

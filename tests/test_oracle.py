@@ -180,6 +180,27 @@ def test_ordered_oracle_matches_live_reference(order):
 
 
 @pytest.mark.skipif(not reference_available(), reason="/root/reference only exists in the build container")
+@pytest.mark.parametrize("name", ["ResidualUNet3D", "ResidualUNetSE3D"])
+@pytest.mark.parametrize("order", ["cge", "cgr", "gcl", "gce", "cgl", "gc", "cg"])
+def test_ordered_residual_oracle_matches_live_reference(name, order):
+    """ResNetBlock in the orders other than 'gcr' (buildingblocks.py:245-275: 'cge' is the class default, the reference's own
+    tests/test_models.py:26-44 builds 'cgr' blocks; the block's final LeakyReLU has slope 0.1, conv2's the nn default 0.01)"""
+    ref = import_reference()
+    cfg = dict(name=name, in_channels=2, out_channels=2, f_maps=[8, 16, 32], num_groups=4, layer_order=order, final_sigmoid=False)
+    torch.manual_seed(13)
+    model = ref.get_model(dict(cfg))
+    x = torch.randn(1, 2, 8, 12, 12)
+    target = (torch.rand(1, 2, 8, 12, 12) > 0.5).float()
+    probs_r, logits_r = model(x, return_logits=True)
+    ((probs_r * target).sum() + 0.5 * (logits_r * logits_r).mean()).backward()
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    probs, logits, _, grads = orc.forward_backward(sd, x, target, 4, False, True, "probs_sum", order=order)
+    assert orc.rel_err(logits, logits_r.detach()) < 1e-6 and orc.rel_err(probs, probs_r.detach()) < 1e-6
+    for k, p in model.named_parameters():
+        assert orc.rel_err(grads[k], p.grad) < 2e-5, k
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference only exists in the build container")
 def test_port_and_live_reference_same_speed():
     """bench.py's cpu_baseline times the oracle (kind "port": /root/reference does not travel to the GPU box).  Here both run
     side by side on BASELINE config 1's shape: identical numerics (1e-6) and the same throughput within noise — the port is a
