@@ -429,6 +429,18 @@ int u3d_affine_add_act_fwd(int device, u3d_stream_t stream, const float* z, cons
                            int64_t V, int C, int mode, float slope, float* out);
 int u3d_pair_stats(int device, u3d_stream_t stream, const float* a, const float* b, int N, int64_t V, int C, double* stats);
 
+/* ---- F.interpolate(mode='trilinear' | 'area') to the skip's size (InterpolateUpsampling, buildingblocks.py:598-614; ATen
+ * upsample_trilinear3d align_corners=False / adaptive_avg_pool3d): separable, <= 2 source samples per output index and
+ * dimension.  Per-dimension host tables (engine.resample_tables_host, ATen's float32 formulas): idx int32[2*n_out] source
+ * indices, wt float[2*n_out] weights, rng int32[2*n_in] = [lo,hi) outputs touching each input.  x (N,D1,H1,W1,C) ->
+ * out (N,D,H,W,C); bwd = the adjoint as a fixed-order gather (no atomics): dx (N,D1,H1,W1,C) from dout (N,D,H,W,C). */
+int u3d_resample2_fwd(int device, u3d_stream_t stream, const float* x, const int32_t* idx_z, const int32_t* idx_y,
+                      const int32_t* idx_x, const float* wt_z, const float* wt_y, const float* wt_x, int N, int D1, int H1, int W1,
+                      int D, int H, int W, int C, float* out);
+int u3d_resample2_bwd(int device, u3d_stream_t stream, const float* dout, const int32_t* rng_z, const int32_t* rng_y,
+                      const int32_t* rng_x, const int32_t* idx_z, const int32_t* idx_y, const int32_t* idx_x, const float* wt_z,
+                      const float* wt_y, const float* wt_x, int N, int D1, int H1, int W1, int D, int H, int W, int C, float* dx);
+
 /* ---- layout: NCDHW <-> NDHWC for multi-channel model inputs ------------------------------------ */
 int u3d_ncdhw_to_ndhwc(int device, u3d_stream_t stream, const float* src, float* dst, int N, int C, int64_t V);
 int u3d_ndhwc_to_ncdhw(int device, u3d_stream_t stream, const float* src, float* dst, int N, int C, int64_t V);

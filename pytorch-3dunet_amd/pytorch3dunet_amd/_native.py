@@ -244,6 +244,8 @@ _PROTOS = {
     "u3d_act_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "u3d_affine_act_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_float, c_void_p]),
     "u3d_affine_add_act_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_float, c_void_p]),
+    "u3d_resample2_fwd": (c_int, [c_int, c_void_p] + [c_void_p] * 7 + [c_int] * 8 + [c_void_p]),
+    "u3d_resample2_bwd": (c_int, [c_int, c_void_p] + [c_void_p] * 10 + [c_int] * 8 + [c_void_p]),
     "u3d_pair_stats": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
     "u3d_cvt_f64_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64]),
     "u3d_ncdhw_to_ndhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64]),

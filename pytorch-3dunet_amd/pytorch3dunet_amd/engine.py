@@ -131,6 +131,51 @@ def unstash_tape(skel, saved, params):
     return _walk(skel, lambda r: params[r.i] if r.param else saved[r.i])
 
 
+def resample_tables_host(mode: str, n_in: int, n_out: int):
+    """Per-dimension tables of F.interpolate(mode='trilinear' | 'area') for one (n_in -> n_out >= n_in) axis, computed with
+    ATen's own float32 formulas (UpSample.h area_pixel_compute_source_index, align_corners=False, scale = in/out because
+    the reference passes `size`; AdaptiveAveragePooling start/end indices): idx (n_out,2) int32 source samples, wt (n_out,2)
+    float32 weights, rng (n_in,2) int32 = [lo, hi) outputs touching each input (the adjoint gathers over them)."""
+    assert n_out >= n_in >= 1, "decoders only upsample"
+    o = torch.arange(n_out)
+    if mode == "trilinear":
+        scale = torch.tensor(float(n_in), dtype=torch.float32) / torch.tensor(float(n_out), dtype=torch.float32)
+        src = (scale * (o.to(torch.float32) + 0.5) - 0.5).clamp_min(0.0)
+        i0 = src.to(torch.int64)
+        i1 = i0 + (i0 < n_in - 1).to(torch.int64)
+        w1 = src - i0.to(torch.float32)
+        w0 = 1.0 - w1
+    elif mode == "area":
+        start = (o * n_in) // n_out
+        end = ((o + 1) * n_in + n_out - 1) // n_out
+        ln = end - start
+        assert int(ln.max()) <= 2 and int(ln.min()) >= 1
+        i0, i1 = start, end - 1
+        w0 = torch.where(ln == 1, torch.tensor(1.0), torch.tensor(0.5))
+        w1 = torch.where(ln == 1, torch.tensor(0.0), torch.tensor(0.5))
+    else:
+        raise ValueError(mode)
+    idx = torch.stack((i0, i1), dim=1).to(torch.int32).contiguous()
+    wt = torch.stack((w0, w1), dim=1).to(torch.float32).contiguous()
+    rng = torch.zeros((n_in, 2), dtype=torch.int32)
+    for i in range(n_in):
+        hit = ((i0 == i) | (i1 == i)).nonzero().flatten()
+        if hit.numel():
+            rng[i, 0], rng[i, 1] = int(hit[0]), int(hit[-1]) + 1
+    return idx, wt, rng
+
+
+_RESAMPLE_CACHE: dict = {}
+
+
+def _resample_tables(dev: torch.device, mode: str, n_in: int, n_out: int):
+    key = (str(dev), mode, n_in, n_out)
+    t = _RESAMPLE_CACHE.get(key)
+    if t is None:
+        t = _RESAMPLE_CACHE[key] = tuple(a.to(dev) for a in resample_tables_host(mode, n_in, n_out))
+    return t
+
+
 class VSrc:
     """A (virtual) NDHWC activation: full-res tensor t0 (N,D,H,W,C0) [+ low-res t1 (N,D1,H1,W1,C1) read through
     nearest maps = the never-materialised torch.cat((skip, interpolate(x)), dim=1)]."""
@@ -353,6 +398,9 @@ class UNet3DEngine:
             bm = dec.basic_module
             self.dec.append((bm.SingleConv1, bm.SingleConv2))
             self.dec_up.append(getattr(getattr(dec.upsampling, "upsample", None), "conv_transposed", None))
+        # upsample='trilinear' / 'area' (buildingblocks.py:598-614): materialised by csrc/u3d_interp.hip, then a same-size concat
+        self.dec_interp = [getattr(dec.upsampling, "mode", None) if getattr(dec.upsampling, "mode", None) in ("trilinear", "area")
+                           else None for dec in model.decoders]
 
     # -- helpers ------------------------------------------------------------------------------------
     def _bf16_layer(self, Cin: int, Cout: int) -> bool:
@@ -542,7 +590,7 @@ class UNet3DEngine:
     def _subpixel_layers(self, size):
         """decoder first convs whose low-res input is upsampled by exactly 2 in every dimension at this input size:
         {id(weight): (C0, C1)} — per-call state, handed down as the `sub` argument"""
-        if not self.subpixel or any(ct is not None for ct in self.dec_up):
+        if not self.subpixel or any(ct is not None for ct in self.dec_up) or any(self.dec_interp):
             return {}  # (a transposed convolution yields 2n-1 voxels, resized to the skip: never an exact 2x replication)
         dims = [tuple(size)]
         for has_pool, _, _ in self.enc:
@@ -888,6 +936,18 @@ class UNet3DEngine:
                 if tape is not None:
                     tape.ups.append(UpRec(cur, ct.weight, None, tuple(t.shape[1:4])))
                 cur, cur_st = t, None
+            elif self.dec_interp[j] is not None:
+                # F.interpolate(mode='trilinear' | 'area') to the skip's size: a real tensor (2-tap separable gather), joined by
+                # a same-size virtual concat
+                Nl, D1, H1, W1, Cl = cur.shape
+                _, Ds, Hs, Ws, _ = sk.shape
+                tabs = [_resample_tables(dev, self.dec_interp[j], a, b) for a, b in ((D1, Ds), (H1, Hs), (W1, Ws))]
+                up = torch.empty((Nl, Ds, Hs, Ws, Cl), dtype=_F32, device=dev)
+                nat.call("u3d_resample2_fwd", dev.index, _stream(dev), _p(cur), _p(tabs[0][0]), _p(tabs[1][0]), _p(tabs[2][0]),
+                         _p(tabs[0][1]), _p(tabs[1][1]), _p(tabs[2][1]), Nl, D1, H1, W1, Ds, Hs, Ws, Cl, _p(up))
+                if tape is not None:
+                    tape.ups.append(UpRec(cur, None, tabs, (Ds, Hs, Ws)))
+                cur, cur_st = up, None
             src = VSrc(sk, cur)  # skip channels first (buildingblocks.py:491)
             y1, s1 = self._single_conv_fwd(c1, f"dec{j}.c1", src, stats_of(src, sk_st, cur_st, pool, dev), pool, tape,
                                            sub=sub)
@@ -989,7 +1049,7 @@ class UNet3DEngine:
                 lz, ly, lx = src.los
                 nat.call("u3d_gn_bwd_apply_up", dev.index, _stream(dev), _p(dg1), Ct, C0, _p(src.t1), C1, _p(coef1), Ct, src.N,
                          src.D, src.H, src.W, src.D1, src.H1, src.W1, _p(lz), _p(ly), _p(lx),
-                         0 if self.dec_up[j] is not None else mk, _p(dzl))
+                         0 if (self.dec_up[j] is not None or self.dec_interp[j] is not None) else mk, _p(dzl))
             del dg1
             if self.dec_up[j] is not None:
                 # dzl is the gradient of the transposed convolution's (linear) output: its two gradients, with the non-linearity
@@ -1005,6 +1065,20 @@ class UNet3DEngine:
                 nat.call("u3d_cvt_f64_f32", dev.index, _stream(dev), _p(acc), _p(gview(self._pindex[id(up.weight)])),
                          up.weight.numel())
                 self._unact(dev, dxl, xl)
+                dzl = dxl
+            elif self.dec_interp[j] is not None:
+                # dzl is the gradient of the interpolated (linear) tensor: the adjoint of the gather, then the non-linearity of
+                # the tensor that was upsampled
+                up = tape.ups[j]
+                xl = up.x_low
+                Nl, D1, H1, W1, Cl = xl.shape
+                Ds, Hs, Ws = up.tdims
+                tz, ty, tx = up.los
+                dxl = torch.empty_like(xl)
+                nat.call("u3d_resample2_bwd", dev.index, _stream(dev), _p(dzl), _p(tz[2]), _p(ty[2]), _p(tx[2]), _p(tz[0]), _p(ty[0]),
+                         _p(tx[0]), _p(tz[1]), _p(ty[1]), _p(tx[1]), Nl, D1, H1, W1, Ds, Hs, Ws, Cl, _p(dxl))
+                if self.act != ACT_NONE:
+                    nat.call("u3d_act_bwd", dev.index, _stream(dev), _p(dxl), _p(xl), dxl.numel(), self.act, self.slope, _p(dxl))
                 dzl = dxl
             else:
                 self._unact(dev, dzl, src.t1)

@@ -190,6 +190,7 @@ class InterpolateUpsampling(AbstractUpsampling):
 
     def __init__(self, mode="nearest"):
         super().__init__(partial(self._interpolate, mode=mode))
+        self.mode = mode  # read by the native executor (plain attribute: no parameters, the state_dict is unchanged)
 
     @staticmethod
     def _interpolate(x, size, mode):

@@ -69,7 +69,7 @@ class AbstractUNet(nn.Module):
             reasons.append("conv kernel/padding other than 3/1")
         if pool_kernel_size != 2:
             reasons.append("pool_kernel_size != 2")
-        if basic_module is DoubleConv and upsample not in ("default", "nearest", "deconv"):
+        if basic_module is DoubleConv and upsample not in ("default", "nearest", "deconv", "trilinear", "area"):
             reasons.append(f"upsample '{upsample}'")
         if basic_module in (ResNetBlock, ResNetBlockSE) and upsample != "default":
             # an EXPLICIT 'deconv' keeps concat joining and a 1x1x1 conv deep->shallow in the block (buildingblocks.py:441-468:

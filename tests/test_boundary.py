@@ -255,3 +255,24 @@ def test_tape_stash_roundtrip_keeps_structure_and_references_parameters_by_posit
     r = t2.convs[0]
     assert r.src.t0 is a and r.src.t1 is b and r.conv_w is eng.params[2] and r.gn_w is eng.params[0] and r.name == "enc0.c1"
     assert r.src.maps[0] is t.convs[0].src.maps[0] and t2.pools[0][1] is b and t2.dims == (1, 1, 2, 2, 2)
+
+
+@pytest.mark.parametrize("mode", ["trilinear", "area"])
+@pytest.mark.parametrize("n_in,n_out", [(4, 8), (4, 9), (5, 11), (1, 2), (7, 7), (6, 13)])
+def test_resample_tables_reproduce_f_interpolate(mode, n_in, n_out):
+    """the host tables of csrc/u3d_interp.hip (engine.resample_tables_host: <= 2 source samples per output index, ATen's float32
+    index formulas) applied as a dense matrix equal F.interpolate along one axis, and the adjoint ranges cover every use"""
+    import torch.nn.functional as F
+    from pytorch3dunet_amd.engine import resample_tables_host
+
+    idx, wt, rng = resample_tables_host(mode, n_in, n_out)
+    M = torch.zeros(n_out, n_in, dtype=torch.float64)
+    for o in range(n_out):
+        for a in range(2):
+            M[o, idx[o, a]] += float(wt[o, a])
+    x = torch.randn(1, 1, n_in, 1, 1, dtype=torch.float64)
+    ref = F.interpolate(x, size=(n_out, 1, 1), mode=mode).flatten()
+    assert torch.allclose(M @ x.flatten(), ref, atol=1e-6)
+    for i in range(n_in):
+        used = M[:, i].nonzero().flatten()
+        assert used.numel() > 0 and int(rng[i, 0]) <= int(used[0]) and int(used[-1]) < int(rng[i, 1])

@@ -201,6 +201,50 @@ def test_ordered_residual_oracle_matches_live_reference(name, order):
 
 
 @pytest.mark.skipif(not reference_available(), reason="/root/reference only exists in the build container")
+@pytest.mark.parametrize("mode", ["trilinear", "area"])
+def test_interpolating_oracle_matches_live_reference(mode):
+    """upsample: trilinear / area (InterpolateUpsampling, buildingblocks.py:598-614) on a ragged size"""
+    ref = import_reference()
+    cfg = dict(name="UNet3D", in_channels=2, out_channels=2, f_maps=[8, 16, 32], num_groups=4, upsample=mode, final_sigmoid=False)
+    torch.manual_seed(17)
+    model = ref.get_model(dict(cfg))
+    x = torch.randn(1, 2, 9, 13, 12)
+    target = (torch.rand(1, 2, 9, 13, 12) > 0.5).float()
+    probs_r, logits_r = model(x, return_logits=True)
+    ((probs_r * target).sum() + 0.5 * (logits_r * logits_r).mean()).backward()
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    probs, logits, _, grads = orc.forward_backward(sd, x, target, 4, False, True, "probs_sum", upsample=mode)
+    assert orc.rel_err(logits, logits_r.detach()) < 1e-6 and orc.rel_err(probs, probs_r.detach()) < 1e-6
+    for k, p in model.named_parameters():
+        assert orc.rel_err(grads[k], p.grad) < 2e-5, k
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference only exists in the build container")
+def test_reference_upsample_modes_that_cannot_run_on_3d_models():
+    """What `upsample` values the REFERENCE itself can execute for 3-D nets (probed on the imported reference, CPU): the drop-in's
+    native coverage claim for row a6 is made against this list.  DoubleConv nets: default/nearest, trilinear, area, deconv run;
+    linear / bilinear / bicubic raise inside F.interpolate on 5-D tensors; 'none' / None fail at torch.cat (the pooled and the
+    skip tensor differ in size).  Residual nets: only 'default' and an explicit 'deconv' run — every InterpolateUpsampling
+    mode keeps concat joining but builds the block for summed channels (buildingblocks.py:441-468) and fails in conv1."""
+    ref = import_reference()
+    x = torch.randn(1, 1, 8, 8, 8)
+
+    def runs(name, mode):
+        try:
+            m = ref.get_model(dict(name=name, in_channels=1, out_channels=1, f_maps=[8, 16], num_groups=4, upsample=mode))
+            with torch.no_grad():
+                m(x)
+            return True
+        except (NotImplementedError, RuntimeError):
+            return False
+
+    assert [m for m in ("default", "nearest", "trilinear", "area", "deconv", "linear", "bilinear", "bicubic", "none", None)
+            if runs("UNet3D", m)] == ["default", "nearest", "trilinear", "area", "deconv"]
+    assert [m for m in ("default", "nearest", "trilinear", "area", "deconv", "linear", "none")
+            if runs("ResidualUNet3D", m)] == ["default", "deconv"]
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference only exists in the build container")
 def test_port_and_live_reference_same_speed():
     """bench.py's cpu_baseline times the oracle (kind "port": /root/reference does not travel to the GPU box).  Here both run
     side by side on BASELINE config 1's shape: identical numerics (1e-6) and the same throughput within noise — the port is a
