@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the HIP-event per-kernel timing")
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="per-GPU batch (default = BASELINE config 2)")
+    ap.add_argument("--compute-dtype", default="fp32", choices=["fp32", "fp32_split"],
+                    help="arithmetic of the TIMED model (default fp32 = fp32 MFMA; fp32_split is reported as an extra leg anyway)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed-by-the-contract extra leg (fp32_split mode)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -147,7 +150,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     torch.manual_seed(0)  # identical initial weights on every rank (also broadcast below)
-    model = UNet3D(**MODEL_CFG).to(dev).train()
+    model = UNet3D(compute_dtype=args.compute_dtype, **MODEL_CFG).to(dev).train()
     sync = parallel.attach(model, force_single=True) if use_dist else None
     opt = torch.optim.Adam(model.parameters(), lr=2e-4, weight_decay=1e-5)  # 3DUnet_confocal_boundary/train_config.yml
     g = torch.Generator(device=dev).manual_seed(1000 + rank)  # per-rank synthetic shard
@@ -209,7 +212,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.compute_dtype == "fp32" else "f32 (3xbf16 operand split, 6 partial products, fp32 accumulate)",
             "data": "synthetic",
             # what torch.distributed actually saw: ranks, backend, gradient collectives issued per step by the engine hooks
             "ranks_seen": ({"world_size": dist.get_world_size(), "backend": dist.get_backend(),
@@ -258,6 +261,36 @@ def main():
                 "families": {k: {"calls": v["calls"], "ms_per_step": round(v["ms"] / args.steps, 3),
                                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None}
                              for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])},
+            }
+        if world == 1 and not use_dist and not args.no_extras and args.compute_dtype == "fp32":
+            # EXTRA leg, not the contract's `value`: the same step with the opt-in fp32_split convolutions (fp32 operands split
+            # exactly into three bf16 values, six partial products accumulated in fp32 on the bf16 MFMA pipe; weight gradients
+            # and the sub-pixel decoder kernels stay on the fp32 MFMA).  Same weights, same batch, same loss + Adam step.
+            torch.manual_seed(0)
+            model2 = UNet3D(compute_dtype="fp32_split", **MODEL_CFG).to(dev).train()
+            opt2 = torch.optim.Adam(model2.parameters(), lr=2e-4, weight_decay=1e-5)
+
+            def step2():
+                probs2, logits2 = model2(x, return_logits=True)
+                loss2 = criterion(logits2, target)
+                opt2.zero_grad(set_to_none=True)
+                loss2.backward()
+                opt2.step()
+                return loss2
+
+            for _ in range(args.warmup):
+                step2()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                loss2 = step2()
+            torch.cuda.synchronize()
+            el2 = time.perf_counter() - t1
+            out["extra_fp32_split"] = {
+                "value": round(B * args.steps / el2, 3), "unit": "patches/s", "ms_per_step": round(1000.0 * el2 / args.steps, 3),
+                "opt_in": "model key compute_dtype: fp32_split (or U3D_F32_SPLIT=1)", "final_loss": round(loss2.item(), 5),
+                "arithmetic": "fwd/dgrad 3x3x3 convs: 3xbf16 exact operand split, 6 bf16 MFMAs per fp32 multiply-add, fp32 "
+                              "accumulation; everything else as the default path",
             }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -379,6 +379,22 @@ int u3d_conv3d_bf16_ex(int device, u3d_stream_t stream, const float* x, const fl
                        int N, int D, int H, int W, int Cin, int Cout, int relu, double* out_stats, const float* gx,
                        double* gstats, const float* residual, float* workspace, long long workspace_floats);
 
+/* ---- opt-in "split fp32" convolutions: FP32 operands on the bf16 matrix pipe --------------------------------------------
+ * The same nn.Conv3d / data gradient as u3d_conv3d with FP32-grade results: every operand is split exactly into three bf16
+ * values (a = a_h + a_m + a_l) and the six partial products down to 2^-16 of a*b are accumulated in FP32 on
+ * v_mfma_f32_32x32x16_bf16 (16x the rate of the fp32 MFMA: 6/16 of its pipe time); the dropped terms are ~2^-23 relative, the
+ * size of one rounding of an fp32 accumulation (csrc/u3d_bf16.hip; measured against float64 next to u3d_conv3d in
+ * tests/test_gpu_f32s.py).  Arguments as u3d_conv3d_bf16_ex; packed_w from u3d_pack_weights_f32s
+ * (u3d_packed_weight_f32s_elems() 2-byte elements: three images), which can read a channel slice [ci_off, ci_off + Cin) of
+ * rows that are `ld` input channels wide (the skip half of a decoder's first convolution).  Workspace:
+ * u3d_conv3d_bf16_workspace_floats(). */
+long long u3d_packed_weight_f32s_elems(int Cin, int Cout, int mode);
+int u3d_pack_weights_f32s(int device, u3d_stream_t stream, const float* w, int Cout, int Cin, int mode, int ld, int ci_off,
+                          void* packed);
+int u3d_conv3d_f32s(int device, u3d_stream_t stream, const float* x, const float* affine, const void* packed_w, float* out, int N,
+                    int D, int H, int W, int Cin, int Cout, int relu, double* out_stats, const float* gx, double* gstats,
+                    const float* residual, float* workspace, long long workspace_floats);
+
 /* Weight gradient of the same convolution with bf16 operands / FP32 accumulation (autograd of trainer.py:245 for
  * buildingblocks.py:56): dw (Cout,Cin,3,3,3) fp32, reference layout, = sum over voxels of g(x)[v+tap] (x) dz[v] with
  * g = a*x + b zero padded.  Needs Cin % 32 == 0, Cout % 64 == 0 and a scratch buffer of

@@ -43,6 +43,7 @@ struct bf16_conv_params {
     const float* maskx;    // (N,D,H,W,K) or null: out = maskx > 0 ? out : 0 (ReLU mask of the tensor this gradient flows into)
     int ksplit;            // > 1: the channel reduction is split over `ksplit` blocks per (tile, channel block); raw partial
     float* ws;             //      sums go to ws[split][voxel][K] and splitk_bf16_reduce_kernel owns the epilogue
+    long long wpart;       // split-fp32 kernels: distance (in bf16x8 records) between the high / middle / low weight images
 };
 
 template <int ZW, int KS>
@@ -64,6 +65,103 @@ struct tile_geom {
     static constexpr int NPARTS = KS * KS;                // staging parts per chunk = (z tap, y tap) groups of KS taps
     static constexpr int PER_PART = (ITERS + NPARTS - 1) / NPARTS;
 };
+
+// Epilogue shared by the bf16-operand and the split-fp32 kernels: residual, ReLU, fp32 store, per-(n,channel) statistics (or, with
+// ksplit > 1, the raw partial sums of this block's chunk range).  `lds` is free for the block reduction when this runs.
+template <int NT, int ZW, int KS>
+__device__ __forceinline__ void conv_tile_epilogue(const bf16_conv_params& p, f32x16 (&acc)[2 * ZW][NT], char* lds, int n, int nb,
+                                                   int split, int z0, int y0, int x0, int t, int lane, int w) {
+    using G = tile_geom<ZW, KS>;
+    // ---- epilogue: residual, ReLU, store, per-(n,channel) statistics.  C/D layout of the 32x32 MFMA: column = lane & 31,
+    // row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5); with row -> (yy = row & 3, xx = row >> 2): yy = e & 3, xx = 2*(e >> 2) + (lane >> 5)
+    const int col = lane & 31, half = lane >> 5;
+    if (p.ksplit > 1) {
+        // raw partial sums of this chunk range; residual / ReLU / statistics happen in the fixed-order reduction
+        float* wsp = p.ws + (size_t)split * p.N * p.D * p.H * p.W * p.K;
+#pragma unroll
+        for (int m = 0; m < G::MT; ++m) {
+            const int z = z0 + w * ZW + (m >> 1);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int y = y0 + (m & 1) * 4 + (e & 3), xx = x0 + 2 * (e >> 2) + half;
+                if (z < p.D && y < p.H && xx < p.W) {
+                    const size_t vox = (((size_t)n * p.D + z) * p.H + y) * p.W + xx;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) wsp[vox * p.K + (size_t)(nb * NT + j) * 32 + col] = acc[m][j][e];
+                }
+            }
+        }
+        return;
+    }
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
+    const bool want_stats = p.out_stats != nullptr, want_g = p.gstats != nullptr;
+    const float* side = p.residual ? p.residual : (want_g ? p.gx : p.maskx);  // the one tensor the epilogue reads (exclusive)
+    // Addressing is hoisted: element e of an accumulator tile sits (e & 3) rows and 2*(e >> 2) voxels from the tile's first
+    // voxel, so one 64-bit base per (m, j) plus sixteen 32-bit offsets replaces a five-term index per element; tiles that lie
+    // wholly inside the volume (all but the ragged rim) skip the per-element bounds tests.
+    const int K = p.K, rowK = p.W * K;
+    const bool full = z0 + G::TZ <= p.D && y0 + 8 <= p.H && x0 + 8 <= p.W;
+    auto emit_tile = [&](auto FULL, int m, int j) {
+        const int z = z0 + w * ZW + (m >> 1), yb = y0 + (m & 1) * 4, xb = x0 + half;
+        const size_t base = ((((size_t)n * p.D + z) * p.H + yb) * p.W + xb) * K + (size_t)(nb * NT + j) * 32 + col;
+        float* yp = p.y + base;
+        const float* sp = side ? side + base : nullptr;
+        auto inside = [&](int e) { return FULL.value || (z < p.D && yb + (e & 3) < p.H && xb + 2 * (e >> 2) < p.W); };
+        f32x16 sv;  // all 16 side loads of this accumulator tile in flight before the first use
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            sv[e] = 0.f;
+            if (sp && inside(e)) sv[e] = sp[(e & 3) * rowK + (e >> 2) * 2 * K];
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (inside(e)) {
+                float v = acc[m][j][e];
+                if (p.residual) v += sv[e];
+                if (p.maskx && !(sv[e] > 0.f)) v = 0.f;
+                if (p.relu) v = fmaxf(v, 0.f);
+                yp[(e & 3) * rowK + (e >> 2) * 2 * K] = v;
+                if (want_stats) {
+                    s1[j] += v;
+                    s2[j] = fmaf(v, v, s2[j]);
+                } else if (want_g) {
+                    s1[j] += v;
+                    s2[j] = fmaf(v, sv[e], s2[j]);
+                }
+            }
+        }
+    };
+#pragma unroll
+    for (int m = 0; m < G::MT; ++m) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (full)
+                emit_tile(std::true_type{}, m, j);
+            else
+                emit_tile(std::false_type{}, m, j);
+        }
+    }
+    if (want_stats || want_g) {
+        // fixed-order block reduction through LDS (the halo buffers are free now), then one f64 atomic per (n, channel)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(lds);  // [8 = wave*2+half][NT*32][2]
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            red[((w * 2 + half) * NT * 32 + j * 32 + col) * 2 + 0] = s1[j];
+            red[((w * 2 + half) * NT * 32 + j * 32 + col) * 2 + 1] = s2[j];
+        }
+        __syncthreads();
+        if (t < NT * 32 * 2) {
+            double sum = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sum += (double)red[i * NT * 32 * 2 + t];
+            double* dst = (want_stats ? p.out_stats : p.gstats) + ((size_t)n * p.K + (size_t)nb * NT * 32) * 2;
+            u3d_atomic_add_f64(dst + t, sum);
+        }
+    }
+}
 
 template <int NT, int ZW, int KS, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_params p) {
@@ -222,95 +320,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
         }
     }
 
-    // ---- epilogue: residual, ReLU, store, per-(n,channel) statistics.  C/D layout of the 32x32 MFMA: column = lane & 31,
-    // row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5); with row -> (yy = row & 3, xx = row >> 2): yy = e & 3, xx = 2*(e >> 2) + (lane >> 5)
-    const int col = lane & 31, half = lane >> 5;
-    if (p.ksplit > 1) {
-        // raw partial sums of this chunk range; residual / ReLU / statistics happen in the fixed-order reduction
-        float* wsp = p.ws + (size_t)split * p.N * p.D * p.H * p.W * p.K;
-#pragma unroll
-        for (int m = 0; m < G::MT; ++m) {
-            const int z = z0 + w * ZW + (m >> 1);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int y = y0 + (m & 1) * 4 + (e & 3), xx = x0 + 2 * (e >> 2) + half;
-                if (z < p.D && y < p.H && xx < p.W) {
-                    const size_t vox = (((size_t)n * p.D + z) * p.H + y) * p.W + xx;
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) wsp[vox * p.K + (size_t)(nb * NT + j) * 32 + col] = acc[m][j][e];
-                }
-            }
-        }
-        return;
-    }
-    float s1[NT], s2[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
-    const bool want_stats = p.out_stats != nullptr, want_g = p.gstats != nullptr;
-    const float* side = p.residual ? p.residual : (want_g ? p.gx : p.maskx);  // the one tensor the epilogue reads (exclusive)
-    // Addressing is hoisted: element e of an accumulator tile sits (e & 3) rows and 2*(e >> 2) voxels from the tile's first
-    // voxel, so one 64-bit base per (m, j) plus sixteen 32-bit offsets replaces a five-term index per element; tiles that lie
-    // wholly inside the volume (all but the ragged rim) skip the per-element bounds tests.
-    const int K = p.K, rowK = p.W * K;
-    const bool full = z0 + G::TZ <= p.D && y0 + 8 <= p.H && x0 + 8 <= p.W;
-    auto emit_tile = [&](auto FULL, int m, int j) {
-        const int z = z0 + w * ZW + (m >> 1), yb = y0 + (m & 1) * 4, xb = x0 + half;
-        const size_t base = ((((size_t)n * p.D + z) * p.H + yb) * p.W + xb) * K + (size_t)(nb * NT + j) * 32 + col;
-        float* yp = p.y + base;
-        const float* sp = side ? side + base : nullptr;
-        auto inside = [&](int e) { return FULL.value || (z < p.D && yb + (e & 3) < p.H && xb + 2 * (e >> 2) < p.W); };
-        f32x16 sv;  // all 16 side loads of this accumulator tile in flight before the first use
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            sv[e] = 0.f;
-            if (sp && inside(e)) sv[e] = sp[(e & 3) * rowK + (e >> 2) * 2 * K];
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            if (inside(e)) {
-                float v = acc[m][j][e];
-                if (p.residual) v += sv[e];
-                if (p.maskx && !(sv[e] > 0.f)) v = 0.f;
-                if (p.relu) v = fmaxf(v, 0.f);
-                yp[(e & 3) * rowK + (e >> 2) * 2 * K] = v;
-                if (want_stats) {
-                    s1[j] += v;
-                    s2[j] = fmaf(v, v, s2[j]);
-                } else if (want_g) {
-                    s1[j] += v;
-                    s2[j] = fmaf(v, sv[e], s2[j]);
-                }
-            }
-        }
-    };
-#pragma unroll
-    for (int m = 0; m < G::MT; ++m) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            if (full)
-                emit_tile(std::true_type{}, m, j);
-            else
-                emit_tile(std::false_type{}, m, j);
-        }
-    }
-    if (want_stats || want_g) {
-        // fixed-order block reduction through LDS (the halo buffers are free now), then one f64 atomic per (n, channel)
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(lds);  // [8 = wave*2+half][NT*32][2]
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            red[((w * 2 + half) * NT * 32 + j * 32 + col) * 2 + 0] = s1[j];
-            red[((w * 2 + half) * NT * 32 + j * 32 + col) * 2 + 1] = s2[j];
-        }
-        __syncthreads();
-        if (t < NT * 32 * 2) {
-            double sum = 0.0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) sum += (double)red[i * NT * 32 * 2 + t];
-            double* dst = (want_stats ? p.out_stats : p.gstats) + ((size_t)n * p.K + (size_t)nb * NT * 32) * 2;
-            u3d_atomic_add_f64(dst + t, sum);
-        }
-    }
+    conv_tile_epilogue<NT, ZW, KS>(p, acc, lds, n, nb, split, z0, y0, x0, t, lane, w);
 }
 
 // out = [relu](sum over splits (fixed order) + residual), statistics like the fused epilogue.
@@ -983,4 +993,321 @@ extern "C" int u3d_convtr3d_wgrad_t8(int device, u3d_stream_t stream, const floa
                        q.S, Cl, Cs, dw);
     U3D_LAUNCH_CHECK();
     return 0;
+}
+
+
+// =====================================================================================================================
+// FP32 convolution on the bf16 matrix pipe ("split fp32", opt-in: compute_dtype 'fp32_split').
+//
+// On gfx950 v_mfma_f32_32x32x16_bf16 delivers 16x the multiply-adds per cycle of v_mfma_f32_32x32x2_f32.  An fp32 value splits
+// EXACTLY into three bf16 values, a = a_h + a_m + a_l (8 + 8 + 8 mantissa bits; a_h = bf16(a), a_m = bf16(a - a_h),
+// a_l = bf16(a - a_h - a_m), every subtraction exact), each bf16 x bf16 product is exact in fp32, and the products whose
+// relative weight is >= 2^-16 of a*b are
+//     a_h*b_h, a_h*b_m, a_m*b_h, a_h*b_l, a_l*b_h, a_m*b_m        (dropped: a_m*b_l, a_l*b_m ~2^-24, a_l*b_l ~2^-32),
+// i.e. SIX bf16 MFMAs with FP32 accumulation reproduce the fp32 product to ~2^-23 relative — the size of ONE rounding of the
+// fp32 MFMA's own accumulation chain, far inside the reduction-order noise of any fp32 convolution (tests/test_gpu_f32s.py
+// measures both kernels against float64).  6/16 of the fp32 pipe time, and operand reuse comes for free: per (tap, 16-channel
+// chunk) a wave reads 3 x 2 A fragments and 3 x NT B fragments for 6 x 2 x NT MFMAs (0.5 loads per MFMA, the bf16 kernel above
+// needs 1.0), so neither the L1 (B) nor the LDS (A) path limits it.
+//
+// Same tiling as conv3d_bf16_kernel<NT, 1, 3>: block = 4 waves, tile 4 x 8 x 8 voxels x 32*NT channels, halo tile of a chunk in
+// LDS as [part h|m|l][channel half][hz][hy][hx pad 12][8 bf16] (6 planes, 69 KB: ONE buffer, two blocks per CU; while one block
+// restages, the other owns the MFMA pipe — a chunk is 27 x 12*NT MFMAs = 10-20 k cycles against ~3 k cycles of staging).
+// Activations are split while staging (GroupNorm affine in fp32 first, zero padding after it), weights by
+// u3d_pack_weights_f32s from the fp32 master copy into three images in pack_weights_bf16_kernel's layout.
+namespace {
+
+template <int NT, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void conv3d_f32s_kernel(const bf16_conv_params p) {
+    constexpr bool g_interleave_off = (ABL & 16) != 0;
+    using G = tile_geom<1, 3>;
+    constexpr int HY = G::HY, NTAPS = 27;
+    constexpr int PART = 2 * G::PLANE;  // bytes per (h | m | l) part = two channel-half planes
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int nblk = p.K / (32 * NT);
+    const int bid = u3d_xcd_remap(blockIdx.x, gridDim.x);
+    const int nb = bid % nblk;
+    int tile = bid / nblk;
+    const int split = tile % p.ksplit;
+    tile /= p.ksplit;
+    const int txi = tile % p.tx;
+    tile /= p.tx;
+    const int tyi = tile % p.ty;
+    tile /= p.ty;
+    const int tzi = tile % p.tz;
+    const int n = tile / p.tz;
+    const int z0 = tzi * G::TZ, y0 = tyi * 8, x0 = txi * 8;
+    const int nch_all = p.C >> 4;
+    const int cps = (nch_all + p.ksplit - 1) / p.ksplit;
+    const int cbeg = split * cps, nch = min(nch_all, cbeg + cps);
+    const int ntiles = p.K >> 5;
+    const int q = t & 3;
+    const int r = lane & 31, kh = lane >> 5;
+    const int a_base = kh * G::PLANE + ((w * HY + (r & 3)) * HS + (r >> 2)) * 16;
+
+    // staging descriptors (as in conv3d_bf16_kernel): element offset from the halo origin, validity bit, LDS byte offset
+    int rel[G::ITERS], lo[G::ITERS];
+    unsigned okmask = 0;
+    {
+        const int hv0 = t >> 2;
+        const int bz = hv0 / (G::HY * G::HX), brem = hv0 - bz * (G::HY * G::HX), by = brem / G::HX, bx = brem - by * G::HX;
+        const int rel_safe = ((p.H + 1) * p.W + 1) * p.C;  // the tile's first output voxel: always inside the volume
+#pragma unroll
+        for (int it = 0; it < G::ITERS; ++it) {
+            constexpr int HYX = G::HY * G::HX;
+            const int dz = (64 * it) / HYX, dy = ((64 * it) % HYX) / G::HX, dx = (64 * it) % G::HX;
+            int hx = bx + dx, hy = by + dy, hz = bz + dz;
+            if (hx >= G::HX) hx -= G::HX, hy += 1;
+            if (hy >= G::HY) hy -= G::HY, hz += 1;
+            const int z = z0 - 1 + hz, y = y0 - 1 + hy, xx = x0 - 1 + hx;
+            const bool ok = hz < G::HZ && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+            rel[it] = ok ? ((hz * p.H + hy) * p.W + hx) * p.C : rel_safe;
+            okmask |= (ok ? 1u : 0u) << it;
+            lo[it] = hz < G::HZ ? (q >> 1) * G::PLANE + ((hz * G::HY + hy) * HS + hx) * 16 + (q & 1) * 8 : G::PLANE - 64 + (t & 7) * 8;
+        }
+    }
+    const float* xo = p.x + ((((long long)n * p.D + (z0 - 1)) * p.H + (y0 - 1)) * p.W + (x0 - 1)) * (long long)p.C + 4 * q;
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][j][e] = 0.f;
+
+    // B fragments one tap ahead (a tap is 12*NT MFMAs = 384-768 pipe cycles, well above the L2 latency); the ring runs across
+    // chunk boundaries (the images are linear in (chunk, tap) and carry tail padding)
+    constexpr int BR = 3;  // B ring: fragments BR - 1 taps ahead (27 % BR == 0 keeps the slots aligned across chunks)
+    bf16x8 bq[BR][3][NT];
+    // the images are block-contiguous, [channel block nb][chunk][tap][j < NT][lane]: one running pointer per image, advanced by the
+    // compile-time tap stride, so that the unrolled loop needs no table of scalar offsets
+    const bf16x8* wq[3];
+#pragma unroll
+    for (int pb = 0; pb < 3; ++pb) wq[pb] = p.wpk + pb * p.wpart + ((size_t)nb * (nch_all * NTAPS + 2) + (size_t)cbeg * NTAPS) * (NT * 64);
+    auto load_b = [&](int slot) {  // the next tap's fragments; advances the pointers
+#pragma unroll
+        for (int pb = 0; pb < 3; ++pb) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bq[slot][pb][j] = wq[pb][j * 64 + lane];
+            if constexpr (!(ABL & 8)) wq[pb] += NT * 64;
+        }
+    };
+    if (cbeg < nch) {
+#pragma unroll
+        for (int d = 0; d < BR - 1; ++d) load_b(d);
+    }
+
+    for (int c = cbeg; c < nch; ++c) {
+        // ---- stage chunk c: fp32 -> affine -> (h, m, l) bf16 planes
+        if (c > cbeg) {
+            __syncthreads();  // everyone is done reading the previous chunk
+            // The bf16 MFMA rounds its accumulation toward -infinity (measured: tools/f32s_error_probe.py — a drift linear in
+            // the number of accumulations, which sums over millions of voxels do not average out).  The weight images carry
+            // the sign (-1)^chunk and the accumulator is negated between chunks (exact), so that the drift alternates in sign
+            // and cancels: result = (-1)^(last chunk) * acc.
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[m][j][e] = -acc[m][j][e];
+        }
+        if (!(ABL & 1) || c == cbeg) {
+            f32x4 ga, gb;
+            u3d_load_affine(p.affine, n, p.C, (c << 4) + 4 * q, true, ga, gb);
+            f32x4 v[G::ITERS];
+#pragma unroll
+            for (int it = 0; it < G::ITERS; ++it) v[it] = *reinterpret_cast<const f32x4*>(xo + rel[it] + (c << 4));
+#pragma unroll
+            for (int it = 0; it < G::ITERS; ++it) {
+                const bool ok = (okmask >> it) & 1u;
+                bf16x4 oh, om, ol;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g = ok ? fmaf(v[it][e], ga[e], gb[e]) : 0.f;
+                    const __bf16 h = (__bf16)g;
+                    const float r1 = g - (float)h;
+                    const __bf16 mm = (__bf16)r1;
+                    oh[e] = h, om[e] = mm, ol[e] = (__bf16)(r1 - (float)mm);
+                }
+                *reinterpret_cast<bf16x4*>(lds + lo[it]) = oh;
+                *reinterpret_cast<bf16x4*>(lds + PART + lo[it]) = om;
+                *reinterpret_cast<bf16x4*>(lds + 2 * PART + lo[it]) = ol;
+            }
+        }
+        __syncthreads();
+        bf16x8 aq[2][3][2] = {};
+        auto load_a = [&](int slot, int tap) {
+            const int tzz = tap / 9, tyy = (tap / 3) % 3, txx = tap % 3;
+#pragma unroll
+            for (int pa = 0; pa < 3; ++pa)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    aq[slot][pa][m] = *reinterpret_cast<const bf16x8*>(lds + pa * PART + a_base + ((tzz * HY + (m * 4 + tyy)) * HS + txx) * 16);
+        };
+        load_a(0, 0);
+#pragma unroll
+        for (int tap = 0; tap < NTAPS; ++tap) {
+            const int cur = tap & 1, nxt = cur ^ 1;
+            if constexpr (!(ABL & 2)) load_b((tap + BR - 1) % BR);  // (the last taps fetch the next chunk's first ones, or the tail padding)
+            if (!(ABL & 4) && tap + 1 < NTAPS) load_a(nxt, tap + 1);
+            if (g_interleave_off) __builtin_amdgcn_sched_barrier(0);
+            // the six product classes, smallest first; consecutive MFMAs go to different accumulators
+#pragma unroll
+            for (int cls = 0; cls < 6; ++cls) {
+                constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[cur][PA[cls]][m], bq[tap % BR][PB[cls]][j], acc[m][j], 0, 0, 0);
+            }
+            if (!g_interleave_off) {
+                // a VMEM issue costs tens of cycles (MI355X_MICROARCH.md: ~60 cyc per 1 KiB load among MFMAs): spread the tap's
+                // prefetches between its MFMAs instead of a burst in front of them
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {  // next tap's A fragments first (needed soonest)
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                    __builtin_amdgcn_sched_group_barrier(0x008, NT, 0); // NT MFMA
+                }
+#pragma unroll
+                for (int i = 0; i < 3 * NT; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMA
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (nch > cbeg && ((nch - 1) & 1)) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[m][j][e] = -acc[m][j][e];
+    }
+    __syncthreads();  // the LDS tile is reused by the epilogue's block reduction
+    conv_tile_epilogue<NT, 1, 3>(p, acc, lds, n, nb, split, z0, y0, x0, t, lane, w);
+}
+
+// image part: 0 = bf16(w), 1 = bf16(w - h), 2 = bf16(w - h - m); source element (row = produced/contraction channel as in
+// pack_weights_bf16_kernel) read with row stride `ld` input channels and input-channel offset `ci_off` (channel slices of a
+// wider weight tensor: the skip half of a decoder's first convolution)
+__global__ void pack_weights_f32s_kernel(const float* __restrict__ w, int Cout, int Cin, int mode, int ld, int ci_off,
+                                         __bf16* __restrict__ out, long long per_part, long long total) {
+    const int Kc = mode == 0 ? Cin : Cout, Nc = mode == 0 ? Cout : Cin;
+    const int NT = Nc % 64 == 0 ? 2 : 1, nchunks = Kc >> 4;
+    // image [nb][chunk (+ one tap of tail padding per nb)][tap][j][lane][8]
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 7);
+        long long rest = i >> 3;
+        const int l = (int)(rest & 63);
+        rest >>= 6;
+        const int j = (int)(rest % NT);
+        rest /= NT;
+        const long long per_nb = (long long)nchunks * 27 + 2;
+        const int ct = (int)(rest % per_nb);  // chunk*27 + tap, or the padding slot
+        const int nb = (int)(rest / per_nb);
+        float v = 0.f;
+        if (ct < nchunks * 27) {
+            const int c = ct / 27, tap = ct - c * 27;
+            const int k = c * 16 + 8 * (l >> 5) + e, col = (nb * NT + j) * 32 + (l & 31);
+            if (mode == 0)
+                v = w[((size_t)col * ld + ci_off + k) * 27 + tap];
+            else
+                v = w[((size_t)k * ld + ci_off + col) * 27 + (26 - tap)];
+            if (c & 1) v = -v;  // sign (-1)^chunk: see the accumulator negation in conv3d_f32s_kernel
+        }
+        const __bf16 h = (__bf16)v;
+        const float r1 = v - (float)h;
+        const __bf16 m = (__bf16)r1;
+        out[i] = h;
+        out[per_part + i] = m;
+        out[2 * per_part + i] = (__bf16)(r1 - (float)m);
+    }
+}
+
+}  // namespace
+
+static long long f32s_part_elems(int Cin, int Cout, int mode) {
+    const int Kc = mode == 0 ? Cin : Cout, Nc = mode == 0 ? Cout : Cin;
+    if (Kc <= 0 || Nc <= 0 || Kc % 16 != 0 || Nc % 32 != 0) return 0;
+    return ((long long)(Kc / 16) * 27 + 2) * (Nc / 32) * 64 * 8;  // two taps of tail padding per channel block (prefetched, never used)
+}
+
+extern "C" long long u3d_packed_weight_f32s_elems(int Cin, int Cout, int mode) { return 3 * f32s_part_elems(Cin, Cout, mode); }
+
+extern "C" int u3d_pack_weights_f32s(int device, u3d_stream_t stream, const float* w, int Cout, int Cin, int mode, int ld,
+                                     int ci_off, void* packed) {
+    U3D_ENTER(device);
+    const long long per = f32s_part_elems(Cin, Cout, mode);
+    U3D_REQUIRE(w && packed && (mode == 0 || mode == 1) && per > 0 && ld >= Cin && ci_off >= 0 && ci_off + Cin <= ld,
+                "u3d_pack_weights_f32s: needs contraction channels %% 16 == 0, produced channels %% 32 == 0 (Cin %d, Cout %d) and a "
+                "channel slice inside the row (ld %d, offset %d)", Cin, Cout, ld, ci_off);
+    const long long total = per;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_weights_f32s_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, mode, ld,
+                       ci_off, reinterpret_cast<__bf16*>(packed), per, total);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int NT, int ABL = 0>
+static int launch_f32s(const bf16_conv_params& p, hipStream_t stream) {
+    using G = tile_geom<1, 3>;
+    bf16_conv_params q = p;
+    q.tz = (p.D + G::TZ - 1) / G::TZ;
+    q.ty = (p.H + 7) / 8;
+    q.tx = (p.W + 7) / 8;
+    const long long blocks = (long long)p.N * q.tz * q.ty * q.tx * (p.K / (32 * NT)) * p.ksplit;
+    if (blocks > 0x7fffffffLL) return u3d_set_err(U3D_EINVAL, "u3d_conv3d_f32s: grid too large");
+    const size_t shmem = 6 * (size_t)G::PLANE;
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_f32s_kernel<NT, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)shmem));
+    hipLaunchKernelGGL((conv3d_f32s_kernel<NT, ABL>), dim3((unsigned)blocks), dim3(256), shmem, stream, q);
+    U3D_LAUNCH_CHECK();
+    if (p.ksplit > 1) {
+        const long long V = (long long)p.D * p.H * p.W;
+        const int vper = 16;
+        hipLaunchKernelGGL(splitk_bf16_reduce_kernel, dim3((unsigned)((V + vper - 1) / vper), (unsigned)((p.K + 255) / 256), (unsigned)p.N),
+                           dim3(256), 0, stream, q, V, vper);
+        U3D_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int u3d_conv3d_f32s(int device, u3d_stream_t stream, const float* x, const float* affine, const void* packed_w, float* out,
+                               int N, int D, int H, int W, int C, int K, int relu, double* out_stats, const float* gx,
+                               double* gstats, const float* residual, float* workspace, long long workspace_floats) {
+    U3D_ENTER(device);
+    U3D_REQUIRE(x && packed_w && out && N > 0 && D > 0 && H > 0 && W > 0, "u3d_conv3d_f32s: bad argument");
+    U3D_REQUIRE(u3d_conv3d_bf16_supported(C, K), "u3d_conv3d_f32s: needs Cin %% 16 == 0 and Cout %% 32 == 0 (got %d, %d)", C, K);
+    U3D_REQUIRE(!(out_stats && gstats), "u3d_conv3d_f32s: out_stats and gstats are mutually exclusive");
+    U3D_REQUIRE(!gstats || gx, "u3d_conv3d_f32s: gstats needs gx");
+    U3D_REQUIRE(!(residual && gstats), "u3d_conv3d_f32s: residual and gx/gstats are mutually exclusive");
+    U3D_REQUIRE((((uintptr_t)x | (uintptr_t)packed_w | (uintptr_t)affine) & 15) == 0, "u3d_conv3d_f32s: 16-byte alignment");
+    bf16_conv_params p{x, affine, reinterpret_cast<const bf16x8*>(packed_w), out, residual, gx, out_stats, gstats,
+                       N, D, H, W, C, K, relu, 0, 0, 0, 1, nullptr, 1, nullptr, 0};
+    p.wpart = f32s_part_elems(C, K, 0) / 8;
+    const int ks = bf16_ksplit(N, D, H, W, C, K);
+    if (ks > 1 && workspace && workspace_floats >= (long long)ks * N * D * H * W * K) {
+        p.ksplit = ks;
+        p.ws = workspace;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (K % 64 == 0 && g_u3d_tune[6] >= 300) {  // TIMING-ONLY ablations (wrong results)
+        switch (g_u3d_tune[6] - 300) {
+            case 1: return launch_f32s<2, 1>(p, s);
+            case 2: return launch_f32s<2, 2>(p, s);
+            case 4: return launch_f32s<2, 4>(p, s);
+            case 7: return launch_f32s<2, 7>(p, s);
+            case 8: return launch_f32s<2, 8>(p, s);
+            case 16: return launch_f32s<2, 16>(p, s);
+        }
+    }
+    return K % 64 == 0 ? launch_f32s<2>(p, s) : launch_f32s<1>(p, s);
 }

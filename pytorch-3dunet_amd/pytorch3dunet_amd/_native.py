@@ -204,6 +204,13 @@ _PROTOS = {
     "u3d_bce_dice_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "u3d_conv3d_bf16_supported": (c_int, [c_int, c_int]),
     "u3d_packed_weight_bf16_elems": (c_int64, [c_int, c_int, c_int]),
+    "u3d_packed_weight_f32s_elems": (c_int64, [c_int, c_int, c_int]),
+    "u3d_pack_weights_f32s": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "u3d_conv3d_f32s": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                                                 c_int64],
+    ),
     "u3d_pack_weights_bf16": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "u3d_conv3d_bf16": (
         c_int,

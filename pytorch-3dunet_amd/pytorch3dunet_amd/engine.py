@@ -357,6 +357,10 @@ class UNet3DEngine:
         # encoder blocks in backward instead of keeping their intermediates.  Set through the model
         # (`compute_dtype: bf16`, `checkpoint_encoders: true` in the YAML's model section, or U3D_BF16=1 / U3D_CHECKPOINT=1).
         self.bf16 = bool(getattr(model, "compute_bf16", False))
+        # opt-in `compute_dtype: fp32_split`: FP32-grade convolutions on the bf16 matrix pipe — every fp32 operand split exactly
+        # into three bf16 values, six partial products per multiply accumulated in fp32 (csrc/u3d_bf16.hip, u3d_conv3d_f32s);
+        # forward and data gradients only, weight gradients stay on the fp32 MFMA kernels
+        self.split = bool(getattr(model, "compute_split", False)) and not self.bf16
         self.checkpoint_encoders = bool(getattr(model, "checkpoint_encoders", False))
         # id(conv weight) -> (C0, C1) of every decoder first conv (static); WHICH of them take the sub-pixel path depends on
         # the input size and is per-call state (`sub` argument / ConvRec.sub), never stored on the engine: forwards at
@@ -407,6 +411,31 @@ class UNet3DEngine:
         """forward AND data gradient of a (Cin -> Cout) 3x3x3 conv can run on the bf16 kernels (both directions need the
         contraction channels % 16 and the produced channels % 32)"""
         return self.bf16 and Cin % 32 == 0 and Cout % 32 == 0
+
+    def _split_fwd(self, Cin: int, Cout: int) -> bool:
+        return self.split and Cin % 16 == 0 and Cout % 32 == 0
+
+    def _split_dgrad(self, Cin: int, Cout: int) -> bool:
+        """data gradient of a (Cin -> Cout) conv: contraction over Cout, produces Cin channels"""
+        return self.split and Cout % 16 == 0 and Cin % 32 == 0
+
+    def _packed_f32s(self, w: torch.Tensor, mode: int, dev, Cin: Optional[int] = None, ci_off: int = 0) -> torch.Tensor:
+        """three-image (high / middle / low bf16) fragment image of an fp32 weight, or of its input-channel slice
+        [ci_off, ci_off + Cin) (u3d_pack_weights_f32s), cached per parameter version"""
+        Cout, Ct = w.shape[0], w.shape[1]
+        Cin = Ct if Cin is None else Cin
+        key = (id(w), 30 + mode, Cin, ci_off)
+        ver = (w._version, w.data_ptr())
+        hit = self._pack_cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        n = nat.get_lib().u3d_packed_weight_f32s_elems(Cin, Cout, mode)
+        assert n > 0
+        out = hit[1] if hit is not None and hit[1].numel() == n and hit[1].device == dev else torch.empty(
+            n, dtype=torch.bfloat16, device=dev)
+        nat.call("u3d_pack_weights_f32s", dev.index, _stream(dev), _p(w.detach()), Cout, Cin, mode, Ct, ci_off, _p(out))
+        self._pack_cache[key] = (ver, out)
+        return out
 
     def _packed_bf16(self, w: torch.Tensor, mode: int, dev) -> torch.Tensor:
         """bf16 fragment image of an fp32 master weight (u3d_pack_weights_bf16), cached per parameter version"""
@@ -675,10 +704,23 @@ class UNet3DEngine:
                      _p(self._pack_cache[(id(conv.weight), 12)][1]), _p(part), N, D1, H1, W1, C1, Cout, _p(kws), need,
                      flops=128.0 * C1 * Cout * N * D1 * H1 * W1)
             a0 = affine[:, :C0].contiguous()
-            s0 = VSrc(src.t0).struct(a0)
-            nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s0), _p(self._pack_cache[(id(conv.weight), 10)][1]),
-                     _p(y), N, D, H, W, Cout, relu, _p(ystats), None, None, _p(part), None, 0,
-                     flops=54.0 * C0 * Cout * N * D * H * W)
+            if self._split_fwd(C0, Cout):
+                nat.call("u3d_conv3d_f32s", dev.index, _stream(dev), _p(src.t0), _p(a0), _p(self._packed_f32s(conv.weight, 0, dev, C0, 0)),
+                         _p(y), N, D, H, W, C0, Cout, relu, _p(ystats), None, None, _p(part), None, 0,
+                         flops=54.0 * C0 * Cout * N * D * H * W)
+            else:
+                s0 = VSrc(src.t0).struct(a0)
+                nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s0), _p(self._pack_cache[(id(conv.weight), 10)][1]),
+                         _p(y), N, D, H, W, Cout, relu, _p(ystats), None, None, _p(part), None, 0,
+                         flops=54.0 * C0 * Cout * N * D * H * W)
+        elif src.t1 is None and self._split_fwd(Ctot, Cout):
+            # fp32 operands split into three bf16 values each, six partial products on the bf16 MFMA pipe (csrc/u3d_bf16.hip)
+            ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
+            need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(N, D, H, W, Ctot, Cout)
+            kws = torch.empty(need, dtype=_F32, device=dev) if need > 0 else None
+            nat.call("u3d_conv3d_f32s", dev.index, _stream(dev), _p(src.t0), _p(affine), _p(self._packed_f32s(conv.weight, 0, dev)),
+                     _p(y), N, D, H, W, Ctot, Cout, relu, _p(ystats), None, None, _p(conv_res), _p(kws), need,
+                     flops=54.0 * Ctot * Cout * N * D * H * W)
         elif src.t1 is None and self._bf16_layer(Ctot, Cout):
             # bf16 MFMA operands, fp32 accumulation / epilogue (csrc/u3d_bf16.hip)
             ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
@@ -797,15 +839,29 @@ class UNet3DEngine:
             dg0 = torch.empty((Nn, Dd, Hh, Ww, C0), dtype=_F32, device=dev)
             dlow = torch.empty_like(src.t1)
             gst0, gst1 = pool.take(Nn * C0 * 2), pool.take(Nn * C1 * 2)
-            s_x0 = VSrc(src.t0).struct()
-            nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s_dz), _p(self._packed_sub(rec, 11, dev)), _p(dg0),
-                     Nn, Dd, Hh, Ww, C0, 0, None, ctypes.byref(s_x0), _p(gst0), None, _p(ws), ws.numel(),
-                     flops=54.0 * C0 * Cout * Nn * Dd * Hh * Ww)
+            if self._split_dgrad(C0, Cout):
+                need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(Nn, Dd, Hh, Ww, Cout, C0)
+                kws = cx.ensure_ws(need) if need > 0 else None
+                nat.call("u3d_conv3d_f32s", dev.index, _stream(dev), _p(dz_), None, _p(self._packed_f32s(rec.conv_w, 1, dev, C0, 0)),
+                         _p(dg0), Nn, Dd, Hh, Ww, Cout, C0, 0, None, _p(src.t0), _p(gst0), None, _p(kws), need,
+                         flops=54.0 * C0 * Cout * Nn * Dd * Hh * Ww)
+            else:
+                s_x0 = VSrc(src.t0).struct()
+                nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s_dz), _p(self._packed_sub(rec, 11, dev)), _p(dg0),
+                         Nn, Dd, Hh, Ww, C0, 0, None, ctypes.byref(s_x0), _p(gst0), None, _p(ws), ws.numel(),
+                         flops=54.0 * C0 * Cout * Nn * Dd * Hh * Ww)
             nat.call("u3d_subpixel_conv_dgrad", dev.index, _stream(dev), _p(dz_), _p(self._packed_sub(rec, 13, dev)), _p(src.t1),
                      _p(dlow), _p(gst1), Nn, src.D1, src.H1, src.W1, C1, Cout,
                      flops=128.0 * C1 * Cout * Nn * src.D1 * src.H1 * src.W1)
             gst = torch.cat((gst0.view(Nn, C0, 2), gst1.view(Nn, C1, 2)), dim=1)
             dg = (dg0, dlow)
+        elif src.t1 is None and not rec.small and self._split_dgrad(src.C, Cout):
+            dg = torch.empty((Nn, Dd, Hh, Ww, src.C), dtype=_F32, device=dev)
+            gst = pool.take(Nn * src.C * 2)
+            need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(Nn, Dd, Hh, Ww, Cout, src.C)
+            kws = cx.ensure_ws(need) if need > 0 else None
+            nat.call("u3d_conv3d_f32s", dev.index, _stream(dev), _p(dz_), None, _p(self._packed_f32s(rec.conv_w, 1, dev)), _p(dg),
+                     Nn, Dd, Hh, Ww, Cout, src.C, 0, None, _p(src.t0), _p(gst), None, _p(kws), need, flops=flops)
         elif bf16:
             dg = torch.empty((Nn, Dd, Hh, Ww, src.C), dtype=_F32, device=dev)
             gst = pool.take(Nn * src.C * 2)

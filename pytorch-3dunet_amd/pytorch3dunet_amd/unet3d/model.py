@@ -80,10 +80,14 @@ class AbstractUNet(nn.Module):
         # opt-in extras of the native executor (extra keys of the YAML's model section are swallowed by the reference's **kwargs):
         # bf16 MFMA operands with fp32 accumulation / master weights, and recomputation of the encoder blocks in backward
         if compute_dtype is None:
-            compute_dtype = "bf16" if os.environ.get("U3D_BF16", "0") == "1" else "fp32"
-        if str(compute_dtype).lower() not in ("fp32", "float32", "bf16", "bfloat16"):
-            raise ValueError(f"compute_dtype must be 'fp32' or 'bf16', got {compute_dtype!r}")
+            compute_dtype = ("bf16" if os.environ.get("U3D_BF16", "0") == "1"
+                             else "fp32_split" if os.environ.get("U3D_F32_SPLIT", "0") == "1" else "fp32")
+        if str(compute_dtype).lower() not in ("fp32", "float32", "bf16", "bfloat16", "fp32_split"):
+            raise ValueError(f"compute_dtype must be 'fp32', 'fp32_split' or 'bf16', got {compute_dtype!r}")
         self.compute_bf16 = str(compute_dtype).lower() in ("bf16", "bfloat16")
+        # 'fp32_split': fp32-grade convolutions on the bf16 matrix pipe (three-way exact operand split, six partial products;
+        # engine.UNet3DEngine.split) — same tensors, same tolerances as 'fp32'
+        self.compute_split = str(compute_dtype).lower() == "fp32_split"
         if checkpoint_encoders is None:
             checkpoint_encoders = os.environ.get("U3D_CHECKPOINT", "0") == "1"
         self.checkpoint_encoders = bool(checkpoint_encoders)

@@ -1,0 +1,209 @@
+"""-m gpu: the opt-in "split fp32" convolutions (csrc/u3d_bf16.hip, u3d_conv3d_f32s): fp32 operands split exactly into three
+bf16 values, six partial products per multiply accumulated in fp32 on the bf16 MFMA pipe.  The claim under test is FP32-GRADE
+accuracy: both this kernel and the fp32-MFMA kernel (u3d_conv3d) are measured against a float64 convolution of the SAME fp32
+operands; the split kernel's error must be of the size of the fp32 kernel's own accumulation error (and orders of magnitude
+below bf16-operand arithmetic).  Tolerances are stated in units of the output's largest magnitude."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import gpu_utils as U
+from conftest import diag
+from pytorch3dunet_amd import _native as nat
+from pytorch3dunet_amd.engine import VSrc, _p, _stream
+
+pytestmark = pytest.mark.gpu
+
+
+def pack_f32s(w, mode, Cin=None, ld=None, ci_off=0):
+    Cout, Ct = w.shape[:2]
+    Cin = Ct if Cin is None else Cin
+    ld = Ct if ld is None else ld
+    n = nat.get_lib().u3d_packed_weight_f32s_elems(Cin, Cout, mode)
+    assert n > 0
+    out = torch.empty(n, dtype=torch.bfloat16, device=U.DEV)
+    wd = w.contiguous().to(U.DEV)
+    nat.call("u3d_pack_weights_f32s", 0, _stream(U.DEV), _p(wd), Cout, Cin, mode, ld, ci_off, _p(out))
+    return out
+
+
+def conv_f32s(x, wp, K, affine=None, relu=0, out_stats=None, gx=None, gstats=None, residual=None, split=False):
+    N, C, D, H, W = x.shape
+    xd = U.ndhwc(x)
+    y = torch.empty((N, D, H, W, K), dtype=torch.float32, device=U.DEV)
+    need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(N, D, H, W, C, K) if split else 0
+    ws = torch.empty(max(need, 4), device=U.DEV)
+    nat.call("u3d_conv3d_f32s", 0, _stream(U.DEV), _p(xd), _p(affine), _p(wp), _p(y), N, D, H, W, C, K, relu, _p(out_stats),
+             _p(gx), _p(gstats), _p(residual), _p(ws) if need else None, need)
+    torch.cuda.synchronize()
+    return U.ncdhw(y)
+
+
+def conv_f32_mfma(x, w, affine):
+    """the default fp32-MFMA kernel on the same operands"""
+    N, C, D, H, W = x.shape
+    K = w.shape[0]
+    xd = U.ndhwc(x)
+    wp = U.pack(w.to(U.DEV), 0)
+    s = VSrc(xd).struct(affine)
+    y = torch.empty((N, D, H, W, K), dtype=torch.float32, device=U.DEV)
+    need = nat.get_lib().u3d_conv3d_workspace_floats(N, D, H, W, C, K)
+    ws = torch.empty(max(need, 4), device=U.DEV)
+    nat.call("u3d_conv3d_ex", 0, _stream(U.DEV), ctypes.byref(s), _p(wp), _p(y), N, D, H, W, K, 0, None, None, None, None, _p(ws), need)
+    torch.cuda.synchronize()
+    return U.ncdhw(y)
+
+
+@pytest.mark.parametrize("shape,C,K", [
+    ((2, 9, 13, 17), 16, 32),     # ragged, one 32-channel n-tile
+    ((1, 16, 24, 24), 32, 64),    # 64 channels per block
+    ((1, 12, 20, 28), 48, 96),    # three chunks, 96 = 3 n-tiles of 32
+    ((1, 8, 16, 16), 128, 128),   # 8 chunks
+])
+def test_conv3d_f32s_forward_is_fp32_grade(shape, C, K):
+    N, D, H, W = shape
+    torch.manual_seed(1)
+    x = torch.randn(N, C, D, H, W) * (1.0 + torch.rand(N, C, 1, 1, 1) * 3.0)  # channel scales differ, like pre-GroupNorm data
+    w = torch.randn(K, C, 3, 3, 3) / (27 * C) ** 0.5
+    a = 1.0 + 0.3 * torch.randn(N, C)
+    b = 0.2 * torch.randn(N, C)
+    aff = torch.stack((a, b), dim=-1).contiguous().to(U.DEV)
+    # the conv input as the kernels form it: fp32 fma(x, a, b)
+    g32 = torch.addcmul(b.view(N, C, 1, 1, 1), x, a.view(N, C, 1, 1, 1))
+    exact = F.conv3d(g32.double(), w.double(), None, padding=1)
+    scale = exact.abs().max().item()
+    stats = torch.zeros((N, K, 2), dtype=torch.float64, device=U.DEV)
+    y = conv_f32s(x, pack_f32s(w, 0), K, affine=aff, relu=1, out_stats=stats)
+    y_mfma = conv_f32_mfma(x, w, aff).clamp_min(0)
+    ref = exact.clamp_min(0)
+    e_split = (y.double() - ref).abs().max().item() / scale
+    e_mfma = (y_mfma.double() - ref).abs().max().item() / scale
+    r_split = ((y.double() - ref).norm() / ref.norm()).item()
+    r_mfma = ((y_mfma.double() - ref).norm() / ref.norm()).item()
+    diag(test="f32s_fwd", shape=list(shape), C=C, K=K, max_split=e_split, max_f32mfma=e_mfma, l2_split=r_split, l2_f32mfma=r_mfma)
+    # fp32 grade: a few ulps of the output range (2^-24 = 6e-8) and within 2.5x of the fp32-MFMA kernel's own distance from the
+    # float64 result (measured: 0.8x at 16 channels to 1.5x at 48+; both include the affine's fma rounding differently from
+    # torch's addcmul by 1 ulp of an operand)
+    assert e_split < 3e-6 and r_split < 1e-6, (e_split, r_split)
+    assert r_split < 2.5 * r_mfma, (r_split, r_mfma)
+    st = stats.cpu()
+    assert torch.allclose(st[..., 0], y.double().sum(dim=(2, 3, 4)), rtol=1e-6, atol=1e-6 * y.numel() / (N * K) * scale)
+    assert torch.allclose(st[..., 1], (y.double() ** 2).sum(dim=(2, 3, 4)), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape,C,K", [((2, 9, 13, 17), 16, 32), ((1, 16, 24, 24), 64, 64)])
+def test_conv3d_f32s_data_gradient_sums_residual(shape, C, K):
+    N, D, H, W = shape
+    cin_f, cout_f = K, C
+    torch.manual_seed(2)
+    w = torch.randn(cout_f, cin_f, 3, 3, 3) / (27 * cin_f) ** 0.5
+    dz = torch.randn(N, cout_f, D, H, W)
+    xin = torch.randn(N, cin_f, D, H, W)
+    ref = F.conv_transpose3d(dz.double(), w.double(), None, padding=1)
+    scale = ref.abs().max().item()
+    gst = torch.zeros((N, cin_f, 2), dtype=torch.float64, device=U.DEV)
+    xin_d = U.ndhwc(xin)
+    wp = pack_f32s(w, 1)
+    dg = conv_f32s(dz, wp, cin_f, gx=xin_d, gstats=gst)
+    assert (dg.double() - ref).abs().max().item() < 2e-6 * scale
+    st = gst.cpu()
+    assert torch.allclose(st[..., 0], dg.double().sum(dim=(2, 3, 4)), rtol=1e-6, atol=1e-6 * dg.abs().sum().item() / (N * cin_f))
+    assert torch.allclose(st[..., 1], (dg.double() * xin.double()).sum(dim=(2, 3, 4)), rtol=1e-6, atol=1e-6 * dg.abs().sum().item() / (N * cin_f))
+    res = torch.randn(N, cin_f, D, H, W)
+    y = conv_f32s(dz, wp, cin_f, relu=1, residual=U.ndhwc(res))
+    assert (y.double() - (ref + res.double()).clamp_min(0)).abs().max().item() < 2e-6 * max(scale, 1.0)
+
+
+def test_conv3d_f32s_channel_slice_of_a_wider_weight():
+    """the skip half of a decoder's first convolution: input channels [0, C0) of a (K, C0 + C1, 3,3,3) weight"""
+    torch.manual_seed(3)
+    N, D, H, W, C0, C1, K = 1, 8, 12, 12, 32, 64, 32
+    x = torch.randn(N, C0, D, H, W)
+    w = torch.randn(K, C0 + C1, 3, 3, 3) / (27 * (C0 + C1)) ** 0.5
+    ref = F.conv3d(x.double(), w[:, :C0].double(), None, padding=1)
+    y = conv_f32s(x, pack_f32s(w, 0, Cin=C0, ld=C0 + C1, ci_off=0), K)
+    assert (y.double() - ref).abs().max().item() < 2e-6 * ref.abs().max().item()
+    # data gradient w.r.t. the slice: dz (K channels) -> (C0 channels)
+    dz = torch.randn(N, K, D, H, W)
+    refg = F.conv_transpose3d(dz.double(), w[:, :C0].double(), None, padding=1)
+    dg = conv_f32s(dz, pack_f32s(w, 1, Cin=C0, ld=C0 + C1, ci_off=0), C0)
+    assert (dg.double() - refg).abs().max().item() < 2e-6 * refg.abs().max().item()
+    # and an offset slice
+    x1 = torch.randn(N, C1, D, H, W)
+    ref1 = F.conv3d(x1.double(), w[:, C0:].double(), None, padding=1)
+    y1 = conv_f32s(x1, pack_f32s(w, 0, Cin=C1, ld=C0 + C1, ci_off=C0), K)
+    assert (y1.double() - ref1).abs().max().item() < 2e-6 * ref1.abs().max().item()
+
+
+@pytest.mark.parametrize("shape,C,K", [((1, 5, 10, 10), 256, 128), ((2, 4, 9, 7), 128, 64)])
+def test_conv3d_f32s_split_k(shape, C, K):
+    N, D, H, W = shape
+    assert nat.get_lib().u3d_conv3d_bf16_workspace_floats(N, D, H, W, C, K) > 0
+    torch.manual_seed(5)
+    x = torch.randn(N, C, D, H, W)
+    w = torch.randn(K, C, 3, 3, 3) / (27 * C) ** 0.5
+    ref = F.conv3d(x.double(), w.double(), None, padding=1).clamp_min(0)
+    wp = pack_f32s(w, 0)
+    y1 = conv_f32s(x, wp, K, relu=1, split=True)
+    y2 = conv_f32s(x, wp, K, relu=1, split=True)
+    assert torch.equal(y1, y2)
+    assert (y1.double() - ref).abs().max().item() < 5e-6 * ref.abs().max().item()  # 27 x 256 terms per output
+    y0 = conv_f32s(x, wp, K, relu=1, split=False)
+    assert (y0.double() - ref).abs().max().item() < 5e-6 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("cls,cfg,shape", [
+    ("UNet3D", dict(in_channels=1, out_channels=1, f_maps=32, num_groups=8), (2, 1, 16, 32, 32)),       # BASELINE config 2's model, small patch
+    ("ResidualUNet3D", dict(in_channels=1, out_channels=1, f_maps=[32, 64, 128], num_groups=8), (1, 1, 16, 24, 24)),
+    ("ResidualUNetSE3D", dict(in_channels=3, out_channels=2, f_maps=[32, 64, 128], num_groups=8, final_sigmoid=False), (1, 3, 12, 16, 20)),
+])
+def test_models_in_split_mode_hold_the_fp32_tolerances(cls, cfg, shape, monkeypatch):
+    """compute_dtype='fp32_split' end to end: the split kernels really run (EventProfiler sees u3d_conv3d_f32s), and logits / loss /
+    gradients meet the SAME gates as the default fp32 path in tests/test_gpu_model.py::test_model_matches_cpu_oracle — 1e-3 on the
+    outputs, gradient distance from float64 within max(1e-3, 3x the reference arithmetic's own distance)"""
+    import unet3d_oracle as orc
+    from conftest import loss_by_name
+    from pytorch3dunet_amd.unet3d import model as M
+
+    monkeypatch.setenv("U3D_STRICT", "1")
+    torch.manual_seed(7)
+    model = getattr(M, cls)(compute_dtype="fp32_split", **cfg)
+    assert model.compute_split and model.native_supported
+    x = torch.randn(shape)
+    loss_name = "bce_dice" if cfg.get("final_sigmoid", True) else "probs_sum"
+    target = (torch.rand((shape[0], cfg["out_channels"]) + shape[2:]) > 0.5).float()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    G, fs = cfg["num_groups"], cfg.get("final_sigmoid", True)
+    p32, l32, v32, g32 = orc.forward_backward(sd, x, target, G, fs, True, loss_name)
+    _, _, _, g64 = orc.forward_backward({k: v.double() for k, v in sd.items()}, x.double(), target.double(), G, fs, True, loss_name)
+    model = model.to(U.DEV).train()
+    prof = nat.EventProfiler()
+    nat.profiler = prof
+    try:
+        probs, logits = model(x.to(U.DEV), return_logits=True)
+        loss = loss_by_name(loss_name, probs, logits, target.to(U.DEV))
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        nat.profiler = None
+    assert prof.summary().get("u3d_conv3d_f32s", {"calls": 0})["calls"] >= 6
+    assert orc.rel_err(logits.detach().cpu(), l32) < 1e-3 and orc.rel_err(probs.detach().cpu(), p32) < 1e-3
+    assert abs(loss.item() - v32.item()) < 1e-3 * max(1.0, abs(v32.item()))
+    keys = list(g32)
+    ours = torch.cat([dict(model.named_parameters())[k].grad.detach().cpu().double().flatten() for k in keys])
+    r32 = torch.cat([g32[k].double().flatten() for k in keys])
+    r64 = torch.cat([g64[k].flatten() for k in keys])
+    e_ours, e_ref = ((ours - r64).norm() / r64.norm()).item(), ((r32 - r64).norm() / r64.norm()).item()
+    diag(test="f32s_model", cls=cls, shape=list(shape), ours_vs_fp64=e_ours, ref32_vs_fp64=e_ref,
+         logits_vs_ref32=orc.rel_err(logits.detach().cpu(), l32))
+    assert e_ours <= max(1e-3, 3.0 * e_ref), (e_ours, e_ref)
+    # against the default fp32 path on the same weights: fp32-grade agreement of the outputs
+    torch.manual_seed(7)
+    ref_model = getattr(M, cls)(**cfg)
+    ref_model.load_state_dict(sd)
+    ref_model = ref_model.to(U.DEV).train()
+    with torch.no_grad():
+        _, l_f32 = ref_model(x.to(U.DEV), return_logits=True)
+    assert orc.rel_err(logits.detach().cpu(), l_f32.cpu()) < 2e-5

@@ -88,6 +88,21 @@ def main():
             tot["f32"] += m32
             tot["bf16"] += m16
             tot["flops"] += flops
+            # the split-fp32 kernel (fp32-grade results on the bf16 pipe: 6 bf16 MFMAs per fp32 multiply-add)
+            n3 = lib.u3d_packed_weight_f32s_elems(C, C, mode)
+            wp3 = torch.empty(n3, dtype=torch.bfloat16, device=dev)
+            nat.call("u3d_pack_weights_f32s", 0, _stream(dev), _p(w), C, C, mode, C, 0, _p(wp3))
+            if mode == 0:
+                s3 = lambda: nat.call("u3d_conv3d_f32s", 0, _stream(dev), _p(x), _p(aff), _p(wp3), _p(y), N, D, H, W, C, C, 1,  # noqa: E731
+                                      _p(st), None, None, None, _p(ws16k), n16k)
+            else:
+                s3 = lambda: nat.call("u3d_conv3d_f32s", 0, _stream(dev), _p(x), None, _p(wp3), _p(y), N, D, H, W, C, C, 0,  # noqa: E731
+                                      None, _p(x), _p(st), None, _p(ws16k), n16k)
+            m3 = timeit(s3, args.iters)
+            tot["f32s"] = tot.get("f32s", 0.0) + m3
+            tot["f32_fd"] = tot.get("f32_fd", 0.0) + m32
+            print(f"L{lvl} {label} split-fp32 {m3:7.3f} ms ({flops / m3 / 1e9:6.1f} TF fp32-equivalent = {6 * flops / m3 / 1e9 / PEAK_BF16:.2f} "
+                  f"of bf16 peak executed)   vs fp32 MFMA {m32 / m3:4.2f}x", flush=True)
             # algorithmic HBM bytes: input + output once (fp32), + gx re-read for the data gradient
             hbm = (2 + (mode == 1)) * 4.0 * C * N * D * H * W
             print(f"L{lvl} {label} {C:4d}->{C:4d} @{D}x{H}x{W}: fp32 {m32:7.3f} ms ({flops / m32 / 1e9:6.1f} TF)   "
@@ -110,6 +125,8 @@ def main():
         print(f"L{lvl} wgrad {C:4d}->{C:4d} @{D}x{H}x{W}: fp32 {m32:7.3f} ms ({flops / m32 / 1e9:6.1f} TF)   "
               f"bf16 {m16:7.3f} ms ({flops / m16 / 1e9:6.1f} TF = {flops / m16 / 1e9 / PEAK_BF16:.2f} of bf16 peak; "
               f"{8.0 * C * N * D * H * W / m16 / 1e6:5.0f} GB/s algorithmic)   speed-up {m32 / m16:4.2f}x", flush=True)
+    if "f32s" in tot:
+        print(f"fwd+dgrad: fp32 MFMA {tot['f32_fd']:.2f} ms, split-fp32 {tot['f32s']:.2f} ms, speed-up {tot['f32_fd'] / tot['f32s']:.2f}x")
     print(f"sum: fp32 {tot['f32']:.2f} ms ({tot['flops'] / tot['f32'] / 1e9:.1f} TF), bf16 {tot['bf16']:.2f} ms "
           f"({tot['flops'] / tot['bf16'] / 1e9:.1f} TF), speed-up {tot['f32'] / tot['bf16']:.2f}x")
 
