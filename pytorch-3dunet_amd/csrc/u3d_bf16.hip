@@ -163,6 +163,8 @@ __device__ __forceinline__ void conv_tile_epilogue(const bf16_conv_params& p, f3
     }
 }
 
+// ABL: timing-only ablation bits that attributed the loop's cost (1 no B loads, 2 no A reads, 4 no staging, 8 no barrier; results
+// in DESIGN.md 4.7).  Only ABL = 0 is instantiated.
 template <int NT, int ZW, int KS, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_params p) {
     using G = tile_geom<ZW, KS>;
@@ -258,6 +260,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[m][j][e] = 0.f;
 
+    // (Spreading a tap's prefetches between its 4 MFMAs with sched_group_barrier — +8-12 % on the split-fp32 kernel below, whose taps
+    // carry 12-24 MFMAs — measured -2 % here.)
     // Software pipeline (hipcc's own schedule issues every load right before its use): B fragments BDIST taps ahead in a register
     // ring that runs across chunk boundaries, A fragments ADIST taps ahead (restarted per chunk: the LDS buffer changes), the next
     // chunk's halo items fetched at the start of a KS-tap part and written at its end; sched_barriers pin "issue the prefetches,
@@ -485,18 +489,6 @@ extern "C" int u3d_conv3d_bf16_ex(int device, u3d_stream_t stream, const float* 
     // left for the staging descriptors and the deeper rings; u3d_set_tuning key 7 = 2 selects them for A/B runs
     const bool zw2 = g_u3d_tune[7] == 2 && big >= 512 && D >= 8 && p.ksplit == 1;
     hipStream_t s = (hipStream_t)stream;
-    if (nt2 && g_u3d_tune[6] >= 200) {  // TIMING-ONLY ablations (results are wrong): which loop memory ops cost what
-        switch (g_u3d_tune[6] - 200) {
-            case 1: return launch_bf16<2, 1, 3, 1>(p, s);
-            case 2: return launch_bf16<2, 1, 3, 2>(p, s);
-            case 4: return launch_bf16<2, 1, 3, 4>(p, s);
-            case 8: return launch_bf16<2, 1, 3, 8>(p, s);
-            case 3: return launch_bf16<2, 1, 3, 3>(p, s);
-            case 12: return launch_bf16<2, 1, 3, 12>(p, s);
-            case 7: return launch_bf16<2, 1, 3, 7>(p, s);
-            case 15: return launch_bf16<2, 1, 3, 15>(p, s);
-        }
-    }
     if (nt2) return zw2 ? launch_bf16<2, 2, 3>(p, s) : launch_bf16<2, 1, 3>(p, s);
     return zw2 ? launch_bf16<1, 2, 3>(p, s) : launch_bf16<1, 1, 3>(p, s);
 }
@@ -1299,14 +1291,10 @@ extern "C" int u3d_conv3d_f32s(int device, u3d_stream_t stream, const float* x, 
         p.ws = workspace;
     }
     hipStream_t s = (hipStream_t)stream;
-    if (K % 64 == 0 && g_u3d_tune[6] >= 300) {  // TIMING-ONLY ablations (wrong results)
+    if (K % 64 == 0 && g_u3d_tune[6] >= 300) {  // TIMING-ONLY ablations (wrong results; DESIGN.md 4.9 quotes them)
         switch (g_u3d_tune[6] - 300) {
-            case 1: return launch_f32s<2, 1>(p, s);
-            case 2: return launch_f32s<2, 2>(p, s);
-            case 4: return launch_f32s<2, 4>(p, s);
-            case 7: return launch_f32s<2, 7>(p, s);
-            case 8: return launch_f32s<2, 8>(p, s);
-            case 16: return launch_f32s<2, 16>(p, s);
+            case 2: return launch_f32s<2, 2>(p, s);    // no B-fragment loads in the loop
+            case 16: return launch_f32s<2, 16>(p, s);  // prefetches as a burst in front of each tap's MFMAs
         }
     }
     return K % 64 == 0 ? launch_f32s<2>(p, s) : launch_f32s<1>(p, s);
