@@ -33,6 +33,24 @@ from ._native import U3DSrc
 _F32 = torch.float32
 
 
+_POISON = os.environ.get("U3D_POISON", "0") == "1"  # debugging: every scratch / output buffer starts as NaN (or 0xFF bytes), so that
+                                                     # a kernel reading memory nobody wrote shows up as NaN instead of stale values
+
+
+def _empty(*size, **kw):
+    t = torch.empty(*size, **kw)
+    if _POISON:
+        t.fill_(float("nan")) if t.is_floating_point() else t.fill_(-1 if t.dtype != torch.uint8 else 255)
+    return t
+
+
+def _empty_like(x, **kw):
+    t = torch.empty_like(x, **kw)
+    if _POISON:
+        t.fill_(float("nan")) if t.is_floating_point() else t.fill_(-1 if t.dtype != torch.uint8 else 255)
+    return t
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -224,15 +242,27 @@ ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU = 0, 1, 2, 3  # activation codes of inclu
 def parse_order(order: str):
     """The layer-order strings (buildingblocks.py:10-96) the executor runs natively -> (post_norm, act, slope), else None.
     Native: one GroupNorm + Conv3d, the GroupNorm before ('gc…': normalises the conv INPUT) or after the conv ('cg…': the
-    conv OUTPUT), optionally followed by ONE non-linearity at the end: ReLU 'r', LeakyReLU(0.01) 'l', ELU 'e'.  Everything
-    else (no norm -> conv with bias, BatchNorm 'b', dropout 'd'/'D', a non-linearity before the norm) runs the module tree."""
+    conv OUTPUT), optionally followed by ONE non-linearity at the end: ReLU 'r', LeakyReLU(0.01) 'l', ELU 'e' — or with the
+    non-linearity between conv and norm ('crg', the reference docstring's own example, 'clg', 'ceg': `act` is then NONE, the
+    layer output is the normalised tensor, and parse_inner names the inner non-linearity).  Everything else (no norm -> conv
+    with bias, BatchNorm 'b', dropout 'd'/'D') runs the module tree."""
     if not order or any(ch not in "gcrle" for ch in order) or order.count("c") != 1 or order.count("g") != 1:
         return None
     acts = [ch for ch in order if ch in "rle"]
+    if len(acts) == 1 and order == "c" + acts[0] + "g":
+        return True, ACT_NONE, 0.0
     if len(acts) > 1 or (acts and order[-1] != acts[0]):
         return None
     act = {"r": ACT_RELU, "l": ACT_LEAKY, "e": ACT_ELU}[acts[0]] if acts else ACT_NONE
     return order.index("g") > order.index("c"), act, (0.01 if act == ACT_LEAKY else 0.0)
+
+
+def parse_inner(order: str):
+    """(act, slope) of a non-linearity sitting BETWEEN the conv and a trailing GroupNorm ('crg' / 'clg' / 'ceg'), else NONE"""
+    if len(order) == 3 and order[0] == "c" and order[2] == "g" and order[1] in "rle":
+        a = {"r": ACT_RELU, "l": ACT_LEAKY, "e": ACT_ELU}[order[1]]
+        return a, (0.01 if a == ACT_LEAKY else 0.0)
+    return ACT_NONE, 0.0
 
 
 @dataclass
@@ -253,7 +283,7 @@ class ConvRec:
     small: bool = False  # ran through the small-Cin (first layer) kernels
     sub: Optional[tuple] = None  # (C0, C1): the upsampled half ran as a sub-pixel convolution (csrc/u3d_subpix.hip)
     pre_norm: bool = True        # GroupNorm on the conv input ('gc…'); False: `affine` is the identity table
-    post: Optional[tuple] = None  # post-norm order ('cg…'): (z = conv output, its GroupNorm affine table); y = f(a*z + b)
+    post: Optional[tuple] = None  # post-norm order ('cg…'): (z = [f_inner](conv output), its GroupNorm affine table, f_inner, slope); y = f(a*z + b)
 
 
 @dataclass
@@ -314,7 +344,7 @@ class _BwdCtx:
         """the shared scratch buffer, grown on demand (kernels already queued on this stream keep using the old block: the
         caching allocator only hands it out again to later work of the same stream)"""
         if self.ws.numel() < floats:
-            self.ws = torch.empty(int(floats), dtype=_F32, device=self.dev)
+            self.ws = _empty(int(floats), dtype=_F32, device=self.dev)
         return self.ws
 
     def side_stream(self, ws_floats):
@@ -327,7 +357,7 @@ class _BwdCtx:
         if self.ws_side is None or self.ws_side.numel() < ws_floats:
             if self.ws_side is not None:
                 self.join()  # the old workspace may still be in use on the side stream
-            self.ws_side = torch.empty(max(int(ws_floats), 4), dtype=_F32, device=self.dev)
+            self.ws_side = _empty(max(int(ws_floats), 4), dtype=_F32, device=self.dev)
         return self.side
 
     def join(self):
@@ -335,6 +365,9 @@ class _BwdCtx:
         if self.side_used:
             torch.cuda.current_stream(self.dev).wait_stream(self.side)
             self.side_used = False
+
+
+_ALWAYS_REPACK = os.environ.get("U3D_ALWAYS_REPACK", "0") == "1"
 
 
 class UNet3DEngine:
@@ -367,6 +400,7 @@ class UNet3DEngine:
         # different sizes, other threads and nn.DataParallel replicas must not see each other's choice
         self._sub_pairs: dict = {}
         self._lock = threading.RLock()  # host-side enqueue of one forward / backward at a time per engine
+        self._salt = 0  # advanced by every training forward: see _ver
         self._const: dict = {}
         # the model-wide layer order (every SingleConv of a DoubleConv net shares it): non-linearity of the layer outputs
         spec = parse_order(getattr(model, "layer_order", "gcr")) or (False, ACT_RELU, 0.0)
@@ -407,6 +441,17 @@ class UNet3DEngine:
                            else None for dec in model.decoders]
 
     # -- helpers ------------------------------------------------------------------------------------
+    def _ver(self, w: torch.Tensor):
+        """Cache key of a packed weight image.  Autograd's version counter sees optimizer steps, load_state_dict and every other
+        tracked in-place update, but NOT writes through `param.data` (EMA swaps, hand-written updates): a TRAINING forward
+        therefore always repacks (weights change every step anyway: `_salt` advances), an inference forward trusts version +
+        storage pointer — after `param.data` edits in eval mode call model.invalidate_native_caches() (or set U3D_ALWAYS_REPACK=1)."""
+        return (w._version, w.data_ptr(), self._salt)
+
+    def begin_forward(self, training: bool):
+        if training or _ALWAYS_REPACK:
+            self._salt += 1
+
     def _bf16_layer(self, Cin: int, Cout: int) -> bool:
         """forward AND data gradient of a (Cin -> Cout) 3x3x3 conv can run on the bf16 kernels (both directions need the
         contraction channels % 16 and the produced channels % 32)"""
@@ -425,13 +470,13 @@ class UNet3DEngine:
         Cout, Ct = w.shape[0], w.shape[1]
         Cin = Ct if Cin is None else Cin
         key = (id(w), 30 + mode, Cin, ci_off)
-        ver = (w._version, w.data_ptr())
+        ver = self._ver(w)
         hit = self._pack_cache.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
         n = nat.get_lib().u3d_packed_weight_f32s_elems(Cin, Cout, mode)
         assert n > 0
-        out = hit[1] if hit is not None and hit[1].numel() == n and hit[1].device == dev else torch.empty(
+        out = hit[1] if hit is not None and hit[1].numel() == n and hit[1].device == dev else _empty(
             n, dtype=torch.bfloat16, device=dev)
         nat.call("u3d_pack_weights_f32s", dev.index, _stream(dev), _p(w.detach()), Cout, Cin, mode, Ct, ci_off, _p(out))
         self._pack_cache[key] = (ver, out)
@@ -440,13 +485,13 @@ class UNet3DEngine:
     def _packed_bf16(self, w: torch.Tensor, mode: int, dev) -> torch.Tensor:
         """bf16 fragment image of an fp32 master weight (u3d_pack_weights_bf16), cached per parameter version"""
         key = (id(w), 20 + mode)
-        ver = (w._version, w.data_ptr())
+        ver = self._ver(w)
         hit = self._pack_cache.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
         Cout, Cin = w.shape[0], w.shape[1]
         n = nat.get_lib().u3d_packed_weight_bf16_elems(Cin, Cout, mode)
-        out = hit[1] if hit is not None and hit[1].numel() == n and hit[1].device == dev else torch.empty(
+        out = hit[1] if hit is not None and hit[1].numel() == n and hit[1].device == dev else _empty(
             n, dtype=torch.bfloat16, device=dev)
         nat.call("u3d_pack_weights_bf16", dev.index, _stream(dev), _p(w.detach()), Cout, Cin, mode, _p(out))
         self._pack_cache[key] = (ver, out)
@@ -455,16 +500,16 @@ class UNet3DEngine:
     def _packed_convtr(self, w: torch.Tensor, mode: int, dev) -> torch.Tensor:
         """[tap][Cin][Cout] (mode 0) / [tap][Cout][Cin] (mode 1) image of a ConvTranspose3d weight, cached per version"""
         key = (id(w), 10 + mode)
-        ver = (w._version, w.data_ptr())
+        ver = self._ver(w)
         hit = self._pack_cache.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
         Cin, Cout = w.shape[0], w.shape[1]
         if mode == 2:  # fragment image of the sub-pixel forward kernel
-            out = torch.empty(nat.get_lib().u3d_convtr3d_subpixel_packed_floats(Cin, Cout), dtype=_F32, device=dev)
+            out = _empty(nat.get_lib().u3d_convtr3d_subpixel_packed_floats(Cin, Cout), dtype=_F32, device=dev)
             nat.call("u3d_pack_convtr3d_subpixel", dev.index, _stream(dev), _p(w.detach()), Cin, Cout, _p(out))
         else:
-            out = torch.empty(27 * Cin * Cout, dtype=_F32, device=dev)
+            out = _empty(27 * Cin * Cout, dtype=_F32, device=dev)
             nat.call("u3d_pack_convtr_weights", dev.index, _stream(dev), _p(w.detach()), Cin, Cout, mode, _p(out))
         self._pack_cache[key] = (ver, out)
         return out
@@ -475,12 +520,12 @@ class UNet3DEngine:
 
     def _packed_convtr_t8(self, w: torch.Tensor, mode: int, dev) -> torch.Tensor:
         key = (id(w), 30 + mode)
-        ver = (w._version, w.data_ptr())
+        ver = self._ver(w)
         hit = self._pack_cache.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
         Cl, Cs = w.shape[0], w.shape[1]
-        out = torch.empty(nat.get_lib().u3d_convtr3d_t8_packed_elems(Cl, Cs, mode), dtype=torch.bfloat16, device=dev)
+        out = _empty(nat.get_lib().u3d_convtr3d_t8_packed_elems(Cl, Cs, mode), dtype=torch.bfloat16, device=dev)
         nat.call("u3d_pack_convtr3d_t8", dev.index, _stream(dev), _p(w.detach()), Cl, Cs, mode, _p(out))
         self._pack_cache[key] = (ver, out)
         return out
@@ -527,7 +572,7 @@ class UNet3DEngine:
                 wmodes = tuple(mm + 10 for mm in modes) + tuple(mm + 12 for mm in modes)
             for mode in wmodes:
                 hit = self._pack_cache.get((id(w), mode))
-                if hit is None or hit[0] != (w._version, w.data_ptr()):
+                if hit is None or hit[0] != self._ver(w):
                     stale.append((w, mode))
         if not stale:
             return
@@ -543,7 +588,7 @@ class UNet3DEngine:
             for i, (w, mode) in enumerate(stale):
                 wptr, Cin, cmode, cstride, n = self._pack_shape(w, mode)
                 hit = self._pack_cache.get((id(w), mode))
-                buf = hit[1] if hit is not None and hit[1].numel() == n and hit[1].device == dev else torch.empty(
+                buf = hit[1] if hit is not None and hit[1].numel() == n and hit[1].device == dev else _empty(
                     n, dtype=_F32, device=dev)
                 bufs.append(buf)
                 descs[i].w, descs[i].packed, descs[i].first = wptr, buf.data_ptr(), first
@@ -556,33 +601,33 @@ class UNet3DEngine:
         table, bufs, total = ent
         nat.call("u3d_pack_weights_batch", dev.index, _stream(dev), _p(table), len(stale), total)
         for (w, mode), buf in zip(stale, bufs):
-            self._pack_cache[(id(w), mode)] = ((w._version, w.data_ptr()), buf)
+            self._pack_cache[(id(w), mode)] = (self._ver(w), buf)
 
     def _packed_sub(self, rec: ConvRec, mode: int, dev) -> torch.Tensor:
         """packed image of a sub-pixel layer (modes 10..13); normally current from the forward's batch pack"""
         w = rec.conv_w
         hit = self._pack_cache.get((id(w), mode))
-        if hit is None or hit[0] != (w._version, w.data_ptr()):  # e.g. a no-grad forward packed only the forward images
+        if hit is None or hit[0] != self._ver(w):  # e.g. a no-grad forward packed only the forward images
             wptr, Cin, cmode, cstride, n = self._pack_shape(w, mode)
-            buf = torch.empty(n, dtype=_F32, device=dev)
+            buf = _empty(n, dtype=_F32, device=dev)
             desc = (nat.U3DPackDesc * 1)()
             desc[0].w, desc[0].packed, desc[0].first = wptr, buf.data_ptr(), 0
             desc[0].Cout, desc[0].Cin, desc[0].mode, desc[0].cin_stride = w.shape[0], Cin, cmode, cstride
             table = torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8).to(dev)
             nat.call("u3d_pack_weights_batch", dev.index, _stream(dev), _p(table), 1, n)
-            hit = ((w._version, w.data_ptr()), buf)
+            hit = (self._ver(w), buf)
             self._pack_cache[(id(w), mode)] = hit
         return hit[1]
 
     def _packed(self, w: torch.Tensor, mode: int, dev) -> torch.Tensor:
         key = (id(w), mode)
-        ver = (w._version, w.data_ptr())
+        ver = self._ver(w)
         hit = self._pack_cache.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
         Cout, Cin = w.shape[0], w.shape[1]
         n = nat.get_lib().u3d_packed_weight_floats(Cin, Cout, mode)
-        out = torch.empty(n, dtype=_F32, device=dev)
+        out = _empty(n, dtype=_F32, device=dev)
         nat.call("u3d_pack_weights", dev.index, _stream(dev), _p(w.detach()), Cout, Cin, mode, _p(out))
         self._pack_cache[key] = (ver, out)
         return out
@@ -666,25 +711,26 @@ class UNet3DEngine:
         Ctot, Cout, G = src.C, conv.out_channels, gn.num_groups
         post, act0, slope0 = parse_order(sc.order)
         act, slope = (act0, slope0) if act is None else act
+        inner, islope = parse_inner(sc.order)  # 'crg' family: non-linearity on the conv output BEFORE its GroupNorm
         assert conv.in_channels == Ctot and gn.num_channels == (Cout if post else Ctot)
-        relu = 1 if (act == ACT_RELU and not post) else 0
+        relu = 1 if ((act == ACT_RELU and not post) or inner == ACT_RELU) else 0
         # `out += residual` follows the block's last GroupNorm: inside the conv epilogue for pre-norm orders, in the
         # GroupNorm-apply pass for post-norm orders
         conv_res = None if post else residual
         # the conv epilogue's statistics describe the conv OUTPUT: they are the next GroupNorm's input only when nothing
         # else transforms it (ReLU is in the epilogue); a post-norm layer needs them for its own GroupNorm
-        want_stats = post or (want_stats and act in (ACT_NONE, ACT_RELU))
+        want_stats = (post and inner in (ACT_NONE, ACT_RELU)) or (not post and want_stats and act in (ACT_NONE, ACT_RELU))
         if post:
             affine, mean_rstd = self._identity_affine(N, Ctot, dev), None
         else:
             st0, C0, sc0, st1, C1, sc1 = st_in
-            affine = torch.empty((N, Ctot, 2), dtype=_F32, device=dev)
-            mean_rstd = torch.empty((N, G, 2), dtype=_F32, device=dev)
+            affine = _empty((N, Ctot, 2), dtype=_F32, device=dev)
+            mean_rstd = _empty((N, G, 2), dtype=_F32, device=dev)
             nat.call("u3d_gn_finalize", dev.index, _stream(dev), _p(st0), C0, sc0, _p(st1), C1, sc1, N, G,
                      float(D * H * W), _p(gn.weight.detach()), _p(gn.bias.detach()), float(gn.eps), _p(affine), _p(mean_rstd))
         # y_out: recomputation under activation checkpointing rewrites the (still alive) block output in place with the
         # bit-identical values instead of allocating a second copy
-        y = y_out if (y_out is not None and not post) else torch.empty((N, D, H, W, Cout), dtype=_F32, device=dev)
+        y = y_out if (y_out is not None and not post) else _empty((N, D, H, W, Cout), dtype=_F32, device=dev)
         small = self.small_cin and src.t1 is None and Ctot <= 4 and Cout <= 32 and residual is None
         if small:
             # first layer of the network: K = 27*Cin is too small for the MFMA tiling (csrc/u3d_smallc.hip)
@@ -696,10 +742,10 @@ class UNet3DEngine:
             # (8/27 of the multiply-adds), then the skip half, whose epilogue adds the partial sums before ReLU / statistics
             C0, C1 = sub[id(conv.weight)]
             ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
-            part = torch.empty((N, D, H, W, Cout), dtype=_F32, device=dev)
+            part = _empty((N, D, H, W, Cout), dtype=_F32, device=dev)
             D1, H1, W1 = D // 2, H // 2, W // 2
             need = nat.get_lib().u3d_subpixel_fwd_workspace_floats(N, D1, H1, W1, C1, Cout)  # split-K scratch, small levels only
-            kws = torch.empty(need, dtype=_F32, device=dev) if need > 0 else None
+            kws = _empty(need, dtype=_F32, device=dev) if need > 0 else None
             nat.call("u3d_subpixel_conv_fwd", dev.index, _stream(dev), _p(src.t1), _p(affine.view(-1)[2 * C0:]), Ctot * 2,
                      _p(self._pack_cache[(id(conv.weight), 12)][1]), _p(part), N, D1, H1, W1, C1, Cout, _p(kws), need,
                      flops=128.0 * C1 * Cout * N * D1 * H1 * W1)
@@ -717,7 +763,7 @@ class UNet3DEngine:
             # fp32 operands split into three bf16 values each, six partial products on the bf16 MFMA pipe (csrc/u3d_bf16.hip)
             ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
             need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(N, D, H, W, Ctot, Cout)
-            kws = torch.empty(need, dtype=_F32, device=dev) if need > 0 else None
+            kws = _empty(need, dtype=_F32, device=dev) if need > 0 else None
             nat.call("u3d_conv3d_f32s", dev.index, _stream(dev), _p(src.t0), _p(affine), _p(self._packed_f32s(conv.weight, 0, dev)),
                      _p(y), N, D, H, W, Ctot, Cout, relu, _p(ystats), None, None, _p(conv_res), _p(kws), need,
                      flops=54.0 * Ctot * Cout * N * D * H * W)
@@ -725,7 +771,7 @@ class UNet3DEngine:
             # bf16 MFMA operands, fp32 accumulation / epilogue (csrc/u3d_bf16.hip)
             ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
             need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(N, D, H, W, Ctot, Cout)  # split-K scratch at the bottom of the U
-            kws = torch.empty(need, dtype=_F32, device=dev) if need > 0 else None
+            kws = _empty(need, dtype=_F32, device=dev) if need > 0 else None
             nat.call("u3d_conv3d_bf16_ex", dev.index, _stream(dev), _p(src.t0), _p(affine), _p(self._packed_bf16(conv.weight, 0, dev)),
                      _p(y), N, D, H, W, Ctot, Cout, relu, _p(ystats), None, None, _p(conv_res), _p(kws), need,
                      flops=54.0 * Ctot * Cout * N * D * H * W)
@@ -735,23 +781,26 @@ class UNet3DEngine:
             s = src.struct(affine)
             # bottom-of-the-U shapes split the channel reduction over blocks through a scratch buffer (0 floats otherwise)
             need = nat.get_lib().u3d_conv3d_workspace_floats(N, D, H, W, Ctot, Cout)
-            kws = torch.empty(need, dtype=_F32, device=dev) if need > 0 else None
+            kws = _empty(need, dtype=_F32, device=dev) if need > 0 else None
             nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s), _p(wp), _p(y), N, D, H, W, Cout, relu,
                      _p(ystats), None, None, _p(conv_res), _p(kws), need, flops=54.0 * Ctot * Cout * N * D * H * W)
         post_rec = None
         if post:
-            # GroupNorm over the conv output z (statistics from the conv epilogue), then the non-linearity: y = f(a*z + b)
+            # GroupNorm over the conv output z (statistics from the conv epilogue), then the non-linearity: y = f(a*z + b);
+            # 'crg' family: z is already f_inner(conv) (ReLU in the epilogue, LeakyReLU / ELU in place here)
+            if inner in (ACT_LEAKY, ACT_ELU):
+                nat.call("u3d_act_fwd", dev.index, _stream(dev), _p(y), y.numel(), inner, islope, _p(y))
             z, zst = y, ystats
             if zst is None:
                 zst = self._stats_of(VSrc(z), None, None, pool, dev)[0]
-            aff2 = torch.empty((N, Cout, 2), dtype=_F32, device=dev)
-            mean_rstd = torch.empty((N, G, 2), dtype=_F32, device=dev)
+            aff2 = _empty((N, Cout, 2), dtype=_F32, device=dev)
+            mean_rstd = _empty((N, G, 2), dtype=_F32, device=dev)
             nat.call("u3d_gn_finalize", dev.index, _stream(dev), _p(zst), Cout, 1.0, None, 0, 0.0, N, G, float(D * H * W),
                      _p(gn.weight.detach()), _p(gn.bias.detach()), float(gn.eps), _p(aff2), _p(mean_rstd))
-            y = y_out if y_out is not None else torch.empty_like(z)
+            y = y_out if y_out is not None else _empty_like(z)
             nat.call("u3d_affine_add_act_fwd", dev.index, _stream(dev), _p(z), _p(aff2), _p(residual), N, D * H * W, Cout, act,
                      slope, _p(y))
-            post_rec, ystats = (z, aff2), None
+            post_rec, ystats = (z, aff2, inner, islope), None
         elif act in (ACT_LEAKY, ACT_ELU):
             nat.call("u3d_act_fwd", dev.index, _stream(dev), _p(y), y.numel(), act, slope, _p(y))
             ystats = None
@@ -774,14 +823,16 @@ class UNet3DEngine:
         if rec.post is not None:
             # post-norm layer: dz_ is the gradient w.r.t. n = a*z + b (the caller removed the non-linearity): GroupNorm backward
             # over the conv output z first — sums (sum dn, sum dn*z), parameter gradients, dz = p*dn + q*z + r
-            z, _ = rec.post
+            z, _, inner, islope = rec.post
             Vz = Dd * Hh * Ww
             gst2 = pool.take(Nn * Cout * 2)
             nat.call("u3d_pair_stats", dev.index, _stream(dev), _p(dz_), _p(z), Nn, Vz, Cout, _p(gst2))
-            coef2 = torch.empty((Nn, 3, Cout), dtype=_F32, device=dev)
+            coef2 = _empty((Nn, 3, Cout), dtype=_F32, device=dev)
             nat.call("u3d_gn_bwd_finalize", dev.index, _stream(dev), _p(gst2), _p(rec.mean_rstd), _p(rec.gn_w.detach()), Nn, Cout,
                      rec.G, float(Vz), _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef2))
-            dz_ = self._plain_apply(cx, dz_, coef2, z, 0)
+            dz_ = self._plain_apply(cx, dz_, coef2, z, 1 if inner == ACT_RELU else 0)  # ('crg': z = relu(conv), mask fused)
+            if inner in (ACT_LEAKY, ACT_ELU):
+                nat.call("u3d_act_bwd", dev.index, _stream(dev), _p(dz_), _p(z), dz_.numel(), inner, islope, _p(dz_))
         if self.debug is not None:
             self.debug[rec.name + ".dz"] = dz_.clone()
         if rec.small and not need_dg:
@@ -792,7 +843,7 @@ class UNet3DEngine:
                      flops=2 * 54.0 * src.C * Cout * Nn * Dd * Hh * Ww)
             if not rec.pre_norm:
                 return None, self._identity_coef(Nn, src.C, dev)
-            coef = torch.empty((Nn, 3, src.C), dtype=_F32, device=dev)
+            coef = _empty((Nn, 3, src.C), dtype=_F32, device=dev)
             nat.call("u3d_gn_bwd_finalize", dev.index, _stream(dev), _p(gst), _p(rec.mean_rstd), _p(rec.gn_w.detach()), Nn,
                      src.C, rec.G, float(Dd * Hh * Ww), _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef))
             return None, coef
@@ -836,8 +887,8 @@ class UNet3DEngine:
             # skip half at full resolution; upsampled half directly at LOW resolution (the children sum of the nearest
             # upsampling is folded into the 4x4x4-tap stride-2 gather).  dg = (dg_skip, dlow)
             C0, C1 = rec.sub
-            dg0 = torch.empty((Nn, Dd, Hh, Ww, C0), dtype=_F32, device=dev)
-            dlow = torch.empty_like(src.t1)
+            dg0 = _empty((Nn, Dd, Hh, Ww, C0), dtype=_F32, device=dev)
+            dlow = _empty_like(src.t1)
             gst0, gst1 = pool.take(Nn * C0 * 2), pool.take(Nn * C1 * 2)
             if self._split_dgrad(C0, Cout):
                 need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(Nn, Dd, Hh, Ww, Cout, C0)
@@ -856,14 +907,14 @@ class UNet3DEngine:
             gst = torch.cat((gst0.view(Nn, C0, 2), gst1.view(Nn, C1, 2)), dim=1)
             dg = (dg0, dlow)
         elif src.t1 is None and not rec.small and self._split_dgrad(src.C, Cout):
-            dg = torch.empty((Nn, Dd, Hh, Ww, src.C), dtype=_F32, device=dev)
+            dg = _empty((Nn, Dd, Hh, Ww, src.C), dtype=_F32, device=dev)
             gst = pool.take(Nn * src.C * 2)
             need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(Nn, Dd, Hh, Ww, Cout, src.C)
             kws = cx.ensure_ws(need) if need > 0 else None
             nat.call("u3d_conv3d_f32s", dev.index, _stream(dev), _p(dz_), None, _p(self._packed_f32s(rec.conv_w, 1, dev)), _p(dg),
                      Nn, Dd, Hh, Ww, Cout, src.C, 0, None, _p(src.t0), _p(gst), None, _p(kws), need, flops=flops)
         elif bf16:
-            dg = torch.empty((Nn, Dd, Hh, Ww, src.C), dtype=_F32, device=dev)
+            dg = _empty((Nn, Dd, Hh, Ww, src.C), dtype=_F32, device=dev)
             gst = pool.take(Nn * src.C * 2)
             need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(Nn, Dd, Hh, Ww, Cout, src.C)
             kws = cx.ensure_ws(need) if need > 0 else None
@@ -871,7 +922,7 @@ class UNet3DEngine:
                      Nn, Dd, Hh, Ww, Cout, src.C, 0, None, _p(src.t0), _p(gst), None, _p(kws), need, flops=flops)
         else:
             wpd = self._packed(rec.conv_w, 1, dev)
-            dg = torch.empty((Nn, Dd, Hh, Ww, src.C), dtype=_F32, device=dev)
+            dg = _empty((Nn, Dd, Hh, Ww, src.C), dtype=_F32, device=dev)
             gst = pool.take(Nn * src.C * 2)
             s_x = src.struct()
             nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s_dz), _p(wpd), _p(dg), Nn, Dd, Hh, Ww, src.C, 0, None,
@@ -880,7 +931,7 @@ class UNet3DEngine:
             self.debug[rec.name + ".dg"] = dg.clone()
         if not rec.pre_norm:
             return dg, self._identity_coef(Nn, src.C, dev)  # no GroupNorm on the conv input: dx = dg
-        coef = torch.empty((Nn, 3, src.C), dtype=_F32, device=dev)
+        coef = _empty((Nn, 3, src.C), dtype=_F32, device=dev)
         nat.call("u3d_gn_bwd_finalize", dev.index, _stream(dev), _p(gst), _p(rec.mean_rstd), _p(rec.gn_w.detach()), Nn, src.C,
                  rec.G, float(Dd * Hh * Ww), _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef))
         return dg, coef
@@ -888,7 +939,7 @@ class UNet3DEngine:
     def _plain_apply(self, cx, dg, coef, x, relu_mask, add=None):
         """GroupNorm backward, elementwise part: (p*dg + q*x + r [+ add]) * (relu_mask ? x > 0 : 1)"""
         dev = cx.dev
-        out = torch.empty_like(x)
+        out = _empty_like(x)
         Nn = x.shape[0]
         C = x.shape[-1]
         if add is None:
@@ -900,7 +951,7 @@ class UNet3DEngine:
         return out
 
     def _wgrad_workspace(self, tape, dev):
-        return torch.empty(max(self._wgrad_workspace_floats(tape.convs), 4), dtype=_F32, device=dev)
+        return _empty(max(self._wgrad_workspace_floats(tape.convs), 4), dtype=_F32, device=dev)
 
     def _layer_ws_floats(self, N, D, H, W, Cin, Cout, sub=None, small=False, virtual=False):
         """scratch floats one 3x3x3 layer's backward needs from the shared buffer, for the kernels it will actually run"""
@@ -937,7 +988,7 @@ class UNet3DEngine:
         if Cin == 1:
             x0 = x.view(N, D, H, W, 1)  # NCDHW == NDHWC when C == 1
         else:
-            x0 = torch.empty((N, D, H, W, Cin), dtype=_F32, device=dev)
+            x0 = _empty((N, D, H, W, Cin), dtype=_F32, device=dev)
             nat.call("u3d_ncdhw_to_ndhwc", dev.index, _stream(dev), _p(x), _p(x0), N, Cin, D * H * W)
         tape = Tape() if save else None
         if tape is not None:
@@ -958,8 +1009,8 @@ class UNet3DEngine:
         for i, (has_pool, c1, c2) in enumerate(self.enc):
             if has_pool:
                 Np, Dp, Hp, Wp, Cp = cur.shape
-                pooled = torch.empty((Np, Dp // 2, Hp // 2, Wp // 2, Cp), dtype=_F32, device=dev)
-                argmax = torch.empty(pooled.shape, dtype=torch.uint8, device=dev)
+                pooled = _empty((Np, Dp // 2, Hp // 2, Wp // 2, Cp), dtype=_F32, device=dev)
+                argmax = _empty(pooled.shape, dtype=torch.uint8, device=dev)
                 pst = None if self.post_norm else pool.take(Np * Cp * 2)
                 nat.call("u3d_maxpool2_fwd", dev.index, _stream(dev), _p(cur), Np, Dp, Hp, Wp, Cp, _p(pooled), _p(argmax),
                          _p(pst))
@@ -982,7 +1033,7 @@ class UNet3DEngine:
                 # to the skip's size (:650-651) and the concat are virtual, like the interpolation path
                 Nl, D1, H1, W1, Cl = cur.shape
                 Cs = ct.out_channels
-                t = torch.empty((Nl, 2 * D1 - 1, 2 * H1 - 1, 2 * W1 - 1, Cs), dtype=_F32, device=dev)
+                t = _empty((Nl, 2 * D1 - 1, 2 * H1 - 1, 2 * W1 - 1, Cs), dtype=_F32, device=dev)
                 if self.subpixel and Cl % 4 == 0 and Cs % 4 == 0:
                     nat.call("u3d_convtr3d_fwd_subpixel", dev.index, _stream(dev), _p(cur), _p(self._packed_convtr(ct.weight, 2, dev)),
                              _p(t), Nl, D1, H1, W1, Cl, Cs, flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
@@ -998,7 +1049,7 @@ class UNet3DEngine:
                 Nl, D1, H1, W1, Cl = cur.shape
                 _, Ds, Hs, Ws, _ = sk.shape
                 tabs = [_resample_tables(dev, self.dec_interp[j], a, b) for a, b in ((D1, Ds), (H1, Hs), (W1, Ws))]
-                up = torch.empty((Nl, Ds, Hs, Ws, Cl), dtype=_F32, device=dev)
+                up = _empty((Nl, Ds, Hs, Ws, Cl), dtype=_F32, device=dev)
                 nat.call("u3d_resample2_fwd", dev.index, _stream(dev), _p(cur), _p(tabs[0][0]), _p(tabs[1][0]), _p(tabs[2][0]),
                          _p(tabs[0][1]), _p(tabs[1][1]), _p(tabs[2][1]), Nl, D1, H1, W1, Ds, Hs, Ws, Cl, _p(up))
                 if tape is not None:
@@ -1015,12 +1066,12 @@ class UNet3DEngine:
         fc = m.final_conv
         Co, Cf = fc.out_channels, fc.in_channels
         V = D * H * W
-        logits = torch.empty((N, Co, D, H, W), dtype=_F32, device=dev)
+        logits = _empty((N, Co, D, H, W), dtype=_F32, device=dev)
         act = 0
         probs = None
         if m.final_activation is not None:
             act = 1 if isinstance(m.final_activation, torch.nn.Sigmoid) else 2
-            probs = torch.empty_like(logits)
+            probs = _empty_like(logits)
         nat.call("u3d_conv1x1_head_fwd", dev.index, _stream(dev), _p(cur), _p(fc.weight.detach()), _p(fc.bias.detach()), N, V,
                  Cf, Co, act, _p(logits), _p(probs))
         if tape is not None:
@@ -1037,7 +1088,7 @@ class UNet3DEngine:
         N, Cin, D, H, W = tape.dims
         V = D * H * W
         dlogits = dlogits.contiguous()
-        flat = torch.empty(self.n_params, dtype=_F32, device=dev)
+        flat = _empty(self.n_params, dtype=_F32, device=dev)
 
         def gview(idx):
             p = self.params[idx]
@@ -1052,7 +1103,7 @@ class UNet3DEngine:
 
         # ---- head backward: dz of the last decoder conv (ReLU mask fused)
         hacc = pool.take(Co * Cf + Co)
-        dz = torch.empty_like(tape.head_x)
+        dz = _empty_like(tape.head_x)
         nat.call("u3d_conv1x1_head_bwd", dev.index, _stream(dev), _p(dlogits), _p(tape.head_x), _p(fc.weight.detach()), N, V,
                  Cf, Co, self.mask, _p(dz), _p(hacc))
         self._unact(dev, dz, tape.head_x)
@@ -1090,7 +1141,7 @@ class UNet3DEngine:
             # skip half -> gradient of the encoder feature: its GroupNorm backward (p*dg + q*e + r on the first C0 channels)
             # is evaluated inside the max-pool merge kernel of that encoder level, never written to HBM
             lvl = n_levels - 2 - j
-            dzl = torch.empty_like(src.t1)
+            dzl = _empty_like(src.t1)
             if r1.sub is not None:
                 dg0, dlow = dg1
                 skip_grad[lvl] = (dg0, C0, coef1, Ct)
@@ -1115,7 +1166,7 @@ class UNet3DEngine:
                 Nl, D1, H1, W1, Cl = xl.shape
                 Cs = up.weight.shape[1]
                 acc = pool.take(up.weight.numel())
-                dxl = torch.empty_like(xl)
+                dxl = _empty_like(xl)
                 nat.call("u3d_convtr3d_bwd", dev.index, _stream(dev), _p(dzl), _p(xl), _p(up.weight.detach()), Nl, D1, H1, W1, Cl, Cs,
                          mk, _p(dxl), _p(acc), _p(self._packed_convtr(up.weight, 1, dev)), flops=4.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
                 nat.call("u3d_cvt_f64_f32", dev.index, _stream(dev), _p(acc), _p(gview(self._pindex[id(up.weight)])),
@@ -1130,7 +1181,7 @@ class UNet3DEngine:
                 Nl, D1, H1, W1, Cl = xl.shape
                 Ds, Hs, Ws = up.tdims
                 tz, ty, tx = up.los
-                dxl = torch.empty_like(xl)
+                dxl = _empty_like(xl)
                 nat.call("u3d_resample2_bwd", dev.index, _stream(dev), _p(dzl), _p(tz[2]), _p(ty[2]), _p(tx[2]), _p(tz[0]), _p(ty[0]),
                          _p(tx[0]), _p(tz[1]), _p(ty[1]), _p(tx[1]), Nl, D1, H1, W1, Ds, Hs, Ws, Cl, _p(dxl))
                 if self.act != ACT_NONE:
@@ -1157,7 +1208,7 @@ class UNet3DEngine:
             if i > 0:
                 pooled, argmax, e_in = tape.pools[i - 1]
                 Ne, De, He, We, Ce = e_in.shape
-                out = torch.empty_like(e_in)
+                out = _empty_like(e_in)
                 sk = skip_grad.pop(i - 1, None)
                 if sk is None:
                     nat.call("u3d_maxpool2_bwd_merge", dev.index, _stream(dev), _p(dg1), _p(pooled), _p(argmax), _p(coef1), None,
@@ -1183,7 +1234,7 @@ class UNet3DEngine:
             if Cin == 1:
                 dx = dx0.view(N, 1, D, H, W)
             else:
-                dx = torch.empty((N, Cin, D, H, W), dtype=_F32, device=dev)
+                dx = _empty((N, Cin, D, H, W), dtype=_F32, device=dev)
                 nat.call("u3d_ndhwc_to_ncdhw", dev.index, _stream(dev), _p(dx0), _p(dx), N, Cin, V)
         return flat, dx
 
@@ -1260,7 +1311,7 @@ class ResUNetEngine(UNet3DEngine):
                 sx = VSrc(r).struct()
                 nat.call("u3d_chan_stats", dev.index, _stream(dev), ctypes.byref(sx), N, D, H, W, _p(r_st))
         else:
-            r = torch.empty((N, D, H, W, Cout), dtype=_F32, device=dev)
+            r = _empty((N, D, H, W, Cout), dtype=_F32, device=dev)
             r_st = pool.take(N * Cout * 2)
             w1 = conv1.weight.detach().view(Cout, Cin)
             nat.call("u3d_conv1x1_fwd", dev.index, _stream(dev), _p(x_in), _p(w1), _p(conv1.bias.detach()), _p(r), N, D * H * W,
@@ -1303,17 +1354,17 @@ class ResUNetEngine(UNet3DEngine):
         st = {"mode": mode, "y": y, "cse": cse, "sse": sse, "gc": None, "a": None}
         if cse is not None:
             Cr = cse.fc1.out_features
-            st["s"] = torch.empty((N, C), dtype=_F32, device=dev)
-            st["h"] = torch.empty((N, Cr), dtype=_F32, device=dev)
-            st["gc"] = torch.empty((N, C), dtype=_F32, device=dev)
+            st["s"] = _empty((N, C), dtype=_F32, device=dev)
+            st["h"] = _empty((N, Cr), dtype=_F32, device=dev)
+            st["gc"] = _empty((N, C), dtype=_F32, device=dev)
             nat.call("u3d_se_gate_fwd", dev.index, _stream(dev), _p(y_st), float(V), _p(cse.fc1.weight.detach()),
                      _p(cse.fc1.bias.detach()), _p(cse.fc2.weight.detach()), _p(cse.fc2.bias.detach()), N, C, Cr, _p(st["s"]),
                      _p(st["h"]), _p(st["gc"]))
         ws = bs = None
         if sse is not None:
             ws, bs = sse.conv.weight.detach().view(C), sse.conv.bias.detach()
-            st["a"] = torch.empty((N * V,), dtype=_F32, device=dev)
-        out = torch.empty_like(y)
+            st["a"] = _empty((N * V,), dtype=_F32, device=dev)
+        out = _empty_like(y)
         nat.call("u3d_se_apply_fwd", dev.index, _stream(dev), _p(y), _p(st["gc"]), _p(ws), _p(bs), N, V, C, mode, _p(out),
                  _p(st["a"]))
         st["out"] = out
@@ -1328,16 +1379,16 @@ class ResUNetEngine(UNet3DEngine):
         mode, cse, sse = se["mode"], se["cse"], se["sse"]
         acc_gc = pool.take(N * C) if cse is not None else None
         acc_ws = pool.take(C + 1) if sse is not None else None
-        dls = torch.empty((N * V,), dtype=_F32, device=dev) if sse is not None else None
+        dls = _empty((N * V,), dtype=_F32, device=dev) if sse is not None else None
         ws = sse.conv.weight.detach().view(C) if sse is not None else None
         nat.call("u3d_se_bwd_reduce", dev.index, _stream(dev), _p(dout), _p(y), _p(se["gc"]), _p(se["a"]), _p(ws), N, V, C, mode,
                  _p(dls), _p(acc_gc), _p(acc_ws))
         ds = None
         if cse is not None:
             Cr = cse.fc1.out_features
-            dz2 = torch.empty((N, C), dtype=_F32, device=dev)
-            dz1 = torch.empty((N, Cr), dtype=_F32, device=dev)
-            ds = torch.empty((N, C), dtype=_F32, device=dev)
+            dz2 = _empty((N, C), dtype=_F32, device=dev)
+            dz1 = _empty((N, Cr), dtype=_F32, device=dev)
+            ds = _empty((N, C), dtype=_F32, device=dev)
             ix = [self._pindex[id(p)] for p in (cse.fc1.weight, cse.fc1.bias, cse.fc2.weight, cse.fc2.bias)]
             nat.call("u3d_se_gate_bwd", dev.index, _stream(dev), _p(acc_gc), _p(se["gc"]), _p(se["h"]), _p(se["s"]),
                      _p(cse.fc1.weight.detach()), _p(cse.fc2.weight.detach()), N, C, Cr, float(V), _p(dz2), _p(dz1), _p(ds),
@@ -1346,7 +1397,7 @@ class ResUNetEngine(UNet3DEngine):
             jw, jb = self._pindex[id(sse.conv.weight)], self._pindex[id(sse.conv.bias)]
             assert self.poffs[jb] == self.poffs[jw] + C
             nat.call("u3d_cvt_f64_f32", dev.index, _stream(dev), _p(acc_ws), _p(gview(jw)), C + 1)
-        m_ = torch.empty_like(y)
+        m_ = _empty_like(y)
         nat.call("u3d_se_bwd_apply", dev.index, _stream(dev), _p(dout), _p(y), _p(se["gc"]), _p(se["a"]), _p(ws), _p(dls), _p(ds),
                  N, V, C, mode, self.mask, _p(m_))
         return m_
@@ -1359,7 +1410,7 @@ class ResUNetEngine(UNet3DEngine):
         if Cin == 1:
             x0 = x.view(N, D, H, W, 1)
         else:
-            x0 = torch.empty((N, D, H, W, Cin), dtype=_F32, device=dev)
+            x0 = _empty((N, D, H, W, Cin), dtype=_F32, device=dev)
             nat.call("u3d_ncdhw_to_ndhwc", dev.index, _stream(dev), _p(x), _p(x0), N, Cin, D * H * W)
         tape = Tape() if save else None
         if tape is not None:
@@ -1376,8 +1427,8 @@ class ResUNetEngine(UNet3DEngine):
         for i, (has_pool, bm) in enumerate(self.enc):
             if has_pool:
                 Np, Dp, Hp, Wp, Cp = cur.shape
-                pooled = torch.empty((Np, Dp // 2, Hp // 2, Wp // 2, Cp), dtype=_F32, device=dev)
-                argmax = torch.empty(pooled.shape, dtype=torch.uint8, device=dev)
+                pooled = _empty((Np, Dp // 2, Hp // 2, Wp // 2, Cp), dtype=_F32, device=dev)
+                argmax = _empty(pooled.shape, dtype=torch.uint8, device=dev)
                 nat.call("u3d_maxpool2_fwd", dev.index, _stream(dev), _p(cur), Np, Dp, Hp, Wp, Cp, _p(pooled), _p(argmax),
                          None)
                 if tape is not None:
@@ -1399,12 +1450,12 @@ class ResUNetEngine(UNet3DEngine):
             Dt, Ht, Wt = 2 * D1 - 1, 2 * H1 - 1, 2 * W1 - 1
             t8 = self._convtr_t8(Cl, Cs)
             (mz, lz), (my, ly), (mx, lx) = _maps(dev, Dt, Ds), _maps(dev, Ht, Hs), _maps(dev, Wt, Ws)
-            joined = torch.empty_like(sk)
+            joined = _empty_like(sk)
             j_st = pool.take(Nl * Cs * 2)
             if t8:
                 # bf16 mode: 2x2x2 convolution on the low-res grid into the space-to-depth layout T8[i][parity*Cs + c] = t[2i + parity];
                 # the resize + join reads that layout directly
-                t = torch.empty((Nl, D1, H1, W1, 8 * Cs), dtype=_F32, device=dev)
+                t = _empty((Nl, D1, H1, W1, 8 * Cs), dtype=_F32, device=dev)
                 nat.call("u3d_convtr3d_fwd_t8", dev.index, _stream(dev), _p(cur), _p(self._packed_convtr_t8(ct.weight, 0, dev)), _p(t),
                          Nl, D1, H1, W1, Cl, Cs, flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
                 nat.call("u3d_nearest_add_fwd_t8", dev.index, _stream(dev), _p(sk), _p(t), _p(mz), _p(my), _p(mx), Nl, Ds, Hs, Ws, Dt,
@@ -1414,7 +1465,7 @@ class ResUNetEngine(UNet3DEngine):
                     tape.ups.append(UpRec(cur, ct.weight, (lz, ly, lx), (Dt, Ht, Wt), True))
                 cur = self._block_fwd(bm, f"dec{j}", joined, j_st, pool, tape, dev)
                 continue
-            t = torch.empty((Nl, Dt, Ht, Wt, Cs), dtype=_F32, device=dev)
+            t = _empty((Nl, Dt, Ht, Wt, Cs), dtype=_F32, device=dev)
             if self.subpixel and Cl % 4 == 0 and Cs % 4 == 0:
                 # 8 output parity classes accumulated from one staged input halo tile (csrc/u3d_subpix.hip, scheme Deconv3s2)
                 nat.call("u3d_convtr3d_fwd_subpixel", dev.index, _stream(dev), _p(cur), _p(self._packed_convtr(ct.weight, 2, dev)),
@@ -1432,12 +1483,12 @@ class ResUNetEngine(UNet3DEngine):
         fc = m.final_conv
         Co, Cf = fc.out_channels, fc.in_channels
         V = D * H * W
-        logits = torch.empty((N, Co, D, H, W), dtype=_F32, device=dev)
+        logits = _empty((N, Co, D, H, W), dtype=_F32, device=dev)
         act = 0
         probs = None
         if m.final_activation is not None:
             act = 1 if isinstance(m.final_activation, torch.nn.Sigmoid) else 2
-            probs = torch.empty_like(logits)
+            probs = _empty_like(logits)
         nat.call("u3d_conv1x1_head_fwd", dev.index, _stream(dev), _p(cur), _p(fc.weight.detach()), _p(fc.bias.detach()), N, V,
                  Cf, Co, act, _p(logits), _p(probs))
         if tape is not None:
@@ -1471,7 +1522,7 @@ class ResUNetEngine(UNet3DEngine):
         N, Cin, D, H, W = tape.dims
         V = D * H * W
         dlogits = dlogits.contiguous()
-        flat = torch.empty(self.n_params, dtype=_F32, device=dev)
+        flat = _empty(self.n_params, dtype=_F32, device=dev)
         fc = m.final_conv
         Co, Cf = fc.out_channels, fc.in_channels
         tot = Co * Cf + Co + sum(N * r.src.C * 2 for r in tape.convs)
@@ -1490,12 +1541,12 @@ class ResUNetEngine(UNet3DEngine):
                 Nb, Db, Hb, Wb, _ = b.x_in.shape
                 Cb = b.bm.conv2.conv.in_channels
                 need = max(need, self._layer_ws_floats(Nb, Db, Hb, Wb, Cb, Cb))
-        ws = torch.empty(max(int(need), 4), dtype=_F32, device=dev)
+        ws = _empty(max(int(need), 4), dtype=_F32, device=dev)
         cx = _BwdCtx(dev, pool, ws, flat, self)
         gview = cx.gview
 
         hacc = pool.take(Co * Cf + Co)
-        dz = torch.empty_like(tape.head_x)
+        dz = _empty_like(tape.head_x)
         mk = self.mask  # ReLU blocks: the consumers' backward kernels mask by (block output > 0); else _block_bwd removes f
         nat.call("u3d_conv1x1_head_bwd", dev.index, _stream(dev), _p(dlogits), _p(tape.head_x), _p(fc.weight.detach()), N, V,
                  Cf, Co, mk, _p(dz), _p(hacc))
@@ -1518,24 +1569,24 @@ class ResUNetEngine(UNet3DEngine):
             Dt, Ht, Wt = up.tdims
             lz, ly, lx = up.los
             if up.t8:
-                dt8 = torch.empty((Nl, D1, H1, W1, 8 * Cs), dtype=_F32, device=dev)
+                dt8 = _empty((Nl, D1, H1, W1, 8 * Cs), dtype=_F32, device=dev)
                 nat.call("u3d_nearest_sum_bwd_t8", dev.index, _stream(dev), _p(dj), _p(lz), _p(ly), _p(lx), Nl, Ds, Hs, Ws, Dt, Ht, Wt,
                          Cs, _p(dt8))
                 need = nat.get_lib().u3d_convtr3d_wgrad_t8_workspace_floats(Nl, D1, H1, W1, Cl, Cs)
                 wsb = cx.ensure_ws(need)
                 nat.call("u3d_convtr3d_wgrad_t8", dev.index, _stream(dev), _p(xl), _p(dt8), _p(gview(self._pindex[id(up.weight)])),
                          Nl, D1, H1, W1, Cl, Cs, _p(wsb), wsb.numel(), flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
-                dxl = torch.empty_like(xl)
+                dxl = _empty_like(xl)
                 nat.call("u3d_convtr3d_dgrad_t8", dev.index, _stream(dev), _p(dt8), _p(self._packed_convtr_t8(up.weight, 1, dev)),
                          _p(xl) if mk else None, _p(dxl), Nl, D1, H1, W1, Cl, Cs, flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
                 del dt8
                 dz = dxl  # ReLU blocks: masked by (x_low > 0)
                 continue
-            dt = torch.empty((Nl, Dt, Ht, Wt, Cs), dtype=_F32, device=dev)
+            dt = _empty((Nl, Dt, Ht, Wt, Cs), dtype=_F32, device=dev)
             nat.call("u3d_nearest_sum_bwd", dev.index, _stream(dev), _p(dj), _p(lz), _p(ly), _p(lx), Nl, Ds, Hs, Ws, Dt, Ht, Wt,
                      Cs, _p(dt))
             acc = pool.take(up.weight.numel())
-            dxl = torch.empty_like(xl)
+            dxl = _empty_like(xl)
             nat.call("u3d_convtr3d_bwd", dev.index, _stream(dev), _p(dt), _p(xl), _p(up.weight.detach()), Nl, D1, H1, W1, Cl, Cs,
                      mk, _p(dxl), _p(acc), _p(self._packed_convtr(up.weight, 1, dev)), flops=4.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
             nat.call("u3d_cvt_f64_f32", dev.index, _stream(dev), _p(acc), _p(gview(self._pindex[id(up.weight)])),
@@ -1565,7 +1616,7 @@ class ResUNetEngine(UNet3DEngine):
                 Cout_, Cin_ = c1.weight.shape[0], c1.weight.shape[1]
                 xin = rec.x_in
                 acc = pool.take(Cout_ * Cin_ + Cout_)
-                dxin = torch.empty_like(xin) if need_dx else None
+                dxin = _empty_like(xin) if need_dx else None
                 nat.call("u3d_conv1x1_bwd", dev.index, _stream(dev), _p(dr), _p(xin), _p(c1.weight.detach().view(Cout_, Cin_)),
                          xin.shape[0], xin.numel() // (xin.shape[0] * Cin_), Cin_, Cout_, _p(dxin), _p(acc),
                          flops=(4.0 if need_dx else 2.0) * Cin_ * Cout_ * (xin.numel() // Cin_))
@@ -1577,7 +1628,7 @@ class ResUNetEngine(UNet3DEngine):
             if i > 0:
                 pooled, argmax, e_in = tape.pools[i - 1]
                 Ne, De, He, We, Ce = e_in.shape
-                out = torch.empty_like(e_in)
+                out = _empty_like(e_in)
                 nat.call("u3d_maxpool2_bwd_merge", dev.index, _stream(dev), _p(dxin), _p(pooled), _p(argmax), None,
                          _p(skip_grad.get(i - 1)), _p(e_in), Ne, De, He, We, Ce, mk, _p(out))
                 dz = out
@@ -1594,7 +1645,7 @@ class ResUNetEngine(UNet3DEngine):
             if Cin == 1:
                 dx = dx0.reshape(N, 1, D, H, W)
             else:
-                dx = torch.empty((N, Cin, D, H, W), dtype=_F32, device=dev)
+                dx = _empty((N, Cin, D, H, W), dtype=_F32, device=dev)
                 nat.call("u3d_ndhwc_to_ncdhw", dev.index, _stream(dev), _p(dx0), _p(dx), N, Cin, V)
         return flat, dx
 
@@ -1607,6 +1658,7 @@ class _UNet3DFunction(torch.autograd.Function):
         # grad mode is always off inside Function.forward: needs_input_grad tells whether a backward can follow
         save = any(ctx.needs_input_grad)
         with engine._lock:
+            engine.begin_forward(save)
             logits, probs, tape = engine.forward(x, save)
         ctx.engine = engine
         ctx.has_probs = probs is not None

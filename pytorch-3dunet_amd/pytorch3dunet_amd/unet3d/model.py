@@ -119,6 +119,13 @@ class AbstractUNet(nn.Module):
         object.__setattr__(self, "_engine", new)
         return new
 
+    def invalidate_native_caches(self):
+        """Drop the executor's packed weight images.  Needed only after writing parameters through `param.data` (which autograd's
+        version counter does not see) while the model is in inference use; training forwards repack every step anyway."""
+        eng = self.__dict__.get("_engine")
+        if eng is not None:
+            eng._salt += 1
+
     def forward(self, x, return_logits=False):
         """(N,C,D,H,W) -> probabilities, or (probabilities, logits) when return_logits (model.py:103-121)."""
         output, logits = self._forward_logits(x)

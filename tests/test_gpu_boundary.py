@@ -278,3 +278,34 @@ def test_bench_under_torch_distributed_run_one_rank():
     r = json.loads(line)
     assert r["ranks_seen"] == {"world_size": 1, "backend": "nccl", "allreduce_per_step": 2}, r["ranks_seen"]
     assert r["n_gpus"] == 1 and r["value"] > 0 and "roofline" in r
+
+
+def test_weight_edits_through_param_data_are_seen():
+    """packed weight images are cached on autograd's version counter, which `param.data` writes bypass: a training forward
+    repacks regardless; in inference `invalidate_native_caches()` (or U3D_ALWAYS_REPACK=1) is the documented hook"""
+    from pytorch3dunet_amd.unet3d.model import UNet3D
+
+    DEV = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    model = UNet3D(in_channels=1, out_channels=1, f_maps=[16, 32], num_groups=8).to(DEV)
+    x = torch.randn(1, 1, 8, 16, 16, device=DEV)
+    target = (torch.rand(1, 1, 8, 16, 16, device=DEV) > 0.5).float()
+    w = model.encoders[1].basic_module.SingleConv1.conv.weight
+    model.train()
+    _, l0 = model(x, return_logits=True)
+    w.data.add_(0.1 * torch.randn_like(w))  # invisible to w._version (a pure rescaling would vanish in the next GroupNorm)
+    _, l1 = model(x, return_logits=True)
+    assert (l1 - l0).abs().max().item() > 1e-4  # the training forward saw the new values
+    torch.nn.functional.binary_cross_entropy_with_logits(l1, target).backward()
+    ref = UNet3D(in_channels=1, out_channels=1, f_maps=[16, 32], num_groups=8).to(DEV).train()
+    ref.load_state_dict(model.state_dict())
+    _, lr = ref(x, return_logits=True)
+    assert torch.equal(lr, l1)
+    # inference: cached by design, explicit invalidation
+    model.eval()
+    with torch.no_grad():
+        e0 = model(x)
+        w.data.add_(0.1 * torch.randn_like(w))
+        model.invalidate_native_caches()
+        e1 = model(x)
+    assert (e1 - e0).abs().max().item() > 1e-5

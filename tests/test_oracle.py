@@ -161,7 +161,7 @@ def test_decision_consistent_oracle_reproduces_plain_oracle():
 
 
 @pytest.mark.skipif(not reference_available(), reason="/root/reference only exists in the build container")
-@pytest.mark.parametrize("order", ["gcl", "gce", "cgr", "cgl", "cge", "cg", "gc"])
+@pytest.mark.parametrize("order", ["gcl", "gce", "cgr", "cgl", "cge", "cg", "gc", "crg", "clg", "ceg"])
 def test_ordered_oracle_matches_live_reference(order):
     """the layer-order mini language (buildingblocks.py:10-96) restated in single_conv_ordered, against the imported reference"""
     ref = import_reference()
@@ -181,7 +181,7 @@ def test_ordered_oracle_matches_live_reference(order):
 
 @pytest.mark.skipif(not reference_available(), reason="/root/reference only exists in the build container")
 @pytest.mark.parametrize("name", ["ResidualUNet3D", "ResidualUNetSE3D"])
-@pytest.mark.parametrize("order", ["cge", "cgr", "gcl", "gce", "cgl", "gc", "cg"])
+@pytest.mark.parametrize("order", ["cge", "cgr", "gcl", "gce", "cgl", "gc", "cg", "crg", "ceg"])
 def test_ordered_residual_oracle_matches_live_reference(name, order):
     """ResNetBlock in the orders other than 'gcr' (buildingblocks.py:245-275: 'cge' is the class default, the reference's own
     tests/test_models.py:26-44 builds 'cgr' blocks; the block's final LeakyReLU has slope 0.1, conv2's the nn default 0.01)"""
