@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define U3D_VERSION 111 /* bf16-operand convolutions; residual blocks in every native layer order */
+#define U3D_VERSION 112 /* bf16-operand convolutions; residual blocks in every native layer order */
 
 #define U3D_OK 0
 #define U3D_EINVAL (-1)  /* bad shape / argument */
@@ -456,6 +456,25 @@ int u3d_resample2_fwd(int device, u3d_stream_t stream, const float* x, const int
 int u3d_resample2_bwd(int device, u3d_stream_t stream, const float* dout, const int32_t* rng_z, const int32_t* rng_y,
                       const int32_t* rng_x, const int32_t* idx_z, const int32_t* idx_y, const int32_t* idx_x, const float* wt_z,
                       const float* wt_y, const float* wt_x, int N, int D1, int H1, int W1, int D, int H, int W, int C, float* dx);
+
+/* ---- the remaining layer-order characters (create_conv, buildingblocks.py:10-96): 'b' nn.BatchNorm3d (:78-88), the conv bias of
+ * layers without a norm (:54-55: 'cr', 'cl', 'ce', 'c'), 'd' / 'D' dropout (:89-92).
+ *   u3d_bn_finalize      per-(n,c) sums (as u3d_gn_finalize: two channel ranges with scales) -> per-CHANNEL batch mean / biased
+ *                        variance (training) or the running statistics (eval), the (a, b) table affine[N][C][2] the convolutions
+ *                        apply, mean_rstd[C][2]; training also updates running_mean / running_var in place like ATen
+ *                        (momentum, unbiased variance); count = voxels per sample
+ *   u3d_bn_bwd_finalize  gstats[N][C][2] = (sum dg, sum dg*x) -> dgamma, dbeta, coef[N][3][C] for u3d_gn_bwd_apply*
+ *   u3d_bias_table       affine[N][C][2] = (1, bias[c]): a layer without a norm is "post-norm with a constant affine"
+ *   u3d_bias_grad        dbias[c] = sum_n stats[n][c][0] (stats from u3d_pair_stats on the pre-activation gradient)
+ *   u3d_mul              out = a * b elementwise (dropout mask, drawn by the caller with torch's generator) */
+int u3d_bn_finalize(int device, u3d_stream_t stream, const double* stats0, int C0, double scale0, const double* stats1, int C1,
+                    double scale1, int N, double count, const float* gamma, const float* beta, float eps, int training,
+                    float momentum, float* running_mean, float* running_var, float* affine, float* mean_rstd);
+int u3d_bn_bwd_finalize(int device, u3d_stream_t stream, const double* gstats, const float* mean_rstd, const float* gamma, int N,
+                        int C, double count, int training, float* dgamma, float* dbeta, float* coef);
+int u3d_bias_table(int device, u3d_stream_t stream, const float* bias, int N, int C, float* affine);
+int u3d_bias_grad(int device, u3d_stream_t stream, const double* stats, int N, int C, float* dbias);
+int u3d_mul(int device, u3d_stream_t stream, const float* a, const float* b, int64_t n, float* out);
 
 /* ---- layout: NCDHW <-> NDHWC for multi-channel model inputs ------------------------------------ */
 int u3d_ncdhw_to_ndhwc(int device, u3d_stream_t stream, const float* src, float* dst, int N, int C, int64_t V);

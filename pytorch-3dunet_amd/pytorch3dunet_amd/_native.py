@@ -253,6 +253,13 @@ _PROTOS = {
     "u3d_affine_add_act_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_float, c_void_p]),
     "u3d_resample2_fwd": (c_int, [c_int, c_void_p] + [c_void_p] * 7 + [c_int] * 8 + [c_void_p]),
     "u3d_resample2_bwd": (c_int, [c_int, c_void_p] + [c_void_p] * 10 + [c_int] * 8 + [c_void_p]),
+    "u3d_bn_finalize": (c_int, [c_int, c_void_p, c_void_p, c_int, c_double, c_void_p, c_int, c_double, c_int, c_double, c_void_p,
+                                c_void_p, c_float, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "u3d_bn_bwd_finalize": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_double, c_int, c_void_p, c_void_p,
+                                    c_void_p]),
+    "u3d_bias_table": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "u3d_bias_grad": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "u3d_mul": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "u3d_pair_stats": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
     "u3d_cvt_f64_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64]),
     "u3d_ncdhw_to_ndhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64]),
@@ -297,7 +304,7 @@ def get_lib():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.u3d_version() < 111:
+        if lib.u3d_version() < 112:
             raise U3DError("libu3d_hip.so is older than the Python host code")
         _lib = lib
     return _lib

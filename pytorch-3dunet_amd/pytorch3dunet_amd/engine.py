@@ -26,6 +26,7 @@ from dataclasses import dataclass, field
 from typing import List, Optional
 
 import torch
+import torch.nn.functional as F
 
 from . import _native as nat
 from ._native import U3DSrc
@@ -239,30 +240,57 @@ class VSrc:
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU = 0, 1, 2, 3  # activation codes of include/u3d.h (u3d_act_fwd)
 
 
-def parse_order(order: str):
-    """The layer-order strings (buildingblocks.py:10-96) the executor runs natively -> (post_norm, act, slope), else None.
-    Native: one GroupNorm + Conv3d, the GroupNorm before ('gc…': normalises the conv INPUT) or after the conv ('cg…': the
-    conv OUTPUT), optionally followed by ONE non-linearity at the end: ReLU 'r', LeakyReLU(0.01) 'l', ELU 'e' — or with the
-    non-linearity between conv and norm ('crg', the reference docstring's own example, 'clg', 'ceg': `act` is then NONE, the
-    layer output is the normalised tensor, and parse_inner names the inner non-linearity).  Everything else (no norm -> conv
-    with bias, BatchNorm 'b', dropout 'd'/'D') runs the module tree."""
-    if not order or any(ch not in "gcrle" for ch in order) or order.count("c") != 1 or order.count("g") != 1:
+@dataclass(frozen=True)
+class LayerSpec:
+    """one SingleConv order string (create_conv, buildingblocks.py:10-96) as the executor runs it"""
+
+    norm: Optional[str]   # 'g' GroupNorm, 'b' BatchNorm3d, None: no norm -> the conv has a bias (:54-55)
+    pre: bool             # the norm acts on the conv INPUT ('gc…', 'bc…')
+    act: int              # non-linearity of the layer output
+    slope: float
+    inner: int            # non-linearity between the conv and a TRAILING norm ('crg', the reference docstring's example)
+    islope: float
+    drop: Optional[str]   # 'd' nn.Dropout / 'D' nn.Dropout2d (per-(n, channel) on 5-D inputs) as the LAST operation
+
+
+_ACTS = {"r": (ACT_RELU, 0.0), "l": (ACT_LEAKY, 0.01), "e": (ACT_ELU, 0.0)}  # nn defaults (:47-51)
+
+
+def layer_spec(order: str) -> Optional[LayerSpec]:
+    """Native grammar:  [g|b] c [r|l|e] [d|D]   |   c [r|l|e] (g|b) [d|D]   |   c (g|b) [r|l|e] [d|D]   |   c [r|l|e] [d|D].
+    Anything else (two norms, dropout in the middle of a layer, ELU before a dropout, …) runs the module tree."""
+    if not order or any(ch not in "gbcrledD" for ch in order) or order.count("c") != 1:
         return None
+    drop = None
+    if order[-1] in "dD":
+        drop, order = order[-1], order[:-1]
+    if any(ch in "dD" for ch in order) or not order:
+        return None
+    norms = [ch for ch in order if ch in "gb"]
     acts = [ch for ch in order if ch in "rle"]
-    if len(acts) == 1 and order == "c" + acts[0] + "g":
-        return True, ACT_NONE, 0.0
-    if len(acts) > 1 or (acts and order[-1] != acts[0]):
+    if len(norms) > 1 or len(acts) > 1:
         return None
-    act = {"r": ACT_RELU, "l": ACT_LEAKY, "e": ACT_ELU}[acts[0]] if acts else ACT_NONE
-    return order.index("g") > order.index("c"), act, (0.01 if act == ACT_LEAKY else 0.0)
+    norm = norms[0] if norms else None
+    a, sl = _ACTS[acts[0]] if acts else (ACT_NONE, 0.0)
+    if drop and a == ACT_ELU:
+        return None  # the consumers remove f through the layer OUTPUT, which the dropout rescales: exact for ReLU / LeakyReLU only
+    ci = order.index("c")
+    if norm is None:
+        return LayerSpec(None, False, a, sl, ACT_NONE, 0.0, drop) if order in ("c", "c" + "".join(acts)) else None
+    ni = order.index(norm)
+    if ni < ci:  # pre-norm: N c [A]
+        return LayerSpec(norm, True, a, sl, ACT_NONE, 0.0, drop) if order == norm + "c" + "".join(acts) else None
+    if order == "c" + norm + "".join(acts):  # post-norm: c N [A]
+        return LayerSpec(norm, False, a, sl, ACT_NONE, 0.0, drop)
+    if acts and order == "c" + acts[0] + norm:  # c A N: the non-linearity sits inside
+        return LayerSpec(norm, False, ACT_NONE, 0.0, a, sl, drop)
+    return None
 
 
-def parse_inner(order: str):
-    """(act, slope) of a non-linearity sitting BETWEEN the conv and a trailing GroupNorm ('crg' / 'clg' / 'ceg'), else NONE"""
-    if len(order) == 3 and order[0] == "c" and order[2] == "g" and order[1] in "rle":
-        a = {"r": ACT_RELU, "l": ACT_LEAKY, "e": ACT_ELU}[order[1]]
-        return a, (0.01 if a == ACT_LEAKY else 0.0)
-    return ACT_NONE, 0.0
+def parse_order(order: str):
+    """(conv input has no norm of its own, act, slope) of a natively executable order, else None — see layer_spec"""
+    sp = layer_spec(order)
+    return None if sp is None else (not sp.pre, sp.act, sp.slope)
 
 
 @dataclass
@@ -284,6 +312,9 @@ class ConvRec:
     sub: Optional[tuple] = None  # (C0, C1): the upsampled half ran as a sub-pixel convolution (csrc/u3d_subpix.hip)
     pre_norm: bool = True        # GroupNorm on the conv input ('gc…'); False: `affine` is the identity table
     post: Optional[tuple] = None  # post-norm order ('cg…'): (z = [f_inner](conv output), its GroupNorm affine table, f_inner, slope); y = f(a*z + b)
+    norm: Optional[str] = "g"    # 'g' GroupNorm, 'b' BatchNorm3d (mean_rstd is (C,2)), None: conv bias (idx_gb = its index)
+    bn_training: bool = True     # BatchNorm normalised with batch statistics (else: running statistics, constants in backward)
+    drop: Optional[tuple] = None  # trailing dropout: ('d', mask NDHWC) or ('D', (N,C,2) table (mask, 0))
 
 
 @dataclass
@@ -700,34 +731,66 @@ class UNet3DEngine:
         nat.call("u3d_chan_stats", dev.index, _stream(dev), ctypes.byref(s), src.N, src.D, src.H, src.W, _p(st))
         return st, src.C, 1.0, None, 0, 0.0
 
+    def _norm_finalize(self, kind, mod, st0, C0, sc0, st1, C1, sc1, N, G, count, affine, dev):
+        """per-(n,c) sums -> the (a, b) table the convolutions / apply passes use; returns what backward needs (mean, rstd)"""
+        if kind == "g":
+            mean_rstd = _empty((N, G, 2), dtype=_F32, device=dev)
+            nat.call("u3d_gn_finalize", dev.index, _stream(dev), _p(st0), C0, sc0, _p(st1), C1, sc1, N, G, count,
+                     _p(mod.weight.detach()), _p(mod.bias.detach()), float(mod.eps), _p(affine), _p(mean_rstd))
+            return mean_rstd
+        # nn.BatchNorm3d (buildingblocks.py:78-88): batch statistics + running-estimate update in training, running statistics in eval
+        C = C0 + C1
+        training = bool(mod.training) or mod.running_mean is None
+        mean_rstd = _empty((C, 2), dtype=_F32, device=dev)
+        momentum = 0.0
+        if training and mod.running_mean is not None:
+            mod.num_batches_tracked.add_(1)  # (ATen's batch_norm does the same before the kernel)
+            momentum = (1.0 / float(mod.num_batches_tracked.item())) if mod.momentum is None else float(mod.momentum)
+        nat.call("u3d_bn_finalize", dev.index, _stream(dev), _p(st0), C0, sc0, _p(st1), C1, sc1, N, count, _p(mod.weight.detach()),
+                 _p(mod.bias.detach()), float(mod.eps), 1 if training else 0, momentum, _p(mod.running_mean), _p(mod.running_var),
+                 _p(affine), _p(mean_rstd))
+        return mean_rstd
+
+    def _norm_bwd_finalize(self, cx, rec: ConvRec, gst, N, C, count, coef):
+        dev, gview = cx.dev, cx.gview
+        if rec.norm == "g":
+            nat.call("u3d_gn_bwd_finalize", dev.index, _stream(dev), _p(gst), _p(rec.mean_rstd), _p(rec.gn_w.detach()), N, C, rec.G,
+                     count, _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef))
+        else:
+            nat.call("u3d_bn_bwd_finalize", dev.index, _stream(dev), _p(gst), _p(rec.mean_rstd), _p(rec.gn_w.detach()), N, C, count,
+                     1 if rec.bn_training else 0, _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef))
+
     def _single_conv_fwd(self, sc, name, src: VSrc, st_in, pool: _StatPool, tape: Optional[Tape], want_stats=True,
                          residual: Optional[torch.Tensor] = None, sub=(), y_out: Optional[torch.Tensor] = None, act=None):
         """One SingleConv (buildingblocks.py:99-135) in any native order (parse_order): 'gcr' = GroupNorm -> Conv3d -> ReLU fully
         fused; other non-linearities / GroupNorm after the conv add one bandwidth pass (csrc/u3d_act.hip).  With `residual`:
         f(conv(GN(x)) + residual), the tail of ResNetBlock.forward (buildingblocks.py:277-288; `act` = the block's f)."""
         dev = src.t0.device
-        gn, conv = sc.groupnorm, sc.conv
+        conv = sc.conv
+        spec = layer_spec(sc.order)
+        gn = getattr(sc, "groupnorm", None) if spec.norm == "g" else (getattr(sc, "batchnorm", None) if spec.norm == "b" else None)
         N, D, H, W = src.N, src.D, src.H, src.W
-        Ctot, Cout, G = src.C, conv.out_channels, gn.num_groups
-        post, act0, slope0 = parse_order(sc.order)
-        act, slope = (act0, slope0) if act is None else act
-        inner, islope = parse_inner(sc.order)  # 'crg' family: non-linearity on the conv output BEFORE its GroupNorm
-        assert conv.in_channels == Ctot and gn.num_channels == (Cout if post else Ctot)
+        Ctot, Cout = src.C, conv.out_channels
+        G = gn.num_groups if spec.norm == "g" else 1
+        post = not spec.pre  # the conv input has no norm of its own (post-norm and norm-free layers)
+        act, slope = (spec.act, spec.slope) if act is None else act
+        inner, islope = spec.inner, spec.islope  # 'crg' family: non-linearity on the conv output BEFORE its norm
+        assert conv.in_channels == Ctot and (gn is None or getattr(gn, "num_channels", getattr(gn, "num_features", None)) == (Cout if post else Ctot))
         relu = 1 if ((act == ACT_RELU and not post) or inner == ACT_RELU) else 0
         # `out += residual` follows the block's last GroupNorm: inside the conv epilogue for pre-norm orders, in the
         # GroupNorm-apply pass for post-norm orders
         conv_res = None if post else residual
         # the conv epilogue's statistics describe the conv OUTPUT: they are the next GroupNorm's input only when nothing
         # else transforms it (ReLU is in the epilogue); a post-norm layer needs them for its own GroupNorm
-        want_stats = (post and inner in (ACT_NONE, ACT_RELU)) or (not post and want_stats and act in (ACT_NONE, ACT_RELU))
+        want_stats = ((post and spec.norm is not None and inner in (ACT_NONE, ACT_RELU))
+                      or (not post and want_stats and act in (ACT_NONE, ACT_RELU)))
+        bn_training = bool(gn.training) if spec.norm == "b" else True
         if post:
             affine, mean_rstd = self._identity_affine(N, Ctot, dev), None
         else:
             st0, C0, sc0, st1, C1, sc1 = st_in
             affine = _empty((N, Ctot, 2), dtype=_F32, device=dev)
-            mean_rstd = _empty((N, G, 2), dtype=_F32, device=dev)
-            nat.call("u3d_gn_finalize", dev.index, _stream(dev), _p(st0), C0, sc0, _p(st1), C1, sc1, N, G,
-                     float(D * H * W), _p(gn.weight.detach()), _p(gn.bias.detach()), float(gn.eps), _p(affine), _p(mean_rstd))
+            mean_rstd = self._norm_finalize(spec.norm, gn, st0, C0, sc0, st1, C1, sc1, N, G, float(D * H * W), affine, dev)
         # y_out: recomputation under activation checkpointing rewrites the (still alive) block output in place with the
         # bit-identical values instead of allocating a second copy
         y = y_out if (y_out is not None and not post) else _empty((N, D, H, W, Cout), dtype=_F32, device=dev)
@@ -791,12 +854,14 @@ class UNet3DEngine:
             if inner in (ACT_LEAKY, ACT_ELU):
                 nat.call("u3d_act_fwd", dev.index, _stream(dev), _p(y), y.numel(), inner, islope, _p(y))
             z, zst = y, ystats
-            if zst is None:
-                zst = self._stats_of(VSrc(z), None, None, pool, dev)[0]
             aff2 = _empty((N, Cout, 2), dtype=_F32, device=dev)
-            mean_rstd = _empty((N, G, 2), dtype=_F32, device=dev)
-            nat.call("u3d_gn_finalize", dev.index, _stream(dev), _p(zst), Cout, 1.0, None, 0, 0.0, N, G, float(D * H * W),
-                     _p(gn.weight.detach()), _p(gn.bias.detach()), float(gn.eps), _p(aff2), _p(mean_rstd))
+            if spec.norm is None:
+                # no norm: the conv's bias (buildingblocks.py:54-55) is the constant affine (1, bias)
+                nat.call("u3d_bias_table", dev.index, _stream(dev), _p(conv.bias.detach()), N, Cout, _p(aff2))
+            else:
+                if zst is None and (spec.norm == "g" or bn_training):
+                    zst = self._stats_of(VSrc(z), None, None, pool, dev)[0]
+                mean_rstd = self._norm_finalize(spec.norm, gn, zst, Cout, 1.0, None, 0, 0.0, N, G, float(D * H * W), aff2, dev)
             y = y_out if y_out is not None else _empty_like(z)
             nat.call("u3d_affine_add_act_fwd", dev.index, _stream(dev), _p(z), _p(aff2), _p(residual), N, D * H * W, Cout, act,
                      slope, _p(y))
@@ -804,12 +869,35 @@ class UNet3DEngine:
         elif act in (ACT_LEAKY, ACT_ELU):
             nat.call("u3d_act_fwd", dev.index, _stream(dev), _p(y), y.numel(), act, slope, _p(y))
             ystats = None
+        drop_rec = None
+        dmod = getattr(sc, "dropout", None) if spec.drop == "d" else (getattr(sc, "dropout2d", None) if spec.drop == "D" else None)
+        if dmod is not None and dmod.training and dmod.p > 0.0:
+            # The MASK comes from torch's generator exactly as the reference draws it (F.dropout on an NCDHW tensor of this
+            # shape / feature_dropout's (N,C,1,1,1) noise: same Philox consumption, same element order), applied natively.
+            if spec.drop == "d":
+                m = F.dropout(torch.ones((N, Cout, D, H, W), dtype=_F32, device=dev), dmod.p, True)
+                if Cout == 1:
+                    mask = m.view(N, D, H, W, 1)
+                else:
+                    mask = _empty((N, D, H, W, Cout), dtype=_F32, device=dev)
+                    nat.call("u3d_ncdhw_to_ndhwc", dev.index, _stream(dev), _p(m), _p(mask), N, Cout, D * H * W)
+                nat.call("u3d_mul", dev.index, _stream(dev), _p(y), _p(mask), y.numel(), _p(y))
+                drop_rec = ("d", mask)
+            else:
+                m = torch.feature_dropout(torch.ones((N, Cout, 1, 1, 1), dtype=_F32, device=dev), dmod.p, True).view(N, Cout)
+                table = torch.stack((m, torch.zeros_like(m)), dim=-1).contiguous()
+                nat.call("u3d_affine_act_fwd", dev.index, _stream(dev), _p(y), _p(table), N, D * H * W, Cout, ACT_NONE, 0.0, _p(y))
+                drop_rec = ("D", table)
+            ystats = None  # the epilogue's sums describe the tensor before the dropout
         if tape is not None:
+            nw = gn.weight if gn is not None else None
             tape.convs.append(
-                ConvRec(name, src, affine, mean_rstd, y, gn.weight, conv.weight, G, self._pindex[id(gn.weight)],
-                        self._pindex[id(gn.bias)], self._pindex[id(conv.weight)], small,
+                ConvRec(name, src, affine, mean_rstd, y, nw, conv.weight, G,
+                        self._pindex[id(gn.weight)] if gn is not None else -1,
+                        self._pindex[id(gn.bias)] if gn is not None else self._pindex[id(conv.bias)],
+                        self._pindex[id(conv.weight)], small,
                         sub.get(id(conv.weight)) if (sub and src.t1 is not None and residual is None) else None,
-                        not post, post_rec)
+                        not post, post_rec, spec.norm, bn_training, drop_rec)
             )
         return y, ystats
 
@@ -820,19 +908,31 @@ class UNet3DEngine:
         src = rec.src
         Nn, Dd, Hh, Ww = src.N, src.D, src.H, src.W
         Cout = rec.y.shape[-1]
+        if rec.drop is not None:
+            # trailing dropout: the consumers already removed f through the (rescaled, sign-preserving) layer output
+            kind, mask = rec.drop
+            g = _empty_like(dz_)
+            if kind == "d":
+                nat.call("u3d_mul", dev.index, _stream(dev), _p(dz_), _p(mask), dz_.numel(), _p(g))
+            else:
+                nat.call("u3d_affine_act_fwd", dev.index, _stream(dev), _p(dz_), _p(mask), Nn, Dd * Hh * Ww, Cout, ACT_NONE, 0.0, _p(g))
+            dz_ = g
         if rec.post is not None:
-            # post-norm layer: dz_ is the gradient w.r.t. n = a*z + b (the caller removed the non-linearity): GroupNorm backward
+            # post-norm layer: dz_ is the gradient w.r.t. n = a*z + b (the caller removed the non-linearity): norm backward
             # over the conv output z first — sums (sum dn, sum dn*z), parameter gradients, dz = p*dn + q*z + r
             z, _, inner, islope = rec.post
             Vz = Dd * Hh * Ww
             gst2 = pool.take(Nn * Cout * 2)
             nat.call("u3d_pair_stats", dev.index, _stream(dev), _p(dz_), _p(z), Nn, Vz, Cout, _p(gst2))
-            coef2 = _empty((Nn, 3, Cout), dtype=_F32, device=dev)
-            nat.call("u3d_gn_bwd_finalize", dev.index, _stream(dev), _p(gst2), _p(rec.mean_rstd), _p(rec.gn_w.detach()), Nn, Cout,
-                     rec.G, float(Vz), _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef2))
-            dz_ = self._plain_apply(cx, dz_, coef2, z, 1 if inner == ACT_RELU else 0)  # ('crg': z = relu(conv), mask fused)
-            if inner in (ACT_LEAKY, ACT_ELU):
-                nat.call("u3d_act_bwd", dev.index, _stream(dev), _p(dz_), _p(z), dz_.numel(), inner, islope, _p(dz_))
+            if rec.norm is None:
+                # norm-free layer: n = z + bias -> dbias = sum dn, dz = dn
+                nat.call("u3d_bias_grad", dev.index, _stream(dev), _p(gst2), Nn, Cout, _p(gview(rec.idx_gb)))
+            else:
+                coef2 = _empty((Nn, 3, Cout), dtype=_F32, device=dev)
+                self._norm_bwd_finalize(cx, rec, gst2, Nn, Cout, float(Vz), coef2)
+                dz_ = self._plain_apply(cx, dz_, coef2, z, 1 if inner == ACT_RELU else 0)  # ('crg': z = relu(conv), mask fused)
+                if inner in (ACT_LEAKY, ACT_ELU):
+                    nat.call("u3d_act_bwd", dev.index, _stream(dev), _p(dz_), _p(z), dz_.numel(), inner, islope, _p(dz_))
         if self.debug is not None:
             self.debug[rec.name + ".dz"] = dz_.clone()
         if rec.small and not need_dg:
@@ -844,8 +944,7 @@ class UNet3DEngine:
             if not rec.pre_norm:
                 return None, self._identity_coef(Nn, src.C, dev)
             coef = _empty((Nn, 3, src.C), dtype=_F32, device=dev)
-            nat.call("u3d_gn_bwd_finalize", dev.index, _stream(dev), _p(gst), _p(rec.mean_rstd), _p(rec.gn_w.detach()), Nn,
-                     src.C, rec.G, float(Dd * Hh * Ww), _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef))
+            self._norm_bwd_finalize(cx, rec, gst, Nn, src.C, float(Dd * Hh * Ww), coef)
             return None, coef
         s_aff = src.struct(rec.affine)
         flops = 54.0 * src.C * Cout * Nn * Dd * Hh * Ww
@@ -932,8 +1031,7 @@ class UNet3DEngine:
         if not rec.pre_norm:
             return dg, self._identity_coef(Nn, src.C, dev)  # no GroupNorm on the conv input: dx = dg
         coef = _empty((Nn, 3, src.C), dtype=_F32, device=dev)
-        nat.call("u3d_gn_bwd_finalize", dev.index, _stream(dev), _p(gst), _p(rec.mean_rstd), _p(rec.gn_w.detach()), Nn, src.C,
-                 rec.G, float(Dd * Hh * Ww), _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef))
+        self._norm_bwd_finalize(cx, rec, gst, Nn, src.C, float(Dd * Hh * Ww), coef)
         return dg, coef
 
     def _plain_apply(self, cx, dg, coef, x, relu_mask, add=None):

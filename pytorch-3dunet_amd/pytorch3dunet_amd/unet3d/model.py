@@ -64,7 +64,10 @@ class AbstractUNet(nn.Module):
 
         self.layer_order = layer_order
         if parse_order(layer_order) is None:
-            reasons.append(f"layer_order '{layer_order}' (native: one GroupNorm before or after the conv + optional final r/l/e)")
+            reasons.append(f"layer_order '{layer_order}' (native: conv with at most one GroupNorm / BatchNorm before or after it, "
+                           "one non-linearity, a trailing dropout)")
+        elif basic_module in (ResNetBlock, ResNetBlockSE) and any(ch in layer_order for ch in "dD"):
+            reasons.append(f"layer_order '{layer_order}': dropout inside residual blocks")
         if conv_kernel_size != 3 or conv_padding != 1:
             reasons.append("conv kernel/padding other than 3/1")
         if pool_kernel_size != 2:

@@ -299,3 +299,115 @@ def test_unet3d_interpolating_upsampling_native(mode, order, cfg, shape, monkeyp
     pr, lr = orc.model_forward(sd, xr, G, fs, True, order=order, upsample=mode)
     loss_by_name(loss_name, pr, lr, target).backward()
     assert orc.rel_err(xd.grad.cpu(), xr.grad) < 2e-2
+
+
+@pytest.mark.parametrize("order", ["bcr", "cbr", "crb", "cbl", "cr", "cl", "ce", "c"])
+@pytest.mark.parametrize("cls,cfg,shape,loss_name", [
+    ("UNet3D", dict(in_channels=1, out_channels=1, f_maps=16, num_levels=3, num_groups=8), (2, 1, 16, 32, 32), "bce_dice"),
+    ("UNet3D", dict(in_channels=2, out_channels=3, f_maps=[8, 16, 32], num_groups=4, final_sigmoid=False), (2, 2, 9, 13, 11), "probs_sum"),
+    ("ResidualUNet3D", dict(in_channels=2, out_channels=2, f_maps=[8, 16, 32], num_groups=4, final_sigmoid=False), (2, 2, 10, 12, 14), "probs_sum"),
+])
+def test_batchnorm_and_norm_free_orders_native(order, cls, cfg, shape, loss_name, monkeypatch):
+    """'b' = nn.BatchNorm3d (batch statistics over N x voxels, running-estimate update, eval mode on the running estimates) and the
+    norm-free orders 'cr' / 'cl' / 'ce' / 'c' (conv WITH bias) of create_conv (buildingblocks.py:10-96), on the native path.
+    Gradient gate: see REL_GRAD — a run whose distance exceeds it (decision flips; measured 'cbr': seed 53 1e-2 in the encoders only,
+    seed 54 clean to 1e-4, seed 55 3e-3 everywhere) is repeated with the next seed; every run must stay below the gross-error bound
+    5e-2 and one of three must be clean."""
+    import unet3d_oracle as orc
+    from pytorch3dunet_amd.unet3d import model as M
+
+    monkeypatch.setenv("U3D_STRICT", "1")
+    G, fs = cfg["num_groups"], cfg.get("final_sigmoid", True)
+    clean = False
+    for seed in (53, 54, 55):
+        torch.manual_seed(seed)
+        model = getattr(M, cls)(layer_order=order, **cfg)
+        assert model.native_supported, model._native_blockers
+        with torch.no_grad():
+            for k, p in model.named_parameters():
+                if "batchnorm" in k or k.endswith("conv.bias"):
+                    p.add_(0.2 * torch.randn_like(p))
+        x = torch.randn(shape)
+        target = (torch.rand((shape[0], cfg["out_channels"]) + shape[2:]) > 0.5).float()
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        bufs = {}
+        p32, l32, v32, g32 = orc.forward_backward(sd, x, target, G, fs, True, loss_name, order=order, buffers_out=bufs)
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        _, _, _, g64 = orc.forward_backward(sd64, x.double(), target.double(), G, fs, True, loss_name, order=order)
+        model = model.to(U.DEV).train()
+        probs, logits = model(x.to(U.DEV), return_logits=True)
+        loss = loss_by_name(loss_name, probs, logits, target.to(U.DEV))
+        model.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        assert orc.rel_err(logits.detach().cpu(), l32) < REL and orc.rel_err(probs.detach().cpu(), p32) < REL
+        keys = list(g32)
+        ours = torch.cat([dict(model.named_parameters())[k].grad.detach().cpu().double().flatten() for k in keys])
+        r32 = torch.cat([g32[k].double().flatten() for k in keys])
+        r64 = torch.cat([g64[k].flatten() for k in keys])
+        e_ours, e_ref = ((ours - r64).norm() / r64.norm()).item(), ((r32 - r64).norm() / r64.norm()).item()
+        diag(test="orders_bn_bias", cls=cls, order=order, shape=list(shape), seed=seed, ours_vs_fp64=e_ours, ref32_vs_fp64=e_ref)
+        assert e_ours < 5e-2, (order, seed, e_ours)
+        # running estimates after the training forward (momentum 0.1, unbiased variance, num_batches_tracked)
+        after = model.state_dict()
+        for k, v in bufs.items():
+            if v.is_floating_point():
+                assert torch.allclose(after[k].cpu(), v, rtol=1e-4, atol=1e-6), k
+            else:  # num_batches_tracked: incremented by the nn.Module (F.batch_norm in the oracle does not touch it)
+                assert int(after[k]) == int(sd[k]) + 1, k
+        if e_ours <= max(REL_GRAD, 3.0 * e_ref):
+            for k in keys:
+                g = dict(model.named_parameters())[k].grad.detach().cpu().double()
+                assert ((g - g64[k]).norm() / g64[k].norm().clamp_min(1e-3 * r64.norm())).item() < max(5e-3, 20 * e_ref), k
+            clean = True
+            break
+    assert clean, (order, "no clean run in three seeds")
+    # eval mode: BatchNorm on the running estimates
+    model.eval()
+    with torch.no_grad():
+        pe, le = model(x.to(U.DEV), return_logits=True)
+    orc.TRAINING = False
+    try:
+        pr, lr = orc.model_forward({k: v.cpu() for k, v in after.items()}, x, G, fs, True, order=order)
+    finally:
+        orc.TRAINING = True
+    assert orc.rel_err(le.cpu(), lr) < REL
+
+
+@pytest.mark.parametrize("order", ["gcrd", "gcrD", "cgld", "crd", "bcrD"])
+def test_trailing_dropout_native_draws_the_reference_masks(order, monkeypatch):
+    """'d' nn.Dropout / 'D' nn.Dropout2d (per-(sample, channel) on 5-D inputs) as the last operation of a layer
+    (buildingblocks.py:89-92): the native path draws its masks from torch's generator exactly as the module tree does, so with
+    the same seed both paths see the SAME masks and must agree like two fp32 implementations"""
+    from pytorch3dunet_amd.unet3d.model import UNet3D
+
+    cfg = dict(in_channels=1, out_channels=1, f_maps=[16, 32], num_groups=8, layer_order=order, dropout_prob=0.25)
+    torch.manual_seed(61)
+    model = UNet3D(**cfg).to(U.DEV).train()
+    assert model.native_supported, model._native_blockers
+    x = torch.randn(2, 1, 8, 16, 16, device=U.DEV)
+    target = (torch.rand(2, 1, 8, 16, 16, device=U.DEV) > 0.5).float()
+    res = {}
+    for tag in ("native", "tree"):
+        blockers = model._native_blockers
+        if tag == "tree":
+            model._native_blockers = ["forced module tree (test)"]
+        torch.manual_seed(1234)
+        n0 = nat.launch_count
+        probs, logits = model(x, return_logits=True)
+        loss = loss_by_name("bce_dice", probs, logits, target)
+        model.zero_grad()
+        loss.backward()
+        assert (nat.launch_count > n0) == (tag == "native")
+        res[tag] = (logits.detach().clone(), torch.cat([p.grad.flatten() for p in model.parameters()]).clone())
+        model._native_blockers = blockers
+    (la, ga), (lb, gb) = res["native"], res["tree"]
+    assert ((la - lb).norm() / lb.norm()).item() < 1e-4                   # same masks: fp32-level agreement
+    assert ((ga - gb).norm() / gb.norm()).item() < REL_GRAD
+    frac_zero = float((la == 0).float().mean())
+    assert frac_zero < 0.5
+    # eval mode: dropout is the identity, the stochastic and the deterministic forward differ
+    model.eval()
+    with torch.no_grad():
+        e1, e2 = model(x), model(x)
+    assert torch.equal(e1, e2)

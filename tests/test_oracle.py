@@ -201,6 +201,32 @@ def test_ordered_residual_oracle_matches_live_reference(name, order):
 
 
 @pytest.mark.skipif(not reference_available(), reason="/root/reference only exists in the build container")
+@pytest.mark.parametrize("name", ["UNet3D", "ResidualUNet3D"])
+@pytest.mark.parametrize("order", ["bcr", "cbr", "crb", "cbl", "cr", "cl", "ce", "c"])
+def test_batchnorm_and_norm_free_oracle_matches_live_reference(name, order):
+    """'b' = nn.BatchNorm3d (buildingblocks.py:78-88; the reference's one 'bcr' YAML is 2-D) incl. the running-estimate update of
+    a training forward, and the norm-free orders of create_conv's docstring ('cr', 'cl', 'ce': conv WITH bias, :54-55)"""
+    ref = import_reference()
+    cfg = dict(name=name, in_channels=2, out_channels=2, f_maps=[8, 16], num_groups=4, layer_order=order, final_sigmoid=False)
+    torch.manual_seed(19)
+    model = ref.get_model(dict(cfg)).train()
+    x = torch.randn(2, 2, 8, 12, 10)
+    target = (torch.rand(2, 2, 8, 12, 10) > 0.5).float()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    probs_r, logits_r = model(x, return_logits=True)
+    ((probs_r * target).sum() + 0.5 * (logits_r * logits_r).mean()).backward()
+    bufs = {}
+    probs, logits, _, grads = orc.forward_backward(sd, x, target, 4, False, True, "probs_sum", order=order, buffers_out=bufs)
+    assert orc.rel_err(logits, logits_r.detach()) < 1e-6 and orc.rel_err(probs, probs_r.detach()) < 1e-6
+    for k, p in model.named_parameters():
+        assert orc.rel_err(grads[k], p.grad) < 2e-5, k
+    after = model.state_dict()
+    for k, v in bufs.items():
+        if v.is_floating_point():
+            assert torch.allclose(v, after[k], rtol=1e-6, atol=1e-7), k
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference only exists in the build container")
 @pytest.mark.parametrize("mode", ["trilinear", "area"])
 def test_interpolating_oracle_matches_live_reference(mode):
     """upsample: trilinear / area (InterpolateUpsampling, buildingblocks.py:598-614) on a ragged size"""
