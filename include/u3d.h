@@ -457,6 +457,13 @@ int u3d_resample2_bwd(int device, u3d_stream_t stream, const float* dout, const 
                       const int32_t* rng_x, const int32_t* idx_z, const int32_t* idx_y, const int32_t* idx_x, const float* wt_z,
                       const float* wt_y, const float* wt_x, int N, int D1, int H1, int W1, int D, int H, int W, int C, float* dx);
 
+/* ---- concat joining for residual decoders with an explicit upsample='deconv' (buildingblocks.py:435-468, :491): the joined
+ * tensor out (N,D,H,W,Cs+Ct) = cat(skip, nearest-resized t) feeds the block's 1x1x1 convolution; u3d_split_channels is its
+ * backward routing (skip gradient | gradient of the resized tensor). */
+int u3d_nearest_cat_fwd(int device, u3d_stream_t stream, const float* skip, const float* t, const int32_t* zmap, const int32_t* ymap,
+                        const int32_t* xmap, int N, int D, int H, int W, int Dt, int Ht, int Wt, int Cs, int Ct, float* out);
+int u3d_split_channels(int device, u3d_stream_t stream, const float* x, int64_t rows, int C0, int C1, float* out0, float* out1);
+
 /* ---- the remaining layer-order characters (create_conv, buildingblocks.py:10-96): 'b' nn.BatchNorm3d (:78-88), the conv bias of
  * layers without a norm (:54-55: 'cr', 'cl', 'ce', 'c'), 'd' / 'D' dropout (:89-92).
  *   u3d_bn_finalize      per-(n,c) sums (as u3d_gn_finalize: two channel ranges with scales) -> per-CHANNEL batch mean / biased

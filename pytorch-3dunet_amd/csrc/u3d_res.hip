@@ -616,3 +616,75 @@ static int nearest_sum_impl(int device, u3d_stream_t stream, const float* dj, co
     U3D_LAUNCH_CHECK();
     return 0;
 }
+
+
+// ---- concat joining for residual decoders with an EXPLICIT upsample='deconv' (buildingblocks.py:435-468: only 'default' selects
+// summation joining; an explicit 'deconv' keeps torch.cat((skip, upsampled)) and the block's 1x1x1 conv maps the 2x channels back).
+// The joined tensor feeds a 1x1x1 convolution, so it is materialised: out[..., :Cs] = skip, out[..., Cs:] = t[zmap, ymap, xmap].
+namespace {
+
+__global__ void nearest_cat_kernel(const float* __restrict__ skip, const float* __restrict__ t, const int32_t* __restrict__ zmap,
+                                   const int32_t* __restrict__ ymap, const int32_t* __restrict__ xmap, int N, int D, int H, int W,
+                                   int Dt, int Ht, int Wt, int Cs, int Ct, float* __restrict__ out) {
+    const int C = Cs + Ct;
+    const long long total = (long long)N * D * H * W * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long v = i / C;
+        if (c < Cs) {
+            out[i] = skip[v * Cs + c];
+            continue;
+        }
+        const int x = (int)(v % W);
+        long long r = v / W;
+        const int y = (int)(r % H);
+        r /= H;
+        const int z = (int)(r % D);
+        const int n = (int)(r / D);
+        out[i] = t[((((size_t)n * Dt + zmap[z]) * Ht + ymap[y]) * Wt + xmap[x]) * Ct + (c - Cs)];
+    }
+}
+
+__global__ void split_channels_kernel(const float* __restrict__ x, long long rows, int C0, int C1, float* __restrict__ out0,
+                                      float* __restrict__ out1) {
+    const int C = C0 + C1;
+    const long long total = rows * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long long v = i / C;
+        if (c < C0)
+            out0[v * C0 + c] = x[i];
+        else
+            out1[v * C1 + (c - C0)] = x[i];
+    }
+}
+
+}  // namespace
+
+extern "C" int u3d_nearest_cat_fwd(int device, u3d_stream_t stream, const float* skip, const float* t, const int32_t* zmap,
+                                   const int32_t* ymap, const int32_t* xmap, int N, int D, int H, int W, int Dt, int Ht, int Wt,
+                                   int Cs, int Ct, float* out) {
+    U3D_ENTER(device);
+    U3D_REQUIRE(skip && t && zmap && ymap && xmap && out && N > 0 && D > 0 && H > 0 && W > 0 && Dt > 0 && Ht > 0 && Wt > 0 && Cs > 0 &&
+                    Ct > 0, "u3d_nearest_cat_fwd: bad argument");
+    const long long total = (long long)N * D * H * W * (Cs + Ct);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 32768) blocks = 32768;
+    hipLaunchKernelGGL(nearest_cat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, skip, t, zmap, ymap, xmap, N, D, H,
+                       W, Dt, Ht, Wt, Cs, Ct, out);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int u3d_split_channels(int device, u3d_stream_t stream, const float* x, int64_t rows, int C0, int C1, float* out0,
+                                  float* out1) {
+    U3D_ENTER(device);
+    U3D_REQUIRE(x && out0 && out1 && rows > 0 && C0 > 0 && C1 > 0, "u3d_split_channels: bad argument");
+    const long long total = (long long)rows * (C0 + C1);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 32768) blocks = 32768;
+    hipLaunchKernelGGL(split_channels_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)rows, C0, C1, out0,
+                       out1);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}

@@ -253,6 +253,8 @@ _PROTOS = {
     "u3d_affine_add_act_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_float, c_void_p]),
     "u3d_resample2_fwd": (c_int, [c_int, c_void_p] + [c_void_p] * 7 + [c_int] * 8 + [c_void_p]),
     "u3d_resample2_bwd": (c_int, [c_int, c_void_p] + [c_void_p] * 10 + [c_int] * 8 + [c_void_p]),
+    "u3d_nearest_cat_fwd": (c_int, [c_int, c_void_p] + [c_void_p] * 5 + [c_int] * 9 + [c_void_p]),
+    "u3d_split_channels": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "u3d_bn_finalize": (c_int, [c_int, c_void_p, c_void_p, c_int, c_double, c_void_p, c_int, c_double, c_int, c_double, c_void_p,
                                 c_void_p, c_float, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "u3d_bn_bwd_finalize": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_double, c_int, c_void_p, c_void_p,

@@ -1369,6 +1369,7 @@ class UpRec:
     los: tuple            # children tables of the nearest resize (2n-1 -> skip size)
     tdims: tuple          # (Dt, Ht, Wt)
     t8: bool = False      # ran in space-to-depth form on the bf16 kernels (csrc/u3d_bf16.hip)
+    concat: Optional[tuple] = None  # explicit upsample='deconv' on a residual net: concat joining, (Cs skip, Ct upsampled) channels
 
 
 class ResUNetEngine(UNet3DEngine):
@@ -1396,6 +1397,8 @@ class ResUNetEngine(UNet3DEngine):
     def _build_layer_table(self, model):
         self.enc = [(e.pooling is not None, e.basic_module) for e in model.encoders]
         self.dec = [(d.upsampling.upsample.conv_transposed, d.basic_module) for d in model.decoders]
+        # explicit upsample='deconv' (buildingblocks.py:435-468): concat joining and a 1x1x1 conv in the block instead of the sum
+        self.dec_concat = [bool(getattr(d, "concat", False)) for d in model.decoders]
 
     # -- forward ------------------------------------------------------------------------------------
     def _block_fwd(self, bm, name, x_in, x_st, pool, tape, dev, y_out=None):
@@ -1546,10 +1549,12 @@ class ResUNetEngine(UNet3DEngine):
             Nl, D1, H1, W1, Cl = cur.shape
             _, Ds, Hs, Ws, Cs = sk.shape
             Dt, Ht, Wt = 2 * D1 - 1, 2 * H1 - 1, 2 * W1 - 1
-            t8 = self._convtr_t8(Cl, Cs)
+            concat = self.dec_concat[j]
+            Ct = ct.out_channels  # (== Cs for summation joining)
+            t8 = self._convtr_t8(Cl, Cs) and not concat
             (mz, lz), (my, ly), (mx, lx) = _maps(dev, Dt, Ds), _maps(dev, Ht, Hs), _maps(dev, Wt, Ws)
-            joined = _empty_like(sk)
-            j_st = pool.take(Nl * Cs * 2)
+            joined = _empty((Nl, Ds, Hs, Ws, Cs + Ct), dtype=_F32, device=dev) if concat else _empty_like(sk)
+            j_st = None if concat else pool.take(Nl * Cs * 2)
             if t8:
                 # bf16 mode: 2x2x2 convolution on the low-res grid into the space-to-depth layout T8[i][parity*Cs + c] = t[2i + parity];
                 # the resize + join reads that layout directly
@@ -1563,19 +1568,23 @@ class ResUNetEngine(UNet3DEngine):
                     tape.ups.append(UpRec(cur, ct.weight, (lz, ly, lx), (Dt, Ht, Wt), True))
                 cur = self._block_fwd(bm, f"dec{j}", joined, j_st, pool, tape, dev)
                 continue
-            t = _empty((Nl, Dt, Ht, Wt, Cs), dtype=_F32, device=dev)
-            if self.subpixel and Cl % 4 == 0 and Cs % 4 == 0:
+            t = _empty((Nl, Dt, Ht, Wt, Ct), dtype=_F32, device=dev)
+            if self.subpixel and Cl % 4 == 0 and Ct % 4 == 0:
                 # 8 output parity classes accumulated from one staged input halo tile (csrc/u3d_subpix.hip, scheme Deconv3s2)
                 nat.call("u3d_convtr3d_fwd_subpixel", dev.index, _stream(dev), _p(cur), _p(self._packed_convtr(ct.weight, 2, dev)),
-                         _p(t), Nl, D1, H1, W1, Cl, Cs, flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
+                         _p(t), Nl, D1, H1, W1, Cl, Ct, flops=2.0 * 27 * Cl * Ct * Nl * D1 * H1 * W1)
             else:
                 nat.call("u3d_convtr3d_fwd", dev.index, _stream(dev), _p(cur), _p(ct.weight.detach()), _p(t), Nl, D1, H1, W1, Cl,
-                         Cs, _p(self._packed_convtr(ct.weight, 0, dev)), flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
-            nat.call("u3d_nearest_add_fwd", dev.index, _stream(dev), _p(sk), _p(t), _p(mz), _p(my), _p(mx), Nl, Ds, Hs, Ws, Dt, Ht,
-                     Wt, Cs, _p(joined), _p(j_st))
+                         Ct, _p(self._packed_convtr(ct.weight, 0, dev)), flops=2.0 * 27 * Cl * Ct * Nl * D1 * H1 * W1)
+            if concat:
+                nat.call("u3d_nearest_cat_fwd", dev.index, _stream(dev), _p(sk), _p(t), _p(mz), _p(my), _p(mx), Nl, Ds, Hs, Ws, Dt, Ht,
+                         Wt, Cs, Ct, _p(joined))
+            else:
+                nat.call("u3d_nearest_add_fwd", dev.index, _stream(dev), _p(sk), _p(t), _p(mz), _p(my), _p(mx), Nl, Ds, Hs, Ws, Dt, Ht,
+                         Wt, Cs, _p(joined), _p(j_st))
             del t
             if tape is not None:
-                tape.ups.append(UpRec(cur, ct.weight, (lz, ly, lx), (Dt, Ht, Wt)))
+                tape.ups.append(UpRec(cur, ct.weight, (lz, ly, lx), (Dt, Ht, Wt), False, (Cs, Ct) if concat else None))
             cur = self._block_fwd(bm, f"dec{j}", joined, j_st, pool, tape, dev)
 
         fc = m.final_conv
@@ -1613,6 +1622,22 @@ class ResUNetEngine(UNet3DEngine):
         del dz2
         # r feeds conv2's GroupNorm AND the `out += residual` shortcut; r itself is linear (no ReLU mask)
         return self._plain_apply(cx, dg2, coef2, rec.r, 0, add=m_)
+
+    def _conv1_bwd(self, cx, rec: ResRec, dr, need_dx: bool):
+        """the block's 1x1x1 conv with bias (buildingblocks.py:248-255): parameter gradients, and dL/d(block input) if wanted"""
+        dev, pool, gview = cx.dev, cx.pool, cx.gview
+        c1 = rec.conv1
+        Cout_, Cin_ = c1.weight.shape[0], c1.weight.shape[1]
+        xin = rec.x_in
+        acc = pool.take(Cout_ * Cin_ + Cout_)
+        dxin = _empty_like(xin) if need_dx else None
+        nat.call("u3d_conv1x1_bwd", dev.index, _stream(dev), _p(dr), _p(xin), _p(c1.weight.detach().view(Cout_, Cin_)),
+                 xin.shape[0], xin.numel() // (xin.shape[0] * Cin_), Cin_, Cout_, _p(dxin), _p(acc),
+                 flops=(4.0 if need_dx else 2.0) * Cin_ * Cout_ * (xin.numel() // Cin_))
+        jw, jb = self._pindex[id(c1.weight)], self._pindex[id(c1.bias)]
+        assert self.poffs[jb] == self.poffs[jw] + Cout_ * Cin_
+        nat.call("u3d_cvt_f64_f32", dev.index, _stream(dev), _p(acc), _p(gview(jw)), Cout_ * Cin_ + Cout_)
+        return dxin
 
     def backward(self, tape: Tape, dlogits: torch.Tensor, need_input_grad: bool):
         m = self.model
@@ -1658,9 +1683,21 @@ class ResUNetEngine(UNet3DEngine):
 
         for j in range(n_dec - 1, -1, -1):
             rec, up = dec_blocks[j], tape.ups[j]
-            dj = self._block_bwd(cx, rec, dz)  # gradient of the joined tensor (conv1 is nn.Identity in decoders)
-            assert rec.conv1 is None
-            skip_grad[n_levels - 2 - j] = dj   # summation joining: the skip receives dj as is
+            dj = self._block_bwd(cx, rec, dz)  # gradient of the block's residual r (= the joined tensor when conv1 is nn.Identity)
+            if up.concat is not None:
+                # concat joining: through the block's 1x1x1 conv, then split into the skip's and the resized tensor's gradient
+                Cs_, Ct_ = up.concat
+                dcat = self._conv1_bwd(cx, rec, dj, True)
+                d_skip = _empty(dcat.shape[:-1] + (Cs_,), dtype=_F32, device=dev)
+                d_up = _empty(dcat.shape[:-1] + (Ct_,), dtype=_F32, device=dev)
+                nat.call("u3d_split_channels", dev.index, _stream(dev), _p(dcat), dcat.numel() // (Cs_ + Ct_), Cs_, Ct_, _p(d_skip),
+                         _p(d_up))
+                skip_grad[n_levels - 2 - j] = d_skip
+                dj = d_up
+                del dcat
+            else:
+                assert rec.conv1 is None
+                skip_grad[n_levels - 2 - j] = dj   # summation joining: the skip receives dj as is
             xl = up.x_low
             Nl, D1, H1, W1, Cl = xl.shape
             _, Ds, Hs, Ws, Cs = dj.shape
@@ -1710,17 +1747,7 @@ class ResUNetEngine(UNet3DEngine):
             dr = self._block_bwd(cx, rec, dz)
             need_dx = i > 0 or need_input_grad
             if rec.conv1 is not None:
-                c1 = rec.conv1
-                Cout_, Cin_ = c1.weight.shape[0], c1.weight.shape[1]
-                xin = rec.x_in
-                acc = pool.take(Cout_ * Cin_ + Cout_)
-                dxin = _empty_like(xin) if need_dx else None
-                nat.call("u3d_conv1x1_bwd", dev.index, _stream(dev), _p(dr), _p(xin), _p(c1.weight.detach().view(Cout_, Cin_)),
-                         xin.shape[0], xin.numel() // (xin.shape[0] * Cin_), Cin_, Cout_, _p(dxin), _p(acc),
-                         flops=(4.0 if need_dx else 2.0) * Cin_ * Cout_ * (xin.numel() // Cin_))
-                jw, jb = self._pindex[id(c1.weight)], self._pindex[id(c1.bias)]
-                assert self.poffs[jb] == self.poffs[jw] + Cout_ * Cin_
-                nat.call("u3d_cvt_f64_f32", dev.index, _stream(dev), _p(acc), _p(gview(jw)), Cout_ * Cin_ + Cout_)
+                dxin = self._conv1_bwd(cx, rec, dr, need_dx)
             else:
                 dxin = dr
             if i > 0:

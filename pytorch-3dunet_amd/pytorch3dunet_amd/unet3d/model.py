@@ -74,9 +74,9 @@ class AbstractUNet(nn.Module):
             reasons.append("pool_kernel_size != 2")
         if basic_module is DoubleConv and upsample not in ("default", "nearest", "deconv", "trilinear", "area"):
             reasons.append(f"upsample '{upsample}'")
-        if basic_module in (ResNetBlock, ResNetBlockSE) and upsample != "default":
-            # an EXPLICIT 'deconv' keeps concat joining and a 1x1x1 conv deep->shallow in the block (buildingblocks.py:441-468:
-            # only 'default' selects summation joining + adapted channels), which the residual executor does not implement
+        if basic_module in (ResNetBlock, ResNetBlockSE) and upsample not in ("default", "deconv"):
+            # (an EXPLICIT 'deconv' keeps concat joining and a 1x1x1 conv deep->shallow in the block, buildingblocks.py:441-468;
+            # the interpolation modes do not even run in the reference for residual nets: tests/test_oracle.py)
             reasons.append(f"upsample '{upsample}' with residual blocks")
         if out_channels > 16 or f_maps[0] > 256:
             reasons.append("head wider than 16 outputs / 256 inputs")

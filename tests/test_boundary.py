@@ -223,17 +223,22 @@ def test_dataparallel_replica_gets_its_own_engine_over_the_broadcast_parameters(
         assert eng2 is not eng and eng2.grad_sync is eng.grad_sync
 
 
-def test_explicit_deconv_on_residual_blocks_is_not_claimed_native():
+def test_explicit_deconv_on_residual_blocks_has_its_own_layout():
     """ResidualUNet3D(upsample='deconv') keeps concat joining + a 1x1x1 conv in the decoder blocks
-    (buildingblocks.py:441-468) — not what the residual executor implements; it must take the module-tree path"""
+    (buildingblocks.py:441-468).  Round 1 wrongly ran it through the summation-joining executor; it is native since round 2
+    through the executor's concat branch (engine.ResUNetEngine.dec_concat; GPU parity in tests/test_gpu_orders.py) — the
+    interpolation modes, which the reference itself cannot run on residual nets, stay on the module tree"""
     import torch
 
     from pytorch3dunet_amd.unet3d.model import ResidualUNet3D
 
     m = ResidualUNet3D(1, 1, f_maps=[8, 16], num_groups=4, upsample="deconv")
-    assert not m.native_supported and m.decoders[0].basic_module.conv1.weight.shape == (8, 16, 1, 1, 1)
+    assert m.native_supported and m.decoders[0].concat and m.decoders[0].basic_module.conv1.weight.shape == (8, 16, 1, 1, 1)
+    assert m._get_engine().dec_concat == [True]
     assert m(torch.randn(1, 1, 4, 8, 8)).shape == (1, 1, 4, 8, 8)
-    assert ResidualUNet3D(1, 1, f_maps=[8, 16], num_groups=4).native_supported
+    d = ResidualUNet3D(1, 1, f_maps=[8, 16], num_groups=4)
+    assert d.native_supported and d._get_engine().dec_concat == [False]
+    assert not ResidualUNet3D(1, 1, f_maps=[8, 16], num_groups=4, upsample="nearest").native_supported
 
 
 def test_tape_stash_roundtrip_keeps_structure_and_references_parameters_by_position():

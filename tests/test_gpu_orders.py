@@ -411,3 +411,54 @@ def test_trailing_dropout_native_draws_the_reference_masks(order, monkeypatch):
     with torch.no_grad():
         e1, e2 = model(x), model(x)
     assert torch.equal(e1, e2)
+
+
+@pytest.mark.parametrize("cls,order", [("ResidualUNet3D", "gcr"), ("ResidualUNetSE3D", "gcr"), ("ResidualUNet3D", "cge")])
+@pytest.mark.parametrize("cfg,shape,loss_name", [
+    (dict(in_channels=1, out_channels=1, f_maps=[16, 32, 64], num_groups=8), (1, 1, 16, 32, 32), "bce_dice"),
+    (dict(in_channels=2, out_channels=2, f_maps=[8, 16, 32], num_groups=4, final_sigmoid=False), (2, 2, 9, 13, 11), "probs_sum"),
+])
+def test_residual_nets_with_explicit_deconv_native(cls, order, cfg, shape, loss_name, monkeypatch):
+    """an EXPLICIT upsample='deconv' on residual nets — the only other value the reference can run for them — keeps concat
+    joining and a 1x1x1 conv (deep -> shallow channels) in the decoder blocks (buildingblocks.py:435-468)"""
+    import unet3d_oracle as orc
+    from pytorch3dunet_amd.unet3d import model as M
+
+    monkeypatch.setenv("U3D_STRICT", "1")
+    G, fs = cfg["num_groups"], cfg.get("final_sigmoid", True)
+    clean = False
+    for seed in (71, 72, 73):
+        torch.manual_seed(seed)
+        model = getattr(M, cls)(layer_order=order, upsample="deconv", **cfg)
+        assert model.native_supported, model._native_blockers
+        assert "decoders.0.basic_module.conv1.weight" in model.state_dict()
+        x = torch.randn(shape)
+        target = (torch.rand((shape[0], cfg["out_channels"]) + shape[2:]) > 0.5).float()
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        p32, l32, v32, g32 = orc.forward_backward(sd, x, target, G, fs, True, loss_name, order=order)
+        _, _, _, g64 = orc.forward_backward({k: v.double() for k, v in sd.items()}, x.double(), target.double(), G, fs, True, loss_name,
+                                            order=order)
+        model = model.to(U.DEV).train()
+        xd = x.to(U.DEV).requires_grad_(True)
+        probs, logits = model(xd, return_logits=True)
+        loss = loss_by_name(loss_name, probs, logits, target.to(U.DEV))
+        model.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        assert orc.rel_err(logits.detach().cpu(), l32) < REL and orc.rel_err(probs.detach().cpu(), p32) < REL
+        keys = list(g32)
+        ours = torch.cat([dict(model.named_parameters())[k].grad.detach().cpu().double().flatten() for k in keys])
+        r32 = torch.cat([g32[k].double().flatten() for k in keys])
+        r64 = torch.cat([g64[k].flatten() for k in keys])
+        e_ours, e_ref = ((ours - r64).norm() / r64.norm()).item(), ((r32 - r64).norm() / r64.norm()).item()
+        diag(test="residual_explicit_deconv", cls=cls, order=order, shape=list(shape), seed=seed, ours_vs_fp64=e_ours, ref32_vs_fp64=e_ref)
+        assert e_ours < 5e-2, (seed, e_ours)
+        if e_ours <= max(REL_GRAD, 3.0 * e_ref):
+            # every parameter on its own (floored at 1e-3 of the whole gradient); a flip that only shows in a tiny gradient
+            # counts like any other flip: next seed
+            per = [((dict(model.named_parameters())[k].grad.detach().cpu().double() - g64[k]).norm()
+                    / g64[k].norm().clamp_min(1e-3 * r64.norm())).item() for k in keys]
+            if max(per) < max(5e-3, 20 * e_ref):
+                clean = True
+                break
+    assert clean

@@ -227,6 +227,26 @@ def test_batchnorm_and_norm_free_oracle_matches_live_reference(name, order):
 
 
 @pytest.mark.skipif(not reference_available(), reason="/root/reference only exists in the build container")
+@pytest.mark.parametrize("name", ["ResidualUNet3D", "ResidualUNetSE3D"])
+def test_residual_oracle_with_explicit_deconv_matches_live_reference(name):
+    """upsample='deconv' spelled out on a residual net: concat joining + the block's 1x1x1 conv (buildingblocks.py:435-468)"""
+    ref = import_reference()
+    cfg = dict(name=name, in_channels=2, out_channels=2, f_maps=[8, 16, 32], num_groups=4, upsample="deconv", final_sigmoid=False)
+    torch.manual_seed(23)
+    model = ref.get_model(dict(cfg))
+    assert any("decoders.0.basic_module.conv1.weight" == k for k in model.state_dict())
+    x = torch.randn(1, 2, 9, 12, 10)
+    target = (torch.rand(1, 2, 9, 12, 10) > 0.5).float()
+    probs_r, logits_r = model(x, return_logits=True)
+    ((probs_r * target).sum() + 0.5 * (logits_r * logits_r).mean()).backward()
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    probs, logits, _, grads = orc.forward_backward(sd, x, target, 4, False, True, "probs_sum")
+    assert orc.rel_err(logits, logits_r.detach()) < 1e-6 and orc.rel_err(probs, probs_r.detach()) < 1e-6
+    for k, p in model.named_parameters():
+        assert orc.rel_err(grads[k], p.grad) < 2e-5, k
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference only exists in the build container")
 @pytest.mark.parametrize("mode", ["trilinear", "area"])
 def test_interpolating_oracle_matches_live_reference(mode):
     """upsample: trilinear / area (InterpolateUpsampling, buildingblocks.py:598-614) on a ragged size"""
