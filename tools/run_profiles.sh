@@ -6,7 +6,7 @@ tag=${1:-rXX}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
-B="python bench.py --no-cpu-baseline --no-roofline"
+B="python bench.py --no-cpu-baseline --no-roofline --no-extras"
 python bench.py > $out/bench.json.log 2> $out/bench.err
 timeout 300 rocprofv3 --kernel-trace --stats -d $out/stats -- $B --steps 3 --warmup 3 > $out/stats.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- $B --steps 2 --warmup 1 > $out/fetch.log 2>&1
@@ -21,3 +21,10 @@ python tools/prof_summary.py tables "$db" 6 $out/sq $out/bench.json.log > $out/$
 cp $out/bench.json.log $out/${tag}_bench.json.log
 rm -rf $out/stats $out/fetch $out/write $out/sq
 tail -1 $out/bench.json.log | cut -c1-400
+# opt-in paths, layer rates and accuracy probes quoted in DESIGN.md 4.7 / 4.9
+python tools/bf16_bench.py > $out/${tag}_bf16_layer_bench.txt 2>&1
+python tools/bf16_bench.py --fmaps 32 --patch 64,128,128 --batch 2 --levels 1 > $out/${tag}_cfg2_fullres_layer_bench.txt 2>&1
+python tools/f32s_error_probe.py > $out/${tag}_f32s_error_probe.txt 2>&1
+python tools/model_bench.py --bf16 > $out/${tag}_cfg4_model_bench.jsonl 2>> $out/bench.err
+python tools/model_bench.py --bf16 --checkpoint >> $out/${tag}_cfg4_model_bench.jsonl 2>> $out/bench.err
+python tools/model_bench.py --split >> $out/${tag}_cfg4_model_bench.jsonl 2>> $out/bench.err
