@@ -743,12 +743,15 @@ class UNet3DEngine:
         training = bool(mod.training) or mod.running_mean is None
         mean_rstd = _empty((C, 2), dtype=_F32, device=dev)
         momentum = 0.0
-        if training and mod.running_mean is not None:
-            mod.num_batches_tracked.add_(1)  # (ATen's batch_norm does the same before the kernel)
-            momentum = (1.0 / float(mod.num_batches_tracked.item())) if mod.momentum is None else float(mod.momentum)
+        rm, rv = mod.running_mean, mod.running_var
+        if training and rm is not None:
+            if getattr(self, "_in_recompute", False):
+                rm = rv = None  # activation checkpointing re-runs this forward in backward: the estimates were updated the first time
+            else:
+                mod.num_batches_tracked.add_(1)  # (ATen's batch_norm does the same before the kernel)
+                momentum = (1.0 / float(mod.num_batches_tracked.item())) if mod.momentum is None else float(mod.momentum)
         nat.call("u3d_bn_finalize", dev.index, _stream(dev), _p(st0), C0, sc0, _p(st1), C1, sc1, N, count, _p(mod.weight.detach()),
-                 _p(mod.bias.detach()), float(mod.eps), 1 if training else 0, momentum, _p(mod.running_mean), _p(mod.running_var),
-                 _p(affine), _p(mean_rstd))
+                 _p(mod.bias.detach()), float(mod.eps), 1 if training else 0, momentum, _p(rm), _p(rv), _p(affine), _p(mean_rstd))
         return mean_rstd
 
     def _norm_bwd_finalize(self, cx, rec: ConvRec, gst, N, C, count, coef):
@@ -1740,7 +1743,11 @@ class ResUNetEngine(UNet3DEngine):
                 # recompute the block's forward (bit-identical kernels, same inputs) to rebuild what backward needs
                 tmp = Tape()
                 fpool = _StatPool(dev, 16 * rec.x_in.shape[0] * rec.bm.conv2.conv.in_channels * 2 + 64)
-                self._block_fwd(rec.bm, rec.name, rec.x_in, None, fpool, tmp, dev, y_out=rec.out)
+                self._in_recompute = True
+                try:
+                    self._block_fwd(rec.bm, rec.name, rec.x_in, None, fpool, tmp, dev, y_out=rec.out)
+                finally:
+                    self._in_recompute = False
                 cx.ensure_ws(self._wgrad_workspace_floats(tmp.convs))
                 rec = tmp.blocks[0]
                 del tmp, fpool

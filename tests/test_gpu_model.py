@@ -104,6 +104,8 @@ def test_model_matches_reference_golden(name):
     # 12x20x24 -> 6x10x12 -> 3x5x6 -> 1x2x3: the two upper decoder levels are exact 2x (sub-pixel kernels), the deepest one is
     # not (virtual-concat kernel with index maps) — both paths in one network, ragged tiles everywhere
     (dict(in_channels=2, out_channels=1, f_maps=8, num_groups=4), (2, 2, 12, 20, 24), "bce_dice"),
+    # conv_upscale=1: the FIRST conv of an encoder DoubleConv widens the channels (buildingblocks.py:200-227)
+    (dict(in_channels=1, out_channels=1, f_maps=16, num_levels=3, num_groups=8, conv_upscale=1), (1, 1, 16, 32, 32), "bce_dice"),
     # residual variant: aligned sizes (persistent conv kernels) and the reference's odd test shape
     (dict(name="ResidualUNet3D", in_channels=1, out_channels=1, f_maps=16, num_levels=4, num_groups=8), (1, 1, 16, 32, 32), "bce_dice"),
     (dict(name="ResidualUNet3D", in_channels=1, out_channels=2, f_maps=[16, 32, 64], num_groups=8, final_sigmoid=False), (1, 1, 17, 33, 35), "probs_sum"),
@@ -378,7 +380,8 @@ def test_uncovered_variant_strict_mode(monkeypatch):
     from pytorch3dunet_amd.unet3d.model import UNet3D
 
     dev = torch.device("cuda", 0)
-    model = UNet3D(1, 1, f_maps=16, num_levels=3, layer_order="bcr").to(dev).eval()  # BatchNorm order: not native
+    model = UNet3D(1, 1, f_maps=16, num_levels=3, layer_order="gcrg").to(dev).eval()  # two norms in one layer: outside engine.layer_spec
+    assert not model.native_supported
     monkeypatch.setenv("U3D_STRICT", "1")
     with pytest.raises(NotImplementedError):
         model(torch.rand(1, 1, 8, 16, 16, device=dev))
