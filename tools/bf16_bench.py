@@ -108,7 +108,9 @@ def main():
             print(f"L{lvl} {label} {C:4d}->{C:4d} @{D}x{H}x{W}: fp32 {m32:7.3f} ms ({flops / m32 / 1e9:6.1f} TF)   "
                   f"bf16 {m16:7.3f} ms ({flops / m16 / 1e9:6.1f} TF = {flops / m16 / 1e9 / PEAK_BF16:.2f} of bf16 peak; "
                   f"{hbm / m16 / 1e6:5.0f} GB/s algorithmic)   speed-up {m32 / m16:4.2f}x", flush=True)
-        # weight gradient
+        # weight gradient (the bf16 kernel needs Cin % 32 == 0 and Cout % 64 == 0)
+        if C % 64 != 0:
+            continue
         dz = torch.randn(N, D, H, W, C, device=dev)
         dw = torch.empty((C, C, 3, 3, 3), device=dev)
         n32 = lib.u3d_wgrad_workspace_floats(N, D, H, W, C, C)
