@@ -281,3 +281,30 @@ def test_resample_tables_reproduce_f_interpolate(mode, n_in, n_out):
     for i in range(n_in):
         used = M[:, i].nonzero().flatten()
         assert used.numel() > 0 and int(rng[i, 0]) <= int(used[0]) and int(used[-1]) < int(rng[i, 1])
+
+
+def test_layer_order_grammar_of_the_native_executor():
+    """engine.layer_spec: which order strings of create_conv's mini language (buildingblocks.py:10-96) run natively — every order
+    the reference documents ('cr', 'gcr', 'cl', 'ce', 'bcr', 'crg') and the ones its tests build ('cgr') included"""
+    from pytorch3dunet_amd.engine import ACT_ELU, ACT_LEAKY, ACT_NONE, ACT_RELU, layer_spec, parse_order
+
+    native = ["gcr", "gcl", "gce", "gc", "cgr", "cgl", "cge", "cg", "crg", "clg", "ceg", "bcr", "bcl", "bc", "cbr", "cb", "crb",
+              "cr", "cl", "ce", "c", "gcrd", "gcrD", "cgld", "crd", "cD", "bcrD"]
+    for o in native:
+        assert layer_spec(o) is not None and parse_order(o) is not None, o
+    for o in ["", "gr", "gcrg", "gbcr", "dgcr", "gcdr", "gced", "crle", "gcrr", "gcx", "ccr"]:
+        assert layer_spec(o) is None, o
+    sp = layer_spec("gcr")
+    assert (sp.norm, sp.pre, sp.act, sp.inner, sp.drop) == ("g", True, ACT_RELU, ACT_NONE, None)
+    sp = layer_spec("crg")
+    assert (sp.norm, sp.pre, sp.act, sp.inner) == ("g", False, ACT_NONE, ACT_RELU)
+    sp = layer_spec("cblD")
+    assert (sp.norm, sp.pre, sp.act, sp.slope, sp.drop) == ("b", False, ACT_LEAKY, 0.01, "D")
+    sp = layer_spec("ce")
+    assert (sp.norm, sp.act) == (None, ACT_ELU)
+    # the model-level switch follows the grammar (+ dropout stays out of residual blocks)
+    assert M.UNet3D(1, 1, f_maps=[8, 16], num_groups=4, layer_order="cbr").native_supported
+    assert M.UNet3D(1, 1, f_maps=[8, 16], num_groups=4, layer_order="crd").native_supported
+    assert not M.UNet3D(1, 1, f_maps=[8, 16], num_groups=4, layer_order="gcrg").native_supported
+    assert M.ResidualUNet3D(1, 1, f_maps=[8, 16], num_groups=4, layer_order="cbr").native_supported
+    assert not M.ResidualUNet3D(1, 1, f_maps=[8, 16], num_groups=4, layer_order="gcrd").native_supported
