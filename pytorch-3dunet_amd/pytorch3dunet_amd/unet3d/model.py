@@ -10,9 +10,11 @@ Contract kept:
 
 Dispatch: tensors on a gfx950 device -> native executor (pytorch3dunet_amd/engine.py), which raises if
 libu3d_hip.so is missing (no silent fallback).  CPU tensors (`device: cpu`) run the torch.nn modules the tree is
-made of.  Model variants the executor does not cover yet (2-D, non-'gcr' orders, other upsampling modes) run the
-same module tree through stock PyTorch-ROCm operators after a one-time warning; set U3D_STRICT=1 to make that an
-error instead.
+made of.  Model variants the executor does not cover (2-D models, layer orders outside engine.layer_spec's grammar,
+conv kernels other than 3/pad 1) run the same module tree through stock PyTorch-ROCm operators after a one-time
+warning; set U3D_STRICT=1 to make that an error instead.  Covered since round 2: every layer order with at most one
+GroupNorm / BatchNorm, one non-linearity and a trailing dropout, every `upsample` value the reference itself can run
+on a 3-D net, nn.DataParallel, activation checkpointing, and the opt-in compute modes `bf16` and `fp32_split`.
 """
 import os
 import warnings
