@@ -269,6 +269,14 @@ def main():
             torch.manual_seed(0)
             model2 = UNet3D(compute_dtype="fp32_split", **MODEL_CFG).to(dev).train()
             opt2 = torch.optim.Adam(model2.parameters(), lr=2e-4, weight_decay=1e-5)
+            # same weights, same batch, before any update: how far the two arithmetics are apart on the logits
+            torch.manual_seed(0)
+            model1 = UNet3D(**MODEL_CFG).to(dev).train()
+            with torch.no_grad():
+                l1 = model1(x, return_logits=True)[1]
+                l2 = model2(x, return_logits=True)[1]
+                logits_rel = float((l1 - l2).norm() / l1.norm())
+            del model1, l1, l2
 
             def step2():
                 probs2, logits2 = model2(x, return_logits=True)
@@ -289,6 +297,7 @@ def main():
             out["extra_fp32_split"] = {
                 "value": round(B * args.steps / el2, 3), "unit": "patches/s", "ms_per_step": round(1000.0 * el2 / args.steps, 3),
                 "opt_in": "model key compute_dtype: fp32_split (or U3D_F32_SPLIT=1)", "final_loss": round(loss2.item(), 5),
+                "logits_rel_l2_vs_fp32_mfma_same_weights": float(f"{logits_rel:.3e}"),
                 "arithmetic": "fwd/dgrad 3x3x3 convs: 3xbf16 exact operand split, 6 bf16 MFMAs per fp32 multiply-add, fp32 "
                               "accumulation; everything else as the default path",
             }
