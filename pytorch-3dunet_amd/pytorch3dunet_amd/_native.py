@@ -322,8 +322,9 @@ class EventProfiler:
     """Per-entry-point device time from HIP events recorded on the launching stream (bench.py's roofline leg).
     Usage: nat.profiler = EventProfiler(); ...run...; torch.cuda.synchronize(); prof.summary()."""
 
-    def __init__(self, flops_only: bool = False):
+    def __init__(self, flops_only: bool = False, only=None):
         self.records = []  # (name, flops, start_event, end_event)
+        self.only = set(only) if only else None  # bracket just these entry points (bench.py: the dominant family in the timed region)
         # flops_only: time only the MFMA families (calls that declare FLOPs) — two event packets per call cost ~1 us of
         # device time each, 0.7 ms per step when every one of the ~320 calls is bracketed
         self.flops_only = flops_only
@@ -331,7 +332,7 @@ class EventProfiler:
     def wrap(self, name, fn, args, flops):
         import torch
 
-        if self.flops_only and flops <= 0.0:
+        if (self.flops_only and flops <= 0.0) or (self.only is not None and name not in self.only):
             return fn(*args)
         st = torch.cuda.Event(enable_timing=True)
         en = torch.cuda.Event(enable_timing=True)
