@@ -109,16 +109,23 @@ class _Ref:
         self.i, self.param = i, param
 
 
+_LEAF_TYPES = (type(None), int, float, str, bool)
+_RECORD_TYPES: set = set()  # dataclasses of the tape + VSrc, filled in below their definitions (cheaper than dataclasses.is_dataclass)
+
+
 def _walk(obj, fn):
     """rebuild the tape's object graph (dataclasses, VSrc, lists/tuples/dicts) with every leaf mapped through fn;
     nn.Modules, numbers and strings stay as they are"""
-    if isinstance(obj, (torch.Tensor, _Ref)):
+    t = type(obj)
+    if t in _LEAF_TYPES:
+        return obj
+    if t is _Ref or isinstance(obj, torch.Tensor):
         return fn(obj)
-    if isinstance(obj, (list, tuple)):
-        return type(obj)(_walk(o, fn) for o in obj)
-    if isinstance(obj, dict):
+    if t is list or t is tuple:
+        return t(_walk(o, fn) for o in obj)
+    if t is dict:
         return {k: _walk(v, fn) for k, v in obj.items()}
-    if dataclasses.is_dataclass(obj) or isinstance(obj, VSrc):
+    if t in _RECORD_TYPES or dataclasses.is_dataclass(obj):
         new = copy.copy(obj)
         for k, v in vars(obj).items():
             setattr(new, k, _walk(v, fn))
@@ -1373,6 +1380,9 @@ class UpRec:
     tdims: tuple          # (Dt, Ht, Wt)
     t8: bool = False      # ran in space-to-depth form on the bf16 kernels (csrc/u3d_bf16.hip)
     concat: Optional[tuple] = None  # explicit upsample='deconv' on a residual net: concat joining, (Cs skip, Ct upsampled) channels
+
+
+_RECORD_TYPES.update({VSrc, ConvRec, Tape, ResRec, CkptRec, UpRec})
 
 
 class ResUNetEngine(UNet3DEngine):
