@@ -104,3 +104,45 @@ def upsample_nearest(x, size):
     y = np.empty((N, C, D, H, W), np.float32)
     lib().ref_upsample_nearest(xp, y.ctypes.data_as(ctypes.c_void_p), N, C, D1, H1, W1, D, H, W)
     return y
+
+
+def batchnorm_fwd(x, gamma, beta, running_mean, running_var, training=True, eps=1e-5, momentum=0.1):
+    """returns (y, running_mean', running_var') — the running estimates are copies, updated like nn.BatchNorm3d does"""
+    N, C = x.shape[:2]
+    V = int(np.prod(x.shape[2:]))
+    x, xp = _f(x)
+    g, gp = _f(gamma)
+    b, bp = _f(beta)
+    rm, rmp = _f(np.array(running_mean, dtype=np.float32, copy=True))
+    rv, rvp = _f(np.array(running_var, dtype=np.float32, copy=True))
+    y = np.empty_like(x)
+    lib().ref_batchnorm_fwd(xp, gp, bp, rmp, rvp, y.ctypes.data_as(ctypes.c_void_p), N, C, ctypes.c_size_t(V), ctypes.c_float(eps),
+                            ctypes.c_float(momentum), 1 if training else 0)
+    return y, rm, rv
+
+
+def _resize(fn, x, size):
+    N, C, D1, H1, W1 = x.shape
+    D, H, W = size
+    x, xp = _f(x)
+    y = np.empty((N, C, D, H, W), np.float32)
+    getattr(lib(), fn)(xp, y.ctypes.data_as(ctypes.c_void_p), N, C, D1, H1, W1, D, H, W)
+    return y
+
+
+def upsample_trilinear(x, size):
+    return _resize("ref_upsample_trilinear", x, size)
+
+
+def upsample_area(x, size):
+    return _resize("ref_upsample_area", x, size)
+
+
+def conv_transpose3d_fwd(x, w):
+    N, Cin, D1, H1, W1 = x.shape
+    Cout = w.shape[1]
+    x, xp = _f(x)
+    w, wp = _f(w)
+    y = np.empty((N, Cout, 2 * D1 - 1, 2 * H1 - 1, 2 * W1 - 1), np.float32)
+    lib().ref_conv_transpose3d_fwd(xp, wp, y.ctypes.data_as(ctypes.c_void_p), N, Cin, Cout, D1, H1, W1)
+    return y

@@ -324,3 +324,30 @@ def test_port_and_live_reference_same_speed():
     ratio = min(t_port) / min(t_ref)
     print(f"reference {min(t_ref) * 1e3:.1f} ms, port {min(t_port) * 1e3:.1f} ms per fwd+bwd (ratio {ratio:.2f})")
     assert 0.7 < ratio < 1.4, (t_ref, t_port)
+
+
+def test_c_restatement_of_the_round2_operators():
+    """oracle/ref_ops.c (plain C, no torch): BatchNorm3d in training (incl. the running-estimate update) and eval mode, trilinear /
+    area resizing to an arbitrary size, ConvTranspose3d(k3, s2, p1) — against the ATen CPU operators the reference calls"""
+    torch.manual_seed(4)
+    x = torch.randn(2, 5, 4, 6, 5) * 2.0 + 0.5
+    bn = torch.nn.BatchNorm3d(5)
+    with torch.no_grad():
+        bn.weight.add_(0.3 * torch.randn(5))
+        bn.bias.add_(0.3 * torch.randn(5))
+        bn.running_mean.add_(0.1 * torch.randn(5))
+    rm0, rv0 = bn.running_mean.clone().numpy(), bn.running_var.clone().numpy()
+    y = bn.train()(x)
+    yc, rm, rv = c_ops.batchnorm_fwd(x.numpy(), bn.weight.detach().numpy(), bn.bias.detach().numpy(), rm0, rv0, training=True)
+    assert np.abs(yc - y.detach().numpy()).max() < 2e-5
+    assert np.allclose(rm, bn.running_mean.numpy(), rtol=1e-6, atol=1e-7) and np.allclose(rv, bn.running_var.numpy(), rtol=1e-5, atol=1e-7)
+    ye = bn.eval()(x)
+    yce, _, _ = c_ops.batchnorm_fwd(x.numpy(), bn.weight.detach().numpy(), bn.bias.detach().numpy(), rm, rv, training=False)
+    assert np.abs(yce - ye.detach().numpy()).max() < 2e-5
+    for size in [(8, 12, 10), (9, 13, 11), (4, 6, 5)]:
+        for mode, fn in (("trilinear", c_ops.upsample_trilinear), ("area", c_ops.upsample_area)):
+            ref = torch.nn.functional.interpolate(x, size=size, mode=mode).numpy()
+            assert np.abs(fn(x.numpy(), size) - ref).max() < 2e-6, (mode, size)
+    w = torch.randn(5, 3, 3, 3, 3)
+    ref = torch.nn.functional.conv_transpose3d(x, w, None, stride=2, padding=1).numpy()
+    assert np.abs(c_ops.conv_transpose3d_fwd(x.numpy(), w.numpy()) - ref).max() < 2e-5
