@@ -478,3 +478,30 @@ def test_subpixel_decoder_path_agrees_with_virtual_concat_path():
         # gamma over a single normalised channel is ~1e-8)
         scale = max(g0[k].abs().max().item(), 1e-3 * gmax)
         assert (g1[k] - g0[k]).abs().max().item() < 2e-4 * scale, k
+
+
+@pytest.mark.parametrize("name", ["UNet3D", "ResidualUNet3D", "ResidualUNetSE3D"])
+def test_reference_own_model_tests_run_native_in_strict_mode(name, monkeypatch):
+    """The 3-D cases of the reference's tests/test_models.py:17-69, constructor for constructor — `X(1, 1, f_maps=16,
+    final_sigmoid=True)`, eval mode, `torch.rand(1, 1, 33, 65, 65)`, outputs in [0, 1] — on the native path with U3D_STRICT=1 (no
+    stock-operator fallback), and equal to the module tree on the CPU for the same weights"""
+    from pytorch3dunet_amd import _native as nat
+    from pytorch3dunet_amd.unet3d import model as M
+
+    monkeypatch.setenv("U3D_STRICT", "1")
+    torch.manual_seed(0)
+    model = getattr(M, name)(1, 1, f_maps=16, final_sigmoid=True).eval()
+    x = torch.rand(1, 1, 33, 65, 65)
+    with torch.no_grad():
+        y_cpu = model(x)
+    dev = torch.device("cuda", 0)
+    model = model.to(dev)
+    n0 = nat.launch_count
+    with torch.no_grad():
+        y = model(x.to(dev))
+    assert nat.launch_count > n0
+    assert torch.all(0 <= y) and torch.all(y <= 1)
+    assert (y.cpu() - y_cpu).abs().max().item() < 1e-4
+    # the residual variants are called WITHOUT no_grad in the reference's tests: the autograd graph must build, too
+    y2 = model(x.to(dev))
+    assert y2.requires_grad and torch.equal(y2.detach(), y)
