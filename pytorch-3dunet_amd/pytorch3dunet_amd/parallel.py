@@ -55,6 +55,61 @@ class GradSync:
         self._pending.clear()
 
 
+class TreeSync(GradSync):
+    """The same two-bucket exchange for a model that runs as the torch.nn MODULE TREE — CPU tensors (`device: cpu`, gloo) or a
+    variant the native executor does not cover (2-D models, …): post-accumulate-grad hooks count the parameters of each bucket;
+    when the last gradient of [decoders | head] has been accumulated its flat copy is all-reduced asynchronously while autograd
+    is still inside the encoders, the encoder bucket follows, and the averaged values are written back into `.grad` before
+    `loss.backward()` returns.  (The native executor does not go through these hooks: it hands RCCL slices of its own flat
+    gradient buffer, engine.py.)  Every parameter that requires grad must take part in the loss, like under torch DDP
+    without `find_unused_parameters`."""
+
+    def __init__(self, model: torch.nn.Module, process_group=None, force_single: Optional[bool] = None):
+        super().__init__(process_group, force_single)
+        params = [p for p in model.parameters() if p.requires_grad]
+        enc = getattr(model, "encoders", None)
+        enc_ids = {id(p) for p in enc.parameters()} if enc is not None else set()
+        # bucket 0 = decoders + head (ready first in backward), bucket 1 = encoders
+        self.buckets = [[p for p in params if id(p) not in enc_ids], [p for p in params if id(p) in enc_ids]]
+        self._left = [len(b) for b in self.buckets]
+        self._flat: List[Optional[torch.Tensor]] = [None, None]
+        self._handles = []
+        for bi, bucket in enumerate(self.buckets):
+            for p in bucket:
+                self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+
+    def _make_hook(self, bi: int):
+        def hook(_param):
+            self._ready(bi)
+
+        return hook
+
+    def _ready(self, bi: int) -> None:
+        if self.world == 1 and not self.force_single:
+            return
+        self._left[bi] -= 1
+        if self._left[bi] == 0:
+            flat = torch.cat([p.grad.reshape(-1) for p in self.buckets[bi]])
+            self._flat[bi] = flat
+            self.launch(flat)
+        if all(n <= 0 for n in self._left):
+            self.finish()
+            with torch.no_grad():
+                for bucket, flat in zip(self.buckets, self._flat):
+                    o = 0
+                    for p in bucket:
+                        n = p.grad.numel()
+                        p.grad.copy_(flat[o:o + n].view_as(p.grad))
+                        o += n
+            self._flat = [None, None]
+            self._left = [len(b) for b in self.buckets]
+
+    def detach(self) -> None:
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+
 def broadcast_parameters(model: torch.nn.Module, src: int = 0, process_group=None) -> None:
     """Identical initial weights on every rank (what DataParallel's replicate() does each step, once)."""
     with torch.no_grad():
@@ -63,17 +118,26 @@ def broadcast_parameters(model: torch.nn.Module, src: int = 0, process_group=Non
 
 
 def attach(model: torch.nn.Module, process_group=None, broadcast: bool = True, force_single: Optional[bool] = None) -> GradSync:
-    """Enable data-parallel training of a natively supported model: after this, `loss.backward()` leaves
-    rank-averaged gradients in `.grad` exactly like torch DDP would, with the exchange overlapped as described."""
+    """Enable data-parallel training: after this, `loss.backward()` leaves rank-averaged gradients in `.grad` exactly like torch
+    DDP would, with the exchange overlapped as described.  A natively covered model on a HIP device gets the executor hook
+    (flat buffer slices handed to RCCL from inside the fused backward); anything that runs as the torch.nn module tree — CPU
+    tensors / gloo, uncovered variants — gets `TreeSync`'s post-accumulate-grad hooks.  Nothing is ever left unsynchronised
+    silently: a natively attached model that later falls back to the module tree raises (unet3d/model.py)."""
     if not dist.is_initialized():
         raise RuntimeError("torch.distributed is not initialised")
-    if not getattr(model, "native_supported", False):
-        raise NotImplementedError("parallel.attach needs a model covered by the native executor; wrap other "
-                                  "variants in torch.nn.parallel.DistributedDataParallel")
     if broadcast:
         broadcast_parameters(model, 0, process_group)
-    sync = GradSync(process_group, force_single)
-    model._get_engine().grad_sync = sync
+    first = next(iter(model.parameters()), None)
+    native = bool(getattr(model, "native_supported", False)) and first is not None and first.is_cuda
+    old = getattr(model, "_u3d_grad_sync", None)
+    if isinstance(old, TreeSync):
+        old.detach()
+    if native:
+        sync = GradSync(process_group, force_single)
+        model._get_engine().grad_sync = sync
+    else:
+        sync = TreeSync(model, process_group, force_single)
+    object.__setattr__(model, "_u3d_grad_sync", sync)
     return sync
 
 

@@ -145,6 +145,11 @@ class AbstractUNet(nn.Module):
 
                 return run_model(self._get_engine(), x)
             why = ", ".join(self._native_blockers) or f"input dtype/rank {x.dtype}/{x.dim()}"
+            eng = self.__dict__.get("_engine")
+            if eng is not None and eng.grad_sync is not None and torch.is_grad_enabled():
+                # parallel.attach hooked the gradient exchange into the native executor: the module tree would train unsynchronised
+                raise RuntimeError(f"u3d: data-parallel model fell back to the module tree ({why}); its gradients would not be "
+                                   "averaged across ranks — call pytorch3dunet_amd.parallel.attach again for this configuration")
             if os.environ.get("U3D_STRICT", "0") == "1":
                 raise NotImplementedError(f"u3d: no native gfx950 path for this configuration ({why})")
             if not self._warned:

@@ -31,6 +31,12 @@ class File:
     def __getitem__(self, name):
         return self.d[name]
 
+    def __contains__(self, name):
+        return name in self.d
+
+    def keys(self):
+        return self.d.keys()
+
 
 def install():
     mod = types.ModuleType("h5py")

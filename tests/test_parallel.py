@@ -62,6 +62,18 @@ def _worker(rank, world, port, out):
         (0.5 * (model(xs[0:1]).mean() + model(xs[1:2]).mean())).backward()
         whole = torch.cat([p.grad.flatten() for p in model.parameters()])
         assert torch.allclose(flat_g, whole, atol=1e-6, rtol=1e-4)
+
+        # parallel.attach on a CPU model: the module tree syncs through post-accumulate-grad hooks, loss.backward() alone
+        # leaves the rank-averaged gradients in .grad (no hand-written launch) — twice, the second time accumulating
+        sync2 = parallel.attach(model, broadcast=False)
+        assert type(sync2).__name__ == "TreeSync" and model._u3d_grad_sync is sync2
+        model.zero_grad()
+        model(shard).mean().backward()
+        hooked = torch.cat([p.grad.flatten() for p in model.parameters()])
+        assert torch.allclose(hooked, whole, atol=1e-6, rtol=1e-4) and sync2.launched == 2
+        model(shard).mean().backward()  # gradient accumulation: avg(avg(g) + g_local) = 2 avg(g)
+        twice = torch.cat([p.grad.flatten() for p in model.parameters()])
+        assert torch.allclose(twice, 2 * whole, atol=2e-6, rtol=1e-4) and sync2.launched == 4
         out.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         out.put((rank, repr(e)))

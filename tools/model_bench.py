@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--bf16", action="store_true", help="compute_dtype='bf16' (fp32 master weights / activations / statistics)")
     ap.add_argument("--split", action="store_true", help="compute_dtype='fp32_split' (fp32-grade convolutions on the bf16 pipe)")
     ap.add_argument("--checkpoint", action="store_true", help="checkpoint_encoders=True")
+    ap.add_argument("--no-events", action="store_true", help="bare timing only (for runs under rocprofv3)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
@@ -72,6 +73,9 @@ def main():
     torch.cuda.synchronize()
     dt_bare = (time.perf_counter() - t0) / args.steps
     peak = torch.cuda.max_memory_allocated()
+    if args.no_events:
+        print(json.dumps({"model": args.name, "ms_per_step_bare": round(dt_bare * 1e3, 2), "peak_mem_gb": round(peak / 2**30, 3)}))
+        return
     prof = nat.EventProfiler()
     nat.profiler = prof
     t0 = time.perf_counter()

@@ -46,7 +46,7 @@ def pmc(d):
                 ndisp[k].add((f, row.get("Dispatch_Id") or row.get("dispatch_id")))
     print(f"# rocprofv3 --pmc summary ({d}); counter sums over all dispatches of a kernel\n")
     for k in sorted(agg, key=lambda k: -agg[k].get("SQ_WAVE_CYCLES", agg[k].get("GRBM_GUI_ACTIVE", 0))):
-        if not any(s in k for s in ("conv3d", "wgrad", "subpixel", "head_", "chan_stats", "gn_", "maxpool")):
+        if not any(s in k for s in ("conv3d", "wgrad", "subpixel", "head_", "chan_stats", "gn_", "maxpool", "gconv", "nearest_", "pack_")):
             continue
         print(f"## `{k[:100]}`  ({len(ndisp[k])} dispatch records)")
         for c, v in sorted(agg[k].items()):
@@ -58,6 +58,8 @@ FAMILIES = {  # C-ABI entry point -> substrings of the kernels it launches
     "u3d_conv3d": ("conv3d_mfma_reg_kernel", "conv3d_mfma_kernel", "splitk_reduce_kernel"),
     "u3d_conv3d_wgrad": ("conv3d_wgrad_kernel", "wgrad_reduce_kernel"),
     "u3d_subpixel_conv_fwd": ("subpixel_fwd_kernel",),
+    "u3d_conv3d_bf16_ex": ("conv3d_bf16_kernel", "splitk_bf16_reduce_kernel"),
+    "u3d_conv3d_wgrad_bf16": ("conv3d_wgrad_bf16_kernel", "wgrad_bf16_reduce"),
 }
 
 
