@@ -333,6 +333,8 @@ class Tape:
     x0: Optional[torch.Tensor] = None
     blocks: list = field(default_factory=list)  # residual executor: ResRec per block (encoders, then decoders)
     ups: list = field(default_factory=list)     # residual executor: UpRec per decoder
+    lean: bool = False      # memory-lean mode (checkpoint_encoders): backward releases every block's tensors as soon as it is done
+    consumed: bool = False  # ... so the tape can be walked only once
 
 
 class _StatPool:
@@ -433,11 +435,19 @@ class UNet3DEngine:
         # forward and data gradients only, weight gradients stay on the fp32 MFMA kernels
         self.split = bool(getattr(model, "compute_split", False)) and not self.bf16
         self.checkpoint_encoders = bool(getattr(model, "checkpoint_encoders", False))
+        # with activation checkpointing the tape is also RELEASED block by block during backward (ResUNetEngine.backward): a feature
+        # whose only purpose is memory must move the peak, and with one autograd node owning the whole tape it otherwise does not
+        self.lean_tape = False  # (ResUNetEngine turns it on together with checkpoint_encoders)
         # id(conv weight) -> (C0, C1) of every decoder first conv (static); WHICH of them take the sub-pixel path depends on
         # the input size and is per-call state (`sub` argument / ConvRec.sub), never stored on the engine: forwards at
         # different sizes, other threads and nn.DataParallel replicas must not see each other's choice
         self._sub_pairs: dict = {}
         self._lock = threading.RLock()  # host-side enqueue of one forward / backward at a time per engine
+        # opt-in static-shape step runner (`hip_graph: true` in the YAML's model section or U3D_GRAPH=1): the ~70 forward and ~110
+        # backward launches of a TRAINING step are captured once per input shape in two hipGraphs and replayed (GraphStep below)
+        self.hip_graph = bool(getattr(model, "hip_graph", False))
+        self._graph_steps: dict = {}
+        self._graph_off_reason = None
         self._salt = 0  # advanced by every training forward: see _ver
         self._const: dict = {}
         # the model-wide layer order (every SingleConv of a DoubleConv net shares it): non-linearity of the layer outputs
@@ -1401,6 +1411,7 @@ class ResUNetEngine(UNet3DEngine):
         # self.slope / self.mask describe the BLOCK outputs (what pooling, joining and the head consume).
         order = getattr(model, "layer_order", "gcr")
         self.act2, self.slope2 = self.act, self.slope
+        self.lean_tape = self.checkpoint_encoders and os.environ.get("U3D_LEAN_TAPE", "1") != "0"
         self.act, self.slope = (ACT_LEAKY, 0.1) if "l" in order else ((ACT_ELU, 0.0) if "e" in order else (ACT_RELU, 0.0))
         self.mask = 1 if self.act == ACT_RELU else 0
 
@@ -1693,9 +1704,22 @@ class ResUNetEngine(UNet3DEngine):
         n_levels, n_dec = len(self.enc), len(self.dec)
         enc_blocks, dec_blocks = tape.blocks[:n_levels], tape.blocks[n_levels:]
         skip_grad = {}
+        lean = tape.lean
+        if lean:
+            # memory-lean mode: this walk is the tape's only one — every block's activations are dropped as soon as its backward
+            # is queued (the caching allocator hands the memory to the next block's temporaries in stream order), so the peak is
+            # one level's working set on top of what is still to be walked, not the whole tape
+            tape.consumed = True
+            tape.convs, tape.blocks, tape.head_x = [], [], None
+            ups, pools = tape.ups, tape.pools
+            tape.ups, tape.pools = [], []
+        else:
+            ups, pools = tape.ups, tape.pools
 
         for j in range(n_dec - 1, -1, -1):
-            rec, up = dec_blocks[j], tape.ups[j]
+            rec, up = dec_blocks[j], ups[j]
+            if lean:
+                dec_blocks[j] = ups[j] = None
             dj = self._block_bwd(cx, rec, dz)  # gradient of the block's residual r (= the joined tensor when conv1 is nn.Identity)
             if up.concat is not None:
                 # concat joining: through the block's 1x1x1 conv, then split into the skip's and the resized tensor's gradient
@@ -1742,6 +1766,7 @@ class ResUNetEngine(UNet3DEngine):
             del dt
             dz = dxl  # ReLU blocks: masked by (x_low > 0), x_low being the output of the block below
 
+        rec = up = None
         if self.grad_sync is not None:
             cx.join()
             self.grad_sync.launch(flat[self.n_enc_params :])
@@ -1749,7 +1774,8 @@ class ResUNetEngine(UNet3DEngine):
         dx0 = None
         for i in range(n_levels - 1, -1, -1):
             rec = enc_blocks[i]
-            if isinstance(rec, CkptRec):
+            recomputed = isinstance(rec, CkptRec)
+            if recomputed:
                 # recompute the block's forward (bit-identical kernels, same inputs) to rebuild what backward needs
                 tmp = Tape()
                 fpool = _StatPool(dev, 16 * rec.x_in.shape[0] * rec.bm.conv2.conv.in_channels * 2 + 64)
@@ -1761,14 +1787,21 @@ class ResUNetEngine(UNet3DEngine):
                 cx.ensure_ws(self._wgrad_workspace_floats(tmp.convs))
                 rec = tmp.blocks[0]
                 del tmp, fpool
+            if lean:
+                enc_blocks[i] = None
             dr = self._block_bwd(cx, rec, dz)
             need_dx = i > 0 or need_input_grad
             if rec.conv1 is not None:
                 dxin = self._conv1_bwd(cx, rec, dr, need_dx)
             else:
                 dxin = dr
+            if recomputed:
+                cx.join()  # a side-stream weight gradient may still read the recomputed tensors released with `rec` below
+            rec = None
             if i > 0:
-                pooled, argmax, e_in = tape.pools[i - 1]
+                pooled, argmax, e_in = pools[i - 1]
+                if lean:
+                    pools[i - 1] = None
                 Ne, De, He, We, Ce = e_in.shape
                 out = _empty_like(e_in)
                 nat.call("u3d_maxpool2_bwd_merge", dev.index, _stream(dev), _p(dxin), _p(pooled), _p(argmax), None,
@@ -1806,7 +1839,16 @@ class _UNet3DFunction(torch.autograd.Function):
         ctx.has_probs = probs is not None
         ctx.x_requires_grad = x.requires_grad
         ctx.skel = None
-        if tape is not None:
+        ctx.lean_tape = None
+        if tape is not None and engine.lean_tape:
+            # memory-lean mode (checkpoint_encoders): the tape stays a plain Python object owned by this node, so that backward can
+            # release it block by block — autograd's saved-tensor slots are only freed when the whole node is done.  The price:
+            # ONE backward per forward (retain_graph is refused with a clear error, see backward)
+            tape.lean = True
+            ctx.lean_tape = tape
+            if probs is not None:
+                ctx.save_for_backward(probs)
+        elif tape is not None:
             ctx.skel, bag = stash_tape(tape, engine._pindex)
             ctx.save_for_backward(*([probs] if probs is not None else []), *bag)
         elif probs is not None:
@@ -1818,12 +1860,19 @@ class _UNet3DFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         engine = ctx.engine
-        if ctx.skel is None:
+        if ctx.skel is None and ctx.lean_tape is None:
             raise RuntimeError("u3d: no activation tape for this backward (the forward ran without any input requiring grad)")
         # a second backward without retain_graph=True raises autograd's own "backward through the graph a second time" here
         saved = ctx.saved_tensors
         probs = saved[0] if ctx.has_probs else None
-        tape = unstash_tape(ctx.skel, saved[1:] if ctx.has_probs else saved, engine.params)
+        if ctx.lean_tape is not None:
+            tape = ctx.lean_tape
+            if tape.consumed:
+                raise RuntimeError("u3d: backward through the graph a second time — with checkpoint_encoders the activation tape is "
+                                   "released block by block DURING backward (that is where the memory saving comes from), so "
+                                   "retain_graph=True is not available in this mode")
+        else:
+            tape = unstash_tape(ctx.skel, saved[1:] if ctx.has_probs else saved, engine.params)
         dlogits = grads[0]
         if ctx.has_probs and len(grads) > 1 and grads[1] is not None:
             # gradient flowing through the probabilities (rare: the reference's trainer takes the loss on logits,
@@ -1845,6 +1894,148 @@ class _UNet3DFunction(torch.autograd.Function):
         return tuple(out)
 
 
+class GraphStep:
+    """The launch sequences of ONE training step at ONE input shape, captured in two hipGraphs (forward: input -> logits /
+    probabilities + the activation tape; backward: dlogits -> flat parameter gradients [+ input gradient]) and replayed with two
+    `hipGraphLaunch` calls instead of ~180 ctypes calls + ~150 tensor allocations (3.3 ms of host time per step, which makes
+    BASELINE config 1's shape host-bound: tools/host_bound_check.py).  The loop it serves is the reference's unchanged
+    `output, loss = self._forward_pass(...); loss.backward(); optimizer.step()` (unet3d/trainer.py:231-246): the model call replays
+    the forward graph, `loss.backward()` reaches `_GraphedUNet3DFunction.backward`, which replays the backward graph.
+
+    What is static: the input / dlogits staging buffers, every activation of the tape, the flat gradient buffer and all scratch —
+    one private allocator pool shared by both graphs; parameters are read through their (stable) storage pointers, and the weight
+    repacking of a training forward is PART of the forward graph, so optimizer steps between replays are seen.  What the caller
+    gets are fresh copies (logits, probabilities, one flat gradient buffer), so holding outputs or `.grad` across steps is as
+    safe as in eager mode.  One tape per shape: a backward must follow ITS forward before the next forward of that shape (the
+    reference loop does); anything else raises instead of silently using a newer tape.  (Until then the tape stays valid, so a
+    second backward over a retained graph replays again, like eager mode with retain_graph=True.)"""
+
+    def __init__(self, engine: "UNet3DEngine", x: torch.Tensor, need_dx: bool):
+        dev = x.device
+        self.engine = engine
+        self.need_dx = need_dx
+        self.gen = 0          # forwards replayed so far (the tape in the pool belongs to the latest one)
+        self.static_x = torch.empty_like(x)
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            # one eager step first: every lazily built constant (index maps, identity tables, the pack descriptor table, the
+            # library's function attributes) must exist before capture — host-to-device copies are illegal inside it
+            self.static_x.copy_(x)
+            engine.begin_forward(True)
+            logits, probs, tape = engine.forward(self.static_x, True)
+            engine.backward(tape, torch.zeros_like(logits), need_dx)
+            del logits, probs, tape
+        cur.wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.pool = torch.cuda.graph_pool_handle()
+        self.g_fwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fwd, pool=self.pool, capture_error_mode="thread_local"):
+            engine.begin_forward(True)
+            self.logits, self.probs, self.tape = engine.forward(self.static_x, True)
+        self.static_dl = torch.zeros_like(self.logits)
+        self.g_bwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_bwd, pool=self.pool, capture_error_mode="thread_local"):
+            self.flat, self.dx = engine.backward(self.tape, self.static_dl, need_dx)
+
+    def forward(self, x: torch.Tensor):
+        self.static_x.copy_(x)
+        self.g_fwd.replay()
+        self.gen += 1
+        return self.logits.clone(), (self.probs.clone() if self.probs is not None else None)
+
+    def backward(self, gen: int, dlogits: torch.Tensor):
+        if gen != self.gen:
+            raise RuntimeError("u3d hip_graph: a later forward of the same input shape has overwritten this step's activation tape "
+                               "(graph mode keeps ONE tape per shape: run forward -> backward in turn, or set hip_graph: false / "
+                               "U3D_GRAPH=0 for interleaved graphs)")
+        self.static_dl.copy_(dlogits)
+        self.g_bwd.replay()
+        return self.flat.clone(), (self.dx.clone() if self.dx is not None else None)
+
+
+class _GraphedUNet3DFunction(torch.autograd.Function):
+    """The same autograd node as _UNet3DFunction with both directions replayed from GraphStep's hipGraphs."""
+
+    @staticmethod
+    def forward(ctx, step: GraphStep, x: torch.Tensor, *params):
+        with step.engine._lock:
+            logits, probs = step.forward(x)
+            ctx.gen = step.gen
+        ctx.step = step
+        ctx.has_probs = probs is not None
+        ctx.x_requires_grad = x.requires_grad
+        if probs is not None:
+            ctx.save_for_backward(probs)
+            return logits, probs
+        return (logits,)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        step = ctx.step
+        engine = step.engine
+        probs = ctx.saved_tensors[0] if ctx.has_probs else None
+        dlogits = grads[0]
+        if ctx.has_probs and len(grads) > 1 and grads[1] is not None:
+            gp = grads[1]
+            if isinstance(engine.model.final_activation, torch.nn.Sigmoid):
+                extra = gp * probs * (1 - probs)
+            else:
+                extra = probs * (gp - (gp * probs).sum(dim=1, keepdim=True))
+            dlogits = extra if dlogits is None else dlogits + extra
+        if dlogits is None:
+            dlogits = torch.zeros_like(probs)
+        with engine._lock:
+            flat, dx = step.backward(ctx.gen, dlogits)
+        out = [None, dx if ctx.x_requires_grad else None]
+        for p, off in zip(engine.params, engine.poffs):
+            out.append(flat[off : off + p.numel()].view(p.shape) if p.requires_grad else None)
+        return tuple(out)
+
+
+_GRAPH_MAX_SHAPES = int(os.environ.get("U3D_GRAPH_SHAPES", 2))  # captured shapes kept per model (each pins its whole tape in HBM)
+
+
+def _graph_blocker(engine: UNet3DEngine) -> Optional[str]:
+    """why this model cannot be captured (None = it can).  Static per engine."""
+    order = getattr(engine.model, "layer_order", "gcr")
+    if any(ch in order for ch in "bdD"):
+        return f"layer_order '{order}': BatchNorm reads its step counter on the host, dropout draws a fresh mask per step"
+    if engine.grad_sync is not None:
+        return "data-parallel gradient exchange attached (RCCL launches stay eager)"
+    if engine.debug is not None or nat.profiler is not None or _POISON:
+        return "debug / profiler / poison mode"
+    return None
+
+
+def graph_step_for(engine: UNet3DEngine, x: torch.Tensor) -> Optional[GraphStep]:
+    """the captured step of this input shape (captured on first use), or None when the eager path must run"""
+    if not engine.hip_graph or not torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing():
+        return None
+    if not any(p.requires_grad for p in engine.params):
+        return None
+    why = _graph_blocker(engine)
+    if why is not None:
+        if engine._graph_off_reason != why:
+            engine._graph_off_reason = why
+            import warnings
+
+            warnings.warn(f"u3d: hip_graph requested but this step runs eagerly ({why})", stacklevel=4)
+        return None
+    key = (tuple(x.shape), bool(x.requires_grad), tuple(p.data_ptr() for p in engine.params))
+    step = engine._graph_steps.get(key)
+    if step is None:
+        while len(engine._graph_steps) >= _GRAPH_MAX_SHAPES:
+            engine._graph_steps.pop(next(iter(engine._graph_steps)))  # oldest shape: its graphs and pool are released
+        with engine._lock:
+            step = GraphStep(engine, x.contiguous(), bool(x.requires_grad))
+        engine._graph_steps[key] = step
+    else:
+        engine._graph_steps[key] = engine._graph_steps.pop(key)  # most recently used last
+    return step
+
+
 def check_placement(engine: UNet3DEngine, x: torch.Tensor):
     """The kernels read raw pointers: every parameter must be fp32 and live on the input's device (stock modules raise
     ATen's device/dtype mismatch errors in the same situations, e.g. model.half() or a model left on another GPU)."""
@@ -1858,7 +2049,11 @@ def check_placement(engine: UNet3DEngine, x: torch.Tensor):
 def run_model(engine: UNet3DEngine, x: torch.Tensor):
     """(probs_or_logits, logits) exactly like AbstractUNet._forward_logits (model.py:123-149)."""
     check_placement(engine, x)
-    outs = _UNet3DFunction.apply(engine, x, *engine.params)
+    step = graph_step_for(engine, x) if engine.hip_graph else None
+    if step is not None:
+        outs = _GraphedUNet3DFunction.apply(step, x, *engine.params)
+    else:
+        outs = _UNet3DFunction.apply(engine, x, *engine.params)
     if len(outs) == 2:
         logits, probs = outs
         return probs, logits

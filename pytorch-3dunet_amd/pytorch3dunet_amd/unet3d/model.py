@@ -34,7 +34,7 @@ class AbstractUNet(nn.Module):
     def __init__(self, in_channels, out_channels, final_sigmoid, basic_module, f_maps=64, layer_order="gcr",
                  num_groups=8, num_levels=4, is_segmentation=True, conv_kernel_size=3, pool_kernel_size=2,
                  conv_padding=1, conv_upscale=2, upsample="default", dropout_prob=0.1, is3d=True, compute_dtype=None,
-                 checkpoint_encoders=None):
+                 checkpoint_encoders=None, hip_graph=None):
         super().__init__()
         if isinstance(f_maps, int):
             f_maps = number_of_features_per_level(f_maps, num_levels=num_levels)
@@ -96,6 +96,10 @@ class AbstractUNet(nn.Module):
         if checkpoint_encoders is None:
             checkpoint_encoders = os.environ.get("U3D_CHECKPOINT", "0") == "1"
         self.checkpoint_encoders = bool(checkpoint_encoders)
+        # `hip_graph: true` / U3D_GRAPH=1: training steps replay two captured hipGraphs per input shape (engine.GraphStep)
+        if hip_graph is None:
+            hip_graph = os.environ.get("U3D_GRAPH", "0") == "1"
+        self.hip_graph = bool(hip_graph)
         self._native_blockers = reasons
         self._residual = basic_module in (ResNetBlock, ResNetBlockSE)
         self._engine = None
@@ -184,7 +188,8 @@ def _variant(name, basic_module, default_levels, is3d, doc):
                               basic_module=basic_module, f_maps=f_maps, layer_order=layer_order, num_groups=num_groups,
                               num_levels=num_levels, is_segmentation=is_segmentation, conv_padding=conv_padding,
                               conv_upscale=conv_upscale, upsample=upsample, dropout_prob=dropout_prob, is3d=is3d,
-                              compute_dtype=kwargs.get("compute_dtype"), checkpoint_encoders=kwargs.get("checkpoint_encoders"))
+                              compute_dtype=kwargs.get("compute_dtype"), checkpoint_encoders=kwargs.get("checkpoint_encoders"),
+                              hip_graph=kwargs.get("hip_graph"))
 
     return type(name, (AbstractUNet,), {"__init__": __init__, "__doc__": doc, "__module__": _THIS_MODULE})
 

@@ -1,0 +1,163 @@
+"""-m gpu: BASELINE.json's configurations 4 and 5 where they actually run (task 1).
+
+* config 4 — ResidualUNet3D f_maps=64 with `compute_dtype: bf16` at its REAL channel ladder 64 … 1024 (golden g10's model and
+  input, 1x1x32x64x64): every layer's output and every level's parameter gradients against the bf16-operand emulation of the
+  oracle and against the fp32 reference (the oracle, and the samples the imported reference left in the fixture), level by
+  level — a wrong layer at the bottom of the U cannot hide in a global L2.  The split-K path (512 / 1024 channels) must have run.
+* config 5 — the reference's `StandardPredictor` protocol (predictor.py:112-214) on the (3,96,192,192) volume with
+  ResidualUNetSE3D against the host loop of oracle/predictor_oracle.py running the torch.nn module tree, fp32 at 1e-3.
+"""
+import numpy as np
+import pytest
+import torch
+
+import gpu_utils as U
+from conftest import Golden, diag
+from pytorch3dunet_amd import _native as nat
+
+pytestmark = pytest.mark.gpu
+
+
+def _level_of(key):
+    parts = key.split(".")
+    return f"{parts[0][:3]}{parts[1]}" if parts[0] in ("encoders", "decoders") else "head"
+
+
+# Measured on the ladder (profiles/r03_parity_diag.jsonl, test = "cfg4_bf16_ladder"); see the assertions below for how they are used.
+LAYER_VS_EMU = 6e-3        # a layer's output against the bf16-operand emulation, relative to the layer's range
+LAYER_VS_FP32 = 2.5e-2     # ... against the fp32 oracle (what bf16 operands cost after up to 18 layers)
+LOGITS_VS_FP32 = 1.5e-2    # logits against the fp32 oracle, relative to their range (round 2's constant was 3e-2)
+LEVEL_GRAD_VS_FP32 = 0.12  # per-level relative L2 of the parameter gradients against the fp32 oracle (round 2: 15 % globally)
+
+
+@pytest.mark.timeout(900)
+def test_config4_bf16_at_the_real_channel_ladder_level_by_level():
+    import unet3d_oracle as orc
+
+    g = Golden("g10_resunet3d_f64_ladder")
+    x, target = g.inputs()
+    model = g.build_model()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    G = g.cfg["num_groups"]
+    # --- CPU: fp32 oracle and its bf16-operand emulation (bf16 operands, wide accumulation), with per-layer traces
+    torch.set_num_threads(32)  # (the fastest oneDNN configuration on the 256-thread GPU-box host is 16-32 threads, tools/cpu_thread_scan.py)
+    tr32, l32 = orc.forward_decisions(sd, x, G, True)
+    _, _, _, g32 = orc.forward_backward(sd, x, target, G, True, True, g.loss_name)
+    orc.BF16_OPERANDS = True
+    try:
+        tr16, l16 = orc.forward_decisions(sd, x, G, True)
+        _, _, _, g16 = orc.forward_backward(sd, x, target, G, True, True, g.loss_name)
+    finally:
+        orc.BF16_OPERANDS = False
+    # --- GPU: compute_dtype = bf16
+    from pytorch3dunet_amd.unet3d.model import get_model
+
+    gm = get_model(dict(g.cfg, compute_dtype="bf16"))
+    gm.load_state_dict(sd)
+    gm = gm.to(U.DEV).train()
+    eng = gm._get_engine()
+    assert eng.bf16
+    eng.debug = {}
+    prof = nat.EventProfiler()
+    nat.profiler = prof
+    try:
+        probs, logits = gm(x.to(U.DEV), return_logits=True)
+        tape = eng.debug["tape"]
+        ys = [U.ncdhw(r.y) for r in tape.convs]
+        names = [r.name for r in tape.convs]
+        eng.debug = None
+        loss = orc.bce_dice_loss(logits, target.to(U.DEV))
+        gm.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        nat.profiler = None
+        eng.debug = None
+    ran = set(prof.summary())
+    assert {"u3d_conv3d_bf16_ex", "u3d_conv3d_wgrad_bf16", "u3d_convtr3d_fwd_t8", "u3d_convtr3d_dgrad_t8", "u3d_convtr3d_wgrad_t8"} <= ran, ran
+    # the bottom of the U really took the split-K path: the library asks for scratch at exactly those shapes (and only there)
+    lib = nat.get_lib()
+    assert lib.u3d_conv3d_bf16_workspace_floats(1, 4, 8, 8, 512, 512) > 0 and lib.u3d_conv3d_bf16_workspace_floats(1, 2, 4, 4, 1024, 1024) > 0
+    assert lib.u3d_conv3d_bf16_workspace_floats(1, 32, 64, 64, 64, 64) == 0
+    widths = [r.y.shape[-1] for r in tape.convs]
+    assert max(widths) == 1024 and len(ys) == len(tr16["pre"]) == 18
+    # --- layer by layer (forward): ours against the emulation and against fp32, relative to the layer's range
+    rows = []
+    for name, y, z16, z32 in zip(names, ys, tr16["pre"], tr32["pre"]):
+        r16, r32 = torch.relu(z16), torch.relu(z32)
+        scale = r32.abs().max().item()
+        rows.append(dict(layer=name, C=int(y.shape[1]), vs_emu=(y - r16).abs().max().item() / scale,
+                         vs_fp32=(y - r32).abs().max().item() / scale, emu_vs_fp32=(r16 - r32).abs().max().item() / scale))
+    lg = logits.detach().cpu()
+    e_l16, e_l32, e_l_or = orc.rel_err(lg, l16), orc.rel_err(lg, l32), orc.rel_err(l16, l32)
+    # --- level by level (backward): parameter gradients grouped by encoder / decoder level
+    grads = {k: p.grad.detach().cpu().double() for k, p in gm.named_parameters()}
+    lv = {}
+    for k in g32:
+        d = lv.setdefault(_level_of(k), dict(n16=0.0, n32=0.0, nor=0.0, den=0.0, ns=0.0, ds=0.0))
+        d["n16"] += (grads[k] - g16[k].double()).pow(2).sum().item()
+        d["n32"] += (grads[k] - g32[k].double()).pow(2).sum().item()
+        d["nor"] += (g16[k].double() - g32[k].double()).pow(2).sum().item()
+        d["den"] += g32[k].double().pow(2).sum().item()
+        rs = g.tensor("grad_s/" + k).double()  # what the IMPORTED reference produced for this parameter (strided samples)
+        d["ns"] += (grads[k].flatten()[::g.sample] - rs).pow(2).sum().item()
+        d["ds"] += rs.pow(2).sum().item()
+    levels = {k: dict(vs_emu=(d["n16"] / d["den"]) ** 0.5, vs_fp32=(d["n32"] / d["den"]) ** 0.5, emu_vs_fp32=(d["nor"] / d["den"]) ** 0.5,
+                      vs_reference_samples=(d["ns"] / d["ds"]) ** 0.5) for k, d in lv.items()}
+    diag(test="cfg4_bf16_ladder", logits_vs_emu=e_l16, logits_vs_fp32=e_l32, emu_vs_fp32_logits=e_l_or, layers=rows, levels=levels,
+         loss=loss.item(), ref_loss=g.loss)
+    for r in rows:
+        print(r)
+    for k, v in levels.items():
+        print(k, v)
+    assert set(levels) == {"enc0", "enc1", "enc2", "enc3", "enc4", "dec0", "dec1", "dec2", "dec3", "head"}
+    # every layer, incl. the 512 / 1024-channel ones, reproduces the emulated arithmetic far better than the emulation tracks fp32 ...
+    for r in rows:
+        assert r["vs_emu"] < LAYER_VS_EMU and r["vs_fp32"] < LAYER_VS_FP32, r
+    assert e_l16 < 0.75 * e_l_or and e_l32 < LOGITS_VS_FP32, (e_l16, e_l32, e_l_or)
+    # ... and every LEVEL's gradients are closer to the emulation than the emulation is to fp32, and within the stated bf16 band of
+    # the fp32 oracle and of the imported reference's own samples
+    for k, v in levels.items():
+        assert v["vs_emu"] < 0.75 * v["emu_vs_fp32"], (k, v)
+        assert v["vs_fp32"] < LEVEL_GRAD_VS_FP32 and v["vs_reference_samples"] < LEVEL_GRAD_VS_FP32, (k, v)
+    assert abs(loss.item() - g.loss) < 5e-3 * max(1.0, abs(g.loss))
+
+
+@pytest.mark.timeout(1500)
+def test_config5_standard_predictor_on_the_full_volume():
+    """ResidualUNetSE3D, 3 input channels, (3,96,192,192) volume, patch 48x96x96 + halo 8x16x16 (= 64x128x128 model inputs, the
+    workload of tools/predict_bench.py) through the drop-in StandardPredictor class on the device, against the reference loop on
+    the host with the torch.nn module tree of the same weights.  f_maps=32 keeps the host side near a minute."""
+    import fake_h5py
+    import predictor_oracle as porc
+    from pytorch3dunet_amd.unet3d import predictor as MP
+    from pytorch3dunet_amd.unet3d.model import get_model
+    from test_predictor import _MemTestDataset, _collate
+
+    fake_h5py.install()
+    torch.manual_seed(11)
+    cfg = dict(name="ResidualUNetSE3D", in_channels=3, out_channels=1, f_maps=32, num_groups=8, final_sigmoid=True)
+    model = get_model(cfg).eval()
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if "groupnorm" in k:
+                p.add_(0.2 * torch.randn_like(p))
+    rng = np.random.RandomState(5)
+    shape, patch, stride, halo = (96, 192, 192), (48, 96, 96), (48, 96, 96), (8, 16, 16)
+    raw = (rng.randn(3, *shape) * 1.7 + 0.3).astype(np.float32)
+    ds = _MemTestDataset(raw, patch, stride, halo, "/mem/in/cfg5.h5")
+    assert len(ds) == 8 and tuple(ds[0][0].shape) == (3, 64, 128, 128)
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, collate_fn=_collate)
+    n0 = nat.launch_count
+    gm = get_model(cfg)
+    gm.load_state_dict(model.state_dict())
+    gm = gm.to(U.DEV)
+    MP.StandardPredictor(gm, "/mem/out_cfg5", 1, "cuda", output_dataset="predictions")(loader)
+    assert nat.launch_count > n0
+    got = fake_h5py.STORE["/mem/out_cfg5/cfg5_predictions.h5"]["predictions"]
+    torch.set_num_threads(32)
+    expect = porc.standard_predict(model, raw, patch, stride, halo, batch_size=2, mean=ds.mean, std=ds.std)
+    assert got.shape == expect.shape == (1,) + shape and got.dtype == expect.dtype
+    err = float(np.abs(got - expect).max())
+    diag(test="cfg5_full_volume_predict", max_abs_err=err, ref_absmax=float(np.abs(expect).max()))
+    assert err < 1e-3 * max(1.0, float(np.abs(expect).max())), err

@@ -173,6 +173,10 @@ def test_model_matches_cpu_oracle(cfg, shape, loss_name):
     (dict(name="ResidualUNet3D", in_channels=1, out_channels=2, f_maps=[16, 32, 64], num_groups=8, final_sigmoid=False), (1, 1, 17, 33, 35), "probs_sum"),
     (dict(name="ResidualUNetSE3D", in_channels=1, out_channels=1, f_maps=16, num_levels=3, num_groups=8), (1, 1, 16, 32, 32), "bce_dice"),
     (dict(name="ResidualUNetSE3D", in_channels=3, out_channels=2, f_maps=[8, 24, 40], num_groups=4, final_sigmoid=False), (2, 3, 9, 13, 11), "probs_sum"),
+    # BASELINE config 2 EXACTLY (UNet3D f_maps=32, per-GPU batch 2x1x64x128x128, BCEDiceLoss): the tight gate at full size — slow,
+    # the float64 oracle is a minute or two of host time
+    pytest.param(dict(in_channels=1, out_channels=1, f_maps=32, num_groups=8), (2, 1, 64, 128, 128), "bce_dice",
+                 marks=pytest.mark.timeout(1800), id="config2-full-size"),
 ])
 def test_gradients_match_decision_consistent_fp64_oracle(cfg, shape, loss_name):
     """The tight gradient check: the float64 oracle with OUR ReLU masks and max-pool arg-maxes imposed

@@ -11,10 +11,10 @@ from pytorch3dunet_amd.unet3d.losses import BCEDiceLoss  # noqa: E402
 from pytorch3dunet_amd.unet3d.model import UNet3D  # noqa: E402
 
 dev = torch.device("cuda", 0)
-for mode in ("fp32", "fp32_split"):
+for mode, graph in (("fp32", False), ("fp32", True), ("fp32_split", False), ("fp32_split", True)):
     for f_maps, shape in ((32, (2, 1, 64, 128, 128)), (16, (1, 1, 32, 64, 64))):
         torch.manual_seed(0)
-        model = UNet3D(in_channels=1, out_channels=1, f_maps=f_maps, num_groups=8, compute_dtype=mode).to(dev).train()
+        model = UNet3D(in_channels=1, out_channels=1, f_maps=f_maps, num_groups=8, compute_dtype=mode, hip_graph=graph).to(dev).train()
         opt = torch.optim.Adam(model.parameters(), lr=2e-4)
         x = torch.randn(shape, device=dev)
         t = (torch.rand(shape, device=dev) > 0.5).float()
@@ -37,4 +37,4 @@ for mode in ("fp32", "fp32_split"):
         t1 = time.perf_counter()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        print(f"{mode} f_maps={f_maps} {shape}: host enqueue {1e3 * (t1 - t0) / K:.2f} ms/step, step {1e3 * (t2 - t0) / K:.2f} ms", flush=True)
+        print(f"{mode}{' hip_graph' if graph else ''} f_maps={f_maps} {shape}: host enqueue {1e3 * (t1 - t0) / K:.2f} ms/step, step {1e3 * (t2 - t0) / K:.2f} ms", flush=True)
