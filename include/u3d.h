@@ -368,6 +368,12 @@ int u3d_bce_dice_bwd(int device, u3d_stream_t stream, const float* logits, const
 int u3d_conv3d_bf16_supported(int Cin, int Cout);
 long long u3d_packed_weight_bf16_elems(int Cin, int Cout, int mode);
 int u3d_pack_weights_bf16(int device, u3d_stream_t stream, const float* w, int Cout, int Cin, int mode, void* packed);
+/* All bf16 images of a model in ONE launch, read and written at HBM rate (every optimizer step changes every weight: 36 + 36
+ * images per config-4 step).  descs: DEVICE array of n u3d_pack_desc_t sorted by `first` = first BLOCK of the image within the
+ * launch (descriptor 0: 0; an image takes u3d_pack_weights_bf16_blocks(Cin, Cout, mode) blocks), `packed` = the bf16 image
+ * (u3d_packed_weight_bf16_elems elements), mode 0 / 1, cin_stride unused; total_blocks = the sum over the descriptors. */
+long long u3d_pack_weights_bf16_blocks(int Cin, int Cout, int mode);
+int u3d_pack_weights_bf16_batch(int device, u3d_stream_t stream, const u3d_pack_desc_t* descs_device, int n, long long total_blocks);
 int u3d_conv3d_bf16(int device, u3d_stream_t stream, const float* x, const float* affine, const void* packed_w, float* out,
                     int N, int D, int H, int W, int Cin, int Cout, int relu, double* out_stats, const float* gx,
                     double* gstats, const float* residual);

@@ -21,7 +21,7 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-extern int g_u3d_tune[8];  // csrc/u3d_conv.hip: run-time A/B knobs (u3d_set_tuning); results never change
+extern int g_u3d_tune[16];  // csrc/u3d_conv.hip: run-time A/B knobs (u3d_set_tuning); results never change
 
 namespace {
 
@@ -412,7 +412,80 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int Cout, 
     }
 }
 
+// The same image for MANY weights in one launch, at HBM rate: a block owns one (16-channel chunk, 32-column n-tile) cell of one
+// descriptor's image — 13,824 floats of the master weight that are 32 (mode 0) or 16 (mode 1) CONTIGUOUS runs in the reference
+// layout — reads them coalesced into LDS and writes its 27 fragments (1 KiB each) 16 bytes per thread.  (The one-weight kernel
+// above reads 4 bytes per thread at a stride of 27 floats: 16x read amplification, 28 us per image, 36 + 16 launches per
+// config-4 step.)  desc.first = first block of the image; the block after an image's cells zeroes its 6-tap prefetch tail.
+constexpr int PK_RS0 = 433;  // mode 0: [32 columns][16 k x 27 taps + 1]   (odd stride: the 32 lanes of a store hit 32 banks)
+constexpr int PK_RS1 = 865;  // mode 1: [16 k][32 columns x 27 taps + 1]
+__global__ __launch_bounds__(256) void pack_weights_bf16_batch_kernel(const u3d_pack_desc_t* __restrict__ descs, int n) {
+    __shared__ float tile[32 * PK_RS0];  // 13,856 floats (>= 16 * PK_RS1 = 13,840)
+    const int t = threadIdx.x;
+    int d = 0;
+    while (d + 1 < n && (long long)blockIdx.x >= descs[d + 1].first) ++d;
+    const u3d_pack_desc_t ds = descs[d];
+    const int Cin = ds.Cin, Cout = ds.Cout, mode = ds.mode;
+    const int Kc = mode == 0 ? Cin : Cout, Nc = mode == 0 ? Cout : Cin;
+    const int ntiles = Nc >> 5, nch = Kc >> 4;
+    const int b = (int)((long long)blockIdx.x - ds.first);
+    __bf16* out = reinterpret_cast<__bf16*>(ds.packed);
+    if (b >= nch * ntiles) {  // tail: BDIST = 6 taps of zero fragments after the last chunk
+        bf16x8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
+        bf16x8* o8 = reinterpret_cast<bf16x8*>(out + (size_t)nch * 27 * ntiles * 512);
+        for (int i = t; i < 6 * ntiles * 64; i += 256) o8[i] = z;
+        return;
+    }
+    const int c = b / ntiles, nt = b - c * ntiles;
+    const float* w = ds.w;
+    if (mode == 0) {
+        // run r = column (output channel) nt*32 + r: floats [(col*Cin + c*16)*27, +432)
+        for (int i = t; i < 32 * 432; i += 256) {
+            const int r = i / 432, o = i - r * 432;
+            tile[r * PK_RS0 + o] = w[((size_t)(nt * 32 + r) * Cin + c * 16) * 27 + o];
+        }
+    } else {
+        // run r = k (output channel) c*16 + r: floats [(k*Cin + nt*32)*27, +864)
+        for (int i = t; i < 16 * 864; i += 256) {
+            const int r = i / 864, o = i - r * 864;
+            tile[r * PK_RS1 + o] = w[((size_t)(c * 16 + r) * Cin + nt * 32) * 27 + o];
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < 27 * 64; i += 256) {
+        const int tap = i >> 6, l = i & 63;
+        bf16x8 v;
+        if (mode == 0) {
+            const float* src = tile + (l & 31) * PK_RS0 + (8 * (l >> 5)) * 27 + tap;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (__bf16)src[e * 27];
+        } else {
+            const float* src = tile + (8 * (l >> 5)) * PK_RS1 + (l & 31) * 27 + (26 - tap);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (__bf16)src[e * PK_RS1];
+        }
+        *reinterpret_cast<bf16x8*>(out + ((((size_t)c * 27 + tap) * ntiles + nt) * 64 + l) * 8) = v;
+    }
+}
+
 }  // namespace
+
+extern "C" long long u3d_pack_weights_bf16_blocks(int Cin, int Cout, int mode) {
+    const int Kc = mode == 0 ? Cin : Cout, Nc = mode == 0 ? Cout : Cin;
+    if (Kc <= 0 || Nc <= 0 || Kc % 16 != 0 || Nc % 32 != 0 || (mode != 0 && mode != 1)) return 0;
+    return (long long)(Kc / 16) * (Nc / 32) + 1;
+}
+
+extern "C" int u3d_pack_weights_bf16_batch(int device, u3d_stream_t stream, const u3d_pack_desc_t* descs_device, int n,
+                                           long long total_blocks) {
+    U3D_ENTER(device);
+    U3D_REQUIRE(descs_device && n > 0 && total_blocks > 0 && total_blocks < 0x7fffffffLL, "u3d_pack_weights_bf16_batch: bad argument");
+    hipLaunchKernelGGL(pack_weights_bf16_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, descs_device, n);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" long long u3d_packed_weight_bf16_elems(int Cin, int Cout, int mode) {
     const int Kc = mode == 0 ? Cin : Cout, Nc = mode == 0 ? Cout : Cin;
@@ -570,6 +643,7 @@ struct bf16_wgrad_params {
     int tiles;            // N*tz*ty*tx
     int per_block;        // tiles per split
     int pco;              // K / 64
+    int xcd;              // 1: XCD-aware block order
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -600,7 +674,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wg
     extern __shared__ __attribute__((aligned(256))) char lds[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int P = (p.C >> 5) * p.pco;
-    const int pair = blockIdx.x % P, split = blockIdx.x / P;
+    // XCD-aware order: the P (input-chunk, output-block) pairs of one split read the SAME voxels — consecutive logical ids, i.e.
+    // one XCD's L2, so that an x / dz tile comes from HBM once per split instead of once per pair (block b runs on XCD b % 8)
+    const int bid = p.xcd ? u3d_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int pair = bid % P, split = bid / P;
     const int cib = pair / p.pco, cob = pair % p.pco;
     const int c0 = cib * 32, k0 = cob * 64;
     const int h = w >> 2, wq = w & 3;
@@ -807,7 +884,10 @@ wgrad_plan plan_wgrad(int N, int D, int H, int W, int C, int K) {
     q.tx = (W + WG_TX - 1) / WG_TX;
     q.tiles = N * q.tz * q.ty * q.tx;
     q.P = (C / 32) * (K / 64);
-    int target = 1024 / q.P;  // ~4 blocks per CU in total, 2 resident
+    // every block writes its 27 x 32 x 64 partial sums (221 KB) and the reduction reads them back: the block count is the
+    // split traffic.  512 = two per CU, all resident at once (one wave of blocks, equal tile counts)
+    const int blocks = g_u3d_tune[8] > 0 ? g_u3d_tune[8] : 512;
+    int target = blocks / q.P;
     if (target < 1) target = 1;
     q.per_block = (q.tiles + target - 1) / target;
     if (q.per_block < 1) q.per_block = 1;
@@ -836,7 +916,8 @@ extern "C" int u3d_conv3d_wgrad_bf16(int device, u3d_stream_t stream, const floa
     const long long need = (long long)q.S * q.P * 27 * 2048;
     if (!workspace || workspace_floats < need)
         return u3d_set_err(U3D_EWORKSPACE, "u3d_conv3d_wgrad_bf16: workspace of %lld floats needed, %lld given", need, workspace_floats);
-    bf16_wgrad_params p{x, affine, dz, workspace, N, D, H, W, C, K, 1, q.tz, q.ty, q.tx, q.tiles, q.per_block, K / 64};
+    bf16_wgrad_params p{x, affine, dz, workspace, N, D, H, W, C, K, 1, q.tz, q.ty, q.tx, q.tiles, q.per_block, K / 64,
+                        g_u3d_tune[9] == 1 ? 0 : 1};
     U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_bf16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 2 * wg_geom<3>::LDS));
     hipLaunchKernelGGL(conv3d_wgrad_bf16_kernel<3>, dim3((unsigned)(q.S * q.P)), dim3(512), 2 * wg_geom<3>::LDS, (hipStream_t)stream, p);
@@ -1005,7 +1086,7 @@ extern "C" int u3d_convtr3d_wgrad_t8(int device, u3d_stream_t stream, const floa
     const long long need = (long long)q.S * q.P * 8 * 2048;
     if (!workspace || workspace_floats < need)
         return u3d_set_err(U3D_EWORKSPACE, "u3d_convtr3d_wgrad_t8: workspace of %lld floats needed, %lld given", need, workspace_floats);
-    bf16_wgrad_params p{x, nullptr, dt8, workspace, N, D1, H1, W1, Cl, 8 * Cs, 0, q.tz, q.ty, q.tx, q.tiles, q.per_block, 8 * Cs / 64};
+    bf16_wgrad_params p{x, nullptr, dt8, workspace, N, D1, H1, W1, Cl, 8 * Cs, 0, q.tz, q.ty, q.tx, q.tiles, q.per_block, 8 * Cs / 64, g_u3d_tune[9] == 1 ? 0 : 1};
     U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_bf16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 2 * wg_geom<2>::LDS));
     hipLaunchKernelGGL(conv3d_wgrad_bf16_kernel<2>, dim3((unsigned)(q.S * q.P)), dim3(512), 2 * wg_geom<2>::LDS, (hipStream_t)stream, p);

@@ -24,7 +24,9 @@
 //   [4] 1 = never use the paired-y variant for <= 16 output channels
 //   [5] start-phase stagger of the persistent kernel in units of 1024 cycles (0 = off)
 //   [6] 1 = one persistent block per CU instead of two (occupancy experiment)
-int g_u3d_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+//   [8] bf16 weight gradient: target number of blocks (0 = default)   [9] 1 = bf16 weight gradient without the XCD-aware block order
+//   [10..15] free
+int g_u3d_tune[16] = {0};
 
 namespace cv {
 constexpr int TZ = 4, TY = 8, TX = 8;
@@ -1756,7 +1758,7 @@ extern "C" int u3d_set_profile_buffer(void* device_buffer, size_t bytes) {
 }
 
 extern "C" int u3d_set_tuning(int key, int value) {
-    if (key < 0 || key >= 8) return u3d_set_err(U3D_EINVAL, "u3d_set_tuning: key out of range");
+    if (key < 0 || key >= 16) return u3d_set_err(U3D_EINVAL, "u3d_set_tuning: key out of range");
     g_u3d_tune[key] = value;
     return 0;
 }

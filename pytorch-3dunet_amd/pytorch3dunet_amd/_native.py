@@ -212,6 +212,8 @@ _PROTOS = {
                                                                                  c_int64],
     ),
     "u3d_pack_weights_bf16": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "u3d_pack_weights_bf16_blocks": (c_int64, [c_int, c_int, c_int]),
+    "u3d_pack_weights_bf16_batch": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int64]),
     "u3d_conv3d_bf16": (
         c_int,
         [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
@@ -308,6 +310,11 @@ def get_lib():
             fn.argtypes = args
         if lib.u3d_version() < 112:
             raise U3DError("libu3d_hip.so is older than the Python host code")
+        for kv in os.environ.get("U3D_TUNE", "").split(","):  # A/B knobs of u3d_set_tuning, e.g. U3D_TUNE=8:256,9:1 (results never change)
+            if ":" in kv:
+                k, v = kv.split(":")
+                if lib.u3d_set_tuning(int(k), int(v)) != 0:
+                    raise U3DError(f"U3D_TUNE: bad knob {kv!r}")
         _lib = lib
     return _lib
 

@@ -448,6 +448,7 @@ class UNet3DEngine:
         self.hip_graph = bool(getattr(model, "hip_graph", False))
         self._graph_steps: dict = {}
         self._graph_off_reason = None
+        self._placed = None  # check_placement's memo
         self._salt = 0  # advanced by every training forward: see _ver
         self._const: dict = {}
         # the model-wide layer order (every SingleConv of a DoubleConv net shares it): non-linearity of the layer outputs
@@ -456,6 +457,9 @@ class UNet3DEngine:
         self.mask = 1 if self.act == ACT_RELU else 0  # ReLU backward is a fused mask in the consumer kernels
         self.params = module_params(model)
         self._pids = [id(p) for p in self.params]
+        # where the first parameter lives (model._get_engine's sentinel reads it back without walking the module tree)
+        self._first_param_owner, self._first_param_name = next(
+            ((mod, name) for mod in model.modules() for name, p in mod._parameters.items() if p is self.params[0]), (None, None))
         self._pindex = {id(p): i for i, p in enumerate(self.params)}
         self._build_layer_table(model)
         self._virtual_w = self._virtual_weights()
@@ -497,8 +501,12 @@ class UNet3DEngine:
         return (w._version, w.data_ptr(), self._salt)
 
     def begin_forward(self, training: bool):
-        if training or _ALWAYS_REPACK:
+        # the FIRST inference forward after a training forward also repacks: weights written through `param.data` while training
+        # (EMA swap before validation, trainer-side weight surgery) are then picked up without anybody calling
+        # invalidate_native_caches(); later inference forwards trust version + storage pointer again
+        if training or _ALWAYS_REPACK or getattr(self, "_last_training", False):
             self._salt += 1
+        self._last_training = training
 
     def _bf16_layer(self, Cin: int, Cout: int) -> bool:
         """forward AND data gradient of a (Cin -> Cout) 3x3x3 conv can run on the bf16 kernels (both directions need the
@@ -602,6 +610,47 @@ class UNet3DEngine:
             return w.data_ptr() + C0 * 27 * 4, C1, 3, Cin, lib.u3d_subpixel_dgrad_packed_floats(Cout, C1)
         return w.data_ptr(), Cin, mode, 0, lib.u3d_packed_weight_floats(Cin, Cout, mode)
 
+    def _repack_bf16_all(self, dev, modes, ws):
+        """bf16 fragment images of every bf16 layer whose parameter changed: ONE launch at HBM rate (u3d_pack_weights_bf16_batch)
+        instead of one strided-read launch per layer and mode (36 + 36 per config-4 step, 1.0 ms -> 0.25 ms)"""
+        lib = nat.get_lib()
+        stale = []
+        for w in ws:
+            if not self._bf16_layer(w.shape[1], w.shape[0]) or id(w) in self._virtual_w:
+                continue
+            for mode in modes:
+                hit = self._pack_cache.get((id(w), 20 + mode))
+                if hit is None or hit[0] != self._ver(w):
+                    stale.append((w, mode))
+        if not stale:
+            return
+        key = tuple((id(w), mode, w.data_ptr()) for w, mode in stale)
+        tab = getattr(self, "_pack_tables_bf16", None)
+        if tab is None:
+            tab = self._pack_tables_bf16 = {}
+        ent = tab.get(key)
+        if ent is None:
+            descs = (nat.U3DPackDesc * len(stale))()
+            bufs, first = [], 0
+            for i, (w, mode) in enumerate(stale):
+                Cout, Cin = w.shape[0], w.shape[1]
+                n = lib.u3d_packed_weight_bf16_elems(Cin, Cout, mode)
+                hit = self._pack_cache.get((id(w), 20 + mode))
+                buf = hit[1] if hit is not None and hit[1].numel() == n and hit[1].device == dev else _empty(
+                    n, dtype=torch.bfloat16, device=dev)
+                bufs.append(buf)
+                descs[i].w, descs[i].packed, descs[i].first = w.data_ptr(), buf.data_ptr(), first
+                descs[i].Cout, descs[i].Cin, descs[i].mode, descs[i].cin_stride = Cout, Cin, mode, 0
+                first += lib.u3d_pack_weights_bf16_blocks(Cin, Cout, mode)
+            host = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8)
+            ent = (host.to(dev), bufs, first)
+            tab.clear()
+            tab[key] = ent
+        table, bufs, total = ent
+        nat.call("u3d_pack_weights_bf16_batch", dev.index, _stream(dev), _p(table), len(stale), total)
+        for (w, mode), buf in zip(stale, bufs):
+            self._pack_cache[(id(w), 20 + mode)] = (self._ver(w), buf)
+
     def _repack_all(self, dev, modes, sub=()):
         """(Re)pack the images of ALL conv weights whose parameter changed since the last pack — one launch for the whole
         model (u3d_pack_weights_batch) instead of one per layer and mode.  The packed buffers and the device descriptor
@@ -609,6 +658,8 @@ class UNet3DEngine:
         ws = getattr(self, "_cw", None)
         if ws is None:
             ws = self._cw = self._conv_weights()
+        if self.bf16:
+            self._repack_bf16_all(dev, modes, ws)
         stale = []
         for w in ws:
             if self.small_cin and w.shape[1] <= 4 and w.shape[0] <= 32:
@@ -804,7 +855,9 @@ class UNet3DEngine:
         # else transforms it (ReLU is in the epilogue); a post-norm layer needs them for its own GroupNorm
         want_stats = ((post and spec.norm is not None and inner in (ACT_NONE, ACT_RELU))
                       or (not post and want_stats and act in (ACT_NONE, ACT_RELU)))
-        bn_training = bool(gn.training) if spec.norm == "b" else True
+        # ONE flag for the finalize call (batch vs running statistics) and for backward (mean / rstd functions of x vs constants): a
+        # BatchNorm3d without running estimates normalises with batch statistics in eval mode too (_norm_finalize)
+        bn_training = (bool(gn.training) or gn.running_mean is None) if spec.norm == "b" else True
         if post:
             affine, mean_rstd = self._identity_affine(N, Ctot, dev), None
         else:
@@ -1721,6 +1774,7 @@ class ResUNetEngine(UNet3DEngine):
             if lean:
                 dec_blocks[j] = ups[j] = None
             dj = self._block_bwd(cx, rec, dz)  # gradient of the block's residual r (= the joined tensor when conv1 is nn.Identity)
+            dz = None
             if up.concat is not None:
                 # concat joining: through the block's 1x1x1 conv, then split into the skip's and the resized tensor's gradient
                 Cs_, Ct_ = up.concat
@@ -1735,6 +1789,7 @@ class ResUNetEngine(UNet3DEngine):
             else:
                 assert rec.conv1 is None
                 skip_grad[n_levels - 2 - j] = dj   # summation joining: the skip receives dj as is
+            rec = None  # (lean tape: the block's activations go back to the allocator before the transposed convolution's buffers)
             xl = up.x_low
             Nl, D1, H1, W1, Cl = xl.shape
             _, Ds, Hs, Ws, Cs = dj.shape
@@ -1790,6 +1845,7 @@ class ResUNetEngine(UNet3DEngine):
             if lean:
                 enc_blocks[i] = None
             dr = self._block_bwd(cx, rec, dz)
+            dz = None
             need_dx = i > 0 or need_input_grad
             if rec.conv1 is not None:
                 dxin = self._conv1_bwd(cx, rec, dr, need_dx)
@@ -1806,6 +1862,7 @@ class ResUNetEngine(UNet3DEngine):
                 out = _empty_like(e_in)
                 nat.call("u3d_maxpool2_bwd_merge", dev.index, _stream(dev), _p(dxin), _p(pooled), _p(argmax), None,
                          _p(skip_grad.get(i - 1)), _p(e_in), Ne, De, He, We, Ce, mk, _p(out))
+                skip_grad.pop(i - 1, None)
                 dz = out
             elif need_input_grad:
                 dx0 = dxin
@@ -1840,6 +1897,9 @@ class _UNet3DFunction(torch.autograd.Function):
         ctx.x_requires_grad = x.requires_grad
         ctx.skel = None
         ctx.lean_tape = None
+        # parameters are referenced by position, not saved: record their versions so that an in-place update between forward and
+        # backward is refused like stock autograd refuses it (backward would otherwise repack and use the NEW weights)
+        ctx.pversions = [p._version for p in engine.params] if tape is not None else None
         if tape is not None and engine.lean_tape:
             # memory-lean mode (checkpoint_encoders): the tape stays a plain Python object owned by this node, so that backward can
             # release it block by block — autograd's saved-tensor slots are only freed when the whole node is done.  The price:
@@ -1865,6 +1925,11 @@ class _UNet3DFunction(torch.autograd.Function):
         # a second backward without retain_graph=True raises autograd's own "backward through the graph a second time" here
         saved = ctx.saved_tensors
         probs = saved[0] if ctx.has_probs else None
+        for p, v in zip(engine.params, ctx.pversions):
+            if p._version != v:
+                raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace operation: "
+                                   f"a parameter of shape {tuple(p.shape)} is at version {p._version}, expected version {v} "
+                                   "(u3d: the weights changed between this forward and its backward)")
         if ctx.lean_tape is not None:
             tape = ctx.lean_tape
             if tape.consumed:
@@ -2039,11 +2104,16 @@ def graph_step_for(engine: UNet3DEngine, x: torch.Tensor) -> Optional[GraphStep]
 def check_placement(engine: UNet3DEngine, x: torch.Tensor):
     """The kernels read raw pointers: every parameter must be fp32 and live on the input's device (stock modules raise
     ATen's device/dtype mismatch errors in the same situations, e.g. model.half() or a model left on another GPU)."""
+    first, last = engine.params[0], engine.params[-1]
+    if engine._placed == (x.device, first.data_ptr(), last.data_ptr()):
+        return  # every parameter was checked for this device and these storages (module.to / .half re-allocate them)
+    engine._placed = None
     for p in engine.params:
         if p.device != x.device or p.dtype != torch.float32:
             raise RuntimeError(f"u3d: parameter of shape {tuple(p.shape)} is {p.dtype} on {p.device}, the input is "
                                f"{x.dtype} on {x.device} — the native gfx950 path needs fp32 parameters on the input's "
                                "device (one process per GPU: pytorch3dunet_amd.parallel.attach; or model.to(x.device))")
+    engine._placed = (x.device, first.data_ptr(), last.data_ptr())
 
 
 def run_model(engine: UNet3DEngine, x: torch.Tensor):

@@ -120,8 +120,17 @@ class AbstractUNet(nn.Module):
         from ..engine import ResUNetEngine, UNet3DEngine, module_params
 
         eng = self.__dict__.get("_engine")
-        if eng is not None and eng.model is self and eng._pids == [id(p) for p in module_params(self)]:
-            return eng
+        if eng is not None and eng.model is self:
+            # cheap per-forward sentinel (this path is host-bound for small patches): the first and the last parameter OBJECT of the
+            # module order; wholesale replacement (load_state_dict(assign=True), parametrizations) changes both.  The full walk
+            # runs only when the sentinel moved
+            fc = self.final_conv
+            last = fc.bias if fc.bias is not None else fc.weight
+            owner = eng._first_param_owner  # (None on an nn.DataParallel replica: its parameters are plain attributes)
+            if owner is not None and id(last) == eng._pids[-1] and id(owner._parameters.get(eng._first_param_name)) == eng._pids[0]:
+                return eng
+            if eng._pids == [id(p) for p in module_params(self)]:
+                return eng
         new = (ResUNetEngine if self._residual else UNet3DEngine)(self)
         if eng is not None and eng.model is self:
             new.grad_sync = eng.grad_sync  # same module, new parameter objects: keep the data-parallel hook

@@ -100,9 +100,17 @@ class StandardPredictor(AbstractPredictor):
             logger.info(f"Using halo: {patch_halo}")
             self.model.eval()  # (:141-143)
             logger.info(f"Running inference on {len(test_loader)} batches")
-            volume = None if self.lazy else torch.zeros(
-                prediction_shape, dtype=torch.int32 if self.save_segmentation else torch.float32, device=dev)
-            stager = _HostStager(dev) if self.lazy else None
+            volume, streamed = None, self.lazy
+            if not self.lazy:
+                try:
+                    volume = torch.zeros(prediction_shape, dtype=torch.int32 if self.save_segmentation else torch.float32, device=dev)
+                except torch.OutOfMemoryError:
+                    # the reference assembles the volume in HOST memory (predictor.py:130-133): a volume that fits there but not
+                    # beside the model's activations in HBM must still predict — stream the patches through the pinned slabs
+                    logger.warning("output volume does not fit in free device memory: staging the patches through pinned host buffers")
+                    torch.cuda.empty_cache()
+                    streamed = True
+            stager = _HostStager(dev) if streamed else None
             with torch.no_grad():
                 for input, indices in test_loader:
                     input = input.to(dev, non_blocking=True)
@@ -114,12 +122,12 @@ class StandardPredictor(AbstractPredictor):
                         prediction = remove_padding(prediction, patch_halo)  # (:166-167)
                     assert len(prediction) == len(indices), "batch of predictions and of patch indices differ in length"
                     placed = [self._patch_and_index(pred, index) for pred, index in zip(prediction, indices)]
-                    if self.lazy:
+                    if streamed:
                         stager.push(placed, prediction_array)
                     else:
                         for index, pred in placed:  # strided device copies; later patches overwrite earlier ones
                             volume[index] = pred
-            if self.lazy:
+            if streamed:
                 stager.drain(prediction_array)
             else:
                 prediction_array[...] = volume.cpu().numpy().astype(prediction_array.dtype, copy=False)  # the ONE D2H trip
@@ -167,30 +175,45 @@ class LazyPredictor(StandardPredictor):
 
 
 class _HostStager:
-    """two-slot pinned staging of per-batch predictions: D2H of batch i on a side stream, H5 write of batch i-1 on the host"""
+    """two-slot pinned staging of per-batch predictions: D2H of batch i on a side stream, H5 write of batch i-1 on the host.
+    The two slabs are allocated once (grown if a later batch is larger) and used alternately — pinned allocations are
+    expensive host calls, one per sample per batch would cost more than the copies."""
 
     def __init__(self, dev: torch.device):
         self.dev = dev
         self.cuda = dev.type == "cuda"
         self.stream = torch.cuda.Stream(dev) if self.cuda else None
-        self.pending = []  # [(event, [(index, host tensor)])], at most two
+        self.pending = []  # [(event, [(index, host view)])], at most two
+        self.slabs = [None, None]  # pinned byte buffers
+        self.turn = 0
+
+    def _slab(self, nbytes: int) -> torch.Tensor:
+        buf = self.slabs[self.turn]
+        if buf is None or buf.numel() < nbytes:
+            buf = self.slabs[self.turn] = torch.empty(max(nbytes, 1), dtype=torch.uint8, pin_memory=True)
+        return buf
 
     def push(self, placed, dest):
         if not self.cuda:
             for index, pred in placed:
                 dest[index] = pred.numpy().astype(dest.dtype, copy=False)
             return
+        # the slab of this turn was last used two pushes ago; its batch has been flushed (at most one batch stays pending)
+        sizes = [(pred.numel() * pred.element_size() + 63) // 64 * 64 for _, pred in placed]
+        slab = self._slab(sum(sizes))
         self.stream.wait_stream(torch.cuda.current_stream(self.dev))
-        items = []
+        items, off = [], 0
         with torch.cuda.stream(self.stream):
-            for index, pred in placed:
-                host = torch.empty(pred.shape, dtype=pred.dtype, pin_memory=True)
+            for (index, pred), size in zip(placed, sizes):
+                host = slab[off:off + pred.numel() * pred.element_size()].view(pred.dtype).view(pred.shape)
+                off += size
                 host.copy_(pred, non_blocking=True)
                 pred.record_stream(self.stream)
                 items.append((index, host))
             ev = torch.cuda.Event()
             ev.record(self.stream)
         self.pending.append((ev, items))
+        self.turn ^= 1
         while len(self.pending) > 1:  # write the previous batch while this one is in flight
             self._flush_one(dest)
 

@@ -23,11 +23,17 @@ def _level_of(key):
     return f"{parts[0][:3]}{parts[1]}" if parts[0] in ("encoders", "decoders") else "head"
 
 
-# Measured on the ladder (profiles/r03_parity_diag.jsonl, test = "cfg4_bf16_ladder"); see the assertions below for how they are used.
-LAYER_VS_EMU = 6e-3        # a layer's output against the bf16-operand emulation, relative to the layer's range
-LAYER_VS_FP32 = 2.5e-2     # ... against the fp32 oracle (what bf16 operands cost after up to 18 layers)
-LOGITS_VS_FP32 = 1.5e-2    # logits against the fp32 oracle, relative to their range (round 2's constant was 3e-2)
-LEVEL_GRAD_VS_FP32 = 0.12  # per-level relative L2 of the parameter gradients against the fp32 oracle (round 2: 15 % globally)
+# Measured on this ladder (profiles/r03_parity_diag.jsonl, test = "cfg4_bf16_ladder"), each bound = 1.5-2x the measured figure:
+#   layer outputs vs the bf16-operand emulation 1.3e-4 (64 ch) ... 5.5e-3 (512 ch decoder), vs fp32 2.3e-3 ... 7.3e-3; logits
+#   2.4e-3 / 4.5e-3 (round 2's constant for small nets was 3e-2).  Gradients are what bf16 operands really cost: per LEVEL the
+#   relative L2 against fp32 grows from 0.5-0.7 % (64 ch) to 13-16 % at the 512 / 1024-channel levels — for the CPU EMULATION
+#   exactly as for the kernels (emu-vs-fp32 0.7 % ... 15.8 %): a ReLU network is chaotic in the last operand bit.  Hence per-level
+#   caps (round 2: one global 15 %) plus the relative gates "not farther from fp32 than the emulation is" below.
+LAYER_VS_EMU = 1e-2
+LAYER_VS_FP32 = 1.2e-2
+LOGITS_VS_EMU, LOGITS_VS_FP32 = 5e-3, 9e-3
+LEVEL_GRAD_VS_FP32 = {"enc0": 0.012, "enc1": 0.035, "enc2": 0.11, "enc3": 0.22, "enc4": 0.22, "dec0": 0.19, "dec1": 0.09, "dec2": 0.022,
+                      "dec3": 0.009, "head": 0.003}
 
 
 @pytest.mark.timeout(900)
@@ -114,12 +120,14 @@ def test_config4_bf16_at_the_real_channel_ladder_level_by_level():
     # every layer, incl. the 512 / 1024-channel ones, reproduces the emulated arithmetic far better than the emulation tracks fp32 ...
     for r in rows:
         assert r["vs_emu"] < LAYER_VS_EMU and r["vs_fp32"] < LAYER_VS_FP32, r
-    assert e_l16 < 0.75 * e_l_or and e_l32 < LOGITS_VS_FP32, (e_l16, e_l32, e_l_or)
-    # ... and every LEVEL's gradients are closer to the emulation than the emulation is to fp32, and within the stated bf16 band of
-    # the fp32 oracle and of the imported reference's own samples
+    assert e_l16 < LOGITS_VS_EMU and e_l16 < 0.75 * e_l_or and e_l32 < LOGITS_VS_FP32, (e_l16, e_l32, e_l_or)
+    # ... and every LEVEL's gradients are no farther from the emulation than the emulation is from fp32, no farther from fp32
+    # than the emulation is (10 % slack), and inside the level's measured bf16 band — against the oracle and against the samples
+    # the imported reference left in the fixture
     for k, v in levels.items():
-        assert v["vs_emu"] < 0.75 * v["emu_vs_fp32"], (k, v)
-        assert v["vs_fp32"] < LEVEL_GRAD_VS_FP32 and v["vs_reference_samples"] < LEVEL_GRAD_VS_FP32, (k, v)
+        assert v["vs_emu"] < v["emu_vs_fp32"], (k, v)
+        assert v["vs_fp32"] < 1.1 * v["emu_vs_fp32"] + 1e-3, (k, v)
+        assert v["vs_fp32"] < LEVEL_GRAD_VS_FP32[k] and v["vs_reference_samples"] < LEVEL_GRAD_VS_FP32[k], (k, v)
     assert abs(loss.item() - g.loss) < 5e-3 * max(1.0, abs(g.loss))
 
 
