@@ -440,17 +440,34 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_batch_kernel(const u3d_
     }
     const int c = b / ntiles, nt = b - c * ntiles;
     const float* w = ds.w;
-    if (mode == 0) {
-        // run r = column (output channel) nt*32 + r: floats [(col*Cin + c*16)*27, +432)
-        for (int i = t; i < 32 * 432; i += 256) {
-            const int r = i / 432, o = i - r * 432;
-            tile[r * PK_RS0 + o] = w[((size_t)(nt * 32 + r) * Cin + c * 16) * 27 + o];
+    // 3456 float4 of the cell, 13.5 per thread, all loads in flight before the first LDS store (runs start at multiples of
+    // 16 * 27 floats = 1728 bytes: 16-byte aligned whenever the parameter is)
+    {
+        const int RUN4 = mode == 0 ? 108 : 216;           // float4 per run: 432 / 864 floats
+        const int RS = mode == 0 ? PK_RS0 : PK_RS1;
+        const size_t run_stride = mode == 0 ? (size_t)Cin * 27 : (size_t)Cin * 27;
+        const float* base = mode == 0 ? w + ((size_t)(nt * 32) * Cin + c * 16) * 27 : w + ((size_t)(c * 16) * Cin + nt * 32) * 27;
+        f32x4 v[14];
+#pragma unroll
+        for (int j = 0; j < 14; ++j) {
+            const int i = t + 256 * j;
+            v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < 3456) {
+                const int r = i / RUN4, o = i - r * RUN4;
+                v[j] = *reinterpret_cast<const f32x4*>(base + (size_t)r * run_stride + 4 * o);
+            }
         }
-    } else {
-        // run r = k (output channel) c*16 + r: floats [(k*Cin + nt*32)*27, +864)
-        for (int i = t; i < 16 * 864; i += 256) {
-            const int r = i / 864, o = i - r * 864;
-            tile[r * PK_RS1 + o] = w[((size_t)(c * 16 + r) * Cin + nt * 32) * 27 + o];
+#pragma unroll
+        for (int j = 0; j < 14; ++j) {
+            const int i = t + 256 * j;
+            if (i < 3456) {
+                const int r = i / RUN4, o = i - r * RUN4;
+                float* dst = tile + r * RS + 4 * o;
+                dst[0] = v[j][0];
+                dst[1] = v[j][1];
+                dst[2] = v[j][2];
+                dst[3] = v[j][3];
+            }
         }
     }
     __syncthreads();
@@ -885,8 +902,9 @@ wgrad_plan plan_wgrad(int N, int D, int H, int W, int C, int K) {
     q.tiles = N * q.tz * q.ty * q.tx;
     q.P = (C / 32) * (K / 64);
     // every block writes its 27 x 32 x 64 partial sums (221 KB) and the reduction reads them back: the block count is the
-    // split traffic.  512 = two per CU, all resident at once (one wave of blocks, equal tile counts)
-    const int blocks = g_u3d_tune[8] > 0 ? g_u3d_tune[8] : 512;
+    // split traffic.  Measured on config 4 (profiles/r03e): 1024 blocks 7.2 ms per step, 512 5.75, 256 (one per CU — the kernel
+    // double-buffers inside the block) 5.13
+    const int blocks = g_u3d_tune[8] > 0 ? g_u3d_tune[8] : 256;
     int target = blocks / q.P;
     if (target < 1) target = 1;
     q.per_block = (q.tiles + target - 1) / target;

@@ -616,8 +616,8 @@ class UNet3DEngine:
         lib = nat.get_lib()
         stale = []
         for w in ws:
-            if not self._bf16_layer(w.shape[1], w.shape[0]) or id(w) in self._virtual_w:
-                continue
+            if not self._bf16_layer(w.shape[1], w.shape[0]) or id(w) in self._virtual_w or w.data_ptr() % 16 != 0:
+                continue  # (the batch kernel reads 16 bytes per lane; an unaligned view is packed on demand by _packed_bf16)
             for mode in modes:
                 hit = self._pack_cache.get((id(w), 20 + mode))
                 if hit is None or hit[0] != self._ver(w):
@@ -1741,6 +1741,7 @@ class ResUNetEngine(UNet3DEngine):
                 Nb, Db, Hb, Wb, _ = b.x_in.shape
                 Cb = b.bm.conv2.conv.in_channels
                 need = max(need, self._layer_ws_floats(Nb, Db, Hb, Wb, Cb, Cb))
+        b = u = None  # (loop variables would pin the LAST decoder block — the full-resolution one — for the whole backward)
         ws = _empty(max(int(need), 4), dtype=_F32, device=dev)
         cx = _BwdCtx(dev, pool, ws, flat, self)
         gview = cx.gview

@@ -81,7 +81,17 @@ def dumping(name, *a, **k):
                 if torch.is_tensor(o) and o.is_cuda:
                     st = o.untyped_storage()
                     if st.nbytes() >= 32 << 20 and st.data_ptr() not in seen:
-                        seen[st.data_ptr()] = (st.nbytes(), tuple(o.shape), str(o.dtype))
+                        who = []
+                        for r in gc.get_referrers(o):
+                            if isinstance(r, dict):
+                                owners = [type(x).__name__ for x in gc.get_referrers(r) if hasattr(x, "__dict__") and x.__dict__ is r]
+                                keys = [k for k, v in r.items() if v is o]
+                                who.append(f"{'/'.join(owners) or 'dict'}.{','.join(map(str, keys))}")
+                            elif isinstance(r, (list, tuple)):
+                                who.append(type(r).__name__)
+                            else:
+                                who.append(type(r).__name__)
+                        seen[st.data_ptr()] = (st.nbytes(), tuple(o.shape), str(o.dtype) + "  <- " + "; ".join(sorted(set(who))[:6]))
             except Exception:
                 pass
         for nb, shp, dt in sorted(seen.values(), reverse=True):
