@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define U3D_VERSION 112 /* bf16-operand convolutions; residual blocks in every native layer order */
+#define U3D_VERSION 113 /* 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16) */
 
 #define U3D_OK 0
 #define U3D_EINVAL (-1)  /* bad shape / argument */
@@ -488,6 +488,47 @@ int u3d_bn_bwd_finalize(int device, u3d_stream_t stream, const double* gstats, c
 int u3d_bias_table(int device, u3d_stream_t stream, const float* bias, int N, int C, float* affine);
 int u3d_bias_grad(int device, u3d_stream_t stream, const double* stats, int N, int C, float* dbias);
 int u3d_mul(int device, u3d_stream_t stream, const float* a, const float* b, int64_t n, float* out);
+
+/* ---- bf16 ACTIVATION STORAGE (`activation_dtype: bf16`, BASELINE config 4: ResidualUNet3D with bf16 compute) ------------------
+ * The same operators with every NDHWC activation / gradient tensor stored as bf16 (`void*` arguments below; what
+ * torch.autocast(bfloat16) leaves in memory between buildingblocks.py:277-288's operators): half the HBM bytes of every
+ * bandwidth-bound pass and of the convolutions' operand traffic.  Unchanged: fp32 arithmetic and accumulation, fp32 parameters,
+ * weight gradients and affine / coefficient tables, f64 statistics (taken over the values AS STORED, so the consuming GroupNorm
+ * normalises exactly the tensor it reads), fp32 logits / probabilities, fp32 split-K scratch.  Stores round to nearest even.
+ * Argument meaning = the entry point of the same name without the suffix.  Channel counts: multiples of 4 (8-byte quads). */
+int u3d_conv3d_bf16_ex_b16(int device, u3d_stream_t stream, const void* x, const float* affine, const void* packed_w, void* out,
+                           int N, int D, int H, int W, int C, int K, int relu, double* out_stats, const void* gx, double* gstats,
+                           const void* residual, float* workspace, long long workspace_floats);
+int u3d_conv3d_wgrad_bf16_b16(int device, u3d_stream_t stream, const void* x, const float* affine, const void* dz, float* dw, int N,
+                              int D, int H, int W, int C, int K, float* workspace, long long workspace_floats);
+int u3d_convtr3d_fwd_t8_b16(int device, u3d_stream_t stream, const void* x, const void* packed, void* t8, int N, int D1, int H1,
+                            int W1, int Cl, int Cs);
+int u3d_convtr3d_dgrad_t8_b16(int device, u3d_stream_t stream, const void* dt8, const void* packed, const void* x_mask, void* dx,
+                              int N, int D1, int H1, int W1, int Cl, int Cs);
+int u3d_convtr3d_wgrad_t8_b16(int device, u3d_stream_t stream, const void* x, const void* dt8, float* dw, int N, int D1, int H1,
+                              int W1, int Cl, int Cs, float* workspace, long long workspace_floats);
+/* x_is_f32: the block input is the fp32 network input (first encoder block) */
+int u3d_conv1x1_fwd_b16(int device, u3d_stream_t stream, const void* x, int x_is_f32, const float* w, const float* bias, void* y,
+                        int N, int64_t V, int Cin, int Cout, double* out_stats);
+int u3d_conv1x1_bwd_b16(int device, u3d_stream_t stream, const void* dy, const void* x, int x_is_f32, const float* w, int N,
+                        int64_t V, int Cin, int Cout, void* dx, double* acc);
+int u3d_maxpool2_fwd_b16(int device, u3d_stream_t stream, const void* x, int N, int D, int H, int W, int C, void* out,
+                         uint8_t* argmax);
+int u3d_maxpool2_bwd_merge_b16(int device, u3d_stream_t stream, const void* dg, const void* pooled, const uint8_t* argmax,
+                               const float* coef, const void* skip_grad, const void* e, int N, int D, int H, int W, int C,
+                               int relu_mask, void* out);
+int u3d_nearest_add_fwd_t8_b16(int device, u3d_stream_t stream, const void* skip, const void* t8, const int32_t* zmap,
+                               const int32_t* ymap, const int32_t* xmap, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C,
+                               void* out, double* out_stats);
+int u3d_nearest_sum_bwd_t8_b16(int device, u3d_stream_t stream, const void* dj, const int32_t* zlo, const int32_t* ylo,
+                               const int32_t* xlo, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C, void* dt8);
+/* add may be NULL (u3d_gn_bwd_apply) */
+int u3d_gn_bwd_apply_b16(int device, u3d_stream_t stream, const void* dg, int Cdg, int coff, const void* x, int Cx, const float* coef,
+                         int Ctot, int64_t voxels_per_n, int N, int relu_mask, const void* add, void* out);
+int u3d_conv1x1_head_fwd_b16(int device, u3d_stream_t stream, const void* x, const float* w, const float* b, int N, int64_t V,
+                             int Cin, int Cout, int act, float* logits, float* probs);
+int u3d_conv1x1_head_bwd_b16(int device, u3d_stream_t stream, const float* dlogits, const void* x, const float* w, int N, int64_t V,
+                             int Cin, int Cout, int relu_mask, void* dx, double* acc);
 
 /* ---- layout: NCDHW <-> NDHWC for multi-channel model inputs ------------------------------------ */
 int u3d_ncdhw_to_ndhwc(int device, u3d_stream_t stream, const float* src, float* dst, int N, int C, int64_t V);

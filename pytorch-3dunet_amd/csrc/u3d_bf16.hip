@@ -44,6 +44,8 @@ struct bf16_conv_params {
     int ksplit;            // > 1: the channel reduction is split over `ksplit` blocks per (tile, channel block); raw partial
     float* ws;             //      sums go to ws[split][voxel][K] and splitk_bf16_reduce_kernel owns the epilogue
     long long wpart;       // split-fp32 kernels: distance (in bf16x8 records) between the high / middle / low weight images
+    int b16;               // 1: x, y, residual, gx, maskx are bf16 tensors (activation storage, `_b16` entry points); the pointer
+                           //    fields keep their float* type and are reinterpreted by the kernels' storage type T
 };
 
 template <int ZW, int KS>
@@ -64,11 +66,16 @@ struct tile_geom {
     static constexpr int ITERS = (ITEMS + 255) / 256;
     static constexpr int NPARTS = KS * KS;                // staging parts per chunk = (z tap, y tap) groups of KS taps
     static constexpr int PER_PART = (ITERS + NPARTS - 1) / NPARTS;
+    // bf16 activation storage: a staging item is a channel OCTET (16 bytes, one halo voxel x one channel-half plane) — half the
+    // vector-memory instructions, half the LDS stores, full 16-byte lanes
+    static constexpr int ITEMS8 = HZ * HY * HX * 2;
+    static constexpr int ITERS8 = (ITEMS8 + 255) / 256;
+    static constexpr int PER_PART8 = (ITERS8 + NPARTS - 1) / NPARTS;
 };
 
 // Epilogue shared by the bf16-operand and the split-fp32 kernels: residual, ReLU, fp32 store, per-(n,channel) statistics (or, with
 // ksplit > 1, the raw partial sums of this block's chunk range).  `lds` is free for the block reduction when this runs.
-template <int NT, int ZW, int KS>
+template <int NT, int ZW, int KS, typename T = float>
 __device__ __forceinline__ void conv_tile_epilogue(const bf16_conv_params& p, f32x16 (&acc)[2 * ZW][NT], char* lds, int n, int nb,
                                                    int split, int z0, int y0, int x0, int t, int lane, int w) {
     using G = tile_geom<ZW, KS>;
@@ -97,7 +104,83 @@ __device__ __forceinline__ void conv_tile_epilogue(const bf16_conv_params& p, f3
 #pragma unroll
     for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
     const bool want_stats = p.out_stats != nullptr, want_g = p.gstats != nullptr;
-    const float* side = p.residual ? p.residual : (want_g ? p.gx : p.maskx);  // the one tensor the epilogue reads (exclusive)
+    const T* side = reinterpret_cast<const T*>(p.residual ? p.residual : (want_g ? p.gx : p.maskx));  // the one tensor the epilogue reads (exclusive)
+    if constexpr (std::is_same<T, __bf16>::value) {
+        // bf16 storage: in the accumulator layout a lane owns ONE channel, i.e. 2-byte stores and 2-byte side loads — 64 + 64
+        // vector-memory instructions per lane for 8 KB per wave (measured: the 64-channel layers 20-30 % slower than with fp32
+        // storage).  The tile therefore goes through LDS (the halo buffers are free now) as [voxel][channel] bf16: the side
+        // tensor comes in and the result goes out as 16-byte items (8 channels of a voxel per lane, 8 + 8 instructions per lane);
+        // residual / mask / ReLU / rounding / statistics happen in between, in the accumulator layout, on 2-byte LDS accesses.
+        constexpr int RSB = NT * 64 + 16;            // bytes per voxel row (+16: the two half-waves' rows land on different banks)
+        constexpr int OCT = NT * 4;                  // 16-byte items per voxel
+        constexpr int NITEM = 64 * G::TZ * OCT / 256;  // items per thread (the tile has 64 * TZ voxels)
+        const int K = p.K;
+        T* yout = reinterpret_cast<T*>(p.y);
+        auto item_addr = [&](int k, int& lds_off, size_t& goff) {  // item t + 256 k -> LDS byte offset, global element offset, inside?
+            const int item = t + 256 * k;
+            const int v = item / OCT, o = item - v * OCT;
+            const int zl = v >> 6, yl = (v >> 3) & 7, xl = v & 7;
+            const int z = z0 + zl, y = y0 + yl, xx = x0 + xl;
+            lds_off = v * RSB + o * 16;
+            goff = ((((size_t)n * p.D + z) * p.H + y) * p.W + xx) * K + (size_t)nb * NT * 32 + o * 8;
+            return z < p.D && y < p.H && xx < p.W;
+        };
+        __syncthreads();  // every wave has left the k-loop: the halo buffers are free
+        if (side) {
+            bf16x8 sv8[NITEM];
+#pragma unroll
+            for (int k = 0; k < NITEM; ++k) {
+                int lo_;
+                size_t go;
+                sv8[k] = bf16x8{};
+                if (item_addr(k, lo_, go)) sv8[k] = *reinterpret_cast<const bf16x8*>(side + go);
+            }
+#pragma unroll
+            for (int k = 0; k < NITEM; ++k) {
+                int lo_;
+                size_t go;
+                item_addr(k, lo_, go);
+                *reinterpret_cast<bf16x8*>(lds + lo_) = sv8[k];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int m = 0; m < G::MT; ++m) {
+            const int zl = w * ZW + (m >> 1);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int yl = (m & 1) * 4 + (e & 3), xl = 2 * (e >> 2) + half;
+                    __bf16* cell = reinterpret_cast<__bf16*>(lds + ((zl * 8 + yl) * 8 + xl) * RSB) + j * 32 + col;
+                    const float sv = side ? (float)*cell : 0.f;
+                    float v = acc[m][j][e];
+                    if (p.residual) v += sv;
+                    if (p.maskx && !(sv > 0.f)) v = 0.f;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    const __bf16 vb = (__bf16)v;
+                    *cell = vb;
+                    v = (float)vb;  // (statistics describe the STORED tensor)
+                    if (z0 + zl < p.D && y0 + yl < p.H && x0 + xl < p.W) {
+                        if (want_stats) {
+                            s1[j] += v;
+                            s2[j] = fmaf(v, v, s2[j]);
+                        } else if (want_g) {
+                            s1[j] += v;
+                            s2[j] = fmaf(v, sv, s2[j]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NITEM; ++k) {
+            int lo_;
+            size_t go;
+            if (item_addr(k, lo_, go)) *reinterpret_cast<bf16x8*>(yout + go) = *reinterpret_cast<const bf16x8*>(lds + lo_);
+        }
+    } else {
     // Addressing is hoisted: element e of an accumulator tile sits (e & 3) rows and 2*(e >> 2) voxels from the tile's first
     // voxel, so one 64-bit base per (m, j) plus sixteen 32-bit offsets replaces a five-term index per element; tiles that lie
     // wholly inside the volume (all but the ragged rim) skip the per-element bounds tests.
@@ -106,14 +189,14 @@ __device__ __forceinline__ void conv_tile_epilogue(const bf16_conv_params& p, f3
     auto emit_tile = [&](auto FULL, int m, int j) {
         const int z = z0 + w * ZW + (m >> 1), yb = y0 + (m & 1) * 4, xb = x0 + half;
         const size_t base = ((((size_t)n * p.D + z) * p.H + yb) * p.W + xb) * K + (size_t)(nb * NT + j) * 32 + col;
-        float* yp = p.y + base;
-        const float* sp = side ? side + base : nullptr;
+        T* yp = reinterpret_cast<T*>(p.y) + base;
+        const T* sp = side ? side + base : nullptr;
         auto inside = [&](int e) { return FULL.value || (z < p.D && yb + (e & 3) < p.H && xb + 2 * (e >> 2) < p.W); };
         f32x16 sv;  // all 16 side loads of this accumulator tile in flight before the first use
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             sv[e] = 0.f;
-            if (sp && inside(e)) sv[e] = sp[(e & 3) * rowK + (e >> 2) * 2 * K];
+            if (sp && inside(e)) sv[e] = u3d_ld(sp + (e & 3) * rowK + (e >> 2) * 2 * K);
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -122,7 +205,8 @@ __device__ __forceinline__ void conv_tile_epilogue(const bf16_conv_params& p, f3
                 if (p.residual) v += sv[e];
                 if (p.maskx && !(sv[e] > 0.f)) v = 0.f;
                 if (p.relu) v = fmaxf(v, 0.f);
-                yp[(e & 3) * rowK + (e >> 2) * 2 * K] = v;
+                v = u3d_stored(v, yp);  // (statistics describe the STORED tensor)
+                u3d_st(yp + (e & 3) * rowK + (e >> 2) * 2 * K, v);
                 if (want_stats) {
                     s1[j] += v;
                     s2[j] = fmaf(v, v, s2[j]);
@@ -143,6 +227,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const bf16_conv_params& p, f3
                 emit_tile(std::false_type{}, m, j);
         }
     }
+    }  // (fp32 storage)
     if (want_stats || want_g) {
         // fixed-order block reduction through LDS (the halo buffers are free now), then one f64 atomic per (n, channel)
         __syncthreads();
@@ -165,7 +250,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const bf16_conv_params& p, f3
 
 // ABL: timing-only ablation bits that attributed the loop's cost (1 no B loads, 2 no A reads, 4 no staging, 8 no barrier; results
 // in DESIGN.md 4.7).  Only ABL = 0 is instantiated.
-template <int NT, int ZW, int KS, int ABL = 0>
+template <int NT, int ZW, int KS, int ABL = 0, typename T = float>
 __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_params p) {
     using G = tile_geom<ZW, KS>;
     constexpr int HY = G::HY;
@@ -188,7 +273,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
     const int cps = (nch_all + p.ksplit - 1) / p.ksplit;          // chunks per split
     const int cbeg = split * cps, nch = min(nch_all, cbeg + cps);  // this block's chunk range [cbeg, nch)
     const int ntiles = p.K >> 5;
-    const int q = t & 3;  // this thread's channel quad within a chunk (item & 3 == t & 3 for every item it stages)
+    constexpr bool B16 = std::is_same<T, __bf16>::value;
+    // staging role of this thread: fp32 storage -> channel QUAD q = t & 3 of halo voxel t >> 2 (+64 per item);
+    // bf16 storage -> channel OCTET (= channel-half plane) q = t & 1 of halo voxel t >> 1 (+128 per item)
+    constexpr int QS = B16 ? 1 : 2, VSTEP = 256 >> QS, NIT = B16 ? G::ITERS8 : G::ITERS, PER = B16 ? G::PER_PART8 : G::PER_PART;
+    const int q = t & ((1 << QS) - 1);
 
     // A-fragment base of this lane: row r = lane & 31 -> (yy = r & 3, xx = r >> 2), channel half kh = lane >> 5
     const int r = lane & 31, kh = lane >> 5;
@@ -199,57 +288,88 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
     // own first voxel) and are zeroed by a select (zero padding applies AFTER the GroupNorm affine, as Conv3d(padding=1) on the
     // normalised tensor requires); items past the tile's halo write into the plane's pad bytes.  (Measured before: ~10 VALU
     // instructions per MFMA and a scalar branch per item and tap; every branch in the unrolled loop cost 1-2 % of the kernel.)
-    int rel[G::ITERS], lo[G::ITERS];
+    int rel[NIT], lo[NIT];
     unsigned okmask = 0;
     {
-        const int hv0 = t >> 2;
+        const int hv0 = t >> QS;
         const int bz = hv0 / (G::HY * G::HX), brem = hv0 - bz * (G::HY * G::HX), by = brem / G::HX, bx = brem - by * G::HX;
         const int rel_safe = ((p.off * p.H + p.off) * p.W + p.off) * p.C;  // the tile's first output voxel: always inside the volume
 #pragma unroll
-        for (int it = 0; it < G::ITERS; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             constexpr int HYX = G::HY * G::HX;
-            const int dz = (64 * it) / HYX, dy = ((64 * it) % HYX) / G::HX, dx = (64 * it) % G::HX;  // compile-time
+            const int dz = (VSTEP * it) / HYX, dy = ((VSTEP * it) % HYX) / G::HX, dx = (VSTEP * it) % G::HX;  // compile-time
             int hx = bx + dx, hy = by + dy, hz = bz + dz;
             if (hx >= G::HX) hx -= G::HX, hy += 1;
             if (hy >= G::HY) hy -= G::HY, hz += 1;
+            if (hy >= G::HY) hy -= G::HY, hz += 1;  // (a 128-voxel step can carry twice into z on the small 2x2x2 halo)
             const int z = z0 - p.off + hz, y = y0 - p.off + hy, xx = x0 - p.off + hx;
             const bool ok = hz < G::HZ && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
             rel[it] = ok ? ((hz * p.H + hy) * p.W + hx) * p.C : rel_safe;
             okmask |= (ok ? 1u : 0u) << it;
-            lo[it] = hz < G::HZ ? (q >> 1) * G::PLANE + ((hz * G::HY + hy) * HS + hx) * 16 + (q & 1) * 8 : G::PLANE - 64 + (t & 7) * 8;
+            if constexpr (B16)
+                lo[it] = hz < G::HZ ? q * G::PLANE + ((hz * G::HY + hy) * HS + hx) * 16 : G::PLANE - 64 + (t & 3) * 16;
+            else
+                lo[it] = hz < G::HZ ? (q >> 1) * G::PLANE + ((hz * G::HY + hy) * HS + hx) * 16 + (q & 1) * 8 : G::PLANE - 64 + (t & 7) * 8;
         }
     }
-    // halo origin of the tile (may lie outside the tensor: only dereferenced through `rel`), this thread's channel quad
-    const float* xo = p.x + ((((long long)n * p.D + (z0 - p.off)) * p.H + (y0 - p.off)) * p.W + (x0 - p.off)) * (long long)p.C + 4 * q;
+    // halo origin of the tile (may lie outside the tensor: only dereferenced through `rel`), this thread's channel quad / octet
+    const T* xo = reinterpret_cast<const T*>(p.x) + ((((long long)n * p.D + (z0 - p.off)) * p.H + (y0 - p.off)) * p.W + (x0 - p.off)) * (long long)p.C + (B16 ? 8 : 4) * q;
     const int rel_dump = ((p.off * p.H + p.off) * p.W + p.off) * p.C;
+    // one staged item in registers: 4 fp32 channels, or 8 bf16 channels (both 16 bytes)
+    using item_t = typename std::conditional<B16, bf16x8, f32x4>::type;
+    // the GroupNorm affine of this thread's channels in the staged chunk: (a, b) x 4 (quad) or x 8 (octet)
+    struct aff_t {
+        f32x4 a0, b0, a1, b1;
+    };
+    const bool has_aff = p.affine != nullptr;  // uniform; the data-gradient launches have none: bf16 items are then copied as they are
     // live = false (the last chunk has nothing to stage): every item re-reads one cached address instead of branching
-    auto load_item = [&](int c, int it, f32x4& v, bool live = true) {
-        v = *reinterpret_cast<const f32x4*>(xo + (live ? rel[it] : rel_dump) + (c << 4));
+    auto load_item = [&](int c, int it, item_t& v, bool live = true) {
+        v = *reinterpret_cast<const item_t*>(xo + (live ? rel[it] : rel_dump) + (c << 4));
     };
-    auto store_item = [&](char* buf, int it, const f32x4& v, const f32x4& ga, const f32x4& gb) {
-        bf16x4 o;
+    auto store_item = [&](char* buf, int it, const item_t& v, const aff_t& g) {
         const bool ok = (okmask >> it) & 1u;
+        if constexpr (B16) {
+            bf16x8 o;
+            if (has_aff) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (__bf16)(ok ? fmaf(v[e], ga[e], gb[e]) : 0.f);
-        *reinterpret_cast<bf16x4*>(buf + lo[it]) = o;
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (__bf16)(ok ? fmaf((float)v[e], g.a0[e], g.b0[e]) : 0.f);
+                    o[4 + e] = (__bf16)(ok ? fmaf((float)v[4 + e], g.a1[e], g.b1[e]) : 0.f);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = ok ? v[e] : (__bf16)0.f;
+            }
+            *reinterpret_cast<bf16x8*>(buf + lo[it]) = o;
+        } else {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (__bf16)(ok ? fmaf(v[e], g.a0[e], g.b0[e]) : 0.f);
+            *reinterpret_cast<bf16x4*>(buf + lo[it]) = o;
+        }
     };
-    auto chunk_affine = [&](int c, f32x4& ga, f32x4& gb) {
-        u3d_load_affine(p.affine, n, p.C, (c << 4) + 4 * q, true, ga, gb);
+    auto chunk_affine = [&](int c, aff_t& g) {
+        if constexpr (B16) {
+            u3d_load_affine(p.affine, n, p.C, (c << 4) + 8 * q, true, g.a0, g.b0);
+            u3d_load_affine(p.affine, n, p.C, (c << 4) + 8 * q + 4, true, g.a1, g.b1);
+        } else {
+            u3d_load_affine(p.affine, n, p.C, (c << 4) + 4 * q, true, g.a0, g.b0);
+        }
     };
 
     // ---- prologue: the first chunk into its buffer, 8 loads in flight per thread (the accumulators are not live yet)
     if (cbeg < nch) {
-        f32x4 ga, gb;
-        chunk_affine(cbeg, ga, gb);
+        aff_t g0;
+        chunk_affine(cbeg, g0);
 #pragma unroll
-        for (int it0 = 0; it0 < G::ITERS; it0 += 8) {
-            f32x4 v[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (it0 + i < G::ITERS) load_item(cbeg, it0 + i, v[i]);
+        for (int it0 = 0; it0 < NIT; it0 += 8) {
+            item_t v[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                if (it0 + i < G::ITERS) store_item(lds + (cbeg & 1) * G::BUF, it0 + i, v[i], ga, gb);
+                if (it0 + i < NIT) load_item(cbeg, it0 + i, v[i]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (it0 + i < NIT) store_item(lds + (cbeg & 1) * G::BUF, it0 + i, v[i], g0);
         }
     }
     f32x16 acc[G::MT][NT];
@@ -280,10 +400,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
         char* nxt = lds + ((c + 1) & 1) * G::BUF;
         const bool more = c + 1 < nch;
         const int cn = more ? c + 1 : c;  // the chunk staged under this one (the last chunk stages a dummy: never read)
-        f32x4 ga, gb;
-        chunk_affine(cn, ga, gb);
+        aff_t gaff;
+        chunk_affine(cn, gaff);
         const bf16x8* wp = p.wpk + ((size_t)c * G::NTAPS * ntiles + (size_t)nb * NT) * 64;  // wave-uniform (scalar) base
-        f32x4 st[G::PER_PART];
+        item_t st[PER];
         bf16x8 aq[G::ADIST + 1][G::MT] = {};
 #pragma unroll
         for (int d = 0; d < G::ADIST; ++d) {
@@ -295,8 +415,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
 #pragma unroll
         for (int part = 0; part < G::NPARTS; ++part) {  // part = (z tap, y tap)
 #pragma unroll
-            for (int i = 0; i < G::PER_PART; ++i)
-                if (!(ABL & 4) && part * G::PER_PART + i < G::ITERS) load_item(cn, part * G::PER_PART + i, st[i], more);
+            for (int i = 0; i < PER; ++i)
+                if (!(ABL & 4) && part * PER + i < NIT) load_item(cn, part * PER + i, st[i], more);
 #pragma unroll
             for (int t3 = 0; t3 < KS; ++t3) {
                 const int tap = part * KS + t3;
@@ -319,17 +439,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int i = 0; i < G::PER_PART; ++i)
-                if (!(ABL & 4) && part * G::PER_PART + i < G::ITERS) store_item(nxt, part * G::PER_PART + i, st[i], ga, gb);
+            for (int i = 0; i < PER; ++i)
+                if (!(ABL & 4) && part * PER + i < NIT) store_item(nxt, part * PER + i, st[i], gaff);
         }
     }
 
-    conv_tile_epilogue<NT, ZW, KS>(p, acc, lds, n, nb, split, z0, y0, x0, t, lane, w);
+    conv_tile_epilogue<NT, ZW, KS, T>(p, acc, lds, n, nb, split, z0, y0, x0, t, lane, w);
 }
 
 // out = [relu](sum over splits (fixed order) + residual), statistics like the fused epilogue.
 // grid (voxel blocks, ceil(K/256), N); thread = one channel, loops over the block's voxels
+template <typename T = float>
 __global__ __launch_bounds__(256) void splitk_bf16_reduce_kernel(const bf16_conv_params p, long long V, int vper) {
+    const T* presidual = reinterpret_cast<const T*>(p.residual);
+    const T* pmaskx = reinterpret_cast<const T*>(p.maskx);
+    const T* pgx = reinterpret_cast<const T*>(p.gx);
+    T* py = reinterpret_cast<T*>(p.y);
     // block = 64 channels (16 float4 quads) x 16 voxel slots; a thread adds the splits of its quad for vper/16 voxels (fixed order),
     // the 16 slots' statistics meet in LDS (fixed order) and the block issues ONE f64 atomic per channel and sum — the first
     // version (thread = channel, one atomic pair per 16 voxels) spent most of its 60 us on 128-way contended atomics
@@ -344,9 +469,9 @@ __global__ __launch_bounds__(256) void splitk_bf16_reduce_kernel(const bf16_conv
             const size_t o = ((size_t)n * V + v) * p.K + c;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             for (int s = 0; s < p.ksplit; ++s) acc += *reinterpret_cast<const f32x4*>(p.ws + s * split_stride + o);
-            if (p.residual) acc += *reinterpret_cast<const f32x4*>(p.residual + o);
+            if (p.residual) acc += u3d_ldq(presidual + o);
             if (p.maskx) {
-                const f32x4 mx = *reinterpret_cast<const f32x4*>(p.maskx + o);
+                const f32x4 mx = u3d_ldq(pmaskx + o);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[e] = mx[e] > 0.f ? acc[e] : 0.f;
             }
@@ -354,12 +479,14 @@ __global__ __launch_bounds__(256) void splitk_bf16_reduce_kernel(const bf16_conv
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.f);
             }
-            *reinterpret_cast<f32x4*>(p.y + o) = acc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = u3d_stored(acc[e], py);
+            u3d_stq(py + o, acc);
             s1 += acc;
             if (p.out_stats)
                 s2 += acc * acc;
             else if (p.gstats)
-                s2 += acc * *reinterpret_cast<const f32x4*>(p.gx + o);
+                s2 += acc * u3d_ldq(pgx + o);
         }
     }
     double* dst = p.out_stats ? p.out_stats : p.gstats;
@@ -527,7 +654,7 @@ extern "C" int u3d_pack_weights_bf16(int device, u3d_stream_t stream, const floa
 
 extern "C" int u3d_conv3d_bf16_supported(int C, int K) { return (C > 0 && K > 0 && C % 16 == 0 && K % 32 == 0) ? 1 : 0; }
 
-template <int NT, int ZW, int KS, int ABL = 0>
+template <int NT, int ZW, int KS, int ABL = 0, typename T = float>
 static int launch_bf16(const bf16_conv_params& p, hipStream_t stream) {
     using G = tile_geom<ZW, KS>;
     bf16_conv_params q = p;
@@ -536,16 +663,17 @@ static int launch_bf16(const bf16_conv_params& p, hipStream_t stream) {
     q.tx = (p.W + 7) / 8;
     const long long blocks = (long long)p.N * q.tz * q.ty * q.tx * (p.K / (32 * NT)) * p.ksplit;
     if (blocks > 0x7fffffffLL) return u3d_set_err(U3D_EINVAL, "u3d_conv3d_bf16: grid too large");
-    const size_t shmem = 2 * (size_t)G::BUF;
+    size_t shmem = 2 * (size_t)G::BUF;
+    if (std::is_same<T, __bf16>::value && shmem < (size_t)64 * G::TZ * (NT * 64 + 16)) shmem = (size_t)64 * G::TZ * (NT * 64 + 16);  // epilogue tile
     // (per device, cheap: set on every launch so that every device of a multi-GPU process has it)
-    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_bf16_kernel<NT, ZW, KS, ABL>),
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_bf16_kernel<NT, ZW, KS, ABL, T>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL((conv3d_bf16_kernel<NT, ZW, KS, ABL>), dim3((unsigned)blocks), dim3(256), shmem, stream, q);
+    hipLaunchKernelGGL((conv3d_bf16_kernel<NT, ZW, KS, ABL, T>), dim3((unsigned)blocks), dim3(256), shmem, stream, q);
     U3D_LAUNCH_CHECK();
     if (p.ksplit > 1) {
         const long long V = (long long)p.D * p.H * p.W;
         const int vper = 64;
-        hipLaunchKernelGGL(splitk_bf16_reduce_kernel, dim3((unsigned)((V + vper - 1) / vper), (unsigned)((p.K + 63) / 64), (unsigned)p.N),
+        hipLaunchKernelGGL(splitk_bf16_reduce_kernel<T>, dim3((unsigned)((V + vper - 1) / vper), (unsigned)((p.K + 63) / 64), (unsigned)p.N),
                            dim3(256), 0, stream, q, V, vper);
         U3D_LAUNCH_CHECK();
     }
@@ -582,10 +710,31 @@ extern "C" int u3d_conv3d_bf16(int device, u3d_stream_t stream, const float* x, 
                               nullptr, 0);
 }
 
+static int conv3d_bf16_impl(int device, u3d_stream_t stream, const float* x, const float* affine, const void* packed_w, float* out,
+                           int N, int D, int H, int W, int C, int K, int relu, double* out_stats, const float* gx, double* gstats,
+                           const float* residual, float* workspace, long long workspace_floats, int b16);
+
 extern "C" int u3d_conv3d_bf16_ex(int device, u3d_stream_t stream, const float* x, const float* affine, const void* packed_w,
                                   float* out, int N, int D, int H, int W, int C, int K, int relu, double* out_stats,
                                   const float* gx, double* gstats, const float* residual, float* workspace,
                                   long long workspace_floats) {
+    return conv3d_bf16_impl(device, stream, x, affine, packed_w, out, N, D, H, W, C, K, relu, out_stats, gx, gstats, residual, workspace,
+                            workspace_floats, 0);
+}
+
+// bf16 ACTIVATION STORAGE (`activation_dtype: bf16`): x, out, gx and residual are bf16 NDHWC tensors (half the HBM bytes of every
+// halo read, output write and epilogue side read); arithmetic, statistics (taken over the stored values), the affine table and
+// the split-K scratch are unchanged
+extern "C" int u3d_conv3d_bf16_ex_b16(int device, u3d_stream_t stream, const void* x, const float* affine, const void* packed_w,
+                                      void* out, int N, int D, int H, int W, int C, int K, int relu, double* out_stats, const void* gx,
+                                      double* gstats, const void* residual, float* workspace, long long workspace_floats) {
+    return conv3d_bf16_impl(device, stream, (const float*)x, affine, packed_w, (float*)out, N, D, H, W, C, K, relu, out_stats,
+                            (const float*)gx, gstats, (const float*)residual, workspace, workspace_floats, 1);
+}
+
+static int conv3d_bf16_impl(int device, u3d_stream_t stream, const float* x, const float* affine, const void* packed_w, float* out,
+                           int N, int D, int H, int W, int C, int K, int relu, double* out_stats, const float* gx, double* gstats,
+                           const float* residual, float* workspace, long long workspace_floats, int b16) {
     U3D_ENTER(device);
     U3D_REQUIRE(x && packed_w && out && N > 0 && D > 0 && H > 0 && W > 0, "u3d_conv3d_bf16: bad argument");
     U3D_REQUIRE(u3d_conv3d_bf16_supported(C, K), "u3d_conv3d_bf16: needs Cin %% 16 == 0 and Cout %% 32 == 0 (got %d, %d)", C, K);
@@ -595,6 +744,7 @@ extern "C" int u3d_conv3d_bf16_ex(int device, u3d_stream_t stream, const float* 
     U3D_REQUIRE((((uintptr_t)x | (uintptr_t)packed_w | (uintptr_t)affine) & 15) == 0, "u3d_conv3d_bf16: 16-byte alignment");
     bf16_conv_params p{x, affine, reinterpret_cast<const bf16x8*>(packed_w), out, residual, gx, out_stats, gstats,
                        N, D, H, W, C, K, relu, 0, 0, 0, 1, nullptr, 1, nullptr};
+    p.b16 = b16;
     const int ks = bf16_ksplit(N, D, H, W, C, K);
     if (ks > 1 && workspace && workspace_floats >= (long long)ks * N * D * H * W * K) {
         p.ksplit = ks;
@@ -608,6 +758,7 @@ extern "C" int u3d_conv3d_bf16_ex(int device, u3d_stream_t stream, const float* 
     // left for the staging descriptors and the deeper rings; u3d_set_tuning key 7 = 2 selects them for A/B runs
     const bool zw2 = g_u3d_tune[7] == 2 && big >= 512 && D >= 8 && p.ksplit == 1;
     hipStream_t s = (hipStream_t)stream;
+    if (b16) return nt2 ? launch_bf16<2, 1, 3, 0, __bf16>(p, s) : launch_bf16<1, 1, 3, 0, __bf16>(p, s);
     if (nt2) return zw2 ? launch_bf16<2, 2, 3>(p, s) : launch_bf16<2, 1, 3>(p, s);
     return zw2 ? launch_bf16<1, 2, 3>(p, s) : launch_bf16<1, 1, 3>(p, s);
 }
@@ -647,6 +798,12 @@ struct wg_geom {
     static constexpr int PER_PART = ITERS / PARTS;
     static constexpr int NTAPS = KS * KS * KS;
     static constexpr int NTW = (NTAPS + 3) / 4;                // taps (= accumulators) per wave: 7 / 2
+    // bf16 activation storage: items are channel OCTETS (16 bytes): half the loads and LDS stores
+    static constexpr int G_ITEMS8 = HZ * HY * HX * 4;
+    static constexpr int G_ITERS8 = (G_ITEMS8 + 511) / 512;
+    static constexpr int DZ_ITERS8 = (WG_TZ * WG_TY * WG_TX * 8 + 511) / 512;
+    static constexpr int ITERS8 = ((G_ITERS8 + DZ_ITERS8 + PARTS - 1) / PARTS) * PARTS;
+    static constexpr int PER_PART8 = ITERS8 / PARTS;
 };
 
 struct bf16_wgrad_params {
@@ -683,8 +840,10 @@ struct wg_tile {
 // One block per CU (8 waves, 163 VGPRs): the staging of tile i+1 must overlap the MFMAs of tile i INSIDE the block — two LDS
 // buffers; the next tile's 20 items per thread are fetched in four batches of five at the start of each 4-row part of the
 // current tile and written (affine, bf16) to the other buffer at the part's end; one barrier per tile.
-template <int KS>
+template <int KS, typename T = float>
 __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wgrad_params p) {
+    const T* px = reinterpret_cast<const T*>(p.x);    // (the parameter block keeps float* fields; T is the storage type)
+    const T* pdz = reinterpret_cast<const T*>(p.dz);
     using G = wg_geom<KS>;
     constexpr int WG_HY = G::HY, WG_HX = G::HX, WG_G_BYTES = G::G_BYTES, WG_LDS = G::LDS, WG_G_ITEMS = G::G_ITEMS,
                   WG_G_ITERS = G::G_ITERS, WG_ITERS = G::ITERS, WG_PARTS = G::PARTS, WG_PER_PART = G::PER_PART, NTW = G::NTW;
@@ -710,50 +869,88 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wg
         r.n = tt / p.tz;
         return r;
     };
-    // staging item `it` of this thread: it < WG_G_ITERS: (halo voxel, quad t & 7) of the g tile, else (voxel, quad t & 15) of dz
-    auto load_item = [&](const wg_tile& tl, int it, f32x4& v) {
-        v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (it < WG_G_ITERS) {
+    // staging item `it` of this thread: it < GI: (halo voxel, channel quad t & 7) of the g tile, else (voxel, quad t & 15) of dz;
+    // bf16 storage: channel OCTETS (t & 3 of g, t & 7 of dz), 16 bytes each, dz copied without a conversion
+    constexpr bool B16 = std::is_same<T, __bf16>::value;
+    constexpr int GI = B16 ? G::G_ITERS8 : WG_G_ITERS, DI = B16 ? G::DZ_ITERS8 : WG_DZ_ITERS, NITEMS_G = B16 ? G::G_ITEMS8 : WG_G_ITEMS;
+    constexpr int NIT = B16 ? G::ITERS8 : WG_ITERS, PER = B16 ? G::PER_PART8 : WG_PER_PART;
+    constexpr int GS = B16 ? 2 : 3, DS = B16 ? 3 : 4;  // log2(items per voxel) of g / dz
+    using item_t = typename std::conditional<B16, bf16x8, f32x4>::type;
+    struct aff_t {
+        f32x4 a0, b0, a1, b1;
+    };
+    const bool has_aff = p.affine != nullptr;
+    auto load_aff = [&](int n_, aff_t& g) {
+        if constexpr (B16) {
+            u3d_load_affine(p.affine, n_, p.C, c0 + 8 * (t & 3), true, g.a0, g.b0);
+            u3d_load_affine(p.affine, n_, p.C, c0 + 8 * (t & 3) + 4, true, g.a1, g.b1);
+        } else {
+            u3d_load_affine(p.affine, n_, p.C, c0 + 4 * (t & 7), true, g.a0, g.b0);
+        }
+    };
+    auto load_item = [&](const wg_tile& tl, int it, item_t& v) {
+        v = item_t{};
+        if (it < GI) {
             const int item = t + it * 512;
-            if (item < WG_G_ITEMS) {
-                const int q = item & 7, hv = item >> 3;
+            if (item < NITEMS_G) {
+                const int q = item & ((1 << GS) - 1), hv = item >> GS;
                 const int hz = hv / (WG_HY * WG_HX), rem = hv - hz * (WG_HY * WG_HX);
                 const int hy = rem / WG_HX, hx = rem - hy * WG_HX;
                 const int z = tl.z0 - p.off + hz, y = tl.y0 - p.off + hy, xx = tl.x0 - p.off + hx;
                 if ((unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
-                    v = *reinterpret_cast<const f32x4*>(p.x + ((((size_t)tl.n * p.D + z) * p.H + y) * p.W + xx) * p.C + c0 + 4 * q);
+                    v = *reinterpret_cast<const item_t*>(px + ((((size_t)tl.n * p.D + z) * p.H + y) * p.W + xx) * p.C + c0 + (B16 ? 8 : 4) * q);
             }
-        } else if (it < WG_G_ITERS + WG_DZ_ITERS) {
-            const int item = t + (it - WG_G_ITERS) * 512;
-            const int q = item & 15, vv = item >> 4;
+        } else if (it < GI + DI) {
+            const int item = t + (it - GI) * 512;
+            const int q = item & ((1 << DS) - 1), vv = item >> DS;
             const int zl = vv / (WG_TY * WG_TX), rem = vv - zl * (WG_TY * WG_TX);
             const int yl = rem / WG_TX, xl = rem - yl * WG_TX;
             const int z = tl.z0 + zl, y = tl.y0 + yl, xx = tl.x0 + xl;
             if (z < p.D && y < p.H && xx < p.W)
-                v = *reinterpret_cast<const f32x4*>(p.dz + ((((size_t)tl.n * p.D + z) * p.H + y) * p.W + xx) * p.K + k0 + 4 * q);
+                v = *reinterpret_cast<const item_t*>(pdz + ((((size_t)tl.n * p.D + z) * p.H + y) * p.W + xx) * p.K + k0 + (B16 ? 8 : 4) * q);
         }
     };
-    auto store_item = [&](char* buf, const wg_tile& tl, int it, const f32x4& v, const f32x4& ga, const f32x4& gb) {
-        bf16x4 o = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-        if (it < WG_G_ITERS) {
+    auto store_item = [&](char* buf, const wg_tile& tl, int it, const item_t& v, const aff_t& g) {
+        if (it < GI) {
             const int item = t + it * 512;
-            if (item < WG_G_ITEMS) {
-                const int q = item & 7, hv = item >> 3;
+            if (item < NITEMS_G) {
+                const int q = item & ((1 << GS) - 1), hv = item >> GS;
                 const int hz = hv / (WG_HY * WG_HX), rem = hv - hz * (WG_HY * WG_HX);
                 const int hy = rem / WG_HX, hx = rem - hy * WG_HX;
                 const int z = tl.z0 - p.off + hz, y = tl.y0 - p.off + hy, xx = tl.x0 - p.off + hx;
-                if ((unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
+                const bool ok = (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+                if constexpr (B16) {
+                    bf16x8 o;
+                    if (has_aff) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)fmaf(v[e], ga[e], gb[e]);  // zero padding applies AFTER the affine
+                        for (int e = 0; e < 4; ++e) {  // zero padding applies AFTER the affine
+                            o[e] = (__bf16)(ok ? fmaf((float)v[e], g.a0[e], g.b0[e]) : 0.f);
+                            o[4 + e] = (__bf16)(ok ? fmaf((float)v[4 + e], g.a1[e], g.b1[e]) : 0.f);
+                        }
+                    } else {
+                        o = v;  // (outside the volume: loaded as zero)
+                    }
+                    *reinterpret_cast<bf16x8*>(buf + hv * 64 + q * 16) = o;
+                } else {
+                    bf16x4 o = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+                    if (ok) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (__bf16)fmaf(v[e], g.a0[e], g.b0[e]);
+                    }
+                    *reinterpret_cast<bf16x4*>(buf + hv * 64 + q * 8) = o;
                 }
-                *reinterpret_cast<bf16x4*>(buf + hv * 64 + q * 8) = o;
             }
-        } else if (it < WG_G_ITERS + WG_DZ_ITERS) {
-            const int item = t + (it - WG_G_ITERS) * 512;
-            const int q = item & 15, vv = item >> 4;
+        } else if (it < GI + DI) {
+            const int item = t + (it - GI) * 512;
+            const int q = item & ((1 << DS) - 1), vv = item >> DS;
+            if constexpr (B16) {
+                *reinterpret_cast<bf16x8*>(buf + WG_G_BYTES + (q >> 2) * WG_DZ_HALF + vv * 64 + (q & 3) * 16) = v;
+            } else {
+                bf16x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];  // (zero outside the volume: loaded as zero)
-            *reinterpret_cast<bf16x4*>(buf + WG_G_BYTES + (q >> 3) * WG_DZ_HALF + vv * 64 + (q & 7) * 8) = o;
+                for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];  // (zero outside the volume: loaded as zero)
+                *reinterpret_cast<bf16x4*>(buf + WG_G_BYTES + (q >> 3) * WG_DZ_HALF + vv * 64 + (q & 7) * 8) = o;
+            }
         }
     };
 
@@ -761,15 +958,15 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wg
     // ---- prologue: the first tile into buffer 0 (the accumulators are not live yet: 10 loads in flight per thread)
     if (first < last) {
         const wg_tile tl = decode(first);
-        f32x4 ga, gb;
-        u3d_load_affine(p.affine, tl.n, p.C, c0 + 4 * (t & 7), true, ga, gb);
+        aff_t g0;
+        load_aff(tl.n, g0);
 #pragma unroll 1
-        for (int it0 = 0; it0 < WG_ITERS; it0 += WG_ITERS / 2) {
-            f32x4 v[WG_ITERS / 2];
+        for (int it0 = 0; it0 < NIT; it0 += NIT / 2) {
+            item_t v[NIT / 2];
 #pragma unroll
-            for (int i = 0; i < WG_ITERS / 2; ++i) load_item(tl, it0 + i, v[i]);
+            for (int i = 0; i < NIT / 2; ++i) load_item(tl, it0 + i, v[i]);
 #pragma unroll
-            for (int i = 0; i < WG_ITERS / 2; ++i) store_item(lds, tl, it0 + i, v[i], ga, gb);
+            for (int i = 0; i < NIT / 2; ++i) store_item(lds, tl, it0 + i, v[i], g0);
         }
     }
 
@@ -798,14 +995,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wg
         char* nxt = lds + ((tile - first + 1) & 1) * WG_LDS;
         const bool more = tile + 1 < last;
         const wg_tile tn = decode(more ? tile + 1 : tile);
-        f32x4 ga, gb;
-        if (more) u3d_load_affine(p.affine, tn.n, p.C, c0 + 4 * (t & 7), true, ga, gb);
+        aff_t gaff;
+        if (more) load_aff(tn.n, gaff);
 #pragma unroll
         for (int part = 0; part < WG_PARTS; ++part) {
-            f32x4 st[WG_PER_PART];
+            item_t st[PER];
             if (more) {
 #pragma unroll
-                for (int i = 0; i < WG_PER_PART; ++i) load_item(tn, part * WG_PER_PART + i, st[i]);
+                for (int i = 0; i < PER; ++i) load_item(tn, part * PER + i, st[i]);
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- 4 rows of 16 voxels: one dz fragment per row, one g fragment + MFMA per tap of this wave (g fragments one tap ahead)
@@ -827,7 +1024,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wg
             __builtin_amdgcn_sched_barrier(0);
             if (more) {
 #pragma unroll
-                for (int i = 0; i < WG_PER_PART; ++i) store_item(nxt, tn, part * WG_PER_PART + i, st[i], ga, gb);
+                for (int i = 0; i < PER; ++i) store_item(nxt, tn, part * PER + i, st[i], gaff);
             }
         }
     }
@@ -923,9 +1120,24 @@ extern "C" long long u3d_wgrad_bf16_workspace_floats(int N, int D, int H, int W,
     return (long long)q.S * q.P * 27 * 2048;
 }
 
+static int conv3d_wgrad_bf16_impl(int device, u3d_stream_t stream, const float* x, const float* affine, const float* dz, float* dw,
+                                  int N, int D, int H, int W, int C, int K, float* workspace, long long workspace_floats, int b16);
+
 extern "C" int u3d_conv3d_wgrad_bf16(int device, u3d_stream_t stream, const float* x, const float* affine, const float* dz,
                                      float* dw, int N, int D, int H, int W, int C, int K, float* workspace,
                                      long long workspace_floats) {
+    return conv3d_wgrad_bf16_impl(device, stream, x, affine, dz, dw, N, D, H, W, C, K, workspace, workspace_floats, 0);
+}
+
+// bf16 activation storage: x and dz are bf16 tensors (half the bytes of a kernel whose operand re-reads make it HBM-bound)
+extern "C" int u3d_conv3d_wgrad_bf16_b16(int device, u3d_stream_t stream, const void* x, const float* affine, const void* dz, float* dw,
+                                         int N, int D, int H, int W, int C, int K, float* workspace, long long workspace_floats) {
+    return conv3d_wgrad_bf16_impl(device, stream, (const float*)x, affine, (const float*)dz, dw, N, D, H, W, C, K, workspace,
+                                  workspace_floats, 1);
+}
+
+static int conv3d_wgrad_bf16_impl(int device, u3d_stream_t stream, const float* x, const float* affine, const float* dz, float* dw,
+                                  int N, int D, int H, int W, int C, int K, float* workspace, long long workspace_floats, int b16) {
     U3D_ENTER(device);
     U3D_REQUIRE(x && dz && dw && N > 0 && D > 0 && H > 0 && W > 0, "u3d_conv3d_wgrad_bf16: bad argument");
     U3D_REQUIRE(u3d_conv3d_wgrad_bf16_supported(C, K), "u3d_conv3d_wgrad_bf16: needs Cin %% 32 == 0 and Cout %% 64 == 0 (got %d, %d)", C, K);
@@ -936,9 +1148,16 @@ extern "C" int u3d_conv3d_wgrad_bf16(int device, u3d_stream_t stream, const floa
         return u3d_set_err(U3D_EWORKSPACE, "u3d_conv3d_wgrad_bf16: workspace of %lld floats needed, %lld given", need, workspace_floats);
     bf16_wgrad_params p{x, affine, dz, workspace, N, D, H, W, C, K, 1, q.tz, q.ty, q.tx, q.tiles, q.per_block, K / 64,
                         g_u3d_tune[9] == 1 ? 0 : 1};
-    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_bf16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                2 * wg_geom<3>::LDS));
-    hipLaunchKernelGGL(conv3d_wgrad_bf16_kernel<3>, dim3((unsigned)(q.S * q.P)), dim3(512), 2 * wg_geom<3>::LDS, (hipStream_t)stream, p);
+    if (b16) {
+        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_bf16_kernel<3, __bf16>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * wg_geom<3>::LDS));
+        hipLaunchKernelGGL((conv3d_wgrad_bf16_kernel<3, __bf16>), dim3((unsigned)(q.S * q.P)), dim3(512), 2 * wg_geom<3>::LDS,
+                           (hipStream_t)stream, p);
+    } else {
+        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_bf16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    2 * wg_geom<3>::LDS));
+        hipLaunchKernelGGL(conv3d_wgrad_bf16_kernel<3>, dim3((unsigned)(q.S * q.P)), dim3(512), 2 * wg_geom<3>::LDS, (hipStream_t)stream, p);
+    }
     U3D_LAUNCH_CHECK();
     if (q.P * 32 >= 1024) {
         hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)(q.P * 32)), dim3(256), 0, (hipStream_t)stream, workspace, q.S, C, K, dw);
@@ -1047,6 +1266,7 @@ __global__ __launch_bounds__(256) void wgrad_t8_reduce_kernel(const float* __res
 int launch_t8_conv(const bf16_conv_params& p0, hipStream_t s) {
     bf16_conv_params p = p0;
     const bool nt2 = p.K % 64 == 0;
+    if (p.b16) return nt2 ? launch_bf16<2, 1, 2, 0, __bf16>(p, s) : launch_bf16<1, 1, 2, 0, __bf16>(p, s);
     return nt2 ? launch_bf16<2, 1, 2>(p, s) : launch_bf16<1, 1, 2>(p, s);
 }
 
@@ -1072,22 +1292,44 @@ extern "C" int u3d_pack_convtr3d_t8(int device, u3d_stream_t stream, const float
     return 0;
 }
 
-extern "C" int u3d_convtr3d_fwd_t8(int device, u3d_stream_t stream, const float* x, const void* packed, float* t8, int N, int D1,
-                                   int H1, int W1, int Cl, int Cs) {
+static int convtr3d_fwd_t8_impl(int device, u3d_stream_t stream, const float* x, const void* packed, float* t8, int N, int D1, int H1,
+                                int W1, int Cl, int Cs, int b16) {
     U3D_ENTER(device);
     U3D_REQUIRE(x && packed && t8 && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && u3d_convtr3d_t8_supported(Cl, Cs), "u3d_convtr3d_fwd_t8: bad argument");
     bf16_conv_params p{x, nullptr, reinterpret_cast<const bf16x8*>(packed), t8, nullptr, nullptr, nullptr, nullptr,
                        N, D1, H1, W1, Cl, 8 * Cs, 0, 0, 0, 0, 0, nullptr, 1, nullptr};
+    p.b16 = b16;
+    return launch_t8_conv(p, (hipStream_t)stream);
+}
+
+extern "C" int u3d_convtr3d_fwd_t8(int device, u3d_stream_t stream, const float* x, const void* packed, float* t8, int N, int D1,
+                                   int H1, int W1, int Cl, int Cs) {
+    return convtr3d_fwd_t8_impl(device, stream, x, packed, t8, N, D1, H1, W1, Cl, Cs, 0);
+}
+
+extern "C" int u3d_convtr3d_fwd_t8_b16(int device, u3d_stream_t stream, const void* x, const void* packed, void* t8, int N, int D1,
+                                       int H1, int W1, int Cl, int Cs) {
+    return convtr3d_fwd_t8_impl(device, stream, (const float*)x, packed, (float*)t8, N, D1, H1, W1, Cl, Cs, 1);
+}
+
+static int convtr3d_dgrad_t8_impl(int device, u3d_stream_t stream, const float* dt8, const void* packed, const float* x_mask, float* dx,
+                                  int N, int D1, int H1, int W1, int Cl, int Cs, int b16) {
+    U3D_ENTER(device);
+    U3D_REQUIRE(dt8 && packed && dx && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && u3d_convtr3d_t8_supported(Cl, Cs), "u3d_convtr3d_dgrad_t8: bad argument");
+    bf16_conv_params p{dt8, nullptr, reinterpret_cast<const bf16x8*>(packed), dx, nullptr, nullptr, nullptr, nullptr,
+                       N, D1, H1, W1, 8 * Cs, Cl, 0, 0, 0, 0, 1, x_mask, 1, nullptr};
+    p.b16 = b16;
     return launch_t8_conv(p, (hipStream_t)stream);
 }
 
 extern "C" int u3d_convtr3d_dgrad_t8(int device, u3d_stream_t stream, const float* dt8, const void* packed, const float* x_mask,
                                      float* dx, int N, int D1, int H1, int W1, int Cl, int Cs) {
-    U3D_ENTER(device);
-    U3D_REQUIRE(dt8 && packed && dx && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && u3d_convtr3d_t8_supported(Cl, Cs), "u3d_convtr3d_dgrad_t8: bad argument");
-    bf16_conv_params p{dt8, nullptr, reinterpret_cast<const bf16x8*>(packed), dx, nullptr, nullptr, nullptr, nullptr,
-                       N, D1, H1, W1, 8 * Cs, Cl, 0, 0, 0, 0, 1, x_mask, 1, nullptr};
-    return launch_t8_conv(p, (hipStream_t)stream);
+    return convtr3d_dgrad_t8_impl(device, stream, dt8, packed, x_mask, dx, N, D1, H1, W1, Cl, Cs, 0);
+}
+
+extern "C" int u3d_convtr3d_dgrad_t8_b16(int device, u3d_stream_t stream, const void* dt8, const void* packed, const void* x_mask,
+                                         void* dx, int N, int D1, int H1, int W1, int Cl, int Cs) {
+    return convtr3d_dgrad_t8_impl(device, stream, (const float*)dt8, packed, (const float*)x_mask, (float*)dx, N, D1, H1, W1, Cl, Cs, 1);
 }
 
 extern "C" long long u3d_convtr3d_wgrad_t8_workspace_floats(int N, int D1, int H1, int W1, int Cl, int Cs) {
@@ -1096,8 +1338,22 @@ extern "C" long long u3d_convtr3d_wgrad_t8_workspace_floats(int N, int D1, int H
     return (long long)q.S * q.P * 8 * 2048;
 }
 
+static int convtr3d_wgrad_t8_impl(int device, u3d_stream_t stream, const float* x, const float* dt8, float* dw, int N, int D1, int H1,
+                                  int W1, int Cl, int Cs, float* workspace, long long workspace_floats, int b16);
+
 extern "C" int u3d_convtr3d_wgrad_t8(int device, u3d_stream_t stream, const float* x, const float* dt8, float* dw, int N, int D1,
                                      int H1, int W1, int Cl, int Cs, float* workspace, long long workspace_floats) {
+    return convtr3d_wgrad_t8_impl(device, stream, x, dt8, dw, N, D1, H1, W1, Cl, Cs, workspace, workspace_floats, 0);
+}
+
+extern "C" int u3d_convtr3d_wgrad_t8_b16(int device, u3d_stream_t stream, const void* x, const void* dt8, float* dw, int N, int D1,
+                                         int H1, int W1, int Cl, int Cs, float* workspace, long long workspace_floats) {
+    return convtr3d_wgrad_t8_impl(device, stream, (const float*)x, (const float*)dt8, dw, N, D1, H1, W1, Cl, Cs, workspace,
+                                  workspace_floats, 1);
+}
+
+static int convtr3d_wgrad_t8_impl(int device, u3d_stream_t stream, const float* x, const float* dt8, float* dw, int N, int D1, int H1,
+                                  int W1, int Cl, int Cs, float* workspace, long long workspace_floats, int b16) {
     U3D_ENTER(device);
     U3D_REQUIRE(x && dt8 && dw && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && u3d_convtr3d_t8_supported(Cl, Cs), "u3d_convtr3d_wgrad_t8: bad argument");
     const wgrad_plan q = plan_wgrad(N, D1, H1, W1, Cl, 8 * Cs);
@@ -1105,9 +1361,16 @@ extern "C" int u3d_convtr3d_wgrad_t8(int device, u3d_stream_t stream, const floa
     if (!workspace || workspace_floats < need)
         return u3d_set_err(U3D_EWORKSPACE, "u3d_convtr3d_wgrad_t8: workspace of %lld floats needed, %lld given", need, workspace_floats);
     bf16_wgrad_params p{x, nullptr, dt8, workspace, N, D1, H1, W1, Cl, 8 * Cs, 0, q.tz, q.ty, q.tx, q.tiles, q.per_block, 8 * Cs / 64, g_u3d_tune[9] == 1 ? 0 : 1};
-    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_bf16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                2 * wg_geom<2>::LDS));
-    hipLaunchKernelGGL(conv3d_wgrad_bf16_kernel<2>, dim3((unsigned)(q.S * q.P)), dim3(512), 2 * wg_geom<2>::LDS, (hipStream_t)stream, p);
+    if (b16) {
+        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_bf16_kernel<2, __bf16>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * wg_geom<2>::LDS));
+        hipLaunchKernelGGL((conv3d_wgrad_bf16_kernel<2, __bf16>), dim3((unsigned)(q.S * q.P)), dim3(512), 2 * wg_geom<2>::LDS,
+                           (hipStream_t)stream, p);
+    } else {
+        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_bf16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    2 * wg_geom<2>::LDS));
+        hipLaunchKernelGGL(conv3d_wgrad_bf16_kernel<2>, dim3((unsigned)(q.S * q.P)), dim3(512), 2 * wg_geom<2>::LDS, (hipStream_t)stream, p);
+    }
     U3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(wgrad_t8_reduce_kernel, dim3((unsigned)(Cl * ((Cs + 63) / 64))), dim3(256), 0, (hipStream_t)stream, workspace,
                        q.S, Cl, Cs, dw);

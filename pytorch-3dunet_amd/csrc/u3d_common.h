@@ -10,6 +10,30 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// ---- activation storage type: fp32 (default) or bf16 (`activation_dtype: bf16`, csrc/u3d_b16 entry points).  All arithmetic
+// is fp32; only the bytes in HBM change.  Stores round to nearest even (v_cvt_pk_bf16_f32).
+typedef __bf16 u3d_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 u3d_ldq(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 u3d_ldq(const __bf16* p) {
+    const u3d_bf16x4 v = *reinterpret_cast<const u3d_bf16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ void u3d_stq(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void u3d_stq(__bf16* p, const f32x4& v) {
+    *reinterpret_cast<u3d_bf16x4*>(p) = u3d_bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+}
+__device__ __forceinline__ float u3d_ld(const float* p) { return *p; }
+__device__ __forceinline__ float u3d_ld(const __bf16* p) { return (float)*p; }
+__device__ __forceinline__ void u3d_st(float* p, float v) { *p = v; }
+__device__ __forceinline__ void u3d_st(__bf16* p, float v) { *p = (__bf16)v; }
+// what a stored value reads back as (statistics are taken over the STORED tensor: the consumer's GroupNorm normalises that)
+__device__ __forceinline__ float u3d_stored(float v, const float*) { return v; }
+__device__ __forceinline__ float u3d_stored(float v, const __bf16*) { return (float)(__bf16)v; }
+template <typename T>
+struct u3d_vec_align {  // bytes a 4-channel quad access needs
+    static constexpr uintptr_t mask = sizeof(T) == 4 ? 15 : 7;
+};
+
 int u3d_set_err(int code, const char* fmt, ...);
 // Every entry point runs with `device` current and RESTORES the caller's current device on return: the library never
 // changes the calling thread's HIP device behind PyTorch (autograd worker threads, nn.DataParallel replica threads).

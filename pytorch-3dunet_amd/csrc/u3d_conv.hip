@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
         //      inside every lane quad (two DPP butterfly stages) leaves lane j of quad k with the 4 consecutive
         //      channels 4k..4k+3 of voxel x = j + 4h: 16-byte stores and 16-byte loads of x for the GroupNorm sums.
         if (ntiles == DBG_TILE) U3D_DBG_STAMP(5);
-        {
+        if (p.stagger != -1) {  // (u3d_set_tuning key 5 = -1: TIMING-ONLY ablation without the epilogue — wrong results by design)
             const int n = T.n, cb = T.cb;
             const int z = T.z0 + w;
             const int cq = (l >> 2) & 7, vl = (l & 3) + 4 * h;
@@ -1992,7 +1992,7 @@ static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, co
         p.gx_x2 = (gx && p.gx.C1 > 0) ? 1 : 0;
         // experiment knob, default off: a sweep of 8..64 k cycles changed no layer by more than noise (profiles/r01q) — a
         // wave that is alone on its SIMD does not run at twice the shared rate, so interleaving the epilogues buys nothing
-        p.stagger = g_u3d_tune[5] > 0 ? g_u3d_tune[5] : 0;
+        p.stagger = g_u3d_tune[5];
         int ncu = 0;
         if (int e = device_cu_count(device, &ncu)) return e;
         long long slots = (g_u3d_tune[6] == 1 ? 1ll : 2ll) * ncu;  // two blocks per CU (LDS); key 6 = 1: one (experiment)

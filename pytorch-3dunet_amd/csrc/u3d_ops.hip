@@ -259,10 +259,10 @@ extern "C" int u3d_gn_bwd_finalize(int device, u3d_stream_t stream, const double
 }
 
 // out = (p*dg[coff+c] + q*x + r) * mask
-template <bool VEC>
-__global__ void gn_bwd_apply_kernel(const float* __restrict__ dg, int Cdg, int coff, const float* __restrict__ x,
+template <bool VEC, typename T = float>
+__global__ void gn_bwd_apply_kernel(const T* __restrict__ dg, int Cdg, int coff, const T* __restrict__ x,
                                     int Cx, const float* __restrict__ coef, int Ctot, long long Vn, int N,
-                                    int relu_mask, const float* __restrict__ add, float* __restrict__ out) {
+                                    int relu_mask, const T* __restrict__ add, T* __restrict__ out) {
     if (VEC) {
         const int Q = Cx >> 2;
         const long long total = (long long)N * Vn * Q;
@@ -272,18 +272,18 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ dg, int Cdg, int c
             const long long v = idx / Q;  // n*Vn + voxel
             const int n = (int)(v / Vn);
             const int c = 4 * qd;
-            const f32x4 d = *reinterpret_cast<const f32x4*>(dg + (size_t)v * Cdg + coff + c);
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)v * Cx + c);
+            const f32x4 d = u3d_ldq(dg + (size_t)v * Cdg + coff + c);
+            const f32x4 xv = u3d_ldq(x + (size_t)v * Cx + c);
             const f32x4 p = *reinterpret_cast<const f32x4*>(coef + ((size_t)n * 3 + 0) * Ctot + coff + c);
             const f32x4 q = *reinterpret_cast<const f32x4*>(coef + ((size_t)n * 3 + 1) * Ctot + coff + c);
             const f32x4 r = *reinterpret_cast<const f32x4*>(coef + ((size_t)n * 3 + 2) * Ctot + coff + c);
             f32x4 o = p * d + q * xv + r;
-            if (add) o += *reinterpret_cast<const f32x4*>(add + (size_t)v * Cx + c);
+            if (add) o += u3d_ldq(add + (size_t)v * Cx + c);
             if (relu_mask) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = xv[e] > 0.f ? o[e] : 0.f;
             }
-            *reinterpret_cast<f32x4*>(out + (size_t)v * Cx + c) = o;
+            u3d_stq(out + (size_t)v * Cx + c, o);
         }
     } else {
         const long long total = (long long)N * Vn * Cx;
@@ -292,50 +292,61 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ dg, int Cdg, int c
             const int c = (int)(idx % Cx);
             const long long v = idx / Cx;
             const int n = (int)(v / Vn);
-            const float d = dg[(size_t)v * Cdg + coff + c];
-            const float xv = x[idx];
+            const float d = u3d_ld(dg + (size_t)v * Cdg + coff + c);
+            const float xv = u3d_ld(x + idx);
             float o = coef[((size_t)n * 3 + 0) * Ctot + coff + c] * d + coef[((size_t)n * 3 + 1) * Ctot + coff + c] * xv +
                       coef[((size_t)n * 3 + 2) * Ctot + coff + c];
-            if (add) o += add[idx];
+            if (add) o += u3d_ld(add + idx);
             if (relu_mask && !(xv > 0.f)) o = 0.f;
-            out[idx] = o;
+            u3d_st(out + idx, o);
         }
     }
 }
 
-static int gn_bwd_apply_impl(int device, u3d_stream_t stream, const float* dg, int Cdg, int coff, const float* x, int Cx,
-                             const float* coef, int Ctot, int64_t voxels_per_n, int N, int relu_mask, const float* add,
-                             float* out);
+template <typename T>
+static int gn_bwd_apply_impl(int device, u3d_stream_t stream, const T* dg, int Cdg, int coff, const T* x, int Cx,
+                             const float* coef, int Ctot, int64_t voxels_per_n, int N, int relu_mask, const T* add,
+                             T* out);
 
 extern "C" int u3d_gn_bwd_apply(int device, u3d_stream_t stream, const float* dg, int Cdg, int coff, const float* x,
                                 int Cx, const float* coef, int Ctot, int64_t voxels_per_n, int N, int relu_mask,
                                 float* out) {
-    return gn_bwd_apply_impl(device, stream, dg, Cdg, coff, x, Cx, coef, Ctot, voxels_per_n, N, relu_mask, nullptr, out);
+    return gn_bwd_apply_impl<float>(device, stream, dg, Cdg, coff, x, Cx, coef, Ctot, voxels_per_n, N, relu_mask, nullptr, out);
+}
+
+// bf16 activation storage: dg, x, add, out are bf16 tensors, the coefficient table stays fp32
+extern "C" int u3d_gn_bwd_apply_b16(int device, u3d_stream_t stream, const void* dg, int Cdg, int coff, const void* x, int Cx,
+                                    const float* coef, int Ctot, int64_t voxels_per_n, int N, int relu_mask, const void* add,
+                                    void* out) {
+    return gn_bwd_apply_impl<__bf16>(device, stream, (const __bf16*)dg, Cdg, coff, (const __bf16*)x, Cx, coef, Ctot, voxels_per_n, N,
+                                     relu_mask, (const __bf16*)add, (__bf16*)out);
 }
 
 extern "C" int u3d_gn_bwd_apply_add(int device, u3d_stream_t stream, const float* dg, int Cdg, int coff, const float* x,
                                     int Cx, const float* coef, int Ctot, int64_t voxels_per_n, int N, int relu_mask,
                                     const float* add, float* out) {
     if (add == nullptr) return u3d_set_err(U3D_EINVAL, "u3d_gn_bwd_apply_add: add is NULL");
-    return gn_bwd_apply_impl(device, stream, dg, Cdg, coff, x, Cx, coef, Ctot, voxels_per_n, N, relu_mask, add, out);
+    return gn_bwd_apply_impl<float>(device, stream, dg, Cdg, coff, x, Cx, coef, Ctot, voxels_per_n, N, relu_mask, add, out);
 }
 
-static int gn_bwd_apply_impl(int device, u3d_stream_t stream, const float* dg, int Cdg, int coff, const float* x, int Cx,
-                             const float* coef, int Ctot, int64_t voxels_per_n, int N, int relu_mask, const float* add,
-                             float* out) {
+template <typename T>
+static int gn_bwd_apply_impl(int device, u3d_stream_t stream, const T* dg, int Cdg, int coff, const T* x, int Cx,
+                             const float* coef, int Ctot, int64_t voxels_per_n, int N, int relu_mask, const T* add,
+                             T* out) {
     U3D_ENTER(device);
     U3D_REQUIRE(dg && x && coef && out && Cdg > 0 && Cx > 0 && coff >= 0 && coff + Cx <= Cdg && Ctot >= coff + Cx &&
                     voxels_per_n > 0 && N > 0,
                 "u3d_gn_bwd_apply: bad argument");
     const bool vec = (Cdg % 4 == 0) && (Cx % 4 == 0) && (coff % 4 == 0) && (Ctot % 4 == 0) &&
-                     (((uintptr_t)dg | (uintptr_t)x | (uintptr_t)coef | (uintptr_t)out | (uintptr_t)add) & 15) == 0;
+                     (((uintptr_t)dg | (uintptr_t)x | (uintptr_t)out | (uintptr_t)add) & u3d_vec_align<T>::mask) == 0 &&
+                     ((uintptr_t)coef & 15) == 0;
     if (vec) {
         const long long total = (long long)N * voxels_per_n * (Cx / 4);
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((gn_bwd_apply_kernel<true, T>), dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream,
                            dg, Cdg, coff, x, Cx, coef, Ctot, (long long)voxels_per_n, N, relu_mask, add, out);
     } else {
         const long long total = (long long)N * voxels_per_n * Cx;
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(grid_for(total, 16384)), dim3(256), 0,
+        hipLaunchKernelGGL((gn_bwd_apply_kernel<false, T>), dim3(grid_for(total, 16384)), dim3(256), 0,
                            (hipStream_t)stream, dg, Cdg, coff, x, Cx, coef, Ctot, (long long)voxels_per_n, N,
                            relu_mask, add, out);
     }
@@ -414,8 +425,9 @@ extern "C" int u3d_gn_bwd_apply_up(int device, u3d_stream_t stream, const float*
 
 // =================================================================================================
 // MaxPool3d(2): stride 2, floor.  One thread per (n, out voxel, channel).
-__global__ void maxpool2_fwd_kernel(const float* __restrict__ x, int N, int D, int H, int W, int C,
-                                    float* __restrict__ out, uint8_t* __restrict__ argmax) {
+template <typename T = float>
+__global__ void maxpool2_fwd_kernel(const T* __restrict__ x, int N, int D, int H, int W, int C,
+                                    T* __restrict__ out, uint8_t* __restrict__ argmax) {
     const int D2 = D >> 1, H2 = H >> 1, W2 = W >> 1;
     const long long total = (long long)N * D2 * H2 * W2 * C;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -433,13 +445,13 @@ __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, int N, int D, i
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int z = 2 * zo + (k >> 2), y = 2 * yo + ((k >> 1) & 1), xx = 2 * xo + (k & 1);
-            const float val = x[((size_t)((n * D + z) * H + y) * W + xx) * C + c];
+            const float val = u3d_ld(x + ((size_t)((n * D + z) * H + y) * W + xx) * C + c);
             if (val > best || val != val) {  // first max in scan order; NaN propagates (ATen max_pool3d)
                 best = val;
                 bi = k;
             }
         }
-        out[idx] = best;
+        u3d_st(out + idx, best);
         argmax[idx] = (uint8_t)bi;
     }
 }
@@ -449,7 +461,7 @@ extern "C" int u3d_maxpool2_fwd(int device, u3d_stream_t stream, const float* x,
     U3D_ENTER(device);
     U3D_REQUIRE(x && out && argmax && N > 0 && D >= 2 && H >= 2 && W >= 2 && C > 0, "u3d_maxpool2_fwd: bad argument");
     const long long total = (long long)N * (D / 2) * (H / 2) * (W / 2) * C;
-    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, x, N, D,
+    hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, x, N, D,
                        H, W, C, out, argmax);
     U3D_LAUNCH_CHECK();
     if (out_stats) {
@@ -461,17 +473,28 @@ extern "C" int u3d_maxpool2_fwd(int device, u3d_stream_t stream, const float* x,
     return 0;
 }
 
+extern "C" int u3d_maxpool2_fwd_b16(int device, u3d_stream_t stream, const void* x, int N, int D, int H, int W, int C, void* out,
+                                    uint8_t* argmax) {
+    U3D_ENTER(device);
+    U3D_REQUIRE(x && out && argmax && N > 0 && D >= 2 && H >= 2 && W >= 2 && C > 0, "u3d_maxpool2_fwd_b16: bad argument");
+    const long long total = (long long)N * (D / 2) * (H / 2) * (W / 2) * C;
+    hipLaunchKernelGGL(maxpool2_fwd_kernel<__bf16>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)x, N, D, H, W, C, (__bf16*)out, argmax);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
 // dz_e = (skip_grad + scatter(dpool)) * (e > 0); one thread per (n, 2x2x2 window, channel unit), windows cover ceil dims.
 // A unit is VW (4 or 1) channels.  The skip gradient is either absent, a plain tensor (sdg with Csdg channels per voxel),
 // or — fused — the GroupNorm backward of the decoder's first conv restricted to the skip channels:
 //     skip = ps*sdg[v, c] + qs*e[v, c] + rs      (scoef[N][3][Cstot], skip channels first => no channel offset)
 // which removes one full write + read of the skip gradient per decoder level.
-template <int VW>
-__global__ void maxpool2_bwd_merge_kernel(const float* __restrict__ dg, const float* __restrict__ pooled,
+template <int VW, typename T = float>
+__global__ void maxpool2_bwd_merge_kernel(const T* __restrict__ dg, const T* __restrict__ pooled,
                                           const uint8_t* __restrict__ argmax, const float* __restrict__ coef,
-                                          const float* __restrict__ sdg, int Csdg, const float* __restrict__ scoef,
-                                          int Cstot, const float* __restrict__ e, int N, int D, int H, int W, int C,
-                                          int relu_mask, float* __restrict__ out) {
+                                          const T* __restrict__ sdg, int Csdg, const float* __restrict__ scoef,
+                                          int Cstot, const T* __restrict__ e, int N, int D, int H, int W, int C,
+                                          int relu_mask, T* __restrict__ out) {
     const int D2 = D >> 1, H2 = H >> 1, W2 = W >> 1;
     const int Dc = (D + 1) >> 1, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1;
     const int Q = C / VW;
@@ -504,9 +527,9 @@ __global__ void maxpool2_bwd_merge_kernel(const float* __restrict__ dg, const fl
             const size_t pi = ((size_t)((n * D2 + zo) * H2 + yo) * W2 + xo) * C + c;
 #pragma unroll
             for (int k = 0; k < VW; ++k) {
-                dp[k] = dg[pi + k];
+                dp[k] = u3d_ld(dg + pi + k);
                 if (coef)
-                    dp[k] = coef[((size_t)n * 3 + 0) * C + c + k] * dp[k] + coef[((size_t)n * 3 + 1) * C + c + k] * pooled[pi + k] +
+                    dp[k] = coef[((size_t)n * 3 + 0) * C + c + k] * dp[k] + coef[((size_t)n * 3 + 1) * C + c + k] * u3d_ld(pooled + pi + k) +
                             coef[((size_t)n * 3 + 2) * C + c + k];
                 am[k] = argmax[pi + k];
             }
@@ -519,13 +542,13 @@ __global__ void maxpool2_bwd_merge_kernel(const float* __restrict__ dg, const fl
                 const size_t ei = vi * C + c;
                 float ev[VW], sv[VW], o[VW];
                 if (VW == 4) {
-                    const f32x4 t = (relu_mask || scoef) ? *reinterpret_cast<const f32x4*>(e + ei) : f32x4{1.f, 1.f, 1.f, 1.f};
-                    const f32x4 u = sdg ? *reinterpret_cast<const f32x4*>(sdg + vi * Csdg + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    const f32x4 t = (relu_mask || scoef) ? u3d_ldq(e + ei) : f32x4{1.f, 1.f, 1.f, 1.f};
+                    const f32x4 u = sdg ? u3d_ldq(sdg + vi * Csdg + c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int k = 0; k < 4; ++k) ev[k] = t[k], sv[k] = u[k];
                 } else {
-                    ev[0] = (relu_mask || scoef) ? e[ei] : 1.f;
-                    sv[0] = sdg ? sdg[vi * Csdg + c] : 0.f;
+                    ev[0] = (relu_mask || scoef) ? u3d_ld(e + ei) : 1.f;
+                    sv[0] = sdg ? u3d_ld(sdg + vi * Csdg + c) : 0.f;
                 }
 #pragma unroll
                 for (int k = 0; k < VW; ++k) {
@@ -535,29 +558,30 @@ __global__ void maxpool2_bwd_merge_kernel(const float* __restrict__ dg, const fl
                     o[k] = g;
                 }
                 if (VW == 4)
-                    *reinterpret_cast<f32x4*>(out + ei) = f32x4{o[0], o[1], o[2], o[3]};
+                    u3d_stq(out + ei, f32x4{o[0], o[1], o[2], o[3]});
                 else
-                    out[ei] = o[0];
+                    u3d_st(out + ei, o[0]);
             }
         }
     }
 }
 
-static int maxpool2_bwd_merge_impl(int device, u3d_stream_t stream, const float* dg, const float* pooled,
-                                   const uint8_t* argmax, const float* coef, const float* sdg, int Csdg, const float* scoef,
-                                   int Cstot, const float* e, int N, int D, int H, int W, int C, int relu_mask, float* out) {
+template <typename T>
+static int maxpool2_bwd_merge_impl(int device, u3d_stream_t stream, const T* dg, const T* pooled,
+                                   const uint8_t* argmax, const float* coef, const T* sdg, int Csdg, const float* scoef,
+                                   int Cstot, const T* e, int N, int D, int H, int W, int C, int relu_mask, T* out) {
     U3D_ENTER(device);
     U3D_REQUIRE(dg && argmax && out && (coef == nullptr || pooled) && (!(relu_mask || scoef) || e) && N > 0 && C > 0 &&
                     (!sdg || Csdg >= C) && (!scoef || (sdg && Cstot >= C)),
                 "u3d_maxpool2_bwd_merge: bad argument");
     const bool vec = C % 4 == 0 && (!sdg || Csdg % 4 == 0) &&
-                     (((uintptr_t)e | (uintptr_t)sdg | (uintptr_t)out) & 15) == 0;
+                     (((uintptr_t)e | (uintptr_t)sdg | (uintptr_t)out) & u3d_vec_align<T>::mask) == 0;
     const long long total = (long long)N * ((D + 1) / 2) * ((H + 1) / 2) * ((W + 1) / 2) * (vec ? C / 4 : C);
     if (vec)
-        hipLaunchKernelGGL(maxpool2_bwd_merge_kernel<4>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, dg,
+        hipLaunchKernelGGL((maxpool2_bwd_merge_kernel<4, T>), dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, dg,
                            pooled, argmax, coef, sdg, Csdg, scoef, Cstot, e, N, D, H, W, C, relu_mask, out);
     else
-        hipLaunchKernelGGL(maxpool2_bwd_merge_kernel<1>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, dg,
+        hipLaunchKernelGGL((maxpool2_bwd_merge_kernel<1, T>), dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, dg,
                            pooled, argmax, coef, sdg, Csdg, scoef, Cstot, e, N, D, H, W, C, relu_mask, out);
     U3D_LAUNCH_CHECK();
     return 0;
@@ -566,8 +590,15 @@ static int maxpool2_bwd_merge_impl(int device, u3d_stream_t stream, const float*
 extern "C" int u3d_maxpool2_bwd_merge(int device, u3d_stream_t stream, const float* dg, const float* pooled,
                                       const uint8_t* argmax, const float* coef, const float* skip_grad,
                                       const float* e, int N, int D, int H, int W, int C, int relu_mask, float* out) {
-    return maxpool2_bwd_merge_impl(device, stream, dg, pooled, argmax, coef, skip_grad, C, nullptr, 0, e, N, D, H, W, C,
-                                   relu_mask, out);
+    return maxpool2_bwd_merge_impl<float>(device, stream, dg, pooled, argmax, coef, skip_grad, C, nullptr, 0, e, N, D, H, W, C,
+                                          relu_mask, out);
+}
+
+extern "C" int u3d_maxpool2_bwd_merge_b16(int device, u3d_stream_t stream, const void* dg, const void* pooled, const uint8_t* argmax,
+                                          const float* coef, const void* skip_grad, const void* e, int N, int D, int H, int W, int C,
+                                          int relu_mask, void* out) {
+    return maxpool2_bwd_merge_impl<__bf16>(device, stream, (const __bf16*)dg, (const __bf16*)pooled, argmax, coef, (const __bf16*)skip_grad,
+                                           C, nullptr, 0, (const __bf16*)e, N, D, H, W, C, relu_mask, (__bf16*)out);
 }
 
 extern "C" int u3d_maxpool2_bwd_merge_gn(int device, u3d_stream_t stream, const float* dg, const float* pooled,
@@ -575,8 +606,8 @@ extern "C" int u3d_maxpool2_bwd_merge_gn(int device, u3d_stream_t stream, const 
                                          const float* skip_coef, int Ctot, const float* e, int N, int D, int H, int W, int C,
                                          int relu_mask, float* out) {
     if (!skip_dg || !skip_coef) return u3d_set_err(U3D_EINVAL, "u3d_maxpool2_bwd_merge_gn: skip_dg / skip_coef are NULL");
-    return maxpool2_bwd_merge_impl(device, stream, dg, pooled, argmax, coef, skip_dg, Cdg, skip_coef, Ctot, e, N, D, H, W, C,
-                                   relu_mask, out);
+    return maxpool2_bwd_merge_impl<float>(device, stream, dg, pooled, argmax, coef, skip_dg, Cdg, skip_coef, Ctot, e, N, D, H, W, C,
+                                          relu_mask, out);
 }
 
 // =================================================================================================
@@ -634,8 +665,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 
 // Vectorised variant: G = Cin/4 lanes (power of two, <= 64) share one voxel, each loads one float4 of the row
 // (fully coalesced 16 B/lane), partial dot products are combined with a butterfly shuffle.
-template <int G>
-__global__ __launch_bounds__(256) void head_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <int G, typename T = float>
+__global__ __launch_bounds__(256) void head_fwd_vec_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ b, int N, long long V, int Cin,
                                                            int Cout, int act, float* __restrict__ logits,
                                                            float* __restrict__ probs) {
@@ -644,7 +675,7 @@ __global__ __launch_bounds__(256) void head_fwd_vec_kernel(const float* __restri
     const long long total = (long long)N * V;
     const long long vpb = 256 / G;
     for (long long idx = (long long)blockIdx.x * vpb + t / G; idx < total; idx += (long long)gridDim.x * vpb) {
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)idx * Cin + 4 * sub);
+        const f32x4 xv = u3d_ldq(x + (size_t)idx * Cin + 4 * sub);
         float acc[HEAD_MAXCO];
 #pragma unroll
         for (int o = 0; o < HEAD_MAXCO; ++o) {
@@ -686,6 +717,32 @@ __global__ __launch_bounds__(256) void head_fwd_vec_kernel(const float* __restri
     }
 }
 
+// bf16 activation storage: x is a bf16 tensor (vector path only: Cin/4 a power of two <= 64), logits / probabilities stay fp32
+extern "C" int u3d_conv1x1_head_fwd_b16(int device, u3d_stream_t stream, const void* x, const float* w, const float* b, int N,
+                                        int64_t V, int Cin, int Cout, int act, float* logits, float* probs) {
+    U3D_ENTER(device);
+    const int G = Cin / 4;
+    U3D_REQUIRE(x && w && b && logits && N > 0 && V > 0 && Cout >= 1 && Cout <= HEAD_MAXCO && Cin % 4 == 0 && G >= 1 && G <= 64 &&
+                    (G & (G - 1)) == 0 && ((uintptr_t)x & 7) == 0 && ((uintptr_t)w & 15) == 0,
+                "u3d_conv1x1_head_fwd_b16: needs Cin/4 a power of two <= 64 and Cout <= %d (got %d, %d)", HEAD_MAXCO, Cin, Cout);
+    hipStream_t st = (hipStream_t)stream;
+    const long long tot = (long long)N * V;
+    const __bf16* xb = (const __bf16*)x;
+#define U3D_HEAD_FWD16(GG)                                                                                                 \
+    hipLaunchKernelGGL((head_fwd_vec_kernel<GG, __bf16>), dim3(grid_for(tot * GG, 8192)), dim3(256), 0, st, xb, w, b, N, \
+                       (long long)V, Cin, Cout, act, logits, probs)
+    if (G == 1) U3D_HEAD_FWD16(1);
+    else if (G == 2) U3D_HEAD_FWD16(2);
+    else if (G == 4) U3D_HEAD_FWD16(4);
+    else if (G == 8) U3D_HEAD_FWD16(8);
+    else if (G == 16) U3D_HEAD_FWD16(16);
+    else if (G == 32) U3D_HEAD_FWD16(32);
+    else U3D_HEAD_FWD16(64);
+#undef U3D_HEAD_FWD16
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int u3d_conv1x1_head_fwd(int device, u3d_stream_t stream, const float* x, const float* w, const float* b,
                                     int N, int64_t V, int Cin, int Cout, int act, float* logits, float* probs) {
     U3D_ENTER(device);
@@ -697,7 +754,7 @@ extern "C" int u3d_conv1x1_head_fwd(int device, u3d_stream_t stream, const float
     hipStream_t st = (hipStream_t)stream;
     const long long tot = (long long)N * V;
 #define U3D_HEAD_FWD(GG)                                                                                            \
-    hipLaunchKernelGGL(head_fwd_vec_kernel<GG>, dim3(grid_for(tot * GG, 8192)), dim3(256), 0, st, x, w, b, N,       \
+    hipLaunchKernelGGL((head_fwd_vec_kernel<GG, float>), dim3(grid_for(tot * GG, 8192)), dim3(256), 0, st, x, w, b, N, \
                        (long long)V, Cin, Cout, act, logits, probs)
     if (vec && G == 1) U3D_HEAD_FWD(1);
     else if (vec && G == 2) U3D_HEAD_FWD(2);
@@ -792,9 +849,10 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* __restric
 // Fused vectorised backward: thread -> (voxel, channel quad) with a FIXED quad per thread (grid stride is a
 // multiple of Q), so dw partials stay in registers; x is read once for both dx (ReLU mask) and dw.
 constexpr int HEAD_VEC_MAXCO = 4;  // the vector kernels keep per-output partials in registers
-__global__ __launch_bounds__(256) void head_bwd_vec_kernel(const float* __restrict__ dl, const float* __restrict__ x,
+template <typename T = float>
+__global__ __launch_bounds__(256) void head_bwd_vec_kernel(const float* __restrict__ dl, const T* __restrict__ x,
                                                            const float* __restrict__ w, int N, long long V, int Cin,
-                                                           int Cout, int relu_mask, float* __restrict__ dx,
+                                                           int Cout, int relu_mask, T* __restrict__ dx,
                                                            double* __restrict__ acc) {
     extern __shared__ float red[];  // [(Cout+1)][Cin]
     const int t = threadIdx.x;
@@ -815,15 +873,15 @@ __global__ __launch_bounds__(256) void head_bwd_vec_kernel(const float* __restri
         // per sample, two voxels per iteration (both loads in flight before the first use); no 64-bit division
         const long long stride = (long long)gridDim.x * rows;
         for (int n = 0; n < N; ++n) {
-            const float* xn = x + (size_t)n * V * Cin + 4 * q;
+            const T* xn = x + (size_t)n * V * Cin + 4 * q;
             const float* dn = dl + (size_t)n * Cout * V;
-            float* dxn = dx ? dx + (size_t)n * V * Cin + 4 * q : nullptr;
+            T* dxn = dx ? dx + (size_t)n * V * Cin + 4 * q : nullptr;
             for (long long v = (long long)blockIdx.x * rows + row; v < V; v += 2 * stride) {
                 const long long v2 = v + stride;
                 const bool two = v2 < V;
                 const long long vb = two ? v2 : v;
-                const f32x4 xa = *reinterpret_cast<const f32x4*>(xn + (size_t)v * Cin);
-                const f32x4 xb = *reinterpret_cast<const f32x4*>(xn + (size_t)vb * Cin);
+                const f32x4 xa = u3d_ldq(xn + (size_t)v * Cin);
+                const f32x4 xb = u3d_ldq(xn + (size_t)vb * Cin);
                 float da[HEAD_VEC_MAXCO], db[HEAD_VEC_MAXCO];
 #pragma unroll
                 for (int o = 0; o < HEAD_VEC_MAXCO; ++o) {
@@ -848,8 +906,8 @@ __global__ __launch_bounds__(256) void head_bwd_vec_kernel(const float* __restri
                     }
                 }
                 if (dxn) {
-                    *reinterpret_cast<f32x4*>(dxn + (size_t)v * Cin) = sa;
-                    if (two) *reinterpret_cast<f32x4*>(dxn + (size_t)vb * Cin) = sb;
+                    u3d_stq(dxn + (size_t)v * Cin, sa);
+                    if (two) u3d_stq(dxn + (size_t)vb * Cin, sb);
                 }
             }
         }
@@ -875,6 +933,22 @@ __global__ __launch_bounds__(256) void head_bwd_vec_kernel(const float* __restri
     }
 }
 
+extern "C" int u3d_conv1x1_head_bwd_b16(int device, u3d_stream_t stream, const float* dlogits, const void* x, const float* w, int N,
+                                        int64_t V, int Cin, int Cout, int relu_mask, void* dx, double* acc) {
+    U3D_ENTER(device);
+    U3D_REQUIRE(dlogits && x && w && N > 0 && V > 0 && Cin % 4 == 0 && Cin <= 256 && Cout >= 1 && Cout <= HEAD_VEC_MAXCO &&
+                    (((uintptr_t)x | (uintptr_t)dx) & 7) == 0 && ((uintptr_t)w & 15) == 0,
+                "u3d_conv1x1_head_bwd_b16: needs Cin %% 4 == 0, Cin <= 256, Cout <= %d (got %d, %d)", HEAD_VEC_MAXCO, Cin, Cout);
+    const int rows = 256 / (Cin / 4);
+    long long blocks = cdivll((long long)V, (long long)rows * 32);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(head_bwd_vec_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), (size_t)rows * (Cout + 1) * Cin * sizeof(float),
+                       (hipStream_t)stream, dlogits, (const __bf16*)x, w, N, (long long)V, Cin, Cout, relu_mask, (__bf16*)dx, acc);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int u3d_conv1x1_head_bwd(int device, u3d_stream_t stream, const float* dlogits, const float* x,
                                     const float* w, int N, int64_t V, int Cin, int Cout, int relu_mask, float* dx,
                                     double* acc) {
@@ -889,7 +963,7 @@ extern "C" int u3d_conv1x1_head_bwd(int device, u3d_stream_t stream, const float
         long long blocks = cdivll((long long)V, (long long)rows * 32);
         if (blocks > 2048) blocks = 2048;
         if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(head_bwd_vec_kernel, dim3((unsigned)blocks), dim3(256), (size_t)rows * (Cout + 1) * Cin * sizeof(float),
+        hipLaunchKernelGGL(head_bwd_vec_kernel<float>, dim3((unsigned)blocks), dim3(256), (size_t)rows * (Cout + 1) * Cin * sizeof(float),
                            (hipStream_t)stream, dlogits, x, w, N, (long long)V, Cin, Cout, relu_mask, dx, acc);
         U3D_LAUNCH_CHECK();
         return 0;

@@ -10,17 +10,18 @@
 // receives only tap 1 of input j, an odd one 2j+1 taps 0 and 2 of inputs j+1 and j — 1/2/4/8 taps per class, no
 // multiplications by the inserted zeros.  (An MFMA version of the 8 parity classes is the next step for this file.)
 #include "u3d_common.h"
+#include <type_traits>
 
 namespace gc {
 constexpr int TM = 64, TN = 64, TK = 16, LD = 68;  // LD: padded LDS row (keeps 16-byte alignment of the quads)
 }
 
 struct GConvParams {
-    const float* x;     // (N, Di, Hi, Wi, Ci)
+    const void* x;      // (N, Di, Hi, Wi, Ci), element type TI of gconv_kernel<TI, TO>
     const float* w;     // element (tap, in-channel i, out-channel j) at w[woff[tap] + i*wsi + j*wsj]
     const float* bias;  // [Cj] or null
-    const float* mask;  // output-shaped or null: out = mask > 0 ? out : 0   (ReLU backward of the producer)
-    float* out;         // (N, Do, Ho, Wo, Cj)
+    const void* mask;   // output-shaped (TO) or null: out = mask > 0 ? out : 0   (ReLU backward of the producer)
+    void* out;          // (N, Do, Ho, Wo, Cj), element type TO
     double* stats;      // [N][Cj][2] += (sum, sum of squares) of the written values, or null
     int N, Di, Hi, Wi, Ci, Do, Ho, Wo, Cj;
     int Rz, Ry, Rx;        // row grid; output coordinate = r * os + oo, input coordinate of tap t = r * is + t?[t]
@@ -37,8 +38,12 @@ struct GConvParams {
 // (w >> 1, w & 1).  The (tap, 16-channel chunk) steps run as ONE flat software pipeline: the A rows (gathered, zero
 // outside the tensor) and the B slice of step s+1 are loaded into registers before the 8 MFMAs of step s are issued from
 // the LDS buffer s & 1, then stored to buffer (s+1) & 1 — one barrier per step.
+template <typename TI = float, typename TO = float>
 __global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
     using namespace gc;
+    const TI* px = reinterpret_cast<const TI*>(p.x);
+    const TO* pmask = reinterpret_cast<const TO*>(p.mask);
+    TO* pout = reinterpret_cast<TO*>(p.out);
     __shared__ __attribute__((aligned(16))) float As[2][TK][LD];  // [buffer][k][row]
     __shared__ __attribute__((aligned(16))) float Bs[2][TK][LD];  // [buffer][k][out channel]
     __shared__ int orow[TM];                                      // output voxel index of each tile row, -1 = no row
@@ -75,13 +80,13 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
             const bool inb = rok && iz >= 0 && iz < p.Di && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
             const int ca = c0 + 4 * lq;
             if (inb) {
-                const float* xrow = p.x + ((size_t)((n * p.Di + iz) * p.Hi + iy) * p.Wi + ix) * p.Ci;
+                const TI* xrow = px + ((size_t)((n * p.Di + iz) * p.Hi + iy) * p.Wi + ix) * p.Ci;
                 if (p.avec && ca + 3 < p.Ci) {
-                    av = *reinterpret_cast<const f32x4*>(xrow + ca);
+                    av = u3d_ldq(xrow + ca);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (ca + e < p.Ci) av[e] = xrow[ca + e];
+                        if (ca + e < p.Ci) av[e] = u3d_ld(xrow + ca + e);
                 }
             }
             const int cb = c0 + bci, jb_ = j0 + 4 * bjq;
@@ -131,8 +136,9 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
             if (ov < 0 || !cok) continue;
             const size_t o = (size_t)ov * p.Cj + col;
             float val = acc[r] + bias;
-            if (p.mask && !(p.mask[o] > 0.f)) val = 0.f;
-            p.out[o] = val;
+            if (pmask && !(u3d_ld(pmask + o) > 0.f)) val = 0.f;
+            val = u3d_stored(val, pout);  // (statistics describe the STORED tensor)
+            u3d_st(pout + o, val);
             s1 += val;
             s2 += val * val;
         }
@@ -153,8 +159,8 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
 
 // ---- weight-gradient twin: acc[tap*dst_t + a*dst_a + b*dst_b] += sum_rows X[row, a] * Y[ycoord(row, tap), b]
 struct GWgradParams {
-    const float* X;  // (N, Rz, Ry, Rx, Ca)
-    const float* Y;  // (N, Dy, Hy, Wy, Cb); coordinate of tap t = r * ys + t?[t], zero outside
+    const void* X;  // (N, Rz, Ry, Rx, Ca), element type T of gwgrad_kernel<T>
+    const void* Y;  // (N, Dy, Hy, Wy, Cb); coordinate of tap t = r * ys + t?[t], zero outside
     double* acc;
     double* bias_acc;  // optional [Cb] += sum_rows Y[row, b] (tap 0 only)
     int N, Ca, Cb;
@@ -167,7 +173,10 @@ struct GWgradParams {
     int xvec, yvec;
 };
 
+template <typename TX = float, typename TY = TX>
 __global__ __launch_bounds__(256) void gwgrad_kernel(const GWgradParams p) {
+    const TX* pX = reinterpret_cast<const TX*>(p.X);
+    const TY* pY = reinterpret_cast<const TY*>(p.Y);
     // same MFMA scheme: D[a][b] += X^T Y over 16-row chunks; wave w owns the 32x32 quadrant (w >> 1, w & 1) of the 64x64 tile;
     // register-prefetched double buffering, one barrier per chunk
     using namespace gc;
@@ -197,24 +206,24 @@ __global__ __launch_bounds__(256) void gwgrad_kernel(const GWgradParams p) {
         const long long q = r / p.Rx;
         const int ry = (int)(q % p.Ry), rz = (int)(q / p.Ry);
         const int ca = a0 + 4 * lqd;
-        const float* xr = p.X + (size_t)row * p.Ca;
+        const TX* xr = pX + (size_t)row * p.Ca;
         if (p.xvec && ca + 3 < p.Ca) {
-            xv = *reinterpret_cast<const f32x4*>(xr + ca);
+            xv = u3d_ldq(xr + ca);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (ca + e < p.Ca) xv[e] = xr[ca + e];
+                if (ca + e < p.Ca) xv[e] = u3d_ld(xr + ca + e);
         }
         const int yz = rz * p.ysz + p.tz[tap], yy = ry * p.ysy + p.ty[tap], yx = rx * p.ysx + p.tx[tap];
         if (yz >= 0 && yz < p.Dy && yy >= 0 && yy < p.Hy && yx >= 0 && yx < p.Wy) {
-            const float* yr = p.Y + ((size_t)((n * p.Dy + yz) * p.Hy + yy) * p.Wy + yx) * p.Cb;
+            const TY* yr = pY + ((size_t)((n * p.Dy + yz) * p.Hy + yy) * p.Wy + yx) * p.Cb;
             const int cb = b0 + 4 * lqd;
             if (p.yvec && cb + 3 < p.Cb) {
-                yv = *reinterpret_cast<const f32x4*>(yr + cb);
+                yv = u3d_ldq(yr + cb);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (cb + e < p.Cb) yv[e] = yr[cb + e];
+                    if (cb + e < p.Cb) yv[e] = u3d_ld(yr + cb + e);
             }
         }
     };
@@ -257,10 +266,11 @@ __global__ __launch_bounds__(256) void gwgrad_kernel(const GWgradParams p) {
 }
 
 // ---- nearest resize + summation joining: out = skip + t[map(voxel)]  (+ per-(n,channel) statistics of out) ----------
-__global__ __launch_bounds__(256) void nearest_add_kernel(const float* __restrict__ skip, const float* __restrict__ tt,
+template <typename T = float>
+__global__ __launch_bounds__(256) void nearest_add_kernel(const T* __restrict__ skip, const T* __restrict__ tt,
                                                           const int* __restrict__ zmap, const int* __restrict__ ymap,
                                                           const int* __restrict__ xmap, int D, int H, int W, int Dt, int Ht,
-                                                          int Wt, int C, int Q, int vecw, int t8, float* __restrict__ out,
+                                                          int Wt, int C, int Q, int vecw, int t8, T* __restrict__ out,
                                                           double* __restrict__ stats) {
     // thread -> (row = t / Q, unit = t % Q); a unit is vecw (4 or 1) channels; rows stride the block's voxel range
     extern __shared__ double sred[];  // [Q*vecw][2]
@@ -289,18 +299,20 @@ __global__ __launch_bounds__(256) void nearest_add_kernel(const float* __restric
                 ti = ((size_t)((n * Dt + zmap[z]) * Ht + ymap[y]) * Wt + xmap[x]) * C + (size_t)unit * vecw;
             }
             if (vecw == 4) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(skip + o);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(tt + ti);
-                const f32x4 r = a + b;
-                *reinterpret_cast<f32x4*>(out + o) = r;
+                const f32x4 a = u3d_ldq(skip + o);
+                const f32x4 b = u3d_ldq(tt + ti);
+                f32x4 r = a + b;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = u3d_stored(r[e], out);
+                u3d_stq(out + o, r);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     s1[e] += r[e];
                     s2[e] += r[e] * r[e];
                 }
             } else {
-                const float r = skip[o] + tt[ti];
-                out[o] = r;
+                const float r = u3d_stored(u3d_ld(skip + o) + u3d_ld(tt + ti), out);
+                u3d_st(out + o, r);
                 s1[0] += r;
                 s2[0] += r * r;
             }
@@ -319,9 +331,10 @@ __global__ __launch_bounds__(256) void nearest_add_kernel(const float* __restric
 }
 
 // dt[s] = sum of dj over the children of s (voxels o with map(o) == s): lo tables of length Dt+1 / Ht+1 / Wt+1
-__global__ void nearest_sum_kernel(const float* __restrict__ dj, const int* __restrict__ zlo, const int* __restrict__ ylo,
+template <typename T = float>
+__global__ void nearest_sum_kernel(const T* __restrict__ dj, const int* __restrict__ zlo, const int* __restrict__ ylo,
                                    const int* __restrict__ xlo, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C,
-                                   int t8, float* __restrict__ dt) {
+                                   int t8, T* __restrict__ dt) {
     const int D1 = (Dt + 1) >> 1, H1 = (Ht + 1) >> 1, W1 = (Wt + 1) >> 1;
     const long long total = t8 ? (long long)N * D1 * H1 * W1 * 8 * C : (long long)N * Dt * Ht * Wt * C;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -338,7 +351,7 @@ __global__ void nearest_sum_kernel(const float* __restrict__ dj, const int* __re
             zz = 2 * (int)(v % D1) + (par >> 2);
             n = (int)(v / D1);
             if (zz >= Dt || yy >= Ht || xx >= Wt) {
-                dt[idx] = 0.f;
+                u3d_st(dt + idx, 0.f);
                 continue;
             }
         } else {
@@ -352,14 +365,15 @@ __global__ void nearest_sum_kernel(const float* __restrict__ dj, const int* __re
         float sum = 0.f;
         for (int z = zlo[zz]; z < zlo[zz + 1]; ++z)
             for (int y = ylo[yy]; y < ylo[yy + 1]; ++y)
-                for (int x = xlo[xx]; x < xlo[xx + 1]; ++x) sum += dj[((size_t)((n * D + z) * H + y) * W + x) * C + c];
-        dt[idx] = sum;
+                for (int x = xlo[xx]; x < xlo[xx + 1]; ++x) sum += u3d_ld(dj + ((size_t)((n * D + z) * H + y) * W + x) * C + c);
+        u3d_st(dt + idx, sum);
     }
 }
 
 // =====================================================================================================================
 static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+template <typename TI = float, typename TO = float>
 static int launch_gconv(GConvParams& p, hipStream_t st) {
     const long long R = (long long)p.Rz * p.Ry * p.Rx;
     if (R <= 0) return 0;
@@ -370,16 +384,17 @@ static int launch_gconv(GConvParams& p, hipStream_t st) {
     const long long cap = p.stats ? (2048 / ((long long)jt * p.N) > 1 ? 2048 / ((long long)jt * p.N) : 1) : 65535 * 16;
     if (gx > cap) gx = cap;
     if (gx > 2147483647ll) gx = 2147483647ll;
-    p.avec = (p.Ci % 4 == 0 && al16(p.x)) ? 1 : 0;
+    p.avec = (p.Ci % 4 == 0 && ((uintptr_t)p.x & u3d_vec_align<TI>::mask) == 0) ? 1 : 0;
     p.ovec = (p.Cj % 4 == 0 && al16(p.out) && (!p.mask || al16(p.mask))) ? 1 : 0;
     p.bvec = (p.wsj == 1 && p.Cj % 4 == 0 && p.wsi % 4 == 0 && al16(p.w)) ? 1 : 0;
     for (int k = 0; k < p.ntaps; ++k)
         if (p.woff[k] % 4 != 0) p.bvec = 0;
-    hipLaunchKernelGGL(gconv_kernel, dim3((unsigned)gx, (unsigned)jt, (unsigned)p.N), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((gconv_kernel<TI, TO>), dim3((unsigned)gx, (unsigned)jt, (unsigned)p.N), dim3(256), 0, st, p);
     U3D_LAUNCH_CHECK();
     return 0;
 }
 
+template <typename TX = float, typename TY = TX>
 static int launch_gwgrad(GWgradParams& p, hipStream_t st) {
     const long long total = (long long)p.N * p.Rz * p.Ry * p.Rx;
     if (total <= 0) return 0;
@@ -395,16 +410,17 @@ static int launch_gwgrad(GWgradParams& p, hipStream_t st) {
     rps = (rps + gc::TK - 1) / gc::TK * gc::TK;
     S = (total + rps - 1) / rps;
     p.rows_per_split = rps;
-    p.xvec = (p.Ca % 4 == 0 && al16(p.X)) ? 1 : 0;
-    p.yvec = (p.Cb % 4 == 0 && al16(p.Y)) ? 1 : 0;
-    hipLaunchKernelGGL(gwgrad_kernel, dim3((unsigned)(p.atiles * p.btiles), (unsigned)p.ntaps, (unsigned)S), dim3(256), 0, st, p);
+    p.xvec = (p.Ca % 4 == 0 && ((uintptr_t)p.X & u3d_vec_align<TX>::mask) == 0) ? 1 : 0;
+    p.yvec = (p.Cb % 4 == 0 && ((uintptr_t)p.Y & u3d_vec_align<TY>::mask) == 0) ? 1 : 0;
+    hipLaunchKernelGGL((gwgrad_kernel<TX, TY>), dim3((unsigned)(p.atiles * p.btiles), (unsigned)p.ntaps, (unsigned)S), dim3(256), 0, st, p);
     U3D_LAUNCH_CHECK();
     return 0;
 }
 
 // ---- 1x1x1 convolution with bias --------------------------------------------------------------------------------------
-extern "C" int u3d_conv1x1_fwd(int device, u3d_stream_t stream, const float* x, const float* w, const float* bias, float* y,
-                               int N, int64_t V, int Cin, int Cout, double* out_stats) {
+template <typename TI, typename TO>
+static int conv1x1_fwd_impl(int device, u3d_stream_t stream, const void* x, const float* w, const float* bias, void* y, int N,
+                            int64_t V, int Cin, int Cout, double* out_stats) {
     U3D_ENTER(device);
     U3D_REQUIRE(x && w && y && N > 0 && V > 0 && Cin > 0 && Cout > 0, "u3d_conv1x1_fwd: bad argument");
     U3D_REQUIRE(V < (1ll << 31) && (long long)N * V < (1ll << 31), "u3d_conv1x1_fwd: N*V must be < 2^31");
@@ -415,11 +431,24 @@ extern "C" int u3d_conv1x1_fwd(int device, u3d_stream_t stream, const float* x, 
     p.osz = p.osy = p.osx = 1, p.ooz = p.ooy = p.oox = 0, p.isz = p.isy = p.isx = 1;
     p.ntaps = 1, p.tz[0] = p.ty[0] = p.tx[0] = 0;
     p.woff[0] = 0, p.wsi = 1, p.wsj = Cin;  // w[cout][cin]
-    return launch_gconv(p, (hipStream_t)stream);
+    return launch_gconv<TI, TO>(p, (hipStream_t)stream);
 }
 
-extern "C" int u3d_conv1x1_bwd(int device, u3d_stream_t stream, const float* dy, const float* x, const float* w, int N,
-                               int64_t V, int Cin, int Cout, float* dx, double* acc) {
+extern "C" int u3d_conv1x1_fwd(int device, u3d_stream_t stream, const float* x, const float* w, const float* bias, float* y,
+                               int N, int64_t V, int Cin, int Cout, double* out_stats) {
+    return conv1x1_fwd_impl<float, float>(device, stream, x, w, bias, y, N, V, Cin, Cout, out_stats);
+}
+
+// bf16 activation storage: y is bf16; x is bf16, or fp32 when x_is_f32 (the network input feeding the first block)
+extern "C" int u3d_conv1x1_fwd_b16(int device, u3d_stream_t stream, const void* x, int x_is_f32, const float* w, const float* bias,
+                                   void* y, int N, int64_t V, int Cin, int Cout, double* out_stats) {
+    if (x_is_f32) return conv1x1_fwd_impl<float, __bf16>(device, stream, x, w, bias, y, N, V, Cin, Cout, out_stats);
+    return conv1x1_fwd_impl<__bf16, __bf16>(device, stream, x, w, bias, y, N, V, Cin, Cout, out_stats);
+}
+
+template <typename TX, typename T>
+static int conv1x1_bwd_impl(int device, u3d_stream_t stream, const void* dy, const void* x, const float* w, int N, int64_t V, int Cin,
+                            int Cout, void* dx, double* acc) {
     U3D_ENTER(device);
     U3D_REQUIRE(dy && x && w && acc && N > 0 && V > 0 && Cin > 0 && Cout > 0, "u3d_conv1x1_bwd: bad argument");
     U3D_REQUIRE(V < (1ll << 31) && (long long)N * V < (1ll << 31), "u3d_conv1x1_bwd: N*V must be < 2^31");
@@ -432,7 +461,7 @@ extern "C" int u3d_conv1x1_bwd(int device, u3d_stream_t stream, const float* dy,
         p.osz = p.osy = p.osx = 1, p.ooz = p.ooy = p.oox = 0, p.isz = p.isy = p.isx = 1;
         p.ntaps = 1, p.tz[0] = p.ty[0] = p.tx[0] = 0;
         p.woff[0] = 0, p.wsi = Cin, p.wsj = 1;
-        if (int e = launch_gconv(p, st)) return e;
+        if (int e = launch_gconv<T, T>(p, st)) return e;
     }
     // dw[k][c] = sum_v dy[v,k] * x[v,c] -> acc[k*Cin + c];  db[k] = sum_v dy[v,k] -> acc[Cout*Cin + k]
     GWgradParams g{};
@@ -441,7 +470,19 @@ extern "C" int u3d_conv1x1_bwd(int device, u3d_stream_t stream, const float* dy,
     g.Rz = 1, g.Ry = 1, g.Rx = (int)V, g.Dy = 1, g.Hy = 1, g.Wy = (int)V, g.ysz = g.ysy = g.ysx = 1;
     g.ntaps = 1, g.tz[0] = g.ty[0] = g.tx[0] = 0;
     g.dst_t = 0, g.dst_a = 1, g.dst_b = Cin;
-    return launch_gwgrad(g, st);
+    return launch_gwgrad<TX, T>(g, st);
+}
+
+extern "C" int u3d_conv1x1_bwd(int device, u3d_stream_t stream, const float* dy, const float* x, const float* w, int N,
+                               int64_t V, int Cin, int Cout, float* dx, double* acc) {
+    return conv1x1_bwd_impl<float, float>(device, stream, dy, x, w, N, V, Cin, Cout, dx, acc);
+}
+
+// bf16 activation storage: dy / dx are bf16; x is bf16, or fp32 when x_is_f32 (the network input: first block's conv1)
+extern "C" int u3d_conv1x1_bwd_b16(int device, u3d_stream_t stream, const void* dy, const void* x, int x_is_f32, const float* w, int N,
+                                   int64_t V, int Cin, int Cout, void* dx, double* acc) {
+    if (x_is_f32) return conv1x1_bwd_impl<float, __bf16>(device, stream, dy, x, w, N, V, Cin, Cout, dx, acc);
+    return conv1x1_bwd_impl<__bf16, __bf16>(device, stream, dy, x, w, N, V, Cin, Cout, dx, acc);
 }
 
 // ---- ConvTranspose3d(k=3, stride=2, padding=1, bias=False): (N,D1,H1,W1,Cin) -> (N,2D1-1,2H1-1,2W1-1,Cout) ------------
@@ -554,30 +595,32 @@ extern "C" int u3d_convtr3d_bwd(int device, u3d_stream_t stream, const float* dt
 }
 
 // ---- nearest resize to the skip's size + summation joining (buildingblocks.py:650-651 + :493) ---------------------------
-static int nearest_add_impl(int device, u3d_stream_t stream, const float* skip, const float* t, const int32_t* zmap,
+template <typename T>
+static int nearest_add_impl(int device, u3d_stream_t stream, const T* skip, const T* t, const int32_t* zmap,
                             const int32_t* ymap, const int32_t* xmap, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C,
-                            float* out, double* out_stats, int t8);
+                            T* out, double* out_stats, int t8);
 
 extern "C" int u3d_nearest_add_fwd(int device, u3d_stream_t stream, const float* skip, const float* t, const int32_t* zmap,
                                    const int32_t* ymap, const int32_t* xmap, int N, int D, int H, int W, int Dt, int Ht,
                                    int Wt, int C, float* out, double* out_stats) {
-    return nearest_add_impl(device, stream, skip, t, zmap, ymap, xmap, N, D, H, W, Dt, Ht, Wt, C, out, out_stats, 0);
+    return nearest_add_impl<float>(device, stream, skip, t, zmap, ymap, xmap, N, D, H, W, Dt, Ht, Wt, C, out, out_stats, 0);
 }
 
 extern "C" int u3d_nearest_add_fwd_t8(int device, u3d_stream_t stream, const float* skip, const float* t8, const int32_t* zmap,
                                       const int32_t* ymap, const int32_t* xmap, int N, int D, int H, int W, int Dt, int Ht,
                                       int Wt, int C, float* out, double* out_stats) {
-    return nearest_add_impl(device, stream, skip, t8, zmap, ymap, xmap, N, D, H, W, Dt, Ht, Wt, C, out, out_stats, 1);
+    return nearest_add_impl<float>(device, stream, skip, t8, zmap, ymap, xmap, N, D, H, W, Dt, Ht, Wt, C, out, out_stats, 1);
 }
 
-static int nearest_add_impl(int device, u3d_stream_t stream, const float* skip, const float* t, const int32_t* zmap,
+template <typename T>
+static int nearest_add_impl(int device, u3d_stream_t stream, const T* skip, const T* t, const int32_t* zmap,
                             const int32_t* ymap, const int32_t* xmap, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C,
-                            float* out, double* out_stats, int t8) {
+                            T* out, double* out_stats, int t8) {
     U3D_ENTER(device);
     U3D_REQUIRE(skip && t && zmap && ymap && xmap && out && N > 0 && D > 0 && H > 0 && W > 0 && Dt > 0 && Ht > 0 && Wt > 0 &&
                     C > 0 && C <= 1024,
                 "u3d_nearest_add_fwd: bad argument (C <= 1024)");
-    const int vecw = (C % 4 == 0 && al16(skip) && al16(t) && al16(out)) ? 4 : 1;
+    const int vecw = (C % 4 == 0 && (((uintptr_t)skip | (uintptr_t)t | (uintptr_t)out) & u3d_vec_align<T>::mask) == 0) ? 4 : 1;
     int Q = C / vecw;
     U3D_REQUIRE(Q <= 256, "u3d_nearest_add_fwd: more than 256 channel units per voxel (C %% 4 != 0 with C > 256)");
     const int rows = 256 / Q;
@@ -585,33 +628,48 @@ static int nearest_add_impl(int device, u3d_stream_t stream, const float* skip, 
     long long bx = (V + rows - 1) / rows;
     const long long cap = 2048 / N > 1 ? 2048 / N : 1;
     if (bx > cap) bx = cap;
-    hipLaunchKernelGGL(nearest_add_kernel, dim3((unsigned)bx, (unsigned)N), dim3(256), sizeof(double) * 2 * (size_t)C,
+    hipLaunchKernelGGL(nearest_add_kernel<T>, dim3((unsigned)bx, (unsigned)N), dim3(256), sizeof(double) * 2 * (size_t)C,
                        (hipStream_t)stream, skip, t, zmap, ymap, xmap, D, H, W, Dt, Ht, Wt, C, Q, vecw, t8, out, out_stats);
     U3D_LAUNCH_CHECK();
     return 0;
 }
 
-static int nearest_sum_impl(int device, u3d_stream_t stream, const float* dj, const int32_t* zlo, const int32_t* ylo,
-                            const int32_t* xlo, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C, float* dt, int t8);
+template <typename T>
+static int nearest_sum_impl(int device, u3d_stream_t stream, const T* dj, const int32_t* zlo, const int32_t* ylo,
+                            const int32_t* xlo, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C, T* dt, int t8);
 
 extern "C" int u3d_nearest_sum_bwd(int device, u3d_stream_t stream, const float* dj, const int32_t* zlo, const int32_t* ylo,
                                    const int32_t* xlo, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C, float* dt) {
-    return nearest_sum_impl(device, stream, dj, zlo, ylo, xlo, N, D, H, W, Dt, Ht, Wt, C, dt, 0);
+    return nearest_sum_impl<float>(device, stream, dj, zlo, ylo, xlo, N, D, H, W, Dt, Ht, Wt, C, dt, 0);
 }
 
 extern "C" int u3d_nearest_sum_bwd_t8(int device, u3d_stream_t stream, const float* dj, const int32_t* zlo, const int32_t* ylo,
                                       const int32_t* xlo, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C, float* dt8) {
-    return nearest_sum_impl(device, stream, dj, zlo, ylo, xlo, N, D, H, W, Dt, Ht, Wt, C, dt8, 1);
+    return nearest_sum_impl<float>(device, stream, dj, zlo, ylo, xlo, N, D, H, W, Dt, Ht, Wt, C, dt8, 1);
 }
 
-static int nearest_sum_impl(int device, u3d_stream_t stream, const float* dj, const int32_t* zlo, const int32_t* ylo,
-                            const int32_t* xlo, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C, float* dt, int t8) {
+// bf16 activation storage (space-to-depth layout only: the bf16 path's transposed convolutions)
+extern "C" int u3d_nearest_add_fwd_t8_b16(int device, u3d_stream_t stream, const void* skip, const void* t8, const int32_t* zmap,
+                                          const int32_t* ymap, const int32_t* xmap, int N, int D, int H, int W, int Dt, int Ht, int Wt,
+                                          int C, void* out, double* out_stats) {
+    return nearest_add_impl<__bf16>(device, stream, (const __bf16*)skip, (const __bf16*)t8, zmap, ymap, xmap, N, D, H, W, Dt, Ht, Wt, C,
+                                    (__bf16*)out, out_stats, 1);
+}
+
+extern "C" int u3d_nearest_sum_bwd_t8_b16(int device, u3d_stream_t stream, const void* dj, const int32_t* zlo, const int32_t* ylo,
+                                          const int32_t* xlo, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C, void* dt8) {
+    return nearest_sum_impl<__bf16>(device, stream, (const __bf16*)dj, zlo, ylo, xlo, N, D, H, W, Dt, Ht, Wt, C, (__bf16*)dt8, 1);
+}
+
+template <typename T>
+static int nearest_sum_impl(int device, u3d_stream_t stream, const T* dj, const int32_t* zlo, const int32_t* ylo,
+                            const int32_t* xlo, int N, int D, int H, int W, int Dt, int Ht, int Wt, int C, T* dt, int t8) {
     U3D_ENTER(device);
     U3D_REQUIRE(dj && zlo && ylo && xlo && dt && N > 0 && C > 0, "u3d_nearest_sum_bwd: bad argument");
     const long long total = t8 ? (long long)N * ((Dt + 1) / 2) * ((Ht + 1) / 2) * ((Wt + 1) / 2) * 8 * C : (long long)N * Dt * Ht * Wt * C;
     long long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(nearest_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dj, zlo, ylo, xlo, N, D, H,
+    hipLaunchKernelGGL(nearest_sum_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dj, zlo, ylo, xlo, N, D, H,
                        W, Dt, Ht, Wt, C, t8, dt);
     U3D_LAUNCH_CHECK();
     return 0;

@@ -212,6 +212,33 @@ _PROTOS = {
                                                                                  c_int64],
     ),
     "u3d_pack_weights_bf16": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    # bf16 activation storage (include/u3d.h, "_b16" entry points)
+    "u3d_conv3d_bf16_ex_b16": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                       c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
+    "u3d_conv3d_wgrad_bf16_b16": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                          c_int, c_void_p, c_int64]),
+    "u3d_convtr3d_fwd_t8_b16": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "u3d_convtr3d_dgrad_t8_b16": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                          c_int]),
+    "u3d_convtr3d_wgrad_t8_b16": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                          c_void_p, c_int64]),
+    "u3d_conv1x1_fwd_b16": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int,
+                                    c_void_p]),
+    "u3d_conv1x1_bwd_b16": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p,
+                                    c_void_p]),
+    "u3d_maxpool2_fwd_b16": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "u3d_maxpool2_bwd_merge_b16": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                           c_int, c_int, c_int, c_int, c_void_p]),
+    "u3d_nearest_add_fwd_t8_b16": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                           c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "u3d_nearest_sum_bwd_t8_b16": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                           c_int, c_int, c_int, c_void_p]),
+    "u3d_gn_bwd_apply_b16": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int,
+                                     c_void_p, c_void_p]),
+    "u3d_conv1x1_head_fwd_b16": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p,
+                                         c_void_p]),
+    "u3d_conv1x1_head_bwd_b16": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p,
+                                         c_void_p]),
     "u3d_pack_weights_bf16_blocks": (c_int64, [c_int, c_int, c_int]),
     "u3d_pack_weights_bf16_batch": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int64]),
     "u3d_conv3d_bf16": (
@@ -308,7 +335,7 @@ def get_lib():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.u3d_version() < 112:
+        if lib.u3d_version() < 113:
             raise U3DError("libu3d_hip.so is older than the Python host code")
         for kv in os.environ.get("U3D_TUNE", "").split(","):  # A/B knobs of u3d_set_tuning, e.g. U3D_TUNE=8:256,9:1 (results never change)
             if ":" in kv:

@@ -438,6 +438,9 @@ class UNet3DEngine:
         # with activation checkpointing the tape is also RELEASED block by block during backward (ResUNetEngine.backward): a feature
         # whose only purpose is memory must move the peak, and with one autograd node owning the whole tape it otherwise does not
         self.lean_tape = False  # (ResUNetEngine turns it on together with checkpoint_encoders)
+        # bf16 ACTIVATION STORAGE (`activation_dtype: bf16`; ResUNetEngine decides whether the model qualifies): every NDHWC
+        # activation / gradient tensor between kernels is bf16, through the `_b16` entry points of include/u3d.h
+        self.act_bf16 = False
         # id(conv weight) -> (C0, C1) of every decoder first conv (static); WHICH of them take the sub-pixel path depends on
         # the input size and is per-call state (`sub` argument / ConvRec.sub), never stored on the engine: forwards at
         # different sizes, other threads and nn.DataParallel replicas must not see each other's choice
@@ -866,8 +869,12 @@ class UNet3DEngine:
             mean_rstd = self._norm_finalize(spec.norm, gn, st0, C0, sc0, st1, C1, sc1, N, G, float(D * H * W), affine, dev)
         # y_out: recomputation under activation checkpointing rewrites the (still alive) block output in place with the
         # bit-identical values instead of allocating a second copy
-        y = y_out if (y_out is not None and not post) else _empty((N, D, H, W, Cout), dtype=_F32, device=dev)
-        small = self.small_cin and src.t1 is None and Ctot <= 4 and Cout <= 32 and residual is None
+        b16 = src.t0.dtype == torch.bfloat16  # bf16 activation storage: only the bf16-operand branch below handles it
+        if b16:
+            assert self.act_bf16 and src.t1 is None and not post and self._bf16_layer(Ctot, Cout) and act == ACT_RELU, \
+                "bf16 activation storage reached a layer outside its envelope"
+        y = y_out if (y_out is not None and not post) else _empty((N, D, H, W, Cout), dtype=src.t0.dtype if b16 else _F32, device=dev)
+        small = self.small_cin and src.t1 is None and Ctot <= 4 and Cout <= 32 and residual is None and not b16
         if small:
             # first layer of the network: K = 27*Cin is too small for the MFMA tiling (csrc/u3d_smallc.hip)
             ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
@@ -904,13 +911,14 @@ class UNet3DEngine:
                      _p(y), N, D, H, W, Ctot, Cout, relu, _p(ystats), None, None, _p(conv_res), _p(kws), need,
                      flops=54.0 * Ctot * Cout * N * D * H * W)
         elif src.t1 is None and self._bf16_layer(Ctot, Cout):
-            # bf16 MFMA operands, fp32 accumulation / epilogue (csrc/u3d_bf16.hip)
+            # bf16 MFMA operands, fp32 accumulation / epilogue (csrc/u3d_bf16.hip); with bf16 activation storage the input, the
+            # output and the residual are bf16 tensors (`_b16` entry point)
             ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
             need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(N, D, H, W, Ctot, Cout)  # split-K scratch at the bottom of the U
             kws = _empty(need, dtype=_F32, device=dev) if need > 0 else None
-            nat.call("u3d_conv3d_bf16_ex", dev.index, _stream(dev), _p(src.t0), _p(affine), _p(self._packed_bf16(conv.weight, 0, dev)),
-                     _p(y), N, D, H, W, Ctot, Cout, relu, _p(ystats), None, None, _p(conv_res), _p(kws), need,
-                     flops=54.0 * Ctot * Cout * N * D * H * W)
+            nat.call("u3d_conv3d_bf16_ex" + ("_b16" if b16 else ""), dev.index, _stream(dev), _p(src.t0), _p(affine),
+                     _p(self._packed_bf16(conv.weight, 0, dev)), _p(y), N, D, H, W, Ctot, Cout, relu, _p(ystats), None, None,
+                     _p(conv_res), _p(kws), need, flops=54.0 * Ctot * Cout * N * D * H * W)
         else:
             wp = self._packed(conv.weight, 0, dev)
             ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
@@ -1022,11 +1030,13 @@ class UNet3DEngine:
         s_aff = src.struct(rec.affine)
         flops = 54.0 * src.C * Cout * Nn * Dd * Hh * Ww
         bf16 = src.t1 is None and rec.sub is None and not rec.small and self._bf16_layer(src.C, Cout)
+        b16 = src.t0.dtype == torch.bfloat16  # bf16 activation storage
+        assert not b16 or (bf16 and Cout % 64 == 0 and dz_.dtype == torch.bfloat16)
         if bf16 and Cout % 64 == 0:
             need = nat.get_lib().u3d_wgrad_bf16_workspace_floats(Nn, Dd, Hh, Ww, src.C, Cout)
             ws = cx.ensure_ws(need)
-            nat.call("u3d_conv3d_wgrad_bf16", dev.index, _stream(dev), _p(src.t0), _p(rec.affine), _p(dz_), _p(gview(rec.idx_w)),
-                     Nn, Dd, Hh, Ww, src.C, Cout, _p(ws), ws.numel(), flops=flops)
+            nat.call("u3d_conv3d_wgrad_bf16" + ("_b16" if b16 else ""), dev.index, _stream(dev), _p(src.t0), _p(rec.affine), _p(dz_),
+                     _p(gview(rec.idx_w)), Nn, Dd, Hh, Ww, src.C, Cout, _p(ws), ws.numel(), flops=flops)
         elif rec.sub is not None:
             # weight gradient in two channel slices of the same (Cout, Ctot, 27) buffer: upsampled channels from the 64
             # (parity class, tap half) matrices over the low-res grid, skip channels from the standard kernel
@@ -1086,12 +1096,13 @@ class UNet3DEngine:
             nat.call("u3d_conv3d_f32s", dev.index, _stream(dev), _p(dz_), None, _p(self._packed_f32s(rec.conv_w, 1, dev)), _p(dg),
                      Nn, Dd, Hh, Ww, Cout, src.C, 0, None, _p(src.t0), _p(gst), None, _p(kws), need, flops=flops)
         elif bf16:
-            dg = _empty((Nn, Dd, Hh, Ww, src.C), dtype=_F32, device=dev)
+            dg = _empty((Nn, Dd, Hh, Ww, src.C), dtype=dz_.dtype if b16 else _F32, device=dev)
             gst = pool.take(Nn * src.C * 2)
             need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(Nn, Dd, Hh, Ww, Cout, src.C)
             kws = cx.ensure_ws(need) if need > 0 else None
-            nat.call("u3d_conv3d_bf16_ex", dev.index, _stream(dev), _p(dz_), None, _p(self._packed_bf16(rec.conv_w, 1, dev)), _p(dg),
-                     Nn, Dd, Hh, Ww, Cout, src.C, 0, None, _p(src.t0), _p(gst), None, _p(kws), need, flops=flops)
+            nat.call("u3d_conv3d_bf16_ex" + ("_b16" if b16 else ""), dev.index, _stream(dev), _p(dz_), None,
+                     _p(self._packed_bf16(rec.conv_w, 1, dev)), _p(dg), Nn, Dd, Hh, Ww, Cout, src.C, 0, None, _p(src.t0), _p(gst),
+                     None, _p(kws), need, flops=flops)
         else:
             wpd = self._packed(rec.conv_w, 1, dev)
             dg = _empty((Nn, Dd, Hh, Ww, src.C), dtype=_F32, device=dev)
@@ -1113,6 +1124,10 @@ class UNet3DEngine:
         out = _empty_like(x)
         Nn = x.shape[0]
         C = x.shape[-1]
+        if x.dtype == torch.bfloat16:  # bf16 activation storage (dg, x, add, out all bf16)
+            nat.call("u3d_gn_bwd_apply_b16", dev.index, _stream(dev), _p(dg), C, 0, _p(x), C, _p(coef), C, x.numel() // (Nn * C), Nn,
+                     relu_mask, _p(add), _p(out))
+            return out
         if add is None:
             nat.call("u3d_gn_bwd_apply", dev.index, _stream(dev), _p(dg), C, 0, _p(x), C, _p(coef), C, x.numel() // (Nn * C), Nn,
                      relu_mask, _p(out))
@@ -1465,6 +1480,40 @@ class ResUNetEngine(UNet3DEngine):
         order = getattr(model, "layer_order", "gcr")
         self.act2, self.slope2 = self.act, self.slope
         self.lean_tape = self.checkpoint_encoders and os.environ.get("U3D_LEAN_TAPE", "1") != "0"
+        self.adt = _F32
+        if bool(getattr(model, "activation_bf16", False)):
+            why = self._act_bf16_blocker(model, order)
+            if why is None:
+                self.act_bf16, self.adt = True, torch.bfloat16
+            else:
+                import warnings
+
+                warnings.warn(f"u3d: activation_dtype bf16 requested but {why}; activations stay fp32 in HBM", stacklevel=3)
+
+    def _act_bf16_blocker(self, model, order) -> Optional[str]:
+        """why this model cannot keep its activations in bf16 (None = it can): the `_b16` entry points cover the 'gcr' residual
+        net whose every 3x3x3 / transposed convolution runs on the bf16 MFMA kernels"""
+        lib = nat.get_lib()
+        if not self.bf16:
+            return "compute_dtype is not bf16"
+        if order != "gcr":
+            return f"layer_order '{order}' (only 'gcr')"
+        if any(self.dec_concat):
+            return "explicit upsample='deconv' (concat joining)"
+        for _, bm in self.enc + [(None, b) for _, b in self.dec]:
+            C = bm.conv2.conv.in_channels
+            if getattr(bm, "se_module", None) is not None:
+                return "squeeze-and-excitation blocks"
+            if C % 64 != 0:
+                return f"a block of {C} channels (multiples of 64: bf16 forward, data- and weight-gradient kernels)"
+        for ct, _ in self.dec:
+            if lib.u3d_convtr3d_t8_supported(ct.weight.shape[0], ct.weight.shape[1]) != 1:
+                return f"a transposed convolution {ct.weight.shape[0]} -> {ct.weight.shape[1]} outside the space-to-depth kernels"
+        fc = model.final_conv
+        g = fc.in_channels // 4
+        if fc.in_channels % 4 or g & (g - 1) or g > 64 or fc.out_channels > 4:
+            return f"a head {fc.in_channels} -> {fc.out_channels} outside the vector kernels"
+        return None
         self.act, self.slope = (ACT_LEAKY, 0.1) if "l" in order else ((ACT_ELU, 0.0) if "e" in order else (ACT_RELU, 0.0))
         self.mask = 1 if self.act == ACT_RELU else 0
 
@@ -1489,11 +1538,15 @@ class ResUNetEngine(UNet3DEngine):
                 sx = VSrc(r).struct()
                 nat.call("u3d_chan_stats", dev.index, _stream(dev), ctypes.byref(sx), N, D, H, W, _p(r_st))
         else:
-            r = _empty((N, D, H, W, Cout), dtype=_F32, device=dev)
+            r = _empty((N, D, H, W, Cout), dtype=self.adt, device=dev)
             r_st = pool.take(N * Cout * 2)
             w1 = conv1.weight.detach().view(Cout, Cin)
-            nat.call("u3d_conv1x1_fwd", dev.index, _stream(dev), _p(x_in), _p(w1), _p(conv1.bias.detach()), _p(r), N, D * H * W,
-                     Cin, Cout, _p(r_st), flops=2.0 * Cin * Cout * N * D * H * W)
+            if self.act_bf16:  # (the first block reads the fp32 network input)
+                nat.call("u3d_conv1x1_fwd_b16", dev.index, _stream(dev), _p(x_in), 1 if x_in.dtype == _F32 else 0, _p(w1),
+                         _p(conv1.bias.detach()), _p(r), N, D * H * W, Cin, Cout, _p(r_st), flops=2.0 * Cin * Cout * N * D * H * W)
+            else:
+                nat.call("u3d_conv1x1_fwd", dev.index, _stream(dev), _p(x_in), _p(w1), _p(conv1.bias.detach()), _p(r), N, D * H * W,
+                         Cin, Cout, _p(r_st), flops=2.0 * Cin * Cout * N * D * H * W)
         n0 = len(tape.convs) if tape is not None else 0
         src2 = VSrc(r)
         out2, st2 = self._single_conv_fwd(bm.conv2, name + ".c2", src2, (r_st, Cout, 1.0, None, 0, 0.0), pool, tape)
@@ -1605,10 +1658,13 @@ class ResUNetEngine(UNet3DEngine):
         for i, (has_pool, bm) in enumerate(self.enc):
             if has_pool:
                 Np, Dp, Hp, Wp, Cp = cur.shape
-                pooled = _empty((Np, Dp // 2, Hp // 2, Wp // 2, Cp), dtype=_F32, device=dev)
+                pooled = _empty((Np, Dp // 2, Hp // 2, Wp // 2, Cp), dtype=self.adt, device=dev)
                 argmax = _empty(pooled.shape, dtype=torch.uint8, device=dev)
-                nat.call("u3d_maxpool2_fwd", dev.index, _stream(dev), _p(cur), Np, Dp, Hp, Wp, Cp, _p(pooled), _p(argmax),
-                         None)
+                if self.act_bf16:
+                    nat.call("u3d_maxpool2_fwd_b16", dev.index, _stream(dev), _p(cur), Np, Dp, Hp, Wp, Cp, _p(pooled), _p(argmax))
+                else:
+                    nat.call("u3d_maxpool2_fwd", dev.index, _stream(dev), _p(cur), Np, Dp, Hp, Wp, Cp, _p(pooled), _p(argmax),
+                             None)
                 if tape is not None:
                     tape.pools.append((pooled, argmax, cur))
                 cur = pooled
@@ -1635,11 +1691,12 @@ class ResUNetEngine(UNet3DEngine):
             if t8:
                 # bf16 mode: 2x2x2 convolution on the low-res grid into the space-to-depth layout T8[i][parity*Cs + c] = t[2i + parity];
                 # the resize + join reads that layout directly
-                t = _empty((Nl, D1, H1, W1, 8 * Cs), dtype=_F32, device=dev)
-                nat.call("u3d_convtr3d_fwd_t8", dev.index, _stream(dev), _p(cur), _p(self._packed_convtr_t8(ct.weight, 0, dev)), _p(t),
-                         Nl, D1, H1, W1, Cl, Cs, flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
-                nat.call("u3d_nearest_add_fwd_t8", dev.index, _stream(dev), _p(sk), _p(t), _p(mz), _p(my), _p(mx), Nl, Ds, Hs, Ws, Dt,
-                         Ht, Wt, Cs, _p(joined), _p(j_st))
+                sfx = "_b16" if self.act_bf16 else ""
+                t = _empty((Nl, D1, H1, W1, 8 * Cs), dtype=self.adt, device=dev)
+                nat.call("u3d_convtr3d_fwd_t8" + sfx, dev.index, _stream(dev), _p(cur), _p(self._packed_convtr_t8(ct.weight, 0, dev)),
+                         _p(t), Nl, D1, H1, W1, Cl, Cs, flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
+                nat.call("u3d_nearest_add_fwd_t8" + sfx, dev.index, _stream(dev), _p(sk), _p(t), _p(mz), _p(my), _p(mx), Nl, Ds, Hs,
+                         Ws, Dt, Ht, Wt, Cs, _p(joined), _p(j_st))
                 del t
                 if tape is not None:
                     tape.ups.append(UpRec(cur, ct.weight, (lz, ly, lx), (Dt, Ht, Wt), True))
@@ -1673,8 +1730,8 @@ class ResUNetEngine(UNet3DEngine):
         if m.final_activation is not None:
             act = 1 if isinstance(m.final_activation, torch.nn.Sigmoid) else 2
             probs = _empty_like(logits)
-        nat.call("u3d_conv1x1_head_fwd", dev.index, _stream(dev), _p(cur), _p(fc.weight.detach()), _p(fc.bias.detach()), N, V,
-                 Cf, Co, act, _p(logits), _p(probs))
+        nat.call("u3d_conv1x1_head_fwd" + ("_b16" if self.act_bf16 else ""), dev.index, _stream(dev), _p(cur), _p(fc.weight.detach()),
+                 _p(fc.bias.detach()), N, V, Cf, Co, act, _p(logits), _p(probs))
         if tape is not None:
             tape.head_x = cur
             if self.debug is not None:
@@ -1707,10 +1764,15 @@ class ResUNetEngine(UNet3DEngine):
         Cout_, Cin_ = c1.weight.shape[0], c1.weight.shape[1]
         xin = rec.x_in
         acc = pool.take(Cout_ * Cin_ + Cout_)
-        dxin = _empty_like(xin) if need_dx else None
-        nat.call("u3d_conv1x1_bwd", dev.index, _stream(dev), _p(dr), _p(xin), _p(c1.weight.detach().view(Cout_, Cin_)),
-                 xin.shape[0], xin.numel() // (xin.shape[0] * Cin_), Cin_, Cout_, _p(dxin), _p(acc),
-                 flops=(4.0 if need_dx else 2.0) * Cin_ * Cout_ * (xin.numel() // Cin_))
+        dxin = _empty(xin.shape, dtype=dr.dtype, device=dev) if need_dx else None
+        if self.act_bf16:
+            nat.call("u3d_conv1x1_bwd_b16", dev.index, _stream(dev), _p(dr), _p(xin), 1 if xin.dtype == _F32 else 0,
+                     _p(c1.weight.detach().view(Cout_, Cin_)), xin.shape[0], xin.numel() // (xin.shape[0] * Cin_), Cin_, Cout_,
+                     _p(dxin), _p(acc), flops=(4.0 if need_dx else 2.0) * Cin_ * Cout_ * (xin.numel() // Cin_))
+        else:
+            nat.call("u3d_conv1x1_bwd", dev.index, _stream(dev), _p(dr), _p(xin), _p(c1.weight.detach().view(Cout_, Cin_)),
+                     xin.shape[0], xin.numel() // (xin.shape[0] * Cin_), Cin_, Cout_, _p(dxin), _p(acc),
+                     flops=(4.0 if need_dx else 2.0) * Cin_ * Cout_ * (xin.numel() // Cin_))
         jw, jb = self._pindex[id(c1.weight)], self._pindex[id(c1.bias)]
         assert self.poffs[jb] == self.poffs[jw] + Cout_ * Cin_
         nat.call("u3d_cvt_f64_f32", dev.index, _stream(dev), _p(acc), _p(gview(jw)), Cout_ * Cin_ + Cout_)
@@ -1749,8 +1811,8 @@ class ResUNetEngine(UNet3DEngine):
         hacc = pool.take(Co * Cf + Co)
         dz = _empty_like(tape.head_x)
         mk = self.mask  # ReLU blocks: the consumers' backward kernels mask by (block output > 0); else _block_bwd removes f
-        nat.call("u3d_conv1x1_head_bwd", dev.index, _stream(dev), _p(dlogits), _p(tape.head_x), _p(fc.weight.detach()), N, V,
-                 Cf, Co, mk, _p(dz), _p(hacc))
+        nat.call("u3d_conv1x1_head_bwd" + ("_b16" if self.act_bf16 else ""), dev.index, _stream(dev), _p(dlogits), _p(tape.head_x),
+                 _p(fc.weight.detach()), N, V, Cf, Co, mk, _p(dz), _p(hacc))
         iw, ib = self._pindex[id(fc.weight)], self._pindex[id(fc.bias)]
         assert self.poffs[ib] == self.poffs[iw] + Co * Cf
         nat.call("u3d_cvt_f64_f32", dev.index, _stream(dev), _p(hacc), _p(gview(iw)), Co * Cf + Co)
@@ -1797,15 +1859,17 @@ class ResUNetEngine(UNet3DEngine):
             Dt, Ht, Wt = up.tdims
             lz, ly, lx = up.los
             if up.t8:
-                dt8 = _empty((Nl, D1, H1, W1, 8 * Cs), dtype=_F32, device=dev)
-                nat.call("u3d_nearest_sum_bwd_t8", dev.index, _stream(dev), _p(dj), _p(lz), _p(ly), _p(lx), Nl, Ds, Hs, Ws, Dt, Ht, Wt,
-                         Cs, _p(dt8))
+                sfx = "_b16" if self.act_bf16 else ""
+                dt8 = _empty((Nl, D1, H1, W1, 8 * Cs), dtype=self.adt, device=dev)
+                nat.call("u3d_nearest_sum_bwd_t8" + sfx, dev.index, _stream(dev), _p(dj), _p(lz), _p(ly), _p(lx), Nl, Ds, Hs, Ws, Dt, Ht,
+                         Wt, Cs, _p(dt8))
                 need = nat.get_lib().u3d_convtr3d_wgrad_t8_workspace_floats(Nl, D1, H1, W1, Cl, Cs)
                 wsb = cx.ensure_ws(need)
-                nat.call("u3d_convtr3d_wgrad_t8", dev.index, _stream(dev), _p(xl), _p(dt8), _p(gview(self._pindex[id(up.weight)])),
-                         Nl, D1, H1, W1, Cl, Cs, _p(wsb), wsb.numel(), flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
+                nat.call("u3d_convtr3d_wgrad_t8" + sfx, dev.index, _stream(dev), _p(xl), _p(dt8),
+                         _p(gview(self._pindex[id(up.weight)])), Nl, D1, H1, W1, Cl, Cs, _p(wsb), wsb.numel(),
+                         flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
                 dxl = _empty_like(xl)
-                nat.call("u3d_convtr3d_dgrad_t8", dev.index, _stream(dev), _p(dt8), _p(self._packed_convtr_t8(up.weight, 1, dev)),
+                nat.call("u3d_convtr3d_dgrad_t8" + sfx, dev.index, _stream(dev), _p(dt8), _p(self._packed_convtr_t8(up.weight, 1, dev)),
                          _p(xl) if mk else None, _p(dxl), Nl, D1, H1, W1, Cl, Cs, flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
                 del dt8
                 dz = dxl  # ReLU blocks: masked by (x_low > 0)
@@ -1861,8 +1925,8 @@ class ResUNetEngine(UNet3DEngine):
                     pools[i - 1] = None
                 Ne, De, He, We, Ce = e_in.shape
                 out = _empty_like(e_in)
-                nat.call("u3d_maxpool2_bwd_merge", dev.index, _stream(dev), _p(dxin), _p(pooled), _p(argmax), None,
-                         _p(skip_grad.get(i - 1)), _p(e_in), Ne, De, He, We, Ce, mk, _p(out))
+                nat.call("u3d_maxpool2_bwd_merge" + ("_b16" if self.act_bf16 else ""), dev.index, _stream(dev), _p(dxin), _p(pooled),
+                         _p(argmax), None, _p(skip_grad.get(i - 1)), _p(e_in), Ne, De, He, We, Ce, mk, _p(out))
                 skip_grad.pop(i - 1, None)
                 dz = out
             elif need_input_grad:
@@ -1875,6 +1939,8 @@ class ResUNetEngine(UNet3DEngine):
 
         dx = None
         if dx0 is not None:
+            if dx0.dtype != _F32:
+                dx0 = dx0.to(_F32)  # (input gradients are rare; the network input and its gradient are fp32 tensors)
             if Cin == 1:
                 dx = dx0.reshape(N, 1, D, H, W)
             else:

@@ -34,7 +34,7 @@ class AbstractUNet(nn.Module):
     def __init__(self, in_channels, out_channels, final_sigmoid, basic_module, f_maps=64, layer_order="gcr",
                  num_groups=8, num_levels=4, is_segmentation=True, conv_kernel_size=3, pool_kernel_size=2,
                  conv_padding=1, conv_upscale=2, upsample="default", dropout_prob=0.1, is3d=True, compute_dtype=None,
-                 checkpoint_encoders=None, hip_graph=None):
+                 checkpoint_encoders=None, hip_graph=None, activation_dtype=None):
         super().__init__()
         if isinstance(f_maps, int):
             f_maps = number_of_features_per_level(f_maps, num_levels=num_levels)
@@ -96,6 +96,13 @@ class AbstractUNet(nn.Module):
         if checkpoint_encoders is None:
             checkpoint_encoders = os.environ.get("U3D_CHECKPOINT", "0") == "1"
         self.checkpoint_encoders = bool(checkpoint_encoders)
+        # `activation_dtype: bf16` / U3D_ACT_BF16=1 (with compute_dtype bf16, residual 'gcr' nets): activations and gradients between
+        # kernels are stored as bf16 (engine.ResUNetEngine.act_bf16); anything else keeps fp32 storage
+        if activation_dtype is None:
+            activation_dtype = "bf16" if os.environ.get("U3D_ACT_BF16", "0") == "1" else "fp32"
+        if str(activation_dtype).lower() not in ("fp32", "float32", "bf16", "bfloat16"):
+            raise ValueError(f"activation_dtype must be 'fp32' or 'bf16', got {activation_dtype!r}")
+        self.activation_bf16 = str(activation_dtype).lower() in ("bf16", "bfloat16")
         # `hip_graph: true` / U3D_GRAPH=1: training steps replay two captured hipGraphs per input shape (engine.GraphStep)
         if hip_graph is None:
             hip_graph = os.environ.get("U3D_GRAPH", "0") == "1"
@@ -198,7 +205,7 @@ def _variant(name, basic_module, default_levels, is3d, doc):
                               num_levels=num_levels, is_segmentation=is_segmentation, conv_padding=conv_padding,
                               conv_upscale=conv_upscale, upsample=upsample, dropout_prob=dropout_prob, is3d=is3d,
                               compute_dtype=kwargs.get("compute_dtype"), checkpoint_encoders=kwargs.get("checkpoint_encoders"),
-                              hip_graph=kwargs.get("hip_graph"))
+                              hip_graph=kwargs.get("hip_graph"), activation_dtype=kwargs.get("activation_dtype"))
 
     return type(name, (AbstractUNet,), {"__init__": __init__, "__doc__": doc, "__module__": _THIS_MODULE})
 

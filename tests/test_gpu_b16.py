@@ -1,0 +1,354 @@
+"""-m gpu: bf16 ACTIVATION STORAGE (`activation_dtype: bf16`; the `_b16` entry points of include/u3d.h, BASELINE config 4).
+
+Kernel level: every `_b16` entry point against the fp32 entry point of the same name on the same (bf16-representable) inputs — the
+arithmetic is shared, so the outputs must be the fp32 results rounded to nearest even, bit for bit, and the fused statistics must
+be the sums of the values as stored.  Model level: the residual net with bf16 storage against the oracle's storage emulation
+(oracle.BF16_STORAGE: forward tensors and gradient tensors rounded where the product stores them)."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import gpu_utils as U
+from conftest import diag
+from pytorch3dunet_amd import _native as nat
+from pytorch3dunet_amd.engine import _maps, _p, _stream
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+lib = None
+
+
+def r16(t):
+    return t.to(BF).to(torch.float32)
+
+
+def dev(t):
+    return t.contiguous().to(U.DEV)
+
+
+def call(name, *a):
+    nat.call(name, 0, _stream(U.DEV), *a)
+
+
+_KEEP = []
+
+
+def b16(t):
+    """bf16 copy that stays alive until the test module is done: _p() hands the kernels a raw pointer, a temporary would be
+    recycled by the caching allocator before the (asynchronous) launch reads it"""
+    if t is None:
+        return None
+    _KEEP.append(t.to(BF))
+    return _KEEP[-1]
+
+
+def same_bits(a, b):
+    return torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
+@pytest.mark.parametrize("shape,C,K,res,ks", [((1, 32, 64, 64), 64, 64, True, False), ((2, 5, 9, 11), 32, 96, False, False),
+                                              ((1, 4, 8, 8), 512, 512, True, True)])
+def test_conv3d_bf16_b16_forward_and_data_gradient(shape, C, K, res, ks):
+    N, D, H, W = shape
+    torch.manual_seed(1)
+    x = dev(r16(torch.randn(N, D, H, W, C)))
+    aff = dev(torch.stack((1.0 + 0.3 * torch.randn(N, C), 0.2 * torch.randn(N, C)), dim=-1))
+    w = dev(torch.randn(K, C, 3, 3, 3) / (27 * C) ** 0.5)
+    residual = dev(r16(torch.randn(N, D, H, W, K))) if res else None
+    L = nat.get_lib()
+    pk = torch.empty(L.u3d_packed_weight_bf16_elems(C, K, 0), dtype=BF, device=U.DEV)
+    call("u3d_pack_weights_bf16", _p(w), K, C, 0, _p(pk))
+    need = L.u3d_conv3d_bf16_workspace_floats(N, D, H, W, C, K)
+    assert (need > 0) == ks
+    ws = torch.empty(max(need, 4), dtype=torch.float32, device=U.DEV)
+    y32 = torch.empty((N, D, H, W, K), dtype=torch.float32, device=U.DEV)
+    st32 = torch.zeros((N, K, 2), dtype=torch.float64, device=U.DEV)
+    call("u3d_conv3d_bf16_ex", _p(x), _p(aff), _p(pk), _p(y32), N, D, H, W, C, K, 1, _p(st32), None, None, _p(residual), _p(ws), need)
+    y16 = torch.full((N, D, H, W, K), float("nan"), dtype=BF, device=U.DEV)
+    st16 = torch.zeros((N, K, 2), dtype=torch.float64, device=U.DEV)
+    xb, rb = x.to(BF), (residual.to(BF) if res else None)
+    call("u3d_conv3d_bf16_ex_b16", _p(xb), _p(aff), _p(pk), _p(y16), N, D, H, W, C, K, 1, _p(st16), None, None, _p(rb), _p(ws), need)
+    torch.cuda.synchronize()
+    assert same_bits(y16, y32.to(BF))
+    yd = y16.double()
+    want = torch.stack((yd.sum(dim=(1, 2, 3)), (yd * yd).sum(dim=(1, 2, 3))), dim=-1)  # statistics of the STORED tensor
+    assert torch.allclose(st16, want, rtol=1e-6, atol=1e-6)
+    # data gradient role: dz -> dg with the GroupNorm-backward sums against gx
+    dz = dev(r16(torch.randn(N, D, H, W, K)))
+    pk1 = torch.empty(L.u3d_packed_weight_bf16_elems(C, K, 1), dtype=BF, device=U.DEV)
+    call("u3d_pack_weights_bf16", _p(w), K, C, 1, _p(pk1))
+    need1 = L.u3d_conv3d_bf16_workspace_floats(N, D, H, W, K, C)
+    ws1 = torch.empty(max(need1, 4), dtype=torch.float32, device=U.DEV)
+    dg32 = torch.empty((N, D, H, W, C), dtype=torch.float32, device=U.DEV)
+    g32 = torch.zeros((N, C, 2), dtype=torch.float64, device=U.DEV)
+    call("u3d_conv3d_bf16_ex", _p(dz), None, _p(pk1), _p(dg32), N, D, H, W, K, C, 0, None, _p(x), _p(g32), None, _p(ws1), need1)
+    dg16 = torch.full((N, D, H, W, C), float("nan"), dtype=BF, device=U.DEV)
+    g16 = torch.zeros((N, C, 2), dtype=torch.float64, device=U.DEV)
+    call("u3d_conv3d_bf16_ex_b16", _p(b16(dz)), None, _p(pk1), _p(dg16), N, D, H, W, K, C, 0, None, _p(xb), _p(g16), None, _p(ws1), need1)
+    torch.cuda.synchronize()
+    assert same_bits(dg16, dg32.to(BF))
+    dgd = dg16.double()
+    want = torch.stack((dgd.sum(dim=(1, 2, 3)), (dgd * x.double()).sum(dim=(1, 2, 3))), dim=-1)
+    assert torch.allclose(g16, want, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("shape,C,K", [((1, 8, 16, 16), 64, 64), ((2, 5, 9, 19), 32, 128)])
+def test_conv3d_wgrad_bf16_b16(shape, C, K):
+    N, D, H, W = shape
+    torch.manual_seed(2)
+    x = dev(r16(torch.randn(N, D, H, W, C)))
+    dz = dev(r16(torch.randn(N, D, H, W, K)))
+    aff = dev(torch.stack((1.0 + 0.3 * torch.randn(N, C), 0.2 * torch.randn(N, C)), dim=-1))
+    L = nat.get_lib()
+    need = L.u3d_wgrad_bf16_workspace_floats(N, D, H, W, C, K)
+    ws = torch.empty(need, dtype=torch.float32, device=U.DEV)
+    a = torch.full((K, C, 3, 3, 3), float("nan"), device=U.DEV)
+    b = torch.full((K, C, 3, 3, 3), float("nan"), device=U.DEV)
+    call("u3d_conv3d_wgrad_bf16", _p(x), _p(aff), _p(dz), _p(a), N, D, H, W, C, K, _p(ws), need)
+    call("u3d_conv3d_wgrad_bf16_b16", _p(b16(x)), _p(aff), _p(b16(dz)), _p(b), N, D, H, W, C, K, _p(ws), need)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+
+
+def test_transposed_convolution_t8_b16():
+    N, D1, H1, W1, Cl, Cs = 1, 4, 6, 5, 64, 32
+    torch.manual_seed(3)
+    L = nat.get_lib()
+    x = dev(r16(torch.relu(torch.randn(N, D1, H1, W1, Cl))))
+    w = dev(torch.randn(Cl, Cs, 3, 3, 3) / (27 * Cl / 8) ** 0.5)
+    dt8 = dev(r16(torch.randn(N, D1, H1, W1, 8 * Cs)))
+    pk = [torch.empty(L.u3d_convtr3d_t8_packed_elems(Cl, Cs, m), dtype=BF, device=U.DEV) for m in (0, 1)]
+    for m in (0, 1):
+        call("u3d_pack_convtr3d_t8", _p(w), Cl, Cs, m, _p(pk[m]))
+    t32 = torch.empty((N, D1, H1, W1, 8 * Cs), device=U.DEV)
+    t16 = torch.empty((N, D1, H1, W1, 8 * Cs), dtype=BF, device=U.DEV)
+    call("u3d_convtr3d_fwd_t8", _p(x), _p(pk[0]), _p(t32), N, D1, H1, W1, Cl, Cs)
+    call("u3d_convtr3d_fwd_t8_b16", _p(b16(x)), _p(pk[0]), _p(t16), N, D1, H1, W1, Cl, Cs)
+    dx32 = torch.empty_like(x)
+    dx16 = torch.empty(x.shape, dtype=BF, device=U.DEV)
+    call("u3d_convtr3d_dgrad_t8", _p(dt8), _p(pk[1]), _p(x), _p(dx32), N, D1, H1, W1, Cl, Cs)
+    call("u3d_convtr3d_dgrad_t8_b16", _p(b16(dt8)), _p(pk[1]), _p(b16(x)), _p(dx16), N, D1, H1, W1, Cl, Cs)
+    need = L.u3d_convtr3d_wgrad_t8_workspace_floats(N, D1, H1, W1, Cl, Cs)
+    ws = torch.empty(need, device=U.DEV)
+    dwa, dwb = torch.empty_like(w), torch.empty_like(w)
+    call("u3d_convtr3d_wgrad_t8", _p(x), _p(dt8), _p(dwa), N, D1, H1, W1, Cl, Cs, _p(ws), need)
+    call("u3d_convtr3d_wgrad_t8_b16", _p(b16(x)), _p(b16(dt8)), _p(dwb), N, D1, H1, W1, Cl, Cs, _p(ws), need)
+    torch.cuda.synchronize()
+    assert same_bits(t16, t32.to(BF)) and same_bits(dx16, dx32.to(BF)) and torch.equal(dwa, dwb)
+
+
+def test_bandwidth_kernels_b16():
+    torch.manual_seed(4)
+    N, D, H, W, C = 2, 6, 9, 10, 64
+    V = D * H * W
+    # GroupNorm backward apply (+ add, + ReLU mask)
+    dg, x, add = (dev(r16(torch.randn(N, D, H, W, C))) for _ in range(3))
+    coef = dev(torch.randn(N, 3, C))
+    for addt, mask in ((None, 1), (add, 0)):
+        o32 = torch.empty_like(x)
+        o16 = torch.empty(x.shape, dtype=BF, device=U.DEV)
+        if addt is None:
+            call("u3d_gn_bwd_apply", _p(dg), C, 0, _p(x), C, _p(coef), C, V, N, mask, _p(o32))
+        else:
+            call("u3d_gn_bwd_apply_add", _p(dg), C, 0, _p(x), C, _p(coef), C, V, N, mask, _p(addt), _p(o32))
+        call("u3d_gn_bwd_apply_b16", _p(b16(dg)), C, 0, _p(b16(x)), C, _p(coef), C, V, N, mask,
+             _p(b16(addt)) if addt is not None else None, _p(o16))
+        torch.cuda.synchronize()
+        assert same_bits(o16, o32.to(BF))
+    # max-pool forward (values and arg-max bytes) and its backward merge with a skip gradient and the ReLU mask
+    p32 = torch.empty((N, D // 2, H // 2, W // 2, C), device=U.DEV)
+    a32 = torch.empty(p32.shape, dtype=torch.uint8, device=U.DEV)
+    p16 = torch.empty(p32.shape, dtype=BF, device=U.DEV)
+    a16 = torch.empty_like(a32)
+    call("u3d_maxpool2_fwd", _p(x), N, D, H, W, C, _p(p32), _p(a32), None)
+    call("u3d_maxpool2_fwd_b16", _p(b16(x)), N, D, H, W, C, _p(p16), _p(a16))
+    dpool = dev(r16(torch.randn(p32.shape)))
+    skip = dev(r16(torch.randn(N, D, H, W, C)))
+    m32 = torch.empty_like(x)
+    m16 = torch.empty(x.shape, dtype=BF, device=U.DEV)
+    call("u3d_maxpool2_bwd_merge", _p(dpool), _p(p32), _p(a32), None, _p(skip), _p(x), N, D, H, W, C, 1, _p(m32))
+    call("u3d_maxpool2_bwd_merge_b16", _p(b16(dpool)), _p(p16), _p(a16), None, _p(b16(skip)), _p(b16(x)), N, D, H, W, C, 1, _p(m16))
+    torch.cuda.synchronize()
+    assert same_bits(p16, p32.to(BF)) and torch.equal(a16, a32) and same_bits(m16, m32.to(BF))
+    # nearest resize + join on the space-to-depth layout, and its backward children sums
+    D1, H1, W1 = 3, 5, 5
+    Dt, Ht, Wt = 2 * D1 - 1, 2 * H1 - 1, 2 * W1 - 1
+    (mz, lz), (my, ly), (mx, lx) = _maps(U.DEV, Dt, D), _maps(U.DEV, Ht, H), _maps(U.DEV, Wt, W)
+    t8 = dev(r16(torch.randn(N, D1, H1, W1, 8 * C)))
+    j32 = torch.empty_like(x)
+    j16 = torch.empty(x.shape, dtype=BF, device=U.DEV)
+    s32, s16 = (torch.zeros((N, C, 2), dtype=torch.float64, device=U.DEV) for _ in range(2))
+    call("u3d_nearest_add_fwd_t8", _p(skip), _p(t8), _p(mz), _p(my), _p(mx), N, D, H, W, Dt, Ht, Wt, C, _p(j32), _p(s32))
+    call("u3d_nearest_add_fwd_t8_b16", _p(b16(skip)), _p(b16(t8)), _p(mz), _p(my), _p(mx), N, D, H, W, Dt, Ht, Wt, C, _p(j16), _p(s16))
+    d32 = torch.empty_like(t8)
+    d16 = torch.empty(t8.shape, dtype=BF, device=U.DEV)
+    call("u3d_nearest_sum_bwd_t8", _p(dg), _p(lz), _p(ly), _p(lx), N, D, H, W, Dt, Ht, Wt, C, _p(d32))
+    call("u3d_nearest_sum_bwd_t8_b16", _p(b16(dg)), _p(lz), _p(ly), _p(lx), N, D, H, W, Dt, Ht, Wt, C, _p(d16))
+    torch.cuda.synchronize()
+    assert same_bits(j16, j32.to(BF)) and same_bits(d16, d32.to(BF))
+    jd = j16.double()
+    assert torch.allclose(s16, torch.stack((jd.sum(dim=(1, 2, 3)), (jd * jd).sum(dim=(1, 2, 3))), dim=-1), rtol=1e-6, atol=1e-6)
+
+
+def test_conv1x1_and_head_b16():
+    torch.manual_seed(5)
+    N, V, Cin, Cout = 2, 700, 64, 128
+    x = dev(r16(torch.randn(N, V, Cin)))
+    w, b = dev(torch.randn(Cout, Cin) / 8), dev(torch.randn(Cout))
+    y32 = torch.empty((N, V, Cout), device=U.DEV)
+    y16 = torch.empty((N, V, Cout), dtype=BF, device=U.DEV)
+    s32, s16 = (torch.zeros((N, Cout, 2), dtype=torch.float64, device=U.DEV) for _ in range(2))
+    call("u3d_conv1x1_fwd", _p(x), _p(w), _p(b), _p(y32), N, V, Cin, Cout, _p(s32))
+    call("u3d_conv1x1_fwd_b16", _p(b16(x)), 0, _p(w), _p(b), _p(y16), N, V, Cin, Cout, _p(s16))
+    # the first block: fp32 network input (one channel) feeding a bf16 tensor
+    x1 = dev(torch.randn(N, V, 1))
+    w1, b1 = dev(torch.randn(Cout, 1)), dev(torch.randn(Cout))
+    z32 = torch.empty((N, V, Cout), device=U.DEV)
+    z16 = torch.empty((N, V, Cout), dtype=BF, device=U.DEV)
+    call("u3d_conv1x1_fwd", _p(x1), _p(w1), _p(b1), _p(z32), N, V, 1, Cout, None)
+    call("u3d_conv1x1_fwd_b16", _p(x1), 1, _p(w1), _p(b1), _p(z16), N, V, 1, Cout, None)
+    dy = dev(r16(torch.randn(N, V, Cout)))
+    dx32 = torch.empty_like(x)
+    dx16 = torch.empty(x.shape, dtype=BF, device=U.DEV)
+    a32, a16_ = (torch.zeros(Cout * Cin + Cout, dtype=torch.float64, device=U.DEV) for _ in range(2))
+    call("u3d_conv1x1_bwd", _p(dy), _p(x), _p(w), N, V, Cin, Cout, _p(dx32), _p(a32))
+    call("u3d_conv1x1_bwd_b16", _p(b16(dy)), _p(b16(x)), 0, _p(w), N, V, Cin, Cout, _p(dx16), _p(a16_))
+    b32, b16_ = (torch.zeros(Cout + Cout, dtype=torch.float64, device=U.DEV) for _ in range(2))
+    call("u3d_conv1x1_bwd", _p(dy), _p(x1), _p(w1), N, V, 1, Cout, None, _p(b32))
+    call("u3d_conv1x1_bwd_b16", _p(b16(dy)), _p(x1), 1, _p(w1), N, V, 1, Cout, None, _p(b16_))
+    torch.cuda.synchronize()
+    assert same_bits(y16, y32.to(BF)) and same_bits(z16, z32.to(BF)) and same_bits(dx16, dx32.to(BF))
+    yd = y16.double()
+    assert torch.allclose(s16, torch.stack((yd.sum(dim=1), (yd * yd).sum(dim=1)), dim=-1), rtol=1e-6, atol=1e-6)
+    assert torch.allclose(a16_, a32, rtol=1e-9, atol=1e-9) and torch.allclose(b16_, b32, rtol=1e-9, atol=1e-9)
+    # head
+    Co = 2
+    wh, bh = dev(torch.randn(Co, Cin) / 8), dev(torch.randn(Co))
+    l32, p32, l16, p16 = (torch.empty((N, Co, V), device=U.DEV) for _ in range(4))
+    call("u3d_conv1x1_head_fwd", _p(x), _p(wh), _p(bh), N, V, Cin, Co, 2, _p(l32), _p(p32))
+    call("u3d_conv1x1_head_fwd_b16", _p(b16(x)), _p(wh), _p(bh), N, V, Cin, Co, 2, _p(l16), _p(p16))
+    dl = dev(torch.randn(N, Co, V))
+    hx32 = torch.empty_like(x)
+    hx16 = torch.empty(x.shape, dtype=BF, device=U.DEV)
+    h32, h16 = (torch.zeros(Co * Cin + Co, dtype=torch.float64, device=U.DEV) for _ in range(2))
+    call("u3d_conv1x1_head_bwd", _p(dl), _p(x), _p(wh), N, V, Cin, Co, 1, _p(hx32), _p(h32))
+    call("u3d_conv1x1_head_bwd_b16", _p(dl), _p(b16(x)), _p(wh), N, V, Cin, Co, 1, _p(hx16), _p(h16))
+    torch.cuda.synchronize()
+    assert torch.equal(l16, l32) and torch.equal(p16, p32) and same_bits(hx16, hx32.to(BF)) and torch.allclose(h16, h32, rtol=1e-12)
+
+
+# ---- model level -----------------------------------------------------------------------------------------------------------------
+CFG = dict(name="ResidualUNet3D", in_channels=1, out_channels=1, f_maps=[64, 128, 256], num_groups=8, final_sigmoid=True)
+
+
+def _prep(extra, shape=(1, 1, 16, 32, 32)):
+    from pytorch3dunet_amd.unet3d.model import get_model
+
+    torch.manual_seed(21)
+    model = get_model(dict(CFG, **extra))
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if "groupnorm" in k:
+                p.add_(0.2 * torch.randn_like(p))
+    x = torch.randn(shape)
+    t = (torch.rand(shape) > 0.5).float()
+    return model, x, t
+
+
+def _step(model, x, t):
+    import unet3d_oracle as orc
+
+    model = model.to(U.DEV).train()
+    prof = nat.EventProfiler()
+    nat.profiler = prof
+    try:
+        _, logits = model(x.to(U.DEV), return_logits=True)
+        loss = orc.bce_dice_loss(logits, t.to(U.DEV))
+        model.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        nat.profiler = None
+    return logits.detach().cpu(), loss.item(), {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}, set(prof.summary())
+
+
+def test_model_with_bf16_activation_storage_against_the_storage_emulation():
+    import unet3d_oracle as orc
+
+    model, x, t = _prep(dict(compute_dtype="bf16", activation_dtype="bf16"))
+    assert model._get_engine().act_bf16
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    _, l32, _, g32 = orc.forward_backward(sd, x, t, 8, True, True, "bce_dice")
+    orc.BF16_OPERANDS = orc.BF16_STORAGE = True
+    try:
+        _, lem, _, gem = orc.forward_backward(sd, x, t, 8, True, True, "bce_dice")
+    finally:
+        orc.BF16_OPERANDS = orc.BF16_STORAGE = False
+    logits, loss, grads, names = _step(model, x, t)
+    b16 = {n for n in names if n.endswith("_b16")}
+    assert {"u3d_conv3d_bf16_ex_b16", "u3d_conv3d_wgrad_bf16_b16", "u3d_convtr3d_fwd_t8_b16", "u3d_convtr3d_dgrad_t8_b16",
+            "u3d_convtr3d_wgrad_t8_b16", "u3d_conv1x1_fwd_b16", "u3d_conv1x1_bwd_b16", "u3d_maxpool2_fwd_b16", "u3d_maxpool2_bwd_merge_b16",
+            "u3d_nearest_add_fwd_t8_b16", "u3d_nearest_sum_bwd_t8_b16", "u3d_gn_bwd_apply_b16", "u3d_conv1x1_head_fwd_b16",
+            "u3d_conv1x1_head_bwd_b16"} <= b16, names
+    # nothing of the fp32-storage family may have run beside them
+    assert not ({"u3d_conv3d_bf16_ex", "u3d_conv3d_wgrad_bf16", "u3d_gn_bwd_apply", "u3d_gn_bwd_apply_add", "u3d_maxpool2_fwd",
+                 "u3d_conv1x1_fwd", "u3d_conv3d", "u3d_conv3d_ex", "u3d_conv3d_wgrad"} & names), names
+    keys = list(g32)
+    cat = lambda d: torch.cat([d[k].flatten().double() for k in keys])  # noqa: E731
+    ours, em, ref = cat(grads), cat(gem), cat(g32)
+    rec = dict(test="bf16_storage_model", logits_vs_emu=orc.rel_err(logits, lem), logits_vs_fp32=orc.rel_err(logits, l32),
+               emu_vs_fp32_logits=orc.rel_err(lem, l32), grad_vs_emu=((ours - em).norm() / em.norm()).item(),
+               grad_vs_fp32=((ours - ref).norm() / ref.norm()).item(), emu_vs_fp32_grad=((em - ref).norm() / ref.norm()).item())
+    diag(**rec)
+    print(rec)
+    assert torch.isfinite(ours).all()
+    # closer to the emulation of its own arithmetic than that emulation is to fp32, and not farther from fp32 than it
+    assert rec["logits_vs_emu"] < 0.75 * rec["emu_vs_fp32_logits"] and rec["grad_vs_emu"] < rec["emu_vs_fp32_grad"], rec
+    assert rec["logits_vs_fp32"] < 1.25 * rec["emu_vs_fp32_logits"] + 1e-3 and rec["grad_vs_fp32"] < 1.15 * rec["emu_vs_fp32_grad"] + 1e-3, rec
+
+
+def test_bf16_storage_is_reproducible_composes_with_checkpointing_and_graphs_and_halves_the_tape():
+    res = {}
+    for tag, extra in (("plain", {}), ("ckpt", dict(checkpoint_encoders=True)), ("graph", dict(hip_graph=True))):
+        import gc
+
+        model, x, t = _prep(dict(compute_dtype="bf16", activation_dtype="bf16", **extra), shape=(1, 1, 24, 48, 48))
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        out = _step(model, x, t)
+        res[tag] = out + (torch.cuda.max_memory_allocated() - base,)
+        if tag == "plain":
+            again = _step(model, x, t)
+            assert torch.equal(out[0], again[0]) and all(torch.equal(out[2][k], again[2][k]) for k in out[2])  # run-to-run identical
+        del model
+    for tag in ("ckpt", "graph"):
+        assert torch.equal(res["plain"][0], res[tag][0]), tag
+        for k in res["plain"][2]:
+            assert torch.equal(res["plain"][2][k], res[tag][2][k]), (tag, k)
+    import gc
+
+    model, x, t = _prep(dict(compute_dtype="bf16"), shape=(1, 1, 24, 48, 48))
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    _step(model, x, t)
+    m32 = torch.cuda.max_memory_allocated() - base
+    diag(test="bf16_storage_peak", fp32_storage_mib=m32 / 2**20, bf16_storage_mib=res["plain"][4] / 2**20, with_ckpt_mib=res["ckpt"][4] / 2**20)
+    assert res["plain"][4] < 0.75 * m32, (res["plain"][4], m32)
+
+
+def test_activation_bf16_falls_back_with_a_warning_outside_its_envelope():
+    from pytorch3dunet_amd.unet3d.model import get_model
+
+    m = get_model(dict(CFG, f_maps=[32, 64], compute_dtype="bf16", activation_dtype="bf16")).to(U.DEV)
+    with pytest.warns(UserWarning, match="activation_dtype bf16 requested"):
+        eng = m._get_engine()
+    assert eng.bf16 and not eng.act_bf16
+    m2 = get_model(dict(CFG, compute_dtype="fp32", activation_dtype="bf16")).to(U.DEV)
+    with pytest.warns(UserWarning, match="compute_dtype is not bf16"):
+        assert not m2._get_engine().act_bf16

@@ -22,12 +22,13 @@ ap.add_argument("--levels", type=int, default=5)
 ap.add_argument("--patch", default="80,160,160")
 ap.add_argument("--bf16", action="store_true")
 ap.add_argument("--checkpoint", action="store_true")
+ap.add_argument("--act-bf16", action="store_true")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 model = get_model(dict(name=args.name, in_channels=1, out_channels=1, f_maps=args.f_maps, num_levels=args.levels, layer_order="gcr",
                        num_groups=8, final_sigmoid=True, compute_dtype="bf16" if args.bf16 else "fp32",
-                       checkpoint_encoders=args.checkpoint)).to(dev).train()
+                       checkpoint_encoders=args.checkpoint, activation_dtype="bf16" if args.act_bf16 else "fp32")).to(dev).train()
 D, H, W = (int(v) for v in args.patch.split(","))
 x = torch.randn(1, 1, D, H, W, device=dev)
 t = (torch.rand(1, 1, D, H, W, device=dev) > 0.5).float()
