@@ -1479,13 +1479,15 @@ class ResUNetEngine(UNet3DEngine):
         # self.slope / self.mask describe the BLOCK outputs (what pooling, joining and the head consume).
         order = getattr(model, "layer_order", "gcr")
         self.act2, self.slope2 = self.act, self.slope
+        self.act, self.slope = (ACT_LEAKY, 0.1) if "l" in order else ((ACT_ELU, 0.0) if "e" in order else (ACT_RELU, 0.0))
+        self.mask = 1 if self.act == ACT_RELU else 0
         self.lean_tape = self.checkpoint_encoders and os.environ.get("U3D_LEAN_TAPE", "1") != "0"
         self.adt = _F32
         if bool(getattr(model, "activation_bf16", False)):
             why = self._act_bf16_blocker(model, order)
             if why is None:
                 self.act_bf16, self.adt = True, torch.bfloat16
-            else:
+            elif getattr(model, "activation_dtype", "bf16") != "auto":
                 import warnings
 
                 warnings.warn(f"u3d: activation_dtype bf16 requested but {why}; activations stay fp32 in HBM", stacklevel=3)
@@ -1514,8 +1516,6 @@ class ResUNetEngine(UNet3DEngine):
         if fc.in_channels % 4 or g & (g - 1) or g > 64 or fc.out_channels > 4:
             return f"a head {fc.in_channels} -> {fc.out_channels} outside the vector kernels"
         return None
-        self.act, self.slope = (ACT_LEAKY, 0.1) if "l" in order else ((ACT_ELU, 0.0) if "e" in order else (ACT_RELU, 0.0))
-        self.mask = 1 if self.act == ACT_RELU else 0
 
     def _virtual_weights(self):
         return set()  # summation joining: every 3x3x3 conv reads one real tensor

@@ -99,10 +99,13 @@ class AbstractUNet(nn.Module):
         # `activation_dtype: bf16` / U3D_ACT_BF16=1 (with compute_dtype bf16, residual 'gcr' nets): activations and gradients between
         # kernels are stored as bf16 (engine.ResUNetEngine.act_bf16); anything else keeps fp32 storage
         if activation_dtype is None:
-            activation_dtype = "bf16" if os.environ.get("U3D_ACT_BF16", "0") == "1" else "fp32"
-        if str(activation_dtype).lower() not in ("fp32", "float32", "bf16", "bfloat16"):
-            raise ValueError(f"activation_dtype must be 'fp32' or 'bf16', got {activation_dtype!r}")
-        self.activation_bf16 = str(activation_dtype).lower() in ("bf16", "bfloat16")
+            activation_dtype = {"1": "bf16", "0": "fp32"}.get(os.environ.get("U3D_ACT_BF16", ""), "auto")
+        if str(activation_dtype).lower() not in ("auto", "fp32", "float32", "bf16", "bfloat16"):
+            raise ValueError(f"activation_dtype must be 'fp32', 'bf16' or 'auto', got {activation_dtype!r}")
+        # 'auto' (default): bf16 storage whenever compute_dtype is bf16 and the model lies inside the `_b16` kernels' envelope
+        # (decided by the executor: engine.ResUNetEngine._act_bf16_blocker), silently fp32 otherwise; 'bf16' warns when it cannot
+        self.activation_dtype = {"float32": "fp32", "bfloat16": "bf16"}.get(str(activation_dtype).lower(), str(activation_dtype).lower())
+        self.activation_bf16 = self.activation_dtype in ("bf16", "auto") and self.compute_bf16
         # `hip_graph: true` / U3D_GRAPH=1: training steps replay two captured hipGraphs per input shape (engine.GraphStep)
         if hip_graph is None:
             hip_graph = os.environ.get("U3D_GRAPH", "0") == "1"

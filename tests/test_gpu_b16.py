@@ -331,7 +331,7 @@ def test_bf16_storage_is_reproducible_composes_with_checkpointing_and_graphs_and
             assert torch.equal(res["plain"][2][k], res[tag][2][k]), (tag, k)
     import gc
 
-    model, x, t = _prep(dict(compute_dtype="bf16"), shape=(1, 1, 24, 48, 48))
+    model, x, t = _prep(dict(compute_dtype="bf16", activation_dtype="fp32"), shape=(1, 1, 24, 48, 48))
     gc.collect()
     torch.cuda.synchronize()
     torch.cuda.reset_peak_memory_stats()
@@ -349,6 +349,13 @@ def test_activation_bf16_falls_back_with_a_warning_outside_its_envelope():
     with pytest.warns(UserWarning, match="activation_dtype bf16 requested"):
         eng = m._get_engine()
     assert eng.bf16 and not eng.act_bf16
+    import warnings
+
     m2 = get_model(dict(CFG, compute_dtype="fp32", activation_dtype="bf16")).to(U.DEV)
-    with pytest.warns(UserWarning, match="compute_dtype is not bf16"):
-        assert not m2._get_engine().act_bf16
+    assert not m2._get_engine().act_bf16  # (bf16 storage belongs to the bf16 compute path)
+    # the default is 'auto': bf16 storage when the model qualifies, silently fp32 when it does not
+    assert get_model(dict(CFG, compute_dtype="bf16")).to(U.DEV)._get_engine().act_bf16
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert not get_model(dict(CFG, f_maps=[32, 64], compute_dtype="bf16")).to(U.DEV)._get_engine().act_bf16
+    assert not get_model(dict(CFG, compute_dtype="bf16", activation_dtype="fp32")).to(U.DEV)._get_engine().act_bf16

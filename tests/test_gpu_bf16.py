@@ -227,6 +227,7 @@ def _prep(cfg, shape, **extra):
     from pytorch3dunet_amd.unet3d.model import get_model
 
     torch.manual_seed(99)
+    extra.setdefault("activation_dtype", "fp32")  # this file pins the bf16-OPERAND kernels (fp32 tensors in HBM); bf16 storage: test_gpu_b16.py
     model = get_model(dict(cfg, **extra))
     with torch.no_grad():
         for k, p in model.named_parameters():
