@@ -173,6 +173,7 @@ def main():
     # u3d_conv3d_ex is u3d_conv3d with a scratch buffer (same kernels): one family
     FAMILY = {"u3d_conv3d_ex": "u3d_conv3d"}
     dominant = {"u3d_conv3d", "u3d_conv3d_ex"}
+    calls_per_step, fam_calls = 32, {"u3d_conv3d": 128}
     for w in range(args.warmup):
         if w == args.warmup - 1 and not args.no_roofline and rank == 0:
             # the last warm-up step finds the dominant MFMA family (HIP events around every call that declares FLOPs), so that the
@@ -183,12 +184,14 @@ def main():
             step()
             torch.cuda.synchronize()
             nat.profiler = None
-            fam_ms = {}
+            fam_ms, fam_calls = {}, {}
             for k, v in scout.summary().items():
                 fam_ms[FAMILY.get(k, k)] = fam_ms.get(FAMILY.get(k, k), 0.0) + v["ms"]
+                fam_calls[FAMILY.get(k, k)] = fam_calls.get(FAMILY.get(k, k), 0) + v["calls"]
             if fam_ms:
                 top = max(fam_ms, key=fam_ms.get)
                 dominant = {top} | {k for k, f in FAMILY.items() if f == top}
+                calls_per_step = fam_calls[top]
         else:
             step()
 
@@ -201,7 +204,10 @@ def main():
     if not args.no_roofline and rank == 0:
         # inside the timed region only the DOMINANT MFMA family is bracketed by HIP events (the `roofline` object describes that
         # family); every other entry point is timed in a few extra steps after it
-        prof = nat.EventProfiler(flops_only=True, only=None if os.environ.get("U3D_BENCH_BRACKET_ALL") == "1" else dominant)
+        # (its events are created HERE, before the clock starts: first-time event creation is 0.1-0.2 ms of host time each)
+        bracket_all = os.environ.get("U3D_BENCH_BRACKET_ALL") == "1"
+        prof = nat.EventProfiler(flops_only=True, only=None if bracket_all else dominant,
+                                 prealloc=2 * args.steps * ((sum(fam_calls.values()) if bracket_all else calls_per_step) + 4))
         nat.profiler = prof
     barrier()
     t0 = time.perf_counter()
