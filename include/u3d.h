@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define U3D_VERSION 113 /* 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16) */
+#define U3D_VERSION 114 /* 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16) */
 
 #define U3D_OK 0
 #define U3D_EINVAL (-1)  /* bad shape / argument */
@@ -512,6 +512,17 @@ int u3d_conv1x1_fwd_b16(int device, u3d_stream_t stream, const void* x, int x_is
                         int N, int64_t V, int Cin, int Cout, double* out_stats);
 int u3d_conv1x1_bwd_b16(int device, u3d_stream_t stream, const void* dy, const void* x, int x_is_f32, const float* w, int N,
                         int64_t V, int Cin, int Cout, void* dx, double* acc);
+/* ResNetBlock.conv1 (1x1x1, bias; reference buildingblocks.py:248-255) under bf16 storage on v_mfma_f32_32x32x16_bf16: the
+ * weights are rounded to bf16 like every MFMA operand of the bf16 path; x, y, dy, dx are bf16 (N, V, C) tensors.
+ * _supported: Cin, Cout powers of two in 64..512.  out_stats (N, Cout, 2) += (sum, sum of squares) of the STORED y.
+ * _bwd: dx (may be NULL) = dy W; dw (Cout, Cin) and db (Cout) are WRITTEN (fp32, fixed-order sums: run-to-run identical). */
+int u3d_conv1x1_mfma_b16_supported(int Cin, int Cout);
+int u3d_conv1x1_fwd_mfma_b16(int device, u3d_stream_t stream, const void* x, const float* w, const float* bias, void* y, int N,
+                             int64_t V, int Cin, int Cout, double* out_stats);
+long long u3d_conv1x1_bwd_mfma_b16_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
+int u3d_conv1x1_bwd_mfma_b16(int device, u3d_stream_t stream, const void* dy, const void* x, const float* w, int N, int D, int H,
+                             int W, int Cin, int Cout, void* dx, float* dw, float* db, float* workspace,
+                             long long workspace_floats);
 int u3d_maxpool2_fwd_b16(int device, u3d_stream_t stream, const void* x, int N, int D, int H, int W, int C, void* out,
                          uint8_t* argmax);
 int u3d_maxpool2_bwd_merge_b16(int device, u3d_stream_t stream, const void* dg, const void* pooled, const uint8_t* argmax,

@@ -251,8 +251,13 @@ __device__ __forceinline__ void conv_tile_epilogue(const bf16_conv_params& p, f3
 // ABL: timing-only ablation bits that attributed the loop's cost (1 no B loads, 2 no A reads, 4 no staging, 8 no barrier; results
 // in DESIGN.md 4.7).  Only ABL = 0 is instantiated.
 template <int NT, int ZW, int KS, int ABL = 0, typename T = float>
-__global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_params p) {
+__global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void conv3d_bf16_kernel(const bf16_conv_params p) {
     using G = tile_geom<ZW, KS>;
+    // The 64-channel 3x3x3 tile with the full B ring (9 slots, 6 taps ahead) needs 202 VGPRs: two blocks per CU.  With fragments
+    // only 2 taps ahead in a ring of 3 it fits 168 — THREE blocks per CU (LDS 46 KB each), and the third wave per SIMD hides more
+    // than the shorter lead exposes: config 4 19.5 -> 19.2 ms per step (same-box pairs, profiles/r03_cfg4_ab.txt)
+    constexpr bool SHORT = NT == 2 && ZW == 1 && KS == 3;
+    constexpr int B_RING = SHORT ? 3 : G::RING, B_DIST = SHORT ? 2 : G::BDIST;
     constexpr int HY = G::HY;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -386,11 +391,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
     // ring that runs across chunk boundaries, A fragments ADIST taps ahead (restarted per chunk: the LDS buffer changes), the next
     // chunk's halo items fetched at the start of a KS-tap part and written at its end; sched_barriers pin "issue the prefetches,
     // then the 2*ZW*NT MFMAs of the tap".  The last chunk prefetches a clamped (repeated) chunk instead of branching.
-    bf16x8 bq[G::RING][NT];
+    bf16x8 bq[B_RING][NT];
     if (cbeg < nch) {
         const bf16x8* wp0 = p.wpk + ((size_t)cbeg * G::NTAPS * ntiles + (size_t)nb * NT) * 64;  // wave-uniform base + lane
 #pragma unroll
-        for (int d = 0; d < G::BDIST; ++d)
+        for (int d = 0; d < B_DIST; ++d)
 #pragma unroll
             for (int j = 0; j < NT; ++j) bq[d][j] = wp0[((size_t)d * ntiles + j) * 64 + lane];
     }
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
                 const int tap = part * KS + t3;
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    if constexpr (!(ABL & 1)) bq[(tap + G::BDIST) % G::RING][j] = wp[((size_t)(tap + G::BDIST) * ntiles + j) * 64 + lane];
+                    if constexpr (!(ABL & 1)) bq[(tap + B_DIST) % B_RING][j] = wp[((size_t)(tap + B_DIST) * ntiles + j) * 64 + lane];
                 if (!(ABL & 2) && tap + G::ADIST < G::NTAPS) {
                     const int nt_ = tap + G::ADIST, tzz = nt_ / (KS * KS), tyy = (nt_ / KS) % KS, txx = nt_ % KS;
 #pragma unroll
@@ -435,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_kernel(const bf16_conv_par
                 for (int m = 0; m < G::MT; ++m)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[tap % (G::ADIST + 1)][m], bq[tap % G::RING][j], acc[m][j], 0, 0, 0);
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[tap % (G::ADIST + 1)][m], bq[tap % B_RING][j], acc[m][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -1379,6 +1384,286 @@ static int convtr3d_wgrad_t8_impl(int device, u3d_stream_t stream, const float* 
     return 0;
 }
 
+
+namespace {
+
+// =====================================================================================================================
+// 1x1x1 convolution WITH bias (ResNetBlock.conv1, buildingblocks.py:248-255) under bf16 activation storage, on
+// v_mfma_f32_32x32x16_bf16.  A plain GEMM per sample, out[v][n] = sum_k in[v][k] * B[k][n] (+ bias[n]):
+//   forward        in = block input (V x Cin),  B[k][n] = w[n][k]   (w: (Cout, Cin) fp32, rounded to bf16 like every MFMA operand)
+//   data gradient  in = dr (V x Cout),          B[k][n] = w[k][n]
+// (the fp32 gather-GEMM of csrc/u3d_res.hip ran these at 13 TF — 1.5 ms of config 4's 20.4 ms step for 25 GFLOP; here they are
+// bandwidth: every tensor once).  A wave keeps its B fragments (KS k-steps x NTW n-tiles) in registers and walks 32-voxel M-tiles
+// persistently: per tile KS 16-byte loads of A straight from global memory (a lane reads 8 channels of its voxel), KS x NTW MFMAs,
+// and an epilogue through a wave-private LDS region ([voxel][channel] bf16: 16-byte stores instead of 2-byte ones), with the
+// per-(sample, channel) statistics of the stored values carried in registers across tiles.
+struct c1_params {
+    const __bf16* in;
+    const float* w;
+    const float* bias;  // [Nc] or null
+    __bf16* out;
+    double* stats;      // [N][Nc][2] += (sum, sum of squares) of the stored values, or null
+    int N;
+    long long V;
+    int K, Nc;
+    long long wsk, wsn;  // B[k][n] = w[k * wsk + n * wsn]
+};
+
+template <int KS, int NTW>
+__global__ __launch_bounds__(256, (KS * NTW > 16 ? 1 : NTW == 4 ? 2 : 3)) void conv1x1_bf16_kernel(const c1_params p) {
+    constexpr int RSB = NTW * 64 + 16;  // bytes per voxel row of the epilogue region
+    constexpr int K_ = KS * 16, NT_ = NTW * 32, BROW = K_ * 2 + 16;  // the block's weight tile in LDS: [n][k] bf16, padded rows
+    constexpr int LDS_BYTES = (4 * 32 * RSB > NT_ * BROW) ? 4 * 32 * RSB : NT_ * BROW;
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    __shared__ float red[4][NTW * 32][2];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, col = lane & 31, kh = lane >> 5;
+    const int n = blockIdx.z, nb0 = blockIdx.y * NTW * 32;
+    // ---- the weight tile once per block: coalesced float4 reads along whichever index is contiguous in memory, bf16 into LDS,
+    // then every wave takes its KS x NTW fragments with 16-byte LDS reads (the region is reused by the epilogue afterwards)
+    const bool wal = ((uintptr_t)p.w & 15) == 0;  // (a parameter inside a flat buffer need not be 16-byte aligned)
+    auto ld4 = [&](const float* src) {
+        if (wal) return *reinterpret_cast<const f32x4*>(src);
+        return f32x4{src[0], src[1], src[2], src[3]};
+    };
+    if (p.wsk == 1) {  // forward: w[n][k], k contiguous
+        for (int i = t; i < NT_ * (K_ / 4); i += 256) {
+            const int nn = i / (K_ / 4), k4 = i - nn * (K_ / 4);
+            const f32x4 v = ld4(p.w + (size_t)(nb0 + nn) * p.wsn + 4 * k4);
+            const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            *reinterpret_cast<bf16x4*>(lds + nn * BROW + k4 * 8) = o;
+        }
+    } else {  // data gradient: w[k][n], n contiguous
+        for (int i = t; i < K_ * (NT_ / 4); i += 256) {
+            const int kk = i / (NT_ / 4), n4 = i - kk * (NT_ / 4);
+            const f32x4 v = ld4(p.w + (size_t)kk * p.wsk + nb0 + 4 * n4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) *reinterpret_cast<__bf16*>(lds + (4 * n4 + e) * BROW + kk * 2) = (__bf16)v[e];
+        }
+    }
+    __syncthreads();
+    bf16x8 B[KS][NTW];
+#pragma unroll
+    for (int s_ = 0; s_ < KS; ++s_)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) B[s_][j] = *reinterpret_cast<const bf16x8*>(lds + (j * 32 + col) * BROW + (16 * s_ + 8 * kh) * 2);
+    __syncthreads();
+    float bias[NTW], s1[NTW], s2[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        bias[j] = p.bias ? p.bias[nb0 + j * 32 + col] : 0.f;
+        s1[j] = s2[j] = 0.f;
+    }
+    const __bf16* in = p.in + (size_t)n * p.V * p.K + 8 * kh;
+    __bf16* out = p.out + (size_t)n * p.V * p.Nc + nb0;
+    char* reg = lds + w * 32 * RSB;
+    const long long mtiles = (p.V + 31) / 32;
+    constexpr int RING = KS < 4 ? KS : 4;
+    bf16x8 a[RING];
+    auto fetch = [&](long long mt_) {  // the first RING k-steps of tile mt_ (issued before the previous tile's epilogue)
+        const long long v_ = mt_ * 32 + col;
+        const __bf16* arow_ = in + (size_t)(v_ < p.V ? v_ : 0) * p.K;
+#pragma unroll
+        for (int s_ = 0; s_ < RING; ++s_) a[s_] = *reinterpret_cast<const bf16x8*>(arow_ + 16 * s_);
+    };
+    const long long mt0 = (long long)blockIdx.x * 4 + w, mstep = (long long)gridDim.x * 4;
+    if (mt0 < mtiles) fetch(mt0);
+    for (long long mt = mt0; mt < mtiles; mt += mstep) {
+        const long long v = mt * 32 + col;
+        const bool vok = v < p.V;
+        const __bf16* arow = in + (size_t)(vok ? v : 0) * p.K;
+        f32x16 acc[NTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+            bf16x8 cur = a[s_ & 3];
+            if (!vok) cur = bf16x8{};
+            if (s_ + 4 < KS) a[s_ & 3] = *reinterpret_cast<const bf16x8*>(arow + 16 * (s_ + 4));
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, B[s_][j], acc[j], 0, 0, 0);
+        }
+        if (mt + mstep < mtiles) fetch(mt + mstep);
+        // C/D layout: column = lane & 31 (channel), row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (voxel of the M-tile)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * kh;
+                const __bf16 vb = (__bf16)(acc[j][e] + bias[j]);
+                *reinterpret_cast<__bf16*>(reg + row * RSB + (j * 32 + col) * 2) = vb;
+                if (mt * 32 + row < p.V) {
+                    const float r = (float)vb;  // (statistics describe the STORED tensor)
+                    s1[j] += r;
+                    s2[j] = fmaf(r, r, s2[j]);
+                }
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 2 * NTW; ++i) {
+            const int item = lane + 64 * i, row = item / (NTW * 4), o = item - row * (NTW * 4);
+            if (mt * 32 + row < p.V)
+                *reinterpret_cast<bf16x8*>(out + (size_t)(mt * 32 + row) * p.Nc + o * 8) = *reinterpret_cast<const bf16x8*>(reg + row * RSB + o * 16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (p.stats == nullptr) return;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        s1[j] += __shfl_xor(s1[j], 32);
+        s2[j] += __shfl_xor(s2[j], 32);
+        if (kh == 0) {
+            red[w][j * 32 + col][0] = s1[j];
+            red[w][j * 32 + col][1] = s2[j];
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < NTW * 32 * 2; i += 256) {
+        const int ch = i >> 1, which = i & 1;
+        const double sum = (double)red[0][ch][which] + (double)red[1][ch][which] + (double)red[2][ch][which] + (double)red[3][ch][which];
+        u3d_atomic_add_f64(p.stats + ((size_t)n * p.Nc + nb0 + ch) * 2 + which, sum);
+    }
+}
+
+static bool c1_mfma_shape(int K, int Nc) { return K % 16 == 0 && K >= 64 && K <= 512 && (K & (K - 1)) == 0 && Nc % 32 == 0 && Nc >= 32; }
+
+static int launch_conv1x1_bf16(const c1_params& p, hipStream_t st) {
+    const int KS = p.K / 16, nt = p.Nc / 32;
+    // B fragments in registers: KS * NTW * 4 VGPRs — at most 64 (3 waves per SIMD: a streaming kernel lives on loads in flight)
+    int ntw = KS >= 16 ? 1 : 16 / KS;
+    while (ntw > 1 && nt % ntw != 0) ntw >>= 1;
+    const int gy = nt / ntw;
+    long long gx = (p.V + 255) / 256;  // at least two M-tiles per wave (the next tile's loads are issued before the epilogue)
+    const long long cap = 2048 / ((long long)gy * p.N) > 8 ? 2048 / ((long long)gy * p.N) : 8;
+    if (gx > cap) gx = cap;
+    if (gx > 8) gx &= ~7LL;  // blocks (x, y) and (x, y + 1) read the same voxels: linear ids a multiple of 8 apart = the same XCD's L2
+    const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)p.N);
+#define U3D_C1(KS_, NTW_)                                                                                    \
+    if (KS == KS_ && ntw == NTW_) {                                                                          \
+        hipLaunchKernelGGL((conv1x1_bf16_kernel<KS_, NTW_>), grid, dim3(256), 0, st, p);                     \
+        U3D_LAUNCH_CHECK();                                                                                  \
+        return 0;                                                                                            \
+    }
+    U3D_C1(4, 4) U3D_C1(4, 2) U3D_C1(4, 1) U3D_C1(8, 2) U3D_C1(8, 1) U3D_C1(16, 1) U3D_C1(32, 1)
+#undef U3D_C1
+    return u3d_set_err(U3D_EINVAL, "u3d_conv1x1_bf16: no kernel for K = %d, Nc = %d", p.K, p.Nc);
+}
+
+// dw[co][ci] = sum over splits (fixed order) of the 1-tap partial sums ws[split][pair][ci 32][co 64]
+__global__ void wgrad_k1_reduce_kernel(const float* __restrict__ ws, int S, int C, int K, float* __restrict__ dw) {
+    const int pco = K >> 6, P = (C >> 5) * pco;
+    const long long total = (long long)C * K;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % K), ci = (int)(i / K);
+        const int pair = (ci >> 5) * pco + (co >> 6);
+        const size_t off = (size_t)pair * 2048 + (ci & 31) * 64 + (co & 63);
+        double sum = 0.0;
+        for (int s_ = 0; s_ < S; ++s_) sum += (double)ws[(size_t)s_ * P * 2048 + off];
+        dw[(size_t)co * C + ci] = (float)sum;
+    }
+}
+
+// db[co] = sum_v dy[v][co]: per-block partial sums (fixed order inside the block), then one fixed-order pass over the blocks
+__global__ __launch_bounds__(256) void colsum_b16_partial_kernel(const __bf16* __restrict__ dy, long long rows, int K, float* __restrict__ part) {
+    extern __shared__ float cred[];  // [rws][K]
+    const int Q = K >> 3, rws = 256 / Q;
+    const int t = threadIdx.x, q = t % Q, row = t / Q;
+    float s_[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (row < rws)
+        for (long long v = (long long)blockIdx.x * rws + row; v < rows; v += (long long)gridDim.x * rws) {
+            const bf16x8 d = *reinterpret_cast<const bf16x8*>(dy + (size_t)v * K + 8 * q);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s_[e] += (float)d[e];
+        }
+    if (row < rws) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cred[row * K + 8 * q + e] = s_[e];
+    }
+    __syncthreads();
+    for (int i = t; i < K; i += 256) {
+        float sum = 0.f;
+        for (int r = 0; r < rws; ++r) sum += cred[r * K + i];
+        part[(size_t)blockIdx.x * K + i] = sum;
+    }
+}
+// block = 16 channels x 16 row groups (a single thread walking all partial rows measured 60 us: 256 dependent loads)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int B, int K, float* __restrict__ db) {
+    __shared__ double red[16][17];
+    const int t = threadIdx.x, cl = t & 15, g = t >> 4, c = blockIdx.x * 16 + cl;
+    double sum = 0.0;
+    if (c < K)
+        for (int b = g; b < B; b += 16) sum += (double)part[(size_t)b * K + c];
+    red[g][cl] = sum;
+    __syncthreads();
+    if (t < 16 && c < K) {
+        double tot = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tot += red[i][t];
+        db[c] = (float)tot;
+    }
+}
+
+}  // namespace
+
+extern "C" int u3d_conv1x1_mfma_b16_supported(int Cin, int Cout) {
+    return (c1_mfma_shape(Cin, Cout) && c1_mfma_shape(Cout, Cin) && Cin % 32 == 0 && Cout % 64 == 0) ? 1 : 0;
+}
+
+extern "C" int u3d_conv1x1_fwd_mfma_b16(int device, u3d_stream_t stream, const void* x, const float* w, const float* bias, void* y, int N,
+                                        int64_t V, int Cin, int Cout, double* out_stats) {
+    U3D_ENTER(device);
+    U3D_REQUIRE(x && w && y && N > 0 && V > 0 && c1_mfma_shape(Cin, Cout) && (((uintptr_t)x | (uintptr_t)y) & 15) == 0,
+                "u3d_conv1x1_fwd_mfma_b16: bad argument (Cin %d, Cout %d)", Cin, Cout);
+    c1_params p{(const __bf16*)x, w, bias, (__bf16*)y, out_stats, N, (long long)V, Cin, Cout, 1, Cin};
+    return launch_conv1x1_bf16(p, (hipStream_t)stream);
+}
+
+extern "C" long long u3d_conv1x1_bwd_mfma_b16_workspace_floats(int N, int D, int H, int W, int Cin, int Cout) {
+    if (!u3d_conv1x1_mfma_b16_supported(Cin, Cout) || N <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    const wgrad_plan q = plan_wgrad(N, D, H, W, Cin, Cout);
+    return (long long)q.S * q.P * 2048 + 256LL * Cout;
+}
+
+// dx (optional) = dy W;  dw (Cout, Cin) fp32 and db (Cout) fp32 written directly (fixed-order reductions: run-to-run identical)
+extern "C" int u3d_conv1x1_bwd_mfma_b16(int device, u3d_stream_t stream, const void* dy, const void* x, const float* w, int N, int D, int H,
+                                        int W, int Cin, int Cout, void* dx, float* dw, float* db, float* workspace,
+                                        long long workspace_floats) {
+    U3D_ENTER(device);
+    U3D_REQUIRE(dy && x && w && dw && db && N > 0 && D > 0 && H > 0 && W > 0 && u3d_conv1x1_mfma_b16_supported(Cin, Cout) &&
+                    (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0,
+                "u3d_conv1x1_bwd_mfma_b16: bad argument (Cin %d, Cout %d)", Cin, Cout);
+    const wgrad_plan q = plan_wgrad(N, D, H, W, Cin, Cout);
+    const long long need = (long long)q.S * q.P * 2048 + 256LL * Cout;
+    if (!workspace || workspace_floats < need)
+        return u3d_set_err(U3D_EWORKSPACE, "u3d_conv1x1_bwd_mfma_b16: workspace of %lld floats needed, %lld given", need, workspace_floats);
+    hipStream_t st = (hipStream_t)stream;
+    const long long V = (long long)D * H * W;
+    if (dx) {
+        c1_params p{(const __bf16*)dy, w, nullptr, (__bf16*)dx, nullptr, N, V, Cout, Cin, Cin, 1};
+        if (int e = launch_conv1x1_bf16(p, st)) return e;
+    }
+    // weight gradient: the transposed-read kernel of the 3x3x3 convolutions with ONE tap
+    bf16_wgrad_params g{(const float*)x, nullptr, (const float*)dy, workspace, N, D, H, W, Cin, Cout, 0, q.tz, q.ty, q.tx, q.tiles, q.per_block,
+                        Cout / 64, 1};
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_bf16_kernel<1, __bf16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * wg_geom<1>::LDS));
+    hipLaunchKernelGGL((conv3d_wgrad_bf16_kernel<1, __bf16>), dim3((unsigned)(q.S * q.P)), dim3(512), 2 * wg_geom<1>::LDS, st, g);
+    U3D_LAUNCH_CHECK();
+    long long rb = ((long long)Cin * Cout + 255) / 256;
+    hipLaunchKernelGGL(wgrad_k1_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, workspace, q.S, Cin, Cout, dw);
+    U3D_LAUNCH_CHECK();
+    float* part = workspace + (long long)q.S * q.P * 2048;
+    const int rws = 256 / (Cout / 8);
+    hipLaunchKernelGGL(colsum_b16_partial_kernel, dim3(256), dim3(256), (size_t)rws * Cout * sizeof(float), st, (const __bf16*)dy, (long long)N * V,
+                       Cout, part);
+    U3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((Cout + 15) / 16)), dim3(256), 0, st, part, 256, Cout, db);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
 
 // =====================================================================================================================
 // FP32 convolution on the bf16 matrix pipe ("split fp32", opt-in: compute_dtype 'fp32_split').

@@ -1541,7 +1541,10 @@ class ResUNetEngine(UNet3DEngine):
             r = _empty((N, D, H, W, Cout), dtype=self.adt, device=dev)
             r_st = pool.take(N * Cout * 2)
             w1 = conv1.weight.detach().view(Cout, Cin)
-            if self.act_bf16:  # (the first block reads the fp32 network input)
+            if self.act_bf16 and x_in.dtype != _F32 and nat.get_lib().u3d_conv1x1_mfma_b16_supported(Cin, Cout):
+                nat.call("u3d_conv1x1_fwd_mfma_b16", dev.index, _stream(dev), _p(x_in), _p(w1), _p(conv1.bias.detach()), _p(r), N,
+                         D * H * W, Cin, Cout, _p(r_st), flops=2.0 * Cin * Cout * N * D * H * W)
+            elif self.act_bf16:  # (the first block reads the fp32 network input)
                 nat.call("u3d_conv1x1_fwd_b16", dev.index, _stream(dev), _p(x_in), 1 if x_in.dtype == _F32 else 0, _p(w1),
                          _p(conv1.bias.detach()), _p(r), N, D * H * W, Cin, Cout, _p(r_st), flops=2.0 * Cin * Cout * N * D * H * W)
             else:
@@ -1763,8 +1766,18 @@ class ResUNetEngine(UNet3DEngine):
         c1 = rec.conv1
         Cout_, Cin_ = c1.weight.shape[0], c1.weight.shape[1]
         xin = rec.x_in
-        acc = pool.take(Cout_ * Cin_ + Cout_)
         dxin = _empty(xin.shape, dtype=dr.dtype, device=dev) if need_dx else None
+        jw, jb = self._pindex[id(c1.weight)], self._pindex[id(c1.bias)]
+        assert self.poffs[jb] == self.poffs[jw] + Cout_ * Cin_
+        if self.act_bf16 and xin.dtype != _F32 and nat.get_lib().u3d_conv1x1_mfma_b16_supported(Cin_, Cout_):
+            Nn, Dd, Hh, Ww = xin.shape[:4]
+            need = nat.get_lib().u3d_conv1x1_bwd_mfma_b16_workspace_floats(Nn, Dd, Hh, Ww, Cin_, Cout_)
+            ws = cx.ensure_ws(need)
+            nat.call("u3d_conv1x1_bwd_mfma_b16", dev.index, _stream(dev), _p(dr), _p(xin), _p(c1.weight.detach().view(Cout_, Cin_)),
+                     Nn, Dd, Hh, Ww, Cin_, Cout_, _p(dxin), _p(gview(jw)), _p(gview(jb)), _p(ws), ws.numel(),
+                     flops=(4.0 if need_dx else 2.0) * Cin_ * Cout_ * (xin.numel() // Cin_))
+            return dxin
+        acc = pool.take(Cout_ * Cin_ + Cout_)
         if self.act_bf16:
             nat.call("u3d_conv1x1_bwd_b16", dev.index, _stream(dev), _p(dr), _p(xin), 1 if xin.dtype == _F32 else 0,
                      _p(c1.weight.detach().view(Cout_, Cin_)), xin.shape[0], xin.numel() // (xin.shape[0] * Cin_), Cin_, Cout_,
@@ -1773,8 +1786,6 @@ class ResUNetEngine(UNet3DEngine):
             nat.call("u3d_conv1x1_bwd", dev.index, _stream(dev), _p(dr), _p(xin), _p(c1.weight.detach().view(Cout_, Cin_)),
                      xin.shape[0], xin.numel() // (xin.shape[0] * Cin_), Cin_, Cout_, _p(dxin), _p(acc),
                      flops=(4.0 if need_dx else 2.0) * Cin_ * Cout_ * (xin.numel() // Cin_))
-        jw, jb = self._pindex[id(c1.weight)], self._pindex[id(c1.bias)]
-        assert self.poffs[jb] == self.poffs[jw] + Cout_ * Cin_
         nat.call("u3d_cvt_f64_f32", dev.index, _stream(dev), _p(acc), _p(gview(jw)), Cout_ * Cin_ + Cout_)
         return dxin
 

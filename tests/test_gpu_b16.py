@@ -243,6 +243,69 @@ def test_conv1x1_and_head_b16():
     assert torch.equal(l16, l32) and torch.equal(p16, p32) and same_bits(hx16, hx32.to(BF)) and torch.allclose(h16, h32, rtol=1e-12)
 
 
+@pytest.mark.parametrize("dims,Cin,Cout", [((2, 3, 7, 11), 64, 128), ((1, 8, 16, 16), 128, 64), ((1, 2, 5, 9), 256, 512),
+                                           ((2, 1, 3, 50), 512, 64), ((1, 16, 32, 32), 64, 64)])
+def test_conv1x1_on_the_bf16_matrix_pipe(dims, Cin, Cout):
+    """ResNetBlock.conv1 under bf16 storage (u3d_conv1x1_*_mfma_b16): bf16 x bf16 products are exact in fp32, so the only freedom
+    against a float64 evaluation with the bf16-rounded weight is the fp32 accumulation order — a last-bit difference before the
+    final rounding to bf16"""
+    torch.manual_seed(11)
+    lib = nat.get_lib()
+    assert lib.u3d_conv1x1_mfma_b16_supported(Cin, Cout) == 1
+    assert lib.u3d_conv1x1_mfma_b16_supported(1, Cout) == 0 and lib.u3d_conv1x1_mfma_b16_supported(1024, 64) == 0
+    N, D, H, W = dims
+    V = D * H * W
+    x = dev(r16(torch.randn(N, V, Cin)))
+    dy = dev(r16(torch.randn(N, V, Cout)))
+    w, b = dev(torch.randn(Cout, Cin) / 8), dev(torch.randn(Cout))
+    if Cin == 512:  # a parameter inside a flat buffer need not be 16-byte aligned
+        wbuf = torch.empty(Cout * Cin + 1, device=U.DEV)
+        wbuf[1:].copy_(w.view(-1))
+        w = wbuf[1:].view(Cout, Cin)
+        assert w.data_ptr() % 16 == 4
+    xb, dyb = b16(x), b16(dy)
+    wr = r16(w).double()
+    y_ref = x.double() @ wr.t() + b.double()
+    dx_ref = dy.double() @ wr
+    dw_ref = torch.einsum("nvo,nvi->oi", dy.double(), x.double())
+    db_ref = dy.double().sum(dim=(0, 1))
+    outs = []
+    need = lib.u3d_conv1x1_bwd_mfma_b16_workspace_floats(N, D, H, W, Cin, Cout)
+    assert need > 0
+    for _ in range(2):
+        y = torch.empty((N, V, Cout), dtype=BF, device=U.DEV)
+        st = torch.zeros((N, Cout, 2), dtype=torch.float64, device=U.DEV)
+        dx = torch.empty((N, V, Cin), dtype=BF, device=U.DEV)
+        dw = torch.full((Cout, Cin), float("nan"), device=U.DEV)
+        db = torch.full((Cout,), float("nan"), device=U.DEV)
+        ws = torch.empty(need, device=U.DEV)
+        call("u3d_conv1x1_fwd_mfma_b16", _p(xb), _p(w), _p(b), _p(y), N, V, Cin, Cout, _p(st))
+        call("u3d_conv1x1_bwd_mfma_b16", _p(dyb), _p(xb), _p(w), N, D, H, W, Cin, Cout, _p(dx), _p(dw), _p(db), _p(ws), need)
+        torch.cuda.synchronize()
+        outs.append((y, st, dx, dw, db))
+    for a_, b_ in zip(*outs):  # fixed-order reductions (the statistics are float64 atomics of per-block sums: last bits may move)
+        if a_.dtype == torch.float64:
+            assert torch.allclose(a_, b_, rtol=1e-12, atol=1e-9)
+        else:
+            assert torch.equal(a_, b_)
+    y, st, dx, dw, db = outs[0]
+    for got, ref in ((y, y_ref), (dx, dx_ref)):
+        d = (got.double() - r16(ref.float()).double()).abs()
+        assert float((d > 0).double().mean()) < 2e-3, float((d > 0).double().mean())
+        assert float((d / ref.abs().clamp_min(1e-2)).max()) < 2.0 ** -7
+    yd = y.double()
+    assert torch.allclose(st, torch.stack((yd.sum(dim=1), (yd * yd).sum(dim=1)), dim=-1), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(dw.double(), dw_ref, rtol=1e-4, atol=1e-4 * float(dw_ref.abs().max()))
+    assert torch.allclose(db.double(), db_ref, rtol=1e-4, atol=1e-4 * float(db_ref.abs().max()))
+    # the data gradient is optional (a block whose input needs no gradient)
+    dw2 = torch.empty_like(dw)
+    call("u3d_conv1x1_bwd_mfma_b16", _p(dyb), _p(xb), _p(w), N, D, H, W, Cin, Cout, None, _p(dw2), _p(db), _p(ws), need)
+    torch.cuda.synchronize()
+    assert torch.equal(dw2, dw)
+    with pytest.raises(nat.U3DError, match="workspace"):
+        call("u3d_conv1x1_bwd_mfma_b16", _p(dyb), _p(xb), _p(w), N, D, H, W, Cin, Cout, None, _p(dw2), _p(db), _p(ws), 16)
+
+
 # ---- model level -----------------------------------------------------------------------------------------------------------------
 CFG = dict(name="ResidualUNet3D", in_channels=1, out_channels=1, f_maps=[64, 128, 256], num_groups=8, final_sigmoid=True)
 
