@@ -20,6 +20,29 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// One staged bf16 item (8 channels of a halo voxel): GroupNorm affine in fp32, back to bf16, zero outside the volume (the padding
+// applies AFTER the affine).  Written on dword pairs so that it compiles to 8 unpack + 4 v_pk_fma_f32 + 4 v_cvt_pk_bf16_f32 + 4
+// v_and (20 VALU; the element-wise form cost ~50: single-source conversions, v_perm repacking, a select per element).
+__device__ __forceinline__ bf16x8 u3d_stage_b16(const bf16x8& v, bool has_aff, bool ok, const f32x4& a0, const f32x4& b0, const f32x4& a1,
+                                                const f32x4& b1) {
+    const u32x4 raw = __builtin_bit_cast(u32x4, v);
+    u32x4 o = raw;
+    if (has_aff) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x2 x = {__builtin_bit_cast(float, raw[e] << 16), __builtin_bit_cast(float, raw[e] & 0xffff0000u)};
+            const f32x2 a = e < 2 ? f32x2{a0[2 * e], a0[2 * e + 1]} : f32x2{a1[2 * e - 4], a1[2 * e - 3]};
+            const f32x2 b = e < 2 ? f32x2{b0[2 * e], b0[2 * e + 1]} : f32x2{b1[2 * e - 4], b1[2 * e - 3]};
+            o[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(__builtin_elementwise_fma(x, a, b), bf16x2));
+        }
+    }
+    const unsigned m = ok ? 0xffffffffu : 0u;
+    return __builtin_bit_cast(bf16x8, u32x4{o[0] & m, o[1] & m, o[2] & m, o[3] & m});
+}
 
 extern int g_u3d_tune[16];  // csrc/u3d_conv.hip: run-time A/B knobs (u3d_set_tuning); results never change
 
@@ -113,73 +136,104 @@ __device__ __forceinline__ void conv_tile_epilogue(const bf16_conv_params& p, f3
         // residual / mask / ReLU / rounding / statistics happen in between, in the accumulator layout, on 2-byte LDS accesses.
         constexpr int RSB = NT * 64 + 16;            // bytes per voxel row (+16: the two half-waves' rows land on different banks)
         constexpr int OCT = NT * 4;                  // 16-byte items per voxel
-        constexpr int NITEM = 64 * G::TZ * OCT / 256;  // items per thread (the tile has 64 * TZ voxels)
+        constexpr int VPK = 256 / OCT;               // voxels per round of 256 items (32 or 64: divides a z-plane of 64)
+        constexpr int NITEM = 64 * G::TZ / VPK;      // items per thread (the tile has 64 * TZ voxels)
         const int K = p.K;
         T* yout = reinterpret_cast<T*>(p.y);
-        auto item_addr = [&](int k, int& lds_off, size_t& goff) {  // item t + 256 k -> LDS byte offset, global element offset, inside?
-            const int item = t + 256 * k;
-            const int v = item / OCT, o = item - v * OCT;
-            const int zl = v >> 6, yl = (v >> 3) & 7, xl = v & 7;
-            const int z = z0 + zl, y = y0 + yl, xx = x0 + xl;
-            lds_off = v * RSB + o * 16;
-            goff = ((((size_t)n * p.D + z) * p.H + y) * p.W + xx) * K + (size_t)nb * NT * 32 + o * 8;
-            return z < p.D && y < p.H && xx < p.W;
+        // item t + 256 k = channel octet o of voxel v0 + VPK k: everything that depends on k is a compile-time multiple of two strides
+        // (this epilogue was ~1200 of the ~3300 VALU instructions a 64-channel tile executed)
+        const int v0 = t / OCT, o = t - v0 * OCT, yv = v0 >> 3, xv = v0 & 7;
+        const size_t sY = (size_t)p.W * K, sZ = (size_t)p.H * sY;
+        const size_t gbase = ((((size_t)n * p.D + z0) * p.H + y0 + yv) * p.W + x0 + xv) * K + (size_t)nb * NT * 32 + o * 8;
+        const int l0 = v0 * RSB + o * 16;
+        const bool full = z0 + G::TZ <= p.D && y0 + 8 <= p.H && x0 + 8 <= p.W;
+        auto item_in = [&](int k) {
+            const int zk = (VPK * k) >> 6, yk = ((VPK * k) & 63) >> 3;
+            return full || (z0 + zk < p.D && y0 + yk + yv < p.H && x0 + xv < p.W);
         };
+        auto item_goff = [&](int k) { return gbase + (size_t)((VPK * k) >> 6) * sZ + (size_t)(((VPK * k) & 63) >> 3) * sY; };
         __syncthreads();  // every wave has left the k-loop: the halo buffers are free
         if (side) {
             bf16x8 sv8[NITEM];
 #pragma unroll
             for (int k = 0; k < NITEM; ++k) {
-                int lo_;
-                size_t go;
                 sv8[k] = bf16x8{};
-                if (item_addr(k, lo_, go)) sv8[k] = *reinterpret_cast<const bf16x8*>(side + go);
+                if (item_in(k)) sv8[k] = *reinterpret_cast<const bf16x8*>(side + item_goff(k));
             }
 #pragma unroll
-            for (int k = 0; k < NITEM; ++k) {
-                int lo_;
-                size_t go;
-                item_addr(k, lo_, go);
-                *reinterpret_cast<bf16x8*>(lds + lo_) = sv8[k];
-            }
+            for (int k = 0; k < NITEM; ++k) *reinterpret_cast<bf16x8*>(lds + l0 + VPK * k * RSB) = sv8[k];
             __syncthreads();
         }
+        // ---- in the accumulator layout, two rows (e, e + 1: neighbours in y) at a time: packed add / convert / statistics.
+        // SIDE: 0 none, 1 residual (added), 2 ReLU mask of the tensor this gradient flows into, 3 gx (GroupNorm-backward sums)
+        char* const cb = lds + ((w * ZW * 8) * 8 + half) * RSB + col * 2;
+        const float lowest = p.relu ? 0.f : -__builtin_inff();
+        f32x2 q1[NT], q2[NT];
 #pragma unroll
-        for (int m = 0; m < G::MT; ++m) {
-            const int zl = w * ZW + (m >> 1);
+        for (int j = 0; j < NT; ++j) q1[j] = q2[j] = f32x2{0.f, 0.f};
+        auto elements = [&](auto SIDE_, auto STATS_, auto FULL_) {
+            constexpr int SIDE = decltype(SIDE_)::value;
+            constexpr bool STATS = decltype(STATS_)::value, FULLT = decltype(FULL_)::value;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
+            for (int m = 0; m < G::MT; ++m) {
+                const int zl = w * ZW + (m >> 1);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int yl = (m & 1) * 4 + (e & 3), xl = 2 * (e >> 2) + half;
-                    __bf16* cell = reinterpret_cast<__bf16*>(lds + ((zl * 8 + yl) * 8 + xl) * RSB) + j * 32 + col;
-                    const float sv = side ? (float)*cell : 0.f;
-                    float v = acc[m][j][e];
-                    if (p.residual) v += sv;
-                    if (p.maskx && !(sv > 0.f)) v = 0.f;
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    const __bf16 vb = (__bf16)v;
-                    *cell = vb;
-                    v = (float)vb;  // (statistics describe the STORED tensor)
-                    if (z0 + zl < p.D && y0 + yl < p.H && x0 + xl < p.W) {
-                        if (want_stats) {
-                            s1[j] += v;
-                            s2[j] = fmaf(v, v, s2[j]);
-                        } else if (want_g) {
-                            s1[j] += v;
-                            s2[j] = fmaf(v, sv, s2[j]);
+                for (int j = 0; j < NT; ++j) {
+#pragma unroll
+                    for (int e = 0; e < 16; e += 2) {
+                        const int yl = (m & 1) * 4 + (e & 3), xl = 2 * (e >> 2);  // (+ half: in cb / below)
+                        char* c0 = cb + (((m >> 1) * 8 + yl) * 8 + xl) * RSB + j * 64;
+                        char* c1 = c0 + 8 * RSB;
+                        f32x2 v = {acc[m][j][e], acc[m][j][e + 1]};
+                        f32x2 sv = {0.f, 0.f};
+                        if constexpr (SIDE != 0) {
+                            const unsigned u0 = *reinterpret_cast<const unsigned short*>(c0), u1 = *reinterpret_cast<const unsigned short*>(c1);
+                            sv = f32x2{__builtin_bit_cast(float, u0 << 16), __builtin_bit_cast(float, u1 << 16)};
+                        }
+                        if constexpr (SIDE == 1) v = v + sv;
+                        if constexpr (SIDE == 2) {
+                            v[0] = sv[0] > 0.f ? v[0] : 0.f;
+                            v[1] = sv[1] > 0.f ? v[1] : 0.f;
+                        }
+                        v[0] = fmaxf(v[0], lowest);
+                        v[1] = fmaxf(v[1], lowest);
+                        const bf16x2 r = __builtin_convertvector(v, bf16x2);
+                        *reinterpret_cast<__bf16*>(c0) = r[0];
+                        *reinterpret_cast<__bf16*>(c1) = r[1];
+                        if constexpr (STATS) {  // (statistics describe the STORED tensor)
+                            const unsigned rb = __builtin_bit_cast(unsigned, r);
+                            f32x2 vr = {__builtin_bit_cast(float, rb << 16), __builtin_bit_cast(float, rb & 0xffff0000u)};
+                            if constexpr (!FULLT) {
+                                const bool in0 = z0 + zl < p.D && x0 + xl + half < p.W;
+                                if (!(in0 && y0 + yl < p.H)) vr[0] = 0.f;
+                                if (!(in0 && y0 + yl + 1 < p.H)) vr[1] = 0.f;
+                            }
+                            q1[j] += vr;
+                            q2[j] = __builtin_elementwise_fma(vr, SIDE == 3 ? sv : vr, q2[j]);
                         }
                     }
                 }
             }
+        };
+        auto with_side = [&](auto SIDE_) {
+            const bool st = want_stats || want_g;
+            if (st && full) elements(SIDE_, std::true_type{}, std::true_type{});
+            else if (st) elements(SIDE_, std::true_type{}, std::false_type{});
+            else elements(SIDE_, std::false_type{}, std::true_type{});
+        };
+        if (!side) with_side(std::integral_constant<int, 0>{});
+        else if (p.residual) with_side(std::integral_constant<int, 1>{});
+        else if (want_g) with_side(std::integral_constant<int, 3>{});
+        else with_side(std::integral_constant<int, 2>{});
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            s1[j] = q1[j][0] + q1[j][1];
+            s2[j] = q2[j][0] + q2[j][1];
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < NITEM; ++k) {
-            int lo_;
-            size_t go;
-            if (item_addr(k, lo_, go)) *reinterpret_cast<bf16x8*>(yout + go) = *reinterpret_cast<const bf16x8*>(lds + lo_);
-        }
+        for (int k = 0; k < NITEM; ++k)
+            if (item_in(k)) *reinterpret_cast<bf16x8*>(yout + item_goff(k)) = *reinterpret_cast<const bf16x8*>(lds + l0 + VPK * k * RSB);
     } else {
     // Addressing is hoisted: element e of an accumulator tile sits (e & 3) rows and 2*(e >> 2) voxels from the tile's first
     // voxel, so one 64-bit base per (m, j) plus sixteen 32-bit offsets replaces a five-term index per element; tiles that lie
@@ -334,18 +388,7 @@ __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void 
     auto store_item = [&](char* buf, int it, const item_t& v, const aff_t& g) {
         const bool ok = (okmask >> it) & 1u;
         if constexpr (B16) {
-            bf16x8 o;
-            if (has_aff) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    o[e] = (__bf16)(ok ? fmaf((float)v[e], g.a0[e], g.b0[e]) : 0.f);
-                    o[4 + e] = (__bf16)(ok ? fmaf((float)v[4 + e], g.a1[e], g.b1[e]) : 0.f);
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = ok ? v[e] : (__bf16)0.f;
-            }
-            *reinterpret_cast<bf16x8*>(buf + lo[it]) = o;
+            *reinterpret_cast<bf16x8*>(buf + lo[it]) = u3d_stage_b16(v, has_aff, ok, g.a0, g.b0, g.a1, g.b1);
         } else {
             bf16x4 o;
 #pragma unroll
@@ -925,18 +968,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wg
                 const int hy = rem / WG_HX, hx = rem - hy * WG_HX;
                 const int z = tl.z0 - p.off + hz, y = tl.y0 - p.off + hy, xx = tl.x0 - p.off + hx;
                 const bool ok = (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-                if constexpr (B16) {
-                    bf16x8 o;
-                    if (has_aff) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {  // zero padding applies AFTER the affine
-                            o[e] = (__bf16)(ok ? fmaf((float)v[e], g.a0[e], g.b0[e]) : 0.f);
-                            o[4 + e] = (__bf16)(ok ? fmaf((float)v[4 + e], g.a1[e], g.b1[e]) : 0.f);
-                        }
-                    } else {
-                        o = v;  // (outside the volume: loaded as zero)
-                    }
-                    *reinterpret_cast<bf16x8*>(buf + hv * 64 + q * 16) = o;
+                if constexpr (B16) {  // (zero padding applies AFTER the affine; without one, outside the volume was loaded as zero)
+                    *reinterpret_cast<bf16x8*>(buf + hv * 64 + q * 16) = u3d_stage_b16(v, has_aff, ok || !has_aff, g.a0, g.b0, g.a1, g.b1);
                 } else {
                     bf16x4 o = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
                     if (ok) {
