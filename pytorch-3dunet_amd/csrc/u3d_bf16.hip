@@ -385,10 +385,10 @@ __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void 
     auto load_item = [&](int c, int it, item_t& v, bool live = true) {
         v = *reinterpret_cast<const item_t*>(xo + (live ? rel[it] : rel_dump) + (c << 4));
     };
-    auto store_item = [&](char* buf, int it, const item_t& v, const aff_t& g) {
+    auto store_item = [&](char* buf, int it, const item_t& v, const aff_t& g, auto AFF) {
         const bool ok = (okmask >> it) & 1u;
         if constexpr (B16) {
-            *reinterpret_cast<bf16x8*>(buf + lo[it]) = u3d_stage_b16(v, has_aff, ok, g.a0, g.b0, g.a1, g.b1);
+            *reinterpret_cast<bf16x8*>(buf + lo[it]) = u3d_stage_b16(v, decltype(AFF)::value, ok, g.a0, g.b0, g.a1, g.b1);
         } else {
             bf16x4 o;
 #pragma unroll
@@ -417,7 +417,10 @@ __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void 
                 if (it0 + i < NIT) load_item(cbeg, it0 + i, v[i]);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                if (it0 + i < NIT) store_item(lds + (cbeg & 1) * G::BUF, it0 + i, v[i], g0);
+                if (it0 + i < NIT) {
+                    if (has_aff) store_item(lds + (cbeg & 1) * G::BUF, it0 + i, v[i], g0, std::true_type{});
+                    else store_item(lds + (cbeg & 1) * G::BUF, it0 + i, v[i], g0, std::false_type{});
+                }
         }
     }
     f32x16 acc[G::MT][NT];
@@ -442,6 +445,9 @@ __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void 
 #pragma unroll
             for (int j = 0; j < NT; ++j) bq[d][j] = wp0[((size_t)d * ntiles + j) * 64 + lane];
     }
+    // (two copies of the chunk loop, with and without the GroupNorm affine in the staging: the data-gradient launches have none
+    // and copy their bf16 items as they are — a select per dword otherwise)
+    auto chunk_loop = [&](auto AFF) {
     for (int c = cbeg; c < nch; ++c) {
         if constexpr (!(ABL & 8)) __syncthreads();  // buffer (c&1) is complete; everyone is done reading buffer ((c+1)&1)
         const char* cur = lds + (c & 1) * G::BUF;
@@ -488,9 +494,12 @@ __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void 
             }
 #pragma unroll
             for (int i = 0; i < PER; ++i)
-                if (!(ABL & 4) && part * PER + i < NIT) store_item(nxt, part * PER + i, st[i], gaff);
+                if (!(ABL & 4) && part * PER + i < NIT) store_item(nxt, part * PER + i, st[i], gaff, AFF);
         }
     }
+    };
+    if (B16 && !has_aff) chunk_loop(std::false_type{});
+    else chunk_loop(std::true_type{});
 
     conv_tile_epilogue<NT, ZW, KS, T>(p, acc, lds, n, nb, split, z0, y0, x0, t, lane, w);
 }

@@ -717,6 +717,106 @@ __global__ __launch_bounds__(256) void head_fwd_vec_kernel(const T* __restrict__
     }
 }
 
+// bf16 storage, Cin = 32 / 64 / 128 and at most 4 outputs (the segmentation heads of the shipped configs): the kernel above lets
+// Cin/4 lanes share a voxel — 8-byte loads, four shuffle rounds per output and a 4-byte store from every 16th lane (1.4 TB/s on
+// config 4's 262 MB input).  Here a wave copies 64 consecutive voxels with 16-byte loads into its own LDS rows, every lane then
+// owns ONE voxel (row reads are conflict-free at a 16-byte row pad), and a wave-instruction stores 64 consecutive voxels.
+// The sum is formed in the SAME order as above (four rounded products added left to right, then the butterfly's pairing s ^ G/2, .., s ^ 1), so
+// the two kernels agree bit for bit.
+// four products, each rounded, summed left to right: what head_fwd_vec_kernel's vectorised multiply compiles to (v_pk_mul_f32 + adds)
+__device__ __forceinline__ float head_dot4(float x0, float x1, float x2, float x3, const f32x4& w4) {
+#pragma clang fp contract(off)
+    return ((x0 * w4[0] + x1 * w4[1]) + x2 * w4[2]) + x3 * w4[3];
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void head_fwd_b16_rows_kernel(const __bf16* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ b, int N, long long V, int act,
+                                                                float* __restrict__ logits, float* __restrict__ probs) {
+    constexpr int ROW = CIN * 2 + 16, OPV = CIN / 8, NLD = OPV, G = CIN / 4;  // octets per voxel = 16-byte loads per lane and round
+    __shared__ __attribute__((aligned(16))) char rows[4][64 * ROW];
+    __shared__ __attribute__((aligned(16))) float wsh[COUT * CIN];  // (uniform reads broadcast; scalar loads of 64-512 weights spill SGPRs)
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    for (int i = t; i < COUT * CIN; i += 256) wsh[i] = w[i];
+    __syncthreads();
+    char* mine = rows[wv];
+    const long long total = (long long)N * V;
+    typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
+    for (long long v0 = ((long long)blockIdx.x * 4 + wv) * 64; v0 < total; v0 += (long long)gridDim.x * 256) {
+        const long long left = total - v0;  // (>= 1; the last round may hold fewer than 64 voxels)
+        b16x8 it[NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int item = i * 64 + lane, vox = item / OPV;
+            it[i] = b16x8{};
+            if (vox < left) it[i] = *reinterpret_cast<const b16x8*>(x + (size_t)v0 * CIN + (size_t)item * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int item = i * 64 + lane, vox = item / OPV, oc = item - vox * OPV;
+            *reinterpret_cast<b16x8*>(mine + vox * ROW + oc * 16) = it[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float xs[CIN];
+#pragma unroll
+        for (int j = 0; j < OPV; ++j) {
+            const b16x8 r = *reinterpret_cast<const b16x8*>(mine + lane * ROW + j * 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xs[8 * j + e] = (float)r[e];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float acc[COUT];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+            asm volatile("" ::: "memory");  // (keeps the weight reads inside the round: hoisted, COUT * CIN of them live in VGPRs)
+            float pr[G];
+#pragma unroll
+            for (int s_ = 0; s_ < G; ++s_) {
+                const f32x4 wr = *reinterpret_cast<const f32x4*>(wsh + o * CIN + 4 * s_);
+                pr[s_] = head_dot4(xs[4 * s_], xs[4 * s_ + 1], xs[4 * s_ + 2], xs[4 * s_ + 3], wr);
+            }
+#pragma unroll
+            for (int m = G >> 1; m > 0; m >>= 1)
+#pragma unroll
+                for (int s_ = 0; s_ < m; ++s_) pr[s_] = pr[s_] + pr[s_ + m];
+            acc[o] = pr[0] + b[o];
+        }
+        if (lane < left) {
+            const long long idx = v0 + lane;
+            const int n = (int)(idx / V);
+            const long long v = idx - (long long)n * V;
+            float mx = -INFINITY, den = 0.f;
+            if (act == 2) {
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) mx = fmaxf(mx, acc[o]);
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) den += expf(acc[o] - mx);
+            }
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) {
+                const size_t oi = ((size_t)n * COUT + o) * V + v;
+                logits[oi] = acc[o];
+                if (probs) {
+                    float p_ = acc[o];
+                    if (act == 1) p_ = 1.f / (1.f + expf(-acc[o]));
+                    if (act == 2) p_ = expf(acc[o] - mx) / den;
+                    probs[oi] = p_;
+                }
+            }
+        }
+    }
+}
+
+template <int CIN, int COUT>
+static void launch_head_rows(const __bf16* x, const float* w, const float* b, int N, long long V, int act, float* logits, float* probs,
+                             hipStream_t st) {
+    long long rounds = ((long long)N * V + 255) / 256;
+    if (rounds > 4096) rounds = 4096;
+    hipLaunchKernelGGL((head_fwd_b16_rows_kernel<CIN, COUT>), dim3((unsigned)rounds), dim3(256), 0, st, x, w, b, N, V, act, logits, probs);
+}
+
 // bf16 activation storage: x is a bf16 tensor (vector path only: Cin/4 a power of two <= 64), logits / probabilities stay fp32
 extern "C" int u3d_conv1x1_head_fwd_b16(int device, u3d_stream_t stream, const void* x, const float* w, const float* b, int N,
                                         int64_t V, int Cin, int Cout, int act, float* logits, float* probs) {
@@ -728,6 +828,15 @@ extern "C" int u3d_conv1x1_head_fwd_b16(int device, u3d_stream_t stream, const v
     hipStream_t st = (hipStream_t)stream;
     const long long tot = (long long)N * V;
     const __bf16* xb = (const __bf16*)x;
+    // (one or two outputs from 32 / 64 channels: the binary heads of the shipped configs; wider ones would keep Cout * Cin weights
+    // in registers)
+    if (((uintptr_t)x & 15) == 0 && ((Cin == 32 && Cout <= 2) || (Cin == 64 && Cout == 1))) {
+        if (Cin == 64) launch_head_rows<64, 1>(xb, w, b, N, (long long)V, act, logits, probs, st);
+        else if (Cout == 1) launch_head_rows<32, 1>(xb, w, b, N, (long long)V, act, logits, probs, st);
+        else launch_head_rows<32, 2>(xb, w, b, N, (long long)V, act, logits, probs, st);
+        U3D_LAUNCH_CHECK();
+        return 0;
+    }
 #define U3D_HEAD_FWD16(GG)                                                                                                 \
     hipLaunchKernelGGL((head_fwd_vec_kernel<GG, __bf16>), dim3(grid_for(tot * GG, 8192)), dim3(256), 0, st, xb, w, b, N, \
                        (long long)V, Cin, Cout, act, logits, probs)

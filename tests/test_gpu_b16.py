@@ -241,6 +241,18 @@ def test_conv1x1_and_head_b16():
     call("u3d_conv1x1_head_bwd_b16", _p(dl), _p(b16(x)), _p(wh), N, V, Cin, Co, 1, _p(hx16), _p(h16))
     torch.cuda.synchronize()
     assert torch.equal(l16, l32) and torch.equal(p16, p32) and same_bits(hx16, hx32.to(BF)) and torch.allclose(h16, h32, rtol=1e-12)
+    # one / two outputs from 32 / 64 channels take the row-per-lane kernel (a wave stages 64 voxels in LDS, each lane owns one):
+    # same summation order as the shuffle kernel, so the fp32 entry point is still matched bit for bit; V = 700 leaves a partial round
+    for ci, co, act in ((64, 1, 1), (32, 2, 2), (32, 1, 0), (64, 1, 0)):
+        xs = dev(r16(torch.randn(N, V, ci)))
+        w2, b2 = dev(torch.randn(co, ci) / 8), dev(torch.randn(co))
+        a32, q32, a16, q16 = (torch.full((N, co, V), float("nan"), device=U.DEV) for _ in range(4))
+        call("u3d_conv1x1_head_fwd", _p(xs), _p(w2), _p(b2), N, V, ci, co, act, _p(a32), _p(q32) if act else None)
+        call("u3d_conv1x1_head_fwd_b16", _p(b16(xs)), _p(w2), _p(b2), N, V, ci, co, act, _p(a16), _p(q16) if act else None)
+        torch.cuda.synchronize()
+        assert torch.equal(a16, a32), (ci, co, act, float((a16 - a32).abs().max()))
+        if act:
+            assert torch.equal(q16, q32), (ci, co, act)
 
 
 @pytest.mark.parametrize("dims,Cin,Cout", [((2, 3, 7, 11), 64, 128), ((1, 8, 16, 16), 128, 64), ((1, 2, 5, 9), 256, 512),
