@@ -67,6 +67,7 @@ struct bf16_conv_params {
     int ksplit;            // > 1: the channel reduction is split over `ksplit` blocks per (tile, channel block); raw partial
     float* ws;             //      sums go to ws[split][voxel][K] and splitk_bf16_reduce_kernel owns the epilogue
     long long wpart;       // split-fp32 kernels: distance (in bf16x8 records) between the high / middle / low weight images
+    int order;             // tile order of the grid: 1 (default) z fastest, then x, then y; 0 (u3d_set_tuning key 11 = 1) x-y-z raster
     int b16;               // 1: x, y, residual, gx, maskx are bf16 tensors (activation storage, `_b16` entry points); the pointer
                            //    fields keep their float* type and are reinterpreted by the kernels' storage type T
 };
@@ -310,8 +311,9 @@ __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void 
     // The 64-channel 3x3x3 tile with the full B ring (9 slots, 6 taps ahead) needs 202 VGPRs: two blocks per CU.  With fragments
     // only 2 taps ahead in a ring of 3 it fits 168 — THREE blocks per CU (LDS 46 KB each), and the third wave per SIMD hides more
     // than the shorter lead exposes: config 4 19.5 -> 19.2 ms per step (same-box pairs, profiles/r03_cfg4_ab.txt)
-    constexpr bool SHORT = NT == 2 && ZW == 1 && KS == 3;
-    constexpr int B_RING = SHORT ? 3 : G::RING, B_DIST = SHORT ? 2 : G::BDIST;
+    constexpr bool SHORT = NT == 2 && KS == 3 && (ZW == 1 || std::is_same<T, __bf16>::value);
+    constexpr int B_RING = SHORT ? (KS == 3 ? 3 : 4) : G::RING, B_DIST = SHORT ? 2 : G::BDIST;
+    constexpr int A_DIST = (ZW == 2 && std::is_same<T, __bf16>::value) ? 1 : G::ADIST;  // (8-plane tiles: 4 A fragments per tap — registers)
     constexpr int HY = G::HY;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -321,12 +323,24 @@ __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void 
     int tile = bid / nblk;
     const int split = tile % p.ksplit;  // (ksplit == 1: 0)
     tile /= p.ksplit;
-    const int txi = tile % p.tx;
-    tile /= p.tx;
-    const int tyi = tile % p.ty;
-    tile /= p.ty;
-    const int tzi = tile % p.tz;
-    const int n = tile / p.tz;
+    int txi, tyi, tzi, n;
+    // z fastest: the tiles an XCD works on at one time (32 CUs x 3 blocks, consecutive ids) then share their z halos — the widest
+    // (6 planes for 4) — through that XCD's L2: 0.49 -> 0.40 GB fetched per launch on config 4 (profiles/r03_tile_order.txt)
+    if (p.order == 1) {
+        tzi = tile % p.tz;
+        tile /= p.tz;
+        txi = tile % p.tx;
+        tile /= p.tx;
+        tyi = tile % p.ty;
+        n = tile / p.ty;
+    } else {
+        txi = tile % p.tx;
+        tile /= p.tx;
+        tyi = tile % p.ty;
+        tile /= p.ty;
+        tzi = tile % p.tz;
+        n = tile / p.tz;
+    }
     const int z0 = tzi * G::TZ, y0 = tyi * 8, x0 = txi * 8;
     const int nch_all = p.C >> 4;
     const int cps = (nch_all + p.ksplit - 1) / p.ksplit;          // chunks per split
@@ -458,9 +472,9 @@ __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void 
         chunk_affine(cn, gaff);
         const bf16x8* wp = p.wpk + ((size_t)c * G::NTAPS * ntiles + (size_t)nb * NT) * 64;  // wave-uniform (scalar) base
         item_t st[PER];
-        bf16x8 aq[G::ADIST + 1][G::MT] = {};
+        bf16x8 aq[A_DIST + 1][G::MT] = {};
 #pragma unroll
-        for (int d = 0; d < G::ADIST; ++d) {
+        for (int d = 0; d < A_DIST; ++d) {
             const int tzz = d / (KS * KS), tyy = (d / KS) % KS, txx = d % KS;
 #pragma unroll
             for (int m = 0; m < G::MT; ++m)
@@ -477,11 +491,11 @@ __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void 
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     if constexpr (!(ABL & 1)) bq[(tap + B_DIST) % B_RING][j] = wp[((size_t)(tap + B_DIST) * ntiles + j) * 64 + lane];
-                if (!(ABL & 2) && tap + G::ADIST < G::NTAPS) {
-                    const int nt_ = tap + G::ADIST, tzz = nt_ / (KS * KS), tyy = (nt_ / KS) % KS, txx = nt_ % KS;
+                if (!(ABL & 2) && tap + A_DIST < G::NTAPS) {
+                    const int nt_ = tap + A_DIST, tzz = nt_ / (KS * KS), tyy = (nt_ / KS) % KS, txx = nt_ % KS;
 #pragma unroll
                     for (int m = 0; m < G::MT; ++m)
-                        aq[nt_ % (G::ADIST + 1)][m] =
+                        aq[nt_ % (A_DIST + 1)][m] =
                             *reinterpret_cast<const bf16x8*>(cur + a_base + ((((m >> 1) + tzz) * HY + ((m & 1) * 4 + tyy)) * HS + txx) * 16);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -489,7 +503,7 @@ __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void 
                 for (int m = 0; m < G::MT; ++m)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[tap % (G::ADIST + 1)][m], bq[tap % B_RING][j], acc[m][j], 0, 0, 0);
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[tap % (A_DIST + 1)][m], bq[tap % B_RING][j], acc[m][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -715,6 +729,7 @@ template <int NT, int ZW, int KS, int ABL = 0, typename T = float>
 static int launch_bf16(const bf16_conv_params& p, hipStream_t stream) {
     using G = tile_geom<ZW, KS>;
     bf16_conv_params q = p;
+    q.order = g_u3d_tune[11] == 1 ? 0 : 1;
     q.tz = (p.D + G::TZ - 1) / G::TZ;
     q.ty = (p.H + 7) / 8;
     q.tx = (p.W + 7) / 8;
@@ -815,7 +830,12 @@ static int conv3d_bf16_impl(int device, u3d_stream_t stream, const float* x, con
     // left for the staging descriptors and the deeper rings; u3d_set_tuning key 7 = 2 selects them for A/B runs
     const bool zw2 = g_u3d_tune[7] == 2 && big >= 512 && D >= 8 && p.ksplit == 1;
     hipStream_t s = (hipStream_t)stream;
-    // (8-plane tiles for bf16 storage: 256 VGPRs + 224 spilled at two blocks per CU — not instantiated)
+    // bf16 storage: 8-plane tiles where they still give two blocks per CU.  A wave then issues 8 MFMAs per pair of B fragments
+    // instead of 4: the B stream (1 KiB per fragment and wave, from L2 through the CU's vector L1) is what bounds this kernel —
+    // without it the same code runs 14-32 % faster (profiles/r03_bf16_ablation.txt) — and the short B ring, the one-deep A ring
+    // and bf16 halo planes (77 KB of LDS per block) make the taller tile fit 256 VGPRs without spills.  +4-7 % on the 64- and
+    // 128-channel layers, config 4 19.4 -> 18.9 ms (u3d_set_tuning key 10 = 1: 4-plane tiles everywhere)
+    if (b16 && nt2 && g_u3d_tune[10] != 1 && big >= 512 && D >= 8 && p.ksplit == 1) return launch_bf16<2, 2, 3, 0, __bf16>(p, s);
     if (b16) return nt2 ? launch_bf16<2, 1, 3, 0, __bf16>(p, s) : launch_bf16<1, 1, 3, 0, __bf16>(p, s);
     if (nt2) return zw2 ? launch_bf16<2, 2, 3>(p, s) : launch_bf16<2, 1, 3>(p, s);
     return zw2 ? launch_bf16<1, 2, 3>(p, s) : launch_bf16<1, 1, 3>(p, s);
@@ -1314,6 +1334,7 @@ __global__ __launch_bounds__(256) void wgrad_t8_reduce_kernel(const float* __res
 int launch_t8_conv(const bf16_conv_params& p0, hipStream_t s) {
     bf16_conv_params p = p0;
     const bool nt2 = p.K % 64 == 0;
+    // (8-plane tiles measured no gain on these 2x2x2 kernels: 0.77 vs 0.80 ms for config 4's data gradients, forward equal)
     if (p.b16) return nt2 ? launch_bf16<2, 1, 2, 0, __bf16>(p, s) : launch_bf16<1, 1, 2, 0, __bf16>(p, s);
     return nt2 ? launch_bf16<2, 1, 2>(p, s) : launch_bf16<1, 1, 2>(p, s);
 }
