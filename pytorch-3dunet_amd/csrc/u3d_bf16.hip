@@ -1065,9 +1065,13 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wg
         const wg_tile tn = decode(more ? tile + 1 : tile);
         aff_t gaff;
         if (more) load_aff(tn.n, gaff);
+        // bf16 storage (DEEP): the loads of part p are written at the end of part p + 1 — two batches in flight, twice the time for a
+        // load to come back (the loop is fetch-latency bound: with cache-resident reads it runs 20 % faster)
+        constexpr bool DEEP = B16 && WG_PARTS == 4;
+        item_t stq[DEEP ? 2 : 1][PER];
 #pragma unroll
         for (int part = 0; part < WG_PARTS; ++part) {
-            item_t st[PER];
+            item_t(&st)[PER] = stq[DEEP ? (part & 1) : 0];
             if (more) {
 #pragma unroll
                 for (int i = 0; i < PER; ++i) load_item(tn, part * PER + i, st[i]);
@@ -1091,8 +1095,19 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wg
             }
             __builtin_amdgcn_sched_barrier(0);
             if (more) {
+                if constexpr (DEEP) {
+                    if (part >= 1) {
 #pragma unroll
-                for (int i = 0; i < PER; ++i) store_item(nxt, tn, part * PER + i, st[i], gaff);
+                        for (int i = 0; i < PER; ++i) store_item(nxt, tn, (part - 1) * PER + i, stq[(part - 1) & 1][i], gaff);
+                    }
+                    if (part == WG_PARTS - 1) {
+#pragma unroll
+                        for (int i = 0; i < PER; ++i) store_item(nxt, tn, part * PER + i, st[i], gaff);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < PER; ++i) store_item(nxt, tn, part * PER + i, st[i], gaff);
+                }
             }
         }
     }
