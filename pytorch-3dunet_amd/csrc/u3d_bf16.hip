@@ -313,7 +313,9 @@ __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void 
     // than the shorter lead exposes: config 4 19.5 -> 19.2 ms per step (same-box pairs, profiles/r03_cfg4_ab.txt)
     constexpr bool SHORT = NT == 2 && KS == 3 && (ZW == 1 || std::is_same<T, __bf16>::value);
     constexpr int B_RING = SHORT ? (KS == 3 ? 3 : 4) : G::RING, B_DIST = SHORT ? 2 : G::BDIST;
-    constexpr int A_DIST = (ZW == 2 && std::is_same<T, __bf16>::value) ? 1 : G::ADIST;  // (8-plane tiles: 4 A fragments per tap — registers)
+    // (bf16 storage: A fragments one tap ahead — the 8-plane tile reads 4 per tap, the 4-plane tile sits at the 168-register line of
+    // three blocks per CU and spilled 8 dwords with two taps of them)
+    constexpr int A_DIST = (NT == 2 && std::is_same<T, __bf16>::value && KS == 3) ? 1 : G::ADIST;
     constexpr int HY = G::HY;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;

@@ -49,7 +49,10 @@ def same_bits(a, b):
 
 
 @pytest.mark.parametrize("shape,C,K,res,ks", [((1, 32, 64, 64), 64, 64, True, False), ((2, 5, 9, 11), 32, 96, False, False),
-                                              ((1, 4, 8, 8), 512, 512, True, True)])
+                                              ((1, 4, 8, 8), 512, 512, True, True),
+                                              # >= 512 blocks of 8 z-planes: the taller tile of the bf16-storage kernel, full and
+                                              # ragged in z (20 = 2 x 8 + 4), one and two 64-channel output blocks
+                                              ((1, 64, 64, 64), 64, 64, True, False), ((1, 20, 80, 208), 64, 128, True, False)])
 def test_conv3d_bf16_b16_forward_and_data_gradient(shape, C, K, res, ks):
     N, D, H, W = shape
     torch.manual_seed(1)
