@@ -68,7 +68,8 @@ const char* u3d_last_error(void);
 /* 0 if `device` is a gfx950 part, U3D_EARCH otherwise. */
 int u3d_check_device(int device);
 /* Process-wide performance knobs for A/B measurements (never change results).
- * key 0: forced N-tiles per block of u3d_conv3d (1,2,3; 0 = automatic); key 1: wgrad split override. */
+ * key 0: forced N-tiles per block of u3d_conv3d (1,2,3; 0 = automatic); key 1: wgrad split override; keys 2-11: see the
+ * list at the top of csrc/u3d_conv.hip (16 keys; the environment variable U3D_TUNE=key:value,... sets them at load time). */
 int u3d_set_tuning(int key, int value);
 /* Developer aid (tools/wave_timeline.py): while a device buffer is registered, u3d_conv3d launches an instrumented
  * twin of the kernel in which every wave records 24 int64 (block, HW_ID, XCC_ID, shader-clock stamps at entry /

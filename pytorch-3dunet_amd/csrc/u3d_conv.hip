@@ -25,7 +25,8 @@
 //   [5] start-phase stagger of the persistent kernel in units of 1024 cycles (0 = off)
 //   [6] 1 = one persistent block per CU instead of two (occupancy experiment)
 //   [8] bf16 weight gradient: target number of blocks (0 = default)   [9] 1 = bf16 weight gradient without the XCD-aware block order
-//   [10..15] free
+//   [10] 1 = bf16-storage convolutions on 4-plane tiles only (no 8-plane tiles)   [11] 1 = x-y-z raster tile order of the bf16 kernels
+//   [12..15] free
 int g_u3d_tune[16] = {0};
 
 namespace cv {
