@@ -1071,6 +1071,18 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wg
         // load to come back (the loop is fetch-latency bound: with cache-resident reads it runs 20 % faster)
         constexpr bool DEEP = B16 && WG_PARTS == 4;
         item_t stq[DEEP ? 2 : 1][PER];
+        static_assert(WG_TZ * WG_TY == 16 && WG_PARTS == 4, "16 rows of 16 voxels per tile, 4 per part");
+        constexpr int NS = 16 * NTW, AD = (NTW >= 2 && (B16 || KS != 3)) ? 2 : 1;  // steps per tile; fragments AD steps ahead (more spills)
+        auto a_addr = [&](int s_) {  // step -> (row, tap slot) -> LDS offset of the g fragment
+            const int rw = s_ / NTW, i = s_ - rw * NTW;
+            const int zl = rw / WG_TY, yl = rw % WG_TY;
+            return a_off[i] + (zl * WG_HY + yl) * WG_HX * 64;
+        };
+        auto b_addr = [&](int rw) { return b_off + rw * WG_TX * 64; };
+        bf16x8 af[AD + 1], bfr[2];
+#pragma unroll
+        for (int s_ = 0; s_ < AD; ++s_) af[s_] = tr_frag(cur + a_addr(s_));
+        bfr[0] = tr_frag(cur + b_addr(0));
 #pragma unroll
         for (int part = 0; part < WG_PARTS; ++part) {
             item_t(&st)[PER] = stq[DEEP ? (part & 1) : 0];
@@ -1079,21 +1091,18 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wg
                 for (int i = 0; i < PER; ++i) load_item(tn, part * PER + i, st[i]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            // ---- 4 rows of 16 voxels: one dz fragment per row, one g fragment + MFMA per tap of this wave (g fragments one tap ahead)
+            // ---- 4 rows of 16 voxels: one dz fragment per row, one g fragment + MFMA per tap of this wave.  The fragments run in a
+            // ring AD steps ahead of their MFMA across the whole tile, pinned by sched_barriers: left to itself the compiler reuses
+            // ONE register quadruple for every g fragment — read, wait for the LDS (100+ cycles), MFMA (32), read, wait, ... — which
+            // is what held this kernel at 0.4 MFMA-busy with two waves per SIMD.
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int kg = part * 4 + r4;
-                const int zl = kg / WG_TY, yl = kg % WG_TY;
-                const int row = (zl * WG_HY + yl) * WG_HX * 64;
-                const bf16x8 b = tr_frag(cur + b_off + (zl * WG_TY + yl) * WG_TX * 64);
-                bf16x8 a = tr_frag(cur + a_off[0] + row);
-#pragma unroll
-                for (int i = 0; i < NTW; ++i) {
-                    bf16x8 an = a;
-                    if (i + 1 < NTW) an = tr_frag(cur + a_off[i + 1] + row);
-                    if (wq + 4 * i < G::NTAPS) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
-                    a = an;
-                }
+            for (int q4 = 0; q4 < 4 * NTW; ++q4) {
+                const int s_ = part * 4 * NTW + q4, rw = s_ / NTW, i = s_ - rw * NTW;
+                if (s_ + AD < NS) af[(s_ + AD) % (AD + 1)] = tr_frag(cur + a_addr(s_ + AD));
+                if (i == 0 && rw + 1 < 16) bfr[(rw + 1) & 1] = tr_frag(cur + b_addr(rw + 1));
+                __builtin_amdgcn_sched_barrier(0);
+                if (wq + 4 * i < G::NTAPS) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s_ % (AD + 1)], bfr[rw & 1], acc[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (more) {
