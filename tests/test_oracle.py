@@ -351,3 +351,38 @@ def test_c_restatement_of_the_round2_operators():
     w = torch.randn(5, 3, 3, 3, 3)
     ref = torch.nn.functional.conv_transpose3d(x, w, None, stride=2, padding=1).numpy()
     assert np.abs(c_ops.conv_transpose3d_fwd(x.numpy(), w.numpy()) - ref).max() < 2e-5
+
+
+def test_bf16_emulation_flags_of_the_oracle_are_inert_by_default_and_do_what_they_say():
+    """The emulation switches the `-m gpu` bf16 tests compare against (BF16_OPERANDS / BF16_STORAGE) must not leak into the default
+    oracle, and each rounding must sit where the product rounds: operands of a convolution in forward AND in the data gradient,
+    stored tensors and their gradients once, a 1x1x1 conv's weight only inside the envelope of the matrix-pipe kernel."""
+    torch.manual_seed(0)
+    r16 = orc._r16
+    x = torch.randn(1, 64, 3, 4, 5, dtype=torch.float64).float().requires_grad_(True)
+    w = (torch.randn(128, 64, 1, 1, 1) / 8).requires_grad_(True)
+    b = torch.randn(128)
+    assert not orc.BF16_OPERANDS and not orc.BF16_STORAGE
+    assert torch.equal(orc.conv1x1_bias(x, w, b), F.conv3d(x, w, b)) and orc.stored(x) is x and orc.grad_stored(x) is x
+    orc.BF16_OPERANDS = orc.BF16_STORAGE = True
+    try:
+        y = orc.conv1x1_bias(x, w, b)
+        assert torch.equal(y, F.conv3d(x, r16(w), b))  # weight rounded, x as it is (a stored tensor is bf16 already), fp32 sums
+        gy = torch.randn_like(y)
+        gx, gw = torch.autograd.grad(y, (x, w), gy)
+        gx_ref, gw_ref = torch.autograd.grad(F.conv3d(x, r16(w).detach().requires_grad_(True), b), (x,), gy)[0], None
+        assert torch.equal(gx, gx_ref)  # the data gradient uses the rounded weight too
+        gw_ref = torch.autograd.grad(F.conv3d(x, w, b), w, gy)[0]
+        assert torch.equal(gw, gw_ref)  # the weight gradient never sees the rounding (dy^T x, both stored tensors)
+        # outside the kernel's envelope (power-of-two widths in 64..512) nothing is rounded
+        w_small = torch.randn(48, 64, 1, 1, 1)
+        assert torch.equal(orc.conv1x1_bias(x, w_small, None), F.conv3d(x, w_small, None))
+        # a stored tensor: value rounded in forward, its gradient rounded once in backward
+        t = torch.randn(7, dtype=torch.float32, requires_grad=True)
+        s = orc.stored(t)
+        assert torch.equal(s, r16(t))
+        g = torch.randn(7)
+        assert torch.equal(torch.autograd.grad(s, t, g)[0], r16(g))
+        assert torch.equal(orc.grad_stored(t), t) and torch.equal(torch.autograd.grad(orc.grad_stored(t), t, g)[0], r16(g))
+    finally:
+        orc.BF16_OPERANDS = orc.BF16_STORAGE = False
