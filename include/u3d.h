@@ -515,7 +515,7 @@ int u3d_conv1x1_bwd_b16(int device, u3d_stream_t stream, const void* dy, const v
                         int64_t V, int Cin, int Cout, void* dx, double* acc);
 /* ResNetBlock.conv1 (1x1x1, bias; reference buildingblocks.py:248-255) under bf16 storage on v_mfma_f32_32x32x16_bf16: the
  * weights are rounded to bf16 like every MFMA operand of the bf16 path; x, y, dy, dx are bf16 (N, V, C) tensors.
- * _supported: Cin, Cout powers of two in 64..512.  out_stats (N, Cout, 2) += (sum, sum of squares) of the STORED y.
+ * _supported: Cin, Cout powers of two in 64..1024.  out_stats (N, Cout, 2) += (sum, sum of squares) of the STORED y.
  * _bwd: dx (may be NULL) = dy W; dw (Cout, Cin) and db (Cout) are WRITTEN (fp32, fixed-order sums: run-to-run identical). */
 int u3d_conv1x1_mfma_b16_supported(int Cin, int Cout);
 int u3d_conv1x1_fwd_mfma_b16(int device, u3d_stream_t stream, const void* x, const float* w, const float* bias, void* y, int N,

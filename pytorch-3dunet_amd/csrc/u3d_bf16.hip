@@ -1498,12 +1498,21 @@ struct c1_params {
     long long wsk, wsn;  // B[k][n] = w[k * wsk + n * wsn]
 };
 
-template <int KS, int NTW>
-__global__ __launch_bounds__(256, (KS * NTW > 16 ? 1 : NTW == 4 ? 2 : 3)) void conv1x1_bf16_kernel(const c1_params p) {
-    constexpr int RSB = NTW * 64 + 16;  // bytes per voxel row of the epilogue region
-    constexpr int K_ = KS * 16, NT_ = NTW * 32, BROW = K_ * 2 + 16;  // the block's weight tile in LDS: [n][k] bf16, padded rows
-    constexpr int LDS_BYTES = (4 * 32 * RSB > NT_ * BROW) ? 4 * 32 * RSB : NT_ * BROW;
-    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+// BL (K = 1024, the bottom of a 5-level net: a few hundred voxels): the B fragments do not fit the register file; they stay in LDS
+// (the weight tile keeps its region, the epilogue gets its own) and are read per k-step — slower per MFMA, irrelevant at that size.
+template <int KS, int NTW, bool BL>
+struct c1_geom {
+    static constexpr int RSB = NTW * 64 + 16;  // bytes per voxel row of the epilogue region
+    static constexpr int K_ = KS * 16, NT_ = NTW * 32, BROW = K_ * 2 + 16;  // the block's weight tile in LDS: [n][k] bf16, padded rows
+    static constexpr int EPI = 4 * 32 * RSB, WT = NT_ * BROW;
+    static constexpr int LDS_BYTES = BL ? WT + EPI : (EPI > WT ? EPI : WT);
+};
+
+template <int KS, int NTW, bool BL = false>
+__global__ __launch_bounds__(256, (BL || KS * NTW > 16 ? 1 : NTW == 4 ? 2 : 3)) void conv1x1_bf16_kernel(const c1_params p) {
+    using CG = c1_geom<KS, NTW, BL>;
+    constexpr int RSB = CG::RSB, K_ = CG::K_, NT_ = CG::NT_, BROW = CG::BROW;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
     __shared__ float red[4][NTW * 32][2];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, col = lane & 31, kh = lane >> 5;
     const int n = blockIdx.z, nb0 = blockIdx.y * NTW * 32;
@@ -1530,12 +1539,14 @@ __global__ __launch_bounds__(256, (KS * NTW > 16 ? 1 : NTW == 4 ? 2 : 3)) void c
         }
     }
     __syncthreads();
-    bf16x8 B[KS][NTW];
+    bf16x8 B[BL ? 1 : KS][NTW];
+    if constexpr (!BL) {
 #pragma unroll
-    for (int s_ = 0; s_ < KS; ++s_)
+        for (int s_ = 0; s_ < KS; ++s_)
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) B[s_][j] = *reinterpret_cast<const bf16x8*>(lds + (j * 32 + col) * BROW + (16 * s_ + 8 * kh) * 2);
-    __syncthreads();
+            for (int j = 0; j < NTW; ++j) B[s_][j] = *reinterpret_cast<const bf16x8*>(lds + (j * 32 + col) * BROW + (16 * s_ + 8 * kh) * 2);
+        __syncthreads();
+    }
     float bias[NTW], s1[NTW], s2[NTW];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
@@ -1544,7 +1555,7 @@ __global__ __launch_bounds__(256, (KS * NTW > 16 ? 1 : NTW == 4 ? 2 : 3)) void c
     }
     const __bf16* in = p.in + (size_t)n * p.V * p.K + 8 * kh;
     __bf16* out = p.out + (size_t)n * p.V * p.Nc + nb0;
-    char* reg = lds + w * 32 * RSB;
+    char* reg = lds + (BL ? CG::WT : 0) + w * 32 * RSB;
     const long long mtiles = (p.V + 31) / 32;
     constexpr int RING = KS < 4 ? KS : 4;
     bf16x8 a[RING];
@@ -1571,7 +1582,12 @@ __global__ __launch_bounds__(256, (KS * NTW > 16 ? 1 : NTW == 4 ? 2 : 3)) void c
             if (!vok) cur = bf16x8{};
             if (s_ + 4 < KS) a[s_ & 3] = *reinterpret_cast<const bf16x8*>(arow + 16 * (s_ + 4));
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, B[s_][j], acc[j], 0, 0, 0);
+            for (int j = 0; j < NTW; ++j) {
+                bf16x8 bb;
+                if constexpr (BL) bb = *reinterpret_cast<const bf16x8*>(lds + (j * 32 + col) * BROW + (16 * s_ + 8 * kh) * 2);
+                else bb = B[s_][j];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, bb, acc[j], 0, 0, 0);
+            }
         }
         if (mt + mstep < mtiles) fetch(mt + mstep);
         // C/D layout: column = lane & 31 (channel), row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (voxel of the M-tile)
@@ -1617,7 +1633,7 @@ __global__ __launch_bounds__(256, (KS * NTW > 16 ? 1 : NTW == 4 ? 2 : 3)) void c
     }
 }
 
-static bool c1_mfma_shape(int K, int Nc) { return K % 16 == 0 && K >= 64 && K <= 512 && (K & (K - 1)) == 0 && Nc % 32 == 0 && Nc >= 32; }
+static bool c1_mfma_shape(int K, int Nc) { return K % 16 == 0 && K >= 64 && K <= 1024 && (K & (K - 1)) == 0 && Nc % 32 == 0 && Nc >= 32; }
 
 static int launch_conv1x1_bf16(const c1_params& p, hipStream_t st) {
     const int KS = p.K / 16, nt = p.Nc / 32;
@@ -1630,13 +1646,17 @@ static int launch_conv1x1_bf16(const c1_params& p, hipStream_t st) {
     if (gx > cap) gx = cap;
     if (gx > 8) gx &= ~7LL;  // blocks (x, y) and (x, y + 1) read the same voxels: linear ids a multiple of 8 apart = the same XCD's L2
     const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)p.N);
-#define U3D_C1(KS_, NTW_)                                                                                    \
-    if (KS == KS_ && ntw == NTW_) {                                                                          \
-        hipLaunchKernelGGL((conv1x1_bf16_kernel<KS_, NTW_>), grid, dim3(256), 0, st, p);                     \
-        U3D_LAUNCH_CHECK();                                                                                  \
-        return 0;                                                                                            \
+#define U3D_C1(KS_, NTW_, BL_)                                                                                             \
+    if (KS == KS_ && ntw == NTW_) {                                                                                         \
+        constexpr int bytes = c1_geom<KS_, NTW_, BL_>::LDS_BYTES;                                                          \
+        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_bf16_kernel<KS_, NTW_, BL_>),                   \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes));                                   \
+        hipLaunchKernelGGL((conv1x1_bf16_kernel<KS_, NTW_, BL_>), grid, dim3(256), bytes, st, p);                          \
+        U3D_LAUNCH_CHECK();                                                                                                 \
+        return 0;                                                                                                           \
     }
-    U3D_C1(4, 4) U3D_C1(4, 2) U3D_C1(4, 1) U3D_C1(8, 2) U3D_C1(8, 1) U3D_C1(16, 1) U3D_C1(32, 1)
+    U3D_C1(4, 4, false) U3D_C1(4, 2, false) U3D_C1(4, 1, false) U3D_C1(8, 2, false) U3D_C1(8, 1, false) U3D_C1(16, 1, false)
+    U3D_C1(32, 1, false) U3D_C1(64, 1, true)
 #undef U3D_C1
     return u3d_set_err(U3D_EINVAL, "u3d_conv1x1_bf16: no kernel for K = %d, Nc = %d", p.K, p.Nc);
 }

@@ -196,13 +196,15 @@ extern "C" int u3d_gn_finalize(int device, u3d_stream_t stream, const double* st
 }
 
 // GroupNorm backward reductions -> dgamma, dbeta, coefficient table coef[N][3][C] (p,q,r).
-// One block; phase 1 over (n,g), phase 2 over channels.
+// One block.  `staged`: the N*C*2 sums are first copied to LDS with coalesced loads.  `par` (the sums AND two product arrays fit
+// LDS: N*C <= 2048, every shipped configuration): the per-channel products of the group sums are formed by all threads, the one
+// thread of a (sample, group) pair only adds them up in channel order, and the coefficient table is written by all threads — with
+// eight pairs (N = 1, 8 groups) the serial version kept 8 threads busy for 13 us, 18 times per config-4 step.
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __restrict__ gs, const float* __restrict__ mean_rstd,
                                                               const float* __restrict__ gamma, int N, int C, int G,
-                                                              double count, int staged, float* __restrict__ dgamma,
+                                                              double count, int staged, int par, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, float* __restrict__ coef) {
-    // `staged`: the N*C*2 sums are first copied to LDS with coalesced loads (threads = elements) so that the per-group
-    // loops below read LDS instead of issuing a serial chain of global loads
+#pragma clang fp contract(off)  // (both paths: products rounded, then added in channel order — identical results)
     extern __shared__ double shb[];
     const double* src = gs;
     if (staged) {
@@ -212,22 +214,55 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __re
     }
     const int cpg = C / G;
     const double m = count * cpg;
+    double* pa = shb + 2 * (size_t)N * C;  // (par only)
+    double* pb = pa + (size_t)N * C;
+    double* qr = pb + (size_t)N * C;       // [N*G][2]
+    if (par) {
+        for (int i = threadIdx.x; i < N * C; i += blockDim.x) {
+            const int n = i / C, c = i - n * C, g = c / cpg;
+            const double mean = (double)mean_rstd[((size_t)n * G + g) * 2], rstd = (double)mean_rstd[((size_t)n * G + g) * 2 + 1];
+            const double S1 = src[(size_t)i * 2], S2 = src[(size_t)i * 2 + 1], gm = (double)gamma[c];
+            pa[i] = gm * S1;
+            pb[i] = gm * rstd * (S2 - mean * S1);
+        }
+        __syncthreads();
+    }
     for (int pair = threadIdx.x; pair < N * G; pair += blockDim.x) {
         const int n = pair / G, g = pair - n * G;
         const double mean = (double)mean_rstd[(size_t)pair * 2], rstd = (double)mean_rstd[(size_t)pair * 2 + 1];
         double A = 0.0, B = 0.0;
         for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-            const double S1 = src[((size_t)n * C + c) * 2], S2 = src[((size_t)n * C + c) * 2 + 1];
-            const double gm = (double)gamma[c];
-            A += gm * S1;
-            B += gm * rstd * (S2 - mean * S1);
+            if (par) {
+                A += pa[(size_t)n * C + c];
+                B += pb[(size_t)n * C + c];
+            } else {
+                const double S1 = src[((size_t)n * C + c) * 2], S2 = src[((size_t)n * C + c) * 2 + 1];
+                const double gm = (double)gamma[c];
+                A += gm * S1;
+                B += gm * rstd * (S2 - mean * S1);
+            }
         }
         const double q = -rstd * rstd * B / m;
         const double r = -rstd * A / m + rstd * rstd * mean * B / m;
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        if (par) {
+            qr[(size_t)pair * 2] = q;
+            qr[(size_t)pair * 2 + 1] = r;
+        } else {
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+                coef[((size_t)n * 3 + 0) * C + c] = (float)(rstd * (double)gamma[c]);
+                coef[((size_t)n * 3 + 1) * C + c] = (float)q;
+                coef[((size_t)n * 3 + 2) * C + c] = (float)r;
+            }
+        }
+    }
+    if (par) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < N * C; i += blockDim.x) {
+            const int n = i / C, c = i - n * C, pair = n * G + c / cpg;
+            const double rstd = (double)mean_rstd[(size_t)pair * 2 + 1];
             coef[((size_t)n * 3 + 0) * C + c] = (float)(rstd * (double)gamma[c]);
-            coef[((size_t)n * 3 + 1) * C + c] = (float)q;
-            coef[((size_t)n * 3 + 2) * C + c] = (float)r;
+            coef[((size_t)n * 3 + 1) * C + c] = (float)qr[(size_t)pair * 2];
+            coef[((size_t)n * 3 + 2) * C + c] = (float)qr[(size_t)pair * 2 + 1];
         }
     }
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -252,8 +287,10 @@ extern "C" int u3d_gn_bwd_finalize(int device, u3d_stream_t stream, const double
                 "u3d_gn_bwd_finalize: bad argument");
     const size_t bytes = sizeof(double) * 2 * (size_t)N * C;
     const int staged = bytes <= 48 * 1024 ? 1 : 0;
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(256), staged ? bytes : 0, (hipStream_t)stream, gstats, mean_rstd,
-                       gamma, N, C, G, count, staged, dgamma, dbeta, coef);
+    const size_t par_bytes = 2 * bytes + sizeof(double) * 2 * (size_t)N * G;
+    const int par = staged && par_bytes <= 64 * 1024 ? 1 : 0;
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(256), par ? par_bytes : (staged ? bytes : 0), (hipStream_t)stream, gstats,
+                       mean_rstd, gamma, N, C, G, count, staged, par, dgamma, dbeta, coef);
     U3D_LAUNCH_CHECK();
     return 0;
 }

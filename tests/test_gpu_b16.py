@@ -259,7 +259,8 @@ def test_conv1x1_and_head_b16():
 
 
 @pytest.mark.parametrize("dims,Cin,Cout", [((2, 3, 7, 11), 64, 128), ((1, 8, 16, 16), 128, 64), ((1, 2, 5, 9), 256, 512),
-                                           ((2, 1, 3, 50), 512, 64), ((1, 16, 32, 32), 64, 64)])
+                                           ((2, 1, 3, 50), 512, 64), ((1, 16, 32, 32), 64, 64),
+                                           ((1, 5, 10, 10), 512, 1024)])  # (K = 1024 in the data gradient: fragments from LDS)
 def test_conv1x1_on_the_bf16_matrix_pipe(dims, Cin, Cout):
     """ResNetBlock.conv1 under bf16 storage (u3d_conv1x1_*_mfma_b16): bf16 x bf16 products are exact in fp32, so the only freedom
     against a float64 evaluation with the bf16-rounded weight is the fp32 accumulation order — a last-bit difference before the
@@ -267,7 +268,7 @@ def test_conv1x1_on_the_bf16_matrix_pipe(dims, Cin, Cout):
     torch.manual_seed(11)
     lib = nat.get_lib()
     assert lib.u3d_conv1x1_mfma_b16_supported(Cin, Cout) == 1
-    assert lib.u3d_conv1x1_mfma_b16_supported(1, Cout) == 0 and lib.u3d_conv1x1_mfma_b16_supported(1024, 64) == 0
+    assert lib.u3d_conv1x1_mfma_b16_supported(1, Cout) == 0 and lib.u3d_conv1x1_mfma_b16_supported(2048, 64) == 0
     N, D, H, W = dims
     V = D * H * W
     x = dev(r16(torch.randn(N, V, Cin)))

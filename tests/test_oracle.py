@@ -374,7 +374,7 @@ def test_bf16_emulation_flags_of_the_oracle_are_inert_by_default_and_do_what_the
         assert torch.equal(gx, gx_ref)  # the data gradient uses the rounded weight too
         gw_ref = torch.autograd.grad(F.conv3d(x, w, b), w, gy)[0]
         assert torch.equal(gw, gw_ref)  # the weight gradient never sees the rounding (dy^T x, both stored tensors)
-        # outside the kernel's envelope (power-of-two widths in 64..512) nothing is rounded
+        # outside the kernel's envelope (power-of-two widths in 64..1024) nothing is rounded
         w_small = torch.randn(48, 64, 1, 1, 1)
         assert torch.equal(orc.conv1x1_bias(x, w_small, None), F.conv3d(x, w_small, None))
         # a stored tensor: value rounded in forward, its gradient rounded once in backward
