@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define U3D_VERSION 114 /* 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16) */
+#define U3D_VERSION 115 /* 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant */
 
 #define U3D_OK 0
 #define U3D_EINVAL (-1)  /* bad shape / argument */
@@ -382,6 +382,11 @@ int u3d_conv3d_bf16(int device, u3d_stream_t stream, const float* x, const float
  * bottom of the U (few tiles, many channels) the reduction over input channels is split over several blocks whose partial sums
  * are added in a fixed order by a second kernel that owns the epilogue — same results contract. */
 long long u3d_conv3d_bf16_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
+/* Host-only: which tile variant u3d_conv3d_bf16_ex (b16 = 0) / u3d_conv3d_bf16_ex_b16 (b16 = 1) runs for a shape —
+ * (ksplit << 16) | (z-planes per tile: 4 or 8) << 8 | (32-channel n-tiles per block: 1 or 2) << 4 | blocks per CU (2 or 3);
+ * -1 for unsupported channel counts.  No reference counterpart (ATen picks its MIOpen / oneDNN algorithm internally, behind
+ * buildingblocks.py:56); the parity tests use it to assert that a pinned shape runs the variants the benchmark shape runs. */
+int u3d_conv3d_bf16_tile_variant(int N, int D, int H, int W, int Cin, int Cout, int b16);
 int u3d_conv3d_bf16_ex(int device, u3d_stream_t stream, const float* x, const float* affine, const void* packed_w, float* out,
                        int N, int D, int H, int W, int Cin, int Cout, int relu, double* out_stats, const float* gx,
                        double* gstats, const float* residual, float* workspace, long long workspace_floats);

@@ -755,6 +755,31 @@ static int launch_bf16(const bf16_conv_params& p, hipStream_t stream) {
 }
 
 // how many ways the channel reduction is split: only when the natural grid (4-plane tiles) leaves most of the 256 CUs idle
+// Tile variant of conv3d_bf16_kernel for a shape — ONE decision used by the launcher and by u3d_conv3d_bf16_tile_variant():
+//   nt      64 output channels per block when possible, else 32;
+//   planes  fp32 storage: 4-plane tiles everywhere (8-plane tiles — twice the B-fragment reuse — timed the same, profiles/r02i, and
+//           have no registers left for the staging descriptors and the deeper rings; u3d_set_tuning key 7 = 2 selects them for A/B);
+//           bf16 storage: 8-plane tiles where they still give two blocks per CU.  A wave then issues 8 MFMAs per pair of B fragments
+//           instead of 4: the B stream (1 KiB per fragment and wave, from L2 through the CU's vector L1) is what bounds this kernel —
+//           without it the same code runs 14-32 % faster (profiles/r03_bf16_ablation.txt) — and the short B ring, the one-deep A
+//           ring and bf16 halo planes (77 KB of LDS per block) make the taller tile fit 256 VGPRs without spills.  +4-7 % on the 64-
+//           and 128-channel layers, config 4 19.4 -> 18.9 ms (u3d_set_tuning key 10 = 1: 4-plane tiles everywhere);
+//   blocks_per_cu  the __launch_bounds__ of the instantiation: three for the 64-channel 4-plane tile (168 VGPRs), else two.
+struct Bf16Tile {
+    int nt, planes, blocks_per_cu;
+};
+static Bf16Tile bf16_tile_choice(int N, int D, int H, int W, int K, bool b16, int ksplit) {
+    Bf16Tile t;
+    const bool nt2 = K % 64 == 0;
+    const long long big = (long long)N * ((D + 7) / 8) * ((H + 7) / 8) * ((W + 7) / 8) * (K / (nt2 ? 64 : 32));
+    const bool fits8 = big >= 512 && D >= 8 && ksplit == 1;
+    const bool zw2 = b16 ? (nt2 && g_u3d_tune[10] != 1 && fits8) : (g_u3d_tune[7] == 2 && fits8);
+    t.nt = nt2 ? 2 : 1;
+    t.planes = zw2 ? 8 : 4;
+    t.blocks_per_cu = (t.nt == 2 && t.planes == 4) ? 3 : 2;
+    return t;
+}
+
 static int bf16_ksplit(int N, int D, int H, int W, int C, int K) {
     const bool nt2 = K % 64 == 0;
     const long long natural = (long long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 7) / 8) * (K / (nt2 ? 64 : 32));
@@ -824,23 +849,20 @@ static int conv3d_bf16_impl(int device, u3d_stream_t stream, const float* x, con
         p.ksplit = ks;
         p.ws = workspace;
     }
-    // tile height: 8 z-planes per block when that still gives >= 2 blocks per CU, else 4 (more, smaller blocks at the bottom
-    // of the U); 64 output channels per block when possible
-    const bool nt2 = K % 64 == 0;
-    const long long big = (long long)N * ((D + 7) / 8) * ((H + 7) / 8) * ((W + 7) / 8) * (K / (nt2 ? 64 : 32));
-    // 4-plane tiles everywhere: 8-plane tiles (twice the B-fragment reuse) timed the same (profiles/r02i) and have no registers
-    // left for the staging descriptors and the deeper rings; u3d_set_tuning key 7 = 2 selects them for A/B runs
-    const bool zw2 = g_u3d_tune[7] == 2 && big >= 512 && D >= 8 && p.ksplit == 1;
+    const Bf16Tile tc = bf16_tile_choice(N, D, H, W, K, b16, p.ksplit);
     hipStream_t s = (hipStream_t)stream;
-    // bf16 storage: 8-plane tiles where they still give two blocks per CU.  A wave then issues 8 MFMAs per pair of B fragments
-    // instead of 4: the B stream (1 KiB per fragment and wave, from L2 through the CU's vector L1) is what bounds this kernel —
-    // without it the same code runs 14-32 % faster (profiles/r03_bf16_ablation.txt) — and the short B ring, the one-deep A ring
-    // and bf16 halo planes (77 KB of LDS per block) make the taller tile fit 256 VGPRs without spills.  +4-7 % on the 64- and
-    // 128-channel layers, config 4 19.4 -> 18.9 ms (u3d_set_tuning key 10 = 1: 4-plane tiles everywhere)
-    if (b16 && nt2 && g_u3d_tune[10] != 1 && big >= 512 && D >= 8 && p.ksplit == 1) return launch_bf16<2, 2, 3, 0, __bf16>(p, s);
-    if (b16) return nt2 ? launch_bf16<2, 1, 3, 0, __bf16>(p, s) : launch_bf16<1, 1, 3, 0, __bf16>(p, s);
-    if (nt2) return zw2 ? launch_bf16<2, 2, 3>(p, s) : launch_bf16<2, 1, 3>(p, s);
-    return zw2 ? launch_bf16<1, 2, 3>(p, s) : launch_bf16<1, 1, 3>(p, s);
+    if (b16 && tc.planes == 8) return launch_bf16<2, 2, 3, 0, __bf16>(p, s);
+    if (b16) return tc.nt == 2 ? launch_bf16<2, 1, 3, 0, __bf16>(p, s) : launch_bf16<1, 1, 3, 0, __bf16>(p, s);
+    if (tc.nt == 2) return tc.planes == 8 ? launch_bf16<2, 2, 3>(p, s) : launch_bf16<2, 1, 3>(p, s);
+    return tc.planes == 8 ? launch_bf16<1, 2, 3>(p, s) : launch_bf16<1, 1, 3>(p, s);
+}
+
+// host-only query of that choice (tests assert that the shapes they pin really run the variants the benchmarks run)
+extern "C" int u3d_conv3d_bf16_tile_variant(int N, int D, int H, int W, int C, int K, int b16) {
+    if (!u3d_conv3d_bf16_supported(C, K) || N <= 0 || D <= 0 || H <= 0 || W <= 0) return -1;
+    const int ks = bf16_ksplit(N, D, H, W, C, K);
+    const Bf16Tile tc = bf16_tile_choice(N, D, H, W, K, b16 != 0, ks);
+    return (ks << 16) | (tc.planes << 8) | (tc.nt << 4) | tc.blocks_per_cu;
 }
 
 // =====================================================================================================================

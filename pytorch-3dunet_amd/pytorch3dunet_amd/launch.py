@@ -10,7 +10,7 @@ feed every rank the same patches (datasets/utils.py:399-422).  This launcher fix
 
   1. each rank sees ONE device (`HIP_VISIBLE_DEVICES` = its LOCAL_RANK's device, set before the HIP runtime starts), so the
      unchanged trainer neither wraps `nn.DataParallel` (trainer.py:203) nor rescales the batch (datasets/utils.py:399-403);
-  2. the `sys.modules` seam of INTEGRATION.md: `pytorch3dunet.unet3d.{model,buildingblocks,se,losses,predictor}` resolve to this
+  2. the `sys.modules` seam of INTEGRATION.md: `pytorch3dunet.unet3d.{model,buildingblocks,se,predictor}` resolve to this
      package before the trainer / predictor import them;
   3. `create_trainer(config)` is the reference's own; the loaders it builds are re-wrapped with a per-rank `DistributedSampler`
      over the same `ConcatDataset` (same batch size, workers and collate function), staged through `DevicePrefetcher` on HIP;
@@ -26,7 +26,7 @@ import os
 import sys
 from typing import Optional
 
-_SEAM = ("model", "buildingblocks", "se", "losses", "predictor")
+_SEAM = ("model", "buildingblocks", "se", "predictor")
 
 
 def rank_info():
@@ -73,6 +73,11 @@ def install_seam() -> None:
 
     for name in _SEAM:
         setattr(pkg, name, sys.modules[f"pytorch3dunet.unet3d.{name}"])
+    # losses: the reference's OWN module stays (option handling, wrappers, every other loss); only the fused family — BCEDiceLoss,
+    # DiceLoss, nn.BCEWithLogitsLoss: csrc/u3d_loss.hip — is patched into it
+    from .unet3d.losses import install_fused
+
+    install_fused(importlib.import_module("pytorch3dunet.unet3d.losses"))
 
 
 def init_distributed(device: str) -> bool:

@@ -10,9 +10,10 @@ Contract kept:
 
 Dispatch: tensors on a gfx950 device -> native executor (pytorch3dunet_amd/engine.py), which raises if
 libu3d_hip.so is missing (no silent fallback).  CPU tensors (`device: cpu`) run the torch.nn modules the tree is
-made of.  Model variants the executor does not cover (2-D models, layer orders outside engine.layer_spec's grammar,
-conv kernels other than 3/pad 1) run the same module tree through stock PyTorch-ROCm operators after a one-time
-warning; set U3D_STRICT=1 to make that an error instead.  Covered since round 2: every layer order with at most one
+made of.  ONE backend: a 3-D model variant the executor does not cover (layer orders outside engine.layer_spec's grammar,
+conv kernels other than 3/pad 1, `pool_type: avg`) RAISES on a HIP device; U3D_ALLOW_TORCH_FALLBACK=1 opts into running
+the same module tree through stock PyTorch-ROCm operators after a one-time warning (never counted as covered).  2-D
+models are outside the 3-D path and keep that warning path by default; U3D_STRICT=1 makes them an error too.  Covered since round 2: every layer order with at most one
 GroupNorm / BatchNorm, one non-linearity and a trailing dropout, every `upsample` value the reference itself can run
 on a 3-D net, nn.DataParallel, activation checkpointing, and the opt-in compute modes `bf16` and `fp32_split`.
 """
@@ -111,6 +112,7 @@ class AbstractUNet(nn.Module):
             hip_graph = os.environ.get("U3D_GRAPH", "0") == "1"
         self.hip_graph = bool(hip_graph)
         self._native_blockers = reasons
+        self._is3d = bool(is3d)
         self._residual = basic_module in (ResNetBlock, ResNetBlockSE)
         self._engine = None
         self._warned = False
@@ -173,13 +175,22 @@ class AbstractUNet(nn.Module):
                 # parallel.attach hooked the gradient exchange into the native executor: the module tree would train unsynchronised
                 raise RuntimeError(f"u3d: data-parallel model fell back to the module tree ({why}); its gradients would not be "
                                    "averaged across ranks — call pytorch3dunet_amd.parallel.attach again for this configuration")
-            if os.environ.get("U3D_STRICT", "0") == "1":
-                raise NotImplementedError(f"u3d: no native gfx950 path for this configuration ({why})")
-            if not self._warned:
-                warnings.warn(f"u3d: {type(self).__name__} ({why}) is not covered by the native gfx950 executor yet; "
-                              "running the module tree through stock PyTorch-ROCm operators", stacklevel=3)
-                self._warned = True
+            self._uncovered_on_hip(why)
         return self._forward_modules(x)
+
+    def _uncovered_on_hip(self, why):
+        """ONE backend by default: a 3-D model the executor does not cover is an ERROR on a HIP device.  The module tree on stock
+        PyTorch-ROCm operators is an explicit opt-in (U3D_ALLOW_TORCH_FALLBACK=1) — it is not this library's product and is never
+        counted as covered.  2-D models are outside the 3-D path altogether (north_star) and keep the warning; U3D_STRICT=1 makes
+        every uncovered configuration an error."""
+        allow = not self._is3d or os.environ.get("U3D_ALLOW_TORCH_FALLBACK", "0") == "1"
+        if os.environ.get("U3D_STRICT", "0") == "1" or not allow:
+            raise NotImplementedError(f"u3d: no native gfx950 path for this configuration ({why}); set "
+                                      "U3D_ALLOW_TORCH_FALLBACK=1 to run the module tree on stock PyTorch-ROCm operators instead")
+        if not self._warned:
+            warnings.warn(f"u3d: {type(self).__name__} ({why}) is not covered by the native gfx950 executor; "
+                          "running the module tree through stock PyTorch-ROCm operators", stacklevel=4)
+            self._warned = True
 
     def _forward_modules(self, x):
         """Plain torch.nn execution of the module tree (CPU tensors; uncovered variants)."""

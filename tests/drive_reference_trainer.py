@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE — drive the reference's UNMODIFIED UNetTrainer (/root/reference/pytorch3dunet/unet3d/trainer.py:93-440)
-with this repository's model / buildingblocks / losses modules aliased into `pytorch3dunet.unet3d.*` BEFORE the trainer is
+with this repository's model / buildingblocks modules aliased (and its fused losses patched) into `pytorch3dunet.unet3d.*` BEFORE the trainer is
 imported (the sys.modules seam of INTEGRATION.md).  Runs in a fresh interpreter (tests/test_reference_trainer.py spawns it):
 
     python tests/drive_reference_trainer.py <workdir> [cpu|cuda]
@@ -31,13 +31,15 @@ def main():
     # the seam: the reference's callers resolve these module names (trainer.py:15,17; utils.get_class model.py:361-363)
     sys.modules["pytorch3dunet.unet3d.model"] = my_model
     sys.modules["pytorch3dunet.unet3d.buildingblocks"] = my_blocks
-    sys.modules["pytorch3dunet.unet3d.losses"] = my_losses
+    # losses: the reference's own module stays; only the fused family is patched into it (losses.install_fused)
+    ref_losses = my_losses.install_fused(__import__("importlib").import_module("pytorch3dunet.unet3d.losses"))
     sys.modules.pop("pytorch3dunet.unet3d.trainer", None)
     import pytorch3dunet.unet3d.trainer as T
     from pytorch3dunet.unet3d.config import TorchDevice
     from pytorch3dunet.unet3d.utils import create_optimizer, load_checkpoint
 
-    assert T.get_model is my_model.get_model and T.get_loss_criterion is my_losses.get_loss_criterion
+    assert T.get_model is my_model.get_model and T.get_loss_criterion is ref_losses.get_loss_criterion
+    assert ref_losses.BCEDiceLoss is my_losses.BCEDiceLoss
 
     torch.manual_seed(0)
     dev = TorchDevice(device)

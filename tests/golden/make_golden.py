@@ -48,9 +48,14 @@ CASES = {
     # config 5's ladder: ResidualUNetSE3D, 3 input channels, f_maps=64, 5 levels, non-cubic patch
     "g11_resunetse3d_in3_ladder": (dict(name="ResidualUNetSE3D", in_channels=3, out_channels=1, f_maps=64, num_groups=8,
                                         final_sigmoid=True), (1, 3, 16, 32, 48), "bce_dice", False),
+    # ---- round 4: BASELINE config 4 AT THE SHAPE IT IS BENCHMARKED ON (ResidualUNet3D f_maps=64, 1x1x80x160x160; tools/model_bench.py).
+    # 11 TFLOP per step on the host: fp32 only (the float64 twin needs > 60 GB) -> no ref_err / grad64 samples in this fixture
+    "g12_resunet3d_f64_cfg4_fullsize": (dict(name="ResidualUNet3D", in_channels=1, out_channels=1, f_maps=64, num_groups=8,
+                                             final_sigmoid=True), (1, 1, 80, 160, 160), "bce_dice", False),
 }
+NO_F64 = {"g12_resunet3d_f64_cfg4_fullsize"}
 SAMPLE = 97  # stride of the samples kept for `big` fixtures
-SAMPLES = {"g10_resunet3d_f64_ladder": 499, "g11_resunetse3d_in3_ladder": 499}  # >100 M parameters: sparser samples
+SAMPLES = {"g10_resunet3d_f64_ladder": 499, "g11_resunetse3d_in3_ladder": 499, "g12_resunet3d_f64_cfg4_fullsize": 499}  # >100 M parameters: sparser samples
 
 
 def loss_fn(ref_losses, name, probs, logits, target):
@@ -100,13 +105,16 @@ def main():
         # from exact.  Some gradients are cancellation-dominated (e.g. the first GroupNorm's gamma: the next
         # GroupNorm makes the loss almost scale-invariant) and carry >1e-3 relative noise in the reference itself;
         # parity tests use tol = max(1e-3 * absmax, 3 * ref_err) per parameter.
-        model64 = ref_model.get_model(dict(cfg)).double()
-        model64.load_state_dict({k: v.double() for k, v in model.state_dict().items()})
-        model64.train()
-        p64, l64 = model64(x.double(), return_logits=True)
-        loss_fn(ref_losses, loss_name, p64, l64, target.double()).backward()
-        ref_err = {k: (p.grad.double() - q.grad).abs().max().item()
-                   for (k, p), (_, q) in zip(model.named_parameters(), model64.named_parameters())}
+        has64 = name not in NO_F64
+        model64, ref_err, l64 = model, {}, None
+        if has64:
+            model64 = ref_model.get_model(dict(cfg)).double()
+            model64.load_state_dict({k: v.double() for k, v in model.state_dict().items()})
+            model64.train()
+            p64, l64 = model64(x.double(), return_logits=True)
+            loss_fn(ref_losses, loss_name, p64, l64, target.double()).backward()
+            ref_err = {k: (p.grad.double() - q.grad).abs().max().item()
+                       for (k, p), (_, q) in zip(model.named_parameters(), model64.named_parameters())}
         out = {"cfg": np.array(repr(cfg)), "loss_name": np.array(loss_name), "seed": np.array(100 + seed),
                "pert_seed": np.array(200 + seed), "x_shape": np.array(shape), "loss": loss.detach().numpy(),
                "full": np.array(full)}
@@ -128,16 +136,18 @@ def main():
                 out["grad_s/" + k] = p.grad.flatten()[::S].numpy()
                 out["grad_norm/" + k] = p.grad.norm().numpy()
                 out["grad_absmax/" + k] = p.grad.abs().max().numpy()
-                if name not in ("g4_unet3d_f16_cfg1",):  # round-2 fixtures also carry the float64 reference's samples
+                if name not in ("g4_unet3d_f16_cfg1",) and has64:  # round-2 fixtures also carry the float64 reference's samples
                     out["grad64_s/" + k] = q.grad.flatten()[::S].numpy()
             # global relative L2 distance of the reference's fp32 gradient from its own float64 gradient
-            num = sum((p.grad.double() - q.grad).pow(2).sum().item()
-                      for (_, p), (_, q) in zip(model.named_parameters(), model64.named_parameters()))
-            den = sum(q.grad.pow(2).sum().item() for _, q in model64.named_parameters())
-            out["ref_grad_rel_l2"] = np.array((num / den) ** 0.5)
+            if has64:
+                num = sum((p.grad.double() - q.grad).pow(2).sum().item()
+                          for (_, p), (_, q) in zip(model.named_parameters(), model64.named_parameters()))
+                den = sum(q.grad.pow(2).sum().item() for _, q in model64.named_parameters())
+                out["ref_grad_rel_l2"] = np.array((num / den) ** 0.5)
         for k, v in ref_err.items():
             out["ref_err/" + k] = np.array(v)
-        out["logits_ref_err"] = np.array((logits.detach().double() - l64.detach()).abs().max().item())
+        if has64:
+            out["logits_ref_err"] = np.array((logits.detach().double() - l64.detach()).abs().max().item())
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **out)
         print(f"{name}: loss={loss.item():.6f} -> {os.path.getsize(path) / 1024:.0f} KiB")

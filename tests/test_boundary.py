@@ -35,7 +35,7 @@ def test_header_symbols_exported():
     lib = ctypes.CDLL(nat.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert nat.get_lib().u3d_version() == 114
+    assert nat.get_lib().u3d_version() == 115
 
 
 def test_host_only_entry_points():
@@ -308,3 +308,33 @@ def test_layer_order_grammar_of_the_native_executor():
     assert not M.UNet3D(1, 1, f_maps=[8, 16], num_groups=4, layer_order="gcrg").native_supported
     assert M.ResidualUNet3D(1, 1, f_maps=[8, 16], num_groups=4, layer_order="cbr").native_supported
     assert not M.ResidualUNet3D(1, 1, f_maps=[8, 16], num_groups=4, layer_order="gcrd").native_supported
+
+
+def test_one_backend_by_default_policy_for_uncovered_variants(monkeypatch):
+    """VERDICT r03 item 7, host logic (the GPU twin is tests/test_gpu_model.py): on a HIP device a 3-D model outside the executor's
+    envelope raises unless U3D_ALLOW_TORCH_FALLBACK=1; 2-D models (reference model.py:281-358, outside the 3-D path) keep the
+    one-time warning; U3D_STRICT=1 turns both into errors.  CPU tensors always run the torch.nn module tree, like the reference."""
+    import warnings
+
+    from pytorch3dunet_amd.unet3d.model import ResidualUNet3D, UNet2D
+
+    for k in ("U3D_ALLOW_TORCH_FALLBACK", "U3D_STRICT"):
+        monkeypatch.delenv(k, raising=False)
+    m3 = ResidualUNet3D(1, 1, f_maps=8, num_levels=2, num_groups=4, layer_order="gcrd")  # dropout inside residual blocks: not native
+    m2 = UNet2D(1, 1, f_maps=8, num_levels=2, num_groups=4)
+    assert not m3.native_supported and not m2.native_supported
+    assert m3(torch.rand(1, 1, 4, 8, 8)).shape == (1, 1, 4, 8, 8)  # device: cpu -> module tree, no policy involved
+    with pytest.raises(NotImplementedError, match="U3D_ALLOW_TORCH_FALLBACK"):
+        m3._uncovered_on_hip("layer_order 'gcrd'")
+    with pytest.warns(UserWarning, match="stock PyTorch-ROCm operators"):
+        m2._uncovered_on_hip("2-D model")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        m2._uncovered_on_hip("2-D model")  # one-time warning
+    monkeypatch.setenv("U3D_ALLOW_TORCH_FALLBACK", "1")
+    with pytest.warns(UserWarning, match="stock PyTorch-ROCm operators"):
+        m3._uncovered_on_hip("layer_order 'gcrd'")
+    monkeypatch.setenv("U3D_STRICT", "1")
+    for m in (m2, m3):
+        with pytest.raises(NotImplementedError):
+            m._uncovered_on_hip("x")

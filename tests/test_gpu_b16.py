@@ -442,3 +442,72 @@ def test_activation_bf16_falls_back_with_a_warning_outside_its_envelope():
         warnings.simplefilter("error")
         assert not get_model(dict(CFG, f_maps=[32, 64], compute_dtype="bf16")).to(U.DEV)._get_engine().act_bf16
     assert not get_model(dict(CFG, compute_dtype="bf16", activation_dtype="fp32")).to(U.DEV)._get_engine().act_bf16
+
+
+# Bands of the trajectory test below.  MEASURED FIGURES are written by diag(test="bf16_adam_trajectory") into
+# profiles/r04_parity_diag.jsonl; the bands are 2-3x those, stated relative to the fp32 run's loss at the same step.
+TRAJ_STEP_BAND = 0.05   # every step: |loss_bf16 - loss_fp32| <= 5 % of loss_fp32
+TRAJ_TAIL_BAND = 0.03   # mean of the last 5 steps: within 3 %
+TRAJ_MIN_DROP = 0.30    # both runs must have learnt: mean(last 5) < 0.30 * loss(step 0) (the host's fp32 module tree: 0.17)
+
+
+@pytest.mark.timeout(900)
+def test_bf16_with_bf16_storage_trains_like_fp32_over_30_adam_steps():
+    """nothing showed that `compute_dtype: bf16` + `activation_dtype: bf16` still TRAINS.  A mid-size residual
+    net (ResidualUNet3D 64/128/256: the bf16-storage envelope; reference buildingblocks.py:230-288, model.py:193-234) is trained
+    for 30 Adam steps (utils.py:307-309 with the shipped config's lr 2e-4, weight decay 1e-5; on the host's module tree the curve
+    falls smoothly 1.17 -> 0.19) on a learnable
+    synthetic task — the target is a threshold of the locally averaged input, 6 batches cycled — once on the default fp32 path
+    and once in bf16 with bf16 storage, from the same initial weights.  Gates: both loss curves fall, they stay within a stated
+    band of each other at every step, and the parameter UPDATE of the bf16 run is reported against the fp32 run's."""
+    from pytorch3dunet_amd.unet3d.losses import BCEDiceLoss
+    from pytorch3dunet_amd.unet3d.model import get_model
+
+    shape, steps = (2, 1, 16, 32, 32), 30
+    g = torch.Generator().manual_seed(2024)
+    batches = []
+    for _ in range(6):
+        x = torch.randn(shape, generator=g)
+        batches.append((x, (F.avg_pool3d(x, 3, stride=1, padding=1) > 0.05).float()))
+    torch.manual_seed(7)
+    init = get_model(dict(CFG)).state_dict()
+    crit = BCEDiceLoss()
+    runs = {}
+    for tag, extra in (("fp32", {}), ("bf16", dict(compute_dtype="bf16", activation_dtype="bf16"))):
+        model = get_model(dict(CFG, **extra))
+        model.load_state_dict(init)
+        model = model.to(U.DEV).train()
+        eng = model._get_engine()
+        assert eng.bf16 == (tag == "bf16") and eng.act_bf16 == (tag == "bf16")
+        opt = torch.optim.Adam(model.parameters(), lr=2e-4, weight_decay=1e-5)  # resources/3DUnet_confocal_boundary/train_config.yml:31-35
+        losses = []
+        n0 = nat.launch_count
+        for i in range(steps):
+            x, t = batches[i % len(batches)]
+            _, logits = model(x.to(U.DEV), return_logits=True)
+            loss = crit(logits, t.to(U.DEV))
+            losses.append(loss.item())
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        assert nat.launch_count > n0
+        runs[tag] = (losses, {k: v.detach().cpu().double() for k, v in model.state_dict().items()})
+        del model, opt
+    l32, l16 = runs["fp32"][0], runs["bf16"][0]
+    num = den = 0.0
+    for k, p0 in init.items():
+        u32, u16 = runs["fp32"][1][k] - p0.double(), runs["bf16"][1][k] - p0.double()
+        num += (u16 - u32).pow(2).sum().item()
+        den += u32.pow(2).sum().item()
+    upd_rel = (num / den) ** 0.5
+    step_dev = max(abs(a - b) / b for a, b in zip(l16, l32))
+    tail32, tail16 = sum(l32[-5:]) / 5, sum(l16[-5:]) / 5
+    diag(test="bf16_adam_trajectory", losses_fp32=l32, losses_bf16=l16, worst_step_rel_dev=step_dev, tail_fp32=tail32, tail_bf16=tail16,
+         update_rel_l2_bf16_vs_fp32=upd_rel)
+    print(f"fp32 {l32[0]:.4f} -> {tail32:.4f}; bf16 {l16[0]:.4f} -> {tail16:.4f}; worst step deviation {step_dev:.3%}; "
+          f"update rel-L2 (bf16 vs fp32) {upd_rel:.3f}")
+    assert all(map(lambda v: v == v and v < 10, l16))  # finite
+    assert tail32 < TRAJ_MIN_DROP * l32[0] and tail16 < TRAJ_MIN_DROP * l16[0], (l32, l16)
+    assert step_dev < TRAJ_STEP_BAND, (step_dev, l32, l16)
+    assert abs(tail16 - tail32) < TRAJ_TAIL_BAND * tail32, (tail16, tail32)
+    assert upd_rel < 1.0, upd_rel  # reported above; Adam moves round-off-level coordinates by +-lr in arbitrary directions (cf. the fp32 test)

@@ -139,6 +139,148 @@ def test_config4_bf16_at_the_real_channel_ladder_level_by_level(storage):
     assert abs(loss.item() - g.loss) < 5e-3 * max(1.0, abs(g.loss))
 
 
+# The variants u3d_conv3d_bf16_ex_b16 selects BY GRID SIZE (csrc/u3d_bf16.hip bf16_tile_choice / bf16_ksplit), per level of config 4
+# at 1x80x160x160: code = (ksplit << 16) | planes << 8 | n-tiles << 4 | blocks per CU
+def _variant(lib, shape, c, b16=1):
+    v = lib.u3d_conv3d_bf16_tile_variant(1, *shape, c, c, b16)
+    return dict(ksplit=v >> 16, planes=(v >> 8) & 255, nt=(v >> 4) & 15, blocks_per_cu=v & 15)
+
+
+@pytest.mark.timeout(2400)
+def test_config4_at_its_benchmarked_shape_bf16_storage_with_checkpointing():
+    """BASELINE config 4 WHERE IT IS BENCHMARKED: ResidualUNet3D f_maps=64 on 1x1x80x160x160 with
+    `compute_dtype: bf16`, `activation_dtype: bf16`, `checkpoint_encoders: true` — the step tools/model_bench.py times.  The
+    ladder test above runs 32x64x64, where none of the big-grid variants is selected; here the 8-plane tiles (levels 0-1), the
+    three-blocks-per-CU 64-channel tile (level 2), ragged z (20 and 10 planes in 4-plane tiles, 5 planes at the bottom) and the
+    split-K levels run at the sizes the benchmark gives them.  Forward layer by layer and gradients level by level against the
+    emulation of the same arithmetic (oracle.BF16_OPERANDS + BF16_STORAGE), the fp32 oracle and the samples the IMPORTED
+    reference left in golden g12 (tests/golden/make_golden.py, fp32 CPU path of the reference at this very shape); the
+    checkpointed run must equal the plain run bit for bit.  ~11 TFLOP per oracle pass on the host: slow."""
+    import gc
+
+    import unet3d_oracle as orc
+
+    g = Golden("g12_resunet3d_f64_cfg4_fullsize")
+    assert g.x_shape == (1, 1, 80, 160, 160) and g.cfg["f_maps"] == 64
+    x, target = g.inputs()
+    model = g.build_model()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    del model
+    G = g.cfg["num_groups"]
+    lib = nat.get_lib()
+    # --- the variants this shape selects (and the ladder shape does not)
+    lv_shapes = [((80, 160, 160), 64), ((40, 80, 80), 128), ((20, 40, 40), 256), ((10, 20, 20), 512), ((5, 10, 10), 1024)]
+    var = [_variant(lib, sh, c) for sh, c in lv_shapes]
+    print(var)
+    assert var[0]["planes"] == 8 and var[1]["planes"] == 8, var                      # 8-plane tiles at the top two levels
+    assert var[2] == dict(ksplit=1, planes=4, nt=2, blocks_per_cu=3), var            # three blocks per CU at 256 channels / 20 planes
+    assert var[3]["ksplit"] > 1 and var[4]["ksplit"] > 1, var                        # split-K at the bottom
+    assert _variant(lib, (32, 64, 64), 64)["planes"] == 4                            # (the ladder test's top level: 4-plane tiles)
+    # --- GPU first (the oracle's traces are several GB each: keep the host lean while the device works)
+    from pytorch3dunet_amd.unet3d.model import get_model
+
+    def run(ckpt, debug):
+        gm = get_model(dict(g.cfg, compute_dtype="bf16", activation_dtype="bf16", checkpoint_encoders=ckpt))
+        gm.load_state_dict(sd)
+        gm = gm.to(U.DEV).train()
+        eng = gm._get_engine()
+        assert eng.bf16 and eng.act_bf16 and bool(eng.checkpoint_encoders) == ckpt
+        ys = names = None
+        if debug:
+            eng.debug = {}
+        prof = nat.EventProfiler()
+        nat.profiler = prof
+        try:
+            probs, logits = gm(x.to(U.DEV), return_logits=True)
+            if debug:
+                tape = eng.debug["tape"]
+                ys = [U.ncdhw(r.y).float() for r in tape.convs]
+                names = [r.name for r in tape.convs]
+                eng.debug = None
+                del tape
+            loss = orc.bce_dice_loss(logits, target.to(U.DEV))
+            gm.zero_grad()
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            nat.profiler = None
+            eng.debug = None
+        ran = set(prof.summary())
+        grads = {k: p.grad.detach().cpu() for k, p in gm.named_parameters()}
+        out = (logits.detach().cpu(), loss.item(), grads, ys, names, ran)
+        del gm, eng, probs, logits, loss
+        gc.collect()
+        torch.cuda.empty_cache()
+        return out
+
+    lg, loss_v, grads, ys, names, ran = run(False, True)
+    lg_c, loss_c, grads_c, _, _, ran_c = run(True, False)
+    need = {n + "_b16" for n in ("u3d_conv3d_bf16_ex", "u3d_conv3d_wgrad_bf16", "u3d_convtr3d_fwd_t8", "u3d_convtr3d_dgrad_t8",
+                                 "u3d_convtr3d_wgrad_t8")}
+    assert need <= ran and need <= ran_c, (ran, ran_c)
+    # activation checkpointing of the encoder blocks re-runs the same kernels on the same inputs: bitwise
+    assert torch.equal(lg, lg_c) and loss_v == loss_c
+    for k in grads:
+        assert torch.equal(grads[k], grads_c[k]), k
+    del grads_c, lg_c
+    # --- CPU: fp32 oracle and the emulation of bf16 operands + bf16 storage, with per-layer traces
+    torch.set_num_threads(32)
+    tr32, l32 = orc.forward_decisions(sd, x, G, True)
+    pre32 = [torch.relu(z) for z in tr32["pre"]]
+    del tr32
+    _, _, _, g32 = orc.forward_backward(sd, x, target, G, True, True, g.loss_name)
+    orc.BF16_OPERANDS = orc.BF16_STORAGE = True
+    try:
+        tr16, l16 = orc.forward_decisions(sd, x, G, True)
+        pre16 = [torch.relu(z) for z in tr16["pre"]]
+        del tr16
+        _, _, _, g16 = orc.forward_backward(sd, x, target, G, True, True, g.loss_name)
+    finally:
+        orc.BF16_OPERANDS = orc.BF16_STORAGE = False
+    assert len(ys) == len(pre16) == 18 and max(y.shape[1] for y in ys) == 1024
+    rows = []
+    for name, y, r16, r32 in zip(names, ys, pre16, pre32):
+        scale = r32.abs().max().item()
+        rows.append(dict(layer=name, C=int(y.shape[1]), vs_emu=(y - r16).abs().max().item() / scale,
+                         vs_fp32=(y - r32).abs().max().item() / scale, emu_vs_fp32=(r16 - r32).abs().max().item() / scale))
+    del ys, pre16, pre32
+    e_l16, e_l32, e_l_or = orc.rel_err(lg, l16), orc.rel_err(lg, l32), orc.rel_err(l16, l32)
+    lv = {}
+    for k in g32:
+        d = lv.setdefault(_level_of(k), dict(n16=0.0, n32=0.0, nor=0.0, den=0.0, ns=0.0, ds=0.0))
+        gk = grads[k].double()
+        d["n16"] += (gk - g16[k].double()).pow(2).sum().item()
+        d["n32"] += (gk - g32[k].double()).pow(2).sum().item()
+        d["nor"] += (g16[k].double() - g32[k].double()).pow(2).sum().item()
+        d["den"] += g32[k].double().pow(2).sum().item()
+        rs = g.tensor("grad_s/" + k).double()  # the IMPORTED reference's fp32 gradient at this shape (strided samples)
+        d["ns"] += (gk.flatten()[::g.sample] - rs).pow(2).sum().item()
+        d["ds"] += rs.pow(2).sum().item()
+    levels = {k: dict(vs_emu=(d["n16"] / d["den"]) ** 0.5, vs_fp32=(d["n32"] / d["den"]) ** 0.5, emu_vs_fp32=(d["nor"] / d["den"]) ** 0.5,
+                      vs_reference_samples=(d["ns"] / d["ds"]) ** 0.5) for k, d in lv.items()}
+    # the oracle restatement itself against the imported reference's samples at this shape (it is what the gates lean on)
+    or_vs_ref = max(orc.rel_err(g32[k].flatten()[::g.sample].double(), g.tensor("grad_s/" + k).double()) for k in g32)
+    lg_vs_ref = orc.rel_err(l32.flatten()[::97], g.tensor("logits_s"))
+    diag(test="cfg4_fullsize_b16_ckpt", variants=var, logits_vs_emu=e_l16, logits_vs_fp32=e_l32, emu_vs_fp32_logits=e_l_or, layers=rows,
+         levels=levels, loss=loss_v, ref_loss=g.loss, oracle_vs_reference_grad_samples=or_vs_ref, oracle_vs_reference_logits=lg_vs_ref)
+    for r in rows:
+        print(r)
+    for k, v in levels.items():
+        print(k, v)
+    assert lg_vs_ref < 1e-4 and or_vs_ref < 5e-2, (lg_vs_ref, or_vs_ref)  # fp32-vs-fp32 on two oneDNN thread counts: flip noise only
+    assert set(levels) == {"enc0", "enc1", "enc2", "enc3", "enc4", "dec0", "dec1", "dec2", "dec3", "head"}
+    kf = STORAGE_FACTOR["bf16"]
+    for r in rows:
+        assert r["vs_emu"] < kf * LAYER_VS_EMU and r["vs_fp32"] < kf * LAYER_VS_FP32, r
+    assert e_l16 < kf * LOGITS_VS_EMU and e_l16 < 0.75 * e_l_or and e_l32 < kf * LOGITS_VS_FP32, (e_l16, e_l32, e_l_or)
+    for k, v in levels.items():
+        assert v["vs_emu"] < v["emu_vs_fp32"], (k, v)
+        assert v["vs_fp32"] < 1.1 * v["emu_vs_fp32"] + 1e-3, (k, v)
+        assert v["vs_fp32"] < kf * LEVEL_GRAD_VS_FP32[k], (k, v)
+        assert v["vs_reference_samples"] < kf * LEVEL_GRAD_VS_FP32[k], (k, v)
+    assert abs(loss_v - g.loss) < 5e-3 * max(1.0, abs(g.loss))
+
+
 @pytest.mark.timeout(1500)
 def test_config5_standard_predictor_on_the_full_volume():
     """ResidualUNetSE3D, 3 input channels, (3,96,192,192) volume, patch 48x96x96 + halo 8x16x16 (= 64x128x128 model inputs, the

@@ -180,7 +180,7 @@ def test_model_matches_cpu_oracle(cfg, shape, loss_name):
 ])
 def test_gradients_match_decision_consistent_fp64_oracle(cfg, shape, loss_name):
     """The tight gradient check: the float64 oracle with OUR ReLU masks and max-pool arg-maxes imposed
-    (oracle.forward_backward_decided) — no flip noise left, so every parameter gradient must agree to 1e-4."""
+    (oracle.forward_backward_decided) — no flip noise left, so the logits and every parameter gradient must agree to 1e-4."""
     import unet3d_oracle as orc
 
     dev = torch.device("cuda", 0)
@@ -206,14 +206,19 @@ def test_gradients_match_decision_consistent_fp64_oracle(cfg, shape, loss_name):
     eng.debug = None
     l64, _, g64 = orc.forward_backward_decided(sd, x, target, masks, argmax, cfg["num_groups"], cfg.get("final_sigmoid", True),
                                                True, loss_name)
-    assert orc.rel_err(logits.detach().cpu().double(), l64) < 1e-4
+    e_logits = orc.rel_err(logits.detach().cpu().double(), l64)
     worst = ("", 0.0)
     for k, p in model.named_parameters():
         e = orc.rel_err(p.grad.detach().cpu().double(), g64[k])
         if e > worst[1]:
             worst = (k, e)
     print(f"decision-consistent fp64 oracle: worst gradient rel err {worst[1]:.2e} ({worst[0]})")
-    assert worst[1] < 1e-3, worst
+    from conftest import diag
+
+    diag(test="decided_fp64_gate", cfg=str(cfg), shape=list(shape), logits_rel=e_logits, worst_grad_rel=worst[1], worst_param=worst[0])
+    # the docstring's 1e-4 — round 3 still asserted the north_star's 1e-3 here ("What's weak" 3); smoke() prints 1.6e-5 for
+    # its case, the per-case figures of this list are recorded by diag() (profiles/r04_parity_diag.jsonl)
+    assert e_logits < 1e-4 and worst[1] < 1e-4, (e_logits, worst)
 
 
 # |pre-activation| (relative to the layer's largest pre-activation) below which OUR ReLU mask may differ from the fp32
@@ -380,15 +385,48 @@ def test_full_size_cfg2_properties():
     assert abs(lhs2 - rhs) < 1e-4 * max(abs(lhs2), abs(rhs), 1.0)
 
 
-def test_uncovered_variant_strict_mode(monkeypatch):
-    from pytorch3dunet_amd.unet3d.model import UNet3D
+def test_uncovered_3d_variant_raises_by_default_and_runs_only_on_opt_in(monkeypatch):
+    """ONE backend by default: a 3-D model outside the executor's envelope raises on a HIP device; the module
+    tree on stock PyTorch-ROCm operators is the explicit opt-in U3D_ALLOW_TORCH_FALLBACK=1 (one warning, no native launch);
+    U3D_STRICT=1 wins over the opt-in."""
+    from pytorch3dunet_amd import _native as nat
+    from pytorch3dunet_amd.unet3d.model import ResidualUNet3D
 
     dev = torch.device("cuda", 0)
-    model = UNet3D(1, 1, f_maps=16, num_levels=3, layer_order="gcrg").to(dev).eval()  # two norms in one layer: outside engine.layer_spec
+    # dropout inside residual blocks: a configuration the reference runs (buildingblocks.py:230-288) and the executor does not cover
+    model = ResidualUNet3D(1, 1, f_maps=16, num_levels=3, layer_order="gcrd").to(dev).eval()
     assert not model.native_supported
+    x = torch.rand(1, 1, 8, 16, 16, device=dev)
+    monkeypatch.delenv("U3D_ALLOW_TORCH_FALLBACK", raising=False)
+    monkeypatch.delenv("U3D_STRICT", raising=False)
+    with pytest.raises(NotImplementedError, match="U3D_ALLOW_TORCH_FALLBACK"):
+        model(x)
+    monkeypatch.setenv("U3D_ALLOW_TORCH_FALLBACK", "1")
+    n0 = nat.launch_count
+    with pytest.warns(UserWarning, match="stock PyTorch-ROCm operators"):
+        y = model(x)
+    assert nat.launch_count == n0 and y.shape == x.shape and bool(((y >= 0) & (y <= 1)).all())
     monkeypatch.setenv("U3D_STRICT", "1")
     with pytest.raises(NotImplementedError):
-        model(torch.rand(1, 1, 8, 16, 16, device=dev))
+        model(x)
+
+
+def test_2d_models_keep_the_warning_path(monkeypatch):
+    """2-D variants (reference model.py:281-358) are outside the 3-D path: module tree + one warning by default, error under
+    U3D_STRICT=1"""
+    from pytorch3dunet_amd.unet3d.model import UNet2D
+
+    dev = torch.device("cuda", 0)
+    monkeypatch.delenv("U3D_ALLOW_TORCH_FALLBACK", raising=False)
+    monkeypatch.delenv("U3D_STRICT", raising=False)
+    model = UNet2D(1, 1, f_maps=8, num_levels=2, num_groups=4).to(dev).eval()
+    x = torch.rand(1, 1, 16, 16, device=dev)  # (N, C, H, W): the trainer squeezes z for 2-D models (trainer.py:352-360)
+    with pytest.warns(UserWarning, match="2-D model"):
+        y = model(x)
+    assert y.shape == x.shape
+    monkeypatch.setenv("U3D_STRICT", "1")
+    with pytest.raises(NotImplementedError):
+        model(x)
 
 
 @pytest.mark.parametrize("name,levels,shape", [("UNet3D", 4, (1, 1, 8, 8, 8)), ("UNet3D", 3, (3, 1, 4, 12, 20)),

@@ -385,6 +385,7 @@ def test_trailing_dropout_native_draws_the_reference_masks(order, monkeypatch):
     torch.manual_seed(61)
     model = UNet3D(**cfg).to(U.DEV).train()
     assert model.native_supported, model._native_blockers
+    monkeypatch.setenv("U3D_ALLOW_TORCH_FALLBACK", "1")  # the 'tree' leg below is the explicit opt-in (default: error)
     x = torch.randn(2, 1, 8, 16, 16, device=U.DEV)
     target = (torch.rand(2, 1, 8, 16, 16, device=U.DEV) > 0.5).float()
     res = {}
