@@ -705,6 +705,14 @@ class UNet3DEngine:
         for (w, mode), buf in zip(stale, bufs):
             self._pack_cache[(id(w), mode)] = (self._ver(w), buf)
 
+    def graph_pins(self) -> list:
+        """every lazily built device buffer a captured step may dereference (GraphStep keeps this list alive): the pack descriptor
+        tables with their packed images, the packed images in `_pack_cache`, the constant tables"""
+        pins = [list(getattr(self, name, {}).values()) for name in ("_pack_tables", "_pack_tables_bf16")]
+        pins.append([hit[1] for hit in self._pack_cache.values()])
+        pins.append(list(self._const.values()))
+        return pins
+
     def _packed_sub(self, rec: ConvRec, mode: int, dev) -> torch.Tensor:
         """packed image of a sub-pixel layer (modes 10..13); normally current from the forward's batch pack"""
         w = rec.conv_w
@@ -2079,8 +2087,44 @@ class GraphStep:
             self.logits, self.probs, self.tape = engine.forward(self.static_x, True)
         self.static_dl = torch.zeros_like(self.logits)
         self.g_bwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_bwd, pool=self.pool, capture_error_mode="thread_local"):
-            self.flat, self.dx = engine.backward(self.tape, self.static_dl, need_dx)
+        # Data parallelism (parallel.GradSync attached): RCCL launches cannot live inside a captured graph that is replayed with
+        # other buckets in flight, so the backward is captured as TWO graphs that meet exactly where engine.backward hands the
+        # [decoders | head] bucket to RCCL — `_CaptureSplit.launch` ends the first capture and begins the second on the same stream
+        # and pool; replay() issues the real all-reduces eagerly between / after the two replays (trainer.py:202-205 is the loop
+        # this serves: one gradient exchange per step, overlapped with the encoder backward).
+        self.g_bwd2 = None
+        self.sync = engine.grad_sync
+        self.buckets: list = []
+        if self.sync is not None:
+            self.g_bwd2 = torch.cuda.CUDAGraph()
+            engine.grad_sync = _CaptureSplit(self)
+        try:
+            if self.g_bwd2 is None:
+                with torch.cuda.graph(self.g_bwd, pool=self.pool, capture_error_mode="thread_local"):
+                    self.flat, self.dx = engine.backward(self.tape, self.static_dl, need_dx)
+            else:
+                # what `torch.cuda.graph` does, by hand: its __exit__ would call capture_end() on the graph it was given, but by then
+                # the capture has moved on to the second graph
+                torch.cuda.synchronize(dev)
+                torch.cuda.empty_cache()
+                cap = torch.cuda.Stream(dev)
+                with torch.cuda.stream(cap):
+                    self.g_bwd.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+                    try:
+                        self.flat, self.dx = engine.backward(self.tape, self.static_dl, need_dx)
+                    finally:
+                        (self.g_bwd2 if self.buckets else self.g_bwd).capture_end()
+                torch.cuda.synchronize(dev)
+                if len(self.buckets) != 2:
+                    raise RuntimeError(f"u3d hip_graph: engine.backward launched {len(self.buckets)} gradient buckets during capture, expected 2")
+        finally:
+            engine.grad_sync = self.sync
+        # Strong references to every PRE-CAPTURE device buffer the graphs dereference: the pack descriptor
+        # tables' only other owner is a one-entry dict that the next eager forward with a different stale set clears
+        # (`tab.clear()` in _repack_all / _repack_bf16_all: validation between training steps does exactly that), the packed
+        # images can be replaced in `_pack_cache`, constants can be rebuilt — the caching allocator (or torch.cuda.empty_cache())
+        # would then hand the blocks to someone else while every later replay still reads / writes them.
+        self._pins = engine.graph_pins()
 
     def forward(self, x: torch.Tensor):
         self.static_x.copy_(x)
@@ -2095,7 +2139,31 @@ class GraphStep:
                                "U3D_GRAPH=0 for interleaved graphs)")
         self.static_dl.copy_(dlogits)
         self.g_bwd.replay()
+        if self.g_bwd2 is not None:
+            n_enc = self.engine.n_enc_params
+            self.sync.launch(self.flat[n_enc:])   # [decoders | head]: final here, exchanged while the encoder graph runs
+            self.g_bwd2.replay()
+            self.sync.launch(self.flat[:n_enc])
+            self.sync.finish()
         return self.flat.clone(), (self.dx.clone() if self.dx is not None else None)
+
+
+class _CaptureSplit:
+    """stands in for parallel.GradSync while GraphStep captures the backward: the first `launch` (the decoder + head bucket,
+    engine.backward) is the cut between the two backward graphs; the second launch and `finish` happen after the capture"""
+
+    def __init__(self, step: "GraphStep"):
+        self.step = step
+
+    def launch(self, bucket: torch.Tensor) -> None:
+        st = self.step
+        st.buckets.append(bucket)
+        if len(st.buckets) == 1:
+            st.g_bwd.capture_end()
+            st.g_bwd2.capture_begin(pool=st.pool, capture_error_mode="thread_local")
+
+    def finish(self) -> None:
+        pass
 
 
 class _GraphedUNet3DFunction(torch.autograd.Function):
@@ -2106,6 +2174,9 @@ class _GraphedUNet3DFunction(torch.autograd.Function):
         with step.engine._lock:
             logits, probs = step.forward(x)
             ctx.gen = step.gen
+        # as in _UNet3DFunction: an in-place weight update between this forward and its backward is refused — the backward graph
+        # would mix packed images of the old weights (data gradients) with raw reads of the new ones (1x1x1 convs, head)
+        ctx.pversions = [p._version for p in step.engine.params]
         ctx.step = step
         ctx.has_probs = probs is not None
         ctx.x_requires_grad = x.requires_grad
@@ -2119,6 +2190,11 @@ class _GraphedUNet3DFunction(torch.autograd.Function):
         step = ctx.step
         engine = step.engine
         probs = ctx.saved_tensors[0] if ctx.has_probs else None
+        for p, v in zip(engine.params, ctx.pversions):
+            if p._version != v:
+                raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace operation: "
+                                   f"a parameter of shape {tuple(p.shape)} is at version {p._version}, expected version {v} "
+                                   "(u3d hip_graph: the weights changed between this forward and its backward)")
         dlogits = grads[0]
         if ctx.has_probs and len(grads) > 1 and grads[1] is not None:
             gp = grads[1]
@@ -2145,8 +2221,6 @@ def _graph_blocker(engine: UNet3DEngine) -> Optional[str]:
     order = getattr(engine.model, "layer_order", "gcr")
     if any(ch in order for ch in "bdD"):
         return f"layer_order '{order}': BatchNorm reads its step counter on the host, dropout draws a fresh mask per step"
-    if engine.grad_sync is not None:
-        return "data-parallel gradient exchange attached (RCCL launches stay eager)"
     if engine.debug is not None or nat.profiler is not None or _POISON:
         return "debug / profiler / poison mode"
     return None
@@ -2168,7 +2242,7 @@ def graph_step_for(engine: UNet3DEngine, x: torch.Tensor) -> Optional[GraphStep]
         return None
     # (the graphs bake the parameters' storage pointers in: first + last pointer is the cheap sentinel that check_placement uses too —
     # module.to() / load_state_dict(assign=True) move all of them, and the executor itself is rebuilt when parameter OBJECTS change)
-    key = (tuple(x.shape), bool(x.requires_grad), engine.params[0].data_ptr(), engine.params[-1].data_ptr())
+    key = (tuple(x.shape), bool(x.requires_grad), engine.params[0].data_ptr(), engine.params[-1].data_ptr(), id(engine.grad_sync))
     step = engine._graph_steps.get(key)
     if step is None:
         while len(engine._graph_steps) >= _GRAPH_MAX_SHAPES:

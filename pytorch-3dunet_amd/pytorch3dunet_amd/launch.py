@@ -16,8 +16,8 @@ feed every rank the same patches (datasets/utils.py:399-422).  This launcher fix
      over the same `ConcatDataset` (same batch size, workers and collate function), staged through `DevicePrefetcher` on HIP;
   4. `parallel.attach(model)`: rank 0's parameters (after `resume` / `pre_trained`) are broadcast, the gradient all-reduce is
      overlapped with the encoder backward (RCCL over xGMI; gloo + hooks for `device: cpu`);
-  5. the validation score is averaged over ranks (every rank validates its shard), so `ReduceLROnPlateau` and the best-score
-     bookkeeping agree everywhere; only rank 0 writes checkpoints, TensorBoard events and the config copy.
+  5. the validation score is the SAMPLE-WEIGHTED mean over ranks (every rank validates its unpadded shard), i.e. the single-process
+     score, so `ReduceLROnPlateau` and the best-score bookkeeping agree everywhere and with a one-process run; only rank 0 writes checkpoints, TensorBoard events and the config copy.
 """
 from __future__ import annotations
 
@@ -109,17 +109,48 @@ class _NullWriter:
         return lambda *a, **k: None
 
 
-class ShardedLoader:
-    """A DataLoader over the SAME dataset, batch size, workers and collate function as the reference's, with a
-    `DistributedSampler` (padded to equal length: every rank runs the same number of iterations, so the collectives pair up);
-    a new epoch — one pass of `UNetTrainer.train`, trainer.py:231 — reshuffles with the epoch number as torch DDP recipes do."""
+class _UnpaddedShard:
+    """Sampler of the VALIDATION shard of one rank: indices rank, rank + world, ... of the (optionally shuffled) dataset order, NOT
+    padded with duplicates — ranks may hold different numbers of samples (validation runs no collective per batch), and the
+    sample-weighted reduction in `create_distributed_trainer` then reproduces the single-process average exactly."""
 
-    def __init__(self, loader, rank: int, world: int, seed: int = 0):
+    def __init__(self, n: int, rank: int, world: int, shuffle: bool, seed: int):
+        self.n, self.rank, self.world, self.shuffle, self.seed, self.epoch = n, rank, world, shuffle, seed, 0
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = epoch
+
+    def __len__(self):
+        return len(range(self.rank, self.n, self.world))
+
+    def __iter__(self):
+        import torch
+
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.seed + self.epoch)
+            order = torch.randperm(self.n, generator=g).tolist()
+        else:
+            order = list(range(self.n))
+        return iter(order[self.rank :: self.world])
+
+
+class ShardedLoader:
+    """A DataLoader over the SAME dataset, batch size, workers and collate function as the reference's, sharded per rank.
+    Training: `DistributedSampler`, padded to equal length — every rank runs the same number of iterations, so the gradient
+    collectives pair up; a new epoch (one pass of `UNetTrainer.train`, trainer.py:231) reshuffles with the epoch number as torch
+    DDP recipes do.  Validation (`pad=False`): `_UnpaddedShard` — no duplicated samples, so the rank-weighted score equals the
+    single-process one."""
+
+    def __init__(self, loader, rank: int, world: int, seed: int = 0, pad: bool = True):
         from torch.utils.data import DataLoader, RandomSampler
         from torch.utils.data.distributed import DistributedSampler
 
         shuffle = isinstance(loader.sampler, RandomSampler)
-        self.sampler = DistributedSampler(loader.dataset, num_replicas=world, rank=rank, shuffle=shuffle, seed=seed, drop_last=False)
+        if pad or len(loader.dataset) < world:  # (fewer samples than ranks: an empty shard would have no score at all)
+            self.sampler = DistributedSampler(loader.dataset, num_replicas=world, rank=rank, shuffle=shuffle, seed=seed, drop_last=False)
+        else:
+            self.sampler = _UnpaddedShard(len(loader.dataset), rank, world, shuffle, seed)
         kw = dict(batch_size=loader.batch_size, sampler=self.sampler, num_workers=loader.num_workers, collate_fn=loader.collate_fn,
                   pin_memory=loader.pin_memory, drop_last=loader.drop_last, timeout=loader.timeout,
                   worker_init_fn=loader.worker_init_fn)
@@ -140,14 +171,40 @@ class ShardedLoader:
         return iter(self.loader)
 
 
+class _CountingLoader:
+    """outermost wrapper of the validation loader: counts the samples of the batches the trainer actually CONSUMED in the current
+    pass (`UNetTrainer._batch_size`, trainer.py:370-379: the first dimension of the input) — the weight of this rank's score"""
+
+    def __init__(self, loader):
+        self.loader = loader
+        self.samples = 0
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __getattr__(self, name):
+        return getattr(self.loader, name)
+
+    def __iter__(self):
+        self.samples = 0
+        for batch in self.loader:
+            first = batch[0] if isinstance(batch, (list, tuple)) else batch
+            while isinstance(first, (list, tuple)):
+                first = first[0]
+            self.samples += int(first.shape[0])  # every batch handed out is scored before the trainer's `break` test (trainer.py:329-341)
+            yield batch
+
+
 def shard_loaders(loaders: dict, rank: int, world: int, seed: int = 0, device: str = "cpu", prefetch: bool = True) -> dict:
     out = {}
     for phase, loader in loaders.items():
-        ld = ShardedLoader(loader, rank, world, seed) if world > 1 else loader
+        ld = ShardedLoader(loader, rank, world, seed, pad=(phase != "val")) if world > 1 else loader
         if prefetch and str(device) == "cuda":
             from .data import DevicePrefetcher
 
             ld = DevicePrefetcher(ld, "cuda")
+        if phase == "val" and world > 1:
+            ld = _CountingLoader(ld)
         out[phase] = ld
     return out
 
@@ -183,10 +240,17 @@ def create_distributed_trainer(config: dict, prefetch: bool = True):
         validate = trainer.validate
 
         def validate_all_ranks():
+            # Sample-weighted mean over the WHOLE validation set: every rank's `val_scores.avg` (trainer.py:309-349, a
+            # running average weighted by batch size) times the samples it consumed, summed over ranks, divided by the total — the
+            # number a single process computes over the same data, so ReduceLROnPlateau and the best-checkpoint decision
+            # (trainer.py:254-262) do not depend on the number of ranks.  (Image logging indices, `max_val_images`, stay per shard:
+            # rank 0 logs images of ITS shard.)
             score = validate()
-            t = torch.tensor([float(score)], dtype=torch.float64, device="cuda" if device == "cuda" else "cpu")
+            val = trainer.loaders.get("val")
+            n = val.samples if isinstance(val, _CountingLoader) else 1
+            t = torch.tensor([float(score) * n, float(n)], dtype=torch.float64, device="cuda" if device == "cuda" else "cpu")
             dist.all_reduce(t)
-            return t.item() / world
+            return (t[0] / t[1]).item()
 
         trainer.validate = validate_all_ranks
         if rank != 0:

@@ -60,7 +60,7 @@ class TreeSync(GradSync):
     variant the native executor does not cover (2-D models, …): post-accumulate-grad hooks count the parameters of each bucket;
     when the last gradient of [decoders | head] has been accumulated its flat copy is all-reduced asynchronously while autograd
     is still inside the encoders, the encoder bucket follows, and the averaged values are written back into `.grad` before
-    `loss.backward()` returns.  (The native executor does not go through these hooks: it hands RCCL slices of its own flat
+    `loss.backward()` returns (autograd's end-of-pass callback).  (The native executor does not go through these hooks: it hands RCCL slices of its own flat
     gradient buffer, engine.py.)  Every parameter that requires grad must take part in the loss, like under torch DDP
     without `find_unused_parameters`."""
 
@@ -73,6 +73,7 @@ class TreeSync(GradSync):
         self.buckets = [[p for p in params if id(p) not in enc_ids], [p for p in params if id(p) in enc_ids]]
         self._left = [len(b) for b in self.buckets]
         self._flat: List[Optional[torch.Tensor]] = [None, None]
+        self._in_backward = False
         self._handles = []
         for bi, bucket in enumerate(self.buckets):
             for p in bucket:
@@ -87,22 +88,41 @@ class TreeSync(GradSync):
     def _ready(self, bi: int) -> None:
         if self.world == 1 and not self.force_single:
             return
+        if not self._in_backward:
+            # first gradient of this backward pass: start from full counters, and have autograd call back when the pass is over
+            self._in_backward = True
+            self._left = [len(b) for b in self.buckets]
+            self._flat = [None, None]
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
         self._left[bi] -= 1
         if self._left[bi] == 0:
             flat = torch.cat([p.grad.reshape(-1) for p in self.buckets[bi]])
             self._flat[bi] = flat
             self.launch(flat)
-        if all(n <= 0 for n in self._left):
-            self.finish()
-            with torch.no_grad():
-                for bucket, flat in zip(self.buckets, self._flat):
-                    o = 0
-                    for p in bucket:
-                        n = p.grad.numel()
-                        p.grad.copy_(flat[o:o + n].view_as(p.grad))
-                        o += n
+
+    def _end_of_backward(self) -> None:
+        """autograd's end-of-pass callback: every bucket must be complete — a parameter without a gradient in this pass (an unused
+        branch, a loss over a subset of the outputs) would otherwise leave its bucket unsent HERE and fire it in the middle of the
+        NEXT backward on partial gradients, pairing different buckets across ranks.  Like torch DDP without
+        `find_unused_parameters`, that is an error, raised on the pass that caused it."""
+        self._in_backward = False
+        left, self._left = self._left, [len(b) for b in self.buckets]
+        if any(n != 0 for n in left):
+            self._pending.clear()  # (a launched bucket's result is dropped: the step is invalid on this rank)
             self._flat = [None, None]
-            self._left = [len(b) for b in self.buckets]
+            missing = [f"{n} of {len(b)} parameters of {name}" for n, b, name in zip(left, self.buckets, ("[decoders | head]", "[encoders]")) if n]
+            raise RuntimeError("u3d TreeSync: this backward pass produced no gradient for " + " and ".join(missing) +
+                               " — every parameter that requires grad must take part in the loss (the gradient exchange is "
+                               "bucketed; torch DDP raises for unused parameters in the same situation)")
+        self.finish()
+        with torch.no_grad():
+            for bucket, flat in zip(self.buckets, self._flat):
+                o = 0
+                for p in bucket:
+                    n = p.grad.numel()
+                    p.grad.copy_(flat[o:o + n].view_as(p.grad))
+                    o += n
+        self._flat = [None, None]
 
     def detach(self) -> None:
         for h in self._handles:

@@ -116,6 +116,9 @@ class AbstractUNet(nn.Module):
         self._residual = basic_module in (ResNetBlock, ResNetBlockSE)
         self._engine = None
         self._warned = False
+        self._engine_stale = False
+        # any load_state_dict on this module may have replaced parameter objects (assign=True): re-walk them on the next forward
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: object.__setattr__(module, "_engine_stale", True))
 
     # ------------------------------------------------------------------------------------------------
     @property
@@ -134,13 +137,21 @@ class AbstractUNet(nn.Module):
         eng = self.__dict__.get("_engine")
         if eng is not None and eng.model is self:
             # cheap per-forward sentinel (this path is host-bound for small patches): the first and the last parameter OBJECT of the
-            # module order; wholesale replacement (load_state_dict(assign=True), parametrizations) changes both.  The full walk
-            # runs only when the sentinel moved
+            # module order; wholesale replacement (load_state_dict(assign=True), parametrizations) changes both.  A replaced MIDDLE
+            # parameter (`module.weight = nn.Parameter(...)`, a partial load_state_dict(assign=True, strict=False), weight surgery)
+            # is caught by the full identity walk, which runs when the sentinel moved, right after any load_state_dict on this
+            # module (post-hook below) and otherwise every 16th forward — i.e. such an edit is seen at once through
+            # load_state_dict and within 16 forwards through plain attribute assignment (call
+            # `invalidate_native_caches()` after weight surgery to force it immediately)
             fc = self.final_conv
             last = fc.bias if fc.bias is not None else fc.weight
             owner = eng._first_param_owner  # (None on an nn.DataParallel replica: its parameters are plain attributes)
-            if owner is not None and id(last) == eng._pids[-1] and id(owner._parameters.get(eng._first_param_name)) == eng._pids[0]:
+            eng._fwd_checks = getattr(eng, "_fwd_checks", 0) + 1
+            stale = self.__dict__.get("_engine_stale", False) or (eng._fwd_checks & 15) == 0
+            if (not stale and owner is not None and id(last) == eng._pids[-1]
+                    and id(owner._parameters.get(eng._first_param_name)) == eng._pids[0]):
                 return eng
+            object.__setattr__(self, "_engine_stale", False)
             if eng._pids == [id(p) for p in module_params(self)]:
                 return eng
         new = (ResUNetEngine if self._residual else UNet3DEngine)(self)
@@ -153,6 +164,7 @@ class AbstractUNet(nn.Module):
         """Drop the executor's packed weight images.  Needed only after writing parameters through `param.data` (which autograd's
         version counter does not see) while the model is in inference use; training forwards repack every step anyway."""
         eng = self.__dict__.get("_engine")
+        object.__setattr__(self, "_engine_stale", True)  # also re-walk the parameter identities on the next forward
         if eng is not None:
             eng._salt += 1
 

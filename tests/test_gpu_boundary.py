@@ -268,6 +268,64 @@ print("RESULT " + json.dumps(res))
 
 
 @pytest.mark.timeout(900)
+def test_hip_graph_under_a_one_rank_rccl_group_is_bitwise_the_eager_synced_run():
+    """`hip_graph` used to refuse to run with the data-parallel exchange attached (every rank paid the eager
+    host enqueue).  Now the backward is captured as two graphs cut where engine.backward hands the [decoders | head] bucket to
+    RCCL; the all-reduces are launched eagerly between / after the replays (trainer.py:202-205's loop, one process per GPU).  On
+    a 1-rank `nccl` group: three SGD steps with graphs == three eager steps with the same hooks, bit for bit (losses, gradients,
+    parameters), two collectives per backward, for UNet3D and ResidualUNet3D."""
+    code = r'''
+import os, sys, json, copy
+sys.path.insert(0, os.path.join(os.getcwd(), "pytorch-3dunet_amd"))
+import torch, torch.distributed as dist
+from pytorch3dunet_amd import parallel
+from pytorch3dunet_amd.unet3d.model import UNet3D, ResidualUNet3D
+from pytorch3dunet_amd.unet3d.losses import BCEDiceLoss
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29547")
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+res = {}
+g = torch.Generator().manual_seed(3)
+xs = [torch.randn(2, 1, 8, 16, 16, generator=g).to(dev) for _ in range(3)]
+for name, cls in (("unet", UNet3D), ("res", ResidualUNet3D)):
+    torch.manual_seed(0)
+    base = cls(1, 1, f_maps=[8, 16, 32], num_groups=4)
+    out = {}
+    for mode in ("eager", "graph"):
+        model = copy.deepcopy(base).to(dev).train()
+        if mode == "graph":
+            model.hip_graph = True
+            model._get_engine().hip_graph = True
+        sync = parallel.attach(model, force_single=True)
+        opt = torch.optim.SGD(model.parameters(), lr=1e-2, momentum=0.9)
+        crit = BCEDiceLoss()
+        losses, grads = [], []
+        for x in xs:
+            _, lg = model(x, return_logits=True)
+            loss = crit(lg, (x > 0.3).float())
+            opt.zero_grad(); loss.backward()
+            grads.append(torch.cat([p.grad.flatten() for p in model.parameters()]).clone())
+            losses.append(loss.detach().clone()); opt.step()
+        torch.cuda.synchronize()
+        eng = model._get_engine()
+        out[mode] = (losses, grads, [p.detach().clone() for p in model.parameters()], sync.launched, len(eng._graph_steps), eng._graph_off_reason)
+    e, gr = out["eager"], out["graph"]
+    res[name] = {"loss": all(torch.equal(a, b) for a, b in zip(e[0], gr[0])), "grads": all(torch.equal(a, b) for a, b in zip(e[1], gr[1])),
+                 "params": all(torch.equal(a, b) for a, b in zip(e[2], gr[2])), "launched_eager": e[3], "launched_graph": gr[3],
+                 "captured": gr[4], "off_reason": gr[5]}
+dist.destroy_process_group()
+print("RESULT " + json.dumps(res))
+'''
+    proc = _spawn([sys.executable, "-c", code], {"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    r = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    for name in ("unet", "res"):
+        # eager: 2 collectives x 3 steps; graph: + 2 of the warm-up step GraphStep runs before it captures
+        assert r[name] == {"loss": True, "grads": True, "params": True, "launched_eager": 6, "launched_graph": 8, "captured": 1,
+                           "off_reason": None}, r
+
+
+@pytest.mark.timeout(900)
 def test_bench_under_torch_distributed_run_one_rank():
     """bench.py's N>1 branch (process group, attach, barrier, max-over-ranks) through the driver's own launcher with one rank"""
     proc = _spawn([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
@@ -309,3 +367,45 @@ def test_weight_edits_through_param_data_are_seen():
         model.invalidate_native_caches()
         e1 = model(x)
     assert (e1 - e0).abs().max().item() > 1e-5
+
+
+def test_replaced_middle_parameter_objects_are_seen():
+    """the cached executor used to be re-validated by the first and last parameter object only.  A partial
+    `load_state_dict(assign=True, strict=False)` (a backbone checkpoint without the first conv and the head) is now seen on the next
+    forward (load_state_dict post-hook -> full identity walk); a plain `module.weight = nn.Parameter(...)` after
+    `invalidate_native_caches()` likewise, and within 16 forwards without it."""
+    from pytorch3dunet_amd.unet3d.model import UNet3D
+
+    DEV = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    cfg = dict(in_channels=1, out_channels=1, f_maps=[16, 32], num_groups=8)
+    model = UNet3D(**cfg).to(DEV).eval()
+    x = torch.randn(1, 1, 8, 16, 16, device=DEV)
+
+    def fresh_output():
+        ref = UNet3D(**cfg).to(DEV).eval()
+        ref.load_state_dict(model.state_dict())
+        with torch.no_grad():
+            return ref(x)
+
+    with torch.no_grad():
+        y0 = model(x)
+        eng0 = model._get_engine()
+        # 1. partial load with assign=True: only the middle layers' tensors are replaced
+        part = {k: (v + 0.05 * torch.randn_like(v)) for k, v in model.state_dict().items()
+                if not k.startswith("final_conv") and "encoders.0.basic_module.SingleConv1" not in k}
+        model.load_state_dict(part, strict=False, assign=True)
+        y1 = model(x)
+        assert model._get_engine() is not eng0 and (y1 - y0).abs().max().item() > 1e-5 and torch.equal(y1, fresh_output())
+        # 2. attribute assignment + the documented hook
+        eng1 = model._get_engine()
+        conv = model.decoders[0].basic_module.SingleConv2.conv
+        conv.weight = torch.nn.Parameter(conv.weight.detach() * 1.5 + 0.01)
+        model.invalidate_native_caches()
+        y2 = model(x)
+        assert model._get_engine() is not eng1 and (y2 - y1).abs().max().item() > 1e-5 and torch.equal(y2, fresh_output())
+        # 3. attribute assignment alone: picked up by the periodic walk
+        conv.weight = torch.nn.Parameter(conv.weight.detach() * 0.5)
+        want = fresh_output()
+        outs = [model(x) for _ in range(17)]
+        assert torch.equal(outs[-1], want)

@@ -133,6 +133,66 @@ def test_graph_misuse_raises_and_outputs_are_private_copies():
         assert torch.equal(p.grad, a)  # the same step again reproduces the first gradients bit for bit
 
 
+@pytest.mark.parametrize("name,kw", [("UNet3D", dict(f_maps=[8, 16, 32], num_groups=4)),
+                                     ("ResidualUNet3D", dict(f_maps=[64, 128], num_groups=8, num_levels=2, compute_dtype="bf16"))])
+def test_graphs_survive_validation_and_empty_cache_between_training_steps(name, kw):
+    """the captured forward graph bakes in the device pointer of the pack descriptor table, whose only other
+    owner was a one-entry dict that the first EAGER forward with a different stale set (validation between training steps,
+    trainer.py:254-262: modes (0,) instead of (0, 1)) cleared — every later replay then ran the pack kernel on freed memory, and
+    `torch.cuda.empty_cache()` (the predictor's OOM fallback calls it) or any reuse of the block made it read garbage pointers.
+    train -> eval forward -> empty_cache + allocator churn -> train must stay bitwise the eager trajectory."""
+    base = _mk(name, **kw)
+    eager = copy.deepcopy(base).to(DEV)
+    graphed = copy.deepcopy(base).to(DEV)
+    graphed.hip_graph = True
+    graphed._get_engine().hip_graph = True
+    shape = (1, 1, 16, 32, 32)
+    batches = _batches([shape] * 6, 11)
+    res = {}
+    for tag, m in (("eager", eager), ("graph", graphed)):
+        out = []
+        out.append(_train(m, batches[:3]))
+        m.eval()
+        with torch.no_grad():
+            ev = m(batches[0][0]).clone()
+        # drop everything the allocator can drop, then churn: a freed descriptor table / packed image would be handed out again
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        junk = [torch.full((n,), float("nan"), device=DEV) for n in (257, 4099, 65537, 1 << 20, 3 << 20)]
+        torch.cuda.synchronize()
+        out.append(_train(m, batches[3:]))
+        del junk
+        res[tag] = (out, ev)
+    assert len(graphed._get_engine()._graph_steps) == 1
+    assert torch.equal(res["eager"][1], res["graph"][1])
+    for phase in range(2):
+        (l0, g0), (l1, g1) = res["eager"][0][phase], res["graph"][0][phase]
+        for step, (a, b) in enumerate(zip(l0, l1)):
+            assert torch.isfinite(b) and torch.equal(a, b), (phase, step, a.item(), b.item())
+        for step, (ga, gb) in enumerate(zip(g0, g1)):
+            for (k, _), a, b in zip(eager.named_parameters(), ga, gb):
+                assert torch.equal(a, b), (phase, step, k)
+    for (k, a), (_, b) in zip(eager.named_parameters(), graphed.named_parameters()):
+        assert torch.equal(a, b), k
+
+
+def test_graphed_backward_refuses_weights_changed_since_its_forward():
+    """the graphed node gets the parameter-version check of the eager node — an in-place update between forward and
+    backward raises like stock autograd instead of mixing old packed images with new raw weights"""
+    m = _mk("UNet3D", f_maps=[8, 16], num_groups=4).to(DEV)
+    m.hip_graph = True
+    m._get_engine().hip_graph = True
+    m.train()
+    (x, t), = _batches([(1, 1, 8, 16, 16)], 3)
+    _, logits = m(x, return_logits=True)
+    with torch.no_grad():
+        m.final_conv.weight.mul_(1.5)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        logits.sum().backward()
+    _, logits = m(x, return_logits=True)  # a fresh forward -> backward pair works again
+    logits.sum().backward()
+
+
 def test_graph_mode_cuts_host_time_on_the_host_bound_shape():
     """BASELINE config 1's shape (UNet3D f_maps=16, 1x1x32x64x64) is host-bound in eager mode (~3.3 ms of ctypes + allocator work
     per step against ~3 ms of kernels, tools/host_bound_check.py); replaying two graphs must take well under a millisecond of

@@ -101,3 +101,43 @@ def test_sharded_loader_partitions_the_dataset_and_reshuffles_per_epoch():
     assert sorted(ep1[0] + ep1[1]) == list(range(10)) and ep1 != ep0  # new epoch, new permutation
     val = ShardedLoader(DataLoader(ds, batch_size=2, shuffle=False), 1, 2)
     assert torch.cat([b[0] for b in val]).flatten().tolist() == [1, 3, 5, 7, 9]  # validation order is deterministic
+
+
+def test_validation_shards_are_unpadded_and_their_weighted_score_is_the_single_process_score():
+    """the distributed validation score must be the sample-weighted mean over the validation set, not the mean of
+    per-rank averages over shards padded with duplicates.  5 samples on 2 ranks, batch 2: shards of 3 and 2 samples, no sample
+    twice; each rank's batch-size-weighted running average (what UNetTrainer.validate returns, trainer.py:309-349) times the
+    samples its `_CountingLoader` handed out, summed and divided, equals the one-process running average.  An early `break`
+    (validate_iters, trainer.py:339-341) still counts the batch that was scored."""
+    from torch.utils.data import DataLoader, TensorDataset
+
+    from pytorch3dunet_amd.launch import _CountingLoader, shard_loaders
+
+    ds = TensorDataset(torch.tensor([1.0, 10.0, 100.0, 1000.0, 10000.0]).view(5, 1))
+    base = {"train": DataLoader(ds, batch_size=2, shuffle=True), "val": DataLoader(ds, batch_size=2, shuffle=False)}
+
+    def running_avg(loader, stop_after=None):  # RunningAverage(score(batch), batch size), utils.py:69-82
+        tot = cnt = 0
+        for i, (b,) in enumerate(loader):
+            tot, cnt = tot + float(b.mean()) * b.shape[0], cnt + b.shape[0]
+            if stop_after is not None and stop_after <= i:
+                break
+        return tot / cnt
+
+    shards = [shard_loaders(base, r, 2, seed=0, device="cpu") for r in range(2)]
+    for sh in shards:
+        assert isinstance(sh["val"], _CountingLoader) and not isinstance(sh["train"], _CountingLoader)
+        assert len(sh["train"]) == 2  # training shards stay padded to equal length (3 samples each -> 2 iterations everywhere)
+    seen = [torch.cat([b[0] for b in sh["val"]]).flatten().tolist() for sh in shards]
+    assert seen == [[1.0, 100.0, 10000.0], [10.0, 1000.0]]  # disjoint, complete, nothing duplicated
+    parts = [(running_avg(sh["val"]), sh["val"].samples) for sh in shards]
+    assert [n for _, n in parts] == [3, 2]
+    weighted = sum(a * n for a, n in parts) / sum(n for _, n in parts)
+    assert abs(weighted - running_avg(base["val"])) < 1e-9 * weighted
+    plain_mean = sum(a for a, _ in parts) / 2
+    assert abs(plain_mean - running_avg(base["val"])) > 1.0  # what round 3 computed was a different number
+    running_avg(shards[0]["val"], stop_after=0)
+    assert shards[0]["val"].samples == 2  # the scored batch is counted although the pass was cut short
+    # fewer samples than ranks: padded shards (an empty shard has no score)
+    tiny = shard_loaders({"val": DataLoader(TensorDataset(torch.ones(1, 1)), batch_size=1)}, 1, 2)
+    assert sum(1 for _ in tiny["val"]) == 1

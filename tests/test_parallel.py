@@ -74,6 +74,19 @@ def _worker(rank, world, port, out):
         model(shard).mean().backward()  # gradient accumulation: avg(avg(g) + g_local) = 2 avg(g)
         twice = torch.cat([p.grad.flatten() for p in model.parameters()])
         assert torch.allclose(twice, 2 * whole, atol=2e-6, rtol=1e-4) and sync2.launched == 4
+        # a pass that leaves a bucket incomplete (here: only two head parameters get a gradient) raises at the END OF
+        # THAT PASS, launches nothing, and does not leak its counters into the next pass
+        model.zero_grad()
+        try:
+            (model.final_conv.weight.sum() + model.final_conv.bias.sum()).backward()
+            raise AssertionError("an incomplete bucket must raise")
+        except RuntimeError as e:
+            assert "produced no gradient" in str(e), e
+        assert sync2.launched == 4
+        model.zero_grad()
+        model(shard).mean().backward()
+        again = torch.cat([p.grad.flatten() for p in model.parameters()])
+        assert torch.allclose(again, whole, atol=1e-6, rtol=1e-4) and sync2.launched == 6
         out.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         out.put((rank, repr(e)))
