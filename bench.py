@@ -287,6 +287,33 @@ def main():
                                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None}
                              for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])},
             }
+        if world == 1 and not use_dist and not args.no_extras:
+            # EXTRA leg, not the contract's `value`: the SAME model, optimizer state and batch driven in the reference trainer's step
+            # order (unet3d/trainer.py:231-246): forward -> loss -> `loss.item()` (a host synchronisation EVERY iteration, :241) ->
+            # zero_grad -> backward -> optimizer step.  The headline loop above never synchronises inside a step; this leg says what
+            # the drop-in delivers through the unmodified loop ("What's missing" 3).
+            def step_ref_order():
+                probs, logits = model(x, return_logits=True)   # trainer.py:362
+                loss = criterion(logits, target)               # :365
+                val = loss.item()                              # :241 train_losses.update(loss.item(), batch size)
+                opt.zero_grad(set_to_none=True)                # :244
+                loss.backward()                                # :245
+                opt.step()                                     # :246
+                return val
+
+            for _ in range(2):
+                step_ref_order()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                last = step_ref_order()
+            torch.cuda.synchronize()
+            el_ref = time.perf_counter() - t1
+            out["extra_reference_step_order"] = {
+                "value": round(B * args.steps / el_ref, 3), "unit": "patches/s", "ms_per_step": round(1000.0 * el_ref / args.steps, 3),
+                "vs_value": round((B * args.steps / el_ref) / value, 4), "final_loss": round(last, 5),
+                "loop": "forward, loss, loss.item() host sync, zero_grad, backward, Adam step (unet3d/trainer.py:231-246), eager launches",
+            }
         if world == 1 and not use_dist and not args.no_extras and args.compute_dtype == "fp32":
             # EXTRA leg, not the contract's `value`: the same step with the opt-in fp32_split convolutions (fp32 operands split
             # exactly into three bf16 values, six partial products accumulated in fp32 on the bf16 MFMA pipe; weight gradients

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define U3D_VERSION 115 /* 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant */
+#define U3D_VERSION 115 /* 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, u3d_streams_create_reserved / u3d_stream_destroy */
 
 #define U3D_OK 0
 #define U3D_EINVAL (-1)  /* bad shape / argument */
@@ -71,6 +71,14 @@ int u3d_check_device(int device);
  * key 0: forced N-tiles per block of u3d_conv3d (1,2,3; 0 = automatic); key 1: wgrad split override; keys 2-11: see the
  * list at the top of csrc/u3d_conv.hip (16 keys; the environment variable U3D_TUNE=key:value,... sets them at load time). */
 int u3d_set_tuning(int key, int value);
+/* A CU budget for the gradient exchange of data-parallel training (the reference has one process and nn.DataParallel,
+ * trainer.py:202-205; here: one process per GPU + RCCL, parallel.py).  Creates `compute_stream` with `reserve` CUs masked out
+ * (hipExtStreamCreateWithCUMask; spread over the XCDs) and sizes the library's persistent / one-block-per-CU grids for the
+ * remaining CUs (tuning key 12): kernels of other, unmasked streams — RCCL's all-reduce — then find idle CUs instead of
+ * waiting behind persistent blocks.  `reserved_stream` (may be NULL) receives a stream confined to exactly the reserved CUs
+ * (NULL when reserve == 0).  Results never depend on it.  The caller owns the streams: u3d_stream_destroy. */
+int u3d_streams_create_reserved(int device, int reserve, u3d_stream_t* compute_stream, u3d_stream_t* reserved_stream);
+int u3d_stream_destroy(int device, u3d_stream_t stream);
 /* Developer aid (tools/wave_timeline.py): while a device buffer is registered, u3d_conv3d launches an instrumented
  * twin of the kernel in which every wave records 24 int64 (block, HW_ID, XCC_ID, shader-clock stamps at entry /
  * first tile staged / end of each chunk's k-loop / epilogue start / exit).  NULL switches it off (default). */

@@ -26,7 +26,11 @@
 //   [6] 1 = one persistent block per CU instead of two (occupancy experiment)
 //   [8] bf16 weight gradient: target number of blocks (0 = default)   [9] 1 = bf16 weight gradient without the XCD-aware block order
 //   [10] 1 = bf16-storage convolutions on 4-plane tiles only (no 8-plane tiles)   [11] 1 = x-y-z raster tile order of the bf16 kernels
-//   [12..15] free
+//   [12] CU budget left to OTHER streams (RCCL): the persistent grids and the one-block-per-CU plans are sized for (CUs - value)
+//        (u3d_streams_create_reserved sets it together with the CU-masked compute stream; results never change)
+//   [13] per-block start-phase spread of the persistent kernel: block b sleeps (b % 16) * value * 1024 cycles once (experiment)
+//   [14] timing-only ablations of the persistent kernel's epilogue: 1 = no global stores, 2 = no transposition (wrong results)
+//   [15] free
 int g_u3d_tune[16] = {0};
 
 namespace cv {
@@ -1807,6 +1811,14 @@ static int device_cu_count(int device, int* out) {
     return 0;
 }
 
+// CUs the library's own grids may count on: all of them minus the budget left to other streams (u3d_set_tuning key 12)
+static int effective_cu_count(int device, int* out) {
+    if (int e = device_cu_count(device, out)) return e;
+    const int r = g_u3d_tune[12];
+    if (r > 0 && r < *out) *out -= r;
+    return 0;
+}
+
 template <int NT>
 static int conv_set_lds_nt() {
     const int bytes = cv::LDS_FLOATS * sizeof(float);
@@ -1949,7 +1961,7 @@ static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, co
     //      summed in a fixed order by splitk_reduce_kernel together with the epilogue (key 7 = 2 turns it off)
     if (ws && p.vec && p.ovec && ((uintptr_t)ws & 15) == 0 && splitk_shape(N, D, H, W, Cin, Cout) && g_u3d_tune[7] != 2) {
         int ncu = 0;
-        if (int e = device_cu_count(device, &ncu)) return e;
+        if (int e = effective_cu_count(device, &ncu)) return e;
         const long long items = ntiles * p.ntot, out_elems = (long long)N * D * H * W * Cout;
         long long ks = (2ll * ncu) / items;
         if (ks > p.nchunks) ks = p.nchunks;
@@ -1995,7 +2007,7 @@ static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, co
         // wave that is alone on its SIMD does not run at twice the shared rate, so interleaving the epilogues buys nothing
         p.stagger = g_u3d_tune[5];
         int ncu = 0;
-        if (int e = device_cu_count(device, &ncu)) return e;
+        if (int e = effective_cu_count(device, &ncu)) return e;
         long long slots = (g_u3d_tune[6] == 1 ? 1ll : 2ll) * ncu;  // two blocks per CU (LDS); key 6 = 1: one (experiment)
         if (slots >= nblk)
             slots = nblk;
@@ -2082,15 +2094,16 @@ static void wgrad_plan(int N, int D, int H, int W, int Cin, int Cout, WgradParam
     // One 8-wave block per CU (135 KB of LDS): pick the split count S whose grid S*pairs fills whole rounds of the
     // 256 CUs best.  cost = rounds * (tiles per split + ~2 tiles of prologue / partial-sum write per block).
     const int pairs = p.nchunks * p.nkb;
+    const int ncu = 256 - ((g_u3d_tune[12] > 0 && g_u3d_tune[12] < 256) ? g_u3d_tune[12] : 0);  // (MI355X; key 12: CU budget of other streams)
     long long best_cost = -1;
     int best_S = 1;
     for (int rounds = 1; rounds <= 8; ++rounds) {
-        int S = (rounds * 256) / pairs;
+        int S = (rounds * ncu) / pairs;
         if (S < 1) S = 1;
         if (S > p.ntiles) S = p.ntiles;
         const int tps = cdiv(p.ntiles, S);
         S = cdiv(p.ntiles, tps);
-        const long long cost = (long long)cdiv(S * pairs, 256) * (tps + 2);
+        const long long cost = (long long)cdiv(S * pairs, ncu) * (tps + 2);
         if (best_cost < 0 || cost < best_cost) {
             best_cost = cost;
             best_S = S;

@@ -43,6 +43,8 @@ class U3DPackDesc(ctypes.Structure):
 _PROTOS = {
     # name: (restype, argtypes)
     "u3d_version": (c_int, []),
+    "u3d_streams_create_reserved": (c_int, [c_int, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p)]),
+    "u3d_stream_destroy": (c_int, [c_int, c_void_p]),
     "u3d_last_error": (c_char_p, []),
     "u3d_check_device": (c_int, [c_int]),
     "u3d_set_tuning": (c_int, [c_int, c_int]),

@@ -237,6 +237,9 @@ def create_distributed_trainer(config: dict, prefetch: bool = True):
         if isinstance(trainer.model, torch.nn.DataParallel):  # pragma: no cover  (pin_device prevents it)
             raise RuntimeError("several devices are visible to this rank: call launch.pin_device() before torch.cuda starts")
         trainer.grad_sync = parallel.attach(trainer.model, broadcast=True)
+        if device == "cuda":
+            # U3D_RESERVE_CUS=k: the step runs on a stream CU-masked to all but k CUs, RCCL finds those idle (parallel.reserve_cus)
+            trainer.compute_streams = parallel.reserve_cus(next(trainer.model.parameters()).device)
         validate = trainer.validate
 
         def validate_all_ranks():

@@ -8,6 +8,12 @@ link (2 * 7/8 * bytes / 153e9).  Reported per model: step time without exchange,
 (overlapped), with the stand-in on the compute stream (serialised), and the stand-in's standalone duration.
 
     python tools/overlap_probe.py            # BASELINE configs 2 and 4
+    python tools/overlap_probe.py --reserve 8 [--only 4]
+
+--reserve k (round 4): the step runs on a stream CU-masked to all but k CUs (`parallel.reserve_cus`: the library sizes its
+persistent grids for 256 - k) and the stand-in runs on a stream confined to exactly those k CUs — RCCL's kernels are link-bound and
+need few CUs, so the stand-in is re-sized on ITS CUs: as many passes as take the ring all-reduce's time there.  Reported in
+addition: the step time without any exchange at 256 CUs, i.e. what the budget itself costs.
 """
 import os
 import sys
@@ -24,16 +30,32 @@ dev = torch.device("cuda", 0)
 
 
 class StandIn:
-    def __init__(self, side: bool, gbps: float = 153.0):
-        self.side = torch.cuda.Stream(dev) if side else None
+    def __init__(self, side: bool, gbps: float = 153.0, side_stream=None):
+        self.side = (side_stream or torch.cuda.Stream(dev)) if side else None
         self.gbps = gbps
         self.pending = False
         self.ms_target = 0.0
+        self.pass_tbps = 4.0  # in-place pass rate on the stream the stand-in runs on (calibrate() measures it on a CU-masked stream)
+
+    def calibrate(self, bucket):
+        """measured rate of one in-place pass over `bucket` on the stand-in's own stream (a few reserved CUs stream far below 4 TB/s)"""
+        s = self.side or torch.cuda.current_stream(dev)
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                bucket.mul_(1.0)
+            s.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                bucket.mul_(1.0)
+            s.synchronize()
+            dt = (time.perf_counter() - t0) / 4
+        self.pass_tbps = 2 * bucket.numel() * 4 / dt / 1e12
+        return self.pass_tbps
 
     def passes_for(self, bucket):
-        # one in-place pass moves 2 x bytes at ~4 TB/s; the exchange takes 2 * 7/8 * bytes / link rate
+        # one in-place pass moves 2 x bytes at pass_tbps; the exchange takes 2 * 7/8 * bytes / link rate
         t_x = 2 * 7 / 8 * bucket.numel() * 4 / (self.gbps * 1e9)
-        t_pass = 2 * bucket.numel() * 4 / 4.0e12
+        t_pass = 2 * bucket.numel() * 4 / (self.pass_tbps * 1e12)
         return max(1, int(round(t_x / t_pass)))
 
     def launch(self, bucket):
@@ -56,7 +78,10 @@ class StandIn:
             self.pending = False
 
 
-def run(name, cfg, shape, steps=8):
+def run(name, cfg, shape, steps=8, reserve=0):
+    from pytorch3dunet_amd import _native as nat
+    from pytorch3dunet_amd import parallel
+
     torch.manual_seed(0)
     model = get_model(cfg).to(dev).train()
     x = torch.randn(shape, device=dev)
@@ -69,9 +94,10 @@ def run(name, cfg, shape, steps=8):
         _, logits = model(x, return_logits=True)
         crit(logits, t).backward()
 
-    out = {}
-    for mode in ("none", "side", "serial"):
-        eng.grad_sync = None if mode == "none" else StandIn(side=(mode == "side"))
+    def timed(mode, side_stream=None, tbps=None):
+        eng.grad_sync = None if mode == "none" else StandIn(side=(mode == "side"), side_stream=side_stream)
+        if tbps is not None and eng.grad_sync is not None:
+            eng.grad_sync.pass_tbps = tbps
         for _ in range(3):
             step()
         torch.cuda.synchronize()
@@ -79,18 +105,48 @@ def run(name, cfg, shape, steps=8):
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
-        out[mode] = 1e3 * (time.perf_counter() - t0) / steps
+        return 1e3 * (time.perf_counter() - t0) / steps
+
+    out = {}
+    full = timed("none")  # all CUs, no exchange: the reference point for what a budget costs
+    comp = res = None
+    tbps = None
+    default_stream = torch.cuda.current_stream(dev)
+    if reserve > 0:
+        comp, res = parallel.reserve_cus(dev, reserve)  # becomes the current stream; tuning key 12 = reserve
+        probe = StandIn(side=True, side_stream=res)
+        n_enc = eng.n_enc_params
+        tbps = probe.calibrate(torch.zeros(eng.n_params - n_enc, device=dev))
+    for mode in ("none", "side", "serial"):
+        out[mode] = timed(mode, side_stream=res, tbps=tbps if mode == "side" else None)
     eng.grad_sync = None
     n_enc = eng.n_enc_params
     flat = torch.zeros(eng.n_params, device=dev)
-    s = StandIn(side=False)
+    s = StandIn(side=res is not None, side_stream=res)
+    if tbps is not None:
+        s.pass_tbps = tbps
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(5):
         s.launch(flat[n_enc:])
         s.launch(flat[:n_enc])
+        s.finish()
     torch.cuda.synchronize()
     alone = 1e3 * (time.perf_counter() - t0) / 5
+    if reserve > 0:
+        # with a budget the stand-in's cost when NOT hidden is its standalone duration on its own CUs
+        hidden = 1.0 - (out["side"] - out["none"]) / max(alone, 1e-9)
+        print(f"{name} [reserve {reserve} CUs]: step {full:.2f} ms on all CUs without exchange -> {out['none']:.2f} ms on {256 - reserve} CUs "
+              f"(the budget costs {100 * (out['none'] / full - 1):.1f} %); with the stand-in on the {reserve} reserved CUs {out['side']:.2f} ms; "
+              f"stand-in alone on those CUs {alone:.2f} ms at {tbps:.2f} TB/s per pass -> {100 * hidden:.0f} % of it hidden; "
+              f"net vs unhidden exchange on all CUs ({full + alone:.2f} ms): {out['side']:.2f} ms", flush=True)
+        torch.cuda.set_stream(default_stream)
+        nat.call("u3d_set_tuning", 12, 0)
+        torch.cuda.synchronize()
+        for st in (comp, res):
+            if st is not None:
+                nat.call("u3d_stream_destroy", dev.index, st.cuda_stream)
+        return
     hidden = (out["serial"] - out["side"]) / max(out["serial"] - out["none"], 1e-9)
     print(f"{name}: params {eng.n_params / 1e6:.1f} M (decoder+head bucket {(eng.n_params - n_enc) * 4 / 1e6:.0f} MB, encoder bucket "
           f"{n_enc * 4 / 1e6:.0f} MB); step {out['none']:.2f} ms without exchange, {out['side']:.2f} ms with the stand-in on a side stream, "
@@ -98,8 +154,18 @@ def run(name, cfg, shape, steps=8):
 
 
 if __name__ == "__main__":
-    run("config 2 (UNet3D f_maps=32, 2x1x64x128x128, fp32)",
-        dict(name="UNet3D", in_channels=1, out_channels=1, f_maps=32, num_groups=8, final_sigmoid=True), (2, 1, 64, 128, 128))
-    run("config 4 (ResidualUNet3D f_maps=64, 1x80x160x160, bf16)",
-        dict(name="ResidualUNet3D", in_channels=1, out_channels=1, f_maps=64, num_groups=8, final_sigmoid=True, compute_dtype="bf16"),
-        (1, 1, 80, 160, 160))
+    import argparse
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reserve", type=int, nargs="*", default=[0])
+    ap.add_argument("--only", type=int, default=0, help="2 or 4: just that BASELINE config")
+    a = ap.parse_args()
+    for r in a.reserve:
+        if a.only in (0, 2):
+            run("config 2 (UNet3D f_maps=32, 2x1x64x128x128, fp32)",
+                dict(name="UNet3D", in_channels=1, out_channels=1, f_maps=32, num_groups=8, final_sigmoid=True), (2, 1, 64, 128, 128),
+                reserve=r)
+        if a.only in (0, 4):
+            run("config 4 (ResidualUNet3D f_maps=64, 1x80x160x160, bf16)",
+                dict(name="ResidualUNet3D", in_channels=1, out_channels=1, f_maps=64, num_groups=8, final_sigmoid=True,
+                     compute_dtype="bf16"), (1, 1, 80, 160, 160), reserve=r)
