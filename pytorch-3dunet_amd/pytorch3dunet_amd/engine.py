@@ -100,6 +100,18 @@ def module_params(module) -> list:
     return out
 
 
+class StaleParameters(KeyError):
+    """a module of the tree holds a parameter OBJECT this executor was not built with (`module.weight = nn.Parameter(...)`, weight
+    surgery): the model rebuilds its executor and runs the forward again (unet3d/model.py)"""
+
+
+class _PIndex(dict):
+    """parameter object id -> position in `engine.params`; a miss means the module tree changed under the executor"""
+
+    def __missing__(self, key):
+        raise StaleParameters("u3d: a parameter object of the module tree is not one this executor was built with")
+
+
 class _Ref:
     """placeholder of a tensor inside a stashed tape: index into ctx.saved_tensors, or into engine.params"""
 
@@ -463,7 +475,7 @@ class UNet3DEngine:
         # where the first parameter lives (model._get_engine's sentinel reads it back without walking the module tree)
         self._first_param_owner, self._first_param_name = next(
             ((mod, name) for mod in model.modules() for name, p in mod._parameters.items() if p is self.params[0]), (None, None))
-        self._pindex = {id(p): i for i, p in enumerate(self.params)}
+        self._pindex = _PIndex({id(p): i for i, p in enumerate(self.params)})
         self._build_layer_table(model)
         self._virtual_w = self._virtual_weights()
         # split point of the flat gradient buffer: encoders first (module order), then decoders + head

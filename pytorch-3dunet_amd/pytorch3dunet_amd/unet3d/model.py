@@ -178,9 +178,16 @@ class AbstractUNet(nn.Module):
     def _forward_logits(self, x):
         if x.is_cuda:
             if self.native_supported and x.dtype == torch.float32 and x.dim() == 5:
-                from ..engine import run_model
+                from ..engine import StaleParameters, run_model
 
-                return run_model(self._get_engine(), x)
+                try:
+                    return run_model(self._get_engine(), x)
+                except StaleParameters:
+                    # a parameter OBJECT was replaced since the executor was built (`module.weight = nn.Parameter(...)`): the cheap
+                    # per-forward sentinel of _get_engine only watches the first and the last one.  Rebuild and run again — nothing
+                    # was handed to the caller yet
+                    object.__setattr__(self, "_engine_stale", True)  # -> full identity walk -> new executor (keeps the grad_sync hook)
+                    return run_model(self._get_engine(), x)
             why = ", ".join(self._native_blockers) or f"input dtype/rank {x.dtype}/{x.dim()}"
             eng = self.__dict__.get("_engine")
             if eng is not None and eng.grad_sync is not None and torch.is_grad_enabled():

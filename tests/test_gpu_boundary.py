@@ -373,7 +373,8 @@ def test_replaced_middle_parameter_objects_are_seen():
     """the cached executor used to be re-validated by the first and last parameter object only.  A partial
     `load_state_dict(assign=True, strict=False)` (a backbone checkpoint without the first conv and the head) is now seen on the next
     forward (load_state_dict post-hook -> full identity walk); a plain `module.weight = nn.Parameter(...)` after
-    `invalidate_native_caches()` likewise, and within 16 forwards without it."""
+    `invalidate_native_caches()` likewise; without it a conv / norm parameter is missed by the executor's index at once (rebuild +
+    re-run), anything else within 16 forwards."""
     from pytorch3dunet_amd.unet3d.model import UNet3D
 
     DEV = torch.device("cuda", 0)
@@ -404,8 +405,11 @@ def test_replaced_middle_parameter_objects_are_seen():
         model.invalidate_native_caches()
         y2 = model(x)
         assert model._get_engine() is not eng1 and (y2 - y1).abs().max().item() > 1e-5 and torch.equal(y2, fresh_output())
-        # 3. attribute assignment alone: picked up by the periodic walk
+        # 3. attribute assignment alone: a conv / norm parameter the executor indexes is missed at once (StaleParameters -> rebuild),
+        #    anything else by the periodic walk at the latest
+        eng2 = model._get_engine()
         conv.weight = torch.nn.Parameter(conv.weight.detach() * 0.5)
         want = fresh_output()
+        assert torch.equal(model(x), want) and model._get_engine() is not eng2
         outs = [model(x) for _ in range(17)]
         assert torch.equal(outs[-1], want)

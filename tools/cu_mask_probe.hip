@@ -46,6 +46,38 @@ static int run(const char* name, hipStream_t s, unsigned* dbuf, int blocks) {
     return 0;
 }
 
+__global__ void empty_kernel() {}
+__global__ void busy_kernel(float* p, int n) {
+    float a = p[threadIdx.x & 63];
+    for (int i = 0; i < n; ++i) a = a * 1.0001f + 0.5f;
+    if (a == 123.f) p[0] = a;
+}
+
+// per-launch cost of back-to-back launches on a stream: `n` empty kernels, and `n` kernels of ~50 us that fill every CU
+static int launch_cost(const char* name, hipStream_t s, float* buf) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int busy = 0; busy < 2; ++busy) {
+        const int n = busy ? 200 : 2000;
+        for (int rep = 0; rep < 2; ++rep) {  // first repetition warms up
+            CK(hipEventRecord(e0, s));
+            for (int i = 0; i < n; ++i) {
+                if (busy)
+                    hipLaunchKernelGGL(busy_kernel, dim3(1024), dim3(256), 0, s, buf, 20000);
+                else
+                    hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s);
+            }
+            CK(hipEventRecord(e1, s));
+            CK(hipStreamSynchronize(s));
+            float ms = 0.f;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep) printf("%-28s: %s %.2f us per launch\n", name, busy ? "chip-filling kernel," : "empty kernel,       ", 1e3 * ms / n);
+        }
+    }
+    return 0;
+}
+
 int main() {
     int ncu = 0;
     CK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
@@ -56,6 +88,24 @@ int main() {
     hipStream_t plain;
     CK(hipStreamCreate(&plain));
     run("unmasked", plain, dbuf, blocks);
+    {
+        float* fb;
+        CK(hipMalloc(&fb, 4096));
+        CK(hipMemset(fb, 0, 4096));
+        hipStream_t nb, masked, maskedall;
+        CK(hipStreamCreateWithFlags(&nb, hipStreamNonBlocking));
+        std::vector<uint32_t> m8(words, 0), mall(words, 0);
+        for (int i = 0; i < ncu; ++i) {
+            mall[i >> 5] |= 1u << (i & 31);
+            if (i < ncu - 8) m8[i >> 5] |= 1u << (i & 31);
+        }
+        CK(hipExtStreamCreateWithCUMask(&masked, words, m8.data()));
+        CK(hipExtStreamCreateWithCUMask(&maskedall, words, mall.data()));
+        launch_cost("hipStreamCreate (blocking)", plain, fb);
+        launch_cost("hipStreamNonBlocking", nb, fb);
+        launch_cost("CU mask, all bits set", maskedall, fb);
+        launch_cost("CU mask, 8 CUs reserved", masked, fb);
+    }
     struct Case {
         const char* name;
         int lo, hi;  // bits [lo, hi) SET
