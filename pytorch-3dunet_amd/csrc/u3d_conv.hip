@@ -28,8 +28,9 @@
 //   [10] 1 = bf16-storage convolutions on 4-plane tiles only (no 8-plane tiles)   [11] 1 = x-y-z raster tile order of the bf16 kernels
 //   [12] CU budget left to OTHER streams (RCCL): the persistent grids and the one-block-per-CU plans are sized for (CUs - value)
 //        (u3d_streams_create_reserved sets it together with the CU-masked compute stream; results never change)
-//   [13] free   [14] 1 = persistent convolution kernel with the round-1..3 operand order and DPP-transposed epilogue (A/B)
-//   [15] 1 = fp32 weight gradient with a barrier per tile instead of LDS counters (A/B)
+//   [13] per-block start-phase spread of the persistent kernel: block b sleeps (b % 16) * value * 1024 cycles once (experiment)
+//   [14] timing-only ablations of the persistent kernel's epilogue: 1 = no global stores, 2 = no transposition (wrong results)
+//   [15] free
 int g_u3d_tune[16] = {0};
 
 namespace cv {
@@ -621,14 +622,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const SplitKParams p
 // voxel y serves both outputs when the tap window is 3 x 4 x 3 (36 taps, the weights of the second half shifted by one
 // in y, zero where that leaves the 3^3 kernel).  A wave then needs only the even rows y = 0,2,4,6 of its z-plane (ONE
 // M-tile): 72 k-steps x 4 MFMAs per chunk instead of 54 x 8 — 2/3 of the padded work.
-//
-// SW (round 4): the two MFMA operands are SWAPPED — the weight fragment is passed as A, the activation fragment as B; every lane
-// loads exactly what it loaded before, but the accumulator tile comes out transposed: lane (m, h) holds voxel m (of the 32-voxel
-// M-tile) and, in registers 4q..4q+3, the FOUR CONSECUTIVE output channels 8q + 4h .. + 3.  The epilogue then stores, loads its
-// side tensors and sums its statistics 16 bytes at a time straight from the accumulator registers: the 4x4 DPP transposition
-// (16 VALU per register quad — half of the epilogue's vector instructions, all of them issued while the SIMD's MFMA pipe idles
-// or at the partner wave's MFMA boundaries) disappears.  u3d_set_tuning key 14 = 1 selects the unswapped twin for A/B runs.
-template <int NT, bool VIRT, bool DBG = false, bool PAIRY = false, bool AFF = true, bool SW = true>
+template <int NT, bool VIRT, bool DBG = false, bool PAIRY = false, bool AFF = true>
 __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParams p) {
     using namespace cv;
     static_assert(!PAIRY || NT == 1, "the paired-y variant has a single N-tile");
@@ -899,14 +893,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
     // that changes: the per-tile epilogue is then transposition + stores only.
     constexpr bool CARRY = NT == 1;
     f32x4 sq1 = {0.f, 0.f, 0.f, 0.f}, sq2 = {0.f, 0.f, 0.f, 0.f};
-    // SW: a lane owns NQ channel quads (8*cq + 4h .. + 3) of ONE voxel per M-tile; its running sums are per channel quad
-    constexpr int NQ = PAIRY ? 2 : 4;
-    f32x4 wq1[SW && CARRY ? NQ : 1], wq2[SW && CARRY ? NQ : 1];
-#pragma unroll
-    for (int i = 0; i < (SW && CARRY ? NQ : 1); ++i) {
-        wq1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        wq2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
     auto quad_sum = [](float v) {
         v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));  // lane ^ 1
         v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));  // lane ^ 2
@@ -920,22 +906,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                 double* r = &red[(((n_ & 1) * NT + nt_) * 32 + c0 + e) * 2];
                 __hip_atomic_fetch_add(r, (double)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(r + 1, (double)b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
-    };
-    // SW: the 32 lanes m of a half-wave hold 32 voxels of the same channels — lanes l^1, l^2 are summed with DPP, every fourth lane
-    // adds to the block's f64 LDS row (8 lanes per address)
-    auto stat_reduce_sw = [&](const f32x4* a1, const f32x4* a2, int n_, int nt_) {
-#pragma unroll
-        for (int cq = 0; cq < NQ; ++cq) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float a = quad_sum(a1[cq][e]), b2 = quad_sum(a2[cq][e]);
-                if ((l & 3) == 0) {
-                    double* r = &red[(((n_ & 1) * NT + nt_) * 32 + 8 * cq + 4 * h + e) * 2];
-                    __hip_atomic_fetch_add(r, (double)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(r + 1, (double)b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
             }
         }
     };
@@ -1023,11 +993,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                             for (int mt = 0; mt < MT; ++mt) {
                                 if (KIND == ROW_LOAD_FIRST && s6 == 0 && j == 0) {
                                     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                                    acc[mt][nt] = SW ? __builtin_amdgcn_mfma_f32_32x32x2f32(bq[0][nt][0], aq[0][mt][0], zero, 0, 0, 0)
-                                                     : __builtin_amdgcn_mfma_f32_32x32x2f32(aq[0][mt][0], bq[0][nt][0], zero, 0, 0, 0);
+                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[0][mt][0], bq[0][nt][0], zero, 0, 0, 0);
                                 } else {
-                                    acc[mt][nt] = SW ? __builtin_amdgcn_mfma_f32_32x32x2f32(bq[s6 % RB][nt][j], aq[s6 & 1][mt][j], acc[mt][nt], 0, 0, 0)
-                                                     : __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s6 & 1][mt][j], bq[s6 % RB][nt][j], acc[mt][nt], 0, 0, 0);
+                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s6 & 1][mt][j], bq[s6 % RB][nt][j], acc[mt][nt], 0, 0, 0);
                                 }
                             }
                         }
@@ -1060,8 +1028,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
                             for (int mt = 0; mt < MT; ++mt)
-                                acc[mt][nt] = SW ? __builtin_amdgcn_mfma_f32_32x32x2f32(bq[s6 % RB][nt][j], aq[s6 & 1][mt][j], acc[mt][nt], 0, 0, 0)
-                                                 : __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s6 & 1][mt][j], bq[s6 % RB][nt][j], acc[mt][nt], 0, 0, 0);
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s6 & 1][mt][j], bq[s6 % RB][nt][j], acc[mt][nt], 0, 0, 0);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -1091,90 +1058,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
         //      inside every lane quad (two DPP butterfly stages) leaves lane j of quad k with the 4 consecutive
         //      channels 4k..4k+3 of voxel x = j + 4h: 16-byte stores and 16-byte loads of x for the GroupNorm sums.
         if (ntiles == DBG_TILE) U3D_DBG_STAMP(5);
-        if constexpr (SW) {
-            if (p.stagger != -1) {  // (u3d_set_tuning key 5 = -1: TIMING-ONLY ablation without the epilogue — wrong results by design)
-                // accumulator layout with swapped operands: D[i][j], i = (r&3) + 8*(r>>2) + 4*(lane>>5) = output channel of the N-tile,
-                // j = lane&31 = voxel of the M-tile (y = j>>3 [x2 PAIRY], x = j&7).  Register quad q = r>>2 of lane (m, h) is the
-                // channel quad 8q + 4h .. + 3 of voxel m; PAIRY: q&1 is the channel quad (of 16 channels), q>>1 the second y row.
-                const int n = T.n, cb = T.cb;
-                const int z = T.z0 + w;
-                const int yl = (PAIRY ? 2 : 1) * (m >> 3), xl = m & 7;
-                const int vlane = ((n * D + z) * H + T.y0 + yl) * W + T.x0 + xl;  // this lane's voxel in M-tile 0
-                const bool tail = p.Cout % 32 != 0;  // uniform: the last N-tile has dead channel quads
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int cbase = (PAIRY ? 0 : (cb * NT + nt) * 32) + 4 * h;  // channel of quad cq: cbase + 8*cq
-                    float* orow = p.out + (size_t)vlane * p.Cout + cbase;
-                    f32x4 q1[NQ], q2[NQ];
-#pragma unroll
-                    for (int i = 0; i < NQ; ++i) {
-                        q1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        q2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        f32x4 xv[4];
-                        if (want_g) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const int cq = PAIRY ? (q & 1) : q, yo = PAIRY ? (q >> 1) : 4 * mt;
-                                const int co = cbase + 8 * cq;
-                                const bool cok = !tail || co < p.Cout;
-                                const float* xp;
-                                if (p.gx_x2) {  // gx's second half is an exact 2x upsampling: low-res voxel, channel co - C0
-                                    const bool from0 = co < p.gx.C0 || !cok;
-                                    const int xi1 = ((n * p.gx.D1 + (z >> 1)) * p.gx.H1 + ((T.y0 + yl + yo) >> 1)) * p.gx.W1 + ((T.x0 + xl) >> 1);
-                                    xp = !cok ? p.gx.p0
-                                              : (from0 ? p.gx.p0 + (size_t)(vlane + yo * W) * p.gx.C0 + co
-                                                       : p.gx.p1 + (size_t)xi1 * p.gx.C1 + (co - p.gx.C0));
-                                } else {
-                                    xp = p.gx.p0 + (cok ? (size_t)(vlane + yo * W) * p.gx.C0 + co : 0);
-                                }
-                                xv[q] = *reinterpret_cast<const f32x4*>(xp);
-                            }
-                        } else if (p.res) {  // residual rows (same voxels / channels as the output)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const int cq = PAIRY ? (q & 1) : q, yo = PAIRY ? (q >> 1) : 4 * mt;
-                                const bool cok = !tail || cbase + 8 * cq < p.Cout;
-                                xv[q] = *reinterpret_cast<const f32x4*>(p.res + (size_t)(vlane + yo * W) * p.Cout + (cok ? cbase + 8 * cq : 0));
-                            }
-                        }
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int cq = PAIRY ? (q & 1) : q, yo = PAIRY ? (q >> 1) : 4 * mt;
-                            f32x4 val = {acc[mt][nt][4 * q + 0], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
-                            if (p.res) val += xv[q];
-                            if (p.relu) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
-                            }
-                            if (tail) {
-                                const bool cok = cbase + 8 * cq < p.Cout;
-                                if (cok) *reinterpret_cast<f32x4*>(orow + (size_t)yo * W * p.Cout + 8 * cq) = val;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) val[e] = cok ? val[e] : 0.f;
-                            } else {
-                                *reinterpret_cast<f32x4*>(orow + (size_t)yo * W * p.Cout + 8 * cq) = val;
-                            }
-                            q1[cq] += val;
-                            q2[cq] += want_g ? val * xv[q] : val * val;
-                        }
-                    }
-                    if (want_stats || want_g) {
-                        if constexpr (CARRY) {
-#pragma unroll
-                            for (int i = 0; i < NQ; ++i) {
-                                wq1[i] += q1[i];
-                                wq2[i] += q2[i];
-                            }
-                        } else {
-                            stat_reduce_sw(q1, q2, n, nt);
-                        }
-                    }
-                }
-            }
-        } else
         if (p.stagger != -1) {  // (u3d_set_tuning key 5 = -1: TIMING-ONLY ablation without the epilogue — wrong results by design)
             const int n = T.n, cb = T.cb;
             const int z = T.z0 + w;
@@ -1261,19 +1144,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
         if (!has_next_tile || TN.n != T.n || TN.cb != T.cb) {
             if constexpr (CARRY) {
                 if (want_stats || want_g) {
-                    if constexpr (SW) {
-                        stat_reduce_sw(wq1, wq2, T.n, 0);
-#pragma unroll
-                        for (int i = 0; i < NQ; ++i) {
-                            wq1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                            wq2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        }
-                    } else {
-                        const int cq_ = (l >> 2) & 7;
-                        stat_reduce(sq1, sq2, T.n, 0, PAIRY ? 4 * (cq_ & 3) : 4 * cq_);
-                        sq1 = f32x4{0.f, 0.f, 0.f, 0.f};
-                        sq2 = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
+                    const int cq_ = (l >> 2) & 7;
+                    stat_reduce(sq1, sq2, T.n, 0, PAIRY ? 4 * (cq_ & 3) : 4 * cq_);
+                    sq1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    sq2 = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
             flush_stats(T.n, T.cb);
@@ -1347,20 +1221,12 @@ struct WgradParams {
 // PAIR (Cin <= 16: the single input chunk fills only half of the 32 MFMA rows): rows 0-15 carry the 16 channels at
 // tap 2q, rows 16-31 the same channels at tap 2q+1 — one MFMA serves two taps, 14 tap pairs instead of 27 taps
 // (wave w owns pairs {w&3, +4, ..}: 4 accumulators instead of 7).
-//
-// FLAGS (round 4): the per-tile rendezvous of the eight waves is replaced by the LDS counters of the convolution kernel
-// (u3d_flag_signal / u3d_flag_wait): a wave enters tile k as soon as all eight have STAGED it (`full`), and overwrites a buffer
-// only after all eight have finished READING it (`freed`).  The two waves of a SIMD share its MFMA pipe in arbitrary phases and
-// the four SIMDs drift; a barrier per 14 k-cycle tile made every wave wait for the slowest at every tile, with flags the drift is
-// absorbed up to ~half a tile.  u3d_set_tuning key 15 = 1 selects the barrier twin for A/B runs.
-template <bool VEC, bool REG = false, bool PAIR = false, bool FLAGS = false>
+template <bool VEC, bool REG = false, bool PAIR = false>
 __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams p) {
     using namespace wg;
-    static_assert(!FLAGS || VEC, "the scalar staging path is synchronous: it keeps the barrier");
     constexpr int NA = PAIR ? 4 : 7;  // accumulators (taps / tap pairs) per wave
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    int* cnt = reinterpret_cast<int*>(lds + 2 * BUF_FLOATS);  // [0,1] full[buf], [2,3] freed[buf] (FLAGS), 16 ints reserved
-    int* zmapl = cnt + 16;                                     // [D | H | W] (virtual source only)
+    int* zmapl = reinterpret_cast<int*>(lds + 2 * BUF_FLOATS);  // [D | H | W] (virtual source only)
     __builtin_amdgcn_s_setprio(3);  // non-MFMA phases outrank co-resident k-loops (see conv3d_mfma_kernel)
     const int t = threadIdx.x;
     const int l = t & 63, i = l & 31, h = l >> 5;
@@ -1375,10 +1241,6 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
     const int Ctot = p.src.C0 + p.src.C1;
     int* ymapl = zmapl + D;
     int* xmapl = ymapl + H;
-    if constexpr (FLAGS) {
-        if (t < 16) cnt[t] = 0;
-        __syncthreads();
-    }
     if (p.src.C1 > 0) {
         for (int k = t; k < D; k += NTHR) zmapl[k] = p.src.zmap[k];
         for (int k = t; k < H; k += NTHR) ymapl[k] = p.src.ymap[k];
@@ -1625,10 +1487,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
             stage_scalar(lds, c);
         }
     }
-    if constexpr (FLAGS)
-        u3d_flag_signal(&cnt[0], l);  // this wave has staged its share of the first tile
-    else
-        __syncthreads();
+    __syncthreads();
 
     // A-operand bases: lane (i = channel, h = voxel parity) + the wave's z-plane + its 7 tap offsets
     int abase[NA];
@@ -1647,18 +1506,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
     // de-interleave): keep it in registers and reload on a sample change (a uniform, rare branch).
     f32x4 gan = {1.f, 1.f, 1.f, 1.f}, gbn = {0.f, 0.f, 0.f, 0.f};
     int n_aff = -1;
-    int kt = 0;  // tiles done by this wave (FLAGS: buffer parity and counter targets)
-    for (int tile = tile_begin; tile < tile_end; ++tile, ++kt) {
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
         const bool has_next = tile + 1 < tile_end;
         if (has_next) tix = tile_next(tix);
         const TileC cn = tile_coords(tix);
         float* nbuf = lds + (cur ^ 1) * BUF_FLOATS;
         f32x4 v[NPF];
-        if constexpr (FLAGS) {
-            __builtin_amdgcn_s_setprio(3);
-            u3d_flag_wait(&cnt[cur], 8 * (kt / 2 + 1));  // all eight waves have staged tile kt into buffer kt & 1
-            __builtin_amdgcn_s_setprio(0);
-        }
         if constexpr (VEC) {
             if (cn.n != n_aff) {
                 load_affine(cn.n, gan, gbn);
@@ -1676,15 +1529,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
         for (int g = 0; g < 32; ++g) {
             if constexpr (VEC) {
                 if (g % 2 == 0 && g / 2 < NPF) v[g / 2] = pf_load(cn, g / 2);
-                if constexpr (FLAGS) {
-                    // the other buffer was read during tile kt - 1: free once all eight waves have left that tile
-                    if (g == ST0 && kt > 0) u3d_flag_wait(&cnt[2 + (cur ^ 1)], 8 * ((kt - 1) / 2 + 1));
-                }
                 // (after the last tile this re-stages it into the idle buffer: harmless and branch-free)
                 if (g >= ST0 && g - ST0 < NPF) pf_store(nbuf, cn, g - ST0, v[g - ST0], gan, gbn);
-                if constexpr (FLAGS) {
-                    if (g == ST0 + NPF - 1) u3d_flag_signal(&cnt[cur ^ 1], l);  // tile kt + 1 staged by this wave
-                }
             }
             if (g + 1 < 32) {
                 const int row = (g + 1) >> 2, tq = (g + 1) & 3;
@@ -1701,15 +1547,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
         if constexpr (!VEC) {
             if (has_next) stage_scalar(nbuf, cn);
         }
-        if constexpr (FLAGS)
-            u3d_flag_signal(&cnt[2 + cur], l);  // this wave no longer reads buffer `cur`
-        else
-            __syncthreads();
+        __syncthreads();
         cur ^= 1;
     }
 
     __builtin_amdgcn_s_setprio(3);
-    if constexpr (FLAGS) __syncthreads();  // the fold below reuses the staging buffers: every wave must have left its last tile
     // ---- fold the two voxel halves (fixed order: hf 0 + hf 1) through LDS, then
     //      partial[s][chunk][kb][tap][c][k]; D rows = c, cols = k
     float* red = lds;  // [tg][k][r][lane]: 4 * 7 * 16 * 64 floats = 112 KiB of the (now idle) staging buffers
@@ -1977,35 +1819,27 @@ static int effective_cu_count(int device, int* out) {
     return 0;
 }
 
-template <int NT, bool SW>
-static int conv_set_lds_reg() {
-    const int bytes = cv::LDS_FLOATS * sizeof(float);
-    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<NT, false, false, false, true, SW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<NT, true, false, false, true, SW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<NT, false, true, false, true, SW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<NT, true, true, false, true, SW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<NT, false, false, false, false, SW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    if (NT == 1) {
-        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<1, false, false, true, false, SW>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<1, false, false, true, true, SW>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<1, true, false, true, true, SW>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    }
-    return 0;
-}
-
 template <int NT>
 static int conv_set_lds_nt() {
     const int bytes = cv::LDS_FLOATS * sizeof(float);
-    if (int e = conv_set_lds_reg<NT, true>()) return e;
-    if (int e = conv_set_lds_reg<NT, false>()) return e;
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<NT, false, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<NT, true, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<NT, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<NT, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<NT, false, false, false, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (NT == 1) {
+        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<1, false, false, true, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<1, false, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<1, true, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    }
     U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_kernel<NT, true, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_kernel<NT, false, false>),
@@ -2185,40 +2019,31 @@ static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, co
         // per-element FMA of the halo stores (key 7 = 1 turns it off for A/B runs)
         const bool noaff = p.src.affine == nullptr && g_u3d_tune[7] == 0;
         p.dbg = (g_u3d_prof_buf && (size_t)slots * 4 <= g_u3d_prof_records) ? g_u3d_prof_buf : nullptr;
-        // operand order of the MFMAs (see the kernel header): swapped = transposition-free epilogue (default); key 14 = 1: the
-        // round-1..3 order with the DPP-transposed epilogue, kept for same-box A/B measurements
-        const bool sw = g_u3d_tune[14] != 1;
-#define U3D_REG_K(NT_, VIRT_, DBG_, PAIRY_, AFF_)                                                                              \
-    do {                                                                                                                       \
-        if (sw)                                                                                                                \
-            hipLaunchKernelGGL((conv3d_mfma_reg_kernel<NT_, VIRT_, DBG_, PAIRY_, AFF_, true>), rgrid, rblock, shmem, st, p);   \
-        else                                                                                                                   \
-            hipLaunchKernelGGL((conv3d_mfma_reg_kernel<NT_, VIRT_, DBG_, PAIRY_, AFF_, false>), rgrid, rblock, shmem, st, p);  \
-    } while (0)
         if (Cout <= 16 && nt == 1 && p.ntot == 1 && !p.dbg && g_u3d_tune[4] == 0) {
             // paired-y variant on the second packed image (u3d_pack_weights appends it for <= 16 output channels)
             p.wp = packed_w + ((size_t)p.nchunks * cv::NSTEP + cv::PACK_PAD) * 256;
             if (virt)
-                U3D_REG_K(1, true, false, true, true);
+                hipLaunchKernelGGL((conv3d_mfma_reg_kernel<1, true, false, true>), rgrid, rblock, shmem, st, p);
             else if (noaff)
-                U3D_REG_K(1, false, false, true, false);
+                hipLaunchKernelGGL((conv3d_mfma_reg_kernel<1, false, false, true, false>), rgrid, rblock, shmem, st, p);
             else
-                U3D_REG_K(1, false, false, true, true);
+                hipLaunchKernelGGL((conv3d_mfma_reg_kernel<1, false, false, true>), rgrid, rblock, shmem, st, p);
             U3D_LAUNCH_CHECK();
             return 0;
         }
-#define U3D_REG_LAUNCH(NT_)                         \
-    do {                                            \
-        if (p.dbg && virt)                          \
-            U3D_REG_K(NT_, true, true, false, true);    \
-        else if (p.dbg)                             \
-            U3D_REG_K(NT_, false, true, false, true);   \
-        else if (virt)                              \
-            U3D_REG_K(NT_, true, false, false, true);   \
-        else if (noaff)                             \
-            U3D_REG_K(NT_, false, false, false, false); \
-        else                                        \
-            U3D_REG_K(NT_, false, false, false, true);  \
+#define U3D_REG_LAUNCH(NT_)                                                                                \
+    do {                                                                                                   \
+        if (p.dbg && virt)                                                                                 \
+            hipLaunchKernelGGL((conv3d_mfma_reg_kernel<NT_, true, true>), rgrid, rblock, shmem, st, p);    \
+        else if (p.dbg)                                                                                    \
+            hipLaunchKernelGGL((conv3d_mfma_reg_kernel<NT_, false, true>), rgrid, rblock, shmem, st, p);   \
+        else if (virt)                                                                                     \
+            hipLaunchKernelGGL((conv3d_mfma_reg_kernel<NT_, true, false>), rgrid, rblock, shmem, st, p);   \
+        else if (noaff)                                                                                    \
+            hipLaunchKernelGGL((conv3d_mfma_reg_kernel<NT_, false, false, false, false>), rgrid, rblock,   \
+                               shmem, st, p);                                                              \
+        else                                                                                               \
+            hipLaunchKernelGGL((conv3d_mfma_reg_kernel<NT_, false, false>), rgrid, rblock, shmem, st, p);  \
     } while (0)
         if (nt == 3)
             U3D_REG_LAUNCH(3);
@@ -2227,7 +2052,6 @@ static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, co
         else
             U3D_REG_LAUNCH(1);
 #undef U3D_REG_LAUNCH
-#undef U3D_REG_K
         U3D_LAUNCH_CHECK();
         return 0;
     }
@@ -2299,17 +2123,14 @@ extern "C" size_t u3d_wgrad_workspace_floats(int N, int D, int H, int W, int Cin
 static int wgrad_set_lds_once(int device) {
     static bool done[64] = {false};
     if (device >= 0 && device < 64 && done[device]) return 0;
-    const int bytes = (wg::LDS_FLOATS + 16 + wg::MAX_MAP_INTS) * sizeof(float);
-#define U3D_WG_ATTR(...) \
-    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wgrad_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes))
-    U3D_WG_ATTR(true, true, false, false);
-    U3D_WG_ATTR(true, true, false, true);
-    U3D_WG_ATTR(true, true, true, false);
-    U3D_WG_ATTR(true, true, true, true);
-    U3D_WG_ATTR(true, false, false, false);
-    U3D_WG_ATTR(true, false, false, true);
-    U3D_WG_ATTR(false, false, false, false);
-#undef U3D_WG_ATTR
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wgrad_kernel<true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (wg::LDS_FLOATS + wg::MAX_MAP_INTS) * sizeof(float)));
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wgrad_kernel<true, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (wg::LDS_FLOATS + wg::MAX_MAP_INTS) * sizeof(float)));
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wgrad_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (wg::LDS_FLOATS + wg::MAX_MAP_INTS) * sizeof(float)));
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wgrad_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (wg::LDS_FLOATS + wg::MAX_MAP_INTS) * sizeof(float)));
     if (device >= 0 && device < 64) done[device] = true;
     return 0;
 }
@@ -2350,23 +2171,18 @@ static int conv3d_wgrad_impl(int device, u3d_stream_t stream, const u3d_src_t* s
     if (int e = wgrad_set_lds_once(device)) return e;
     const int nblk = p.S * p.nchunks * p.nkb;
     U3D_REQUIRE(D + H + W <= wg::MAX_MAP_INTS, "u3d_conv3d_wgrad: D+H+W must be <= %d", wg::MAX_MAP_INTS);
-    const size_t shmem = (wg::LDS_FLOATS + 16 + (size_t)(D + H + W)) * sizeof(float);
+    const size_t shmem = (wg::LDS_FLOATS + (size_t)(D + H + W)) * sizeof(float);
     // every tile fully inside the volume and no table look-ups -> constant-offset staging (REG)
     const bool reg = D % wg::TZ == 0 && H % wg::TY == 0 && W % wg::TX == 0 &&
                      (src->C1 == 0 || (D == 2 * src->D1 && H == 2 * src->H1 && W == 2 * src->W1));
-    const bool flags = g_u3d_tune[15] != 1;  // LDS counters instead of a barrier per tile (key 15 = 1: the barrier twin, for A/B)
-#define U3D_WG_K(...) \
-    hipLaunchKernelGGL((conv3d_wgrad_kernel<__VA_ARGS__>), dim3(nblk), dim3(wg::NTHR), shmem, (hipStream_t)stream, p)
-    if (p.vec && p.dzvec && reg && Cin <= 16) {
-        if (flags) U3D_WG_K(true, true, true, true); else U3D_WG_K(true, true, true, false);
-    } else if (p.vec && p.dzvec && reg) {
-        if (flags) U3D_WG_K(true, true, false, true); else U3D_WG_K(true, true, false, false);
-    } else if (p.vec && p.dzvec) {
-        if (flags) U3D_WG_K(true, false, false, true); else U3D_WG_K(true, false, false, false);
-    } else {
-        U3D_WG_K(false, false, false, false);
-    }
-#undef U3D_WG_K
+    if (p.vec && p.dzvec && reg && Cin <= 16)
+        hipLaunchKernelGGL((conv3d_wgrad_kernel<true, true, true>), dim3(nblk), dim3(wg::NTHR), shmem, (hipStream_t)stream, p);
+    else if (p.vec && p.dzvec && reg)
+        hipLaunchKernelGGL((conv3d_wgrad_kernel<true, true>), dim3(nblk), dim3(wg::NTHR), shmem, (hipStream_t)stream, p);
+    else if (p.vec && p.dzvec)
+        hipLaunchKernelGGL(conv3d_wgrad_kernel<true>, dim3(nblk), dim3(wg::NTHR), shmem, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(conv3d_wgrad_kernel<false>, dim3(nblk), dim3(wg::NTHR), shmem, (hipStream_t)stream, p);
     U3D_LAUNCH_CHECK();
     const long long total = (long long)Cin * 27 * Cout;
     const int rblocks = (int)((total + 63) / 64);
