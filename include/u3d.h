@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define U3D_VERSION 115 /* 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, u3d_streams_create_reserved / u3d_stream_destroy */
+#define U3D_VERSION 115 /* 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids) */
 
 #define U3D_OK 0
 #define U3D_EINVAL (-1)  /* bad shape / argument */
@@ -68,21 +68,18 @@ const char* u3d_last_error(void);
 /* 0 if `device` is a gfx950 part, U3D_EARCH otherwise. */
 int u3d_check_device(int device);
 /* Process-wide performance knobs for A/B measurements (never change results).
- * key 0: forced N-tiles per block of u3d_conv3d (1,2,3; 0 = automatic); key 1: wgrad split override; keys 2-11: see the
- * list at the top of csrc/u3d_conv.hip (16 keys; the environment variable U3D_TUNE=key:value,... sets them at load time). */
+ * key 0: forced N-tiles per block of u3d_conv3d (1,2,3; 0 = automatic); key 1: wgrad split override; key 12: block slots the
+ * persistent convolution grids leave FREE (of 2 per CU) so that kernels of other streams — RCCL's gradient all-reduce,
+ * parallel.py — find room beside them; the other keys: see the list at the top of csrc/u3d_conv.hip (16 keys; the environment
+ * variable U3D_TUNE=key:value,... sets them at load time). */
 int u3d_set_tuning(int key, int value);
-/* A CU budget for the gradient exchange of data-parallel training (the reference has one process and nn.DataParallel,
- * trainer.py:202-205; here: one process per GPU + RCCL, parallel.py).  Creates `compute_stream` with `reserve` CUs masked out
- * (hipExtStreamCreateWithCUMask; spread over the XCDs) and sizes the library's persistent / one-block-per-CU grids for the
- * remaining CUs (tuning key 12): kernels of other, unmasked streams — RCCL's all-reduce — then find idle CUs instead of
- * waiting behind persistent blocks.  `reserved_stream` (may be NULL) receives a stream confined to exactly the reserved CUs
- * (NULL when reserve == 0).  Results never depend on it.  The caller owns the streams: u3d_stream_destroy. */
-int u3d_streams_create_reserved(int device, int reserve, u3d_stream_t* compute_stream, u3d_stream_t* reserved_stream);
-int u3d_stream_destroy(int device, u3d_stream_t stream);
 /* Developer aid (tools/wave_timeline.py): while a device buffer is registered, u3d_conv3d launches an instrumented
  * twin of the kernel in which every wave records 24 int64 (block, HW_ID, XCC_ID, shader-clock stamps at entry /
  * first tile staged / end of each chunk's k-loop / epilogue start / exit).  NULL switches it off (default). */
 int u3d_set_profile_buffer(void* device_buffer, size_t bytes);
+/* Developer aid (tools/overlap_probe.py): `blocks` workgroups stream `n` floats in place `passes` times — the shape of a link-bound
+ * RCCL ring all-reduce (a handful of channels), which a 1-rank process group cannot launch.  Values are unchanged. */
+int u3d_debug_stream_pass(int device, u3d_stream_t stream, float* buf, long long n, int blocks, int passes);
 
 /* ---- weight packing -------------------------------------------------------------------------
  * Reference weights stay nn.Parameters in (Cout,Cin,3,3,3) layout (checkpoint compatibility,

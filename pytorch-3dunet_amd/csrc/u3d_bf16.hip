@@ -1217,7 +1217,7 @@ wgrad_plan plan_wgrad(int N, int D, int H, int W, int C, int K) {
     // every block writes its 27 x 32 x 64 partial sums (221 KB) and the reduction reads them back: the block count is the
     // split traffic.  Measured on config 4 (profiles/r03e): 1024 blocks 7.2 ms per step, 512 5.75, 256 (one per CU — the kernel
     // double-buffers inside the block) 5.13
-    const int blocks = g_u3d_tune[8] > 0 ? g_u3d_tune[8] : 256 - ((g_u3d_tune[12] > 0 && g_u3d_tune[12] < 256) ? g_u3d_tune[12] : 0);
+    const int blocks = g_u3d_tune[8] > 0 ? g_u3d_tune[8] : 256;
     int target = blocks / q.P;
     if (target < 1) target = 1;
     q.per_block = (q.tiles + target - 1) / target;

@@ -13,6 +13,7 @@
 // both y-halves (MT = 2).  B fragments (weights) are read straight from the packed global image (1 KiB
 // contiguous per wave-load, L1/L2 resident), software-prefetched two k-steps ahead.
 #include <type_traits>
+#include <utility>
 
 #include "u3d_common.h"
 #include "u3d_subpix.h"
@@ -26,8 +27,9 @@
 //   [6] 1 = one persistent block per CU instead of two (occupancy experiment)
 //   [8] bf16 weight gradient: target number of blocks (0 = default)   [9] 1 = bf16 weight gradient without the XCD-aware block order
 //   [10] 1 = bf16-storage convolutions on 4-plane tiles only (no 8-plane tiles)   [11] 1 = x-y-z raster tile order of the bf16 kernels
-//   [12] CU budget left to OTHER streams (RCCL): the persistent grids and the one-block-per-CU plans are sized for (CUs - value)
-//        (u3d_streams_create_reserved sets it together with the CU-masked compute stream; results never change)
+//   [12] block slots (of 2 per CU) that the persistent convolution grids leave FREE for kernels of other streams (RCCL's gradient
+//        all-reduce: parallel.cu_budget).  A CU-MASKED compute queue was measured instead and rejected: the same kernels run 40-75 %
+//        slower on a queue masked to 248 of 256 CUs (profiles/r04_cu_mask_*.txt)
 //   [13] per-block start-phase spread of the persistent kernel: block b sleeps (b % 16) * value * 1024 cycles once (experiment)
 //   [14] timing-only ablations of the persistent kernel's epilogue: 1 = no global stores, 2 = no transposition (wrong results)
 //   [15] free
@@ -596,6 +598,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const SplitKParams p
     }
 }
 
+// compile-time row ranges of the persistent kernel's k-loop: f(integral_constant<int, B>), ..., f(integral_constant<int, E - 1>)
+template <int B, int... I, class F>
+__device__ __forceinline__ void u3d_for_rows_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, B + I>{}), ...);
+}
+template <int B, int E, class F>
+__device__ __forceinline__ void u3d_for_rows(F&& f) {
+    if constexpr (E > B) u3d_for_rows_impl<B>(std::make_integer_sequence<int, E - B>{}, static_cast<F&&>(f));
+}
+
 // =================================================================================================
 // The fast variant of the same convolution: PERSISTENT blocks and a VALU diet.
 //
@@ -626,7 +638,9 @@ template <int NT, bool VIRT, bool DBG = false, bool PAIRY = false, bool AFF = tr
 __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParams p) {
     using namespace cv;
     static_assert(!PAIRY || NT == 1, "the paired-y variant has a single N-tile");
-    constexpr int RB = NT == 1 ? 6 : 3;  // B ring depth (54 % RB == 0, 72 % RB == 0, 6 % RB == 0)
+    // B ring depth: fragments are fetched RB-1 k-steps ahead; slots are indexed by the k-step within the chunk (54 % RB == 0,
+    // 72 % RB == 0).  NT = 1 has the registers for 9 (round 4: 6 -> 9, 8 steps = 4 k cycles of slack behind a halo load)
+    constexpr int RB = NT == 1 ? 9 : 3;
     constexpr int MT = PAIRY ? 1 : 2;    // M-tiles (4 y-rows x 8 x) per wave
     constexpr int RY = PAIRY ? 4 : 3;    // taps along y
     constexpr int NROWS = 3 * RY;        // tap rows (z, y) of 3 x-taps x 2 channel octets = 6 k-steps each
@@ -950,8 +964,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
             // ROW_LOAD_FIRST: row 0 of a tile's first chunk — its very first MFMA per accumulator takes C = 0 (inline constant),
             // which replaces 32*NT v_mov of accumulator zeroing per tile
             enum { ROW_PLAIN = 0, ROW_LOAD = 1, ROW_AFFINE = 2, ROW_STORE = 3, ROW_LAST = 4, ROW_LOAD_FIRST = 5 };
-            auto row_body = [&](auto kind_c, int row) __attribute__((always_inline)) {
+            auto row_body = [&](auto kind_c, auto row_c) __attribute__((always_inline)) {
                 constexpr int KIND = decltype(kind_c)::value;
+                constexpr int row = decltype(row_c)::value;
                 const int rz = row / RY, ry = row - RY * rz;
                 const float* arow = cur + abase + rz * PS + ry * RS;
                 const int nrow = row + 1;
@@ -963,26 +978,28 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                 }
 #pragma unroll
                 for (int s6 = 0; s6 < 6; ++s6) {
-                    if constexpr (KIND == ROW_LOAD || KIND == ROW_LOAD_FIRST) {
-                        if (s6 < NIT / 2) {
-                            if (masked) {
-                                v[2 * s6] = halo_load(cn, S, 2 * s6, true);
-                                v[2 * s6 + 1] = halo_load(cn, S, 2 * s6 + 1, true);
-                            } else {
-                                v[2 * s6] = halo_load(cn, S, 2 * s6, false);
-                                v[2 * s6 + 1] = halo_load(cn, S, 2 * s6 + 1, false);
-                            }
-                        }
-                    }
                     {
                         // B fragments of step + RB-1; past the end of a tile's image continue with the next tile's.
                         // (recomputed from uniform scalars, not carried as a mutated pointer: keeps the address in SGPRs)
                         const f32x4* wsrc = wch0 + (size_t)(row * 6 + s6) * wstep;
-                        if constexpr (KIND == ROW_LAST) {
-                            if (s6 + RB - 1 >= 6 && last) wsrc = wqn + (size_t)(s6 + RB - 1 - 6) * wstep;
-                        }
+                        if (row * 6 + s6 + RB - 1 >= NSTEPL && last) wsrc = wqn + (size_t)(row * 6 + s6 + RB - 1 - NSTEPL) * wstep;
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) bq[(s6 + RB - 1) % RB][nt] = wsrc[nt * 64 + l];
+                        for (int nt = 0; nt < NT; ++nt) bq[(row * 6 + s6 + RB - 1) % RB][nt] = wsrc[nt * 64 + l];
+                    }
+                    // vmcnt retires in order: a B fragment fetched AFTER a halo load cannot be consumed before that halo load (an
+                    // HBM / remote-L2 round trip) has landed.  Spread two per k-step, every B fragment of the row sat behind the halo
+                    // loads of its own step with only RB-1 steps of slack; issued as ONE burst right after step 0's B fetch, the first
+                    // B fragment behind them is step 1's — RB steps of slack — and the slack grows by a step from there on.
+                    if constexpr (KIND == ROW_LOAD || KIND == ROW_LOAD_FIRST) {
+                        if (s6 == 0) {
+                            if (masked) {
+#pragma unroll
+                                for (int it = 0; it < NIT; ++it) v[it] = halo_load(cn, S, it, true);
+                            } else {
+#pragma unroll
+                                for (int it = 0; it < NIT; ++it) v[it] = halo_load(cn, S, it, false);
+                            }
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -995,7 +1012,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                                     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[0][mt][0], bq[0][nt][0], zero, 0, 0, 0);
                                 } else {
-                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s6 & 1][mt][j], bq[s6 % RB][nt][j], acc[mt][nt], 0, 0, 0);
+                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s6 & 1][mt][j], bq[(row * 6 + s6) % RB][nt][j], acc[mt][nt], 0, 0, 0);
                                 }
                             }
                         }
@@ -1028,26 +1045,26 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
                             for (int mt = 0; mt < MT; ++mt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s6 & 1][mt][j], bq[s6 % RB][nt][j], acc[mt][nt], 0, 0, 0);
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s6 & 1][mt][j], bq[(row * 6 + s6) % RB][nt][j], acc[mt][nt], 0, 0, 0);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
             static_assert(ISTORE - 1 > 1 && ISTORE + 1 < NROWS - 1, "row kinds must not collide");
+            static_assert(NSTEPL % RB == 0, "B ring slots are indexed by the k-step within the chunk");
+            using R0 = std::integral_constant<int, 0>;
             if (ZEROC && ch == 0)
-                row_body(std::integral_constant<int, ROW_LOAD_FIRST>{}, 0);
+                row_body(std::integral_constant<int, ROW_LOAD_FIRST>{}, R0{});
             else
-                row_body(std::integral_constant<int, ROW_LOAD>{}, 0);
-            // plain rows as straight-line code (compile-time row: LDS offsets become immediates, no loop-carried scalars):
-            // measured per row alone on a SIMD 3140-3260 cycles straight-line vs 3440 inside a run-time loop (ideal 3072)
-#pragma unroll
-            for (int row = 1; row < ISTORE - 1; ++row) row_body(std::integral_constant<int, ROW_PLAIN>{}, row);
-            row_body(std::integral_constant<int, ROW_AFFINE>{}, ISTORE - 1);
-            row_body(std::integral_constant<int, ROW_STORE>{}, ISTORE);
-#pragma unroll
-            for (int row = ISTORE + 1; row < NROWS - 1; ++row) row_body(std::integral_constant<int, ROW_PLAIN>{}, row);
-            row_body(std::integral_constant<int, ROW_LAST>{}, NROWS - 1);
+                row_body(std::integral_constant<int, ROW_LOAD>{}, R0{});
+            // plain rows as straight-line code (compile-time row: LDS offsets and ring slots become immediates, no loop-carried
+            // scalars): measured per row alone on a SIMD 3140-3260 cycles straight-line vs 3440 inside a run-time loop (ideal 3072)
+            u3d_for_rows<1, ISTORE - 1>([&](auto r) { row_body(std::integral_constant<int, ROW_PLAIN>{}, r); });
+            row_body(std::integral_constant<int, ROW_AFFINE>{}, std::integral_constant<int, ISTORE - 1>{});
+            row_body(std::integral_constant<int, ROW_STORE>{}, std::integral_constant<int, ISTORE>{});
+            u3d_for_rows<ISTORE + 1, NROWS - 1>([&](auto r) { row_body(std::integral_constant<int, ROW_PLAIN>{}, r); });
+            row_body(std::integral_constant<int, ROW_LAST>{}, std::integral_constant<int, NROWS - 1>{});
             if (ntiles == DBG_TILE && ch < 7) U3D_DBG_STAMP(9 + 2 * ch);
             u3d_flag_signal(&cnt[2 + b], l);  // this wave no longer reads buffer b
         }
@@ -1811,14 +1828,6 @@ static int device_cu_count(int device, int* out) {
     return 0;
 }
 
-// CUs the library's own grids may count on: all of them minus the budget left to other streams (u3d_set_tuning key 12)
-static int effective_cu_count(int device, int* out) {
-    if (int e = device_cu_count(device, out)) return e;
-    const int r = g_u3d_tune[12];
-    if (r > 0 && r < *out) *out -= r;
-    return 0;
-}
-
 template <int NT>
 static int conv_set_lds_nt() {
     const int bytes = cv::LDS_FLOATS * sizeof(float);
@@ -1961,7 +1970,7 @@ static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, co
     //      summed in a fixed order by splitk_reduce_kernel together with the epilogue (key 7 = 2 turns it off)
     if (ws && p.vec && p.ovec && ((uintptr_t)ws & 15) == 0 && splitk_shape(N, D, H, W, Cin, Cout) && g_u3d_tune[7] != 2) {
         int ncu = 0;
-        if (int e = effective_cu_count(device, &ncu)) return e;
+        if (int e = device_cu_count(device, &ncu)) return e;
         const long long items = ntiles * p.ntot, out_elems = (long long)N * D * H * W * Cout;
         long long ks = (2ll * ncu) / items;
         if (ks > p.nchunks) ks = p.nchunks;
@@ -2007,8 +2016,9 @@ static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, co
         // wave that is alone on its SIMD does not run at twice the shared rate, so interleaving the epilogues buys nothing
         p.stagger = g_u3d_tune[5];
         int ncu = 0;
-        if (int e = effective_cu_count(device, &ncu)) return e;
+        if (int e = device_cu_count(device, &ncu)) return e;
         long long slots = (g_u3d_tune[6] == 1 ? 1ll : 2ll) * ncu;  // two blocks per CU (LDS); key 6 = 1: one (experiment)
+        if (g_u3d_tune[12] > 0 && g_u3d_tune[12] < slots / 2) slots -= g_u3d_tune[12];  // slots left to other streams (key 12)
         if (slots >= nblk)
             slots = nblk;
         else if (slots > p.ncb)
@@ -2094,7 +2104,7 @@ static void wgrad_plan(int N, int D, int H, int W, int Cin, int Cout, WgradParam
     // One 8-wave block per CU (135 KB of LDS): pick the split count S whose grid S*pairs fills whole rounds of the
     // 256 CUs best.  cost = rounds * (tiles per split + ~2 tiles of prologue / partial-sum write per block).
     const int pairs = p.nchunks * p.nkb;
-    const int ncu = 256 - ((g_u3d_tune[12] > 0 && g_u3d_tune[12] < 256) ? g_u3d_tune[12] : 0);  // (MI355X; key 12: CU budget of other streams)
+    const int ncu = 256;  // (MI355X)
     long long best_cost = -1;
     int best_S = 1;
     for (int rounds = 1; rounds <= 8; ++rounds) {

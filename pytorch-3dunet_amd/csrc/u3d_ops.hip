@@ -39,45 +39,25 @@ extern "C" int u3d_check_device(int device) {
     return 0;
 }
 
-// ---- a CU budget for the gradient exchange ------------------------------------------------------------------------
-// The persistent convolution grids own every CU's LDS and most of its registers: kernels of another stream (RCCL's all-reduce of
-// the gradient buckets, parallel.py) make no progress beside them (profiles/r03_overlap_probe.txt: 3 % of a side-stream exchange
-// hidden).  The hardware answer is a CU mask per queue: the compute stream is created with `reserve` CUs masked OUT — one per XCD
-// in turn, so every XCD keeps the same number and the XCD-aware tile order stays balanced — and the library's one-block-per-CU
-// plans are sized for the rest (u3d_set_tuning key 12).  Anything launched on an unmasked stream (RCCL) finds those CUs idle.
-// `reserved_stream` (optional) is the complement: a stream confined to the reserved CUs (tools/overlap_probe.py runs its
-// link-rate stand-in there).  The caller owns both streams (u3d_stream_destroy).
-extern "C" int u3d_streams_create_reserved(int device, int reserve, u3d_stream_t* compute_stream, u3d_stream_t* reserved_stream) {
-    U3D_ENTER(device);
-    U3D_REQUIRE(compute_stream != nullptr, "u3d_streams_create_reserved: compute_stream is NULL");
-    int ncu = 0;
-    U3D_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
-    U3D_REQUIRE(reserve >= 0 && reserve < ncu && ncu <= 1024, "u3d_streams_create_reserved: reserve %d of %d CUs", reserve, ncu);
-    const int words = (ncu + 31) / 32;
-    uint32_t keep[32] = {0}, rest[32] = {0};
-    // bit i of the mask = CU i in the driver's enumeration, which interleaves the XCDs (bit i -> XCD i % 8; established on the
-    // hardware with tools/cu_mask_probe.hip): taking the TOP `reserve` bits removes CUs from all XCDs in turn
-    for (int i = 0; i < ncu; ++i) {
-        const bool res = i >= ncu - reserve;
-        (res ? rest : keep)[i >> 5] |= 1u << (i & 31);
-    }
-    hipStream_t s = nullptr;
-    U3D_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, keep));
-    *compute_stream = (u3d_stream_t)s;
-    if (reserved_stream) {
-        *reserved_stream = nullptr;
-        if (reserve > 0) {
-            hipStream_t r = nullptr;
-            U3D_HIP(hipExtStreamCreateWithCUMask(&r, (uint32_t)words, rest));
-            *reserved_stream = (u3d_stream_t)r;
+// ---- developer aid: a stand-in for a link-bound collective (tools/overlap_probe.py) ----------------------------------------
+// RCCL's ring all-reduce runs a handful of workgroups (one per channel) that move data at the rate of the xGMI links, not of
+// HBM.  A 1-rank group launches nothing, so the single-GPU overlap probe needs a kernel of that shape: `blocks` workgroups of 256
+// threads stream `n` floats in place `passes` times (x <- x * 1).  Results never change.
+__global__ __launch_bounds__(256) void debug_stream_pass_kernel(float* __restrict__ buf, long long n4, int passes) {
+    f32x4* b = reinterpret_cast<f32x4*>(buf);
+    for (int p = 0; p < passes; ++p)
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+            f32x4 v = b[i];
+            v *= 1.0f;
+            b[i] = v;
         }
-    }
-    return u3d_set_tuning(12, reserve);
 }
 
-extern "C" int u3d_stream_destroy(int device, u3d_stream_t stream) {
+extern "C" int u3d_debug_stream_pass(int device, u3d_stream_t stream, float* buf, long long n, int blocks, int passes) {
     U3D_ENTER(device);
-    if (stream) U3D_HIP(hipStreamDestroy((hipStream_t)stream));
+    U3D_REQUIRE(buf && n >= 4 && blocks > 0 && passes > 0 && ((uintptr_t)buf & 15) == 0, "u3d_debug_stream_pass: bad argument");
+    hipLaunchKernelGGL(debug_stream_pass_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, buf, n / 4, passes);
+    U3D_LAUNCH_CHECK();
     return 0;
 }
 

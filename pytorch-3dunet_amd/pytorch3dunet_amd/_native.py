@@ -10,7 +10,8 @@ import threading
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libu3d_hip.so")
+# (U3D_LIB_PATH: another build of the same library — same-box A/B runs of compile-time kernel experiments, tools/ab_libs.sh)
+LIB_PATH = os.environ.get("U3D_LIB_PATH") or os.path.join(_HERE, "lib", "libu3d_hip.so")
 
 U3D_OK = 0
 
@@ -43,8 +44,7 @@ class U3DPackDesc(ctypes.Structure):
 _PROTOS = {
     # name: (restype, argtypes)
     "u3d_version": (c_int, []),
-    "u3d_streams_create_reserved": (c_int, [c_int, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p)]),
-    "u3d_stream_destroy": (c_int, [c_int, c_void_p]),
+    "u3d_debug_stream_pass": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int, c_int]),
     "u3d_last_error": (c_char_p, []),
     "u3d_check_device": (c_int, [c_int]),
     "u3d_set_tuning": (c_int, [c_int, c_int]),

@@ -481,12 +481,35 @@ class UNet3DEngine:
         # split point of the flat gradient buffer: encoders first (module order), then decoders + head
         n_enc = sum(p.numel() for p in module_params(model.encoders))
         self.n_enc_params = n_enc
+        # per-level offsets inside the encoder part [enc0 | enc1 | ...]: the encoder backward walks the levels deepest first, and the
+        # deepest levels hold most of the parameters (config 4: 170 of 305 MB in the last one) — their gradients are final early and
+        # are handed to RCCL level by level (`_enc_bucket_plan`)
+        self.enc_level_offs = [0]
+        for enc in model.encoders:
+            self.enc_level_offs.append(self.enc_level_offs[-1] + sum(p.numel() for p in module_params(enc)))
+        assert self.enc_level_offs[-1] == n_enc
         self.n_params = sum(p.numel() for p in self.params)
         offs, o = [], 0
         for p in self.params:
             offs.append(o)
             o += p.numel()
         self.poffs = offs
+
+    # gradient buckets smaller than this are merged with the next (shallower) encoder level's: an all-reduce costs ~20-30 us of latency
+    MIN_BUCKET_FLOATS = int(os.environ.get("U3D_MIN_BUCKET_MB", "1")) * (1 << 20) // 4
+
+    def _sync_encoder_level(self, cx, flat, level: int, pending_hi: int) -> int:
+        """Called by backward when encoder level `level` is done (levels run deepest first).  Hands the gradient slice
+        [offs[level], pending_hi) to the exchange once it holds MIN_BUCKET_FLOATS (or level 0 is reached) and returns the new upper end
+        of the not-yet-exchanged range.  With the decoder + head bucket that makes 2 + (number of big encoder levels) collectives per
+        step; the last one is followed by `finish()`."""
+        lo = self.enc_level_offs[level]
+        if level > 0 and pending_hi - lo < self.MIN_BUCKET_FLOATS:
+            return pending_hi
+        if pending_hi > lo:
+            cx.join()  # (a side-stream weight gradient of this level may still be writing its slice)
+            self.grad_sync.launch(flat[lo:pending_hi])
+        return lo
 
     def _virtual_weights(self):
         """ids of the conv weights whose input is a virtual concat (decoder first convs): fp32 kernels only"""
@@ -1404,6 +1427,7 @@ class UNet3DEngine:
 
         # ---- encoders, deepest to first
         dx0 = None
+        pending_hi = self.n_enc_params  # upper end of the encoder gradients not yet handed to the exchange
         for i in range(n_levels - 1, -1, -1):
             r1, r2 = enc_recs[i]
             dg2, coef2 = conv_bwd(r2, dz)
@@ -1411,6 +1435,8 @@ class UNet3DEngine:
             self._unact(dev, dz1, r2.src.t0)
             del dg2
             dg1, coef1 = conv_bwd(r1, dz1, need_dg=(i > 0 or need_input_grad))
+            if self.grad_sync is not None:
+                pending_hi = self._sync_encoder_level(cx, flat, i, pending_hi)  # this level's parameter gradients are final
             if i > 0:
                 pooled, argmax, e_in = tape.pools[i - 1]
                 Ne, De, He, We, Ce = e_in.shape
@@ -1432,7 +1458,6 @@ class UNet3DEngine:
 
         cx.join()
         if self.grad_sync is not None:
-            self.grad_sync.launch(flat[: self.n_enc_params])
             self.grad_sync.finish()
 
         dx = None
@@ -1923,6 +1948,7 @@ class ResUNetEngine(UNet3DEngine):
             self.grad_sync.launch(flat[self.n_enc_params :])
 
         dx0 = None
+        pending_hi = self.n_enc_params
         for i in range(n_levels - 1, -1, -1):
             rec = enc_blocks[i]
             recomputed = isinstance(rec, CkptRec)
@@ -1947,6 +1973,8 @@ class ResUNetEngine(UNet3DEngine):
                 dxin = self._conv1_bwd(cx, rec, dr, need_dx)
             else:
                 dxin = dr
+            if self.grad_sync is not None:
+                pending_hi = self._sync_encoder_level(cx, flat, i, pending_hi)  # this level's parameter gradients are final
             if recomputed:
                 cx.join()  # a side-stream weight gradient may still read the recomputed tensors released with `rec` below
             rec = None
@@ -1965,7 +1993,6 @@ class ResUNetEngine(UNet3DEngine):
 
         cx.join()
         if self.grad_sync is not None:
-            self.grad_sync.launch(flat[: self.n_enc_params])
             self.grad_sync.finish()
 
         dx = None
@@ -2098,37 +2125,29 @@ class GraphStep:
             engine.begin_forward(True)
             self.logits, self.probs, self.tape = engine.forward(self.static_x, True)
         self.static_dl = torch.zeros_like(self.logits)
-        self.g_bwd = torch.cuda.CUDAGraph()
         # Data parallelism (parallel.GradSync attached): RCCL launches cannot live inside a captured graph that is replayed with
-        # other buckets in flight, so the backward is captured as TWO graphs that meet exactly where engine.backward hands the
-        # [decoders | head] bucket to RCCL — `_CaptureSplit.launch` ends the first capture and begins the second on the same stream
-        # and pool; replay() issues the real all-reduces eagerly between / after the two replays (trainer.py:202-205 is the loop
-        # this serves: one gradient exchange per step, overlapped with the encoder backward).
-        self.g_bwd2 = None
+        # other buckets in flight, so the backward is captured as a CHAIN of graphs cut exactly where engine.backward hands a gradient
+        # bucket to RCCL ([decoders | head] first, then the encoder levels deepest first) — `_CaptureSplit.launch` ends the running
+        # capture and begins the next on the same stream and pool; backward() issues the real all-reduces eagerly between the replays
+        # (trainer.py:202-205 is the loop this serves: one gradient exchange per step, overlapped with the rest of the backward).
+        self.g_bwds = [torch.cuda.CUDAGraph()]
         self.sync = engine.grad_sync
         self.buckets: list = []
         if self.sync is not None:
-            self.g_bwd2 = torch.cuda.CUDAGraph()
             engine.grad_sync = _CaptureSplit(self)
         try:
-            if self.g_bwd2 is None:
-                with torch.cuda.graph(self.g_bwd, pool=self.pool, capture_error_mode="thread_local"):
+            # (what `torch.cuda.graph` does, by hand: its __exit__ would call capture_end() on the graph it was given, but with a split
+            # the capture has moved on to a later graph by then)
+            torch.cuda.synchronize(dev)
+            torch.cuda.empty_cache()
+            cap = torch.cuda.Stream(dev)
+            with torch.cuda.stream(cap):
+                self.g_bwds[0].capture_begin(pool=self.pool, capture_error_mode="thread_local")
+                try:
                     self.flat, self.dx = engine.backward(self.tape, self.static_dl, need_dx)
-            else:
-                # what `torch.cuda.graph` does, by hand: its __exit__ would call capture_end() on the graph it was given, but by then
-                # the capture has moved on to the second graph
-                torch.cuda.synchronize(dev)
-                torch.cuda.empty_cache()
-                cap = torch.cuda.Stream(dev)
-                with torch.cuda.stream(cap):
-                    self.g_bwd.capture_begin(pool=self.pool, capture_error_mode="thread_local")
-                    try:
-                        self.flat, self.dx = engine.backward(self.tape, self.static_dl, need_dx)
-                    finally:
-                        (self.g_bwd2 if self.buckets else self.g_bwd).capture_end()
-                torch.cuda.synchronize(dev)
-                if len(self.buckets) != 2:
-                    raise RuntimeError(f"u3d hip_graph: engine.backward launched {len(self.buckets)} gradient buckets during capture, expected 2")
+                finally:
+                    self.g_bwds[-1].capture_end()
+            torch.cuda.synchronize(dev)
         finally:
             engine.grad_sync = self.sync
         # Strong references to every PRE-CAPTURE device buffer the graphs dereference: the pack descriptor
@@ -2150,19 +2169,18 @@ class GraphStep:
                                "(graph mode keeps ONE tape per shape: run forward -> backward in turn, or set hip_graph: false / "
                                "U3D_GRAPH=0 for interleaved graphs)")
         self.static_dl.copy_(dlogits)
-        self.g_bwd.replay()
-        if self.g_bwd2 is not None:
-            n_enc = self.engine.n_enc_params
-            self.sync.launch(self.flat[n_enc:])   # [decoders | head]: final here, exchanged while the encoder graph runs
-            self.g_bwd2.replay()
-            self.sync.launch(self.flat[:n_enc])
+        for i, g in enumerate(self.g_bwds):
+            g.replay()
+            if i < len(self.buckets):
+                self.sync.launch(self.buckets[i])  # final here: exchanged while the following graphs run
+        if self.sync is not None:
             self.sync.finish()
         return self.flat.clone(), (self.dx.clone() if self.dx is not None else None)
 
 
 class _CaptureSplit:
-    """stands in for parallel.GradSync while GraphStep captures the backward: the first `launch` (the decoder + head bucket,
-    engine.backward) is the cut between the two backward graphs; the second launch and `finish` happen after the capture"""
+    """stands in for parallel.GradSync while GraphStep captures the backward: every `launch` (a gradient bucket that is final at
+    that point of engine.backward) is a cut between two backward graphs; the collectives themselves are issued at replay time"""
 
     def __init__(self, step: "GraphStep"):
         self.step = step
@@ -2170,9 +2188,9 @@ class _CaptureSplit:
     def launch(self, bucket: torch.Tensor) -> None:
         st = self.step
         st.buckets.append(bucket)
-        if len(st.buckets) == 1:
-            st.g_bwd.capture_end()
-            st.g_bwd2.capture_begin(pool=st.pool, capture_error_mode="thread_local")
+        st.g_bwds[-1].capture_end()
+        st.g_bwds.append(torch.cuda.CUDAGraph())
+        st.g_bwds[-1].capture_begin(pool=st.pool, capture_error_mode="thread_local")
 
     def finish(self) -> None:
         pass

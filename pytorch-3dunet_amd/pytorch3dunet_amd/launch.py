@@ -238,8 +238,7 @@ def create_distributed_trainer(config: dict, prefetch: bool = True):
             raise RuntimeError("several devices are visible to this rank: call launch.pin_device() before torch.cuda starts")
         trainer.grad_sync = parallel.attach(trainer.model, broadcast=True)
         if device == "cuda":
-            # U3D_RESERVE_CUS=k: the step runs on a stream CU-masked to all but k CUs, RCCL finds those idle (parallel.reserve_cus)
-            trainer.compute_streams = parallel.reserve_cus(next(trainer.model.parameters()).device)
+            parallel.cu_budget()  # U3D_RCCL_SLOTS=k: block slots the persistent convolution grids leave free for RCCL's kernels
         validate = trainer.validate
 
         def validate_all_ranks():

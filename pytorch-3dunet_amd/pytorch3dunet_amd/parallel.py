@@ -161,32 +161,20 @@ def attach(model: torch.nn.Module, process_group=None, broadcast: bool = True, f
     return sync
 
 
-def reserve_cus(device: torch.device, reserve: Optional[int] = None, make_current: bool = True):
-    """A CU budget for RCCL: returns `(compute_stream, reserved_stream)`.  `compute_stream` is a
-    HIP stream whose queue is CU-masked to all but `reserve` CUs (spread over the XCDs) and — unless `make_current=False` — becomes
-    this thread's current stream, so every kernel of the step is confined to those CUs while the library sizes its persistent and
-    one-block-per-CU grids for them (`u3d_streams_create_reserved`, tuning key 12).  RCCL's own streams are unmasked: its all-reduce
-    kernels find `reserve` idle CUs instead of queueing behind persistent blocks that own every CU's LDS and registers
-    (profiles/r03_overlap_probe.txt: 3 % of the exchange hidden without a budget).  `reserved_stream` is confined to exactly the
-    reserved CUs (None when reserve is 0); tools/overlap_probe.py runs its link-rate stand-in there.  `reserve=None` reads
-    U3D_RESERVE_CUS (default 0 = no budget: right for small models, whose whole exchange is ~1 % of a step — config 2: 0.25 of
-    17.5 ms — while every reserved CU costs 1/256 of the compute).  Results never depend on the budget."""
-    import ctypes
-
+def cu_budget(slots: Optional[int] = None) -> int:
+    """Leave `slots` block slots of the persistent convolution grids free (of 2 per CU; `u3d_set_tuning` key 12) so that RCCL's
+    all-reduce kernels find CUs with room beside them: the persistent grids otherwise own every CU's LDS and most of its registers,
+    and a kernel of another stream makes no progress until they end (profiles/r03_overlap_probe.txt: 3 % of the exchange hidden).
+    Each slot costs 1/512 of the convolution throughput.  `slots=None` reads U3D_RCCL_SLOTS (default 0: right for small models, whose
+    whole exchange is ~1 % of a step).  Process-wide; results never depend on it.  (A CU-MASKED compute queue — the textbook way to
+    reserve whole CUs — was measured and rejected: the same kernels run 40-75 % slower on a queue masked to 248 of 256 CUs,
+    profiles/r04_cu_mask_layer_bench_reserve8.txt.)"""
     from . import _native as nat
 
-    if reserve is None:
-        reserve = int(os.environ.get("U3D_RESERVE_CUS", "0"))
-    if reserve <= 0:
-        return torch.cuda.current_stream(device), None
-    cs, rs = ctypes.c_void_p(), ctypes.c_void_p()
-    nat.call("u3d_streams_create_reserved", device.index, int(reserve), ctypes.byref(cs), ctypes.byref(rs))
-    comp = torch.cuda.ExternalStream(cs.value, device=device)
-    res = torch.cuda.ExternalStream(rs.value, device=device) if rs.value else None
-    if make_current:
-        comp.wait_stream(torch.cuda.current_stream(device))
-        torch.cuda.set_stream(comp)
-    return comp, res
+    if slots is None:
+        slots = int(os.environ.get("U3D_RCCL_SLOTS", "0"))
+    nat.call("u3d_set_tuning", 12, int(slots))
+    return int(slots)
 
 
 def shard_batch(global_batch: int, rank: int, world: int) -> range:

@@ -268,12 +268,15 @@ print("RESULT " + json.dumps(res))
 
 
 @pytest.mark.timeout(900)
-def test_hip_graph_under_a_one_rank_rccl_group_is_bitwise_the_eager_synced_run():
+@pytest.mark.parametrize("min_bucket_mb,per_step", [("1", 2), ("0", 4)])
+def test_hip_graph_under_a_one_rank_rccl_group_is_bitwise_the_eager_synced_run(min_bucket_mb, per_step):
     """`hip_graph` used to refuse to run with the data-parallel exchange attached (every rank paid the eager
     host enqueue).  Now the backward is captured as two graphs cut where engine.backward hands the [decoders | head] bucket to
     RCCL; the all-reduces are launched eagerly between / after the replays (trainer.py:202-205's loop, one process per GPU).  On
     a 1-rank `nccl` group: three SGD steps with graphs == three eager steps with the same hooks, bit for bit (losses, gradients,
-    parameters), two collectives per backward, for UNet3D and ResidualUNet3D."""
+    parameters), for UNet3D and ResidualUNet3D.  The encoder gradients are exchanged level by level, deepest first, in buckets
+    of at least U3D_MIN_BUCKET_MB: these small nets make ONE encoder bucket at the default 1 MiB (2 collectives per backward) and
+    one per level at 0 (1 + 3 collectives: the backward is captured as a chain of four graphs)."""
     code = r'''
 import os, sys, json, copy
 sys.path.insert(0, os.path.join(os.getcwd(), "pytorch-3dunet_amd"))
@@ -316,13 +319,13 @@ for name, cls in (("unet", UNet3D), ("res", ResidualUNet3D)):
 dist.destroy_process_group()
 print("RESULT " + json.dumps(res))
 '''
-    proc = _spawn([sys.executable, "-c", code], {"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    proc = _spawn([sys.executable, "-c", code], {"HSA_ENABLE_IPC_MODE_LEGACY": "0", "U3D_MIN_BUCKET_MB": min_bucket_mb})
     assert proc.returncode == 0, proc.stderr[-3000:]
     r = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
     for name in ("unet", "res"):
-        # eager: 2 collectives x 3 steps; graph: + 2 of the warm-up step GraphStep runs before it captures
-        assert r[name] == {"loss": True, "grads": True, "params": True, "launched_eager": 6, "launched_graph": 8, "captured": 1,
-                           "off_reason": None}, r
+        # eager: per_step collectives x 3 steps; graph: + those of the warm-up step GraphStep runs before it captures
+        assert r[name] == {"loss": True, "grads": True, "params": True, "launched_eager": 3 * per_step, "launched_graph": 4 * per_step,
+                           "captured": 1, "off_reason": None}, r
 
 
 @pytest.mark.timeout(900)
@@ -334,7 +337,8 @@ def test_bench_under_torch_distributed_run_one_rank():
     assert proc.returncode == 0, proc.stderr[-3000:]
     line = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1]
     r = json.loads(line)
-    assert r["ranks_seen"] == {"world_size": 1, "backend": "nccl", "allreduce_per_step": 2}, r["ranks_seen"]
+    # [decoders | head], then the encoder levels deepest first in buckets of >= 1 MiB: enc3 (5.3 MB), enc2 (1.3 MB), enc1 + enc0
+    assert r["ranks_seen"] == {"world_size": 1, "backend": "nccl", "allreduce_per_step": 4}, r["ranks_seen"]
     assert r["n_gpus"] == 1 and r["value"] > 0 and "roofline" in r
 
 

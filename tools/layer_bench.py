@@ -47,13 +47,7 @@ def main():
     ap.add_argument("--only", default="fwd,dgrad,wgrad")
     ap.add_argument("--patch", default="64,128,128")
     ap.add_argument("--layers", default="", help="comma-separated layer names (default: all)")
-    ap.add_argument("--reserve", type=int, default=0, help="run on a stream CU-masked to all but this many CUs (parallel.reserve_cus)")
     args = ap.parse_args()
-    if args.reserve > 0:
-        from pytorch3dunet_amd import parallel
-
-        parallel.reserve_cus(dev, args.reserve)  # becomes the current stream: events, launches and allocations follow it
-        print(f"[compute stream CU-masked: {args.reserve} CUs reserved, tuning key 12 = {args.reserve}]")
     only = args.only.split(",")
     N = args.batch
     D0, H0, W0 = (int(v) for v in args.patch.split(","))

@@ -1,19 +1,22 @@
-"""Single-GPU probe of the gradient-exchange overlap (VERDICT r02 "weak" 10 / task 7): do kernels of ANOTHER HIP stream make
-progress beside the persistent convolution kernels of the encoder backward, or only at kernel boundaries / after them?
+"""Single-GPU probe of the gradient-exchange overlap (VERDICT r02 "weak" 10 / task 7): do kernels of ANOTHER HIP
+stream make progress beside the backward, or only after it?
 
 RCCL itself cannot be exercised with one rank (a 1-rank all-reduce in place launches nothing), so the exchange is replaced by a
-STAND-IN on the same hook (`engine.grad_sync.launch(bucket)` right after the decoder backward, `finish()` at the end): `passes`
-streaming passes over the bucket on a side stream, sized to the time a ring all-reduce of that bucket takes on one 153 GB/s xGMI
-link (2 * 7/8 * bytes / 153e9).  Reported per model: step time without exchange, with the stand-in on the side stream
-(overlapped), with the stand-in on the compute stream (serialised), and the stand-in's standalone duration.
+STAND-IN on the same hooks (`engine.grad_sync.launch(bucket)` wherever the engine hands a final gradient bucket to the exchange,
+`finish()` at the end), on a side stream.  Two stand-ins:
 
-    python tools/overlap_probe.py            # BASELINE configs 2 and 4
-    python tools/overlap_probe.py --reserve 8 [--only 4]
+  --standin torch   (round 3) chip-wide streaming passes (`bucket.mul_(1)`, thousands of workgroups at HBM rate), as many as take the
+                    time of a ring all-reduce of the bucket on one 153 GB/s xGMI link.  Pessimistic: it competes for HBM and for
+                    every CU, which a link-bound collective does not.
+  --standin link    (round 4, default) `u3d_debug_stream_pass`: 16 workgroups — the shape of RCCL's ring kernels, one per channel —
+                    streaming the bucket in place; the number of passes is CALIBRATED on the idle GPU so that the stand-in alone
+                    takes the ring all-reduce's time (2 * 7/8 * bytes / 153 GB/s).
 
---reserve k (round 4): the step runs on a stream CU-masked to all but k CUs (`parallel.reserve_cus`: the library sizes its
-persistent grids for 256 - k) and the stand-in runs on a stream confined to exactly those k CUs — RCCL's kernels are link-bound and
-need few CUs, so the stand-in is re-sized on ITS CUs: as many passes as take the ring all-reduce's time there.  Reported in
-addition: the step time without any exchange at 256 CUs, i.e. what the budget itself costs.
+--slots k: the persistent convolution grids leave k block slots free (parallel.cu_budget, tuning key 12).  Reported per model: step
+time without exchange (and without / with the budget), with the stand-in on the side stream, with the stand-in serialised on the
+compute stream, the stand-in's standalone duration, and the share of it that was hidden.
+
+    python tools/overlap_probe.py [--only 2|4] [--slots 0 16 32] [--standin link|torch]
 """
 import os
 import sys
@@ -30,46 +33,57 @@ dev = torch.device("cuda", 0)
 
 
 class StandIn:
-    def __init__(self, side: bool, gbps: float = 153.0, side_stream=None):
-        self.side = (side_stream or torch.cuda.Stream(dev)) if side else None
-        self.gbps = gbps
+    """engine.grad_sync stand-in: every launch(bucket) issues a kernel sequence that lasts as long as the ring all-reduce of that
+    bucket on one xGMI link; finish() makes the compute stream wait for them"""
+
+    BLOCKS = 16  # workgroups of the link-rate stand-in (RCCL: one per channel)
+
+    def __init__(self, side: bool, kind: str = "link", gbps: float = 153.0):
+        self.side = torch.cuda.Stream(dev) if side else None
+        self.kind, self.gbps = kind, gbps
         self.pending = False
-        self.ms_target = 0.0
-        self.pass_tbps = 4.0  # in-place pass rate on the stream the stand-in runs on (calibrate() measures it on a CU-masked stream)
+        self.launched = 0
+        self.bytes_per_ms = None  # link stand-in: measured in-place streaming rate of BLOCKS workgroups on the idle GPU
 
-    def calibrate(self, bucket):
-        """measured rate of one in-place pass over `bucket` on the stand-in's own stream (a few reserved CUs stream far below 4 TB/s)"""
-        s = self.side or torch.cuda.current_stream(dev)
-        with torch.cuda.stream(s):
-            for _ in range(2):
-                bucket.mul_(1.0)
-            s.synchronize()
+    def calibrate(self):
+        from pytorch3dunet_amd import _native as nat
+
+        buf = torch.zeros(32 << 20, device=dev)  # 128 MB
+        st = torch.cuda.current_stream(dev)
+        for reps in (1, 4):
+            torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(4):
-                bucket.mul_(1.0)
-            s.synchronize()
-            dt = (time.perf_counter() - t0) / 4
-        self.pass_tbps = 2 * bucket.numel() * 4 / dt / 1e12
-        return self.pass_tbps
+            nat.call("u3d_debug_stream_pass", dev.index, st.cuda_stream, buf.data_ptr(), buf.numel(), self.BLOCKS, reps)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        self.bytes_per_ms = 4 * buf.numel() * 4 / (dt * 1e3)
+        return self.bytes_per_ms
 
-    def passes_for(self, bucket):
-        # one in-place pass moves 2 x bytes at pass_tbps; the exchange takes 2 * 7/8 * bytes / link rate
-        t_x = 2 * 7 / 8 * bucket.numel() * 4 / (self.gbps * 1e9)
-        t_pass = 2 * bucket.numel() * 4 / (self.pass_tbps * 1e12)
-        return max(1, int(round(t_x / t_pass)))
+    def _issue(self, bucket, stream):
+        from pytorch3dunet_amd import _native as nat
 
-    def launch(self, bucket):
-        if bucket.numel() == 0:
-            return
-        n = self.passes_for(bucket)
-        if self.side is None:
+        t_x_ms = 2 * 7 / 8 * bucket.numel() * 4 / (self.gbps * 1e9) * 1e3
+        if self.kind == "torch":
+            n = max(1, int(round(t_x_ms / (2 * bucket.numel() * 4 / 4.0e12 * 1e3))))
             for _ in range(n):
                 bucket.mul_(1.0)
+            return
+        n4 = bucket.numel() - bucket.numel() % 4
+        off = (-bucket.data_ptr() // 4) % 4  # 16-byte alignment of the slice
+        view = bucket[off : off + ((n4 - off) // 4) * 4]
+        passes = max(1, int(round(t_x_ms * self.bytes_per_ms / (view.numel() * 4))))
+        nat.call("u3d_debug_stream_pass", dev.index, stream.cuda_stream, view.data_ptr(), view.numel(), self.BLOCKS, passes)
+
+    def launch(self, bucket):
+        if bucket.numel() < 16:
+            return
+        self.launched += 1
+        if self.side is None:
+            self._issue(bucket, torch.cuda.current_stream(dev))
             return
         self.side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(self.side):
-            for _ in range(n):
-                bucket.mul_(1.0)
+            self._issue(bucket, self.side)
         self.pending = True
 
     def finish(self):
@@ -78,8 +92,7 @@ class StandIn:
             self.pending = False
 
 
-def run(name, cfg, shape, steps=8, reserve=0):
-    from pytorch3dunet_amd import _native as nat
+def run(name, cfg, shape, steps=8, slots=0, kind="link"):
     from pytorch3dunet_amd import parallel
 
     torch.manual_seed(0)
@@ -88,16 +101,18 @@ def run(name, cfg, shape, steps=8, reserve=0):
     t = (torch.rand(shape, device=dev) > 0.5).float()
     crit = BCEDiceLoss()
     eng = model._get_engine()
+    rate = StandIn(False, kind).calibrate() if kind == "link" else None
 
     def step():
         model.zero_grad(set_to_none=True)
         _, logits = model(x, return_logits=True)
         crit(logits, t).backward()
 
-    def timed(mode, side_stream=None, tbps=None):
-        eng.grad_sync = None if mode == "none" else StandIn(side=(mode == "side"), side_stream=side_stream)
-        if tbps is not None and eng.grad_sync is not None:
-            eng.grad_sync.pass_tbps = tbps
+    def timed(mode):
+        sync = None if mode == "none" else StandIn(side=(mode == "side"), kind=kind)
+        if sync is not None:
+            sync.bytes_per_ms = rate
+        eng.grad_sync = sync
         for _ in range(3):
             step()
         torch.cuda.synchronize()
@@ -105,67 +120,39 @@ def run(name, cfg, shape, steps=8, reserve=0):
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
-        return 1e3 * (time.perf_counter() - t0) / steps
+        return 1e3 * (time.perf_counter() - t0) / steps, (sync.launched // (steps + 3) if sync else 0)
 
-    out = {}
-    full = timed("none")  # all CUs, no exchange: the reference point for what a budget costs
-    comp = res = None
-    tbps = None
-    default_stream = torch.cuda.current_stream(dev)
-    if reserve > 0:
-        comp, res = parallel.reserve_cus(dev, reserve)  # becomes the current stream; tuning key 12 = reserve
-        probe = StandIn(side=True, side_stream=res)
-        n_enc = eng.n_enc_params
-        tbps = probe.calibrate(torch.zeros(eng.n_params - n_enc, device=dev))
-    for mode in ("none", "side", "serial"):
-        out[mode] = timed(mode, side_stream=res, tbps=tbps if mode == "side" else None)
+    parallel.cu_budget(0)
+    full, _ = timed("none")
+    parallel.cu_budget(slots)
+    out = {m: timed(m) for m in ("none", "side", "serial")}
     eng.grad_sync = None
+    parallel.cu_budget(0)
     n_enc = eng.n_enc_params
-    flat = torch.zeros(eng.n_params, device=dev)
-    s = StandIn(side=res is not None, side_stream=res)
-    if tbps is not None:
-        s.pass_tbps = tbps
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(5):
-        s.launch(flat[n_enc:])
-        s.launch(flat[:n_enc])
-        s.finish()
-    torch.cuda.synchronize()
-    alone = 1e3 * (time.perf_counter() - t0) / 5
-    if reserve > 0:
-        # with a budget the stand-in's cost when NOT hidden is its standalone duration on its own CUs
-        hidden = 1.0 - (out["side"] - out["none"]) / max(alone, 1e-9)
-        print(f"{name} [reserve {reserve} CUs]: step {full:.2f} ms on all CUs without exchange -> {out['none']:.2f} ms on {256 - reserve} CUs "
-              f"(the budget costs {100 * (out['none'] / full - 1):.1f} %); with the stand-in on the {reserve} reserved CUs {out['side']:.2f} ms; "
-              f"stand-in alone on those CUs {alone:.2f} ms at {tbps:.2f} TB/s per pass -> {100 * hidden:.0f} % of it hidden; "
-              f"net vs unhidden exchange on all CUs ({full + alone:.2f} ms): {out['side']:.2f} ms", flush=True)
-        torch.cuda.set_stream(default_stream)
-        nat.call("u3d_set_tuning", 12, 0)
-        torch.cuda.synchronize()
-        for st in (comp, res):
-            if st is not None:
-                nat.call("u3d_stream_destroy", dev.index, st.cuda_stream)
-        return
-    hidden = (out["serial"] - out["side"]) / max(out["serial"] - out["none"], 1e-9)
-    print(f"{name}: params {eng.n_params / 1e6:.1f} M (decoder+head bucket {(eng.n_params - n_enc) * 4 / 1e6:.0f} MB, encoder bucket "
-          f"{n_enc * 4 / 1e6:.0f} MB); step {out['none']:.2f} ms without exchange, {out['side']:.2f} ms with the stand-in on a side stream, "
-          f"{out['serial']:.2f} ms serialised; stand-in alone {alone:.2f} ms -> {100 * hidden:.0f} % of its cost hidden", flush=True)
+    alone = out["serial"][0] - out["none"][0]  # the stand-in's own duration = what serialising it adds
+    hidden = (out["serial"][0] - out["side"][0]) / max(alone, 1e-9)
+    print(f"{name} [{kind} stand-in, {slots} free slots]: params {eng.n_params / 1e6:.1f} M (decoder+head {(eng.n_params - n_enc) * 4 / 1e6:.0f} MB, "
+          f"encoders {n_enc * 4 / 1e6:.0f} MB in {out['side'][1] - 1} level buckets); step {full:.2f} ms without exchange"
+          + (f" ({out['none'][0]:.2f} ms with the budget: {100 * (out['none'][0] / full - 1):+.1f} %)" if slots else "")
+          + f", {out['side'][0]:.2f} ms with the stand-in on a side stream, {out['serial'][0]:.2f} ms serialised (stand-in {alone:.2f} ms) -> "
+          f"{100 * hidden:.0f} % of the exchange hidden; net cost of the exchange {out['side'][0] - full:.2f} ms = "
+          f"{100 * (out['side'][0] / full - 1):.1f} % of the step", flush=True)
 
 
 if __name__ == "__main__":
     import argparse
 
     ap = argparse.ArgumentParser()
-    ap.add_argument("--reserve", type=int, nargs="*", default=[0])
+    ap.add_argument("--slots", type=int, nargs="*", default=[0])
     ap.add_argument("--only", type=int, default=0, help="2 or 4: just that BASELINE config")
+    ap.add_argument("--standin", default="link", choices=["link", "torch"])
     a = ap.parse_args()
-    for r in a.reserve:
+    for k in a.slots:
         if a.only in (0, 2):
             run("config 2 (UNet3D f_maps=32, 2x1x64x128x128, fp32)",
                 dict(name="UNet3D", in_channels=1, out_channels=1, f_maps=32, num_groups=8, final_sigmoid=True), (2, 1, 64, 128, 128),
-                reserve=r)
+                slots=k, kind=a.standin)
         if a.only in (0, 4):
             run("config 4 (ResidualUNet3D f_maps=64, 1x80x160x160, bf16)",
                 dict(name="ResidualUNet3D", in_channels=1, out_channels=1, f_maps=64, num_groups=8, final_sigmoid=True,
-                     compute_dtype="bf16"), (1, 1, 80, 160, 160), reserve=r)
+                     compute_dtype="bf16"), (1, 1, 80, 160, 160), slots=k, kind=a.standin)
