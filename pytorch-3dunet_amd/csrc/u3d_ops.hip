@@ -43,12 +43,12 @@ extern "C" int u3d_check_device(int device) {
 // RCCL's ring all-reduce runs a handful of workgroups (one per channel) that move data at the rate of the xGMI links, not of
 // HBM.  A 1-rank group launches nothing, so the single-GPU overlap probe needs a kernel of that shape: `blocks` workgroups of 256
 // threads stream `n` floats in place `passes` times (x <- x * 1).  Results never change.
-__global__ __launch_bounds__(256) void debug_stream_pass_kernel(float* __restrict__ buf, long long n4, int passes) {
+__global__ __launch_bounds__(256) void debug_stream_pass_kernel(float* __restrict__ buf, long long n4, int passes, float one) {
     f32x4* b = reinterpret_cast<f32x4*>(buf);
     for (int p = 0; p < passes; ++p)
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
             f32x4 v = b[i];
-            v *= 1.0f;
+            v *= one;  // (a run-time 1.0: a literal would let the compiler drop the load / store pair)
             b[i] = v;
         }
 }
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void debug_stream_pass_kernel(float* __restric
 extern "C" int u3d_debug_stream_pass(int device, u3d_stream_t stream, float* buf, long long n, int blocks, int passes) {
     U3D_ENTER(device);
     U3D_REQUIRE(buf && n >= 4 && blocks > 0 && passes > 0 && ((uintptr_t)buf & 15) == 0, "u3d_debug_stream_pass: bad argument");
-    hipLaunchKernelGGL(debug_stream_pass_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, buf, n / 4, passes);
+    hipLaunchKernelGGL(debug_stream_pass_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, buf, n / 4, passes, 1.0f);
     U3D_LAUNCH_CHECK();
     return 0;
 }

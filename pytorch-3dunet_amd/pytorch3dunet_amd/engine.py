@@ -2011,9 +2011,11 @@ class _UNet3DFunction(torch.autograd.Function):
     """The whole encoder-decoder as one autograd node (forward = engine.forward, backward = engine.backward)."""
 
     @staticmethod
-    def forward(ctx, engine: UNet3DEngine, x: torch.Tensor, *params):
-        # grad mode is always off inside Function.forward: needs_input_grad tells whether a backward can follow
-        save = any(ctx.needs_input_grad)
+    def forward(ctx, engine: UNet3DEngine, grad_mode: bool, x: torch.Tensor, *params):
+        # Grad mode is always off inside Function.forward, and `ctx.needs_input_grad` reports the inputs' requires_grad flags even
+        # when the CALLER runs under torch.no_grad() (round 4: inference forwards therefore kept a tape, advanced the repack salt and
+        # repacked every weight image each time — 6 ms per volume of BASELINE config 5).  The caller's grad mode is passed in.
+        save = grad_mode and any(ctx.needs_input_grad)
         with engine._lock:
             engine.begin_forward(save)
             logits, probs, tape = engine.forward(x, save)
@@ -2078,7 +2080,7 @@ class _UNet3DFunction(torch.autograd.Function):
         with engine._lock:
             flat, dx = engine.backward(tape, dlogits, ctx.x_requires_grad)
         del tape, saved
-        out = [None, dx]
+        out = [None, None, dx]
         for p, off in zip(engine.params, engine.poffs):
             out.append(flat[off : off + p.numel()].view(p.shape) if p.requires_grad else None)
         return tuple(out)
@@ -2307,7 +2309,7 @@ def run_model(engine: UNet3DEngine, x: torch.Tensor):
     if step is not None:
         outs = _GraphedUNet3DFunction.apply(step, x, *engine.params)
     else:
-        outs = _UNet3DFunction.apply(engine, x, *engine.params)
+        outs = _UNet3DFunction.apply(engine, torch.is_grad_enabled(), x, *engine.params)
     if len(outs) == 2:
         logits, probs = outs
         return probs, logits

@@ -417,3 +417,49 @@ def test_replaced_middle_parameter_objects_are_seen():
         assert torch.equal(model(x), want) and model._get_engine() is not eng2
         outs = [model(x) for _ in range(17)]
         assert torch.equal(outs[-1], want)
+
+
+def test_forward_under_no_grad_is_a_real_inference_forward():
+    """`ctx.needs_input_grad` inside an autograd.Function reports the parameters' requires_grad flags even when the caller is under
+    torch.no_grad(): until round 4 every inference forward (predictor.py:144-163 runs the model under no_grad) therefore kept an
+    activation tape, advanced the repack salt and repacked every weight image — 6 ms per volume of BASELINE config 5
+    (profiles/r04_cfg5_*).  Now the caller's grad mode decides: no pack launch after the first no_grad forward, no tape (peak memory
+    well below a forward that can be followed by a backward), identical outputs."""
+    from pytorch3dunet_amd import _native as nat
+    from pytorch3dunet_amd.unet3d.model import ResidualUNetSE3D
+
+    DEV = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    model = ResidualUNetSE3D(in_channels=3, out_channels=1, f_maps=[16, 32, 64], num_groups=8).to(DEV).eval()
+    assert all(p.requires_grad for p in model.parameters())
+    x = torch.randn(2, 3, 16, 32, 32, device=DEV)
+    with torch.no_grad():
+        y0 = model(x)
+        prof = nat.EventProfiler()
+        nat.profiler = prof
+        try:
+            y1 = model(x)
+            torch.cuda.synchronize()
+        finally:
+            nat.profiler = None
+    assert torch.equal(y0, y1)
+    packs = [k for k in prof.summary() if "pack" in k]
+    assert not packs, packs
+    del y0, y1
+
+    def peak(fn):
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        out = fn()
+        torch.cuda.synchronize()
+        return torch.cuda.max_memory_allocated() - base, out
+
+    def infer():
+        with torch.no_grad():
+            return model(x)
+
+    m_inf, y_inf = peak(infer)
+    m_grad, y_grad = peak(lambda: model(x))
+    assert y_grad.grad_fn is not None and y_inf.grad_fn is None and torch.equal(y_inf, y_grad.detach())
+    assert m_inf < 0.6 * m_grad, (m_inf, m_grad)

@@ -319,3 +319,61 @@ def test_config5_standard_predictor_on_the_full_volume():
     err = float(np.abs(got - expect).max())
     diag(test="cfg5_full_volume_predict", max_abs_err=err, ref_absmax=float(np.abs(expect).max()))
     assert err < 1e-3 * max(1.0, float(np.abs(expect).max())), err
+
+
+@pytest.mark.timeout(1500)
+def test_config5_bf16_predictor_against_the_bf16_operand_emulation(monkeypatch):
+    """BASELINE config 5 in `compute_dtype: bf16`: `predict_volume` — the device-resident form of
+    StandardPredictor's loop, predictor.py:112-214 — with a ResidualUNetSE3D whose 3x3x3 convolutions run on the bf16 matrix pipe,
+    against the reference loop on the host (oracle/predictor_oracle.py) driving the oracle's EMULATION of the same arithmetic
+    (oracle.BF16_OPERANDS: bf16 operands, wide accumulation) and its fp32 form.  SE nets keep fp32 activation storage.  Gates as
+    for the training path: closer to the emulation than the emulation is to fp32, and within the stated band of fp32."""
+    import predictor_oracle as porc
+    import unet3d_oracle as orc
+    from pytorch3dunet_amd.predictor import predict_volume
+    from pytorch3dunet_amd.unet3d.model import get_model
+
+    torch.manual_seed(21)
+    cfg = dict(name="ResidualUNetSE3D", in_channels=3, out_channels=1, f_maps=[32, 64, 128], num_groups=8, final_sigmoid=True)
+    base = get_model(dict(cfg)).eval()
+    with torch.no_grad():
+        for k, p in base.named_parameters():
+            if "groupnorm" in k:
+                p.add_(0.2 * torch.randn_like(p))
+    sd = {k: v.detach().clone() for k, v in base.state_dict().items()}
+    rng = np.random.RandomState(9)
+    shape, patch, stride, halo = (48, 96, 96), (24, 48, 48), (24, 48, 48), (4, 8, 8)
+    raw = (rng.randn(3, *shape) * 1.3 + 0.2).astype(np.float32)
+    gm = get_model(dict(cfg, compute_dtype="bf16"))
+    gm.load_state_dict(sd)
+    gm = gm.to(U.DEV).eval()
+    eng = gm._get_engine()
+    assert eng.bf16 and not eng.act_bf16
+    n0 = nat.launch_count
+    prof = nat.EventProfiler()
+    nat.profiler = prof
+    try:
+        got = predict_volume(gm, raw, patch, stride, halo, batch_size=2)
+        torch.cuda.synchronize()
+    finally:
+        nat.profiler = None
+    assert nat.launch_count > n0 and "u3d_conv3d_bf16_ex" in prof.summary()
+    torch.set_num_threads(32)
+
+    def host(x):
+        return orc.model_forward(sd, x, cfg["num_groups"], True, True)[0]
+
+    want32 = porc.standard_predict(host, raw, patch, stride, halo, batch_size=2)
+    orc.BF16_OPERANDS = True
+    try:
+        want16 = porc.standard_predict(host, raw, patch, stride, halo, batch_size=2)
+    finally:
+        orc.BF16_OPERANDS = False
+    assert got.shape == want32.shape == (1,) + shape
+    e_emu = float(np.abs(got - want16).max())
+    e_32 = float(np.abs(got - want32).max())
+    e_or = float(np.abs(want16 - want32).max())
+    diag(test="cfg5_bf16_predict", vs_emu=e_emu, vs_fp32=e_32, emu_vs_fp32=e_or)
+    print(dict(vs_emu=e_emu, vs_fp32=e_32, emu_vs_fp32=e_or))
+    # probabilities in [0, 1]: bf16 operands move them by ~1e-2 (the training-path tests: logits within 3e-2 of their range)
+    assert e_emu < 0.75 * e_or and e_32 < 1.25 * e_or + 1e-3 and e_32 < 5e-2, (e_emu, e_32, e_or)

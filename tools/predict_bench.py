@@ -57,11 +57,24 @@ def main():
     med = times[len(times) // 2]
     summ = prof.summary()
     fams = {k: round(v["ms"] / args.reps, 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:8]}
+    # roofline of the dominant MFMA family (HIP events around its C-ABI calls; FLOPs as declared by the executor = algorithmic FLOPs of
+    # the launches): fp32 MFMA peak 157.3 TFLOP/s, dense bf16 2500 (MI355X_MICROARCH.md)
+    mf = {k: v for k, v in summ.items() if v.get("flops")}
+    roof = None
+    if mf:
+        top = max(mf, key=lambda k: mf[k]["ms"])
+        peak = 2500.0 if "bf16" in top or "_t8" in top else 157.3
+        tf = mf[top]["flops"] / (mf[top]["ms"] * 1e-3) / 1e12
+        tot_fl = sum(v["flops"] for v in mf.values())
+        roof = {"bound": "mfma", "kernel": top, "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 3),
+                "launches_per_volume": mf[top]["calls"] // args.reps, "ms_per_volume": round(mf[top]["ms"] / args.reps, 3),
+                "all_mfma_tflops_over_the_whole_volume_time": round(tot_fl / args.reps / med / 1e12, 1)}
     print(json.dumps({"model": args.name, "f_maps": args.f_maps, "levels": args.levels, "volume": [args.in_channels, *vol],
                       "patch": patch, "stride": stride, "halo": halo, "model_input": [p + 2 * h for p, h in zip(patch, halo)],
                       "patches": n_patches, "batch": args.batch, "seconds_per_volume": round(med, 4),
                       "Mvoxels_per_s": round(vol[0] * vol[1] * vol[2] / med / 1e6, 2), "patches_per_s": round(n_patches / med, 2),
-                      "out_shape": list(out.shape), "kernel_ms_per_volume_top": fams}))
+                      "out_shape": list(out.shape), "compute": "bf16" if os.environ.get("U3D_BF16") == "1" else ("fp32_split" if os.environ.get("U3D_F32_SPLIT") == "1" else "fp32"),
+                      "roofline": roof, "kernel_ms_per_volume_top": fams}))
 
 
 if __name__ == "__main__":
