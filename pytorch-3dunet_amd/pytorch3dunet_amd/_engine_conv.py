@@ -1,0 +1,454 @@
+"""One SingleConv / ResNetBlock convolution (reference buildingblocks.py:99-135) forward and backward on the native kernels: which
+kernel FAMILY runs a layer (first-layer small-Cin, sub-pixel decoder, split-fp32, bf16 operands / bf16 storage, fp32 MFMA) is decided
+in ONE place per direction (`_fwd_family` / `_bwd_family`) and dispatched through a table — a new family is a new entry, not a
+new flag inside the layer code.  Mixin of `engine.UNet3DEngine`."""
+from __future__ import annotations
+
+import copy
+import ctypes
+import dataclasses
+import os
+import threading
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import _native as nat
+from ._native import U3DSrc
+
+from ._engine_base import *  # noqa: F401,F403  (explicit __all__: helpers, records, activation codes)
+
+
+class ConvLayers:
+    """mixin: layer-level forward / backward building blocks shared by the DoubleConv and the residual executors"""
+
+    def _identity_affine(self, N, C, dev):
+        """(N,C,2) table a = 1, b = 0: the 'GroupNorm affine' of a conv input that has no GroupNorm (post-norm orders)"""
+        key = ("ida", N, C, str(dev))
+        t = self._const.get(key)
+        if t is None:
+            t = self._const[key] = torch.tensor([1.0, 0.0], dtype=_F32, device=dev).repeat(N, C, 1).contiguous()
+        return t
+
+    def _identity_coef(self, N, C, dev):
+        """(N,3,C) table p = 1, q = 0, r = 0: GroupNorm backward of 'no GroupNorm' (dx = dg)"""
+        key = ("idc", N, C, str(dev))
+        t = self._const.get(key)
+        if t is None:
+            t = self._const[key] = torch.tensor([1.0, 0.0, 0.0], dtype=_F32, device=dev).view(1, 3, 1).repeat(N, 1, C).contiguous()
+        return t
+
+    def _unact(self, dev, g, y):
+        """in place: gradient w.r.t. the activated tensor y -> gradient w.r.t. its pre-activation (LeakyReLU / ELU; ReLU is
+        fused into the producing kernels as a mask, 'no activation' needs nothing)"""
+        if self.act in (ACT_LEAKY, ACT_ELU):
+            nat.call("u3d_act_bwd", dev.index, _stream(dev), _p(g), _p(y), g.numel(), self.act, self.slope, _p(g))
+
+    def _up_scale(self, dev):
+        """(1, 8, 8) on the (p, q, r) rows of a GroupNorm-backward coefficient table: a low-res voxel stands for 8 children"""
+        t = getattr(self, "_up_scale_t", None)
+        if t is None or t.device != dev:
+            t = self._up_scale_t = torch.tensor([1.0, 8.0, 8.0], dtype=_F32, device=dev).view(1, 3, 1)
+        return t
+
+    def _subpixel_layers(self, size):
+        """decoder first convs whose low-res input is upsampled by exactly 2 in every dimension at this input size:
+        {id(weight): (C0, C1)} — per-call state, handed down as the `sub` argument"""
+        if not self.subpixel or any(ct is not None for ct in self.dec_up) or any(self.dec_interp):
+            return {}  # (a transposed convolution yields 2n-1 voxels, resized to the skip: never an exact 2x replication)
+        dims = [tuple(size)]
+        for has_pool, _, _ in self.enc:
+            if has_pool:
+                dims.append(tuple(d // 2 for d in dims[-1]))
+        out = {}
+        L = len(self.enc)
+        for j, (c1, _) in enumerate(self.dec):
+            skip_lvl, low_lvl = L - 2 - j, L - 1 - j
+            if skip_lvl < 0 or low_lvl >= len(dims):
+                continue
+            C0 = self.enc[skip_lvl][2].conv.out_channels
+            C1 = c1.conv.in_channels - C0
+            if (all(a == 2 * b for a, b in zip(dims[skip_lvl], dims[low_lvl])) and C0 > 0 and C1 > 0 and C0 % 4 == 0
+                    and C1 % 4 == 0 and c1.conv.out_channels % 4 == 0):
+                out[id(c1.conv.weight)] = (C0, C1)
+        self._sub_pairs.update(out)
+        return out
+
+    def _stats_of(self, src: VSrc, st0, st1, pool: _StatPool, dev):
+        """(stats0, C0, scale0, stats1, C1, scale1) describing the per-channel sums of a (virtual) tensor"""
+        if src.t1 is None:
+            if st0 is None:
+                st0 = pool.take(src.N * src.C0 * 2)
+                s = src.struct()
+                nat.call("u3d_chan_stats", dev.index, _stream(dev), ctypes.byref(s), src.N, src.D, src.H, src.W, _p(st0))
+            return st0, src.C0, 1.0, None, 0, 0.0
+        if st0 is not None and st1 is not None and src.exact2x and self.fused_stats:
+            # every low-res voxel is replicated exactly 8x: reuse the producer's sums
+            return st0, src.C0, 1.0, st1, src.C1, 8.0
+        st = pool.take(src.N * src.C * 2)
+        s = src.struct()
+        nat.call("u3d_chan_stats", dev.index, _stream(dev), ctypes.byref(s), src.N, src.D, src.H, src.W, _p(st))
+        return st, src.C, 1.0, None, 0, 0.0
+
+    def _norm_finalize(self, kind, mod, st0, C0, sc0, st1, C1, sc1, N, G, count, affine, dev):
+        """per-(n,c) sums -> the (a, b) table the convolutions / apply passes use; returns what backward needs (mean, rstd)"""
+        if kind == "g":
+            mean_rstd = _empty((N, G, 2), dtype=_F32, device=dev)
+            nat.call("u3d_gn_finalize", dev.index, _stream(dev), _p(st0), C0, sc0, _p(st1), C1, sc1, N, G, count,
+                     _p(mod.weight.detach()), _p(mod.bias.detach()), float(mod.eps), _p(affine), _p(mean_rstd))
+            return mean_rstd
+        # nn.BatchNorm3d (buildingblocks.py:78-88): batch statistics + running-estimate update in training, running statistics in eval
+        C = C0 + C1
+        training = bool(mod.training) or mod.running_mean is None
+        mean_rstd = _empty((C, 2), dtype=_F32, device=dev)
+        momentum = 0.0
+        rm, rv = mod.running_mean, mod.running_var
+        if training and rm is not None:
+            if getattr(self, "_in_recompute", False):
+                rm = rv = None  # activation checkpointing re-runs this forward in backward: the estimates were updated the first time
+            else:
+                mod.num_batches_tracked.add_(1)  # (ATen's batch_norm does the same before the kernel)
+                momentum = (1.0 / float(mod.num_batches_tracked.item())) if mod.momentum is None else float(mod.momentum)
+        nat.call("u3d_bn_finalize", dev.index, _stream(dev), _p(st0), C0, sc0, _p(st1), C1, sc1, N, count, _p(mod.weight.detach()),
+                 _p(mod.bias.detach()), float(mod.eps), 1 if training else 0, momentum, _p(rm), _p(rv), _p(affine), _p(mean_rstd))
+        return mean_rstd
+
+    def _norm_bwd_finalize(self, cx, rec: ConvRec, gst, N, C, count, coef):
+        dev, gview = cx.dev, cx.gview
+        if rec.norm == "g":
+            nat.call("u3d_gn_bwd_finalize", dev.index, _stream(dev), _p(gst), _p(rec.mean_rstd), _p(rec.gn_w.detach()), N, C, rec.G,
+                     count, _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef))
+        else:
+            nat.call("u3d_bn_bwd_finalize", dev.index, _stream(dev), _p(gst), _p(rec.mean_rstd), _p(rec.gn_w.detach()), N, C, count,
+                     1 if rec.bn_training else 0, _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef))
+
+    def _single_conv_fwd(self, sc, name, src: VSrc, st_in, pool: _StatPool, tape: Optional[Tape], want_stats=True,
+                         residual: Optional[torch.Tensor] = None, sub=(), y_out: Optional[torch.Tensor] = None, act=None):
+        """One SingleConv (buildingblocks.py:99-135) in any native order (parse_order): 'gcr' = GroupNorm -> Conv3d -> ReLU fully
+        fused; other non-linearities / GroupNorm after the conv add one bandwidth pass (csrc/u3d_act.hip).  With `residual`:
+        f(conv(GN(x)) + residual), the tail of ResNetBlock.forward (buildingblocks.py:277-288; `act` = the block's f)."""
+        dev = src.t0.device
+        conv = sc.conv
+        spec = layer_spec(sc.order)
+        gn = getattr(sc, "groupnorm", None) if spec.norm == "g" else (getattr(sc, "batchnorm", None) if spec.norm == "b" else None)
+        N, D, H, W = src.N, src.D, src.H, src.W
+        Ctot, Cout = src.C, conv.out_channels
+        G = gn.num_groups if spec.norm == "g" else 1
+        post = not spec.pre  # the conv input has no norm of its own (post-norm and norm-free layers)
+        act, slope = (spec.act, spec.slope) if act is None else act
+        inner, islope = spec.inner, spec.islope  # 'crg' family: non-linearity on the conv output BEFORE its norm
+        assert conv.in_channels == Ctot and (gn is None or getattr(gn, "num_channels", getattr(gn, "num_features", None)) == (Cout if post else Ctot))
+        relu = 1 if ((act == ACT_RELU and not post) or inner == ACT_RELU) else 0
+        # `out += residual` follows the block's last GroupNorm: inside the conv epilogue for pre-norm orders, in the
+        # GroupNorm-apply pass for post-norm orders
+        conv_res = None if post else residual
+        # the conv epilogue's statistics describe the conv OUTPUT: they are the next GroupNorm's input only when nothing
+        # else transforms it (ReLU is in the epilogue); a post-norm layer needs them for its own GroupNorm
+        want_stats = ((post and spec.norm is not None and inner in (ACT_NONE, ACT_RELU))
+                      or (not post and want_stats and act in (ACT_NONE, ACT_RELU)))
+        # ONE flag for the finalize call (batch vs running statistics) and for backward (mean / rstd functions of x vs constants): a
+        # BatchNorm3d without running estimates normalises with batch statistics in eval mode too (_norm_finalize)
+        bn_training = (bool(gn.training) or gn.running_mean is None) if spec.norm == "b" else True
+        if post:
+            affine, mean_rstd = self._identity_affine(N, Ctot, dev), None
+        else:
+            st0, C0, sc0, st1, C1, sc1 = st_in
+            affine = _empty((N, Ctot, 2), dtype=_F32, device=dev)
+            mean_rstd = self._norm_finalize(spec.norm, gn, st0, C0, sc0, st1, C1, sc1, N, G, float(D * H * W), affine, dev)
+        # y_out: recomputation under activation checkpointing rewrites the (still alive) block output in place with the
+        # bit-identical values instead of allocating a second copy
+        b16 = src.t0.dtype == torch.bfloat16  # bf16 activation storage: only the bf16-operand branch below handles it
+        if b16:
+            assert self.act_bf16 and src.t1 is None and not post and self._bf16_layer(Ctot, Cout) and act == ACT_RELU, \
+                "bf16 activation storage reached a layer outside its envelope"
+        y = y_out if (y_out is not None and not post) else _empty((N, D, H, W, Cout), dtype=src.t0.dtype if b16 else _F32, device=dev)
+        small = self.small_cin and src.t1 is None and Ctot <= 4 and Cout <= 32 and residual is None and not b16
+        if small:
+            # first layer of the network: K = 27*Cin is too small for the MFMA tiling (csrc/u3d_smallc.hip)
+            ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
+            nat.call("u3d_conv3d_small_cin_fwd", dev.index, _stream(dev), _p(src.t0), _p(affine), _p(conv.weight.detach()),
+                     _p(y), N, D, H, W, Ctot, Cout, relu, _p(ystats), flops=54.0 * Ctot * Cout * N * D * H * W)
+        elif src.t1 is not None and residual is None and id(conv.weight) in sub:
+            # cat(skip, nearest2x(low)): the upsampled half as 8 parity-class 2x2x2 convolutions over the low-res tensor
+            # (8/27 of the multiply-adds), then the skip half, whose epilogue adds the partial sums before ReLU / statistics
+            C0, C1 = sub[id(conv.weight)]
+            ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
+            part = _empty((N, D, H, W, Cout), dtype=_F32, device=dev)
+            D1, H1, W1 = D // 2, H // 2, W // 2
+            need = nat.get_lib().u3d_subpixel_fwd_workspace_floats(N, D1, H1, W1, C1, Cout)  # split-K scratch, small levels only
+            kws = _empty(need, dtype=_F32, device=dev) if need > 0 else None
+            nat.call("u3d_subpixel_conv_fwd", dev.index, _stream(dev), _p(src.t1), _p(affine.view(-1)[2 * C0:]), Ctot * 2,
+                     _p(self._pack_cache[(id(conv.weight), 12)][1]), _p(part), N, D1, H1, W1, C1, Cout, _p(kws), need,
+                     flops=128.0 * C1 * Cout * N * D1 * H1 * W1)
+            a0 = affine[:, :C0].contiguous()
+            if self._split_fwd(C0, Cout):
+                nat.call("u3d_conv3d_f32s", dev.index, _stream(dev), _p(src.t0), _p(a0), _p(self._packed_f32s(conv.weight, 0, dev, C0, 0)),
+                         _p(y), N, D, H, W, C0, Cout, relu, _p(ystats), None, None, _p(part), None, 0,
+                         flops=54.0 * C0 * Cout * N * D * H * W)
+            else:
+                s0 = VSrc(src.t0).struct(a0)
+                nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s0), _p(self._pack_cache[(id(conv.weight), 10)][1]),
+                         _p(y), N, D, H, W, Cout, relu, _p(ystats), None, None, _p(part), None, 0,
+                         flops=54.0 * C0 * Cout * N * D * H * W)
+        elif src.t1 is None and self._split_fwd(Ctot, Cout):
+            # fp32 operands split into three bf16 values each, six partial products on the bf16 MFMA pipe (csrc/u3d_bf16.hip)
+            ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
+            need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(N, D, H, W, Ctot, Cout)
+            kws = _empty(need, dtype=_F32, device=dev) if need > 0 else None
+            nat.call("u3d_conv3d_f32s", dev.index, _stream(dev), _p(src.t0), _p(affine), _p(self._packed_f32s(conv.weight, 0, dev)),
+                     _p(y), N, D, H, W, Ctot, Cout, relu, _p(ystats), None, None, _p(conv_res), _p(kws), need,
+                     flops=54.0 * Ctot * Cout * N * D * H * W)
+        elif src.t1 is None and self._bf16_layer(Ctot, Cout):
+            # bf16 MFMA operands, fp32 accumulation / epilogue (csrc/u3d_bf16.hip); with bf16 activation storage the input, the
+            # output and the residual are bf16 tensors (`_b16` entry point)
+            ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
+            need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(N, D, H, W, Ctot, Cout)  # split-K scratch at the bottom of the U
+            kws = _empty(need, dtype=_F32, device=dev) if need > 0 else None
+            nat.call("u3d_conv3d_bf16_ex" + ("_b16" if b16 else ""), dev.index, _stream(dev), _p(src.t0), _p(affine),
+                     _p(self._packed_bf16(conv.weight, 0, dev)), _p(y), N, D, H, W, Ctot, Cout, relu, _p(ystats), None, None,
+                     _p(conv_res), _p(kws), need, flops=54.0 * Ctot * Cout * N * D * H * W)
+        else:
+            wp = self._packed(conv.weight, 0, dev)
+            ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
+            s = src.struct(affine)
+            # bottom-of-the-U shapes split the channel reduction over blocks through a scratch buffer (0 floats otherwise)
+            need = nat.get_lib().u3d_conv3d_workspace_floats(N, D, H, W, Ctot, Cout)
+            kws = _empty(need, dtype=_F32, device=dev) if need > 0 else None
+            nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s), _p(wp), _p(y), N, D, H, W, Cout, relu,
+                     _p(ystats), None, None, _p(conv_res), _p(kws), need, flops=54.0 * Ctot * Cout * N * D * H * W)
+        post_rec = None
+        if post:
+            # GroupNorm over the conv output z (statistics from the conv epilogue), then the non-linearity: y = f(a*z + b);
+            # 'crg' family: z is already f_inner(conv) (ReLU in the epilogue, LeakyReLU / ELU in place here)
+            if inner in (ACT_LEAKY, ACT_ELU):
+                nat.call("u3d_act_fwd", dev.index, _stream(dev), _p(y), y.numel(), inner, islope, _p(y))
+            z, zst = y, ystats
+            aff2 = _empty((N, Cout, 2), dtype=_F32, device=dev)
+            if spec.norm is None:
+                # no norm: the conv's bias (buildingblocks.py:54-55) is the constant affine (1, bias)
+                nat.call("u3d_bias_table", dev.index, _stream(dev), _p(conv.bias.detach()), N, Cout, _p(aff2))
+            else:
+                if zst is None and (spec.norm == "g" or bn_training):
+                    zst = self._stats_of(VSrc(z), None, None, pool, dev)[0]
+                mean_rstd = self._norm_finalize(spec.norm, gn, zst, Cout, 1.0, None, 0, 0.0, N, G, float(D * H * W), aff2, dev)
+            y = y_out if y_out is not None else _empty_like(z)
+            nat.call("u3d_affine_add_act_fwd", dev.index, _stream(dev), _p(z), _p(aff2), _p(residual), N, D * H * W, Cout, act,
+                     slope, _p(y))
+            post_rec, ystats = (z, aff2, inner, islope), None
+        elif act in (ACT_LEAKY, ACT_ELU):
+            nat.call("u3d_act_fwd", dev.index, _stream(dev), _p(y), y.numel(), act, slope, _p(y))
+            ystats = None
+        drop_rec = None
+        dmod = getattr(sc, "dropout", None) if spec.drop == "d" else (getattr(sc, "dropout2d", None) if spec.drop == "D" else None)
+        if dmod is not None and dmod.training and dmod.p > 0.0:
+            # The MASK comes from torch's generator exactly as the reference draws it (F.dropout on an NCDHW tensor of this
+            # shape / feature_dropout's (N,C,1,1,1) noise: same Philox consumption, same element order), applied natively.
+            if spec.drop == "d":
+                m = F.dropout(torch.ones((N, Cout, D, H, W), dtype=_F32, device=dev), dmod.p, True)
+                if Cout == 1:
+                    mask = m.view(N, D, H, W, 1)
+                else:
+                    mask = _empty((N, D, H, W, Cout), dtype=_F32, device=dev)
+                    nat.call("u3d_ncdhw_to_ndhwc", dev.index, _stream(dev), _p(m), _p(mask), N, Cout, D * H * W)
+                nat.call("u3d_mul", dev.index, _stream(dev), _p(y), _p(mask), y.numel(), _p(y))
+                drop_rec = ("d", mask)
+            else:
+                m = torch.feature_dropout(torch.ones((N, Cout, 1, 1, 1), dtype=_F32, device=dev), dmod.p, True).view(N, Cout)
+                table = torch.stack((m, torch.zeros_like(m)), dim=-1).contiguous()
+                nat.call("u3d_affine_act_fwd", dev.index, _stream(dev), _p(y), _p(table), N, D * H * W, Cout, ACT_NONE, 0.0, _p(y))
+                drop_rec = ("D", table)
+            ystats = None  # the epilogue's sums describe the tensor before the dropout
+        if tape is not None:
+            nw = gn.weight if gn is not None else None
+            tape.convs.append(
+                ConvRec(name, src, affine, mean_rstd, y, nw, conv.weight, G,
+                        self._pindex[id(gn.weight)] if gn is not None else -1,
+                        self._pindex[id(gn.bias)] if gn is not None else self._pindex[id(conv.bias)],
+                        self._pindex[id(conv.weight)], small,
+                        sub.get(id(conv.weight)) if (sub and src.t1 is not None and residual is None) else None,
+                        not post, post_rec, spec.norm, bn_training, drop_rec)
+            )
+        return y, ystats
+
+    # -- backward building blocks (shared by the DoubleConv and the residual executors) -----------------------
+    def _conv_bwd(self, cx, rec: ConvRec, dz_, need_dg=True):
+        """wgrad + dgrad + GroupNorm-backward reductions of one SingleConv; returns (dg, coef)"""
+        dev, pool, ws, gview = cx.dev, cx.pool, cx.ws, cx.gview
+        src = rec.src
+        Nn, Dd, Hh, Ww = src.N, src.D, src.H, src.W
+        Cout = rec.y.shape[-1]
+        if rec.drop is not None:
+            # trailing dropout: the consumers already removed f through the (rescaled, sign-preserving) layer output
+            kind, mask = rec.drop
+            g = _empty_like(dz_)
+            if kind == "d":
+                nat.call("u3d_mul", dev.index, _stream(dev), _p(dz_), _p(mask), dz_.numel(), _p(g))
+            else:
+                nat.call("u3d_affine_act_fwd", dev.index, _stream(dev), _p(dz_), _p(mask), Nn, Dd * Hh * Ww, Cout, ACT_NONE, 0.0, _p(g))
+            dz_ = g
+        if rec.post is not None:
+            # post-norm layer: dz_ is the gradient w.r.t. n = a*z + b (the caller removed the non-linearity): norm backward
+            # over the conv output z first — sums (sum dn, sum dn*z), parameter gradients, dz = p*dn + q*z + r
+            z, _, inner, islope = rec.post
+            Vz = Dd * Hh * Ww
+            gst2 = pool.take(Nn * Cout * 2)
+            nat.call("u3d_pair_stats", dev.index, _stream(dev), _p(dz_), _p(z), Nn, Vz, Cout, _p(gst2))
+            if rec.norm is None:
+                # norm-free layer: n = z + bias -> dbias = sum dn, dz = dn
+                nat.call("u3d_bias_grad", dev.index, _stream(dev), _p(gst2), Nn, Cout, _p(gview(rec.idx_gb)))
+            else:
+                coef2 = _empty((Nn, 3, Cout), dtype=_F32, device=dev)
+                self._norm_bwd_finalize(cx, rec, gst2, Nn, Cout, float(Vz), coef2)
+                dz_ = self._plain_apply(cx, dz_, coef2, z, 1 if inner == ACT_RELU else 0)  # ('crg': z = relu(conv), mask fused)
+                if inner in (ACT_LEAKY, ACT_ELU):
+                    nat.call("u3d_act_bwd", dev.index, _stream(dev), _p(dz_), _p(z), dz_.numel(), inner, islope, _p(dz_))
+        if self.debug is not None:
+            self.debug[rec.name + ".dz"] = dz_.clone()
+        if rec.small and not need_dg:
+            # one pass gives dw and the GroupNorm-backward sums; no data gradient needed (csrc/u3d_smallc.hip)
+            gst = pool.take(Nn * src.C * 2)
+            nat.call("u3d_conv3d_small_cin_bwd", dev.index, _stream(dev), _p(src.t0), _p(rec.affine), _p(dz_),
+                     _p(rec.conv_w.detach()), _p(gview(rec.idx_w)), _p(gst), Nn, Dd, Hh, Ww, src.C, Cout, _p(ws), ws.numel(),
+                     flops=2 * 54.0 * src.C * Cout * Nn * Dd * Hh * Ww)
+            if not rec.pre_norm:
+                return None, self._identity_coef(Nn, src.C, dev)
+            coef = _empty((Nn, 3, src.C), dtype=_F32, device=dev)
+            self._norm_bwd_finalize(cx, rec, gst, Nn, src.C, float(Dd * Hh * Ww), coef)
+            return None, coef
+        s_aff = src.struct(rec.affine)
+        flops = 54.0 * src.C * Cout * Nn * Dd * Hh * Ww
+        bf16 = src.t1 is None and rec.sub is None and not rec.small and self._bf16_layer(src.C, Cout)
+        b16 = src.t0.dtype == torch.bfloat16  # bf16 activation storage
+        assert not b16 or (bf16 and Cout % 64 == 0 and dz_.dtype == torch.bfloat16)
+        if bf16 and Cout % 64 == 0:
+            need = nat.get_lib().u3d_wgrad_bf16_workspace_floats(Nn, Dd, Hh, Ww, src.C, Cout)
+            ws = cx.ensure_ws(need)
+            nat.call("u3d_conv3d_wgrad_bf16" + ("_b16" if b16 else ""), dev.index, _stream(dev), _p(src.t0), _p(rec.affine), _p(dz_),
+                     _p(gview(rec.idx_w)), Nn, Dd, Hh, Ww, src.C, Cout, _p(ws), ws.numel(), flops=flops)
+        elif rec.sub is not None:
+            # weight gradient in two channel slices of the same (Cout, Ctot, 27) buffer: upsampled channels from the 64
+            # (parity class, tap half) matrices over the low-res grid, skip channels from the standard kernel
+            C0, C1 = rec.sub
+            Ct = src.C
+            dwv = gview(rec.idx_w)
+            nat.call("u3d_subpixel_conv_wgrad", dev.index, _stream(dev), _p(src.t1), _p(rec.affine.view(-1)[2 * C0:]), Ct * 2,
+                     _p(dz_), _p(dwv[C0 * 27:]), Ct, Nn, src.D1, src.H1, src.W1, C1, Cout, _p(ws), ws.numel(),
+                     flops=128.0 * C1 * Cout * Nn * src.D1 * src.H1 * src.W1)
+            a0 = rec.affine[:, :C0].contiguous()
+            s0 = VSrc(src.t0).struct(a0)
+            nat.call("u3d_conv3d_wgrad_strided", dev.index, _stream(dev), ctypes.byref(s0), _p(dz_), _p(dwv), Ct, Nn, Dd, Hh, Ww,
+                     Cout, _p(ws), ws.numel(), flops=54.0 * C0 * Cout * Nn * Dd * Hh * Ww)
+        elif self.overlap_small_wgrad and Nn * Dd * Hh * Ww <= cx.SIDE_MAX_VOXELS and self.debug is None:
+            # small layer: neither kernel fills the chip on its own -> weight gradient on the side stream, data gradient
+            # (below) on the caller's stream; joined before anything consumes the flat gradient buffer
+            need = nat.get_lib().u3d_wgrad_workspace_floats(Nn, Dd, Hh, Ww, src.C, Cout)
+            side = cx.side_stream(need)
+            side.wait_stream(torch.cuda.current_stream(dev))  # dz_ (and the flat buffer) are ready
+            with torch.cuda.stream(side):
+                nat.call("u3d_conv3d_wgrad", dev.index, _stream(dev), ctypes.byref(s_aff), _p(dz_), _p(gview(rec.idx_w)), Nn,
+                         Dd, Hh, Ww, Cout, _p(cx.ws_side), cx.ws_side.numel(), flops=flops)
+            dz_.record_stream(side)  # dz_ is released on the main stream while the side stream may still read it
+            cx.side_used = True
+        else:
+            nat.call("u3d_conv3d_wgrad", dev.index, _stream(dev), ctypes.byref(s_aff), _p(dz_), _p(gview(rec.idx_w)), Nn, Dd,
+                     Hh, Ww, Cout, _p(ws), ws.numel(), flops=flops)
+        s_dz = VSrc(dz_).struct()
+        if rec.sub is not None:
+            # skip half at full resolution; upsampled half directly at LOW resolution (the children sum of the nearest
+            # upsampling is folded into the 4x4x4-tap stride-2 gather).  dg = (dg_skip, dlow)
+            C0, C1 = rec.sub
+            dg0 = _empty((Nn, Dd, Hh, Ww, C0), dtype=_F32, device=dev)
+            dlow = _empty_like(src.t1)
+            gst0, gst1 = pool.take(Nn * C0 * 2), pool.take(Nn * C1 * 2)
+            if self._split_dgrad(C0, Cout):
+                need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(Nn, Dd, Hh, Ww, Cout, C0)
+                kws = cx.ensure_ws(need) if need > 0 else None
+                nat.call("u3d_conv3d_f32s", dev.index, _stream(dev), _p(dz_), None, _p(self._packed_f32s(rec.conv_w, 1, dev, C0, 0)),
+                         _p(dg0), Nn, Dd, Hh, Ww, Cout, C0, 0, None, _p(src.t0), _p(gst0), None, _p(kws), need,
+                         flops=54.0 * C0 * Cout * Nn * Dd * Hh * Ww)
+            else:
+                s_x0 = VSrc(src.t0).struct()
+                nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s_dz), _p(self._packed_sub(rec, 11, dev)), _p(dg0),
+                         Nn, Dd, Hh, Ww, C0, 0, None, ctypes.byref(s_x0), _p(gst0), None, _p(ws), ws.numel(),
+                         flops=54.0 * C0 * Cout * Nn * Dd * Hh * Ww)
+            nat.call("u3d_subpixel_conv_dgrad", dev.index, _stream(dev), _p(dz_), _p(self._packed_sub(rec, 13, dev)), _p(src.t1),
+                     _p(dlow), _p(gst1), Nn, src.D1, src.H1, src.W1, C1, Cout,
+                     flops=128.0 * C1 * Cout * Nn * src.D1 * src.H1 * src.W1)
+            gst = torch.cat((gst0.view(Nn, C0, 2), gst1.view(Nn, C1, 2)), dim=1)
+            dg = (dg0, dlow)
+        elif src.t1 is None and not rec.small and self._split_dgrad(src.C, Cout):
+            dg = _empty((Nn, Dd, Hh, Ww, src.C), dtype=_F32, device=dev)
+            gst = pool.take(Nn * src.C * 2)
+            need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(Nn, Dd, Hh, Ww, Cout, src.C)
+            kws = cx.ensure_ws(need) if need > 0 else None
+            nat.call("u3d_conv3d_f32s", dev.index, _stream(dev), _p(dz_), None, _p(self._packed_f32s(rec.conv_w, 1, dev)), _p(dg),
+                     Nn, Dd, Hh, Ww, Cout, src.C, 0, None, _p(src.t0), _p(gst), None, _p(kws), need, flops=flops)
+        elif bf16:
+            dg = _empty((Nn, Dd, Hh, Ww, src.C), dtype=dz_.dtype if b16 else _F32, device=dev)
+            gst = pool.take(Nn * src.C * 2)
+            need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(Nn, Dd, Hh, Ww, Cout, src.C)
+            kws = cx.ensure_ws(need) if need > 0 else None
+            nat.call("u3d_conv3d_bf16_ex" + ("_b16" if b16 else ""), dev.index, _stream(dev), _p(dz_), None,
+                     _p(self._packed_bf16(rec.conv_w, 1, dev)), _p(dg), Nn, Dd, Hh, Ww, Cout, src.C, 0, None, _p(src.t0), _p(gst),
+                     None, _p(kws), need, flops=flops)
+        else:
+            wpd = self._packed(rec.conv_w, 1, dev)
+            dg = _empty((Nn, Dd, Hh, Ww, src.C), dtype=_F32, device=dev)
+            gst = pool.take(Nn * src.C * 2)
+            s_x = src.struct()
+            nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s_dz), _p(wpd), _p(dg), Nn, Dd, Hh, Ww, src.C, 0, None,
+                     ctypes.byref(s_x), _p(gst), None, _p(ws), ws.numel(), flops=flops)
+        if self.debug is not None and rec.sub is None:
+            self.debug[rec.name + ".dg"] = dg.clone()
+        if not rec.pre_norm:
+            return dg, self._identity_coef(Nn, src.C, dev)  # no GroupNorm on the conv input: dx = dg
+        coef = _empty((Nn, 3, src.C), dtype=_F32, device=dev)
+        self._norm_bwd_finalize(cx, rec, gst, Nn, src.C, float(Dd * Hh * Ww), coef)
+        return dg, coef
+
+    def _plain_apply(self, cx, dg, coef, x, relu_mask, add=None):
+        """GroupNorm backward, elementwise part: (p*dg + q*x + r [+ add]) * (relu_mask ? x > 0 : 1)"""
+        dev = cx.dev
+        out = _empty_like(x)
+        Nn = x.shape[0]
+        C = x.shape[-1]
+        if x.dtype == torch.bfloat16:  # bf16 activation storage (dg, x, add, out all bf16)
+            nat.call("u3d_gn_bwd_apply_b16", dev.index, _stream(dev), _p(dg), C, 0, _p(x), C, _p(coef), C, x.numel() // (Nn * C), Nn,
+                     relu_mask, _p(add), _p(out))
+            return out
+        if add is None:
+            nat.call("u3d_gn_bwd_apply", dev.index, _stream(dev), _p(dg), C, 0, _p(x), C, _p(coef), C, x.numel() // (Nn * C), Nn,
+                     relu_mask, _p(out))
+        else:
+            nat.call("u3d_gn_bwd_apply_add", dev.index, _stream(dev), _p(dg), C, 0, _p(x), C, _p(coef), C,
+                     x.numel() // (Nn * C), Nn, relu_mask, _p(add), _p(out))
+        return out
+
+    def _wgrad_workspace(self, tape, dev):
+        return _empty(max(self._wgrad_workspace_floats(tape.convs), 4), dtype=_F32, device=dev)
+
+    def _layer_ws_floats(self, N, D, H, W, Cin, Cout, sub=None, small=False, virtual=False):
+        """scratch floats one 3x3x3 layer's backward needs from the shared buffer, for the kernels it will actually run"""
+        lib = nat.get_lib()
+        if small:
+            return lib.u3d_small_cin_bwd_workspace_floats(N, D, H, W, Cin, Cout)
+        if sub is not None:  # skip slice (fp32 kernels) + sub-pixel slice
+            return max(lib.u3d_wgrad_workspace_floats(N, D, H, W, sub[0], Cout),
+                       lib.u3d_subpixel_wgrad_workspace_floats(N, D // 2, H // 2, W // 2, sub[1], Cout),
+                       lib.u3d_conv3d_workspace_floats(N, D, H, W, Cout, sub[0]))
+        if not virtual and self._bf16_layer(Cin, Cout):
+            need = lib.u3d_conv3d_bf16_workspace_floats(N, D, H, W, Cout, Cin)  # data gradient: roles swapped
+            wg = lib.u3d_wgrad_bf16_workspace_floats(N, D, H, W, Cin, Cout) if Cout % 64 == 0 else lib.u3d_wgrad_workspace_floats(
+                N, D, H, W, Cin, Cout)
+            return max(need, wg)
+        return max(lib.u3d_wgrad_workspace_floats(N, D, H, W, Cin, Cout), lib.u3d_conv3d_workspace_floats(N, D, H, W, Cout, Cin))
+
+    def _wgrad_workspace_floats(self, convs):
+        """scratch floats the backward kernels of these recorded layers need (one shared buffer, sized once per backward)"""
+        need = 0
+        for r in convs:
+            need = max(need, self._layer_ws_floats(r.src.N, r.src.D, r.src.H, r.src.W, r.src.C, r.y.shape[-1], r.sub, r.small,
+                                                   r.src.t1 is not None))
+        return int(need)

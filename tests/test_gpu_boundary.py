@@ -409,14 +409,23 @@ def test_replaced_middle_parameter_objects_are_seen():
         model.invalidate_native_caches()
         y2 = model(x)
         assert model._get_engine() is not eng1 and (y2 - y1).abs().max().item() > 1e-5 and torch.equal(y2, fresh_output())
-        # 3. attribute assignment alone: a conv / norm parameter the executor indexes is missed at once (StaleParameters -> rebuild),
-        #    anything else by the periodic walk at the latest
+        # 3. attribute assignment alone.  Inference reads the module's tensors live (the weight image cache is keyed by object and
+        #    version), so the output is right at once; the periodic identity walk replaces the executor within 16 forwards
         eng2 = model._get_engine()
         conv.weight = torch.nn.Parameter(conv.weight.detach() * 0.5)
         want = fresh_output()
-        assert torch.equal(model(x), want) and model._get_engine() is not eng2
+        assert torch.equal(model(x), want)
         outs = [model(x) for _ in range(17)]
-        assert torch.equal(outs[-1], want)
+        assert torch.equal(outs[-1], want) and model._get_engine() is not eng2
+    # 4. ... and a TRAINING forward indexes its parameters (tape records): the replaced object is missed at once (StaleParameters ->
+    #    the executor is rebuilt and the forward re-run), so the gradient lands in the NEW parameter
+    model.train()
+    eng3 = model._get_engine()
+    conv.weight = torch.nn.Parameter(conv.weight.detach() * 1.25)
+    _, logits = model(x, return_logits=True)
+    assert model._get_engine() is not eng3
+    logits.square().mean().backward()
+    assert conv.weight.grad is not None and conv.weight.grad.abs().sum().item() > 0
 
 
 def test_forward_under_no_grad_is_a_real_inference_forward():
