@@ -77,9 +77,10 @@ int u3d_set_tuning(int key, int value);
  * twin of the kernel in which every wave records 24 int64 (block, HW_ID, XCC_ID, shader-clock stamps at entry /
  * first tile staged / end of each chunk's k-loop / epilogue start / exit).  NULL switches it off (default). */
 int u3d_set_profile_buffer(void* device_buffer, size_t bytes);
-/* Developer aid (tools/overlap_probe.py): `blocks` workgroups stream `n` floats in place `passes` times — the shape of a link-bound
- * RCCL ring all-reduce (a handful of channels), which a 1-rank process group cannot launch.  Values are unchanged. */
-int u3d_debug_stream_pass(int device, u3d_stream_t stream, float* buf, long long n, int blocks, int passes);
+/* Developer aid (tools/overlap_probe.py): `blocks` workgroups stream `n` floats in place `passes` times in 64 KiB pieces, paced
+ * against the wall clock so that the launch lasts at least `min_seconds` (0 = unpaced) — the shape of a link-bound RCCL ring
+ * all-reduce (a handful of channels moving data at xGMI rate), which a 1-rank process group cannot launch.  Values are unchanged. */
+int u3d_debug_stream_pass(int device, u3d_stream_t stream, float* buf, long long n, int blocks, int passes, double min_seconds);
 
 /* ---- weight packing -------------------------------------------------------------------------
  * Reference weights stay nn.Parameters in (Cout,Cin,3,3,3) layout (checkpoint compatibility,

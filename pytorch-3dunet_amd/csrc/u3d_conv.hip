@@ -30,9 +30,7 @@
 //   [12] block slots (of 2 per CU) that the persistent convolution grids leave FREE for kernels of other streams (RCCL's gradient
 //        all-reduce: parallel.cu_budget).  A CU-MASKED compute queue was measured instead and rejected: the same kernels run 40-75 %
 //        slower on a queue masked to 248 of 256 CUs (profiles/r04_cu_mask_*.txt)
-//   [13] per-block start-phase spread of the persistent kernel: block b sleeps (b % 16) * value * 1024 cycles once (experiment)
-//   [14] timing-only ablations of the persistent kernel's epilogue: 1 = no global stores, 2 = no transposition (wrong results)
-//   [15] free
+//   [13] 1 = first-layer forward on the direct kernel instead of the matrix-pipe one (csrc/u3d_smallc.hip, A/B)   [14..15] free
 int g_u3d_tune[16] = {0};
 
 namespace cv {
@@ -1691,9 +1689,53 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
         out[idx] = pack_elem(w, Cout, Cin, Cin, mode, nchunks, ntot, idx);
 }
 
-// all layers of a model in ONE launch: descs (device memory) hold cumulative element offsets in `first`
+// the four elements of one packed f32x4 (j = 0..3: four consecutive contraction channels of one (step, n-tile, lane) slot) share
+// every index but the channel: decode once, gather four values
+__device__ __forceinline__ f32x4 pack_quad(const float* __restrict__ w, int Cout, int Cin, int cstride, int mode, int nchunks,
+                                           int ntot, long long idx4) {
+    const long long total = ((long long)nchunks * cv::NSTEP + cv::PACK_PAD) * ntot * 256;
+    const long long idx = idx4 * 4;
+    const bool pair = idx >= total;
+    const long long id = pair ? idx - total : idx;
+    const int lane = (int)((id >> 2) & 63);
+    long long r = id >> 8;
+    const int nstep = pair ? cv::NSTEP_PAIRY : cv::NSTEP;
+    const int ntg = pair ? 0 : (int)(r % ntot);
+    if (!pair) r /= ntot;
+    const int st = (int)(r % nstep);
+    const int ch = (int)(r / nstep);
+    const int kc0 = ch * 16 + 8 * (st & 1) + 4 * (lane >> 5);
+    int tap = st >> 1;
+    int nc = ntg * 32 + (lane & 31);
+    bool tap_ok = true;
+    if (pair) {
+        const int tz = tap / 12, ty4 = (tap / 3) % 4, tx = tap % 3;
+        const int ty = ty4 - ((lane & 31) >> 4);  // second half: kernel shifted by one row
+        tap_ok = ty >= 0 && ty <= 2;
+        tap = (tz * 3 + ty) * 3 + tx;
+        nc = lane & 15;
+    }
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (ch >= nchunks || !tap_ok) return v;  // the trailing zero steps / taps outside the 3^3 kernel
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int kc = kc0 + j;
+        if (mode == 0) {
+            if (kc < Cin && nc < Cout) v[j] = w[((size_t)nc * cstride + kc) * 27 + tap];
+        } else {  // dgrad: contraction over original cout (kc), output = original cin (nc), flipped taps
+            if (kc < Cout && nc < Cin) v[j] = w[((size_t)kc * cstride + nc) * 27 + (26 - tap)];
+        }
+    }
+    return v;
+}
+
+// all layers of a model in ONE launch: descs (device memory) hold cumulative element offsets in `first` (multiples of 4: every image
+// is a whole number of f32x4 slots).  One thread per f32x4 slot: 16-byte stores, index arithmetic once per four elements (round 4:
+// 0.105 -> 0.0xx ms per step of the bench workload).
 __global__ void pack_weights_batch_kernel(const u3d_pack_desc_t* __restrict__ descs, int n, long long total) {
-    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const long long total4 = total >> 2;
+    for (long long g4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; g4 < total4; g4 += (long long)gridDim.x * blockDim.x) {
+        const long long g = g4 << 2;
         int lo = 0, hi = n - 1;  // last descriptor with first <= g
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
@@ -1701,16 +1743,21 @@ __global__ void pack_weights_batch_kernel(const u3d_pack_desc_t* __restrict__ de
         }
         const u3d_pack_desc_t d = descs[lo];
         const int cstride = d.cin_stride > 0 ? d.cin_stride : d.Cin;
+        const long long e = g - d.first;
+        f32x4 v;
         if (d.mode == 2) {  // sub-pixel image of the channel slice [w, w + Cin) (csrc/u3d_subpix.h)
-            d.packed[g - d.first] = sp::pack_elem(d.w, d.Cout, cstride, d.Cin, (d.Cin + 15) / 16, (d.Cout + 31) / 32, g - d.first);
-            continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                v[j] = sp::pack_elem(d.w, d.Cout, cstride, d.Cin, (d.Cin + 15) / 16, (d.Cout + 31) / 32, e + j);
+        } else if (d.mode == 3) {  // its data-gradient image (contraction over the layer's output channels)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                v[j] = spd::pack_elem(d.w, d.Cout, cstride, d.Cin, (d.Cout + 15) / 16, (d.Cin + 31) / 32, e + j);
+        } else {
+            const int K = d.mode == 0 ? d.Cin : d.Cout, Nn = d.mode == 0 ? d.Cout : d.Cin;
+            v = pack_quad(d.w, d.Cout, d.Cin, cstride, d.mode, (K + 15) / 16, (Nn + 31) / 32, e >> 2);
         }
-        if (d.mode == 3) {  // its data-gradient image (contraction over the layer's output channels)
-            d.packed[g - d.first] = spd::pack_elem(d.w, d.Cout, cstride, d.Cin, (d.Cout + 15) / 16, (d.Cin + 31) / 32, g - d.first);
-            continue;
-        }
-        const int K = d.mode == 0 ? d.Cin : d.Cout, Nn = d.mode == 0 ? d.Cout : d.Cin;
-        d.packed[g - d.first] = pack_elem(d.w, d.Cout, d.Cin, cstride, d.mode, (K + 15) / 16, (Nn + 31) / 32, g - d.first);
+        *reinterpret_cast<f32x4*>(d.packed + e) = v;
     }
 }
 
@@ -1806,7 +1853,8 @@ extern "C" int u3d_pack_weights_batch(int device, u3d_stream_t stream, const u3d
                                       int64_t total_floats) {
     U3D_ENTER(device);
     U3D_REQUIRE(descs_device && n > 0 && total_floats > 0, "u3d_pack_weights_batch: bad argument");
-    long long blocks = (total_floats + 255) / 256;
+    U3D_REQUIRE(total_floats % 4 == 0, "u3d_pack_weights_batch: image sizes are multiples of 4 floats");
+    long long blocks = (total_floats / 4 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(pack_weights_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, descs_device, n,
                        (long long)total_floats);

@@ -40,23 +40,46 @@ extern "C" int u3d_check_device(int device) {
 }
 
 // ---- developer aid: a stand-in for a link-bound collective (tools/overlap_probe.py) ----------------------------------------
-// RCCL's ring all-reduce runs a handful of workgroups (one per channel) that move data at the rate of the xGMI links, not of
-// HBM.  A 1-rank group launches nothing, so the single-GPU overlap probe needs a kernel of that shape: `blocks` workgroups of 256
-// threads stream `n` floats in place `passes` times (x <- x * 1).  Results never change.
-__global__ __launch_bounds__(256) void debug_stream_pass_kernel(float* __restrict__ buf, long long n4, int passes, float one) {
+// RCCL's ring all-reduce runs a handful of workgroups (one per channel) that move data at the rate of the xGMI links — an
+// order of magnitude below HBM — for as long as the links need.  A 1-rank group launches nothing, so the single-GPU overlap probe
+// needs a kernel of that shape: `blocks` workgroups of 256 threads stream `n` floats in place (x <- x * 1) in 64 KiB pieces and
+// PACE themselves against the constant-rate wall clock so that the launch lasts `min_seconds` however fast memory is (0 = no
+// pacing, `passes` repetitions).  Like the collective it occupies few CUs, needs little bandwidth and does not finish early when
+// it gets more of either.  Values never change.
+__global__ __launch_bounds__(256) void debug_stream_pass_kernel(float* __restrict__ buf, long long n4, int passes, float one,
+                                                               long long ticks_total) {
     f32x4* b = reinterpret_cast<f32x4*>(buf);
+    constexpr long long PIECE = 4096;  // float4 elements per piece = 64 KiB
+    const long long npieces = (n4 + PIECE - 1) / PIECE;
+    const long long mine = (npieces - blockIdx.x + gridDim.x - 1) / gridDim.x;  // pieces blockIdx.x, + gridDim.x, ...
+    const long long t0 = wall_clock64();
+    long long done = 0;
     for (int p = 0; p < passes; ++p)
-        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-            f32x4 v = b[i];
-            v *= one;  // (a run-time 1.0: a literal would let the compiler drop the load / store pair)
-            b[i] = v;
+        for (long long pc = blockIdx.x; pc < npieces; pc += gridDim.x) {
+            const long long lo = pc * PIECE, hi = lo + PIECE < n4 ? lo + PIECE : n4;
+            for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+                f32x4 v = b[i];
+                v *= one;  // (a run-time 1.0: a literal would let the compiler drop the load / store pair)
+                b[i] = v;
+            }
+            ++done;
+            if (ticks_total > 0) {
+                const long long due = t0 + ticks_total * done / (mine * passes);
+                while (wall_clock64() < due) __builtin_amdgcn_s_sleep(64);
+            }
         }
 }
 
-extern "C" int u3d_debug_stream_pass(int device, u3d_stream_t stream, float* buf, long long n, int blocks, int passes) {
+extern "C" int u3d_debug_stream_pass(int device, u3d_stream_t stream, float* buf, long long n, int blocks, int passes,
+                                     double min_seconds) {
     U3D_ENTER(device);
-    U3D_REQUIRE(buf && n >= 4 && blocks > 0 && passes > 0 && ((uintptr_t)buf & 15) == 0, "u3d_debug_stream_pass: bad argument");
-    hipLaunchKernelGGL(debug_stream_pass_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, buf, n / 4, passes, 1.0f);
+    U3D_REQUIRE(buf && n >= 4 && blocks > 0 && passes > 0 && min_seconds >= 0.0 && ((uintptr_t)buf & 15) == 0,
+                "u3d_debug_stream_pass: bad argument");
+    int khz = 0;
+    U3D_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device));
+    const long long ticks = (long long)(min_seconds * 1e3 * (double)khz);
+    hipLaunchKernelGGL(debug_stream_pass_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, buf, n / 4, passes, 1.0f,
+                       ticks);
     U3D_LAUNCH_CHECK();
     return 0;
 }

@@ -11,6 +11,10 @@
 //             so one pass over (dz, x) replaces wgrad + dgrad + their reductions.
 #include "u3d_common.h"
 
+extern int g_u3d_tune[16];  // u3d_set_tuning (csrc/u3d_conv.hip); key 13 = 1: first-layer forward on the direct (non-MFMA) kernel, for A/B
+
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+
 namespace sc {
 constexpr int TZ = 4, TY = 8, TX = 8;
 constexpr int HZ = 6, HY = 10, HX = 10;
@@ -135,6 +139,114 @@ __global__ __launch_bounds__(256) void conv3d_small_fwd_kernel(const SmallFwdPar
     }
 }
 
+// ---- forward on the matrix pipe (round 4) ---------------------------------------------------------------------------------------
+// The direct kernel above spends its time in LDS broadcast reads of the weights (4 x ds_read_b128 + 1 x ds_read_b32 per 16 FMAs and
+// thread): 0.136 ms per step of the bench workload for a layer that moves 142 MB (1 TB/s).  With K = 27*Cin padded to a multiple of
+// 4 the layer is a GEMM  out[k][v] = sum_kk W[k][kk] * xs[v + tap(kk)][c(kk)]  on v_mfma_f32_16x16x4_f32 with the WEIGHTS as the A
+// operand (rows = output channels: KS registers per lane, loaded once per block) and the halo tile as B (columns = 16 voxels, one
+// ds_read_b32 per MFMA and lane).  The accumulator then holds, per lane, FOUR CONSECUTIVE output channels (rows 4*(lane>>4) .. +3)
+// of ONE voxel (column lane&15): the 16-channel record of a voxel leaves as four 16-byte lane stores, 8 voxels of a row = 512
+// contiguous bytes, no transposition.  Wave w owns z-plane w of the 4x8x8 tile = 4 M-tiles of 2 rows x 8 voxels.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3d_small_fwd_mfma_kernel(const SmallFwdParams p) {
+    using namespace sc;
+    constexpr int K = 27 * CIN;
+    constexpr int KS = (K + 3) / 4;  // k-steps of 4
+    __shared__ __attribute__((aligned(16))) float xs[HV * CIN];
+    __shared__ double sred[16][2];
+    const int t = threadIdx.x, l = t & 63, w = t >> 6;
+    const int j = l & 15, kq = l >> 4;  // B column (voxel of the M-tile) / A row (output channel); k index within a step
+    const int n = blockIdx.y;
+    const int D = p.D, H = p.H, W = p.W;
+    // A fragments: W[k = j][kk = 4*s + kq], kk = tap*CIN + c
+    float wa[KS];
+    int boff[KS];  // LDS offset of this lane's B element of step s, relative to the voxel's halo origin
+#pragma unroll
+    for (int s_ = 0; s_ < KS; ++s_) {
+        const int kk = 4 * s_ + kq;
+        const int tap = kk / CIN, c = kk - tap * CIN;
+        const bool ok = kk < K;
+        wa[s_] = (ok && j < p.Cout) ? p.w[((size_t)j * CIN + c) * 27 + tap] : 0.f;
+        boff[s_] = ok ? ((tap / 9) * (HY * HX) + ((tap / 3) % 3) * HX + tap % 3) * CIN + c : 0;  // dead k: any valid slot (A is 0)
+    }
+    if (t < 16) sred[t][0] = sred[t][1] = 0.0;
+    f32x4s s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};  // this lane's channels 4*kq .. +3 over its voxels
+    // voxel of column j in M-tile mt: z = w, y = 2*mt + (j >> 3), x = j & 7
+    const int vbase = (w * HY + (j >> 3)) * HX + (j & 7);
+    const int ntiles = p.tz * p.ty * p.tx;
+    for (int tile = blockIdx.x; tile < ntiles; tile += p.B) {
+        int tt = tile;
+        const int txi = tt % p.tx;
+        tt /= p.tx;
+        const int tyi = tt % p.ty;
+        const int tzi = tt / p.ty;
+        const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
+        __syncthreads();  // the previous tile's reads of xs are done (and sred is initialised)
+        for (int i = t; i < HV * CIN; i += 256) {
+            const int c = i % CIN;
+            const int hv = i / CIN;
+            const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+            const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            float v = 0.f;
+            if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                v = p.x[((size_t)((n * D + gz) * H + gy) * W + gx) * CIN + c];
+                if (p.affine) v = v * p.affine[((size_t)n * CIN + c) * 2] + p.affine[((size_t)n * CIN + c) * 2 + 1];
+            }
+            xs[hv * CIN + c] = v;
+        }
+        __syncthreads();
+        f32x4s acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4s{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const float b = xs[(vbase + 2 * mt * HX) * CIN + boff[s_]];
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s_], b, acc[mt], 0, 0, 0);
+            }
+        }
+        const int z = z0 + w;
+        const bool cok = 4 * kq < p.Cout;  // (Cout % 4 == 0 on this path)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int y = y0 + 2 * mt + (j >> 3), x = x0 + (j & 7);
+            f32x4s v = acc[mt];
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (cok && z < D && y < H && x < W) {
+                *reinterpret_cast<f32x4s*>(p.out + ((size_t)((n * D + z) * H + y) * W + x) * p.Cout + 4 * kq) = v;
+                s1 += v;
+                s2 += v * v;
+            }
+        }
+    }
+    if (p.out_stats) {
+        // the 16 lanes j of a k-group hold 16 voxel columns of the same four channels: butterfly over j, then the four waves
+        // through LDS (f64), one global f64 atomic per channel and block
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = s1[e], b2 = s2[e];
+#pragma unroll
+            for (int m = 8; m > 0; m >>= 1) {
+                a += __shfl_xor(a, m);
+                b2 += __shfl_xor(b2, m);
+            }
+            if (j == 0 && 4 * kq + e < p.Cout) {
+                __hip_atomic_fetch_add(&sred[4 * kq + e][0], (double)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&sred[4 * kq + e][1], (double)b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __syncthreads();
+        if (t < p.Cout) {
+            u3d_atomic_add_f64(&p.out_stats[((size_t)n * p.Cout + t) * 2], sred[t][0]);
+            u3d_atomic_add_f64(&p.out_stats[((size_t)n * p.Cout + t) * 2 + 1], sred[t][1]);
+        }
+    }
+}
+
 extern "C" int u3d_conv3d_small_cin_fwd(int device, u3d_stream_t stream, const float* x, const float* affine,
                                         const float* w, float* out, int N, int D, int H, int W, int Cin, int Cout,
                                         int relu, double* out_stats) {
@@ -153,7 +265,17 @@ extern "C" int u3d_conv3d_small_cin_fwd(int device, u3d_stream_t stream, const f
     p.B = (int)B;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)B, (unsigned)N);
-    if (Cout <= 8)
+    // <= 16 output channels in whole quads (the network's first layer: Cin -> f_maps/2): matrix pipe; key 13 = 1: the direct kernel
+    const bool mfma = Cout <= 16 && Cout % 4 == 0 && ((uintptr_t)out & 15) == 0 && g_u3d_tune[13] != 1;
+    if (mfma && Cin == 1)
+        hipLaunchKernelGGL(conv3d_small_fwd_mfma_kernel<1>, grid, dim3(256), 0, st, p);
+    else if (mfma && Cin == 2)
+        hipLaunchKernelGGL(conv3d_small_fwd_mfma_kernel<2>, grid, dim3(256), 0, st, p);
+    else if (mfma && Cin == 3)
+        hipLaunchKernelGGL(conv3d_small_fwd_mfma_kernel<3>, grid, dim3(256), 0, st, p);
+    else if (mfma && Cin == 4)
+        hipLaunchKernelGGL(conv3d_small_fwd_mfma_kernel<4>, grid, dim3(256), 0, st, p);
+    else if (Cout <= 8)
         hipLaunchKernelGGL(conv3d_small_fwd_kernel<8>, grid, dim3(256), 0, st, p);
     else if (Cout <= 16)
         hipLaunchKernelGGL(conv3d_small_fwd_kernel<16>, grid, dim3(256), 0, st, p);
@@ -178,7 +300,6 @@ struct SmallBwdParams {
     int tz, ty, tx, B;
 };
 
-typedef float f32x4s __attribute__((ext_vector_type(4)));
 
 template <int CIN, int RT>  // RT = row tiles of 16 output channels (Cout <= 16*RT)
 __global__ __launch_bounds__(256) void conv3d_small_bwd_kernel(const SmallBwdParams p) {

@@ -21,6 +21,55 @@ from ._native import U3DSrc
 from ._engine_base import *  # noqa: F401,F403  (explicit __all__: helpers, records, activation codes)
 
 
+@dataclass
+class _ConvCall:
+    """everything a forward kernel family needs to launch one convolution (filled by ConvLayers._single_conv_fwd)"""
+    dev: torch.device
+    conv: torch.nn.Module
+    src: VSrc
+    affine: torch.Tensor
+    y: torch.Tensor
+    N: int
+    D: int
+    H: int
+    W: int
+    Ctot: int
+    Cout: int
+    relu: int
+    stats: bool                          # the epilogue accumulates (sum, sum of squares) of the written values
+    pool: _StatPool
+    residual: Optional[torch.Tensor]     # added before the ReLU inside the conv epilogue (pre-norm residual blocks)
+    sub: dict                            # sub-pixel layers of this forward: id(weight) -> (C0, C1)
+    b16: bool                            # bf16 activation storage
+
+    def take_stats(self):
+        return self.pool.take(self.N * self.Cout * 2) if self.stats else None
+
+    @property
+    def flops(self):
+        return 54.0 * self.Ctot * self.Cout * self.N * self.D * self.H * self.W
+
+
+@dataclass
+class _BwdCall:
+    """everything a backward kernel family needs for one convolution (filled by ConvLayers._conv_bwd)"""
+    cx: "_BwdCtx"
+    rec: ConvRec
+    dz: torch.Tensor
+    src: VSrc
+    N: int
+    D: int
+    H: int
+    W: int
+    Cout: int
+    bf16: bool   # both directions of this layer run on the bf16-operand kernels
+    b16: bool    # bf16 activation storage
+
+    @property
+    def flops(self):
+        return 54.0 * self.src.C * self.Cout * self.N * self.D * self.H * self.W
+
+
 class ConvLayers:
     """mixin: layer-level forward / backward building blocks shared by the DoubleConv and the residual executors"""
 
@@ -124,6 +173,89 @@ class ConvLayers:
             nat.call("u3d_bn_bwd_finalize", dev.index, _stream(dev), _p(gst), _p(rec.mean_rstd), _p(rec.gn_w.detach()), N, C, count,
                      1 if rec.bn_training else 0, _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef))
 
+    # ---- forward kernel families (csrc file; what selects it) -------------------------------------------------------------------
+    _FWD_KERNELS = {
+        "small": "_fwd_small",        # u3d_smallc.hip: first layer, Cin <= 4
+        "subpixel": "_fwd_subpixel",  # u3d_subpix.hip + u3d_conv.hip: cat(skip, nearest2x(low)) on the low-res grid, 8/27 of the MACs
+        "f32s": "_fwd_f32s",          # u3d_bf16.hip: compute_dtype fp32_split
+        "bf16": "_fwd_bf16",          # u3d_bf16.hip: compute_dtype bf16 (fp32 or bf16 activation storage)
+        "fp32": "_fwd_fp32",          # u3d_conv.hip: fp32 MFMA (persistent / generic / split-K chosen by the library)
+    }
+
+    def _fwd_family(self, c: "_ConvCall", residual) -> str:
+        if self.small_cin and c.src.t1 is None and c.Ctot <= 4 and c.Cout <= 32 and residual is None and not c.b16:
+            return "small"
+        if c.src.t1 is not None and residual is None and id(c.conv.weight) in c.sub:
+            return "subpixel"
+        if c.src.t1 is None and self._split_fwd(c.Ctot, c.Cout):
+            return "f32s"
+        if c.src.t1 is None and self._bf16_layer(c.Ctot, c.Cout):
+            return "bf16"
+        return "fp32"
+
+    def _fwd_small(self, c: "_ConvCall"):
+        # first layer of the network: K = 27*Cin is too small for the MFMA tiling (csrc/u3d_smallc.hip)
+        ystats = c.take_stats()
+        nat.call("u3d_conv3d_small_cin_fwd", c.dev.index, _stream(c.dev), _p(c.src.t0), _p(c.affine), _p(c.conv.weight.detach()),
+                 _p(c.y), c.N, c.D, c.H, c.W, c.Ctot, c.Cout, c.relu, _p(ystats), flops=c.flops)
+        return ystats
+
+    def _fwd_subpixel(self, c: "_ConvCall"):
+        # cat(skip, nearest2x(low)): the upsampled half as 8 parity-class 2x2x2 convolutions over the low-res tensor
+        # (8/27 of the multiply-adds), then the skip half, whose epilogue adds the partial sums before ReLU / statistics
+        dev, conv, src, N, D, H, W, Cout = c.dev, c.conv, c.src, c.N, c.D, c.H, c.W, c.Cout
+        C0, C1 = c.sub[id(conv.weight)]
+        ystats = c.take_stats()
+        part = _empty((N, D, H, W, Cout), dtype=_F32, device=dev)
+        D1, H1, W1 = D // 2, H // 2, W // 2
+        need = nat.get_lib().u3d_subpixel_fwd_workspace_floats(N, D1, H1, W1, C1, Cout)  # split-K scratch, small levels only
+        kws = _empty(need, dtype=_F32, device=dev) if need > 0 else None
+        nat.call("u3d_subpixel_conv_fwd", dev.index, _stream(dev), _p(src.t1), _p(c.affine.view(-1)[2 * C0:]), c.Ctot * 2,
+                 _p(self._pack_cache[(id(conv.weight), 12)][1]), _p(part), N, D1, H1, W1, C1, Cout, _p(kws), need,
+                 flops=128.0 * C1 * Cout * N * D1 * H1 * W1)
+        a0 = c.affine[:, :C0].contiguous()
+        if self._split_fwd(C0, Cout):
+            nat.call("u3d_conv3d_f32s", dev.index, _stream(dev), _p(src.t0), _p(a0), _p(self._packed_f32s(conv.weight, 0, dev, C0, 0)),
+                     _p(c.y), N, D, H, W, C0, Cout, c.relu, _p(ystats), None, None, _p(part), None, 0,
+                     flops=54.0 * C0 * Cout * N * D * H * W)
+        else:
+            s0 = VSrc(src.t0).struct(a0)
+            nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s0), _p(self._pack_cache[(id(conv.weight), 10)][1]),
+                     _p(c.y), N, D, H, W, Cout, c.relu, _p(ystats), None, None, _p(part), None, 0,
+                     flops=54.0 * C0 * Cout * N * D * H * W)
+        return ystats
+
+    def _fwd_f32s(self, c: "_ConvCall"):
+        # fp32 operands split into three bf16 values each, six partial products on the bf16 MFMA pipe (csrc/u3d_bf16.hip)
+        ystats = c.take_stats()
+        need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(c.N, c.D, c.H, c.W, c.Ctot, c.Cout)
+        kws = _empty(need, dtype=_F32, device=c.dev) if need > 0 else None
+        nat.call("u3d_conv3d_f32s", c.dev.index, _stream(c.dev), _p(c.src.t0), _p(c.affine), _p(self._packed_f32s(c.conv.weight, 0, c.dev)),
+                 _p(c.y), c.N, c.D, c.H, c.W, c.Ctot, c.Cout, c.relu, _p(ystats), None, None, _p(c.residual), _p(kws), need, flops=c.flops)
+        return ystats
+
+    def _fwd_bf16(self, c: "_ConvCall"):
+        # bf16 MFMA operands, fp32 accumulation / epilogue (csrc/u3d_bf16.hip); with bf16 activation storage the input, the
+        # output and the residual are bf16 tensors (`_b16` entry point)
+        ystats = c.take_stats()
+        need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(c.N, c.D, c.H, c.W, c.Ctot, c.Cout)  # split-K scratch at the bottom of the U
+        kws = _empty(need, dtype=_F32, device=c.dev) if need > 0 else None
+        nat.call("u3d_conv3d_bf16_ex" + ("_b16" if c.b16 else ""), c.dev.index, _stream(c.dev), _p(c.src.t0), _p(c.affine),
+                 _p(self._packed_bf16(c.conv.weight, 0, c.dev)), _p(c.y), c.N, c.D, c.H, c.W, c.Ctot, c.Cout, c.relu, _p(ystats), None, None,
+                 _p(c.residual), _p(kws), need, flops=c.flops)
+        return ystats
+
+    def _fwd_fp32(self, c: "_ConvCall"):
+        wp = self._packed(c.conv.weight, 0, c.dev)
+        ystats = c.take_stats()
+        s = c.src.struct(c.affine)
+        # bottom-of-the-U shapes split the channel reduction over blocks through a scratch buffer (0 floats otherwise)
+        need = nat.get_lib().u3d_conv3d_workspace_floats(c.N, c.D, c.H, c.W, c.Ctot, c.Cout)
+        kws = _empty(need, dtype=_F32, device=c.dev) if need > 0 else None
+        nat.call("u3d_conv3d_ex", c.dev.index, _stream(c.dev), ctypes.byref(s), _p(wp), _p(c.y), c.N, c.D, c.H, c.W, c.Cout, c.relu,
+                 _p(ystats), None, None, _p(c.residual), _p(kws), need, flops=c.flops)
+        return ystats
+
     def _single_conv_fwd(self, sc, name, src: VSrc, st_in, pool: _StatPool, tape: Optional[Tape], want_stats=True,
                          residual: Optional[torch.Tensor] = None, sub=(), y_out: Optional[torch.Tensor] = None, act=None):
         """One SingleConv (buildingblocks.py:99-135) in any native order (parse_order): 'gcr' = GroupNorm -> Conv3d -> ReLU fully
@@ -164,60 +296,12 @@ class ConvLayers:
             assert self.act_bf16 and src.t1 is None and not post and self._bf16_layer(Ctot, Cout) and act == ACT_RELU, \
                 "bf16 activation storage reached a layer outside its envelope"
         y = y_out if (y_out is not None and not post) else _empty((N, D, H, W, Cout), dtype=src.t0.dtype if b16 else _F32, device=dev)
-        small = self.small_cin and src.t1 is None and Ctot <= 4 and Cout <= 32 and residual is None and not b16
-        if small:
-            # first layer of the network: K = 27*Cin is too small for the MFMA tiling (csrc/u3d_smallc.hip)
-            ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
-            nat.call("u3d_conv3d_small_cin_fwd", dev.index, _stream(dev), _p(src.t0), _p(affine), _p(conv.weight.detach()),
-                     _p(y), N, D, H, W, Ctot, Cout, relu, _p(ystats), flops=54.0 * Ctot * Cout * N * D * H * W)
-        elif src.t1 is not None and residual is None and id(conv.weight) in sub:
-            # cat(skip, nearest2x(low)): the upsampled half as 8 parity-class 2x2x2 convolutions over the low-res tensor
-            # (8/27 of the multiply-adds), then the skip half, whose epilogue adds the partial sums before ReLU / statistics
-            C0, C1 = sub[id(conv.weight)]
-            ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
-            part = _empty((N, D, H, W, Cout), dtype=_F32, device=dev)
-            D1, H1, W1 = D // 2, H // 2, W // 2
-            need = nat.get_lib().u3d_subpixel_fwd_workspace_floats(N, D1, H1, W1, C1, Cout)  # split-K scratch, small levels only
-            kws = _empty(need, dtype=_F32, device=dev) if need > 0 else None
-            nat.call("u3d_subpixel_conv_fwd", dev.index, _stream(dev), _p(src.t1), _p(affine.view(-1)[2 * C0:]), Ctot * 2,
-                     _p(self._pack_cache[(id(conv.weight), 12)][1]), _p(part), N, D1, H1, W1, C1, Cout, _p(kws), need,
-                     flops=128.0 * C1 * Cout * N * D1 * H1 * W1)
-            a0 = affine[:, :C0].contiguous()
-            if self._split_fwd(C0, Cout):
-                nat.call("u3d_conv3d_f32s", dev.index, _stream(dev), _p(src.t0), _p(a0), _p(self._packed_f32s(conv.weight, 0, dev, C0, 0)),
-                         _p(y), N, D, H, W, C0, Cout, relu, _p(ystats), None, None, _p(part), None, 0,
-                         flops=54.0 * C0 * Cout * N * D * H * W)
-            else:
-                s0 = VSrc(src.t0).struct(a0)
-                nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s0), _p(self._pack_cache[(id(conv.weight), 10)][1]),
-                         _p(y), N, D, H, W, Cout, relu, _p(ystats), None, None, _p(part), None, 0,
-                         flops=54.0 * C0 * Cout * N * D * H * W)
-        elif src.t1 is None and self._split_fwd(Ctot, Cout):
-            # fp32 operands split into three bf16 values each, six partial products on the bf16 MFMA pipe (csrc/u3d_bf16.hip)
-            ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
-            need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(N, D, H, W, Ctot, Cout)
-            kws = _empty(need, dtype=_F32, device=dev) if need > 0 else None
-            nat.call("u3d_conv3d_f32s", dev.index, _stream(dev), _p(src.t0), _p(affine), _p(self._packed_f32s(conv.weight, 0, dev)),
-                     _p(y), N, D, H, W, Ctot, Cout, relu, _p(ystats), None, None, _p(conv_res), _p(kws), need,
-                     flops=54.0 * Ctot * Cout * N * D * H * W)
-        elif src.t1 is None and self._bf16_layer(Ctot, Cout):
-            # bf16 MFMA operands, fp32 accumulation / epilogue (csrc/u3d_bf16.hip); with bf16 activation storage the input, the
-            # output and the residual are bf16 tensors (`_b16` entry point)
-            ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
-            need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(N, D, H, W, Ctot, Cout)  # split-K scratch at the bottom of the U
-            kws = _empty(need, dtype=_F32, device=dev) if need > 0 else None
-            nat.call("u3d_conv3d_bf16_ex" + ("_b16" if b16 else ""), dev.index, _stream(dev), _p(src.t0), _p(affine),
-                     _p(self._packed_bf16(conv.weight, 0, dev)), _p(y), N, D, H, W, Ctot, Cout, relu, _p(ystats), None, None,
-                     _p(conv_res), _p(kws), need, flops=54.0 * Ctot * Cout * N * D * H * W)
-        else:
-            wp = self._packed(conv.weight, 0, dev)
-            ystats = pool.take(N * Cout * 2) if (want_stats and self.fused_stats) else None
-            s = src.struct(affine)
-            # bottom-of-the-U shapes split the channel reduction over blocks through a scratch buffer (0 floats otherwise)
-            need = nat.get_lib().u3d_conv3d_workspace_floats(N, D, H, W, Ctot, Cout)
-            kws = _empty(need, dtype=_F32, device=dev) if need > 0 else None
-            nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s), _p(wp), _p(y), N, D, H, W, Cout, relu,
-                     _p(ystats), None, None, _p(conv_res), _p(kws), need, flops=54.0 * Ctot * Cout * N * D * H * W)
+        # ---- the convolution itself: ONE decision (which kernel family), then the family's launcher from the table
+        call = _ConvCall(dev, conv, src, affine, y, N, D, H, W, Ctot, Cout, relu, bool(want_stats and self.fused_stats), pool, conv_res,
+                         sub, b16)
+        family = self._fwd_family(call, residual)
+        small = family == "small"
+        ystats = getattr(self, self._FWD_KERNELS[family])(call)
         post_rec = None
         if post:
             # GroupNorm over the conv output z (statistics from the conv epilogue), then the non-linearity: y = f(a*z + b);
@@ -272,6 +356,137 @@ class ConvLayers:
             )
         return y, ystats
 
+    # ---- backward kernel families ---------------------------------------------------------------------------------------------------
+    _WGRAD_KERNELS = {
+        "bf16": "_wgrad_bf16",          # u3d_bf16.hip (needs Cout % 64 == 0)
+        "subpixel": "_wgrad_subpixel",  # u3d_subpix.hip (upsampled channels) + u3d_conv.hip strided (skip channels)
+        "fp32_side": "_wgrad_fp32_side",  # u3d_conv.hip on the side stream (U3D_SIDE_VOXELS, off by default)
+        "fp32": "_wgrad_fp32",          # u3d_conv.hip
+    }
+    _DGRAD_KERNELS = {
+        "subpixel": "_dgrad_subpixel",  # skip half at full resolution + upsampled half directly at LOW resolution
+        "f32s": "_dgrad_f32s",
+        "bf16": "_dgrad_bf16",
+        "fp32": "_dgrad_fp32",
+    }
+
+    def _wgrad_family(self, c: "_BwdCall") -> str:
+        if c.bf16 and c.Cout % 64 == 0:
+            return "bf16"
+        if c.rec.sub is not None:
+            return "subpixel"
+        if self.overlap_small_wgrad and c.N * c.D * c.H * c.W <= c.cx.SIDE_MAX_VOXELS and self.debug is None:
+            return "fp32_side"
+        return "fp32"
+
+    def _dgrad_family(self, c: "_BwdCall") -> str:
+        if c.rec.sub is not None:
+            return "subpixel"
+        if c.src.t1 is None and not c.rec.small and self._split_dgrad(c.src.C, c.Cout):
+            return "f32s"
+        return "bf16" if c.bf16 else "fp32"
+
+    def _wgrad_bf16(self, c: "_BwdCall"):
+        cx, dev, src, rec = c.cx, c.cx.dev, c.src, c.rec
+        need = nat.get_lib().u3d_wgrad_bf16_workspace_floats(c.N, c.D, c.H, c.W, src.C, c.Cout)
+        ws = cx.ensure_ws(need)
+        nat.call("u3d_conv3d_wgrad_bf16" + ("_b16" if c.b16 else ""), dev.index, _stream(dev), _p(src.t0), _p(rec.affine), _p(c.dz),
+                 _p(cx.gview(rec.idx_w)), c.N, c.D, c.H, c.W, src.C, c.Cout, _p(ws), ws.numel(), flops=c.flops)
+
+    def _wgrad_subpixel(self, c: "_BwdCall"):
+        # weight gradient in two channel slices of the same (Cout, Ctot, 27) buffer: upsampled channels from the 64
+        # (parity class, tap half) matrices over the low-res grid, skip channels from the standard kernel
+        cx, dev, src, rec, ws = c.cx, c.cx.dev, c.src, c.rec, c.cx.ws
+        C0, C1 = rec.sub
+        Ct = src.C
+        dwv = cx.gview(rec.idx_w)
+        nat.call("u3d_subpixel_conv_wgrad", dev.index, _stream(dev), _p(src.t1), _p(rec.affine.view(-1)[2 * C0:]), Ct * 2,
+                 _p(c.dz), _p(dwv[C0 * 27:]), Ct, c.N, src.D1, src.H1, src.W1, C1, c.Cout, _p(ws), ws.numel(),
+                 flops=128.0 * C1 * c.Cout * c.N * src.D1 * src.H1 * src.W1)
+        a0 = rec.affine[:, :C0].contiguous()
+        s0 = VSrc(src.t0).struct(a0)
+        nat.call("u3d_conv3d_wgrad_strided", dev.index, _stream(dev), ctypes.byref(s0), _p(c.dz), _p(dwv), Ct, c.N, c.D, c.H, c.W,
+                 c.Cout, _p(ws), ws.numel(), flops=54.0 * C0 * c.Cout * c.N * c.D * c.H * c.W)
+
+    def _wgrad_fp32_side(self, c: "_BwdCall"):
+        # small layer: neither kernel fills the chip on its own -> weight gradient on the side stream, data gradient
+        # on the caller's stream; joined before anything consumes the flat gradient buffer
+        cx, dev, src, rec = c.cx, c.cx.dev, c.src, c.rec
+        s_aff = src.struct(rec.affine)
+        need = nat.get_lib().u3d_wgrad_workspace_floats(c.N, c.D, c.H, c.W, src.C, c.Cout)
+        side = cx.side_stream(need)
+        side.wait_stream(torch.cuda.current_stream(dev))  # dz (and the flat buffer) are ready
+        with torch.cuda.stream(side):
+            nat.call("u3d_conv3d_wgrad", dev.index, _stream(dev), ctypes.byref(s_aff), _p(c.dz), _p(cx.gview(rec.idx_w)), c.N,
+                     c.D, c.H, c.W, c.Cout, _p(cx.ws_side), cx.ws_side.numel(), flops=c.flops)
+        c.dz.record_stream(side)  # dz is released on the main stream while the side stream may still read it
+        cx.side_used = True
+
+    def _wgrad_fp32(self, c: "_BwdCall"):
+        cx, dev, src, rec, ws = c.cx, c.cx.dev, c.src, c.rec, c.cx.ws
+        s_aff = src.struct(rec.affine)
+        nat.call("u3d_conv3d_wgrad", dev.index, _stream(dev), ctypes.byref(s_aff), _p(c.dz), _p(cx.gview(rec.idx_w)), c.N, c.D,
+                 c.H, c.W, c.Cout, _p(ws), ws.numel(), flops=c.flops)
+
+    def _dgrad_subpixel(self, c: "_BwdCall"):
+        # skip half at full resolution; upsampled half directly at LOW resolution (the children sum of the nearest
+        # upsampling is folded into the 4x4x4-tap stride-2 gather).  dg = (dg_skip, dlow)
+        cx, dev, src, rec, ws, pool = c.cx, c.cx.dev, c.src, c.rec, c.cx.ws, c.cx.pool
+        Nn, Dd, Hh, Ww, Cout = c.N, c.D, c.H, c.W, c.Cout
+        C0, C1 = rec.sub
+        dg0 = _empty((Nn, Dd, Hh, Ww, C0), dtype=_F32, device=dev)
+        dlow = _empty_like(src.t1)
+        gst0, gst1 = pool.take(Nn * C0 * 2), pool.take(Nn * C1 * 2)
+        if self._split_dgrad(C0, Cout):
+            need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(Nn, Dd, Hh, Ww, Cout, C0)
+            kws = cx.ensure_ws(need) if need > 0 else None
+            nat.call("u3d_conv3d_f32s", dev.index, _stream(dev), _p(c.dz), None, _p(self._packed_f32s(rec.conv_w, 1, dev, C0, 0)),
+                     _p(dg0), Nn, Dd, Hh, Ww, Cout, C0, 0, None, _p(src.t0), _p(gst0), None, _p(kws), need,
+                     flops=54.0 * C0 * Cout * Nn * Dd * Hh * Ww)
+        else:
+            s_dz = VSrc(c.dz).struct()
+            s_x0 = VSrc(src.t0).struct()
+            nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s_dz), _p(self._packed_sub(rec, 11, dev)), _p(dg0),
+                     Nn, Dd, Hh, Ww, C0, 0, None, ctypes.byref(s_x0), _p(gst0), None, _p(ws), ws.numel(),
+                     flops=54.0 * C0 * Cout * Nn * Dd * Hh * Ww)
+        nat.call("u3d_subpixel_conv_dgrad", dev.index, _stream(dev), _p(c.dz), _p(self._packed_sub(rec, 13, dev)), _p(src.t1),
+                 _p(dlow), _p(gst1), Nn, src.D1, src.H1, src.W1, C1, Cout,
+                 flops=128.0 * C1 * Cout * Nn * src.D1 * src.H1 * src.W1)
+        gst = torch.cat((gst0.view(Nn, C0, 2), gst1.view(Nn, C1, 2)), dim=1)
+        return (dg0, dlow), gst
+
+    def _dgrad_f32s(self, c: "_BwdCall"):
+        cx, dev, src, rec = c.cx, c.cx.dev, c.src, c.rec
+        dg = _empty((c.N, c.D, c.H, c.W, src.C), dtype=_F32, device=dev)
+        gst = cx.pool.take(c.N * src.C * 2)
+        need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(c.N, c.D, c.H, c.W, c.Cout, src.C)
+        kws = cx.ensure_ws(need) if need > 0 else None
+        nat.call("u3d_conv3d_f32s", dev.index, _stream(dev), _p(c.dz), None, _p(self._packed_f32s(rec.conv_w, 1, dev)), _p(dg),
+                 c.N, c.D, c.H, c.W, c.Cout, src.C, 0, None, _p(src.t0), _p(gst), None, _p(kws), need, flops=c.flops)
+        return dg, gst
+
+    def _dgrad_bf16(self, c: "_BwdCall"):
+        cx, dev, src, rec = c.cx, c.cx.dev, c.src, c.rec
+        dg = _empty((c.N, c.D, c.H, c.W, src.C), dtype=c.dz.dtype if c.b16 else _F32, device=dev)
+        gst = cx.pool.take(c.N * src.C * 2)
+        need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(c.N, c.D, c.H, c.W, c.Cout, src.C)
+        kws = cx.ensure_ws(need) if need > 0 else None
+        nat.call("u3d_conv3d_bf16_ex" + ("_b16" if c.b16 else ""), dev.index, _stream(dev), _p(c.dz), None,
+                 _p(self._packed_bf16(rec.conv_w, 1, dev)), _p(dg), c.N, c.D, c.H, c.W, c.Cout, src.C, 0, None, _p(src.t0), _p(gst),
+                 None, _p(kws), need, flops=c.flops)
+        return dg, gst
+
+    def _dgrad_fp32(self, c: "_BwdCall"):
+        cx, dev, src, rec, ws = c.cx, c.cx.dev, c.src, c.rec, c.cx.ws
+        wpd = self._packed(rec.conv_w, 1, dev)
+        dg = _empty((c.N, c.D, c.H, c.W, src.C), dtype=_F32, device=dev)
+        gst = cx.pool.take(c.N * src.C * 2)
+        s_dz = VSrc(c.dz).struct()
+        s_x = src.struct()
+        nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s_dz), _p(wpd), _p(dg), c.N, c.D, c.H, c.W, src.C, 0, None,
+                 ctypes.byref(s_x), _p(gst), None, _p(ws), ws.numel(), flops=c.flops)
+        return dg, gst
+
     # -- backward building blocks (shared by the DoubleConv and the residual executors) -----------------------
     def _conv_bwd(self, cx, rec: ConvRec, dz_, need_dg=True):
         """wgrad + dgrad + GroupNorm-backward reductions of one SingleConv; returns (dg, coef)"""
@@ -317,89 +532,13 @@ class ConvLayers:
             coef = _empty((Nn, 3, src.C), dtype=_F32, device=dev)
             self._norm_bwd_finalize(cx, rec, gst, Nn, src.C, float(Dd * Hh * Ww), coef)
             return None, coef
-        s_aff = src.struct(rec.affine)
-        flops = 54.0 * src.C * Cout * Nn * Dd * Hh * Ww
         bf16 = src.t1 is None and rec.sub is None and not rec.small and self._bf16_layer(src.C, Cout)
         b16 = src.t0.dtype == torch.bfloat16  # bf16 activation storage
         assert not b16 or (bf16 and Cout % 64 == 0 and dz_.dtype == torch.bfloat16)
-        if bf16 and Cout % 64 == 0:
-            need = nat.get_lib().u3d_wgrad_bf16_workspace_floats(Nn, Dd, Hh, Ww, src.C, Cout)
-            ws = cx.ensure_ws(need)
-            nat.call("u3d_conv3d_wgrad_bf16" + ("_b16" if b16 else ""), dev.index, _stream(dev), _p(src.t0), _p(rec.affine), _p(dz_),
-                     _p(gview(rec.idx_w)), Nn, Dd, Hh, Ww, src.C, Cout, _p(ws), ws.numel(), flops=flops)
-        elif rec.sub is not None:
-            # weight gradient in two channel slices of the same (Cout, Ctot, 27) buffer: upsampled channels from the 64
-            # (parity class, tap half) matrices over the low-res grid, skip channels from the standard kernel
-            C0, C1 = rec.sub
-            Ct = src.C
-            dwv = gview(rec.idx_w)
-            nat.call("u3d_subpixel_conv_wgrad", dev.index, _stream(dev), _p(src.t1), _p(rec.affine.view(-1)[2 * C0:]), Ct * 2,
-                     _p(dz_), _p(dwv[C0 * 27:]), Ct, Nn, src.D1, src.H1, src.W1, C1, Cout, _p(ws), ws.numel(),
-                     flops=128.0 * C1 * Cout * Nn * src.D1 * src.H1 * src.W1)
-            a0 = rec.affine[:, :C0].contiguous()
-            s0 = VSrc(src.t0).struct(a0)
-            nat.call("u3d_conv3d_wgrad_strided", dev.index, _stream(dev), ctypes.byref(s0), _p(dz_), _p(dwv), Ct, Nn, Dd, Hh, Ww,
-                     Cout, _p(ws), ws.numel(), flops=54.0 * C0 * Cout * Nn * Dd * Hh * Ww)
-        elif self.overlap_small_wgrad and Nn * Dd * Hh * Ww <= cx.SIDE_MAX_VOXELS and self.debug is None:
-            # small layer: neither kernel fills the chip on its own -> weight gradient on the side stream, data gradient
-            # (below) on the caller's stream; joined before anything consumes the flat gradient buffer
-            need = nat.get_lib().u3d_wgrad_workspace_floats(Nn, Dd, Hh, Ww, src.C, Cout)
-            side = cx.side_stream(need)
-            side.wait_stream(torch.cuda.current_stream(dev))  # dz_ (and the flat buffer) are ready
-            with torch.cuda.stream(side):
-                nat.call("u3d_conv3d_wgrad", dev.index, _stream(dev), ctypes.byref(s_aff), _p(dz_), _p(gview(rec.idx_w)), Nn,
-                         Dd, Hh, Ww, Cout, _p(cx.ws_side), cx.ws_side.numel(), flops=flops)
-            dz_.record_stream(side)  # dz_ is released on the main stream while the side stream may still read it
-            cx.side_used = True
-        else:
-            nat.call("u3d_conv3d_wgrad", dev.index, _stream(dev), ctypes.byref(s_aff), _p(dz_), _p(gview(rec.idx_w)), Nn, Dd,
-                     Hh, Ww, Cout, _p(ws), ws.numel(), flops=flops)
-        s_dz = VSrc(dz_).struct()
-        if rec.sub is not None:
-            # skip half at full resolution; upsampled half directly at LOW resolution (the children sum of the nearest
-            # upsampling is folded into the 4x4x4-tap stride-2 gather).  dg = (dg_skip, dlow)
-            C0, C1 = rec.sub
-            dg0 = _empty((Nn, Dd, Hh, Ww, C0), dtype=_F32, device=dev)
-            dlow = _empty_like(src.t1)
-            gst0, gst1 = pool.take(Nn * C0 * 2), pool.take(Nn * C1 * 2)
-            if self._split_dgrad(C0, Cout):
-                need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(Nn, Dd, Hh, Ww, Cout, C0)
-                kws = cx.ensure_ws(need) if need > 0 else None
-                nat.call("u3d_conv3d_f32s", dev.index, _stream(dev), _p(dz_), None, _p(self._packed_f32s(rec.conv_w, 1, dev, C0, 0)),
-                         _p(dg0), Nn, Dd, Hh, Ww, Cout, C0, 0, None, _p(src.t0), _p(gst0), None, _p(kws), need,
-                         flops=54.0 * C0 * Cout * Nn * Dd * Hh * Ww)
-            else:
-                s_x0 = VSrc(src.t0).struct()
-                nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s_dz), _p(self._packed_sub(rec, 11, dev)), _p(dg0),
-                         Nn, Dd, Hh, Ww, C0, 0, None, ctypes.byref(s_x0), _p(gst0), None, _p(ws), ws.numel(),
-                         flops=54.0 * C0 * Cout * Nn * Dd * Hh * Ww)
-            nat.call("u3d_subpixel_conv_dgrad", dev.index, _stream(dev), _p(dz_), _p(self._packed_sub(rec, 13, dev)), _p(src.t1),
-                     _p(dlow), _p(gst1), Nn, src.D1, src.H1, src.W1, C1, Cout,
-                     flops=128.0 * C1 * Cout * Nn * src.D1 * src.H1 * src.W1)
-            gst = torch.cat((gst0.view(Nn, C0, 2), gst1.view(Nn, C1, 2)), dim=1)
-            dg = (dg0, dlow)
-        elif src.t1 is None and not rec.small and self._split_dgrad(src.C, Cout):
-            dg = _empty((Nn, Dd, Hh, Ww, src.C), dtype=_F32, device=dev)
-            gst = pool.take(Nn * src.C * 2)
-            need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(Nn, Dd, Hh, Ww, Cout, src.C)
-            kws = cx.ensure_ws(need) if need > 0 else None
-            nat.call("u3d_conv3d_f32s", dev.index, _stream(dev), _p(dz_), None, _p(self._packed_f32s(rec.conv_w, 1, dev)), _p(dg),
-                     Nn, Dd, Hh, Ww, Cout, src.C, 0, None, _p(src.t0), _p(gst), None, _p(kws), need, flops=flops)
-        elif bf16:
-            dg = _empty((Nn, Dd, Hh, Ww, src.C), dtype=dz_.dtype if b16 else _F32, device=dev)
-            gst = pool.take(Nn * src.C * 2)
-            need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(Nn, Dd, Hh, Ww, Cout, src.C)
-            kws = cx.ensure_ws(need) if need > 0 else None
-            nat.call("u3d_conv3d_bf16_ex" + ("_b16" if b16 else ""), dev.index, _stream(dev), _p(dz_), None,
-                     _p(self._packed_bf16(rec.conv_w, 1, dev)), _p(dg), Nn, Dd, Hh, Ww, Cout, src.C, 0, None, _p(src.t0), _p(gst),
-                     None, _p(kws), need, flops=flops)
-        else:
-            wpd = self._packed(rec.conv_w, 1, dev)
-            dg = _empty((Nn, Dd, Hh, Ww, src.C), dtype=_F32, device=dev)
-            gst = pool.take(Nn * src.C * 2)
-            s_x = src.struct()
-            nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s_dz), _p(wpd), _p(dg), Nn, Dd, Hh, Ww, src.C, 0, None,
-                     ctypes.byref(s_x), _p(gst), None, _p(ws), ws.numel(), flops=flops)
+        call = _BwdCall(cx, rec, dz_, src, Nn, Dd, Hh, Ww, Cout, bf16, b16)
+        # ---- weight gradient, then data gradient (+ the GroupNorm-backward sums of the conv input): one family decision each
+        getattr(self, self._WGRAD_KERNELS[self._wgrad_family(call)])(call)
+        dg, gst = getattr(self, self._DGRAD_KERNELS[self._dgrad_family(call)])(call)
         if self.debug is not None and rec.sub is None:
             self.debug[rec.name + ".dg"] = dg.clone()
         if not rec.pre_norm:

@@ -9,8 +9,9 @@ STAND-IN on the same hooks (`engine.grad_sync.launch(bucket)` wherever the engin
                     time of a ring all-reduce of the bucket on one 153 GB/s xGMI link.  Pessimistic: it competes for HBM and for
                     every CU, which a link-bound collective does not.
   --standin link    (round 4, default) `u3d_debug_stream_pass`: 16 workgroups — the shape of RCCL's ring kernels, one per channel —
-                    streaming the bucket in place; the number of passes is CALIBRATED on the idle GPU so that the stand-in alone
-                    takes the ring all-reduce's time (2 * 7/8 * bytes / 153 GB/s).
+                    streaming the bucket once in place and PACED against the wall clock so that the launch lasts the ring
+                    all-reduce's time (2 * 7/8 * bytes / 153 GB/s) however much bandwidth it gets: like the collective it needs few CUs
+                    and little HBM bandwidth and does not finish early.
 
 --slots k: the persistent convolution grids leave k block slots free (parallel.cu_budget, tuning key 12).  Reported per model: step
 time without exchange (and without / with the budget), with the stand-in on the side stream, with the stand-in serialised on the
@@ -46,33 +47,21 @@ class StandIn:
         self.bytes_per_ms = None  # link stand-in: measured in-place streaming rate of BLOCKS workgroups on the idle GPU
 
     def calibrate(self):
-        from pytorch3dunet_amd import _native as nat
-
-        buf = torch.zeros(32 << 20, device=dev)  # 128 MB
-        st = torch.cuda.current_stream(dev)
-        for reps in (1, 4):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            nat.call("u3d_debug_stream_pass", dev.index, st.cuda_stream, buf.data_ptr(), buf.numel(), self.BLOCKS, reps)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-        self.bytes_per_ms = 4 * buf.numel() * 4 / (dt * 1e3)
-        return self.bytes_per_ms
+        return None  # (the link stand-in paces itself against the wall clock: nothing to calibrate)
 
     def _issue(self, bucket, stream):
         from pytorch3dunet_amd import _native as nat
 
-        t_x_ms = 2 * 7 / 8 * bucket.numel() * 4 / (self.gbps * 1e9) * 1e3
+        t_x = 2 * 7 / 8 * bucket.numel() * 4 / (self.gbps * 1e9)  # ring all-reduce of this bucket on one xGMI link, seconds
         if self.kind == "torch":
-            n = max(1, int(round(t_x_ms / (2 * bucket.numel() * 4 / 4.0e12 * 1e3))))
+            n = max(1, int(round(t_x / (2 * bucket.numel() * 4 / 4.0e12))))
             for _ in range(n):
                 bucket.mul_(1.0)
             return
-        n4 = bucket.numel() - bucket.numel() % 4
-        off = (-bucket.data_ptr() // 4) % 4  # 16-byte alignment of the slice
-        view = bucket[off : off + ((n4 - off) // 4) * 4]
-        passes = max(1, int(round(t_x_ms * self.bytes_per_ms / (view.numel() * 4))))
-        nat.call("u3d_debug_stream_pass", dev.index, stream.cuda_stream, view.data_ptr(), view.numel(), self.BLOCKS, passes)
+        off = (-(bucket.data_ptr() // 4)) % 4  # 16-byte alignment of the slice
+        n4 = (bucket.numel() - off) // 4 * 4
+        view = bucket[off : off + n4]
+        nat.call("u3d_debug_stream_pass", dev.index, stream.cuda_stream, view.data_ptr(), view.numel(), self.BLOCKS, 1, t_x)
 
     def launch(self, bucket):
         if bucket.numel() < 16:
@@ -101,7 +90,6 @@ def run(name, cfg, shape, steps=8, slots=0, kind="link"):
     t = (torch.rand(shape, device=dev) > 0.5).float()
     crit = BCEDiceLoss()
     eng = model._get_engine()
-    rate = StandIn(False, kind).calibrate() if kind == "link" else None
 
     def step():
         model.zero_grad(set_to_none=True)
@@ -110,8 +98,6 @@ def run(name, cfg, shape, steps=8, slots=0, kind="link"):
 
     def timed(mode):
         sync = None if mode == "none" else StandIn(side=(mode == "side"), kind=kind)
-        if sync is not None:
-            sync.bytes_per_ms = rate
         eng.grad_sync = sync
         for _ in range(3):
             step()
