@@ -609,6 +609,18 @@ def test_small_cin_first_layer_kernels(N, Cin, Cout, D, H, W):
     assert U.relerr(U.ncdhw(y), F.relu(z.detach())) < TOL
     yr = F.relu(z.detach()).double()
     assert U.relerr(yst.cpu(), torch.stack([yr.sum(dim=(2, 3, 4)), (yr * yr).sum(dim=(2, 3, 4))], dim=-1)) < 1e-5
+    # <= 16 output channels in whole quads run on the matrix pipe (round 4); the direct kernel (u3d_set_tuning key 13 = 1) must agree
+    # with it like two fp32 summation orders, and both are run-to-run reproducible
+    y2, yst2 = torch.empty_like(y), torch.zeros_like(yst)
+    nat.call("u3d_set_tuning", 13, 1)
+    try:
+        nat.call("u3d_conv3d_small_cin_fwd", 0, _stream(U.DEV), _p(xd), _p(abd), _p(wd), _p(y2), N, D, H, W, Cin, Cout, 1, _p(yst2))
+    finally:
+        nat.call("u3d_set_tuning", 13, 0)
+    assert U.relerr(y2, y) < 1e-5 and U.relerr(yst2, yst) < 1e-6
+    y3 = torch.empty_like(y)
+    nat.call("u3d_conv3d_small_cin_fwd", 0, _stream(U.DEV), _p(xd), _p(abd), _p(wd), _p(y3), N, D, H, W, Cin, Cout, 1, None)
+    assert torch.equal(y3, y)
     n = nat.get_lib().u3d_small_cin_bwd_workspace_floats(N, D, H, W, Cin, Cout)
     ws = torch.empty(n, device=U.DEV)
     dw = torch.empty((Cout, Cin, 3, 3, 3), device=U.DEV)
