@@ -22,7 +22,7 @@
 //   [0] forced N-tiles per block of u3d_conv3d (1,2,3; 0 = automatic)   [1] wgrad split override (0 = automatic)
 //   [2] ablation mask of the instrumented conv twin (timing experiments, wrong results)
 //   [3] 1 = never use the persistent fast variant of u3d_conv3d (A/B against the generic kernel)
-//   [4] 1 = never use the paired-y variant for <= 16 output channels
+//   [4] <= 16 output channels: 0 = 16-column variant (v_mfma_f32_16x16x4_f32), 2 = paired-y variant (round 1), 1 = padded 32-column kernel
 //   [5] start-phase stagger of the persistent kernel in units of 1024 cycles (0 = off)
 //   [6] 1 = one persistent block per CU instead of two (occupancy experiment)
 //   [8] bf16 weight gradient: target number of blocks (0 = default)   [9] 1 = bf16 weight gradient without the XCD-aware block order
@@ -48,6 +48,7 @@ constexpr int NITEMS = HZ * HY * HX * (CC / 4);   // 2400 float4 items per chunk
 constexpr int NIT = (NITEMS + 255) / 256;         // 10
 constexpr int NSTEP = 27 * (CC / 8);              // 54 k-steps of 8 channels per chunk
 constexpr int NSTEP_PAIRY = 36 * (CC / 8);        // 72 k-steps: 3 x 4 x 3 tap window of the paired-y variant
+constexpr int NSTEP_N16 = 27;                     // 16-column variant: one k-step per tap over the chunk's 16 channels
 constexpr int ST0 = 30;                           // k-step of the first halo store into the other buffer
 constexpr int ISTORE = 5;                         // persistent variant: tap row (of 9) whose k-steps store the halo
 constexpr int PACK_PAD = 5;                       // zero k-steps appended to the packed weight image (B prefetch overrun)
@@ -632,17 +633,26 @@ __device__ __forceinline__ void u3d_for_rows(F&& f) {
 // voxel y serves both outputs when the tap window is 3 x 4 x 3 (36 taps, the weights of the second half shifted by one
 // in y, zero where that leaves the 3^3 kernel).  A wave then needs only the even rows y = 0,2,4,6 of its z-plane (ONE
 // M-tile): 72 k-steps x 4 MFMAs per chunk instead of 54 x 8 — 2/3 of the padded work.
-template <int NT, bool VIRT, bool DBG = false, bool PAIRY = false, bool AFF = true>
+//
+// N16 (round 4; Cout <= 16, NT = 1, supersedes PAIRY): the same GEMM on v_mfma_f32_16x16x4_f32 — 16 output channels are exactly
+// one MFMA tile, no padded or zero work at all (PAIRY still executes 4/3 of the algorithmic multiply-adds).  The WEIGHT fragment
+// is the A operand (rows = output channels, one packed f32x4 per lane and TAP: channels 4*(lane>>4) .. +3 of column lane&15), the
+// activation fragment the B operand (columns = 16 voxels: two y rows x 8 x; a wave's z-plane is 4 M-tiles), so a lane's four
+// accumulator registers of an M-tile are FOUR CONSECUTIVE output channels of ONE voxel: 16-byte stores / side loads without the
+// DPP transposition.  A k-step is one tap over the chunk's 16 channels: 4 A reads, one B fetch, 16 MFMAs of 32 cycles.
+template <int NT, bool VIRT, bool DBG = false, bool PAIRY = false, bool AFF = true, bool N16 = false>
 __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParams p) {
     using namespace cv;
     static_assert(!PAIRY || NT == 1, "the paired-y variant has a single N-tile");
+    static_assert(!N16 || (NT == 1 && !PAIRY), "the 16-column variant has a single N-tile");
     // B ring depth: fragments are fetched RB-1 k-steps ahead; slots are indexed by the k-step within the chunk (54 % RB == 0,
     // 72 % RB == 0).  NT = 1 has the registers for 9 (round 4: 6 -> 9, 8 steps = 4 k cycles of slack behind a halo load)
     constexpr int RB = NT == 1 ? 9 : 3;
-    constexpr int MT = PAIRY ? 1 : 2;    // M-tiles (4 y-rows x 8 x) per wave
+    constexpr int MT = N16 ? 4 : (PAIRY ? 1 : 2);  // M-tiles per wave (32 voxels = 4 y-rows x 8 x; N16: 16 voxels = 2 y-rows x 8 x)
     constexpr int RY = PAIRY ? 4 : 3;    // taps along y
-    constexpr int NROWS = 3 * RY;        // tap rows (z, y) of 3 x-taps x 2 channel octets = 6 k-steps each
-    constexpr int NSTEPL = NROWS * 6;    // k-steps per chunk
+    constexpr int NROWS = 3 * RY;        // tap rows (z, y) of 3 x-taps
+    constexpr int SPR = N16 ? 3 : 6;     // k-steps per tap row: 3 taps x 2 channel octets (N16: 3 taps over all 16 channels)
+    constexpr int NSTEPL = NROWS * SPR;  // k-steps per chunk
     constexpr int DBG_TILE = 1;          // timeline twin: which tile of a block is stamped (1 = steady state, not the cold first)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int* cnt = reinterpret_cast<int*>(lds + CNT_OFF);
@@ -766,9 +776,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
 
     // NT <= 2: the accumulators are written first by the C = 0 MFMAs of every tile's first k-step (ROW_LOAD_FIRST); NT = 3
     // keeps explicit zeroing (the extra row variant costs it registers it does not have: +90 B of spills, -3 %)
-    constexpr bool ZEROC = NT < 3;
-    f32x16 acc[MT][NT];
-    if constexpr (!ZEROC) {
+    constexpr bool ZEROC = NT < 3 && !N16;
+    f32x16 acc[N16 ? 1 : MT][NT];
+    f32x4 acc16[N16 ? MT : 1];  // N16: per M-tile, rows = channels 4*(lane>>4) .. +3, column = voxel lane & 15
+    if constexpr (N16) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc16[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else if constexpr (!ZEROC) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -778,8 +792,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
     }
 
     // A-fragment base: lane (m,h) -> voxel (zl = w, yl = (m>>3) [+4 for mt=1], xl = m&7), channels 4h..4h+3;
-    // PAIRY: yl = 2*(m>>3) (even rows only)
-    const int abase = w * PS + (m >> 3) * (PAIRY ? 2 : 1) * RS + (m & 7) * CS + 4 * h;
+    // PAIRY: yl = 2*(m>>3) (even rows only); N16: lane (v = l&15, kq = l>>4) -> voxel (yl = v>>3 [+2 per M-tile], xl = v&7),
+    // channels 4kq..4kq+3 (all 16 channels of the chunk in one read)
+    const int v16 = l & 15, kq = l >> 4;
+    // (N16: an M-tile pairs the rows y and y + 2 — with the row stride of 164 floats that is the pairing whose 16 x 4 lanes hit
+    // distinct banks in every ds_read_b128 service group, tools/lds_bank_model.py; rows y, y + 1 are 2-way conflicted)
+    const int abase = N16 ? w * PS + 2 * (v16 >> 3) * RS + (v16 & 7) * CS + 4 * kq
+                          : w * PS + (m >> 3) * (PAIRY ? 2 : 1) * RS + (m & 7) * CS + 4 * h;
+    auto mrow = [](int mt) { return N16 ? (mt >> 1) * 4 + (mt & 1) : 4 * mt; };  // first y row of M-tile mt
 
     // B stream: uniform base pointer of the block's channel block + the lane's 16-byte slot (no VALU per step)
     const f32x4* wimg = reinterpret_cast<const f32x4*>(p.wp);
@@ -951,7 +971,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
             //      the 10 halo loads of the next chunk, tap row ISTORE their LDS stores
             f32x4 aq[2][MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) aq[0][mt] = *reinterpret_cast<const f32x4*>(&cur[abase + 4 * mt * RS]);
+            for (int mt = 0; mt < MT; ++mt) aq[0][mt] = *reinterpret_cast<const f32x4*>(&cur[abase + mrow(mt) * RS]);
             const f32x4* wch0 = wq + (size_t)(ch * NSTEPL + RB - 1) * wstep;  // B fragments of step (row 0, 0) + RB-1
             // One tap row = 6 k-steps.  The rows differ in what rides along with the MFMAs (halo loads in row 0, the affine
             // rows in row ISTORE-1, the halo stores in row ISTORE, the switch to the next tile's weight image in the last
@@ -975,14 +995,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                     if (do_store) u3d_flag_wait(&cnt[2 + (b ^ 1)], 4 * ((gch + 1) / 2));  // other buffer free
                 }
 #pragma unroll
-                for (int s6 = 0; s6 < 6; ++s6) {
+                for (int s6 = 0; s6 < SPR; ++s6) {
+                    constexpr int STORES_PER_STEP = (NIT + SPR - 2) / (SPR - 1);  // the halo stores of a row: spread over its first steps
                     {
                         // B fragments of step + RB-1; past the end of a tile's image continue with the next tile's.
                         // (recomputed from uniform scalars, not carried as a mutated pointer: keeps the address in SGPRs)
-                        const f32x4* wsrc = wch0 + (size_t)(row * 6 + s6) * wstep;
-                        if (row * 6 + s6 + RB - 1 >= NSTEPL && last) wsrc = wqn + (size_t)(row * 6 + s6 + RB - 1 - NSTEPL) * wstep;
+                        const f32x4* wsrc = wch0 + (size_t)(row * SPR + s6) * wstep;
+                        if (row * SPR + s6 + RB - 1 >= NSTEPL && last) wsrc = wqn + (size_t)(row * SPR + s6 + RB - 1 - NSTEPL) * wstep;
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) bq[(row * 6 + s6 + RB - 1) % RB][nt] = wsrc[nt * 64 + l];
+                        for (int nt = 0; nt < NT; ++nt) bq[(row * SPR + s6 + RB - 1) % RB][nt] = wsrc[nt * 64 + l];
                     }
                     // vmcnt retires in order: a B fragment fetched AFTER a halo load cannot be consumed before that halo load (an
                     // HBM / remote-L2 round trip) has landed.  Spread two per k-step, every B fragment of the row sat behind the halo
@@ -1002,48 +1023,64 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
+                        if constexpr (N16) {
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
+                            for (int mt = 0; mt < MT; ++mt)
+                                acc16[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[(row * SPR + s6) % RB][0][j], aq[(row * SPR + s6) & 1][mt][j], acc16[mt], 0, 0, 0);
+                        } else {
 #pragma unroll
-                            for (int mt = 0; mt < MT; ++mt) {
-                                if (KIND == ROW_LOAD_FIRST && s6 == 0 && j == 0) {
-                                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[0][mt][0], bq[0][nt][0], zero, 0, 0, 0);
-                                } else {
-                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s6 & 1][mt][j], bq[(row * 6 + s6) % RB][nt][j], acc[mt][nt], 0, 0, 0);
+                            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                                for (int mt = 0; mt < MT; ++mt) {
+                                    if (KIND == ROW_LOAD_FIRST && s6 == 0 && j == 0) {
+                                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[0][mt][0], bq[0][nt][0], zero, 0, 0, 0);
+                                    } else {
+                                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[(row * SPR + s6) & 1][mt][j], bq[(row * SPR + s6) % RB][nt][j], acc[mt][nt], 0, 0, 0);
+                                    }
                                 }
                             }
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (s6 < 5) {
-                        const int aoff = ((s6 + 1) >> 1) * CS + 8 * ((s6 + 1) & 1);
+                    if (s6 < SPR - 1) {
+                        // next k-step of this tap row: (tap, channel octet) -> (s+1)>>1, (s+1)&1; N16: the next tap, all 16 channels
+                        const int aoff = N16 ? (s6 + 1) * CS : ((s6 + 1) >> 1) * CS + 8 * ((s6 + 1) & 1);
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) aq[(s6 + 1) & 1][mt] = *reinterpret_cast<const f32x4*>(&arow[4 * mt * RS + aoff]);
+                        for (int mt = 0; mt < MT; ++mt) aq[(row * SPR + s6 + 1) & 1][mt] = *reinterpret_cast<const f32x4*>(&arow[mrow(mt) * RS + aoff]);
                     } else if constexpr (KIND != ROW_LAST) {
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) aq[0][mt] = *reinterpret_cast<const f32x4*>(&anext[4 * mt * RS]);
+                        for (int mt = 0; mt < MT; ++mt) aq[(row * SPR + s6 + 1) & 1][mt] = *reinterpret_cast<const f32x4*>(&anext[mrow(mt) * RS]);
                     }
                     if constexpr (KIND == ROW_STORE) {
-                        if (do_store && s6 < NIT / 2) {
-                            if (masked) {
-                                halo_store(nxt, cn, S, 2 * s6, v[2 * s6], true);
-                                halo_store(nxt, cn, S, 2 * s6 + 1, v[2 * s6 + 1], true);
-                            } else {
-                                halo_store(nxt, cn, S, 2 * s6, v[2 * s6], false);
-                                halo_store(nxt, cn, S, 2 * s6 + 1, v[2 * s6 + 1], false);
+                        if (do_store && s6 * STORES_PER_STEP < NIT) {
+#pragma unroll
+                            for (int k = 0; k < STORES_PER_STEP; ++k) {
+                                const int it = s6 * STORES_PER_STEP + k;
+                                if (it < NIT) {
+                                    if (masked)
+                                        halo_store(nxt, cn, S, it, v[it], true);
+                                    else
+                                        halo_store(nxt, cn, S, it, v[it], false);
+                                }
                             }
-                            if (s6 == NIT / 2 - 1) u3d_flag_signal(&cnt[b ^ 1], l);
+                            if ((s6 + 1) * STORES_PER_STEP >= NIT) u3d_flag_signal(&cnt[b ^ 1], l);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 2; j < 4; ++j) {
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
+                        if constexpr (N16) {
 #pragma unroll
                             for (int mt = 0; mt < MT; ++mt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s6 & 1][mt][j], bq[(row * 6 + s6) % RB][nt][j], acc[mt][nt], 0, 0, 0);
+                                acc16[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[(row * SPR + s6) % RB][0][j], aq[(row * SPR + s6) & 1][mt][j], acc16[mt], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                                for (int mt = 0; mt < MT; ++mt)
+                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[(row * SPR + s6) & 1][mt][j], bq[(row * SPR + s6) % RB][nt][j], acc[mt][nt], 0, 0, 0);
+                            }
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -1073,6 +1110,51 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
         //      inside every lane quad (two DPP butterfly stages) leaves lane j of quad k with the 4 consecutive
         //      channels 4k..4k+3 of voxel x = j + 4h: 16-byte stores and 16-byte loads of x for the GroupNorm sums.
         if (ntiles == DBG_TILE) U3D_DBG_STAMP(5);
+        if constexpr (N16) {
+            // accumulator of M-tile mt, lane (v = l&15, kq = l>>4): channels 4kq .. 4kq+3 of voxel (z, y0 + mrow(mt) + 2*(v>>3), x0 + (v&7))
+            const int n = T.n;
+            const int z = T.z0 + w;
+            const int co = 4 * kq;
+            const bool cok = co < p.Cout;
+            const int vlane = ((n * D + z) * H + T.y0 + 2 * (v16 >> 3)) * W + T.x0 + (v16 & 7);  // this lane's voxel of M-tile 0
+            float* orow = p.out + (size_t)vlane * p.Cout + co;
+            const size_t rstep = (size_t)W * p.Cout;  // one y row of the output
+            f32x4 xv[MT];
+            if (want_g) {
+                // gx (the layer's input, for the GroupNorm-backward sums): plain, or its channels beyond C0 from the exact-2x low-res half
+                const bool from0 = co < p.gx.C0 || !cok;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int y = T.y0 + mrow(mt) + 2 * (v16 >> 3), x = T.x0 + (v16 & 7);
+                    const int xi1 = ((n * p.gx.D1 + (z >> 1)) * p.gx.H1 + (y >> 1)) * p.gx.W1 + (x >> 1);
+                    const float* xp = !cok ? p.gx.p0
+                                           : (from0 ? p.gx.p0 + (size_t)(vlane + mrow(mt) * W) * p.gx.C0 + co
+                                                    : p.gx.p1 + (size_t)xi1 * p.gx.C1 + (co - p.gx.C0));
+                    xv[mt] = *reinterpret_cast<const f32x4*>(xp);
+                }
+            } else if (p.res) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    xv[mt] = *reinterpret_cast<const f32x4*>(p.res + (size_t)(vlane + mrow(mt) * W) * p.Cout + (cok ? co : 0));
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x4 val = acc16[mt];
+                if (p.res) val += xv[mt];
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
+                }
+                if (cok) *reinterpret_cast<f32x4*>(orow + mrow(mt) * rstep) = val;
+                if (p.Cout % 16 != 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] = cok ? val[e] : 0.f;
+                }
+                sq1 += val;  // (CARRY: NT == 1) running sums of this lane's four channels over its voxels and tiles
+                sq2 += want_g ? val * xv[mt] : val * val;
+                acc16[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else
         if (p.stagger != -1) {  // (u3d_set_tuning key 5 = -1: TIMING-ONLY ablation without the epilogue — wrong results by design)
             const int n = T.n, cb = T.cb;
             const int z = T.z0 + w;
@@ -1159,8 +1241,26 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
         if (!has_next_tile || TN.n != T.n || TN.cb != T.cb) {
             if constexpr (CARRY) {
                 if (want_stats || want_g) {
-                    const int cq_ = (l >> 2) & 7;
-                    stat_reduce(sq1, sq2, T.n, 0, PAIRY ? 4 * (cq_ & 3) : 4 * cq_);
+                    if constexpr (N16) {
+                        // the 16 lanes v of a k-group hold 16 voxels of the same four channels
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float a = sq1[e], b2 = sq2[e];
+#pragma unroll
+                            for (int msk = 8; msk > 0; msk >>= 1) {
+                                a += __shfl_xor(a, msk);
+                                b2 += __shfl_xor(b2, msk);
+                            }
+                            if (v16 == 0) {
+                                double* r = &red[(((T.n & 1) * NT) * 32 + 4 * kq + e) * 2];
+                                __hip_atomic_fetch_add(r, (double)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_fetch_add(r + 1, (double)b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                        }
+                    } else {
+                        const int cq_ = (l >> 2) & 7;
+                        stat_reduce(sq1, sq2, T.n, 0, PAIRY ? 4 * (cq_ & 3) : 4 * cq_);
+                    }
                     sq1 = f32x4{0.f, 0.f, 0.f, 0.f};
                     sq2 = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
@@ -1628,6 +1728,37 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         dw[((size_t)k * cstride + c) * 27 + tap] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
+// the packed image(s) of one layer: the standard image, then — for <= 16 produced channels — the paired-y image and the 16-column
+// image (conv3d_mfma_reg_kernel PAIRY / N16).  Splits a flat element index into (image, index inside it).
+__device__ __forceinline__ int pack_image_of(long long idx, int nchunks, int ntot, long long& id) {
+    const long long std_total = ((long long)nchunks * cv::NSTEP + cv::PACK_PAD) * ntot * 256;
+    const long long pair_total = ((long long)nchunks * cv::NSTEP_PAIRY + cv::PACK_PAD) * 256;
+    if (idx < std_total) {
+        id = idx;
+        return 0;
+    }
+    if (idx < std_total + pair_total) {
+        id = idx - std_total;
+        return 1;
+    }
+    id = idx - std_total - pair_total;
+    return 2;
+}
+
+// element j of the 16-column image: f32x4 index ((ch*27 + tap)*64 + lane): contraction channel ch*16 + 4*(lane>>4) + j, produced
+// channel lane & 15
+__device__ __forceinline__ float pack_elem_n16(const float* __restrict__ w, int Cout, int Cin, int cstride, int mode, int nchunks,
+                                               long long id) {
+    const int j = (int)(id & 3);
+    const int lane = (int)((id >> 2) & 63);
+    const long long r = id >> 8;
+    const int tap = (int)(r % cv::NSTEP_N16), ch = (int)(r / cv::NSTEP_N16);
+    const int kc = ch * 16 + 4 * (lane >> 4) + j, nc = lane & 15;
+    if (ch >= nchunks) return 0.f;
+    if (mode == 0) return (kc < Cin && nc < Cout) ? w[((size_t)nc * cstride + kc) * 27 + tap] : 0.f;
+    return (kc < Cout && nc < Cin) ? w[((size_t)kc * cstride + nc) * 27 + (26 - tap)] : 0.f;
+}
+
 // =================================================================================================
 // weight packing: packed f32x4 index (((ch*54 + st)*ntot + ntg)*64 + lane), element j:
 //   k-channel  c  = ch*16 + 8*(st&1) + 4*(lane>>5) + j,  tap = st>>1,  n-channel = ntg*32 + (lane&31)
@@ -1636,11 +1767,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // cstride: channels per output-channel row of `w` (Cin, or the parent's channel count when w points into a channel slice)
 __device__ __forceinline__ float pack_elem(const float* __restrict__ w, int Cout, int Cin, int cstride, int mode, int nchunks,
                                            int ntot, long long idx) {
-    const long long total = ((long long)nchunks * cv::NSTEP + cv::PACK_PAD) * ntot * 256;
     // narrow outputs (<= 16 channels) get a second image for the paired-y kernel variant: 72 k-steps per chunk over the
-    // 3 x 4 x 3 tap window, columns 16-31 = the same channels with the kernel shifted by one row in y
-    const bool pair = idx >= total;
-    const long long id = pair ? idx - total : idx;
+    // 3 x 4 x 3 tap window, columns 16-31 = the same channels with the kernel shifted by one row in y — and a third one for the
+    // 16-column variant
+    long long id;
+    const int image = pack_image_of(idx, nchunks, ntot, id);
+    if (image == 2) return pack_elem_n16(w, Cout, Cin, cstride, mode, nchunks, id);
+    const bool pair = image == 1;
     const int j = (int)(id & 3);
     const int lane = (int)((id >> 2) & 63);
     long long r = id >> 8;
@@ -1676,7 +1809,7 @@ static long long pack_total_floats(int Cin, int Cout, int mode, int* nchunks_out
     const int K = mode == 0 ? Cin : Cout, Nn = mode == 0 ? Cout : Cin;
     const int nchunks = (K + 15) / 16, ntot = (Nn + 31) / 32;
     long long total = ((long long)nchunks * cv::NSTEP + cv::PACK_PAD) * ntot * 256;
-    if (Nn <= 16) total += ((long long)nchunks * cv::NSTEP_PAIRY + cv::PACK_PAD) * 256;
+    if (Nn <= 16) total += ((long long)nchunks * cv::NSTEP_PAIRY + cv::PACK_PAD) * 256 + ((long long)nchunks * cv::NSTEP_N16 + cv::PACK_PAD) * 256;
     if (nchunks_out) *nchunks_out = nchunks;
     if (ntot_out) *ntot_out = ntot;
     return total;
@@ -1693,10 +1826,15 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 // every index but the channel: decode once, gather four values
 __device__ __forceinline__ f32x4 pack_quad(const float* __restrict__ w, int Cout, int Cin, int cstride, int mode, int nchunks,
                                            int ntot, long long idx4) {
-    const long long total = ((long long)nchunks * cv::NSTEP + cv::PACK_PAD) * ntot * 256;
-    const long long idx = idx4 * 4;
-    const bool pair = idx >= total;
-    const long long id = pair ? idx - total : idx;
+    long long id;
+    const int image = pack_image_of(idx4 * 4, nchunks, ntot, id);
+    if (image == 2) {
+        f32x4 q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j] = pack_elem_n16(w, Cout, Cin, cstride, mode, nchunks, id + j);
+        return q;
+    }
+    const bool pair = image == 1;
     const int lane = (int)((id >> 2) & 63);
     long long r = id >> 8;
     const int nstep = pair ? cv::NSTEP_PAIRY : cv::NSTEP;
@@ -1896,6 +2034,12 @@ static int conv_set_lds_nt() {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<1, true, false, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<1, true, false, false, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<1, false, false, false, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<1, false, false, false, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     }
     U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_kernel<NT, true, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -2077,15 +2221,28 @@ static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, co
         // per-element FMA of the halo stores (key 7 = 1 turns it off for A/B runs)
         const bool noaff = p.src.affine == nullptr && g_u3d_tune[7] == 0;
         p.dbg = (g_u3d_prof_buf && (size_t)slots * 4 <= g_u3d_prof_records) ? g_u3d_prof_buf : nullptr;
-        if (Cout <= 16 && nt == 1 && p.ntot == 1 && !p.dbg && g_u3d_tune[4] == 0) {
-            // paired-y variant on the second packed image (u3d_pack_weights appends it for <= 16 output channels)
-            p.wp = packed_w + ((size_t)p.nchunks * cv::NSTEP + cv::PACK_PAD) * 256;
-            if (virt)
-                hipLaunchKernelGGL((conv3d_mfma_reg_kernel<1, true, false, true>), rgrid, rblock, shmem, st, p);
-            else if (noaff)
-                hipLaunchKernelGGL((conv3d_mfma_reg_kernel<1, false, false, true, false>), rgrid, rblock, shmem, st, p);
-            else
-                hipLaunchKernelGGL((conv3d_mfma_reg_kernel<1, false, false, true>), rgrid, rblock, shmem, st, p);
+        if (Cout <= 16 && nt == 1 && p.ntot == 1 && !p.dbg && g_u3d_tune[4] != 1) {
+            // <= 16 output channels (the 32 -> 16 data gradient at full resolution): the 16-column variant on the THIRD packed image
+            // (u3d_pack_weights appends the paired-y and the 16-column image for <= 16 produced channels); key 4 = 2: the round-1
+            // paired-y variant on the second image (A/B), key 4 = 1: the padded 32-column kernel
+            const size_t std_floats = ((size_t)p.nchunks * cv::NSTEP + cv::PACK_PAD) * 256;
+            if (g_u3d_tune[4] == 2) {
+                p.wp = packed_w + std_floats;
+                if (virt)
+                    hipLaunchKernelGGL((conv3d_mfma_reg_kernel<1, true, false, true>), rgrid, rblock, shmem, st, p);
+                else if (noaff)
+                    hipLaunchKernelGGL((conv3d_mfma_reg_kernel<1, false, false, true, false>), rgrid, rblock, shmem, st, p);
+                else
+                    hipLaunchKernelGGL((conv3d_mfma_reg_kernel<1, false, false, true>), rgrid, rblock, shmem, st, p);
+            } else {
+                p.wp = packed_w + std_floats + ((size_t)p.nchunks * cv::NSTEP_PAIRY + cv::PACK_PAD) * 256;
+                if (virt)
+                    hipLaunchKernelGGL((conv3d_mfma_reg_kernel<1, true, false, false, true, true>), rgrid, rblock, shmem, st, p);
+                else if (noaff)
+                    hipLaunchKernelGGL((conv3d_mfma_reg_kernel<1, false, false, false, false, true>), rgrid, rblock, shmem, st, p);
+                else
+                    hipLaunchKernelGGL((conv3d_mfma_reg_kernel<1, false, false, false, true, true>), rgrid, rblock, shmem, st, p);
+            }
             U3D_LAUNCH_CHECK();
             return 0;
         }

@@ -387,6 +387,52 @@ def test_conv3d_dgrad_and_groupnorm_reductions(N, Cin, Cout, D, H, W):
     assert U.relerr(U.ncdhw(dn), ref) < TOL
 
 
+@pytest.mark.parametrize("N,Cin,Cout,D,H,W,res", [(2, 32, 16, 8, 16, 32, False), (1, 16, 8, 4, 8, 8, True), (1, 48, 12, 4, 16, 8, False)])
+def test_narrow_output_variants_agree(N, Cin, Cout, D, H, W, res):
+    """<= 16 produced channels on aligned dims: the 16-column variant (v_mfma_f32_16x16x4_f32, round 4, default), the paired-y
+    variant (key 4 = 2) and the padded 32-column kernel (key 4 = 1) compute the same convolution, statistics and GroupNorm-backward
+    sums (fp32 summation orders differ), forward (affine, ReLU, statistics[, residual]) and data gradient (gx sums)"""
+    U, nat, VSrc, _p, _stream = _mods()
+    torch.manual_seed(3 * Cin + Cout)
+    x = torch.randn(N, Cin, D, H, W)
+    w = torch.randn(Cout, Cin, 3, 3, 3) / (27 * Cin) ** 0.5
+    ab = torch.randn(N, Cin, 2)
+    aff = ab.contiguous().to(U.DEV)
+    g = x * ab[:, :, 0].view(N, Cin, 1, 1, 1) + ab[:, :, 1].view(N, Cin, 1, 1, 1)
+    r = torch.randn(N, Cout, D, H, W) if res else None
+    ref = F.conv3d(g, w, None, padding=1) + (r if res else 0.0)
+    ref = F.relu(ref)
+    # data gradient of a (Cout -> Cin') layer whose INPUT has <= 16 channels: dz (N, Kd, ...) -> dx (N, Cout, ...)
+    Kd = 32
+    wd = torch.randn(Kd, Cout, 3, 3, 3) / (27 * Cout) ** 0.5
+    xx = torch.randn(N, Cout, D, H, W)
+    dz = torch.randn(N, Kd, D, H, W)
+    xl = xx.clone().requires_grad_(True)
+    F.conv3d(xl, wd, None, padding=1).backward(dz)
+    dref = xl.grad
+    out = {}
+    for key in (0, 2, 1):
+        nat.call("u3d_set_tuning", 4, key)
+        try:
+            st = torch.zeros((N, Cout, 2), dtype=torch.float64, device=U.DEV)
+            if res:
+                y, _ = U.conv3d_ex(VSrc(U.ndhwc(x)), w, Cout, relu=1, affine=aff, out_stats=st, residual=U.ndhwc(r))
+            else:
+                y = U.conv3d(VSrc(U.ndhwc(x)), w, Cout, relu=1, affine=aff, out_stats=st)
+            gst = torch.zeros((N, Cout, 2), dtype=torch.float64, device=U.DEV)
+            dg = U.conv3d(VSrc(U.ndhwc(dz)), wd, Cout, relu=0, mode=1, gx=VSrc(U.ndhwc(xx)), gstats=gst)
+            torch.cuda.synchronize()
+        finally:
+            nat.call("u3d_set_tuning", 4, 0)
+        out[key] = (U.ncdhw(y), st.cpu(), U.ncdhw(dg), gst.cpu())
+        assert U.relerr(out[key][0], ref) < TOL and U.relerr(out[key][2], dref) < TOL, key
+        s_ref = torch.stack([ref.double().sum(dim=(2, 3, 4)), (ref.double() ** 2).sum(dim=(2, 3, 4))], dim=-1)
+        g_ref = torch.stack([dref.double().sum(dim=(2, 3, 4)), (dref.double() * xx.double()).sum(dim=(2, 3, 4))], dim=-1)
+        assert U.relerr(out[key][1], s_ref) < 1e-5 and U.relerr(out[key][3], g_ref) < 1e-5, key
+    for key in (2, 1):
+        assert U.relerr(out[key][0], out[0][0]) < 1e-5 and U.relerr(out[key][2], out[0][2]) < 1e-5
+
+
 WGRAD_CASES = [(1, 16, 32, 8, 16, 16, False), (2, 32, 64, 9, 13, 11, True), (1, 1, 16, 8, 16, 16, True),
                (1, 96, 32, 4, 8, 8, True), (1, 3, 8, 5, 9, 7, True), (1, 64, 128, 4, 8, 8, False),
                (1, 32, 32, 16, 32, 32, True),
