@@ -444,10 +444,10 @@ def test_activation_bf16_falls_back_with_a_warning_outside_its_envelope():
     assert not get_model(dict(CFG, compute_dtype="bf16", activation_dtype="fp32")).to(U.DEV)._get_engine().act_bf16
 
 
-# Bands of the trajectory test below.  MEASURED FIGURES are written by diag(test="bf16_adam_trajectory") into
-# profiles/r04_parity_diag.jsonl; the bands are 2-3x those, stated relative to the fp32 run's loss at the same step.
-TRAJ_STEP_BAND = 0.05   # every step: |loss_bf16 - loss_fp32| <= 5 % of loss_fp32
-TRAJ_TAIL_BAND = 0.03   # mean of the last 5 steps: within 3 %
+# Bands of the trajectory test below, 3x the measured figures (profiles/r04_parity_diag.jsonl, test "bf16_adam_trajectory": worst step
+# deviation 0.83 %, mean of the last five steps 0.33 % apart, update rel-L2 0.39), relative to the fp32 run's loss at the same step.
+TRAJ_STEP_BAND = 0.025  # every step: |loss_bf16 - loss_fp32| <= 2.5 % of loss_fp32
+TRAJ_TAIL_BAND = 0.01   # mean of the last 5 steps: within 1 %
 TRAJ_MIN_DROP = 0.30    # both runs must have learnt: mean(last 5) < 0.30 * loss(step 0) (the host's fp32 module tree: 0.17)
 
 
