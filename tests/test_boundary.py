@@ -43,8 +43,9 @@ def test_host_only_entry_points():
     # packed image: (ceil(K/16) chunks x 54 steps + 5 zero pad steps) x ceil(N/32) n-tiles x 256 floats
     assert lib.u3d_packed_weight_floats(96, 32, 0) == (6 * 54 + 5) * 1 * 256
     assert lib.u3d_packed_weight_floats(96, 32, 1) == (2 * 54 + 5) * 3 * 256
-    # <= 16 output channels: a second image (72 k-steps per chunk) for the paired-y kernel variant is appended
-    assert lib.u3d_packed_weight_floats(1, 16, 0) == (1 * 54 + 5) * 1 * 256 + (1 * 72 + 5) * 256
+    # <= 16 output channels: two more images are appended — the paired-y kernel variant's (72 k-steps per chunk) and, since round 4,
+    # the 16-column variant's (27 k-steps per chunk, one per tap)
+    assert lib.u3d_packed_weight_floats(1, 16, 0) == (1 * 54 + 5) * 1 * 256 + (1 * 72 + 5) * 256 + (1 * 27 + 5) * 256
     assert lib.u3d_packed_weight_floats(32, 16, 1) == (1 * 54 + 5) * 1 * 256  # dgrad of 32->16: 32 output channels
     ws = lib.u3d_wgrad_workspace_floats(1, 64, 128, 128, 96, 32)
     assert ws % (27 * 1024) == 0 and 0 < ws < (1 << 28)

@@ -318,11 +318,15 @@ def test_port_and_live_reference_same_speed():
     l_ref, l_port = step_ref(), step_port()  # warm-up + numerics
     assert orc.rel_err(l_port, l_ref) < 1e-6
     t_ref, t_port = [], []
-    for _ in range(4):  # interleaved, best-of: robust against a noisy shared host
-        t0 = time.perf_counter(); step_ref(); t_ref.append(time.perf_counter() - t0)     # noqa: E702
-        t0 = time.perf_counter(); step_port(); t_port.append(time.perf_counter() - t0)   # noqa: E702
-    ratio = min(t_port) / min(t_ref)
-    print(f"reference {min(t_ref) * 1e3:.1f} ms, port {min(t_port) * 1e3:.1f} ms per fwd+bwd (ratio {ratio:.2f})")
+    ratio = 0.0
+    for attempt in range(5):  # interleaved, best-of over ALL rounds so far: a shared build host has bursts of seconds of noise
+        for _ in range(4):
+            t0 = time.perf_counter(); step_ref(); t_ref.append(time.perf_counter() - t0)     # noqa: E702
+            t0 = time.perf_counter(); step_port(); t_port.append(time.perf_counter() - t0)   # noqa: E702
+        ratio = min(t_port) / min(t_ref)
+        if 0.8 < ratio < 1.25:
+            break
+    print(f"reference {min(t_ref) * 1e3:.1f} ms, port {min(t_port) * 1e3:.1f} ms per fwd+bwd (ratio {ratio:.2f}, {len(t_ref)} timed pairs)")
     assert 0.7 < ratio < 1.4, (t_ref, t_port)
 
 
