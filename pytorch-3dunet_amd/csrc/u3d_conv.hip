@@ -30,7 +30,9 @@
 //   [12] block slots (of 2 per CU) that the persistent convolution grids leave FREE for kernels of other streams (RCCL's gradient
 //        all-reduce: parallel.cu_budget).  A CU-MASKED compute queue was measured instead and rejected: the same kernels run 40-75 %
 //        slower on a queue masked to 248 of 256 CUs (profiles/r04_cu_mask_*.txt)
-//   [13] 1 = first-layer forward on the direct kernel instead of the matrix-pipe one (csrc/u3d_smallc.hip, A/B)   [14..15] free
+//   [13] 1 = first-layer forward on the direct kernel instead of the matrix-pipe one (csrc/u3d_smallc.hip, A/B)
+//   [14] 1 = persistent convolution kernel walks its tiles x-fastest (rounds 1-3) instead of z-fastest
+//   [15] 1 = sub-pixel weight gradient with per-element coordinate arithmetic for its B loads (A/B of the constant-offset path)
 int g_u3d_tune[16] = {0};
 
 namespace cv {
@@ -70,6 +72,7 @@ struct ConvParams {
     int total;   // REG kernel: work items = tiles * ncb
     int gx_x2;   // REG kernel: gx's low-res half is an exact 2x upsampling (index = i >> 1, no table)
     int stagger; // REG kernel: start delay of the second half of the grid, in units of 1024 cycles
+    int zfast;   // REG kernel: tiles are walked z-fastest (1) or x-fastest (0)
     int ksplit, cps;        // generic kernel, split-K: the chunk range is cut into ksplit runs of cps chunks, one per block,
     long long part_stride;  // each run writing its partial sums to out + run * part_stride (summed by splitk_reduce_kernel)
     long long* dbg;  // optional per-wave timeline records (u3d_set_profile_buffer), 24 int64 per wave
@@ -723,43 +726,50 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
     struct Digits {
         int cb, xi, yi, zi, n;
     };
+    // Order of the tiles inside the flat item sequence.  At any time the 512 blocks work on 512 CONSECUTIVE items and every XCD on a
+    // contiguous run of 64 of them, i.e. that run is what shares an L2.  x-fastest (rounds 1-3) makes it a 16 x 4 patch of (x, y) tiles
+    // at ONE z: the z halos (6 planes fetched for 4 computed) are shared with nobody and most of them come from HBM again — 1.65x the
+    // algorithmic traffic.  z-fastest (round 4, default; key 14 = 1: x-fastest) walks all z tiles of an (x, y) column first: the run is
+    // a slab whose z halos are its own neighbours' interiors.
+    const bool zfast = p.zfast != 0;
+    const int r1 = zfast ? p.tz : p.tx, r3 = zfast ? p.tx : p.tz;  // radices of the first / third tile digit (the second is y)
     auto decode = [&](int idx) {
-        Digits d;
+        Digits d;  // (xi, yi, zi) hold the first / second / third digit; item_of maps them to coordinates
         d.cb = idx % p.ncb;
         int tile = idx / p.ncb;
-        d.xi = tile % p.tx;
-        tile /= p.tx;
+        d.xi = tile % r1;
+        tile /= r1;
         d.yi = tile % p.ty;
         tile /= p.ty;
-        d.zi = tile % p.tz;
-        d.n = tile / p.tz;
+        d.zi = tile % r3;
+        d.n = tile / r3;
         return d;
     };
     const Digits dG = decode(G);
-    auto advance = [&](const Digits& a) {  // a + G in the mixed radix (ncb, tx, ty, tz, unbounded)
+    auto advance = [&](const Digits& a) {  // a + G in the mixed radix (ncb, r1, ty, r3, unbounded)
         Digits r;
         int c;
         r.cb = a.cb + dG.cb;
         c = r.cb >= p.ncb ? 1 : 0;
         r.cb -= c ? p.ncb : 0;
         r.xi = a.xi + dG.xi + c;
-        c = r.xi >= p.tx ? 1 : 0;
-        r.xi -= c ? p.tx : 0;
+        c = r.xi >= r1 ? 1 : 0;
+        r.xi -= c ? r1 : 0;
         r.yi = a.yi + dG.yi + c;
         c = r.yi >= p.ty ? 1 : 0;
         r.yi -= c ? p.ty : 0;
         r.zi = a.zi + dG.zi + c;
-        c = r.zi >= p.tz ? 1 : 0;
-        r.zi -= c ? p.tz : 0;
+        c = r.zi >= r3 ? 1 : 0;
+        r.zi -= c ? r3 : 0;
         r.n = a.n + dG.n + c;
         return r;
     };
     auto item_of = [&](const Digits& d) {
         Item c;
         c.cb = d.cb;
-        c.x0 = d.xi * TX;
+        c.x0 = (zfast ? d.zi : d.xi) * TX;
         c.y0 = d.yi * TY;
-        c.z0 = d.zi * TZ;
+        c.z0 = (zfast ? d.xi : d.zi) * TZ;
         c.n = d.n;
         c.base0 = ((c.n * D + c.z0 - 1) * H + c.y0 - 1) * W + c.x0 - 1;
         c.base1 = VIRT ? ((c.n * D1 + (c.z0 >> 1)) * H1 + (c.y0 >> 1)) * W1 + (c.x0 >> 1) : 0;
@@ -2207,6 +2217,7 @@ static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, co
         // experiment knob, default off: a sweep of 8..64 k cycles changed no layer by more than noise (profiles/r01q) — a
         // wave that is alone on its SIMD does not run at twice the shared rate, so interleaving the epilogues buys nothing
         p.stagger = g_u3d_tune[5];
+        p.zfast = g_u3d_tune[14] == 1 ? 0 : 1;
         int ncu = 0;
         if (int e = device_cu_count(device, &ncu)) return e;
         long long slots = (g_u3d_tune[6] == 1 ? 1ll : 2ll) * ncu;  // two blocks per CU (LDS); key 6 = 1: one (experiment)

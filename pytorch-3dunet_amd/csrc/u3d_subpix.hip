@@ -22,6 +22,8 @@
 // u3d_conv3d_residual, whose epilogue applies ReLU and the GroupNorm statistics to the sum.
 #include "u3d_subpix.h"
 
+extern int g_u3d_tune[16];  // u3d_set_tuning (csrc/u3d_conv.hip); key 15 = 1: sub-pixel weight gradient without the constant-offset B loads
+
 
 struct SubpixParams {
     const float* low;     // (N, D1, H1, W1, C1)
@@ -508,6 +510,11 @@ struct SubpixWgradParams {
     int nchunks, nkb, S, tz, ty, tx, ntiles, tps;
 };
 
+// FULL (round 4): every tile lies inside the volume and K is a multiple of 32 — the address of a lane's dz element is then
+// (uniform tile / group offset, SALU) + (per-lane constant): ONE vector add per B load instead of the ~13 vector instructions of the
+// coordinate arithmetic and bounds tests (the kernel issued 2.4 vector instructions per MFMA, the plain weight gradient 1.9; fp32
+// MFMAs lose ~5 pipe cycles per vector instruction of any co-resident wave).
+template <bool FULL>
 __global__ __launch_bounds__(512, 2) void subpixel_wgrad_kernel(const SubpixWgradParams p) {
     using namespace spw;
     using sp::static_for;
@@ -587,7 +594,18 @@ __global__ __launch_bounds__(512, 2) void subpixel_wgrad_kernel(const SubpixWgra
     // ---- B operand: lane (i = dz channel, h = voxel of the pair) of group g reads dz[2(j) + p][kb*32 + i] of its own class
     const int kch = kb * 32 + i;
     const bool kok = kch < K;
+    // FULL: byte offset of this lane's element relative to the (tile, group) origin dz[n][2*z0 + 2*zl][2*y0 + 2*yl][2*x0 + 4*(g&3)][0]
+    const unsigned lane_off = 4u * ((unsigned)K * (unsigned)((pz * H + py) * W + 2 * h + px) + (unsigned)kch);
+    const __amdgpu_buffer_rsrc_t dz_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.dz), 0, FULL ? (int)((long long)p.N * 8 * D1 * H1 * W1 * K * 4) : 0, 0x00020000);  // (FULL: < 2^31 bytes, host check)
     auto b_load = [&](const Tile& c, int g) {
+        if constexpr (FULL) {
+            // buffer load: (resource = dz, scalar offset = the tile / group origin, vector offset = the lane constant) — no vector
+            // instruction at all for the address (a flat `base + lane_off` made the compiler form 64-bit addresses per lane)
+            const int zl = g >> 4, yl = (g >> 2) & 3;
+            const int vox = ((c.n * 2 * D1 + 2 * (c.z0 + zl)) * H + 2 * (c.y0 + yl)) * W + 2 * c.x0 + 4 * (g & 3);  // uniform
+            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dz_rsrc, (int)lane_off, vox * K * 4, 0));
+        }
         const int zl = g >> 4, yl = (g >> 2) & 3, xl = 2 * (g & 3) + h;
         const bool ok = kok & (c.z0 + zl < D1) & (c.y0 + yl < H1) & (c.x0 + xl < W1);
         const int vz = 2 * (c.z0 + zl) + pz, vy = 2 * (c.y0 + yl) + py, vx = 2 * (c.x0 + xl) + px;
@@ -947,8 +965,15 @@ extern "C" int u3d_subpixel_conv_wgrad(int device, u3d_stream_t stream, const fl
         return u3d_set_err(U3D_EWORKSPACE, "u3d_subpixel_conv_wgrad: workspace %lld < %lld floats", workspace_floats, need);
     p.low = low, p.affine = affine, p.aff_nstride = affine_sample_stride, p.dz = dz, p.partial = workspace;
     p.N = N, p.D1 = D1, p.H1 = H1, p.W1 = W1, p.C1 = C1, p.K = Cout;
-    hipLaunchKernelGGL(subpixel_wgrad_kernel, dim3((unsigned)(p.S * p.nchunks * p.nkb)), dim3(spw::NTHR), 0,
-                       (hipStream_t)stream, p);
+    // every tile inside the volume, whole 32-channel dz blocks: constant-offset B loads (key 15 = 1: the general kernel, for A/B)
+    const bool full = D1 % spw::TZ == 0 && H1 % spw::TY == 0 && W1 % spw::TX == 0 && Cout % 32 == 0 && g_u3d_tune[15] != 1 &&
+                      (long long)N * 8 * D1 * H1 * W1 * Cout * 4 < (1ll << 31);
+    if (full)
+        hipLaunchKernelGGL(subpixel_wgrad_kernel<true>, dim3((unsigned)(p.S * p.nchunks * p.nkb)), dim3(spw::NTHR), 0,
+                           (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(subpixel_wgrad_kernel<false>, dim3((unsigned)(p.S * p.nchunks * p.nkb)), dim3(spw::NTHR), 0,
+                           (hipStream_t)stream, p);
     U3D_LAUNCH_CHECK();
     const long long total = (long long)C1 * 27 * Cout;
     hipLaunchKernelGGL(subpixel_wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
