@@ -1160,6 +1160,300 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wg
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4: the bf16-STORAGE 3x3x3 weight gradient, second form (same tile, LDS layout, splits, workspace layout and — operand for
+// operand, in the same order — the same MFMA sequence per accumulator as the kernel above: results are bit-identical).  What round
+// 3's counters said about the first form: 5.4 vector instructions per MFMA in the tile loop and an LDS pipe busier than the matrix
+// pipe (8 waves x 128 fragments x 8 cycles = 8192 cycles per tile against 7168 of MFMA).  Changes:
+//   * a wave owns taps {w, w + 8, w + 16, w + 24} and BOTH output-channel halves: a g fragment feeds two MFMAs, 43 fragment reads
+//     per row and block instead of 64 (LDS pipe 8192 -> 5504 cycles per tile);
+//   * staging without coordinate arithmetic: item k of a thread is (halo voxel (t >> 2) + 128 k, channel octet t & 3) — its offset
+//     inside the tile's halo box is ONE register computed before the loop, its LDS address t * 16 + 8192 k an immediate, the tile
+//     origin the scalar offset of a buffer load.  Border / ragged tiles derive a validity bit per item from the packed halo
+//     coordinates and send invalid lanes out of the buffer's range (they read zero); interior tiles skip even that;
+//   * loads in three batches (4 + 3 + 3 items) that are written one part LATER than they were issued (>= 2 parts in flight);
+//   * the tile index is advanced digit-wise (scalar), not decoded by divisions.
+#ifndef U3D_WG_ABLATE
+#define U3D_WG_ABLATE 0  // timing experiments (tools/ab_libs.sh; WRONG results): 1 no global loads, 2 no LDS stores, 4 no g fragment
+#endif                   // reads in the loop, 8 no dz fragment reads, 16 no per-tile barrier
+__global__ __launch_bounds__(512, 2) void conv3d_wgrad_b16v2_kernel(const bf16_wgrad_params p) {
+    using G = wg_geom<3>;
+    constexpr int HY = G::HY, HX = G::HX, GB = G::G_BYTES, LDSB = G::LDS;
+    static_assert(G::G_ITEMS8 == 2880 && GB == 46080, "halo 4 x 10 x 18 voxels of 32 channels");
+    extern __shared__ __attribute__((aligned(256))) char lds[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int P = (p.C >> 5) * p.pco;
+    const int bid = p.xcd ? u3d_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int pair = bid % P, split = bid / P;
+    const int cib = pair / p.pco, cob = pair % p.pco;
+    const int c0 = cib * 32, k0 = cob * 64;
+    const int D = p.D, H = p.H, W = p.W;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((long long)p.N * D * H * W * p.C * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dz), 0, (int)((long long)p.N * D * H * W * p.K * 2), 0x00020000);
+    constexpr int NG = 6, ND = 4;  // g / dz items per thread and tile
+    // ---- per-thread staging constants
+    int relg[NG];       // byte offset of g item k relative to the halo origin
+    unsigned gpos[NG / 2] = {0, 0, 0};  // 16 bits per item: hz | hy << 4 | hx << 8 of its halo voxel (hz >= 4: dead tail item)
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        const int hv = (t >> 2) + 128 * k;
+        const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+        relg[k] = (((hz * H + hy) * W + hx) * p.C + c0 + 8 * (t & 3)) * 2;
+        gpos[k >> 1] |= ((unsigned)hz | ((unsigned)hy << 4) | ((unsigned)hx << 8)) << (16 * (k & 1));
+    }
+    // dz item k: voxel (t >> 3) + 64 k = (z k >> 1, y 4 (k & 1) + (t >> 7), x (t >> 3) & 15), channel octet t & 7
+    const int dyl = t >> 7, dxl = (t >> 3) & 15;
+    const int reld = ((dyl * W + dxl) * p.K + k0 + 8 * (t & 7)) * 2;
+    const int ldsg = t * 16;
+    const int ldsd = GB + ((t & 7) >> 2) * WG_DZ_HALF + (t >> 3) * 64 + (t & 3) * 16;
+    const bool has_aff = p.affine != nullptr;
+    struct aff_t {
+        f32x4 a0, b0, a1, b1;
+    };
+    auto load_aff = [&](int n_, aff_t& g) {
+        u3d_load_affine(p.affine, n_, p.C, c0 + 8 * (t & 3), true, g.a0, g.b0);
+        u3d_load_affine(p.affine, n_, p.C, c0 + 8 * (t & 3) + 4, true, g.a1, g.b1);
+    };
+    struct tile_t {
+        int n, zi, yi, xi;
+    };
+    struct tinfo {       // everything a tile's staging needs (uniform except gmask)
+        int baseg, based;  // byte offsets of the halo origin in x / of the tile origin in dz
+        bool interior;     // whole halo box inside the volume
+        unsigned gmask;    // bit k: g item k of THIS thread is inside the volume
+        int zrem, yrem, xrem;  // D - z0, H - y0, W - x0 (dz validity on ragged tiles)
+    };
+    auto info_of = [&](const tile_t& c) {
+        tinfo r;
+        const int z0 = c.zi * WG_TZ, y0 = c.yi * WG_TY, x0 = c.xi * WG_TX;
+        r.baseg = ((((c.n * D + z0 - 1) * H + y0 - 1) * W + x0 - 1) * p.C) * 2;
+        r.based = ((((c.n * D + z0) * H + y0) * W + x0) * p.K) * 2;
+        r.interior = z0 >= 1 && z0 + WG_TZ + 1 <= D && y0 >= 1 && y0 + WG_TY + 1 <= H && x0 >= 1 && x0 + WG_TX + 1 <= W;
+        r.zrem = D - z0;
+        r.yrem = H - y0;
+        r.xrem = W - x0;
+        r.gmask = 0x3fu;
+        if (!r.interior) {
+            // halo coordinate h is inside iff lo <= h < hi with lo = max(0, 1 - origin), hi = min(extent, size + 1 - origin)
+            const unsigned zlo = z0 == 0 ? 1u : 0u, zn = (unsigned)min(G::HZ, D + 1 - z0) - zlo;
+            const unsigned ylo = y0 == 0 ? 1u : 0u, yn = (unsigned)min(HY, H + 1 - y0) - ylo;
+            const unsigned xlo = x0 == 0 ? 1u : 0u, xn = (unsigned)min(HX, W + 1 - x0) - xlo;
+            r.gmask = 0;
+#pragma unroll
+            for (int k = 0; k < NG; ++k) {
+                const unsigned gp = gpos[k >> 1] >> (16 * (k & 1));
+                const unsigned hz = gp & 0xfu, hy = (gp >> 4) & 0xfu, hx = (gp >> 8) & 0xffu;
+                const bool ok = hz - zlo < zn && hy - ylo < yn && hx - xlo < xn;
+                r.gmask |= (ok ? 1u : 0u) << k;
+            }
+        }
+        return r;
+    };
+    auto advance = [&](tile_t& c) {
+        if (++c.xi == p.tx) {
+            c.xi = 0;
+            if (++c.yi == p.ty) {
+                c.yi = 0;
+                if (++c.zi == p.tz) {
+                    c.zi = 0;
+                    ++c.n;
+                }
+            }
+        }
+    };
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    // item slot j of a tile: j < 6: g item j, else dz item j - 6
+    auto load_slot = [&](const tinfo& ti, int j) -> bf16x8 {
+        if constexpr ((U3D_WG_ABLATE & 1) != 0) return bf16x8{};
+        if (j < NG) {
+            if (ti.interior)
+                return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rx, relg[j], ti.baseg, 0));
+            const int off = ((ti.gmask >> j) & 1u) ? relg[j] + ti.baseg : -1;  // -1: beyond the range, reads zero
+            return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+        }
+        const int k = j - NG;
+        const int sk = (((k >> 1) * H + 4 * (k & 1)) * W * p.K) * 2;
+        if (ti.interior) return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rdz, reld, ti.based + sk, 0));
+        const bool ok = (k >> 1) < ti.zrem && 4 * (k & 1) + dyl < ti.yrem && dxl < ti.xrem;
+        const int off = ok ? reld + ti.based + sk : -1;
+        return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rdz, off, 0, 0));
+    };
+    auto store_slot = [&](char* buf, const tinfo& ti, int j, const bf16x8& v, const aff_t& g) {
+        if constexpr ((U3D_WG_ABLATE & 2) != 0) return;
+        if (j < NG) {
+            if (j == NG - 1 && w >= 5) return;  // items 2880 .. 3071 do not exist (uniform per wave)
+            const bool ok = ti.interior || ((ti.gmask >> j) & 1u);
+            *reinterpret_cast<bf16x8*>(buf + ldsg + 8192 * j) = u3d_stage_b16(v, has_aff, ok, g.a0, g.b0, g.a1, g.b1);
+        } else {
+            *reinterpret_cast<bf16x8*>(buf + ldsd + 4096 * (j - NG)) = v;
+        }
+    };
+
+    const int first = split * p.per_block, last = min(p.tiles, first + p.per_block);
+    tile_t cur_t;
+    {
+        int tt = first;
+        cur_t.xi = tt % p.tx;
+        tt /= p.tx;
+        cur_t.yi = tt % p.ty;
+        tt /= p.ty;
+        cur_t.zi = tt % p.tz;
+        cur_t.n = tt / p.tz;
+    }
+    aff_t gaff;
+    int aff_n = -1;
+    if (first < last) {  // prologue: the first tile into buffer 0
+        const tinfo ti = info_of(cur_t);
+        load_aff(cur_t.n, gaff);
+        aff_n = cur_t.n;
+#pragma unroll 1
+        for (int j0 = 0; j0 < NG + ND; j0 += 5) {
+            bf16x8 v[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) v[i] = load_slot(ti, j0 + i);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) store_slot(lds, ti, j0 + i, v[i], gaff);
+        }
+    }
+
+    constexpr int NTW = 4;
+    f32x16 acc[NTW][2];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][hh][e] = 0.f;
+
+    const int g4 = lane >> 4, sidx = lane & 15;
+    const int lane_off = (8 * (g4 >> 1) + (sidx >> 2)) * 64 + (16 * (g4 & 1) + 4 * (sidx & 3)) * 2;
+    int a_off[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int tap = min(w + 8 * i, 26);
+        const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
+        a_off[i] = lane_off + ((tz * HY + ty) * HX + tx) * 64;
+    }
+    const int b_off = GB + lane_off;
+    const bool four = w < 3;  // this wave's fourth tap exists (w + 24 < 27)
+
+#ifdef U3D_WG_TRACE  // timeline build (tools/wgrad_timeline.py): s_memtime stamps of tiles 4 .. 15 of every wave of block 0 -> ws
+    unsigned* trace = reinterpret_cast<unsigned*>(lds + 2 * LDSB);
+#define WG_STAMP(k)                                                                             \
+    do {                                                                                        \
+        const int tr_ = tile - first - 4;                                                       \
+        if (tr_ >= 0 && tr_ < 12) {                                                             \
+            const unsigned c_ = (unsigned)__builtin_amdgcn_s_memtime();                         \
+            if (lane == 0) trace[(w * 12 + tr_) * 14 + (k)] = c_;                               \
+        }                                                                                       \
+    } while (0)
+#else
+#define WG_STAMP(k)
+#endif
+    for (int tile = first; tile < last; ++tile) {
+        WG_STAMP(0);
+        if constexpr ((U3D_WG_ABLATE & 16) == 0) __syncthreads();  // buffer (tile - first) & 1 is complete; everyone is done reading the other one
+        WG_STAMP(1);
+        const char* cur = lds + ((tile - first) & 1) * LDSB;
+        char* nxt = lds + ((tile - first + 1) & 1) * LDSB;
+        const bool more = tile + 1 < last;
+        tile_t tn = cur_t;
+        if (more) advance(tn);
+        const tinfo ti = info_of(tn);
+        if (more && tn.n != aff_n) {
+            load_aff(tn.n, gaff);
+            aff_n = tn.n;
+        }
+        constexpr int NS = 16 * NTW, AD = 2;
+        auto a_addr = [&](int s_) {
+            const int rw = s_ / NTW, i = s_ - rw * NTW;
+            return a_off[i] + ((rw / WG_TY) * HY + (rw % WG_TY)) * HX * 64;
+        };
+        auto b_addr = [&](int rw, int hh) { return b_off + hh * WG_DZ_HALF + rw * WG_TX * 64; };
+        bf16x8 af[AD + 1], bfr[2][2];
+#pragma unroll
+        for (int s_ = 0; s_ < AD; ++s_) af[s_] = tr_frag(cur + a_addr(s_));
+        bfr[0][0] = tr_frag(cur + b_addr(0, 0));
+        bfr[0][1] = tr_frag(cur + b_addr(0, 1));
+        bf16x8 b0[4], b1[3], b2[3];  // batches: slots 0-3 | 4-6 | 7-9
+#pragma unroll
+        for (int part = 0; part < 4; ++part) {
+            if (more) {
+                if (part == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) b0[i] = load_slot(ti, i);
+                } else if (part == 1) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) b1[i] = load_slot(ti, 4 + i);
+                } else if (part == 2) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) b2[i] = load_slot(ti, 7 + i);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            WG_STAMP(2 + 3 * part);
+#pragma unroll
+            for (int q4 = 0; q4 < 4 * NTW; ++q4) {
+                const int s_ = part * 4 * NTW + q4, rw = s_ / NTW, i = s_ - rw * NTW;
+                if (s_ + AD < NS) {
+                    const int i2 = (s_ + AD) % NTW;
+                    if (((U3D_WG_ABLATE & 4) == 0) && (i2 < 3 || four)) af[(s_ + AD) % (AD + 1)] = tr_frag(cur + a_addr(s_ + AD));
+                }
+                if (((U3D_WG_ABLATE & 8) == 0) && i == 0 && rw + 1 < 16) {
+                    bfr[(rw + 1) & 1][0] = tr_frag(cur + b_addr(rw + 1, 0));
+                    bfr[(rw + 1) & 1][1] = tr_frag(cur + b_addr(rw + 1, 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (i < 3 || four) {
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s_ % (AD + 1)], bfr[rw & 1][0], acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s_ % (AD + 1)], bfr[rw & 1][1], acc[i][1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            WG_STAMP(3 + 3 * part);
+            if (more) {
+                if (part == 1) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) store_slot(nxt, ti, i, b0[i], gaff);
+                } else if (part == 2) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) store_slot(nxt, ti, 4 + i, b1[i], gaff);
+                } else if (part == 3) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) store_slot(nxt, ti, 7 + i, b2[i], gaff);
+                }
+            }
+            WG_STAMP(4 + 3 * part);
+        }
+        cur_t = tn;
+    }
+#ifdef U3D_WG_TRACE
+    if (bid == 0) {
+        __syncthreads();
+        for (int i = t; i < 8 * 12 * 14; i += 512) reinterpret_cast<unsigned*>(p.ws)[i] = trace[i];
+        return;
+    }
+#endif
+    // ---- partial sums: ws[split][pair][tap][ci 32][co 64]; D layout: column = lane & 31 (co), row = ci
+    float* dst = p.ws + ((size_t)split * P + pair) * 27 * 2048;
+    const int col = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int tap = w + 8 * i;
+        if (tap < 27) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ci = (e & 3) + 8 * (e >> 2) + 4 * half;
+                    dst[(size_t)tap * 2048 + ci * 64 + hh * 32 + col] = acc[i][hh][e];
+                }
+        }
+    }
+}
+
 // dw[co][ci][tap] = sum over splits, fixed order.  One block per (pair, input channel): the 27 x 64 partial sums of that row are
 // read coalesced over the output channel (256-byte runs), transposed through LDS, and written as 64 runs of 27 consecutive
 // floats (the reference layout has the tap innermost) — a thread-per-element version writes 4 bytes every 27*Cin floats and
@@ -1264,7 +1558,16 @@ static int conv3d_wgrad_bf16_impl(int device, u3d_stream_t stream, const float* 
         return u3d_set_err(U3D_EWORKSPACE, "u3d_conv3d_wgrad_bf16: workspace of %lld floats needed, %lld given", need, workspace_floats);
     bf16_wgrad_params p{x, affine, dz, workspace, N, D, H, W, C, K, 1, q.tz, q.ty, q.tx, q.tiles, q.per_block, K / 64,
                         g_u3d_tune[9] == 1 ? 0 : 1};
-    if (b16) {
+    const long long vox = (long long)N * D * H * W;
+    if (b16 && g_u3d_tune[7] != 1 && vox * (C > K ? C : K) * 2 < (1ll << 31)) {  // (buffer offsets are 32-bit)
+#ifdef U3D_WG_TRACE
+        constexpr int v2_lds = 2 * wg_geom<3>::LDS + 8 * 12 * 14 * 4;
+#else
+        constexpr int v2_lds = 2 * wg_geom<3>::LDS;
+#endif
+        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_b16v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, v2_lds));
+        hipLaunchKernelGGL(conv3d_wgrad_b16v2_kernel, dim3((unsigned)(q.S * q.P)), dim3(512), v2_lds, (hipStream_t)stream, p);
+    } else if (b16) {
         U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_bf16_kernel<3, __bf16>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * wg_geom<3>::LDS));
         hipLaunchKernelGGL((conv3d_wgrad_bf16_kernel<3, __bf16>), dim3((unsigned)(q.S * q.P)), dim3(512), 2 * wg_geom<3>::LDS,

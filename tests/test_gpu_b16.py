@@ -97,22 +97,36 @@ def test_conv3d_bf16_b16_forward_and_data_gradient(shape, C, K, res, ks):
     assert torch.allclose(g16, want, rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize("shape,C,K", [((1, 8, 16, 16), 64, 64), ((2, 5, 9, 19), 32, 128)])
-def test_conv3d_wgrad_bf16_b16(shape, C, K):
+@pytest.mark.parametrize("with_affine", [True, False])
+@pytest.mark.parametrize("shape,C,K,blocks", [((1, 8, 16, 16), 64, 64, 0), ((2, 5, 9, 19), 32, 128, 0),
+                                              ((1, 6, 24, 50), 32, 64, 0),    # interior, border and ragged tiles, one per block
+                                              ((2, 6, 24, 50), 32, 64, 5),    # ... walked by 5 blocks: tile loop across samples
+                                              ((1, 7, 26, 66), 64, 128, 12)])
+def test_conv3d_wgrad_bf16_b16(shape, C, K, blocks, with_affine):
+    """bf16 storage: the round-4 kernel (constant-offset staging, two output halves per wave) and the round-3 kernel (key 7 = 1)
+    both reproduce the fp32-storage kernel fed with bf16-representable values bit for bit (same operands, same MFMA order)."""
     N, D, H, W = shape
     torch.manual_seed(2)
     x = dev(r16(torch.randn(N, D, H, W, C)))
     dz = dev(r16(torch.randn(N, D, H, W, K)))
-    aff = dev(torch.stack((1.0 + 0.3 * torch.randn(N, C), 0.2 * torch.randn(N, C)), dim=-1))
+    aff = dev(torch.stack((1.0 + 0.3 * torch.randn(N, C), 0.2 * torch.randn(N, C)), dim=-1)) if with_affine else None
     L = nat.get_lib()
-    need = L.u3d_wgrad_bf16_workspace_floats(N, D, H, W, C, K)
-    ws = torch.empty(need, dtype=torch.float32, device=U.DEV)
-    a = torch.full((K, C, 3, 3, 3), float("nan"), device=U.DEV)
-    b = torch.full((K, C, 3, 3, 3), float("nan"), device=U.DEV)
-    call("u3d_conv3d_wgrad_bf16", _p(x), _p(aff), _p(dz), _p(a), N, D, H, W, C, K, _p(ws), need)
-    call("u3d_conv3d_wgrad_bf16_b16", _p(b16(x)), _p(aff), _p(b16(dz)), _p(b), N, D, H, W, C, K, _p(ws), need)
-    torch.cuda.synchronize()
-    assert torch.equal(a, b) and torch.isfinite(a).all()
+    nat.call("u3d_set_tuning", 8, blocks)
+    try:
+        need = L.u3d_wgrad_bf16_workspace_floats(N, D, H, W, C, K)
+        ws = torch.empty(need, dtype=torch.float32, device=U.DEV)
+        a, b, c = (torch.full((K, C, 3, 3, 3), float("nan"), device=U.DEV) for _ in range(3))
+        call("u3d_conv3d_wgrad_bf16", _p(x), _p(aff), _p(dz), _p(a), N, D, H, W, C, K, _p(ws), need)
+        call("u3d_conv3d_wgrad_bf16_b16", _p(b16(x)), _p(aff), _p(b16(dz)), _p(b), N, D, H, W, C, K, _p(ws), need)
+        nat.call("u3d_set_tuning", 7, 1)
+        call("u3d_conv3d_wgrad_bf16_b16", _p(b16(x)), _p(aff), _p(b16(dz)), _p(c), N, D, H, W, C, K, _p(ws), need)
+        torch.cuda.synchronize()
+    finally:
+        nat.call("u3d_set_tuning", 7, 0)
+        nat.call("u3d_set_tuning", 8, 0)
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, c)
+    assert torch.equal(a, b)
 
 
 def test_transposed_convolution_t8_b16():
