@@ -1208,44 +1208,40 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_b16v2_kernel(const bf16_w
     const int ldsg = t * 16;
     const int ldsd = GB + ((t & 7) >> 2) * WG_DZ_HALF + (t >> 3) * 64 + (t & 3) * 16;
     const bool has_aff = p.affine != nullptr;
-    struct aff_t {
-        f32x4 a0, b0, a1, b1;
-    };
-    auto load_aff = [&](int n_, aff_t& g) {
-        u3d_load_affine(p.affine, n_, p.C, c0 + 8 * (t & 3), true, g.a0, g.b0);
-        u3d_load_affine(p.affine, n_, p.C, c0 + 8 * (t & 3) + 4, true, g.a1, g.b1);
-    };
     struct tile_t {
         int n, zi, yi, xi;
     };
-    struct tinfo {       // everything a tile's staging needs (uniform except gmask)
-        int baseg, based;  // byte offsets of the halo origin in x / of the tile origin in dz
-        bool interior;     // whole halo box inside the volume
-        unsigned gmask;    // bit k: g item k of THIS thread is inside the volume
-        int zrem, yrem, xrem;  // D - z0, H - y0, W - x0 (dz validity on ragged tiles)
+    struct tinfo {         // everything a tile's staging needs
+        int baseg, based;  // byte offsets of the halo origin in x / of the tile origin in dz (uniform)
+        unsigned mask;     // bits 0..5: g item k of THIS thread is inside the volume; bits 8..11: dz item k is
     };
-    auto info_of = [&](const tile_t& c) {
+    auto info_of = [&](const tile_t& c, bool exists) {
         tinfo r;
         const int z0 = c.zi * WG_TZ, y0 = c.yi * WG_TY, x0 = c.xi * WG_TX;
         r.baseg = ((((c.n * D + z0 - 1) * H + y0 - 1) * W + x0 - 1) * p.C) * 2;
         r.based = ((((c.n * D + z0) * H + y0) * W + x0) * p.K) * 2;
-        r.interior = z0 >= 1 && z0 + WG_TZ + 1 <= D && y0 >= 1 && y0 + WG_TY + 1 <= H && x0 >= 1 && x0 + WG_TX + 1 <= W;
-        r.zrem = D - z0;
-        r.yrem = H - y0;
-        r.xrem = W - x0;
-        r.gmask = 0x3fu;
-        if (!r.interior) {
+        const bool interior = z0 >= 1 && z0 + WG_TZ + 1 <= D && y0 >= 1 && y0 + WG_TY + 1 <= H && x0 >= 1 && x0 + WG_TX + 1 <= W;
+        if (!exists) {
+            r.mask = 0;  // past the block's last tile: every lane reads beyond the buffers' range (zeros, no traffic)
+        } else if (interior) {
+            r.mask = w < 5 ? 0xf3fu : 0xf1fu;  // (g items 2880 .. 3071 do not exist: item 5 of waves 5 - 7)
+        } else {
             // halo coordinate h is inside iff lo <= h < hi with lo = max(0, 1 - origin), hi = min(extent, size + 1 - origin)
             const unsigned zlo = z0 == 0 ? 1u : 0u, zn = (unsigned)min(G::HZ, D + 1 - z0) - zlo;
             const unsigned ylo = y0 == 0 ? 1u : 0u, yn = (unsigned)min(HY, H + 1 - y0) - ylo;
             const unsigned xlo = x0 == 0 ? 1u : 0u, xn = (unsigned)min(HX, W + 1 - x0) - xlo;
-            r.gmask = 0;
+            r.mask = 0;
 #pragma unroll
             for (int k = 0; k < NG; ++k) {
                 const unsigned gp = gpos[k >> 1] >> (16 * (k & 1));
                 const unsigned hz = gp & 0xfu, hy = (gp >> 4) & 0xfu, hx = (gp >> 8) & 0xffu;
                 const bool ok = hz - zlo < zn && hy - ylo < yn && hx - xlo < xn;
-                r.gmask |= (ok ? 1u : 0u) << k;
+                r.mask |= (ok ? 1u : 0u) << k;
+            }
+#pragma unroll
+            for (int k = 0; k < ND; ++k) {
+                const bool ok = (k >> 1) < D - z0 && 4 * (k & 1) + dyl < H - y0 && dxl < W - x0;
+                r.mask |= (ok ? 1u : 0u) << (8 + k);
             }
         }
         return r;
@@ -1262,51 +1258,59 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_b16v2_kernel(const bf16_w
             }
         }
     };
-    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-    // item slot j of a tile: j < 6: g item j, else dz item j - 6
+    // item slot j of a tile: j < 6: g item j, else dz item j - 6.  Invalid lanes read at offset -1: beyond the range, zero.
     auto load_slot = [&](const tinfo& ti, int j) -> bf16x8 {
         if constexpr ((U3D_WG_ABLATE & 1) != 0) return bf16x8{};
         if (j < NG) {
-            if (ti.interior)
-                return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rx, relg[j], ti.baseg, 0));
-            const int off = ((ti.gmask >> j) & 1u) ? relg[j] + ti.baseg : -1;  // -1: beyond the range, reads zero
+            const int off = ((ti.mask >> j) & 1u) ? relg[j] + ti.baseg : -1;
             return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
         }
         const int k = j - NG;
-        const int sk = (((k >> 1) * H + 4 * (k & 1)) * W * p.K) * 2;
-        if (ti.interior) return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rdz, reld, ti.based + sk, 0));
-        const bool ok = (k >> 1) < ti.zrem && 4 * (k & 1) + dyl < ti.yrem && dxl < ti.xrem;
-        const int off = ok ? reld + ti.based + sk : -1;
+        const int sk = ti.based + (((k >> 1) * H + 4 * (k & 1)) * W * p.K) * 2;  // uniform
+        const int off = ((ti.mask >> (8 + k)) & 1u) ? reld + sk : -1;
         return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rdz, off, 0, 0));
+    };
+    struct aff_t {
+        f32x4 a0, b0, a1, b1;
     };
     auto store_slot = [&](char* buf, const tinfo& ti, int j, const bf16x8& v, const aff_t& g) {
         if constexpr ((U3D_WG_ABLATE & 2) != 0) return;
         if (j < NG) {
-            if (j == NG - 1 && w >= 5) return;  // items 2880 .. 3071 do not exist (uniform per wave)
-            const bool ok = ti.interior || ((ti.gmask >> j) & 1u);
-            *reinterpret_cast<bf16x8*>(buf + ldsg + 8192 * j) = u3d_stage_b16(v, has_aff, ok, g.a0, g.b0, g.a1, g.b1);
+            if (j == NG - 1 && w >= 5) return;  // (uniform per wave; the slot would land in the dz tile)
+            *reinterpret_cast<bf16x8*>(buf + ldsg + 8192 * j) = u3d_stage_b16(v, has_aff, ((ti.mask >> j) & 1u) != 0, g.a0, g.b0, g.a1, g.b1);
         } else {
             *reinterpret_cast<bf16x8*>(buf + ldsd + 4096 * (j - NG)) = v;
         }
     };
+    auto load_aff = [&](int n_, aff_t& g) {
+        u3d_load_affine(p.affine, n_, p.C, c0 + 8 * (t & 3), true, g.a0, g.b0);
+        u3d_load_affine(p.affine, n_, p.C, c0 + 8 * (t & 3) + 4, true, g.a1, g.b1);
+    };
 
     const int first = split * p.per_block, last = min(p.tiles, first + p.per_block);
-    tile_t cur_t;
+    tile_t t1;  // the tile AFTER the one being computed (first + 1 at loop entry)
     {
         int tt = first;
-        cur_t.xi = tt % p.tx;
+        t1.xi = tt % p.tx;
         tt /= p.tx;
-        cur_t.yi = tt % p.ty;
+        t1.yi = tt % p.ty;
         tt /= p.ty;
-        cur_t.zi = tt % p.tz;
-        cur_t.n = tt / p.tz;
+        t1.zi = tt % p.tz;
+        t1.n = tt / p.tz;
     }
     aff_t gaff;
     int aff_n = -1;
-    if (first < last) {  // prologue: the first tile into buffer 0
-        const tinfo ti = info_of(cur_t);
-        load_aff(cur_t.n, gaff);
-        aff_n = cur_t.n;
+    // Staging schedule (steps of the 64-step tile loop; every item waits 36 steps = ~half a tile between its load and its LDS write;
+    // one load and one store every six steps instead of batches — a batch of four 1 KiB loads issued by all eight waves at the same
+    // step blocked each of them for 400-1300 cycles, profiles/r04_wgrad_b16v2_ablation.txt):
+    //   items 0-4 of tile i+2: loaded at steps 34, 40, .., 58 of iteration i, written at steps 6, 12, .., 30 of iteration i+1
+    //   items 5-9 of tile i+1: loaded at steps  2,  8, .., 26 of iteration i, written at steps 38, 44, .., 62 of iteration i
+    bf16x8 ra[5], rb[5];
+    tinfo i1;  // of tile i + 1 (whose items are written during iteration i)
+    if (first < last) {  // prologue: the first tile into buffer 0, items 0-4 of the second into registers
+        const tinfo ti = info_of(t1, true);
+        load_aff(t1.n, gaff);
+        aff_n = t1.n;
 #pragma unroll 1
         for (int j0 = 0; j0 < NG + ND; j0 += 5) {
             bf16x8 v[5];
@@ -1315,6 +1319,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_b16v2_kernel(const bf16_w
 #pragma unroll
             for (int i = 0; i < 5; ++i) store_slot(lds, ti, j0 + i, v[i], gaff);
         }
+        advance(t1);
+        i1 = info_of(t1, first + 1 < last);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) ra[i] = load_slot(i1, i);
     }
 
     constexpr int NTW = 4;
@@ -1338,7 +1346,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_b16v2_kernel(const bf16_w
     const int b_off = GB + lane_off;
     const bool four = w < 3;  // this wave's fourth tap exists (w + 24 < 27)
 
-#ifdef U3D_WG_TRACE  // timeline build (tools/wgrad_timeline.py): s_memtime stamps of tiles 4 .. 15 of every wave of block 0 -> ws
+#ifdef U3D_WG_TRACE  // timeline build (tools/wgrad_timeline.py): s_memtime stamps of tiles 4 .. 15 of every wave of the middle block -> its ws region
     unsigned* trace = reinterpret_cast<unsigned*>(lds + 2 * LDSB);
 #define WG_STAMP(k)                                                                             \
     do {                                                                                        \
@@ -1357,14 +1365,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_b16v2_kernel(const bf16_w
         WG_STAMP(1);
         const char* cur = lds + ((tile - first) & 1) * LDSB;
         char* nxt = lds + ((tile - first + 1) & 1) * LDSB;
-        const bool more = tile + 1 < last;
-        tile_t tn = cur_t;
-        if (more) advance(tn);
-        const tinfo ti = info_of(tn);
-        if (more && tn.n != aff_n) {
-            load_aff(tn.n, gaff);
-            aff_n = tn.n;
+        if (tile + 1 < last && t1.n != aff_n) {  // (every LDS write of this iteration belongs to tile + 1)
+            load_aff(t1.n, gaff);
+            aff_n = t1.n;
         }
+        tile_t t2 = t1;
+        tinfo i2;
         constexpr int NS = 16 * NTW, AD = 2;
         auto a_addr = [&](int s_) {
             const int rw = s_ / NTW, i = s_ - rw * NTW;
@@ -1376,33 +1382,36 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_b16v2_kernel(const bf16_w
         for (int s_ = 0; s_ < AD; ++s_) af[s_] = tr_frag(cur + a_addr(s_));
         bfr[0][0] = tr_frag(cur + b_addr(0, 0));
         bfr[0][1] = tr_frag(cur + b_addr(0, 1));
-        bf16x8 b0[4], b1[3], b2[3];  // batches: slots 0-3 | 4-6 | 7-9
 #pragma unroll
         for (int part = 0; part < 4; ++part) {
-            if (more) {
-                if (part == 0) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) b0[i] = load_slot(ti, i);
-                } else if (part == 1) {
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) b1[i] = load_slot(ti, 4 + i);
-                } else if (part == 2) {
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) b2[i] = load_slot(ti, 7 + i);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
             WG_STAMP(2 + 3 * part);
 #pragma unroll
             for (int q4 = 0; q4 < 4 * NTW; ++q4) {
                 const int s_ = part * 4 * NTW + q4, rw = s_ / NTW, i = s_ - rw * NTW;
                 if (s_ + AD < NS) {
-                    const int i2 = (s_ + AD) % NTW;
-                    if (((U3D_WG_ABLATE & 4) == 0) && (i2 < 3 || four)) af[(s_ + AD) % (AD + 1)] = tr_frag(cur + a_addr(s_ + AD));
+                    const int i2_ = (s_ + AD) % NTW;
+                    if (((U3D_WG_ABLATE & 4) == 0) && (i2_ < 3 || four)) af[(s_ + AD) % (AD + 1)] = tr_frag(cur + a_addr(s_ + AD));
                 }
                 if (((U3D_WG_ABLATE & 8) == 0) && i == 0 && rw + 1 < 16) {
                     bfr[(rw + 1) & 1][0] = tr_frag(cur + b_addr(rw + 1, 0));
                     bfr[(rw + 1) & 1][1] = tr_frag(cur + b_addr(rw + 1, 1));
+                }
+                // (A progress-fair s_setprio between the two waves of a SIMD — each wave publishing its row count in LDS and raising its
+                // priority while it was behind — did balance them (barrier waits 2000 -> 300 cycles) and made the kernel 8 % SLOWER:
+                // profiles/r04_wgrad_b16v2_ablation.txt.  The older wave wins the pipe by default, its partner finishes the tile alone.)
+                // ---- the tile after next: coordinates and validity masks, computed under this tile's MFMAs (right after the barrier they
+                // were ~900 exposed cycles per border tile)
+                if (s_ == 30) {
+                    advance(t2);
+                    i2 = info_of(t2, tile + 2 < last);
+                }
+                // ---- one staging operation every third step (see the schedule above)
+                if (s_ < 32) {
+                    if (s_ % 6 == 2) rb[s_ / 6] = load_slot(i1, 5 + s_ / 6);
+                    if (s_ % 6 == 0 && s_ > 0) store_slot(nxt, i1, s_ / 6 - 1, ra[s_ / 6 - 1], gaff);
+                } else {
+                    if ((s_ - 32) % 6 == 2) ra[(s_ - 32) / 6] = load_slot(i2, (s_ - 32) / 6);
+                    if ((s_ - 32) % 6 == 0 && s_ > 32) store_slot(nxt, i1, 5 + (s_ - 32) / 6 - 1, rb[(s_ - 32) / 6 - 1], gaff);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (i < 3 || four) {
@@ -1411,28 +1420,17 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_b16v2_kernel(const bf16_w
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
             WG_STAMP(3 + 3 * part);
-            if (more) {
-                if (part == 1) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) store_slot(nxt, ti, i, b0[i], gaff);
-                } else if (part == 2) {
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) store_slot(nxt, ti, 4 + i, b1[i], gaff);
-                } else if (part == 3) {
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) store_slot(nxt, ti, 7 + i, b2[i], gaff);
-                }
-            }
             WG_STAMP(4 + 3 * part);
         }
-        cur_t = tn;
+        t1 = t2;
+        i1 = i2;
     }
 #ifdef U3D_WG_TRACE
-    if (bid == 0) {
+    if (bid == (int)gridDim.x / 2) {
         __syncthreads();
-        for (int i = t; i < 8 * 12 * 14; i += 512) reinterpret_cast<unsigned*>(p.ws)[i] = trace[i];
+        unsigned* out = reinterpret_cast<unsigned*>(p.ws + ((size_t)split * P + pair) * 27 * 2048);  // (this block's own region)
+        for (int i = t; i < 8 * 12 * 14; i += 512) out[i] = trace[i];
         return;
     }
 #endif

@@ -3,8 +3,8 @@
     bash tools/ab_libs.sh u3d_bf16.hip trace "-DU3D_WG_TRACE"          # + any -DU3D_WG_ABLATE=.. to combine
     U3D_LIB_PATH=$PWD/pytorch-3dunet_amd/pytorch3dunet_amd/lib/libu3d_hip_trace.so python tools/wgrad_timeline.py [--level 0]
 
-The trace build stamps s_memtime (core clock) at 14 points of tiles 4 .. 15 of every wave of block 0 and dumps them into the
-workspace instead of that block's partial sums (results are wrong; timing only).  Stamps: 0 loop top, 1 after the barrier, then
+The trace build stamps s_memtime (core clock) at 14 points of tiles 4 .. 15 of every wave of the middle block and dumps them into
+that block's workspace region instead of its partial sums (results are wrong; timing only).  Stamps: 0 loop top, 1 after the barrier, then
 per part p = 0..3: 2+3p after the loads were issued, 3+3p after the part's 16 steps of fragment reads + MFMAs, 4+3p after the
 LDS stores of the batch written in that part.  Every stamp drains the wave's LDS queue (s_memtime is a scalar-memory read that the
 compiler waits for with lgkmcnt(0)): the fragment ring restarts 4 times per tile, so read the numbers as an upper bound.
@@ -40,12 +40,14 @@ def main():
     for _ in range(3):
         nat.call("u3d_conv3d_wgrad_bf16_b16", 0, _stream(dev), _p(x), _p(aff), _p(dz), _p(dw), N, D, H, W, C, C, _p(ws), nw)
     torch.cuda.synchronize()
-    st = ws[: 8 * 12 * 14].view(torch.int32).cpu().view(8, 12, 14).long() & 0xFFFFFFFF
+    blocks = nw // (27 * 2048)  # S * P; the trace build stamps the block with (XCD-remapped) index blocks / 2
+    off = (blocks // 2) * 27 * 2048
+    st = ws[off: off + 8 * 12 * 14].view(torch.int32).cpu().view(8, 12, 14).long() & 0xFFFFFFFF
     if int(st.max()) == 0:
         print("no stamps: not a -DU3D_WG_TRACE build of the library (U3D_LIB_PATH)")
         return
     names = ["barrier"] + [f"{k}{p}" for p in range(4) for k in ("ld", "mfma", "st")]
-    print(f"level {args.level}: {C}->{C} @{D}x{H}x{W}; cycles between consecutive stamps, median over tiles 4..15 of block 0")
+    print(f"level {args.level}: {C}->{C} @{D}x{H}x{W}; cycles between consecutive stamps, median over tiles 4..15 of the middle block")
     print("wave " + " ".join(f"{n:>7s}" for n in names) + "   tile")
     for w in range(8):
         d = (st[w, :, 1:] - st[w, :, :-1]) & 0xFFFFFFFF
