@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define U3D_VERSION 115 /* 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids) */
+#define U3D_VERSION 116 /* 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant */
 
 #define U3D_OK 0
 #define U3D_EINVAL (-1)  /* bad shape / argument */
@@ -513,6 +513,11 @@ int u3d_conv3d_bf16_ex_b16(int device, u3d_stream_t stream, const void* x, const
                            const void* residual, float* workspace, long long workspace_floats);
 int u3d_conv3d_wgrad_bf16_b16(int device, u3d_stream_t stream, const void* x, const float* affine, const void* dz, float* dw, int N,
                               int D, int H, int W, int C, int K, float* workspace, long long workspace_floats);
+/* Host-only: which kernel u3d_conv3d_wgrad_bf16_b16 runs for a shape — 16: 2 x 8 x 16-voxel tiles (bit-identical to
+ * u3d_conv3d_wgrad_bf16 fed with the same bf16-representable values), 8: 4 x 8 x 8-voxel tiles (fewer wasted voxels on extents
+ * that are not multiples of 16; another summation order over the voxels), 0: the round-3 kernel (tensors beyond 2 GiB), -1:
+ * unsupported channel counts.  No reference counterpart (ATen picks its algorithm behind buildingblocks.py:56). */
+int u3d_conv3d_wgrad_bf16_b16_variant(int N, int D, int H, int W, int C, int K);
 int u3d_convtr3d_fwd_t8_b16(int device, u3d_stream_t stream, const void* x, const void* packed, void* t8, int N, int D1, int H1,
                             int W1, int Cl, int Cs);
 int u3d_convtr3d_dgrad_t8_b16(int device, u3d_stream_t stream, const void* dt8, const void* packed, const void* x_mask, void* dx,

@@ -303,8 +303,8 @@ __device__ __forceinline__ void conv_tile_epilogue(const bf16_conv_params& p, f3
     }
 }
 
-// ABL: timing-only ablation bits that attributed the loop's cost (1 no B loads, 2 no A reads, 4 no staging, 8 no barrier; results
-// in DESIGN.md 4.7).  Only ABL = 0 is instantiated.
+// ABL: timing-only ablation bits that attributed the loop's cost (1 no B loads, 2 no A reads, 4 no staging, 8 no barrier, 16 no epilogue,
+// 32 no prologue staging; results in DESIGN.md 4.7).  Only ABL = 0 is instantiated (-DU3D_CONV_ABL=.. builds: tools/ab_libs.sh).
 template <int NT, int ZW, int KS, int ABL = 0, typename T = float>
 __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void conv3d_bf16_kernel(const bf16_conv_params p) {
     using G = tile_geom<ZW, KS>;
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void 
     };
 
     // ---- prologue: the first chunk into its buffer, 8 loads in flight per thread (the accumulators are not live yet)
-    if (cbeg < nch) {
+    if (!(ABL & 32) && cbeg < nch) {
         aff_t g0;
         chunk_affine(cbeg, g0);
 #pragma unroll
@@ -517,6 +517,17 @@ __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void 
     if (B16 && !has_aff) chunk_loop(std::false_type{});
     else chunk_loop(std::true_type{});
 
+    if constexpr ((ABL & 16) != 0) {  // (timing: no epilogue; one store keeps the accumulators alive)
+        float s_ = 0.f;
+#pragma unroll
+        for (int m = 0; m < G::MT; ++m)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s_ += acc[m][j][e];
+        if (s_ == 123.456f) p.y[0] = s_;
+        return;
+    }
     conv_tile_epilogue<NT, ZW, KS, T>(p, acc, lds, n, nb, split, z0, y0, x0, t, lane, w);
 }
 
@@ -851,7 +862,10 @@ static int conv3d_bf16_impl(int device, u3d_stream_t stream, const float* x, con
     }
     const Bf16Tile tc = bf16_tile_choice(N, D, H, W, K, b16, p.ksplit);
     hipStream_t s = (hipStream_t)stream;
-    if (b16 && tc.planes == 8) return launch_bf16<2, 2, 3, 0, __bf16>(p, s);
+#ifndef U3D_CONV_ABL
+#define U3D_CONV_ABL 0  // timing experiments on the 8-plane bf16-storage tile (tools/ab_libs.sh; WRONG results): see the kernel's ABL bits
+#endif
+    if (b16 && tc.planes == 8) return launch_bf16<2, 2, 3, U3D_CONV_ABL, __bf16>(p, s);
     if (b16) return tc.nt == 2 ? launch_bf16<2, 1, 3, 0, __bf16>(p, s) : launch_bf16<1, 1, 3, 0, __bf16>(p, s);
     if (tc.nt == 2) return tc.planes == 8 ? launch_bf16<2, 2, 3>(p, s) : launch_bf16<2, 1, 3>(p, s);
     return tc.planes == 8 ? launch_bf16<1, 2, 3>(p, s) : launch_bf16<1, 1, 3>(p, s);
@@ -1176,10 +1190,22 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wg
 #ifndef U3D_WG_ABLATE
 #define U3D_WG_ABLATE 0  // timing experiments (tools/ab_libs.sh; WRONG results): 1 no global loads, 2 no LDS stores, 4 no g fragment
 #endif                   // reads in the loop, 8 no dz fragment reads, 16 no per-tile barrier
+// X8: tile 4 x 8 x 8 voxels (an MFMA's 16 voxels = two y rows of 8) instead of 2 x 8 x 16 — a halo of 600 instead of 720 voxels, and
+// no 16-voxel rounding of W (config 4's 40-, 20- and 10-wide levels).  The summation order over voxels differs from the 16-wide tile's.
+template <bool X8>
+struct wg2_geom {
+    static constexpr int TZ = X8 ? 4 : 2, TY = 8, TX = X8 ? 8 : 16;
+    static constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, NH = HZ * HY * HX;
+    static constexpr int GB = NH * 64, LDSB = GB + 2 * WG_DZ_HALF;   // g halo tile + the two dz halves
+    static constexpr int NG = (NH * 4 + 511) / 512, ND = 4;          // g / dz items (16 bytes) per thread and tile
+    static constexpr int GLAST = NH * 4 - 512 * (NG - 1);            // threads that own a last g item (320 / 352)
+    static constexpr int LDS_TOTAL = 2 * LDSB + 16;                  // + the dump slot of the others
+};
+template <bool X8>
 __global__ __launch_bounds__(512, 2) void conv3d_wgrad_b16v2_kernel(const bf16_wgrad_params p) {
-    using G = wg_geom<3>;
-    constexpr int HY = G::HY, HX = G::HX, GB = G::G_BYTES, LDSB = G::LDS;
-    static_assert(G::G_ITEMS8 == 2880 && GB == 46080, "halo 4 x 10 x 18 voxels of 32 channels");
+    using G = wg2_geom<X8>;
+    constexpr int TZ = G::TZ, TY = G::TY, TX = G::TX, HZ = G::HZ, HY = G::HY, HX = G::HX, GB = G::GB, LDSB = G::LDSB;
+    static_assert(TZ * TY * TX == 256 && G::NG <= 6 && G::NG >= 5, "256 voxels per tile = 16 rows of 16; 5 or 6 g items");
     extern __shared__ __attribute__((aligned(256))) char lds[];
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1191,10 +1217,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_b16v2_kernel(const bf16_w
     const int D = p.D, H = p.H, W = p.W;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((long long)p.N * D * H * W * p.C * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rdz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dz), 0, (int)((long long)p.N * D * H * W * p.K * 2), 0x00020000);
-    constexpr int NG = 6, ND = 4;  // g / dz items per thread and tile
+    constexpr int NG = G::NG, ND = G::ND, NTOT = NG + ND;
     // ---- per-thread staging constants
     int relg[NG];       // byte offset of g item k relative to the halo origin
-    unsigned gpos[NG / 2] = {0, 0, 0};  // 16 bits per item: hz | hy << 4 | hx << 8 of its halo voxel (hz >= 4: dead tail item)
+    unsigned gpos[3] = {0, 0, 0};  // 16 bits per item: hz | hy << 4 | hx << 8 of its halo voxel (hz >= 4: dead tail item)
 #pragma unroll
     for (int k = 0; k < NG; ++k) {
         const int hv = (t >> 2) + 128 * k;
@@ -1202,8 +1228,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_b16v2_kernel(const bf16_w
         relg[k] = (((hz * H + hy) * W + hx) * p.C + c0 + 8 * (t & 3)) * 2;
         gpos[k >> 1] |= ((unsigned)hz | ((unsigned)hy << 4) | ((unsigned)hx << 8)) << (16 * (k & 1));
     }
-    // dz item k: voxel (t >> 3) + 64 k = (z k >> 1, y 4 (k & 1) + (t >> 7), x (t >> 3) & 15), channel octet t & 7
-    const int dyl = t >> 7, dxl = (t >> 3) & 15;
+    // dz item k: voxel (t >> 3) + 64 k, channel octet t & 7; 16-wide tile: (z k >> 1, y 4 (k & 1) + (t >> 7), x (t >> 3) & 15),
+    // 8-wide tile: (z k, y t >> 6, x (t >> 3) & 7)
+    const int dyl = X8 ? t >> 6 : t >> 7, dxl = (t >> 3) & (TX - 1);
+    auto dz_zk = [](int k) { return X8 ? k : k >> 1; };
+    auto dz_yk = [](int k) { return X8 ? 0 : 4 * (k & 1); };
+    const unsigned imask = 0xf00u | ((1u << NG) - 1u) & ~(t < G::GLAST ? 0u : 1u << (NG - 1));  // interior tile: this thread's live items
     const int reld = ((dyl * W + dxl) * p.K + k0 + 8 * (t & 7)) * 2;
     const int ldsg = t * 16;
     const int ldsd = GB + ((t & 7) >> 2) * WG_DZ_HALF + (t >> 3) * 64 + (t & 3) * 16;
@@ -1217,17 +1247,17 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_b16v2_kernel(const bf16_w
     };
     auto info_of = [&](const tile_t& c, bool exists) {
         tinfo r;
-        const int z0 = c.zi * WG_TZ, y0 = c.yi * WG_TY, x0 = c.xi * WG_TX;
+        const int z0 = c.zi * TZ, y0 = c.yi * TY, x0 = c.xi * TX;
         r.baseg = ((((c.n * D + z0 - 1) * H + y0 - 1) * W + x0 - 1) * p.C) * 2;
         r.based = ((((c.n * D + z0) * H + y0) * W + x0) * p.K) * 2;
-        const bool interior = z0 >= 1 && z0 + WG_TZ + 1 <= D && y0 >= 1 && y0 + WG_TY + 1 <= H && x0 >= 1 && x0 + WG_TX + 1 <= W;
+        const bool interior = z0 >= 1 && z0 + TZ + 1 <= D && y0 >= 1 && y0 + TY + 1 <= H && x0 >= 1 && x0 + TX + 1 <= W;
         if (!exists) {
             r.mask = 0;  // past the block's last tile: every lane reads beyond the buffers' range (zeros, no traffic)
         } else if (interior) {
-            r.mask = w < 5 ? 0xf3fu : 0xf1fu;  // (g items 2880 .. 3071 do not exist: item 5 of waves 5 - 7)
+            r.mask = imask;
         } else {
             // halo coordinate h is inside iff lo <= h < hi with lo = max(0, 1 - origin), hi = min(extent, size + 1 - origin)
-            const unsigned zlo = z0 == 0 ? 1u : 0u, zn = (unsigned)min(G::HZ, D + 1 - z0) - zlo;
+            const unsigned zlo = z0 == 0 ? 1u : 0u, zn = (unsigned)min(HZ, D + 1 - z0) - zlo;
             const unsigned ylo = y0 == 0 ? 1u : 0u, yn = (unsigned)min(HY, H + 1 - y0) - ylo;
             const unsigned xlo = x0 == 0 ? 1u : 0u, xn = (unsigned)min(HX, W + 1 - x0) - xlo;
             r.mask = 0;
@@ -1240,7 +1270,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_b16v2_kernel(const bf16_w
             }
 #pragma unroll
             for (int k = 0; k < ND; ++k) {
-                const bool ok = (k >> 1) < D - z0 && 4 * (k & 1) + dyl < H - y0 && dxl < W - x0;
+                const bool ok = dz_zk(k) < D - z0 && dz_yk(k) + dyl < H - y0 && dxl < W - x0;
                 r.mask |= (ok ? 1u : 0u) << (8 + k);
             }
         }
@@ -1266,7 +1296,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_b16v2_kernel(const bf16_w
             return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
         }
         const int k = j - NG;
-        const int sk = ti.based + (((k >> 1) * H + 4 * (k & 1)) * W * p.K) * 2;  // uniform
+        const int sk = ti.based + ((dz_zk(k) * H + dz_yk(k)) * W * p.K) * 2;  // uniform
         const int off = ((ti.mask >> (8 + k)) & 1u) ? reld + sk : -1;
         return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rdz, off, 0, 0));
     };
@@ -1276,8 +1306,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_b16v2_kernel(const bf16_w
     auto store_slot = [&](char* buf, const tinfo& ti, int j, const bf16x8& v, const aff_t& g) {
         if constexpr ((U3D_WG_ABLATE & 2) != 0) return;
         if (j < NG) {
-            if (j == NG - 1 && w >= 5) return;  // (uniform per wave; the slot would land in the dz tile)
-            *reinterpret_cast<bf16x8*>(buf + ldsg + 8192 * j) = u3d_stage_b16(v, has_aff, ((ti.mask >> j) & 1u) != 0, g.a0, g.b0, g.a1, g.b1);
+            char* dst = buf + ldsg + 8192 * j;
+            if (j == NG - 1) dst = t < G::GLAST ? dst : lds + 2 * LDSB;  // (the others' last slot would land in the dz tile: dump slot)
+            *reinterpret_cast<bf16x8*>(dst) = u3d_stage_b16(v, has_aff, ((ti.mask >> j) & 1u) != 0, g.a0, g.b0, g.a1, g.b1);
         } else {
             *reinterpret_cast<bf16x8*>(buf + ldsd + 4096 * (j - NG)) = v;
         }
@@ -1312,12 +1343,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_b16v2_kernel(const bf16_w
         load_aff(t1.n, gaff);
         aff_n = t1.n;
 #pragma unroll 1
-        for (int j0 = 0; j0 < NG + ND; j0 += 5) {
+        for (int j0 = 0; j0 < 10; j0 += 5) {
             bf16x8 v[5];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) v[i] = load_slot(ti, j0 + i);
+            for (int i = 0; i < 5; ++i)
+                if (j0 + i < NTOT) v[i] = load_slot(ti, j0 + i);
 #pragma unroll
-            for (int i = 0; i < 5; ++i) store_slot(lds, ti, j0 + i, v[i], gaff);
+            for (int i = 0; i < 5; ++i)
+                if (j0 + i < NTOT) store_slot(lds, ti, j0 + i, v[i], gaff);
         }
         advance(t1);
         i1 = info_of(t1, first + 1 < last);
@@ -1335,7 +1368,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_b16v2_kernel(const bf16_w
             for (int e = 0; e < 16; ++e) acc[i][hh][e] = 0.f;
 
     const int g4 = lane >> 4, sidx = lane & 15;
-    const int lane_off = (8 * (g4 >> 1) + (sidx >> 2)) * 64 + (16 * (g4 & 1) + 4 * (sidx & 3)) * 2;
+    // (voxel half g4 >> 1 of an MFMA's 16 voxels: x + 8 on the 16-wide tile, the next y row on the 8-wide one)
+    const int lane_off = ((X8 ? HX : 8) * (g4 >> 1) + (sidx >> 2)) * 64 + (16 * (g4 & 1) + 4 * (sidx & 3)) * 2;
     int a_off[NTW];
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
@@ -1343,11 +1377,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_b16v2_kernel(const bf16_w
         const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
         a_off[i] = lane_off + ((tz * HY + ty) * HX + tx) * 64;
     }
-    const int b_off = GB + lane_off;
+    const int b_off = GB + (8 * (g4 >> 1) + (sidx >> 2)) * 64 + (16 * (g4 & 1) + 4 * (sidx & 3)) * 2;  // (the dz tile's 16 voxels of a row are contiguous)
     const bool four = w < 3;  // this wave's fourth tap exists (w + 24 < 27)
 
 #ifdef U3D_WG_TRACE  // timeline build (tools/wgrad_timeline.py): s_memtime stamps of tiles 4 .. 15 of every wave of the middle block -> its ws region
-    unsigned* trace = reinterpret_cast<unsigned*>(lds + 2 * LDSB);
+    unsigned* trace = reinterpret_cast<unsigned*>(lds + 2 * LDSB + 16);
 #define WG_STAMP(k)                                                                             \
     do {                                                                                        \
         const int tr_ = tile - first - 4;                                                       \
@@ -1374,9 +1408,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_b16v2_kernel(const bf16_w
         constexpr int NS = 16 * NTW, AD = 2;
         auto a_addr = [&](int s_) {
             const int rw = s_ / NTW, i = s_ - rw * NTW;
-            return a_off[i] + ((rw / WG_TY) * HY + (rw % WG_TY)) * HX * 64;
+            return a_off[i] + (X8 ? ((rw >> 2) * HY + 2 * (rw & 3)) : ((rw >> 3) * HY + (rw & 7))) * HX * 64;
         };
-        auto b_addr = [&](int rw, int hh) { return b_off + hh * WG_DZ_HALF + rw * WG_TX * 64; };
+        auto b_addr = [&](int rw, int hh) { return b_off + hh * WG_DZ_HALF + rw * 16 * 64; };
         bf16x8 af[AD + 1], bfr[2][2];
 #pragma unroll
         for (int s_ = 0; s_ < AD; ++s_) af[s_] = tr_frag(cur + a_addr(s_));
@@ -1407,11 +1441,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_b16v2_kernel(const bf16_w
                 }
                 // ---- one staging operation every third step (see the schedule above)
                 if (s_ < 32) {
-                    if (s_ % 6 == 2) rb[s_ / 6] = load_slot(i1, 5 + s_ / 6);
+                    if (s_ % 6 == 2 && 5 + s_ / 6 < NTOT) rb[s_ / 6] = load_slot(i1, 5 + s_ / 6);
                     if (s_ % 6 == 0 && s_ > 0) store_slot(nxt, i1, s_ / 6 - 1, ra[s_ / 6 - 1], gaff);
                 } else {
                     if ((s_ - 32) % 6 == 2) ra[(s_ - 32) / 6] = load_slot(i2, (s_ - 32) / 6);
-                    if ((s_ - 32) % 6 == 0 && s_ > 32) store_slot(nxt, i1, 5 + (s_ - 32) / 6 - 1, rb[(s_ - 32) / 6 - 1], gaff);
+                    if ((s_ - 32) % 6 == 0 && s_ > 32 && 5 + (s_ - 32) / 6 - 1 < NTOT) store_slot(nxt, i1, 5 + (s_ - 32) / 6 - 1, rb[(s_ - 32) / 6 - 1], gaff);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (i < 3 || four) {
@@ -1499,11 +1533,11 @@ __global__ void wgrad_bf16_reduce_flat_kernel(const float* __restrict__ ws, int 
 struct wgrad_plan {
     int tz, ty, tx, tiles, per_block, S, P;
 };
-wgrad_plan plan_wgrad(int N, int D, int H, int W, int C, int K) {
+wgrad_plan plan_wgrad(int N, int D, int H, int W, int C, int K, bool x8 = false) {  // x8: the 4 x 8 x 8 tile of conv3d_wgrad_b16v2_kernel<true>
     wgrad_plan q;
-    q.tz = (D + WG_TZ - 1) / WG_TZ;
+    q.tz = x8 ? (D + 3) / 4 : (D + WG_TZ - 1) / WG_TZ;
     q.ty = (H + WG_TY - 1) / WG_TY;
-    q.tx = (W + WG_TX - 1) / WG_TX;
+    q.tx = x8 ? (W + 7) / 8 : (W + WG_TX - 1) / WG_TX;
     q.tiles = N * q.tz * q.ty * q.tx;
     q.P = (C / 32) * (K / 64);
     // every block writes its 27 x 32 x 64 partial sums (221 KB) and the reduction reads them back: the block count is the
@@ -1524,8 +1558,24 @@ extern "C" int u3d_conv3d_wgrad_bf16_supported(int C, int K) { return (C > 0 && 
 
 extern "C" long long u3d_wgrad_bf16_workspace_floats(int N, int D, int H, int W, int C, int K) {
     if (!u3d_conv3d_wgrad_bf16_supported(C, K) || N <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
-    const wgrad_plan q = plan_wgrad(N, D, H, W, C, K);
-    return (long long)q.S * q.P * 27 * 2048;
+    const wgrad_plan q = plan_wgrad(N, D, H, W, C, K), q8 = plan_wgrad(N, D, H, W, C, K, true);  // (either tile shape of the bf16-storage kernel)
+    return (long long)(q.S > q8.S ? q.S : q8.S) * q.P * 27 * 2048;
+}
+
+// Which kernel u3d_conv3d_wgrad_bf16_b16 runs for a shape: 0 the round-3 kernel (u3d_set_tuning key 7 = 1, or tensors beyond 2 GiB),
+// 16 / 8: conv3d_wgrad_b16v2_kernel on 2 x 8 x 16 / 4 x 8 x 8 tiles — the shape that wastes fewer voxels on ragged extents, the
+// 8-wide one on a tie (smaller halo; key 7 = 16 / 8 force one).  The 16-wide variant is bit-identical to the fp32-storage kernel fed
+// with the same values; the 8-wide one sums the voxels in another order.
+static int wgrad_b16_variant(int N, int D, int H, int W, int C, int K) {
+    const long long vox = (long long)N * D * H * W;
+    if (g_u3d_tune[7] == 1 || vox * (C > K ? C : K) * 2 >= (1ll << 31)) return 0;  // (buffer offsets are 32-bit)
+    if (g_u3d_tune[7] == 16 || g_u3d_tune[7] == 8) return g_u3d_tune[7];
+    const long long v16 = (long long)((D + 1) / 2) * ((H + 7) / 8) * ((W + 15) / 16), v8 = (long long)((D + 3) / 4) * ((H + 7) / 8) * ((W + 7) / 8);
+    return v8 <= v16 ? 8 : 16;  // (tiles of 256 voxels each)
+}
+extern "C" int u3d_conv3d_wgrad_bf16_b16_variant(int N, int D, int H, int W, int C, int K) {
+    if (!u3d_conv3d_wgrad_bf16_supported(C, K) || N <= 0 || D <= 0 || H <= 0 || W <= 0) return -1;
+    return wgrad_b16_variant(N, D, H, W, C, K);
 }
 
 static int conv3d_wgrad_bf16_impl(int device, u3d_stream_t stream, const float* x, const float* affine, const float* dz, float* dw,
@@ -1550,21 +1600,26 @@ static int conv3d_wgrad_bf16_impl(int device, u3d_stream_t stream, const float* 
     U3D_REQUIRE(x && dz && dw && N > 0 && D > 0 && H > 0 && W > 0, "u3d_conv3d_wgrad_bf16: bad argument");
     U3D_REQUIRE(u3d_conv3d_wgrad_bf16_supported(C, K), "u3d_conv3d_wgrad_bf16: needs Cin %% 32 == 0 and Cout %% 64 == 0 (got %d, %d)", C, K);
     U3D_REQUIRE((((uintptr_t)x | (uintptr_t)dz | (uintptr_t)affine) & 15) == 0, "u3d_conv3d_wgrad_bf16: 16-byte alignment");
-    const wgrad_plan q = plan_wgrad(N, D, H, W, C, K);
+    const int variant = b16 ? wgrad_b16_variant(N, D, H, W, C, K) : 0;
+    const wgrad_plan q = plan_wgrad(N, D, H, W, C, K, variant == 8);
     const long long need = (long long)q.S * q.P * 27 * 2048;
     if (!workspace || workspace_floats < need)
         return u3d_set_err(U3D_EWORKSPACE, "u3d_conv3d_wgrad_bf16: workspace of %lld floats needed, %lld given", need, workspace_floats);
     bf16_wgrad_params p{x, affine, dz, workspace, N, D, H, W, C, K, 1, q.tz, q.ty, q.tx, q.tiles, q.per_block, K / 64,
                         g_u3d_tune[9] == 1 ? 0 : 1};
-    const long long vox = (long long)N * D * H * W;
-    if (b16 && g_u3d_tune[7] != 1 && vox * (C > K ? C : K) * 2 < (1ll << 31)) {  // (buffer offsets are 32-bit)
 #ifdef U3D_WG_TRACE
-        constexpr int v2_lds = 2 * wg_geom<3>::LDS + 8 * 12 * 14 * 4;
+    constexpr int v2_extra = 8 * 12 * 14 * 4;
 #else
-        constexpr int v2_lds = 2 * wg_geom<3>::LDS;
+    constexpr int v2_extra = 0;
 #endif
-        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_b16v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, v2_lds));
-        hipLaunchKernelGGL(conv3d_wgrad_b16v2_kernel, dim3((unsigned)(q.S * q.P)), dim3(512), v2_lds, (hipStream_t)stream, p);
+    if (variant == 8) {
+        constexpr int v2_lds = wg2_geom<true>::LDS_TOTAL + v2_extra;
+        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_b16v2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, v2_lds));
+        hipLaunchKernelGGL(conv3d_wgrad_b16v2_kernel<true>, dim3((unsigned)(q.S * q.P)), dim3(512), v2_lds, (hipStream_t)stream, p);
+    } else if (variant == 16) {
+        constexpr int v2_lds = wg2_geom<false>::LDS_TOTAL + v2_extra;
+        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_b16v2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, v2_lds));
+        hipLaunchKernelGGL(conv3d_wgrad_b16v2_kernel<false>, dim3((unsigned)(q.S * q.P)), dim3(512), v2_lds, (hipStream_t)stream, p);
     } else if (b16) {
         U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_bf16_kernel<3, __bf16>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * wg_geom<3>::LDS));

@@ -25,7 +25,8 @@
 //   [4] <= 16 output channels: 0 = 16-column variant (v_mfma_f32_16x16x4_f32), 2 = paired-y variant (round 1), 1 = padded 32-column kernel
 //   [5] start-phase stagger of the persistent kernel in units of 1024 cycles (0 = off)
 //   [6] 1 = one persistent block per CU instead of two (occupancy experiment)
-//   [7] 1 = bf16-storage weight gradient on the round-3 kernel (A/B of conv3d_wgrad_b16v2_kernel)
+//   [7] bf16-storage weight gradient: 1 = the round-3 kernel, 16 / 8 = force the 16- / 8-wide tile of conv3d_wgrad_b16v2_kernel (A/B);
+//       2 = fp32-storage bf16 convolutions on 8-plane tiles
 //   [8] bf16 weight gradient: target number of blocks (0 = default)   [9] 1 = bf16 weight gradient without the XCD-aware block order
 //   [10] 1 = bf16-storage convolutions on 4-plane tiles only (no 8-plane tiles)   [11] 1 = x-y-z raster tile order of the bf16 kernels
 //   [12] block slots (of 2 per CU) that the persistent convolution grids leave FREE for kernels of other streams (RCCL's gradient

@@ -101,10 +101,13 @@ def test_conv3d_bf16_b16_forward_and_data_gradient(shape, C, K, res, ks):
 @pytest.mark.parametrize("shape,C,K,blocks", [((1, 8, 16, 16), 64, 64, 0), ((2, 5, 9, 19), 32, 128, 0),
                                               ((1, 6, 24, 50), 32, 64, 0),    # interior, border and ragged tiles, one per block
                                               ((2, 6, 24, 50), 32, 64, 5),    # ... walked by 5 blocks: tile loop across samples
-                                              ((1, 7, 26, 66), 64, 128, 12)])
+                                              ((1, 7, 26, 66), 64, 128, 12),
+                                              ((1, 12, 40, 40), 64, 64, 7)])   # (config 4's 40-wide level: the 8-wide tile by default)
 def test_conv3d_wgrad_bf16_b16(shape, C, K, blocks, with_affine):
-    """bf16 storage: the round-4 kernel (constant-offset staging, two output halves per wave) and the round-3 kernel (key 7 = 1)
-    both reproduce the fp32-storage kernel fed with bf16-representable values bit for bit (same operands, same MFMA order)."""
+    """bf16 storage.  The round-3 kernel (key 7 = 1) and the round-4 kernel on 2 x 8 x 16 tiles (key 7 = 16) reproduce the
+    fp32-storage kernel fed with bf16-representable values bit for bit (same operands, same MFMA order per accumulator); the
+    4 x 8 x 8 tile (key 7 = 8) sums the same products in another order — fp32 rounding of a sum, far inside 1e-4 of the
+    gradient's scale; the default is one of the two (u3d_conv3d_wgrad_bf16_b16_variant)."""
     N, D, H, W = shape
     torch.manual_seed(2)
     x = dev(r16(torch.randn(N, D, H, W, C)))
@@ -112,21 +115,29 @@ def test_conv3d_wgrad_bf16_b16(shape, C, K, blocks, with_affine):
     aff = dev(torch.stack((1.0 + 0.3 * torch.randn(N, C), 0.2 * torch.randn(N, C)), dim=-1)) if with_affine else None
     L = nat.get_lib()
     nat.call("u3d_set_tuning", 8, blocks)
+    out = {}
     try:
         need = L.u3d_wgrad_bf16_workspace_floats(N, D, H, W, C, K)
         ws = torch.empty(need, dtype=torch.float32, device=U.DEV)
-        a, b, c = (torch.full((K, C, 3, 3, 3), float("nan"), device=U.DEV) for _ in range(3))
-        call("u3d_conv3d_wgrad_bf16", _p(x), _p(aff), _p(dz), _p(a), N, D, H, W, C, K, _p(ws), need)
-        call("u3d_conv3d_wgrad_bf16_b16", _p(b16(x)), _p(aff), _p(b16(dz)), _p(b), N, D, H, W, C, K, _p(ws), need)
-        nat.call("u3d_set_tuning", 7, 1)
-        call("u3d_conv3d_wgrad_bf16_b16", _p(b16(x)), _p(aff), _p(b16(dz)), _p(c), N, D, H, W, C, K, _p(ws), need)
+        ref = torch.full((K, C, 3, 3, 3), float("nan"), device=U.DEV)
+        call("u3d_conv3d_wgrad_bf16", _p(x), _p(aff), _p(dz), _p(ref), N, D, H, W, C, K, _p(ws), need)
+        default = L.u3d_conv3d_wgrad_bf16_b16_variant(N, D, H, W, C, K)
+        assert default in (8, 16)
+        for key in (0, 1, 16, 8):
+            nat.call("u3d_set_tuning", 7, key)
+            assert L.u3d_conv3d_wgrad_bf16_b16_variant(N, D, H, W, C, K) == {0: default, 1: 0}.get(key, key)
+            out[key] = torch.full((K, C, 3, 3, 3), float("nan"), device=U.DEV)
+            call("u3d_conv3d_wgrad_bf16_b16", _p(b16(x)), _p(aff), _p(b16(dz)), _p(out[key]), N, D, H, W, C, K, _p(ws), need)
         torch.cuda.synchronize()
     finally:
         nat.call("u3d_set_tuning", 7, 0)
         nat.call("u3d_set_tuning", 8, 0)
-    assert torch.isfinite(a).all()
-    assert torch.equal(a, c)
-    assert torch.equal(a, b)
+    assert torch.isfinite(ref).all()
+    assert torch.equal(ref, out[1])
+    assert torch.equal(ref, out[16])
+    scale = float(ref.abs().max())
+    assert float((out[8] - ref).abs().max()) < 1e-4 * scale
+    assert torch.equal(out[0], out[default])
 
 
 def test_transposed_convolution_t8_b16():
@@ -436,7 +447,9 @@ def test_bf16_storage_is_reproducible_composes_with_checkpointing_and_graphs_and
     _step(model, x, t)
     m32 = torch.cuda.max_memory_allocated() - base
     diag(test="bf16_storage_peak", fp32_storage_mib=m32 / 2**20, bf16_storage_mib=res["plain"][4] / 2**20, with_ckpt_mib=res["ckpt"][4] / 2**20)
-    assert res["plain"][4] < 0.75 * m32, (res["plain"][4], m32)
+    # (0.75 until the weight gradient's fp32 split-K scratch — shared by all layers, not tape — was sized for the larger of its two tile
+    # shapes: 48 instead of 32 MB of this small step's 242 MB peak; config 4 at its full shape: 4.66 vs 7.48 GB, profiles/r04_cfg4_model_bench.jsonl / r03_f32act_cfg4_model_bench.jsonl)
+    assert res["plain"][4] < 0.78 * m32, (res["plain"][4], m32)
 
 
 def test_activation_bf16_falls_back_with_a_warning_outside_its_envelope():
