@@ -70,6 +70,8 @@ struct bf16_conv_params {
     int order;             // tile order of the grid: 1 (default) z fastest, then x, then y; 0 (u3d_set_tuning key 11 = 1) x-y-z raster
     int b16;               // 1: x, y, residual, gx, maskx are bf16 tensors (activation storage, `_b16` entry points); the pointer
                            //    fields keep their float* type and are reinterpreted by the kernels' storage type T
+    int t8mode, t8cs;      // 2x2x2 kernels of the transposed convolution (space-to-depth form, below): 1 forward / 2 data gradient,
+                           //    Cs — which (tap, parity) weight blocks are structurally zero and are skipped; 0: nothing is skipped
 };
 
 template <int ZW, int KS>
@@ -463,6 +465,20 @@ __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void 
     }
     // (two copies of the chunk loop, with and without the GroupNorm affine in the staging: the data-gradient launches have none
     // and copy their bf16 items as they are — a select per dword otherwise)
+    // Transposed convolution in space-to-depth form (KS = 2): of the 64 (tap, output parity) weight blocks only 27 are non-zero.  A
+    // block's output channels (forward) / a chunk's input channels (data gradient) belong to one parity p = pz*4 + py*2 + px when
+    // Cs is a multiple of the channel run (else the union of the parities it touches): forward tap a is live iff a & ~p == 0, data-
+    // gradient tap tau iff tau | p == 7.  Dead taps are skipped whole — B load, A reads, MFMAs: uniform branches.
+    auto t8_mask_of = [&](int ch0, int nchan) -> unsigned {  // live-tap mask of the channel run [ch0, ch0 + nchan)
+        if (KS != 2 || p.t8mode == 0) return 0xffu;
+        const int p0 = min(ch0 / p.t8cs, 7), p1 = min((ch0 + nchan - 1) / p.t8cs, 7);
+        unsigned m = 0;
+        for (int pp = p0; pp <= p1; ++pp)
+            for (int a = 0; a < 8; ++a)
+                if (p.t8mode == 1 ? (a & ~pp & 7) == 0 : (a | pp) == 7) m |= 1u << a;
+        return m;
+    };
+    const unsigned fwd_mask = (KS == 2 && p.t8mode == 1) ? t8_mask_of(nb * NT * 32, NT * 32) : 0xffu;
     auto chunk_loop = [&](auto AFF) {
     for (int c = cbeg; c < nch; ++c) {
         if constexpr (!(ABL & 8)) __syncthreads();  // buffer (c&1) is complete; everyone is done reading buffer ((c+1)&1)
@@ -473,6 +489,12 @@ __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void 
         aff_t gaff;
         chunk_affine(cn, gaff);
         const bf16x8* wp = p.wpk + ((size_t)c * G::NTAPS * ntiles + (size_t)nb * NT) * 64;  // wave-uniform (scalar) base
+        unsigned tm = 0xffffffffu, tm1 = 0xffffffffu;  // live taps of this chunk / of the next (the B ring runs ahead across chunks)
+        if constexpr (KS == 2) {
+            tm = p.t8mode == 2 ? t8_mask_of(c << 4, 16) : fwd_mask;
+            tm1 = p.t8mode == 2 ? t8_mask_of((c + 1) << 4, 16) : fwd_mask;
+        }
+        auto live = [&](int tap_) { return KS != 2 || (((tap_ < G::NTAPS ? tm : tm1) >> (tap_ % G::NTAPS)) & 1u) != 0; };
         item_t st[PER];
         bf16x8 aq[A_DIST + 1][G::MT] = {};
 #pragma unroll
@@ -490,10 +512,12 @@ __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void 
 #pragma unroll
             for (int t3 = 0; t3 < KS; ++t3) {
                 const int tap = part * KS + t3;
+                if (live(tap + B_DIST)) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    if constexpr (!(ABL & 1)) bq[(tap + B_DIST) % B_RING][j] = wp[((size_t)(tap + B_DIST) * ntiles + j) * 64 + lane];
-                if (!(ABL & 2) && tap + A_DIST < G::NTAPS) {
+                    for (int j = 0; j < NT; ++j)
+                        if constexpr (!(ABL & 1)) bq[(tap + B_DIST) % B_RING][j] = wp[((size_t)(tap + B_DIST) * ntiles + j) * 64 + lane];
+                }
+                if (!(ABL & 2) && tap + A_DIST < G::NTAPS && live(tap + A_DIST)) {
                     const int nt_ = tap + A_DIST, tzz = nt_ / (KS * KS), tyy = (nt_ / KS) % KS, txx = nt_ % KS;
 #pragma unroll
                     for (int m = 0; m < G::MT; ++m)
@@ -501,11 +525,13 @@ __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void 
                             *reinterpret_cast<const bf16x8*>(cur + a_base + ((((m >> 1) + tzz) * HY + ((m & 1) * 4 + tyy)) * HS + txx) * 16);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (live(tap)) {
 #pragma unroll
-                for (int m = 0; m < G::MT; ++m)
+                    for (int m = 0; m < G::MT; ++m)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[tap % (A_DIST + 1)][m], bq[tap % B_RING][j], acc[m][j], 0, 0, 0);
+                        for (int j = 0; j < NT; ++j)
+                            acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[tap % (A_DIST + 1)][m], bq[tap % B_RING][j], acc[m][j], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -1772,6 +1798,8 @@ static int convtr3d_fwd_t8_impl(int device, u3d_stream_t stream, const float* x,
     bf16_conv_params p{x, nullptr, reinterpret_cast<const bf16x8*>(packed), t8, nullptr, nullptr, nullptr, nullptr,
                        N, D1, H1, W1, Cl, 8 * Cs, 0, 0, 0, 0, 0, nullptr, 1, nullptr};
     p.b16 = b16;
+    p.t8mode = g_u3d_tune[10] == 2 ? 0 : 1;  // (key 10 = 2: A/B without the zero-block skipping)
+    p.t8cs = Cs;
     return launch_t8_conv(p, (hipStream_t)stream);
 }
 
@@ -1792,6 +1820,8 @@ static int convtr3d_dgrad_t8_impl(int device, u3d_stream_t stream, const float* 
     bf16_conv_params p{dt8, nullptr, reinterpret_cast<const bf16x8*>(packed), dx, nullptr, nullptr, nullptr, nullptr,
                        N, D1, H1, W1, 8 * Cs, Cl, 0, 0, 0, 0, 1, x_mask, 1, nullptr};
     p.b16 = b16;
+    p.t8mode = g_u3d_tune[10] == 2 ? 0 : 2;
+    p.t8cs = Cs;
     return launch_t8_conv(p, (hipStream_t)stream);
 }
 

@@ -366,7 +366,8 @@ def _t_to_t8(t, D1, H1, W1):
     return v.contiguous().to(U.DEV)
 
 
-@pytest.mark.parametrize("shape,Cl,Cs", [((1, 5, 10, 10), 64, 32), ((2, 4, 9, 7), 32, 8), ((1, 16, 24, 40), 32, 16), ((1, 40, 48, 48), 32, 16)])
+@pytest.mark.parametrize("shape,Cl,Cs", [((1, 5, 10, 10), 64, 32), ((2, 4, 9, 7), 32, 8), ((1, 16, 24, 40), 32, 16), ((1, 40, 48, 48), 32, 16),
+                                         ((1, 6, 10, 12), 128, 64)])  # (Cs = 64: a block / chunk = ONE output parity, dead taps skipped)
 def test_convtranspose3d_space_to_depth_bf16(shape, Cl, Cs):
     """forward, data gradient (with the ReLU mask of x) and weight gradient of nn.ConvTranspose3d(Cl, Cs, 3, stride=2, padding=1,
     bias=False) against torch with the operands rounded to bf16 the same way"""
