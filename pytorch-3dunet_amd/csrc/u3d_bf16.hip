@@ -23,6 +23,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // One staged bf16 item (8 channels of a halo voxel): GroupNorm affine in fp32, back to bf16, zero outside the volume (the padding
 // applies AFTER the affine).  Written on dword pairs so that it compiles to 8 unpack + 4 v_pk_fma_f32 + 4 v_cvt_pk_bf16_f32 + 4
@@ -111,6 +112,24 @@ __device__ __forceinline__ void conv_tile_epilogue(const bf16_conv_params& p, f3
     if (p.ksplit > 1) {
         // raw partial sums of this chunk range; residual / ReLU / statistics happen in the fixed-order reduction
         float* wsp = p.ws + (size_t)split * p.N * p.D * p.H * p.W * p.K;
+        if constexpr (std::is_same<T, __bf16>::value) {
+            // (bf16 storage runs the MFMAs with swapped operands: lane = voxel (yy = col & 3, xx = col >> 2), register quad g = four
+            // consecutive channels 8 g + 4 half .. + 3 — see the epilogue below)
+#pragma unroll
+            for (int m = 0; m < G::MT; ++m) {
+                const int z = z0 + w * ZW + (m >> 1), y = y0 + (m & 1) * 4 + (col & 3), xx = x0 + (col >> 2);
+                if (z < p.D && y < p.H && xx < p.W) {
+                    const size_t vox = (((size_t)n * p.D + z) * p.H + y) * p.W + xx;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *reinterpret_cast<f32x4*>(wsp + vox * p.K + (size_t)(nb * NT + j) * 32 + 8 * g + 4 * half) =
+                                f32x4{acc[m][j][4 * g], acc[m][j][4 * g + 1], acc[m][j][4 * g + 2], acc[m][j][4 * g + 3]};
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int m = 0; m < G::MT; ++m) {
             const int z = z0 + w * ZW + (m >> 1);
@@ -156,87 +175,102 @@ __device__ __forceinline__ void conv_tile_epilogue(const bf16_conv_params& p, f3
         };
         auto item_goff = [&](int k) { return gbase + (size_t)((VPK * k) >> 6) * sZ + (size_t)(((VPK * k) & 63) >> 3) * sY; };
         __syncthreads();  // every wave has left the k-loop: the halo buffers are free
+        bf16x8 sv8[NITEM];
+#pragma unroll
+        for (int k = 0; k < NITEM; ++k) sv8[k] = bf16x8{};
         if (side) {
-            bf16x8 sv8[NITEM];
 #pragma unroll
-            for (int k = 0; k < NITEM; ++k) {
-                sv8[k] = bf16x8{};
+            for (int k = 0; k < NITEM; ++k)
                 if (item_in(k)) sv8[k] = *reinterpret_cast<const bf16x8*>(side + item_goff(k));
+            if (!want_g) {  // (residual / mask: needed per element, in the accumulator layout; gx only by the statistics, from sv8)
+#pragma unroll
+                for (int k = 0; k < NITEM; ++k) *reinterpret_cast<bf16x8*>(lds + l0 + VPK * k * RSB) = sv8[k];
+                __syncthreads();
             }
-#pragma unroll
-            for (int k = 0; k < NITEM; ++k) *reinterpret_cast<bf16x8*>(lds + l0 + VPK * k * RSB) = sv8[k];
-            __syncthreads();
         }
-        // ---- in the accumulator layout, two rows (e, e + 1: neighbours in y) at a time: packed add / convert / statistics.
-        // SIDE: 0 none, 1 residual (added), 2 ReLU mask of the tensor this gradient flows into, 3 gx (GroupNorm-backward sums)
-        char* const cb = lds + ((w * ZW * 8) * 8 + half) * RSB + col * 2;
+        // ---- in the accumulator layout.  The bf16-storage kernels run their MFMAs with SWAPPED operands (weights = A, voxels = B):
+        // a lane then owns ONE voxel (column col: yy = col & 3, xx = col >> 2 of the M-tile) and its register quad g holds FOUR
+        // CONSECUTIVE channels 8 g + 4 half .. + 3 of the n-tile — one 8-byte LDS access per quad for the side value and one for the
+        // result (32 + 32 per lane) instead of the 128 + 128 two-byte accesses of the channel-per-lane layout, which were 19 % of the
+        // 64-channel layers (profiles/r04_conv_b16_ablation.txt).  SIDE: 0 none, 1 residual (added), 2 ReLU mask of the tensor this
+        // gradient flows into, 3 gx (GroupNorm-backward sums).  Statistics are taken in the output pass below, from the 16-byte items.
+        char* const cb = lds + ((w * ZW * 8 + (col & 3)) * 8 + (col >> 2)) * RSB + half * 8;
         const float lowest = p.relu ? 0.f : -__builtin_inff();
-        f32x2 q1[NT], q2[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) q1[j] = q2[j] = f32x2{0.f, 0.f};
-        auto elements = [&](auto SIDE_, auto STATS_, auto FULL_) {
+        auto elements = [&](auto SIDE_) {
             constexpr int SIDE = decltype(SIDE_)::value;
-            constexpr bool STATS = decltype(STATS_)::value, FULLT = decltype(FULL_)::value;
 #pragma unroll
             for (int m = 0; m < G::MT; ++m) {
-                const int zl = w * ZW + (m >> 1);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
 #pragma unroll
-                    for (int e = 0; e < 16; e += 2) {
-                        const int yl = (m & 1) * 4 + (e & 3), xl = 2 * (e >> 2);  // (+ half: in cb / below)
-                        char* c0 = cb + (((m >> 1) * 8 + yl) * 8 + xl) * RSB + j * 64;
-                        char* c1 = c0 + 8 * RSB;
-                        f32x2 v = {acc[m][j][e], acc[m][j][e + 1]};
-                        f32x2 sv = {0.f, 0.f};
-                        if constexpr (SIDE != 0) {
-                            const unsigned u0 = *reinterpret_cast<const unsigned short*>(c0), u1 = *reinterpret_cast<const unsigned short*>(c1);
-                            sv = f32x2{__builtin_bit_cast(float, u0 << 16), __builtin_bit_cast(float, u1 << 16)};
-                        }
-                        if constexpr (SIDE == 1) v = v + sv;
-                        if constexpr (SIDE == 2) {
-                            v[0] = sv[0] > 0.f ? v[0] : 0.f;
-                            v[1] = sv[1] > 0.f ? v[1] : 0.f;
-                        }
-                        v[0] = fmaxf(v[0], lowest);
-                        v[1] = fmaxf(v[1], lowest);
-                        const bf16x2 r = __builtin_convertvector(v, bf16x2);
-                        *reinterpret_cast<__bf16*>(c0) = r[0];
-                        *reinterpret_cast<__bf16*>(c1) = r[1];
-                        if constexpr (STATS) {  // (statistics describe the STORED tensor)
-                            const unsigned rb = __builtin_bit_cast(unsigned, r);
-                            f32x2 vr = {__builtin_bit_cast(float, rb << 16), __builtin_bit_cast(float, rb & 0xffff0000u)};
-                            if constexpr (!FULLT) {
-                                const bool in0 = z0 + zl < p.D && x0 + xl + half < p.W;
-                                if (!(in0 && y0 + yl < p.H)) vr[0] = 0.f;
-                                if (!(in0 && y0 + yl + 1 < p.H)) vr[1] = 0.f;
+                    for (int g = 0; g < 4; ++g) {
+                        char* c0 = cb + (((m >> 1) * 8 + (m & 1) * 4) * 8) * RSB + j * 64 + g * 16;
+                        f32x4 v = {acc[m][j][4 * g], acc[m][j][4 * g + 1], acc[m][j][4 * g + 2], acc[m][j][4 * g + 3]};
+                        if constexpr (SIDE == 1 || SIDE == 2) {
+                            const u32x2 raw = *reinterpret_cast<const u32x2*>(c0);  // four bf16 (integer lanes: no float semantics on bit pairs)
+                            const unsigned u0 = raw[0], u1 = raw[1];
+                            const f32x4 sv = {__builtin_bit_cast(float, u0 << 16), __builtin_bit_cast(float, u0 & 0xffff0000u),
+                                              __builtin_bit_cast(float, u1 << 16), __builtin_bit_cast(float, u1 & 0xffff0000u)};
+                            if constexpr (SIDE == 1) v = v + sv;
+                            if constexpr (SIDE == 2) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = sv[e] > 0.f ? v[e] : 0.f;
                             }
-                            q1[j] += vr;
-                            q2[j] = __builtin_elementwise_fma(vr, SIDE == 3 ? sv : vr, q2[j]);
                         }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lowest);
+                        const bf16x2 r0 = __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2), r1 = __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2);
+                        *reinterpret_cast<u32x2*>(c0) = u32x2{__builtin_bit_cast(unsigned, r0), __builtin_bit_cast(unsigned, r1)};
                     }
                 }
             }
         };
-        auto with_side = [&](auto SIDE_) {
-            const bool st = want_stats || want_g;
-            if (st && full) elements(SIDE_, std::true_type{}, std::true_type{});
-            else if (st) elements(SIDE_, std::true_type{}, std::false_type{});
-            else elements(SIDE_, std::false_type{}, std::true_type{});
-        };
-        if (!side) with_side(std::integral_constant<int, 0>{});
-        else if (p.residual) with_side(std::integral_constant<int, 1>{});
-        else if (want_g) with_side(std::integral_constant<int, 3>{});
-        else with_side(std::integral_constant<int, 2>{});
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            s1[j] = q1[j][0] + q1[j][1];
-            s2[j] = q2[j][0] + q2[j][1];
-        }
+        // (gx is only needed by the statistics: it stays in the sv8 registers; the accumulators are dead after this pass)
+        if (p.residual) elements(std::integral_constant<int, 1>{});
+        else if (side && !want_g) elements(std::integral_constant<int, 2>{});
+        else elements(std::integral_constant<int, 0>{});
         __syncthreads();
+        // ---- output pass: 16-byte items (8 channels of a voxel) to global; per-channel sums of this thread's channel octet
+        f32x2 q1[4], q2[4];
 #pragma unroll
-        for (int k = 0; k < NITEM; ++k)
-            if (item_in(k)) *reinterpret_cast<bf16x8*>(yout + item_goff(k)) = *reinterpret_cast<const bf16x8*>(lds + l0 + VPK * k * RSB);
+        for (int i = 0; i < 4; ++i) q1[i] = q2[i] = f32x2{0.f, 0.f};
+        const bool st = want_stats || want_g;
+#pragma unroll
+        for (int k = 0; k < NITEM; ++k) {
+            if (item_in(k)) {
+                const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(lds + l0 + VPK * k * RSB);
+                *reinterpret_cast<bf16x8*>(yout + item_goff(k)) = o8;
+                if (st) {  // (statistics describe the STORED tensor)
+                    const u32x4 ou = __builtin_bit_cast(u32x4, o8), gu = __builtin_bit_cast(u32x4, sv8[k]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x2 vr = {__builtin_bit_cast(float, ou[i] << 16), __builtin_bit_cast(float, ou[i] & 0xffff0000u)};
+                        const f32x2 gr = {__builtin_bit_cast(float, gu[i] << 16), __builtin_bit_cast(float, gu[i] & 0xffff0000u)};
+                        q1[i] += vr;
+                        q2[i] = __builtin_elementwise_fma(vr, want_g ? gr : vr, q2[i]);
+                    }
+                }
+            }
+        }
+        if (st) {
+            // fixed-order block reduction: the 256 / OCT threads of a channel octet, then one f64 atomic per (n, channel)
+            __syncthreads();
+            float* red = reinterpret_cast<float*>(lds);  // [thread][8 channels][2]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<f32x4*>(red + t * 16 + 4 * i) = f32x4{q1[i][0], q2[i][0], q1[i][1], q2[i][1]};
+            }
+            __syncthreads();
+            if (t < NT * 32 * 2) {
+                const int ch = t >> 1, o_ = ch >> 3;
+                double sum = 0.0;
+#pragma unroll 4
+                for (int i = 0; i < 256 / OCT; ++i) sum += (double)red[(i * OCT + o_) * 16 + (ch & 7) * 2 + (t & 1)];
+                double* dst = (want_stats ? p.out_stats : p.gstats) + ((size_t)n * p.K + (size_t)nb * NT * 32) * 2;
+                u3d_atomic_add_f64(dst + t, sum);
+            }
+        }
+        return;
     } else {
     // Addressing is hoisted: element e of an accumulator tile sits (e & 3) rows and 2*(e >> 2) voxels from the tile's first
     // voxel, so one 64-bit base per (m, j) plus sixteen 32-bit offsets replaces a five-term index per element; tiles that lie
@@ -530,7 +564,8 @@ __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void 
                     for (int m = 0; m < G::MT; ++m)
 #pragma unroll
                         for (int j = 0; j < NT; ++j)
-                            acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[tap % (A_DIST + 1)][m], bq[tap % B_RING][j], acc[m][j], 0, 0, 0);
+                            acc[m][j] = B16 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[tap % B_RING][j], aq[tap % (A_DIST + 1)][m], acc[m][j], 0, 0, 0)
+                                            : __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[tap % (A_DIST + 1)][m], bq[tap % B_RING][j], acc[m][j], 0, 0, 0);  // (B16: D^T, see the epilogue)
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
