@@ -59,7 +59,7 @@ FAMILIES = {  # C-ABI entry point -> substrings of the kernels it launches
     "u3d_conv3d_wgrad": ("conv3d_wgrad_kernel", "wgrad_reduce_kernel"),
     "u3d_subpixel_conv_fwd": ("subpixel_fwd_kernel",),
     "u3d_conv3d_bf16_ex": ("conv3d_bf16_kernel", "splitk_bf16_reduce_kernel"),
-    "u3d_conv3d_wgrad_bf16": ("conv3d_wgrad_bf16_kernel", "wgrad_bf16_reduce"),
+    "u3d_conv3d_wgrad_bf16": ("conv3d_wgrad_bf16_kernelILi3", "conv3d_wgrad_b16v2_kernel", "wgrad_bf16_reduce"),
 }
 
 
