@@ -68,7 +68,8 @@ struct bf16_conv_params {
     int ksplit;            // > 1: the channel reduction is split over `ksplit` blocks per (tile, channel block); raw partial
     float* ws;             //      sums go to ws[split][voxel][K] and splitk_bf16_reduce_kernel owns the epilogue
     long long wpart;       // split-fp32 kernels: distance (in bf16x8 records) between the high / middle / low weight images
-    int order;             // tile order of the grid: 1 (default) z fastest, then x, then y; 0 (u3d_set_tuning key 11 = 1) x-y-z raster
+    int order;             // bit 0: tile order of the grid: 1 (default) z fastest, then x, then y; 0 (u3d_set_tuning key 11 = 1) x-y-z raster;
+                           // bit 1: the tile index runs fastest over the block ids (see the kernel)
     int b16;               // 1: x, y, residual, gx, maskx are bf16 tensors (activation storage, `_b16` entry points); the pointer
                            //    fields keep their float* type and are reinterpreted by the kernels' storage type T
     int t8mode, t8cs;      // 2x2x2 kernels of the transposed convolution (space-to-depth form, below): 1 forward / 2 data gradient,
@@ -357,14 +358,29 @@ __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int nblk = p.K / (32 * NT);
     const int bid = u3d_xcd_remap(blockIdx.x, gridDim.x);
-    const int nb = bid % nblk;
-    int tile = bid / nblk;
-    const int split = tile % p.ksplit;  // (ksplit == 1: 0)
-    tile /= p.ksplit;
+    // Which index runs fastest over consecutive block ids (= blocks that run on one XCD at one time and share its L2):
+    //   order bit 1 clear: the output-channel block, then the split, then the tile — neighbouring blocks share the ACTIVATION halo (large
+    //     volumes: the halo is the traffic, a layer's weights stay L2-resident);
+    //   order bit 1 set: the tile, then the split, then the channel block — neighbouring blocks stream the SAME weight fragments (small
+    //     volumes with wide layers: config 4's 512 / 1024-channel levels have 27 / 8 tiles and 14 / 57 MB of bf16 weights, which every tile
+    //     used to pull through the fabric again: 380-450 MB per launch).
+    int nb, tile, split;
+    if (p.order & 2) {
+        const int ntile = p.N * p.tz * p.ty * p.tx;
+        tile = bid % ntile;
+        const int rest = bid / ntile;
+        split = rest % p.ksplit;
+        nb = rest / p.ksplit;
+    } else {
+        nb = bid % nblk;
+        tile = bid / nblk;
+        split = tile % p.ksplit;  // (ksplit == 1: 0)
+        tile /= p.ksplit;
+    }
     int txi, tyi, tzi, n;
     // z fastest: the tiles an XCD works on at one time (32 CUs x 3 blocks, consecutive ids) then share their z halos — the widest
     // (6 planes for 4) — through that XCD's L2: 0.49 -> 0.40 GB fetched per launch on config 4 (profiles/r03_tile_order.txt)
-    if (p.order == 1) {
+    if (p.order & 1) {
         tzi = tile % p.tz;
         tile /= p.tz;
         txi = tile % p.tx;
@@ -807,6 +823,10 @@ static int launch_bf16(const bf16_conv_params& p, hipStream_t stream) {
     q.tz = (p.D + G::TZ - 1) / G::TZ;
     q.ty = (p.H + 7) / 8;
     q.tx = (p.W + 7) / 8;
+    // few tiles, many channel blocks: blocks of one (channel block, split) — the same weights — next to each other (key 11 = 2 / 3: never / always)
+    const long long ntile = (long long)p.N * q.tz * q.ty * q.tx;
+    // (measured, profiles/r04_block_order_ab.txt: 3x3x3 at 10x20x20 / 5x10x10 -8...-10 %; the 2x2x2 kernels mixed: left on the old order)
+    if (g_u3d_tune[11] == 3 || (g_u3d_tune[11] != 2 && KS == 3 && ntile <= 64 && (long long)p.C * p.K >= 256 * 256)) q.order |= 2;
     const long long blocks = (long long)p.N * q.tz * q.ty * q.tx * (p.K / (32 * NT)) * p.ksplit;
     if (blocks > 0x7fffffffLL) return u3d_set_err(U3D_EINVAL, "u3d_conv3d_bf16: grid too large");
     size_t shmem = 2 * (size_t)G::BUF;

@@ -29,7 +29,8 @@
 //       2 = fp32-storage bf16 convolutions on 8-plane tiles
 //   [8] bf16 weight gradient: target number of blocks (0 = default)   [9] 1 = bf16 weight gradient without the XCD-aware block order
 //   [10] 1 = bf16-storage convolutions on 4-plane tiles only (no 8-plane tiles); 2 = transposed-convolution 2x2x2 kernels without
-//        skipping their structurally zero weight blocks   [11] 1 = x-y-z raster tile order of the bf16 kernels
+//        skipping their structurally zero weight blocks   [11] bf16 kernels: 1 = x-y-z raster tile order; 2 / 3 = the tile index never / always runs
+//        fastest over the block ids (default: on small volumes with wide layers)
 //   [12] block slots (of 2 per CU) that the persistent convolution grids leave FREE for kernels of other streams (RCCL's gradient
 //        all-reduce: parallel.cu_budget).  A CU-MASKED compute queue was measured instead and rejected: the same kernels run 40-75 %
 //        slower on a queue masked to 248 of 256 CUs (profiles/r04_cu_mask_*.txt)
