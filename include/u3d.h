@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define U3D_VERSION 116 /* 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant */
+#define U3D_VERSION 117 /* 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K) */
 
 #define U3D_OK 0
 #define U3D_EINVAL (-1)  /* bad shape / argument */
@@ -522,6 +522,14 @@ int u3d_convtr3d_fwd_t8_b16(int device, u3d_stream_t stream, const void* x, cons
                             int W1, int Cl, int Cs);
 int u3d_convtr3d_dgrad_t8_b16(int device, u3d_stream_t stream, const void* dt8, const void* packed, const void* x_mask, void* dx,
                               int N, int D1, int H1, int W1, int Cl, int Cs);
+/* Split-K forms of the two data-gradient entry points above (the contraction runs over 8*Cs channels: hundreds of serial 16-channel
+ * chunks on few blocks at the bottom of the U).  `workspace`: u3d_convtr3d_dgrad_t8_workspace_floats() fp32 elements, or NULL / too small
+ * = unsplit.  Partial sums are added in a fixed order by the reduction kernel of u3d_conv3d_bf16_ex, which applies the ReLU mask. */
+long long u3d_convtr3d_dgrad_t8_workspace_floats(int N, int D1, int H1, int W1, int Cl, int Cs);
+int u3d_convtr3d_dgrad_t8_ex(int device, u3d_stream_t stream, const float* dt8, const void* packed, const float* x_mask, float* dx,
+                             int N, int D1, int H1, int W1, int Cl, int Cs, float* workspace, long long workspace_floats);
+int u3d_convtr3d_dgrad_t8_b16_ex(int device, u3d_stream_t stream, const void* dt8, const void* packed, const void* x_mask, void* dx,
+                                 int N, int D1, int H1, int W1, int Cl, int Cs, float* workspace, long long workspace_floats);
 int u3d_convtr3d_wgrad_t8_b16(int device, u3d_stream_t stream, const void* x, const void* dt8, float* dw, int N, int D1, int H1,
                               int W1, int Cl, int Cs, float* workspace, long long workspace_floats);
 /* x_is_f32: the block input is the fp32 network input (first encoder block) */

@@ -1868,8 +1868,18 @@ extern "C" int u3d_convtr3d_fwd_t8_b16(int device, u3d_stream_t stream, const vo
     return convtr3d_fwd_t8_impl(device, stream, (const float*)x, packed, (float*)t8, N, D1, H1, W1, Cl, Cs, 1);
 }
 
+// The data gradient contracts over 8*Cs channels (hundreds of 16-channel chunks at the bottom of the U) into Cl outputs on the low-res
+// grid: at config 4's two bottom levels that is 128 / 216 blocks of 256 / 128 serial chunks each (0.37 / 0.19 ms).  The `_ex` entry
+// points take the split-K scratch of u3d_conv3d_bf16_ex (same rule, bf16_ksplit; same fixed-order reduction kernel, which owns the
+// ReLU mask); without a workspace they run unsplit, like the plain entry points.
+extern "C" long long u3d_convtr3d_dgrad_t8_workspace_floats(int N, int D1, int H1, int W1, int Cl, int Cs) {
+    if (!u3d_convtr3d_t8_supported(Cl, Cs) || N <= 0 || D1 <= 0 || H1 <= 0 || W1 <= 0) return 0;
+    const int ks = bf16_ksplit(N, D1, H1, W1, 8 * Cs, Cl);
+    return ks > 1 ? (long long)ks * N * D1 * H1 * W1 * Cl : 0;
+}
+
 static int convtr3d_dgrad_t8_impl(int device, u3d_stream_t stream, const float* dt8, const void* packed, const float* x_mask, float* dx,
-                                  int N, int D1, int H1, int W1, int Cl, int Cs, int b16) {
+                                  int N, int D1, int H1, int W1, int Cl, int Cs, int b16, float* workspace, long long workspace_floats) {
     U3D_ENTER(device);
     U3D_REQUIRE(dt8 && packed && dx && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && u3d_convtr3d_t8_supported(Cl, Cs), "u3d_convtr3d_dgrad_t8: bad argument");
     bf16_conv_params p{dt8, nullptr, reinterpret_cast<const bf16x8*>(packed), dx, nullptr, nullptr, nullptr, nullptr,
@@ -1877,17 +1887,34 @@ static int convtr3d_dgrad_t8_impl(int device, u3d_stream_t stream, const float* 
     p.b16 = b16;
     p.t8mode = g_u3d_tune[10] == 2 ? 0 : 2;
     p.t8cs = Cs;
+    const int ks = bf16_ksplit(N, D1, H1, W1, 8 * Cs, Cl);
+    if (ks > 1 && workspace && workspace_floats >= (long long)ks * N * D1 * H1 * W1 * Cl) {
+        p.ksplit = ks;
+        p.ws = workspace;
+    }
     return launch_t8_conv(p, (hipStream_t)stream);
 }
 
 extern "C" int u3d_convtr3d_dgrad_t8(int device, u3d_stream_t stream, const float* dt8, const void* packed, const float* x_mask,
                                      float* dx, int N, int D1, int H1, int W1, int Cl, int Cs) {
-    return convtr3d_dgrad_t8_impl(device, stream, dt8, packed, x_mask, dx, N, D1, H1, W1, Cl, Cs, 0);
+    return convtr3d_dgrad_t8_impl(device, stream, dt8, packed, x_mask, dx, N, D1, H1, W1, Cl, Cs, 0, nullptr, 0);
 }
 
 extern "C" int u3d_convtr3d_dgrad_t8_b16(int device, u3d_stream_t stream, const void* dt8, const void* packed, const void* x_mask,
                                          void* dx, int N, int D1, int H1, int W1, int Cl, int Cs) {
-    return convtr3d_dgrad_t8_impl(device, stream, (const float*)dt8, packed, (const float*)x_mask, (float*)dx, N, D1, H1, W1, Cl, Cs, 1);
+    return convtr3d_dgrad_t8_impl(device, stream, (const float*)dt8, packed, (const float*)x_mask, (float*)dx, N, D1, H1, W1, Cl, Cs, 1, nullptr, 0);
+}
+
+extern "C" int u3d_convtr3d_dgrad_t8_ex(int device, u3d_stream_t stream, const float* dt8, const void* packed, const float* x_mask,
+                                        float* dx, int N, int D1, int H1, int W1, int Cl, int Cs, float* workspace, long long workspace_floats) {
+    return convtr3d_dgrad_t8_impl(device, stream, dt8, packed, x_mask, dx, N, D1, H1, W1, Cl, Cs, 0, workspace, workspace_floats);
+}
+
+extern "C" int u3d_convtr3d_dgrad_t8_b16_ex(int device, u3d_stream_t stream, const void* dt8, const void* packed, const void* x_mask,
+                                            void* dx, int N, int D1, int H1, int W1, int Cl, int Cs, float* workspace,
+                                            long long workspace_floats) {
+    return convtr3d_dgrad_t8_impl(device, stream, (const float*)dt8, packed, (const float*)x_mask, (float*)dx, N, D1, H1, W1, Cl, Cs, 1, workspace,
+                                  workspace_floats);
 }
 
 extern "C" long long u3d_convtr3d_wgrad_t8_workspace_floats(int N, int D1, int H1, int W1, int Cl, int Cs) {

@@ -433,14 +433,17 @@ class ResUNetEngine(UNet3DEngine):
                 dt8 = _empty((Nl, D1, H1, W1, 8 * Cs), dtype=self.adt, device=dev)
                 nat.call("u3d_nearest_sum_bwd_t8" + sfx, dev.index, _stream(dev), _p(dj), _p(lz), _p(ly), _p(lx), Nl, Ds, Hs, Ws, Dt, Ht,
                          Wt, Cs, _p(dt8))
-                need = nat.get_lib().u3d_convtr3d_wgrad_t8_workspace_floats(Nl, D1, H1, W1, Cl, Cs)
+                lib = nat.get_lib()
+                need = max(lib.u3d_convtr3d_wgrad_t8_workspace_floats(Nl, D1, H1, W1, Cl, Cs),
+                           lib.u3d_convtr3d_dgrad_t8_workspace_floats(Nl, D1, H1, W1, Cl, Cs))  # (both kernels: same stream, one after the other)
                 wsb = cx.ensure_ws(need)
                 nat.call("u3d_convtr3d_wgrad_t8" + sfx, dev.index, _stream(dev), _p(xl), _p(dt8),
                          _p(gview(self._pindex[id(up.weight)])), Nl, D1, H1, W1, Cl, Cs, _p(wsb), wsb.numel(),
                          flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
                 dxl = _empty_like(xl)
-                nat.call("u3d_convtr3d_dgrad_t8" + sfx, dev.index, _stream(dev), _p(dt8), _p(self._packed_convtr_t8(up.weight, 1, dev)),
-                         _p(xl) if mk else None, _p(dxl), Nl, D1, H1, W1, Cl, Cs, flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
+                nat.call("u3d_convtr3d_dgrad_t8" + sfx + "_ex", dev.index, _stream(dev), _p(dt8), _p(self._packed_convtr_t8(up.weight, 1, dev)),
+                         _p(xl) if mk else None, _p(dxl), Nl, D1, H1, W1, Cl, Cs, _p(wsb), wsb.numel(),
+                         flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
                 del dt8
                 dz = dxl  # ReLU blocks: masked by (x_low > 0)
                 continue

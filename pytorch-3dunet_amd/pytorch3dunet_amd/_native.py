@@ -273,6 +273,11 @@ _PROTOS = {
     "u3d_pack_convtr3d_t8": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "u3d_convtr3d_fwd_t8": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
     "u3d_convtr3d_dgrad_t8": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "u3d_convtr3d_dgrad_t8_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "u3d_convtr3d_dgrad_t8_ex": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                         c_void_p, c_int64]),
+    "u3d_convtr3d_dgrad_t8_b16_ex": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                             c_void_p, c_int64]),
     "u3d_convtr3d_wgrad_t8_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "u3d_convtr3d_wgrad_t8": (
         c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64]),
@@ -345,7 +350,7 @@ def get_lib():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.u3d_version() < 116:
+        if lib.u3d_version() < 117:
             raise U3DError("libu3d_hip.so is older than the Python host code")
         for kv in os.environ.get("U3D_TUNE", "").split(","):  # A/B knobs of u3d_set_tuning, e.g. U3D_TUNE=8:256,9:1 (results never change)
             if ":" in kv:

@@ -395,8 +395,8 @@ def test_model_with_bf16_activation_storage_against_the_storage_emulation():
     finally:
         orc.BF16_OPERANDS = orc.BF16_STORAGE = False
     logits, loss, grads, names = _step(model, x, t)
-    b16 = {n for n in names if n.endswith("_b16")}
-    assert {"u3d_conv3d_bf16_ex_b16", "u3d_conv3d_wgrad_bf16_b16", "u3d_convtr3d_fwd_t8_b16", "u3d_convtr3d_dgrad_t8_b16",
+    b16 = {n for n in names if n.endswith("_b16") or n.endswith("_b16_ex")}
+    assert {"u3d_conv3d_bf16_ex_b16", "u3d_conv3d_wgrad_bf16_b16", "u3d_convtr3d_fwd_t8_b16", "u3d_convtr3d_dgrad_t8_b16_ex",
             "u3d_convtr3d_wgrad_t8_b16", "u3d_conv1x1_fwd_b16", "u3d_conv1x1_bwd_b16", "u3d_maxpool2_fwd_b16", "u3d_maxpool2_bwd_merge_b16",
             "u3d_nearest_add_fwd_t8_b16", "u3d_nearest_sum_bwd_t8_b16", "u3d_gn_bwd_apply_b16", "u3d_conv1x1_head_fwd_b16",
             "u3d_conv1x1_head_bwd_b16"} <= b16, names

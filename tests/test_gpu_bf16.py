@@ -367,7 +367,8 @@ def _t_to_t8(t, D1, H1, W1):
 
 
 @pytest.mark.parametrize("shape,Cl,Cs", [((1, 5, 10, 10), 64, 32), ((2, 4, 9, 7), 32, 8), ((1, 16, 24, 40), 32, 16), ((1, 40, 48, 48), 32, 16),
-                                         ((1, 6, 10, 12), 128, 64)])  # (Cs = 64: a block / chunk = ONE output parity, dead taps skipped)
+                                         ((1, 6, 10, 12), 128, 64),   # (Cs = 64: a block / chunk = ONE output parity, dead taps skipped)
+                                         ((1, 3, 5, 6), 256, 128)])    # (64 chunks on 8 tile blocks: the split-K data gradient)
 def test_convtranspose3d_space_to_depth_bf16(shape, Cl, Cs):
     """forward, data gradient (with the ReLU mask of x) and weight gradient of nn.ConvTranspose3d(Cl, Cs, 3, stride=2, padding=1,
     bias=False) against torch with the operands rounded to bf16 the same way"""
@@ -411,6 +412,15 @@ def test_convtranspose3d_space_to_depth_bf16(shape, Cl, Cs):
     torch.cuda.synchronize()
     gx_masked = gx * (x > 0)
     assert (U.ncdhw(dx).double() - gx_masked).abs().max().item() < 1e-3 * gx.abs().max().item()
+    # the split-K entry point: same result up to the fp32 summation order (its scratch is 0 floats where the rule does not split)
+    nsk = lib.u3d_convtr3d_dgrad_t8_workspace_floats(N, D1, H1, W1, Cl, Cs)
+    wsk = torch.empty(max(nsk, 4), dtype=torch.float32, device=U.DEV)
+    dx2 = torch.full((N, D1, H1, W1, Cl), float("nan"), dtype=torch.float32, device=U.DEV)
+    nat.call("u3d_convtr3d_dgrad_t8_ex", 0, _stream(U.DEV), _p(dt8), _p(pk1), _p(xd), _p(dx2), N, D1, H1, W1, Cl, Cs, _p(wsk), nsk)
+    torch.cuda.synchronize()
+    assert (U.ncdhw(dx2).double() - gx_masked).abs().max().item() < 1e-3 * gx.abs().max().item()
+    if nsk == 0:
+        assert torch.equal(dx, dx2)
     assert torch.isfinite(dw).all()
     assert (dw.cpu().double() - gw).abs().max().item() < 1e-3 * gw.abs().max().item()
 
