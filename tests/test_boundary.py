@@ -49,6 +49,16 @@ def test_host_only_entry_points():
     assert lib.u3d_packed_weight_floats(32, 16, 1) == (1 * 54 + 5) * 1 * 256  # dgrad of 32->16: 32 output channels
     ws = lib.u3d_wgrad_workspace_floats(1, 64, 128, 128, 96, 32)
     assert ws % (27 * 1024) == 0 and 0 < ws < (1 << 28)
+    # bf16 path, host-only decisions (round 4): tile shape of the bf16-storage weight gradient per level of config 4 (4 x 8 x 8 wherever it
+    # wastes no more voxels than 2 x 8 x 16; the old kernel beyond 2 GiB; -1 for unsupported channel counts) ...
+    lv = [((80, 160, 160), 64), ((40, 80, 80), 128), ((20, 40, 40), 256), ((10, 20, 20), 512), ((5, 10, 10), 1024)]
+    assert [lib.u3d_conv3d_wgrad_bf16_b16_variant(1, *sh, c, c) for sh, c in lv] == [8, 8, 8, 8, 16]
+    assert lib.u3d_conv3d_wgrad_bf16_b16_variant(8, 80, 160, 160, 128, 128) == 0 and lib.u3d_conv3d_wgrad_bf16_b16_variant(1, 8, 8, 8, 48, 64) == -1
+    assert lib.u3d_wgrad_bf16_workspace_floats(1, 20, 40, 40, 256, 256) % (27 * 2048) == 0
+    # ... and the split-K rule of the transposed convolution's data gradient: only the two bottom levels ask for scratch
+    t8 = [(5, 10, 10, 1024, 512), (10, 20, 20, 512, 256), (20, 40, 40, 256, 128), (40, 80, 80, 128, 64)]
+    need = [lib.u3d_convtr3d_dgrad_t8_workspace_floats(1, *a) for a in t8]
+    assert need[0] == 8 * 500 * 1024 and need[1] == 5 * 4000 * 512 and need[2] == 0 and need[3] == 0, need
 
 
 def test_missing_library_fails_loudly(monkeypatch):
