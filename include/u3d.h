@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define U3D_VERSION 117 /* 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K) */
+#define U3D_VERSION 118 /* 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K); 118: u3d_se_*_b16 */
 
 #define U3D_OK 0
 #define U3D_EINVAL (-1)  /* bad shape / argument */
@@ -565,6 +565,16 @@ int u3d_conv1x1_head_fwd_b16(int device, u3d_stream_t stream, const void* x, con
                              int Cin, int Cout, int act, float* logits, float* probs);
 int u3d_conv1x1_head_bwd_b16(int device, u3d_stream_t stream, const float* dlogits, const void* x, const float* w, int N, int64_t V,
                              int Cin, int Cout, int relu_mask, void* dx, double* acc);
+/* squeeze-and-excitation gates (se.py:18-114, ResNetBlockSE buildingblocks.py:291-307) on bf16 block outputs: y / out / dout / the
+ * returned gradient are bf16; the channel gate gc, the spatial gate a, d logit_s and every sum stay fp32 / f64 (u3d_se_gate_fwd and
+ * u3d_se_gate_bwd touch no activation tensor and serve both storage modes) */
+int u3d_se_apply_fwd_b16(int device, u3d_stream_t stream, const void* y, const float* gc, const float* ws, const float* bs, int N,
+                         int64_t V, int C, int mode, void* out, float* a);
+int u3d_se_bwd_reduce_b16(int device, u3d_stream_t stream, const void* dout, const void* y, const float* gc, const float* a,
+                          const float* ws, int N, int64_t V, int C, int mode, float* dls, double* acc_gc, double* acc_ws);
+int u3d_se_bwd_apply_b16(int device, u3d_stream_t stream, const void* dout, const void* y, const float* gc, const float* a,
+                         const float* ws, const float* dls, const float* ds, int N, int64_t V, int C, int mode, int relu_mask,
+                         void* out);
 
 /* ---- layout: NCDHW <-> NDHWC for multi-channel model inputs ------------------------------------ */
 int u3d_ncdhw_to_ndhwc(int device, u3d_stream_t stream, const float* src, float* dst, int N, int C, int64_t V);

@@ -54,10 +54,11 @@ __global__ __launch_bounds__(256) void se_fc_rows_kernel(const double* __restric
 }
 
 // ---- spatial gate + apply: LPV lanes share one voxel, lane `sub` owns channel quads sub, sub+LPV, ... (<= 4 of them) ----
-template <int LPV>
-__global__ __launch_bounds__(256) void se_apply_fwd_kernel(const float* __restrict__ y, const float* __restrict__ gc,
+// (T: storage type of the activation tensors y / out / dout — float, or __bf16 for `activation_dtype: bf16`; gates and sums stay fp32)
+template <int LPV, typename T = float>
+__global__ __launch_bounds__(256) void se_apply_fwd_kernel(const T* __restrict__ y, const float* __restrict__ gc,
                                                            const float* __restrict__ ws, const float* __restrict__ bs, int N,
-                                                           long long V, int C, int mode, float* __restrict__ out,
+                                                           long long V, int C, int mode, T* __restrict__ out,
                                                            float* __restrict__ a_out) {
     const int t = threadIdx.x, sub = t & (LPV - 1);
     const int Q = C >> 2;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void se_apply_fwd_kernel(const float* __restri
             const int q = sub + it * LPV;
             yv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (q < Q) {
-                yv[it] = *reinterpret_cast<const f32x4*>(y + (size_t)idx * C + 4 * q);
+                yv[it] = u3d_ldq(y + (size_t)idx * C + 4 * q);
                 dot += yv[it][0] * wq[it][0] + yv[it][1] * wq[it][1] + yv[it][2] * wq[it][2] + yv[it][3] * wq[it][3];
             }
         }
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void se_apply_fwd_kernel(const float* __restri
 #pragma unroll
                     for (int e = 0; e < 4; ++e) g[e] = mode == 0 ? (yv[it][e] >= 0.f ? fmaxf(gv[e], a) : fminf(gv[e], a)) : gv[e];
                 }
-                *reinterpret_cast<f32x4*>(out + (size_t)idx * C + 4 * q) = yv[it] * g;
+                u3d_stq(out + (size_t)idx * C + 4 * q, yv[it] * g);
             }
         }
         if (a_out && sub == 0) a_out[idx] = a;
@@ -105,8 +106,8 @@ __global__ __launch_bounds__(256) void se_apply_fwd_kernel(const float* __restri
 // ---- backward reduction: grid (bx, N).  Per voxel: split dout*y between the two gates (torch.max backward: the larger
 //      operand takes the gradient, a tie halves it), d logit_s = da * a(1-a); per-thread register accumulators for
 //      d gc[n, c], d ws[c] over the block's voxels, folded through LDS (f64) into one global f64 atomic per block --------
-template <int LPV>
-__global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+template <int LPV, typename T = float>
+__global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y,
                                                             const float* __restrict__ gc, const float* __restrict__ a_in,
                                                             const float* __restrict__ ws, long long V, int C, int mode,
                                                             float* __restrict__ dls, double* __restrict__ acc_gc,
@@ -141,8 +142,8 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const float* __restr
             const int q = sub + it * LPV;
             yv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (q < Q) {
-                yv[it] = *reinterpret_cast<const f32x4*>(y + idx * C + 4 * q);
-                const f32x4 d = *reinterpret_cast<const f32x4*>(dout + idx * C + 4 * q);
+                yv[it] = u3d_ldq(y + idx * C + 4 * q);
+                const f32x4 d = u3d_ldq(dout + idx * C + 4 * q);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float tv = d[e] * yv[it][e];
@@ -251,18 +252,19 @@ __global__ void se_gate_wgrad_kernel(const float* __restrict__ dz2, const float*
 }
 
 // m = (dout * gate + dls[v] * ws[c] + ds[n,c]) * (y > 0)
-__global__ void se_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ y, const float* __restrict__ gc,
+template <typename T = float>
+__global__ void se_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y, const float* __restrict__ gc,
                                     const float* __restrict__ a_in, const float* __restrict__ ws, const float* __restrict__ dls,
                                     const float* __restrict__ ds, int N, long long V, int C, int mode, int relu_mask,
-                                    float* __restrict__ out) {
+                                    T* __restrict__ out) {
     const int Q = C >> 2;
     const long long total = (long long)N * V * Q;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int q = (int)(i % Q);
         const long long idx = i / Q;
         const int n = (int)(idx / V);
-        const f32x4 d = *reinterpret_cast<const f32x4*>(dout + (size_t)idx * C + 4 * q);
-        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + (size_t)idx * C + 4 * q);
+        const f32x4 d = u3d_ldq(dout + (size_t)idx * C + 4 * q);
+        const f32x4 yv = u3d_ldq(y + (size_t)idx * C + 4 * q);
         const float a = mode != 1 ? a_in[idx] : 0.f;
         const float dl = mode != 1 ? dls[idx] : 0.f;
         f32x4 g = {a, a, a, a}, wv = {0.f, 0.f, 0.f, 0.f}, dsv = {0.f, 0.f, 0.f, 0.f};
@@ -278,7 +280,7 @@ __global__ void se_bwd_apply_kernel(const float* __restrict__ dout, const float*
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = yv[e] > 0.f ? o[e] : 0.f;
         }
-        *reinterpret_cast<f32x4*>(out + (size_t)idx * C + 4 * q) = o;
+        u3d_stq(out + (size_t)idx * C + 4 * q, o);
     }
 }
 
@@ -290,18 +292,18 @@ inline int lanes_per_voxel(int Q) {  // largest power of two <= min(64, Q) (at l
 
 }  // namespace
 
-#define U3D_SE_DISPATCH(KERNEL, LPV_, ...)                                                              \
+#define U3D_SE_DISPATCH(KERNEL, T_, LPV_, ...)                                                          \
     do {                                                                                                \
         if (LPV_ == 4)                                                                                  \
-            hipLaunchKernelGGL((KERNEL<4>), __VA_ARGS__);                                               \
+            hipLaunchKernelGGL((KERNEL<4, T_>), __VA_ARGS__);                                           \
         else if (LPV_ == 8)                                                                             \
-            hipLaunchKernelGGL((KERNEL<8>), __VA_ARGS__);                                               \
+            hipLaunchKernelGGL((KERNEL<8, T_>), __VA_ARGS__);                                           \
         else if (LPV_ == 16)                                                                            \
-            hipLaunchKernelGGL((KERNEL<16>), __VA_ARGS__);                                              \
+            hipLaunchKernelGGL((KERNEL<16, T_>), __VA_ARGS__);                                          \
         else if (LPV_ == 32)                                                                            \
-            hipLaunchKernelGGL((KERNEL<32>), __VA_ARGS__);                                              \
+            hipLaunchKernelGGL((KERNEL<32, T_>), __VA_ARGS__);                                          \
         else                                                                                            \
-            hipLaunchKernelGGL((KERNEL<64>), __VA_ARGS__);                                              \
+            hipLaunchKernelGGL((KERNEL<64, T_>), __VA_ARGS__);                                          \
     } while (0)
 
 static int se_check(int N, int64_t V, int C, int mode, const char* what) {
@@ -325,8 +327,9 @@ extern "C" int u3d_se_gate_fwd(int device, u3d_stream_t stream, const double* ys
     return 0;
 }
 
-extern "C" int u3d_se_apply_fwd(int device, u3d_stream_t stream, const float* y, const float* gc, const float* ws,
-                                const float* bs, int N, int64_t V, int C, int mode, float* out, float* a) {
+template <typename T>
+static int se_apply_fwd_impl(int device, u3d_stream_t stream, const T* y, const float* gc, const float* ws, const float* bs, int N,
+                             int64_t V, int C, int mode, T* out, float* a) {
     U3D_ENTER(device);
     if (int e = se_check(N, V, C, mode, "u3d_se_apply_fwd")) return e;
     U3D_REQUIRE(y && out && (mode == 2 || gc) && (mode == 1 || (ws && bs)), "u3d_se_apply_fwd: missing gate inputs");
@@ -334,15 +337,26 @@ extern "C" int u3d_se_apply_fwd(int device, u3d_stream_t stream, const float* y,
     const long long total = (long long)N * V, vpb = 256 / lpv;
     long long blocks = (total + vpb - 1) / vpb;
     if (blocks > 8192) blocks = 8192;
-    U3D_SE_DISPATCH(se_apply_fwd_kernel, lpv, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, gc, ws, bs, N,
+    U3D_SE_DISPATCH(se_apply_fwd_kernel, T, lpv, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, gc, ws, bs, N,
                     (long long)V, C, mode, out, a);
     U3D_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int u3d_se_bwd_reduce(int device, u3d_stream_t stream, const float* dout, const float* y, const float* gc,
-                                 const float* a, const float* ws, int N, int64_t V, int C, int mode, float* dls, double* acc_gc,
-                                 double* acc_ws) {
+extern "C" int u3d_se_apply_fwd(int device, u3d_stream_t stream, const float* y, const float* gc, const float* ws,
+                                const float* bs, int N, int64_t V, int C, int mode, float* out, float* a) {
+    return se_apply_fwd_impl<float>(device, stream, y, gc, ws, bs, N, V, C, mode, out, a);
+}
+
+// bf16 activation storage (y, out: bf16 NDHWC; the spatial gate `a` and every table stay fp32)
+extern "C" int u3d_se_apply_fwd_b16(int device, u3d_stream_t stream, const void* y, const float* gc, const float* ws,
+                                    const float* bs, int N, int64_t V, int C, int mode, void* out, float* a) {
+    return se_apply_fwd_impl<__bf16>(device, stream, (const __bf16*)y, gc, ws, bs, N, V, C, mode, (__bf16*)out, a);
+}
+
+template <typename T>
+static int se_bwd_reduce_impl(int device, u3d_stream_t stream, const T* dout, const T* y, const float* gc, const float* a,
+                              const float* ws, int N, int64_t V, int C, int mode, float* dls, double* acc_gc, double* acc_ws) {
     U3D_ENTER(device);
     if (int e = se_check(N, V, C, mode, "u3d_se_bwd_reduce")) return e;
     U3D_REQUIRE(dout && y && (mode == 2 || (gc && acc_gc)) && (mode == 1 || (a && ws && dls && acc_ws)),
@@ -352,10 +366,22 @@ extern "C" int u3d_se_bwd_reduce(int device, u3d_stream_t stream, const float* d
     long long bx = (V + vpb - 1) / vpb;
     const long long cap = 1024 / N > 1 ? 1024 / N : 1;
     if (bx > cap) bx = cap;
-    U3D_SE_DISPATCH(se_bwd_reduce_kernel, lpv, dim3((unsigned)bx, (unsigned)N), dim3(256), 0, (hipStream_t)stream, dout, y, gc, a,
+    U3D_SE_DISPATCH(se_bwd_reduce_kernel, T, lpv, dim3((unsigned)bx, (unsigned)N), dim3(256), 0, (hipStream_t)stream, dout, y, gc, a,
                     ws, (long long)V, C, mode, dls, acc_gc, acc_ws);
     U3D_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int u3d_se_bwd_reduce(int device, u3d_stream_t stream, const float* dout, const float* y, const float* gc,
+                                 const float* a, const float* ws, int N, int64_t V, int C, int mode, float* dls, double* acc_gc,
+                                 double* acc_ws) {
+    return se_bwd_reduce_impl<float>(device, stream, dout, y, gc, a, ws, N, V, C, mode, dls, acc_gc, acc_ws);
+}
+
+extern "C" int u3d_se_bwd_reduce_b16(int device, u3d_stream_t stream, const void* dout, const void* y, const float* gc,
+                                     const float* a, const float* ws, int N, int64_t V, int C, int mode, float* dls, double* acc_gc,
+                                     double* acc_ws) {
+    return se_bwd_reduce_impl<__bf16>(device, stream, (const __bf16*)dout, (const __bf16*)y, gc, a, ws, N, V, C, mode, dls, acc_gc, acc_ws);
 }
 
 extern "C" int u3d_se_gate_bwd(int device, u3d_stream_t stream, const double* acc_gc, const float* gc, const float* h,
@@ -376,17 +402,30 @@ extern "C" int u3d_se_gate_bwd(int device, u3d_stream_t stream, const double* ac
     return 0;
 }
 
-extern "C" int u3d_se_bwd_apply(int device, u3d_stream_t stream, const float* dout, const float* y, const float* gc,
-                                const float* a, const float* ws, const float* dls, const float* ds, int N, int64_t V, int C,
-                                int mode, int relu_mask, float* out) {
+template <typename T>
+static int se_bwd_apply_impl(int device, u3d_stream_t stream, const T* dout, const T* y, const float* gc, const float* a,
+                             const float* ws, const float* dls, const float* ds, int N, int64_t V, int C, int mode, int relu_mask, T* out) {
     U3D_ENTER(device);
     if (int e = se_check(N, V, C, mode, "u3d_se_bwd_apply")) return e;
     U3D_REQUIRE(dout && y && out && (mode == 2 || (gc && ds)) && (mode == 1 || (a && ws && dls)), "u3d_se_bwd_apply: missing argument");
     const long long total = (long long)N * V * (C / 4);
     long long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(se_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dout, y, gc, a, ws, dls, ds, N,
+    hipLaunchKernelGGL(se_bwd_apply_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dout, y, gc, a, ws, dls, ds, N,
                        (long long)V, C, mode, relu_mask, out);
     U3D_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int u3d_se_bwd_apply(int device, u3d_stream_t stream, const float* dout, const float* y, const float* gc,
+                                const float* a, const float* ws, const float* dls, const float* ds, int N, int64_t V, int C,
+                                int mode, int relu_mask, float* out) {
+    return se_bwd_apply_impl<float>(device, stream, dout, y, gc, a, ws, dls, ds, N, V, C, mode, relu_mask, out);
+}
+
+extern "C" int u3d_se_bwd_apply_b16(int device, u3d_stream_t stream, const void* dout, const void* y, const float* gc,
+                                    const float* a, const float* ws, const float* dls, const float* ds, int N, int64_t V, int C,
+                                    int mode, int relu_mask, void* out) {
+    return se_bwd_apply_impl<__bf16>(device, stream, (const __bf16*)dout, (const __bf16*)y, gc, a, ws, dls, ds, N, V, C, mode, relu_mask,
+                                     (__bf16*)out);
 }

@@ -63,8 +63,6 @@ class ResUNetEngine(UNet3DEngine):
             return "explicit upsample='deconv' (concat joining)"
         for _, bm in self.enc + [(None, b) for _, b in self.dec]:
             C = bm.conv2.conv.in_channels
-            if getattr(bm, "se_module", None) is not None:
-                return "squeeze-and-excitation blocks"
             if C % 64 != 0:
                 return f"a block of {C} channels (multiples of 64: bf16 forward, data- and weight-gradient kernels)"
         for ct, _ in self.dec:
@@ -158,7 +156,7 @@ class ResUNetEngine(UNet3DEngine):
             ws, bs = sse.conv.weight.detach().view(C), sse.conv.bias.detach()
             st["a"] = _empty((N * V,), dtype=_F32, device=dev)
         out = _empty_like(y)
-        nat.call("u3d_se_apply_fwd", dev.index, _stream(dev), _p(y), _p(st["gc"]), _p(ws), _p(bs), N, V, C, mode, _p(out),
+        nat.call("u3d_se_apply_fwd" + ("_b16" if self.act_bf16 else ""), dev.index, _stream(dev), _p(y), _p(st["gc"]), _p(ws), _p(bs), N, V, C, mode, _p(out),
                  _p(st["a"]))
         st["out"] = out
         return st
@@ -174,7 +172,7 @@ class ResUNetEngine(UNet3DEngine):
         acc_ws = pool.take(C + 1) if sse is not None else None
         dls = _empty((N * V,), dtype=_F32, device=dev) if sse is not None else None
         ws = sse.conv.weight.detach().view(C) if sse is not None else None
-        nat.call("u3d_se_bwd_reduce", dev.index, _stream(dev), _p(dout), _p(y), _p(se["gc"]), _p(se["a"]), _p(ws), N, V, C, mode,
+        nat.call("u3d_se_bwd_reduce" + ("_b16" if self.act_bf16 else ""), dev.index, _stream(dev), _p(dout), _p(y), _p(se["gc"]), _p(se["a"]), _p(ws), N, V, C, mode,
                  _p(dls), _p(acc_gc), _p(acc_ws))
         ds = None
         if cse is not None:
@@ -191,7 +189,7 @@ class ResUNetEngine(UNet3DEngine):
             assert self.poffs[jb] == self.poffs[jw] + C
             nat.call("u3d_cvt_f64_f32", dev.index, _stream(dev), _p(acc_ws), _p(gview(jw)), C + 1)
         m_ = _empty_like(y)
-        nat.call("u3d_se_bwd_apply", dev.index, _stream(dev), _p(dout), _p(y), _p(se["gc"]), _p(se["a"]), _p(ws), _p(dls), _p(ds),
+        nat.call("u3d_se_bwd_apply" + ("_b16" if self.act_bf16 else ""), dev.index, _stream(dev), _p(dout), _p(y), _p(se["gc"]), _p(se["a"]), _p(ws), _p(dls), _p(ds),
                  N, V, C, mode, self.mask, _p(m_))
         return m_
 

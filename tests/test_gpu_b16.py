@@ -382,10 +382,12 @@ def _step(model, x, t):
     return logits.detach().cpu(), loss.item(), {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}, set(prof.summary())
 
 
-def test_model_with_bf16_activation_storage_against_the_storage_emulation():
+@pytest.mark.parametrize("net", ["ResidualUNet3D", "ResidualUNetSE3D"])
+def test_model_with_bf16_activation_storage_against_the_storage_emulation(net):
+    """(ResidualUNetSE3D since round 4: the squeeze-and-excitation gates read and write bf16 block outputs, `u3d_se_*_b16`)"""
     import unet3d_oracle as orc
 
-    model, x, t = _prep(dict(compute_dtype="bf16", activation_dtype="bf16"))
+    model, x, t = _prep(dict(name=net, compute_dtype="bf16", activation_dtype="bf16"))
     assert model._get_engine().act_bf16
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     _, l32, _, g32 = orc.forward_backward(sd, x, t, 8, True, True, "bce_dice")
@@ -400,13 +402,15 @@ def test_model_with_bf16_activation_storage_against_the_storage_emulation():
             "u3d_convtr3d_wgrad_t8_b16", "u3d_conv1x1_fwd_b16", "u3d_conv1x1_bwd_b16", "u3d_maxpool2_fwd_b16", "u3d_maxpool2_bwd_merge_b16",
             "u3d_nearest_add_fwd_t8_b16", "u3d_nearest_sum_bwd_t8_b16", "u3d_gn_bwd_apply_b16", "u3d_conv1x1_head_fwd_b16",
             "u3d_conv1x1_head_bwd_b16"} <= b16, names
+    if net == "ResidualUNetSE3D":
+        assert {"u3d_se_apply_fwd_b16", "u3d_se_bwd_reduce_b16", "u3d_se_bwd_apply_b16"} <= b16 and not ({"u3d_se_apply_fwd", "u3d_se_bwd_apply"} & names), names
     # nothing of the fp32-storage family may have run beside them
     assert not ({"u3d_conv3d_bf16_ex", "u3d_conv3d_wgrad_bf16", "u3d_gn_bwd_apply", "u3d_gn_bwd_apply_add", "u3d_maxpool2_fwd",
                  "u3d_conv1x1_fwd", "u3d_conv3d", "u3d_conv3d_ex", "u3d_conv3d_wgrad"} & names), names
     keys = list(g32)
     cat = lambda d: torch.cat([d[k].flatten().double() for k in keys])  # noqa: E731
     ours, em, ref = cat(grads), cat(gem), cat(g32)
-    rec = dict(test="bf16_storage_model", logits_vs_emu=orc.rel_err(logits, lem), logits_vs_fp32=orc.rel_err(logits, l32),
+    rec = dict(test="bf16_storage_model", net=net, logits_vs_emu=orc.rel_err(logits, lem), logits_vs_fp32=orc.rel_err(logits, l32),
                emu_vs_fp32_logits=orc.rel_err(lem, l32), grad_vs_emu=((ours - em).norm() / em.norm()).item(),
                grad_vs_fp32=((ours - ref).norm() / ref.norm()).item(), emu_vs_fp32_grad=((em - ref).norm() / ref.norm()).item())
     diag(**rec)

@@ -325,19 +325,22 @@ def test_config5_standard_predictor_on_the_full_volume():
 
 
 @pytest.mark.timeout(1500)
-def test_config5_bf16_predictor_against_the_bf16_operand_emulation(monkeypatch):
+@pytest.mark.parametrize("f_maps,storage", [([32, 64, 128], False), ([64, 128], True)])
+def test_config5_bf16_predictor_against_the_bf16_operand_emulation(monkeypatch, f_maps, storage):
     """BASELINE config 5 in `compute_dtype: bf16`: `predict_volume` — the device-resident form of
     StandardPredictor's loop, predictor.py:112-214 — with a ResidualUNetSE3D whose 3x3x3 convolutions run on the bf16 matrix pipe,
     against the reference loop on the host (oracle/predictor_oracle.py) driving the oracle's EMULATION of the same arithmetic
-    (oracle.BF16_OPERANDS: bf16 operands, wide accumulation) and its fp32 form.  SE nets keep fp32 activation storage.  Gates as
-    for the training path: closer to the emulation than the emulation is to fp32, and within the stated band of fp32."""
+    (oracle.BF16_OPERANDS: bf16 operands, wide accumulation; + BF16_STORAGE where the product keeps bf16 tensors) and its fp32 form.
+    Widths that are multiples of 64 (config 5's f_maps = 64) run with bf16 ACTIVATION STORAGE since round 4 (the SE gates have `_b16`
+    forms); the 32-wide ladder keeps fp32 tensors.  Gates as for the training path: closer to the emulation than the emulation is to
+    fp32, and within the stated band of fp32."""
     import predictor_oracle as porc
     import unet3d_oracle as orc
     from pytorch3dunet_amd.predictor import predict_volume
     from pytorch3dunet_amd.unet3d.model import get_model
 
     torch.manual_seed(21)
-    cfg = dict(name="ResidualUNetSE3D", in_channels=3, out_channels=1, f_maps=[32, 64, 128], num_groups=8, final_sigmoid=True)
+    cfg = dict(name="ResidualUNetSE3D", in_channels=3, out_channels=1, f_maps=f_maps, num_groups=8, final_sigmoid=True)
     base = get_model(dict(cfg)).eval()
     with torch.no_grad():
         for k, p in base.named_parameters():
@@ -351,7 +354,7 @@ def test_config5_bf16_predictor_against_the_bf16_operand_emulation(monkeypatch):
     gm.load_state_dict(sd)
     gm = gm.to(U.DEV).eval()
     eng = gm._get_engine()
-    assert eng.bf16 and not eng.act_bf16
+    assert eng.bf16 and bool(eng.act_bf16) == storage
     n0 = nat.launch_count
     prof = nat.EventProfiler()
     nat.profiler = prof
@@ -360,23 +363,25 @@ def test_config5_bf16_predictor_against_the_bf16_operand_emulation(monkeypatch):
         torch.cuda.synchronize()
     finally:
         nat.profiler = None
-    assert nat.launch_count > n0 and "u3d_conv3d_bf16_ex" in prof.summary()
+    ran = set(prof.summary())
+    assert nat.launch_count > n0 and ("u3d_conv3d_bf16_ex_b16" if storage else "u3d_conv3d_bf16_ex") in ran
+    assert ("u3d_se_apply_fwd_b16" if storage else "u3d_se_apply_fwd") in ran, ran
     torch.set_num_threads(32)
 
     def host(x):
         return orc.model_forward(sd, x, cfg["num_groups"], True, True)[0]
 
     want32 = porc.standard_predict(host, raw, patch, stride, halo, batch_size=2)
-    orc.BF16_OPERANDS = True
+    orc.BF16_OPERANDS, orc.BF16_STORAGE = True, storage
     try:
         want16 = porc.standard_predict(host, raw, patch, stride, halo, batch_size=2)
     finally:
-        orc.BF16_OPERANDS = False
+        orc.BF16_OPERANDS = orc.BF16_STORAGE = False
     assert got.shape == want32.shape == (1,) + shape
     e_emu = float(np.abs(got - want16).max())
     e_32 = float(np.abs(got - want32).max())
     e_or = float(np.abs(want16 - want32).max())
-    diag(test="cfg5_bf16_predict", vs_emu=e_emu, vs_fp32=e_32, emu_vs_fp32=e_or)
+    diag(test="cfg5_bf16_predict", storage=storage, vs_emu=e_emu, vs_fp32=e_32, emu_vs_fp32=e_or)
     print(dict(vs_emu=e_emu, vs_fp32=e_32, emu_vs_fp32=e_or))
     # probabilities in [0, 1]: bf16 operands move them by ~1e-2 (the training-path tests: logits within 3e-2 of their range)
     assert e_emu < 0.75 * e_or and e_32 < 1.25 * e_or + 1e-3 and e_32 < 5e-2, (e_emu, e_32, e_or)
