@@ -119,7 +119,7 @@ def main():
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="per-GPU batch (default = BASELINE config 2)")
     ap.add_argument("--compute-dtype", default="fp32", choices=["fp32", "fp32_split"],
                     help="arithmetic of the TIMED model (default fp32 = fp32 MFMA; fp32_split is reported as an extra leg anyway)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the untimed-by-the-contract extra leg (fp32_split mode)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra legs outside the contract (reference step order, fp32_split, partial bf16)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -315,44 +315,56 @@ def main():
                 "loop": "forward, loss, loss.item() host sync, zero_grad, backward, Adam step (unet3d/trainer.py:231-246), eager launches",
             }
         if world == 1 and not use_dist and not args.no_extras and args.compute_dtype == "fp32":
-            # EXTRA leg, not the contract's `value`: the same step with the opt-in fp32_split convolutions (fp32 operands split
-            # exactly into three bf16 values, six partial products accumulated in fp32 on the bf16 MFMA pipe; weight gradients
-            # and the sub-pixel decoder kernels stay on the fp32 MFMA).  Same weights, same batch, same loss + Adam step.
-            torch.manual_seed(0)
-            model2 = UNet3D(compute_dtype="fp32_split", **MODEL_CFG).to(dev).train()
-            opt2 = torch.optim.Adam(model2.parameters(), lr=2e-4, weight_decay=1e-5)
-            # same weights, same batch, before any update: how far the two arithmetics are apart on the logits
-            torch.manual_seed(0)
-            model1 = UNet3D(**MODEL_CFG).to(dev).train()
-            with torch.no_grad():
-                l1 = model1(x, return_logits=True)[1]
-                l2 = model2(x, return_logits=True)[1]
-                logits_rel = float((l1 - l2).norm() / l1.norm())
-            del model1, l1, l2
+            # EXTRA legs, not the contract's `value`: the same step (same weights, same batch, same loss + Adam step) in the two opt-in
+            # arithmetics.  fp32_split: fp32 operands split exactly into three bf16 values, six partial products accumulated in fp32 on
+            # the bf16 MFMA pipe (forward / data gradient of the 3x3x3 convolutions; weight gradients and the sub-pixel decoder kernels
+            # stay on the fp32 MFMA).  bf16: REDUCED precision — bf16 MFMA operands wherever the bf16 kernels cover a layer of THIS
+            # model; UNet3D's virtual-concat convolutions (the sub-pixel kernels) and the first layer are not covered and stay fp32.
+            EXTRAS = (
+                ("fp32_split", "model key compute_dtype: fp32_split (or U3D_F32_SPLIT=1)",
+                 "fwd/dgrad 3x3x3 convs: 3xbf16 exact operand split, 6 bf16 MFMAs per fp32 multiply-add, fp32 accumulation; everything "
+                 "else as the default path"),
+                ("bf16", "model key compute_dtype: bf16 (or U3D_BF16=1)",
+                 "REDUCED precision, PARTIAL coverage on this model: bf16 MFMA operands (fp32 accumulation, fp32 tensors in HBM) for the "
+                 "single-source 3x3x3 convolutions — forward / data gradient with Cin % 16 == 0 and Cout % 32 == 0, weight gradient with "
+                 "Cin % 32 == 0 and Cout % 64 == 0; the decoders' first convolutions (virtual concat: sub-pixel kernels), the first layer and "
+                 "the remaining weight gradients run on the fp32 MFMA as in the default path"),
+            )
+            for mode, opt_in, arithmetic in EXTRAS:
+                torch.manual_seed(0)
+                model2 = UNet3D(compute_dtype=mode, **MODEL_CFG).to(dev).train()
+                opt2 = torch.optim.Adam(model2.parameters(), lr=2e-4, weight_decay=1e-5)
+                # same weights, same batch, before any update: how far the two arithmetics are apart on the logits
+                torch.manual_seed(0)
+                model1 = UNet3D(**MODEL_CFG).to(dev).train()
+                with torch.no_grad():
+                    l1 = model1(x, return_logits=True)[1]
+                    l2 = model2(x, return_logits=True)[1]
+                    logits_rel = float((l1 - l2).norm() / l1.norm())
+                del model1, l1, l2
 
-            def step2():
-                probs2, logits2 = model2(x, return_logits=True)
-                loss2 = criterion(logits2, target)
-                opt2.zero_grad(set_to_none=True)
-                loss2.backward()
-                opt2.step()
-                return loss2
+                def step2():
+                    probs2, logits2 = model2(x, return_logits=True)
+                    loss2 = criterion(logits2, target)
+                    opt2.zero_grad(set_to_none=True)
+                    loss2.backward()
+                    opt2.step()
+                    return loss2
 
-            for _ in range(args.warmup):
-                step2()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                loss2 = step2()
-            torch.cuda.synchronize()
-            el2 = time.perf_counter() - t1
-            out["extra_fp32_split"] = {
-                "value": round(B * args.steps / el2, 3), "unit": "patches/s", "ms_per_step": round(1000.0 * el2 / args.steps, 3),
-                "opt_in": "model key compute_dtype: fp32_split (or U3D_F32_SPLIT=1)", "final_loss": round(loss2.item(), 5),
-                "logits_rel_l2_vs_fp32_mfma_same_weights": float(f"{logits_rel:.3e}"),
-                "arithmetic": "fwd/dgrad 3x3x3 convs: 3xbf16 exact operand split, 6 bf16 MFMAs per fp32 multiply-add, fp32 "
-                              "accumulation; everything else as the default path",
-            }
+                for _ in range(args.warmup):
+                    step2()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    loss2 = step2()
+                torch.cuda.synchronize()
+                el2 = time.perf_counter() - t1
+                out["extra_" + mode] = {
+                    "value": round(B * args.steps / el2, 3), "unit": "patches/s", "ms_per_step": round(1000.0 * el2 / args.steps, 3),
+                    "opt_in": opt_in, "final_loss": round(loss2.item(), 5),
+                    "logits_rel_l2_vs_fp32_mfma_same_weights": float(f"{logits_rel:.3e}"), "arithmetic": arithmetic,
+                }
+                del model2, opt2
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
