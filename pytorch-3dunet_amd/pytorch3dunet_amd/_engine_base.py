@@ -387,6 +387,7 @@ class Tape:
     x0: Optional[torch.Tensor] = None
     blocks: list = field(default_factory=list)  # residual executor: ResRec per block (encoders, then decoders)
     ups: list = field(default_factory=list)     # residual executor: UpRec per decoder
+    cats: dict = field(default_factory=dict)    # DoubleConv executor, bf16 mode: decoder index -> the VIRTUAL source whose concat was materialised
     lean: bool = False      # memory-lean mode (checkpoint_encoders): backward releases every block's tensors as soon as it is done
     consumed: bool = False  # ... so the tape can be walked only once
 

@@ -115,7 +115,7 @@ class ConvLayers:
         L = len(self.enc)
         for j, (c1, _) in enumerate(self.dec):
             skip_lvl, low_lvl = L - 2 - j, L - 1 - j
-            if skip_lvl < 0 or low_lvl >= len(dims):
+            if skip_lvl < 0 or low_lvl >= len(dims) or self._cat_bf16(c1):  # (bf16 mode: the concat is materialised, an ordinary layer)
                 continue
             C0 = self.enc[skip_lvl][2].conv.out_channels
             C1 = c1.conv.in_channels - C0

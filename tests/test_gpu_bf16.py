@@ -218,7 +218,8 @@ MODEL_CASES = [
     # config 4's model family at reduced width / size: every 3x3x3 conv has channel counts that are multiples of 32
     (dict(name="ResidualUNet3D", in_channels=1, out_channels=1, f_maps=[32, 64, 128], num_groups=8), (1, 1, 16, 32, 32)),
     (dict(name="ResidualUNet3D", in_channels=2, out_channels=2, f_maps=[64, 128], num_groups=8, final_sigmoid=False), (2, 2, 9, 13, 21)),
-    # UNet3D: the encoder / second decoder convs run bf16, the first layer and the virtual-concat convs stay fp32
+    # UNet3D: every conv whose channel counts fit runs bf16 — the decoders' first convs on a MATERIALISED concat since round 4 (the
+    # engine's _cat_bf16); the first layer stays fp32
     (dict(name="UNet3D", in_channels=1, out_channels=1, f_maps=32, num_levels=3, num_groups=8), (1, 1, 16, 32, 32)),
 ]
 
@@ -282,6 +283,8 @@ def test_model_bf16_against_bf16_operand_oracle_and_fp32_oracle(cfg, shape):
         orc.BF16_OPERANDS = False
     logits, loss, grads, names = _step(model, x, target, loss_name)
     assert "u3d_conv3d_bf16_ex" in names and "u3d_conv3d_wgrad_bf16" in names, names
+    if cfg["name"] == "UNet3D":  # the decoders' concat was written out and no sub-pixel (fp32) kernel ran on it
+        assert "u3d_nearest_cat_fwd" in names and not any(n.startswith("u3d_subpixel") for n in names), names
     keys = list(g32)
     cat = lambda d: torch.cat([d[k].flatten().double() for k in keys])  # noqa: E731
     ours, r16, r32 = cat(grads), cat(g16), cat(g32)
