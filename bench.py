@@ -320,7 +320,7 @@ def main():
             # the bf16 MFMA pipe (forward / data gradient of the 3x3x3 convolutions; weight gradients and the sub-pixel decoder kernels
             # stay on the fp32 MFMA).  bf16: REDUCED precision — bf16 MFMA operands wherever the bf16 kernels cover a layer of THIS
             # model: the decoders' first convolutions run on a materialised concat (no bf16 sub-pixel kernels exist), the first two
-            # layers and the weight gradients of the 32-output-channel layers stay on the fp32 MFMA.
+            # layers stay on the fp32 MFMA.
             EXTRAS = (
                 ("fp32_split", "model key compute_dtype: fp32_split (or U3D_F32_SPLIT=1)",
                  "fwd/dgrad 3x3x3 convs: 3xbf16 exact operand split, 6 bf16 MFMAs per fp32 multiply-add, fp32 accumulation; everything "
@@ -328,8 +328,8 @@ def main():
                 ("bf16", "model key compute_dtype: bf16 (or U3D_BF16=1)",
                  "REDUCED precision, PARTIAL coverage on this model: bf16 MFMA operands (fp32 accumulation, fp32 tensors in HBM) for every "
                  "3x3x3 convolution with Cin % 32 == 0 and Cout % 32 == 0 in forward / data gradient (the decoders' first convolutions on a "
-                 "materialised torch.cat((skip, upsampled)) instead of the fp32 path's virtual concat + sub-pixel kernels) and with Cout % 64 "
-                 "== 0 in the weight gradient; the first two layers (1 -> 16 -> 32) and the other weight gradients run on the fp32 MFMA"),
+                 "materialised torch.cat((skip, upsampled)) instead of the fp32 path's virtual concat + sub-pixel kernels) and in the weight "
+                 "gradient; the first two layers (1 -> 16 -> 32) run on the fp32 MFMA"),
             )
             for mode, opt_in, arithmetic in EXTRAS:
                 torch.manual_seed(0)

@@ -415,7 +415,8 @@ int u3d_conv3d_f32s(int device, u3d_stream_t stream, const float* x, const float
 
 /* Weight gradient of the same convolution with bf16 operands / FP32 accumulation (autograd of trainer.py:245 for
  * buildingblocks.py:56): dw (Cout,Cin,3,3,3) fp32, reference layout, = sum over voxels of g(x)[v+tap] (x) dz[v] with
- * g = a*x + b zero padded.  Needs Cin % 32 == 0, Cout % 64 == 0 and a scratch buffer of
+ * g = a*x + b zero padded.  Needs Cin % 32 == 0, Cout % 32 == 0 (Cout % 64 == 32: 64-column blocks whose upper half is read as zero)
+ * and a scratch buffer of
  * u3d_wgrad_bf16_workspace_floats() floats (split partial sums, reduced in a fixed order: run-to-run identical). */
 int u3d_conv3d_wgrad_bf16_supported(int Cin, int Cout);
 long long u3d_wgrad_bf16_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);

@@ -1103,7 +1103,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wg
             const int zl = vv / (WG_TY * WG_TX), rem = vv - zl * (WG_TY * WG_TX);
             const int yl = rem / WG_TX, xl = rem - yl * WG_TX;
             const int z = tl.z0 + zl, y = tl.y0 + yl, xx = tl.x0 + xl;
-            if (z < p.D && y < p.H && xx < p.W)
+            if (z < p.D && y < p.H && xx < p.W && k0 + (B16 ? 8 : 4) * q < p.K)  // (K % 64 == 32: the block's upper columns do not exist)
                 v = *reinterpret_cast<const item_t*>(pdz + ((((size_t)tl.n * p.D + z) * p.H + y) * p.W + xx) * p.K + k0 + (B16 ? 8 : 4) * q);
         }
     };
@@ -1573,7 +1573,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_b16v2_kernel(const bf16_w
 // costs more than the GEMM at 1024 channels.
 __global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __restrict__ ws, int S, int C, int K, float* __restrict__ dw) {
     __shared__ float tile[64][28];
-    const int pco = K >> 6, P = (C >> 5) * pco;
+    const int pco = (K + 63) >> 6, P = (C >> 5) * pco;  // (K % 64 == 32: the last block's upper 32 columns are zeros, not written)
     const int pair = blockIdx.x >> 5, cil = blockIdx.x & 31;
     const int cib = pair / pco, cob = pair - cib * pco;
     const int t = threadIdx.x;
@@ -1589,14 +1589,14 @@ __global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __r
     const int ci = cib * 32 + cil;
     for (int i = t; i < 27 * 64; i += 256) {
         const int co = i / 27, tap = i - co * 27;
-        dw[((size_t)(cob * 64 + co) * C + ci) * 27 + tap] = tile[co][tap];
+        if (cob * 64 + co < K) dw[((size_t)(cob * 64 + co) * C + ci) * 27 + tap] = tile[co][tap];
     }
 }
 
 // few (pair, channel) rows but many splits (64-channel layers at full resolution): one thread per output element instead, so
 // that the sum over hundreds of splits is spread over the whole chip (the scattered 4-byte writes are few there)
 __global__ void wgrad_bf16_reduce_flat_kernel(const float* __restrict__ ws, int S, int C, int K, float* __restrict__ dw) {
-    const int pco = K >> 6, P = (C >> 5) * pco;
+    const int pco = (K + 63) >> 6, P = (C >> 5) * pco;
     const long long total = (long long)C * K * 27;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int co = (int)(i % K);  // read-coalesced order: co fastest, then ci, then tap
@@ -1620,7 +1620,7 @@ wgrad_plan plan_wgrad(int N, int D, int H, int W, int C, int K, bool x8 = false)
     q.ty = (H + WG_TY - 1) / WG_TY;
     q.tx = x8 ? (W + 7) / 8 : (W + WG_TX - 1) / WG_TX;
     q.tiles = N * q.tz * q.ty * q.tx;
-    q.P = (C / 32) * (K / 64);
+    q.P = (C / 32) * ((K + 63) / 64);
     // every block writes its 27 x 32 x 64 partial sums (221 KB) and the reduction reads them back: the block count is the
     // split traffic.  Measured on config 4 (profiles/r03e): 1024 blocks 7.2 ms per step, 512 5.75, 256 (one per CU — the kernel
     // double-buffers inside the block) 5.13
@@ -1635,7 +1635,9 @@ wgrad_plan plan_wgrad(int N, int D, int H, int W, int C, int K, bool x8 = false)
 
 }  // namespace
 
-extern "C" int u3d_conv3d_wgrad_bf16_supported(int C, int K) { return (C > 0 && K > 0 && C % 32 == 0 && K % 64 == 0) ? 1 : 0; }
+// (K % 64 == 32 — e.g. the 32-output-channel layers of config 2's model — runs the 64-column blocks with the upper half's dz columns read
+// as zero: twice the MFMAs those 32 columns need, still several times the fp32 kernel's rate)
+extern "C" int u3d_conv3d_wgrad_bf16_supported(int C, int K) { return (C > 0 && K > 0 && C % 32 == 0 && K % 32 == 0) ? 1 : 0; }
 
 extern "C" long long u3d_wgrad_bf16_workspace_floats(int N, int D, int H, int W, int C, int K) {
     if (!u3d_conv3d_wgrad_bf16_supported(C, K) || N <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
@@ -1649,7 +1651,7 @@ extern "C" long long u3d_wgrad_bf16_workspace_floats(int N, int D, int H, int W,
 // with the same values; the 8-wide one sums the voxels in another order.
 static int wgrad_b16_variant(int N, int D, int H, int W, int C, int K) {
     const long long vox = (long long)N * D * H * W;
-    if (g_u3d_tune[7] == 1 || vox * (C > K ? C : K) * 2 >= (1ll << 31)) return 0;  // (buffer offsets are 32-bit)
+    if (g_u3d_tune[7] == 1 || K % 64 != 0 || vox * (C > K ? C : K) * 2 >= (1ll << 31)) return 0;  // (buffer offsets are 32-bit; whole 64-column blocks)
     if (g_u3d_tune[7] == 16 || g_u3d_tune[7] == 8) return g_u3d_tune[7];
     const long long v16 = (long long)((D + 1) / 2) * ((H + 7) / 8) * ((W + 15) / 16), v8 = (long long)((D + 3) / 4) * ((H + 7) / 8) * ((W + 7) / 8);
     return v8 <= v16 ? 8 : 16;  // (tiles of 256 voxels each)
@@ -1679,14 +1681,14 @@ static int conv3d_wgrad_bf16_impl(int device, u3d_stream_t stream, const float* 
                                   int N, int D, int H, int W, int C, int K, float* workspace, long long workspace_floats, int b16) {
     U3D_ENTER(device);
     U3D_REQUIRE(x && dz && dw && N > 0 && D > 0 && H > 0 && W > 0, "u3d_conv3d_wgrad_bf16: bad argument");
-    U3D_REQUIRE(u3d_conv3d_wgrad_bf16_supported(C, K), "u3d_conv3d_wgrad_bf16: needs Cin %% 32 == 0 and Cout %% 64 == 0 (got %d, %d)", C, K);
+    U3D_REQUIRE(u3d_conv3d_wgrad_bf16_supported(C, K), "u3d_conv3d_wgrad_bf16: needs Cin %% 32 == 0 and Cout %% 32 == 0 (got %d, %d)", C, K);
     U3D_REQUIRE((((uintptr_t)x | (uintptr_t)dz | (uintptr_t)affine) & 15) == 0, "u3d_conv3d_wgrad_bf16: 16-byte alignment");
     const int variant = b16 ? wgrad_b16_variant(N, D, H, W, C, K) : 0;
     const wgrad_plan q = plan_wgrad(N, D, H, W, C, K, variant == 8);
     const long long need = (long long)q.S * q.P * 27 * 2048;
     if (!workspace || workspace_floats < need)
         return u3d_set_err(U3D_EWORKSPACE, "u3d_conv3d_wgrad_bf16: workspace of %lld floats needed, %lld given", need, workspace_floats);
-    bf16_wgrad_params p{x, affine, dz, workspace, N, D, H, W, C, K, 1, q.tz, q.ty, q.tx, q.tiles, q.per_block, K / 64,
+    bf16_wgrad_params p{x, affine, dz, workspace, N, D, H, W, C, K, 1, q.tz, q.ty, q.tx, q.tiles, q.per_block, (K + 63) / 64,
                         g_u3d_tune[9] == 1 ? 0 : 1};
 #ifdef U3D_WG_TRACE
     constexpr int v2_extra = 8 * 12 * 14 * 4;

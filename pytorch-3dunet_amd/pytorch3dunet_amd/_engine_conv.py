@@ -358,7 +358,7 @@ class ConvLayers:
 
     # ---- backward kernel families ---------------------------------------------------------------------------------------------------
     _WGRAD_KERNELS = {
-        "bf16": "_wgrad_bf16",          # u3d_bf16.hip (needs Cout % 64 == 0)
+        "bf16": "_wgrad_bf16",          # u3d_bf16.hip (Cin % 32 == 0 and Cout % 32 == 0: every layer the bf16 forward covers)
         "subpixel": "_wgrad_subpixel",  # u3d_subpix.hip (upsampled channels) + u3d_conv.hip strided (skip channels)
         "fp32_side": "_wgrad_fp32_side",  # u3d_conv.hip on the side stream (U3D_SIDE_VOXELS, off by default)
         "fp32": "_wgrad_fp32",          # u3d_conv.hip
@@ -371,7 +371,7 @@ class ConvLayers:
     }
 
     def _wgrad_family(self, c: "_BwdCall") -> str:
-        if c.bf16 and c.Cout % 64 == 0:
+        if c.bf16 and c.Cout % 32 == 0:  # (Cout % 64 == 32 since round 4: 64-column blocks with a zero upper half)
             return "bf16"
         if c.rec.sub is not None:
             return "subpixel"
@@ -579,8 +579,7 @@ class ConvLayers:
                        lib.u3d_conv3d_workspace_floats(N, D, H, W, Cout, sub[0]))
         if not virtual and self._bf16_layer(Cin, Cout):
             need = lib.u3d_conv3d_bf16_workspace_floats(N, D, H, W, Cout, Cin)  # data gradient: roles swapped
-            wg = lib.u3d_wgrad_bf16_workspace_floats(N, D, H, W, Cin, Cout) if Cout % 64 == 0 else lib.u3d_wgrad_workspace_floats(
-                N, D, H, W, Cin, Cout)
+            wg = lib.u3d_wgrad_bf16_workspace_floats(N, D, H, W, Cin, Cout)
             return max(need, wg)
         return max(lib.u3d_wgrad_workspace_floats(N, D, H, W, Cin, Cout), lib.u3d_conv3d_workspace_floats(N, D, H, W, Cout, Cin))
 

@@ -103,6 +103,7 @@ def test_conv3d_bf16_b16_forward_and_data_gradient(shape, C, K, res, ks):
                                               ((2, 6, 24, 50), 32, 64, 5),    # ... walked by 5 blocks: tile loop across samples
                                               ((1, 7, 26, 66), 64, 128, 12),
                                               ((1, 12, 40, 40), 64, 64, 7)])   # (config 4's 40-wide level: the 8-wide tile by default)
+# (Cout % 64 == 32 runs the round-3 kernel with a masked upper half in both storage modes: tests/test_gpu_bf16.py::test_conv3d_wgrad_bf16)
 def test_conv3d_wgrad_bf16_b16(shape, C, K, blocks, with_affine):
     """bf16 storage.  The round-3 kernel (key 7 = 1) and the round-4 kernel on 2 x 8 x 16 tiles (key 7 = 16) reproduce the
     fp32-storage kernel fed with bf16-representable values bit for bit (same operands, same MFMA order per accumulator); the

@@ -157,6 +157,8 @@ def wgrad_bf16(x, dz, affine=None):
     ((1, 16, 24, 40), 64, 128),   # 2 x 2 pairs
     ((1, 32, 64, 64), 32, 64),    # many tiles per split
     ((1, 5, 10, 10), 128, 256),   # bottom-of-the-U shape: one tile per split, many pairs
+    ((1, 8, 24, 40), 96, 32),     # Cout % 64 == 32 (config 2's dec2.c1): 64-column blocks, upper half read as zero
+    ((2, 6, 9, 17), 32, 96),      # ... with a whole block before the half one
 ])
 def test_conv3d_wgrad_bf16(shape, C, K):
     N, D, H, W = shape
