@@ -123,6 +123,25 @@ def test_nearest_add_and_sum(N, C, lo, hi):
     assert U.relerr(U.ncdhw(dtd), t.grad) < 1e-5
 
 
+@pytest.mark.parametrize("N,Cs,Ct,lo,hi", [(2, 32, 64, (4, 6, 5), (8, 12, 10)),   # channel quads (16-byte path), exact 2x
+                                          (1, 8, 4, (3, 4, 5), (5, 7, 9)),        # quads, a (2n-1)-sized tensor resized to the skip
+                                          (1, 6, 5, (2, 3, 4), (4, 6, 8))])       # element path
+def test_nearest_cat(N, Cs, Ct, lo, hi):
+    """torch.cat((skip, F.interpolate(t, size=skip.shape[2:])), dim=1) (buildingblocks.py:491 after :650-651 / :614) written out:
+    the explicit-`deconv` residual decoders and, in bf16 mode, the DoubleConv decoders' first convolution read it"""
+    U, nat, VSrc, _maps, _p, _stream = _mods()
+    torch.manual_seed(Cs + Ct)
+    t = torch.randn(N, Ct, *lo)
+    skip = torch.randn(N, Cs, *hi)
+    want = torch.cat((skip, F.interpolate(t, size=hi)), dim=1)
+    maps = [_maps(U.DEV, a, b)[0] for a, b in zip(lo, hi)]
+    td, sd = U.ndhwc(t), U.ndhwc(skip)
+    out = torch.full((N, *hi, Cs + Ct), float("nan"), device=U.DEV)
+    nat.call("u3d_nearest_cat_fwd", 0, _stream(U.DEV), _p(sd), _p(td), _p(maps[0]), _p(maps[1]), _p(maps[2]), N, *hi, *lo, Cs, Ct, _p(out))
+    torch.cuda.synchronize()
+    assert torch.equal(U.ncdhw(out).cpu(), want)
+
+
 @pytest.mark.parametrize("N,Cin,Cout,size", [(1, 16, 32, (8, 16, 16)), (2, 32, 32, (4, 8, 8)), (1, 8, 12, (5, 9, 7)),
                                              (1, 64, 96, (4, 8, 16)), (1, 6, 5, (3, 4, 5))])
 def test_conv3d_residual_epilogue(N, Cin, Cout, size):
