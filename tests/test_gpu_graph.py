@@ -63,6 +63,10 @@ CASES = [
     ("UNet3D", dict(f_maps=[8, 16, 32], num_groups=4), [(2, 1, 8, 16, 16), (1, 1, 17, 33, 35), (2, 1, 8, 16, 16), (1, 1, 17, 33, 35)]),
     ("ResidualUNet3D", dict(f_maps=[8, 16, 32], num_groups=4, num_levels=3), [(1, 1, 16, 32, 32)] * 3 + [(1, 1, 8, 16, 24)]),
     ("ResidualUNetSE3D", dict(f_maps=[8, 16, 32], num_groups=4, num_levels=3), [(1, 1, 16, 32, 32)] * 3),
+    # bf16 mode (round 4): DoubleConv decoders on a materialised concat + the bf16 weight gradient with 32 output channels ...
+    ("UNet3D", dict(f_maps=32, num_levels=3, num_groups=8, compute_dtype="bf16"), [(1, 1, 16, 32, 32)] * 3),
+    # ... and an SE net with bf16 activation storage (the `_b16` gates)
+    ("ResidualUNetSE3D", dict(f_maps=[64, 128], num_groups=8, compute_dtype="bf16"), [(1, 1, 8, 16, 16)] * 3),
 ]
 
 
