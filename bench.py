@@ -209,12 +209,25 @@ def main():
         prof = nat.EventProfiler(flops_only=True, only=None if bracket_all else dominant,
                                  prealloc=2 * args.steps * ((sum(fam_calls.values()) if bracket_all else calls_per_step) + 4))
         nat.profiler = prof
+    # Python's cyclic collector: a full (generation 2) pass over this process's objects takes ~75 ms of HOST time, and whether one falls
+    # into the timed region depended on --steps / --warmup through the number of event objects allocated above (measured: 17.4 -> 24-28 ms
+    # per step at --steps 10 --warmup 1..3, the whole difference in the first timed step's enqueue).  Collect now and move everything
+    # alive into the permanent generation; the collector itself stays ON during the timed steps (their garbage is young and cheap).
+    import gc
+
+    gc.collect()
+    gc.freeze()
     barrier()
     t0 = time.perf_counter()
+    host_marks = []
     for _ in range(args.steps):
         loss = step()
+        if os.environ.get("U3D_BENCH_HOST_TRACE") == "1":
+            host_marks.append(time.perf_counter() - t0)  # (debugging aid: when each step's launches were all enqueued)
     barrier()
     elapsed = time.perf_counter() - t0
+    if host_marks and rank == 0:
+        print("host enqueue marks (ms):", [round(1000 * v, 1) for v in host_marks], "elapsed", round(1000 * elapsed, 1), file=sys.stderr)
     nat.profiler = None
     if use_dist:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -303,6 +316,7 @@ def main():
 
             for _ in range(2):
                 step_ref_order()
+            gc.collect()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(args.steps):
@@ -354,6 +368,7 @@ def main():
 
                 for _ in range(args.warmup):
                     step2()
+                gc.collect()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 for _ in range(args.steps):

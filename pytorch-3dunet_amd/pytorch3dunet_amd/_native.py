@@ -390,6 +390,11 @@ class EventProfiler:
         # freed): a timed region that creates ~50 events per step becomes host-bound (measured: 3.3 -> 12.4 ms of host time per
         # step, 17.5 -> 20 ms per step).  `prealloc` events are therefore created up front, outside any timed region.
         self._pool = [torch.cuda.Event(enable_timing=True) for _ in range(int(prealloc))]
+        for ev in self._pool:
+            ev.record()  # torch creates the HIP event lazily, at the first record(): force it NOW (measured: with few warm-up steps the
+                         # timed region otherwise paid ~75 ms of event creation, 17.4 -> 24 ms per step at --steps 10 --warmup 1..3)
+        if self._pool:
+            torch.cuda.synchronize()
         self.records = []  # (name, flops, start_event, end_event)
         self.only = set(only) if only else None  # bracket just these entry points (bench.py: the dominant family in the timed region)
         # flops_only: time only the MFMA families (calls that declare FLOPs) — two event packets per call cost ~1 us of
