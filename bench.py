@@ -7,6 +7,7 @@ weights.  A "step" = forward + loss + backward (+ gradient all-reduce when N>1) 
 HBM.  One process per GPU (torch.distributed over RCCL); weak scaling: the per-GPU batch is fixed.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8 --steps 20 --warmup 3      # launches its own 8 ranks through torch.distributed.run
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus 8 --steps 20 --warmup 3
 
@@ -109,6 +110,28 @@ def pmc_traffic(family):
         return None, None
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without an external launcher: re-exec this command line under torch.distributed.run with N
+    local ranks (the reference itself is single-process `nn.DataParallel`, unet3d/trainer.py:202-205; here it is one process per
+    GPU).  Returns the launcher's exit code; the ranks inherit stdout, so rank 0's JSON line is the only line printed."""
+    import socket
+    import subprocess
+
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    have = torch.cuda.device_count()
+    assert have >= n, f"bench.py --gpus {n}: only {have} GPU(s) visible"
+    with socket.socket() as s:  # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.pop("U3D_BENCH_SELF_LAUNCH", None)  # (test hook: forces this path at --gpus 1 on a one-GPU box)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")             # (the launcher would set 1 and print a warning)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,9 +148,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("U3D_BENCH_SELF_LAUNCH") == "1"):
+        # plain `python bench.py --gpus N`: launch our own ranks (one process per GPU, the same command line the driver's
+        # torch.distributed.run form uses) and let rank 0's single JSON line through
+        raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     from pytorch3dunet_amd import _native as nat

@@ -70,7 +70,8 @@ int u3d_check_device(int device);
 /* Process-wide performance knobs for A/B measurements (never change results).
  * key 0: forced N-tiles per block of u3d_conv3d (1,2,3; 0 = automatic); key 1: wgrad split override; key 12: block slots the
  * persistent convolution grids leave FREE (of 2 per CU) so that kernels of other streams — RCCL's gradient all-reduce,
- * parallel.py — find room beside them; the other keys: see the list at the top of csrc/u3d_conv.hip (16 keys; the environment
+ * parallel.py — find room beside them (it shrinks the fp32 persistent grids of u3d_conv3d ONLY: the bf16 kernels and every other
+ * launch ignore it); the other keys: see the list at the top of csrc/u3d_conv.hip (16 keys; the environment
  * variable U3D_TUNE=key:value,... sets them at load time). */
 int u3d_set_tuning(int key, int value);
 /* Developer aid (tools/wave_timeline.py): while a device buffer is registered, u3d_conv3d launches an instrumented

@@ -1580,6 +1580,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __r
     const size_t split_stride = (size_t)P * 27 * 2048;
     for (int i = t; i < 27 * 64; i += 256) {
         const int tap = i >> 6, co = i & 63;
+        if (cob * 64 + co >= K) continue;  // K % 64 == 32: those workspace columns were never written (and are never stored)
         const size_t off = ((size_t)pair * 27 + tap) * 2048 + cil * 64 + co;
         double sum = 0.0;
         for (int s = 0; s < S; ++s) sum += (double)ws[(size_t)s * split_stride + off];

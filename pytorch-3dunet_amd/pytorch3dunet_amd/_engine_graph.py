@@ -46,14 +46,22 @@ class GraphStep:
         cur = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(dev)
         side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            # one eager step first: every lazily built constant (index maps, identity tables, the pack descriptor table, the
-            # library's function attributes) must exist before capture — host-to-device copies are illegal inside it
-            self.static_x.copy_(x)
-            engine.begin_forward(True)
-            logits, probs, tape = engine.forward(self.static_x, True)
-            engine.backward(tape, torch.zeros_like(logits), need_dx)
-            del logits, probs, tape
+        # the warm-up step and the capture run WITHOUT the data-parallel hook: a capture is a per-rank event (a new input
+        # shape, an LRU eviction, a re-attach on ONE rank), so nothing in it may issue a collective — the warm-up's gradients are
+        # garbage anyway.  Only `backward()` below, which every rank runs once per step, talks to RCCL.
+        self.sync = engine.grad_sync
+        engine.grad_sync = None
+        try:
+            with torch.cuda.stream(side):
+                # one eager step first: every lazily built constant (index maps, identity tables, the pack descriptor table, the
+                # library's function attributes) must exist before capture — host-to-device copies are illegal inside it
+                self.static_x.copy_(x)
+                engine.begin_forward(True)
+                logits, probs, tape = engine.forward(self.static_x, True)
+                engine.backward(tape, torch.zeros_like(logits), need_dx)
+                del logits, probs, tape
+        finally:
+            engine.grad_sync = self.sync
         cur.wait_stream(side)
         torch.cuda.synchronize(dev)
         self.pool = torch.cuda.graph_pool_handle()
@@ -68,7 +76,6 @@ class GraphStep:
         # capture and begins the next on the same stream and pool; backward() issues the real all-reduces eagerly between the replays
         # (trainer.py:202-205 is the loop this serves: one gradient exchange per step, overlapped with the rest of the backward).
         self.g_bwds = [torch.cuda.CUDAGraph()]
-        self.sync = engine.grad_sync
         self.buckets: list = []
         if self.sync is not None:
             engine.grad_sync = _CaptureSplit(self)

@@ -78,12 +78,30 @@ class TreeSync(GradSync):
         for bi, bucket in enumerate(self.buckets):
             for p in bucket:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+        # pass boundary: autograd skips its end-of-pass callbacks when `loss.backward()` RAISES after the first hook fired
+        # (OOM, an anomaly check, a hook of the caller) — `_in_backward` would stay set, and the next pass would neither reset its
+        # counters nor queue the callback.  The next forward of the model re-arms an aborted pass.
+        self._handles.append(model.register_forward_pre_hook(self._on_forward))
 
     def _make_hook(self, bi: int):
         def hook(_param):
             self._ready(bi)
 
         return hook
+
+    def _on_forward(self, _module, _args) -> None:
+        if self._in_backward:
+            # the previous backward never reached _end_of_backward: drop its half-sent state (the step was invalid on this rank;
+            # buckets it did launch were complete collectives, so the ranks' sequences still pair up)
+            self._in_backward = False
+            for work, _bucket in self._pending:
+                try:
+                    work.wait()
+                except Exception:
+                    pass
+            self._pending.clear()
+            self._left = [len(b) for b in self.buckets]
+            self._flat = [None, None]
 
     def _ready(self, bi: int) -> None:
         if self.world == 1 and not self.force_single:
@@ -165,7 +183,8 @@ def cu_budget(slots: Optional[int] = None) -> int:
     """Leave `slots` block slots of the persistent convolution grids free (of 2 per CU; `u3d_set_tuning` key 12) so that RCCL's
     all-reduce kernels find CUs with room beside them: the persistent grids otherwise own every CU's LDS and most of its registers,
     and a kernel of another stream makes no progress until they end (profiles/r03_overlap_probe.txt: 3 % of the exchange hidden).
-    Each slot costs 1/512 of the convolution throughput.  `slots=None` reads U3D_RCCL_SLOTS (default 0: right for small models, whose
+    Each slot costs 1/512 of the convolution throughput.  Key 12 acts on the fp32 persistent 3x3x3 convolution only — the bf16 kernels
+    (compute_dtype: bf16) and all other launches are not persistent-grid kernels and ignore it.  `slots=None` reads U3D_RCCL_SLOTS (default 0: right for small models, whose
     whole exchange is ~1 % of a step).  Process-wide; results never depend on it.  (A CU-MASKED compute queue — the textbook way to
     reserve whole CUs — was measured and rejected: the same kernels run 40-75 % slower on a queue masked to 248 of 256 CUs,
     profiles/r04_cu_mask_layer_bench_reserve8.txt.)"""

@@ -29,6 +29,11 @@ from .utils import get_class, number_of_features_per_level
 _THIS_MODULE = __name__
 
 
+def _mark_engine_stale(module, incompatible_keys):
+    """load_state_dict post-hook: parameter OBJECTS may have been replaced (assign=True) -> re-walk them on the next forward"""
+    object.__setattr__(module, "_engine_stale", True)
+
+
 class AbstractUNet(nn.Module):
     """Encoder-decoder skeleton shared by all variants (reference model.py:7-149)."""
 
@@ -118,7 +123,16 @@ class AbstractUNet(nn.Module):
         self._warned = False
         self._engine_stale = False
         # any load_state_dict on this module may have replaced parameter objects (assign=True): re-walk them on the next forward
-        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: object.__setattr__(module, "_engine_stale", True))
+        # (a module-level function, not a lambda: the hook dict is part of the module's pickled state — torch.save(model), mp.spawn)
+        self.register_load_state_dict_post_hook(_mark_engine_stale)
+
+    def __getstate__(self):
+        """torch.save(model) / pickle / copy.deepcopy: the executor (ctypes handles, device scratch, a reference back to this
+        module) is per-process state and is rebuilt by the next forward — the reference's models are plain picklable nn.Modules."""
+        state = dict(self.__dict__)
+        state["_engine"] = None
+        state["_engine_stale"] = False
+        return state
 
     # ------------------------------------------------------------------------------------------------
     @property
@@ -188,7 +202,10 @@ class AbstractUNet(nn.Module):
                     # was handed to the caller yet
                     object.__setattr__(self, "_engine_stale", True)  # -> full identity walk -> new executor (keeps the grad_sync hook)
                     return run_model(self._get_engine(), x)
-            why = ", ".join(self._native_blockers) or f"input dtype/rank {x.dtype}/{x.dim()}"
+            why = ", ".join(self._native_blockers) or (
+                f"input is {x.dim()}-D, the 3-D path takes (N,C,D,H,W)" if x.dim() != 5 else
+                f"input dtype {x.dtype}: the native path takes float32 tensors (pass x.float(); reduced-precision arithmetic is the "
+                "model key compute_dtype: bf16, not a half-precision input / model.half() / autocast)")
             eng = self.__dict__.get("_engine")
             if eng is not None and eng.grad_sync is not None and torch.is_grad_enabled():
                 # parallel.attach hooked the gradient exchange into the native executor: the module tree would train unsynchronised

@@ -3,6 +3,7 @@ the C-ABI library loads and exports every symbol include/u3d.h declares (no comp
 import ctypes
 import os
 import re
+import sys
 
 import pytest
 import torch
@@ -349,3 +350,39 @@ def test_one_backend_by_default_policy_for_uncovered_variants(monkeypatch):
     for m in (m2, m3):
         with pytest.raises(NotImplementedError):
             m._uncovered_on_hip("x")
+
+
+def test_bench_self_launch_fails_at_the_gpu_check_not_at_usage():
+    """`python bench.py --gpus 2` without torch.distributed.run launches its own ranks; on this CPU-only container that path must stop
+    at "needs an MI355X" (VERDICT r04 item 3), not at a usage message"""
+    import subprocess
+
+    if torch.cuda.is_available():
+        pytest.skip("CPU-container check")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                          capture_output=True, text=True, env=env, timeout=300)
+    assert proc.returncode != 0
+    assert "needs an MI355X" in proc.stderr and "launch with" not in proc.stderr, proc.stderr[-1500:]
+
+
+@pytest.mark.parametrize("cfg", ALL_CFGS[:4], ids=lambda c: c["name"])
+def test_models_pickle_and_torch_save_like_the_reference_modules(cfg, tmp_path):
+    """the reference's models are plain picklable nn.Modules (torch.save(model), mp.spawn arguments, copy.deepcopy): ADVICE r04 —
+    a lambda in the load_state_dict post-hook dict broke that"""
+    import copy
+    import pickle
+
+    torch.manual_seed(0)
+    model = M.get_model(dict(cfg))
+    blob = pickle.dumps(model)
+    twin = pickle.loads(blob)
+    path = tmp_path / "m.pt"
+    torch.save(model, path)
+    loaded = torch.load(path, weights_only=False)
+    for other in (twin, loaded, copy.deepcopy(model)):
+        assert type(other) is type(model) and other.__dict__.get("_engine") is None
+        for (k, a), (k2, b) in zip(model.state_dict().items(), other.state_dict().items()):
+            assert k == k2 and torch.equal(a, b)
+        other.load_state_dict(model.state_dict())          # the hook survives the round trip ...
+        assert other.__dict__["_engine_stale"] is True     # ... and still marks the executor stale

@@ -323,8 +323,9 @@ print("RESULT " + json.dumps(res))
     assert proc.returncode == 0, proc.stderr[-3000:]
     r = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
     for name in ("unet", "res"):
-        # eager: per_step collectives x 3 steps; graph: + those of the warm-up step GraphStep runs before it captures
-        assert r[name] == {"loss": True, "grads": True, "params": True, "launched_eager": 3 * per_step, "launched_graph": 4 * per_step,
+        # per_step collectives x 3 steps in BOTH modes: GraphStep's warm-up step and its capture issue no collective (a
+        # capture is a per-rank event — a new shape or an eviction on one rank must not unpair the ranks' collective sequences)
+        assert r[name] == {"loss": True, "grads": True, "params": True, "launched_eager": 3 * per_step, "launched_graph": 3 * per_step,
                            "captured": 1, "off_reason": None}, r
 
 
@@ -338,6 +339,19 @@ def test_bench_under_torch_distributed_run_one_rank():
     line = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1]
     r = json.loads(line)
     # [decoders | head], then the encoder levels deepest first in buckets of >= 1 MiB: enc3 (5.3 MB), enc2 (1.3 MB), enc1 + enc0
+    assert r["ranks_seen"] == {"world_size": 1, "backend": "nccl", "allreduce_per_step": 4}, r["ranks_seen"]
+    assert r["n_gpus"] == 1 and r["value"] > 0 and "roofline" in r
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` without an external launcher re-execs itself under torch.distributed.run (forced at N = 1 here:
+    the box has one GPU); the one JSON line comes from rank 0 of an RCCL group"""
+    proc = _spawn([sys.executable, "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                  {"HSA_ENABLE_IPC_MODE_LEGACY": "0", "U3D_BENCH_SELF_LAUNCH": "1"})
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    r = json.loads(lines[0])
     assert r["ranks_seen"] == {"world_size": 1, "backend": "nccl", "allreduce_per_step": 4}, r["ranks_seen"]
     assert r["n_gpus"] == 1 and r["value"] > 0 and "roofline" in r
 

@@ -87,6 +87,26 @@ def _worker(rank, world, port, out):
         model(shard).mean().backward()
         again = torch.cat([p.grad.flatten() for p in model.parameters()])
         assert torch.allclose(again, whole, atol=1e-6, rtol=1e-4) and sync2.launched == 6
+        # a backward that RAISES after the first hook fired (autograd then skips its end-of-pass callbacks) must not leave
+        # the pass flag set — the next forward re-arms, and the next backward is a complete, correctly paired exchange again
+        w_first = next(model.encoders.parameters())
+
+        def boom(_g):
+            raise ValueError("boom")
+
+        h = w_first.register_hook(boom)
+        model.zero_grad()
+        try:
+            model(shard).mean().backward()
+            raise AssertionError("the hook must abort this pass")
+        except ValueError:
+            pass
+        h.remove()
+        assert sync2._in_backward and sync2.launched == 7  # [decoders | head] went out, the encoder bucket never completed
+        model.zero_grad()
+        model(shard).mean().backward()
+        healed = torch.cat([p.grad.flatten() for p in model.parameters()])
+        assert torch.allclose(healed, whole, atol=1e-6, rtol=1e-4) and sync2.launched == 9 and not sync2._in_backward
         out.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         out.put((rank, repr(e)))
