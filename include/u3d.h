@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define U3D_VERSION 118 /* 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K); 118: u3d_se_*_b16 */
+#define U3D_VERSION 119 /* 119: round 5 — ragged volumes on the persistent kernels, u3d_conv3d_variant / u3d_conv3d_wgrad_variant; 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K); 118: u3d_se_*_b16 */
 
 #define U3D_OK 0
 #define U3D_EINVAL (-1)  /* bad shape / argument */
@@ -181,6 +181,18 @@ int u3d_subpixel_conv_fwd(int device, u3d_stream_t stream, const float* low, con
 size_t u3d_wgrad_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
 int u3d_conv3d_wgrad(int device, u3d_stream_t stream, const u3d_src_t* src, const float* dz, float* dw, int N,
                      int D, int H, int W, int Cout, float* workspace, size_t workspace_floats);
+
+/* Host-only: which kernel variant u3d_conv3d[_ex|_residual] / u3d_conv3d_wgrad[_strided] run for a shape (16-byte aligned tensors,
+ * channel counts that are multiples of 4).  src_kind: 0 = plain source, 1 = virtual source whose low-res half is an exact 2x
+ * upsampling, 2 = virtual source through general index maps (odd sizes: F.interpolate to 2n+1, buildingblocks.py:598-614).
+ * u3d_conv3d_variant: 0 = generic kernel (one block per tile, per-item bounds arithmetic), 1 = persistent kernel, every tile
+ * inside the volume, 2 = persistent kernel with ragged last tiles (round 5: sizes that are not multiples of 4 x 8 x 8, e.g. the
+ * reference's shipped 80 x 170 x 170 patch, resources/3DUnet_confocal_boundary/train_config.yml:94), 3 = split-K (has_workspace).
+ * u3d_conv3d_wgrad_variant: 0 = generic staging, 1 / 2 = constant-offset staging without / with ragged last tiles, | 4 = tap pairs
+ * (Cin <= 16).  No reference counterpart (ATen picks its algorithm behind buildingblocks.py:56); the parity tests assert with it
+ * that a ragged shape runs the fast variants. */
+int u3d_conv3d_variant(int N, int D, int H, int W, int Cin, int Cout, int src_kind, int has_workspace);
+int u3d_conv3d_wgrad_variant(int N, int D, int H, int W, int Cin, int Cout, int src_kind);
 
 /* Same, writing the gradient of a CHANNEL SLICE of a wider weight: dw points at the slice's first input channel inside the
  * (Cout, dw_cin_stride, 3,3,3) gradient; src holds only the slice's channels. */

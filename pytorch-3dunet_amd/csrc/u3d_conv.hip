@@ -647,9 +647,18 @@ __device__ __forceinline__ void u3d_for_rows(F&& f) {
 // activation fragment the B operand (columns = 16 voxels: two y rows x 8 x; a wave's z-plane is 4 M-tiles), so a lane's four
 // accumulator registers of an M-tile are FOUR CONSECUTIVE output channels of ONE voxel: 16-byte stores / side loads without the
 // DPP transposition.  A k-step is one tap over the chunk's 16 channels: 4 A reads, one B fetch, 16 MFMAs of 32 cycles.
-template <int NT, bool VIRT, bool DBG = false, bool PAIRY = false, bool AFF = true, bool N16 = false>
+//
+// RAG (round 5): volumes whose sizes are NOT multiples of the 4 x 8 x 8 tile (the reference's shipped patch is 80 x 170 x 170 and its
+// pooled levels 85, 42, 21: resources/3DUnet_confocal_boundary/train_config.yml:94).  The last tile of an axis overhangs the volume:
+// its far-face item mask covers every halo plane from the first one beyond the volume on (still six per-thread masks built once per
+// block, nothing per tile), so the staged values there are the convolution's zero padding; the k-loop is unchanged (it computes
+// values for the overhanging voxels that nobody reads) and only the epilogue differs — rows / planes beyond the volume are skipped
+// by uniform branches, lanes beyond W by the store mask, and neither enters the GroupNorm sums.  A separate instantiation, so the
+// aligned launches keep their exact code.
+template <int NT, bool VIRT, bool DBG = false, bool PAIRY = false, bool AFF = true, bool N16 = false, bool RAG = false>
 __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParams p) {
     using namespace cv;
+    static_assert(!RAG || (!PAIRY && !DBG), "ragged tiles: standard and 16-column variants only");
     static_assert(!PAIRY || NT == 1, "the paired-y variant has a single N-tile");
     static_assert(!N16 || (NT == 1 && !PAIRY), "the 16-column variant has a single N-tile");
     // B ring depth: fragments are fetched RB-1 k-steps ahead; slots are indexed by the k-step within the chunk (54 % RB == 0,
@@ -701,6 +710,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
     const int q = t & 3, tv = t >> 2;
     int rel0[NIT], rel1[VIRT ? NIT : 1], loff[NIT];
     unsigned fz0 = 0, fz1 = 0, fy0 = 0, fy1 = 0, fx0 = 0, fx1 = 0, fdead = 0;
+    // valid voxels of the LAST tile of each axis (RAG: 1 .. tile size; otherwise the tile size: far face = halo plane HZ-1 / HY-1 / HX-1)
+    const int vz = RAG && D % TZ ? D % TZ : TZ, vy = RAG && H % TY ? H % TY : TY, vx = RAG && W % TX ? W % TX : TX;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int vox = tv + 64 * it;
@@ -715,11 +726,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
         if constexpr (VIRT) rel1[it] = in ? (((hz - 1) >> 1) * H1 + ((hy - 1) >> 1)) * W1 + ((hx - 1) >> 1) : 0;
         loff[it] = in ? hz * PS + hy * RS + hx * CS + 4 * q : HZ * PS;  // tail items -> dummy slot
         fz0 |= (in && hz == 0 ? 1u : 0u) << it;
-        fz1 |= (in && hz == HZ - 1 ? 1u : 0u) << it;
+        fz1 |= (in && hz > vz ? 1u : 0u) << it;
         fy0 |= (in && hy == 0 ? 1u : 0u) << it;
-        fy1 |= (in && hy == HY - 1 ? 1u : 0u) << it;
+        fy1 |= (in && hy > vy ? 1u : 0u) << it;
         fx0 |= (in && hx == 0 ? 1u : 0u) << it;
-        fx1 |= (in && hx == HX - 1 ? 1u : 0u) << it;
+        fx1 |= (in && hx > vx ? 1u : 0u) << it;
         fdead |= (in ? 0u : 1u) << it;
     }
     // Work items are walked with stride G.  Decoding an item index costs five integer divisions (VALU sequences — and a
@@ -777,8 +788,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
         c.n = d.n;
         c.base0 = ((c.n * D + c.z0 - 1) * H + c.y0 - 1) * W + c.x0 - 1;
         c.base1 = VIRT ? ((c.n * D1 + (c.z0 >> 1)) * H1 + (c.y0 >> 1)) * W1 + (c.x0 >> 1) : 0;
-        const bool bz0 = c.z0 == 0, bz1 = c.z0 + TZ == D, by0 = c.y0 == 0, by1 = c.y0 + TY == H, bx0 = c.x0 == 0,
-                   bx1 = c.x0 + TX == W;
+        const bool bz0 = c.z0 == 0, bz1 = c.z0 + TZ >= D, by0 = c.y0 == 0, by1 = c.y0 + TY >= H, bx0 = c.x0 == 0,
+                   bx1 = c.x0 + TX >= W;
         c.border = bz0 || bz1 || by0 || by1 || bx0 || bx1;
         c.inv = fdead | (bz0 ? fz0 : 0u) | (bz1 ? fz1 : 0u) | (by0 ? fy0 : 0u) | (by1 ? fy1 : 0u) | (bx0 ? fx0 : 0u) |
                 (bx1 ? fx1 : 0u);
@@ -1133,6 +1144,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
             const int vlane = ((n * D + z) * H + T.y0 + 2 * (v16 >> 3)) * W + T.x0 + (v16 & 7);  // this lane's voxel of M-tile 0
             float* orow = p.out + (size_t)vlane * p.Cout + co;
             const size_t rstep = (size_t)W * p.Cout;  // one y row of the output
+            // RAG: is this lane's voxel of M-tile mt inside the volume?
+            auto vin = [&](int mt) { return !RAG || (z < D && T.y0 + mrow(mt) + 2 * (v16 >> 3) < H && T.x0 + (v16 & 7) < W); };
             f32x4 xv[MT];
             if (want_g) {
                 // gx (the layer's input, for the GroupNorm-backward sums): plain, or its channels beyond C0 from the exact-2x low-res half
@@ -1141,7 +1154,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                 for (int mt = 0; mt < MT; ++mt) {
                     const int y = T.y0 + mrow(mt) + 2 * (v16 >> 3), x = T.x0 + (v16 & 7);
                     const int xi1 = ((n * p.gx.D1 + (z >> 1)) * p.gx.H1 + (y >> 1)) * p.gx.W1 + (x >> 1);
-                    const float* xp = !cok ? p.gx.p0
+                    const float* xp = !(cok && vin(mt)) ? p.gx.p0
                                            : (from0 ? p.gx.p0 + (size_t)(vlane + mrow(mt) * W) * p.gx.C0 + co
                                                     : p.gx.p1 + (size_t)xi1 * p.gx.C1 + (co - p.gx.C0));
                     xv[mt] = *reinterpret_cast<const f32x4*>(xp);
@@ -1149,7 +1162,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
             } else if (p.res) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    xv[mt] = *reinterpret_cast<const f32x4*>(p.res + (size_t)(vlane + mrow(mt) * W) * p.Cout + (cok ? co : 0));
+                    xv[mt] = *reinterpret_cast<const f32x4*>(p.res + (vin(mt) ? (size_t)(vlane + mrow(mt) * W) * p.Cout + (cok ? co : 0) : (size_t)0));
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -1159,10 +1172,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
 #pragma unroll
                     for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
                 }
-                if (cok) *reinterpret_cast<f32x4*>(orow + mrow(mt) * rstep) = val;
-                if (p.Cout % 16 != 0) {
+                if (cok && vin(mt)) *reinterpret_cast<f32x4*>(orow + mrow(mt) * rstep) = val;
+                if (RAG || p.Cout % 16 != 0) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) val[e] = cok ? val[e] : 0.f;
+                    for (int e = 0; e < 4; ++e) val[e] = (cok && vin(mt)) ? val[e] : 0.f;
                 }
                 sq1 += val;  // (CARRY: NT == 1) running sums of this lane's four channels over its voxels and tiles
                 sq2 += want_g ? val * xv[mt] : val * val;
@@ -1201,7 +1214,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                 const int ysh = PAIRY ? (cq >> 2) : 0;
                 const int co = PAIRY ? 4 * (cq & 3) : (cb * NT + nt) * 32 + 4 * cq;
                 auto yoff = [&](int st) { return PAIRY ? 2 * st + ysh : st; };
-                const bool cok = co < p.Cout;
+                // RAG: a lane beyond W neither stores nor counts (folded into cok); rows beyond H / planes beyond D are uniform skips
+                const bool cok = co < p.Cout && (!RAG || T.x0 + vl < W);
+                auto row_in = [&](int st) { return !RAG || (z < D && T.y0 + yoff(st) < H); };  // uniform
                 float* orow = p.out + (size_t)vrow * p.Cout + co;
                 const bool xfrom0 = co < p.gx.C0 || !cok;
                 const float* xb = !cok ? p.gx.p0 : (xfrom0 ? p.gx.p0 + co : p.gx.p1 + (co - p.gx.C0));
@@ -1213,17 +1228,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const int yo = yoff(4 * half + k);
-                            const int xi = xfrom0 ? vrow + yo * W : xrow + (yo >> 1) * p.gx.W1;
+                            int xi = xfrom0 ? vrow + yo * W : xrow + (yo >> 1) * p.gx.W1;
+                            if constexpr (RAG) xi = (cok && row_in(4 * half + k)) ? xi : 0;
                             xv[k] = *reinterpret_cast<const f32x4*>(xb + (size_t)xi * xcs);
                         }
                     } else if (p.res) {  // residual rows (same voxels / channels as the output rows)
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            xv[k] = *reinterpret_cast<const f32x4*>(p.res + (size_t)(vrow + yoff(4 * half + k) * W) * p.Cout + (cok ? co : 0));
+                        for (int k = 0; k < 4; ++k) {
+                            size_t ri = (size_t)(vrow + yoff(4 * half + k) * W) * p.Cout + (cok ? co : 0);
+                            if constexpr (RAG) ri = (cok && row_in(4 * half + k)) ? ri : 0;
+                            xv[k] = *reinterpret_cast<const f32x4*>(p.res + ri);
+                        }
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int st = 4 * half + k;
+                        if (!row_in(st)) continue;
                         f32x4 val = tq[st];
                         if (p.res) val += xv[k];
                         if (p.relu) {
@@ -1231,7 +1251,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
                             for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
                         }
                         if (cok) *reinterpret_cast<f32x4*>(orow + (size_t)yoff(st) * W * p.Cout) = val;
-                        if (p.Cout % 32 != 0) {
+                        if (RAG || p.Cout % 32 != 0) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) val[e] = cok ? val[e] : 0.f;
                         }
@@ -1397,6 +1417,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
     int rel[NPFC], loff[NPFC];
     unsigned fz0 = 0, fz1 = 0, fy0 = 0, fy1 = 0, fx0 = 0, fx1 = 0, fdead = 0;
     if constexpr (REG) {
+        // RAGGED volumes (round 5: D % 2, H % 8, W % 8 need not vanish — the reference's shipped patch is 80 x 170 x 170,
+        // resources/3DUnet_confocal_boundary/train_config.yml:94): the LAST tile of an axis overhangs the volume.  Its far-face
+        // mask simply covers every item from the first plane beyond the volume on (halo coordinate >= valid voxels + 1; for an
+        // exact fit that is the halo plane HZ-1 as before); the staged values there are the convolution's zero padding / dz = 0,
+        // so the overhanging voxels add nothing.  Still six per-thread masks built once per block, no per-tile arithmetic.
+        const int vz = D % TZ ? D % TZ : TZ, vy = H % TY ? H % TY : TY, vx = W % TX ? W % TX : TX;  // valid voxels of the last tile
 #pragma unroll
         for (int it = 0; it < NIT_G; ++it) {
             const int vox = tv + 64 * it;
@@ -1410,11 +1436,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
                             : (((hz - 1) >> 1) * p.src.H1 + ((hy - 1) >> 1)) * p.src.W1 + ((hx - 1) >> 1);
             loff[it] = in ? hz * PSg + hy * RSg + hx * CSg + 4 * q : DUMMY_OFF;
             fz0 |= (in && hz == 0 ? 1u : 0u) << it;
-            fz1 |= (in && hz == HZ - 1 ? 1u : 0u) << it;
+            fz1 |= (in && hz > vz ? 1u : 0u) << it;
             fy0 |= (in && hy == 0 ? 1u : 0u) << it;
-            fy1 |= (in && hy == HY - 1 ? 1u : 0u) << it;
+            fy1 |= (in && hy > vy ? 1u : 0u) << it;
             fx0 |= (in && hx == 0 ? 1u : 0u) << it;
-            fx1 |= (in && hx == HX - 1 ? 1u : 0u) << it;
+            fx1 |= (in && hx > vx ? 1u : 0u) << it;
             fdead |= (in && cok ? 0u : 1u) << it;
         }
 #pragma unroll
@@ -1422,18 +1448,21 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
             const int vox = tv + 64 * it;
             rel[NIT_G + it] = ((vox >> 6) * H + ((vox >> 3) & 7)) * W + (vox & 7);
             loff[NIT_G + it] = G_FLOATS + vox * 32 + 4 * q;
+            fz1 |= ((vox >> 6) >= vz ? 1u : 0u) << (NIT_G + it);
+            fy1 |= (((vox >> 3) & 7) >= vy ? 1u : 0u) << (NIT_G + it);
+            fx1 |= ((vox & 7) >= vx ? 1u : 0u) << (NIT_G + it);
         }
         fdead |= (dcok ? 0u : 3u) << NIT_G;
     }
-    // invalid-item mask of a (fully inside) tile: uniform face tests select the per-thread face masks
+    // invalid-item mask of a tile: uniform face tests select the per-thread face masks
     auto tile_invalid = [&](int z0, int y0, int x0) {
         unsigned inv = fdead;
         inv |= z0 == 0 ? fz0 : 0u;
-        inv |= z0 + TZ == D ? fz1 : 0u;
+        inv |= z0 + TZ >= D ? fz1 : 0u;
         inv |= y0 == 0 ? fy0 : 0u;
-        inv |= y0 + TY == H ? fy1 : 0u;
+        inv |= y0 + TY >= H ? fy1 : 0u;
         inv |= x0 == 0 ? fx0 : 0u;
-        inv |= x0 + TX == W ? fx1 : 0u;
+        inv |= x0 + TX >= W ? fx1 : 0u;
         return inv;
     };
 
@@ -2041,7 +2070,19 @@ static int conv_set_lds_nt() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<NT, false, false, false, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<NT, true, false, false, true, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<NT, false, false, false, false, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<NT, false, false, false, true, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     if (NT == 1) {
+        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<1, true, false, false, true, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<1, false, false, false, false, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<1, false, false, false, true, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<1, false, false, true, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_mfma_reg_kernel<1, false, false, true>),
@@ -2213,8 +2254,10 @@ static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, co
     auto plain_or_x2 = [&](const u3d_src_t& s_) {
         return s_.C1 == 0 || (D == 2 * s_.D1 && H == 2 * s_.H1 && W == 2 * s_.W1);
     };
-    const bool reg = p.vec && p.ovec && D % cv::TZ == 0 && H % cv::TY == 0 && W % cv::TX == 0 && plain_or_x2(p.src) &&
-                     (!gx || plain_or_x2(p.gx)) && g_u3d_tune[3] == 0;
+    // ragged volumes (last tiles overhang) run the RAG instantiations of the same kernel (key 3 = 2: the round-4 gate, generic kernel)
+    const bool ragged = D % cv::TZ != 0 || H % cv::TY != 0 || W % cv::TX != 0;
+    const bool reg = p.vec && p.ovec && plain_or_x2(p.src) && (!gx || plain_or_x2(p.gx)) && g_u3d_tune[3] == 0 ||
+                     (g_u3d_tune[3] == 2 && !ragged && p.vec && p.ovec && plain_or_x2(p.src) && (!gx || plain_or_x2(p.gx)));
     if (reg) {
         p.total = (int)nblk;
         p.gx_x2 = (gx && p.gx.C1 > 0) ? 1 : 0;
@@ -2235,7 +2278,38 @@ static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, co
         // a source without a GroupNorm affine (every dgrad launch: dz is plain) runs the variant compiled without the
         // per-element FMA of the halo stores (key 7 = 1 turns it off for A/B runs)
         const bool noaff = p.src.affine == nullptr && g_u3d_tune[7] == 0;
-        p.dbg = (g_u3d_prof_buf && (size_t)slots * 4 <= g_u3d_prof_records) ? g_u3d_prof_buf : nullptr;
+        p.dbg = (!ragged && g_u3d_prof_buf && (size_t)slots * 4 <= g_u3d_prof_records) ? g_u3d_prof_buf : nullptr;
+        if (ragged) {
+            if (Cout <= 16 && nt == 1 && p.ntot == 1) {  // 16-column variant on the third packed image, as below
+                p.wp = packed_w + ((size_t)p.nchunks * cv::NSTEP + cv::PACK_PAD) * 256 + ((size_t)p.nchunks * cv::NSTEP_PAIRY + cv::PACK_PAD) * 256;
+                if (virt)
+                    hipLaunchKernelGGL((conv3d_mfma_reg_kernel<1, true, false, false, true, true, true>), rgrid, rblock, shmem, st, p);
+                else if (noaff)
+                    hipLaunchKernelGGL((conv3d_mfma_reg_kernel<1, false, false, false, false, true, true>), rgrid, rblock, shmem, st, p);
+                else
+                    hipLaunchKernelGGL((conv3d_mfma_reg_kernel<1, false, false, false, true, true, true>), rgrid, rblock, shmem, st, p);
+                U3D_LAUNCH_CHECK();
+                return 0;
+            }
+#define U3D_RAG_LAUNCH(NT_)                                                                                                        \
+    do {                                                                                                                           \
+        if (virt)                                                                                                                  \
+            hipLaunchKernelGGL((conv3d_mfma_reg_kernel<NT_, true, false, false, true, false, true>), rgrid, rblock, shmem, st, p);  \
+        else if (noaff)                                                                                                            \
+            hipLaunchKernelGGL((conv3d_mfma_reg_kernel<NT_, false, false, false, false, false, true>), rgrid, rblock, shmem, st, p); \
+        else                                                                                                                       \
+            hipLaunchKernelGGL((conv3d_mfma_reg_kernel<NT_, false, false, false, true, false, true>), rgrid, rblock, shmem, st, p); \
+    } while (0)
+            if (nt == 3)
+                U3D_RAG_LAUNCH(3);
+            else if (nt == 2)
+                U3D_RAG_LAUNCH(2);
+            else
+                U3D_RAG_LAUNCH(1);
+#undef U3D_RAG_LAUNCH
+            U3D_LAUNCH_CHECK();
+            return 0;
+        }
         if (Cout <= 16 && nt == 1 && p.ntot == 1 && !p.dbg && g_u3d_tune[4] != 1) {
             // <= 16 output channels (the 32 -> 16 data gradient at full resolution): the 16-column variant on the THIRD packed image
             // (u3d_pack_weights appends the paired-y and the 16-column image for <= 16 produced channels); key 4 = 2: the round-1
@@ -2402,8 +2476,9 @@ static int conv3d_wgrad_impl(int device, u3d_stream_t stream, const u3d_src_t* s
     const int nblk = p.S * p.nchunks * p.nkb;
     U3D_REQUIRE(D + H + W <= wg::MAX_MAP_INTS, "u3d_conv3d_wgrad: D+H+W must be <= %d", wg::MAX_MAP_INTS);
     const size_t shmem = (wg::LDS_FLOATS + (size_t)(D + H + W)) * sizeof(float);
-    // every tile fully inside the volume and no table look-ups -> constant-offset staging (REG)
-    const bool reg = D % wg::TZ == 0 && H % wg::TY == 0 && W % wg::TX == 0 &&
+    // no table look-ups (plain or exact-2x source) -> constant-offset staging (REG); ragged last tiles are part of its face masks
+    // (key 3 = 2: the round-4 gate "every tile fully inside the volume", for A/B runs)
+    const bool reg = (g_u3d_tune[3] != 2 || (D % wg::TZ == 0 && H % wg::TY == 0 && W % wg::TX == 0)) &&
                      (src->C1 == 0 || (D == 2 * src->D1 && H == 2 * src->H1 && W == 2 * src->W1));
     if (p.vec && p.dzvec && reg && Cin <= 16)
         hipLaunchKernelGGL((conv3d_wgrad_kernel<true, true, true>), dim3(nblk), dim3(wg::NTHR), shmem, (hipStream_t)stream, p);
@@ -2420,6 +2495,33 @@ static int conv3d_wgrad_impl(int device, u3d_stream_t stream, const u3d_src_t* s
                        p.nchunks, p.nkb, Cin, Cout, cstride > 0 ? cstride : Cin);
     U3D_LAUNCH_CHECK();
     return 0;
+}
+
+// Host-only: which kernel variant a shape runs (the gates of conv3d_impl / conv3d_wgrad_impl restated for 16-byte aligned tensors with
+// channel counts that are multiples of 4).  src_kind: 0 = plain source, 1 = virtual source whose low-res half is an exact 2x upsampling,
+// 2 = virtual source through general index maps.
+extern "C" int u3d_conv3d_variant(int N, int D, int H, int W, int Cin, int Cout, int src_kind, int has_workspace) {
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return -1;
+    if (Cin % 4 != 0 || Cout % 4 != 0) return 0;
+    const long long ntiles = (long long)N * cdiv(D, cv::TZ) * cdiv(H, cv::TY) * cdiv(W, cv::TX);
+    const int nchunks = cdiv(Cin, 16), ntot = cdiv(Cout, 32);
+    if (has_workspace && splitk_shape(N, D, H, W, Cin, Cout) && g_u3d_tune[7] != 2) {
+        long long ks = (2ll * 256) / (ntiles * ntot);
+        if (ks > nchunks) ks = nchunks;
+        if (ks > SPLITK_MAX) ks = SPLITK_MAX;
+        if (ks >= 2 && cdiv(nchunks, cdiv(nchunks, (int)ks)) >= 2) return 3;
+    }
+    const bool ragged = D % cv::TZ != 0 || H % cv::TY != 0 || W % cv::TX != 0;
+    if (src_kind == 2 || g_u3d_tune[3] == 1 || (g_u3d_tune[3] == 2 && ragged)) return 0;
+    return ragged ? 2 : 1;
+}
+
+extern "C" int u3d_conv3d_wgrad_variant(int N, int D, int H, int W, int Cin, int Cout, int src_kind) {
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return -1;
+    if (Cin % 4 != 0 || Cout % 4 != 0) return 0;
+    const bool ragged = D % wg::TZ != 0 || H % wg::TY != 0 || W % wg::TX != 0;
+    if (src_kind == 2 || (g_u3d_tune[3] == 2 && ragged)) return 0;
+    return (ragged ? 2 : 1) | (Cin <= 16 ? 4 : 0);
 }
 
 extern "C" int u3d_conv3d_naive(int device, u3d_stream_t stream, const u3d_src_t* src, const float* w, float* out,

@@ -58,6 +58,8 @@ _PROTOS = {
          POINTER(U3DSrc), c_void_p],
     ),
     "u3d_wgrad_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "u3d_conv3d_variant": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "u3d_conv3d_wgrad_variant": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "u3d_conv3d_wgrad": (
         c_int,
         [c_int, c_void_p, POINTER(U3DSrc), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t],

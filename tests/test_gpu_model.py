@@ -20,20 +20,67 @@ def _make(cfg):
     return get_model(dict(cfg)) if "name" in cfg else UNet3D(**cfg)
 
 
-def _run_native(model, x, target, loss_name):
+def _run_native(model, x, target, loss_name, decisions=None):
+    """one native step; `decisions` (a dict) receives the ReLU masks / pool arg-maxes the step took (NCDHW, CPU)"""
     from pytorch3dunet_amd import _native as nat
 
     dev = torch.device("cuda", 0)
     model = model.to(dev).train()
     before = nat.launch_count
+    eng = model._get_engine() if decisions is not None else None
+    if eng is not None:
+        eng.debug = {}
     probs, logits = model(x.to(dev), return_logits=True)
+    if eng is not None:
+        tape = eng.debug["tape"]
+        ncdhw = lambda t: t.permute(0, 4, 1, 2, 3).contiguous().cpu()  # noqa: E731
+        decisions["masks"] = [ncdhw(r.y > 0) for r in tape.convs]
+        decisions["argmax"] = [ncdhw(am) for (_, am, _) in tape.pools]
+        decisions["names"] = [r.name for r in tape.convs]
     loss = loss_by_name(loss_name, probs, logits, target.to(dev))
     model.zero_grad()
     loss.backward()
     torch.cuda.synchronize()
+    if eng is not None:
+        eng.debug = None
     assert nat.launch_count > before, "native HIP path did not run"
     grads = {k: p.grad.detach().cpu() for k, p in model.named_parameters()}
     return probs.detach().cpu(), logits.detach().cpu(), loss.item(), grads
+
+
+def _flip_audit(g, sd, x, target, decisions, grads):
+    """A `full` golden whose direct per-parameter gate fails: the only legitimate cause is a DISCRETE decision taken differently at a
+    pre-activation within fp32 round-off of zero (one ReLU flip is an O(1e-3) event in these tiny nets; the reference's own fixtures
+    for them happen to contain none).  Audit exactly that: (1) every ReLU mask of ours that differs from the fp32 oracle's own sits at
+    |pre-activation| <= DECISION_TOL of its layer's range, at most 4 per layer, no arg-max differs; (2) with OUR decisions imposed, the
+    float64 oracle reproduces every gradient to 1e-4 (first GroupNorm gamma 1e-3) — nothing but those flips separates the two."""
+    import unet3d_oracle as orc
+
+    cfg = g.cfg
+    G, fs, seg = cfg.get("num_groups", 8), cfg.get("final_sigmoid", True), cfg.get("is_segmentation", True)
+    trace, _ = orc.forward_decisions(sd, x, G, fs, seg)
+    flips, worst = 0, 0.0
+    assert len(decisions["masks"]) == len(trace["pre"])
+    for name, ours, z in zip(decisions["names"], decisions["masks"], trace["pre"]):
+        diff = ours != (z > 0)
+        n = int(diff.sum())
+        if n:
+            rel = (z[diff].abs().max() / z.abs().max()).item()
+            assert rel <= DECISION_TOL and n <= 4, (name, n, rel)
+            worst = max(worst, rel)
+        flips += n
+    for ours, h in zip(decisions["argmax"], trace["pool"]):
+        _, idx = F.max_pool3d(h, 2, return_indices=True)
+        Hh, Ww = h.shape[3:]
+        theirs = ((idx // (Hh * Ww)) % 2) * 4 + (((idx // Ww) % Hh) % 2) * 2 + (idx % Ww) % 2
+        assert int((ours.long() != theirs).sum()) == 0
+    assert flips > 0, "the direct gate failed without a single decision flip: an arithmetic error"
+    _, _, g64 = orc.forward_backward_decided(sd, x, target, decisions["masks"], decisions["argmax"], G, fs, seg, g.loss_name)
+    first_gamma = next(k for k in grads if k.endswith("groupnorm.weight"))
+    for k, v in grads.items():
+        e = orc.rel_err(v.double(), g64[k])
+        assert e < (1e-3 if k == first_gamma else 1e-4), (k, e)
+    return flips, worst
 
 
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
@@ -43,17 +90,28 @@ def test_model_matches_reference_golden(name):
     g = Golden(name)
     model = g.build_model()
     x, target = g.inputs()
-    probs, logits, loss, grads = _run_native(model, x, target, g.loss_name)
+    decisions = {} if g.full else None
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    probs, logits, loss, grads = _run_native(model, x, target, g.loss_name, decisions)
     assert abs(loss - g.loss) <= REL * max(1.0, abs(g.loss))
     if g.full:
         assert orc.rel_err(logits, g.tensor("logits")) < REL
         assert orc.rel_err(probs, g.tensor("probs")) < REL
-        worst = 0.0
+        worst, failing = 0.0, []
         for k, rg in g.group("grad/").items():
             e = orc.rel_err(grads[k], rg)
             worst = max(worst, e)
-            assert orc.grad_within_tolerance(grads[k], rg, float(g.z["ref_err/" + k]), REL), f"{k}: {e}"
+            if not orc.grad_within_tolerance(grads[k], rg, float(g.z["ref_err/" + k]), REL):
+                failing.append((k, e))
         print(f"{name}: logits rel {orc.rel_err(logits, g.tensor('logits')):.2e}, worst grad rel {worst:.2e}")
+        if failing:
+            # (round 5: g3's last layer — 8 output channels on a 12 x 20 x 17 volume — moved from the generic kernel to the 16-column
+            # persistent variant, whose MFMA shape sums in another order: ONE ReLU mask at a pre-activation of 1e-7 of the layer's range
+            # flips, and with it every gradient upstream by 1e-3 ... 5e-3, tools/diag_golden.py)
+            flips, worst_pre = _flip_audit(g, sd, x, target, decisions, grads)
+            print(f"{name}: {len(failing)} parameters outside the direct gate through {flips} ReLU flip(s) at |pre-activation| <= "
+                  f"{worst_pre:.1e} of the layer's range; decision-consistent float64 gate passed")
+            assert worst < 2e-2, failing[:3]  # (a handful of round-off flips cannot move a gradient further than this)
     else:
         # sampled fixture of a BASELINE-size configuration (g4 = config 1, g9 = config 2 at full size, g10 / g11 = the channel
         # ladders of configs 4 / 5).  Logits: 1e-3 of the reference's range.  Gradients, per parameter:
