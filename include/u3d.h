@@ -293,7 +293,9 @@ int u3d_maxpool2_bwd_merge_gn(int device, u3d_stream_t stream, const float* dg, 
 
 /* ---- final 1x1x1 conv with bias + Sigmoid/Softmax (model.py:88-101,141-147) -------------------
  * x (N,V,Cin) NDHWC; w (Cout,Cin), b (Cout).  logits/probs are written in the reference's NCDHW
- * layout (N,Cout,V).  act: 0 none, 1 sigmoid, 2 softmax over channels.  Cout <= 16.
+ * layout (N,Cout,V).  act: 0 none, 1 sigmoid, 2 softmax over channels.  Cout <= 1024, Cin <= 256 (more than 16 outputs —
+ * multi-class heads, model.py:88-91 allows any out_channels — run in tiles of 16 outputs; Softmax then takes a second pass over
+ * the logits; round 5).
  * bwd: dlogits (N,Cout,V) -> dx (N,V,Cin) masked by (x>0) when relu_mask (x is a post-ReLU conv output);
  *      acc double[Cout*Cin + Cout] += (dw, db)  (convert with u3d_cvt_f64_f32). */
 int u3d_conv1x1_head_fwd(int device, u3d_stream_t stream, const float* x, const float* w, const float* b, int N,

@@ -934,12 +934,79 @@ extern "C" int u3d_conv1x1_head_fwd_b16(int device, u3d_stream_t stream, const v
     return 0;
 }
 
+// ---- wide heads (round 5): more than HEAD_MAXCO outputs (model.py:88-91 allows any out_channels — multi-class segmentation).  Outputs
+// are processed in tiles of HEAD_MAXCO (grid.y): a thread owns one voxel and one tile, the tile's weights sit in LDS; Sigmoid is
+// applied in the same pass, Softmax(dim=1) needs every logit of the voxel and runs as a second pass over the logits (coalesced:
+// the voxel index is the fastest dimension of NCDHW).
+constexpr int HEAD_WIDE_MAXCO = 1024;
+
+__global__ __launch_bounds__(256) void head_fwd_wide_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                            int N, long long V, int Cin, int Cout, int act, float* __restrict__ logits,
+                                                            float* __restrict__ probs) {
+    __shared__ float ws[HEAD_MAXCO * HEAD_MAXCI + HEAD_MAXCO];
+    const int o0 = blockIdx.y * HEAD_MAXCO, no = min(HEAD_MAXCO, Cout - o0);
+    for (int i = threadIdx.x; i < no * Cin; i += blockDim.x) ws[i] = w[(size_t)o0 * Cin + i];
+    for (int i = threadIdx.x; i < no; i += blockDim.x) ws[HEAD_MAXCO * HEAD_MAXCI + i] = b[o0 + i];
+    __syncthreads();
+    const long long total = (long long)N * V;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(idx / V);
+        const long long v = idx - (long long)n * V;
+        float acc[HEAD_MAXCO];
+#pragma unroll
+        for (int o = 0; o < HEAD_MAXCO; ++o) acc[o] = o < no ? ws[HEAD_MAXCO * HEAD_MAXCI + o] : 0.f;
+        const float* xr = x + (size_t)idx * Cin;
+        for (int c = 0; c < Cin; ++c) {
+            const float xv = xr[c];
+#pragma unroll
+            for (int o = 0; o < HEAD_MAXCO; ++o)
+                if (o < no) acc[o] = fmaf(xv, ws[o * Cin + c], acc[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < HEAD_MAXCO; ++o) {
+            if (o < no) {
+                const size_t oi = ((size_t)n * Cout + o0 + o) * V + v;
+                logits[oi] = acc[o];
+                if (probs && act != 2) probs[oi] = act == 1 ? 1.f / (1.f + expf(-acc[o])) : acc[o];
+            }
+        }
+    }
+}
+
+// probs[n,:,v] = softmax(logits[n,:,v]) — max, denominator and quotient exactly as the fused kernels compute them
+__global__ __launch_bounds__(256) void head_softmax_wide_kernel(const float* __restrict__ logits, int N, long long V, int Cout,
+                                                                float* __restrict__ probs) {
+    const long long total = (long long)N * V;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(idx / V);
+        const long long v = idx - (long long)n * V;
+        const float* lp = logits + (size_t)n * Cout * V + v;
+        float mx = -INFINITY, den = 0.f;
+        for (int o = 0; o < Cout; ++o) mx = fmaxf(mx, lp[(size_t)o * V]);
+        for (int o = 0; o < Cout; ++o) den += expf(lp[(size_t)o * V] - mx);
+        float* pp = probs + (size_t)n * Cout * V + v;
+        for (int o = 0; o < Cout; ++o) pp[(size_t)o * V] = expf(lp[(size_t)o * V] - mx) / den;
+    }
+}
+
 extern "C" int u3d_conv1x1_head_fwd(int device, u3d_stream_t stream, const float* x, const float* w, const float* b,
                                     int N, int64_t V, int Cin, int Cout, int act, float* logits, float* probs) {
     U3D_ENTER(device);
     U3D_REQUIRE(x && w && b && logits && N > 0 && V > 0, "u3d_conv1x1_head_fwd: bad argument");
-    U3D_REQUIRE(Cout >= 1 && Cout <= HEAD_MAXCO && Cin >= 1 && Cin <= HEAD_MAXCI,
-                "u3d_conv1x1_head_fwd: supports Cout<=%d, Cin<=%d (got %d,%d)", HEAD_MAXCO, HEAD_MAXCI, Cout, Cin);
+    U3D_REQUIRE(Cout >= 1 && Cout <= HEAD_WIDE_MAXCO && Cin >= 1 && Cin <= HEAD_MAXCI,
+                "u3d_conv1x1_head_fwd: supports Cout<=%d, Cin<=%d (got %d,%d)", HEAD_WIDE_MAXCO, HEAD_MAXCI, Cout, Cin);
+    if (Cout > HEAD_MAXCO) {
+        const long long tot_ = (long long)N * V;
+        hipLaunchKernelGGL(head_fwd_wide_kernel, dim3(grid_for(tot_, 2048), (unsigned)((Cout + HEAD_MAXCO - 1) / HEAD_MAXCO)), dim3(256), 0,
+                           (hipStream_t)stream, x, w, b, N, (long long)V, Cin, Cout, act, logits, probs);
+        U3D_LAUNCH_CHECK();
+        if (probs && act == 2) {
+            hipLaunchKernelGGL(head_softmax_wide_kernel, dim3(grid_for(tot_, 4096)), dim3(256), 0, (hipStream_t)stream, logits, N,
+                               (long long)V, Cout, probs);
+            U3D_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     const int G = Cin / 4;
     const bool vec = (Cin % 4 == 0) && (G & (G - 1)) == 0 && G >= 1 && G <= 64 && (((uintptr_t)x | (uintptr_t)w) & 15) == 0;
     hipStream_t st = (hipStream_t)stream;
@@ -1140,13 +1207,96 @@ extern "C" int u3d_conv1x1_head_bwd_b16(int device, u3d_stream_t stream, const f
     return 0;
 }
 
+// ---- wide heads: dx reads the (cached) weights from global memory instead of a Cout x Cin LDS copy; dw / db run per tile of
+// HEAD_MAXCO outputs (grid.y) with the same fixed-order block reduction and f64 accumulation as the narrow kernel
+__global__ __launch_bounds__(256) void head_bwd_dx_wide_kernel(const float* __restrict__ dl, const float* __restrict__ x,
+                                                               const float* __restrict__ w, int N, long long V, int Cin, int Cout,
+                                                               int relu_mask, float* __restrict__ dx) {
+    const long long total = (long long)N * V * Cin;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % Cin);
+        const long long nv = idx / Cin;
+        const int n = (int)(nv / V);
+        const long long v = nv - (long long)n * V;
+        float s_ = 0.f;
+        for (int o = 0; o < Cout; ++o) s_ = fmaf(dl[((size_t)n * Cout + o) * V + v], w[(size_t)o * Cin + c], s_);
+        if (relu_mask && !(x[idx] > 0.f)) s_ = 0.f;
+        dx[idx] = s_;
+    }
+}
+
+__global__ __launch_bounds__(256) void head_bwd_dw_wide_kernel(const float* __restrict__ dl, const float* __restrict__ x, int N, long long V,
+                                                               int Cin, int Cout, double* __restrict__ acc) {
+    extern __shared__ float red[];
+    const int t = threadIdx.x;
+    const int o0 = blockIdx.y * HEAD_MAXCO, no = min(HEAD_MAXCO, Cout - o0);
+    const int rows = 256 / Cin;
+    const int row = t / Cin, c = t - row * Cin;
+    float a[HEAD_MAXCO], bsum[HEAD_MAXCO];
+#pragma unroll
+    for (int o = 0; o < HEAD_MAXCO; ++o) a[o] = bsum[o] = 0.f;
+    const long long total = (long long)N * V;
+    const long long per = (total + gridDim.x - 1) / gridDim.x;
+    const long long beg = (long long)blockIdx.x * per, end = min(total, beg + per);
+    if (row < rows) {
+        for (long long nv = beg + row; nv < end; nv += rows) {
+            const int n = (int)(nv / V);
+            const long long v = nv - (long long)n * V;
+            const float xv = x[(size_t)nv * Cin + c];
+#pragma unroll
+            for (int o = 0; o < HEAD_MAXCO; ++o) {
+                if (o < no) {
+                    const float d = dl[((size_t)n * Cout + o0 + o) * V + v];
+                    a[o] = fmaf(d, xv, a[o]);
+                    if (c == 0) bsum[o] += d;
+                }
+            }
+        }
+    }
+    const int L = (no + 1) * Cin;
+    if (row < rows) {
+#pragma unroll
+        for (int o = 0; o < HEAD_MAXCO; ++o) {
+            if (o < no) {
+                red[row * L + o * Cin + c] = a[o];
+                if (c == 0) red[row * L + no * Cin + o] = bsum[o];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < no * Cin + no; i += 256) {
+        double sum = 0.0;
+        for (int r = 0; r < rows; ++r) sum += (double)red[r * L + i];
+        // acc = [Cout x Cin weights | Cout biases]
+        double* dst = i < no * Cin ? &acc[(size_t)o0 * Cin + i] : &acc[(size_t)Cout * Cin + o0 + (i - no * Cin)];
+        u3d_atomic_add_f64(dst, sum);
+    }
+}
+
 extern "C" int u3d_conv1x1_head_bwd(int device, u3d_stream_t stream, const float* dlogits, const float* x,
                                     const float* w, int N, int64_t V, int Cin, int Cout, int relu_mask, float* dx,
                                     double* acc) {
     U3D_ENTER(device);
     U3D_REQUIRE(dlogits && x && w && N > 0 && V > 0, "u3d_conv1x1_head_bwd: bad argument");
-    U3D_REQUIRE(Cout >= 1 && Cout <= HEAD_MAXCO && Cin >= 1 && Cin <= HEAD_MAXCI,
-                "u3d_conv1x1_head_bwd: supports Cout<=%d, Cin<=%d (got %d,%d)", HEAD_MAXCO, HEAD_MAXCI, Cout, Cin);
+    U3D_REQUIRE(Cout >= 1 && Cout <= HEAD_WIDE_MAXCO && Cin >= 1 && Cin <= HEAD_MAXCI,
+                "u3d_conv1x1_head_bwd: supports Cout<=%d, Cin<=%d (got %d,%d)", HEAD_WIDE_MAXCO, HEAD_MAXCI, Cout, Cin);
+    if (Cout > HEAD_MAXCO) {
+        if (dx) {
+            hipLaunchKernelGGL(head_bwd_dx_wide_kernel, dim3(grid_for((long long)N * V * Cin, 16384)), dim3(256), 0, (hipStream_t)stream,
+                               dlogits, x, w, N, (long long)V, Cin, Cout, relu_mask, dx);
+            U3D_LAUNCH_CHECK();
+        }
+        if (acc) {
+            long long blocks = cdivll((long long)N * V, 4096);
+            if (blocks > 512) blocks = 512;
+            if (blocks < 1) blocks = 1;
+            const size_t shmem = (size_t)(256 / Cin) * (HEAD_MAXCO + 1) * Cin * sizeof(float);
+            hipLaunchKernelGGL(head_bwd_dw_wide_kernel, dim3((unsigned)blocks, (unsigned)((Cout + HEAD_MAXCO - 1) / HEAD_MAXCO)), dim3(256),
+                               shmem, (hipStream_t)stream, dlogits, x, N, (long long)V, Cin, Cout, acc);
+            U3D_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     const bool vec = (Cin % 4 == 0) && Cin <= 1024 && Cout <= HEAD_VEC_MAXCO &&
                      (((uintptr_t)x | (uintptr_t)w | (uintptr_t)dx) & 15) == 0;
     if (vec) {

@@ -86,8 +86,8 @@ class AbstractUNet(nn.Module):
             # (an EXPLICIT 'deconv' keeps concat joining and a 1x1x1 conv deep->shallow in the block, buildingblocks.py:441-468;
             # the interpolation modes do not even run in the reference for residual nets: tests/test_oracle.py)
             reasons.append(f"upsample '{upsample}' with residual blocks")
-        if out_channels > 16 or f_maps[0] > 256:
-            reasons.append("head wider than 16 outputs / 256 inputs")
+        if out_channels > 1024 or f_maps[0] > 256:
+            reasons.append("head wider than 1024 outputs / 256 inputs")  # (> 16 outputs: the tiled wide-head kernels, round 5)
         # opt-in extras of the native executor (extra keys of the YAML's model section are swallowed by the reference's **kwargs):
         # bf16 MFMA operands with fp32 accumulation / master weights, and recomputation of the encoder blocks in backward
         if compute_dtype is None:

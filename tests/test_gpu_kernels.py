@@ -574,7 +574,9 @@ def test_maxpool_forward_backward_merge(N, C, size):
     assert U.relerr(U.ncdhw(res), pre.grad) < 1e-6
 
 
-@pytest.mark.parametrize("N,Cin,Cout,act", [(2, 32, 1, 1), (1, 8, 3, 2), (1, 16, 2, 0)])
+@pytest.mark.parametrize("N,Cin,Cout,act", [(2, 32, 1, 1), (1, 8, 3, 2), (1, 16, 2, 0),
+                                            # wide heads (round 5): > 16 outputs run in tiles of 16, softmax as a second pass
+                                            (2, 32, 24, 2), (1, 16, 17, 1), (1, 64, 40, 0), (1, 6, 33, 2)])
 def test_head_forward_backward(N, Cin, Cout, act):
     U, nat, VSrc, _p, _stream = _mods()
     torch.manual_seed(Cin + Cout)

@@ -369,6 +369,36 @@ def test_discrete_decisions_agree_with_fp32_oracle(cfg, shape):
     print(rec)
 
 
+def test_wide_multi_class_head_24_outputs_softmax():
+    """model.py:88-101 allows any out_channels; heads wider than 16 outputs used to raise on a HIP device.  UNet3D
+    with 24 classes and Softmax: logits / probabilities / every gradient against the CPU oracle, like test_model_matches_cpu_oracle"""
+    import unet3d_oracle as orc
+
+    cfg = dict(in_channels=2, out_channels=24, f_maps=[16, 32], num_groups=4, final_sigmoid=False)
+    shape = (2, 2, 8, 16, 16)
+    torch.manual_seed(99)
+    model = _make(cfg)
+    assert model.native_supported
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if "groupnorm" in k:
+                p.add_(0.2 * torch.randn_like(p))
+    x = torch.randn(shape)
+    target = torch.rand((shape[0], 24) + shape[2:])
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    p_ref, l_ref, loss_ref, g_ref, ref_err = orc.forward_backward_with_truth(sd, x, target, 4, False, True, "probs_sum")
+    probs, logits, loss, grads = _run_native(model, x, target, "probs_sum")
+    assert orc.rel_err(logits, l_ref) < 1e-4 and orc.rel_err(probs, p_ref) < 1e-4
+    assert abs(loss - loss_ref.item()) < REL * max(1.0, abs(loss_ref.item()))
+    assert orc.rel_err(grads["final_conv.weight"], g_ref["final_conv.weight"]) < 1e-4
+    assert orc.rel_err(grads["final_conv.bias"], g_ref["final_conv.bias"]) < 1e-4
+    keys = list(g_ref)
+    ours = torch.cat([grads[k].flatten().double() for k in keys])
+    ref = torch.cat([g_ref[k].flatten().double() for k in keys])
+    e_ref = (sum(ref_err[k] ** 2 * g_ref[k].numel() for k in keys) ** 0.5) / ref.norm().item()
+    assert ((ours - ref).norm() / ref.norm()).item() <= max(3e-3, 4 * e_ref)
+
+
 def test_inference_no_grad_and_eval_matches_train_forward():
     from pytorch3dunet_amd.unet3d.model import UNet3D
 
