@@ -393,7 +393,10 @@ int u3d_pack_weights_bf16(int device, u3d_stream_t stream, const float* w, int C
 /* All bf16 images of a model in ONE launch, read and written at HBM rate (every optimizer step changes every weight: 36 + 36
  * images per config-4 step).  descs: DEVICE array of n u3d_pack_desc_t sorted by `first` = first BLOCK of the image within the
  * launch (descriptor 0: 0; an image takes u3d_pack_weights_bf16_blocks(Cin, Cout, mode) blocks), `packed` = the bf16 image
- * (u3d_packed_weight_bf16_elems elements), mode 0 / 1, cin_stride unused; total_blocks = the sum over the descriptors. */
+ * (u3d_packed_weight_bf16_elems elements), mode 0 / 1, cin_stride unused; total_blocks = the sum over the descriptors.
+ * Modes 4 / 5 (round 5): the forward / data-gradient space-to-depth images of a ConvTranspose3d weight (Cin, Cout, 3,3,3) —
+ * desc.Cin = Cin, desc.Cout = Cout, `packed` = u3d_convtr3d_t8_packed_elems(Cin, Cout, mode - 4) elements, bit for bit what
+ * u3d_pack_convtr3d_t8 writes; needs Cin % 32 == 0 and Cout % 32 == 0 (u3d_pack_weights_bf16_blocks returns 0 otherwise). */
 long long u3d_pack_weights_bf16_blocks(int Cin, int Cout, int mode);
 int u3d_pack_weights_bf16_batch(int device, u3d_stream_t stream, const u3d_pack_desc_t* descs_device, int n, long long total_blocks);
 int u3d_conv3d_bf16(int device, u3d_stream_t stream, const float* x, const float* affine, const void* packed_w, float* out,

@@ -705,8 +705,25 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int Cout, 
 // layout — reads them coalesced into LDS and writes its 27 fragments (1 KiB each) 16 bytes per thread.  (The one-weight kernel
 // above reads 4 bytes per thread at a stride of 27 floats: 16x read amplification, 28 us per image, 36 + 16 launches per
 // config-4 step.)  desc.first = first block of the image; the block after an image's cells zeroes its 6-tap prefetch tail.
+// Modes 4 / 5 (round 5): the 2x2x2 images of a ConvTranspose3d(k3, s2, p1) weight (Cl, Cs, 3,3,3) in space-to-depth form (forward /
+// data gradient; see "Transposed convolution in SPACE-TO-DEPTH form" below: V[a][ci][p*Cs + co] = w[ci][co][s(a,p)], 27 of the 64 (tap,
+// parity) blocks non-zero).  desc.Cin = Cl, desc.Cout = Cs, Cs % 32 == 0: a cell's 32 columns (mode 4) / 16 contraction rows (mode 5)
+// then lie inside ONE parity and are the same contiguous runs of the reference layout as in modes 1 / 0 — the per-weight kernel
+// (pack_convtr_t8_kernel: 4 bytes per thread at a stride of 27 floats, 8 launches of ~33 us per config-4 step) is only the fallback.
 constexpr int PK_RS0 = 433;  // mode 0: [32 columns][16 k x 27 taps + 1]   (odd stride: the 32 lanes of a store hit 32 banks)
 constexpr int PK_RS1 = 865;  // mode 1: [16 k][32 columns x 27 taps + 1]
+__device__ __forceinline__ int pk_t8_sidx(int tap, int pp, bool fwd) {  // 3x3x3 tap index carried by (2x2x2 tap, parity), or -1
+    int sidx = 0;
+#pragma unroll
+    for (int dd = 0; dd < 3; ++dd) {  // z (bit 2), y, x
+        const int bit = 2 - dd;
+        const int tb = (tap >> bit) & 1, pb = (pp >> bit) & 1, a = fwd ? tb : 1 - tb;
+        const int sd = a == 0 ? (pb == 0 ? 1 : 2) : (pb == 1 ? 0 : -1);
+        if (sd < 0) return -1;
+        sidx = sidx * 3 + sd;
+    }
+    return sidx;
+}
 __global__ __launch_bounds__(256) void pack_weights_bf16_batch_kernel(const u3d_pack_desc_t* __restrict__ descs, int n) {
     __shared__ float tile[32 * PK_RS0];  // 13,856 floats (>= 16 * PK_RS1 = 13,840)
     const int t = threadIdx.x;
@@ -714,27 +731,37 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_batch_kernel(const u3d_
     while (d + 1 < n && (long long)blockIdx.x >= descs[d + 1].first) ++d;
     const u3d_pack_desc_t ds = descs[d];
     const int Cin = ds.Cin, Cout = ds.Cout, mode = ds.mode;
-    const int Kc = mode == 0 ? Cin : Cout, Nc = mode == 0 ? Cout : Cin;
+    const bool t8 = mode >= 4;  // 4: T8 forward (Kc = Cl, Nc = 8 Cs), 5: T8 data gradient (Kc = 8 Cs, Nc = Cl)
+    const int Kc = t8 ? (mode == 4 ? Cin : 8 * Cout) : (mode == 0 ? Cin : Cout), Nc = t8 ? (mode == 4 ? 8 * Cout : Cin) : (mode == 0 ? Cout : Cin);
+    const int NTAPS = t8 ? 8 : 27;
     const int ntiles = Nc >> 5, nch = Kc >> 4;
+    // T8: a block owns one SOURCE region — (16 input channels, 32 output channels) in mode 4, (16 output channels, 32 input channels) in
+    // mode 5 — and writes the cells of all 8 parities that are made of it (one read of the weight per image instead of eight)
+    const int src_tiles = t8 ? (mode == 4 ? Cout >> 5 : Cin >> 5) : ntiles, src_ch = t8 ? (mode == 4 ? Cin >> 4 : Cout >> 4) : nch;
     const int b = (int)((long long)blockIdx.x - ds.first);
     __bf16* out = reinterpret_cast<__bf16*>(ds.packed);
-    if (b >= nch * ntiles) {  // tail: BDIST = 6 taps of zero fragments after the last chunk
+    if (b >= src_ch * src_tiles) {  // tail: BDIST = 6 taps of zero fragments after the last chunk
         bf16x8 z;
 #pragma unroll
         for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
-        bf16x8* o8 = reinterpret_cast<bf16x8*>(out + (size_t)nch * 27 * ntiles * 512);
+        bf16x8* o8 = reinterpret_cast<bf16x8*>(out + (size_t)nch * NTAPS * ntiles * 512);
         for (int i = t; i < 6 * ntiles * 64; i += 256) o8[i] = z;
         return;
     }
-    const int c = b / ntiles, nt = b - c * ntiles;
+    const int c = b / src_tiles, nt = b - c * src_tiles;  // (T8: indices of the source region)
     const float* w = ds.w;
+    const int co0 = t8 ? (mode == 4 ? nt * 32 : c * 16) : 0;  // T8: first output channel (inside a parity) of the region
+    const bool geo0 = mode == 0 || mode == 5;  // [32 runs (columns)][16 k x 27]; else [16 runs (k)][32 columns x 27]
     // 3456 float4 of the cell, 13.5 per thread, all loads in flight before the first LDS store (runs start at multiples of
     // 16 * 27 floats = 1728 bytes: 16-byte aligned whenever the parameter is)
     {
-        const int RUN4 = mode == 0 ? 108 : 216;           // float4 per run: 432 / 864 floats
-        const int RS = mode == 0 ? PK_RS0 : PK_RS1;
-        const size_t run_stride = mode == 0 ? (size_t)Cin * 27 : (size_t)Cin * 27;
-        const float* base = mode == 0 ? w + ((size_t)(nt * 32) * Cin + c * 16) * 27 : w + ((size_t)(c * 16) * Cin + nt * 32) * 27;
+        const int RUN4 = geo0 ? 108 : 216;           // float4 per run: 432 / 864 floats
+        const int RS = geo0 ? PK_RS0 : PK_RS1;
+        const size_t run_stride = t8 ? (size_t)Cout * 27 : (size_t)Cin * 27;
+        const float* base = mode == 0 ? w + ((size_t)(nt * 32) * Cin + c * 16) * 27
+                          : mode == 1 ? w + ((size_t)(c * 16) * Cin + nt * 32) * 27
+                          : mode == 4 ? w + ((size_t)(c * 16) * Cout + co0) * 27     // rows = 16 input channels, 32 output channels x 27 each
+                                      : w + ((size_t)(nt * 32) * Cout + co0) * 27;   // rows = 32 input channels (columns), 16 output channels x 27 each
         f32x4 v[14];
 #pragma unroll
         for (int j = 0; j < 14; ++j) {
@@ -759,6 +786,29 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_batch_kernel(const u3d_
         }
     }
     __syncthreads();
+    if (t8) {
+        // 8 parities x 8 taps = 64 fragments of this region: parity pp places it at column tile (pp*Cs + co0) / 32 (mode 4) or at
+        // chunk (pp*Cs + co0) / 16 (mode 5); 27 of the 64 carry a tap, the others are written as zeros
+        for (int i = t; i < 64 * 64; i += 256) {
+            const int l = i & 63, tap = (i >> 6) & 7, pp = i >> 9;
+            const int sidx = pk_t8_sidx(tap, pp, mode == 4);  // uniform per wave
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+            if (sidx >= 0 && mode == 4) {
+                const float* src = tile + (8 * (l >> 5)) * PK_RS1 + (l & 31) * 27 + sidx;  // k = input channel, column = output channel
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (__bf16)src[e * PK_RS1];
+            } else if (sidx >= 0) {
+                const float* src = tile + (l & 31) * PK_RS0 + (8 * (l >> 5)) * 27 + sidx;  // column = input channel, k = output channel
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (__bf16)src[e * 27];
+            }
+            const int oc = mode == 4 ? c : (pp * Cout + co0) >> 4, ont = mode == 4 ? (pp * Cout + co0) >> 5 : nt;
+            *reinterpret_cast<bf16x8*>(out + ((((size_t)oc * 8 + tap) * ntiles + ont) * 64 + l) * 8) = v;
+        }
+        return;
+    }
     for (int i = t; i < 27 * 64; i += 256) {
         const int tap = i >> 6, l = i & 63;
         bf16x8 v;
@@ -778,6 +828,10 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_batch_kernel(const u3d_
 }  // namespace
 
 extern "C" long long u3d_pack_weights_bf16_blocks(int Cin, int Cout, int mode) {
+    if (mode == 4 || mode == 5) {  // T8 images of a transposed-convolution weight (Cin = Cl, Cout = Cs); 0 = not batchable
+        if (Cin <= 0 || Cout <= 0 || Cin % 32 != 0 || Cout % 32 != 0) return 0;
+        return mode == 4 ? (long long)(Cin / 16) * (Cout / 32) + 1 : (long long)(Cout / 16) * (Cin / 32) + 1;  // source regions + tail
+    }
     const int Kc = mode == 0 ? Cin : Cout, Nc = mode == 0 ? Cout : Cin;
     if (Kc <= 0 || Nc <= 0 || Kc % 16 != 0 || Nc % 32 != 0 || (mode != 0 && mode != 1)) return 0;
     return (long long)(Kc / 16) * (Nc / 32) + 1;
@@ -850,7 +904,7 @@ static int launch_bf16(const bf16_conv_params& p, hipStream_t stream) {
 // Tile variant of conv3d_bf16_kernel for a shape — ONE decision used by the launcher and by u3d_conv3d_bf16_tile_variant():
 //   nt      64 output channels per block when possible, else 32;
 //   planes  fp32 storage: 4-plane tiles everywhere (8-plane tiles — twice the B-fragment reuse — timed the same, profiles/r02i, and
-//           have no registers left for the staging descriptors and the deeper rings; u3d_set_tuning key 7 = 2 selects them for A/B);
+//           have no registers left for the staging descriptors and the deeper rings: 223 spilled VGPRs; removed in round 5);
 //           bf16 storage: 8-plane tiles where they still give two blocks per CU.  A wave then issues 8 MFMAs per pair of B fragments
 //           instead of 4: the B stream (1 KiB per fragment and wave, from L2 through the CU's vector L1) is what bounds this kernel —
 //           without it the same code runs 14-32 % faster (profiles/r03_bf16_ablation.txt) — and the short B ring, the one-deep A
@@ -865,7 +919,9 @@ static Bf16Tile bf16_tile_choice(int N, int D, int H, int W, int K, bool b16, in
     const bool nt2 = K % 64 == 0;
     const long long big = (long long)N * ((D + 7) / 8) * ((H + 7) / 8) * ((W + 7) / 8) * (K / (nt2 ? 64 : 32));
     const bool fits8 = big >= 512 && D >= 8 && ksplit == 1;
-    const bool zw2 = b16 ? (nt2 && g_u3d_tune[10] != 1 && fits8) : (g_u3d_tune[7] == 2 && fits8);
+    // (round 5: the fp32-storage 8-plane instantiations — an A/B experiment behind tuning key 7 = 2 that never beat the 4-plane tile and
+    // spilled 223 VGPRs — are gone: no shipped instantiation of conv3d_bf16_kernel spills inside its k-loop)
+    const bool zw2 = b16 && nt2 && g_u3d_tune[10] != 1 && fits8;
     t.nt = nt2 ? 2 : 1;
     t.planes = zw2 ? 8 : 4;
     t.blocks_per_cu = (t.nt == 2 && t.planes == 4) ? 3 : 2;
@@ -948,8 +1004,7 @@ static int conv3d_bf16_impl(int device, u3d_stream_t stream, const float* x, con
 #endif
     if (b16 && tc.planes == 8) return launch_bf16<2, 2, 3, U3D_CONV_ABL, __bf16>(p, s);
     if (b16) return tc.nt == 2 ? launch_bf16<2, 1, 3, 0, __bf16>(p, s) : launch_bf16<1, 1, 3, 0, __bf16>(p, s);
-    if (tc.nt == 2) return tc.planes == 8 ? launch_bf16<2, 2, 3>(p, s) : launch_bf16<2, 1, 3>(p, s);
-    return tc.planes == 8 ? launch_bf16<1, 2, 3>(p, s) : launch_bf16<1, 1, 3>(p, s);
+    return tc.nt == 2 ? launch_bf16<2, 1, 3>(p, s) : launch_bf16<1, 1, 3>(p, s);
 }
 
 // host-only query of that choice (tests assert that the shapes they pin really run the variants the benchmarks run)

@@ -26,7 +26,7 @@
 //   [5] start-phase stagger of the persistent kernel in units of 1024 cycles (0 = off)
 //   [6] 1 = one persistent block per CU instead of two (occupancy experiment)
 //   [7] bf16-storage weight gradient: 1 = the round-3 kernel, 16 / 8 = force the 16- / 8-wide tile of conv3d_wgrad_b16v2_kernel (A/B);
-//       2 = fp32-storage bf16 convolutions on 8-plane tiles
+//       2 = u3d_conv3d_ex never splits the channel reduction (A/B of the split-K path)
 //   [8] bf16 weight gradient: target number of blocks (0 = default)   [9] 1 = bf16 weight gradient without the XCD-aware block order
 //   [10] 1 = bf16-storage convolutions on 4-plane tiles only (no 8-plane tiles); 2 = transposed-convolution 2x2x2 kernels without
 //        skipping their structurally zero weight blocks   [11] bf16 kernels: 1 = x-y-z raster tile order; 2 / 3 = the tile index never / always runs

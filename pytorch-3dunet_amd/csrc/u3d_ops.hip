@@ -1086,7 +1086,7 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* __restric
     }
     // reduce the rows through LDS in a FIXED order (red[row][(Cout+1)*Cin]; no floating-point atomics: the block's
     // partial is bit-reproducible, the cross-block sum is carried in f64)
-    const int L = (Cout + 1) * Cin;
+    const int L = Cout * Cin + Cout;  // a row = [Cout x Cin | Cout biases] (round 5: (Cout + 1) * Cin overlapped the next row when Cout > Cin)
     if (row < rows) {
 #pragma unroll
         for (int o = 0; o < HEAD_MAXCO; ++o) {
@@ -1253,7 +1253,7 @@ __global__ __launch_bounds__(256) void head_bwd_dw_wide_kernel(const float* __re
             }
         }
     }
-    const int L = (no + 1) * Cin;
+    const int L = no * Cin + no;  // a row = [no x Cin weight partials | no bias partials]  (no may exceed Cin)
     if (row < rows) {
 #pragma unroll
         for (int o = 0; o < HEAD_MAXCO; ++o) {
@@ -1290,7 +1290,7 @@ extern "C" int u3d_conv1x1_head_bwd(int device, u3d_stream_t stream, const float
             long long blocks = cdivll((long long)N * V, 4096);
             if (blocks > 512) blocks = 512;
             if (blocks < 1) blocks = 1;
-            const size_t shmem = (size_t)(256 / Cin) * (HEAD_MAXCO + 1) * Cin * sizeof(float);
+            const size_t shmem = (size_t)(256 / Cin) * (HEAD_MAXCO * Cin + HEAD_MAXCO) * sizeof(float);
             hipLaunchKernelGGL(head_bwd_dw_wide_kernel, dim3((unsigned)blocks, (unsigned)((Cout + HEAD_MAXCO - 1) / HEAD_MAXCO)), dim3(256),
                                shmem, (hipStream_t)stream, dlogits, x, N, (long long)V, Cin, Cout, acc);
             U3D_LAUNCH_CHECK();
@@ -1318,7 +1318,7 @@ extern "C" int u3d_conv1x1_head_bwd(int device, u3d_stream_t stream, const float
         long long blocks = cdivll((long long)N * V, 4096);
         if (blocks > 1024) blocks = 1024;
         if (blocks < 1) blocks = 1;
-        const size_t shmem = (size_t)(256 / Cin) * (Cout + 1) * Cin * sizeof(float);
+        const size_t shmem = (size_t)(256 / Cin) * (Cout * Cin + Cout) * sizeof(float);
         hipLaunchKernelGGL(head_bwd_dw_kernel, dim3((unsigned)blocks), dim3(256), shmem, (hipStream_t)stream, dlogits,
                            x, N, (long long)V, Cin, Cout, acc);
         U3D_LAUNCH_CHECK();

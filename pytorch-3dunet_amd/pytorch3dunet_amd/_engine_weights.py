@@ -117,6 +117,19 @@ class WeightImages:
         self._pack_cache[key] = (ver, out)
         return out
 
+    def _t8_weights(self):
+        """ConvTranspose3d weights whose forward / data gradient run in space-to-depth form (residual nets, summation joining)"""
+        ws = getattr(self, "_t8w", None)
+        if ws is None:
+            ws = []
+            concat = getattr(self, "dec_concat", None)
+            if self.bf16 and concat is not None:
+                for j, (ct, _) in enumerate(self.dec):
+                    if isinstance(ct, torch.nn.ConvTranspose3d) and not concat[j] and self._convtr_t8(ct.in_channels, ct.out_channels):
+                        ws.append(ct.weight)
+            self._t8w = ws
+        return ws
+
     def _conv_weights(self):
         """every 3x3x3 conv weight the MFMA kernels read through a packed image"""
         out = []
@@ -145,17 +158,26 @@ class WeightImages:
         """bf16 fragment images of every bf16 layer whose parameter changed: ONE launch at HBM rate (u3d_pack_weights_bf16_batch)
         instead of one strided-read launch per layer and mode (36 + 36 per config-4 step, 1.0 ms -> 0.25 ms)"""
         lib = nat.get_lib()
-        stale = []
+        stale = []  # (weight, C-ABI mode of the batch kernel, cache slot): 3x3x3 images 0 / 1 -> slots 20 / 21; T8 images 4 / 5 -> 30 / 31
         for w in ws:
             if not self._bf16_layer(w.shape[1], w.shape[0]) or id(w) in self._virtual_w or w.data_ptr() % 16 != 0:
                 continue  # (the batch kernel reads 16 bytes per lane; an unaligned view is packed on demand by _packed_bf16)
             for mode in modes:
                 hit = self._pack_cache.get((id(w), 20 + mode))
                 if hit is None or hit[0] != self._ver(w):
-                    stale.append((w, mode))
+                    stale.append((w, mode, 20 + mode))
+        # the space-to-depth images of the transposed convolutions ride in the same launch (round 5; the per-weight kernel read 4
+        # bytes per lane at a stride of 27 floats: 8 launches of ~33 us per config-4 step)
+        for w in self._t8_weights():
+            if w.data_ptr() % 16 != 0 or lib.u3d_pack_weights_bf16_blocks(w.shape[0], w.shape[1], 4) == 0:
+                continue  # (Cs % 32 != 0: packed on demand by _packed_convtr_t8)
+            for mode in modes:
+                hit = self._pack_cache.get((id(w), 30 + mode))
+                if hit is None or hit[0] != self._ver(w):
+                    stale.append((w, 4 + mode, 30 + mode))
         if not stale:
             return
-        key = tuple((id(w), mode, w.data_ptr()) for w, mode in stale)
+        key = tuple((id(w), mode, w.data_ptr()) for w, mode, _ in stale)
         tab = getattr(self, "_pack_tables_bf16", None)
         if tab is None:
             tab = self._pack_tables_bf16 = {}
@@ -163,10 +185,14 @@ class WeightImages:
         if ent is None:
             descs = (nat.U3DPackDesc * len(stale))()
             bufs, first = [], 0
-            for i, (w, mode) in enumerate(stale):
-                Cout, Cin = w.shape[0], w.shape[1]
-                n = lib.u3d_packed_weight_bf16_elems(Cin, Cout, mode)
-                hit = self._pack_cache.get((id(w), 20 + mode))
+            for i, (w, mode, slot) in enumerate(stale):
+                if mode >= 4:  # ConvTranspose3d weight (Cl, Cs, 3,3,3): desc.Cin = Cl, desc.Cout = Cs
+                    Cin, Cout = w.shape[0], w.shape[1]
+                    n = lib.u3d_convtr3d_t8_packed_elems(Cin, Cout, mode - 4)
+                else:
+                    Cout, Cin = w.shape[0], w.shape[1]
+                    n = lib.u3d_packed_weight_bf16_elems(Cin, Cout, mode)
+                hit = self._pack_cache.get((id(w), slot))
                 buf = hit[1] if hit is not None and hit[1].numel() == n and hit[1].device == dev else _empty(
                     n, dtype=torch.bfloat16, device=dev)
                 bufs.append(buf)
@@ -179,8 +205,8 @@ class WeightImages:
             tab[key] = ent
         table, bufs, total = ent
         nat.call("u3d_pack_weights_bf16_batch", dev.index, _stream(dev), _p(table), len(stale), total)
-        for (w, mode), buf in zip(stale, bufs):
-            self._pack_cache[(id(w), 20 + mode)] = (self._ver(w), buf)
+        for (w, mode, slot), buf in zip(stale, bufs):
+            self._pack_cache[(id(w), slot)] = (self._ver(w), buf)
 
     def _repack_all(self, dev, modes, sub=()):
         """(Re)pack the images of ALL conv weights whose parameter changed since the last pack — one launch for the whole

@@ -215,6 +215,44 @@ def test_batched_bf16_weight_pack_equals_the_per_layer_pack():
         assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), (co, ci, mode)
 
 
+def test_batched_pack_of_the_transposed_convolution_images_equals_the_per_weight_pack():
+    """round 5: modes 4 / 5 of u3d_pack_weights_bf16_batch — the space-to-depth (T8) images of ConvTranspose3d weights (Cl, Cs, 3,3,3)
+    ride in the model's one pack launch; bit for bit the images of u3d_pack_convtr3d_t8 (forward / data gradient), mixed with 3x3x3
+    images in one descriptor table, incl. the zeroed prefetch tails"""
+    lib = nat.get_lib()
+    torch.manual_seed(21)
+    t8 = [torch.randn(cl, cs, 3, 3, 3, device=U.DEV) for cl, cs in [(64, 32), (128, 64), (256, 128), (96, 160)]]
+    w3 = torch.randn(64, 32, 3, 3, 3, device=U.DEV)
+    jobs = [(t8[0], 4), (w3, 0), (t8[1], 5), (t8[1], 4), (t8[2], 4), (t8[2], 5), (w3, 1), (t8[3], 4), (t8[3], 5), (t8[0], 5)]
+    assert lib.u3d_pack_weights_bf16_blocks(64, 24, 4) == 0  # Cs % 32 != 0: not batchable (falls back to the per-weight kernel)
+    descs = (nat.U3DPackDesc * len(jobs))()
+    outs, first = [], 0
+    for i, (w, mode) in enumerate(jobs):
+        if mode >= 4:
+            ci, co = w.shape[:2]  # desc.Cin = Cl, desc.Cout = Cs
+            n = lib.u3d_convtr3d_t8_packed_elems(ci, co, mode - 4)
+        else:
+            co, ci = w.shape[:2]
+            n = lib.u3d_packed_weight_bf16_elems(ci, co, mode)
+        buf = torch.full((n,), float("nan"), dtype=torch.bfloat16, device=U.DEV)
+        outs.append(buf)
+        descs[i].w, descs[i].packed, descs[i].first = w.data_ptr(), buf.data_ptr(), first
+        descs[i].Cout, descs[i].Cin, descs[i].mode, descs[i].cin_stride = co, ci, mode, 0
+        blocks = lib.u3d_pack_weights_bf16_blocks(ci, co, mode)
+        assert blocks > 0
+        first += blocks
+    table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(U.DEV)
+    nat.call("u3d_pack_weights_bf16_batch", 0, _stream(U.DEV), _p(table), len(jobs), first)
+    for (w, mode), got in zip(jobs, outs):
+        ref = torch.full_like(got, float("nan"))
+        if mode >= 4:
+            nat.call("u3d_pack_convtr3d_t8", 0, _stream(U.DEV), _p(w), w.shape[0], w.shape[1], mode - 4, _p(ref))
+        else:
+            nat.call("u3d_pack_weights_bf16", 0, _stream(U.DEV), _p(w), w.shape[0], w.shape[1], mode, _p(ref))
+        torch.cuda.synchronize()
+        assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), (tuple(w.shape), mode)
+
+
 # ---- model level ------------------------------------------------------------------------------------------------------
 MODEL_CASES = [
     # config 4's model family at reduced width / size: every 3x3x3 conv has channel counts that are multiples of 32

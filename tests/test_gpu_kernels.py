@@ -576,7 +576,9 @@ def test_maxpool_forward_backward_merge(N, C, size):
 
 @pytest.mark.parametrize("N,Cin,Cout,act", [(2, 32, 1, 1), (1, 8, 3, 2), (1, 16, 2, 0),
                                             # wide heads (round 5): > 16 outputs run in tiles of 16, softmax as a second pass
-                                            (2, 32, 24, 2), (1, 16, 17, 1), (1, 64, 40, 0), (1, 6, 33, 2)])
+                                            (2, 32, 24, 2), (1, 16, 17, 1), (1, 64, 40, 0), (1, 6, 33, 2),
+                                            # more outputs than inputs on the narrow kernels (the reduction rows overlapped until round 5)
+                                            (1, 6, 12, 1), (2, 5, 16, 2)])
 def test_head_forward_backward(N, Cin, Cout, act):
     U, nat, VSrc, _p, _stream = _mods()
     torch.manual_seed(Cin + Cout)
