@@ -210,6 +210,44 @@ int u3d_subpixel_conv_wgrad(int device, u3d_stream_t stream, const float* low, c
                             long long affine_sample_stride, const float* dz, float* dw, int dw_cin_stride, int N, int D1,
                             int H1, int W1, int C1, int Cout, float* workspace, long long workspace_floats);
 
+/* ---- decoder levels that upsample n -> 2n + 1 along some axes (round 5) --------------------------------------------------
+ * F.interpolate(x, size=skip, mode="nearest") to an ODD skip size (buildingblocks.py:598-614, :491 — the reference's shipped
+ * 80 x 170 x 170 patch pools 85 -> 42 and upsamples 42 -> 85) reads src = (dst - 1) >> 1 for dst >= 1 and 0 for dst = 0: the exact
+ * 2x upsampling shifted by one voxel with low[0] once more in front.  Every output voxel d >= 2 along such an axis sees exactly the
+ * shifted 2x tensor under its three taps, so the three sub-pixel kernels run on a WINDOW — out[d] / dz[d] with d = u + o, u the voxel
+ * of the 2x grid — and the slab d < 2 runs on the general kernel restricted to a box:
+ *   win (forward)  = {Do, Ho, Wo, oz, oy, ox}: dims of `out`, shift o = 1 on an n -> 2n + 1 axis (0 on an exact one).  Voxels d = o on
+ *                    a shifted axis are written but WRONG (they miss the extra copy of low[0]); u3d_conv3d_box overwrites the slab.
+ *   win (gradients) = {Dd, Hd, Wd, oz, oy, ox, lz, ly, lx}: dims of dz, shift, and the first voxel u of the 2x grid that counts (1 on
+ *                    a shifted axis: the outputs d >= 2).
+ *   u3d_conv3d_box: plain convolution of `src` (C0 may be 0: only the upsampled half; p0 must still be readable) for the output
+ *                    voxels inside out_box = {z0, y0, x0, z1, y1, x1}; in_mask = {mz, my, mx} or NULL: a source voxel counts only if
+ *                    mz && z < mz || my && y < my || mx && x < mx (the data gradient of the slab: dz outside it is zero).
+ *   u3d_conv3d_wgrad_box: weight gradient over the dz voxels inside `box` only (workspace: u3d_wgrad_workspace_floats of the box dims).
+ *   u3d_nearest_childsum_add: dlow[j] += sum over the children of low-res cell j of dv (a full-resolution gradient that is valid in
+ *                    the slab's dilation) for the cells with cz && jz < cz || cy && jy < cy || cx && jx < cx, + their share of the
+ *                    GroupNorm-backward sums gstats[n][c] += (sum, sum * x_low).  zlo / ylo / xlo: first child of every low-res
+ *                    index (n_in + 1 entries), as for u3d_gn_bwd_apply_up. */
+int u3d_subpixel_conv_fwd_win(int device, u3d_stream_t stream, const float* low, const float* affine, long long affine_sample_stride,
+                              const float* packed, float* out, int N, int D1, int H1, int W1, int C1, int Cout, const int* win);
+int u3d_subpixel_conv_dgrad_win(int device, u3d_stream_t stream, const float* dz, const float* packed, const float* x_low, float* dlow,
+                                double* gstats, int N, int D1, int H1, int W1, int C1, int Cout, const int* win);
+int u3d_subpixel_conv_wgrad_win(int device, u3d_stream_t stream, const float* low, const float* affine, long long affine_sample_stride,
+                                const float* dz, float* dw, int dw_cin_stride, int N, int D1, int H1, int W1, int C1, int Cout,
+                                float* workspace, long long workspace_floats, const int* win);
+int u3d_conv3d_box(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w, float* out, int N, int D, int H, int W,
+                   int Cout, const int* out_box, const int* in_mask);
+int u3d_conv3d_wgrad_box(int device, u3d_stream_t stream, const u3d_src_t* src, const float* dz, float* dw, int N, int D, int H, int W,
+                         int Cout, float* workspace, size_t workspace_floats, const int* box);
+/* GroupNorm backward on the low-res producer of such a level: out = (p * dlow + children * (q * x + r)) * [x > 0 if relu_mask] with
+ * children = (2 + [ez && z == 0]) (2 + [ey && y == 0]) (2 + [ex && x == 0]) per low-res cell and (p, q, r) = coef[n][0..2][coff + c]
+ * (the table of u3d_gn_bwd_finalize over Ctot channels; exact-2x levels use u3d_gn_bwd_apply with the constant 8 folded in). */
+int u3d_gn_bwd_apply_children(int device, u3d_stream_t stream, const float* dlow, const float* x, const float* coef, int Ctot, int coff,
+                              int N, int D1, int H1, int W1, int C, int ez, int ey, int ex, int relu_mask, float* out);
+int u3d_nearest_childsum_add(int device, u3d_stream_t stream, const float* dv, const float* x_low, float* dlow, double* gstats, int N,
+                             int D, int H, int W, int D1, int H1, int W1, int C, const int32_t* zlo, const int32_t* ylo,
+                             const int32_t* xlo, int cz, int cy, int cx);
+
 /* The network's first convolution (in_channels 1..4 behind a one-group GroupNorm): K = 27*Cin is too small for
  * the MFMA tiling, so it has bandwidth-shaped kernels of its own (same semantics as u3d_conv3d / u3d_conv3d_wgrad;
  * x is a plain (N,D,H,W,Cin) tensor, w the reference (Cout,Cin,3,3,3) weights, Cin <= 4, Cout <= 32).

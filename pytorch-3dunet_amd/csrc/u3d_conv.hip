@@ -80,6 +80,11 @@ struct ConvParams {
     int ksplit, cps;        // generic kernel, split-K: the chunk range is cut into ksplit runs of cps chunks, one per block,
     long long part_stride;  // each run writing its partial sums to out + run * part_stride (summed by splitk_reduce_kernel)
     long long* dbg;  // optional per-wave timeline records (u3d_set_profile_buffer), 24 int64 per wave
+    // generic kernel only (round 5, u3d_conv3d_box): OUTPUT BOX [o*0, o*1) — tiles are enumerated from its origin and only voxels inside
+    // are stored — and an INPUT SLAB MASK (mz, my, mx; all 0 = none): a source voxel counts only if mz && z < mz || my && y < my ||
+    // mx && x < mx, everything else reads as zero.  Defaults: the whole volume, no mask.
+    int oz0, oy0, ox0, oz1, oy1, ox1;
+    int mz, my, mx;
 };
 
 // timeline record of one wave (DBG kernels only), 24 int64: [0] block, [1] HW_ID, [2] XCC_ID, [3] t_entry,
@@ -161,9 +166,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvParams p)
     tile /= p.ty;
     const int tzi = tile % p.tz;
     const int n = tile / p.tz;
-    const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
+    const int z0 = p.oz0 + tzi * TZ, y0 = p.oy0 + tyi * TY, x0 = p.ox0 + txi * TX;
     const int D = p.D, H = p.H, W = p.W;
     const int Ctot = p.src.C0 + p.src.C1;
+    const bool slab_mask = (p.mz | p.my | p.mx) != 0;
 
     // ---- per-thread staging descriptors (constant across chunks)
     int ldsoff[NIT], gv0[NIT], gv1[NIT];
@@ -179,7 +185,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvParams p)
         const int hx = rem - hy * HX;
         ldsoff[it] = in ? hz * PS + hy * RS + hx * CS + 4 * q : HZ * PS;  // tail items -> dummy slot
         const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gxx = x0 - 1 + hx;
-        const bool ok = in && gz >= 0 && gz < D && gy >= 0 && gy < H && gxx >= 0 && gxx < W;
+        bool ok = in && gz >= 0 && gz < D && gy >= 0 && gy < H && gxx >= 0 && gxx < W;
+        if (slab_mask) ok = ok && ((p.mz && gz < p.mz) || (p.my && gy < p.my) || (p.mx && gxx < p.mx));
         gv0[it] = -1;
         gv1[it] = 0;
         if (ok) u3d_vox_index(p.src, n, gz, gy, gxx, D, H, W, gv0[it], gv1[it]);
@@ -418,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvParams p)
                 for (int k = 0; k < 4; ++k) {
                     const int st = 4 * half + k;
                     const int y = y0 + st;
-                    const bool ok = cok && z < D && y < H && x < W;
+                    const bool ok = cok && z < p.oz1 && y < p.oy1 && x < p.ox1;
                     f32x4 val = tq[st];
                     const size_t vidx = (size_t)((n * D + z) * H + y) * W + x;
                     if (p.res && ok) val += *reinterpret_cast<const f32x4*>(p.res + vidx * p.Cout + co);
@@ -477,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const ConvParams p)
             for (int r = 0; r < 16; ++r) {
                 const int y = y0 + mt * 4 + (r >> 2);
                 const int x = x0 + (r & 3) + 4 * h;
-                const bool vok = z < D && y < H && x < W;
+                const bool vok = z < p.oz1 && y < p.oy1 && x < p.ox1;
                 int v0 = 0, v1 = 0;
                 if (want_g) {
                     // clamped coordinates: always a valid address, masked below
@@ -1351,6 +1358,9 @@ struct WgradParams {
     int nchunks, nkb, S;
     int tz, ty, tx, ntiles, tps;
     int vec, dzvec;
+    // generic staging only (round 5, u3d_conv3d_wgrad_box): the voxels v of dz that take part — tiles are enumerated over this box
+    // and dz outside it reads as zero; g is read from the whole volume.  Default: the whole volume.
+    int bz0, by0, bx0, bz1, by1, bx1;
 };
 
 // One block = 8 waves (512 threads) per CU: wave w owns the 7 taps {tg, tg+4, ..} (tg = w & 3) on voxel half
@@ -1503,9 +1513,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
     };
     auto tile_coords = [&](const TileIdx& d) {
         TileC c;
-        c.x0 = d.xi * TX;
-        c.y0 = d.yi * TY;
-        c.z0 = d.zi * TZ;
+        c.x0 = (REG ? 0 : p.bx0) + d.xi * TX;
+        c.y0 = (REG ? 0 : p.by0) + d.yi * TY;
+        c.z0 = (REG ? 0 : p.bz0) + d.zi * TZ;
         c.n = d.n;
         c.base = c.dzb = 0;
         c.inv = 0;
@@ -1538,7 +1548,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
     auto dz_item = [&](const TileC& c, int it, bool& ok, int& idx) {
         const int vox = tv + 64 * it;
         const int z = c.z0 + (vox >> 6), y = c.y0 + ((vox >> 3) & 7), x = c.x0 + (vox & 7);
-        ok = dcok && z < D && y < H && x < W;
+        ok = dcok && z < p.bz1 && y < p.by1 && x < p.bx1;
         idx = ok ? ((c.n * D + z) * H + y) * W + x : 0;
     };
     auto load_affine = [&](int n, f32x4& ga, f32x4& gb) {
@@ -1614,7 +1624,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
             const int vox = tv + 64 * it;
             const int z = c.z0 + (vox >> 6), y = c.y0 + ((vox >> 3) & 7), x = c.x0 + (vox & 7);
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (z < D && y < H && x < W) {
+            if (z < p.bz1 && y < p.by1 && x < p.bx1) {
                 const float* sp = p.dz + ((size_t)((c.n * D + z) * H + y) * W + x) * p.Cout + co;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -1990,7 +2000,8 @@ static bool src_vec_ok(const u3d_src_t* s) {
 }
 
 static int check_src(const u3d_src_t* s, const char* what) {
-    U3D_REQUIRE(s != nullptr && s->p0 != nullptr && s->C0 > 0, "%s: null source", what);
+    // (C0 == 0: only the upsampled half — the box launches of round 5; p0 must still be a readable pointer: dead lanes load from it)
+    U3D_REQUIRE(s != nullptr && s->p0 != nullptr && (s->C0 > 0 || s->C1 > 0) && s->C0 >= 0, "%s: null source", what);
     U3D_REQUIRE(s->C1 >= 0, "%s: negative C1", what);
     if (s->C1 > 0)
         U3D_REQUIRE(s->p1 && s->zmap && s->ymap && s->xmap && s->D1 > 0 && s->H1 > 0 && s->W1 > 0,
@@ -2127,7 +2138,8 @@ static int conv_set_lds_once(int device) {
 
 static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w, float* out, int N,
                        int D, int H, int W, int Cout, int relu, double* out_stats, const u3d_src_t* gx, double* gstats,
-                       const float* residual, float* ws = nullptr, long long ws_floats = 0);
+                       const float* residual, float* ws = nullptr, long long ws_floats = 0, const int* out_box = nullptr,
+                       const int* in_mask = nullptr);
 
 extern "C" int u3d_conv3d(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w, float* out,
                           int N, int D, int H, int W, int Cout, int relu, double* out_stats, const u3d_src_t* gx,
@@ -2136,6 +2148,14 @@ extern "C" int u3d_conv3d(int device, u3d_stream_t stream, const u3d_src_t* src,
 }
 
 // split-K (see splitk_reduce_kernel): used when one block per (tile, 32-channel block) leaves most CUs idle
+// Plain convolution (no ReLU / statistics / residual) restricted to a BOX of output voxels, optionally reading only an input SLAB
+// (round 5: the near-boundary slab of a decoder level that upsamples n -> 2n + 1, see u3d_subpixel_conv_fwd_win).
+extern "C" int u3d_conv3d_box(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w, float* out, int N, int D,
+                              int H, int W, int Cout, const int* out_box, const int* in_mask) {
+    return conv3d_impl(device, stream, src, packed_w, out, N, D, H, W, Cout, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, out_box,
+                       in_mask);
+}
+
 constexpr int SPLITK_MAX = 16;
 static bool splitk_shape(int N, int D, int H, int W, int Cin, int Cout) {
     const long long items = (long long)N * cdiv(D, cv::TZ) * cdiv(H, cv::TY) * cdiv(W, cv::TX) * cdiv(Cout, 32);
@@ -2165,7 +2185,7 @@ extern "C" int u3d_conv3d_residual(int device, u3d_stream_t stream, const u3d_sr
 
 static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w, float* out, int N,
                        int D, int H, int W, int Cout, int relu, double* out_stats, const u3d_src_t* gx, double* gstats,
-                       const float* residual, float* ws, long long ws_floats) {
+                       const float* residual, float* ws, long long ws_floats, const int* out_box, const int* in_mask) {
     U3D_ENTER(device);
     if (int e = check_src(src, "u3d_conv3d")) return e;
     U3D_REQUIRE(packed_w && out && N > 0 && D > 0 && H > 0 && W > 0 && Cout > 0, "u3d_conv3d: bad argument");
@@ -2193,6 +2213,17 @@ static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, co
     p.nchunks = cdiv(Cin, 16);
     p.ntot = cdiv(Cout, 32);
     p.tz = cdiv(D, cv::TZ), p.ty = cdiv(H, cv::TY), p.tx = cdiv(W, cv::TX);
+    p.oz0 = p.oy0 = p.ox0 = 0, p.oz1 = D, p.oy1 = H, p.ox1 = W;
+    p.mz = p.my = p.mx = 0;
+    const bool boxed = out_box != nullptr || in_mask != nullptr;  // u3d_conv3d_box: the generic kernel on a sub-box of the volume
+    if (out_box) {
+        U3D_REQUIRE(out_box[0] >= 0 && out_box[1] >= 0 && out_box[2] >= 0 && out_box[3] <= D && out_box[4] <= H && out_box[5] <= W &&
+                        out_box[0] < out_box[3] && out_box[1] < out_box[4] && out_box[2] < out_box[5],
+                    "u3d_conv3d_box: output box outside the volume or empty");
+        p.oz0 = out_box[0], p.oy0 = out_box[1], p.ox0 = out_box[2], p.oz1 = out_box[3], p.oy1 = out_box[4], p.ox1 = out_box[5];
+        p.tz = cdiv(p.oz1 - p.oz0, cv::TZ), p.ty = cdiv(p.oy1 - p.oy0, cv::TY), p.tx = cdiv(p.ox1 - p.ox0, cv::TX);
+    }
+    if (in_mask) p.mz = in_mask[0], p.my = in_mask[1], p.mx = in_mask[2];
     p.relu = relu;
     p.vec = src_vec_ok(src) ? 1 : 0;
     // wide (16-byte) epilogue: whole channel quads, aligned output and (for dgrad) an x source readable in quads
@@ -2215,7 +2246,7 @@ static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, co
     p.ksplit = 1, p.cps = p.nchunks, p.part_stride = 0;
     // ---- split-K on small volumes: ksplit blocks per (tile, 32-channel block), partial sums in the caller's workspace,
     //      summed in a fixed order by splitk_reduce_kernel together with the epilogue (key 7 = 2 turns it off)
-    if (ws && p.vec && p.ovec && ((uintptr_t)ws & 15) == 0 && splitk_shape(N, D, H, W, Cin, Cout) && g_u3d_tune[7] != 2) {
+    if (!boxed && ws && p.vec && p.ovec && ((uintptr_t)ws & 15) == 0 && splitk_shape(N, D, H, W, Cin, Cout) && g_u3d_tune[7] != 2) {
         int ncu = 0;
         if (int e = device_cu_count(device, &ncu)) return e;
         const long long items = ntiles * p.ntot, out_elems = (long long)N * D * H * W * Cout;
@@ -2258,7 +2289,7 @@ static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, co
     const bool ragged = D % cv::TZ != 0 || H % cv::TY != 0 || W % cv::TX != 0;
     const bool reg = p.vec && p.ovec && plain_or_x2(p.src) && (!gx || plain_or_x2(p.gx)) && g_u3d_tune[3] == 0 ||
                      (g_u3d_tune[3] == 2 && !ragged && p.vec && p.ovec && plain_or_x2(p.src) && (!gx || plain_or_x2(p.gx)));
-    if (reg) {
+    if (reg && !boxed) {
         p.total = (int)nblk;
         p.gx_x2 = (gx && p.gx.C1 > 0) ? 1 : 0;
         // experiment knob, default off: a sweep of 8..64 k cycles changed no layer by more than noise (profiles/r01q) — a
@@ -2390,7 +2421,7 @@ static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, co
     return 0;
 }
 
-static void wgrad_plan(int N, int D, int H, int W, int Cin, int Cout, WgradParams& p) {
+static void wgrad_plan(int N, int D, int H, int W, int Cin, int Cout, WgradParams& p) {  // (D, H, W: of the dz box)
     p.nchunks = cdiv(Cin, 32);
     p.nkb = cdiv(Cout, 32);
     p.tz = cdiv(D, wg::TZ), p.ty = cdiv(H, wg::TY), p.tx = cdiv(W, wg::TX);
@@ -2440,7 +2471,15 @@ static int wgrad_set_lds_once(int device) {
 }
 
 static int conv3d_wgrad_impl(int device, u3d_stream_t stream, const u3d_src_t* src, const float* dz, float* dw, int cstride,
-                             int N, int D, int H, int W, int Cout, float* workspace, size_t workspace_floats);
+                             int N, int D, int H, int W, int Cout, float* workspace, size_t workspace_floats, const int* box = nullptr);
+
+// Weight gradient over a BOX of dz voxels only (dz outside the box counts as zero; g is read from the whole volume): round 5, the
+// near-boundary slab of a decoder level that upsamples n -> 2n + 1.  Workspace: u3d_wgrad_workspace_floats of the BOX dims.
+extern "C" int u3d_conv3d_wgrad_box(int device, u3d_stream_t stream, const u3d_src_t* src, const float* dz, float* dw, int N, int D,
+                                    int H, int W, int Cout, float* workspace, size_t workspace_floats, const int* box) {
+    U3D_REQUIRE(box != nullptr, "u3d_conv3d_wgrad_box: box is NULL");
+    return conv3d_wgrad_impl(device, stream, src, dz, dw, 0, N, D, H, W, Cout, workspace, workspace_floats, box);
+}
 
 extern "C" int u3d_conv3d_wgrad(int device, u3d_stream_t stream, const u3d_src_t* src, const float* dz, float* dw,
                                 int N, int D, int H, int W, int Cout, float* workspace, size_t workspace_floats) {
@@ -2455,14 +2494,20 @@ extern "C" int u3d_conv3d_wgrad_strided(int device, u3d_stream_t stream, const u
 }
 
 static int conv3d_wgrad_impl(int device, u3d_stream_t stream, const u3d_src_t* src, const float* dz, float* dw, int cstride,
-                             int N, int D, int H, int W, int Cout, float* workspace, size_t workspace_floats) {
+                             int N, int D, int H, int W, int Cout, float* workspace, size_t workspace_floats, const int* box) {
     U3D_ENTER(device);
     if (int e = check_src(src, "u3d_conv3d_wgrad")) return e;
     U3D_REQUIRE(dz && dw && workspace && N > 0 && D > 0 && H > 0 && W > 0 && Cout > 0, "u3d_conv3d_wgrad: bad argument");
     U3D_REQUIRE((long long)N * D * H * W < (1ll << 31), "u3d_conv3d_wgrad: N*D*H*W must be < 2^31");
     WgradParams p;
     const int Cin = src->C0 + src->C1;
-    wgrad_plan(N, D, H, W, Cin, Cout, p);
+    p.bz0 = p.by0 = p.bx0 = 0, p.bz1 = D, p.by1 = H, p.bx1 = W;
+    if (box) {
+        U3D_REQUIRE(box[0] >= 0 && box[1] >= 0 && box[2] >= 0 && box[3] <= D && box[4] <= H && box[5] <= W && box[0] < box[3] &&
+                        box[1] < box[4] && box[2] < box[5], "u3d_conv3d_wgrad_box: box outside the volume or empty");
+        p.bz0 = box[0], p.by0 = box[1], p.bx0 = box[2], p.bz1 = box[3], p.by1 = box[4], p.bx1 = box[5];
+    }
+    wgrad_plan(N, p.bz1 - p.bz0, p.by1 - p.by0, p.bx1 - p.bx0, Cin, Cout, p);
     const size_t need = (size_t)p.S * p.nchunks * p.nkb * 27 * 1024;
     if (workspace_floats < need)
         return u3d_set_err(U3D_EWORKSPACE, "u3d_conv3d_wgrad: workspace %zu < %zu floats", workspace_floats, need);
@@ -2478,7 +2523,7 @@ static int conv3d_wgrad_impl(int device, u3d_stream_t stream, const u3d_src_t* s
     const size_t shmem = (wg::LDS_FLOATS + (size_t)(D + H + W)) * sizeof(float);
     // no table look-ups (plain or exact-2x source) -> constant-offset staging (REG); ragged last tiles are part of its face masks
     // (key 3 = 2: the round-4 gate "every tile fully inside the volume", for A/B runs)
-    const bool reg = (g_u3d_tune[3] != 2 || (D % wg::TZ == 0 && H % wg::TY == 0 && W % wg::TX == 0)) &&
+    const bool reg = !box && (g_u3d_tune[3] != 2 || (D % wg::TZ == 0 && H % wg::TY == 0 && W % wg::TX == 0)) &&
                      (src->C1 == 0 || (D == 2 * src->D1 && H == 2 * src->H1 && W == 2 * src->W1));
     if (p.vec && p.dzvec && reg && Cin <= 16)
         hipLaunchKernelGGL((conv3d_wgrad_kernel<true, true, true>), dim3(nblk), dim3(wg::NTHR), shmem, (hipStream_t)stream, p);

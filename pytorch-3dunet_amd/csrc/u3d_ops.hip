@@ -505,6 +505,121 @@ extern "C" int u3d_gn_bwd_apply_up(int device, u3d_stream_t stream, const float*
     return 0;
 }
 
+// GroupNorm backward on the LOW-RES producer of a level that upsamples n -> 2n + 1 along the axes with e = 1 (round 5): dlow holds the
+// children sums of dg, and a low-res cell has (2 + [e_z && z == 0]) (2 + [e_y && y == 0]) (2 + [e_x && x == 0]) children (the first cell
+// of a shifted axis has three), so  out = (p * dlow + children * (q * x + r)) * [x > 0 if relu_mask]  — the exact-2x levels fold the
+// constant 8 into the coefficient table instead (u3d_gn_bwd_apply).
+__global__ void gn_bwd_apply_cnt_kernel(const float* __restrict__ dlow, const float* __restrict__ x, const float* __restrict__ coef,
+                                        int Ctot, int coff, int N, int D1, int H1, int W1, int C, int ez, int ey, int ex, int relu_mask,
+                                        float* __restrict__ out) {
+    const int Q = C >> 2;
+    const long long total = (long long)N * D1 * H1 * W1 * Q;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % Q) * 4;
+        long long v = idx / Q;
+        const int xx = (int)(v % W1);
+        v /= W1;
+        const int yy = (int)(v % H1);
+        v /= H1;
+        const int zz = (int)(v % D1);
+        const int n = (int)(v / D1);
+        const float cnt = (float)((2 + (ez && zz == 0)) * (2 + (ey && yy == 0)) * (2 + (ex && xx == 0)));
+        const size_t oi = (size_t)(idx / Q) * C + c;
+        const f32x4 dg = *reinterpret_cast<const f32x4*>(dlow + oi), xv = *reinterpret_cast<const f32x4*>(x + oi);
+        const f32x4 pp = *reinterpret_cast<const f32x4*>(coef + ((size_t)n * 3 + 0) * Ctot + coff + c);
+        const f32x4 qq = *reinterpret_cast<const f32x4*>(coef + ((size_t)n * 3 + 1) * Ctot + coff + c);
+        const f32x4 rr = *reinterpret_cast<const f32x4*>(coef + ((size_t)n * 3 + 2) * Ctot + coff + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = pp[e] * dg[e] + cnt * (qq[e] * xv[e] + rr[e]);
+            if (relu_mask && !(xv[e] > 0.f)) o[e] = 0.f;
+        }
+        *reinterpret_cast<f32x4*>(out + oi) = o;
+    }
+}
+
+extern "C" int u3d_gn_bwd_apply_children(int device, u3d_stream_t stream, const float* dlow, const float* x, const float* coef, int Ctot,
+                                         int coff, int N, int D1, int H1, int W1, int C, int ez, int ey, int ex, int relu_mask,
+                                         float* out) {
+    U3D_ENTER(device);
+    U3D_REQUIRE(dlow && x && coef && out && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && C > 0 && C % 4 == 0 && coff >= 0 && coff % 4 == 0 &&
+                    Ctot % 4 == 0 && coff + C <= Ctot && (((uintptr_t)dlow | (uintptr_t)x | (uintptr_t)coef | (uintptr_t)out) & 15) == 0,
+                "u3d_gn_bwd_apply_children: bad argument (channel counts / offsets must be multiples of 4, 16-byte aligned pointers)");
+    const long long total = (long long)N * D1 * H1 * W1 * (C / 4);
+    hipLaunchKernelGGL(gn_bwd_apply_cnt_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, dlow, x, coef, Ctot, coff,
+                       N, D1, H1, W1, C, ez, ey, ex, relu_mask, out);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// Round 5, decoder levels that upsample n -> 2n + 1 (F.interpolate(nearest) to an odd skip size, buildingblocks.py:598-614): the
+// data gradient of the outputs in the near-boundary slab arrives as a FULL-RESOLUTION gradient dv of the upsampled channels (written by
+// u3d_conv3d_box inside the slab's one-voxel dilation only).  Backward of the nearest upsampling for exactly those low-res cells whose
+// children lie in that region — cell j is AFFECTED if cz && jz < cz || cy && jy < cy || cx && jx < cx (every child of an affected
+// cell is inside the region) — ADDED to dlow, with the cell's share of the GroupNorm-backward sums (sum add, sum add * x_low).
+__global__ __launch_bounds__(256) void nearest_childsum_add_kernel(const float* __restrict__ dv, const float* __restrict__ xlow,
+                                                                   float* __restrict__ dlow, double* __restrict__ gstats, int N, int D,
+                                                                   int H, int W, int D1, int H1, int W1, int C,
+                                                                   const int* __restrict__ zlo, const int* __restrict__ ylo,
+                                                                   const int* __restrict__ xlo, int cz, int cy, int cx) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char childsum_lds[];
+    double* red = reinterpret_cast<double*>(childsum_lds);  // [C][2]: this block's partial sums of the sample it is working on
+    const int Q = C >> 2;
+    const long long per_n = (long long)D1 * H1 * W1 * Q;
+    for (int n = 0; n < N; ++n) {
+        for (int k = threadIdx.x; k < 2 * C; k += blockDim.x) red[k] = 0.0;
+        __syncthreads();
+        for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < per_n; idx += (long long)gridDim.x * blockDim.x) {
+            const int c = (int)(idx % Q) * 4;
+            long long v = idx / Q;
+            const int xx = (int)(v % W1);
+            v /= W1;
+            const int yy = (int)(v % H1);
+            const int zz = (int)(v / H1);
+            if (!((cz && zz < cz) || (cy && yy < cy) || (cx && xx < cx))) continue;
+            f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+            for (int z = zlo[zz]; z < zlo[zz + 1]; ++z)
+                for (int y = ylo[yy]; y < ylo[yy + 1]; ++y)
+                    for (int x = xlo[xx]; x < xlo[xx + 1]; ++x)
+                        sum += *reinterpret_cast<const f32x4*>(dv + ((size_t)((n * D + z) * H + y) * W + x) * C + c);
+            const size_t oi = ((size_t)((n * D1 + zz) * H1 + yy) * W1 + xx) * C + c;
+            f32x4* dst = reinterpret_cast<f32x4*>(dlow + oi);
+            *dst = *dst + sum;
+            if (gstats) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xlow + oi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    __hip_atomic_fetch_add(&red[2 * (c + e)], (double)sum[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&red[2 * (c + e) + 1], (double)sum[e] * (double)xv[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        __syncthreads();
+        if (gstats)
+            for (int k = threadIdx.x; k < 2 * C; k += blockDim.x)
+                if (red[k] != 0.0) u3d_atomic_add_f64(&gstats[(size_t)n * C * 2 + k], red[k]);
+        __syncthreads();
+    }
+}
+
+extern "C" int u3d_nearest_childsum_add(int device, u3d_stream_t stream, const float* dv, const float* x_low, float* dlow,
+                                        double* gstats, int N, int D, int H, int W, int D1, int H1, int W1, int C, const int32_t* zlo,
+                                        const int32_t* ylo, const int32_t* xlo, int cz, int cy, int cx) {
+    U3D_ENTER(device);
+    U3D_REQUIRE(dv && dlow && zlo && ylo && xlo && N > 0 && D > 0 && H > 0 && W > 0 && D1 > 0 && H1 > 0 && W1 > 0 && C > 0 && C % 4 == 0 &&
+                    C <= 2048 && (gstats == nullptr || x_low != nullptr) && (cz > 0 || cy > 0 || cx > 0),
+                "u3d_nearest_childsum_add: bad argument (C must be a multiple of 4, <= 2048)");
+    U3D_REQUIRE((((uintptr_t)dv | (uintptr_t)dlow | (uintptr_t)x_low) & 15) == 0, "u3d_nearest_childsum_add: 16-byte alignment");
+    const long long per_n = (long long)D1 * H1 * W1 * (C / 4);
+    long long blocks = (per_n + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(nearest_childsum_add_kernel, dim3((unsigned)blocks), dim3(256), (size_t)2 * C * sizeof(double), (hipStream_t)stream,
+                       dv, x_low, dlow, gstats, N, D, H, W, D1, H1, W1, C, zlo, ylo, xlo, cz, cy, cx);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
 // =================================================================================================
 // MaxPool3d(2): stride 2, floor.  One thread per (n, out voxel, channel).
 template <typename T = float>

@@ -35,6 +35,8 @@ struct SubpixParams {
     int tz, ty, tx, nchunks, ncb;
     int ksplit, cps;        // split-K on small grids: ksplit blocks per (tile, channel block), each over a run of cps chunks,
     long long part_stride;  // writing its partial sums to out + run * part_stride (summed by sum_partials_kernel)
+    int oz, oy, ox;         // round 5 (u3d_subpixel_conv_fwd_win): full-res voxel u of the 2x grid is written to out[u + o] — a decoder
+                            // level that upsamples n -> 2n + 1 is the exact 2x upsampling shifted by one (see the entry point)
 };
 
 __device__ __forceinline__ void sp_flag_signal(int* c, int lane) {
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void subpixel_fwd_kernel(const SubpixParams
     // output channel m of voxel x = (r&3) + 4h, so one 4-byte store per register writes two full 128-byte channel rows.  The
     // address is a UNIFORM base (scalar arithmetic) plus a per-lane constant: no VALU at all, against 4 VALU per value for
     // the in-register transposition below (a VALU instruction issued beside another wave's MFMA stream waits ~45 cycles).
-    const bool full = 2 * (z0 + TZ) - 1 < D && 2 * (y0 + TY) - 1 < H && 2 * (x0 + TX) - 1 < W && cb * 32 + 32 <= p.Cout;
+    const bool full = 2 * (z0 + TZ) - 1 + p.oz < D && 2 * (y0 + TY) - 1 + p.oy < H && 2 * (x0 + TX) - 1 + p.ox < W && cb * 32 + 32 <= p.Cout;
     if (full) {
         const int wz = __builtin_amdgcn_readfirstlane(z);
         const int lane_off = 8 * h * p.Cout + m;  // x = x0 + (r&3) + 4h  ->  full-res 2x: 8h voxels further
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void subpixel_fwd_kernel(const SubpixParams
             constexpr int pz = c >> 2, py = (c >> 1) & 1, px = c & 1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const size_t vu = ((size_t)(n * D + 2 * wz + pz) * H + 2 * (y0 + (r >> 2)) + py) * W + 2 * (x0 + (r & 3)) + px;
+                const size_t vu = ((size_t)(n * D + 2 * wz + pz + p.oz) * H + 2 * (y0 + (r >> 2)) + py + p.oy) * W + 2 * (x0 + (r & 3)) + px + p.ox;
                 float* ob = outp + vu * p.Cout + cb * 32;
                 ob[lane_off] = acc[c][r];
             }
@@ -269,8 +271,8 @@ __global__ __launch_bounds__(256, 2) void subpixel_fwd_kernel(const SubpixParams
             const float u0 = xlane(c2, X2{}), u2 = xlane(c0, X2{}), u1 = xlane(c3, X2{}), u3 = xlane(c1, X2{});
             const f32x4 val = {hi2 ? u0 : c0, hi2 ? u1 : c1, hi2 ? c2 : u2, hi2 ? c3 : u3};
             const int y = y0 + bi;
-            if (cok && 2 * z + pz < D && 2 * y + py < H && 2 * x + px < W) {
-                const size_t vidx = ((size_t)(n * D + 2 * z + pz) * H + 2 * y + py) * W + 2 * x + px;
+            if (cok && 2 * z + pz + p.oz < D && 2 * y + py + p.oy < H && 2 * x + px + p.ox < W) {
+                const size_t vidx = ((size_t)(n * D + 2 * z + pz + p.oz) * H + 2 * y + py + p.oy) * W + 2 * x + px + p.ox;
                 *reinterpret_cast<f32x4*>(outp + vidx * p.Cout + co) = val;
             }
         }
@@ -304,6 +306,9 @@ struct SubpixDgradParams {
     double* gstats;     // [N][C1][2] += (sum dlow, sum dlow*x), may be null
     int N, D1, H1, W1, C1, K;
     int tz, ty, tx, nchunks, ncb, ntot;
+    // round 5 (u3d_subpixel_conv_dgrad_win): voxel u of the 2x grid is dz[u + o] of a (Dd, Hd, Wd) tensor and counts only if u >= l
+    // (below l: zero — those outputs belong to the boundary slab, whose gradient comes from the box launches)
+    int Dd, Hd, Wd, oz, oy, ox, lz, ly, lx;
 };
 
 __global__ __launch_bounds__(256, 2) void subpixel_dgrad_kernel(const SubpixDgradParams p) {
@@ -346,8 +351,8 @@ __global__ __launch_bounds__(256, 2) void subpixel_dgrad_kernel(const SubpixDgra
         ldsoff[it] = in ? ((rz * 2 + (ry & 1)) * (RY / 2) + (ry >> 1)) * ROW + ((rx & 1) * (RX / 2) + (rx >> 1)) * 16 + 4 * q
                         : REGION_FLOATS;
         const int gz = 2 * z0 - 1 + rz, gy = 2 * y0 - 1 + ry, gx = 2 * x0 - 1 + rx;
-        const bool ok = in && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        gv[it] = ok ? ((n * D + gz) * H + gy) * W + gx : -1;
+        const bool ok = in && gz >= p.lz && gz < D && gy >= p.ly && gy < H && gx >= p.lx && gx < W;
+        gv[it] = ok ? ((n * p.Dd + gz + p.oz) * p.Hd + gy + p.oy) * p.Wd + gx + p.ox : -1;
     }
 
     f32x16 acc;
@@ -508,6 +513,7 @@ struct SubpixWgradParams {
     float* partial;       // [S][nchunks][nkb][64 (p, e)][32 c][32 k]
     int N, D1, H1, W1, C1, K;
     int nchunks, nkb, S, tz, ty, tx, ntiles, tps;
+    int Dd, Hd, Wd, oz, oy, ox, lz, ly, lx;  // dz window as in SubpixDgradParams (general B loads only: never with FULL)
 };
 
 // FULL (round 4): every tile lies inside the volume and K is a multiple of 32 — the address of a lane's dz element is then
@@ -607,9 +613,9 @@ __global__ __launch_bounds__(512, 2) void subpixel_wgrad_kernel(const SubpixWgra
             return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dz_rsrc, (int)lane_off, vox * K * 4, 0));
         }
         const int zl = g >> 4, yl = (g >> 2) & 3, xl = 2 * (g & 3) + h;
-        const bool ok = kok & (c.z0 + zl < D1) & (c.y0 + yl < H1) & (c.x0 + xl < W1);
         const int vz = 2 * (c.z0 + zl) + pz, vy = 2 * (c.y0 + yl) + py, vx = 2 * (c.x0 + xl) + px;
-        int vi = ok ? ((c.n * 2 * D1 + vz) * H + vy) * W + vx : 0;
+        const bool ok = kok & (c.z0 + zl < D1) & (c.y0 + yl < H1) & (c.x0 + xl < W1) & (vz >= p.lz) & (vy >= p.ly) & (vx >= p.lx);
+        int vi = ok ? ((c.n * p.Dd + vz + p.oz) * p.Hd + vy + p.oy) * p.Wd + vx + p.ox : 0;
         asm volatile("" : "+v"(vi));  // opaque: an unconditional load from a clamped address, no exec-masked branch
         const float v = p.dz[(size_t)vi * K + (kok ? kch : 0)];
         return ok ? v : 0.f;
@@ -771,9 +777,36 @@ extern "C" long long u3d_subpixel_fwd_workspace_floats(int N, int D1, int H1, in
     return ks > 1 ? (long long)ks * N * D1 * H1 * W1 * 8 * Cout : 0;
 }
 
+static int subpixel_conv_fwd_impl(int device, u3d_stream_t stream, const float* low, const float* affine,
+                                  long long affine_sample_stride, const float* packed, float* out, int N, int D1, int H1, int W1,
+                                  int C1, int Cout, float* workspace, long long workspace_floats, const int* win);
+
 extern "C" int u3d_subpixel_conv_fwd(int device, u3d_stream_t stream, const float* low, const float* affine,
                                      long long affine_sample_stride, const float* packed, float* out, int N, int D1,
                                      int H1, int W1, int C1, int Cout, float* workspace, long long workspace_floats) {
+    return subpixel_conv_fwd_impl(device, stream, low, affine, affine_sample_stride, packed, out, N, D1, H1, W1, C1, Cout, workspace,
+                                  workspace_floats, nullptr);
+}
+
+// ... into a WINDOW of a larger output (round 5).  F.interpolate(x, size=skip, mode="nearest") from n to 2n + 1 voxels along an axis
+// (buildingblocks.py:598-614; the shipped 80 x 170 x 170 patch pools 85 -> 42 and upsamples 42 -> 85) reads src = floor(dst * n / (2n+1))
+// = (dst - 1) >> 1 for dst >= 1 and 0 for dst = 0: the exact 2x upsampling SHIFTED BY ONE, with low[0] once more in front.  For every
+// output voxel d >= 2 along such an axis the three taps of the convolution see exactly the shifted 2x tensor, so
+//     out[d] = (exact-2x sub-pixel convolution)[d - 1],
+// zero padding at the far end included; only the slab d < 2 needs the general kernel (u3d_conv3d_box).  win = {Do, Ho, Wo, oz, oy, ox}:
+// dims of `out` and the shift (1 on an n -> 2n + 1 axis, 0 on an exact one).  Voxels d = o (u = 0) are written too and are WRONG on
+// shifted axes (they miss the extra copy of low[0]): the caller overwrites the slab afterwards.  No split-K (workspace unused).
+extern "C" int u3d_subpixel_conv_fwd_win(int device, u3d_stream_t stream, const float* low, const float* affine,
+                                         long long affine_sample_stride, const float* packed, float* out, int N, int D1, int H1,
+                                         int W1, int C1, int Cout, const int* win) {
+    U3D_REQUIRE(win != nullptr, "u3d_subpixel_conv_fwd_win: win is NULL");
+    return subpixel_conv_fwd_impl(device, stream, low, affine, affine_sample_stride, packed, out, N, D1, H1, W1, C1, Cout, nullptr, 0,
+                                  win);
+}
+
+static int subpixel_conv_fwd_impl(int device, u3d_stream_t stream, const float* low, const float* affine,
+                                  long long affine_sample_stride, const float* packed, float* out, int N, int D1, int H1, int W1,
+                                  int C1, int Cout, float* workspace, long long workspace_floats, const int* win) {
     U3D_ENTER(device);
     U3D_REQUIRE(low && packed && out && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && C1 > 0 && Cout > 0,
                 "u3d_subpixel_conv_fwd: bad argument");
@@ -787,12 +820,20 @@ extern "C" int u3d_subpixel_conv_fwd(int device, u3d_stream_t stream, const floa
     p.low = low, p.affine = affine, p.aff_nstride = affine_sample_stride, p.wp = packed, p.out = out;
     p.N = N, p.D1 = D1, p.H1 = H1, p.W1 = W1, p.C1 = C1, p.Cout = Cout;
     p.Do = 2 * D1, p.Ho = 2 * H1, p.Wo = 2 * W1;
+    p.oz = p.oy = p.ox = 0;
+    if (win) {
+        p.Do = win[0], p.Ho = win[1], p.Wo = win[2], p.oz = win[3], p.oy = win[4], p.ox = win[5];
+        U3D_REQUIRE(p.oz >= 0 && p.oy >= 0 && p.ox >= 0 && 2 * D1 + p.oz <= p.Do && 2 * H1 + p.oy <= p.Ho && 2 * W1 + p.ox <= p.Wo,
+                    "u3d_subpixel_conv_fwd_win: the shifted 2x grid does not fit the output");
+        U3D_REQUIRE((long long)N * p.Do * p.Ho * p.Wo < (1ll << 31), "u3d_subpixel_conv_fwd_win: volume too large");
+    }
     p.tz = sp_cdiv(D1, sp::TZ), p.ty = sp_cdiv(H1, sp::TY), p.tx = sp_cdiv(W1, sp::TX);
     p.nchunks = sp_cdiv(C1, 16), p.ncb = sp_cdiv(Cout, 32);
     long long nblk = (long long)N * p.tz * p.ty * p.tx * p.ncb;
     U3D_REQUIRE(nblk < (1ll << 31), "u3d_subpixel_conv_fwd: grid too large");
     const long long out_elems = (long long)N * D1 * H1 * W1 * 8 * Cout;
     subpixel_fwd_split(nblk, p.nchunks, &p.ksplit, &p.cps);
+    if (win) p.ksplit = 1;  // (the split partials are laid out like an exact-2x output)
     if (p.ksplit > 1 && workspace && ((uintptr_t)workspace & 15) == 0 && (long long)p.ksplit * out_elems <= workspace_floats) {
         p.out = workspace, p.part_stride = out_elems;
         nblk *= p.ksplit;
@@ -851,6 +892,7 @@ extern "C" int u3d_convtr3d_fwd_subpixel(int device, u3d_stream_t stream, const 
     p.low = x, p.affine = nullptr, p.aff_nstride = 0, p.wp = packed, p.out = t;
     p.N = N, p.D1 = D1, p.H1 = H1, p.W1 = W1, p.C1 = Cin, p.Cout = Cout;
     p.Do = 2 * D1 - 1, p.Ho = 2 * H1 - 1, p.Wo = 2 * W1 - 1;
+    p.oz = p.oy = p.ox = 0;
     p.tz = sp_cdiv(D1, sp::TZ), p.ty = sp_cdiv(H1, sp::TY), p.tx = sp_cdiv(W1, sp::TX);
     p.nchunks = sp_cdiv(Cin, 16), p.ncb = sp_cdiv(Cout, 32);
     p.ksplit = 1, p.cps = p.nchunks, p.part_stride = 0;
@@ -887,9 +929,28 @@ extern "C" int u3d_pack_subpixel_dgrad_weights(int device, u3d_stream_t stream, 
     return 0;
 }
 
+static int subpixel_conv_dgrad_impl(int device, u3d_stream_t stream, const float* dz, const float* packed, const float* x_low,
+                                    float* dlow, double* gstats, int N, int D1, int H1, int W1, int C1, int Cout, const int* win);
+
 extern "C" int u3d_subpixel_conv_dgrad(int device, u3d_stream_t stream, const float* dz, const float* packed,
                                        const float* x_low, float* dlow, double* gstats, int N, int D1, int H1, int W1, int C1,
                                        int Cout) {
+    return subpixel_conv_dgrad_impl(device, stream, dz, packed, x_low, dlow, gstats, N, D1, H1, W1, C1, Cout, nullptr);
+}
+
+// ... reading dz through the window of u3d_subpixel_conv_fwd_win: win = {Dd, Hd, Wd, oz, oy, ox, lz, ly, lx} — dz is (N, Dd, Hd, Wd,
+// Cout), voxel u of the 2x grid is dz[u + o], and voxels u < l do not count (l = 1 on an n -> 2n + 1 axis: output d = 1 belongs to the
+// boundary slab, whose share of the gradient the box launches + u3d_nearest_childsum_add deliver).  dlow / gstats: the share of the
+// outputs d >= 2.
+extern "C" int u3d_subpixel_conv_dgrad_win(int device, u3d_stream_t stream, const float* dz, const float* packed, const float* x_low,
+                                           float* dlow, double* gstats, int N, int D1, int H1, int W1, int C1, int Cout,
+                                           const int* win) {
+    U3D_REQUIRE(win != nullptr, "u3d_subpixel_conv_dgrad_win: win is NULL");
+    return subpixel_conv_dgrad_impl(device, stream, dz, packed, x_low, dlow, gstats, N, D1, H1, W1, C1, Cout, win);
+}
+
+static int subpixel_conv_dgrad_impl(int device, u3d_stream_t stream, const float* dz, const float* packed, const float* x_low,
+                                    float* dlow, double* gstats, int N, int D1, int H1, int W1, int C1, int Cout, const int* win) {
     U3D_ENTER(device);
     U3D_REQUIRE(dz && packed && dlow && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && C1 > 0 && Cout > 0,
                 "u3d_subpixel_conv_dgrad: bad argument");
@@ -902,6 +963,13 @@ extern "C" int u3d_subpixel_conv_dgrad(int device, u3d_stream_t stream, const fl
     SubpixDgradParams p;
     p.dz = dz, p.wp = packed, p.xlow = x_low, p.out = dlow, p.gstats = gstats;
     p.N = N, p.D1 = D1, p.H1 = H1, p.W1 = W1, p.C1 = C1, p.K = Cout;
+    p.Dd = 2 * D1, p.Hd = 2 * H1, p.Wd = 2 * W1, p.oz = p.oy = p.ox = 0, p.lz = p.ly = p.lx = 0;
+    if (win) {
+        p.Dd = win[0], p.Hd = win[1], p.Wd = win[2], p.oz = win[3], p.oy = win[4], p.ox = win[5], p.lz = win[6], p.ly = win[7], p.lx = win[8];
+        U3D_REQUIRE(p.oz >= 0 && p.oy >= 0 && p.ox >= 0 && 2 * D1 + p.oz <= p.Dd && 2 * H1 + p.oy <= p.Hd && 2 * W1 + p.ox <= p.Wd &&
+                        p.lz >= 0 && p.ly >= 0 && p.lx >= 0 && (long long)N * p.Dd * p.Hd * p.Wd < (1ll << 31),
+                    "u3d_subpixel_conv_dgrad_win: bad window");
+    }
     p.tz = sp_cdiv(D1, spd::TZ), p.ty = sp_cdiv(H1, spd::TY), p.tx = sp_cdiv(W1, spd::TX);
     p.nchunks = sp_cdiv(Cout, 16), p.ntot = sp_cdiv(C1, 32), p.ncb = sp_cdiv(p.ntot, 2);
     const long long nblk = (long long)N * p.tz * p.ty * p.tx * p.ncb;
@@ -946,10 +1014,32 @@ extern "C" long long u3d_subpixel_wgrad_workspace_floats(int N, int D1, int H1, 
     return (long long)p.S * p.nchunks * p.nkb * 64 * 1024;
 }
 
+static int subpixel_conv_wgrad_impl(int device, u3d_stream_t stream, const float* low, const float* affine, long long affine_sample_stride,
+                                    const float* dz, float* dw, int dw_cin_stride, int N, int D1, int H1, int W1, int C1, int Cout,
+                                    float* workspace, long long workspace_floats, const int* win);
+
 extern "C" int u3d_subpixel_conv_wgrad(int device, u3d_stream_t stream, const float* low, const float* affine,
                                        long long affine_sample_stride, const float* dz, float* dw, int dw_cin_stride, int N,
                                        int D1, int H1, int W1, int C1, int Cout, float* workspace,
                                        long long workspace_floats) {
+    return subpixel_conv_wgrad_impl(device, stream, low, affine, affine_sample_stride, dz, dw, dw_cin_stride, N, D1, H1, W1, C1, Cout,
+                                    workspace, workspace_floats, nullptr);
+}
+
+// ... with dz read through the window of u3d_subpixel_conv_dgrad_win (same 9 integers): the weight gradient of the outputs d >= 2 of a
+// level that upsamples n -> 2n + 1; the boundary slab's share comes from u3d_conv3d_wgrad_box.
+extern "C" int u3d_subpixel_conv_wgrad_win(int device, u3d_stream_t stream, const float* low, const float* affine,
+                                           long long affine_sample_stride, const float* dz, float* dw, int dw_cin_stride, int N, int D1,
+                                           int H1, int W1, int C1, int Cout, float* workspace, long long workspace_floats,
+                                           const int* win) {
+    U3D_REQUIRE(win != nullptr, "u3d_subpixel_conv_wgrad_win: win is NULL");
+    return subpixel_conv_wgrad_impl(device, stream, low, affine, affine_sample_stride, dz, dw, dw_cin_stride, N, D1, H1, W1, C1, Cout,
+                                    workspace, workspace_floats, win);
+}
+
+static int subpixel_conv_wgrad_impl(int device, u3d_stream_t stream, const float* low, const float* affine, long long affine_sample_stride,
+                                    const float* dz, float* dw, int dw_cin_stride, int N, int D1, int H1, int W1, int C1, int Cout,
+                                    float* workspace, long long workspace_floats, const int* win) {
     U3D_ENTER(device);
     U3D_REQUIRE(low && dz && dw && workspace && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && C1 > 0 && Cout > 0 &&
                     dw_cin_stride >= C1,
@@ -965,8 +1055,15 @@ extern "C" int u3d_subpixel_conv_wgrad(int device, u3d_stream_t stream, const fl
         return u3d_set_err(U3D_EWORKSPACE, "u3d_subpixel_conv_wgrad: workspace %lld < %lld floats", workspace_floats, need);
     p.low = low, p.affine = affine, p.aff_nstride = affine_sample_stride, p.dz = dz, p.partial = workspace;
     p.N = N, p.D1 = D1, p.H1 = H1, p.W1 = W1, p.C1 = C1, p.K = Cout;
+    p.Dd = 2 * D1, p.Hd = 2 * H1, p.Wd = 2 * W1, p.oz = p.oy = p.ox = 0, p.lz = p.ly = p.lx = 0;
+    if (win) {
+        p.Dd = win[0], p.Hd = win[1], p.Wd = win[2], p.oz = win[3], p.oy = win[4], p.ox = win[5], p.lz = win[6], p.ly = win[7], p.lx = win[8];
+        U3D_REQUIRE(p.oz >= 0 && p.oy >= 0 && p.ox >= 0 && 2 * D1 + p.oz <= p.Dd && 2 * H1 + p.oy <= p.Hd && 2 * W1 + p.ox <= p.Wd &&
+                        p.lz >= 0 && p.ly >= 0 && p.lx >= 0 && (long long)N * p.Dd * p.Hd * p.Wd < (1ll << 31),
+                    "u3d_subpixel_conv_wgrad_win: bad window");
+    }
     // every tile inside the volume, whole 32-channel dz blocks: constant-offset B loads (key 15 = 1: the general kernel, for A/B)
-    const bool full = D1 % spw::TZ == 0 && H1 % spw::TY == 0 && W1 % spw::TX == 0 && Cout % 32 == 0 && g_u3d_tune[15] != 1 &&
+    const bool full = !win && D1 % spw::TZ == 0 && H1 % spw::TY == 0 && W1 % spw::TX == 0 && Cout % 32 == 0 && g_u3d_tune[15] != 1 &&
                       (long long)N * 8 * D1 * H1 * W1 * Cout * 4 < (1ll << 31);
     if (full)
         hipLaunchKernelGGL(subpixel_wgrad_kernel<true>, dim3((unsigned)(p.S * p.nchunks * p.nkb)), dim3(spw::NTHR), 0,

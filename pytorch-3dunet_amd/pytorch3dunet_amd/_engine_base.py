@@ -30,6 +30,7 @@ __all__ = [
     "Optional",
     "ResRec",
     "StaleParameters",
+    "slab_boxes",
     "Tape",
     "U3DSrc",
     "UpRec",
@@ -295,6 +296,46 @@ class VSrc:
             s.zmap, s.ymap, s.xmap = (m.data_ptr() for m in self.maps)
             s.D1, s.H1, s.W1 = self.D1, self.H1, self.W1
         return s
+
+
+    def up_only_struct(self, affine: Optional[torch.Tensor] = None) -> U3DSrc:
+        """the UPSAMPLED half alone as a source (C0 = 0; p0 only has to be readable): the box launches of a level that upsamples
+        n -> 2n + 1 convolve just those channels.  `affine`: the compact (N, C1, 2) rows of these channels."""
+        s = U3DSrc()
+        s.p0 = self.t1.data_ptr()
+        s.C0 = 0
+        s.C1 = self.C1
+        s.affine = affine.data_ptr() if affine is not None else None
+        s.p1 = self.t1.data_ptr()
+        s.zmap, s.ymap, s.xmap = (m.data_ptr() for m in self.maps)
+        s.D1, s.H1, s.W1 = self.D1, self.H1, self.W1
+        return s
+
+    @property
+    def plus(self):
+        """per axis: 0 if the low-res half is upsampled by exactly 2, 1 if n -> 2n + 1 (nearest: src = (dst - 1) >> 1, src(0) = 0), None
+        for any other ratio (tests/test_boundary.py::test_nearest_maps_match_interpolate pins the closed form on ATen's operator)"""
+        if self.t1 is None:
+            return None
+        e = tuple(full - 2 * low for full, low in zip((self.D, self.H, self.W), (self.D1, self.H1, self.W1)))
+        return e if all(v in (0, 1) for v in e) else None
+
+
+def slab_boxes(dims, plus, t):
+    """disjoint boxes (z0, y0, x0, z1, y1, x1) covering {voxels with coordinate < t along at least one axis a with plus[a]} — the
+    near-boundary slab of a level that upsamples n -> 2n + 1 (t = 2: the outputs the sub-pixel window cannot produce; t = 3: the source
+    voxels their data gradient reaches)"""
+    boxes = []
+    lo = [0, 0, 0]
+    for a in range(3):
+        if not plus[a]:
+            continue
+        b0, b1 = list(lo), list(dims)
+        b1[a] = min(t, dims[a])
+        if all(x < y for x, y in zip(b0, b1)):
+            boxes.append(tuple(b0) + tuple(b1))
+        lo[a] = min(t, dims[a])  # the later boxes start beyond this axis' slab
+    return boxes
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -21,6 +21,13 @@ from ._native import U3DSrc
 from ._engine_base import *  # noqa: F401,F403  (explicit __all__: helpers, records, activation codes)
 
 
+class _SubLayers(dict):
+    """{id(conv weight): (C0, C1)} of the decoder first convs that take the sub-pixel path at one input size; `plus` = the ids whose level
+    upsamples n -> 2n + 1 along some axis"""
+
+    plus = frozenset()
+
+
 @dataclass
 class _ConvCall:
     """everything a forward kernel family needs to launch one convolution (filled by ConvLayers._single_conv_fwd)"""
@@ -103,15 +110,15 @@ class ConvLayers:
         return t
 
     def _subpixel_layers(self, size):
-        """decoder first convs whose low-res input is upsampled by exactly 2 in every dimension at this input size:
-        {id(weight): (C0, C1)} — per-call state, handed down as the `sub` argument"""
+        """decoder first convs whose low-res input is upsampled by exactly 2 — or, round 5, from n to 2n + 1 voxels — in every dimension at
+        this input size: {id(weight): (C0, C1)} (+ `.plus`: the ids with an n -> 2n + 1 axis) — per-call state, handed down as `sub`"""
         if not self.subpixel or any(ct is not None for ct in self.dec_up) or any(self.dec_interp):
-            return {}  # (a transposed convolution yields 2n-1 voxels, resized to the skip: never an exact 2x replication)
+            return _SubLayers()  # (a transposed convolution yields 2n-1 voxels, resized to the skip: never an exact 2x replication)
         dims = [tuple(size)]
         for has_pool, _, _ in self.enc:
             if has_pool:
                 dims.append(tuple(d // 2 for d in dims[-1]))
-        out = {}
+        out, plus = _SubLayers(), set()
         L = len(self.enc)
         for j, (c1, _) in enumerate(self.dec):
             skip_lvl, low_lvl = L - 2 - j, L - 1 - j
@@ -119,10 +126,16 @@ class ConvLayers:
                 continue
             C0 = self.enc[skip_lvl][2].conv.out_channels
             C1 = c1.conv.in_channels - C0
-            if (all(a == 2 * b for a, b in zip(dims[skip_lvl], dims[low_lvl])) and C0 > 0 and C1 > 0 and C0 % 4 == 0
+            # every axis upsampled by exactly 2, or n -> 2n + 1 (the pooled size of an odd level; round 5: the sub-pixel kernels on a
+            # shifted window + the general kernels on the near-boundary slab, _fwd_subpixel / _dgrad_subpixel / _wgrad_subpixel)
+            ratio = [a - 2 * b for a, b in zip(dims[skip_lvl], dims[low_lvl])]
+            if (all(r in (0, 1) for r in ratio) and (self.subpixel_plus or not any(ratio)) and C0 > 0 and C1 > 0 and C0 % 4 == 0
                     and C1 % 4 == 0 and c1.conv.out_channels % 4 == 0):
                 out[id(c1.conv.weight)] = (C0, C1)
+                if any(ratio):
+                    plus.add(id(c1.conv.weight))
         self._sub_pairs.update(out)
+        out.plus = frozenset(plus)  # the layers of this call whose packed set includes the slab images (_repack_all)
         return out
 
     def _stats_of(self, src: VSrc, st0, st1, pool: _StatPool, dev):
@@ -207,12 +220,27 @@ class ConvLayers:
         C0, C1 = c.sub[id(conv.weight)]
         ystats = c.take_stats()
         part = _empty((N, D, H, W, Cout), dtype=_F32, device=dev)
-        D1, H1, W1 = D // 2, H // 2, W // 2
-        need = nat.get_lib().u3d_subpixel_fwd_workspace_floats(N, D1, H1, W1, C1, Cout)  # split-K scratch, small levels only
-        kws = _empty(need, dtype=_F32, device=dev) if need > 0 else None
-        nat.call("u3d_subpixel_conv_fwd", dev.index, _stream(dev), _p(src.t1), _p(c.affine.view(-1)[2 * C0:]), c.Ctot * 2,
-                 _p(self._pack_cache[(id(conv.weight), 12)][1]), _p(part), N, D1, H1, W1, C1, Cout, _p(kws), need,
-                 flops=128.0 * C1 * Cout * N * D1 * H1 * W1)
+        D1, H1, W1 = src.D1, src.H1, src.W1
+        plus = src.plus
+        if any(plus):
+            # n -> 2n + 1 along the axes with plus = 1: the sub-pixel kernel writes the window d = u + plus, the general kernel the slab
+            # d < 2 of those axes (overwriting the window's first plane, which misses the extra copy of low[0])
+            win = (ctypes.c_int * 6)(D, H, W, *plus)
+            nat.call("u3d_subpixel_conv_fwd_win", dev.index, _stream(dev), _p(src.t1), _p(c.affine.view(-1)[2 * C0:]), c.Ctot * 2,
+                     _p(self._pack_cache[(id(conv.weight), 12)][1]), _p(part), N, D1, H1, W1, C1, Cout, win,
+                     flops=128.0 * C1 * Cout * N * D1 * H1 * W1)
+            s_up = src.up_only_struct(c.affine[:, C0:].contiguous())
+            wp1 = self._pack_cache[(id(conv.weight), 14)][1]  # 27-tap forward image of the upsampled channels (slab launches)
+            for box in slab_boxes((D, H, W), plus, 2):
+                nat.call("u3d_conv3d_box", dev.index, _stream(dev), ctypes.byref(s_up), _p(wp1), _p(part), N, D, H, W, Cout,
+                         (ctypes.c_int * 6)(*box), None,
+                         flops=54.0 * C1 * Cout * N * (box[3] - box[0]) * (box[4] - box[1]) * (box[5] - box[2]))
+        else:
+            need = nat.get_lib().u3d_subpixel_fwd_workspace_floats(N, D1, H1, W1, C1, Cout)  # split-K scratch, small levels only
+            kws = _empty(need, dtype=_F32, device=dev) if need > 0 else None
+            nat.call("u3d_subpixel_conv_fwd", dev.index, _stream(dev), _p(src.t1), _p(c.affine.view(-1)[2 * C0:]), c.Ctot * 2,
+                     _p(self._pack_cache[(id(conv.weight), 12)][1]), _p(part), N, D1, H1, W1, C1, Cout, _p(kws), need,
+                     flops=128.0 * C1 * Cout * N * D1 * H1 * W1)
         a0 = c.affine[:, :C0].contiguous()
         if self._split_fwd(C0, Cout):
             nat.call("u3d_conv3d_f32s", dev.index, _stream(dev), _p(src.t0), _p(a0), _p(self._packed_f32s(conv.weight, 0, dev, C0, 0)),
@@ -400,9 +428,26 @@ class ConvLayers:
         C0, C1 = rec.sub
         Ct = src.C
         dwv = cx.gview(rec.idx_w)
-        nat.call("u3d_subpixel_conv_wgrad", dev.index, _stream(dev), _p(src.t1), _p(rec.affine.view(-1)[2 * C0:]), Ct * 2,
-                 _p(c.dz), _p(dwv[C0 * 27:]), Ct, c.N, src.D1, src.H1, src.W1, C1, c.Cout, _p(ws), ws.numel(),
-                 flops=128.0 * C1 * c.Cout * c.N * src.D1 * src.H1 * src.W1)
+        plus = src.plus
+        if any(plus):
+            # n -> 2n + 1: outputs d >= 2 of the shifted axes through the windowed sub-pixel kernel, the slab d < 2 through the general
+            # kernel on disjoint boxes of dz (each into scratch, added to the same channel slice)
+            win = (ctypes.c_int * 9)(c.D, c.H, c.W, *plus, *plus)
+            nat.call("u3d_subpixel_conv_wgrad_win", dev.index, _stream(dev), _p(src.t1), _p(rec.affine.view(-1)[2 * C0:]), Ct * 2,
+                     _p(c.dz), _p(dwv[C0 * 27:]), Ct, c.N, src.D1, src.H1, src.W1, C1, c.Cout, _p(ws), ws.numel(), win,
+                     flops=128.0 * C1 * c.Cout * c.N * src.D1 * src.H1 * src.W1)
+            s_up = src.up_only_struct(rec.affine[:, C0:].contiguous())
+            slice_view = dwv.view(c.Cout, Ct, 27)[:, C0:, :]
+            for box in slab_boxes((c.D, c.H, c.W), plus, 2):
+                tmp = _empty((c.Cout, C1, 27), dtype=_F32, device=dev)
+                nat.call("u3d_conv3d_wgrad_box", dev.index, _stream(dev), ctypes.byref(s_up), _p(c.dz), _p(tmp), c.N, c.D, c.H, c.W,
+                         c.Cout, _p(ws), ws.numel(), (ctypes.c_int * 6)(*box),
+                         flops=54.0 * C1 * c.Cout * c.N * (box[3] - box[0]) * (box[4] - box[1]) * (box[5] - box[2]))
+                slice_view += tmp
+        else:
+            nat.call("u3d_subpixel_conv_wgrad", dev.index, _stream(dev), _p(src.t1), _p(rec.affine.view(-1)[2 * C0:]), Ct * 2,
+                     _p(c.dz), _p(dwv[C0 * 27:]), Ct, c.N, src.D1, src.H1, src.W1, C1, c.Cout, _p(ws), ws.numel(),
+                     flops=128.0 * C1 * c.Cout * c.N * src.D1 * src.H1 * src.W1)
         a0 = rec.affine[:, :C0].contiguous()
         s0 = VSrc(src.t0).struct(a0)
         nat.call("u3d_conv3d_wgrad_strided", dev.index, _stream(dev), ctypes.byref(s0), _p(c.dz), _p(dwv), Ct, c.N, c.D, c.H, c.W,
@@ -449,9 +494,31 @@ class ConvLayers:
             nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s_dz), _p(self._packed_sub(rec, 11, dev)), _p(dg0),
                      Nn, Dd, Hh, Ww, C0, 0, None, ctypes.byref(s_x0), _p(gst0), None, _p(ws), ws.numel(),
                      flops=54.0 * C0 * Cout * Nn * Dd * Hh * Ww)
-        nat.call("u3d_subpixel_conv_dgrad", dev.index, _stream(dev), _p(c.dz), _p(self._packed_sub(rec, 13, dev)), _p(src.t1),
-                 _p(dlow), _p(gst1), Nn, src.D1, src.H1, src.W1, C1, Cout,
-                 flops=128.0 * C1 * Cout * Nn * src.D1 * src.H1 * src.W1)
+        plus = src.plus
+        if any(plus):
+            # n -> 2n + 1: the share of the outputs d >= 2 from the windowed sub-pixel kernel; the slab's share as a full-resolution
+            # gradient of the upsampled channels inside the slab's dilation (general kernel on dz masked to the slab), folded into the
+            # first low-res cells of the shifted axes together with its part of the GroupNorm-backward sums
+            win = (ctypes.c_int * 9)(Dd, Hh, Ww, *plus, *plus)
+            nat.call("u3d_subpixel_conv_dgrad_win", dev.index, _stream(dev), _p(c.dz), _p(self._packed_sub(rec, 13, dev)), _p(src.t1),
+                     _p(dlow), _p(gst1), Nn, src.D1, src.H1, src.W1, C1, Cout, win,
+                     flops=128.0 * C1 * Cout * Nn * src.D1 * src.H1 * src.W1)
+            dv = _empty((Nn, Dd, Hh, Ww, C1), dtype=_F32, device=dev)
+            s_dz2 = VSrc(c.dz).struct()
+            wpd1 = self._packed_sub(rec, 15, dev)
+            mask = (ctypes.c_int * 3)(*(2 * e for e in plus))
+            for box in slab_boxes((Dd, Hh, Ww), plus, 3):
+                nat.call("u3d_conv3d_box", dev.index, _stream(dev), ctypes.byref(s_dz2), _p(wpd1), _p(dv), Nn, Dd, Hh, Ww, C1,
+                         (ctypes.c_int * 6)(*box), mask,
+                         flops=54.0 * C1 * Cout * Nn * (box[3] - box[0]) * (box[4] - box[1]) * (box[5] - box[2]))
+            lz, ly, lx = src.los
+            nat.call("u3d_nearest_childsum_add", dev.index, _stream(dev), _p(dv), _p(src.t1), _p(dlow), _p(gst1), Nn, Dd, Hh, Ww,
+                     src.D1, src.H1, src.W1, C1, _p(lz), _p(ly), _p(lx), *plus)
+            del dv
+        else:
+            nat.call("u3d_subpixel_conv_dgrad", dev.index, _stream(dev), _p(c.dz), _p(self._packed_sub(rec, 13, dev)), _p(src.t1),
+                     _p(dlow), _p(gst1), Nn, src.D1, src.H1, src.W1, C1, Cout,
+                     flops=128.0 * C1 * Cout * Nn * src.D1 * src.H1 * src.W1)
         gst = torch.cat((gst0.view(Nn, C0, 2), gst1.view(Nn, C1, 2)), dim=1)
         return (dg0, dlow), gst
 
@@ -573,10 +640,13 @@ class ConvLayers:
         lib = nat.get_lib()
         if small:
             return lib.u3d_small_cin_bwd_workspace_floats(N, D, H, W, Cin, Cout)
-        if sub is not None:  # skip slice (fp32 kernels) + sub-pixel slice
-            return max(lib.u3d_wgrad_workspace_floats(N, D, H, W, sub[0], Cout),
-                       lib.u3d_subpixel_wgrad_workspace_floats(N, D // 2, H // 2, W // 2, sub[1], Cout),
-                       lib.u3d_conv3d_workspace_floats(N, D, H, W, Cout, sub[0]))
+        if sub is not None:  # skip slice (fp32 kernels) + sub-pixel slice + the slab boxes of an n -> 2n + 1 level
+            # (a sub-pixel level's odd axes are its n -> 2n + 1 axes)
+            boxes = slab_boxes((D, H, W), (D % 2, H % 2, W % 2), 2)
+            return max([lib.u3d_wgrad_workspace_floats(N, D, H, W, sub[0], Cout),
+                        lib.u3d_subpixel_wgrad_workspace_floats(N, D // 2, H // 2, W // 2, sub[1], Cout),
+                        lib.u3d_conv3d_workspace_floats(N, D, H, W, Cout, sub[0])] +
+                       [lib.u3d_wgrad_workspace_floats(N, b[3] - b[0], b[4] - b[1], b[5] - b[2], sub[1], Cout) for b in boxes])
         if not virtual and self._bf16_layer(Cin, Cout):
             need = lib.u3d_conv3d_bf16_workspace_floats(N, D, H, W, Cout, Cin)  # data gradient: roles swapped
             wg = lib.u3d_wgrad_bf16_workspace_floats(N, D, H, W, Cin, Cout)

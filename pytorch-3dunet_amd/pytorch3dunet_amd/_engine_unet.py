@@ -37,6 +37,10 @@ class UNet3DEngine(WeightImages, ConvLayers):
         self.overlap_small_wgrad = True  # weight gradients of small layers on a second HIP stream (see _BwdCtx)
         # decoder first convs over an exact-2x upsampling: sub-pixel convolution of the upsampled half (csrc/u3d_subpix.hip)
         self.subpixel = os.environ.get("U3D_SUBPIXEL", "1") != "0"
+        # ... and over a level that upsamples n -> 2n + 1 along some axes (an odd skip size: 42 -> 85 in the shipped 80 x 170 x 170 patch):
+        # sub-pixel kernels on a shifted window + the general kernels on the near-boundary slab (round 5; U3D_SUBPIXEL_PLUS=0: such
+        # levels keep the 27-tap virtual-concat kernels)
+        self.subpixel_plus = os.environ.get("U3D_SUBPIXEL_PLUS", "1") != "0"
         # opt-in (BASELINE config 4): bf16 MFMA operands with fp32 accumulation for the 3x3x3 convolutions whose channel
         # counts allow it (csrc/u3d_bf16.hip), fp32 master weights / activations / statistics; and recomputation of the
         # encoder blocks in backward instead of keeping their intermediates.  Set through the model
@@ -320,10 +324,15 @@ class UNet3DEngine(WeightImages, ConvLayers):
             if r1.sub is not None:
                 dg0, dlow = dg1
                 skip_grad[lvl] = (dg0, C0, coef1, Ct)
-                # dlow already holds the children sums: (p*dlow + 8*(q*x + r)) * (x > 0) on the low-res producer
-                coef_up = coef1[:, :, C0:] * self._up_scale(dev)
-                nat.call("u3d_gn_bwd_apply", dev.index, _stream(dev), _p(dlow), C1, 0, _p(src.t1), C1, _p(coef_up), C1,
-                         src.D1 * src.H1 * src.W1, src.N, mk, _p(dzl))
+                if any(src.plus):
+                    # n -> 2n + 1 along some axes: the first low-res cell of such an axis has three children
+                    nat.call("u3d_gn_bwd_apply_children", dev.index, _stream(dev), _p(dlow), _p(src.t1), _p(coef1), Ct, C0, src.N, src.D1,
+                             src.H1, src.W1, C1, *src.plus, mk, _p(dzl))
+                else:
+                    # dlow already holds the children sums: (p*dlow + 8*(q*x + r)) * (x > 0) on the low-res producer
+                    coef_up = coef1[:, :, C0:] * self._up_scale(dev)
+                    nat.call("u3d_gn_bwd_apply", dev.index, _stream(dev), _p(dlow), C1, 0, _p(src.t1), C1, _p(coef_up), C1,
+                             src.D1 * src.H1 * src.W1, src.N, mk, _p(dzl))
                 del dg0, dlow
             else:
                 skip_grad[lvl] = (dg1, Ct, coef1, Ct)

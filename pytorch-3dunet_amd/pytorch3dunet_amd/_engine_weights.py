@@ -140,7 +140,8 @@ class WeightImages:
 
     # pack modes: 0 forward, 1 data gradient (u3d_pack_weights).  Layers in self._sub (sub-pixel path) use instead: 10 / 11 =
     # forward / data-gradient image of the first C0 input channels, 12 / 13 = sub-pixel forward / data-gradient image of the
-    # remaining C1 — and no mode-0 / mode-1 image.
+    # remaining C1 — and no mode-0 / mode-1 image; levels that upsample n -> 2n + 1 add 14 / 15 = the plain 27-tap images of
+    # those C1 channels (slab launches).
     def _pack_shape(self, w, mode):
         """(w pointer, Cin, C-ABI mode, cin_stride, floats) of one packed image"""
         lib = nat.get_lib()
@@ -151,6 +152,8 @@ class WeightImages:
                 return w.data_ptr(), C0, mode - 10, Cin, lib.u3d_packed_weight_floats(C0, Cout, mode - 10)
             if mode == 12:
                 return w.data_ptr() + C0 * 27 * 4, C1, 2, Cin, lib.u3d_subpixel_packed_floats(C1, Cout)
+            if mode in (14, 15):  # the plain 27-tap images of the upsampled channels: the slab launches of an n -> 2n + 1 level
+                return w.data_ptr() + C0 * 27 * 4, C1, mode - 14, Cin, lib.u3d_packed_weight_floats(C1, Cout, mode - 14)
             return w.data_ptr() + C0 * 27 * 4, C1, 3, Cin, lib.u3d_subpixel_dgrad_packed_floats(Cout, C1)
         return w.data_ptr(), Cin, mode, 0, lib.u3d_packed_weight_floats(Cin, Cout, mode)
 
@@ -226,6 +229,8 @@ class WeightImages:
             wmodes = modes
             if id(w) in sub:
                 wmodes = tuple(mm + 10 for mm in modes) + tuple(mm + 12 for mm in modes)
+                if id(w) in getattr(sub, "plus", ()):
+                    wmodes += tuple(mm + 14 for mm in modes)
             for mode in wmodes:
                 hit = self._pack_cache.get((id(w), mode))
                 if hit is None or hit[0] != self._ver(w):

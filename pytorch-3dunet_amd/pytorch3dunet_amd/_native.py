@@ -139,6 +139,21 @@ _PROTOS = {
         [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int],
     ),
     "u3d_pack_subpixel_weights": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    # round 5: decoder levels that upsample n -> 2n + 1 (sub-pixel kernels on a window + the general kernels on the boundary slab)
+    "u3d_subpixel_conv_fwd_win": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                          c_int, c_int, POINTER(c_int)]),
+    "u3d_subpixel_conv_dgrad_win": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                            c_int, c_int, POINTER(c_int)]),
+    "u3d_subpixel_conv_wgrad_win": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                            c_int, c_int, c_int, c_void_p, c_int64, POINTER(c_int)]),
+    "u3d_conv3d_box": (c_int, [c_int, c_void_p, POINTER(U3DSrc), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_int),
+                               POINTER(c_int)]),
+    "u3d_conv3d_wgrad_box": (c_int, [c_int, c_void_p, POINTER(U3DSrc), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                     c_size_t, POINTER(c_int)]),
+    "u3d_gn_bwd_apply_children": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                          c_int, c_int, c_int, c_int, c_void_p]),
+    "u3d_nearest_childsum_add": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                         c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
     "u3d_subpixel_fwd_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "u3d_subpixel_conv_fwd": (
         c_int,

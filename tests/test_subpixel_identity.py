@@ -44,10 +44,20 @@ def test_engine_selects_subpixel_layers_only_for_exact_2x_levels():
     w = {id(d.basic_module.SingleConv1.conv.weight): d.basic_module.SingleConv1.conv.weight for d in model.decoders}
     assert set(sub) == set(w)
     assert sorted(sub.values()) == [(32, 64), (64, 128), (128, 256)]  # (skip channels, upsampled channels)
-    # 20 -> 10 -> 5 -> 2: the deepest level is not an exact 2x (5 != 2*2), the other two are
+    assert sub.plus == frozenset()
+    # 20 -> 10 -> 5 -> 2: the deepest level upsamples 2 -> 5 = 2n + 1 (round 5: sub-pixel kernels on a shifted window + the general
+    # kernels on the boundary slab), the other two are exact
     sub = eng._subpixel_layers((20, 40, 40))
-    assert sorted(sub.values()) == [(32, 64), (64, 128)]
-    # odd input: no level qualifies
+    assert sorted(sub.values()) == [(32, 64), (64, 128), (128, 256)]
+    assert sub.plus == {id(model.decoders[0].basic_module.SingleConv1.conv.weight)}
+    # the shipped patch (resources/3DUnet_confocal_boundary/train_config.yml:94): 170 -> 85 -> 42 -> 21, the middle decoder is 42 -> 85
+    sub = eng._subpixel_layers((80, 170, 170))
+    assert len(sub) == 3 and sub.plus == {id(model.decoders[1].basic_module.SingleConv1.conv.weight)}
+    # odd input: every level is n -> 2n + 1 along some axis
+    sub = eng._subpixel_layers((9, 13, 11))
+    assert len(sub) == 3 and sub.plus == set(w)
+    eng.subpixel_plus = False   # U3D_SUBPIXEL_PLUS=0: exact levels only (rounds 1-4)
+    assert sorted(eng._subpixel_layers((20, 40, 40)).values()) == [(32, 64), (64, 128)]
     assert eng._subpixel_layers((9, 13, 11)) == {}
     eng.subpixel = False
     assert eng._subpixel_layers((64, 128, 128)) == {}
