@@ -1070,6 +1070,9 @@ struct bf16_wgrad_params {
     int per_block;        // tiles per split
     int pco;              // K / 64
     int xcd;              // 1: XCD-aware block order
+    int t8cs;             // 2x2x2 weight gradient of the transposed convolution (KS = 2, space-to-depth form): Cs if a block's 64 output
+                          // columns lie inside ONE output parity (Cs % 64 == 0), else 0.  Only 27 of the 64 (tap, parity) blocks carry a tap
+                          // (tap a is live for parity p iff a & ~p == 0): a wave skips the fragment reads, MFMAs and stores of its dead taps
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -1109,6 +1112,20 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wg
     const int cib = pair / p.pco, cob = pair % p.pco;
     const int c0 = cib * 32, k0 = cob * 64;
     const int h = w >> 2, wq = w & 3;
+    // (round 5) live tap slots of this wave, wave-uniform; all of them except in the transposed convolution's 2x2x2 weight gradient,
+    // whose LDS pipe — 3 transposed fragment reads per 2 MFMAs — was busy with blocks that are structurally zero: 0.075 of the bf16 peak
+    unsigned live = (1u << NTW) - 1;
+    if constexpr (KS == 2) {
+        if (p.t8cs > 0) {
+            const int pp = k0 / p.t8cs;
+            live = 0;
+#pragma unroll
+            for (int i = 0; i < NTW; ++i)
+                if (wq + 4 * i < G::NTAPS && ((wq + 4 * i) & ~pp & 7) == 0) live |= 1u << i;
+        }
+        live = __builtin_amdgcn_readfirstlane(live);
+    }
+    auto slot_live = [&](int i) { return KS != 2 || ((live >> i) & 1u) != 0; };
 
     auto decode = [&](int tile) {
         wg_tile r;
@@ -1251,10 +1268,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wg
             return a_off[i] + (zl * WG_HY + yl) * WG_HX * 64;
         };
         auto b_addr = [&](int rw) { return b_off + rw * WG_TX * 64; };
-        bf16x8 af[AD + 1], bfr[2];
+        bf16x8 af[AD + 1] = {}, bfr[2] = {};
 #pragma unroll
-        for (int s_ = 0; s_ < AD; ++s_) af[s_] = tr_frag(cur + a_addr(s_));
-        bfr[0] = tr_frag(cur + b_addr(0));
+        for (int s_ = 0; s_ < AD; ++s_)
+            if (slot_live(s_ % NTW)) af[s_] = tr_frag(cur + a_addr(s_));
+        if (KS != 2 || live != 0) bfr[0] = tr_frag(cur + b_addr(0));
 #pragma unroll
         for (int part = 0; part < WG_PARTS; ++part) {
             item_t(&st)[PER] = stq[DEEP ? (part & 1) : 0];
@@ -1270,10 +1288,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wg
 #pragma unroll
             for (int q4 = 0; q4 < 4 * NTW; ++q4) {
                 const int s_ = part * 4 * NTW + q4, rw = s_ / NTW, i = s_ - rw * NTW;
-                if (s_ + AD < NS) af[(s_ + AD) % (AD + 1)] = tr_frag(cur + a_addr(s_ + AD));
-                if (i == 0 && rw + 1 < 16) bfr[(rw + 1) & 1] = tr_frag(cur + b_addr(rw + 1));
+                if (s_ + AD < NS && slot_live((s_ + AD) % NTW)) af[(s_ + AD) % (AD + 1)] = tr_frag(cur + a_addr(s_ + AD));
+                if (i == 0 && rw + 1 < 16 && (KS != 2 || live != 0)) bfr[(rw + 1) & 1] = tr_frag(cur + b_addr(rw + 1));
                 __builtin_amdgcn_sched_barrier(0);
-                if (wq + 4 * i < G::NTAPS) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s_ % (AD + 1)], bfr[rw & 1], acc[i], 0, 0, 0);
+                if (wq + 4 * i < G::NTAPS && slot_live(i))
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s_ % (AD + 1)], bfr[rw & 1], acc[i], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1300,7 +1319,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_kernel(const bf16_wg
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
         const int tap = wq + 4 * i;
-        if (tap < G::NTAPS) {
+        if (tap < G::NTAPS && slot_live(i)) {  // (a dead block is never read by wgrad_t8_reduce_kernel)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int ci = (e & 3) + 8 * (e >> 2) + 4 * half;
@@ -1619,6 +1638,214 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_b16v2_kernel(const bf16_w
                     dst[(size_t)tap * 2048 + ci * 64 + hh * 32 + col] = acc[i][hh][e];
                 }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the SAME staging scheme for the 2x2x2 weight gradient of the transposed convolution in space-to-depth form (KS = 2, bf16
+// storage).  It ran on the round-3 kernel (conv3d_wgrad_bf16_kernel<2>): per-item coordinate arithmetic with integer divisions for
+// every staged item of every tile, and only 2 accumulators per wave to hide it behind — 8 us per 256-voxel tile, 0.075 of the bf16 peak,
+// 1.1 ms per config-4 step; skipping its structurally zero blocks changed nothing (3 %): it is the staging, not the MFMAs.  Here: 4 x 8
+// x 8 tiles with a 5 x 9 x 9 forward-looking halo (the 2x2x2 taps read x[i + a], a in {0,1}^3), staging items as per-thread constants +
+// buffer loads (invalid lanes read beyond the range), wave w = tap w with BOTH 32-column halves (one g fragment feeds two MFMAs), a tile
+// loop of 16 steps in which item j of tile i + 2 is loaded at step 2j right after the same register's item of tile i + 1 was written to
+// LDS — every load a whole tile period in flight — and dead (tap, parity) blocks skipped (p.t8cs).
+struct wgt_geom {
+    static constexpr int TZ = 4, TY = 8, TX = 8, HZ = 5, HY = 9, HX = 9, NH = HZ * HY * HX;  // 405 halo voxels
+    static constexpr int GB = NH * 64, LDSB = GB + 2 * WG_DZ_HALF;
+    static constexpr int NG = (NH * 4 + 511) / 512, ND = 4, NTOT = NG + ND;                   // 4 + 4 items of 16 bytes per thread and tile
+    static constexpr int GLAST = NH * 4 - 512 * (NG - 1);                                     // threads that own a last g item (84)
+    static constexpr int LDS_TOTAL = 2 * LDSB + 16;
+};
+__global__ __launch_bounds__(512, 2) void conv3d_wgrad_t8v2_kernel(const bf16_wgrad_params p) {
+    using G = wgt_geom;
+    constexpr int TZ = G::TZ, TY = G::TY, TX = G::TX, HZ = G::HZ, HY = G::HY, HX = G::HX, GB = G::GB, LDSB = G::LDSB;
+    constexpr int NG = G::NG, ND = G::ND, NTOT = G::NTOT;
+    static_assert(TZ * TY * TX == 256 && NTOT == 8, "256 voxels per tile = 16 rows of 16; 8 staging items per thread");
+    extern __shared__ __attribute__((aligned(256))) char lds[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int P = (p.C >> 5) * p.pco;
+    const int bid = p.xcd ? u3d_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int pair = bid % P, split = bid / P;
+    const int cib = pair / p.pco, cob = pair % p.pco;
+    const int c0 = cib * 32, k0 = cob * 64;
+    const int D = p.D, H = p.H, W = p.W;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((long long)p.N * D * H * W * p.C * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dz), 0, (int)((long long)p.N * D * H * W * p.K * 2), 0x00020000);
+    // tap of this wave (8 waves = the 8 taps) and whether its (tap, parity) block carries a tap at all
+    bool live = true;
+    if (p.t8cs > 0) live = (w & ~(k0 / p.t8cs) & 7) == 0;
+    // ---- per-thread staging constants
+    int relg[NG];
+    unsigned gpos[2] = {0, 0};  // 16 bits per item: hz | hy << 4 | hx << 8 of its halo voxel (beyond the halo: a dead tail item)
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        const int hv = (t >> 2) + 128 * k;
+        const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+        relg[k] = (((hz * H + hy) * W + hx) * p.C + c0 + 8 * (t & 3)) * 2;
+        gpos[k >> 1] |= ((unsigned)hz | ((unsigned)hy << 4) | ((unsigned)hx << 8)) << (16 * (k & 1));
+    }
+    // dz item k: voxel (t >> 3) + 64 k = (z k, y t >> 6, x (t >> 3) & 7), channel octet t & 7
+    const int dyl = t >> 6, dxl = (t >> 3) & 7;
+    const unsigned imask = 0xf00u | (((1u << NG) - 1u) & ~(t < G::GLAST ? 0u : 1u << (NG - 1)));
+    const int reld = ((dyl * W + dxl) * p.K + k0 + 8 * (t & 7)) * 2;
+    const int ldsg = t * 16;
+    const int ldsd = GB + ((t & 7) >> 2) * WG_DZ_HALF + (t >> 3) * 64 + (t & 3) * 16;
+    struct tile_t {
+        int n, zi, yi, xi;
+    };
+    struct tinfo {
+        int baseg, based;
+        unsigned mask;  // bits 0..3: g item k of THIS thread is inside the volume; bits 8..11: dz item k is
+    };
+    auto info_of = [&](const tile_t& c, bool exists) {
+        tinfo r;
+        const int z0 = c.zi * TZ, y0 = c.yi * TY, x0 = c.xi * TX;
+        r.baseg = ((((c.n * D + z0) * H + y0) * W + x0) * p.C) * 2;  // (forward-looking halo: its origin is the tile's)
+        r.based = ((((c.n * D + z0) * H + y0) * W + x0) * p.K) * 2;
+        const bool interior = z0 + TZ + 1 <= D && y0 + TY + 1 <= H && x0 + TX + 1 <= W;
+        if (!exists) {
+            r.mask = 0;
+        } else if (interior) {
+            r.mask = imask;
+        } else {
+            const unsigned zn = (unsigned)min(HZ, D - z0), yn = (unsigned)min(HY, H - y0), xn = (unsigned)min(HX, W - x0);
+            r.mask = 0;
+#pragma unroll
+            for (int k = 0; k < NG; ++k) {
+                const unsigned gp = gpos[k >> 1] >> (16 * (k & 1));
+                const unsigned hz = gp & 0xfu, hy = (gp >> 4) & 0xfu, hx = (gp >> 8) & 0xffu;
+                r.mask |= ((hz < zn && hy < yn && hx < xn) ? 1u : 0u) << k;
+            }
+#pragma unroll
+            for (int k = 0; k < ND; ++k) r.mask |= ((k < D - z0 && dyl < H - y0 && dxl < W - x0) ? 1u : 0u) << (8 + k);
+        }
+        return r;
+    };
+    auto advance = [&](tile_t& c) {
+        if (++c.xi == p.tx) {
+            c.xi = 0;
+            if (++c.yi == p.ty) {
+                c.yi = 0;
+                if (++c.zi == p.tz) {
+                    c.zi = 0;
+                    ++c.n;
+                }
+            }
+        }
+    };
+    auto load_slot = [&](const tinfo& ti, int j) -> bf16x8 {
+        if (j < NG) {
+            const int off = ((ti.mask >> j) & 1u) ? relg[j] + ti.baseg : -1;
+            return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+        }
+        const int k = j - NG;
+        const int off = ((ti.mask >> (8 + k)) & 1u) ? reld + ti.based + (k * H * W * p.K) * 2 : -1;
+        return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rdz, off, 0, 0));
+    };
+    auto store_slot = [&](char* buf, int j, const bf16x8& v) {  // (no GroupNorm affine on this path: beyond the volume was loaded as zero)
+        if (j < NG) {
+            char* dst = buf + ldsg + 8192 * j;
+            if (j == NG - 1) dst = t < G::GLAST ? dst : lds + 2 * LDSB;  // (the others' last slot would land in the dz tile: dump slot)
+            *reinterpret_cast<bf16x8*>(dst) = v;
+        } else {
+            *reinterpret_cast<bf16x8*>(buf + ldsd + 4096 * (j - NG)) = v;
+        }
+    };
+
+    const int first = split * p.per_block, last = min(p.tiles, first + p.per_block);
+    tile_t tc;
+    {
+        int tt = first;
+        tc.xi = tt % p.tx;
+        tt /= p.tx;
+        tc.yi = tt % p.ty;
+        tt /= p.ty;
+        tc.zi = tt % p.tz;
+        tc.n = tt / p.tz;
+    }
+    bf16x8 ra[NTOT];
+    tinfo i1, i2;  // of tiles i + 1 (its items sit in ra and are written during iteration i) and i + 2 (loaded during iteration i)
+    if (first < last) {
+        const tinfo ti = info_of(tc, true);
+#pragma unroll
+        for (int j = 0; j < NTOT; ++j) ra[j] = load_slot(ti, j);
+#pragma unroll
+        for (int j = 0; j < NTOT; ++j) store_slot(lds, j, ra[j]);
+        advance(tc);
+        i1 = info_of(tc, first + 1 < last);
+#pragma unroll
+        for (int j = 0; j < NTOT; ++j) ra[j] = load_slot(i1, j);
+        advance(tc);
+        i2 = info_of(tc, first + 2 < last);
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[hh][e] = 0.f;
+
+    const int g4 = lane >> 4, sidx = lane & 15;
+    // (voxel half g4 >> 1 of an MFMA's 16 voxels: the next y row of the 8-wide tile)
+    const int lane_off = (HX * (g4 >> 1) + (sidx >> 2)) * 64 + (16 * (g4 & 1) + 4 * (sidx & 3)) * 2;
+    const int a_off = lane_off + (((w >> 2) * HY + ((w >> 1) & 1)) * HX + (w & 1)) * 64;
+    const int b_off = GB + (8 * (g4 >> 1) + (sidx >> 2)) * 64 + (16 * (g4 & 1) + 4 * (sidx & 3)) * 2;
+    for (int tile = first; tile < last; ++tile) {
+        __syncthreads();  // buffer (tile - first) & 1 is complete; everyone is done reading the other one
+        const char* cur = lds + ((tile - first) & 1) * LDSB;
+        char* nxt = lds + ((tile - first + 1) & 1) * LDSB;
+        tinfo i3;
+        constexpr int AD = 2;
+        auto a_addr = [&](int rw) { return a_off + ((rw >> 2) * HY + 2 * (rw & 3)) * HX * 64; };
+        auto b_addr = [&](int rw, int hh) { return b_off + hh * WG_DZ_HALF + rw * 16 * 64; };
+        bf16x8 af[AD + 1] = {}, bfr[2][2] = {};
+        if (live) {
+#pragma unroll
+            for (int s_ = 0; s_ < AD; ++s_) af[s_] = tr_frag(cur + a_addr(s_));
+            bfr[0][0] = tr_frag(cur + b_addr(0, 0));
+            bfr[0][1] = tr_frag(cur + b_addr(0, 1));
+        }
+#pragma unroll
+        for (int rw = 0; rw < 16; ++rw) {
+            if (live) {
+                if (rw + AD < 16) af[(rw + AD) % (AD + 1)] = tr_frag(cur + a_addr(rw + AD));
+                if (rw + 1 < 16) {
+                    bfr[(rw + 1) & 1][0] = tr_frag(cur + b_addr(rw + 1, 0));
+                    bfr[(rw + 1) & 1][1] = tr_frag(cur + b_addr(rw + 1, 1));
+                }
+            }
+            // ---- staging: at even steps the register of item j hands tile i + 1's item to LDS and takes tile i + 2's
+            if ((rw & 1) == 0) {
+                const int j = rw >> 1;
+                store_slot(nxt, j, ra[j]);
+                ra[j] = load_slot(i2, j);
+            }
+            if (rw == 9) {  // the tile after those: coordinates and masks under this tile's MFMAs
+                advance(tc);
+                i3 = info_of(tc, tile + 3 < last);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (live) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rw % (AD + 1)], bfr[rw & 1][0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rw % (AD + 1)], bfr[rw & 1][1], acc[1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        i1 = i2;
+        i2 = i3;
+    }
+    // ---- partial sums: ws[split][pair][tap 8][ci 32][co 64]; D layout: column = lane & 31 (co), row = ci
+    if (live) {
+        float* dst = p.ws + (((size_t)split * P + pair) * 8 + w) * 2048;
+        const int col = lane & 31, half = lane >> 5;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ci = (e & 3) + 8 * (e >> 2) + 4 * half;
+                dst[ci * 64 + hh * 32 + col] = acc[hh][e];
+            }
     }
 }
 
@@ -1977,8 +2204,8 @@ extern "C" int u3d_convtr3d_dgrad_t8_b16_ex(int device, u3d_stream_t stream, con
 
 extern "C" long long u3d_convtr3d_wgrad_t8_workspace_floats(int N, int D1, int H1, int W1, int Cl, int Cs) {
     if (!u3d_convtr3d_t8_supported(Cl, Cs) || N <= 0 || D1 <= 0 || H1 <= 0 || W1 <= 0) return 0;
-    const wgrad_plan q = plan_wgrad(N, D1, H1, W1, Cl, 8 * Cs);
-    return (long long)q.S * q.P * 8 * 2048;
+    const wgrad_plan q = plan_wgrad(N, D1, H1, W1, Cl, 8 * Cs), q8 = plan_wgrad(N, D1, H1, W1, Cl, 8 * Cs, true);  // (either kernel's tiling)
+    return (long long)(q.S > q8.S ? q.S : q8.S) * q.P * 8 * 2048;
 }
 
 static int convtr3d_wgrad_t8_impl(int device, u3d_stream_t stream, const float* x, const float* dt8, float* dw, int N, int D1, int H1,
@@ -2004,6 +2231,22 @@ static int convtr3d_wgrad_t8_impl(int device, u3d_stream_t stream, const float* 
     if (!workspace || workspace_floats < need)
         return u3d_set_err(U3D_EWORKSPACE, "u3d_convtr3d_wgrad_t8: workspace of %lld floats needed, %lld given", need, workspace_floats);
     bf16_wgrad_params p{x, nullptr, dt8, workspace, N, D1, H1, W1, Cl, 8 * Cs, 0, q.tz, q.ty, q.tx, q.tiles, q.per_block, 8 * Cs / 64, g_u3d_tune[9] == 1 ? 0 : 1};
+    p.t8cs = (Cs % 64 == 0 && g_u3d_tune[10] != 2) ? Cs : 0;  // (key 10 = 2: no structurally-zero blocks skipped, as for the forward / data gradient)
+    // bf16 storage: the round-5 kernel (4 x 8 x 8 tiles, constant-offset staging; key 7 = 1: the round-3 kernel; buffer offsets are 32-bit)
+    if (b16 && g_u3d_tune[7] != 1 && (long long)N * D1 * H1 * W1 * (Cl > 8 * Cs ? Cl : 8 * Cs) * 2 < (1ll << 31)) {
+        const wgrad_plan q8 = plan_wgrad(N, D1, H1, W1, Cl, 8 * Cs, true);
+        if ((long long)q8.S * q8.P * 8 * 2048 <= workspace_floats) {
+            p.tz = q8.tz, p.ty = q8.ty, p.tx = q8.tx, p.tiles = q8.tiles, p.per_block = q8.per_block;
+            U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_t8v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        wgt_geom::LDS_TOTAL));
+            hipLaunchKernelGGL(conv3d_wgrad_t8v2_kernel, dim3((unsigned)(q8.S * q8.P)), dim3(512), wgt_geom::LDS_TOTAL, (hipStream_t)stream, p);
+            U3D_LAUNCH_CHECK();
+            hipLaunchKernelGGL(wgrad_t8_reduce_kernel, dim3((unsigned)(Cl * ((Cs + 63) / 64))), dim3(256), 0, (hipStream_t)stream, workspace,
+                               q8.S, Cl, Cs, dw);
+            U3D_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (b16) {
         U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_bf16_kernel<2, __bf16>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * wg_geom<2>::LDS));
