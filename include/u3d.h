@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define U3D_VERSION 119 /* 119: round 5 — ragged volumes on the persistent kernels, u3d_conv3d_variant / u3d_conv3d_wgrad_variant; 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K); 118: u3d_se_*_b16 */
+#define U3D_VERSION 120 /* 120: flat 5 x 10 x 10 tile of the bf16-storage convolutions (u3d_conv3d_bf16_tile_variant planes = 5), 24 tuning keys; 119: round 5 — ragged volumes on the persistent kernels, u3d_conv3d_variant / u3d_conv3d_wgrad_variant; 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K); 118: u3d_se_*_b16 */
 
 #define U3D_OK 0
 #define U3D_EINVAL (-1)  /* bad shape / argument */
@@ -71,7 +71,7 @@ int u3d_check_device(int device);
  * key 0: forced N-tiles per block of u3d_conv3d (1,2,3; 0 = automatic); key 1: wgrad split override; key 12: block slots the
  * persistent convolution grids leave FREE (of 2 per CU) so that kernels of other streams — RCCL's gradient all-reduce,
  * parallel.py — find room beside them (it shrinks the fp32 persistent grids of u3d_conv3d ONLY: the bf16 kernels and every other
- * launch ignore it); the other keys: see the list at the top of csrc/u3d_conv.hip (16 keys; the environment
+ * launch ignore it); the other keys: see the list at the top of csrc/u3d_conv.hip (24 slots; the environment
  * variable U3D_TUNE=key:value,... sets them at load time). */
 int u3d_set_tuning(int key, int value);
 /* Developer aid (tools/wave_timeline.py): while a device buffer is registered, u3d_conv3d launches an instrumented
@@ -446,6 +446,9 @@ int u3d_conv3d_bf16(int device, u3d_stream_t stream, const float* x, const float
 long long u3d_conv3d_bf16_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
 /* Host-only: which tile variant u3d_conv3d_bf16_ex (b16 = 0) / u3d_conv3d_bf16_ex_b16 (b16 = 1) runs for a shape —
  * (ksplit << 16) | (z-planes per tile: 4 or 8) << 8 | (32-channel n-tiles per block: 1 or 2) << 4 | blocks per CU (2 or 3);
+ * planes = 5 (b16 only, round 5): the FLAT 5 x 10 x 10 tile — 500 voxels in raster order are the GEMM rows of one block, one block per
+ * CU, always with ksplit > 1 — which the small wide levels take when it executes at most 3/4 of the padded rows of the 4 x 8 x 8 tiling
+ * (config 4's 10 x 20 x 20 and 5 x 10 x 10 levels; u3d_set_tuning key 16 = 1: never);
  * -1 for unsupported channel counts.  No reference counterpart (ATen picks its MIOpen / oneDNN algorithm internally, behind
  * buildingblocks.py:56); the parity tests use it to assert that a pinned shape runs the variants the benchmark shape runs. */
 int u3d_conv3d_bf16_tile_variant(int N, int D, int H, int W, int Cin, int Cout, int b16);

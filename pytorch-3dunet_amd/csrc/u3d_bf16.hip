@@ -45,7 +45,7 @@ __device__ __forceinline__ bf16x8 u3d_stage_b16(const bf16x8& v, bool has_aff, b
     return __builtin_bit_cast(bf16x8, u32x4{o[0] & m, o[1] & m, o[2] & m, o[3] & m});
 }
 
-extern int g_u3d_tune[16];  // csrc/u3d_conv.hip: run-time A/B knobs (u3d_set_tuning); results never change
+extern int g_u3d_tune[24];  // csrc/u3d_conv.hip: run-time A/B knobs (u3d_set_tuning); results never change
 
 namespace {
 
@@ -78,7 +78,13 @@ struct bf16_conv_params {
 
 template <int ZW, int KS>
 struct tile_geom {
-    static constexpr int TZ = 4 * ZW, HZ = TZ + KS - 1, HY = 8 + KS - 1, HX = 8 + KS - 1, MT = 2 * ZW;
+    // ZW = 3 is the FLAT tile (round 5): 5 x 10 x 10 voxels whose 500 voxels ARE the GEMM rows in raster order (row v = (z*10 + y)*10 + x,
+    // 16 M-tiles of 32 rows, the last 12 rows idle) — the shape of config 4's bottom level (5 x 10 x 10: ONE tile instead of eight
+    // 4 x 8 x 8 tiles that are 3/4 padding) and an exact divisor of the 10 x 20 x 20 level above it (8 tiles at 98 % instead of 27 at 58 %)
+    static constexpr bool FLAT = ZW == 3;
+    static constexpr int TZ = FLAT ? 5 : 4 * ZW, TY = FLAT ? 10 : 8, TX = FLAT ? 10 : 8;
+    static constexpr int HZ = TZ + KS - 1, HY = TY + KS - 1, HX = TX + KS - 1, MT = FLAT ? 4 : 2 * ZW;
+    static_assert(HX <= HS, "halo rows are HS records long");
     static constexpr int NTAPS = KS * KS * KS;
     // B-fragment ring: NTAPS % RING == 0 keeps the slots aligned across chunks (the packed image is linear in (chunk, tap));
     // fragments are fetched BDIST taps ahead — a tap is only 4*ZW*NT MFMAs = 128-256 cycles against ~500 cycles of L2 latency for
@@ -104,7 +110,7 @@ struct tile_geom {
 // Epilogue shared by the bf16-operand and the split-fp32 kernels: residual, ReLU, fp32 store, per-(n,channel) statistics (or, with
 // ksplit > 1, the raw partial sums of this block's chunk range).  `lds` is free for the block reduction when this runs.
 template <int NT, int ZW, int KS, typename T = float>
-__device__ __forceinline__ void conv_tile_epilogue(const bf16_conv_params& p, f32x16 (&acc)[2 * ZW][NT], char* lds, int n, int nb,
+__device__ __forceinline__ void conv_tile_epilogue(const bf16_conv_params& p, f32x16 (&acc)[tile_geom<ZW, KS>::MT][NT], char* lds, int n, int nb,
                                                    int split, int z0, int y0, int x0, int t, int lane, int w) {
     using G = tile_geom<ZW, KS>;
     // ---- epilogue: residual, ReLU, store, per-(n,channel) statistics.  C/D layout of the 32x32 MFMA: column = lane & 31,
@@ -118,8 +124,16 @@ __device__ __forceinline__ void conv_tile_epilogue(const bf16_conv_params& p, f3
             // consecutive channels 8 g + 4 half .. + 3 — see the epilogue below)
 #pragma unroll
             for (int m = 0; m < G::MT; ++m) {
-                const int z = z0 + w * ZW + (m >> 1), y = y0 + (m & 1) * 4 + (col & 3), xx = x0 + (col >> 2);
-                if (z < p.D && y < p.H && xx < p.W) {
+                int z, y, xx;
+                bool row_ok = true;
+                if constexpr (G::FLAT) {  // GEMM row = raster index of the voxel inside the 5 x 10 x 10 tile
+                    const int v = (w * G::MT + m) * 32 + col, vz = v / (G::TY * G::TX), vr = v - vz * (G::TY * G::TX), vy = vr / G::TX;
+                    z = z0 + vz, y = y0 + vy, xx = x0 + vr - vy * G::TX;
+                    row_ok = v < G::TZ * G::TY * G::TX;
+                } else {
+                    z = z0 + w * ZW + (m >> 1), y = y0 + (m & 1) * 4 + (col & 3), xx = x0 + (col >> 2);
+                }
+                if (row_ok && z < p.D && y < p.H && xx < p.W) {
                     const size_t vox = (((size_t)n * p.D + z) * p.H + y) * p.W + xx;
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
@@ -131,6 +145,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const bf16_conv_params& p, f3
             }
             return;
         }
+        if constexpr (G::FLAT) return;  // (bf16 storage only)
 #pragma unroll
         for (int m = 0; m < G::MT; ++m) {
             const int z = z0 + w * ZW + (m >> 1);
@@ -146,6 +161,9 @@ __device__ __forceinline__ void conv_tile_epilogue(const bf16_conv_params& p, f3
         }
         return;
     }
+    if constexpr (G::FLAT) {
+        return;  // the flat tile is launched with ksplit > 1 only (the fixed-order reduction owns the epilogue)
+    } else {
     float s1[NT], s2[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
@@ -338,21 +356,31 @@ __device__ __forceinline__ void conv_tile_epilogue(const bf16_conv_params& p, f3
             u3d_atomic_add_f64(dst + t, sum);
         }
     }
+    }  // (!FLAT)
 }
 
 // ABL: timing-only ablation bits that attributed the loop's cost (1 no B loads, 2 no A reads, 4 no staging, 8 no barrier, 16 no epilogue,
 // 32 no prologue staging; results in DESIGN.md 4.7).  Only ABL = 0 is instantiated (-DU3D_CONV_ABL=.. builds: tools/ab_libs.sh).
 template <int NT, int ZW, int KS, int ABL = 0, typename T = float>
-__global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void conv3d_bf16_kernel(const bf16_conv_params p) {
+__global__ __launch_bounds__(256, ZW == 3 ? 1 : (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void conv3d_bf16_kernel(const bf16_conv_params p) {
     using G = tile_geom<ZW, KS>;
     // The 64-channel 3x3x3 tile with the full B ring (9 slots, 6 taps ahead) needs 202 VGPRs: two blocks per CU.  With fragments
     // only 2 taps ahead in a ring of 3 it fits 168 — THREE blocks per CU (LDS 46 KB each), and the third wave per SIMD hides more
     // than the shorter lead exposes: config 4 19.5 -> 19.2 ms per step (same-box pairs, profiles/r03_cfg4_ab.txt)
     constexpr bool SHORT = NT == 2 && KS == 3 && (ZW == 1 || std::is_same<T, __bf16>::value);
-    constexpr int B_RING = SHORT ? (KS == 3 ? 3 : 4) : G::RING, B_DIST = SHORT ? 2 : G::BDIST;
+    // FLAT (the small wide levels: a few hundred blocks, each streaming ITS OWN slice of 14-57 MB of weights, most of it from HBM): ONE
+    // block per CU with the whole register file — the ring holds U3D_FLAT_BDIST taps of fragments in flight per wave (the short ring's two
+    // taps = 4 KB per block left the weight stream latency-bound: 0.9 k cycles per tap measured against 256 of MFMA work)
+#ifndef U3D_FLAT_BRING
+#define U3D_FLAT_BRING 9
+#define U3D_FLAT_BDIST 8
+#endif
+    constexpr int B_RING = G::FLAT ? (KS == 3 ? U3D_FLAT_BRING : 8) : SHORT ? (KS == 3 ? 3 : 4) : G::RING;
+    constexpr int B_DIST = G::FLAT ? (KS == 3 ? U3D_FLAT_BDIST : 7) : SHORT ? 2 : G::BDIST;
+    static_assert(G::NTAPS % B_RING == 0 && B_DIST < B_RING || B_RING == G::NTAPS, "ring slots stay aligned across chunks");
     // (bf16 storage: A fragments one tap ahead — the 8-plane tile reads 4 per tap, the 4-plane tile sits at the 168-register line of
     // three blocks per CU and spilled 8 dwords with two taps of them)
-    constexpr int A_DIST = (NT == 2 && std::is_same<T, __bf16>::value && KS == 3) ? 1 : G::ADIST;
+    constexpr int A_DIST = (NT == 2 && std::is_same<T, __bf16>::value && KS == 3 && !G::FLAT) ? 1 : G::ADIST;
     constexpr int HY = G::HY;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -395,7 +423,7 @@ __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void 
         tzi = tile % p.tz;
         n = tile / p.tz;
     }
-    const int z0 = tzi * G::TZ, y0 = tyi * 8, x0 = txi * 8;
+    const int z0 = tzi * G::TZ, y0 = tyi * G::TY, x0 = txi * G::TX;
     const int nch_all = p.C >> 4;
     const int cps = (nch_all + p.ksplit - 1) / p.ksplit;          // chunks per split
     const int cbeg = split * cps, nch = min(nch_all, cbeg + cps);  // this block's chunk range [cbeg, nch)
@@ -409,6 +437,22 @@ __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void 
     // A-fragment base of this lane: row r = lane & 31 -> (yy = r & 3, xx = r >> 2), channel half kh = lane >> 5
     const int r = lane & 31, kh = lane >> 5;
     const int a_base = kh * G::PLANE + (((w * ZW) * HY + (r & 3)) * HS + (r >> 2)) * 16;
+    // FLAT: row r of M-tile m of wave w is voxel v = (4 w + m) * 32 + r of the tile in raster order (rows past the 500th read voxel 0:
+    // computed, never stored) — one base per M-tile instead of one per lane
+    int a_flat[G::FLAT ? G::MT : 1];
+    if constexpr (G::FLAT) {
+#pragma unroll
+        for (int m = 0; m < G::MT; ++m) {
+            int v = (w * G::MT + m) * 32 + r;
+            v = v < G::TZ * G::TY * G::TX ? v : 0;
+            const int vz = v / (G::TY * G::TX), vr = v - vz * (G::TY * G::TX), vy = vr / G::TX, vx = vr - vy * G::TX;
+            a_flat[m] = kh * G::PLANE + ((vz * HY + vy) * HS + vx) * 16;
+        }
+    }
+    auto a_addr = [&](int m, int tzz, int tyy, int txx) {  // byte offset of lane's A record for M-tile m at tap (tzz, tyy, txx)
+        if constexpr (G::FLAT) return a_flat[m] + ((tzz * HY + tyy) * HS + txx) * 16;
+        else return a_base + ((((m >> 1) + tzz) * HY + ((m & 1) * 4 + tyy)) * HS + txx) * 16;
+    };
 
     // Staging descriptors, computed ONCE per block: per item the element offset from the tile's halo origin, a validity bit and
     // the LDS byte offset.  The hot loop is then BRANCH-FREE: out-of-volume items load a harmless in-tensor address (the tile's
@@ -511,7 +555,8 @@ __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void 
 #pragma unroll
         for (int d = 0; d < B_DIST; ++d)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bq[d][j] = wp0[((size_t)d * ntiles + j) * 64 + lane];
+            for (int j = 0; j < NT; ++j)
+                if (B_DIST <= G::BDIST || cbeg * G::NTAPS + d < nch_all * G::NTAPS + G::BDIST) bq[d][j] = wp0[((size_t)d * ntiles + j) * 64 + lane];
     }
     // (two copies of the chunk loop, with and without the GroupNorm affine in the staging: the data-gradient launches have none
     // and copy their bf16 items as they are — a select per dword otherwise)
@@ -552,7 +597,7 @@ __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void 
             const int tzz = d / (KS * KS), tyy = (d / KS) % KS, txx = d % KS;
 #pragma unroll
             for (int m = 0; m < G::MT; ++m)
-                aq[d][m] = *reinterpret_cast<const bf16x8*>(cur + a_base + ((((m >> 1) + tzz) * HY + ((m & 1) * 4 + tyy)) * HS + txx) * 16);
+                aq[d][m] = *reinterpret_cast<const bf16x8*>(cur + a_addr(m, tzz, tyy, txx));
         }
 #pragma unroll
         for (int part = 0; part < G::NPARTS; ++part) {  // part = (z tap, y tap)
@@ -562,7 +607,8 @@ __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void 
 #pragma unroll
             for (int t3 = 0; t3 < KS; ++t3) {
                 const int tap = part * KS + t3;
-                if (live(tap + B_DIST)) {
+                // (the image carries G::BDIST taps of tail padding: a longer lead stops at its end — uniform, last chunk only)
+                if (live(tap + B_DIST) && (B_DIST <= G::BDIST || c * G::NTAPS + tap + B_DIST < nch_all * G::NTAPS + G::BDIST)) {
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
                         if constexpr (!(ABL & 1)) bq[(tap + B_DIST) % B_RING][j] = wp[((size_t)(tap + B_DIST) * ntiles + j) * 64 + lane];
@@ -571,8 +617,7 @@ __global__ __launch_bounds__(256, (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void 
                     const int nt_ = tap + A_DIST, tzz = nt_ / (KS * KS), tyy = (nt_ / KS) % KS, txx = nt_ % KS;
 #pragma unroll
                     for (int m = 0; m < G::MT; ++m)
-                        aq[nt_ % (A_DIST + 1)][m] =
-                            *reinterpret_cast<const bf16x8*>(cur + a_base + ((((m >> 1) + tzz) * HY + ((m & 1) * 4 + tyy)) * HS + txx) * 16);
+                        aq[nt_ % (A_DIST + 1)][m] = *reinterpret_cast<const bf16x8*>(cur + a_addr(m, tzz, tyy, txx));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (live(tap)) {
@@ -629,6 +674,7 @@ __global__ __launch_bounds__(256) void splitk_bf16_reduce_kernel(const bf16_conv
         for (long long v = v0 + slot; v < v1; v += 16) {
             const size_t o = ((size_t)n * V + v) * p.K + c;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
             for (int s = 0; s < p.ksplit; ++s) acc += *reinterpret_cast<const f32x4*>(p.ws + s * split_stride + o);
             if (p.residual) acc += u3d_ldq(presidual + o);
             if (p.maskx) {
@@ -875,8 +921,8 @@ static int launch_bf16(const bf16_conv_params& p, hipStream_t stream) {
     bf16_conv_params q = p;
     q.order = g_u3d_tune[11] == 1 ? 0 : 1;
     q.tz = (p.D + G::TZ - 1) / G::TZ;
-    q.ty = (p.H + 7) / 8;
-    q.tx = (p.W + 7) / 8;
+    q.ty = (p.H + G::TY - 1) / G::TY;
+    q.tx = (p.W + G::TX - 1) / G::TX;
     // few tiles, many channel blocks: blocks of one (channel block, split) — the same weights — next to each other (key 11 = 2 / 3: never / always)
     const long long ntile = (long long)p.N * q.tz * q.ty * q.tx;
     // (measured, profiles/r04_block_order_ab.txt: 3x3x3 at 10x20x20 / 5x10x10 -8...-10 %; the 2x2x2 kernels mixed: left on the old order)
@@ -884,7 +930,7 @@ static int launch_bf16(const bf16_conv_params& p, hipStream_t stream) {
     const long long blocks = (long long)p.N * q.tz * q.ty * q.tx * (p.K / (32 * NT)) * p.ksplit;
     if (blocks > 0x7fffffffLL) return u3d_set_err(U3D_EINVAL, "u3d_conv3d_bf16: grid too large");
     size_t shmem = 2 * (size_t)G::BUF;
-    if (std::is_same<T, __bf16>::value && shmem < (size_t)64 * G::TZ * (NT * 64 + 16)) shmem = (size_t)64 * G::TZ * (NT * 64 + 16);  // epilogue tile
+    if (std::is_same<T, __bf16>::value && !G::FLAT && shmem < (size_t)64 * G::TZ * (NT * 64 + 16)) shmem = (size_t)64 * G::TZ * (NT * 64 + 16);  // epilogue tile
     // (per device, cheap: set on every launch so that every device of a multi-GPU process has it)
     U3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_bf16_kernel<NT, ZW, KS, ABL, T>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -892,7 +938,9 @@ static int launch_bf16(const bf16_conv_params& p, hipStream_t stream) {
     U3D_LAUNCH_CHECK();
     if (p.ksplit > 1) {
         const long long V = (long long)p.D * p.H * p.W;
-        const int vper = 64;
+        // voxels per block: 64 on big volumes; 16 (one per thread slot) where that would leave most CUs without a block — the 5 x 10 x 10
+        // level ran this pass on 128 blocks, 4 voxels x ksplit serial 16-byte loads per thread: 24 us for 32 MB (rocprofv3, round 5)
+        const int vper = (V + 63) / 64 * ((p.K + 63) / 64) * p.N >= 1024 ? 64 : 16;
         hipLaunchKernelGGL(splitk_bf16_reduce_kernel<T>, dim3((unsigned)((V + vper - 1) / vper), (unsigned)((p.K + 63) / 64), (unsigned)p.N),
                            dim3(256), 0, stream, q, V, vper);
         U3D_LAUNCH_CHECK();
@@ -939,9 +987,29 @@ static int bf16_ksplit(int N, int D, int H, int W, int C, int K) {
     return ks < 2 ? 1 : (int)ks;
 }
 
+// Round 5: the FLAT 5 x 10 x 10 tile (tile_geom<3, 3>) for the small, wide levels that already split their channel reduction — bf16 storage,
+// 64-channel blocks.  Chosen where it executes at most 3/4 of the padded GEMM rows of the 4 x 8 x 8 tiling (config 4: 512 instead of 2048
+// rows at 5 x 10 x 10, 4096 instead of 6912 at 10 x 20 x 20); its split count aims at one block per CU (the kernel's occupancy) with at least two chunks per block.
+// Returns the split count, 0 = not used.  u3d_set_tuning key 16: 1 = never, >= 2 = that split count (A/B).
+static int bf16_flat_ksplit(int N, int D, int H, int W, int C, int K) {
+    if (g_u3d_tune[16] == 1 || K % 64 != 0 || bf16_ksplit(N, D, H, W, C, K) < 2) return 0;
+    const long long tiles4 = (long long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 7) / 8);
+    const long long tilesf = (long long)N * ((D + 4) / 5) * ((H + 9) / 10) * ((W + 9) / 10);
+    if (tilesf * 512 * 4 > tiles4 * 256 * 3) return 0;
+    const int nch = C / 16;
+    const long long natural = tilesf * (K / 64);
+    long long ks = (256 + natural - 1) / natural;  // one block per CU
+    if (g_u3d_tune[16] >= 2) ks = g_u3d_tune[16];
+    if (ks > nch / 2) ks = nch / 2;
+    if (ks > 32) ks = 32;
+    return ks < 2 ? 0 : (int)ks;
+}
+
 extern "C" long long u3d_conv3d_bf16_workspace_floats(int N, int D, int H, int W, int C, int K) {
     if (!u3d_conv3d_bf16_supported(C, K) || N <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
-    const int ks = bf16_ksplit(N, D, H, W, C, K);
+    int ks = bf16_ksplit(N, D, H, W, C, K);
+    const int kf = bf16_flat_ksplit(N, D, H, W, C, K);  // (the b16 entry points may take the flat tile's plan: room for either)
+    if (kf > ks) ks = kf;
     return ks > 1 ? (long long)ks * N * D * H * W * K : 0;
 }
 
@@ -993,12 +1061,18 @@ static int conv3d_bf16_impl(int device, u3d_stream_t stream, const float* x, con
                        N, D, H, W, C, K, relu, 0, 0, 0, 1, nullptr, 1, nullptr};
     p.b16 = b16;
     const int ks = bf16_ksplit(N, D, H, W, C, K);
+    const int kf = b16 ? bf16_flat_ksplit(N, D, H, W, C, K) : 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (kf > 1 && workspace && workspace_floats >= (long long)kf * N * D * H * W * K) {
+        p.ksplit = kf;
+        p.ws = workspace;
+        return launch_bf16<2, 3, 3, 0, __bf16>(p, s);
+    }
     if (ks > 1 && workspace && workspace_floats >= (long long)ks * N * D * H * W * K) {
         p.ksplit = ks;
         p.ws = workspace;
     }
     const Bf16Tile tc = bf16_tile_choice(N, D, H, W, K, b16, p.ksplit);
-    hipStream_t s = (hipStream_t)stream;
 #ifndef U3D_CONV_ABL
 #define U3D_CONV_ABL 0  // timing experiments on the 8-plane bf16-storage tile (tools/ab_libs.sh; WRONG results): see the kernel's ABL bits
 #endif
@@ -1011,6 +1085,8 @@ static int conv3d_bf16_impl(int device, u3d_stream_t stream, const float* x, con
 extern "C" int u3d_conv3d_bf16_tile_variant(int N, int D, int H, int W, int C, int K, int b16) {
     if (!u3d_conv3d_bf16_supported(C, K) || N <= 0 || D <= 0 || H <= 0 || W <= 0) return -1;
     const int ks = bf16_ksplit(N, D, H, W, C, K);
+    const int kf = b16 ? bf16_flat_ksplit(N, D, H, W, C, K) : 0;
+    if (kf > 1) return (kf << 16) | (5 << 8) | (2 << 4) | 2;  // planes = 5: the flat 5 x 10 x 10 tile
     const Bf16Tile tc = bf16_tile_choice(N, D, H, W, K, b16 != 0, ks);
     return (ks << 16) | (tc.planes << 8) | (tc.nt << 4) | tc.blocks_per_cu;
 }
@@ -2159,7 +2235,9 @@ extern "C" int u3d_convtr3d_fwd_t8_b16(int device, u3d_stream_t stream, const vo
 // ReLU mask); without a workspace they run unsplit, like the plain entry points.
 extern "C" long long u3d_convtr3d_dgrad_t8_workspace_floats(int N, int D1, int H1, int W1, int Cl, int Cs) {
     if (!u3d_convtr3d_t8_supported(Cl, Cs) || N <= 0 || D1 <= 0 || H1 <= 0 || W1 <= 0) return 0;
-    const int ks = bf16_ksplit(N, D1, H1, W1, 8 * Cs, Cl);
+    int ks = bf16_ksplit(N, D1, H1, W1, 8 * Cs, Cl);
+    const int kf = bf16_flat_ksplit(N, D1, H1, W1, 8 * Cs, Cl);  // (bf16 storage may take the flat tile's plan: room for either)
+    if (kf > ks) ks = kf;
     return ks > 1 ? (long long)ks * N * D1 * H1 * W1 * Cl : 0;
 }
 
@@ -2173,6 +2251,12 @@ static int convtr3d_dgrad_t8_impl(int device, u3d_stream_t stream, const float* 
     p.t8mode = g_u3d_tune[10] == 2 ? 0 : 2;
     p.t8cs = Cs;
     const int ks = bf16_ksplit(N, D1, H1, W1, 8 * Cs, Cl);
+    const int kf = b16 ? bf16_flat_ksplit(N, D1, H1, W1, 8 * Cs, Cl) : 0;
+    if (kf > 1 && workspace && workspace_floats >= (long long)kf * N * D1 * H1 * W1 * Cl) {  // the flat 5 x 10 x 10 tile (see u3d_conv3d_bf16_ex_b16)
+        p.ksplit = kf;
+        p.ws = workspace;
+        return launch_bf16<2, 3, 2, 0, __bf16>(p, (hipStream_t)stream);
+    }
     if (ks > 1 && workspace && workspace_floats >= (long long)ks * N * D1 * H1 * W1 * Cl) {
         p.ksplit = ks;
         p.ws = workspace;

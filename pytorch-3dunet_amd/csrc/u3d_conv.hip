@@ -37,7 +37,8 @@
 //   [13] 1 = first-layer forward on the direct kernel instead of the matrix-pipe one (csrc/u3d_smallc.hip, A/B)
 //   [14] 1 = persistent convolution kernel walks its tiles x-fastest (rounds 1-3) instead of z-fastest
 //   [15] 1 = sub-pixel weight gradient with per-element coordinate arithmetic for its B loads (A/B of the constant-offset path)
-int g_u3d_tune[16] = {0};
+//   [16] bf16-storage 3x3x3 convolution, flat 5 x 10 x 10 tile of the small wide levels: 1 = never, >= 2 = force that split count
+int g_u3d_tune[24] = {0};
 
 namespace cv {
 constexpr int TZ = 4, TY = 8, TX = 8;
@@ -2019,7 +2020,7 @@ extern "C" int u3d_set_profile_buffer(void* device_buffer, size_t bytes) {
 }
 
 extern "C" int u3d_set_tuning(int key, int value) {
-    if (key < 0 || key >= 16) return u3d_set_err(U3D_EINVAL, "u3d_set_tuning: key out of range");
+    if (key < 0 || key >= 24) return u3d_set_err(U3D_EINVAL, "u3d_set_tuning: key out of range");
     g_u3d_tune[key] = value;
     return 0;
 }

@@ -11,7 +11,7 @@
 //             so one pass over (dz, x) replaces wgrad + dgrad + their reductions.
 #include "u3d_common.h"
 
-extern int g_u3d_tune[16];  // u3d_set_tuning (csrc/u3d_conv.hip); key 13 = 1: first-layer forward on the direct (non-MFMA) kernel, for A/B
+extern int g_u3d_tune[24];  // u3d_set_tuning (csrc/u3d_conv.hip); key 13 = 1: first-layer forward on the direct (non-MFMA) kernel, for A/B
 
 typedef float f32x4s __attribute__((ext_vector_type(4)));
 

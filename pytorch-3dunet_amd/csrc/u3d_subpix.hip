@@ -22,7 +22,7 @@
 // u3d_conv3d_residual, whose epilogue applies ReLU and the GroupNorm statistics to the sum.
 #include "u3d_subpix.h"
 
-extern int g_u3d_tune[16];  // u3d_set_tuning (csrc/u3d_conv.hip); key 15 = 1: sub-pixel weight gradient without the constant-offset B loads
+extern int g_u3d_tune[24];  // u3d_set_tuning (csrc/u3d_conv.hip); key 15 = 1: sub-pixel weight gradient without the constant-offset B loads
 
 
 struct SubpixParams {

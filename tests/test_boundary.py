@@ -36,7 +36,7 @@ def test_header_symbols_exported():
     lib = ctypes.CDLL(nat.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert nat.get_lib().u3d_version() == 119
+    assert nat.get_lib().u3d_version() == 120
 
 
 def test_host_only_entry_points():
@@ -59,7 +59,10 @@ def test_host_only_entry_points():
     # ... and the split-K rule of the transposed convolution's data gradient: only the two bottom levels ask for scratch
     t8 = [(5, 10, 10, 1024, 512), (10, 20, 20, 512, 256), (20, 40, 40, 256, 128), (40, 80, 80, 128, 64)]
     need = [lib.u3d_convtr3d_dgrad_t8_workspace_floats(1, *a) for a in t8]
-    assert need[0] == 8 * 500 * 1024 and need[1] == 5 * 4000 * 512 and need[2] == 0 and need[3] == 0, need
+    # (round 5: the bottom level's bf16-storage launch takes the flat 5 x 10 x 10 tile with 16 splits — the scratch has room for either plan)
+    assert need[0] == 16 * 500 * 1024 and need[1] == 5 * 4000 * 512 and need[2] == 0 and need[3] == 0, need
+    v = [lib.u3d_conv3d_bf16_tile_variant(1, *sh, c, c, 1) for sh, c in lv]
+    assert [(x >> 8) & 255 for x in v] == [8, 8, 4, 5, 5] and [x >> 16 for x in v] == [1, 1, 1, 4, 16], v
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -97,6 +97,72 @@ def test_conv3d_bf16_b16_forward_and_data_gradient(shape, C, K, res, ks):
     assert torch.allclose(g16, want, rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("shape,C,K", [((1, 5, 10, 10), 128, 128), ((2, 5, 10, 20), 64, 192), ((1, 9, 17, 10), 128, 64),
+                                       ((1, 10, 20, 20), 256, 128)])
+def test_conv3d_bf16_b16_flat_tile_of_the_small_wide_levels(shape, C, K):
+    """Round 5: the 5 x 10 x 10 FLAT tile (GEMM rows = the tile's voxels in raster order; config 4's 10 x 20 x 20 and 5 x 10 x 10 levels)
+    against the 4 x 8 x 8 tiling it replaces there (u3d_set_tuning key 16 = 1).  Both run the same (chunk, tap) sequence per output
+    element, so with the SAME split count (key 16 = that count) the two must agree bit for bit — forward (affine, residual, ReLU,
+    statistics) and data-gradient role (GroupNorm-backward sums); with its own split count the flat plan differs by fp32 round-off of
+    the split sums only.  Full, N = 2, and ragged (9 x 17 x 10: partial tiles along z and y) volumes."""
+    N, D, H, W = shape
+    torch.manual_seed(5)
+    L = nat.get_lib()
+    x = dev(r16(torch.randn(N, D, H, W, C))).to(BF)
+    aff = dev(torch.stack((1.0 + 0.3 * torch.randn(N, C), 0.2 * torch.randn(N, C)), dim=-1))
+    w = dev(torch.randn(K, C, 3, 3, 3) / (27 * C) ** 0.5)
+    res = dev(r16(torch.randn(N, D, H, W, K))).to(BF)
+    dz = dev(r16(torch.randn(N, D, H, W, K))).to(BF)
+    pk = torch.empty(L.u3d_packed_weight_bf16_elems(C, K, 0), dtype=BF, device=U.DEV)
+    call("u3d_pack_weights_bf16", _p(w), K, C, 0, _p(pk))
+    pk1 = torch.empty(L.u3d_packed_weight_bf16_elems(C, K, 1), dtype=BF, device=U.DEV)
+    call("u3d_pack_weights_bf16", _p(w), K, C, 1, _p(pk1))
+
+    def variant(c, k):
+        v = L.u3d_conv3d_bf16_tile_variant(N, D, H, W, c, k, 1)
+        return v >> 16, (v >> 8) & 255
+
+    def run(role):  # 0: forward (affine, residual, ReLU, statistics), 1: data gradient (GroupNorm-backward sums against gx)
+        c, k = (C, K) if role == 0 else (K, C)
+        need = L.u3d_conv3d_bf16_workspace_floats(N, D, H, W, c, k)
+        assert need > 0
+        ws = torch.empty(need, dtype=torch.float32, device=U.DEV)
+        y = torch.full((N, D, H, W, k), float("nan"), dtype=BF, device=U.DEV)
+        st = torch.zeros((N, k, 2), dtype=torch.float64, device=U.DEV)
+        if role == 0:
+            call("u3d_conv3d_bf16_ex_b16", _p(x), _p(aff), _p(pk), _p(y), N, D, H, W, C, K, 1, _p(st), None, None, _p(res), _p(ws), need)
+        else:
+            call("u3d_conv3d_bf16_ex_b16", _p(dz), None, _p(pk1), _p(y), N, D, H, W, K, C, 0, None, _p(x), _p(st), None, _p(ws), need)
+        torch.cuda.synchronize()
+        return y, st
+
+    auto = None
+    for role in (0, 1):
+        c, k = (C, K) if role == 0 else (K, C)
+        try:
+            assert variant(c, k)[1] == 5, variant(c, k)  # the flat tile is what runs by default
+            auto_r = run(role)
+            nat.call("u3d_set_tuning", 16, 1)
+            ks, planes = variant(c, k)
+            assert planes == 4 and ks > 1
+            old = run(role)
+            nat.call("u3d_set_tuning", 16, ks)
+            assert variant(c, k) == (ks, 5)
+            same = run(role)
+        finally:
+            nat.call("u3d_set_tuning", 16, 0)
+        assert same_bits(same[0], old[0]) and torch.allclose(same[1], old[1], rtol=1e-9, atol=1e-9), role
+        assert not torch.isnan(auto_r[0].float()).any()
+        assert torch.allclose(auto_r[0].float(), old[0].float(), rtol=1e-2, atol=1e-3)
+        assert torch.allclose(auto_r[1], old[1], rtol=1e-3, atol=1e-2)
+        auto = auto or auto_r
+    ref = F.conv3d(U.ncdhw((x.float() * aff[:, :, 0].view(N, 1, 1, 1, C) + aff[:, :, 1].view(N, 1, 1, 1, C)).cpu()), w.cpu(), None, padding=1)
+    ref = torch.relu(ref + U.ncdhw(res.float().cpu()))
+    err = (U.ncdhw(auto[0].float().cpu()) - ref).norm() / ref.norm()
+    diag(kind="bf16_flat_tile", shape=list(shape), C=C, K=K, rel_l2_vs_fp32=float(err))
+    assert err < 1e-2
+
+
 @pytest.mark.parametrize("with_affine", [True, False])
 @pytest.mark.parametrize("shape,C,K,blocks", [((1, 8, 16, 16), 64, 64, 0), ((2, 5, 9, 19), 32, 128, 0),
                                               ((1, 6, 24, 50), 32, 64, 0),    # interior, border and ragged tiles, one per block
@@ -175,6 +241,43 @@ def test_transposed_convolution_t8_b16():
         nat.call("u3d_set_tuning", 7, 0)
     assert same_bits(t16, t32.to(BF)) and same_bits(dx16, dx32.to(BF)) and torch.equal(dwa, dwc)
     assert torch.isfinite(dwb).all() and float((dwb - dwa).abs().max()) < 1e-4 * float(dwa.abs().max())
+
+
+@pytest.mark.parametrize("dims,Cl,Cs", [((1, 5, 10, 10), 128, 64), ((1, 9, 17, 10), 64, 32)])
+def test_transposed_convolution_data_gradient_on_the_flat_tile(dims, Cl, Cs):
+    """u3d_convtr3d_dgrad_t8_b16_ex on the flat 5 x 10 x 10 tile (round 5, config 4's two bottom levels) against the 4 x 8 x 8 tiling
+    (u3d_set_tuning key 16 = 1): bit-identical with the same split count (key 16 = that count), fp32 round-off of the split sums apart
+    with its own; the ReLU mask of x is applied by the fixed-order reduction in both."""
+    N, D1, H1, W1 = dims
+    torch.manual_seed(6)
+    L = nat.get_lib()
+    x = dev(r16(torch.relu(torch.randn(N, D1, H1, W1, Cl)))).to(BF)
+    w = dev(torch.randn(Cl, Cs, 3, 3, 3) / (27 * Cl / 8) ** 0.5)
+    dt8 = dev(r16(torch.randn(N, D1, H1, W1, 8 * Cs))).to(BF)
+    pk = torch.empty(L.u3d_convtr3d_t8_packed_elems(Cl, Cs, 1), dtype=BF, device=U.DEV)
+    call("u3d_pack_convtr3d_t8", _p(w), Cl, Cs, 1, _p(pk))
+
+    def run():
+        need = L.u3d_convtr3d_dgrad_t8_workspace_floats(N, D1, H1, W1, Cl, Cs)
+        assert need > 0
+        ws = torch.empty(need, device=U.DEV)
+        dx = torch.full(x.shape, float("nan"), dtype=BF, device=U.DEV)
+        call("u3d_convtr3d_dgrad_t8_b16_ex", _p(dt8), _p(pk), _p(x), _p(dx), N, D1, H1, W1, Cl, Cs, _p(ws), need)
+        torch.cuda.synchronize()
+        return dx, need // (N * D1 * H1 * W1 * Cl)
+
+    try:
+        auto, _ = run()
+        nat.call("u3d_set_tuning", 16, 1)
+        old, ks = run()
+        assert ks > 1
+        nat.call("u3d_set_tuning", 16, ks)
+        same, ks2 = run()
+    finally:
+        nat.call("u3d_set_tuning", 16, 0)
+    assert ks2 == ks and same_bits(same, old)
+    assert not torch.isnan(auto.float()).any() and torch.allclose(auto.float(), old.float(), rtol=1e-2, atol=1e-3)
+    assert bool((auto.float()[x.float() <= 0] == 0).all())
 
 
 def test_bandwidth_kernels_b16():

@@ -175,6 +175,7 @@ def test_config4_at_its_benchmarked_shape_bf16_storage_with_checkpointing():
     assert var[0]["planes"] == 8 and var[1]["planes"] == 8, var                      # 8-plane tiles at the top two levels
     assert var[2] == dict(ksplit=1, planes=4, nt=2, blocks_per_cu=3), var            # three blocks per CU at 256 channels / 20 planes
     assert var[3]["ksplit"] > 1 and var[4]["ksplit"] > 1, var                        # split-K at the bottom
+    assert var[3]["planes"] == 5 and var[4]["planes"] == 5, var                      # ... on the flat 5 x 10 x 10 tile (round 5)
     assert _variant(lib, (32, 64, 64), 64)["planes"] == 4                            # (the ladder test's top level: 4-plane tiles)
     # the round-4 weight gradient: 4 x 8 x 8 tiles wherever they waste no more voxels than 2 x 8 x 16 ones (all but the 5 x 10 x 10 level)
     wv = [lib.u3d_conv3d_wgrad_bf16_b16_variant(1, *sh, c, c) for sh, c in lv_shapes]
