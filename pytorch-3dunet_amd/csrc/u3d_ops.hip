@@ -703,11 +703,57 @@ __global__ void maxpool2_fwd_kernel(const T* __restrict__ x, int N, int D, int H
     }
 }
 
+// 16-byte version (bf16 storage: 0.142 -> 0.086 ms per step on config 4): a thread owns VW consecutive channels (8 bf16) of one output voxel — eight 16-byte loads in flight, one
+// 16-byte store and VW arg-max bytes; same scan order and NaN rule per element as the scalar kernel above (which moves 4 / 2 bytes per lane)
+template <typename T, int VW>
+__global__ __launch_bounds__(256) void maxpool2_fwd_vec_kernel(const T* __restrict__ x, int N, int D, int H, int W, int C, T* __restrict__ out,
+                                                               uint8_t* __restrict__ argmax) {
+    typedef T vec_t __attribute__((ext_vector_type(VW)));
+    typedef uint8_t idx_t __attribute__((ext_vector_type(VW)));
+    const int D2 = D >> 1, H2 = H >> 1, W2 = W >> 1, Q = C / VW;
+    const long long total = (long long)N * D2 * H2 * W2 * Q;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int qd = (int)(idx % Q);
+        long long v = idx / Q;
+        const int xo = (int)(v % W2);
+        v /= W2;
+        const int yo = (int)(v % H2);
+        v /= H2;
+        const int zo = (int)(v % D2);
+        const int n = (int)(v / D2);
+        const T* base = x + ((size_t)((n * D + 2 * zo) * H + 2 * yo) * W + 2 * xo) * C + qd * VW;
+        vec_t val[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            val[k] = *reinterpret_cast<const vec_t*>(base + ((size_t)((k >> 2) * H + ((k >> 1) & 1)) * W + (k & 1)) * C);
+        vec_t best;
+        idx_t bi;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+            float b = -INFINITY;
+            int i = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float f = (float)val[k][e];
+                if (f > b || f != f) {
+                    b = f;
+                    i = k;
+                }
+            }
+            best[e] = (T)b;  // (one of the inputs: exact in T)
+            bi[e] = (uint8_t)i;
+        }
+        *reinterpret_cast<vec_t*>(out + idx * VW) = best;
+        *reinterpret_cast<idx_t*>(argmax + idx * VW) = bi;
+    }
+}
+
 extern "C" int u3d_maxpool2_fwd(int device, u3d_stream_t stream, const float* x, int N, int D, int H, int W, int C,
                                 float* out, uint8_t* argmax, double* out_stats) {
     U3D_ENTER(device);
     U3D_REQUIRE(x && out && argmax && N > 0 && D >= 2 && H >= 2 && W >= 2 && C > 0, "u3d_maxpool2_fwd: bad argument");
     const long long total = (long long)N * (D / 2) * (H / 2) * (W / 2) * C;
+    // (the 16-byte variant below is for bf16 storage: with fp32 tensors it measured 0.131 against this kernel's 0.116 ms per step on config 2)
     hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, x, N, D,
                        H, W, C, out, argmax);
     U3D_LAUNCH_CHECK();
@@ -725,8 +771,12 @@ extern "C" int u3d_maxpool2_fwd_b16(int device, u3d_stream_t stream, const void*
     U3D_ENTER(device);
     U3D_REQUIRE(x && out && argmax && N > 0 && D >= 2 && H >= 2 && W >= 2 && C > 0, "u3d_maxpool2_fwd_b16: bad argument");
     const long long total = (long long)N * (D / 2) * (H / 2) * (W / 2) * C;
-    hipLaunchKernelGGL(maxpool2_fwd_kernel<__bf16>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream,
-                       (const __bf16*)x, N, D, H, W, C, (__bf16*)out, argmax);
+    if (C % 8 == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0 && ((uintptr_t)argmax & 7) == 0)
+        hipLaunchKernelGGL((maxpool2_fwd_vec_kernel<__bf16, 8>), dim3(grid_for(total / 8, 16384)), dim3(256), 0, (hipStream_t)stream,
+                           (const __bf16*)x, N, D, H, W, C, (__bf16*)out, argmax);
+    else
+        hipLaunchKernelGGL(maxpool2_fwd_kernel<__bf16>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream,
+                           (const __bf16*)x, N, D, H, W, C, (__bf16*)out, argmax);
     U3D_LAUNCH_CHECK();
     return 0;
 }
