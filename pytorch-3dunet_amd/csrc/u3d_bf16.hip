@@ -1149,6 +1149,8 @@ struct bf16_wgrad_params {
     int t8cs;             // 2x2x2 weight gradient of the transposed convolution (KS = 2, space-to-depth form): Cs if a block's 64 output
                           // columns lie inside ONE output parity (Cs % 64 == 0), else 0.  Only 27 of the 64 (tap, parity) blocks carry a tap
                           // (tap a is live for parity p iff a & ~p == 0): a wave skips the fragment reads, MFMAs and stores of its dead taps
+    float* dw;            // conv3d_wgrad_b16v2_kernel with ONE split (every block owns all tiles of its pair): the block writes its 27 x 32 x 64
+                          // sums straight into dw[co][ci][tap] (through LDS, 3456-byte runs) and no reduction kernel follows; else null
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -1699,9 +1701,42 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_b16v2_kernel(const bf16_w
         return;
     }
 #endif
+    const int col = lane & 31, half = lane >> 5;
+    if (p.dw) {
+        // ---- one split: this block's sums ARE the gradient.  The reference layout dw[co][ci][tap] makes a block's output 64 rows (co) of
+        // 32 x 27 = 864 consecutive floats; the accumulators hold (ci, co) tiles per tap.  Two passes (one 32-column half each) through
+        // LDS [co 32][864 + 1] (the staging buffers are free now): 16-byte coalesced stores instead of the 113 MB of partial sums +
+        // a transposing reduction pass (51 us at 1024 channels, rocprofv3) that the workspace path costs when there is nothing to reduce
+        constexpr int RS = 27 * 32 + 1;
+        static_assert(32 * RS * 4 <= G::LDS_TOTAL, "the transposition tile must fit the staging buffers");
+        float* tl = reinterpret_cast<float*>(lds);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) {
+                const int tap = w + 8 * i;
+                if (tap < 27) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int ci = (e & 3) + 8 * (e >> 2) + 4 * half;
+                        tl[col * RS + ci * 27 + tap] = acc[i][hh][e];
+                    }
+                }
+            }
+            __syncthreads();
+            for (int idx = t; idx < 32 * 216; idx += 512) {
+                const int r = idx / 216, q4 = idx - r * 216, co = k0 + hh * 32 + r;
+                if (co < p.K) {
+                    const float* src = tl + r * RS + 4 * q4;
+                    *reinterpret_cast<f32x4*>(p.dw + ((size_t)co * p.C + c0) * 27 + 4 * q4) = f32x4{src[0], src[1], src[2], src[3]};
+                }
+            }
+        }
+        return;
+    }
     // ---- partial sums: ws[split][pair][tap][ci 32][co 64]; D layout: column = lane & 31 (co), row = ci
     float* dst = p.ws + ((size_t)split * P + pair) * 27 * 2048;
-    const int col = lane & 31, half = lane >> 5;
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
         const int tap = w + 8 * i;
@@ -2063,6 +2098,10 @@ static int conv3d_wgrad_bf16_impl(int device, u3d_stream_t stream, const float* 
         return u3d_set_err(U3D_EWORKSPACE, "u3d_conv3d_wgrad_bf16: workspace of %lld floats needed, %lld given", need, workspace_floats);
     bf16_wgrad_params p{x, affine, dz, workspace, N, D, H, W, C, K, 1, q.tz, q.ty, q.tx, q.tiles, q.per_block, (K + 63) / 64,
                         g_u3d_tune[9] == 1 ? 0 : 1};
+    // one split (every block owns all tiles of its (32 input, 64 output channels) pair: config 4's 1024-channel level): the round-4 kernel
+    // writes dw itself (u3d_set_tuning key 17 = 1: through the workspace and the reduction, as before; same bits)
+    const bool direct = (variant == 8 || variant == 16) && q.S == 1 && g_u3d_tune[17] != 1 && ((uintptr_t)dw & 15) == 0;
+    p.dw = direct ? dw : nullptr;
 #ifdef U3D_WG_TRACE
     constexpr int v2_extra = 8 * 12 * 14 * 4;
 #else
@@ -2087,6 +2126,7 @@ static int conv3d_wgrad_bf16_impl(int device, u3d_stream_t stream, const float* 
         hipLaunchKernelGGL(conv3d_wgrad_bf16_kernel<3>, dim3((unsigned)(q.S * q.P)), dim3(512), 2 * wg_geom<3>::LDS, (hipStream_t)stream, p);
     }
     U3D_LAUNCH_CHECK();
+    if (direct) return 0;
     if (q.P * 32 >= 1024) {
         hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)(q.P * 32)), dim3(256), 0, (hipStream_t)stream, workspace, q.S, C, K, dw);
     } else {

@@ -38,6 +38,7 @@
 //   [14] 1 = persistent convolution kernel walks its tiles x-fastest (rounds 1-3) instead of z-fastest
 //   [15] 1 = sub-pixel weight gradient with per-element coordinate arithmetic for its B loads (A/B of the constant-offset path)
 //   [16] bf16-storage 3x3x3 convolution, flat 5 x 10 x 10 tile of the small wide levels: 1 = never, >= 2 = force that split count
+//   [17] 1 = bf16-storage weight gradient with ONE split still goes through the workspace + reduction kernel (A/B of the direct dw write)
 int g_u3d_tune[24] = {0};
 
 namespace cv {

@@ -168,7 +168,10 @@ def test_conv3d_bf16_b16_flat_tile_of_the_small_wide_levels(shape, C, K):
                                               ((1, 6, 24, 50), 32, 64, 0),    # interior, border and ragged tiles, one per block
                                               ((2, 6, 24, 50), 32, 64, 5),    # ... walked by 5 blocks: tile loop across samples
                                               ((1, 7, 26, 66), 64, 128, 12),
-                                              ((1, 12, 40, 40), 64, 64, 7)])   # (config 4's 40-wide level: the 8-wide tile by default)
+                                              ((1, 12, 40, 40), 64, 64, 7),    # (config 4's 40-wide level: the 8-wide tile by default)
+                                              # ONE split (a block owns all tiles of its channel pair — config 4's 1024-channel level): the
+                                              # round-4 kernel writes dw itself, no workspace pass; same bits as through the reduction
+                                              ((2, 5, 9, 19), 32, 128, 1), ((1, 7, 26, 66), 64, 128, 1)])
 # (Cout % 64 == 32 runs the round-3 kernel with a masked upper half in both storage modes: tests/test_gpu_bf16.py::test_conv3d_wgrad_bf16)
 def test_conv3d_wgrad_bf16_b16(shape, C, K, blocks, with_affine):
     """bf16 storage.  The round-3 kernel (key 7 = 1) and the round-4 kernel on 2 x 8 x 16 tiles (key 7 = 16) reproduce the
