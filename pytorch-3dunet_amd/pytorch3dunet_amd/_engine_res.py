@@ -228,7 +228,7 @@ class ResUNetEngine(UNet3DEngine):
                 if tape is not None:
                     tape.pools.append((pooled, argmax, cur))
                 cur = pooled
-            if tape is not None and self.checkpoint_encoders:
+            if tape is not None and self.checkpoint_encoders and (self.checkpoint_levels is None or i < self.checkpoint_levels):
                 # activation checkpointing of the encoder blocks (BASELINE config 4): keep the block input only
                 x_in = cur
                 cur = self._block_fwd(bm, f"enc{i}", cur, None, pool, None, dev)

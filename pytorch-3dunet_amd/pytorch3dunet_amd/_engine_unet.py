@@ -51,6 +51,7 @@ class UNet3DEngine(WeightImages, ConvLayers):
         # forward and data gradients only, weight gradients stay on the fp32 MFMA kernels
         self.split = bool(getattr(model, "compute_split", False)) and not self.bf16
         self.checkpoint_encoders = bool(getattr(model, "checkpoint_encoders", False))
+        self.checkpoint_levels = getattr(model, "checkpoint_levels", None)  # None: every encoder level; k: the k highest-resolution ones
         # with activation checkpointing the tape is also RELEASED block by block during backward (ResUNetEngine.backward): a feature
         # whose only purpose is memory must move the peak, and with one autograd node owning the whole tape it otherwise does not
         self.lean_tape = False  # (ResUNetEngine turns it on together with checkpoint_encoders)

@@ -101,7 +101,15 @@ class AbstractUNet(nn.Module):
         self.compute_split = str(compute_dtype).lower() == "fp32_split"
         if checkpoint_encoders is None:
             checkpoint_encoders = os.environ.get("U3D_CHECKPOINT", "0") == "1"
+            if checkpoint_encoders and os.environ.get("U3D_CHECKPOINT_LEVELS", ""):
+                checkpoint_encoders = int(os.environ["U3D_CHECKPOINT_LEVELS"])
+        # `checkpoint_encoders: true` recomputes EVERY encoder block in backward; an integer k only the k encoder levels of highest
+        # resolution (the first two levels of a 5-level net hold ~9/10 of the encoder tape; the deeper ones cost recomputation for a few
+        # megabytes each).  U3D_CHECKPOINT=1 [+ U3D_CHECKPOINT_LEVELS=k] likewise.
+        if not isinstance(checkpoint_encoders, (bool, int)) or int(checkpoint_encoders) < 0:
+            raise ValueError(f"checkpoint_encoders must be true / false or a number of encoder levels, got {checkpoint_encoders!r}")
         self.checkpoint_encoders = bool(checkpoint_encoders)
+        self.checkpoint_levels = None if isinstance(checkpoint_encoders, bool) or not checkpoint_encoders else int(checkpoint_encoders)
         # `activation_dtype: bf16` / U3D_ACT_BF16=1 (with compute_dtype bf16, residual 'gcr' nets): activations and gradients between
         # kernels are stored as bf16 (engine.ResUNetEngine.act_bf16); anything else keeps fp32 storage
         if activation_dtype is None:

@@ -389,3 +389,22 @@ def test_models_pickle_and_torch_save_like_the_reference_modules(cfg, tmp_path):
             assert k == k2 and torch.equal(a, b)
         other.load_state_dict(model.state_dict())          # the hook survives the round trip ...
         assert other.__dict__["_engine_stale"] is True     # ... and still marks the executor stale
+
+
+def test_checkpoint_encoders_accepts_a_number_of_levels(monkeypatch):
+    """`checkpoint_encoders: true` = every encoder block is recomputed in backward, an integer k = only the k highest-resolution levels
+    (round 5); false / absent = none; the environment variables set the default of the model key"""
+    from pytorch3dunet_amd.unet3d.model import get_model
+
+    cfg = dict(name="ResidualUNet3D", in_channels=1, out_channels=1, f_maps=8, num_groups=4)
+    for v, want in ((True, (True, None)), (False, (False, None)), (2, (True, 2)), (1, (True, 1)), (0, (False, None))):
+        m = get_model(dict(cfg, checkpoint_encoders=v))
+        assert (m.checkpoint_encoders, m.checkpoint_levels) == want, v
+    m = get_model(dict(cfg))
+    assert (m.checkpoint_encoders, m.checkpoint_levels) == (False, None)
+    monkeypatch.setenv("U3D_CHECKPOINT", "1")
+    assert get_model(dict(cfg)).checkpoint_levels is None and get_model(dict(cfg)).checkpoint_encoders
+    monkeypatch.setenv("U3D_CHECKPOINT_LEVELS", "2")
+    assert get_model(dict(cfg)).checkpoint_levels == 2
+    with pytest.raises(ValueError):
+        get_model(dict(cfg, checkpoint_encoders="yes"))

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--bf16", action="store_true", help="compute_dtype='bf16' (fp32 master weights / activations / statistics)")
     ap.add_argument("--split", action="store_true", help="compute_dtype='fp32_split' (fp32-grade convolutions on the bf16 pipe)")
     ap.add_argument("--checkpoint", action="store_true", help="checkpoint_encoders=True")
+    ap.add_argument("--checkpoint-levels", type=int, default=0, help="checkpoint_encoders=k: only the k highest-resolution encoder levels")
     ap.add_argument("--no-events", action="store_true", help="bare timing only (for runs under rocprofv3)")
     ap.add_argument("--act-bf16", action="store_true", help="activation_dtype='bf16' (with --bf16: activations and gradients stored as bf16)")
     ap.add_argument("--graph", action="store_true", help="hip_graph=True")
@@ -46,7 +47,7 @@ def main():
     torch.manual_seed(0)
     model = get_model(dict(name=args.name, in_channels=args.in_channels, out_channels=args.out_channels, f_maps=args.f_maps,
                            num_levels=args.levels, layer_order="gcr", num_groups=8, final_sigmoid=True,
-                           compute_dtype="bf16" if args.bf16 else ("fp32_split" if args.split else "fp32"), checkpoint_encoders=args.checkpoint,
+                           compute_dtype="bf16" if args.bf16 else ("fp32_split" if args.split else "fp32"), checkpoint_encoders=(args.checkpoint_levels if args.checkpoint_levels > 0 else args.checkpoint),
                            activation_dtype="bf16" if args.act_bf16 else "fp32", hip_graph=args.graph)).to(dev)
     assert model.native_supported, model._native_blockers
     D, H, W = (int(v) for v in args.patch.split(","))
@@ -77,7 +78,7 @@ def main():
     dt_bare = (time.perf_counter() - t0) / args.steps
     peak = torch.cuda.max_memory_allocated()
     if args.no_events:
-        print(json.dumps({"model": args.name, "activation_dtype": "bf16" if args.act_bf16 else "fp32", "checkpoint_encoders": args.checkpoint,
+        print(json.dumps({"model": args.name, "activation_dtype": "bf16" if args.act_bf16 else "fp32", "checkpoint_encoders": (args.checkpoint_levels if args.checkpoint_levels > 0 else args.checkpoint),
                           "ms_per_step_bare": round(dt_bare * 1e3, 2), "peak_mem_gb": round(peak / 2**30, 3)}))
         return
     prof = nat.EventProfiler()
@@ -101,7 +102,7 @@ def main():
             # most bandwidth-hungry level)
             fams[k]["frac_of_bf16_mfma_peak"] = round(tf / PEAK[k], 3)
             fams[k]["hbm_gbps_algorithmic_level0"] = round(tf * 1e12 * 8.0 / (54.0 * args.f_maps) / 1e9, 1)
-    print(json.dumps({"model": args.name, "compute": "bf16" if args.bf16 else ("fp32_split" if args.split else "fp32"), "checkpoint_encoders": args.checkpoint, "activation_dtype": "bf16" if args.act_bf16 else "fp32",
+    print(json.dumps({"model": args.name, "compute": "bf16" if args.bf16 else ("fp32_split" if args.split else "fp32"), "checkpoint_encoders": (args.checkpoint_levels if args.checkpoint_levels > 0 else args.checkpoint), "activation_dtype": "bf16" if args.act_bf16 else "fp32",
                       "ms_per_step_bare": round(dt_bare * 1e3, 2), "patches_per_s_bare": round(args.batch / dt_bare, 3), "f_maps": args.f_maps, "levels": args.levels, "patch": [D, H, W], "batch": args.batch,
                       "mode": "fwd" if args.forward_only else "fwd+bwd", "ms_per_step": round(dt * 1e3, 2),
                       "patches_per_s": round(args.batch / dt, 3), "peak_mem_gb": round(peak / 2**30, 3),
