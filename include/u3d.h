@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define U3D_VERSION 120 /* 120: flat 5 x 10 x 10 tile of the bf16-storage convolutions (u3d_conv3d_bf16_tile_variant planes = 5), 24 tuning keys; 119: round 5 — ragged volumes on the persistent kernels, u3d_conv3d_variant / u3d_conv3d_wgrad_variant; 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K); 118: u3d_se_*_b16 */
+#define U3D_VERSION 121 /* 121: u3d_convtr3d_fwd_t8_b16_ex; 120: flat 5 x 10 x 10 tile of the bf16-storage convolutions (u3d_conv3d_bf16_tile_variant planes = 5), 24 tuning keys; 119: round 5 — ragged volumes on the persistent kernels, u3d_conv3d_variant / u3d_conv3d_wgrad_variant; 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K); 118: u3d_se_*_b16 */
 
 #define U3D_OK 0
 #define U3D_EINVAL (-1)  /* bad shape / argument */
@@ -582,6 +582,13 @@ int u3d_convtr3d_fwd_t8_b16(int device, u3d_stream_t stream, const void* x, cons
                             int W1, int Cl, int Cs);
 int u3d_convtr3d_dgrad_t8_b16(int device, u3d_stream_t stream, const void* dt8, const void* packed, const void* x_mask, void* dx,
                               int N, int D1, int H1, int W1, int Cl, int Cs);
+/* Forward with scratch (round 5): on small low-res grids with many channels (config 4's 1024 -> 512 level on 5 x 10 x 10) the flat
+ * 5 x 10 x 10 tile of the bf16-storage convolutions runs the 2x2x2 kernel with a split channel reduction — one tile instead of eight
+ * 3/4-padded ones.  u3d_convtr3d_fwd_t8_workspace_floats() = 0 where the plan of u3d_convtr3d_fwd_t8_b16 stays; NULL / too small = that plan.
+ * Same contract (buildingblocks.py:617-664: ConvTranspose3d k3 s2 p1 before the resize + join). */
+long long u3d_convtr3d_fwd_t8_workspace_floats(int N, int D1, int H1, int W1, int Cl, int Cs);
+int u3d_convtr3d_fwd_t8_b16_ex(int device, u3d_stream_t stream, const void* x, const void* packed, void* t8, int N, int D1, int H1,
+                               int W1, int Cl, int Cs, float* workspace, long long workspace_floats);
 /* Split-K forms of the two data-gradient entry points above (the contraction runs over 8*Cs channels: hundreds of serial 16-channel
  * chunks on few blocks at the bottom of the U).  `workspace`: u3d_convtr3d_dgrad_t8_workspace_floats() fp32 elements, or NULL / too small
  * = unsplit.  Partial sums are added in a fixed order by the reduction kernel of u3d_conv3d_bf16_ex, which applies the ReLU mask. */

@@ -991,8 +991,11 @@ static int bf16_ksplit(int N, int D, int H, int W, int C, int K) {
 // 64-channel blocks.  Chosen where it executes at most 3/4 of the padded GEMM rows of the 4 x 8 x 8 tiling (config 4: 512 instead of 2048
 // rows at 5 x 10 x 10, 4096 instead of 6912 at 10 x 20 x 20); its split count aims at one block per CU (the kernel's occupancy) with at least two chunks per block.
 // Returns the split count, 0 = not used.  u3d_set_tuning key 16: 1 = never, >= 2 = that split count (A/B).
-static int bf16_flat_ksplit(int N, int D, int H, int W, int C, int K) {
-    if (g_u3d_tune[16] == 1 || K % 64 != 0 || bf16_ksplit(N, D, H, W, C, K) < 2) return 0;
+// (need_split: the 3x3x3 convolutions and the transposed convolution's data gradient take it only where the 4 x 8 x 8 plan already splits its
+// channel reduction; the transposed convolution's FORWARD — 8 Cs output columns, never split before — takes it wherever one block per CU needs
+// at least two splits, i.e. on grids of at most 128 (tile, channel block) items)
+static int bf16_flat_ksplit(int N, int D, int H, int W, int C, int K, bool need_split = true) {
+    if (g_u3d_tune[16] == 1 || K % 64 != 0 || (need_split && bf16_ksplit(N, D, H, W, C, K) < 2)) return 0;
     const long long tiles4 = (long long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 7) / 8);
     const long long tilesf = (long long)N * ((D + 4) / 5) * ((H + 9) / 10) * ((W + 9) / 10);
     if (tilesf * 512 * 4 > tiles4 * 256 * 3) return 0;
@@ -2260,7 +2263,7 @@ extern "C" int u3d_pack_convtr3d_t8(int device, u3d_stream_t stream, const float
 }
 
 static int convtr3d_fwd_t8_impl(int device, u3d_stream_t stream, const float* x, const void* packed, float* t8, int N, int D1, int H1,
-                                int W1, int Cl, int Cs, int b16) {
+                                int W1, int Cl, int Cs, int b16, float* workspace = nullptr, long long workspace_floats = 0) {
     U3D_ENTER(device);
     U3D_REQUIRE(x && packed && t8 && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && u3d_convtr3d_t8_supported(Cl, Cs), "u3d_convtr3d_fwd_t8: bad argument");
     bf16_conv_params p{x, nullptr, reinterpret_cast<const bf16x8*>(packed), t8, nullptr, nullptr, nullptr, nullptr,
@@ -2268,7 +2271,26 @@ static int convtr3d_fwd_t8_impl(int device, u3d_stream_t stream, const float* x,
     p.b16 = b16;
     p.t8mode = g_u3d_tune[10] == 2 ? 0 : 1;  // (key 10 = 2: A/B without the zero-block skipping)
     p.t8cs = Cs;
+    const int kf = b16 ? bf16_flat_ksplit(N, D1, H1, W1, Cl, 8 * Cs, false) : 0;
+    if (kf > 1 && workspace && workspace_floats >= (long long)kf * N * D1 * H1 * W1 * 8 * Cs) {  // the flat 5 x 10 x 10 tile (see u3d_conv3d_bf16_ex_b16)
+        p.ksplit = kf;
+        p.ws = workspace;
+        return launch_bf16<2, 3, 2, 0, __bf16>(p, (hipStream_t)stream);
+    }
     return launch_t8_conv(p, (hipStream_t)stream);
+}
+
+// bf16 storage at the bottom of the U (config 4: 1024 -> 512 channels on 5 x 10 x 10): the flat tile with a split channel reduction needs
+// scratch; 0 floats where the plain entry point's plan stays
+extern "C" long long u3d_convtr3d_fwd_t8_workspace_floats(int N, int D1, int H1, int W1, int Cl, int Cs) {
+    if (!u3d_convtr3d_t8_supported(Cl, Cs) || N <= 0 || D1 <= 0 || H1 <= 0 || W1 <= 0) return 0;
+    const int kf = bf16_flat_ksplit(N, D1, H1, W1, Cl, 8 * Cs, false);
+    return kf > 1 ? (long long)kf * N * D1 * H1 * W1 * 8 * Cs : 0;
+}
+
+extern "C" int u3d_convtr3d_fwd_t8_b16_ex(int device, u3d_stream_t stream, const void* x, const void* packed, void* t8, int N, int D1,
+                                          int H1, int W1, int Cl, int Cs, float* workspace, long long workspace_floats) {
+    return convtr3d_fwd_t8_impl(device, stream, (const float*)x, packed, (float*)t8, N, D1, H1, W1, Cl, Cs, 1, workspace, workspace_floats);
 }
 
 extern "C" int u3d_convtr3d_fwd_t8(int device, u3d_stream_t stream, const float* x, const void* packed, float* t8, int N, int D1,

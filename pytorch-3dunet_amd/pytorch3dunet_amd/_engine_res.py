@@ -253,8 +253,14 @@ class ResUNetEngine(UNet3DEngine):
                 # the resize + join reads that layout directly
                 sfx = "_b16" if self.act_bf16 else ""
                 t = _empty((Nl, D1, H1, W1, 8 * Cs), dtype=self.adt, device=dev)
-                nat.call("u3d_convtr3d_fwd_t8" + sfx, dev.index, _stream(dev), _p(cur), _p(self._packed_convtr_t8(ct.weight, 0, dev)),
-                         _p(t), Nl, D1, H1, W1, Cl, Cs, flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
+                need = nat.get_lib().u3d_convtr3d_fwd_t8_workspace_floats(Nl, D1, H1, W1, Cl, Cs) if self.act_bf16 else 0
+                if need > 0:  # small grid, many channels: the flat tile with a split channel reduction (csrc/u3d_bf16.hip)
+                    kws = _empty(need, dtype=_F32, device=dev)
+                    nat.call("u3d_convtr3d_fwd_t8_b16_ex", dev.index, _stream(dev), _p(cur), _p(self._packed_convtr_t8(ct.weight, 0, dev)),
+                             _p(t), Nl, D1, H1, W1, Cl, Cs, _p(kws), need, flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
+                else:
+                    nat.call("u3d_convtr3d_fwd_t8" + sfx, dev.index, _stream(dev), _p(cur), _p(self._packed_convtr_t8(ct.weight, 0, dev)),
+                             _p(t), Nl, D1, H1, W1, Cl, Cs, flops=2.0 * 27 * Cl * Cs * Nl * D1 * H1 * W1)
                 nat.call("u3d_nearest_add_fwd_t8" + sfx, dev.index, _stream(dev), _p(sk), _p(t), _p(mz), _p(my), _p(mx), Nl, Ds, Hs,
                          Ws, Dt, Ht, Wt, Cs, _p(joined), _p(j_st))
                 del t

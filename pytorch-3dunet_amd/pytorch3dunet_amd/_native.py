@@ -303,6 +303,9 @@ _PROTOS = {
     "u3d_convtr3d_fwd_t8": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
     "u3d_convtr3d_dgrad_t8": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
     "u3d_convtr3d_dgrad_t8_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "u3d_convtr3d_fwd_t8_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "u3d_convtr3d_fwd_t8_b16_ex": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                           c_void_p, c_int64]),
     "u3d_convtr3d_dgrad_t8_ex": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                          c_void_p, c_int64]),
     "u3d_convtr3d_dgrad_t8_b16_ex": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -283,6 +283,39 @@ def test_transposed_convolution_data_gradient_on_the_flat_tile(dims, Cl, Cs):
     assert bool((auto.float()[x.float() <= 0] == 0).all())
 
 
+def test_transposed_convolution_forward_on_the_flat_tile():
+    """u3d_convtr3d_fwd_t8_b16_ex: on a small low-res grid with many channels (config 4's bottom level) the forward runs the flat
+    5 x 10 x 10 tile with a split channel reduction (scratch from u3d_convtr3d_fwd_t8_workspace_floats); against the plain entry point
+    (4 x 8 x 8 tiles, unsplit): the same products summed in another grouping — fp32 round-off before the bf16 rounding — and against the
+    fp32 reference of the transposed convolution in space-to-depth form."""
+    N, D1, H1, W1, Cl, Cs = 1, 5, 10, 10, 128, 64
+    torch.manual_seed(8)
+    L = nat.get_lib()
+    x = dev(r16(torch.relu(torch.randn(N, D1, H1, W1, Cl)))).to(BF)
+    w = dev(torch.randn(Cl, Cs, 3, 3, 3) / (27 * Cl / 8) ** 0.5)
+    pk = torch.empty(L.u3d_convtr3d_t8_packed_elems(Cl, Cs, 0), dtype=BF, device=U.DEV)
+    call("u3d_pack_convtr3d_t8", _p(w), Cl, Cs, 0, _p(pk))
+    need = L.u3d_convtr3d_fwd_t8_workspace_floats(N, D1, H1, W1, Cl, Cs)
+    assert need > 0 and need % (N * D1 * H1 * W1 * 8 * Cs) == 0
+    assert L.u3d_convtr3d_fwd_t8_workspace_floats(1, 20, 40, 40, 256, 128) == 0  # (config 4's upper levels keep the plain plan)
+    ws = torch.empty(need, device=U.DEV)
+    plain = torch.full((N, D1, H1, W1, 8 * Cs), float("nan"), dtype=BF, device=U.DEV)
+    flat = torch.full_like(plain, float("nan"))
+    call("u3d_convtr3d_fwd_t8_b16", _p(x), _p(pk), _p(plain), N, D1, H1, W1, Cl, Cs)
+    call("u3d_convtr3d_fwd_t8_b16_ex", _p(x), _p(pk), _p(flat), N, D1, H1, W1, Cl, Cs, _p(ws), need)
+    nows = torch.full_like(plain, float("nan"))
+    call("u3d_convtr3d_fwd_t8_b16_ex", _p(x), _p(pk), _p(nows), N, D1, H1, W1, Cl, Cs, None, 0)  # no scratch: the plain plan
+    torch.cuda.synchronize()
+    assert same_bits(nows, plain)
+    assert not torch.isnan(flat.float()).any() and torch.allclose(flat.float(), plain.float(), rtol=1e-2, atol=1e-3)
+    # reference: ConvTranspose3d(k3, s2, p1) on the bf16-rounded operands, T8[i][parity*Cs + c] = t[2i + parity]; output_padding = 1 supplies
+    # the 2n-th plane / row / column the space-to-depth form computes as well (the join never reads it)
+    full = F.conv_transpose3d(U.ncdhw(x.float()), r16(w.cpu()), stride=2, padding=1, output_padding=1)
+    ref = full.view(N, Cs, D1, 2, H1, 2, W1, 2).permute(0, 2, 4, 6, 3, 5, 7, 1).reshape(N, D1, H1, W1, 8 * Cs)
+    err = (flat.float().cpu() - ref).norm() / ref.norm()
+    assert err < 1e-2, err
+
+
 def test_bandwidth_kernels_b16():
     torch.manual_seed(4)
     N, D, H, W, C = 2, 6, 9, 10, 64

@@ -61,7 +61,9 @@ def main():
         nsd = 0 if os.environ.get("U3D_T8_NOSPLIT") else lib.u3d_convtr3d_dgrad_t8_workspace_floats(N, D1, H1, W1, Cl, Cs)  # (A/B: unsplit)
         wsd = torch.empty(max(nsd, 4), device=dev)
         flops = 2.0 * 27 * Cl * Cs * N * D1 * H1 * W1
-        ms = (timeit(lambda: nat.call("u3d_convtr3d_fwd_t8_b16", 0, S, _p(x), _p(pk[0]), _p(t8), N, D1, H1, W1, Cl, Cs), args.iters),
+        nsf = lib.u3d_convtr3d_fwd_t8_workspace_floats(N, D1, H1, W1, Cl, Cs)  # (> 0: the flat tile with a split reduction, as the engine calls it)
+        wsf = torch.empty(max(nsf, 4), device=dev)
+        ms = (timeit(lambda: nat.call("u3d_convtr3d_fwd_t8_b16_ex", 0, S, _p(x), _p(pk[0]), _p(t8), N, D1, H1, W1, Cl, Cs, _p(wsf), nsf), args.iters),
               timeit(lambda: nat.call("u3d_convtr3d_dgrad_t8_b16_ex", 0, S, _p(dt8), _p(pk[1]), _p(x), _p(dx), N, D1, H1, W1, Cl, Cs, _p(wsd), nsd),
                      args.iters),
               timeit(lambda: nat.call("u3d_convtr3d_wgrad_t8_b16", 0, S, _p(x), _p(dt8), _p(dw), N, D1, H1, W1, Cl, Cs, _p(ws), need), args.iters))
