@@ -61,6 +61,8 @@ def test_host_only_entry_points():
     need = [lib.u3d_convtr3d_dgrad_t8_workspace_floats(1, *a) for a in t8]
     # (round 5: the bottom level's bf16-storage launch takes the flat 5 x 10 x 10 tile with 16 splits — the scratch has room for either plan)
     assert need[0] == 16 * 500 * 1024 and need[1] == 5 * 4000 * 512 and need[2] == 0 and need[3] == 0, need
+    # ... and its forward only at the bottom level (flat tile with 4 splits; elsewhere one block per CU needs no split: the plain plan)
+    assert [lib.u3d_convtr3d_fwd_t8_workspace_floats(1, *a) for a in t8] == [4 * 500 * 8 * 512, 0, 0, 0]
     v = [lib.u3d_conv3d_bf16_tile_variant(1, *sh, c, c, 1) for sh, c in lv]
     assert [(x >> 8) & 255 for x in v] == [8, 8, 4, 5, 5] and [x >> 16 for x in v] == [1, 1, 1, 4, 16], v
 
