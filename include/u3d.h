@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define U3D_VERSION 121 /* 121: u3d_convtr3d_fwd_t8_b16_ex; 120: flat 5 x 10 x 10 tile of the bf16-storage convolutions (u3d_conv3d_bf16_tile_variant planes = 5), 24 tuning keys; 119: round 5 — ragged volumes on the persistent kernels, u3d_conv3d_variant / u3d_conv3d_wgrad_variant; 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K); 118: u3d_se_*_b16 */
+#define U3D_VERSION 122 /* 122: round 6 — u3d_gn_finalize_split / u3d_gn_bwd_finalize_split (compact half tables of a virtual-concat layer), statistics fused into u3d_maxpool2_fwd, tuning key 18; 121: u3d_convtr3d_fwd_t8_b16_ex; 120: flat 5 x 10 x 10 tile of the bf16-storage convolutions (u3d_conv3d_bf16_tile_variant planes = 5), 24 tuning keys; 119: round 5 — ragged volumes on the persistent kernels, u3d_conv3d_variant / u3d_conv3d_wgrad_variant; 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K); 118: u3d_se_*_b16 */
 
 #define U3D_OK 0
 #define U3D_EINVAL (-1)  /* bad shape / argument */
@@ -287,6 +287,23 @@ int u3d_gn_finalize(int device, u3d_stream_t stream, const double* stats0, int C
 int u3d_gn_bwd_finalize(int device, u3d_stream_t stream, const double* gstats, const float* mean_rstd,
                         const float* gamma, int N, int C, int G, double count, float* dgamma, float* dbeta,
                         float* coef);
+/* The same two reductions for the first convolution of a decoder, whose input is the virtual concat cat(skip [0,C0), upsampled [C0,C0+C1))
+ * (buildingblocks.py:491) and whose halves are read by DIFFERENT kernels as plain tensors (sub-pixel path, csrc/u3d_subpix.hip):
+ *   u3d_gn_finalize_split      additionally writes compact tables affine_lo[N][Csplit][2] / affine_hi[N][C-Csplit][2] (either may be
+ *                              NULL) — the rows of `affine` for the channels below / from Csplit (the skip / upsampled half; Csplit is
+ *                              independent of how the statistics arrive) — instead of a strided-copy launch per half and direction;
+ *   u3d_gn_bwd_finalize_split  takes the GroupNorm-backward sums as TWO tables gstats_lo[N][C0][2] / gstats_hi[N][C1][2] (the skip-half
+ *                              and low-res data-gradient kernels each write their own) and additionally writes coef_hi[N][3][C1] =
+ *                              (p, hi_scale*q, hi_scale*r) of the upper channels (NULL: none; hi_scale = 8: a low-res voxel of an exact
+ *                              2x nearest upsampling stands for 8 children).  Needs N*C small enough for the kernel's LDS-staged path
+ *                              (u3d_gn_bwd_finalize_split_supported == 1: every shipped configuration); identical arithmetic. */
+int u3d_gn_finalize_split(int device, u3d_stream_t stream, const double* stats0, int C0, double scale0, const double* stats1, int C1,
+                          double scale1, int N, int G, double count, const float* gamma, const float* beta, float eps, float* affine,
+                          float* mean_rstd, int Csplit, float* affine_lo, float* affine_hi);
+int u3d_gn_bwd_finalize_split_supported(int N, int C, int G);
+int u3d_gn_bwd_finalize_split(int device, u3d_stream_t stream, const double* gstats_lo, int C0, const double* gstats_hi, int C1,
+                              const float* mean_rstd, const float* gamma, int N, int G, double count, float* dgamma, float* dbeta,
+                              float* coef, float hi_scale, float* coef_hi);
 
 /* GroupNorm backward, elementwise part (+ fused ReLU backward of the producer, buildingblocks.py:47):
  *   out[n,v,c] = (p*dg[n,v,coff+c] + q*x[n,v,c] + r) * (relu_mask ? x>0 : 1),   c in [0,Cx)

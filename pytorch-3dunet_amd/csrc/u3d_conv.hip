@@ -39,6 +39,8 @@
 //   [15] 1 = sub-pixel weight gradient with per-element coordinate arithmetic for its B loads (A/B of the constant-offset path)
 //   [16] bf16-storage 3x3x3 convolution, flat 5 x 10 x 10 tile of the small wide levels: 1 = never, >= 2 = force that split count
 //   [17] 1 = bf16-storage weight gradient with ONE split still goes through the workspace + reduction kernel (A/B of the direct dw write)
+//   [18] 1 = u3d_maxpool2_fwd computes its output statistics in a second pass (u3d_chan_stats) and the one-channel input statistics run
+//        on the general kernel — the round-5 forms (A/B of the fused / 16-byte kernels, csrc/u3d_ops.hip)
 int g_u3d_tune[24] = {0};
 
 namespace cv {

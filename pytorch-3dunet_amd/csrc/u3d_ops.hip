@@ -6,6 +6,8 @@
 
 #include <string.h>
 
+extern int g_u3d_tune[24];  // u3d_set_tuning (csrc/u3d_conv.hip); key 18 = 1: max-pool / input statistics in their two-pass round-5 form (A/B)
+
 // ---- library plumbing ----------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
@@ -151,11 +153,59 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const u3d_src_t src, in
     }
 }
 
+// ONE channel (the network's input patch, model.py:123): 16-byte loads, wave butterflies, one f64 atomic pair per block.  (The general
+// kernel above reads 4 bytes per lane and folds its 256 rows with ONE thread: 23 us for the 8 MB input of the bench workload.)
+__global__ __launch_bounds__(256) void scalar_stats_kernel(const float* __restrict__ x, long long V, double* __restrict__ stats) {
+    __shared__ float red[2][4];
+    const int n = blockIdx.y, t = threadIdx.x;
+    const float* xn = x + (size_t)n * V;
+    const long long V4 = V >> 2;
+    float s1 = 0.f, s2 = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + t; i < V4; i += (long long)gridDim.x * 256) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(xn + 4 * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s1 += q[e];
+            s2 += q[e] * q[e];
+        }
+    }
+    if (blockIdx.x == 0 && t < (int)(V & 3)) {  // tail voxels
+        const float q = xn[4 * V4 + t];
+        s1 += q;
+        s2 += q * q;
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        s1 += __shfl_xor(s1, m);
+        s2 += __shfl_xor(s2, m);
+    }
+    if ((t & 63) == 0) {
+        red[0][t >> 6] = s1;
+        red[1][t >> 6] = s2;
+    }
+    __syncthreads();
+    if (t == 0) {
+        u3d_atomic_add_f64(&stats[(size_t)n * 2], (double)(((red[0][0] + red[0][1]) + red[0][2]) + red[0][3]));
+        u3d_atomic_add_f64(&stats[(size_t)n * 2 + 1], (double)(((red[1][0] + red[1][1]) + red[1][2]) + red[1][3]));
+    }
+}
+
 extern "C" int u3d_chan_stats(int device, u3d_stream_t stream, const u3d_src_t* src, int N, int D, int H, int W,
                               double* stats) {
     U3D_ENTER(device);
     U3D_REQUIRE(src && src->p0 && stats && N > 0 && D > 0 && H > 0 && W > 0, "u3d_chan_stats: bad argument");
     const int Ctot = src->C0 + src->C1;
+    if (Ctot == 1 && src->C1 == 0 && N <= 65535 && ((long long)D * H * W) % 4 == 0 && ((uintptr_t)src->p0 & 15) == 0 &&
+        g_u3d_tune[18] != 1) {
+        const long long V = (long long)D * H * W;
+        long long bpn = (V / 4 + 256 * 8 - 1) / (256 * 8);  // >= 8 loads per thread
+        const long long want = (512 + N - 1) / N;
+        if (bpn > want) bpn = want;
+        if (bpn < 1) bpn = 1;
+        hipLaunchKernelGGL(scalar_stats_kernel, dim3((unsigned)bpn, (unsigned)N), dim3(256), 0, (hipStream_t)stream, src->p0, V, stats);
+        U3D_LAUNCH_CHECK();
+        return 0;
+    }
     const int Q = (Ctot + 3) / 4;
     U3D_REQUIRE(Q <= 256, "u3d_chan_stats: at most 1024 channels supported");
     const int rows = 256 / Q;
@@ -182,7 +232,9 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
                                                           const double* __restrict__ st1, int C1, double sc1, int N, int G,
                                                           double count, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps,
-                                                          float* __restrict__ affine, float* __restrict__ mean_rstd) {
+                                                          float* __restrict__ affine, float* __restrict__ mean_rstd,
+                                                          float* __restrict__ affine_lo, float* __restrict__ affine_hi,
+                                                          int Cs) {
     extern __shared__ double sh[];  // [C][2] channel sums, then [G][2] mean / rstd
     const int C = C0 + C1, cpg = C / G, n = blockIdx.x, t = threadIdx.x;
     double* gmr = sh + 2 * (size_t)C;
@@ -219,25 +271,50 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
     for (int c = t; c < C; c += blockDim.x) {
         const int g = c / cpg;
         const double a = gmr[2 * g + 1] * (double)gamma[c];
-        affine[((size_t)n * C + c) * 2] = (float)a;
-        affine[((size_t)n * C + c) * 2 + 1] = (float)((double)beta[c] - gmr[2 * g] * a);
+        const float fa = (float)a, fb = (float)((double)beta[c] - gmr[2 * g] * a);
+        affine[((size_t)n * C + c) * 2] = fa;
+        affine[((size_t)n * C + c) * 2 + 1] = fb;
+        // (u3d_gn_finalize_split) compact copies of the rows of [0, Cs) / [Cs, C): what a kernel that reads ONE half of a virtual
+        // concat as a plain tensor takes as its table
+        if (affine_lo && c < Cs) {
+            affine_lo[((size_t)n * Cs + c) * 2] = fa;
+            affine_lo[((size_t)n * Cs + c) * 2 + 1] = fb;
+        }
+        if (affine_hi && c >= Cs) {
+            affine_hi[((size_t)n * (C - Cs) + (c - Cs)) * 2] = fa;
+            affine_hi[((size_t)n * (C - Cs) + (c - Cs)) * 2 + 1] = fb;
+        }
     }
+}
+
+static int gn_finalize_impl(int device, u3d_stream_t stream, const double* stats0, int C0, double scale0, const double* stats1, int C1,
+                            double scale1, int N, int G, double count, const float* gamma, const float* beta, float eps, float* affine,
+                            float* mean_rstd, float* affine_lo, float* affine_hi, int Csplit) {
+    U3D_ENTER(device);
+    const int C = C0 + C1;
+    U3D_REQUIRE(stats0 && C0 > 0 && C1 >= 0 && (C1 == 0 || stats1) && gamma && beta && affine && mean_rstd && N > 0 && G > 0 &&
+                    count > 0.0 && Csplit >= 0 && Csplit <= C, "u3d_gn_finalize: bad argument");
+    U3D_REQUIRE(C % G == 0, "u3d_gn_finalize: channels %d not divisible by groups %d", C, G);
+    U3D_REQUIRE(C <= 4096, "u3d_gn_finalize: more than 4096 channels");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), sizeof(double) * 2 * ((size_t)C + G), (hipStream_t)stream,
+                       stats0, C0, scale0, stats1, C1, scale1, N, G, count, gamma, beta, eps, affine, mean_rstd, affine_lo, affine_hi, Csplit);
+    U3D_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int u3d_gn_finalize(int device, u3d_stream_t stream, const double* stats0, int C0, double scale0,
                                const double* stats1, int C1, double scale1, int N, int G, double count,
                                const float* gamma, const float* beta, float eps, float* affine, float* mean_rstd) {
-    U3D_ENTER(device);
-    U3D_REQUIRE(stats0 && C0 > 0 && C1 >= 0 && (C1 == 0 || stats1) && N > 0 && G > 0 && gamma && beta && affine &&
-                    mean_rstd && count > 0,
-                "u3d_gn_finalize: bad argument");
-    U3D_REQUIRE((C0 + C1) % G == 0, "u3d_gn_finalize: channels %d not divisible by groups %d", C0 + C1, G);
-    const int C = C0 + C1;
-    U3D_REQUIRE(C <= 4096, "u3d_gn_finalize: more than 4096 channels");
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), sizeof(double) * 2 * ((size_t)C + G), (hipStream_t)stream,
-                       stats0, C0, scale0, stats1, C1, scale1, N, G, count, gamma, beta, eps, affine, mean_rstd);
-    U3D_LAUNCH_CHECK();
-    return 0;
+    return gn_finalize_impl(device, stream, stats0, C0, scale0, stats1, C1, scale1, N, G, count, gamma, beta, eps, affine, mean_rstd,
+                            nullptr, nullptr, 0);
+}
+
+extern "C" int u3d_gn_finalize_split(int device, u3d_stream_t stream, const double* stats0, int C0, double scale0,
+                                     const double* stats1, int C1, double scale1, int N, int G, double count,
+                                     const float* gamma, const float* beta, float eps, float* affine, float* mean_rstd,
+                                     int Csplit, float* affine_lo, float* affine_hi) {
+    return gn_finalize_impl(device, stream, stats0, C0, scale0, stats1, C1, scale1, N, G, count, gamma, beta, eps, affine, mean_rstd,
+                            affine_lo, affine_hi, Csplit);
 }
 
 // GroupNorm backward reductions -> dgamma, dbeta, coefficient table coef[N][3][C] (p,q,r).
@@ -248,12 +325,24 @@ extern "C" int u3d_gn_finalize(int device, u3d_stream_t stream, const double* st
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __restrict__ gs, const float* __restrict__ mean_rstd,
                                                               const float* __restrict__ gamma, int N, int C, int G,
                                                               double count, int staged, int par, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, float* __restrict__ coef) {
+                                                              float* __restrict__ dbeta, float* __restrict__ coef,
+                                                              const double* __restrict__ gs_hi, int C0, float hi_scale,
+                                                              float* __restrict__ coef_hi) {
 #pragma clang fp contract(off)  // (both paths: products rounded, then added in channel order — identical results)
     extern __shared__ double shb[];
     const double* src = gs;
     if (staged) {
-        for (int i = threadIdx.x; i < N * C * 2; i += blockDim.x) shb[i] = gs[i];
+        if (gs_hi) {
+            // (u3d_gn_bwd_finalize_split: the sums of channels [0, C0) and [C0, C) arrive as two tables [N][C0][2] / [N][C - C0][2] —
+            // the skip-half and low-res data-gradient kernels of a sub-pixel decoder level each write their own)
+            const int C1 = C - C0;
+            for (int i = threadIdx.x; i < N * C * 2; i += blockDim.x) {
+                const int e = i & 1, nc = i >> 1, n = nc / C, c = nc - n * C;
+                shb[i] = c < C0 ? gs[((size_t)n * C0 + c) * 2 + e] : gs_hi[((size_t)n * C1 + (c - C0)) * 2 + e];
+            }
+        } else {
+            for (int i = threadIdx.x; i < N * C * 2; i += blockDim.x) shb[i] = gs[i];
+        }
         __syncthreads();
         src = shb;
     }
@@ -305,9 +394,17 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __re
         for (int i = threadIdx.x; i < N * C; i += blockDim.x) {
             const int n = i / C, c = i - n * C, pair = n * G + c / cpg;
             const double rstd = (double)mean_rstd[(size_t)pair * 2 + 1];
-            coef[((size_t)n * 3 + 0) * C + c] = (float)(rstd * (double)gamma[c]);
-            coef[((size_t)n * 3 + 1) * C + c] = (float)qr[(size_t)pair * 2];
-            coef[((size_t)n * 3 + 2) * C + c] = (float)qr[(size_t)pair * 2 + 1];
+            const float fp = (float)(rstd * (double)gamma[c]), fq = (float)qr[(size_t)pair * 2], fr = (float)qr[(size_t)pair * 2 + 1];
+            coef[((size_t)n * 3 + 0) * C + c] = fp;
+            coef[((size_t)n * 3 + 1) * C + c] = fq;
+            coef[((size_t)n * 3 + 2) * C + c] = fr;
+            if (coef_hi && c >= C0) {
+                // compact table of the upper channels with (q, r) scaled: a low-res voxel of an exact 2x upsampling stands for 8 children
+                const int C1 = C - C0;
+                coef_hi[((size_t)n * 3 + 0) * C1 + (c - C0)] = fp;
+                coef_hi[((size_t)n * 3 + 1) * C1 + (c - C0)] = fq * hi_scale;
+                coef_hi[((size_t)n * 3 + 2) * C1 + (c - C0)] = fr * hi_scale;
+            }
         }
     }
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -335,7 +432,29 @@ extern "C" int u3d_gn_bwd_finalize(int device, u3d_stream_t stream, const double
     const size_t par_bytes = 2 * bytes + sizeof(double) * 2 * (size_t)N * G;
     const int par = staged && par_bytes <= 64 * 1024 ? 1 : 0;
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(256), par ? par_bytes : (staged ? bytes : 0), (hipStream_t)stream, gstats,
-                       mean_rstd, gamma, N, C, G, count, staged, par, dgamma, dbeta, coef);
+                       mean_rstd, gamma, N, C, G, count, staged, par, dgamma, dbeta, coef, (const double*)nullptr, C, 1.0f, (float*)nullptr);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int u3d_gn_bwd_finalize_split_supported(int N, int C, int G) {
+    // the two-table form lives in the LDS-staged path of the kernel (every shipped configuration: N * C <= 2048)
+    const size_t bytes = sizeof(double) * 2 * (size_t)N * C;
+    return (N > 0 && C > 0 && G > 0 && 2 * bytes + sizeof(double) * 2 * (size_t)N * G <= 64 * 1024) ? 1 : 0;
+}
+
+extern "C" int u3d_gn_bwd_finalize_split(int device, u3d_stream_t stream, const double* gstats_lo, int C0, const double* gstats_hi,
+                                         int C1, const float* mean_rstd, const float* gamma, int N, int G, double count,
+                                         float* dgamma, float* dbeta, float* coef, float hi_scale, float* coef_hi) {
+    U3D_ENTER(device);
+    const int C = C0 + C1;
+    U3D_REQUIRE(gstats_lo && gstats_hi && mean_rstd && gamma && dgamma && dbeta && coef && N > 0 && C0 > 0 && C1 > 0 && G > 0 &&
+                    C % G == 0, "u3d_gn_bwd_finalize_split: bad argument");
+    U3D_REQUIRE(u3d_gn_bwd_finalize_split_supported(N, C, G) == 1, "u3d_gn_bwd_finalize_split: N * C = %d exceeds the staged path", N * C);
+    const size_t bytes = sizeof(double) * 2 * (size_t)N * C;
+    const size_t par_bytes = 2 * bytes + sizeof(double) * 2 * (size_t)N * G;
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(256), par_bytes, (hipStream_t)stream, gstats_lo, mean_rstd, gamma, N, C, G,
+                       count, 1, 1, dgamma, dbeta, coef, gstats_hi, C0, hi_scale, coef_hi);
     U3D_LAUNCH_CHECK();
     return 0;
 }
@@ -748,11 +867,75 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_vec_kernel(const T* __restri
     }
 }
 
+// The same pooling with the per-(n, channel) sums of its OUTPUT (the next GroupNorm's statistics) accumulated on the way (round 6:
+// the separate u3d_chan_stats pass re-read the pooled tensor at 1.5 TB/s behind a serial LDS fold — 23 + 11 + 8 us per bench step).
+// grid (blocks per sample, N); 256 % C == 0, so a thread keeps ONE channel over all its elements (block stride = a multiple of C):
+// fp32 running sums per thread, folded per channel through LDS in a fixed order, one f64 atomic pair per (block, channel).
+__global__ __launch_bounds__(256) void maxpool2_fwd_stats_kernel(const float* __restrict__ x, int D, int H, int W, int C,
+                                                                 float* __restrict__ out, uint8_t* __restrict__ argmax,
+                                                                 double* __restrict__ stats) {
+    __shared__ float red[2][256];
+    const int D2 = D >> 1, H2 = H >> 1, W2 = W >> 1;
+    const int n = blockIdx.y, t = threadIdx.x;
+    const long long per_n = (long long)D2 * H2 * W2 * C;
+    const int c = t % C;  // (blockIdx.x * 256 + t + k * gridDim.x * 256) % C for every k
+    float s1 = 0.f, s2 = 0.f;
+    for (long long idx = (long long)blockIdx.x * 256 + t; idx < per_n; idx += (long long)gridDim.x * 256) {
+        long long v = idx / C;
+        const int xo = (int)(v % W2);
+        v /= W2;
+        const int yo = (int)(v % H2);
+        const int zo = (int)(v / H2);
+        float best = -INFINITY;
+        int bi = 0;
+        float val[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int z = 2 * zo + (k >> 2), y = 2 * yo + ((k >> 1) & 1), xx = 2 * xo + (k & 1);
+            val[k] = x[((size_t)((n * D + z) * H + y) * W + xx) * C + c];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (val[k] > best || val[k] != val[k]) {  // first max in scan order; NaN propagates (ATen max_pool3d)
+                best = val[k];
+                bi = k;
+            }
+        }
+        out[(size_t)n * per_n + idx] = best;
+        argmax[(size_t)n * per_n + idx] = (uint8_t)bi;
+        s1 += best;
+        s2 += best * best;
+    }
+    red[0][t] = s1;
+    red[1][t] = s2;
+    __syncthreads();
+    if (t < C) {
+        float a = 0.f, b = 0.f;
+        for (int r = t; r < 256; r += C) {  // fixed order
+            a += red[0][r];
+            b += red[1][r];
+        }
+        u3d_atomic_add_f64(&stats[((size_t)n * C + t) * 2], (double)a);
+        u3d_atomic_add_f64(&stats[((size_t)n * C + t) * 2 + 1], (double)b);
+    }
+}
+
 extern "C" int u3d_maxpool2_fwd(int device, u3d_stream_t stream, const float* x, int N, int D, int H, int W, int C,
                                 float* out, uint8_t* argmax, double* out_stats) {
     U3D_ENTER(device);
     U3D_REQUIRE(x && out && argmax && N > 0 && D >= 2 && H >= 2 && W >= 2 && C > 0, "u3d_maxpool2_fwd: bad argument");
     const long long total = (long long)N * (D / 2) * (H / 2) * (W / 2) * C;
+    if (out_stats && 256 % C == 0 && N <= 65535 && g_u3d_tune[18] != 1) {  // (key 18 = 1: the two-pass form, A/B)
+        const long long per_n = total / N;
+        long long bpn = (per_n + 256 * 8 - 1) / (256 * 8);  // >= 8 elements per thread, ~1024 blocks in total
+        const long long want = (1024 + N - 1) / N;
+        if (bpn > want) bpn = want;
+        if (bpn < 1) bpn = 1;
+        hipLaunchKernelGGL(maxpool2_fwd_stats_kernel, dim3((unsigned)bpn, (unsigned)N), dim3(256), 0, (hipStream_t)stream, x, D, H, W, C,
+                           out, argmax, out_stats);
+        U3D_LAUNCH_CHECK();
+        return 0;
+    }
     // (the 16-byte variant below is for bf16 storage: with fp32 tensors it measured 0.131 against this kernel's 0.116 ms per step on config 2)
     hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, x, N, D,
                        H, W, C, out, argmax);

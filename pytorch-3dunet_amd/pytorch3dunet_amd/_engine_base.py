@@ -48,6 +48,7 @@ __all__ = [
     "_Ref",
     "_SIDE_STREAMS",
     "_StatPool",
+    "_side_stream",
     "_empty",
     "_empty_like",
     "_maps",
@@ -417,6 +418,10 @@ class ConvRec:
     norm: Optional[str] = "g"    # 'g' GroupNorm, 'b' BatchNorm3d (mean_rstd is (C,2)), None: conv bias (idx_gb = its index)
     bn_training: bool = True     # BatchNorm normalised with batch statistics (else: running statistics, constants in backward)
     drop: Optional[tuple] = None  # trailing dropout: ('d', mask NDHWC) or ('D', (N,C,2) table (mask, 0))
+    # sub-pixel decoder layers: compact (N,C0,2) / (N,C1,2) copies of `affine`'s rows for the skip / upsampled half, written by the
+    # GroupNorm finalize itself (u3d_gn_finalize_split) — the kernels that read ONE half as a plain tensor take these
+    affine_lo: Optional[torch.Tensor] = None
+    affine_hi: Optional[torch.Tensor] = None
 
 
 @dataclass
@@ -454,6 +459,15 @@ class _StatPool:
 _SIDE_STREAMS: dict = {}
 
 
+def _side_stream(dev):
+    """the process-wide second HIP stream of a device (weight packing beside the first layer; side-stream weight gradients)"""
+    key = (dev.type, dev.index)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(dev)
+    return st
+
+
 class _BwdCtx:
     """per-backward scratch shared by the helper methods: zeroed double pool, wgrad workspace, flat gradient buffer, and the
     side stream on which the weight gradients of SMALL layers run concurrently with their data gradients"""
@@ -471,6 +485,7 @@ class _BwdCtx:
         self.side = None
         self.ws_side = None
         self.side_used = False
+        self.coef_hi = None  # set by ConvLayers._norm_bwd_finalize for a sub-pixel layer: (N,3,C1) table (p, 8q, 8r) of the upsampled channels
 
     def gview(self, idx):
         e = self._e
@@ -485,11 +500,7 @@ class _BwdCtx:
 
     def side_stream(self, ws_floats):
         if self.side is None:
-            key = (self.dev.type, self.dev.index)
-            st = _SIDE_STREAMS.get(key)
-            if st is None:
-                st = _SIDE_STREAMS[key] = torch.cuda.Stream(self.dev)
-            self.side = st
+            self.side = _side_stream(self.dev)
         if self.ws_side is None or self.ws_side.numel() < ws_floats:
             if self.ws_side is not None:
                 self.join()  # the old workspace may still be in use on the side stream

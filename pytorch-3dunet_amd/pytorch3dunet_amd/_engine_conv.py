@@ -48,6 +48,8 @@ class _ConvCall:
     residual: Optional[torch.Tensor]     # added before the ReLU inside the conv epilogue (pre-norm residual blocks)
     sub: dict                            # sub-pixel layers of this forward: id(weight) -> (C0, C1)
     b16: bool                            # bf16 activation storage
+    affine_lo: Optional[torch.Tensor] = None  # sub-pixel layers: compact rows of `affine` for the skip / upsampled channels
+    affine_hi: Optional[torch.Tensor] = None
 
     def take_stats(self):
         return self.pool.take(self.N * self.Cout * 2) if self.stats else None
@@ -154,10 +156,17 @@ class ConvLayers:
         nat.call("u3d_chan_stats", dev.index, _stream(dev), ctypes.byref(s), src.N, src.D, src.H, src.W, _p(st))
         return st, src.C, 1.0, None, 0, 0.0
 
-    def _norm_finalize(self, kind, mod, st0, C0, sc0, st1, C1, sc1, N, G, count, affine, dev):
-        """per-(n,c) sums -> the (a, b) table the convolutions / apply passes use; returns what backward needs (mean, rstd)"""
+    def _norm_finalize(self, kind, mod, st0, C0, sc0, st1, C1, sc1, N, G, count, affine, dev, split=None):
+        """per-(n,c) sums -> the (a, b) table the convolutions / apply passes use; returns what backward needs (mean, rstd).
+        `split` = (Csplit, affine_lo, affine_hi): compact tables of the channel ranges [0, Csplit) / [Csplit, C) written in the same
+        launch (GroupNorm over a virtual concat whose halves are read by different kernels; None entries are skipped)"""
         if kind == "g":
             mean_rstd = _empty((N, G, 2), dtype=_F32, device=dev)
+            if split is not None:
+                nat.call("u3d_gn_finalize_split", dev.index, _stream(dev), _p(st0), C0, sc0, _p(st1), C1, sc1, N, G, count,
+                         _p(mod.weight.detach()), _p(mod.bias.detach()), float(mod.eps), _p(affine), _p(mean_rstd), split[0],
+                         _p(split[1]), _p(split[2]))
+                return mean_rstd
             nat.call("u3d_gn_finalize", dev.index, _stream(dev), _p(st0), C0, sc0, _p(st1), C1, sc1, N, G, count,
                      _p(mod.weight.detach()), _p(mod.bias.detach()), float(mod.eps), _p(affine), _p(mean_rstd))
             return mean_rstd
@@ -179,6 +188,19 @@ class ConvLayers:
 
     def _norm_bwd_finalize(self, cx, rec: ConvRec, gst, N, C, count, coef):
         dev, gview = cx.dev, cx.gview
+        cx.coef_hi = None
+        if isinstance(gst, tuple):
+            # sub-pixel decoder layer: the sums of the skip / upsampled channels come from two kernels as two tables
+            g0, g1 = gst
+            C0 = g0.numel() // (2 * N)
+            if rec.norm == "g" and nat.get_lib().u3d_gn_bwd_finalize_split_supported(N, C, rec.G) == 1:
+                # ... and the low-res apply pass of an exact-2x level wants the upper channels' (p, 8q, 8r) as a compact table
+                coef_hi = _empty((N, 3, C - C0), dtype=_F32, device=dev) if not any(rec.src.plus) else None
+                nat.call("u3d_gn_bwd_finalize_split", dev.index, _stream(dev), _p(g0), C0, _p(g1), C - C0, _p(rec.mean_rstd),
+                         _p(rec.gn_w.detach()), N, rec.G, count, _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef), 8.0, _p(coef_hi))
+                cx.coef_hi = coef_hi
+                return
+            gst = torch.cat((g0.view(N, C0, 2), g1.view(N, C - C0, 2)), dim=1)
         if rec.norm == "g":
             nat.call("u3d_gn_bwd_finalize", dev.index, _stream(dev), _p(gst), _p(rec.mean_rstd), _p(rec.gn_w.detach()), N, C, rec.G,
                      count, _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef))
@@ -229,7 +251,7 @@ class ConvLayers:
             nat.call("u3d_subpixel_conv_fwd_win", dev.index, _stream(dev), _p(src.t1), _p(c.affine.view(-1)[2 * C0:]), c.Ctot * 2,
                      _p(self._pack_cache[(id(conv.weight), 12)][1]), _p(part), N, D1, H1, W1, C1, Cout, win,
                      flops=128.0 * C1 * Cout * N * D1 * H1 * W1)
-            s_up = src.up_only_struct(c.affine[:, C0:].contiguous())
+            s_up = src.up_only_struct(c.affine_hi if c.affine_hi is not None else c.affine[:, C0:].contiguous())
             wp1 = self._pack_cache[(id(conv.weight), 14)][1]  # 27-tap forward image of the upsampled channels (slab launches)
             for box in slab_boxes((D, H, W), plus, 2):
                 nat.call("u3d_conv3d_box", dev.index, _stream(dev), ctypes.byref(s_up), _p(wp1), _p(part), N, D, H, W, Cout,
@@ -241,7 +263,7 @@ class ConvLayers:
             nat.call("u3d_subpixel_conv_fwd", dev.index, _stream(dev), _p(src.t1), _p(c.affine.view(-1)[2 * C0:]), c.Ctot * 2,
                      _p(self._pack_cache[(id(conv.weight), 12)][1]), _p(part), N, D1, H1, W1, C1, Cout, _p(kws), need,
                      flops=128.0 * C1 * Cout * N * D1 * H1 * W1)
-        a0 = c.affine[:, :C0].contiguous()
+        a0 = c.affine_lo if c.affine_lo is not None else c.affine[:, :C0].contiguous()
         if self._split_fwd(C0, Cout):
             nat.call("u3d_conv3d_f32s", dev.index, _stream(dev), _p(src.t0), _p(a0), _p(self._packed_f32s(conv.weight, 0, dev, C0, 0)),
                      _p(c.y), N, D, H, W, C0, Cout, c.relu, _p(ystats), None, None, _p(part), None, 0,
@@ -311,12 +333,18 @@ class ConvLayers:
         # ONE flag for the finalize call (batch vs running statistics) and for backward (mean / rstd functions of x vs constants): a
         # BatchNorm3d without running estimates normalises with batch statistics in eval mode too (_norm_finalize)
         bn_training = (bool(gn.training) or gn.running_mean is None) if spec.norm == "b" else True
+        split = None  # sub-pixel layers: compact (N,C0,2) / (N,C1,2) copies of the affine rows, written by the finalize launch
         if post:
             affine, mean_rstd = self._identity_affine(N, Ctot, dev), None
         else:
             st0, C0, sc0, st1, C1, sc1 = st_in
             affine = _empty((N, Ctot, 2), dtype=_F32, device=dev)
-            mean_rstd = self._norm_finalize(spec.norm, gn, st0, C0, sc0, st1, C1, sc1, N, G, float(D * H * W), affine, dev)
+            if spec.norm == "g" and src.t1 is not None and residual is None and sub and id(conv.weight) in sub:
+                # sub-pixel layer: its two halves are read by different kernels as plain tensors
+                Cs0, Cs1 = sub[id(conv.weight)]
+                split = (Cs0, _empty((N, Cs0, 2), dtype=_F32, device=dev),
+                         _empty((N, Cs1, 2), dtype=_F32, device=dev) if any(src.plus) else None)
+            mean_rstd = self._norm_finalize(spec.norm, gn, st0, C0, sc0, st1, C1, sc1, N, G, float(D * H * W), affine, dev, split)
         # y_out: recomputation under activation checkpointing rewrites the (still alive) block output in place with the
         # bit-identical values instead of allocating a second copy
         b16 = src.t0.dtype == torch.bfloat16  # bf16 activation storage: only the bf16-operand branch below handles it
@@ -326,7 +354,7 @@ class ConvLayers:
         y = y_out if (y_out is not None and not post) else _empty((N, D, H, W, Cout), dtype=src.t0.dtype if b16 else _F32, device=dev)
         # ---- the convolution itself: ONE decision (which kernel family), then the family's launcher from the table
         call = _ConvCall(dev, conv, src, affine, y, N, D, H, W, Ctot, Cout, relu, bool(want_stats and self.fused_stats), pool, conv_res,
-                         sub, b16)
+                         sub, b16, *(split[1:] if split is not None else (None, None)))
         family = self._fwd_family(call, residual)
         small = family == "small"
         ystats = getattr(self, self._FWD_KERNELS[family])(call)
@@ -380,7 +408,7 @@ class ConvLayers:
                         self._pindex[id(gn.bias)] if gn is not None else self._pindex[id(conv.bias)],
                         self._pindex[id(conv.weight)], small,
                         sub.get(id(conv.weight)) if (sub and src.t1 is not None and residual is None) else None,
-                        not post, post_rec, spec.norm, bn_training, drop_rec)
+                        not post, post_rec, spec.norm, bn_training, drop_rec, call.affine_lo, call.affine_hi)
             )
         return y, ystats
 
@@ -436,7 +464,7 @@ class ConvLayers:
             nat.call("u3d_subpixel_conv_wgrad_win", dev.index, _stream(dev), _p(src.t1), _p(rec.affine.view(-1)[2 * C0:]), Ct * 2,
                      _p(c.dz), _p(dwv[C0 * 27:]), Ct, c.N, src.D1, src.H1, src.W1, C1, c.Cout, _p(ws), ws.numel(), win,
                      flops=128.0 * C1 * c.Cout * c.N * src.D1 * src.H1 * src.W1)
-            s_up = src.up_only_struct(rec.affine[:, C0:].contiguous())
+            s_up = src.up_only_struct(rec.affine_hi if rec.affine_hi is not None else rec.affine[:, C0:].contiguous())
             slice_view = dwv.view(c.Cout, Ct, 27)[:, C0:, :]
             for box in slab_boxes((c.D, c.H, c.W), plus, 2):
                 tmp = _empty((c.Cout, C1, 27), dtype=_F32, device=dev)
@@ -448,7 +476,7 @@ class ConvLayers:
             nat.call("u3d_subpixel_conv_wgrad", dev.index, _stream(dev), _p(src.t1), _p(rec.affine.view(-1)[2 * C0:]), Ct * 2,
                      _p(c.dz), _p(dwv[C0 * 27:]), Ct, c.N, src.D1, src.H1, src.W1, C1, c.Cout, _p(ws), ws.numel(),
                      flops=128.0 * C1 * c.Cout * c.N * src.D1 * src.H1 * src.W1)
-        a0 = rec.affine[:, :C0].contiguous()
+        a0 = rec.affine_lo if rec.affine_lo is not None else rec.affine[:, :C0].contiguous()
         s0 = VSrc(src.t0).struct(a0)
         nat.call("u3d_conv3d_wgrad_strided", dev.index, _stream(dev), ctypes.byref(s0), _p(c.dz), _p(dwv), Ct, c.N, c.D, c.H, c.W,
                  c.Cout, _p(ws), ws.numel(), flops=54.0 * C0 * c.Cout * c.N * c.D * c.H * c.W)
@@ -519,8 +547,7 @@ class ConvLayers:
             nat.call("u3d_subpixel_conv_dgrad", dev.index, _stream(dev), _p(c.dz), _p(self._packed_sub(rec, 13, dev)), _p(src.t1),
                      _p(dlow), _p(gst1), Nn, src.D1, src.H1, src.W1, C1, Cout,
                      flops=128.0 * C1 * Cout * Nn * src.D1 * src.H1 * src.W1)
-        gst = torch.cat((gst0.view(Nn, C0, 2), gst1.view(Nn, C1, 2)), dim=1)
-        return (dg0, dlow), gst
+        return (dg0, dlow), (gst0, gst1)  # (_norm_bwd_finalize takes the two tables as they are)
 
     def _dgrad_f32s(self, c: "_BwdCall"):
         cx, dev, src, rec = c.cx, c.cx.dev, c.src, c.rec

@@ -145,6 +145,7 @@ class _GraphedUNet3DFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, step: GraphStep, x: torch.Tensor, *params):
+        ctx.set_materialize_grads(False)  # (as in _UNet3DFunction: an unused output's gradient arrives as None)
         with step.engine._lock:
             logits, probs = step.forward(x)
             ctx.gen = step.gen

@@ -331,7 +331,7 @@ class UNet3DEngine(WeightImages, ConvLayers):
                              src.H1, src.W1, C1, *src.plus, mk, _p(dzl))
                 else:
                     # dlow already holds the children sums: (p*dlow + 8*(q*x + r)) * (x > 0) on the low-res producer
-                    coef_up = coef1[:, :, C0:] * self._up_scale(dev)
+                    coef_up = cx.coef_hi if cx.coef_hi is not None else coef1[:, :, C0:] * self._up_scale(dev)
                     nat.call("u3d_gn_bwd_apply", dev.index, _stream(dev), _p(dlow), C1, 0, _p(src.t1), C1, _p(coef_up), C1,
                              src.D1 * src.H1 * src.W1, src.N, mk, _p(dzl))
                 del dg0, dlow

@@ -88,6 +88,17 @@ _PROTOS = {
         c_int,
         [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p],
     ),
+    "u3d_gn_finalize_split": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_int, c_double, c_void_p, c_int, c_double, c_int, c_int, c_double, c_void_p,
+         c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+    ),
+    "u3d_gn_bwd_finalize_split_supported": (c_int, [c_int, c_int, c_int]),
+    "u3d_gn_bwd_finalize_split": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_double, c_void_p, c_void_p,
+         c_void_p, c_float, c_void_p],
+    ),
     "u3d_gn_bwd_apply": (
         c_int,
         [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p],
@@ -382,7 +393,7 @@ def get_lib():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.u3d_version() < 118:
+        if lib.u3d_version() < 122:
             raise U3DError("libu3d_hip.so is older than the Python host code")
         for kv in os.environ.get("U3D_TUNE", "").split(","):  # A/B knobs of u3d_set_tuning, e.g. U3D_TUNE=8:256,9:1 (results never change)
             if ":" in kv:

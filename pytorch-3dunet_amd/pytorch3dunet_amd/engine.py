@@ -49,6 +49,9 @@ class _UNet3DFunction(torch.autograd.Function):
         # when the CALLER runs under torch.no_grad() (round 4: inference forwards therefore kept a tape, advanced the repack salt and
         # repacked every weight image each time — 6 ms per volume of BASELINE config 5).  The caller's grad mode is passed in.
         save = grad_mode and any(ctx.needs_input_grad)
+        # an output the loss never touches (the reference's trainer takes the loss on the logits only, trainer.py:362-365) must reach
+        # backward as None, not as a zero tensor: materialised, the unused `probs` cost a fill + four elementwise launches per step
+        ctx.set_materialize_grads(False)
         with engine._lock:
             engine.begin_forward(save)
             logits, probs, tape = engine.forward(x, save)

@@ -96,7 +96,10 @@ class Golden:
 GOLDEN_NAMES = ["g1_unet3d_small", "g2_unet3d_multi_odd", "g3_unet3d_regression", "g4_unet3d_f16_cfg1",
                 "g5_resunet3d_small", "g6_resunet3d_multi_odd", "g7_resunetse3d_small", "g8_resunetse3d_multi_odd",
                 # BASELINE.json configurations at full channel width (sampled fixtures): config 2 itself, config 4's and 5's ladders
-                "g9_unet3d_f32_cfg2", "g10_resunet3d_f64_ladder", "g11_resunetse3d_in3_ladder"]
+                "g9_unet3d_f32_cfg2", "g10_resunet3d_f64_ladder", "g11_resunetse3d_in3_ladder",
+                # the patch shape the reference SHIPS for training (80x170x170, resources/3DUnet_confocal_boundary/train_config.yml:94):
+                # ragged tiles + n -> 2n + 1 decoder levels at full width
+                "g13_unet3d_f32_shipped_80x170x170"]
 
 
 @pytest.fixture(params=GOLDEN_NAMES)

@@ -52,6 +52,10 @@ CASES = {
     # 11 TFLOP per step on the host: fp32 only (the float64 twin needs > 60 GB) -> no ref_err / grad64 samples in this fixture
     "g12_resunet3d_f64_cfg4_fullsize": (dict(name="ResidualUNet3D", in_channels=1, out_channels=1, f_maps=64, num_groups=8,
                                              final_sigmoid=True), (1, 1, 80, 160, 160), "bce_dice", False),
+    # ---- round 6: the shape the reference SHIPS for training (resources/3DUnet_confocal_boundary/train_config.yml:94, patch 80x170x170,
+    # UNet3D f_maps=32): the only shape where the ragged tiles and the n -> 2n + 1 decoder levels (170 -> 85 -> 42 -> 21) all run at full width
+    "g13_unet3d_f32_shipped_80x170x170": (dict(name="UNet3D", in_channels=1, out_channels=1, f_maps=32, num_groups=8,
+                                               final_sigmoid=True), (1, 1, 80, 170, 170), "bce_dice", False),
 }
 NO_F64 = {"g12_resunet3d_f64_cfg4_fullsize"}
 SAMPLE = 97  # stride of the samples kept for `big` fixtures

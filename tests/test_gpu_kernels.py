@@ -546,7 +546,48 @@ def test_groupnorm_backward_concat_split(size):
     assert U.relerr(U.ncdhw(dzl), lowpre.grad) < 1e-4
 
 
-@pytest.mark.parametrize("N,C,size", [(2, 8, (8, 12, 16)), (1, 5, (9, 13, 11)), (1, 32, (4, 6, 2))])
+@pytest.mark.parametrize("N,C0,C1,G,Cs", [(2, 8, 16, 4, 8), (1, 32, 64, 8, 32), (2, 96, 0, 8, 32), (2, 128, 256, 8, 128)])
+def test_groupnorm_finalize_split_forms_equal_the_plain_ones_bit_for_bit(N, C0, C1, G, Cs):
+    """u3d_gn_finalize_split / u3d_gn_bwd_finalize_split (round 6: the compact half tables of a virtual-concat layer written by the
+    finalize launches themselves instead of strided-copy / cat / scale launches around them): same `affine`, `mean_rstd`, dgamma, dbeta,
+    `coef` as the plain entry points, and the compact tables are exactly the rows / the (1, 8, 8)-scaled rows of those"""
+    U, nat, VSrc, _p, _stream = _mods()
+    torch.manual_seed(C0 + C1)
+    C, V = C0 + C1, 4096.0
+    dev = U.DEV
+    st0 = (torch.randn(N, C0, 2, dtype=torch.float64, device=dev) * 50).abs_() + torch.tensor([0.0, 4000.0], dtype=torch.float64, device=dev)
+    st1 = ((torch.randn(N, max(C1, 1), 2, dtype=torch.float64, device=dev) * 5).abs_() + torch.tensor([0.0, 500.0], dtype=torch.float64, device=dev))
+    gamma, beta = torch.randn(C, device=dev), torch.randn(C, device=dev)
+    aff, mr = U.gn_finalize(st0, C0, 1.0, st1 if C1 else None, C1, 8.0, N, G, V, gamma, beta)
+    aff2, mr2 = torch.empty_like(aff), torch.empty_like(mr)
+    lo, hi = torch.empty((N, Cs, 2), device=dev), torch.empty((N, C - Cs, 2), device=dev)
+    nat.call("u3d_gn_finalize_split", 0, _stream(dev), _p(st0), C0, 1.0, _p(st1 if C1 else None), C1, 8.0, N, G, V, _p(gamma), _p(beta), 1e-5,
+             _p(aff2), _p(mr2), Cs, _p(lo), _p(hi))
+    assert torch.equal(aff, aff2) and torch.equal(mr, mr2)
+    assert torch.equal(lo, aff[:, :Cs]) and torch.equal(hi, aff[:, Cs:])
+    if C1 == 0:
+        return
+    g0 = torch.randn(N, C0, 2, dtype=torch.float64, device=dev)
+    g1 = torch.randn(N, C1, 2, dtype=torch.float64, device=dev)
+    gcat = torch.cat((g0, g1), dim=1).contiguous()
+    outs = []
+    for split in (False, True):
+        dgam, dbet, coef = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty((N, 3, C), device=dev)
+        chi = torch.empty((N, 3, C1), device=dev)
+        if split:
+            assert nat.get_lib().u3d_gn_bwd_finalize_split_supported(N, C, G) == 1
+            nat.call("u3d_gn_bwd_finalize_split", 0, _stream(dev), _p(g0), C0, _p(g1), C1, _p(mr), _p(gamma), N, G, V, _p(dgam), _p(dbet),
+                     _p(coef), 8.0, _p(chi))
+        else:
+            nat.call("u3d_gn_bwd_finalize", 0, _stream(dev), _p(gcat), _p(mr), _p(gamma), N, C, G, V, _p(dgam), _p(dbet), _p(coef))
+        outs.append((dgam, dbet, coef, chi))
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert torch.equal(a, b)
+    scale = torch.tensor([1.0, 8.0, 8.0], device=dev).view(1, 3, 1)
+    assert torch.equal(outs[1][3], outs[0][2][:, :, C0:] * scale)
+
+
+@pytest.mark.parametrize("N,C,size", [(2, 8, (8, 12, 16)), (1, 5, (9, 13, 11)), (1, 32, (4, 6, 2)), (2, 64, (8, 16, 16))])
 def test_maxpool_forward_backward_merge(N, C, size):
     U, nat, VSrc, _p, _stream = _mods()
     torch.manual_seed(C)

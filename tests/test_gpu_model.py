@@ -235,6 +235,10 @@ def test_model_matches_cpu_oracle(cfg, shape, loss_name):
     # the float64 oracle is a minute or two of host time
     pytest.param(dict(in_channels=1, out_channels=1, f_maps=32, num_groups=8), (2, 1, 64, 128, 128), "bce_dice",
                  marks=pytest.mark.timeout(1800), id="config2-full-size"),
+    # the reference's SHIPPED training patch (resources/3DUnet_confocal_boundary/train_config.yml:94): 80 -> 40 -> 20 -> 10 planes,
+    # 170 -> 85 -> 42 -> 21 rows: ragged tiles at every level, two n -> 2n + 1 decoder levels, one plain 2x level
+    pytest.param(dict(in_channels=1, out_channels=1, f_maps=32, num_groups=8), (1, 1, 80, 170, 170), "bce_dice",
+                 marks=pytest.mark.timeout(1800), id="shipped-80x170x170"),
 ])
 def test_gradients_match_decision_consistent_fp64_oracle(cfg, shape, loss_name):
     """The tight gradient check: the float64 oracle with OUR ReLU masks and max-pool arg-maxes imposed
