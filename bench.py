@@ -196,7 +196,13 @@ def main():
     torch.manual_seed(0)  # identical initial weights on every rank (also broadcast below)
     model = UNet3D(compute_dtype=args.compute_dtype, **MODEL_CFG).to(dev).train()
     sync = parallel.attach(model, force_single=True) if use_dist else None
-    opt = torch.optim.Adam(model.parameters(), lr=2e-4, weight_decay=1e-5)  # 3DUnet_confocal_boundary/train_config.yml
+    # Adam with the hyper-parameters of 3DUnet_confocal_boundary/train_config.yml (the reference's create_optimizer, utils.py:246-316,
+    # builds torch.optim.Adam): the same update as ONE launch over all 44 parameters (pytorch3dunet_amd.optim.FusedAdam; torch's
+    # multi-tensor form is 8 launches / 0.17 ms of the 17 ms step; U3D_BENCH_TORCH_ADAM=1 times that one instead)
+    from pytorch3dunet_amd.optim import FusedAdam
+
+    Adam = torch.optim.Adam if os.environ.get("U3D_BENCH_TORCH_ADAM") == "1" else FusedAdam
+    opt = Adam(model.parameters(), lr=2e-4, weight_decay=1e-5)
     g = torch.Generator(device=dev).manual_seed(1000 + rank)  # per-rank synthetic shard
     B = args.batch
     x = torch.randn((B, 1, *PATCH), device=dev, generator=g)
@@ -311,7 +317,7 @@ def main():
                             "allreduce_per_step": sync.launched // (args.steps + args.warmup)} if use_dist
                            else {"world_size": 1, "backend": None, "allreduce_per_step": 0}),
             "config": {"workload": f"UNet3D in=1 out=1 f_maps=32 gcr num_groups=8, per-GPU batch {B}x1x64x128x128 fp32, "
-                                   "BCEDiceLoss, fwd+loss+bwd+Adam step, random-init weights",
+                                   "BCEDiceLoss, fwd+loss+bwd+Adam step (" + ("torch.optim.Adam" if Adam is torch.optim.Adam else "one-launch FusedAdam") + "), random-init weights",
                        "global_batch": world * B, "parallelism": f"dp{world}",
                        "conv_gflop_per_patch_fwd": round(f_fwd / 1e9, 3),
                        # 3x the forward convolution FLOPs of the REFERENCE formulation per patch over the
@@ -408,7 +414,7 @@ def main():
             for mode, opt_in, arithmetic in EXTRAS:
                 torch.manual_seed(0)
                 model2 = UNet3D(compute_dtype=mode, **MODEL_CFG).to(dev).train()
-                opt2 = torch.optim.Adam(model2.parameters(), lr=2e-4, weight_decay=1e-5)
+                opt2 = Adam(model2.parameters(), lr=2e-4, weight_decay=1e-5)
                 # same weights, same batch, before any update: how far the two arithmetics are apart on the logits
                 torch.manual_seed(0)
                 model1 = UNet3D(**MODEL_CFG).to(dev).train()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define U3D_VERSION 122 /* 122: round 6 — u3d_gn_finalize_split / u3d_gn_bwd_finalize_split (compact half tables of a virtual-concat layer), statistics fused into u3d_maxpool2_fwd, tuning key 18; 121: u3d_convtr3d_fwd_t8_b16_ex; 120: flat 5 x 10 x 10 tile of the bf16-storage convolutions (u3d_conv3d_bf16_tile_variant planes = 5), 24 tuning keys; 119: round 5 — ragged volumes on the persistent kernels, u3d_conv3d_variant / u3d_conv3d_wgrad_variant; 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K); 118: u3d_se_*_b16 */
+#define U3D_VERSION 122 /* 122: round 6 — u3d_gn_finalize_split / u3d_gn_bwd_finalize_split (compact half tables of a virtual-concat layer), u3d_adam_step, tuning key 18; 121: u3d_convtr3d_fwd_t8_b16_ex; 120: flat 5 x 10 x 10 tile of the bf16-storage convolutions (u3d_conv3d_bf16_tile_variant planes = 5), 24 tuning keys; 119: round 5 — ragged volumes on the persistent kernels, u3d_conv3d_variant / u3d_conv3d_wgrad_variant; 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K); 118: u3d_se_*_b16 */
 
 #define U3D_OK 0
 #define U3D_EINVAL (-1)  /* bad shape / argument */
@@ -358,6 +358,24 @@ int u3d_conv1x1_head_fwd(int device, u3d_stream_t stream, const float* x, const 
 int u3d_conv1x1_head_bwd(int device, u3d_stream_t stream, const float* dlogits, const float* x, const float* w,
                          int N, int64_t V, int Cin, int Cout, int relu_mask, float* dx, double* acc);
 int u3d_cvt_f64_f32(int device, u3d_stream_t stream, const double* src, float* dst, int64_t n);
+
+/* ---- optimizer step (trainer.py:246 `self.optimizer.step()`; create_optimizer, utils.py:246-316: torch.optim.Adam) ------------
+ * The Adam update of ALL parameters in ONE launch (csrc/u3d_optim.hip): torch's multi-tensor form is 8 launches / 0.17 ms per step
+ * for the 44 parameters of UNet3D f_maps=32.  descs: DEVICE array of n descriptors sorted by `first` = running element offset with
+ * every parameter padded to a multiple of 4 elements (descriptor 0: 0); total_padded = the padded sum.  Per element, in torch's
+ * operation order (torch/optim/adam.py, amsgrad=False, maximize=False, L2-style weight decay):
+ *   g = grad + weight_decay*p;  m += (1-beta1)*(g-m);  v = beta2*v + (1-beta2)*g*g;  p -= lr/(1-beta1^step) * m / (sqrt(v)/sqrt(1-beta2^step) + eps)
+ * `step` is the 1-based step count of THIS update (all parameters of a launch share it). */
+typedef struct {
+    float* p;       /* parameter, updated in place */
+    const float* g; /* its gradient */
+    float* m;       /* exp_avg */
+    float* v;       /* exp_avg_sq */
+    int64_t first;
+    int64_t numel;
+} u3d_adam_desc_t;
+int u3d_adam_step(int device, u3d_stream_t stream, const u3d_adam_desc_t* descs_device, int n, int64_t total_padded, double lr,
+                  double beta1, double beta2, double eps, double weight_decay, int64_t step);
 
 /* ---- residual variants (ResidualUNet3D / ResidualUNetSE3D, model.py:193-278) -------------------------------------
  * 1x1x1 convolution WITH bias (ResNetBlock.conv1, buildingblocks.py:248-255).  x (N,V,Cin), w (Cout,Cin), y (N,V,Cout),

@@ -39,8 +39,9 @@
 //   [15] 1 = sub-pixel weight gradient with per-element coordinate arithmetic for its B loads (A/B of the constant-offset path)
 //   [16] bf16-storage 3x3x3 convolution, flat 5 x 10 x 10 tile of the small wide levels: 1 = never, >= 2 = force that split count
 //   [17] 1 = bf16-storage weight gradient with ONE split still goes through the workspace + reduction kernel (A/B of the direct dw write)
-//   [18] 1 = u3d_maxpool2_fwd computes its output statistics in a second pass (u3d_chan_stats) and the one-channel input statistics run
-//        on the general kernel — the round-5 forms (A/B of the fused / 16-byte kernels, csrc/u3d_ops.hip)
+//   [18] 1 = the one-channel input statistics run on the general u3d_chan_stats kernel — the round-5 form (A/B of the 16-byte kernel,
+//        csrc/u3d_ops.hip).  (A max-pool with the statistics fused into its pass was built and measured in round 6: 77 / 43 / 12 us per level
+//        against 52 + 23 / 14 + 11 / 5 + 8 for the massively parallel pool + a statistics pass — the pool alone moves 6 TB/s; not kept.)
 int g_u3d_tune[24] = {0};
 
 namespace cv {

@@ -6,7 +6,7 @@
 
 #include <string.h>
 
-extern int g_u3d_tune[24];  // u3d_set_tuning (csrc/u3d_conv.hip); key 18 = 1: max-pool / input statistics in their two-pass round-5 form (A/B)
+extern int g_u3d_tune[24];  // u3d_set_tuning (csrc/u3d_conv.hip); key 18 = 1: one-channel input statistics on the general kernel (A/B)
 
 // ---- library plumbing ----------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -117,7 +117,24 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const u3d_src_t src, in
     const int row = t / Q, qd = t - row * Q;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     if (row < rows) {
-        for (long long v = vbeg + row; v < vend; v += rows) {
+        long long v = vbeg + row;
+        if (src.C1 == 0) {
+            // plain tensor: 8 independent 16-byte loads in flight per thread (round 6; one at a time, the pass was latency-bound:
+            // 23 us for the 33 MB pooled tensor of the bench workload)
+            for (; v + 7LL * rows < vend; v += 8LL * rows) {
+                f32x4 q[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) q[k] = u3d_load_quad(src, (int)((long long)n * V + v + (long long)k * rows), 0, 4 * qd, vec != 0);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s1[e] += q[k][e];
+                        s2[e] += q[k][e] * q[k][e];
+                    }
+            }
+        }
+        for (; v < vend; v += rows) {
             int v0 = (int)((long long)n * V + v), v1 = 0;
             if (src.C1 > 0) {
                 const int x = (int)(v % W);
@@ -867,75 +884,11 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_vec_kernel(const T* __restri
     }
 }
 
-// The same pooling with the per-(n, channel) sums of its OUTPUT (the next GroupNorm's statistics) accumulated on the way (round 6:
-// the separate u3d_chan_stats pass re-read the pooled tensor at 1.5 TB/s behind a serial LDS fold — 23 + 11 + 8 us per bench step).
-// grid (blocks per sample, N); 256 % C == 0, so a thread keeps ONE channel over all its elements (block stride = a multiple of C):
-// fp32 running sums per thread, folded per channel through LDS in a fixed order, one f64 atomic pair per (block, channel).
-__global__ __launch_bounds__(256) void maxpool2_fwd_stats_kernel(const float* __restrict__ x, int D, int H, int W, int C,
-                                                                 float* __restrict__ out, uint8_t* __restrict__ argmax,
-                                                                 double* __restrict__ stats) {
-    __shared__ float red[2][256];
-    const int D2 = D >> 1, H2 = H >> 1, W2 = W >> 1;
-    const int n = blockIdx.y, t = threadIdx.x;
-    const long long per_n = (long long)D2 * H2 * W2 * C;
-    const int c = t % C;  // (blockIdx.x * 256 + t + k * gridDim.x * 256) % C for every k
-    float s1 = 0.f, s2 = 0.f;
-    for (long long idx = (long long)blockIdx.x * 256 + t; idx < per_n; idx += (long long)gridDim.x * 256) {
-        long long v = idx / C;
-        const int xo = (int)(v % W2);
-        v /= W2;
-        const int yo = (int)(v % H2);
-        const int zo = (int)(v / H2);
-        float best = -INFINITY;
-        int bi = 0;
-        float val[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int z = 2 * zo + (k >> 2), y = 2 * yo + ((k >> 1) & 1), xx = 2 * xo + (k & 1);
-            val[k] = x[((size_t)((n * D + z) * H + y) * W + xx) * C + c];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (val[k] > best || val[k] != val[k]) {  // first max in scan order; NaN propagates (ATen max_pool3d)
-                best = val[k];
-                bi = k;
-            }
-        }
-        out[(size_t)n * per_n + idx] = best;
-        argmax[(size_t)n * per_n + idx] = (uint8_t)bi;
-        s1 += best;
-        s2 += best * best;
-    }
-    red[0][t] = s1;
-    red[1][t] = s2;
-    __syncthreads();
-    if (t < C) {
-        float a = 0.f, b = 0.f;
-        for (int r = t; r < 256; r += C) {  // fixed order
-            a += red[0][r];
-            b += red[1][r];
-        }
-        u3d_atomic_add_f64(&stats[((size_t)n * C + t) * 2], (double)a);
-        u3d_atomic_add_f64(&stats[((size_t)n * C + t) * 2 + 1], (double)b);
-    }
-}
-
 extern "C" int u3d_maxpool2_fwd(int device, u3d_stream_t stream, const float* x, int N, int D, int H, int W, int C,
                                 float* out, uint8_t* argmax, double* out_stats) {
     U3D_ENTER(device);
     U3D_REQUIRE(x && out && argmax && N > 0 && D >= 2 && H >= 2 && W >= 2 && C > 0, "u3d_maxpool2_fwd: bad argument");
     const long long total = (long long)N * (D / 2) * (H / 2) * (W / 2) * C;
-    if (out_stats && 256 % C == 0 && N <= 65535 && g_u3d_tune[18] != 1) {  // (key 18 = 1: the two-pass form, A/B)
-        const long long per_n = total / N;
-        long long bpn = (per_n + 256 * 8 - 1) / (256 * 8);  // >= 8 elements per thread, ~1024 blocks in total
-        const long long want = (1024 + N - 1) / N;
-        if (bpn > want) bpn = want;
-        if (bpn < 1) bpn = 1;
-        hipLaunchKernelGGL(maxpool2_fwd_stats_kernel, dim3((unsigned)bpn, (unsigned)N), dim3(256), 0, (hipStream_t)stream, x, D, H, W, C,
-                           out, argmax, out_stats);
-        U3D_LAUNCH_CHECK();
-        return 0;
-    }
     // (the 16-byte variant below is for bf16 storage: with fp32 tensors it measured 0.131 against this kernel's 0.116 ms per step on config 2)
     hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, x, N, D,
                        H, W, C, out, argmax);

@@ -34,6 +34,12 @@ class U3DSrc(ctypes.Structure):
     ]
 
 
+class U3DAdamDesc(ctypes.Structure):
+    """mirror of u3d_adam_desc_t (include/u3d.h)"""
+
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("first", c_int64), ("numel", c_int64)]
+
+
 class U3DPackDesc(ctypes.Structure):
     """mirror of u3d_pack_desc_t (include/u3d.h)"""
 
@@ -94,6 +100,7 @@ _PROTOS = {
          c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     ),
     "u3d_gn_bwd_finalize_split_supported": (c_int, [c_int, c_int, c_int]),
+    "u3d_adam_step": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int64, c_double, c_double, c_double, c_double, c_double, c_int64]),
     "u3d_gn_bwd_finalize_split": (
         c_int,
         [c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_double, c_void_p, c_void_p,

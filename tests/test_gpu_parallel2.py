@@ -1,0 +1,132 @@
+"""-m gpu: the data-parallel step on REAL ranks over RCCL (`nccl` backend) — one process per GPU, gradients exchanged from inside the
+fused backward (pytorch3dunet_amd/parallel.py, engine.backward), the replacement of the reference's single-process nn.DataParallel
+(unet3d/trainer.py:202-205).  The two-rank test needs two visible GPUs and is skipped otherwise (the build container's GPU box has
+one); the one-rank variant runs the very same worker on every box, so the script itself is exercised wherever `-m gpu` runs.
+
+What is asserted on every rank: `.grad` after `loss.backward()` equals the single-process gradient of the CONCATENATED batch (a
+per-sample-mean loss; GroupNorm statistics are per sample, buildingblocks.py:75, so data parallelism is exact), eager and with
+`hip_graph: true`, and the number of collectives per step is what the bucket rule of DESIGN.md section 7 predicts."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WORKER = r'''
+import os, sys, json, copy
+sys.path.insert(0, os.path.join(os.getcwd(), "pytorch-3dunet_amd"))
+import torch, torch.distributed as dist, torch.multiprocessing as mp
+
+def predicted_collectives(eng):
+    """[decoders | head] first, then the encoder levels deepest first, a level's slice merged into the next shallower one while the
+    pending range is below MIN_BUCKET_FLOATS (UNet3DEngine._sync_encoder_level)"""
+    n, hi = 1, eng.n_enc_params
+    for level in range(len(eng.enc_level_offs) - 2, -1, -1):
+        lo = eng.enc_level_offs[level]
+        if level > 0 and hi - lo < eng.MIN_BUCKET_FLOATS:
+            continue
+        if hi > lo:
+            n += 1
+        hi = lo
+    return n
+
+def worker(rank, world, port, q):
+    from pytorch3dunet_amd import parallel
+    from pytorch3dunet_amd.unet3d.model import UNet3D, ResidualUNet3D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", rank); torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    res = {}
+    try:
+        g = torch.Generator().manual_seed(7)
+        xs = torch.randn(2 * world, 1, 16, 32, 32, generator=g)      # the global batch: 2 samples per rank
+        for name, cls, kw in (("unet", UNet3D, dict(f_maps=16, num_groups=8)), ("res", ResidualUNet3D, dict(f_maps=16, num_levels=4, num_groups=8))):
+            torch.manual_seed(0)
+            base = cls(1, 1, **kw)
+            with torch.no_grad():
+                for k, p in base.named_parameters():
+                    if "groupnorm" in k:
+                        p.add_(0.2 * torch.randn_like(p))
+            # single process, whole batch (every rank computes it on its own GPU: the reference answer)
+            ref = copy.deepcopy(base).to(dev).train()
+            _, lg = ref(xs.to(dev), return_logits=True)
+            (lg * lg).mean().backward()
+            gref = torch.cat([p.grad.flatten() for p in ref.parameters()])
+            for mode in ("eager", "graph"):
+                m = copy.deepcopy(base).to(dev).train()
+                if mode == "graph":
+                    m.hip_graph = True
+                    m._get_engine().hip_graph = True
+                sync = parallel.attach(m, force_single=True)   # (broadcasts rank 0's parameters; one rank still issues the collectives)
+                shard = xs[2 * rank: 2 * rank + 2].to(dev)
+                errs, per_step = [], []
+                for it in range(3):
+                    n0 = sync.launched
+                    m.zero_grad(set_to_none=True)
+                    _, lg = m(shard, return_logits=True)
+                    (lg * lg).mean().backward()
+                    per_step.append(sync.launched - n0)
+                    got = torch.cat([p.grad.flatten() for p in m.parameters()])
+                    errs.append(((got - gref).norm() / gref.norm()).item())
+                    errs.append(((got - gref).abs().max() / gref.abs().max()).item())
+                res[name + "/" + mode] = {"err": max(errs), "per_step": per_step, "predicted": predicted_collectives(m._get_engine()),
+                                          "captured": len(m._get_engine()._graph_steps), "off": m._get_engine()._graph_off_reason}
+        q.put((rank, res))
+    except Exception as e:
+        import traceback
+        q.put((rank, "ERROR " + repr(e) + "\n" + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+if __name__ == "__main__":
+    world, port = int(sys.argv[1]), int(sys.argv[2])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    out = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs: p.join(60)
+    print("RESULT " + json.dumps({str(k): v for k, v in out.items()}))
+'''
+
+
+def _run(world, port):
+    path = os.path.join(ROOT, "gpurun_out", f"_parallel2_worker_{world}.py")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as fh:
+        fh.write(WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    proc = subprocess.run([sys.executable, path, str(world), str(port)], capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    res = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    assert len(res) == world
+    for rank, r in res.items():
+        assert not isinstance(r, str), f"rank {rank}: {r}"
+        for key, v in r.items():
+            # averaged gradients == the single-process gradient of the concatenated batch
+            assert v["err"] < 1e-5, (rank, key, v)
+            # ... through exactly the predicted number of collectives, every step, in both launch modes
+            assert v["per_step"] == [v["predicted"]] * 3, (rank, key, v)
+            if key.endswith("/graph"):
+                assert v["captured"] == 1 and v["off"] is None, (rank, key, v)
+    return res
+
+
+@pytest.mark.timeout(1500)
+def test_one_rank_runs_the_same_worker_script():
+    """world size 1 (every box): the averaged gradient is the local one; the collectives are still issued (force_single)"""
+    res = _run(1, 29561)
+    # UNet3D f_maps=16: [decoders | head], enc3 (1.3 MB >= the 1 MiB bucket floor), then enc2 + enc1 + enc0 together
+    assert res["0"]["unet/eager"]["predicted"] == 3
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the first multi-GPU box arms it)")
+def test_two_ranks_average_gradients_like_one_process_on_the_whole_batch():
+    _run(2, 29563)

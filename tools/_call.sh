@@ -1,13 +1,8 @@
-set -u
-out=gpurun_out/r06f; mkdir -p $out; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k "groupnorm or maxpool or small_cin" 2>&1 | tail -8
-timeout 900 python -m pytest tests/test_gpu_model.py -x -q -k "golden or cpu_oracle" 2>&1 | tail -8
+timeout 1500 python -m pytest tests/test_optim.py tests/test_gpu_kernels.py -x -q -k "adam or groupnorm or maxpool" 2>&1 | grep -v '^$' | tail -8
+out=gpurun_out/r06j; mkdir -p $out
 B="python bench.py --no-cpu-baseline --no-roofline --no-extras"
-for i in 1 2; do
-$B > $out/new$i.log 2>&1
-U3D_TUNE=18:1 $B > $out/twopass$i.log 2>&1
-done
-for f in new1 twopass1 new2 twopass2; do python - $out/$f.log $f <<'PY'
+$B > $out/new1.log 2>&1; U3D_TUNE=18:1 $B > $out/k18.log 2>&1; $B > $out/new2.log 2>&1
+for f in new1 k18 new2; do python - $out/$f.log $f <<'PY'
 import sys,json
 for ln in open(sys.argv[1]):
     if ln.startswith('{'):
@@ -16,4 +11,4 @@ PY
 done
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $out/trace -- $B --steps 3 --warmup 3 > $out/trace.log 2>&1
 f=$(find $out/trace -name "*kernel_trace.csv" | head -1); mkdir -p $out/t; cp "$f" $out/t/x_kernel_trace.csv; rm -rf $out/trace
-python tools/gap_analysis.py $out/t --list > $out/step_launches.txt; head -3 $out/step_launches.txt
+python tools/gap_analysis.py $out/t --list > $out/step_launches.txt; grep -n 'maxpool2_fwd\|adam\|_stats' $out/step_launches.txt
