@@ -244,6 +244,11 @@ int u3d_conv3d_wgrad_box(int device, u3d_stream_t stream, const u3d_src_t* src, 
  * (the table of u3d_gn_bwd_finalize over Ctot channels; exact-2x levels use u3d_gn_bwd_apply with the constant 8 folded in). */
 int u3d_gn_bwd_apply_children(int device, u3d_stream_t stream, const float* dlow, const float* x, const float* coef, int Ctot, int coff,
                               int N, int D1, int H1, int W1, int C, int ez, int ey, int ex, int relu_mask, float* out);
+/* Per-(n, channel) sums of the nearest-upsampled image of x_low (N,D1,H1,W1,C) taken on the LOW-RES grid: stats[N][C][2] += (sum w x,
+ * sum w x^2), w = children of a low-res voxel = (2 + [ez && z == 0]) (2 + [ey && y == 0]) (2 + [ex && x == 0]) — the GroupNorm statistics
+ * of the upsampled half of such a level's virtual concat (u3d_gn_finalize takes them with scale 1). */
+int u3d_chan_stats_children(int device, u3d_stream_t stream, const float* x_low, int N, int D1, int H1, int W1, int C, int ez, int ey,
+                            int ex, double* stats);
 int u3d_nearest_childsum_add(int device, u3d_stream_t stream, const float* dv, const float* x_low, float* dlow, double* gstats, int N,
                              int D, int H, int W, int D1, int H1, int W1, int C, const int32_t* zlo, const int32_t* ylo,
                              const int32_t* xlo, int cz, int cy, int cx);

@@ -240,6 +240,70 @@ extern "C" int u3d_chan_stats(int device, u3d_stream_t stream, const u3d_src_t* 
     return 0;
 }
 
+// Per-(n, channel) sums of the NEAREST-UPSAMPLED image of a low-res tensor without touching the upsampled grid: along an axis that is
+// upsampled n -> 2n + 1 (the pooled size of an odd level, buildingblocks.py:614 to the skip's size) low-res cell 0 has three children,
+// every other cell two; along an exact-2x axis every cell has two.  stats[N][C][2] += (sum_v w(v) x, sum_v w(v) x^2), w = the
+// number of children of low-res voxel v.  (Round 6: such a level's GroupNorm statistics were taken by u3d_chan_stats over the
+// VIRTUAL concat — every full-resolution voxel through the index maps: 164 us at the 40 x 85 x 85 level of the shipped 80 x 170 x 170
+// patch, against the 18 MB low-res tensor read once here.)
+__global__ __launch_bounds__(256) void chan_stats_children_kernel(const float* __restrict__ x, int D1, int H1, int W1, int C, int Q, int rows,
+                                                                  int ez, int ey, int ex, double* __restrict__ stats) {
+    extern __shared__ float red[];  // [rows][Q][8]
+    const int t = threadIdx.x, n = blockIdx.y;
+    const long long V = (long long)D1 * H1 * W1;
+    const long long per = cdivll_dev(V, gridDim.x);
+    const long long vbeg = (long long)blockIdx.x * per, vend = min(V, vbeg + per);
+    const int row = t / Q, qd = t - row * Q;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (row < rows) {
+        for (long long v = vbeg + row; v < vend; v += rows) {
+            const int xi = (int)(v % W1);
+            const long long r = v / W1;
+            const int yi = (int)(r % H1), zi = (int)(r / H1);
+            const float wgt = (float)((2 + (ez && zi == 0)) * (2 + (ey && yi == 0)) * (2 + (ex && xi == 0)));
+            const f32x4 q = *reinterpret_cast<const f32x4*>(x + ((size_t)n * V + v) * C + 4 * qd);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s1[e] += wgt * q[e];
+                s2[e] += wgt * (q[e] * q[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[(row * Q + qd) * 8 + e] = s1[e];
+            red[(row * Q + qd) * 8 + 4 + e] = s2[e];
+        }
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {
+        const int qd2 = c >> 2, e = c & 3;
+        float a = 0.f, b = 0.f;
+        for (int r = 0; r < rows; ++r) {
+            a += red[(r * Q + qd2) * 8 + e];
+            b += red[(r * Q + qd2) * 8 + 4 + e];
+        }
+        u3d_atomic_add_f64(&stats[((size_t)n * C + c) * 2 + 0], (double)a);
+        u3d_atomic_add_f64(&stats[((size_t)n * C + c) * 2 + 1], (double)b);
+    }
+}
+
+extern "C" int u3d_chan_stats_children(int device, u3d_stream_t stream, const float* x_low, int N, int D1, int H1, int W1, int C, int ez,
+                                       int ey, int ex, double* stats) {
+    U3D_ENTER(device);
+    U3D_REQUIRE(x_low && stats && N > 0 && N <= 65535 && D1 > 0 && H1 > 0 && W1 > 0 && C > 0 && C % 4 == 0 && C <= 1024 &&
+                    ((uintptr_t)x_low & 15) == 0, "u3d_chan_stats_children: bad argument (C a multiple of 4, <= 1024, 16-byte aligned)");
+    const int Q = C / 4, rows = 256 / Q;
+    const long long V = (long long)D1 * H1 * W1;
+    long long bpn = cdivll(V, (long long)rows * 16);
+    const long long want = cdivll(1024, N);
+    if (bpn > want) bpn = want;
+    if (bpn < 1) bpn = 1;
+    hipLaunchKernelGGL(chan_stats_children_kernel, dim3((unsigned)bpn, (unsigned)N), dim3(256), (size_t)rows * Q * 8 * sizeof(float),
+                       (hipStream_t)stream, x_low, D1, H1, W1, C, Q, rows, ez, ey, ex, stats);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
 // =================================================================================================
 // GroupNorm finalize: (n,group) mean / rstd from channel sums, then the per-channel affine table.
 // One block per sample: threads = channels (coalesced loads of the per-channel sums into LDS), then one thread per group

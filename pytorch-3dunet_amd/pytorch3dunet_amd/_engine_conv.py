@@ -151,6 +151,13 @@ class ConvLayers:
         if st0 is not None and st1 is not None and src.exact2x and self.fused_stats:
             # every low-res voxel is replicated exactly 8x: reuse the producer's sums
             return st0, src.C0, 1.0, st1, src.C1, 8.0
+        plus = src.plus
+        if st0 is not None and plus is not None and any(plus) and self.fused_stats and src.C1 % 4 == 0 and src.t1.dtype == _F32:
+            # n -> 2n + 1 along some axes: the first low-res cell of such an axis has three children, every other cell two — the sums of
+            # the upsampled half as a weighted pass over the LOW-RES tensor (round 6), the skip half from its producer
+            st1w = pool.take(src.N * src.C1 * 2)
+            nat.call("u3d_chan_stats_children", dev.index, _stream(dev), _p(src.t1), src.N, src.D1, src.H1, src.W1, src.C1, *plus, _p(st1w))
+            return st0, src.C0, 1.0, st1w, src.C1, 1.0
         st = pool.take(src.N * src.C * 2)
         s = src.struct()
         nat.call("u3d_chan_stats", dev.index, _stream(dev), ctypes.byref(s), src.N, src.D, src.H, src.W, _p(st))
@@ -535,6 +542,9 @@ class ConvLayers:
             s_dz2 = VSrc(c.dz).struct()
             wpd1 = self._packed_sub(rec, 15, dev)
             mask = (ctypes.c_int * 3)(*(2 * e for e in plus))
+            # (the two slab launches are one tile-time each on less than half of the chip's block slots — a 2-voxel slab in 4 x 8 x 8
+            # tiles — but running them side by side on two streams was measured in round 6: each takes twice as long, 192 + 214 us
+            # against 114 + 113; the waste is MFMA work on dead tile rows, not idle slots)
             for box in slab_boxes((Dd, Hh, Ww), plus, 3):
                 nat.call("u3d_conv3d_box", dev.index, _stream(dev), ctypes.byref(s_dz2), _p(wpd1), _p(dv), Nn, Dd, Hh, Ww, C1,
                          (ctypes.c_int * 6)(*box), mask,

@@ -100,6 +100,7 @@ _PROTOS = {
          c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     ),
     "u3d_gn_bwd_finalize_split_supported": (c_int, [c_int, c_int, c_int]),
+    "u3d_chan_stats_children": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "u3d_adam_step": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int64, c_double, c_double, c_double, c_double, c_double, c_int64]),
     "u3d_gn_bwd_finalize_split": (
         c_int,
