@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define U3D_VERSION 122 /* 122: round 6 — u3d_gn_finalize_split / u3d_gn_bwd_finalize_split (compact half tables of a virtual-concat layer), u3d_adam_step, tuning key 18; 121: u3d_convtr3d_fwd_t8_b16_ex; 120: flat 5 x 10 x 10 tile of the bf16-storage convolutions (u3d_conv3d_bf16_tile_variant planes = 5), 24 tuning keys; 119: round 5 — ragged volumes on the persistent kernels, u3d_conv3d_variant / u3d_conv3d_wgrad_variant; 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K); 118: u3d_se_*_b16 */
+#define U3D_VERSION 122 /* 122: round 6 — u3d_gn_finalize_split / u3d_gn_bwd_finalize_split (compact half tables of a virtual-concat layer), u3d_adam_step, u3d_chan_stats_children, u3d_pack_weights_batch_cells, tuning key 18; 121: u3d_convtr3d_fwd_t8_b16_ex; 120: flat 5 x 10 x 10 tile of the bf16-storage convolutions (u3d_conv3d_bf16_tile_variant planes = 5), 24 tuning keys; 119: round 5 — ragged volumes on the persistent kernels, u3d_conv3d_variant / u3d_conv3d_wgrad_variant; 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K); 118: u3d_se_*_b16 */
 
 #define U3D_OK 0
 #define U3D_EINVAL (-1)  /* bad shape / argument */
@@ -106,6 +106,14 @@ typedef struct {
 } u3d_pack_desc_t;
 int u3d_pack_weights_batch(int device, u3d_stream_t stream, const u3d_pack_desc_t* descs_device, int n,
                            int64_t total_floats);
+/* The same images (modes 0..3, bit for bit) at memory rate (round 6): a block owns one (16-channel contraction chunk, 32-channel
+ * n-tile) cell of one image — contiguous runs of the reference layout read with 16-byte loads, transposed through LDS, written 16 bytes
+ * per lane — instead of one 4-byte gather at a stride of 27 floats per element.  descs: as above, but `first` = first BLOCK of the image
+ * within the launch; an image takes u3d_pack_weights_cells_blocks(w, Cin, Cout, mode, cin_stride) blocks (its cells + one tail block;
+ * 0 = not eligible — w not 16-byte aligned, or Cin / Cout / cin_stride not multiples of 4 — such an image stays on
+ * u3d_pack_weights_batch); total_blocks = the sum over the descriptors. */
+long long u3d_pack_weights_cells_blocks(const float* w, int Cin, int Cout, int mode, int cin_stride);
+int u3d_pack_weights_batch_cells(int device, u3d_stream_t stream, const u3d_pack_desc_t* descs_device, int n, long long total_blocks);
 
 /* ---- Conv3d 3x3x3, stride 1, pad 1, bias=False ------------------------------------------------
  * Replaces nn.Conv3d(in,out,3,padding=1,bias=False) (buildingblocks.py:56) forward, and — called with

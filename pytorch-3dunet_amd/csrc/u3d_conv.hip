@@ -1957,6 +1957,154 @@ __global__ void pack_weights_batch_kernel(const u3d_pack_desc_t* __restrict__ de
     }
 }
 
+// ---- the same images through LDS (round 6) --------------------------------------------------------------------------------------------
+// The thread-per-slot kernel above gathers every 4-byte element at a stride of 27 floats (and another 27 * cstride between lanes): 64
+// cache lines per wave load, 0.10 ms per bench step for 33 MB of images.  Here a block owns one CELL of one image — a 16-channel
+// contraction chunk x a 32-channel n-tile: 13,824 floats of the master weight that are 32 (contraction over the weight's input
+// channels: modes 0 / 2) or 16 (over its output channels: modes 1 / 3) CONTIGUOUS runs of the reference layout — reads them with
+// 16-byte loads into an odd-stride LDS tile and writes all fragments of the cell 16 bytes per lane: the standard image, the paired-y
+// and 16-column images of a layer with <= 16 produced channels, or the pre-summed sub-pixel images (same summation order as
+// sp::pack_elem / spd::pack_elem: bit-identical).  One extra block per image writes its zero prefetch tail.  Needs 16-byte aligned
+// runs: cstride, Cin and Cout multiples of 4 and an aligned base (u3d_pack_weights_cells_blocks returns 0 otherwise: those images
+// stay on the kernel above).
+namespace pk {
+constexpr int RS0 = 433;  // [32 n rows][16 k x 27 taps + 1]  (odd: the 32 lanes of a fragment read hit 32 banks)
+constexpr int RS1 = 865;  // [16 k rows][32 n x 27 taps + 1]
+constexpr int TILE = 32 * RS0;  // 13,856 floats >= 16 * RS1
+}  // namespace pk
+
+__host__ __device__ inline long long pack_cells_of(int Cin, int Cout, int mode) {  // cells of one image (without the tail block)
+    const int K = (mode == 0 || mode == 2) ? Cin : Cout, Nn = (mode == 0 || mode == 2) ? Cout : Cin;
+    return (long long)((K + 15) / 16) * ((Nn + 31) / 32);
+}
+
+__global__ __launch_bounds__(256) void pack_weights_cells_kernel(const u3d_pack_desc_t* __restrict__ descs, int n) {
+    __shared__ float tile[pk::TILE];
+    const int t = threadIdx.x;
+    int di = 0;
+    {
+        int lo = 0, hi = n - 1;  // last descriptor with first <= blockIdx.x
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (descs[mid].first <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        di = lo;
+    }
+    const u3d_pack_desc_t d = descs[di];
+    const int mode = d.mode, Cin = d.Cin, Cout = d.Cout;
+    const int cstride = d.cin_stride > 0 ? d.cin_stride : d.Cin;
+    const bool geo0 = mode == 0 || mode == 2;       // rows = produced channels of the image (weight's OUTPUT channels), k = its input channels
+    const int K = geo0 ? Cin : Cout, Nn = geo0 ? Cout : Cin;
+    const int nchunks = (K + 15) / 16, ntot = (Nn + 31) / 32;
+    const int b = (int)((long long)blockIdx.x - d.first);
+    f32x4* out4 = reinterpret_cast<f32x4*>(d.packed);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const bool narrow = mode <= 1 && Nn <= 16;  // the paired-y and 16-column images follow the standard one
+    const long long std4 = ((long long)nchunks * cv::NSTEP + cv::PACK_PAD) * ntot * 64;  // f32x4 slots of the standard image
+    const long long pair4 = ((long long)nchunks * cv::NSTEP_PAIRY + cv::PACK_PAD) * 64;
+    if (b >= nchunks * ntot) {
+        // tail block: the zero k-steps / fragments behind the last chunk of every image of this descriptor
+        if (mode <= 1) {
+            for (int i = t; i < cv::PACK_PAD * ntot * 64; i += 256) out4[(long long)nchunks * cv::NSTEP * ntot * 64 + i] = zero4;
+            if (narrow) {
+                for (int i = t; i < cv::PACK_PAD * 64; i += 256) {
+                    out4[std4 + (long long)nchunks * cv::NSTEP_PAIRY * 64 + i] = zero4;
+                    out4[std4 + pair4 + (long long)nchunks * cv::NSTEP_N16 * 64 + i] = zero4;
+                }
+            }
+        } else {
+            const int pad = mode == 2 ? sp::PACK_PAD : spd::PACK_PAD;
+            const int nfrag = mode == 2 ? sp::NFRAG : spd::NFRAG;
+            for (int i = t; i < pad * ntot * 64; i += 256) out4[(long long)nchunks * nfrag * ntot * 64 + i] = zero4;
+        }
+        return;
+    }
+    const int ch = b / ntot, ntg = b - ch * ntot;
+    // ---- the cell's runs -> LDS (zero where the cell overhangs the channel counts)
+    const int kval = min(16, K - ch * 16), nval = min(32, Nn - ntg * 32);  // valid contraction / produced channels of this cell
+    const int rows = geo0 ? nval : kval, run = (geo0 ? kval : nval) * 27;   // runs and their length in floats (a multiple of 4)
+    const int RS = geo0 ? pk::RS0 : pk::RS1;
+    if (kval < 16 || nval < 32) {
+        for (int i = t; i < pk::TILE; i += 256) tile[i] = 0.f;
+        __syncthreads();
+    }
+    {
+        const float* base = geo0 ? d.w + ((size_t)(ntg * 32) * cstride + ch * 16) * 27 : d.w + ((size_t)(ch * 16) * cstride + ntg * 32) * 27;
+        const int run4 = run >> 2, total4 = rows * run4;
+        for (int i0 = t; i0 < total4; i0 += 256 * 4) {  // four loads in flight per thread
+            f32x4 v[4];
+            int rr[4], oo[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 256 * u;
+                rr[u] = i / run4;
+                oo[u] = i - rr[u] * run4;
+                v[u] = i < total4 ? *reinterpret_cast<const f32x4*>(base + (size_t)rr[u] * cstride * 27 + 4 * oo[u]) : zero4;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + 256 * u < total4) {
+                    float* dst = tile + rr[u] * RS + 4 * oo[u];
+                    dst[0] = v[u][0], dst[1] = v[u][1], dst[2] = v[u][2], dst[3] = v[u][3];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // 27 taps of (produced channel nl, contraction channel kl) of this cell; tap order of the image: forward t, data gradient 26 - t
+    auto row_of = [&](int nl, int kl) { return geo0 ? tile + nl * pk::RS0 + kl * 27 : tile + kl * pk::RS1 + nl * 27; };
+    if (mode <= 1) {
+        const bool flip = mode == 1;
+        for (int i = t; i < cv::NSTEP * 64; i += 256) {
+            const int st = i >> 6, lane = i & 63;
+            const int tap = st >> 1, kl = 8 * (st & 1) + 4 * (lane >> 5), nl = lane & 31;
+            const float* r0 = row_of(nl, kl) + (flip ? 26 - tap : tap);
+            const int ks = geo0 ? 27 : pk::RS1;  // stride between consecutive contraction channels
+            out4[(((long long)ch * cv::NSTEP + st) * ntot + ntg) * 64 + lane] = f32x4{r0[0], r0[ks], r0[2 * ks], r0[3 * ks]};
+        }
+        if (narrow) {
+            const int ks = geo0 ? 27 : pk::RS1;
+            for (int i = t; i < cv::NSTEP_PAIRY * 64; i += 256) {  // paired-y image: 3 x 4 x 3 tap window, columns 16-31 shifted by one row
+                const int st = i >> 6, lane = i & 63;
+                const int tp = st >> 1, tz = tp / 12, ty4 = (tp / 3) % 4, tx = tp % 3;
+                const int ty = ty4 - ((lane & 31) >> 4);
+                f32x4 v = zero4;
+                if (ty >= 0 && ty <= 2) {
+                    const int tap = (tz * 3 + ty) * 3 + tx, kl = 8 * (st & 1) + 4 * (lane >> 5), nl = lane & 15;
+                    const float* r0 = row_of(nl, kl) + (flip ? 26 - tap : tap);
+                    v = f32x4{r0[0], r0[ks], r0[2 * ks], r0[3 * ks]};
+                }
+                out4[std4 + ((long long)ch * cv::NSTEP_PAIRY + st) * 64 + lane] = v;
+            }
+            for (int i = t; i < cv::NSTEP_N16 * 64; i += 256) {  // 16-column image: one k-step per tap over the chunk's 16 channels
+                const int tap = i >> 6, lane = i & 63;
+                const int kl = 4 * (lane >> 4), nl = lane & 15;
+                const float* r0 = row_of(nl, kl) + (flip ? 26 - tap : tap);
+                out4[std4 + pair4 + ((long long)ch * cv::NSTEP_N16 + tap) * 64 + lane] = f32x4{r0[0], r0[ks], r0[2 * ks], r0[3 * ks]};
+            }
+        }
+    } else if (mode == 2) {
+        for (int i = t; i < sp::NFRAG * 64; i += 256) {
+            const int f = i >> 6, lane = i & 63;
+            const int st = sp::frag_tab().st[f];
+            const int kl = 8 * (st & 1) + 4 * (lane >> 5), nl = lane & 31;
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = sp::frag_value(row_of(nl, kl + j), f);  // (a zero row where the cell overhangs: sums of zeros)
+            out4[(((long long)ch * sp::NFRAG + f) * ntot + ntg) * 64 + lane] = v;
+        }
+    } else {
+        for (int i = t; i < spd::NFRAG * 64; i += 256) {
+            const int f = i >> 6, lane = i & 63;
+            const int kl = 8 * (f & 1) + 4 * (lane >> 5), nl = lane & 31;
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = spd::frag_value(row_of(nl, kl + j), f);
+            out4[(((long long)ch * spd::NFRAG + f) * ntot + ntg) * 64 + lane] = v;
+        }
+    }
+}
+
 // =================================================================================================
 __global__ void conv3d_naive_kernel(const u3d_src_t src, const float* __restrict__ w, float* __restrict__ out,
                                     int N, int D, int H, int W, int Cin, int Cout, int relu, int flip) {
@@ -2055,6 +2203,23 @@ extern "C" int u3d_pack_weights_batch(int device, u3d_stream_t stream, const u3d
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(pack_weights_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, descs_device, n,
                        (long long)total_floats);
+    U3D_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" long long u3d_pack_weights_cells_blocks(const float* w, int Cin, int Cout, int mode, int cin_stride) {
+    // blocks one image takes in u3d_pack_weights_batch_cells (its cells + the tail block); 0 = this image cannot go through the cell
+    // kernel (runs not 16-byte aligned) and stays on u3d_pack_weights_batch
+    const int cs = cin_stride > 0 ? cin_stride : Cin;
+    if (Cin <= 0 || Cout <= 0 || mode < 0 || mode > 3 || Cin % 4 != 0 || Cout % 4 != 0 || cs % 4 != 0 || ((uintptr_t)w & 15) != 0) return 0;
+    return pack_cells_of(Cin, Cout, mode) + 1;
+}
+
+extern "C" int u3d_pack_weights_batch_cells(int device, u3d_stream_t stream, const u3d_pack_desc_t* descs_device, int n,
+                                            long long total_blocks) {
+    U3D_ENTER(device);
+    U3D_REQUIRE(descs_device && n > 0 && total_blocks > 0 && total_blocks < 0x7fffffffLL, "u3d_pack_weights_batch_cells: bad argument");
+    hipLaunchKernelGGL(pack_weights_cells_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, descs_device, n);
     U3D_LAUNCH_CHECK();
     return 0;
 }

@@ -117,22 +117,11 @@ __host__ __device__ inline long long packed_floats(int C1, int Cout) {
     return ((long long)((C1 + 15) / 16) * NFRAG + PACK_PAD) * ((Cout + 31) / 32) * 256;
 }
 
-__device__ __forceinline__ float pack_elem(const float* __restrict__ w, int Cout, int cstride, int C1, int nchunks, int ncb,
-                                           long long idx) {
-    const int j = (int)(idx & 3);
-    const int lane = (int)((idx >> 2) & 63);
-    long long r = idx >> 8;
-    const int cb = (int)(r % ncb);
-    r /= ncb;
-    const int f = (int)(r % NFRAG);
-    const int ch = (int)(r / NFRAG);
-    if (ch >= nchunks) return 0.f;  // the trailing zero fragments
+// value of fragment f for ONE (n-channel, k-channel) pair whose 27 original taps start at wr (global memory or an LDS copy)
+__device__ __forceinline__ float frag_value(const float* wr, int f) {
     const FragTab& ft = frag_tab();
     const int st = ft.st[f];
     const int tap = st >> 1, ci = cls(tap, ft.i[f]);
-    const int kc = ch * 16 + 8 * (st & 1) + 4 * (lane >> 5) + j;
-    const int nc = cb * 32 + (lane & 31);
-    if (kc >= C1 || nc >= Cout) return 0.f;
     const int hh[3] = {tap / 9, (tap / 3) % 3, tap % 3};
     const int pp[3] = {ci >> 2, (ci >> 1) & 1, ci & 1};
     int lo[3], num[3];  // original taps t in [lo, lo+num) of parity p read halo offset h
@@ -145,12 +134,28 @@ __device__ __forceinline__ float pack_elem(const float* __restrict__ w, int Cout
             num[d] = hh[d] == 1 ? 2 : 1;
         }
     }
-    const float* wr = w + ((size_t)nc * cstride + kc) * 27;
     float v = 0.f;
     for (int a = 0; a < num[0]; ++a)
         for (int b = 0; b < num[1]; ++b)
             for (int c = 0; c < num[2]; ++c) v += wr[((lo[0] + a) * 3 + lo[1] + b) * 3 + lo[2] + c];
     return v;
+}
+
+__device__ __forceinline__ float pack_elem(const float* __restrict__ w, int Cout, int cstride, int C1, int nchunks, int ncb,
+                                           long long idx) {
+    const int j = (int)(idx & 3);
+    const int lane = (int)((idx >> 2) & 63);
+    long long r = idx >> 8;
+    const int cb = (int)(r % ncb);
+    r /= ncb;
+    const int f = (int)(r % NFRAG);
+    const int ch = (int)(r / NFRAG);
+    if (ch >= nchunks) return 0.f;  // the trailing zero fragments
+    const int st = frag_tab().st[f];
+    const int kc = ch * 16 + 8 * (st & 1) + 4 * (lane >> 5) + j;
+    const int nc = cb * 32 + (lane & 31);
+    if (kc >= C1 || nc >= Cout) return 0.f;
+    return frag_value(w + ((size_t)nc * cstride + kc) * 27, f);
 }
 
 // ConvTranspose3d(k=3, s=2, p=1) weight (Cin, Cout, 3,3,3) in the same fragment layout (54 fragments per chunk): every (class,
@@ -204,6 +209,22 @@ __host__ __device__ inline long long packed_floats(int K, int C1) {
 // f32x4 index (((ch*128 + f)*ntot + ntg)*64 + lane), element j; f = tap*2 + octet, tap = (dz+1)*16 + (dy+1)*4 + (dx+1);
 // k (dz channel) = ch*16 + 8*octet + 4*(lane>>5) + j, n (low-res channel) = ntg*32 + (lane&31).  `w` points at the first
 // upsampled input channel of the (K, cstride, 3,3,3) weight.
+// value of fragment f (tap = f >> 1) for ONE (dz channel k, low-res channel n) pair whose 27 original taps start at wr
+__device__ __forceinline__ float frag_value(const float* wr, int f) {
+    const int tap = f >> 1;
+    const int di[3] = {tap >> 4, (tap >> 2) & 3, tap & 3};
+    int lo[3], num[3];
+    for (int d = 0; d < 3; ++d) {
+        lo[d] = di[d] == 0 ? 2 : (di[d] == 1 ? 1 : 0);
+        num[d] = (di[d] == 1 || di[d] == 2) ? 2 : 1;
+    }
+    float v = 0.f;
+    for (int a = 0; a < num[0]; ++a)
+        for (int b = 0; b < num[1]; ++b)
+            for (int c = 0; c < num[2]; ++c) v += wr[((lo[0] + a) * 3 + lo[1] + b) * 3 + lo[2] + c];
+    return v;
+}
+
 __device__ __forceinline__ float pack_elem(const float* __restrict__ w, int K, int cstride, int C1, int nchunks, int ntot,
                                            long long idx) {
     const int j = (int)(idx & 3);
@@ -214,21 +235,9 @@ __device__ __forceinline__ float pack_elem(const float* __restrict__ w, int K, i
     const int f = (int)(r % NFRAG);
     const int ch = (int)(r / NFRAG);
     if (ch >= nchunks) return 0.f;
-    const int tap = f >> 1;
     const int kc = ch * 16 + 8 * (f & 1) + 4 * (lane >> 5) + j;
     const int nc = ntg * 32 + (lane & 31);
     if (kc >= K || nc >= C1) return 0.f;
-    const int di[3] = {tap >> 4, (tap >> 2) & 3, tap & 3};
-    int lo[3], num[3];
-    for (int d = 0; d < 3; ++d) {
-        lo[d] = di[d] == 0 ? 2 : (di[d] == 1 ? 1 : 0);
-        num[d] = (di[d] == 1 || di[d] == 2) ? 2 : 1;
-    }
-    const float* wr = w + ((size_t)kc * cstride + nc) * 27;
-    float v = 0.f;
-    for (int a = 0; a < num[0]; ++a)
-        for (int b = 0; b < num[1]; ++b)
-            for (int c = 0; c < num[2]; ++c) v += wr[((lo[0] + a) * 3 + lo[1] + b) * 3 + lo[2] + c];
-    return v;
+    return frag_value(w + ((size_t)kc * cstride + nc) * 27, f);
 }
 }  // namespace spd

@@ -20,6 +20,9 @@ from ._native import U3DSrc
 from ._engine_base import *  # noqa: F401,F403  (explicit __all__: helpers, records, activation codes)
 
 
+_PACK_ELEMENTWISE = os.environ.get("U3D_PACK_ELEMENTWISE", "0") == "1"  # A/B: every image through the thread-per-slot packer
+
+
 class WeightImages:
     """mixin: needs self._pack_cache, self._salt, self._const, self.bf16, self.split, self.small_cin, self._sub_pairs"""
 
@@ -244,23 +247,36 @@ class WeightImages:
             tab = self._pack_tables = {}
         ent = tab.get(key)
         if ent is None:
-            descs = (nat.U3DPackDesc * len(stale))()
-            bufs, first = [], 0
-            for i, (w, mode) in enumerate(stale):
-                wptr, Cin, cmode, cstride, n = self._pack_shape(w, mode)
+            # two descriptor tables: images whose runs are 16-byte aligned go through the LDS cell kernel (u3d_pack_weights_batch_cells,
+            # `first` = first block), the rest through the element-wise kernel (`first` = first float)
+            shapes = [self._pack_shape(w, mode) for w, mode in stale]
+            blocks = [0 if _PACK_ELEMENTWISE else lib.u3d_pack_weights_cells_blocks(wptr, Cin, w.shape[0], cmode, cstride)
+                      for (w, _), (wptr, Cin, cmode, cstride, _) in zip(stale, shapes)]
+            bufs = []
+            for (w, mode), (wptr, Cin, cmode, cstride, n) in zip(stale, shapes):
                 hit = self._pack_cache.get((id(w), mode))
-                buf = hit[1] if hit is not None and hit[1].numel() == n and hit[1].device == dev else _empty(
-                    n, dtype=_F32, device=dev)
-                bufs.append(buf)
-                descs[i].w, descs[i].packed, descs[i].first = wptr, buf.data_ptr(), first
-                descs[i].Cout, descs[i].Cin, descs[i].mode, descs[i].cin_stride = w.shape[0], Cin, cmode, cstride
-                first += n
-            host = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8)
-            ent = (host.to(dev), bufs, first)
+                bufs.append(hit[1] if hit is not None and hit[1].numel() == n and hit[1].device == dev else _empty(n, dtype=_F32, device=dev))
+            tables = []
+            for cells in (True, False):
+                idx = [i for i, b in enumerate(blocks) if (b > 0) == cells]
+                descs = (nat.U3DPackDesc * max(len(idx), 1))()
+                first = 0
+                for k, i in enumerate(idx):
+                    (w, mode), (wptr, Cin, cmode, cstride, n) = stale[i], shapes[i]
+                    descs[k].w, descs[k].packed, descs[k].first = wptr, bufs[i].data_ptr(), first
+                    descs[k].Cout, descs[k].Cin, descs[k].mode, descs[k].cin_stride = w.shape[0], Cin, cmode, cstride
+                    first += blocks[i] if cells else n
+                host = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8)
+                tables.append((host.to(dev), len(idx), first))
+            ent = (tables, bufs)
             tab.clear()  # one live table per (set of stale weights): parameters are re-packed together every step
             tab[key] = ent
-        table, bufs, total = ent
-        nat.call("u3d_pack_weights_batch", dev.index, _stream(dev), _p(table), len(stale), total)
+        tables, bufs = ent
+        (tc, nc, bc), (te, ne, fe) = tables
+        if nc:
+            nat.call("u3d_pack_weights_batch_cells", dev.index, _stream(dev), _p(tc), nc, bc)
+        if ne:
+            nat.call("u3d_pack_weights_batch", dev.index, _stream(dev), _p(te), ne, fe)
         for (w, mode), buf in zip(stale, bufs):
             self._pack_cache[(id(w), mode)] = (self._ver(w), buf)
 

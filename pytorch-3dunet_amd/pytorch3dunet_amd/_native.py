@@ -58,6 +58,8 @@ _PROTOS = {
     "u3d_packed_weight_floats": (c_size_t, [c_int, c_int, c_int]),
     "u3d_pack_weights": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "u3d_pack_weights_batch": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int64]),
+    "u3d_pack_weights_cells_blocks": (c_int64, [c_void_p, c_int, c_int, c_int, c_int]),
+    "u3d_pack_weights_batch_cells": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int64]),
     "u3d_conv3d": (
         c_int,
         [c_int, c_void_p, POINTER(U3DSrc), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,

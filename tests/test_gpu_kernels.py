@@ -722,3 +722,44 @@ def test_small_cin_first_layer_kernels(N, Cin, Cout, D, H, W):
     dg = g.grad.double()
     s_ref = torch.stack([dg.sum(dim=(2, 3, 4)), (dg * x.double()).sum(dim=(2, 3, 4))], dim=-1)
     assert U.relerr(gst.cpu(), s_ref) < 1e-4
+
+
+@pytest.mark.parametrize("Cout,Cin,C0", [(32, 16, 0), (16, 32, 0), (32, 96, 32), (36, 20, 8), (256, 128, 0), (64, 192, 64), (8, 12, 4)])
+def test_cell_packer_writes_the_element_wise_packers_images_bit_for_bit(Cout, Cin, C0):
+    """u3d_pack_weights_batch_cells (round 6: contiguous runs of the reference layout -> LDS -> 16-byte fragment stores) against
+    u3d_pack_weights_batch (one strided 4-byte gather per element) for every image kind the executor packs: forward / data-gradient
+    images of a whole weight (incl. the paired-y and 16-column images of <= 16 produced channels and cells that overhang the channel
+    counts), of the channel slice [0, C0) of a decoder's first conv, and the pre-summed sub-pixel images of its slice [C0, Cin)"""
+    U, nat, VSrc, _p, _stream = _mods()
+    lib = nat.get_lib()
+    torch.manual_seed(Cout * 1000 + Cin)
+    w = torch.randn(Cout, Cin, 3, 3, 3, device=U.DEV)
+    jobs = [(w.data_ptr(), Cin, 0, 0, lib.u3d_packed_weight_floats(Cin, Cout, 0)), (w.data_ptr(), Cin, 1, 0, lib.u3d_packed_weight_floats(Cin, Cout, 1))]
+    if C0:
+        C1 = Cin - C0
+        up = w.data_ptr() + C0 * 27 * 4
+        jobs += [(w.data_ptr(), C0, 0, Cin, lib.u3d_packed_weight_floats(C0, Cout, 0)), (w.data_ptr(), C0, 1, Cin, lib.u3d_packed_weight_floats(C0, Cout, 1)),
+                 (up, C1, 2, Cin, lib.u3d_subpixel_packed_floats(C1, Cout)), (up, C1, 3, Cin, lib.u3d_subpixel_dgrad_packed_floats(Cout, C1)),
+                 (up, C1, 0, Cin, lib.u3d_packed_weight_floats(C1, Cout, 0)), (up, C1, 1, Cin, lib.u3d_packed_weight_floats(C1, Cout, 1))]
+    outs = {}
+    for cells in (False, True):
+        descs = (nat.U3DPackDesc * len(jobs))()
+        bufs, first = [], 0
+        for i, (wptr, ci, mode, cstride, n) in enumerate(jobs):
+            buf = torch.full((n,), float("nan"), device=U.DEV)
+            bufs.append(buf)
+            descs[i].w, descs[i].packed, descs[i].first = wptr, buf.data_ptr(), first
+            descs[i].Cout, descs[i].Cin, descs[i].mode, descs[i].cin_stride = Cout, ci, mode, cstride
+            nb = lib.u3d_pack_weights_cells_blocks(wptr, ci, Cout, mode, cstride)
+            assert nb > 0
+            first += nb if cells else n
+        table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(U.DEV)
+        nat.call("u3d_pack_weights_batch_cells" if cells else "u3d_pack_weights_batch", 0, _stream(U.DEV), _p(table), len(jobs), first)
+        torch.cuda.synchronize()
+        outs[cells] = bufs
+    for i, (a, b) in enumerate(zip(outs[False], outs[True])):
+        assert not torch.isnan(b).any(), (i, jobs[i][1:4])
+        assert torch.equal(a, b), (i, jobs[i][1:4], int((a != b).sum()))
+    # not eligible: unaligned base / channel counts that are not multiples of 4 -> 0 blocks (the executor keeps those on the old kernel)
+    assert lib.u3d_pack_weights_cells_blocks(w.data_ptr() + 4, Cin, Cout, 0, 0) == 0
+    assert lib.u3d_pack_weights_cells_blocks(w.data_ptr(), 6, Cout, 0, 0) == 0 and lib.u3d_pack_weights_cells_blocks(w.data_ptr(), Cin, Cout, 0, 6) == 0

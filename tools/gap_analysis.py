@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Where a bench step's wall time goes between kernels: from a `rocprofv3 --kernel-trace --output-format csv` trace compute, per
-step (a step starts at a launch of --marker, default the one-per-step weight packer), the wall time first start -> next step's
+step (a step starts at a launch of --marker, default the one-per-step weight packer, "pack_weights_"), the wall time first start -> next step's
 first start, the sum of kernel durations, the idle time between consecutive kernels and which kernels the idle time follows.
 
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace -- python bench.py --no-cpu-baseline --no-roofline --no-extras --steps 3 --warmup 3
@@ -24,7 +24,7 @@ def short(name):
 
 def main():
     d = sys.argv[1]
-    marker = "pack_weights_batch_kernel"
+    marker = "pack_weights_"
     if "--marker" in sys.argv:
         marker = sys.argv[sys.argv.index("--marker") + 1]
     files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
