@@ -152,7 +152,8 @@ __global__ __launch_bounds__(256) void conv3d_small_fwd_mfma_kernel(const SmallF
     using namespace sc;
     constexpr int K = 27 * CIN;
     constexpr int KS = (K + 3) / 4;  // k-steps of 4
-    __shared__ __attribute__((aligned(16))) float xs[HV * CIN];
+    constexpr int NH = (HV * CIN + 255) / 256;  // halo elements per thread
+    __shared__ __attribute__((aligned(16))) float xsb[2][HV * CIN];
     __shared__ double sred[16][2];
     const int t = threadIdx.x, l = t & 63, w = t >> 6;
     const int j = l & 15, kq = l >> 4;  // B column (voxel of the M-tile) / A row (output channel); k index within a step
@@ -174,27 +175,60 @@ __global__ __launch_bounds__(256) void conv3d_small_fwd_mfma_kernel(const SmallF
     // voxel of column j in M-tile mt: z = w, y = 2*mt + (j >> 3), x = j & 7
     const int vbase = (w * HY + (j >> 3)) * HX + (j & 7);
     const int ntiles = p.tz * p.ty * p.tx;
-    for (int tile = blockIdx.x; tile < ntiles; tile += p.B) {
-        int tt = tile;
-        const int txi = tt % p.tx;
-        tt /= p.tx;
-        const int tyi = tt % p.ty;
-        const int tzi = tt / p.ty;
-        const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
-        __syncthreads();  // the previous tile's reads of xs are done (and sred is initialised)
-        for (int i = t; i < HV * CIN; i += 256) {
-            const int c = i % CIN;
-            const int hv = i / CIN;
-            const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
-            const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-            float v = 0.f;
-            if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                v = p.x[((size_t)((n * D + gz) * H + gy) * W + gx) * CIN + c];
-                if (p.affine) v = v * p.affine[((size_t)n * CIN + c) * 2] + p.affine[((size_t)n * CIN + c) * 2 + 1];
-            }
-            xs[hv * CIN + c] = v;
+    // this thread's halo elements (element i = hv * CIN + c): constant coordinates inside the tile, and the GroupNorm affine of its channel
+    int hrel[NH];  // (hz * H + hy) * W + hx relative to the halo origin, in voxels; -1: beyond the 600 halo voxels
+    int hco[NH];   // hz | hy << 8 | hx << 16 | c << 24
+    float ha[NH], hb[NH];
+#pragma unroll
+    for (int it = 0; it < NH; ++it) {
+        const int i = t + 256 * it;
+        const int c = i % CIN, hv = i / CIN;
+        const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+        hrel[it] = i < HV * CIN ? (hz * H + hy) * W + hx : -1;
+        hco[it] = hz | (hy << 8) | (hx << 16) | (c << 24);
+        ha[it] = p.affine ? p.affine[((size_t)n * CIN + c) * 2] : 1.f;
+        hb[it] = p.affine ? p.affine[((size_t)n * CIN + c) * 2 + 1] : 0.f;
+    }
+    auto origin = [&](int tile, int& z0, int& y0, int& x0) {
+        const int txi = tile % p.tx;
+        const int tt = tile / p.tx;
+        z0 = (tt / p.ty) * TZ, y0 = (tt % p.ty) * TY, x0 = txi * TX;
+    };
+    // raw halo values of a tile into registers (loads only: the affine and the LDS stores follow after the current tile's MFMAs, so the
+    // memory round trip of tile t+1 runs under the arithmetic of tile t — round 6; fill -> barrier -> compute -> barrier per tile
+    // left every load latency exposed: 93 us for a layer that moves 142 MB)
+    auto halo_load = [&](int tile, float (&hv)[NH], unsigned& inside) {
+        int z0, y0, x0;
+        origin(tile, z0, y0, x0);
+        const int base = ((n * D + z0 - 1) * H + y0 - 1) * W + x0 - 1;
+        inside = 0;
+#pragma unroll
+        for (int it = 0; it < NH; ++it) {
+            const int gz = z0 - 1 + (hco[it] & 255), gy = y0 - 1 + ((hco[it] >> 8) & 255), gx = x0 - 1 + ((hco[it] >> 16) & 255);
+            const bool in = hrel[it] >= 0 && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            inside |= (in ? 1u : 0u) << it;
+            hv[it] = in ? p.x[(size_t)(base + hrel[it]) * CIN + (hco[it] >> 24)] : 0.f;
         }
-        __syncthreads();
+    };
+    auto halo_store = [&](float* xs, const float (&hv)[NH], unsigned inside) {
+#pragma unroll
+        for (int it = 0; it < NH; ++it)
+            if (t + 256 * it < HV * CIN) xs[t + 256 * it] = ((inside >> it) & 1u) ? hv[it] * ha[it] + hb[it] : 0.f;  // zero padding stays 0
+    };
+    float hv[NH];
+    unsigned hin = 0;
+    int cur = 0;
+    if ((int)blockIdx.x < ntiles) {
+        halo_load(blockIdx.x, hv, hin);
+        halo_store(xsb[0], hv, hin);
+    }
+    __syncthreads();  // (also: sred initialised)
+    for (int tile = blockIdx.x; tile < ntiles; tile += p.B) {
+        int z0, y0, x0;
+        origin(tile, z0, y0, x0);
+        const float* xs = xsb[cur];
+        const bool has_next = tile + p.B < ntiles;
+        if (has_next) halo_load(tile + p.B, hv, hin);
         f32x4s acc[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4s{0.f, 0.f, 0.f, 0.f};
@@ -222,6 +256,9 @@ __global__ __launch_bounds__(256) void conv3d_small_fwd_mfma_kernel(const SmallF
                 s2 += v * v;
             }
         }
+        if (has_next) halo_store(xsb[cur ^ 1], hv, hin);
+        __syncthreads();  // the next tile's halo is complete; nobody reads the current buffer any more
+        cur ^= 1;
     }
     if (p.out_stats) {
         // the 16 lanes j of a k-group hold 16 voxel columns of the same four channels: butterfly over j, then the four waves
@@ -259,7 +296,10 @@ extern "C" int u3d_conv3d_small_cin_fwd(int device, u3d_stream_t stream, const f
     p.N = N, p.D = D, p.H = H, p.W = W, p.Cin = Cin, p.Cout = Cout, p.relu = relu;
     p.tz = (D + sc::TZ - 1) / sc::TZ, p.ty = (H + sc::TY - 1) / sc::TY, p.tx = (W + sc::TX - 1) / sc::TX;
     const long long ntiles = (long long)p.tz * p.ty * p.tx;
-    long long B = 2048 / N;  // ~8 blocks per CU in total
+    // 2 blocks per CU in total: every block ends with one f64 atomic pair per output channel on the SAME 2*Cout addresses per sample, and
+    // same-address atomics retire at ~24 ns each — measured on the bench workload (tools/small_bench.py, round 6): 2048 blocks 86 us
+    // (38 us without the statistics), 1024 blocks 62, 512 blocks 57, 4096 blocks 138 (key 19: A/B of the block count)
+    long long B = (g_u3d_tune[19] > 0 ? g_u3d_tune[19] : 512) / N;
     if (B < 1) B = 1;
     if (B > ntiles) B = ntiles;
     p.B = (int)B;
@@ -307,7 +347,8 @@ __global__ __launch_bounds__(256) void conv3d_small_bwd_kernel(const SmallBwdPar
     constexpr int C1 = CIN + 1;
     constexpr int NCOL = 27 * C1;
     constexpr int NCT = (NCOL + 15) / 16;
-    __shared__ float xs[HV * C1];  // [hv][CIN+1]: raw x, then the in-bounds indicator
+    constexpr int NH = (HV + 255) / 256;  // halo voxels per thread (3)
+    __shared__ float xsb[2][HV * C1];  // [hv][CIN+1]: raw x, then the in-bounds indicator; two buffers (round 6, see below)
     const int t = threadIdx.x, l = t & 63, w = t >> 6;
     const int n = blockIdx.y;
     const int j = l & 15, kk = l >> 4;
@@ -327,44 +368,78 @@ __global__ __launch_bounds__(256) void conv3d_small_bwd_kernel(const SmallBwdPar
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) acc[rt][ct] = f32x4s{0.f, 0.f, 0.f, 0.f};
     const int ntiles = p.tz * p.ty * p.tx;
-    for (int tile = blockIdx.x; tile < ntiles; tile += p.B) {
-        int tt = tile;
-        const int txi = tt % p.tx;
-        tt /= p.tx;
-        const int tyi = tt % p.ty;
-        const int tzi = tt / p.ty;
-        const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
-        // A operands of the whole tile: dz[voxel(step, kk)][k = j + 16*rt], zero outside the volume / beyond Cout
-        float a[RT][16];
-        {
-            const int z = z0 + w;
+    auto origin = [&](int tile, int& z0, int& y0, int& x0) {
+        const int txi = tile % p.tx;
+        const int tt = tile / p.tx;
+        z0 = (tt / p.ty) * TZ, y0 = (tt % p.ty) * TY, x0 = txi * TX;
+    };
+    // A operands of a whole tile: dz[voxel(step, kk)][k = j + 16*rt], zero outside the volume / beyond Cout
+    auto a_load = [&](int tile, float (&a)[RT][16]) {
+        int z0, y0, x0;
+        origin(tile, z0, y0, x0);
+        const int z = z0 + w;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int y = y0 + (s >> 1), x = x0 + (s & 1) * 4 + kk;
-                const bool vin = z < D && y < H && x < W;
-                const size_t vox = (size_t)((n * D + (vin ? z : 0)) * H + (vin ? y : 0)) * W + (vin ? x : 0);
+        for (int s_ = 0; s_ < 16; ++s_) {
+            const int y = y0 + (s_ >> 1), x = x0 + (s_ & 1) * 4 + kk;
+            const bool vin = z < D && y < H && x < W;
+            const size_t vox = (size_t)((n * D + (vin ? z : 0)) * H + (vin ? y : 0)) * W + (vin ? x : 0);
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    const int k = j + 16 * rt;
-                    const float v = p.dz[vox * Cout + (k < Cout ? k : 0)];
-                    a[rt][s] = (vin && k < Cout) ? v : 0.f;
-                }
+            for (int rt = 0; rt < RT; ++rt) {
+                const int k = j + 16 * rt;
+                const float v = p.dz[vox * Cout + (k < Cout ? k : 0)];
+                a[rt][s_] = (vin && k < Cout) ? v : 0.f;
             }
         }
-        __syncthreads();  // previous tile's B reads are done
-        for (int i = t; i < HV; i += 256) {
-            const int hz = i / (HY * HX), rem = i - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
-            const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-            const bool in = gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    };
+    // raw halo voxels of a tile into registers; the LDS stores follow after the current tile's MFMAs (round 6: both operand fetches of
+    // tile t+1 run under the arithmetic of tile t — with fill -> barrier -> compute -> barrier per tile every load latency was exposed)
+    auto halo_load = [&](int tile, float (&hx)[NH][CIN], unsigned& inside) {
+        int z0, y0, x0;
+        origin(tile, z0, y0, x0);
+        inside = 0;
+#pragma unroll
+        for (int it = 0; it < NH; ++it) {
+            const int i = t + 256 * it;
+            const int hz = i / (HY * HX), rem = i - hz * (HY * HX), hy = rem / HX, hxx = rem - hy * HX;
+            const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hxx;
+            const bool in = i < HV && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            inside |= (in ? 1u : 0u) << it;
             const float* src = p.x + ((size_t)((n * D + (in ? gz : 0)) * H + (in ? gy : 0)) * W + (in ? gx : 0)) * CIN;
 #pragma unroll
-            for (int c = 0; c < CIN; ++c) xs[i * C1 + c] = in ? src[c] : 0.f;
-            xs[i * C1 + CIN] = in ? 1.f : 0.f;
+            for (int c = 0; c < CIN; ++c) hx[it][c] = in ? src[c] : 0.f;
         }
-        __syncthreads();
+    };
+    auto halo_store = [&](float* xs, const float (&hx)[NH][CIN], unsigned inside) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int so = ((s >> 1) * HX + (s & 1) * 4) * C1;
+        for (int it = 0; it < NH; ++it) {
+            const int i = t + 256 * it;
+            if (i < HV) {
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) xs[i * C1 + c] = hx[it][c];
+                xs[i * C1 + CIN] = ((inside >> it) & 1u) ? 1.f : 0.f;
+            }
+        }
+    };
+    float a[RT][16], hx[NH][CIN];
+    unsigned hin = 0;
+    int cur = 0;
+    if ((int)blockIdx.x < ntiles) {
+        a_load(blockIdx.x, a);
+        halo_load(blockIdx.x, hx, hin);
+        halo_store(xsb[0], hx, hin);
+    }
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < ntiles; tile += p.B) {
+        const float* xs = xsb[cur];
+        const bool has_next = tile + p.B < ntiles;
+        float an[RT][16];
+        if (has_next) {
+            a_load(tile + p.B, an);
+            halo_load(tile + p.B, hx, hin);
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) {
+            const int so = ((s_ >> 1) * HX + (s_ & 1) * 4) * C1;
             float b[NCT];
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) b[ct] = xs[bbase + so + boff[ct]];
@@ -372,8 +447,17 @@ __global__ __launch_bounds__(256) void conv3d_small_bwd_kernel(const SmallBwdPar
             for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][s], b[ct], acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][s_], b[ct], acc[rt][ct], 0, 0, 0);
         }
+        if (has_next) {
+            halo_store(xsb[cur ^ 1], hx, hin);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int s_ = 0; s_ < 16; ++s_) a[rt][s_] = an[rt][s_];
+        }
+        __syncthreads();  // the next tile's halo is complete; nobody reads the current buffer any more
+        cur ^= 1;
     }
     // fold the four z-plane partials (fixed order 0+1+2+3) through LDS, then write the block's partial.
     // D layout of 16x16x4: col = lane & 15, row = 4*(lane >> 4) + reg
@@ -493,7 +577,7 @@ __global__ __launch_bounds__(64 * FIN_GROUPS) void conv3d_small_bwd_finalize_ker
 
 static int small_bwd_blocks(int N, int D, int H, int W) {
     const long long ntiles = (long long)((D + 3) / 4) * ((H + 7) / 8) * ((W + 7) / 8);
-    long long B = 1024 / (N > 0 ? N : 1);  // ~4 blocks per CU in total (latency hiding); each walks its share of tiles
+    long long B = (g_u3d_tune[20] > 0 ? g_u3d_tune[20] : 1024) / (N > 0 ? N : 1);  // ~4 blocks per CU in total (latency hiding); each walks its share of tiles (key 20: A/B)
     if (B < 1) B = 1;
     if (B > ntiles) B = ntiles;
     return (int)B;

@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--only", default="fwd,dgrad,wgrad")
     ap.add_argument("--patch", default="64,128,128")
     ap.add_argument("--layers", default="", help="comma-separated layer names (default: all)")
+    ap.add_argument("--no-stats", action="store_true", help="forward without the output statistics (what the f64 atomics of the epilogue cost)")
     args = ap.parse_args()
     only = args.only.split(",")
     N = args.batch
@@ -81,7 +82,7 @@ def main():
             kn = lib.u3d_conv3d_workspace_floats(N, D, H, W, Cin, Cout)
             kws = torch.empty(kn, device=dev) if kn else None
             ms = timeit(lambda: nat.call("u3d_conv3d_ex", 0, _stream(dev), ctypes.byref(s), _p(wp), _p(y), N, D, H, W, Cout, 1,
-                                         _p(st), None, None, None, _p(kws), kn), args.iters)
+                                         None if args.no_stats else _p(st), None, None, None, _p(kws), kn), args.iters)
             line += f"fwd {ms:7.3f} ms {flops / ms / 1e9:6.1f} TF | "
             tot["fwd"][0] += ms
             tot["fwd"][1] += flops
