@@ -110,25 +110,6 @@ def pmc_traffic(family):
         return None, None
 
 
-def rocprof_fraction(family):
-    """(fraction of the fp32-MFMA peak, TFLOP/s, source file) of a kernel family by rocprofv3 KERNEL DURATIONS, from the newest committed
-    table (profiles/*_tables.md, generated by tools/prof_summary.py from `rocprofv3 --kernel-trace --stats` of this very command).  The
-    bench line's own `frac` is the HIP-event figure measured live; the two differ by the few percent the event brackets cost / hide
-    (DESIGN.md section 6), and the judge recomputes the rocprofv3 one from profiles/ — so both are in the line, labelled."""
-    import glob
-    import re
-
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_tables.md")), reverse=True):
-        try:
-            for ln in open(f):
-                m = re.match(r"\| `%s[^`]*` \| ([0-9.]+) \| ([0-9.]+) \| ([0-9.]+) \| ([0-9.]+) \|" % re.escape(family), ln)
-                if m:
-                    return float(m.group(4)), float(m.group(3)), os.path.relpath(f, ROOT)
-        except Exception:
-            continue
-    return None, None, None
-
-
 def self_launch(n):
     """`python bench.py --gpus N` without an external launcher: re-exec this command line under torch.distributed.run with N
     local ranks (the reference itself is single-process `nn.DataParallel`, unet3d/trainer.py:202-205; here it is one process per
@@ -348,15 +329,13 @@ def main():
             d = summ[dom]
             achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
             traffic, traffic_src = pmc_traffic(dom)
-            frac_rp, tf_rp, rp_src = rocprof_fraction(dom)
             executed = sum(v["flops"] for v in summ.values())
             out["roofline"] = {
                 "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                 "frac_source": "HIP events on the launching stream, this run",
-                # the same family by rocprofv3 kernel durations, from the newest committed profile of this command (a few percent
-                # below the HIP-event figure: an event pair closes before the kernel's last wave has drained)
-                "frac_rocprof": frac_rp, "achieved_rocprof": tf_rp, "frac_rocprof_source": rp_src,
+                # (the same family by rocprofv3 kernel durations is in profiles/*_tables.md, generated from a profile of this command; it is
+                # not repeated here: a number read from a committed file would sit beside the live one as if it described HEAD — ADVICE r05)
                 "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,
                 "launches": d["calls"], "avg_launch_ms": round(d["ms"] / d["calls"], 4),

@@ -2328,6 +2328,23 @@ extern "C" int u3d_conv3d_box(int device, u3d_stream_t stream, const u3d_src_t* 
 }
 
 constexpr int SPLITK_MAX = 16;
+// ONE statement of the split-K decision, used by the launcher (conv3d_impl) and by the host-only query u3d_conv3d_variant (ADVICE r05:
+// the query restated it with 256 CUs hard-coded): ksplit blocks per (tile, 32-channel block) so that ~2 blocks per CU exist, over runs
+// of cps chunks; 1 = no split.
+static int g_u3d_ncu_seen = 256;  // CU count of the last device a launcher ran on (the query has no device argument; MI355X: 256)
+static int splitk_count(int ncu, long long ntiles, int ntot, int nchunks, int* cps_out) {
+    long long ks = (2ll * ncu) / (ntiles * ntot);
+    if (ks > nchunks) ks = nchunks;
+    if (ks > SPLITK_MAX) ks = SPLITK_MAX;
+    int cps = nchunks, ksplit = 1;
+    if (ks >= 2) {
+        cps = (nchunks + (int)ks - 1) / (int)ks;
+        ksplit = (nchunks + cps - 1) / cps;
+    }
+    if (cps_out) *cps_out = cps;
+    return ksplit;
+}
+
 static bool splitk_shape(int N, int D, int H, int W, int Cin, int Cout) {
     const long long items = (long long)N * cdiv(D, cv::TZ) * cdiv(H, cv::TY) * cdiv(W, cv::TX) * cdiv(Cout, 32);
     return Cin > 16 && Cout % 4 == 0 && Cout <= 1024 && items < 256;
@@ -2420,14 +2437,9 @@ static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, co
     if (!boxed && ws && p.vec && p.ovec && ((uintptr_t)ws & 15) == 0 && splitk_shape(N, D, H, W, Cin, Cout) && g_u3d_tune[7] != 2) {
         int ncu = 0;
         if (int e = device_cu_count(device, &ncu)) return e;
+        g_u3d_ncu_seen = ncu;
         const long long items = ntiles * p.ntot, out_elems = (long long)N * D * H * W * Cout;
-        long long ks = (2ll * ncu) / items;
-        if (ks > p.nchunks) ks = p.nchunks;
-        if (ks > SPLITK_MAX) ks = SPLITK_MAX;
-        if (ks >= 2) {
-            p.cps = cdiv(p.nchunks, (int)ks);
-            p.ksplit = cdiv(p.nchunks, p.cps);
-        }
+        p.ksplit = splitk_count(ncu, ntiles, p.ntot, p.nchunks, &p.cps);
         if (p.ksplit >= 2 && (long long)p.ksplit * out_elems <= ws_floats) {
             p.ncb = p.ntot;  // NT = 1: most blocks
             p.part_stride = out_elems;
@@ -2722,10 +2734,8 @@ extern "C" int u3d_conv3d_variant(int N, int D, int H, int W, int Cin, int Cout,
     const long long ntiles = (long long)N * cdiv(D, cv::TZ) * cdiv(H, cv::TY) * cdiv(W, cv::TX);
     const int nchunks = cdiv(Cin, 16), ntot = cdiv(Cout, 32);
     if (has_workspace && splitk_shape(N, D, H, W, Cin, Cout) && g_u3d_tune[7] != 2) {
-        long long ks = (2ll * 256) / (ntiles * ntot);
-        if (ks > nchunks) ks = nchunks;
-        if (ks > SPLITK_MAX) ks = SPLITK_MAX;
-        if (ks >= 2 && cdiv(nchunks, cdiv(nchunks, (int)ks)) >= 2) return 3;
+        // (the launcher additionally needs the workspace to hold ksplit partial tensors: u3d_conv3d_workspace_floats sizes it for that)
+        if (splitk_count(g_u3d_ncu_seen, ntiles, ntot, nchunks, nullptr) >= 2) return 3;
     }
     const bool ragged = D % cv::TZ != 0 || H % cv::TY != 0 || W % cv::TX != 0;
     if (src_kind == 2 || g_u3d_tune[3] == 1 || (g_u3d_tune[3] == 2 && ragged)) return 0;

@@ -90,18 +90,31 @@ class TreeSync(GradSync):
         return hook
 
     def _on_forward(self, _module, _args) -> None:
-        if self._in_backward:
-            # the previous backward never reached _end_of_backward: drop its half-sent state (the step was invalid on this rank;
-            # buckets it did launch were complete collectives, so the ranks' sequences still pair up)
-            self._in_backward = False
-            for work, _bucket in self._pending:
-                try:
-                    work.wait()
-                except Exception:
-                    pass
-            self._pending.clear()
-            self._left = [len(b) for b in self.buckets]
-            self._flat = [None, None]
+        if not self._in_backward:
+            return
+        # A forward that runs INSIDE an autograd pass is not a new step: torch.utils.checkpoint around the model, or a forward issued
+        # from a backward hook, re-enter the model while this very backward is still exchanging — leave its state alone.
+        try:
+            in_graph_task = torch._C._current_graph_task_id() != -1
+        except AttributeError:  # (very old torch: no way to tell; keep the re-arm, the common case)
+            in_graph_task = False
+        if in_graph_task:
+            return
+        # The previous backward never reached _end_of_backward (it raised after the first hook fired): drop its half-sent state.  The
+        # step was invalid on THIS rank only — the other ranks may have launched more buckets than this one did, so after such an abort
+        # the ranks' collective sequences are only guaranteed to pair up again if every rank aborts the step (or the group is
+        # re-initialised); a mismatch shows as a hang / size error of the next collective, never as silently wrong gradients.
+        self._in_backward = False
+        for work, _bucket in self._pending:
+            try:
+                work.wait()
+            except Exception as e:  # noqa: BLE001  (the collective of an aborted step may itself have failed: say so, then go on)
+                import warnings
+
+                warnings.warn(f"u3d TreeSync: a gradient all-reduce of the aborted backward pass failed while being drained: {e!r}")
+        self._pending.clear()
+        self._left = [len(b) for b in self.buckets]
+        self._flat = [None, None]
 
     def _ready(self, bi: int) -> None:
         if self.world == 1 and not self.force_single:

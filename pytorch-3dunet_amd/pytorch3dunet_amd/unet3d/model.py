@@ -40,7 +40,7 @@ class AbstractUNet(nn.Module):
     def __init__(self, in_channels, out_channels, final_sigmoid, basic_module, f_maps=64, layer_order="gcr",
                  num_groups=8, num_levels=4, is_segmentation=True, conv_kernel_size=3, pool_kernel_size=2,
                  conv_padding=1, conv_upscale=2, upsample="default", dropout_prob=0.1, is3d=True, compute_dtype=None,
-                 checkpoint_encoders=None, hip_graph=None, activation_dtype=None):
+                 checkpoint_encoders=None, hip_graph=None, activation_dtype=None, checkpoint_levels=None):
         super().__init__()
         if isinstance(f_maps, int):
             f_maps = number_of_features_per_level(f_maps, num_levels=num_levels)
@@ -99,17 +99,30 @@ class AbstractUNet(nn.Module):
         # 'fp32_split': fp32-grade convolutions on the bf16 matrix pipe (three-way exact operand split, six partial products;
         # engine.UNet3DEngine.split) — same tensors, same tolerances as 'fp32'
         self.compute_split = str(compute_dtype).lower() == "fp32_split"
+        # `checkpoint_encoders: true` (any truthy YAML value: true, 1) recomputes EVERY encoder block in backward.  `checkpoint_levels: k`
+        # (its own key since round 6 — ADVICE r05: an integer `checkpoint_encoders: 1` had silently come to mean "one level") restricts
+        # that to the k encoder levels of highest resolution (the first two levels of a 5-level net hold ~9/10 of the encoder tape; the
+        # deeper ones cost recomputation for a few megabytes each).  An integer `checkpoint_encoders: k` with k >= 2 is still read as
+        # `checkpoint_levels: k` (round-5 configurations).  U3D_CHECKPOINT=1 [+ U3D_CHECKPOINT_LEVELS=k] set the defaults of both keys.
         if checkpoint_encoders is None:
             checkpoint_encoders = os.environ.get("U3D_CHECKPOINT", "0") == "1"
-            if checkpoint_encoders and os.environ.get("U3D_CHECKPOINT_LEVELS", ""):
-                checkpoint_encoders = int(os.environ["U3D_CHECKPOINT_LEVELS"])
-        # `checkpoint_encoders: true` recomputes EVERY encoder block in backward; an integer k only the k encoder levels of highest
-        # resolution (the first two levels of a 5-level net hold ~9/10 of the encoder tape; the deeper ones cost recomputation for a few
-        # megabytes each).  U3D_CHECKPOINT=1 [+ U3D_CHECKPOINT_LEVELS=k] likewise.
+            if checkpoint_encoders and checkpoint_levels is None and os.environ.get("U3D_CHECKPOINT_LEVELS", ""):
+                checkpoint_levels = int(os.environ["U3D_CHECKPOINT_LEVELS"])
         if not isinstance(checkpoint_encoders, (bool, int)) or int(checkpoint_encoders) < 0:
-            raise ValueError(f"checkpoint_encoders must be true / false or a number of encoder levels, got {checkpoint_encoders!r}")
+            raise ValueError(f"checkpoint_encoders must be true / false (or a number of encoder levels >= 2), got {checkpoint_encoders!r}")
+        if not isinstance(checkpoint_encoders, bool) and int(checkpoint_encoders) >= 2 and checkpoint_levels is None:
+            checkpoint_levels = int(checkpoint_encoders)
+        if checkpoint_levels is not None:
+            if isinstance(checkpoint_levels, bool) or not isinstance(checkpoint_levels, int) or checkpoint_levels < 1:
+                raise ValueError(f"checkpoint_levels must be a positive number of encoder levels, got {checkpoint_levels!r} "
+                                 "(to switch checkpointing off set checkpoint_encoders: false)")
+            if checkpoint_levels > len(f_maps):
+                import warnings
+
+                warnings.warn(f"u3d: checkpoint_levels={checkpoint_levels} exceeds the {len(f_maps)} encoder levels of this model: every level is recomputed")
+                checkpoint_levels = len(f_maps)
         self.checkpoint_encoders = bool(checkpoint_encoders)
-        self.checkpoint_levels = None if isinstance(checkpoint_encoders, bool) or not checkpoint_encoders else int(checkpoint_encoders)
+        self.checkpoint_levels = checkpoint_levels if self.checkpoint_encoders else None
         # `activation_dtype: bf16` / U3D_ACT_BF16=1 (with compute_dtype bf16, residual 'gcr' nets): activations and gradients between
         # kernels are stored as bf16 (engine.ResUNetEngine.act_bf16); anything else keeps fp32 storage
         if activation_dtype is None:
@@ -263,7 +276,8 @@ def _variant(name, basic_module, default_levels, is3d, doc):
                               num_levels=num_levels, is_segmentation=is_segmentation, conv_padding=conv_padding,
                               conv_upscale=conv_upscale, upsample=upsample, dropout_prob=dropout_prob, is3d=is3d,
                               compute_dtype=kwargs.get("compute_dtype"), checkpoint_encoders=kwargs.get("checkpoint_encoders"),
-                              hip_graph=kwargs.get("hip_graph"), activation_dtype=kwargs.get("activation_dtype"))
+                              hip_graph=kwargs.get("hip_graph"), activation_dtype=kwargs.get("activation_dtype"),
+                              checkpoint_levels=kwargs.get("checkpoint_levels"))
 
     return type(name, (AbstractUNet,), {"__init__": __init__, "__doc__": doc, "__module__": _THIS_MODULE})
 

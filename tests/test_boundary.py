@@ -394,19 +394,36 @@ def test_models_pickle_and_torch_save_like_the_reference_modules(cfg, tmp_path):
 
 
 def test_checkpoint_encoders_accepts_a_number_of_levels(monkeypatch):
-    """`checkpoint_encoders: true` = every encoder block is recomputed in backward, an integer k = only the k highest-resolution levels
-    (round 5); false / absent = none; the environment variables set the default of the model key"""
+    """`checkpoint_encoders: true` (or any truthy YAML value such as 1) = every encoder block is recomputed in backward;
+    `checkpoint_levels: k` (its own key) = only the k highest-resolution levels; an integer `checkpoint_encoders: k >= 2` is
+    still read as that; false / absent = none; the environment variables set the defaults of the model keys"""
+    import warnings
+
     from pytorch3dunet_amd.unet3d.model import get_model
 
     cfg = dict(name="ResidualUNet3D", in_channels=1, out_channels=1, f_maps=8, num_groups=4)
-    for v, want in ((True, (True, None)), (False, (False, None)), (2, (True, 2)), (1, (True, 1)), (0, (False, None))):
+    for v, want in ((True, (True, None)), (False, (False, None)), (2, (True, 2)), (1, (True, None)), (0, (False, None))):
         m = get_model(dict(cfg, checkpoint_encoders=v))
         assert (m.checkpoint_encoders, m.checkpoint_levels) == want, v
+    m = get_model(dict(cfg, checkpoint_encoders=True, checkpoint_levels=1))
+    assert (m.checkpoint_encoders, m.checkpoint_levels) == (True, 1)
+    m = get_model(dict(cfg, checkpoint_encoders=False, checkpoint_levels=2))
+    assert (m.checkpoint_encoders, m.checkpoint_levels) == (False, None)
+    with pytest.raises(ValueError):
+        get_model(dict(cfg, checkpoint_encoders=True, checkpoint_levels=0))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m = get_model(dict(cfg, checkpoint_encoders=True, checkpoint_levels=9))
+    assert m.checkpoint_levels == 5 and any("exceeds" in str(x.message) for x in w)
     m = get_model(dict(cfg))
     assert (m.checkpoint_encoders, m.checkpoint_levels) == (False, None)
     monkeypatch.setenv("U3D_CHECKPOINT", "1")
     assert get_model(dict(cfg)).checkpoint_levels is None and get_model(dict(cfg)).checkpoint_encoders
     monkeypatch.setenv("U3D_CHECKPOINT_LEVELS", "2")
     assert get_model(dict(cfg)).checkpoint_levels == 2
+    monkeypatch.setenv("U3D_CHECKPOINT_LEVELS", "0")
+    with pytest.raises(ValueError):
+        get_model(dict(cfg))
+    monkeypatch.delenv("U3D_CHECKPOINT_LEVELS")
     with pytest.raises(ValueError):
         get_model(dict(cfg, checkpoint_encoders="yes"))

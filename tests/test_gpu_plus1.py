@@ -175,3 +175,45 @@ def test_model_with_two_n_plus_one_levels_runs_the_windowed_kernels_and_matches(
     assert new <= calls[True] and not (new & calls[False]), (sorted(calls[True]), sorted(calls[False]))
     assert U.relerr(res[True][0], res[False][0]) < 2e-5
     assert ((res[True][1] - res[False][1]).norm() / res[False][1].norm()).item() < 3e-3
+
+
+@pytest.mark.timeout(600)
+def test_no_kernel_of_an_n_plus_one_level_reads_memory_nobody_wrote():
+    """the data gradient of an n -> 2n + 1 level fills only the slab boxes of a full-resolution scratch tensor
+    (`dv`, _engine_conv._dgrad_subpixel) and relies on u3d_nearest_childsum_add reading nothing outside them — and the forward's `part`
+    tensor is written by the windowed kernel plus the slab launches.  Pin both invariants: with every scratch / output buffer
+    NaN-poisoned before use (U3D_POISON=1) the step must produce exactly the gradients of the unpoisoned run."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    code = r'''
+import os, sys, json
+sys.path.insert(0, os.path.join(os.getcwd(), "pytorch-3dunet_amd"))
+import torch
+from pytorch3dunet_amd.unet3d.model import UNet3D
+from pytorch3dunet_amd.unet3d.losses import BCEDiceLoss
+dev = torch.device("cuda", 0)
+out = {}
+for patch in ((12, 42, 26), (10, 21, 37)):          # 42 -> 21 -> 10 and 26 -> 13 -> 6: n -> 2n + 1 along y / x at different levels
+    torch.manual_seed(0)
+    m = UNet3D(1, 1, f_maps=[16, 32, 64], num_groups=8).to(dev).train()
+    x = torch.randn(1, 1, *patch, device=dev); t = (torch.rand(1, 1, *patch, device=dev) > 0.5).float()
+    _, lg = m(x, return_logits=True)
+    BCEDiceLoss()(lg, t).backward()
+    g = torch.cat([p.grad.flatten() for p in m.parameters()])
+    out[str(patch)] = [bool(torch.isfinite(g).all()), float(g.double().abs().sum()), float(lg.double().abs().sum())]
+print("RESULT " + json.dumps(out))
+'''
+    res = {}
+    for poison in ("0", "1"):
+        proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=500, cwd=ROOT,
+                              env=dict(os.environ, U3D_POISON=poison))
+        assert proc.returncode == 0, proc.stderr[-2000:]
+        res[poison] = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    for k, (finite, gsum, lsum) in res["1"].items():
+        assert finite, k
+        assert (gsum, lsum) == tuple(res["0"][k][1:]), (k, res["0"][k], res["1"][k])

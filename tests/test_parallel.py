@@ -107,6 +107,18 @@ def _worker(rank, world, port, out):
         model(shard).mean().backward()
         healed = torch.cat([p.grad.flatten() for p in model.parameters()])
         assert torch.allclose(healed, whole, atol=1e-6, rtol=1e-4) and sync2.launched == 9 and not sync2._in_backward
+        # a forward that runs INSIDE the backward pass (torch.utils.checkpoint around the model, a forward issued from a
+        # hook) is not a new step — the exchange state of the running pass must survive it
+        def reenter(_g):
+            with torch.no_grad():
+                model(shard)
+
+        h = w_first.register_hook(reenter)  # an encoder weight: fires after [decoders | head] went out
+        model.zero_grad()
+        model(shard).mean().backward()
+        h.remove()
+        re = torch.cat([p.grad.flatten() for p in model.parameters()])
+        assert torch.allclose(re, whole, atol=1e-6, rtol=1e-4) and sync2.launched == 11 and not sync2._in_backward
         out.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         out.put((rank, repr(e)))

@@ -1,6 +1,3 @@
-timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k "head" 2>&1 | grep -v '^$' | tail -2
-out=gpurun_out/r06p; mkdir -p $out; export TMPDIR=/tmp
-B="python bench.py --no-cpu-baseline --no-roofline --no-extras"
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $out/trace -- $B --steps 3 --warmup 3 > $out/trace.log 2>&1
-f=$(find $out/trace -name "*kernel_trace.csv" | head -1); mkdir -p $out/t; cp "$f" $out/t/x_kernel_trace.csv; rm -rf $out/trace
-python tools/gap_analysis.py $out/t --list > $out/step_launches.txt; grep -n 'small\|head_' $out/step_launches.txt
+timeout 900 python -m pytest tests/test_gpu_plus1.py tests/test_gpu_kernels.py -x -q -k "nobody_wrote or splitk or small_cin or variants" 2>&1 | grep -v '^$' | tail -5
+B="python bench.py --no-cpu-baseline --no-extras"
+$B 2>&1 | tail -1 | cut -c1-500

@@ -47,7 +47,7 @@ def main():
     torch.manual_seed(0)
     model = get_model(dict(name=args.name, in_channels=args.in_channels, out_channels=args.out_channels, f_maps=args.f_maps,
                            num_levels=args.levels, layer_order="gcr", num_groups=8, final_sigmoid=True,
-                           compute_dtype="bf16" if args.bf16 else ("fp32_split" if args.split else "fp32"), checkpoint_encoders=(args.checkpoint_levels if args.checkpoint_levels > 0 else args.checkpoint),
+                           compute_dtype="bf16" if args.bf16 else ("fp32_split" if args.split else "fp32"), checkpoint_encoders=bool(args.checkpoint or args.checkpoint_levels > 0), checkpoint_levels=(args.checkpoint_levels if args.checkpoint_levels > 0 else None),
                            activation_dtype="bf16" if args.act_bf16 else "fp32", hip_graph=args.graph)).to(dev)
     assert model.native_supported, model._native_blockers
     D, H, W = (int(v) for v in args.patch.split(","))
