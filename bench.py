@@ -194,7 +194,7 @@ def main():
     criterion = BCEDiceLoss()  # fused HIP kernels on the logits (u3d_bce_dice_fwd/_bwd)
 
     # (experiment hooks, off by default: U3D_AB_SLEEP = idle cycles / U3D_AB_COPY = MiB of device-to-device copy inserted per step —
-    # how the step time responds says whether the chip is time- or power-bound, DESIGN.md section 6)
+    # how the step time responds says whether the chip is time- or power-bound, DESIGN.md section 5)
     ab_sleep = int(os.environ.get("U3D_AB_SLEEP", "0"))
     ab_copy = int(os.environ.get("U3D_AB_COPY", "0"))
     ab_buf = torch.empty((2, ab_copy << 18), device=dev) if ab_copy else None

@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE ONLY (see oracle/README or DESIGN.md §5): a CPU restatement, on plain torch tensor algebra, of the
+"""TEST INFRASTRUCTURE ONLY (see oracle/README or DESIGN.md §6): a CPU restatement, on plain torch tensor algebra, of the
 sub-pixel identities that csrc/u3d_subpix.hip builds on.  Nothing under pytorch-3dunet_amd/ imports this module.
 
 The reference computes, for the upsampled half of a decoder's first convolution (buildingblocks.py:491 torch.cat,

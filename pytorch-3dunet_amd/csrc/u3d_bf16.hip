@@ -182,7 +182,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const bf16_conv_params& p, f3
         const int K = p.K;
         T* yout = reinterpret_cast<T*>(p.y);
         // item t + 256 k = channel octet o of voxel v0 + VPK k: everything that depends on k is a compile-time multiple of two strides
-        // (this epilogue was ~1200 of the ~3300 VALU instructions a 64-channel tile executed)
+        // (this epilogue was ~1200 of the ~3300 VALU instructions a 64-channel tile executed; see DESIGN_HISTORY.md 4.7b)
         const int v0 = t / OCT, o = t - v0 * OCT, yv = v0 >> 3, xv = v0 & 7;
         const size_t sY = (size_t)p.W * K, sZ = (size_t)p.H * sY;
         const size_t gbase = ((((size_t)n * p.D + z0) * p.H + y0 + yv) * p.W + x0 + xv) * K + (size_t)nb * NT * 32 + o * 8;
@@ -360,7 +360,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const bf16_conv_params& p, f3
 }
 
 // ABL: timing-only ablation bits that attributed the loop's cost (1 no B loads, 2 no A reads, 4 no staging, 8 no barrier, 16 no epilogue,
-// 32 no prologue staging; results in DESIGN.md 4.7).  Only ABL = 0 is instantiated (-DU3D_CONV_ABL=.. builds: tools/ab_libs.sh).
+// 32 no prologue staging; results in DESIGN_HISTORY.md 4.7).  Only ABL = 0 is instantiated (-DU3D_CONV_ABL=.. builds: tools/ab_libs.sh).
 template <int NT, int ZW, int KS, int ABL = 0, typename T = float>
 __global__ __launch_bounds__(256, ZW == 3 ? 1 : (NT == 2 && ZW == 1 && KS == 3) ? 3 : 2) void conv3d_bf16_kernel(const bf16_conv_params p) {
     using G = tile_geom<ZW, KS>;
@@ -3024,7 +3024,7 @@ extern "C" int u3d_conv3d_f32s(int device, u3d_stream_t stream, const float* x, 
         p.ws = workspace;
     }
     hipStream_t s = (hipStream_t)stream;
-    if (K % 64 == 0 && g_u3d_tune[6] >= 300) {  // TIMING-ONLY ablations (wrong results; DESIGN.md 4.9 quotes them)
+    if (K % 64 == 0 && g_u3d_tune[6] >= 300) {  // TIMING-ONLY ablations (wrong results; DESIGN_HISTORY.md 4.9 quotes them)
         switch (g_u3d_tune[6] - 300) {
             case 2: return launch_f32s<2, 2>(p, s);    // no B-fragment loads in the loop
             case 16: return launch_f32s<2, 16>(p, s);  // prefetches as a burst in front of each tap's MFMAs

@@ -1928,7 +1928,7 @@ __device__ __forceinline__ f32x4 pack_quad(const float* __restrict__ w, int Cout
 
 // all layers of a model in ONE launch: descs (device memory) hold cumulative element offsets in `first` (multiples of 4: every image
 // is a whole number of f32x4 slots).  One thread per f32x4 slot: 16-byte stores, index arithmetic once per four elements (round 4:
-// 0.105 -> 0.0xx ms per step of the bench workload).
+// 0.105 -> 0.0xx ms per step of the bench workload, see DESIGN_HISTORY.md 6; superseded by the LDS cell kernel below).
 __global__ void pack_weights_batch_kernel(const u3d_pack_desc_t* __restrict__ descs, int n, long long total) {
     const long long total4 = total >> 2;
     for (long long g4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; g4 < total4; g4 += (long long)gridDim.x * blockDim.x) {

@@ -3,7 +3,7 @@ nearest-upsample + concat up, 1x1x1 head) — the hot path of pytorch3dunet/unet
 buildingblocks.py:138-227,380-384,482-493 of the reference, run as hand-written gfx950 HIP kernels through the
 C-ABI of include/u3d.h.
 
-Design (DESIGN.md §3-§5):
+Design (DESIGN.md §2-§4):
   * activations live in HBM as NDHWC fp32 torch tensors; skip tensors are never copied (virtual concat),
     the upsampled tensor is never materialised (nearest index maps), GroupNorm apply is fused into the conv
     A-tile load, ReLU and the next GroupNorm's statistics into the conv epilogue;

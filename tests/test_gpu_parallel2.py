@@ -5,7 +5,7 @@ one); the one-rank variant runs the very same worker on every box, so the script
 
 What is asserted on every rank: `.grad` after `loss.backward()` equals the single-process gradient of the CONCATENATED batch (a
 per-sample-mean loss; GroupNorm statistics are per sample, buildingblocks.py:75, so data parallelism is exact), eager and with
-`hip_graph: true`, and the number of collectives per step is what the bucket rule of DESIGN.md section 7 predicts."""
+`hip_graph: true`, and the number of collectives per step is what the bucket rule of DESIGN.md section 8 predicts."""
 import json
 import os
 import subprocess

@@ -4,7 +4,7 @@
 
 Compiles the file to gfx950 assembly with the build's flags, cuts out the first kernel whose mangled name contains the pattern and
 counts VALU / SALU / DS / VMEM / MFMA instructions before the first MFMA loop, inside each loop that holds MFMAs, and after the last.
-This is how round 3 found where the 7.4 VALU instructions per MFMA of the bf16-storage convolution kernel lived:
+This is how round 3 found where the 7.4 VALU instructions per MFMA of the bf16-storage convolution kernel lived (DESIGN_HISTORY.md 4.7b):
 static counts — multiply a loop's by its trip count, and read the epilogue's as an upper bound (it holds every mode's variant).
 """
 import argparse

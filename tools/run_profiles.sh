@@ -23,7 +23,7 @@ rm -rf $out/stats $out/fetch $out/write $out/sq
 tail -1 $out/bench.json.log | cut -c1-400
 # (U3D_PROFILES_CORE=1: only the bench line and its rocprofv3 / PMC evidence — the GPU budget of a round is 90 minutes)
 [ "${U3D_PROFILES_CORE:-0}" = "1" ] && exit 0
-# opt-in paths, layer rates and accuracy probes quoted in DESIGN.md 4.7 / 4.9
+# opt-in paths, layer rates and accuracy probes quoted in DESIGN_HISTORY.md 4.7 / 4.9
 python tools/bf16_bench.py > $out/${tag}_bf16_layer_bench.txt 2>&1
 python tools/bf16_bench.py --fmaps 32 --patch 64,128,128 --batch 2 --levels 1 > $out/${tag}_cfg2_fullres_layer_bench.txt 2>&1
 python tools/f32s_error_probe.py > $out/${tag}_f32s_error_probe.txt 2>&1
