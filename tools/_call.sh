@@ -1,2 +1,1 @@
-U3D_PROFILES_CORE=1 bash tools/run_profiles.sh r06b 2>&1 | tail -3
-ls gpurun_out/r06b
+U3D_POISON=1 timeout 2400 python -m pytest tests -m gpu -q --deselect tests/test_gpu_graph.py -k "not hip_graph and not graph" 2>&1 | grep -v '^$' | tail -12
