@@ -330,12 +330,33 @@ def main():
             achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
             traffic, traffic_src = pmc_traffic(dom)
             executed = sum(v["flops"] for v in summ.values())
+            # the matrix pipe's own ceiling on this box, measured now: a launch of nothing but fp32 MFMAs on register operands, ~8 ms each
+            # (the sustained rate depends on the operand data; random operands are what activations look like)
+            import ctypes
+
+            def mfma_rate(mode):
+                sink = torch.zeros(4, device=dev)
+                flop = ctypes.c_double(0.0)
+                st_ = torch.cuda.current_stream(dev).cuda_stream
+                for _ in range(3):  # ~25 ms of the same load first: the rate depends on the chip's recent power history
+                    nat.call("u3d_debug_mfma_f32_rate", local_rank, st_, sink.data_ptr(), 4000, mode, ctypes.byref(flop))
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                nat.call("u3d_debug_mfma_f32_rate", local_rank, st_, sink.data_ptr(), 4000, mode, ctypes.byref(flop))
+                e1.record()
+                torch.cuda.synchronize()
+                return flop.value / (e0.elapsed_time(e1) * 1e-3) / 1e12
+
+            ceil_rand, ceil_const = mfma_rate(2), mfma_rate(1)
             out["roofline"] = {
                 "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                 "frac_source": "HIP events on the launching stream, this run",
                 # (the same family by rocprofv3 kernel durations is in profiles/*_tables.md, generated from a profile of this command; it is
                 # not repeated here: a number read from a committed file would sit beside the live one as if it described HEAD — ADVICE r05)
+                # NOT the contract's peak: what a bare fp32-MFMA stream sustains on this box right now, by operand data
+                "mfma_ceiling_random_operands": round(ceil_rand, 1), "mfma_ceiling_constant_operands": round(ceil_const, 1),
+                "frac_of_random_operand_ceiling": round(achieved / ceil_rand, 4),
                 "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,
                 "launches": d["calls"], "avg_launch_ms": round(d["ms"] / d["calls"], 4),

@@ -82,6 +82,10 @@ int u3d_set_profile_buffer(void* device_buffer, size_t bytes);
  * against the wall clock so that the launch lasts at least `min_seconds` (0 = unpaced) — the shape of a link-bound RCCL ring
  * all-reduce (a handful of channels moving data at xGMI rate), which a 1-rank process group cannot launch.  Values are unchanged. */
 int u3d_debug_stream_pass(int device, u3d_stream_t stream, float* buf, long long n, int blocks, int passes, double min_seconds);
+/* Measurement aid: 2 blocks per CU of nothing but v_mfma_f32_32x32x2_f32 on register operands (mode 0 zeros, 1 one constant pair, 2
+ * random values per lane and step); *flop_out (host) = FLOPs executed.  Timed by bench.py: the fp32 matrix pipe's sustained rate depends
+ * on the operand data (142 TFLOP/s on random operands, 155-158 on constants) — the ceiling of any roofline fraction on real activations. */
+int u3d_debug_mfma_f32_rate(int device, u3d_stream_t stream, float* sink, int iters, int mode, double* flop_out);
 
 /* ---- weight packing -------------------------------------------------------------------------
  * Reference weights stay nn.Parameters in (Cout,Cin,3,3,3) layout (checkpoint compatibility,

@@ -86,6 +86,54 @@ extern "C" int u3d_debug_stream_pass(int device, u3d_stream_t stream, float* buf
     return 0;
 }
 
+// ---- the matrix pipe's sustained fp32 rate as a function of the OPERAND DATA (round 6; tools/mfma_peak_data.hip is the stand-alone
+// twin).  A launch of 2 blocks per CU that does nothing but v_mfma_f32_32x32x2_f32 on register operands — no memory traffic, no other
+// instruction: mode 0 all-zero operands, 1 one constant pair, 2 N(0,1)-like values that differ per lane and step.  The chip clocks the pipe
+// by the power its operands' toggling draws: mode 2 (what a convolution of real activations looks like) is the ceiling a roofline
+// fraction against the 157.3 TFLOP/s datasheet peak can reach.  bench.py times it beside the step (roofline.mfma_ceiling_*).
+__device__ __forceinline__ float dbg_hash_unit(unsigned x) {
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) {
+        x ^= x >> 16, x *= 0x7feb352dU, x ^= x >> 15, x *= 0x846ca68bU, x ^= x >> 16;
+        s += (float)(x & 0xffffff) * (1.0f / 16777216.0f);
+    }
+    return (s - 2.0f) * 1.7320508f;
+}
+__global__ __launch_bounds__(256) void debug_mfma_rate_kernel(float* __restrict__ sink, int iters, int mode) {
+    f32x16 acc[2];
+    for (int k = 0; k < 2; ++k)
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    float a[16], b[16];
+    const unsigned id = blockIdx.x * 256 + threadIdx.x;
+    for (int i = 0; i < 16; ++i) {
+        a[i] = mode == 0 ? 0.f : (mode == 1 ? 0.37f : dbg_hash_unit(id * 32 + i));
+        b[i] = mode == 0 ? 0.f : (mode == 1 ? -1.21f : dbg_hash_unit(id * 32 + 16 + i));
+    }
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[(u + 5 * k) & 15], acc[k], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int k = 0; k < 2; ++k)
+        for (int r = 0; r < 16; ++r) s += acc[k][r];
+    if (s == 123.456f) sink[0] = s;
+}
+
+// returns (through *flop_out, host memory) the FLOPs the launch executes: blocks x 4 waves x iters x 32 MFMAs x 4096
+extern "C" int u3d_debug_mfma_f32_rate(int device, u3d_stream_t stream, float* sink, int iters, int mode, double* flop_out) {
+    U3D_ENTER(device);
+    U3D_REQUIRE(sink && iters > 0 && mode >= 0 && mode <= 2, "u3d_debug_mfma_f32_rate: bad argument");
+    int ncu = 0;
+    U3D_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+    const int blocks = 2 * ncu;
+    hipLaunchKernelGGL(debug_mfma_rate_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, sink, iters, mode);
+    U3D_LAUNCH_CHECK();
+    if (flop_out) *flop_out = (double)blocks * 4.0 * iters * 32.0 * 4096.0;
+    return 0;
+}
+
 static inline long long cdivll(long long a, long long b) { return (a + b - 1) / b; }
 __device__ __forceinline__ long long cdivll_dev(long long a, long long b) { return (a + b - 1) / b; }
 static inline int grid_for(long long total, int cap = 8192) {

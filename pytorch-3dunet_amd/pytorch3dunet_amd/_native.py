@@ -51,6 +51,7 @@ _PROTOS = {
     # name: (restype, argtypes)
     "u3d_version": (c_int, []),
     "u3d_debug_stream_pass": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_double]),
+    "u3d_debug_mfma_f32_rate": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, POINTER(c_double)]),
     "u3d_last_error": (c_char_p, []),
     "u3d_check_device": (c_int, [c_int]),
     "u3d_set_tuning": (c_int, [c_int, c_int]),
