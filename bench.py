@@ -456,4 +456,16 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001
+        # a rank that dies says WHICH rank it was before the launcher tears the others down (its own summary names the first failure only by
+        # local rank and exit code); the non-zero exit code travels through torch.distributed.run / self_launch to the caller
+        import traceback
+
+        traceback.print_exc()
+        print(f"[bench rank {os.environ.get('RANK', '0')} of {os.environ.get('WORLD_SIZE', '1')}, local rank {os.environ.get('LOCAL_RANK', '0')}] "
+              f"failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        sys.exit(1)

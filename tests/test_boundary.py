@@ -369,6 +369,10 @@ def test_bench_self_launch_fails_at_the_gpu_check_not_at_usage():
                           capture_output=True, text=True, env=env, timeout=300)
     assert proc.returncode != 0
     assert "needs an MI355X" in proc.stderr and "launch with" not in proc.stderr, proc.stderr[-1500:]
+    # a rank that dies names itself (round 6): here the launched ranks die at the same check inside torch.distributed.run
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"],
+                          capture_output=True, text=True, env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), timeout=300)
+    assert proc.returncode == 1 and "[bench rank 0 of 1, local rank 0] failed: AssertionError" in proc.stderr, proc.stderr[-1500:]
 
 
 @pytest.mark.parametrize("cfg", ALL_CFGS[:4], ids=lambda c: c["name"])
