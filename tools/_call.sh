@@ -1,2 +1,3 @@
-python __graft_entry__.py --smoke 2>&1 | grep -E "smoke|Error|error" | cut -c1-400
-U3D_PROFILES_CORE=1 bash tools/run_profiles.sh r06c 2>&1 | tail -2 | cut -c1-300
+U3D_TUNE=22:1 timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k "conv3d_fwd or dgrad or many_tiles" 2>&1 | grep -v '^$' | tail -4
+echo BASE; python tools/layer_bench.py --only fwd,dgrad --iters 10 2>&1 | grep -v amdgpu
+echo W3; U3D_TUNE=22:1 python tools/layer_bench.py --only fwd,dgrad --iters 10 2>&1 | grep -v amdgpu
