@@ -42,6 +42,7 @@
 //   [18] 1 = the one-channel input statistics run on the general u3d_chan_stats kernel — the round-5 form (A/B of the 16-byte kernel,
 //        csrc/u3d_ops.hip).  (A max-pool with the statistics fused into its pass was built and measured in round 6: 77 / 43 / 12 us per level
 //        against 52 + 23 / 14 + 11 / 5 + 8 for the massively parallel pool + a statistics pass — the pool alone moves 6 TB/s; not kept.)
+//   [21] 1 = head forward of the 32 / 64-channel -> 1 / 2-output heads on the vectorised kernel instead of the LDS-rows kernel (A/B)
 //   [19] / [20] total block count of the first-layer forward / backward kernels (csrc/u3d_smallc.hip; 0 = default 512 / 1024)
 int g_u3d_tune[24] = {0};
 

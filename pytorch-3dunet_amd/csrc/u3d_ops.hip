@@ -1452,6 +1452,96 @@ __global__ __launch_bounds__(256) void head_softmax_wide_kernel(const float* __r
     }
 }
 
+// fp32 twin of head_fwd_b16_rows_kernel (round 6): the vectorised kernel lets Cin / 4 lanes share a voxel — one 16-byte load per lane and
+// round, three shuffle rounds per output and a 4-byte store from every 8th lane: 3.1 TB/s on the 268 MB input of the bench workload.  Here
+// a wave copies 64 consecutive voxels with CIN / 4 independent 16-byte loads per lane into its own LDS rows, every lane then owns ONE voxel
+// and a wave-instruction stores 64 consecutive voxels.  Same summation order (head_dot4, then the butterfly's pairing): bit-identical.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void head_fwd_f32_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ b, int N, long long V, int act,
+                                                                float* __restrict__ logits, float* __restrict__ probs) {
+    constexpr int ROW = CIN * 4 + 16, QPV = CIN / 4, G = CIN / 4;  // bytes per LDS row (16-byte pad); quads per voxel = loads per lane
+    __shared__ __attribute__((aligned(16))) char rows[4][64 * ROW];
+    __shared__ __attribute__((aligned(16))) float wsh[COUT * CIN];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    for (int i = t; i < COUT * CIN; i += 256) wsh[i] = w[i];
+    __syncthreads();
+    char* mine = rows[wv];
+    const long long total = (long long)N * V;
+    for (long long v0 = ((long long)blockIdx.x * 4 + wv) * 64; v0 < total; v0 += (long long)gridDim.x * 256) {
+        const long long left = total - v0;  // (>= 1; the last round may hold fewer than 64 voxels)
+        f32x4 it[QPV];
+#pragma unroll
+        for (int i = 0; i < QPV; ++i) {
+            const int item = i * 64 + lane, vox = item / QPV;
+            it[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (vox < left) it[i] = *reinterpret_cast<const f32x4*>(x + (size_t)v0 * CIN + (size_t)item * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < QPV; ++i) {
+            const int item = i * 64 + lane, vox = item / QPV, qc = item - vox * QPV;
+            *reinterpret_cast<f32x4*>(mine + vox * ROW + qc * 16) = it[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float xs[CIN];
+#pragma unroll
+        for (int j = 0; j < QPV; ++j) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(mine + lane * ROW + j * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xs[4 * j + e] = r[e];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float acc[COUT];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+            asm volatile("" ::: "memory");  // (keeps the weight reads inside the round)
+            float pr[G];
+#pragma unroll
+            for (int s_ = 0; s_ < G; ++s_) {
+                const f32x4 wr = *reinterpret_cast<const f32x4*>(wsh + o * CIN + 4 * s_);
+                pr[s_] = head_dot4(xs[4 * s_], xs[4 * s_ + 1], xs[4 * s_ + 2], xs[4 * s_ + 3], wr);
+            }
+#pragma unroll
+            for (int m = G >> 1; m > 0; m >>= 1)
+#pragma unroll
+                for (int s_ = 0; s_ < m; ++s_) pr[s_] = pr[s_] + pr[s_ + m];
+            acc[o] = pr[0] + b[o];
+        }
+        if (lane < left) {
+            const long long idx = v0 + lane;
+            const int n = (int)(idx / V);
+            const long long v = idx - (long long)n * V;
+            float mx = -INFINITY, den = 0.f;
+            if (act == 2) {
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) mx = fmaxf(mx, acc[o]);
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) den += expf(acc[o] - mx);
+            }
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) {
+                const size_t oi = ((size_t)n * COUT + o) * V + v;
+                logits[oi] = acc[o];
+                if (probs) {
+                    float p_ = acc[o];
+                    if (act == 1) p_ = 1.f / (1.f + expf(-acc[o]));
+                    if (act == 2) p_ = expf(acc[o] - mx) / den;
+                    probs[oi] = p_;
+                }
+            }
+        }
+    }
+}
+template <int CIN, int COUT>
+static void launch_head_rows_f32(const float* x, const float* w, const float* b, int N, long long V, int act, float* logits, float* probs,
+                                 hipStream_t st) {
+    long long rounds = ((long long)N * V + 255) / 256;
+    if (rounds > 4096) rounds = 4096;
+    hipLaunchKernelGGL((head_fwd_f32_rows_kernel<CIN, COUT>), dim3((unsigned)rounds), dim3(256), 0, st, x, w, b, N, V, act, logits, probs);
+}
+
 extern "C" int u3d_conv1x1_head_fwd(int device, u3d_stream_t stream, const float* x, const float* w, const float* b,
                                     int N, int64_t V, int Cin, int Cout, int act, float* logits, float* probs) {
     U3D_ENTER(device);
@@ -1474,6 +1564,16 @@ extern "C" int u3d_conv1x1_head_fwd(int device, u3d_stream_t stream, const float
     const bool vec = (Cin % 4 == 0) && (G & (G - 1)) == 0 && G >= 1 && G <= 64 && (((uintptr_t)x | (uintptr_t)w) & 15) == 0;
     hipStream_t st = (hipStream_t)stream;
     const long long tot = (long long)N * V;
+    // the segmentation heads of the shipped configurations (32 or 64 channels -> 1 or 2 outputs): one voxel per lane through LDS rows
+    // (key 21 = 1: the vectorised kernel, A/B; results are bit-identical)
+    if (vec && (Cin == 32 || Cin == 64) && Cout <= 2 && g_u3d_tune[21] != 1) {
+        if (Cin == 64 && Cout == 1) launch_head_rows_f32<64, 1>(x, w, b, N, (long long)V, act, logits, probs, st);
+        else if (Cin == 64) launch_head_rows_f32<64, 2>(x, w, b, N, (long long)V, act, logits, probs, st);
+        else if (Cout == 1) launch_head_rows_f32<32, 1>(x, w, b, N, (long long)V, act, logits, probs, st);
+        else launch_head_rows_f32<32, 2>(x, w, b, N, (long long)V, act, logits, probs, st);
+        U3D_LAUNCH_CHECK();
+        return 0;
+    }
 #define U3D_HEAD_FWD(GG)                                                                                            \
     hipLaunchKernelGGL((head_fwd_vec_kernel<GG, float>), dim3(grid_for(tot * GG, 8192)), dim3(256), 0, st, x, w, b, N, \
                        (long long)V, Cin, Cout, act, logits, probs)

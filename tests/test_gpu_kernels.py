@@ -763,3 +763,29 @@ def test_cell_packer_writes_the_element_wise_packers_images_bit_for_bit(Cout, Ci
     # not eligible: unaligned base / channel counts that are not multiples of 4 -> 0 blocks (the executor keeps those on the old kernel)
     assert lib.u3d_pack_weights_cells_blocks(w.data_ptr() + 4, Cin, Cout, 0, 0) == 0
     assert lib.u3d_pack_weights_cells_blocks(w.data_ptr(), 6, Cout, 0, 0) == 0 and lib.u3d_pack_weights_cells_blocks(w.data_ptr(), Cin, Cout, 0, 6) == 0
+
+
+@pytest.mark.parametrize("N,Cin,Cout,act,V", [(2, 32, 1, 1, 64 * 128), (1, 64, 2, 2, 4099), (1, 32, 2, 0, 777), (3, 64, 1, 1, 65)])
+def test_head_forward_rows_kernel_equals_the_vectorised_kernel_bit_for_bit(N, Cin, Cout, act, V):
+    """round 6: 32 / 64-channel heads with 1 or 2 outputs run one voxel per lane through LDS rows (u3d_set_tuning key 21 = 1 selects the
+    vectorised kernel); same products, same summation order -> identical logits and probabilities, ragged last rounds included"""
+    U, nat, VSrc, _p, _stream = _mods()
+    torch.manual_seed(Cin + Cout)
+    x = torch.randn(N, V, Cin, device=U.DEV)
+    w, b = torch.randn(Cout, Cin, device=U.DEV), torch.randn(Cout, device=U.DEV)
+    outs = []
+    for key in (1, 0):
+        nat.call("u3d_set_tuning", 21, key)
+        try:
+            lg = torch.full((N, Cout, V), float("nan"), device=U.DEV)
+            pr = torch.full((N, Cout, V), float("nan"), device=U.DEV) if act else None
+            nat.call("u3d_conv1x1_head_fwd", 0, _stream(U.DEV), _p(x), _p(w), _p(b), N, V, Cin, Cout, act, _p(lg), _p(pr))
+            torch.cuda.synchronize()
+        finally:
+            nat.call("u3d_set_tuning", 21, 0)
+        outs.append((lg, pr))
+    assert torch.equal(outs[0][0], outs[1][0])
+    if act:
+        assert torch.equal(outs[0][1], outs[1][1])
+    ref = torch.einsum("nvc,oc->nov", x.double(), w.double()) + b.double().view(1, -1, 1)
+    assert U.relerr(outs[1][0], ref) < 1e-5
