@@ -1975,9 +1975,12 @@ constexpr int RS1 = 865;  // [16 k rows][32 n x 27 taps + 1]
 constexpr int TILE = 32 * RS0;  // 13,856 floats >= 16 * RS1
 }  // namespace pk
 
-__host__ __device__ inline long long pack_cells_of(int Cin, int Cout, int mode) {  // cells of one image (without the tail block)
+// A sub-pixel cell carries 128 pre-summed fragments (up to 8 LDS reads per value) against the 54 plain ones of a standard cell: it is dealt
+// to PK_SUBQ blocks of 32 fragments each (every one re-reads the 54 KB cell from L2), so that the launch does not wait for its heaviest cells
+constexpr int PK_SUBQ = 4;
+__host__ __device__ inline long long pack_cells_of(int Cin, int Cout, int mode) {  // blocks of one image (without the tail block)
     const int K = (mode == 0 || mode == 2) ? Cin : Cout, Nn = (mode == 0 || mode == 2) ? Cout : Cin;
-    return (long long)((K + 15) / 16) * ((Nn + 31) / 32);
+    return (long long)((K + 15) / 16) * ((Nn + 31) / 32) * (mode >= 2 ? PK_SUBQ : 1);
 }
 
 __global__ __launch_bounds__(256) void pack_weights_cells_kernel(const u3d_pack_desc_t* __restrict__ descs, int n) {
@@ -2004,7 +2007,8 @@ __global__ __launch_bounds__(256) void pack_weights_cells_kernel(const u3d_pack_
     const bool narrow = mode <= 1 && Nn <= 16;  // the paired-y and 16-column images follow the standard one
     const long long std4 = ((long long)nchunks * cv::NSTEP + cv::PACK_PAD) * ntot * 64;  // f32x4 slots of the standard image
     const long long pair4 = ((long long)nchunks * cv::NSTEP_PAIRY + cv::PACK_PAD) * 64;
-    if (b >= nchunks * ntot) {
+    const int subq = mode >= 2 ? PK_SUBQ : 1;
+    if (b >= nchunks * ntot * subq) {
         // tail block: the zero k-steps / fragments behind the last chunk of every image of this descriptor
         if (mode <= 1) {
             for (int i = t; i < cv::PACK_PAD * ntot * 64; i += 256) out4[(long long)nchunks * cv::NSTEP * ntot * 64 + i] = zero4;
@@ -2021,7 +2025,8 @@ __global__ __launch_bounds__(256) void pack_weights_cells_kernel(const u3d_pack_
         }
         return;
     }
-    const int ch = b / ntot, ntg = b - ch * ntot;
+    const int cell = b / subq, fq = b - cell * subq;  // (sub-pixel images: this block's quarter of the cell's fragments)
+    const int ch = cell / ntot, ntg = cell - ch * ntot;
     // ---- the cell's runs -> LDS (zero where the cell overhangs the channel counts)
     const int kval = min(16, K - ch * 16), nval = min(32, Nn - ntg * 32);  // valid contraction / produced channels of this cell
     const int rows = geo0 ? nval : kval, run = (geo0 ? kval : nval) * 27;   // runs and their length in floats (a multiple of 4)
@@ -2086,8 +2091,9 @@ __global__ __launch_bounds__(256) void pack_weights_cells_kernel(const u3d_pack_
             }
         }
     } else if (mode == 2) {
-        for (int i = t; i < sp::NFRAG * 64; i += 256) {
-            const int f = i >> 6, lane = i & 63;
+        static_assert(sp::NFRAG % PK_SUBQ == 0 && spd::NFRAG % PK_SUBQ == 0, "fragments per sub-block");
+        for (int i = t; i < sp::NFRAG / PK_SUBQ * 64; i += 256) {
+            const int f = fq * (sp::NFRAG / PK_SUBQ) + (i >> 6), lane = i & 63;
             const int st = sp::frag_tab().st[f];
             const int kl = 8 * (st & 1) + 4 * (lane >> 5), nl = lane & 31;
             f32x4 v;
@@ -2096,8 +2102,8 @@ __global__ __launch_bounds__(256) void pack_weights_cells_kernel(const u3d_pack_
             out4[(((long long)ch * sp::NFRAG + f) * ntot + ntg) * 64 + lane] = v;
         }
     } else {
-        for (int i = t; i < spd::NFRAG * 64; i += 256) {
-            const int f = i >> 6, lane = i & 63;
+        for (int i = t; i < spd::NFRAG / PK_SUBQ * 64; i += 256) {
+            const int f = fq * (spd::NFRAG / PK_SUBQ) + (i >> 6), lane = i & 63;
             const int kl = 8 * (f & 1) + 4 * (lane >> 5), nl = lane & 31;
             f32x4 v;
 #pragma unroll
