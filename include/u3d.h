@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define U3D_VERSION 122 /* 122: round 6 — u3d_gn_finalize_split / u3d_gn_bwd_finalize_split (compact half tables of a virtual-concat layer), u3d_adam_step, u3d_chan_stats_children, u3d_pack_weights_batch_cells, tuning key 18; 121: u3d_convtr3d_fwd_t8_b16_ex; 120: flat 5 x 10 x 10 tile of the bf16-storage convolutions (u3d_conv3d_bf16_tile_variant planes = 5), 24 tuning keys; 119: round 5 — ragged volumes on the persistent kernels, u3d_conv3d_variant / u3d_conv3d_wgrad_variant; 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K); 118: u3d_se_*_b16 */
+#define U3D_VERSION 123 /* 123: u3d_conv3d_wgrad_job (the GroupNorm-backward reduction rides in the weight-gradient reduce launch); 122: round 6 — u3d_gn_finalize_split / u3d_gn_bwd_finalize_split (compact half tables of a virtual-concat layer), u3d_adam_step, u3d_chan_stats_children, u3d_pack_weights_batch_cells, tuning key 18; 121: u3d_convtr3d_fwd_t8_b16_ex; 120: flat 5 x 10 x 10 tile of the bf16-storage convolutions (u3d_conv3d_bf16_tile_variant planes = 5), 24 tuning keys; 119: round 5 — ragged volumes on the persistent kernels, u3d_conv3d_variant / u3d_conv3d_wgrad_variant; 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K); 118: u3d_se_*_b16 */
 
 #define U3D_OK 0
 #define U3D_EINVAL (-1)  /* bad shape / argument */
@@ -211,6 +211,31 @@ int u3d_conv3d_wgrad_variant(int N, int D, int H, int W, int Cin, int Cout, int 
 int u3d_conv3d_wgrad_strided(int device, u3d_stream_t stream, const u3d_src_t* src, const float* dz, float* dw,
                              int dw_cin_stride, int N, int D, int H, int W, int Cout, float* workspace,
                              size_t workspace_floats);
+
+/* u3d_conv3d_wgrad_strided with the GroupNorm-backward reduction of the SAME layer's input (u3d_gn_bwd_finalize /
+ * u3d_gn_bwd_finalize_split: one block) riding as one extra block of the launch that reduces the weight gradient: the caller
+ * runs the data gradient (which produces gstats) first, then this.  Results are those of the two separate calls, bit for bit
+ * (same device code, csrc/u3d_gn.h).  job == NULL: plain u3d_conv3d_wgrad_strided; dw_cin_stride == 0: the source's channel count.
+ * u3d_conv3d_wgrad_job_supported(N, C, G): 1 when the reduction of N x C channels in G groups fits the block's LDS.
+ * Reference: the two are separate autograd nodes (ConvolutionBackward0 / NativeGroupNormBackward0 behind buildingblocks.py:56,70). */
+typedef struct u3d_gn_bwd_job {
+    const double* gstats_lo; /* [N][C0][2] sums (sum dg, sum dg * x) of channels [0, C0) */
+    const double* gstats_hi; /* [N][C1][2] sums of channels [C0, C0 + C1), or NULL (C1 == 0: one table) */
+    const float* mean_rstd;  /* [N][G][2] from the forward finalize */
+    const float* gamma;      /* [C] */
+    float* dgamma;           /* [C] out */
+    float* dbeta;            /* [C] out */
+    float* coef;             /* [N][3][C] out: (p, q, r) of dx = p * dg + q * x + r */
+    float* coef_hi;          /* [N][3][C1] out or NULL: (p, hi_scale * q, hi_scale * r) of the upper channels */
+    double count;            /* voxels per sample */
+    int32_t C0, C1, N, G;
+    float hi_scale;
+    int32_t reserved;
+} u3d_gn_bwd_job_t;
+int u3d_conv3d_wgrad_job_supported(int N, int C, int G);
+int u3d_conv3d_wgrad_job(int device, u3d_stream_t stream, const u3d_src_t* src, const float* dz, float* dw, int dw_cin_stride,
+                         int N, int D, int H, int W, int Cout, float* workspace, size_t workspace_floats,
+                         const u3d_gn_bwd_job_t* job);
 
 /* Weight gradient of the upsampled half of a decoder's first convolution (see u3d_subpixel_conv_fwd): the 64 matrices
  * sum_j g_low[j + p - 1 + e] (x) dz[2j + p] (8 parity classes p x 8 tap halves e) over the low-res grid — 8/27 of the

@@ -16,6 +16,7 @@
 #include <utility>
 
 #include "u3d_common.h"
+#include "u3d_gn.h"
 #include "u3d_subpix.h"
 
 // run-time tuning knobs (u3d_set_tuning), for A/B measurements only — results never change:
@@ -1753,9 +1754,17 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
 }
 
 // deterministic second pass of the split-K: block = 64 outputs x 4 split-groups, fixed summation order
+// (has_job: the grid carries ONE extra block that runs the GroupNorm-backward reduction of the layer's input — u3d_conv3d_wgrad_job)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                                           int S, int nchunks, int nkb, int Cin, int Cout, int cstride) {
+                                                           int S, int nchunks, int nkb, int Cin, int Cout, int cstride,
+                                                           int has_job, u3d_gn_bwd_job_t job) {
     __shared__ float red[4][64];
+    if (has_job && blockIdx.x == gridDim.x - 1) {
+        extern __shared__ double shb[];
+        u3d_gn_bwd_finalize_body(job.gstats_lo, job.mean_rstd, job.gamma, job.N, job.C0 + job.C1, job.G, job.count, 1, 1, job.dgamma,
+                                 job.dbeta, job.coef, job.gstats_hi, job.C0, job.hi_scale, job.coef_hi, shb);
+        return;
+    }
     const long long total = (long long)Cin * 27 * Cout;
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const long long idx = (long long)blockIdx.x * 64 + lane;  // (c, tap, k) with k fastest: coalesced partial reads
@@ -2661,7 +2670,8 @@ static int wgrad_set_lds_once(int device) {
 }
 
 static int conv3d_wgrad_impl(int device, u3d_stream_t stream, const u3d_src_t* src, const float* dz, float* dw, int cstride,
-                             int N, int D, int H, int W, int Cout, float* workspace, size_t workspace_floats, const int* box = nullptr);
+                             int N, int D, int H, int W, int Cout, float* workspace, size_t workspace_floats, const int* box = nullptr,
+                             const u3d_gn_bwd_job_t* job = nullptr);
 
 // Weight gradient over a BOX of dz voxels only (dz outside the box counts as zero; g is read from the whole volume): round 5, the
 // near-boundary slab of a decoder level that upsamples n -> 2n + 1.  Workspace: u3d_wgrad_workspace_floats of the BOX dims.
@@ -2683,8 +2693,31 @@ extern "C" int u3d_conv3d_wgrad_strided(int device, u3d_stream_t stream, const u
     return conv3d_wgrad_impl(device, stream, src, dz, dw, dw_cin_stride, N, D, H, W, Cout, workspace, workspace_floats);
 }
 
+static size_t wgrad_job_lds_bytes(int N, int C, int G) { return sizeof(double) * (4 * (size_t)N * C + 2 * (size_t)N * G); }
+
+extern "C" int u3d_conv3d_wgrad_job_supported(int N, int C, int G) {
+    // (the reduce kernel's own 1 KB of static LDS sits beside the job's tables)
+    return (N > 0 && C > 0 && G > 0 && C % G == 0 && wgrad_job_lds_bytes(N, C, G) + 1024 <= 64 * 1024) ? 1 : 0;
+}
+
+extern "C" int u3d_conv3d_wgrad_job(int device, u3d_stream_t stream, const u3d_src_t* src, const float* dz, float* dw,
+                                    int dw_cin_stride, int N, int D, int H, int W, int Cout, float* workspace,
+                                    size_t workspace_floats, const u3d_gn_bwd_job_t* job) {
+    U3D_REQUIRE(src && (dw_cin_stride == 0 || dw_cin_stride >= src->C0 + src->C1), "u3d_conv3d_wgrad_job: dw_cin_stride < channels of src");
+    if (job) {
+        U3D_REQUIRE(job->gstats_lo && job->mean_rstd && job->gamma && job->dgamma && job->dbeta && job->coef && job->C0 > 0 &&
+                        job->C1 >= 0 && (job->C1 == 0) == (job->gstats_hi == nullptr) && (job->coef_hi == nullptr || job->C1 > 0),
+                    "u3d_conv3d_wgrad_job: bad job");
+        U3D_REQUIRE(u3d_conv3d_wgrad_job_supported(job->N, job->C0 + job->C1, job->G) == 1,
+                    "u3d_conv3d_wgrad_job: the reduction of %d x %d channels in %d groups does not fit one block's LDS", job->N,
+                    job->C0 + job->C1, job->G);
+    }
+    return conv3d_wgrad_impl(device, stream, src, dz, dw, dw_cin_stride, N, D, H, W, Cout, workspace, workspace_floats, nullptr, job);
+}
+
 static int conv3d_wgrad_impl(int device, u3d_stream_t stream, const u3d_src_t* src, const float* dz, float* dw, int cstride,
-                             int N, int D, int H, int W, int Cout, float* workspace, size_t workspace_floats, const int* box) {
+                             int N, int D, int H, int W, int Cout, float* workspace, size_t workspace_floats, const int* box,
+                             const u3d_gn_bwd_job_t* job) {
     U3D_ENTER(device);
     if (int e = check_src(src, "u3d_conv3d_wgrad")) return e;
     U3D_REQUIRE(dz && dw && workspace && N > 0 && D > 0 && H > 0 && W > 0 && Cout > 0, "u3d_conv3d_wgrad: bad argument");
@@ -2726,8 +2759,15 @@ static int conv3d_wgrad_impl(int device, u3d_stream_t stream, const u3d_src_t* s
     U3D_LAUNCH_CHECK();
     const long long total = (long long)Cin * 27 * Cout;
     const int rblocks = (int)((total + 63) / 64);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, (hipStream_t)stream, workspace, dw, p.S,
-                       p.nchunks, p.nkb, Cin, Cout, cstride > 0 ? cstride : Cin);
+    u3d_gn_bwd_job_t jb = {};
+    size_t job_lds = 0;
+    if (job) {
+        jb = *job;
+        if (!jb.gstats_hi) jb.C1 = 0, jb.hi_scale = 1.0f, jb.coef_hi = nullptr;
+        job_lds = wgrad_job_lds_bytes(jb.N, jb.C0 + jb.C1, jb.G);
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks + (job ? 1 : 0)), dim3(256), job_lds, (hipStream_t)stream, workspace, dw, p.S,
+                       p.nchunks, p.nkb, Cin, Cout, cstride > 0 ? cstride : Cin, job ? 1 : 0, jb);
     U3D_LAUNCH_CHECK();
     return 0;
 }

@@ -3,6 +3,7 @@
 // transposes.  Reference call sites: buildingblocks.py:47 (ReLU), :62-75 (GroupNorm), :356 (MaxPool3d),
 // :491 (cat), :614 (nearest interpolate), model.py:88-101,141-147 (final conv + activation).
 #include "u3d_common.h"
+#include "u3d_gn.h"
 
 #include <string.h>
 
@@ -457,97 +458,8 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __re
                                                               float* __restrict__ dbeta, float* __restrict__ coef,
                                                               const double* __restrict__ gs_hi, int C0, float hi_scale,
                                                               float* __restrict__ coef_hi) {
-#pragma clang fp contract(off)  // (both paths: products rounded, then added in channel order — identical results)
     extern __shared__ double shb[];
-    const double* src = gs;
-    if (staged) {
-        if (gs_hi) {
-            // (u3d_gn_bwd_finalize_split: the sums of channels [0, C0) and [C0, C) arrive as two tables [N][C0][2] / [N][C - C0][2] —
-            // the skip-half and low-res data-gradient kernels of a sub-pixel decoder level each write their own)
-            const int C1 = C - C0;
-            for (int i = threadIdx.x; i < N * C * 2; i += blockDim.x) {
-                const int e = i & 1, nc = i >> 1, n = nc / C, c = nc - n * C;
-                shb[i] = c < C0 ? gs[((size_t)n * C0 + c) * 2 + e] : gs_hi[((size_t)n * C1 + (c - C0)) * 2 + e];
-            }
-        } else {
-            for (int i = threadIdx.x; i < N * C * 2; i += blockDim.x) shb[i] = gs[i];
-        }
-        __syncthreads();
-        src = shb;
-    }
-    const int cpg = C / G;
-    const double m = count * cpg;
-    double* pa = shb + 2 * (size_t)N * C;  // (par only)
-    double* pb = pa + (size_t)N * C;
-    double* qr = pb + (size_t)N * C;       // [N*G][2]
-    if (par) {
-        for (int i = threadIdx.x; i < N * C; i += blockDim.x) {
-            const int n = i / C, c = i - n * C, g = c / cpg;
-            const double mean = (double)mean_rstd[((size_t)n * G + g) * 2], rstd = (double)mean_rstd[((size_t)n * G + g) * 2 + 1];
-            const double S1 = src[(size_t)i * 2], S2 = src[(size_t)i * 2 + 1], gm = (double)gamma[c];
-            pa[i] = gm * S1;
-            pb[i] = gm * rstd * (S2 - mean * S1);
-        }
-        __syncthreads();
-    }
-    for (int pair = threadIdx.x; pair < N * G; pair += blockDim.x) {
-        const int n = pair / G, g = pair - n * G;
-        const double mean = (double)mean_rstd[(size_t)pair * 2], rstd = (double)mean_rstd[(size_t)pair * 2 + 1];
-        double A = 0.0, B = 0.0;
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-            if (par) {
-                A += pa[(size_t)n * C + c];
-                B += pb[(size_t)n * C + c];
-            } else {
-                const double S1 = src[((size_t)n * C + c) * 2], S2 = src[((size_t)n * C + c) * 2 + 1];
-                const double gm = (double)gamma[c];
-                A += gm * S1;
-                B += gm * rstd * (S2 - mean * S1);
-            }
-        }
-        const double q = -rstd * rstd * B / m;
-        const double r = -rstd * A / m + rstd * rstd * mean * B / m;
-        if (par) {
-            qr[(size_t)pair * 2] = q;
-            qr[(size_t)pair * 2 + 1] = r;
-        } else {
-            for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-                coef[((size_t)n * 3 + 0) * C + c] = (float)(rstd * (double)gamma[c]);
-                coef[((size_t)n * 3 + 1) * C + c] = (float)q;
-                coef[((size_t)n * 3 + 2) * C + c] = (float)r;
-            }
-        }
-    }
-    if (par) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < N * C; i += blockDim.x) {
-            const int n = i / C, c = i - n * C, pair = n * G + c / cpg;
-            const double rstd = (double)mean_rstd[(size_t)pair * 2 + 1];
-            const float fp = (float)(rstd * (double)gamma[c]), fq = (float)qr[(size_t)pair * 2], fr = (float)qr[(size_t)pair * 2 + 1];
-            coef[((size_t)n * 3 + 0) * C + c] = fp;
-            coef[((size_t)n * 3 + 1) * C + c] = fq;
-            coef[((size_t)n * 3 + 2) * C + c] = fr;
-            if (coef_hi && c >= C0) {
-                // compact table of the upper channels with (q, r) scaled: a low-res voxel of an exact 2x upsampling stands for 8 children
-                const int C1 = C - C0;
-                coef_hi[((size_t)n * 3 + 0) * C1 + (c - C0)] = fp;
-                coef_hi[((size_t)n * 3 + 1) * C1 + (c - C0)] = fq * hi_scale;
-                coef_hi[((size_t)n * 3 + 2) * C1 + (c - C0)] = fr * hi_scale;
-            }
-        }
-    }
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const int g = c / cpg;
-        double dg = 0.0, db = 0.0;
-        for (int n = 0; n < N; ++n) {
-            const double mean = (double)mean_rstd[((size_t)n * G + g) * 2], rstd = (double)mean_rstd[((size_t)n * G + g) * 2 + 1];
-            const double S1 = src[((size_t)n * C + c) * 2], S2 = src[((size_t)n * C + c) * 2 + 1];
-            dg += rstd * (S2 - mean * S1);
-            db += S1;
-        }
-        dgamma[c] = (float)dg;
-        dbeta[c] = (float)db;
-    }
+    u3d_gn_bwd_finalize_body(gs, mean_rstd, gamma, N, C, G, count, staged, par, dgamma, dbeta, coef, gs_hi, C0, hi_scale, coef_hi, shb);
 }
 
 extern "C" int u3d_gn_bwd_finalize(int device, u3d_stream_t stream, const double* gstats, const float* mean_rstd,

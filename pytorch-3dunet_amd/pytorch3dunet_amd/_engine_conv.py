@@ -20,6 +20,8 @@ from ._native import U3DSrc
 
 from ._engine_base import *  # noqa: F401,F403  (explicit __all__: helpers, records, activation codes)
 
+_WGRAD_JOB = os.environ.get("U3D_WGRAD_JOB", "1") != "0"  # A/B: 0 = GroupNorm-backward reductions as launches of their own
+
 
 class _SubLayers(dict):
     """{id(conv weight): (C0, C1)} of the decoder first convs that take the sub-pixel path at one input size; `plus` = the ids whose level
@@ -73,6 +75,7 @@ class _BwdCall:
     Cout: int
     bf16: bool   # both directions of this layer run on the bf16-operand kernels
     b16: bool    # bf16 activation storage
+    job: object = None  # U3DGnBwdJob for the weight-gradient reduce launch to carry (the family that takes it sets it back to None)
 
     @property
     def flops(self):
@@ -192,6 +195,27 @@ class ConvLayers:
         nat.call("u3d_bn_finalize", dev.index, _stream(dev), _p(st0), C0, sc0, _p(st1), C1, sc1, N, count, _p(mod.weight.detach()),
                  _p(mod.bias.detach()), float(mod.eps), 1 if training else 0, momentum, _p(rm), _p(rv), _p(affine), _p(mean_rstd))
         return mean_rstd
+
+    def _norm_bwd_job(self, cx, rec: ConvRec, gst, N, C, count, coef):
+        """The GroupNorm-backward reduction of a layer's input as a job for the launch that reduces the layer's weight gradient
+        (u3d_conv3d_wgrad_job: one launch less per layer); None when it has to run on its own (_norm_bwd_finalize)."""
+        if rec.norm != "g" or not _WGRAD_JOB or nat.get_lib().u3d_conv3d_wgrad_job_supported(N, C, rec.G) != 1:
+            return None
+        dev, gview = cx.dev, cx.gview
+        cx.coef_hi = None
+        job = nat.U3DGnBwdJob()
+        if isinstance(gst, tuple):
+            g0, g1 = gst
+            C0 = g0.numel() // (2 * N)
+            coef_hi = _empty((N, 3, C - C0), dtype=_F32, device=dev) if not any(rec.src.plus) else None
+            job.gstats_lo, job.gstats_hi, job.C0, job.C1, job.hi_scale, job.coef_hi = _p(g0), _p(g1), C0, C - C0, 8.0, _p(coef_hi)
+            cx.coef_hi = coef_hi
+        else:
+            job.gstats_lo, job.gstats_hi, job.C0, job.C1, job.hi_scale, job.coef_hi = _p(gst), None, C, 0, 1.0, None
+        job.mean_rstd, job.gamma = _p(rec.mean_rstd), _p(rec.gn_w.detach())
+        job.dgamma, job.dbeta, job.coef = _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef)
+        job.count, job.N, job.G = count, N, rec.G
+        return job
 
     def _norm_bwd_finalize(self, cx, rec: ConvRec, gst, N, C, count, coef):
         dev, gview = cx.dev, cx.gview
@@ -485,8 +509,10 @@ class ConvLayers:
                      flops=128.0 * C1 * c.Cout * c.N * src.D1 * src.H1 * src.W1)
         a0 = rec.affine_lo if rec.affine_lo is not None else rec.affine[:, :C0].contiguous()
         s0 = VSrc(src.t0).struct(a0)
-        nat.call("u3d_conv3d_wgrad_strided", dev.index, _stream(dev), ctypes.byref(s0), _p(c.dz), _p(dwv), Ct, c.N, c.D, c.H, c.W,
-                 c.Cout, _p(ws), ws.numel(), flops=54.0 * C0 * c.Cout * c.N * c.D * c.H * c.W)
+        nat.call("u3d_conv3d_wgrad_job", dev.index, _stream(dev), ctypes.byref(s0), _p(c.dz), _p(dwv), Ct, c.N, c.D, c.H, c.W,
+                 c.Cout, _p(ws), ws.numel(), ctypes.byref(c.job) if c.job is not None else None,
+                 flops=54.0 * C0 * c.Cout * c.N * c.D * c.H * c.W)
+        c.job = None
 
     def _wgrad_fp32_side(self, c: "_BwdCall"):
         # small layer: neither kernel fills the chip on its own -> weight gradient on the side stream, data gradient
@@ -505,8 +531,9 @@ class ConvLayers:
     def _wgrad_fp32(self, c: "_BwdCall"):
         cx, dev, src, rec, ws = c.cx, c.cx.dev, c.src, c.rec, c.cx.ws
         s_aff = src.struct(rec.affine)
-        nat.call("u3d_conv3d_wgrad", dev.index, _stream(dev), ctypes.byref(s_aff), _p(c.dz), _p(cx.gview(rec.idx_w)), c.N, c.D,
-                 c.H, c.W, c.Cout, _p(ws), ws.numel(), flops=c.flops)
+        nat.call("u3d_conv3d_wgrad_job", dev.index, _stream(dev), ctypes.byref(s_aff), _p(c.dz), _p(cx.gview(rec.idx_w)), 0, c.N, c.D,
+                 c.H, c.W, c.Cout, _p(ws), ws.numel(), ctypes.byref(c.job) if c.job is not None else None, flops=c.flops)
+        c.job = None
 
     def _dgrad_subpixel(self, c: "_BwdCall"):
         # skip half at full resolution; upsampled half directly at LOW resolution (the children sum of the nearest
@@ -640,15 +667,21 @@ class ConvLayers:
         b16 = src.t0.dtype == torch.bfloat16  # bf16 activation storage
         assert not b16 or (bf16 and Cout % 64 == 0 and dz_.dtype == torch.bfloat16)
         call = _BwdCall(cx, rec, dz_, src, Nn, Dd, Hh, Ww, Cout, bf16, b16)
-        # ---- weight gradient, then data gradient (+ the GroupNorm-backward sums of the conv input): one family decision each
-        getattr(self, self._WGRAD_KERNELS[self._wgrad_family(call)])(call)
+        # ---- data gradient (+ the GroupNorm-backward sums of the conv input), then weight gradient: one family decision each.  The
+        # one-block reduction of those sums rides in the weight gradient's reduce launch where the family takes a job (round 6)
         dg, gst = getattr(self, self._DGRAD_KERNELS[self._dgrad_family(call)])(call)
         if self.debug is not None and rec.sub is None:
             self.debug[rec.name + ".dg"] = dg.clone()
+        coef = None
+        if rec.pre_norm:
+            coef = _empty((Nn, 3, src.C), dtype=_F32, device=dev)
+            call.job = self._norm_bwd_job(cx, rec, gst, Nn, src.C, float(Dd * Hh * Ww), coef)
+        had_job = call.job is not None
+        getattr(self, self._WGRAD_KERNELS[self._wgrad_family(call)])(call)
         if not rec.pre_norm:
             return dg, self._identity_coef(Nn, src.C, dev)  # no GroupNorm on the conv input: dx = dg
-        coef = _empty((Nn, 3, src.C), dtype=_F32, device=dev)
-        self._norm_bwd_finalize(cx, rec, gst, Nn, src.C, float(Dd * Hh * Ww), coef)
+        if not had_job or call.job is not None:  # (no job, or a weight-gradient family without a reduce launch to carry it)
+            self._norm_bwd_finalize(cx, rec, gst, Nn, src.C, float(Dd * Hh * Ww), coef)
         return dg, coef
 
     def _plain_apply(self, cx, dg, coef, x, relu_mask, add=None):

@@ -40,6 +40,14 @@ class U3DAdamDesc(ctypes.Structure):
     _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("first", c_int64), ("numel", c_int64)]
 
 
+class U3DGnBwdJob(ctypes.Structure):
+    """mirror of u3d_gn_bwd_job_t (include/u3d.h)"""
+
+    _fields_ = [("gstats_lo", c_void_p), ("gstats_hi", c_void_p), ("mean_rstd", c_void_p), ("gamma", c_void_p), ("dgamma", c_void_p),
+                ("dbeta", c_void_p), ("coef", c_void_p), ("coef_hi", c_void_p), ("count", ctypes.c_double), ("C0", c_int32),
+                ("C1", c_int32), ("N", c_int32), ("G", c_int32), ("hi_scale", ctypes.c_float), ("reserved", c_int32)]
+
+
 class U3DPackDesc(ctypes.Structure):
     """mirror of u3d_pack_desc_t (include/u3d.h)"""
 
@@ -141,6 +149,12 @@ _PROTOS = {
     "u3d_conv3d_wgrad_strided": (
         c_int,
         [c_int, c_void_p, POINTER(U3DSrc), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t],
+    ),
+    "u3d_conv3d_wgrad_job_supported": (c_int, [c_int, c_int, c_int]),
+    "u3d_conv3d_wgrad_job": (
+        c_int,
+        [c_int, c_void_p, POINTER(U3DSrc), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
+         POINTER(U3DGnBwdJob)],
     ),
     "u3d_subpixel_wgrad_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "u3d_subpixel_conv_wgrad": (
@@ -404,7 +418,7 @@ def get_lib():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.u3d_version() < 122:
+        if lib.u3d_version() < 123:
             raise U3DError("libu3d_hip.so is older than the Python host code")
         for kv in os.environ.get("U3D_TUNE", "").split(","):  # A/B knobs of u3d_set_tuning, e.g. U3D_TUNE=8:256,9:1 (results never change)
             if ":" in kv:

@@ -587,6 +587,61 @@ def test_groupnorm_finalize_split_forms_equal_the_plain_ones_bit_for_bit(N, C0, 
     assert torch.equal(outs[1][3], outs[0][2][:, :, C0:] * scale)
 
 
+@pytest.mark.parametrize("N,Cin,Cout,D,H,W,C0,C1,G", [(1, 32, 64, 8, 16, 16, 32, 0, 8), (2, 16, 32, 5, 9, 7, 16, 0, 4),
+                                                      (1, 32, 32, 8, 16, 16, 32, 64, 8), (2, 64, 32, 4, 8, 8, 64, 128, 8)])
+def test_wgrad_job_equals_wgrad_then_groupnorm_backward_finalize_bit_for_bit(N, Cin, Cout, D, H, W, C0, C1, G):
+    """u3d_conv3d_wgrad_job (round 6): the weight gradient and the GroupNorm-backward reduction of the layer's input in the reduce
+    launch's extra block are those of u3d_conv3d_wgrad_strided + u3d_gn_bwd_finalize[_split], bit for bit; C1 > 0: the source holds
+    the C0 skip channels of a (C0 + C1)-channel weight and the sums arrive as two tables"""
+    U, nat, VSrc, _p, _stream = _mods()
+    torch.manual_seed(Cin + Cout + C1)
+    dev = U.DEV
+    assert Cin == C0
+    C, V = C0 + C1, float(D * H * W)
+    x = U.ndhwc(torch.randn(N, Cin, D, H, W))
+    dz = U.ndhwc(torch.randn(N, Cout, D, H, W))
+    aff = torch.randn(N, Cin, 2, device=dev)
+    gamma = torch.randn(C, device=dev)
+    mr = torch.rand(N, G, 2, device=dev) + 0.5
+    g0 = torch.randn(N, C0, 2, dtype=torch.float64, device=dev) * 100
+    g1 = torch.randn(N, max(C1, 1), 2, dtype=torch.float64, device=dev) * 100
+    lib = nat.get_lib()
+    assert lib.u3d_conv3d_wgrad_job_supported(N, C, G) == 1
+    n = lib.u3d_wgrad_workspace_floats(N, D, H, W, Cin, Cout)
+    ws = torch.empty(n, device=dev)
+    s = VSrc(x).struct(aff)
+    outs = []
+    for fused in (False, True):
+        dw = torch.full((Cout, C, 27), 7.0, device=dev)
+        dgam, dbet, coef = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty((N, 3, C), device=dev)
+        chi = torch.zeros((N, 3, max(C1, 1)), device=dev)
+        if fused:
+            job = nat.U3DGnBwdJob()
+            job.gstats_lo, job.gstats_hi, job.C0, job.C1 = _p(g0), _p(g1) if C1 else None, C0, C1
+            job.hi_scale, job.coef_hi = (8.0, _p(chi)) if C1 else (1.0, None)
+            job.mean_rstd, job.gamma, job.dgamma, job.dbeta, job.coef = _p(mr), _p(gamma), _p(dgam), _p(dbet), _p(coef)
+            job.count, job.N, job.G = V, N, G
+            nat.call("u3d_conv3d_wgrad_job", 0, _stream(dev), ctypes.byref(s), _p(dz), _p(dw), C, N, D, H, W, Cout, _p(ws), n,
+                     ctypes.byref(job))
+        else:
+            nat.call("u3d_conv3d_wgrad_strided", 0, _stream(dev), ctypes.byref(s), _p(dz), _p(dw), C, N, D, H, W, Cout, _p(ws), n)
+            if C1:
+                nat.call("u3d_gn_bwd_finalize_split", 0, _stream(dev), _p(g0), C0, _p(g1), C1, _p(mr), _p(gamma), N, G, V, _p(dgam),
+                         _p(dbet), _p(coef), 8.0, _p(chi))
+            else:
+                nat.call("u3d_gn_bwd_finalize", 0, _stream(dev), _p(g0), _p(mr), _p(gamma), N, C, G, V, _p(dgam), _p(dbet), _p(coef))
+        outs.append((dw, dgam, dbet, coef, chi))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert bool((outs[1][0].view(Cout, C, 27)[:, C0:] == 7.0).all())  # the slice of the other channels is left alone
+    # job == NULL with stride 0 is the plain weight gradient
+    dw0 = torch.empty((Cout, Cin, 27), device=dev)
+    nat.call("u3d_conv3d_wgrad_job", 0, _stream(dev), ctypes.byref(s), _p(dz), _p(dw0), 0, N, D, H, W, Cout, _p(ws), n, None)
+    assert torch.equal(dw0, outs[0][0].view(Cout, C, 27)[:, :C0])
+    # a reduction that does not fit the block's LDS is refused, not truncated
+    assert lib.u3d_conv3d_wgrad_job_supported(4, 1024, 8) == 0
+
+
 @pytest.mark.parametrize("N,C,size", [(2, 8, (8, 12, 16)), (1, 5, (9, 13, 11)), (1, 32, (4, 6, 2)), (2, 64, (8, 16, 16))])
 def test_maxpool_forward_backward_merge(N, C, size):
     U, nat, VSrc, _p, _stream = _mods()
