@@ -44,6 +44,8 @@
 //        csrc/u3d_ops.hip).  (A max-pool with the statistics fused into its pass was built and measured in round 6: 77 / 43 / 12 us per level
 //        against 52 + 23 / 14 + 11 / 5 + 8 for the massively parallel pool + a statistics pass — the pool alone moves 6 TB/s; not kept.)
 //   [21] 1 = head forward of the 32 / 64-channel -> 1 / 2-output heads on the vectorised kernel instead of the LDS-rows kernel (A/B)
+//   [22] sub-pixel weight gradient: 1 = always reduced by the one-thread-per-output kernel of round 2, 2 = always by the read-once kernel
+//        (default: read-once from 256 blocks on, csrc/u3d_subpix.hip)
 //   [19] / [20] total block count of the first-layer forward / backward kernels (csrc/u3d_smallc.hip; 0 = default 512 / 1024)
 int g_u3d_tune[24] = {0};
 

@@ -729,6 +729,54 @@ __global__ __launch_bounds__(256) void subpixel_wgrad_reduce_kernel(const float*
         dw[((size_t)k * cstride + c) * 27 + tap] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
+// Round 6: the same reduction with every partial read ONCE.  The kernel above reads each of the 64 (class, tap-half) matrices once per
+// tap it belongs to (3.4 reads per element: 216 MB of L2 traffic for 64 MB of partials, 27-32 us per level).  Here a thread owns one
+// (input channel c, output channel k) element and the splits g, g + G, ..: it sums the 64 matrices over its splits in registers, folds them
+// into the 27 taps (8 matrices each, ascending parity class), and the G groups of a block are added in ascending order through LDS.
+// block = 32 output channels x G split groups, grid = C1 x ceil(K / 32).  Fixed order: results are run-to-run identical (they differ from
+// the kernel above in the last bits: splits are summed before the fold, not after).
+__global__ __launch_bounds__(512) void subpixel_wgrad_reduce_once_kernel(const float* __restrict__ partial, float* __restrict__ dw, int S,
+                                                                         int nchunks, int nkb, int C1, int K, int cstride) {
+    extern __shared__ float red[];  // [G][27][32]
+    const int k32 = threadIdx.x & 31, grp = threadIdx.x >> 5, G = blockDim.x >> 5;
+    const int c = blockIdx.x / nkb, kb = blockIdx.x - c * nkb;
+    const int k = kb * 32 + k32;
+    const float* base = partial + ((size_t)((c >> 5) * nkb + kb) * 64) * 1024 + (c & 31) * 32 + k32;
+    const size_t sstride = (size_t)nchunks * nkb * 64 * 1024;
+    float m[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) m[j] = 0.f;
+    for (int sp_ = grp; sp_ < S; sp_ += G) {
+        const float* ps = base + (size_t)sp_ * sstride;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) m[j] += ps[(size_t)j * 1024];
+    }
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+        const int t3[3] = {tap / 9, (tap / 3) % 3, tap % 3};
+        float a = 0.f;
+#pragma unroll
+        for (int pc = 0; pc < 8; ++pc) {
+            int e = 0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int pd = (pc >> (2 - d)) & 1;
+                e = e * 2 + (pd == 0 ? (t3[d] == 0 ? 0 : 1) : (t3[d] == 2 ? 1 : 0));
+            }
+            a += m[pc * 8 + e];
+        }
+        red[(grp * 27 + tap) * 32 + k32] = a;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 27 * 32; o += blockDim.x) {
+        const int tap = o >> 5, kk = o & 31;
+        float sum = 0.f;
+        for (int g = 0; g < G; ++g) sum += red[(g * 27 + tap) * 32 + kk];
+        if (c < C1 && kb * 32 + kk < K) dw[((size_t)(kb * 32 + kk) * cstride + c) * 27 + tap] = sum;
+    }
+    (void)k;
+}
+
 __global__ void pack_subpixel_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int cstride, int C1,
                                      int nchunks, int ncb, long long total) {
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -1072,9 +1120,18 @@ static int subpixel_conv_wgrad_impl(int device, u3d_stream_t stream, const float
         hipLaunchKernelGGL(subpixel_wgrad_kernel<false>, dim3((unsigned)(p.S * p.nchunks * p.nkb)), dim3(spw::NTHR), 0,
                            (hipStream_t)stream, p);
     U3D_LAUNCH_CHECK();
-    const long long total = (long long)C1 * 27 * Cout;
-    hipLaunchKernelGGL(subpixel_wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
-                       workspace, dw, p.S, p.nchunks, p.nkb, C1, Cout, dw_cin_stride);
+    // (the read-once kernel has C1 * nkb blocks: with 64 of them — the 64 -> 32-channel top level — it is latency-bound at 75 us against
+    // 28 us of the one-thread-per-output kernel; from 256 blocks on it wins, 32 -> 23 and 27 -> 17 us on the two levels below)
+    if (g_u3d_tune[22] == 1 || (g_u3d_tune[22] != 2 && C1 * p.nkb < 256)) {  // key 22 = 1 / 2: always the round-2 / the read-once reduction (A/B)
+        const long long total = (long long)C1 * 27 * Cout;
+        hipLaunchKernelGGL(subpixel_wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
+                           workspace, dw, p.S, p.nchunks, p.nkb, C1, Cout, dw_cin_stride);
+    } else {
+        int G = 16;  // split groups per block: every group at least one split, at most 512 threads
+        while (G > 1 && G > p.S) G >>= 1;
+        hipLaunchKernelGGL(subpixel_wgrad_reduce_once_kernel, dim3((unsigned)(C1 * p.nkb)), dim3(32 * G), (size_t)G * 27 * 32 * sizeof(float),
+                           (hipStream_t)stream, workspace, dw, p.S, p.nchunks, p.nkb, C1, Cout, dw_cin_stride);
+    }
     U3D_LAUNCH_CHECK();
     return 0;
 }

@@ -324,12 +324,23 @@ def test_subpixel_conv_dgrad_to_low_res(N, C1, Cout, D1, H1, W1):
     assert U.relerr(gst.cpu(), s_ref) < 1e-5
 
 
+@pytest.fixture
+def _tuning_key_22(request):
+    from pytorch3dunet_amd import _native as nat
+    nat.call("u3d_set_tuning", 22, request.param)
+    yield request.param
+    nat.call("u3d_set_tuning", 22, 0)
+
+
+@pytest.mark.parametrize("_tuning_key_22", [0, 1, 2], indirect=True, ids=["reduce-default", "reduce-per-output", "reduce-read-once"])
 @pytest.mark.parametrize("N,C0,C1,Cout,D1,H1,W1,affine", [(2, 32, 64, 32, 4, 8, 8, True), (1, 16, 40, 48, 2, 4, 8, True),
-                                                           (1, 8, 24, 20, 3, 5, 6, False), (2, 4, 32, 32, 2, 4, 16, True)])
-def test_subpixel_conv_wgrad_and_strided_skip_half(N, C0, C1, Cout, D1, H1, W1, affine):
+                                                           (1, 8, 24, 20, 3, 5, 6, False), (2, 4, 32, 32, 2, 4, 16, True),
+                                                           (1, 8, 128, 64, 2, 4, 8, True)])
+def test_subpixel_conv_wgrad_and_strided_skip_half(N, C0, C1, Cout, D1, H1, W1, affine, _tuning_key_22):
     """weight gradient of conv3d(cat(skip, nearest2x(low))): upsampled channels from the 64 (class, tap-half) matrices over
     the low-res grid (u3d_subpixel_conv_wgrad), skip channels from u3d_conv3d_wgrad_strided — both write their channel slice
-    of ONE (Cout, C0+C1, 3,3,3) gradient"""
+    of ONE (Cout, C0+C1, 3,3,3) gradient.  Both reductions of the 64 matrices (key 22: one thread per output / every partial read
+    once, round 6; the last case has the 256 blocks from which the default picks the latter)"""
     U, nat, VSrc, _p, _stream = _mods()
     torch.manual_seed(C1 + 7 * Cout + H1)
     D, H, W = 2 * D1, 2 * H1, 2 * W1
