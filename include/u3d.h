@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define U3D_VERSION 123 /* 123: u3d_conv3d_wgrad_job (the GroupNorm-backward reduction rides in the weight-gradient reduce launch); 122: round 6 — u3d_gn_finalize_split / u3d_gn_bwd_finalize_split (compact half tables of a virtual-concat layer), u3d_adam_step, u3d_chan_stats_children, u3d_pack_weights_batch_cells, tuning key 18; 121: u3d_convtr3d_fwd_t8_b16_ex; 120: flat 5 x 10 x 10 tile of the bf16-storage convolutions (u3d_conv3d_bf16_tile_variant planes = 5), 24 tuning keys; 119: round 5 — ragged volumes on the persistent kernels, u3d_conv3d_variant / u3d_conv3d_wgrad_variant; 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K); 118: u3d_se_*_b16 */
+#define U3D_VERSION 124 /* 124: u3d_bce_dice_scratch_doubles (per-block partials instead of atomics); 123: u3d_conv3d_wgrad_job (the GroupNorm-backward reduction rides in the weight-gradient reduce launch); 122: round 6 — u3d_gn_finalize_split / u3d_gn_bwd_finalize_split (compact half tables of a virtual-concat layer), u3d_adam_step, u3d_chan_stats_children, u3d_pack_weights_batch_cells, tuning key 18; 121: u3d_convtr3d_fwd_t8_b16_ex; 120: flat 5 x 10 x 10 tile of the bf16-storage convolutions (u3d_conv3d_bf16_tile_variant planes = 5), 24 tuning keys; 119: round 5 — ragged volumes on the persistent kernels, u3d_conv3d_variant / u3d_conv3d_wgrad_variant; 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K); 118: u3d_se_*_b16 */
 
 #define U3D_OK 0
 #define U3D_EINVAL (-1)  /* bad shape / argument */
@@ -482,8 +482,10 @@ int u3d_se_bwd_apply(int device, u3d_stream_t stream, const float* dout, const f
  * BCEDiceLoss(alpha) = (w_bce 1, w_dice alpha); DiceLoss() = (0, 1); nn.BCEWithLogitsLoss() = (1, 0).
  * logits / target: (N, C, V) contiguous fp32 (the reference's NCDHW).  weight: optional device float[C] (DiceLoss's
  * per-class weight) or NULL.
- * fwd : sums double[1 + 3C] (scratch, zeroed by the call), loss float[1], coef float[2C + 1] (saved for backward)
+ * fwd : sums double[u3d_bce_dice_scratch_doubles(N, C, V)] (scratch: per-block partial sums, need not be initialised; summed in a
+ *       fixed order, so the loss is bit-reproducible), loss float[1], coef float[2C + 1] (saved for backward)
  * bwd : dlogits = grad_out[0] * dloss/dlogits; grad_out is a DEVICE scalar (NULL = 1) — no host synchronisation. */
+long long u3d_bce_dice_scratch_doubles(int N, int C, int64_t V);
 int u3d_bce_dice_fwd(int device, u3d_stream_t stream, const float* logits, const float* target, const float* weight,
                      int N, int C, int64_t V, float w_bce, float w_dice, float eps, double* sums, float* loss,
                      float* coef);

@@ -5,8 +5,9 @@
 // (dice_c = 2 * w_c * sum(p*t) / clamp(sum(p^2) + sum(t^2), eps), sums over (N, spatial) per channel, flatten :253-271).
 // The stock path launches ~15 elementwise / reduction kernels plus a permute+contiguous copy and keeps 6 full-size
 // temporaries for autograd; here:
-//   pass 1  one read of (logits, target): 4 sums per channel in double (BCE terms, p*t, p^2, t^2)
-//   pass 2  one block: the scalar loss + per-channel gradient coefficients (dL/dp_c = a_c*t + b_c*p is affine)
+//   pass 1  one read of (logits, target): 4 sums per block (BCE terms, p*t, p^2, t^2) as per-block partials in double
+//   pass 2  one block: the partials summed in a fixed order (bit-reproducible), the scalar loss + per-channel gradient
+//           coefficients (dL/dp_c = a_c*t + b_c*p is affine)
 //   pass 3  backward: one read of (logits, target), one write of dlogits, scaled by the upstream scalar ON DEVICE
 // logits / target are (N, C, V) contiguous fp32 — the reference's NCDHW, which is what the model's head writes.
 #include "u3d_common.h"
@@ -63,32 +64,57 @@ __global__ __launch_bounds__(256) void loss_sums_kernel(const float* __restrict_
         for (int k = 0; k < 4; ++k) red[w][k] = v[k];
     __syncthreads();
     if (threadIdx.x < 4) {
+        // per-block partial, plain store (round 6: 512 blocks adding to the same four doubles were 10 of the kernel's 15 us — a
+        // same-address f64 atomic retires every 19.5 ns, tools/atomic_bench.hip; the one-block second pass sums them in a fixed order)
         const int k = threadIdx.x;
-        const double s = ((double)red[0][k] + (double)red[1][k]) + ((double)red[2][k] + (double)red[3][k]);
-        u3d_atomic_add_f64(k == 0 ? &sums[0] : &sums[1 + 3 * c + (k - 1)], s);
+        sums[((size_t)row * gridDim.x + blockIdx.x) * 4 + k] = ((double)red[0][k] + (double)red[1][k]) + ((double)red[2][k] + (double)red[3][k]);
     }
 }
 
-// one block: loss[0] and coef[2*C + 1] = {a_c, b_c}_c, k_bce
-__global__ void loss_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ weight, int C, double count,
-                                     float w_bce, float w_dice, float eps, float* __restrict__ loss,
-                                     float* __restrict__ coef) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double dice_sum = 0.0;
+// one block of 256 threads: the partials [N*C rows][per_row blocks][4] -> loss[0] and coef[2*C + 1] = {a_c, b_c}_c, k_bce
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const double* __restrict__ partial, int N, int per_row,
+                                                            const float* __restrict__ weight, int C, double count, float w_bce,
+                                                            float w_dice, float eps, float* __restrict__ loss, float* __restrict__ coef) {
+    __shared__ double red[256][4];
+    __shared__ double acc_bce, acc_dice;
+    const int t = threadIdx.x;
+    if (t == 0) acc_bce = 0.0, acc_dice = 0.0;
     for (int c = 0; c < C; ++c) {
-        const double I = sums[1 + 3 * c], A = sums[2 + 3 * c], B = sums[3 + 3 * c];
-        const double wc = weight ? (double)weight[c] : 1.0;
-        const double raw = A + B;
-        const bool clamped = raw < (double)eps;  // torch.clamp(min=eps): gradient 0 through the clamped branch
-        const double den = clamped ? (double)eps : raw;
-        dice_sum += 2.0 * wc * I / den;
-        // L_dice = w_dice * (1 - (1/C) sum_c dice_c);  d dice_c / dp = 2 wc t / den - (clamped ? 0 : 2 wc I * 2p / den^2)
-        const double k = -(double)w_dice / C;
-        coef[2 * c + 0] = (float)(k * 2.0 * wc / den);
-        coef[2 * c + 1] = clamped ? 0.f : (float)(-k * 4.0 * wc * I / (den * den));
+        double v[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int i = t; i < N * per_row; i += 256) {
+            const int n = i / per_row, bx = i - n * per_row;
+            const double* pp = partial + ((size_t)(n * C + c) * per_row + bx) * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += pp[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[t][k] = v[k];
+        __syncthreads();
+        for (int m = 128; m > 0; m >>= 1) {  // fixed-order tree
+            if (t < m)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) red[t][k] += red[t + m][k];
+            __syncthreads();
+        }
+        if (t == 0) {
+            const double I = red[0][1], A = red[0][2], B = red[0][3];
+            const double wc = weight ? (double)weight[c] : 1.0;
+            const double raw = A + B;
+            const bool clamped = raw < (double)eps;  // torch.clamp(min=eps): gradient 0 through the clamped branch
+            const double den = clamped ? (double)eps : raw;
+            acc_bce += red[0][0];
+            acc_dice += 2.0 * wc * I / den;
+            // L_dice = w_dice * (1 - (1/C) sum_c dice_c);  d dice_c / dp = 2 wc t / den - (clamped ? 0 : 2 wc I * 2p / den^2)
+            const double k = -(double)w_dice / C;
+            coef[2 * c + 0] = (float)(k * 2.0 * wc / den);
+            coef[2 * c + 1] = clamped ? 0.f : (float)(-k * 4.0 * wc * I / (den * den));
+        }
+        __syncthreads();
     }
-    coef[2 * C] = (float)((double)w_bce / count);
-    loss[0] = (float)((double)w_bce * sums[0] / count + (double)w_dice * (1.0 - dice_sum / C));
+    if (t == 0) {
+        coef[2 * C] = (float)((double)w_bce / count);
+        loss[0] = (float)((double)w_bce * acc_bce / count + (double)w_dice * (1.0 - acc_dice / C));
+    }
 }
 
 // dlogits = g * [ k_bce * (p - t) + (a_c * t + b_c * p) * p * (1 - p) ],  g = *grad_out (device scalar) or 1
@@ -138,6 +164,11 @@ inline dim3 loss_grid(int rows, long long V) {
 
 }  // namespace
 
+extern "C" long long u3d_bce_dice_scratch_doubles(int N, int C, int64_t V) {
+    if (N <= 0 || C <= 0 || V <= 0) return 0;
+    return (long long)N * C * loss_grid(N * C, V).x * 4;
+}
+
 extern "C" int u3d_bce_dice_fwd(int device, u3d_stream_t stream, const float* logits, const float* target,
                                 const float* weight, int N, int C, int64_t V, float w_bce, float w_dice, float eps,
                                 double* sums, float* loss, float* coef) {
@@ -145,12 +176,12 @@ extern "C" int u3d_bce_dice_fwd(int device, u3d_stream_t stream, const float* lo
     U3D_REQUIRE(logits && target && sums && loss && coef && N > 0 && C > 0 && V > 0, "u3d_bce_dice_fwd: bad argument");
     U3D_REQUIRE((long long)N * C < 65536, "u3d_bce_dice_fwd: N*C must be < 65536");
     hipStream_t st = (hipStream_t)stream;
-    U3D_HIP(hipMemsetAsync(sums, 0, sizeof(double) * (1 + 3 * (size_t)C), st));
     const int vec = rows_vec_ok(logits, target, logits, V) ? 1 : 0;
-    hipLaunchKernelGGL(loss_sums_kernel, loss_grid(N * C, V), dim3(256), 0, st, logits, target, C, (long long)V, vec, sums);
+    const dim3 grid = loss_grid(N * C, V);
+    hipLaunchKernelGGL(loss_sums_kernel, grid, dim3(256), 0, st, logits, target, C, (long long)V, vec, sums);
     U3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, sums, weight, C, (double)N * C * (double)V, w_bce,
-                       w_dice, eps, loss, coef);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, sums, N, (int)grid.x, weight, C, (double)N * C * (double)V,
+                       w_bce, w_dice, eps, loss, coef);
     U3D_LAUNCH_CHECK();
     return 0;
 }

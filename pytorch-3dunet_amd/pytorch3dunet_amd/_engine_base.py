@@ -436,6 +436,7 @@ class Tape:
     cats: dict = field(default_factory=dict)    # DoubleConv executor, bf16 mode: decoder index -> the VIRTUAL source whose concat was materialised
     lean: bool = False      # memory-lean mode (checkpoint_encoders): backward releases every block's tensors as soon as it is done
     consumed: bool = False  # ... so the tape can be walked only once
+    bwd_pool: Optional[object] = None  # DoubleConv executor: the backward pass's zeroed scratch, carved from the forward's pool (one fill launch)
 
 
 class _StatPool:
@@ -454,6 +455,13 @@ class _StatPool:
         s = self.buf[self.off : self.off + n]
         self.off += n
         return s
+
+    def carve(self, n: int) -> "_StatPool":
+        """a pool of its own over the next n zeroed doubles of this one (the backward pass's scratch inside the forward's fill launch)"""
+        sub = _StatPool.__new__(_StatPool)
+        sub.buf = self.take(n)
+        sub.off = 0
+        return sub
 
 
 _SIDE_STREAMS: dict = {}

@@ -171,7 +171,19 @@ class UNet3DEngine(WeightImages, ConvLayers):
             tot += 4 * N * (c1.conv.in_channels + c1.conv.out_channels + c2.conv.out_channels) * 2
         for c1, c2 in self.dec:
             tot += 4 * N * (c1.conv.in_channels + c1.conv.out_channels + c2.conv.out_channels) * 2
-        pool = _StatPool(dev, tot)
+        # (round 6) the backward pass's zeroed scratch — head (dw, db) + 2 doubles per (n, input channel) of every conv — rides in the same
+        # fill launch; handed over through the tape, used by the FIRST backward over it
+        fcm = self.model.final_conv
+        btot = 0
+        if save:
+            btot = fcm.out_channels * fcm.in_channels + fcm.out_channels
+            for _, c1, c2 in self.enc:
+                btot += N * (c1.conv.in_channels + c2.conv.in_channels) * 2
+            for c1, c2 in self.dec:
+                btot += N * (c1.conv.in_channels + c2.conv.in_channels) * 2
+        pool = _StatPool(dev, tot + btot)
+        if tape is not None:
+            tape.bwd_pool = pool.carve(btot)
 
         feats = []  # (tensor, stats) of every encoder output
         cur, cur_st = x0, None
@@ -278,7 +290,11 @@ class UNet3DEngine(WeightImages, ConvLayers):
         fc = m.final_conv
         Co, Cf = fc.out_channels, fc.in_channels
         tot = Co * Cf + Co + sum(N * r.src.C * 2 for r in tape.convs)
-        pool = _StatPool(dev, tot)
+        pool = getattr(tape, "bwd_pool", None)  # zeroed by the forward's fill launch; a second backward over the tape takes a fresh one
+        tape.bwd_pool = None
+        # (a backward pass being captured into a hipGraph is replayed without its forward: it zeroes its own scratch inside the graph)
+        if pool is None or pool.buf.numel() < tot or pool.buf.device != dev or torch.cuda.is_current_stream_capturing():
+            pool = _StatPool(dev, tot)
         ws = self._wgrad_workspace(tape, dev)
 
         # ---- head backward: dz of the last decoder conv (ReLU mask fused)

@@ -59,7 +59,7 @@ class _FusedBCEDice(torch.autograd.Function):
         dev = logits.device
         n, c = logits.shape[0], logits.shape[1]
         v = logits.numel() // (n * c)
-        sums = torch.empty(1 + 3 * c, dtype=torch.float64, device=dev)
+        sums = torch.empty(nat.get_lib().u3d_bce_dice_scratch_doubles(n, c, v), dtype=torch.float64, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         coef = torch.empty(2 * c + 1, dtype=torch.float32, device=dev)
         wt = None
