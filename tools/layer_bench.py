@@ -73,7 +73,11 @@ def main():
         aff = torch.randn(N, Cin, 2, device=dev)
         w = torch.randn(Cout, Cin, 3, 3, 3, device=dev) / (27 * Cin) ** 0.5
         flops = 54.0 * Cin * Cout * N * D * H * W
-        line = f"{name:8s} {Cin:3d}->{Cout:3d} @{D}x{H}x{W}: "
+        kind = 0 if t1 is None else (1 if (D, H, W) == (2 * (D // 2), 2 * (H // 2), 2 * (W // 2)) else 2)
+        kn_ = lib.u3d_conv3d_workspace_floats(N, D, H, W, Cin, Cout)
+        var = (lib.u3d_conv3d_variant(N, D, H, W, Cin, Cout, kind, 1 if kn_ else 0), lib.u3d_conv3d_variant(N, D, H, W, Cout, Cin, 0, 1),
+               lib.u3d_conv3d_wgrad_variant(N, D, H, W, Cin, Cout, kind))
+        line = f"{name:8s} {Cin:3d}->{Cout:3d} @{D}x{H}x{W} variants {var[0]}/{var[1]}/{var[2]}: "
         if "fwd" in only:
             wp = U.pack(w, 0)
             y = torch.empty((N, D, H, W, Cout), device=dev)
