@@ -211,9 +211,11 @@ def main():
         opt.step()
         return loss
 
-    # u3d_conv3d_ex is u3d_conv3d with a scratch buffer (same kernels): one family
-    FAMILY = {"u3d_conv3d_ex": "u3d_conv3d"}
-    dominant = {"u3d_conv3d", "u3d_conv3d_ex"}
+    # u3d_conv3d_ex is u3d_conv3d with a scratch buffer, u3d_conv3d_ex_reps that with replica rows of the statistics table (same kernels):
+    # one family; likewise the weight gradient's strided / job-carrying forms
+    FAMILY = {"u3d_conv3d_ex": "u3d_conv3d", "u3d_conv3d_ex_reps": "u3d_conv3d", "u3d_conv3d_wgrad_job": "u3d_conv3d_wgrad",
+              "u3d_conv3d_wgrad_strided": "u3d_conv3d_wgrad"}
+    dominant = {"u3d_conv3d", "u3d_conv3d_ex", "u3d_conv3d_ex_reps"}
     calls_per_step, fam_calls = 32, {"u3d_conv3d": 128}
     for w in range(args.warmup):
         if w == args.warmup - 1 and not args.no_roofline and rank == 0:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define U3D_VERSION 124 /* 124: u3d_bce_dice_scratch_doubles (per-block partials instead of atomics); 123: u3d_conv3d_wgrad_job (the GroupNorm-backward reduction rides in the weight-gradient reduce launch); 122: round 6 — u3d_gn_finalize_split / u3d_gn_bwd_finalize_split (compact half tables of a virtual-concat layer), u3d_adam_step, u3d_chan_stats_children, u3d_pack_weights_batch_cells, tuning key 18; 121: u3d_convtr3d_fwd_t8_b16_ex; 120: flat 5 x 10 x 10 tile of the bf16-storage convolutions (u3d_conv3d_bf16_tile_variant planes = 5), 24 tuning keys; 119: round 5 — ragged volumes on the persistent kernels, u3d_conv3d_variant / u3d_conv3d_wgrad_variant; 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K); 118: u3d_se_*_b16 */
+#define U3D_VERSION 125 /* 125: replica rows of the statistics tables (u3d_conv3d_ex_reps, u3d_gn_finalize_reps, u3d_gn_bwd_job_t::reps_lo); 124: u3d_bce_dice_scratch_doubles (per-block partials instead of atomics); 123: u3d_conv3d_wgrad_job (the GroupNorm-backward reduction rides in the weight-gradient reduce launch); 122: round 6 — u3d_gn_finalize_split / u3d_gn_bwd_finalize_split (compact half tables of a virtual-concat layer), u3d_adam_step, u3d_chan_stats_children, u3d_pack_weights_batch_cells, tuning key 18; 121: u3d_convtr3d_fwd_t8_b16_ex; 120: flat 5 x 10 x 10 tile of the bf16-storage convolutions (u3d_conv3d_bf16_tile_variant planes = 5), 24 tuning keys; 119: round 5 — ragged volumes on the persistent kernels, u3d_conv3d_variant / u3d_conv3d_wgrad_variant; 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K); 118: u3d_se_*_b16 */
 
 #define U3D_OK 0
 #define U3D_EINVAL (-1)  /* bad shape / argument */
@@ -155,6 +155,15 @@ int u3d_conv3d_ex(int device, u3d_stream_t stream, const u3d_src_t* src, const f
                   int D, int H, int W, int Cout, int relu, double* out_stats, const u3d_src_t* gx, double* gstats,
                   const float* residual, float* workspace, long long workspace_floats);
 
+/* u3d_conv3d_ex with a statistics table of stat_reps replica rows: out_stats / gstats are [stat_reps][N][Cout][2] doubles, zeroed by the
+ * caller.  The persistent kernels' 512 blocks flush a sample's sums at the same time, and a same-address f64 atomic retires every 19.5 ns
+ * (tools/atomic_bench.hip): 10 us behind the last tile of a launch on one row, 1.3 us on eight.  Block b adds to row b % stat_reps; every
+ * other kernel variant adds to row 0.  The table the reference's GroupNorm sees (buildingblocks.py:70) is the sum over the rows:
+ * u3d_gn_finalize_reps / u3d_gn_bwd_job_t::reps_lo take it in that form.  stat_reps = 1 is u3d_conv3d_ex. */
+int u3d_conv3d_ex_reps(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w, float* out, int N,
+                       int D, int H, int W, int Cout, int relu, double* out_stats, const u3d_src_t* gx, double* gstats,
+                       const float* residual, float* workspace, long long workspace_floats, int stat_reps);
+
 /* ---- 3x3x3 convolution over a nearest-2x-upsampled tensor, without the upsampled work ------------------------
  * The upsampled half of cat(skip, F.interpolate(low, nearest)) (buildingblocks.py:491,:614) feeding the decoder's first
  * Conv3d (buildingblocks.py:56): for an output voxel of parity p the three taps per dimension read only two low-res
@@ -230,7 +239,7 @@ typedef struct u3d_gn_bwd_job {
     double count;            /* voxels per sample */
     int32_t C0, C1, N, G;
     float hi_scale;
-    int32_t reserved;
+    int32_t reps_lo; /* 0 / 1: gstats_lo is one table; r > 1: r replica rows [r][N][C0][2] whose sum is the table (u3d_conv3d_ex_reps) */
 } u3d_gn_bwd_job_t;
 int u3d_conv3d_wgrad_job_supported(int N, int C, int G);
 int u3d_conv3d_wgrad_job(int device, u3d_stream_t stream, const u3d_src_t* src, const float* dz, float* dw, int dw_cin_stride,
@@ -342,6 +351,11 @@ int u3d_gn_bwd_finalize(int device, u3d_stream_t stream, const double* gstats, c
 int u3d_gn_finalize_split(int device, u3d_stream_t stream, const double* stats0, int C0, double scale0, const double* stats1, int C1,
                           double scale1, int N, int G, double count, const float* gamma, const float* beta, float eps, float* affine,
                           float* mean_rstd, int Csplit, float* affine_lo, float* affine_hi);
+/* u3d_gn_finalize_split on statistics tables with replica rows (u3d_conv3d_ex_reps): stats0 is [reps0][N][C0][2], stats1 [reps1][N][C1][2];
+ * the rows are summed in ascending order before anything else (reps 1 = the plain table). */
+int u3d_gn_finalize_reps(int device, u3d_stream_t stream, const double* stats0, int C0, double scale0, int reps0, const double* stats1,
+                         int C1, double scale1, int reps1, int N, int G, double count, const float* gamma, const float* beta, float eps,
+                         float* affine, float* mean_rstd, int Csplit, float* affine_lo, float* affine_hi);
 int u3d_gn_bwd_finalize_split_supported(int N, int C, int G);
 int u3d_gn_bwd_finalize_split(int device, u3d_stream_t stream, const double* gstats_lo, int C0, const double* gstats_hi, int C1,
                               const float* mean_rstd, const float* gamma, int N, int G, double count, float* dgamma, float* dbeta,

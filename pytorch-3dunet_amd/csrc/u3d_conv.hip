@@ -86,6 +86,7 @@ struct ConvParams {
     int total;   // REG kernel: work items = tiles * ncb
     int gx_x2;   // REG kernel: gx's low-res half is an exact 2x upsampling (index = i >> 1, no table)
     int stagger; // REG kernel: start delay of the second half of the grid, in units of 1024 cycles
+    int stat_reps;  // REG kernel: the statistics table has this many replica rows [reps][N][Cout][2]; block b adds to row b % reps (u3d_conv3d_ex_reps)
     int zfast;   // REG kernel: tiles are walked z-fastest (1) or x-fastest (0)
     int ksplit, cps;        // generic kernel, split-K: the chunk range is cut into ksplit runs of cps chunks, one per block,
     long long part_stride;  // each run writing its partial sums to out + run * part_stride (summed by splitk_reduce_kernel)
@@ -920,6 +921,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
         arrived = __builtin_amdgcn_readfirstlane(arrived);
         asm volatile("" ::: "memory");
         if ((arrived & 3) != 3) return;
+        const int rep = p.stat_reps > 1 ? (int)(blockIdx.x % (unsigned)p.stat_reps) : 0;
         for (int k = l; k < NT * 32; k += 64) {
             double* r = &red[(par * NT * 32 + k) * 2];
             const double a = r[0], b = r[1];
@@ -927,7 +929,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_reg_kernel(const ConvParam
             r[1] = 0.0;
             const int co = cb * NT * 32 + k;
             if (co < p.Cout) {
-                double* dst = (want_stats ? p.out_stats : p.gstats) + ((size_t)n * p.Cout + co) * 2;
+                // (replica row: a same-address f64 atomic retires every 19.5 ns and all 512 blocks flush a sample at the same time —
+                // 10 us behind the last tile of every launch on ONE row, 1.3 us on eight; tools/atomic_bench.hip)
+                double* dst = (want_stats ? p.out_stats : p.gstats) + ((size_t)rep * p.N * p.Cout + (size_t)n * p.Cout + co) * 2;
                 u3d_atomic_add_f64(dst, a);
                 u3d_atomic_add_f64(dst + 1, b);
             }
@@ -1764,7 +1768,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (has_job && blockIdx.x == gridDim.x - 1) {
         extern __shared__ double shb[];
         u3d_gn_bwd_finalize_body(job.gstats_lo, job.mean_rstd, job.gamma, job.N, job.C0 + job.C1, job.G, job.count, 1, 1, job.dgamma,
-                                 job.dbeta, job.coef, job.gstats_hi, job.C0, job.hi_scale, job.coef_hi, shb);
+                                 job.dbeta, job.coef, job.gstats_hi, job.C0, job.hi_scale, job.coef_hi, shb, job.reps_lo);
         return;
     }
     const long long total = (long long)Cin * 27 * Cout;
@@ -2328,7 +2332,7 @@ static int conv_set_lds_once(int device) {
 static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w, float* out, int N,
                        int D, int H, int W, int Cout, int relu, double* out_stats, const u3d_src_t* gx, double* gstats,
                        const float* residual, float* ws = nullptr, long long ws_floats = 0, const int* out_box = nullptr,
-                       const int* in_mask = nullptr);
+                       const int* in_mask = nullptr, int stat_reps = 1);
 
 extern "C" int u3d_conv3d(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w, float* out,
                           int N, int D, int H, int W, int Cout, int relu, double* out_stats, const u3d_src_t* gx,
@@ -2382,6 +2386,17 @@ extern "C" int u3d_conv3d_ex(int device, u3d_stream_t stream, const u3d_src_t* s
                        workspace, workspace_floats);
 }
 
+// ... with a statistics table of stat_reps replica rows [stat_reps][N][Cout][2] (zeroed by the caller): the persistent kernels' blocks
+// spread their per-sample flush over the rows, every other variant adds to row 0 — the true sums are the sums over the rows
+// (u3d_gn_finalize_reps, u3d_gn_bwd_job_t::reps_lo).
+extern "C" int u3d_conv3d_ex_reps(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w, float* out,
+                                  int N, int D, int H, int W, int Cout, int relu, double* out_stats, const u3d_src_t* gx,
+                                  double* gstats, const float* residual, float* workspace, long long workspace_floats, int stat_reps) {
+    U3D_REQUIRE(!(residual && gx), "u3d_conv3d_ex_reps: residual and gx are mutually exclusive");
+    return conv3d_impl(device, stream, src, packed_w, out, N, D, H, W, Cout, relu, out_stats, gx, gstats, residual,
+                       workspace, workspace_floats, nullptr, nullptr, stat_reps);
+}
+
 extern "C" int u3d_conv3d_residual(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w,
                                    float* out, int N, int D, int H, int W, int Cout, int relu, double* out_stats,
                                    const float* residual) {
@@ -2391,9 +2406,10 @@ extern "C" int u3d_conv3d_residual(int device, u3d_stream_t stream, const u3d_sr
 
 static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, const float* packed_w, float* out, int N,
                        int D, int H, int W, int Cout, int relu, double* out_stats, const u3d_src_t* gx, double* gstats,
-                       const float* residual, float* ws, long long ws_floats, const int* out_box, const int* in_mask) {
+                       const float* residual, float* ws, long long ws_floats, const int* out_box, const int* in_mask, int stat_reps) {
     U3D_ENTER(device);
     if (int e = check_src(src, "u3d_conv3d")) return e;
+    U3D_REQUIRE(stat_reps >= 1 && stat_reps <= 64, "u3d_conv3d: stat_reps must be 1 .. 64");
     U3D_REQUIRE(packed_w && out && N > 0 && D > 0 && H > 0 && W > 0 && Cout > 0, "u3d_conv3d: bad argument");
     U3D_REQUIRE((long long)N * D * H * W < (1ll << 31), "u3d_conv3d: N*D*H*W must be < 2^31");
     U3D_REQUIRE(!(out_stats && gstats), "u3d_conv3d: out_stats and gstats are mutually exclusive");
@@ -2496,6 +2512,7 @@ static int conv3d_impl(int device, u3d_stream_t stream, const u3d_src_t* src, co
         // experiment knob, default off: a sweep of 8..64 k cycles changed no layer by more than noise (profiles/r01q) — a
         // wave that is alone on its SIMD does not run at twice the shared rate, so interleaving the epilogues buys nothing
         p.stagger = g_u3d_tune[5];
+        p.stat_reps = stat_reps;
         p.zfast = g_u3d_tune[14] == 1 ? 0 : 1;
         int ncu = 0;
         if (int e = device_cu_count(device, &ncu)) return e;
@@ -2708,7 +2725,8 @@ extern "C" int u3d_conv3d_wgrad_job(int device, u3d_stream_t stream, const u3d_s
     U3D_REQUIRE(src && (dw_cin_stride == 0 || dw_cin_stride >= src->C0 + src->C1), "u3d_conv3d_wgrad_job: dw_cin_stride < channels of src");
     if (job) {
         U3D_REQUIRE(job->gstats_lo && job->mean_rstd && job->gamma && job->dgamma && job->dbeta && job->coef && job->C0 > 0 &&
-                        job->C1 >= 0 && (job->C1 == 0) == (job->gstats_hi == nullptr) && (job->coef_hi == nullptr || job->C1 > 0),
+                        job->C1 >= 0 && (job->C1 == 0) == (job->gstats_hi == nullptr) && (job->coef_hi == nullptr || job->C1 > 0) &&
+                        job->reps_lo >= 0 && job->reps_lo <= 64,
                     "u3d_conv3d_wgrad_job: bad job");
         U3D_REQUIRE(u3d_conv3d_wgrad_job_supported(job->N, job->C0 + job->C1, job->G) == 1,
                     "u3d_conv3d_wgrad_job: the reduction of %d x %d channels in %d groups does not fit one block's LDS", job->N,
@@ -2766,6 +2784,7 @@ static int conv3d_wgrad_impl(int device, u3d_stream_t stream, const u3d_src_t* s
     if (job) {
         jb = *job;
         if (!jb.gstats_hi) jb.C1 = 0, jb.hi_scale = 1.0f, jb.coef_hi = nullptr;
+        if (jb.reps_lo < 1) jb.reps_lo = 1;
         job_lds = wgrad_job_lds_bytes(jb.N, jb.C0 + jb.C1, jb.G);
     }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks + (job ? 1 : 0)), dim3(256), job_lds, (hipStream_t)stream, workspace, dw, p.S,

@@ -4,12 +4,27 @@
 #pragma once
 #include "u3d_common.h"
 
+// Sum of the replica rows of one statistics entry (u3d_conv3d_ex_reps): p[0] + p[stride] + .. + p[(reps - 1) * stride], ascending, with
+// eight loads in flight (a dependent chain of `reps` global loads per thread made a 16-row finalize launch slower than the atomics it saves).
+__device__ __forceinline__ double u3d_sum_replicas(const double* __restrict__ p, size_t stride, int reps) {
+    double v = p[0];
+    for (int r0 = 1; r0 < reps; r0 += 8) {
+        double t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = r0 + j < reps ? p[(size_t)(r0 + j) * stride] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += t[j];
+    }
+    return v;
+}
+
 // One block of 256 threads; shb = dynamic LDS of (par ? 2 * 16 * N * C + 16 * N * G : staged ? 16 * N * C : 0) bytes.
 __device__ inline void u3d_gn_bwd_finalize_body(const double* __restrict__ gs, const float* __restrict__ mean_rstd,
                                                 const float* __restrict__ gamma, int N, int C, int G, double count, int staged, int par,
                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef,
                                                 const double* __restrict__ gs_hi, int C0, float hi_scale, float* __restrict__ coef_hi,
-                                                double* shb) {
+                                                double* shb, int reps = 1) {
+    // reps > 1 (staged paths only): gs holds `reps` replica rows [reps][N][C0 or C][2] whose sum is the table (u3d_conv3d_ex_reps)
 
 #pragma clang fp contract(off)  // (both paths: products rounded, then added in channel order — identical results)
     const double* src = gs;
@@ -20,10 +35,11 @@ __device__ inline void u3d_gn_bwd_finalize_body(const double* __restrict__ gs, c
             const int C1 = C - C0;
             for (int i = threadIdx.x; i < N * C * 2; i += blockDim.x) {
                 const int e = i & 1, nc = i >> 1, n = nc / C, c = nc - n * C;
-                shb[i] = c < C0 ? gs[((size_t)n * C0 + c) * 2 + e] : gs_hi[((size_t)n * C1 + (c - C0)) * 2 + e];
+                shb[i] = c < C0 ? u3d_sum_replicas(gs + ((size_t)n * C0 + c) * 2 + e, (size_t)N * C0 * 2, reps)
+                                : gs_hi[((size_t)n * C1 + (c - C0)) * 2 + e];
             }
         } else {
-            for (int i = threadIdx.x; i < N * C * 2; i += blockDim.x) shb[i] = gs[i];
+            for (int i = threadIdx.x; i < N * C * 2; i += blockDim.x) shb[i] = u3d_sum_replicas(gs + i, (size_t)N * C * 2, reps);
         }
         __syncthreads();
         src = shb;

@@ -364,18 +364,21 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
                                                           const float* __restrict__ beta, float eps,
                                                           float* __restrict__ affine, float* __restrict__ mean_rstd,
                                                           float* __restrict__ affine_lo, float* __restrict__ affine_hi,
-                                                          int Cs) {
+                                                          int Cs, int reps0, int reps1) {
+    // reps0 / reps1 > 1 (u3d_gn_finalize_reps): st0 / st1 hold that many replica rows [reps][N][C][2], summed here in ascending order
     extern __shared__ double sh[];  // [C][2] channel sums, then [G][2] mean / rstd
     const int C = C0 + C1, cpg = C / G, n = blockIdx.x, t = threadIdx.x;
     double* gmr = sh + 2 * (size_t)C;
     for (int c = t; c < C; c += blockDim.x) {
         double s, ss;
         if (c < C0) {
-            s = sc0 * st0[((size_t)n * C0 + c) * 2];
-            ss = sc0 * st0[((size_t)n * C0 + c) * 2 + 1];
+            const double* q = st0 + ((size_t)n * C0 + c) * 2;
+            s = sc0 * u3d_sum_replicas(q, (size_t)gridDim.x * C0 * 2, reps0);
+            ss = sc0 * u3d_sum_replicas(q + 1, (size_t)gridDim.x * C0 * 2, reps0);
         } else {
-            s = sc1 * st1[((size_t)n * C1 + (c - C0)) * 2];
-            ss = sc1 * st1[((size_t)n * C1 + (c - C0)) * 2 + 1];
+            const double* q = st1 + ((size_t)n * C1 + (c - C0)) * 2;
+            s = sc1 * u3d_sum_replicas(q, (size_t)gridDim.x * C1 * 2, reps1);
+            ss = sc1 * u3d_sum_replicas(q + 1, (size_t)gridDim.x * C1 * 2, reps1);
         }
         sh[2 * c] = s;
         sh[2 * c + 1] = ss;
@@ -419,15 +422,17 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
 
 static int gn_finalize_impl(int device, u3d_stream_t stream, const double* stats0, int C0, double scale0, const double* stats1, int C1,
                             double scale1, int N, int G, double count, const float* gamma, const float* beta, float eps, float* affine,
-                            float* mean_rstd, float* affine_lo, float* affine_hi, int Csplit) {
+                            float* mean_rstd, float* affine_lo, float* affine_hi, int Csplit, int reps0 = 1, int reps1 = 1) {
     U3D_ENTER(device);
     const int C = C0 + C1;
+    U3D_REQUIRE(reps0 >= 1 && reps0 <= 64 && reps1 >= 1 && reps1 <= 64, "u3d_gn_finalize_reps: replica counts must be 1 .. 64");
     U3D_REQUIRE(stats0 && C0 > 0 && C1 >= 0 && (C1 == 0 || stats1) && gamma && beta && affine && mean_rstd && N > 0 && G > 0 &&
                     count > 0.0 && Csplit >= 0 && Csplit <= C, "u3d_gn_finalize: bad argument");
     U3D_REQUIRE(C % G == 0, "u3d_gn_finalize: channels %d not divisible by groups %d", C, G);
     U3D_REQUIRE(C <= 4096, "u3d_gn_finalize: more than 4096 channels");
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), sizeof(double) * 2 * ((size_t)C + G), (hipStream_t)stream,
-                       stats0, C0, scale0, stats1, C1, scale1, N, G, count, gamma, beta, eps, affine, mean_rstd, affine_lo, affine_hi, Csplit);
+                       stats0, C0, scale0, stats1, C1, scale1, N, G, count, gamma, beta, eps, affine, mean_rstd, affine_lo, affine_hi, Csplit,
+                       reps0, reps1);
     U3D_LAUNCH_CHECK();
     return 0;
 }
@@ -445,6 +450,14 @@ extern "C" int u3d_gn_finalize_split(int device, u3d_stream_t stream, const doub
                                      int Csplit, float* affine_lo, float* affine_hi) {
     return gn_finalize_impl(device, stream, stats0, C0, scale0, stats1, C1, scale1, N, G, count, gamma, beta, eps, affine, mean_rstd,
                             affine_lo, affine_hi, Csplit);
+}
+
+extern "C" int u3d_gn_finalize_reps(int device, u3d_stream_t stream, const double* stats0, int C0, double scale0, int reps0,
+                                    const double* stats1, int C1, double scale1, int reps1, int N, int G, double count,
+                                    const float* gamma, const float* beta, float eps, float* affine, float* mean_rstd,
+                                    int Csplit, float* affine_lo, float* affine_hi) {
+    return gn_finalize_impl(device, stream, stats0, C0, scale0, stats1, C1, scale1, N, G, count, gamma, beta, eps, affine, mean_rstd,
+                            affine_lo, affine_hi, Csplit, reps0, reps1);
 }
 
 // GroupNorm backward reductions -> dgamma, dbeta, coefficient table coef[N][3][C] (p,q,r).

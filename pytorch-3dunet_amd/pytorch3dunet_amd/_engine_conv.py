@@ -23,6 +23,25 @@ from ._engine_base import *  # noqa: F401,F403  (explicit __all__: helpers, reco
 _WGRAD_JOB = os.environ.get("U3D_WGRAD_JOB", "1") != "0"  # A/B: 0 = GroupNorm-backward reductions as launches of their own
 
 
+def _reps(t) -> int:
+    """replica rows of a statistics table (u3d_conv3d_ex_reps): the tensor a persistent convolution wrote carries the count as an
+    attribute; every other table is one row"""
+    return getattr(t, "_u3d_reps", 1) if t is not None else 1
+
+
+def _take_reps(pool, n: int, reps: int):
+    t = pool.take(reps * n)
+    if reps > 1:
+        t._u3d_reps = reps
+    return t
+
+
+def _fold_reps(t):
+    """the plain table of a replicated one (consumers without a replica-aware entry point: BatchNorm, stand-alone backward finalize)"""
+    r = _reps(t)
+    return t if r == 1 else t.view(r, -1).sum(0)
+
+
 class _SubLayers(dict):
     """{id(conv weight): (C0, C1)} of the decoder first convs that take the sub-pixel path at one input size; `plus` = the ids whose level
     upsamples n -> 2n + 1 along some axis"""
@@ -53,8 +72,8 @@ class _ConvCall:
     affine_lo: Optional[torch.Tensor] = None  # sub-pixel layers: compact rows of `affine` for the skip / upsampled channels
     affine_hi: Optional[torch.Tensor] = None
 
-    def take_stats(self):
-        return self.pool.take(self.N * self.Cout * 2) if self.stats else None
+    def take_stats(self, reps: int = 1):
+        return _take_reps(self.pool, self.N * self.Cout * 2, reps) if self.stats else None
 
     @property
     def flops(self):
@@ -76,6 +95,7 @@ class _BwdCall:
     bf16: bool   # both directions of this layer run on the bf16-operand kernels
     b16: bool    # bf16 activation storage
     job: object = None  # U3DGnBwdJob for the weight-gradient reduce launch to carry (the family that takes it sets it back to None)
+    greps: int = 1      # replica rows of the GroupNorm-backward sums the fp32 data-gradient kernel writes (u3d_conv3d_ex_reps)
 
     @property
     def flops(self):
@@ -170,6 +190,14 @@ class ConvLayers:
         """per-(n,c) sums -> the (a, b) table the convolutions / apply passes use; returns what backward needs (mean, rstd).
         `split` = (Csplit, affine_lo, affine_hi): compact tables of the channel ranges [0, Csplit) / [Csplit, C) written in the same
         launch (GroupNorm over a virtual concat whose halves are read by different kernels; None entries are skipped)"""
+        r0, r1 = _reps(st0), _reps(st1)
+        if kind == "g" and (r0 > 1 or r1 > 1):
+            mean_rstd = _empty((N, G, 2), dtype=_F32, device=dev)
+            sp = split if split is not None else (0, None, None)
+            nat.call("u3d_gn_finalize_reps", dev.index, _stream(dev), _p(st0), C0, sc0, r0, _p(st1), C1, sc1, r1, N, G, count,
+                     _p(mod.weight.detach()), _p(mod.bias.detach()), float(mod.eps), _p(affine), _p(mean_rstd), sp[0], _p(sp[1]), _p(sp[2]))
+            return mean_rstd
+        st0, st1 = _fold_reps(st0), _fold_reps(st1)
         if kind == "g":
             mean_rstd = _empty((N, G, 2), dtype=_F32, device=dev)
             if split is not None:
@@ -206,12 +234,14 @@ class ConvLayers:
         job = nat.U3DGnBwdJob()
         if isinstance(gst, tuple):
             g0, g1 = gst
-            C0 = g0.numel() // (2 * N)
+            assert _reps(g1) == 1
+            C0 = g0.numel() // (2 * N * _reps(g0))
             coef_hi = _empty((N, 3, C - C0), dtype=_F32, device=dev) if not any(rec.src.plus) else None
             job.gstats_lo, job.gstats_hi, job.C0, job.C1, job.hi_scale, job.coef_hi = _p(g0), _p(g1), C0, C - C0, 8.0, _p(coef_hi)
             cx.coef_hi = coef_hi
         else:
             job.gstats_lo, job.gstats_hi, job.C0, job.C1, job.hi_scale, job.coef_hi = _p(gst), None, C, 0, 1.0, None
+        job.reps_lo = _reps(gst[0] if isinstance(gst, tuple) else gst)
         job.mean_rstd, job.gamma = _p(rec.mean_rstd), _p(rec.gn_w.detach())
         job.dgamma, job.dbeta, job.coef = _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef)
         job.count, job.N, job.G = count, N, rec.G
@@ -220,6 +250,7 @@ class ConvLayers:
     def _norm_bwd_finalize(self, cx, rec: ConvRec, gst, N, C, count, coef):
         dev, gview = cx.dev, cx.gview
         cx.coef_hi = None
+        gst = tuple(_fold_reps(g) for g in gst) if isinstance(gst, tuple) else _fold_reps(gst)
         if isinstance(gst, tuple):
             # sub-pixel decoder layer: the sums of the skip / upsampled channels come from two kernels as two tables
             g0, g1 = gst
@@ -271,7 +302,7 @@ class ConvLayers:
         # (8/27 of the multiply-adds), then the skip half, whose epilogue adds the partial sums before ReLU / statistics
         dev, conv, src, N, D, H, W, Cout = c.dev, c.conv, c.src, c.N, c.D, c.H, c.W, c.Cout
         C0, C1 = c.sub[id(conv.weight)]
-        ystats = c.take_stats()
+        ystats = c.take_stats(1 if self._split_fwd(C0, Cout) else self.stat_reps)
         part = _empty((N, D, H, W, Cout), dtype=_F32, device=dev)
         D1, H1, W1 = src.D1, src.H1, src.W1
         plus = src.plus
@@ -301,8 +332,8 @@ class ConvLayers:
                      flops=54.0 * C0 * Cout * N * D * H * W)
         else:
             s0 = VSrc(src.t0).struct(a0)
-            nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s0), _p(self._pack_cache[(id(conv.weight), 10)][1]),
-                     _p(c.y), N, D, H, W, Cout, c.relu, _p(ystats), None, None, _p(part), None, 0,
+            nat.call("u3d_conv3d_ex_reps", dev.index, _stream(dev), ctypes.byref(s0), _p(self._pack_cache[(id(conv.weight), 10)][1]),
+                     _p(c.y), N, D, H, W, Cout, c.relu, _p(ystats), None, None, _p(part), None, 0, _reps(ystats),
                      flops=54.0 * C0 * Cout * N * D * H * W)
         return ystats
 
@@ -328,13 +359,13 @@ class ConvLayers:
 
     def _fwd_fp32(self, c: "_ConvCall"):
         wp = self._packed(c.conv.weight, 0, c.dev)
-        ystats = c.take_stats()
+        ystats = c.take_stats(self.stat_reps)  # (replica rows: the persistent kernel's blocks spread their same-address f64 atomics)
         s = c.src.struct(c.affine)
         # bottom-of-the-U shapes split the channel reduction over blocks through a scratch buffer (0 floats otherwise)
         need = nat.get_lib().u3d_conv3d_workspace_floats(c.N, c.D, c.H, c.W, c.Ctot, c.Cout)
         kws = _empty(need, dtype=_F32, device=c.dev) if need > 0 else None
-        nat.call("u3d_conv3d_ex", c.dev.index, _stream(c.dev), ctypes.byref(s), _p(wp), _p(c.y), c.N, c.D, c.H, c.W, c.Cout, c.relu,
-                 _p(ystats), None, None, _p(c.residual), _p(kws), need, flops=c.flops)
+        nat.call("u3d_conv3d_ex_reps", c.dev.index, _stream(c.dev), ctypes.byref(s), _p(wp), _p(c.y), c.N, c.D, c.H, c.W, c.Cout, c.relu,
+                 _p(ystats), None, None, _p(c.residual), _p(kws), need, _reps(ystats), flops=c.flops)
         return ystats
 
     def _single_conv_fwd(self, sc, name, src: VSrc, st_in, pool: _StatPool, tape: Optional[Tape], want_stats=True,
@@ -543,8 +574,9 @@ class ConvLayers:
         C0, C1 = rec.sub
         dg0 = _empty((Nn, Dd, Hh, Ww, C0), dtype=_F32, device=dev)
         dlow = _empty_like(src.t1)
-        gst0, gst1 = pool.take(Nn * C0 * 2), pool.take(Nn * C1 * 2)
-        if self._split_dgrad(C0, Cout):
+        split0 = self._split_dgrad(C0, Cout)
+        gst0, gst1 = _take_reps(pool, Nn * C0 * 2, 1 if split0 else c.greps), pool.take(Nn * C1 * 2)
+        if split0:
             need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(Nn, Dd, Hh, Ww, Cout, C0)
             kws = cx.ensure_ws(need) if need > 0 else None
             nat.call("u3d_conv3d_f32s", dev.index, _stream(dev), _p(c.dz), None, _p(self._packed_f32s(rec.conv_w, 1, dev, C0, 0)),
@@ -553,8 +585,8 @@ class ConvLayers:
         else:
             s_dz = VSrc(c.dz).struct()
             s_x0 = VSrc(src.t0).struct()
-            nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s_dz), _p(self._packed_sub(rec, 11, dev)), _p(dg0),
-                     Nn, Dd, Hh, Ww, C0, 0, None, ctypes.byref(s_x0), _p(gst0), None, _p(ws), ws.numel(),
+            nat.call("u3d_conv3d_ex_reps", dev.index, _stream(dev), ctypes.byref(s_dz), _p(self._packed_sub(rec, 11, dev)), _p(dg0),
+                     Nn, Dd, Hh, Ww, C0, 0, None, ctypes.byref(s_x0), _p(gst0), None, _p(ws), ws.numel(), _reps(gst0),
                      flops=54.0 * C0 * Cout * Nn * Dd * Hh * Ww)
         plus = src.plus
         if any(plus):
@@ -611,11 +643,11 @@ class ConvLayers:
         cx, dev, src, rec, ws = c.cx, c.cx.dev, c.src, c.rec, c.cx.ws
         wpd = self._packed(rec.conv_w, 1, dev)
         dg = _empty((c.N, c.D, c.H, c.W, src.C), dtype=_F32, device=dev)
-        gst = cx.pool.take(c.N * src.C * 2)
+        gst = _take_reps(cx.pool, c.N * src.C * 2, c.greps)
         s_dz = VSrc(c.dz).struct()
         s_x = src.struct()
-        nat.call("u3d_conv3d_ex", dev.index, _stream(dev), ctypes.byref(s_dz), _p(wpd), _p(dg), c.N, c.D, c.H, c.W, src.C, 0, None,
-                 ctypes.byref(s_x), _p(gst), None, _p(ws), ws.numel(), flops=c.flops)
+        nat.call("u3d_conv3d_ex_reps", dev.index, _stream(dev), ctypes.byref(s_dz), _p(wpd), _p(dg), c.N, c.D, c.H, c.W, src.C, 0, None,
+                 ctypes.byref(s_x), _p(gst), None, _p(ws), ws.numel(), _reps(gst), flops=c.flops)
         return dg, gst
 
     # -- backward building blocks (shared by the DoubleConv and the residual executors) -----------------------
@@ -669,6 +701,10 @@ class ConvLayers:
         call = _BwdCall(cx, rec, dz_, src, Nn, Dd, Hh, Ww, Cout, bf16, b16)
         # ---- data gradient (+ the GroupNorm-backward sums of the conv input), then weight gradient: one family decision each.  The
         # one-block reduction of those sums rides in the weight gradient's reduce launch where the family takes a job (round 6)
+        # (replica rows for the sums only where the weight-gradient launch will take the reduction as a job: it reads them in that form)
+        if (self.stat_reps > 1 and rec.pre_norm and rec.norm == "g" and _WGRAD_JOB and self._wgrad_family(call) in ("fp32", "subpixel")
+                and nat.get_lib().u3d_conv3d_wgrad_job_supported(Nn, src.C, rec.G) == 1):
+            call.greps = self.stat_reps
         dg, gst = getattr(self, self._DGRAD_KERNELS[self._dgrad_family(call)])(call)
         if self.debug is not None and rec.sub is None:
             self.debug[rec.name + ".dg"] = dg.clone()

@@ -33,6 +33,7 @@ class ResUNetEngine(UNet3DEngine):
 
     def __init__(self, model):
         super().__init__(model)
+        self.stat_reps = 1  # (the residual executor's own consumers of the statistics tables read plain ones)
         # two non-linearities per block: conv2's own (from the order string, nn defaults: LeakyReLU 0.01) and the block's final
         # one after `out += residual` (buildingblocks.py:270-275: LeakyReLU(0.1) if 'l', ELU if 'e', else ReLU).  self.act /
         # self.slope / self.mask describe the BLOCK outputs (what pooling, joining and the head consume).

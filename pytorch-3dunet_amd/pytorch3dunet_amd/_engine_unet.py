@@ -33,6 +33,8 @@ class UNet3DEngine(WeightImages, ConvLayers):
         self.grad_sync = None  # set by parallel.GradSync (RCCL all-reduce overlapped with the encoder backward)
         self.debug = None  # dict -> backward stores clones of per-layer dz / dg (tools/gpu_layer_diag.py)
         self.fused_stats = True
+        # replica rows of the statistics tables the persistent fp32 convolutions write (u3d_conv3d_ex_reps; 1 = plain tables)
+        self.stat_reps = max(1, min(64, int(os.environ.get("U3D_STAT_REPS", "8"))))
         self.small_cin = True  # dedicated kernels for the in_channels<=4 first layer
         self.overlap_small_wgrad = True  # weight gradients of small layers on a second HIP stream (see _BwdCtx)
         # decoder first convs over an exact-2x upsampling: sub-pixel convolution of the upsampled half (csrc/u3d_subpix.hip)
@@ -167,10 +169,11 @@ class UNet3DEngine(WeightImages, ConvLayers):
         self._repack_all(dev, (0, 1) if save else (0,), sub)
         # stat doubles: every conv output + every GN input computed standalone; generous upper bound
         tot = 0
+        R = self.stat_reps
         for _, c1, c2 in self.enc:
-            tot += 4 * N * (c1.conv.in_channels + c1.conv.out_channels + c2.conv.out_channels) * 2
+            tot += N * (4 * c1.conv.in_channels + (3 + R) * (c1.conv.out_channels + c2.conv.out_channels)) * 2
         for c1, c2 in self.dec:
-            tot += 4 * N * (c1.conv.in_channels + c1.conv.out_channels + c2.conv.out_channels) * 2
+            tot += N * (4 * c1.conv.in_channels + (3 + R) * (c1.conv.out_channels + c2.conv.out_channels)) * 2
         # (round 6) the backward pass's zeroed scratch — head (dw, db) + 2 doubles per (n, input channel) of every conv — rides in the same
         # fill launch; handed over through the tape, used by the FIRST backward over it
         fcm = self.model.final_conv
@@ -178,9 +181,9 @@ class UNet3DEngine(WeightImages, ConvLayers):
         if save:
             btot = fcm.out_channels * fcm.in_channels + fcm.out_channels
             for _, c1, c2 in self.enc:
-                btot += N * (c1.conv.in_channels + c2.conv.in_channels) * 2
+                btot += R * N * (c1.conv.in_channels + c2.conv.in_channels) * 2
             for c1, c2 in self.dec:
-                btot += N * (c1.conv.in_channels + c2.conv.in_channels) * 2
+                btot += R * N * (c1.conv.in_channels + c2.conv.in_channels) * 2
         pool = _StatPool(dev, tot + btot)
         if tape is not None:
             tape.bwd_pool = pool.carve(btot)
@@ -289,7 +292,7 @@ class UNet3DEngine(WeightImages, ConvLayers):
         # zeroed double scratch: head (dw,db) + 2 doubles per (n, channel) per conv layer
         fc = m.final_conv
         Co, Cf = fc.out_channels, fc.in_channels
-        tot = Co * Cf + Co + sum(N * r.src.C * 2 for r in tape.convs)
+        tot = Co * Cf + Co + sum(self.stat_reps * N * r.src.C * 2 for r in tape.convs)
         pool = getattr(tape, "bwd_pool", None)  # zeroed by the forward's fill launch; a second backward over the tape takes a fresh one
         tape.bwd_pool = None
         # (a backward pass being captured into a hipGraph is replayed without its forward: it zeroes its own scratch inside the graph)

@@ -45,7 +45,7 @@ class U3DGnBwdJob(ctypes.Structure):
 
     _fields_ = [("gstats_lo", c_void_p), ("gstats_hi", c_void_p), ("mean_rstd", c_void_p), ("gamma", c_void_p), ("dgamma", c_void_p),
                 ("dbeta", c_void_p), ("coef", c_void_p), ("coef_hi", c_void_p), ("count", ctypes.c_double), ("C0", c_int32),
-                ("C1", c_int32), ("N", c_int32), ("G", c_int32), ("hi_scale", ctypes.c_float), ("reserved", c_int32)]
+                ("C1", c_int32), ("N", c_int32), ("G", c_int32), ("hi_scale", ctypes.c_float), ("reps_lo", c_int32)]
 
 
 class U3DPackDesc(ctypes.Structure):
@@ -149,6 +149,16 @@ _PROTOS = {
     "u3d_conv3d_wgrad_strided": (
         c_int,
         [c_int, c_void_p, POINTER(U3DSrc), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t],
+    ),
+    "u3d_conv3d_ex_reps": (
+        c_int,
+        [c_int, c_void_p, POINTER(U3DSrc), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, POINTER(U3DSrc),
+         c_void_p, c_void_p, c_void_p, c_int64, c_int],
+    ),
+    "u3d_gn_finalize_reps": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_int, c_double, c_int, c_void_p, c_int, c_double, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
+         c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     ),
     "u3d_conv3d_wgrad_job_supported": (c_int, [c_int, c_int, c_int]),
     "u3d_conv3d_wgrad_job": (
@@ -419,7 +429,7 @@ def get_lib():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.u3d_version() < 124:
+        if lib.u3d_version() < 125:
             raise U3DError("libu3d_hip.so is older than the Python host code")
         for kv in os.environ.get("U3D_TUNE", "").split(","):  # A/B knobs of u3d_set_tuning, e.g. U3D_TUNE=8:256,9:1 (results never change)
             if ":" in kv:

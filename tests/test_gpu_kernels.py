@@ -653,6 +653,72 @@ def test_wgrad_job_equals_wgrad_then_groupnorm_backward_finalize_bit_for_bit(N, 
     assert lib.u3d_conv3d_wgrad_job_supported(4, 1024, 8) == 0
 
 
+@pytest.mark.parametrize("N,Cin,Cout,D,H,W,reps", [(2, 32, 32, 8, 16, 16, 8), (1, 16, 64, 8, 16, 32, 4), (2, 32, 64, 9, 13, 11, 8)])
+def test_statistics_replica_rows_sum_to_the_plain_tables(N, Cin, Cout, D, H, W, reps):
+    """u3d_conv3d_ex_reps (round 6): the persistent kernels' blocks spread the per-sample flush of their f64 sums over `reps` rows of the
+    table; the rows sum to what u3d_conv3d_ex writes, the outputs are bit-identical, u3d_gn_finalize_reps / a weight-gradient job with
+    reps_lo read the rows and give what the plain entry points give on the folded table"""
+    U, nat, VSrc, _p, _stream = _mods()
+    torch.manual_seed(N * 100 + Cin + Cout + D)
+    dev = U.DEV
+    x = U.ndhwc(torch.randn(N, Cin, D, H, W))
+    w = torch.randn(Cout, Cin, 3, 3, 3) / (27 * Cin) ** 0.5
+    aff = torch.randn(N, Cin, 2, device=dev)
+    wp = U.pack(w.to(dev), 0)
+    s = VSrc(x).struct(aff)
+    y0, y1 = torch.empty((N, D, H, W, Cout), device=dev), torch.empty((N, D, H, W, Cout), device=dev)
+    st = torch.zeros((N, Cout, 2), dtype=torch.float64, device=dev)
+    str_ = torch.zeros((reps, N, Cout, 2), dtype=torch.float64, device=dev)
+    nat.call("u3d_conv3d_ex", 0, _stream(dev), ctypes.byref(s), _p(wp), _p(y0), N, D, H, W, Cout, 1, _p(st), None, None, None, None, 0)
+    nat.call("u3d_conv3d_ex_reps", 0, _stream(dev), ctypes.byref(s), _p(wp), _p(y1), N, D, H, W, Cout, 1, _p(str_), None, None, None, None, 0, reps)
+    assert torch.equal(y0, y1)
+    assert torch.allclose(str_.sum(0), st, rtol=1e-12, atol=1e-9)
+    persistent = nat.get_lib().u3d_conv3d_variant(N, D, H, W, Cin, Cout, 0, 0) in (1, 2)
+    if persistent:
+        assert int((str_.abs().sum(dim=(1, 2, 3)) > 0).sum()) > 1, "the persistent kernel must use more than one row"
+    # forward finalize on the rows == on the folded table
+    G = 8
+    gamma, beta = torch.randn(Cout, device=dev), torch.randn(Cout, device=dev)
+    V = float(D * H * W)
+    folded = str_.sum(0).contiguous()
+    a0, m0 = U.gn_finalize(folded, Cout, 1.0, None, 0, 0.0, N, G, V, gamma, beta)
+    a1, m1 = torch.empty_like(a0), torch.empty_like(m0)
+    nat.call("u3d_gn_finalize_reps", 0, _stream(dev), _p(str_), Cout, 1.0, reps, None, 0, 0.0, 1, N, G, V, _p(gamma), _p(beta), 1e-5,
+             _p(a1), _p(m1), 0, None, None)
+    assert torch.allclose(a0, a1, rtol=1e-6, atol=1e-6) and torch.allclose(m0, m1, rtol=1e-6, atol=1e-7)
+    # data gradient role: GroupNorm-backward sums in rows, consumed by the weight-gradient job
+    dz = U.ndhwc(torch.randn(N, Cout, D, H, W))
+    wpd = U.pack(w.to(dev), 1)
+    s_dz, s_x = VSrc(dz).struct(), VSrc(x).struct()
+    dg0, dg1 = torch.empty_like(x), torch.empty_like(x)
+    g_plain = torch.zeros((N, Cin, 2), dtype=torch.float64, device=dev)
+    g_rows = torch.zeros((reps, N, Cin, 2), dtype=torch.float64, device=dev)
+    nat.call("u3d_conv3d_ex", 0, _stream(dev), ctypes.byref(s_dz), _p(wpd), _p(dg0), N, D, H, W, Cin, 0, None, ctypes.byref(s_x), _p(g_plain),
+             None, None, 0)
+    nat.call("u3d_conv3d_ex_reps", 0, _stream(dev), ctypes.byref(s_dz), _p(wpd), _p(dg1), N, D, H, W, Cin, 0, None, ctypes.byref(s_x),
+             _p(g_rows), None, None, 0, reps)
+    assert torch.equal(dg0, dg1) and torch.allclose(g_rows.sum(0), g_plain, rtol=1e-12, atol=1e-9)
+    Gi = 4
+    gam_i, mr = torch.randn(Cin, device=dev), torch.rand(N, Gi, 2, device=dev) + 0.5
+    lib = nat.get_lib()
+    n = lib.u3d_wgrad_workspace_floats(N, D, H, W, Cin, Cout)
+    ws = torch.empty(n, device=dev)
+    outs = []
+    for rows in (False, True):
+        dw = torch.empty((Cout, Cin, 27), device=dev)
+        dgam, dbet, coef = torch.empty(Cin, device=dev), torch.empty(Cin, device=dev), torch.empty((N, 3, Cin), device=dev)
+        table = g_rows if rows else g_rows.sum(0).contiguous()
+        job = nat.U3DGnBwdJob()
+        job.gstats_lo, job.gstats_hi, job.C0, job.C1, job.hi_scale, job.coef_hi, job.reps_lo = _p(table), None, Cin, 0, 1.0, None, reps if rows else 1
+        job.mean_rstd, job.gamma, job.dgamma, job.dbeta, job.coef = _p(mr), _p(gam_i), _p(dgam), _p(dbet), _p(coef)
+        job.count, job.N, job.G = V, N, Gi
+        nat.call("u3d_conv3d_wgrad_job", 0, _stream(dev), ctypes.byref(s), _p(dz), _p(dw), 0, N, D, H, W, Cout, _p(ws), n, ctypes.byref(job))
+        outs.append((dw, dgam, dbet, coef))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("N,C,size", [(2, 8, (8, 12, 16)), (1, 5, (9, 13, 11)), (1, 32, (4, 6, 2)), (2, 64, (8, 16, 16))])
 def test_maxpool_forward_backward_merge(N, C, size):
     U, nat, VSrc, _p, _stream = _mods()
