@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define U3D_VERSION 125 /* 125: replica rows of the statistics tables (u3d_conv3d_ex_reps, u3d_gn_finalize_reps, u3d_gn_bwd_job_t::reps_lo); 124: u3d_bce_dice_scratch_doubles (per-block partials instead of atomics); 123: u3d_conv3d_wgrad_job (the GroupNorm-backward reduction rides in the weight-gradient reduce launch); 122: round 6 — u3d_gn_finalize_split / u3d_gn_bwd_finalize_split (compact half tables of a virtual-concat layer), u3d_adam_step, u3d_chan_stats_children, u3d_pack_weights_batch_cells, tuning key 18; 121: u3d_convtr3d_fwd_t8_b16_ex; 120: flat 5 x 10 x 10 tile of the bf16-storage convolutions (u3d_conv3d_bf16_tile_variant planes = 5), 24 tuning keys; 119: round 5 — ragged volumes on the persistent kernels, u3d_conv3d_variant / u3d_conv3d_wgrad_variant; 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K); 118: u3d_se_*_b16 */
+#define U3D_VERSION 126 /* 126: replica rows also from u3d_chan_stats_reps, u3d_conv3d_small_cin_fwd_reps, u3d_conv1x1_head_bwd_reps + u3d_cvt_f64_f32_sum; 125: replica rows of the statistics tables (u3d_conv3d_ex_reps, u3d_gn_finalize_reps, u3d_gn_bwd_job_t::reps_lo); 124: u3d_bce_dice_scratch_doubles (per-block partials instead of atomics); 123: u3d_conv3d_wgrad_job (the GroupNorm-backward reduction rides in the weight-gradient reduce launch); 122: round 6 — u3d_gn_finalize_split / u3d_gn_bwd_finalize_split (compact half tables of a virtual-concat layer), u3d_adam_step, u3d_chan_stats_children, u3d_pack_weights_batch_cells, tuning key 18; 121: u3d_convtr3d_fwd_t8_b16_ex; 120: flat 5 x 10 x 10 tile of the bf16-storage convolutions (u3d_conv3d_bf16_tile_variant planes = 5), 24 tuning keys; 119: round 5 — ragged volumes on the persistent kernels, u3d_conv3d_variant / u3d_conv3d_wgrad_variant; 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K); 118: u3d_se_*_b16 */
 
 #define U3D_OK 0
 #define U3D_EINVAL (-1)  /* bad shape / argument */
@@ -307,6 +307,9 @@ int u3d_nearest_childsum_add(int device, u3d_stream_t stream, const float* dv, c
  *          without computing the data gradient dg (see csrc/u3d_smallc.hip for the identity). */
 int u3d_conv3d_small_cin_fwd(int device, u3d_stream_t stream, const float* x, const float* affine, const float* w,
                              float* out, int N, int D, int H, int W, int Cin, int Cout, int relu, double* out_stats);
+/* ... with out_stats as `reps` replica rows [reps][N][Cout][2] (u3d_conv3d_ex_reps). */
+int u3d_conv3d_small_cin_fwd_reps(int device, u3d_stream_t stream, const float* x, const float* affine, const float* w, float* out, int N,
+                                  int D, int H, int W, int Cin, int Cout, int relu, double* out_stats, int reps);
 size_t u3d_small_cin_bwd_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
 int u3d_conv3d_small_cin_bwd(int device, u3d_stream_t stream, const float* x, const float* affine, const float* dz,
                              const float* w, float* dw, double* gstats, int N, int D, int H, int W, int Cin, int Cout,
@@ -328,6 +331,9 @@ int u3d_conv3d_naive(int device, u3d_stream_t stream, const u3d_src_t* src, cons
  */
 int u3d_chan_stats(int device, u3d_stream_t stream, const u3d_src_t* src, int N, int D, int H, int W,
                    double* stats);
+/* ... into `reps` replica rows [reps][N][C][2] (zeroed by the caller): block b adds to row b % reps; the table is the sum of the rows
+ * (u3d_gn_finalize_reps).  Same reason as u3d_conv3d_ex_reps: ~1000 blocks per sample adding to the same 2 C doubles. */
+int u3d_chan_stats_reps(int device, u3d_stream_t stream, const u3d_src_t* src, int N, int D, int H, int W, double* stats, int reps);
 int u3d_gn_finalize(int device, u3d_stream_t stream, const double* stats0, int C0, double scale0,
                     const double* stats1, int C1, double scale1, int N, int G, double count, const float* gamma,
                     const float* beta, float eps, float* affine, float* mean_rstd);
@@ -413,7 +419,12 @@ int u3d_conv1x1_head_fwd(int device, u3d_stream_t stream, const float* x, const 
                          int64_t V, int Cin, int Cout, int act, float* logits, float* probs);
 int u3d_conv1x1_head_bwd(int device, u3d_stream_t stream, const float* dlogits, const float* x, const float* w,
                          int N, int64_t V, int Cin, int Cout, int relu_mask, float* dx, double* acc);
+/* ... with acc as `reps` replica rows [reps][Cout * Cin + Cout] (zeroed by the caller), folded by u3d_cvt_f64_f32_sum. */
+int u3d_conv1x1_head_bwd_reps(int device, u3d_stream_t stream, const float* dlogits, const float* x, const float* w, int N, int64_t V,
+                              int Cin, int Cout, int relu_mask, float* dx, double* acc, int reps);
 int u3d_cvt_f64_f32(int device, u3d_stream_t stream, const double* src, float* dst, int64_t n);
+/* dst[i] = float(src[0][i] + .. + src[reps - 1][i]), rows of n doubles, ascending order. */
+int u3d_cvt_f64_f32_sum(int device, u3d_stream_t stream, const double* src, float* dst, int64_t n, int reps);
 
 /* ---- optimizer step (trainer.py:246 `self.optimizer.step()`; create_optimizer, utils.py:246-316: torch.optim.Adam) ------------
  * The Adam update of ALL parameters in ONE launch (csrc/u3d_optim.hip): torch's multi-tensor form is 8 launches / 0.17 ms per step

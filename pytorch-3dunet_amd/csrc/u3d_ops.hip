@@ -154,7 +154,7 @@ static bool src_vec_ok(const u3d_src_t* s) {
 // per-(n,channel) sum / sum of squares of a (virtual) tensor.  grid (blocks_per_n, N), 256 threads:
 // thread -> (row = t / Q, quad = t % Q), Q = ceil(C/4); rows stride the block's voxel range.
 __global__ __launch_bounds__(256) void chan_stats_kernel(const u3d_src_t src, int D, int H, int W, int Q, int rows,
-                                                         int vec, double* __restrict__ stats) {
+                                                         int vec, double* __restrict__ stats, int reps) {
     extern __shared__ float red[];  // [rows][Q][8]
     const int t = threadIdx.x;
     const int n = blockIdx.y;
@@ -214,8 +214,10 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const u3d_src_t src, in
             a += red[(r * Q + qd2) * 8 + e];
             b += red[(r * Q + qd2) * 8 + 4 + e];
         }
-        u3d_atomic_add_f64(&stats[((size_t)n * Ctot + c) * 2 + 0], (double)a);
-        u3d_atomic_add_f64(&stats[((size_t)n * Ctot + c) * 2 + 1], (double)b);
+        // (replica row blockIdx.x % reps, u3d_chan_stats_reps: ~1000 blocks per sample on the same 2 C addresses were most of this pass)
+        double* dst = stats + ((size_t)(blockIdx.x % (unsigned)reps) * gridDim.y * Ctot + (size_t)n * Ctot + c) * 2;
+        u3d_atomic_add_f64(dst, (double)a);
+        u3d_atomic_add_f64(dst + 1, (double)b);
     }
 }
 
@@ -256,8 +258,7 @@ __global__ __launch_bounds__(256) void scalar_stats_kernel(const float* __restri
     }
 }
 
-extern "C" int u3d_chan_stats(int device, u3d_stream_t stream, const u3d_src_t* src, int N, int D, int H, int W,
-                              double* stats) {
+static int chan_stats_impl(int device, u3d_stream_t stream, const u3d_src_t* src, int N, int D, int H, int W, double* stats, int reps) {
     U3D_ENTER(device);
     U3D_REQUIRE(src && src->p0 && stats && N > 0 && D > 0 && H > 0 && W > 0, "u3d_chan_stats: bad argument");
     const int Ctot = src->C0 + src->C1;
@@ -284,9 +285,20 @@ extern "C" int u3d_chan_stats(int device, u3d_stream_t stream, const u3d_src_t* 
     if (bpn > 4096) bpn = 4096;
     const size_t shmem = (size_t)rows * Q * 8 * sizeof(float);
     hipLaunchKernelGGL(chan_stats_kernel, dim3((unsigned)bpn, (unsigned)N), dim3(256), shmem, (hipStream_t)stream,
-                       *src, D, H, W, Q, rows, src_vec_ok(src) ? 1 : 0, stats);
+                       *src, D, H, W, Q, rows, src_vec_ok(src) ? 1 : 0, stats, reps);
     U3D_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int u3d_chan_stats(int device, u3d_stream_t stream, const u3d_src_t* src, int N, int D, int H, int W, double* stats) {
+    return chan_stats_impl(device, stream, src, N, D, H, W, stats, 1);
+}
+
+// ... into a table of `reps` replica rows [reps][N][C][2] (zeroed by the caller; see u3d_conv3d_ex_reps): block b adds to row b % reps
+extern "C" int u3d_chan_stats_reps(int device, u3d_stream_t stream, const u3d_src_t* src, int N, int D, int H, int W, double* stats,
+                                   int reps) {
+    U3D_REQUIRE(reps >= 1 && reps <= 64, "u3d_chan_stats_reps: reps must be 1 .. 64");
+    return chan_stats_impl(device, stream, src, N, D, H, W, stats, reps);
 }
 
 // Per-(n, channel) sums of the NEAREST-UPSAMPLED image of a low-res tensor without touching the upsampled grid: along an axis that is
@@ -1599,7 +1611,7 @@ template <typename T = float>
 __global__ __launch_bounds__(256) void head_bwd_vec_kernel(const float* __restrict__ dl, const T* __restrict__ x,
                                                            const float* __restrict__ w, int N, long long V, int Cin,
                                                            int Cout, int relu_mask, T* __restrict__ dx,
-                                                           double* __restrict__ acc) {
+                                                           double* __restrict__ acc, int reps) {
     extern __shared__ float red[];  // [(Cout+1)][Cin]
     const int t = threadIdx.x;
     const int Q = Cin >> 2;
@@ -1675,7 +1687,8 @@ __global__ __launch_bounds__(256) void head_bwd_vec_kernel(const float* __restri
     for (int i = t; i < Cout * Cin + Cout; i += 256) {
         double sum = 0.0;
         for (int r = 0; r < rows; ++r) sum += (double)red[r * L + i];
-        u3d_atomic_add_f64(&acc[i], sum);
+        // (replica row blockIdx.x % reps of acc[reps][Cout * Cin + Cout], u3d_conv1x1_head_bwd_reps: 2048 blocks on the same 33 doubles)
+        u3d_atomic_add_f64(&acc[(size_t)(blockIdx.x % (unsigned)reps) * (Cout * Cin + Cout) + i], sum);
     }
 }
 
@@ -1690,7 +1703,7 @@ extern "C" int u3d_conv1x1_head_bwd_b16(int device, u3d_stream_t stream, const f
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(head_bwd_vec_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), (size_t)rows * (Cout + 1) * Cin * sizeof(float),
-                       (hipStream_t)stream, dlogits, (const __bf16*)x, w, N, (long long)V, Cin, Cout, relu_mask, (__bf16*)dx, acc);
+                       (hipStream_t)stream, dlogits, (const __bf16*)x, w, N, (long long)V, Cin, Cout, relu_mask, (__bf16*)dx, acc, 1);
     U3D_LAUNCH_CHECK();
     return 0;
 }
@@ -1761,9 +1774,25 @@ __global__ __launch_bounds__(256) void head_bwd_dw_wide_kernel(const float* __re
     }
 }
 
+static int head_bwd_impl(int device, u3d_stream_t stream, const float* dlogits, const float* x, const float* w, int N, int64_t V, int Cin,
+                         int Cout, int relu_mask, float* dx, double* acc, int reps);
+
 extern "C" int u3d_conv1x1_head_bwd(int device, u3d_stream_t stream, const float* dlogits, const float* x,
                                     const float* w, int N, int64_t V, int Cin, int Cout, int relu_mask, float* dx,
                                     double* acc) {
+    return head_bwd_impl(device, stream, dlogits, x, w, N, V, Cin, Cout, relu_mask, dx, acc, 1);
+}
+
+// ... with acc as `reps` replica rows [reps][Cout * Cin + Cout] (zeroed by the caller; the vectorised kernel's block b adds to row
+// b % reps, every other variant to row 0); u3d_cvt_f64_f32_sum folds the rows into the float gradient
+extern "C" int u3d_conv1x1_head_bwd_reps(int device, u3d_stream_t stream, const float* dlogits, const float* x, const float* w, int N,
+                                         int64_t V, int Cin, int Cout, int relu_mask, float* dx, double* acc, int reps) {
+    U3D_REQUIRE(reps >= 1 && reps <= 64, "u3d_conv1x1_head_bwd_reps: reps must be 1 .. 64");
+    return head_bwd_impl(device, stream, dlogits, x, w, N, V, Cin, Cout, relu_mask, dx, acc, reps);
+}
+
+static int head_bwd_impl(int device, u3d_stream_t stream, const float* dlogits, const float* x, const float* w, int N, int64_t V, int Cin,
+                         int Cout, int relu_mask, float* dx, double* acc, int reps) {
     U3D_ENTER(device);
     U3D_REQUIRE(dlogits && x && w && N > 0 && V > 0, "u3d_conv1x1_head_bwd: bad argument");
     U3D_REQUIRE(Cout >= 1 && Cout <= HEAD_WIDE_MAXCO && Cin >= 1 && Cin <= HEAD_MAXCI,
@@ -1793,7 +1822,7 @@ extern "C" int u3d_conv1x1_head_bwd(int device, u3d_stream_t stream, const float
         if (blocks > 2048) blocks = 2048;
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(head_bwd_vec_kernel<float>, dim3((unsigned)blocks), dim3(256), (size_t)rows * (Cout + 1) * Cin * sizeof(float),
-                           (hipStream_t)stream, dlogits, x, w, N, (long long)V, Cin, Cout, relu_mask, dx, acc);
+                           (hipStream_t)stream, dlogits, x, w, N, (long long)V, Cin, Cout, relu_mask, dx, acc, reps);
         U3D_LAUNCH_CHECK();
         return 0;
     }
@@ -1817,6 +1846,20 @@ extern "C" int u3d_conv1x1_head_bwd(int device, u3d_stream_t stream, const float
 __global__ void cvt_f64_f32_kernel(const double* __restrict__ s, float* __restrict__ d, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         d[i] = (float)s[i];
+}
+
+__global__ void cvt_f64_f32_sum_kernel(const double* __restrict__ s, float* __restrict__ d, long long n, int reps) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        d[i] = (float)u3d_sum_replicas(s + i, (size_t)n, reps);
+}
+
+// dst[i] = float(src[0][i] + src[1][i] + .. + src[reps - 1][i]) (ascending): the fold of a replicated f64 accumulator
+extern "C" int u3d_cvt_f64_f32_sum(int device, u3d_stream_t stream, const double* src, float* dst, int64_t n, int reps) {
+    U3D_ENTER(device);
+    U3D_REQUIRE(src && dst && n > 0 && reps >= 1 && reps <= 64, "u3d_cvt_f64_f32_sum: bad argument");
+    hipLaunchKernelGGL(cvt_f64_f32_sum_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, src, dst, (long long)n, reps);
+    U3D_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int u3d_cvt_f64_f32(int device, u3d_stream_t stream, const double* src, float* dst, int64_t n) {

@@ -30,6 +30,7 @@ struct SmallFwdParams {
     double* out_stats;    // optional [N][Cout][2] += (sum, sum of squares) of the written values
     int N, D, H, W, Cin, Cout, relu;
     int tz, ty, tx, B;
+    int reps;             // out_stats has this many replica rows [reps][N][Cout][2]; block b adds to row b % reps (u3d_conv3d_small_cin_fwd_reps)
 };
 
 // grid (B, N): a block walks tiles b, b+B, ... of sample n (weights staged in LDS once per block; the statistics of the
@@ -133,8 +134,9 @@ __global__ __launch_bounds__(256) void conv3d_small_fwd_kernel(const SmallFwdPar
         }
         __syncthreads();
         if (t < p.Cout) {
-            u3d_atomic_add_f64(&p.out_stats[((size_t)n * p.Cout + t) * 2], sred[t][0]);
-            u3d_atomic_add_f64(&p.out_stats[((size_t)n * p.Cout + t) * 2 + 1], sred[t][1]);
+            double* dst = p.out_stats + ((size_t)(blockIdx.x % (unsigned)p.reps) * p.N * p.Cout + (size_t)n * p.Cout + t) * 2;
+            u3d_atomic_add_f64(dst, sred[t][0]);
+            u3d_atomic_add_f64(dst + 1, sred[t][1]);
         }
     }
 }
@@ -278,15 +280,32 @@ __global__ __launch_bounds__(256) void conv3d_small_fwd_mfma_kernel(const SmallF
         }
         __syncthreads();
         if (t < p.Cout) {
-            u3d_atomic_add_f64(&p.out_stats[((size_t)n * p.Cout + t) * 2], sred[t][0]);
-            u3d_atomic_add_f64(&p.out_stats[((size_t)n * p.Cout + t) * 2 + 1], sred[t][1]);
+            double* dst = p.out_stats + ((size_t)(blockIdx.x % (unsigned)p.reps) * p.N * p.Cout + (size_t)n * p.Cout + t) * 2;
+            u3d_atomic_add_f64(dst, sred[t][0]);
+            u3d_atomic_add_f64(dst + 1, sred[t][1]);
         }
     }
 }
 
+static int small_cin_fwd_impl(int device, u3d_stream_t stream, const float* x, const float* affine, const float* w, float* out, int N,
+                              int D, int H, int W, int Cin, int Cout, int relu, double* out_stats, int reps);
+
 extern "C" int u3d_conv3d_small_cin_fwd(int device, u3d_stream_t stream, const float* x, const float* affine,
                                         const float* w, float* out, int N, int D, int H, int W, int Cin, int Cout,
                                         int relu, double* out_stats) {
+    return small_cin_fwd_impl(device, stream, x, affine, w, out, N, D, H, W, Cin, Cout, relu, out_stats, 1);
+}
+
+// ... with out_stats as `reps` replica rows [reps][N][Cout][2] (zeroed by the caller; see u3d_conv3d_ex_reps)
+extern "C" int u3d_conv3d_small_cin_fwd_reps(int device, u3d_stream_t stream, const float* x, const float* affine, const float* w,
+                                             float* out, int N, int D, int H, int W, int Cin, int Cout, int relu, double* out_stats,
+                                             int reps) {
+    U3D_REQUIRE(reps >= 1 && reps <= 64, "u3d_conv3d_small_cin_fwd_reps: reps must be 1 .. 64");
+    return small_cin_fwd_impl(device, stream, x, affine, w, out, N, D, H, W, Cin, Cout, relu, out_stats, reps);
+}
+
+static int small_cin_fwd_impl(int device, u3d_stream_t stream, const float* x, const float* affine, const float* w, float* out, int N,
+                              int D, int H, int W, int Cin, int Cout, int relu, double* out_stats, int reps) {
     U3D_ENTER(device);
     U3D_REQUIRE(x && w && out && N > 0 && D > 0 && H > 0 && W > 0, "u3d_conv3d_small_cin_fwd: bad argument");
     U3D_REQUIRE(Cin >= 1 && Cin <= sc::MAXC && Cout >= 1 && Cout <= 32,
@@ -294,6 +313,7 @@ extern "C" int u3d_conv3d_small_cin_fwd(int device, u3d_stream_t stream, const f
     SmallFwdParams p;
     p.x = x, p.affine = affine, p.w = w, p.out = out, p.out_stats = out_stats;
     p.N = N, p.D = D, p.H = H, p.W = W, p.Cin = Cin, p.Cout = Cout, p.relu = relu;
+    p.reps = reps;
     p.tz = (D + sc::TZ - 1) / sc::TZ, p.ty = (H + sc::TY - 1) / sc::TY, p.tx = (W + sc::TX - 1) / sc::TX;
     const long long ntiles = (long long)p.tz * p.ty * p.tx;
     // 2 blocks per CU in total: every block ends with one f64 atomic pair per output channel on the SAME 2*Cout addresses per sample, and

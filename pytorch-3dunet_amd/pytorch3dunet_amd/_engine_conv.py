@@ -167,9 +167,9 @@ class ConvLayers:
         """(stats0, C0, scale0, stats1, C1, scale1) describing the per-channel sums of a (virtual) tensor"""
         if src.t1 is None:
             if st0 is None:
-                st0 = pool.take(src.N * src.C0 * 2)
+                st0 = _take_reps(pool, src.N * src.C0 * 2, self.stat_reps)
                 s = src.struct()
-                nat.call("u3d_chan_stats", dev.index, _stream(dev), ctypes.byref(s), src.N, src.D, src.H, src.W, _p(st0))
+                nat.call("u3d_chan_stats_reps", dev.index, _stream(dev), ctypes.byref(s), src.N, src.D, src.H, src.W, _p(st0), _reps(st0))
             return st0, src.C0, 1.0, None, 0, 0.0
         if st0 is not None and st1 is not None and src.exact2x and self.fused_stats:
             # every low-res voxel is replicated exactly 8x: reuse the producer's sums
@@ -181,9 +181,9 @@ class ConvLayers:
             st1w = pool.take(src.N * src.C1 * 2)
             nat.call("u3d_chan_stats_children", dev.index, _stream(dev), _p(src.t1), src.N, src.D1, src.H1, src.W1, src.C1, *plus, _p(st1w))
             return st0, src.C0, 1.0, st1w, src.C1, 1.0
-        st = pool.take(src.N * src.C * 2)
+        st = _take_reps(pool, src.N * src.C * 2, self.stat_reps)
         s = src.struct()
-        nat.call("u3d_chan_stats", dev.index, _stream(dev), ctypes.byref(s), src.N, src.D, src.H, src.W, _p(st))
+        nat.call("u3d_chan_stats_reps", dev.index, _stream(dev), ctypes.byref(s), src.N, src.D, src.H, src.W, _p(st), _reps(st))
         return st, src.C, 1.0, None, 0, 0.0
 
     def _norm_finalize(self, kind, mod, st0, C0, sc0, st1, C1, sc1, N, G, count, affine, dev, split=None):
@@ -292,9 +292,9 @@ class ConvLayers:
 
     def _fwd_small(self, c: "_ConvCall"):
         # first layer of the network: K = 27*Cin is too small for the MFMA tiling (csrc/u3d_smallc.hip)
-        ystats = c.take_stats()
-        nat.call("u3d_conv3d_small_cin_fwd", c.dev.index, _stream(c.dev), _p(c.src.t0), _p(c.affine), _p(c.conv.weight.detach()),
-                 _p(c.y), c.N, c.D, c.H, c.W, c.Ctot, c.Cout, c.relu, _p(ystats), flops=c.flops)
+        ystats = c.take_stats(self.stat_reps)
+        nat.call("u3d_conv3d_small_cin_fwd_reps", c.dev.index, _stream(c.dev), _p(c.src.t0), _p(c.affine), _p(c.conv.weight.detach()),
+                 _p(c.y), c.N, c.D, c.H, c.W, c.Ctot, c.Cout, c.relu, _p(ystats), _reps(ystats), flops=c.flops)
         return ystats
 
     def _fwd_subpixel(self, c: "_ConvCall"):

@@ -179,7 +179,7 @@ class UNet3DEngine(WeightImages, ConvLayers):
         fcm = self.model.final_conv
         btot = 0
         if save:
-            btot = fcm.out_channels * fcm.in_channels + fcm.out_channels
+            btot = R * (fcm.out_channels * fcm.in_channels + fcm.out_channels)
             for _, c1, c2 in self.enc:
                 btot += R * N * (c1.conv.in_channels + c2.conv.in_channels) * 2
             for c1, c2 in self.dec:
@@ -292,7 +292,7 @@ class UNet3DEngine(WeightImages, ConvLayers):
         # zeroed double scratch: head (dw,db) + 2 doubles per (n, channel) per conv layer
         fc = m.final_conv
         Co, Cf = fc.out_channels, fc.in_channels
-        tot = Co * Cf + Co + sum(self.stat_reps * N * r.src.C * 2 for r in tape.convs)
+        tot = self.stat_reps * (Co * Cf + Co) + sum(self.stat_reps * N * r.src.C * 2 for r in tape.convs)
         pool = getattr(tape, "bwd_pool", None)  # zeroed by the forward's fill launch; a second backward over the tape takes a fresh one
         tape.bwd_pool = None
         # (a backward pass being captured into a hipGraph is replayed without its forward: it zeroes its own scratch inside the graph)
@@ -301,14 +301,15 @@ class UNet3DEngine(WeightImages, ConvLayers):
         ws = self._wgrad_workspace(tape, dev)
 
         # ---- head backward: dz of the last decoder conv (ReLU mask fused)
-        hacc = pool.take(Co * Cf + Co)
+        hreps = self.stat_reps  # (replica rows of the head's f64 accumulator: 2048 blocks on the same Co * (Cf + 1) doubles)
+        hacc = pool.take(hreps * (Co * Cf + Co))
         dz = _empty_like(tape.head_x)
-        nat.call("u3d_conv1x1_head_bwd", dev.index, _stream(dev), _p(dlogits), _p(tape.head_x), _p(fc.weight.detach()), N, V,
-                 Cf, Co, self.mask, _p(dz), _p(hacc))
+        nat.call("u3d_conv1x1_head_bwd_reps", dev.index, _stream(dev), _p(dlogits), _p(tape.head_x), _p(fc.weight.detach()), N, V,
+                 Cf, Co, self.mask, _p(dz), _p(hacc), hreps)
         self._unact(dev, dz, tape.head_x)
         iw, ib = self._pindex[id(fc.weight)], self._pindex[id(fc.bias)]
         assert self.poffs[ib] == self.poffs[iw] + Co * Cf
-        nat.call("u3d_cvt_f64_f32", dev.index, _stream(dev), _p(hacc), _p(gview(iw)), Co * Cf + Co)
+        nat.call("u3d_cvt_f64_f32_sum", dev.index, _stream(dev), _p(hacc), _p(gview(iw)), Co * Cf + Co, hreps)
 
         n_levels = len(self.enc)
         n_dec = len(self.dec)

@@ -85,6 +85,10 @@ _PROTOS = {
         c_int,
         [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     ),
+    "u3d_conv3d_small_cin_fwd_reps": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int],
+    ),
     "u3d_small_cin_bwd_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "u3d_conv3d_small_cin_bwd": (
         c_int,
@@ -96,6 +100,7 @@ _PROTOS = {
         [c_int, c_void_p, POINTER(U3DSrc), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
     ),
     "u3d_chan_stats": (c_int, [c_int, c_void_p, POINTER(U3DSrc), c_int, c_int, c_int, c_int, c_void_p]),
+    "u3d_chan_stats_reps": (c_int, [c_int, c_void_p, POINTER(U3DSrc), c_int, c_int, c_int, c_int, c_void_p, c_int]),
     "u3d_gn_finalize": (
         c_int,
         [c_int, c_void_p, c_void_p, c_int, c_double, c_void_p, c_int, c_double, c_int, c_int, c_double, c_void_p,
@@ -145,6 +150,10 @@ _PROTOS = {
     "u3d_conv1x1_head_bwd": (
         c_int,
         [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p],
+    ),
+    "u3d_conv1x1_head_bwd_reps": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_int],
     ),
     "u3d_conv3d_wgrad_strided": (
         c_int,
@@ -387,6 +396,7 @@ _PROTOS = {
     "u3d_mul": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "u3d_pair_stats": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
     "u3d_cvt_f64_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64]),
+    "u3d_cvt_f64_f32_sum": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int]),
     "u3d_ncdhw_to_ndhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64]),
     "u3d_ndhwc_to_ncdhw": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64]),
 }
@@ -429,7 +439,7 @@ def get_lib():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.u3d_version() < 125:
+        if lib.u3d_version() < 126:
             raise U3DError("libu3d_hip.so is older than the Python host code")
         for kv in os.environ.get("U3D_TUNE", "").split(","):  # A/B knobs of u3d_set_tuning, e.g. U3D_TUNE=8:256,9:1 (results never change)
             if ":" in kv:

@@ -719,6 +719,47 @@ def test_statistics_replica_rows_sum_to_the_plain_tables(N, Cin, Cout, D, H, W, 
         assert torch.allclose(a, b, rtol=1e-6, atol=1e-6)
 
 
+def test_replica_rows_of_the_other_statistics_producers():
+    """u3d_chan_stats_reps, u3d_conv3d_small_cin_fwd_reps, u3d_conv1x1_head_bwd_reps + u3d_cvt_f64_f32_sum (round 6): the rows sum to
+    what the plain entry points accumulate, everything else they write is bit-identical"""
+    U, nat, VSrc, _p, _stream = _mods()
+    torch.manual_seed(5)
+    dev, R = U.DEV, 8
+    N, C, D, H, W = 2, 16, 16, 32, 32
+    x = U.ndhwc(torch.randn(N, C, D, H, W))
+    s = VSrc(x).struct()
+    st = U.chan_stats(VSrc(x))
+    rows = torch.zeros((R, N, C, 2), dtype=torch.float64, device=dev)
+    nat.call("u3d_chan_stats_reps", 0, _stream(dev), ctypes.byref(s), N, D, H, W, _p(rows), R)
+    assert torch.allclose(rows.sum(0), st, rtol=1e-12, atol=1e-9) and int((rows.abs().sum(dim=(1, 2, 3)) > 0).sum()) > 1
+    # first-layer forward
+    Cin, Cout = 1, 16
+    x1 = U.ndhwc(torch.randn(N, Cin, D, H, W))
+    w = torch.randn(Cout, Cin, 3, 3, 3, device=dev)
+    aff = torch.randn(N, Cin, 2, device=dev)
+    y0, y1 = torch.empty((N, D, H, W, Cout), device=dev), torch.empty((N, D, H, W, Cout), device=dev)
+    s0 = torch.zeros((N, Cout, 2), dtype=torch.float64, device=dev)
+    s1 = torch.zeros((R, N, Cout, 2), dtype=torch.float64, device=dev)
+    nat.call("u3d_conv3d_small_cin_fwd", 0, _stream(dev), _p(x1), _p(aff), _p(w), _p(y0), N, D, H, W, Cin, Cout, 1, _p(s0))
+    nat.call("u3d_conv3d_small_cin_fwd_reps", 0, _stream(dev), _p(x1), _p(aff), _p(w), _p(y1), N, D, H, W, Cin, Cout, 1, _p(s1), R)
+    assert torch.equal(y0, y1) and torch.allclose(s1.sum(0), s0, rtol=1e-12, atol=1e-9)
+    # head backward
+    Cf, Co, V = 32, 1, D * H * W
+    hx = torch.randn(N, V, Cf, device=dev)
+    hw = torch.randn(Co, Cf, device=dev)
+    dl = torch.randn(N, Co, V, device=dev)
+    d0, d1 = torch.empty_like(hx), torch.empty_like(hx)
+    a0 = torch.zeros(Co * Cf + Co, dtype=torch.float64, device=dev)
+    a1 = torch.zeros((R, Co * Cf + Co), dtype=torch.float64, device=dev)
+    nat.call("u3d_conv1x1_head_bwd", 0, _stream(dev), _p(dl), _p(hx), _p(hw), N, V, Cf, Co, 1, _p(d0), _p(a0))
+    nat.call("u3d_conv1x1_head_bwd_reps", 0, _stream(dev), _p(dl), _p(hx), _p(hw), N, V, Cf, Co, 1, _p(d1), _p(a1), R)
+    assert torch.equal(d0, d1) and torch.allclose(a1.sum(0), a0, rtol=1e-12, atol=1e-9)
+    g0, g1 = torch.empty(Co * Cf + Co, device=dev), torch.empty(Co * Cf + Co, device=dev)
+    nat.call("u3d_cvt_f64_f32", 0, _stream(dev), _p(a0), _p(g0), Co * Cf + Co)
+    nat.call("u3d_cvt_f64_f32_sum", 0, _stream(dev), _p(a1), _p(g1), Co * Cf + Co, R)
+    assert torch.allclose(g0, g1, rtol=1e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("N,C,size", [(2, 8, (8, 12, 16)), (1, 5, (9, 13, 11)), (1, 32, (4, 6, 2)), (2, 64, (8, 16, 16))])
 def test_maxpool_forward_backward_merge(N, C, size):
     U, nat, VSrc, _p, _stream = _mods()
