@@ -1,6 +1,5 @@
-B="python bench.py --no-cpu-baseline --no-roofline --no-extras --steps 100 --warmup 10"
-for i in 1 2 3; do
-for t in "19:512" "19:1024" "19:2048"; do
-U3D_TUNE=$t $B 2>/dev/null | python -c "import sys,json; print('$t ', json.loads(sys.stdin.read().strip().splitlines()[-1])['ms_per_step'])"
+for i in 1 2; do
+for w in 3 5 10; do
+python bench.py --no-cpu-baseline --no-extras --steps 20 --warmup $w 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('steps20 warmup$w ', d['ms_per_step'])"
 done
 done
