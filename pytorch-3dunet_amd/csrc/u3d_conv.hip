@@ -1760,12 +1760,13 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
 }
 
 // deterministic second pass of the split-K: block = 64 outputs x 4 split-groups, fixed summation order
-// (has_job: the grid carries ONE extra block that runs the GroupNorm-backward reduction of the layer's input — u3d_conv3d_wgrad_job)
+// (has_job: the grid carries ONE extra block — block 0 — that runs the GroupNorm-backward reduction of the layer's input — u3d_conv3d_wgrad_job)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                            int S, int nchunks, int nkb, int Cin, int Cout, int cstride,
                                                            int has_job, u3d_gn_bwd_job_t job) {
     __shared__ float red[4][64];
-    if (has_job && blockIdx.x == gridDim.x - 1) {
+    // (the job is block 0: dispatched first, its ~5 us dependent chain runs beside the reduction instead of behind its last block)
+    if (has_job && blockIdx.x == 0) {
         extern __shared__ double shb[];
         u3d_gn_bwd_finalize_body(job.gstats_lo, job.mean_rstd, job.gamma, job.N, job.C0 + job.C1, job.G, job.count, 1, 1, job.dgamma,
                                  job.dbeta, job.coef, job.gstats_hi, job.C0, job.hi_scale, job.coef_hi, shb, job.reps_lo);
@@ -1773,7 +1774,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
     const long long total = (long long)Cin * 27 * Cout;
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const long long idx = (long long)blockIdx.x * 64 + lane;  // (c, tap, k) with k fastest: coalesced partial reads
+    const long long idx = (long long)(blockIdx.x - (has_job ? 1 : 0)) * 64 + lane;  // (c, tap, k) with k fastest: coalesced partial reads
     float sum = 0.f;
     int k = 0, tap = 0, c = 0;
     if (idx < total) {
