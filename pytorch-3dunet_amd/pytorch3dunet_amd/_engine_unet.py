@@ -17,7 +17,7 @@ from . import _native as nat
 from ._native import U3DSrc
 
 from ._engine_base import *  # noqa: F401,F403  (explicit __all__: helpers, records, activation codes)
-from ._engine_conv import ConvLayers
+from ._engine_conv import ConvLayers, _reps, _take_reps
 from ._engine_weights import WeightImages
 
 
@@ -195,9 +195,12 @@ class UNet3DEngine(WeightImages, ConvLayers):
                 Np, Dp, Hp, Wp, Cp = cur.shape
                 pooled = _empty((Np, Dp // 2, Hp // 2, Wp // 2, Cp), dtype=_F32, device=dev)
                 argmax = _empty(pooled.shape, dtype=torch.uint8, device=dev)
-                pst = None if self.post_norm else pool.take(Np * Cp * 2)
-                nat.call("u3d_maxpool2_fwd", dev.index, _stream(dev), _p(cur), Np, Dp, Hp, Wp, Cp, _p(pooled), _p(argmax),
-                         _p(pst))
+                pst = None if self.post_norm else _take_reps(pool, Np * Cp * 2, self.stat_reps)
+                nat.call("u3d_maxpool2_fwd", dev.index, _stream(dev), _p(cur), Np, Dp, Hp, Wp, Cp, _p(pooled), _p(argmax), None)
+                if pst is not None:  # (the pooled tensor's statistics: a pass of its own — fused into the pool it was slower — into replica rows)
+                    s_p = VSrc(pooled).struct()
+                    nat.call("u3d_chan_stats_reps", dev.index, _stream(dev), ctypes.byref(s_p), Np, Dp // 2, Hp // 2, Wp // 2, _p(pst),
+                             _reps(pst))
                 if tape is not None:
                     tape.pools.append((pooled, argmax, cur))
                 cur, cur_st = pooled, pst
