@@ -586,6 +586,44 @@ def test_eval_no_grad_on_residual_variants_saves_no_tape():
     assert torch.allclose(y2.detach(), y, atol=1e-6) and logits.requires_grad
 
 
+@pytest.mark.parametrize("shape", [(2, 1, 16, 24, 32), (1, 1, 12, 22, 18)], ids=["aligned", "odd"])
+def test_statistics_replica_rows_do_not_change_the_model(shape):
+    """The DoubleConv executor keeps every f64 statistics table as 8 replica rows (round 6: the blocks of a persistent kernel flush a
+    sample's sums at the same time, and same-address f64 atomics serialize).  With one row (`stat_reps = 1`, the plain entry points'
+    layout) the same model gives the same loss, logits and gradients up to the order of a few f64 additions; the replica-aware entry
+    points really are the ones that run."""
+    from pytorch3dunet_amd import _native as nat
+
+    cfg = dict(in_channels=1, out_channels=2, f_maps=16, layer_order="gcr", num_groups=4, final_sigmoid=True, num_levels=3)
+    torch.manual_seed(9)
+    model = _make(cfg)
+    x = torch.randn(*shape)
+    target = (torch.rand(shape[0], 2, *shape[2:]) > 0.5).float()
+    engine = model.to(torch.device("cuda", 0))._get_engine()
+    keep = engine.stat_reps
+    res = {}
+    try:
+        for reps in (8, 1):
+            engine.stat_reps = reps
+            prof = nat.EventProfiler()
+            nat.profiler = prof
+            try:
+                res[reps] = _run_native(model, x, target, "bce_dice")
+            finally:
+                nat.profiler = None
+            names = set(prof.summary())
+            assert "u3d_conv3d_ex_reps" in names and ("u3d_gn_finalize_reps" in names) == (reps > 1)
+    finally:
+        engine.stat_reps = keep
+    (p8, l8, loss8, g8), (p1, l1, loss1, g1) = res[8], res[1]
+    assert abs(loss8 - loss1) < 1e-6 * max(1.0, abs(loss1))
+    assert (l8 - l1).abs().max().item() < 1e-5 * l1.abs().max().item()
+    gmax = max(v.abs().max().item() for v in g1.values())
+    for k in g1:
+        scale = max(g1[k].abs().max().item(), 1e-3 * gmax)
+        assert (g8[k] - g1[k]).abs().max().item() < 2e-4 * scale, k
+
+
 def test_subpixel_decoder_path_agrees_with_virtual_concat_path():
     """The decoder first convs run the upsampled half as sub-pixel convolutions over the low-res tensor (8/27 of the
     multiply-adds, csrc/u3d_subpix.hip) whenever the upsampling is an exact 2x; with the path switched off the same layers
