@@ -266,8 +266,8 @@ def main():
     # HIP events around the dominant family's launches cost ~7 us of stream time per bracketed launch (measured on one box, round 6: 16.71 ms
     # per step with every launch of every timed step bracketed, 16.51 without any) — that is inside `value`.  The roofline figure needs
     # an average launch duration over the timed region, not every launch of it: every `bracket_every`-th timed step is bracketed
-    # (steps 0, 5, 10, ..), the others run as a user's step does.  U3D_BENCH_BRACKET_EVERY=1: every step (the round-5 behaviour).
-    bracket_every = max(1, int(os.environ.get("U3D_BENCH_BRACKET_EVERY", "5")))
+    # (steps 0, 10, 20, ..), the others run as a user's step does.  U3D_BENCH_BRACKET_EVERY=1: every step (the round-5 behaviour).
+    bracket_every = max(1, int(os.environ.get("U3D_BENCH_BRACKET_EVERY", "10")))
     n_bracketed = (args.steps + bracket_every - 1) // bracket_every
     for i_step in range(args.steps):
         if prof is not None:

@@ -1,1 +1,2 @@
-timeout 2400 python -m pytest tests/ -q -m gpu 2>&1 | grep -v '^$' | grep -v 'RCCL\|HIP version\|ROCm\|Hostname\|Librccl' | tail -6
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4
+python bench.py --gpus 1 --steps 20 --warmup 3 2>/dev/null | tail -1 | cut -c1-330
