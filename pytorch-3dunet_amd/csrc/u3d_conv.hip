@@ -46,6 +46,7 @@
 //   [21] 1 = head forward of the 32 / 64-channel -> 1 / 2-output heads on the vectorised kernel instead of the LDS-rows kernel (A/B)
 //   [22] sub-pixel weight gradient: 1 = always reduced by the one-thread-per-output kernel of round 2, 2 = always by the read-once kernel
 //        (default: read-once from 256 blocks on, csrc/u3d_subpix.hip)
+//   [23] 1 = the weight-gradient reduction always with four split groups per output (A/B of the one-thread-per-output form for <= 16 splits)
 //   [19] / [20] total block count of the first-layer forward / backward kernels (csrc/u3d_smallc.hip; 0 = default 512 / 1024)
 int g_u3d_tune[24] = {0};
 
@@ -1759,8 +1760,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_kernel(const WgradParams 
     }
 }
 
-// deterministic second pass of the split-K: block = 64 outputs x 4 split-groups, fixed summation order
+// deterministic second pass of the split-K: block = 64 outputs x 4 split-groups (G = 4) or 256 outputs, every split in one thread (G = 1:
+// few splits — the deep levels, where four groups of two splits each spent their time on block scheduling and the LDS fold); fixed order
 // (has_job: the grid carries ONE extra block — block 0 — that runs the GroupNorm-backward reduction of the layer's input — u3d_conv3d_wgrad_job)
+template <int G>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                            int S, int nchunks, int nkb, int Cin, int Cout, int cstride,
                                                            int has_job, u3d_gn_bwd_job_t job) {
@@ -1773,8 +1776,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         return;
     }
     const long long total = (long long)Cin * 27 * Cout;
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const long long idx = (long long)(blockIdx.x - (has_job ? 1 : 0)) * 64 + lane;  // (c, tap, k) with k fastest: coalesced partial reads
+    const int lane = G == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63), grp = G == 1 ? 0 : (int)(threadIdx.x >> 6);
+    // (c, tap, k) with k fastest: coalesced partial reads
+    const long long idx = (long long)(blockIdx.x - (has_job ? 1 : 0)) * (G == 1 ? 256 : 64) + lane;
     float sum = 0.f;
     int k = 0, tap = 0, c = 0;
     if (idx < total) {
@@ -1785,7 +1789,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         const int chunk = c >> 5, kb = k >> 5;
         const size_t off = ((size_t)(chunk * nkb + kb) * 27 + tap) * 1024 + (c & 31) * 32 + (k & 31);
         const size_t sstride = (size_t)nchunks * nkb * 27 * 1024;
-        const int per = (S + 3) / 4;
+        const int per = (S + G - 1) / G;
         const int s0 = grp * per, s1 = min(S, s0 + per);
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         int s = s0;
@@ -1798,10 +1802,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         for (; s < s1; ++s) a0 += partial[(size_t)s * sstride + off];
         sum = (a0 + a1) + (a2 + a3);
     }
-    red[grp][lane] = sum;
-    __syncthreads();
-    if (grp == 0 && idx < total)
-        dw[((size_t)k * cstride + c) * 27 + tap] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if constexpr (G == 1) {
+        if (idx < total) dw[((size_t)k * cstride + c) * 27 + tap] = sum;
+    } else {
+        red[grp][lane] = sum;
+        __syncthreads();
+        if (grp == 0 && idx < total)
+            dw[((size_t)k * cstride + c) * 27 + tap] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    }
 }
 
 // the packed image(s) of one layer: the standard image, then — for <= 16 produced channels — the paired-y image and the 16-column
@@ -2779,7 +2787,8 @@ static int conv3d_wgrad_impl(int device, u3d_stream_t stream, const u3d_src_t* s
         hipLaunchKernelGGL(conv3d_wgrad_kernel<false>, dim3(nblk), dim3(wg::NTHR), shmem, (hipStream_t)stream, p);
     U3D_LAUNCH_CHECK();
     const long long total = (long long)Cin * 27 * Cout;
-    const int rblocks = (int)((total + 63) / 64);
+    const bool one_group = p.S <= 16 && g_u3d_tune[23] != 1;  // key 23 = 1: always four split groups (A/B)
+    const int rblocks = (int)((total + (one_group ? 255 : 63)) / (one_group ? 256 : 64));
     u3d_gn_bwd_job_t jb = {};
     size_t job_lds = 0;
     if (job) {
@@ -2788,8 +2797,12 @@ static int conv3d_wgrad_impl(int device, u3d_stream_t stream, const u3d_src_t* s
         if (jb.reps_lo < 1) jb.reps_lo = 1;
         job_lds = wgrad_job_lds_bytes(jb.N, jb.C0 + jb.C1, jb.G);
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks + (job ? 1 : 0)), dim3(256), job_lds, (hipStream_t)stream, workspace, dw, p.S,
-                       p.nchunks, p.nkb, Cin, Cout, cstride > 0 ? cstride : Cin, job ? 1 : 0, jb);
+    if (one_group)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(rblocks + (job ? 1 : 0)), dim3(256), job_lds, (hipStream_t)stream, workspace, dw, p.S,
+                           p.nchunks, p.nkb, Cin, Cout, cstride > 0 ? cstride : Cin, job ? 1 : 0, jb);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(rblocks + (job ? 1 : 0)), dim3(256), job_lds, (hipStream_t)stream, workspace, dw, p.S,
+                           p.nchunks, p.nkb, Cin, Cout, cstride > 0 ? cstride : Cin, job ? 1 : 0, jb);
     U3D_LAUNCH_CHECK();
     return 0;
 }
