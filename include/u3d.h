@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define U3D_VERSION 126 /* 126: replica rows also from u3d_chan_stats_reps, u3d_conv3d_small_cin_fwd_reps, u3d_conv1x1_head_bwd_reps + u3d_cvt_f64_f32_sum; 125: replica rows of the statistics tables (u3d_conv3d_ex_reps, u3d_gn_finalize_reps, u3d_gn_bwd_job_t::reps_lo); 124: u3d_bce_dice_scratch_doubles (per-block partials instead of atomics); 123: u3d_conv3d_wgrad_job (the GroupNorm-backward reduction rides in the weight-gradient reduce launch); 122: round 6 — u3d_gn_finalize_split / u3d_gn_bwd_finalize_split (compact half tables of a virtual-concat layer), u3d_adam_step, u3d_chan_stats_children, u3d_pack_weights_batch_cells, tuning key 18; 121: u3d_convtr3d_fwd_t8_b16_ex; 120: flat 5 x 10 x 10 tile of the bf16-storage convolutions (u3d_conv3d_bf16_tile_variant planes = 5), 24 tuning keys; 119: round 5 — ragged volumes on the persistent kernels, u3d_conv3d_variant / u3d_conv3d_wgrad_variant; 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K); 118: u3d_se_*_b16 */
+#define U3D_VERSION 127 /* 127: u3d_subpixel_conv_dgrad_reps, u3d_gn_bwd_job_t::reps_hi; 126: replica rows also from u3d_chan_stats_reps, u3d_conv3d_small_cin_fwd_reps, u3d_conv1x1_head_bwd_reps + u3d_cvt_f64_f32_sum; 125: replica rows of the statistics tables (u3d_conv3d_ex_reps, u3d_gn_finalize_reps, u3d_gn_bwd_job_t::reps_lo); 124: u3d_bce_dice_scratch_doubles (per-block partials instead of atomics); 123: u3d_conv3d_wgrad_job (the GroupNorm-backward reduction rides in the weight-gradient reduce launch); 122: round 6 — u3d_gn_finalize_split / u3d_gn_bwd_finalize_split (compact half tables of a virtual-concat layer), u3d_adam_step, u3d_chan_stats_children, u3d_pack_weights_batch_cells, tuning key 18; 121: u3d_convtr3d_fwd_t8_b16_ex; 120: flat 5 x 10 x 10 tile of the bf16-storage convolutions (u3d_conv3d_bf16_tile_variant planes = 5), 24 tuning keys; 119: round 5 — ragged volumes on the persistent kernels, u3d_conv3d_variant / u3d_conv3d_wgrad_variant; 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K); 118: u3d_se_*_b16 */
 
 #define U3D_OK 0
 #define U3D_EINVAL (-1)  /* bad shape / argument */
@@ -186,6 +186,9 @@ int u3d_pack_subpixel_dgrad_weights(int device, u3d_stream_t stream, const float
                                     int C1, float* packed);
 int u3d_subpixel_conv_dgrad(int device, u3d_stream_t stream, const float* dz, const float* packed, const float* x_low,
                             float* dlow, double* gstats, int N, int D1, int H1, int W1, int C1, int Cout);
+/* ... with gstats as `reps` replica rows [reps][N][C1][2] (zeroed by the caller; see u3d_conv3d_ex_reps; u3d_gn_bwd_job_t::reps_hi). */
+int u3d_subpixel_conv_dgrad_reps(int device, u3d_stream_t stream, const float* dz, const float* packed, const float* x_low, float* dlow,
+                                 double* gstats, int N, int D1, int H1, int W1, int C1, int Cout, int reps);
 int u3d_pack_subpixel_weights(int device, u3d_stream_t stream, const float* w, int Cout, int Cin_total, int c_off, int C1,
                               float* packed);
 /*   workspace (optional, u3d_subpixel_fwd_workspace_floats() floats, 0 for shapes that never split): on small grids the
@@ -240,6 +243,8 @@ typedef struct u3d_gn_bwd_job {
     int32_t C0, C1, N, G;
     float hi_scale;
     int32_t reps_lo; /* 0 / 1: gstats_lo is one table; r > 1: r replica rows [r][N][C0][2] whose sum is the table (u3d_conv3d_ex_reps) */
+    int32_t reps_hi; /* the same for gstats_hi (u3d_subpixel_conv_dgrad_reps) */
+    int32_t reserved;
 } u3d_gn_bwd_job_t;
 int u3d_conv3d_wgrad_job_supported(int N, int C, int G);
 int u3d_conv3d_wgrad_job(int device, u3d_stream_t stream, const u3d_src_t* src, const float* dz, float* dw, int dw_cin_stride,

@@ -1772,7 +1772,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (has_job && blockIdx.x == 0) {
         extern __shared__ double shb[];
         u3d_gn_bwd_finalize_body(job.gstats_lo, job.mean_rstd, job.gamma, job.N, job.C0 + job.C1, job.G, job.count, 1, 1, job.dgamma,
-                                 job.dbeta, job.coef, job.gstats_hi, job.C0, job.hi_scale, job.coef_hi, shb, job.reps_lo);
+                                 job.dbeta, job.coef, job.gstats_hi, job.C0, job.hi_scale, job.coef_hi, shb, job.reps_lo, job.reps_hi);
         return;
     }
     const long long total = (long long)Cin * 27 * Cout;
@@ -2735,7 +2735,7 @@ extern "C" int u3d_conv3d_wgrad_job(int device, u3d_stream_t stream, const u3d_s
     if (job) {
         U3D_REQUIRE(job->gstats_lo && job->mean_rstd && job->gamma && job->dgamma && job->dbeta && job->coef && job->C0 > 0 &&
                         job->C1 >= 0 && (job->C1 == 0) == (job->gstats_hi == nullptr) && (job->coef_hi == nullptr || job->C1 > 0) &&
-                        job->reps_lo >= 0 && job->reps_lo <= 64,
+                        job->reps_lo >= 0 && job->reps_lo <= 64 && job->reps_hi >= 0 && job->reps_hi <= 64,
                     "u3d_conv3d_wgrad_job: bad job");
         U3D_REQUIRE(u3d_conv3d_wgrad_job_supported(job->N, job->C0 + job->C1, job->G) == 1,
                     "u3d_conv3d_wgrad_job: the reduction of %d x %d channels in %d groups does not fit one block's LDS", job->N,
@@ -2795,6 +2795,7 @@ static int conv3d_wgrad_impl(int device, u3d_stream_t stream, const u3d_src_t* s
         jb = *job;
         if (!jb.gstats_hi) jb.C1 = 0, jb.hi_scale = 1.0f, jb.coef_hi = nullptr;
         if (jb.reps_lo < 1) jb.reps_lo = 1;
+        if (jb.reps_hi < 1 || !jb.gstats_hi) jb.reps_hi = 1;
         job_lds = wgrad_job_lds_bytes(jb.N, jb.C0 + jb.C1, jb.G);
     }
     if (one_group)

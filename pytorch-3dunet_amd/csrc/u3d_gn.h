@@ -23,7 +23,7 @@ __device__ inline void u3d_gn_bwd_finalize_body(const double* __restrict__ gs, c
                                                 const float* __restrict__ gamma, int N, int C, int G, double count, int staged, int par,
                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef,
                                                 const double* __restrict__ gs_hi, int C0, float hi_scale, float* __restrict__ coef_hi,
-                                                double* shb, int reps = 1) {
+                                                double* shb, int reps = 1, int reps_hi = 1) {
     // reps > 1 (staged paths only): gs holds `reps` replica rows [reps][N][C0 or C][2] whose sum is the table (u3d_conv3d_ex_reps)
 
 #pragma clang fp contract(off)  // (both paths: products rounded, then added in channel order — identical results)
@@ -36,7 +36,7 @@ __device__ inline void u3d_gn_bwd_finalize_body(const double* __restrict__ gs, c
             for (int i = threadIdx.x; i < N * C * 2; i += blockDim.x) {
                 const int e = i & 1, nc = i >> 1, n = nc / C, c = nc - n * C;
                 shb[i] = c < C0 ? u3d_sum_replicas(gs + ((size_t)n * C0 + c) * 2 + e, (size_t)N * C0 * 2, reps)
-                                : gs_hi[((size_t)n * C1 + (c - C0)) * 2 + e];
+                                : u3d_sum_replicas(gs_hi + ((size_t)n * C1 + (c - C0)) * 2 + e, (size_t)N * C1 * 2, reps_hi);
             }
         } else {
             for (int i = threadIdx.x; i < N * C * 2; i += blockDim.x) shb[i] = u3d_sum_replicas(gs + i, (size_t)N * C * 2, reps);

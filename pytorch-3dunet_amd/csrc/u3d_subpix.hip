@@ -303,7 +303,8 @@ struct SubpixDgradParams {
     const float* wp;
     const float* xlow;  // (N, D1, H1, W1, C1): forward input of the upsampled half (for the sums), may be null
     float* out;         // (N, D1, H1, W1, C1)
-    double* gstats;     // [N][C1][2] += (sum dlow, sum dlow*x), may be null
+    double* gstats;     // [reps][N][C1][2] += (sum dlow, sum dlow*x), may be null
+    int greps;          // replica rows of gstats (block b adds to row b % greps; u3d_subpixel_conv_dgrad_reps)
     int N, D1, H1, W1, C1, K;
     int tz, ty, tx, nchunks, ncb, ntot;
     // round 5 (u3d_subpixel_conv_dgrad_win): voxel u of the 2x grid is dz[u + o] of a (Dd, Hd, Wd) tensor and counts only if u >= l
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void subpixel_dgrad_kernel(const SubpixDgra
             const int cc = (cb * 2 + nh) * 32 + c;
             if (cc < p.C1) {
                 const float sum = red[((nh * 2 + 0) * 32 + c) * 2 + j] + red[((nh * 2 + 1) * 32 + c) * 2 + j];
-                u3d_atomic_add_f64(&p.gstats[((size_t)n * p.C1 + cc) * 2 + j], (double)sum);
+                u3d_atomic_add_f64(&p.gstats[((size_t)(blockIdx.x % (unsigned)p.greps) * p.N * p.C1 + (size_t)n * p.C1 + cc) * 2 + j], (double)sum);
             }
         }
     }
@@ -978,12 +979,21 @@ extern "C" int u3d_pack_subpixel_dgrad_weights(int device, u3d_stream_t stream, 
 }
 
 static int subpixel_conv_dgrad_impl(int device, u3d_stream_t stream, const float* dz, const float* packed, const float* x_low,
-                                    float* dlow, double* gstats, int N, int D1, int H1, int W1, int C1, int Cout, const int* win);
+                                    float* dlow, double* gstats, int N, int D1, int H1, int W1, int C1, int Cout, const int* win,
+                                    int greps = 1);
 
 extern "C" int u3d_subpixel_conv_dgrad(int device, u3d_stream_t stream, const float* dz, const float* packed,
                                        const float* x_low, float* dlow, double* gstats, int N, int D1, int H1, int W1, int C1,
                                        int Cout) {
     return subpixel_conv_dgrad_impl(device, stream, dz, packed, x_low, dlow, gstats, N, D1, H1, W1, C1, Cout, nullptr);
+}
+
+// ... with gstats as `reps` replica rows [reps][N][C1][2] (zeroed by the caller; u3d_conv3d_ex_reps): the last wave of resident blocks
+// flushes onto the same 2 C1 doubles at the end of the launch
+extern "C" int u3d_subpixel_conv_dgrad_reps(int device, u3d_stream_t stream, const float* dz, const float* packed, const float* x_low,
+                                            float* dlow, double* gstats, int N, int D1, int H1, int W1, int C1, int Cout, int reps) {
+    U3D_REQUIRE(reps >= 1 && reps <= 64, "u3d_subpixel_conv_dgrad_reps: reps must be 1 .. 64");
+    return subpixel_conv_dgrad_impl(device, stream, dz, packed, x_low, dlow, gstats, N, D1, H1, W1, C1, Cout, nullptr, reps);
 }
 
 // ... reading dz through the window of u3d_subpixel_conv_fwd_win: win = {Dd, Hd, Wd, oz, oy, ox, lz, ly, lx} — dz is (N, Dd, Hd, Wd,
@@ -998,7 +1008,8 @@ extern "C" int u3d_subpixel_conv_dgrad_win(int device, u3d_stream_t stream, cons
 }
 
 static int subpixel_conv_dgrad_impl(int device, u3d_stream_t stream, const float* dz, const float* packed, const float* x_low,
-                                    float* dlow, double* gstats, int N, int D1, int H1, int W1, int C1, int Cout, const int* win) {
+                                    float* dlow, double* gstats, int N, int D1, int H1, int W1, int C1, int Cout, const int* win,
+                                    int greps) {
     U3D_ENTER(device);
     U3D_REQUIRE(dz && packed && dlow && N > 0 && D1 > 0 && H1 > 0 && W1 > 0 && C1 > 0 && Cout > 0,
                 "u3d_subpixel_conv_dgrad: bad argument");
@@ -1010,6 +1021,7 @@ static int subpixel_conv_dgrad_impl(int device, u3d_stream_t stream, const float
     U3D_REQUIRE((long long)N * D1 * H1 * W1 * 8 < (1ll << 31), "u3d_subpixel_conv_dgrad: volume too large");
     SubpixDgradParams p;
     p.dz = dz, p.wp = packed, p.xlow = x_low, p.out = dlow, p.gstats = gstats;
+    p.greps = greps;
     p.N = N, p.D1 = D1, p.H1 = H1, p.W1 = W1, p.C1 = C1, p.K = Cout;
     p.Dd = 2 * D1, p.Hd = 2 * H1, p.Wd = 2 * W1, p.oz = p.oy = p.ox = 0, p.lz = p.ly = p.lx = 0;
     if (win) {

@@ -234,7 +234,6 @@ class ConvLayers:
         job = nat.U3DGnBwdJob()
         if isinstance(gst, tuple):
             g0, g1 = gst
-            assert _reps(g1) == 1
             C0 = g0.numel() // (2 * N * _reps(g0))
             coef_hi = _empty((N, 3, C - C0), dtype=_F32, device=dev) if not any(rec.src.plus) else None
             job.gstats_lo, job.gstats_hi, job.C0, job.C1, job.hi_scale, job.coef_hi = _p(g0), _p(g1), C0, C - C0, 8.0, _p(coef_hi)
@@ -242,6 +241,7 @@ class ConvLayers:
         else:
             job.gstats_lo, job.gstats_hi, job.C0, job.C1, job.hi_scale, job.coef_hi = _p(gst), None, C, 0, 1.0, None
         job.reps_lo = _reps(gst[0] if isinstance(gst, tuple) else gst)
+        job.reps_hi = _reps(gst[1]) if isinstance(gst, tuple) else 1
         job.mean_rstd, job.gamma = _p(rec.mean_rstd), _p(rec.gn_w.detach())
         job.dgamma, job.dbeta, job.coef = _p(gview(rec.idx_gw)), _p(gview(rec.idx_gb)), _p(coef)
         job.count, job.N, job.G = count, N, rec.G
@@ -575,7 +575,9 @@ class ConvLayers:
         dg0 = _empty((Nn, Dd, Hh, Ww, C0), dtype=_F32, device=dev)
         dlow = _empty_like(src.t1)
         split0 = self._split_dgrad(C0, Cout)
-        gst0, gst1 = _take_reps(pool, Nn * C0 * 2, 1 if split0 else c.greps), pool.take(Nn * C1 * 2)
+        plus = src.plus
+        gst0 = _take_reps(pool, Nn * C0 * 2, 1 if split0 else c.greps)
+        gst1 = _take_reps(pool, Nn * C1 * 2, 1 if any(plus) else c.greps)  # (the windowed form of an n -> 2n + 1 level keeps one row)
         if split0:
             need = nat.get_lib().u3d_conv3d_bf16_workspace_floats(Nn, Dd, Hh, Ww, Cout, C0)
             kws = cx.ensure_ws(need) if need > 0 else None
@@ -613,8 +615,8 @@ class ConvLayers:
                      src.D1, src.H1, src.W1, C1, _p(lz), _p(ly), _p(lx), *plus)
             del dv
         else:
-            nat.call("u3d_subpixel_conv_dgrad", dev.index, _stream(dev), _p(c.dz), _p(self._packed_sub(rec, 13, dev)), _p(src.t1),
-                     _p(dlow), _p(gst1), Nn, src.D1, src.H1, src.W1, C1, Cout,
+            nat.call("u3d_subpixel_conv_dgrad_reps", dev.index, _stream(dev), _p(c.dz), _p(self._packed_sub(rec, 13, dev)), _p(src.t1),
+                     _p(dlow), _p(gst1), Nn, src.D1, src.H1, src.W1, C1, Cout, _reps(gst1),
                      flops=128.0 * C1 * Cout * Nn * src.D1 * src.H1 * src.W1)
         return (dg0, dlow), (gst0, gst1)  # (_norm_bwd_finalize takes the two tables as they are)
 

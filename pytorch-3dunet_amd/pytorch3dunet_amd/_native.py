@@ -45,7 +45,7 @@ class U3DGnBwdJob(ctypes.Structure):
 
     _fields_ = [("gstats_lo", c_void_p), ("gstats_hi", c_void_p), ("mean_rstd", c_void_p), ("gamma", c_void_p), ("dgamma", c_void_p),
                 ("dbeta", c_void_p), ("coef", c_void_p), ("coef_hi", c_void_p), ("count", ctypes.c_double), ("C0", c_int32),
-                ("C1", c_int32), ("N", c_int32), ("G", c_int32), ("hi_scale", ctypes.c_float), ("reps_lo", c_int32)]
+                ("C1", c_int32), ("N", c_int32), ("G", c_int32), ("hi_scale", ctypes.c_float), ("reps_lo", c_int32), ("reps_hi", c_int32), ("reserved", c_int32)]
 
 
 class U3DPackDesc(ctypes.Structure):
@@ -192,6 +192,10 @@ _PROTOS = {
     "u3d_subpixel_conv_dgrad": (
         c_int,
         [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int],
+    ),
+    "u3d_subpixel_conv_dgrad_reps": (
+        c_int,
+        [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
     ),
     "u3d_pack_subpixel_weights": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     # round 5: decoder levels that upsample n -> 2n + 1 (sub-pixel kernels on a window + the general kernels on the boundary slab)
@@ -439,7 +443,7 @@ def get_lib():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.u3d_version() < 126:
+        if lib.u3d_version() < 127:
             raise U3DError("libu3d_hip.so is older than the Python host code")
         for kv in os.environ.get("U3D_TUNE", "").split(","):  # A/B knobs of u3d_set_tuning, e.g. U3D_TUNE=8:256,9:1 (results never change)
             if ":" in kv:

@@ -322,6 +322,12 @@ def test_subpixel_conv_dgrad_to_low_res(N, C1, Cout, D1, H1, W1):
     assert U.relerr(U.ncdhw(out), ref) < TOL
     s_ref = torch.stack([ref.double().sum(dim=(2, 3, 4)), (ref.double() * low.double()).sum(dim=(2, 3, 4))], dim=-1)
     assert U.relerr(gst.cpu(), s_ref) < 1e-5
+    # replica rows of the sums (round 6): same gradient bit for bit, rows add up to the plain table
+    out2 = torch.empty_like(out)
+    rows = torch.zeros((8, N, C1, 2), dtype=torch.float64, device=U.DEV)
+    nat.call("u3d_subpixel_conv_dgrad_reps", 0, _stream(U.DEV), _p(U.ndhwc(dz)), _p(pk), _p(lowd), _p(out2), _p(rows), N, D1, H1, W1, C1,
+             Cout, 8)
+    assert torch.equal(out, out2) and torch.allclose(rows.sum(0), gst, rtol=1e-12, atol=1e-9)
 
 
 @pytest.fixture
@@ -616,6 +622,7 @@ def test_wgrad_job_equals_wgrad_then_groupnorm_backward_finalize_bit_for_bit(N, 
     mr = torch.rand(N, G, 2, device=dev) + 0.5
     g0 = torch.randn(N, C0, 2, dtype=torch.float64, device=dev) * 100
     g1 = torch.randn(N, max(C1, 1), 2, dtype=torch.float64, device=dev) * 100
+    g1r = torch.stack((g1 * 0.5, g1 * 0.25, g1 * 0.25)).contiguous()  # (exact binary fractions: the rows sum to g1 bit for bit)
     lib = nat.get_lib()
     assert lib.u3d_conv3d_wgrad_job_supported(N, C, G) == 1
     n = lib.u3d_wgrad_workspace_floats(N, D, H, W, Cin, Cout)
@@ -628,7 +635,8 @@ def test_wgrad_job_equals_wgrad_then_groupnorm_backward_finalize_bit_for_bit(N, 
         chi = torch.zeros((N, 3, max(C1, 1)), device=dev)
         if fused:
             job = nat.U3DGnBwdJob()
-            job.gstats_lo, job.gstats_hi, job.C0, job.C1 = _p(g0), _p(g1) if C1 else None, C0, C1
+            job.gstats_lo, job.gstats_hi, job.C0, job.C1 = _p(g0), _p(g1r) if C1 else None, C0, C1
+            job.reps_hi = 3 if C1 else 1  # (the upper table as three replica rows that add up to g1)
             job.hi_scale, job.coef_hi = (8.0, _p(chi)) if C1 else (1.0, None)
             job.mean_rstd, job.gamma, job.dgamma, job.dbeta, job.coef = _p(mr), _p(gamma), _p(dgam), _p(dbet), _p(coef)
             job.count, job.N, job.G = V, N, G
