@@ -361,14 +361,20 @@ struct SmallBwdParams {
 };
 
 
-template <int CIN, int RT>  // RT = row tiles of 16 output channels (Cout <= 16*RT)
+// VA (round 6; RT = 1: two 16 KB dz buffers fit the static LDS limit): Cout == 16, every tile inside the volume, dz 16-byte aligned — the dz tile goes through LDS with 16-byte loads at
+// per-thread CONSTANT offsets from a scalar tile base (the first form fetched every A operand as a 4-byte global load with its own
+// coordinate arithmetic: 330 vector instructions per tile and wave beside 64 MFMAs that run on the same lanes — 91 us for a pass whose
+// 134 MB take 25 us at HBM rate), and the halo indices are per-thread constants too (coordinates only on tiles that touch a face).
+template <int CIN, int RT, bool VA = false>  // RT = row tiles of 16 output channels (Cout <= 16*RT)
 __global__ __launch_bounds__(256) void conv3d_small_bwd_kernel(const SmallBwdParams p) {
     using namespace sc;
     constexpr int C1 = CIN + 1;
     constexpr int NCOL = 27 * C1;
     constexpr int NCT = (NCOL + 15) / 16;
     constexpr int NH = (HV + 255) / 256;  // halo voxels per thread (3)
+    constexpr int NQ = 4 * RT;            // VA: channel quads per voxel = 16-byte items per thread and tile
     __shared__ float xsb[2][HV * C1];  // [hv][CIN+1]: raw x, then the in-bounds indicator; two buffers (round 6, see below)
+    __shared__ __attribute__((aligned(16))) float dzs[VA ? 2 : 1][VA ? 256 * 16 * RT : 4];  // VA: [voxel][16 * RT channels], two buffers
     const int t = threadIdx.x, l = t & 63, w = t >> 6;
     const int n = blockIdx.y;
     const int j = l & 15, kk = l >> 4;
@@ -411,20 +417,53 @@ __global__ __launch_bounds__(256) void conv3d_small_bwd_kernel(const SmallBwdPar
             }
         }
     };
+    // VA: item i = t + 256 * it of a tile = (voxel i / NQ, channel quad i % NQ): constant element offset from the tile's first voxel
+    int drel[VA ? NQ : 1];
+    if constexpr (VA) {
+#pragma unroll
+        for (int it = 0; it < NQ; ++it) {
+            const int i = t + 256 * it, vox = i / NQ, q = i - vox * NQ;
+            drel[it] = (((vox >> 6) * H + ((vox >> 3) & 7)) * W + (vox & 7)) * (16 * RT) + 4 * q;
+        }
+    }
+    auto dz_load = [&](int tile, f32x4 (&v)[VA ? NQ : 1]) {
+        int z0, y0, x0;
+        origin(tile, z0, y0, x0);
+        const float* base = p.dz + ((size_t)((n * D + z0) * H + y0) * W + x0) * (16 * RT);
+#pragma unroll
+        for (int it = 0; it < NQ; ++it) v[it] = *reinterpret_cast<const f32x4*>(base + drel[it]);
+    };
+    auto dz_store = [&](float* buf, const f32x4 (&v)[VA ? NQ : 1]) {
+#pragma unroll
+        for (int it = 0; it < NQ; ++it) *reinterpret_cast<f32x4*>(buf + (size_t)(t + 256 * it) * 4) = v[it];
+    };
+    const int abase = ((w * 64 + kk) * 16 * RT) + j;  // VA: LDS offset of this lane's A element at step 0, row tile 0
+    // halo item `it` of a thread: packed halo coordinates and the voxel offset from the tile's first voxel (constants)
+    int hpk[NH], hrel[NH];
+#pragma unroll
+    for (int it = 0; it < NH; ++it) {
+        const int i = t + 256 * it;
+        const int hz = i / (HY * HX), rem = i - hz * (HY * HX), hy = rem / HX, hxx = rem - hy * HX;
+        hpk[it] = i < HV ? (hz | (hy << 8) | (hxx << 16)) : -1;
+        hrel[it] = ((hz - 1) * H + (hy - 1)) * W + (hxx - 1);
+    }
     // raw halo voxels of a tile into registers; the LDS stores follow after the current tile's MFMAs (round 6: both operand fetches of
     // tile t+1 run under the arithmetic of tile t — with fill -> barrier -> compute -> barrier per tile every load latency was exposed)
     auto halo_load = [&](int tile, float (&hx)[NH][CIN], unsigned& inside) {
         int z0, y0, x0;
         origin(tile, z0, y0, x0);
         inside = 0;
+        const int vbase = ((n * D + z0) * H + y0) * W + x0;
+        const bool interior = z0 > 0 && z0 + TZ < D && y0 > 0 && y0 + TY < H && x0 > 0 && x0 + TX < W;  // (uniform)
 #pragma unroll
         for (int it = 0; it < NH; ++it) {
-            const int i = t + 256 * it;
-            const int hz = i / (HY * HX), rem = i - hz * (HY * HX), hy = rem / HX, hxx = rem - hy * HX;
-            const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hxx;
-            const bool in = i < HV && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            bool in = hpk[it] >= 0;
+            if (!interior) {
+                const int gz = z0 - 1 + (hpk[it] & 255), gy = y0 - 1 + ((hpk[it] >> 8) & 255), gx = x0 - 1 + ((hpk[it] >> 16) & 255);
+                in = in && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            }
             inside |= (in ? 1u : 0u) << it;
-            const float* src = p.x + ((size_t)((n * D + (in ? gz : 0)) * H + (in ? gy : 0)) * W + (in ? gx : 0)) * CIN;
+            const float* src = p.x + (size_t)(in ? vbase + hrel[it] : 0) * CIN;
 #pragma unroll
             for (int c = 0; c < CIN; ++c) hx[it][c] = in ? src[c] : 0.f;
         }
@@ -440,11 +479,17 @@ __global__ __launch_bounds__(256) void conv3d_small_bwd_kernel(const SmallBwdPar
             }
         }
     };
-    float a[RT][16], hx[NH][CIN];
+    float a[VA ? 1 : RT][16], hx[NH][CIN];
+    f32x4 dv[VA ? NQ : 1];
     unsigned hin = 0;
     int cur = 0;
     if ((int)blockIdx.x < ntiles) {
-        a_load(blockIdx.x, a);
+        if constexpr (VA) {
+            dz_load(blockIdx.x, dv);
+            dz_store(dzs[0], dv);
+        } else {
+            a_load(blockIdx.x, a);
+        }
         halo_load(blockIdx.x, hx, hin);
         halo_store(xsb[0], hx, hin);
     }
@@ -452,29 +497,39 @@ __global__ __launch_bounds__(256) void conv3d_small_bwd_kernel(const SmallBwdPar
     for (int tile = blockIdx.x; tile < ntiles; tile += p.B) {
         const float* xs = xsb[cur];
         const bool has_next = tile + p.B < ntiles;
-        float an[RT][16];
+        float an[VA ? 1 : RT][16];
         if (has_next) {
-            a_load(tile + p.B, an);
+            if constexpr (VA) dz_load(tile + p.B, dv);
+            else a_load(tile + p.B, an);
             halo_load(tile + p.B, hx, hin);
         }
 #pragma unroll
         for (int s_ = 0; s_ < 16; ++s_) {
             const int so = ((s_ >> 1) * HX + (s_ & 1) * 4) * C1;
-            float b[NCT];
+            float b[NCT], as[RT];
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) b[ct] = xs[bbase + so + boff[ct]];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                if constexpr (VA) as[rt] = dzs[cur][abase + ((s_ >> 1) * 8 + (s_ & 1) * 4) * 16 * RT + 16 * rt];
+                else as[rt] = a[rt][s_];
+            }
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][s_], b[ct], acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[rt], b[ct], acc[rt][ct], 0, 0, 0);
         }
         if (has_next) {
             halo_store(xsb[cur ^ 1], hx, hin);
+            if constexpr (VA) {
+                dz_store(dzs[cur ^ 1], dv);
+            } else {
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
+                for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int s_ = 0; s_ < 16; ++s_) a[rt][s_] = an[rt][s_];
+                    for (int s_ = 0; s_ < 16; ++s_) a[rt][s_] = an[rt][s_];
+            }
         }
         __syncthreads();  // the next tile's halo is complete; nobody reads the current buffer any more
         cur ^= 1;
@@ -624,12 +679,17 @@ extern "C" int u3d_conv3d_small_cin_bwd(int device, u3d_stream_t stream, const f
         return u3d_set_err(U3D_EWORKSPACE, "u3d_conv3d_small_cin_bwd: workspace %zu < %zu floats", workspace_floats, need);
     const dim3 grid((unsigned)p.B, (unsigned)N), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define U3D_SMALL_BWD(CIN_)                                                                   \
-    do {                                                                                      \
-        if (Cout <= 16)                                                                       \
-            hipLaunchKernelGGL((conv3d_small_bwd_kernel<CIN_, 1>), grid, block, 0, st, p);    \
-        else                                                                                  \
-            hipLaunchKernelGGL((conv3d_small_bwd_kernel<CIN_, 2>), grid, block, 0, st, p);    \
+    // whole tiles, whole row tiles of 16 channels, aligned dz: the dz tile through LDS (VA); key 20 = -1: the first form (A/B; bit-identical)
+    const bool va = Cout == 16 && D % sc::TZ == 0 && H % sc::TY == 0 && W % sc::TX == 0 && ((uintptr_t)dz & 15) == 0 &&
+                    g_u3d_tune[20] != -1;
+#define U3D_SMALL_BWD(CIN_)                                                                          \
+    do {                                                                                             \
+        if (Cout <= 16 && va)                                                                        \
+            hipLaunchKernelGGL((conv3d_small_bwd_kernel<CIN_, 1, true>), grid, block, 0, st, p);     \
+        else if (Cout <= 16)                                                                         \
+            hipLaunchKernelGGL((conv3d_small_bwd_kernel<CIN_, 1>), grid, block, 0, st, p);           \
+        else                                                                                         \
+            hipLaunchKernelGGL((conv3d_small_bwd_kernel<CIN_, 2>), grid, block, 0, st, p);           \
     } while (0)
     if (Cin == 1)
         U3D_SMALL_BWD(1);

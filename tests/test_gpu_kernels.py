@@ -858,7 +858,8 @@ def test_error_convention():
         nat.call("u3d_gn_finalize", 0, _stream(U.DEV), _p(x), 5, 1.0, None, 0, 0.0, 1, 2, 8.0, _p(x), _p(x), 1e-5, _p(x), _p(x))
 
 
-@pytest.mark.parametrize("N,Cin,Cout,D,H,W", [(2, 1, 16, 8, 16, 16), (1, 3, 8, 5, 9, 7), (1, 2, 32, 9, 13, 11), (1, 4, 12, 4, 8, 8), (1, 1, 6, 6, 7, 5)])
+@pytest.mark.parametrize("N,Cin,Cout,D,H,W", [(2, 1, 16, 8, 16, 16), (1, 3, 8, 5, 9, 7), (1, 2, 32, 9, 13, 11), (1, 4, 12, 4, 8, 8), (1, 1, 6, 6, 7, 5),
+                                              (1, 3, 16, 8, 8, 24)])
 def test_small_cin_first_layer_kernels(N, Cin, Cout, D, H, W):
     """dedicated first-layer kernels: forward == conv3d(GN-affine(x)); backward yields dw and the GroupNorm
     reductions (sum dg, sum dg*x) WITHOUT computing dg — compare with autograd of the conv"""
@@ -903,6 +904,16 @@ def test_small_cin_first_layer_kernels(N, Cin, Cout, D, H, W):
     dg = g.grad.double()
     s_ref = torch.stack([dg.sum(dim=(2, 3, 4)), (dg * x.double()).sum(dim=(2, 3, 4))], dim=-1)
     assert U.relerr(gst.cpu(), s_ref) < 1e-4
+    # round 6: 16 output channels on whole tiles stage the dz tile through LDS (16-byte loads at constant offsets); the first form
+    # (u3d_set_tuning key 20 = -1: 4-byte operand loads) runs the same MFMA sequence — bit-identical dw
+    dw2, gst2 = torch.empty_like(dw), torch.zeros_like(gst)
+    nat.call("u3d_set_tuning", 20, -1)
+    try:
+        nat.call("u3d_conv3d_small_cin_bwd", 0, _stream(U.DEV), _p(xd), _p(abd), _p(dzd), _p(wd), _p(dw2), _p(gst2), N, D, H, W, Cin,
+                 Cout, _p(ws), n)
+    finally:
+        nat.call("u3d_set_tuning", 20, 0)
+    assert torch.equal(dw2, dw)
 
 
 @pytest.mark.parametrize("Cout,Cin,C0", [(32, 16, 0), (16, 32, 0), (32, 96, 32), (36, 20, 8), (256, 128, 0), (64, 192, 64), (8, 12, 4)])
