@@ -48,7 +48,7 @@
 //        (default: read-once from 256 blocks on, csrc/u3d_subpix.hip)
 //   [23] 1 = the weight-gradient reduction always with four split groups per output (A/B of the one-thread-per-output form for <= 16 splits)
 //   [19] / [20] total block count of the first-layer forward / backward kernels (csrc/u3d_smallc.hip; 0 = default 512 / 1024); [20] = -1: the
-//        backward kernel's first form (4-byte operand loads from global memory) at the default block count (A/B; bit-identical)
+//        backward kernel's first form (4-byte operand loads from global memory) at its default block count (A/B)
 int g_u3d_tune[24] = {0};
 
 namespace cv {

@@ -650,9 +650,12 @@ __global__ __launch_bounds__(64 * FIN_GROUPS) void conv3d_small_bwd_finalize_ker
         for (int c = 0; c < Cin; ++c) dw[((size_t)k * Cin + c) * 27 + tap] = (float)dwacc[c];
 }
 
-static int small_bwd_blocks(int N, int D, int H, int W) {
+static int small_bwd_blocks(int N, int D, int H, int W, bool va = false) {
     const long long ntiles = (long long)((D + 3) / 4) * ((H + 7) / 8) * ((W + 7) / 8);
-    long long B = (g_u3d_tune[20] > 0 ? g_u3d_tune[20] : 1024) / (N > 0 ? N : 1);  // ~4 blocks per CU in total (latency hiding); each walks its share of tiles (key 20: A/B)
+    // ~4 blocks per CU in total (latency hiding), each walks its share of tiles (key 20: A/B).  The LDS-staged form (va; 46 KB per block:
+    // three per CU) with 2 per CU: 48 + 14 us (kernel + finalize, whose work is proportional to the block count) against 45 + 18 at 3 per
+    // CU and 56 + 22 at 4
+    long long B = (g_u3d_tune[20] > 0 ? g_u3d_tune[20] : (va ? 512 : 1024)) / (N > 0 ? N : 1);
     if (B < 1) B = 1;
     if (B > ntiles) B = ntiles;
     return (int)B;
@@ -673,15 +676,15 @@ extern "C" int u3d_conv3d_small_cin_bwd(int device, u3d_stream_t stream, const f
     p.x = x, p.dz = dz, p.partial = workspace;
     p.N = N, p.D = D, p.H = H, p.W = W, p.Cin = Cin, p.Cout = Cout;
     p.tz = (D + sc::TZ - 1) / sc::TZ, p.ty = (H + sc::TY - 1) / sc::TY, p.tx = (W + sc::TX - 1) / sc::TX;
-    p.B = small_bwd_blocks(N, D, H, W);
+    // whole tiles, whole row tiles of 16 channels, aligned dz: the dz tile through LDS (VA); key 20 = -1: the first form (A/B)
+    const bool va = Cout == 16 && D % sc::TZ == 0 && H % sc::TY == 0 && W % sc::TX == 0 && ((uintptr_t)dz & 15) == 0 &&
+                    g_u3d_tune[20] != -1;
+    p.B = small_bwd_blocks(N, D, H, W, va);  // (<= the count u3d_small_cin_bwd_workspace_floats sizes for)
     const size_t need = (size_t)N * p.B * Cout * 27 * (Cin + 1);
     if (workspace_floats < need)
         return u3d_set_err(U3D_EWORKSPACE, "u3d_conv3d_small_cin_bwd: workspace %zu < %zu floats", workspace_floats, need);
     const dim3 grid((unsigned)p.B, (unsigned)N), block(256);
     hipStream_t st = (hipStream_t)stream;
-    // whole tiles, whole row tiles of 16 channels, aligned dz: the dz tile through LDS (VA); key 20 = -1: the first form (A/B; bit-identical)
-    const bool va = Cout == 16 && D % sc::TZ == 0 && H % sc::TY == 0 && W % sc::TX == 0 && ((uintptr_t)dz & 15) == 0 &&
-                    g_u3d_tune[20] != -1;
 #define U3D_SMALL_BWD(CIN_)                                                                          \
     do {                                                                                             \
         if (Cout <= 16 && va)                                                                        \

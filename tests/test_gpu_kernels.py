@@ -905,7 +905,8 @@ def test_small_cin_first_layer_kernels(N, Cin, Cout, D, H, W):
     s_ref = torch.stack([dg.sum(dim=(2, 3, 4)), (dg * x.double()).sum(dim=(2, 3, 4))], dim=-1)
     assert U.relerr(gst.cpu(), s_ref) < 1e-4
     # round 6: 16 output channels on whole tiles stage the dz tile through LDS (16-byte loads at constant offsets); the first form
-    # (u3d_set_tuning key 20 = -1: 4-byte operand loads) runs the same MFMA sequence — bit-identical dw
+    # (u3d_set_tuning key 20 = -1: 4-byte operand loads) runs the same MFMA sequence per tile over another block count: dw agrees like two
+    # orders of summing the per-block partials
     dw2, gst2 = torch.empty_like(dw), torch.zeros_like(gst)
     nat.call("u3d_set_tuning", 20, -1)
     try:
@@ -913,7 +914,7 @@ def test_small_cin_first_layer_kernels(N, Cin, Cout, D, H, W):
                  Cout, _p(ws), n)
     finally:
         nat.call("u3d_set_tuning", 20, 0)
-    assert torch.equal(dw2, dw)
+    assert U.relerr(dw2, dw) < 2e-6 and U.relerr(gst2, gst) < 1e-9
 
 
 @pytest.mark.parametrize("Cout,Cin,C0", [(32, 16, 0), (16, 32, 0), (32, 96, 32), (36, 20, 8), (256, 128, 0), (64, 192, 64), (8, 12, 4)])
