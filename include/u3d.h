@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define U3D_VERSION 127 /* 127: u3d_subpixel_conv_dgrad_reps, u3d_gn_bwd_job_t::reps_hi; 126: replica rows also from u3d_chan_stats_reps, u3d_conv3d_small_cin_fwd_reps, u3d_conv1x1_head_bwd_reps + u3d_cvt_f64_f32_sum; 125: replica rows of the statistics tables (u3d_conv3d_ex_reps, u3d_gn_finalize_reps, u3d_gn_bwd_job_t::reps_lo); 124: u3d_bce_dice_scratch_doubles (per-block partials instead of atomics); 123: u3d_conv3d_wgrad_job (the GroupNorm-backward reduction rides in the weight-gradient reduce launch); 122: round 6 — u3d_gn_finalize_split / u3d_gn_bwd_finalize_split (compact half tables of a virtual-concat layer), u3d_adam_step, u3d_chan_stats_children, u3d_pack_weights_batch_cells, tuning key 18; 121: u3d_convtr3d_fwd_t8_b16_ex; 120: flat 5 x 10 x 10 tile of the bf16-storage convolutions (u3d_conv3d_bf16_tile_variant planes = 5), 24 tuning keys; 119: round 5 — ragged volumes on the persistent kernels, u3d_conv3d_variant / u3d_conv3d_wgrad_variant; 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K); 118: u3d_se_*_b16 */
+#define U3D_VERSION 128 /* 128: u3d_conv3d_wgrad_bf16_job / _b16_job (the GroupNorm-backward reduction rides in the bf16 weight gradient's reduce launch too); 127: u3d_subpixel_conv_dgrad_reps, u3d_gn_bwd_job_t::reps_hi; 126: replica rows also from u3d_chan_stats_reps, u3d_conv3d_small_cin_fwd_reps, u3d_conv1x1_head_bwd_reps + u3d_cvt_f64_f32_sum; 125: replica rows of the statistics tables (u3d_conv3d_ex_reps, u3d_gn_finalize_reps, u3d_gn_bwd_job_t::reps_lo); 124: u3d_bce_dice_scratch_doubles (per-block partials instead of atomics); 123: u3d_conv3d_wgrad_job (the GroupNorm-backward reduction rides in the weight-gradient reduce launch); 122: round 6 — u3d_gn_finalize_split / u3d_gn_bwd_finalize_split (compact half tables of a virtual-concat layer), u3d_adam_step, u3d_chan_stats_children, u3d_pack_weights_batch_cells, tuning key 18; 121: u3d_convtr3d_fwd_t8_b16_ex; 120: flat 5 x 10 x 10 tile of the bf16-storage convolutions (u3d_conv3d_bf16_tile_variant planes = 5), 24 tuning keys; 119: round 5 — ragged volumes on the persistent kernels, u3d_conv3d_variant / u3d_conv3d_wgrad_variant; 112: BatchNorm / conv-bias / dropout entry points (u3d_norm.hip); 113: one-launch bf16 weight packing (u3d_pack_weights_bf16_batch), 16 tuning keys, bf16 activation storage (*_b16); 114: 1x1x1 convolution on the bf16 matrix pipe (u3d_conv1x1_*_mfma_b16); 115: round 4 — u3d_conv3d_bf16_tile_variant, tuning key 12 (free slots in the persistent grids); 116: u3d_conv3d_wgrad_bf16_b16_variant; 117: u3d_convtr3d_dgrad_t8*_ex (split-K); 118: u3d_se_*_b16 */
 
 #define U3D_OK 0
 #define U3D_EINVAL (-1)  /* bad shape / argument */
@@ -687,6 +687,19 @@ int u3d_conv3d_wgrad_bf16_b16(int device, u3d_stream_t stream, const void* x, co
  * that are not multiples of 16; another summation order over the voxels), 0: the round-3 kernel (tensors beyond 2 GiB), -1:
  * unsupported channel counts.  No reference counterpart (ATen picks its algorithm behind buildingblocks.py:56). */
 int u3d_conv3d_wgrad_bf16_b16_variant(int N, int D, int H, int W, int C, int K);
+/* u3d_conv3d_wgrad_bf16 / _b16 with the GroupNorm-backward reduction of the layer's INPUT (u3d_gn_bwd_job_t, see u3d_conv3d_wgrad_job:
+ * what u3d_gn_bwd_finalize / _split would do in a launch of their own) as one extra block of the launch that adds the weight gradient's
+ * splits — config 4 ran 18 single-block finalize launches of ~7 us per step behind its weight gradients (buildingblocks.py:75 under
+ * autograd).  Same bits as the separate launch.  Only a shape whose weight gradient HAS a reduce launch can carry the job (with one split
+ * — config 4's 1024-channel level — the main kernel writes dw itself): u3d_conv3d_wgrad_bf16_job_supported(shape, b16 = 0 / 1 for the
+ * fp32- / bf16-storage entry point, the dw pointer, the job's N, C0 + C1, G) says so (host-only); job = NULL is the plain entry point. */
+int u3d_conv3d_wgrad_bf16_job_supported(int N, int D, int H, int W, int C, int K, int b16, const float* dw, int jobN, int jobC, int jobG);
+int u3d_conv3d_wgrad_bf16_job(int device, u3d_stream_t stream, const float* x, const float* affine, const float* dz, float* dw, int N,
+                              int D, int H, int W, int Cin, int Cout, float* workspace, long long workspace_floats,
+                              const u3d_gn_bwd_job_t* job);
+int u3d_conv3d_wgrad_bf16_b16_job(int device, u3d_stream_t stream, const void* x, const float* affine, const void* dz, float* dw, int N,
+                                  int D, int H, int W, int C, int K, float* workspace, long long workspace_floats,
+                                  const u3d_gn_bwd_job_t* job);
 int u3d_convtr3d_fwd_t8_b16(int device, u3d_stream_t stream, const void* x, const void* packed, void* t8, int N, int D1, int H1,
                             int W1, int Cl, int Cs);
 int u3d_convtr3d_dgrad_t8_b16(int device, u3d_stream_t stream, const void* dt8, const void* packed, const void* x_mask, void* dx,

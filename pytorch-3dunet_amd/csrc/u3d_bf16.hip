@@ -16,6 +16,7 @@
 // three batches under the three z-tap groups of chunk c and written to the other buffer after each group; one barrier
 // per chunk.
 #include "u3d_common.h"
+#include "u3d_gn.h"
 #include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -1983,10 +1984,20 @@ __device__ __forceinline__ double u3d_sum_splits(const float* __restrict__ p, si
 // read coalesced over the output channel (256-byte runs), transposed through LDS, and written as 64 runs of 27 consecutive
 // floats (the reference layout has the tap innermost) — a thread-per-element version writes 4 bytes every 27*Cin floats and
 // costs more than the GEMM at 1024 channels.
-__global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __restrict__ ws, int S, int C, int K, float* __restrict__ dw) {
+// (has_job, round 6: the grid carries ONE extra block — block 0 — that runs the GroupNorm-backward reduction of the layer's input, as in
+// wgrad_reduce_kernel of csrc/u3d_conv.hip: u3d_conv3d_wgrad_bf16_job)
+__global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __restrict__ ws, int S, int C, int K, float* __restrict__ dw,
+                                                                int has_job, u3d_gn_bwd_job_t job) {
     __shared__ float tile[64][28];
+    if (has_job && blockIdx.x == 0) {
+        extern __shared__ double shb[];
+        u3d_gn_bwd_finalize_body(job.gstats_lo, job.mean_rstd, job.gamma, job.N, job.C0 + job.C1, job.G, job.count, 1, 1, job.dgamma,
+                                 job.dbeta, job.coef, job.gstats_hi, job.C0, job.hi_scale, job.coef_hi, shb, job.reps_lo, job.reps_hi);
+        return;
+    }
+    const int bx = (int)blockIdx.x - (has_job ? 1 : 0);
     const int pco = (K + 63) >> 6, P = (C >> 5) * pco;  // (K % 64 == 32: the last block's upper 32 columns are zeros, not written)
-    const int pair = blockIdx.x >> 5, cil = blockIdx.x & 31;
+    const int pair = bx >> 5, cil = bx & 31;
     const int cib = pair / pco, cob = pair - cib * pco;
     const int t = threadIdx.x;
     const size_t split_stride = (size_t)P * 27 * 2048;
@@ -2007,10 +2018,18 @@ __global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __r
 
 // few (pair, channel) rows but many splits (64-channel layers at full resolution): one thread per output element instead, so
 // that the sum over hundreds of splits is spread over the whole chip (the scattered 4-byte writes are few there)
-__global__ void wgrad_bf16_reduce_flat_kernel(const float* __restrict__ ws, int S, int C, int K, float* __restrict__ dw) {
+__global__ __launch_bounds__(256) void wgrad_bf16_reduce_flat_kernel(const float* __restrict__ ws, int S, int C, int K, float* __restrict__ dw,
+                                                                     int has_job, u3d_gn_bwd_job_t job) {
+    if (has_job && blockIdx.x == 0) {
+        extern __shared__ double shb[];
+        u3d_gn_bwd_finalize_body(job.gstats_lo, job.mean_rstd, job.gamma, job.N, job.C0 + job.C1, job.G, job.count, 1, 1, job.dgamma,
+                                 job.dbeta, job.coef, job.gstats_hi, job.C0, job.hi_scale, job.coef_hi, shb, job.reps_lo, job.reps_hi);
+        return;
+    }
+    const long long bx = (long long)blockIdx.x - (has_job ? 1 : 0), nb = (long long)gridDim.x - (has_job ? 1 : 0);
     const int pco = (K + 63) >> 6, P = (C >> 5) * pco;
     const long long total = (long long)C * K * 27;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = bx * blockDim.x + threadIdx.x; i < total; i += nb * blockDim.x) {
         const int co = (int)(i % K);  // read-coalesced order: co fastest, then ci, then tap
         long long r = i / K;
         const int ci = (int)(r % C);
@@ -2073,7 +2092,39 @@ extern "C" int u3d_conv3d_wgrad_bf16_b16_variant(int N, int D, int H, int W, int
 }
 
 static int conv3d_wgrad_bf16_impl(int device, u3d_stream_t stream, const float* x, const float* affine, const float* dz, float* dw,
-                                  int N, int D, int H, int W, int C, int K, float* workspace, long long workspace_floats, int b16);
+                                  int N, int D, int H, int W, int C, int K, float* workspace, long long workspace_floats, int b16,
+                                  const u3d_gn_bwd_job_t* job = nullptr);
+// does the launch that writes dw for this shape have a reduce pass (one split: the round-4 kernels write dw themselves)?
+static bool wgrad_bf16_has_reduce(int N, int D, int H, int W, int C, int K, int b16, const float* dw) {
+    const int variant = b16 ? wgrad_b16_variant(N, D, H, W, C, K) : 0;
+    const wgrad_plan q = plan_wgrad(N, D, H, W, C, K, variant == 8);
+    return !((variant == 8 || variant == 16) && q.S == 1 && g_u3d_tune[17] != 1 && ((uintptr_t)dw & 15) == 0);
+}
+static size_t wgrad_bf16_job_lds_bytes(int N, int C, int G) { return sizeof(double) * (4 * (size_t)N * C + 2 * (size_t)N * G); }
+
+// The GroupNorm-backward reduction of the layer's INPUT (u3d_gn_bwd_job_t, see u3d_conv3d_wgrad_job) as one extra block of the launch that
+// reduces the weight gradient's splits: config 4 ran 18 single-block finalize launches of ~7 us per step behind these.  Only shapes whose
+// weight gradient HAS a reduce launch can carry it (one split — the 1024-channel level — writes dw from the main kernel): ask first.
+extern "C" int u3d_conv3d_wgrad_bf16_job_supported(int N, int D, int H, int W, int C, int K, int b16, const float* dw, int jobN, int jobC,
+                                                   int jobG) {
+    if (!u3d_conv3d_wgrad_bf16_supported(C, K) || N <= 0 || D <= 0 || H <= 0 || W <= 0 || jobN <= 0 || jobC <= 0 || jobG <= 0 ||
+        jobC % jobG != 0)
+        return 0;
+    // (the reduce kernel's own 7 KB of static LDS sits beside the job's tables)
+    if (wgrad_bf16_job_lds_bytes(jobN, jobC, jobG) + 8 * 1024 > 64 * 1024) return 0;
+    return wgrad_bf16_has_reduce(N, D, H, W, C, K, b16, dw) ? 1 : 0;
+}
+extern "C" int u3d_conv3d_wgrad_bf16_job(int device, u3d_stream_t stream, const float* x, const float* affine, const float* dz, float* dw,
+                                         int N, int D, int H, int W, int C, int K, float* workspace, long long workspace_floats,
+                                         const u3d_gn_bwd_job_t* job) {
+    return conv3d_wgrad_bf16_impl(device, stream, x, affine, dz, dw, N, D, H, W, C, K, workspace, workspace_floats, 0, job);
+}
+extern "C" int u3d_conv3d_wgrad_bf16_b16_job(int device, u3d_stream_t stream, const void* x, const float* affine, const void* dz, float* dw,
+                                             int N, int D, int H, int W, int C, int K, float* workspace, long long workspace_floats,
+                                             const u3d_gn_bwd_job_t* job) {
+    return conv3d_wgrad_bf16_impl(device, stream, (const float*)x, affine, (const float*)dz, dw, N, D, H, W, C, K, workspace,
+                                  workspace_floats, 1, job);
+}
 
 extern "C" int u3d_conv3d_wgrad_bf16(int device, u3d_stream_t stream, const float* x, const float* affine, const float* dz,
                                      float* dw, int N, int D, int H, int W, int C, int K, float* workspace,
@@ -2089,8 +2140,19 @@ extern "C" int u3d_conv3d_wgrad_bf16_b16(int device, u3d_stream_t stream, const 
 }
 
 static int conv3d_wgrad_bf16_impl(int device, u3d_stream_t stream, const float* x, const float* affine, const float* dz, float* dw,
-                                  int N, int D, int H, int W, int C, int K, float* workspace, long long workspace_floats, int b16) {
+                                  int N, int D, int H, int W, int C, int K, float* workspace, long long workspace_floats, int b16,
+                                  const u3d_gn_bwd_job_t* job) {
     U3D_ENTER(device);
+    if (job) {
+        U3D_REQUIRE(job->gstats_lo && job->mean_rstd && job->gamma && job->dgamma && job->dbeta && job->coef && job->C0 > 0 &&
+                        job->C1 >= 0 && (job->C1 == 0) == (job->gstats_hi == nullptr) && (job->coef_hi == nullptr || job->C1 > 0) &&
+                        job->reps_lo >= 0 && job->reps_lo <= 64 && job->reps_hi >= 0 && job->reps_hi <= 64,
+                    "u3d_conv3d_wgrad_bf16_job: bad job");
+        U3D_REQUIRE(u3d_conv3d_wgrad_bf16_job_supported(N, D, H, W, C, K, b16, dw, job->N, job->C0 + job->C1, job->G) == 1,
+                    "u3d_conv3d_wgrad_bf16_job: this shape's weight gradient has no reduce launch to carry the job (or %d x %d channels in "
+                    "%d groups do not fit one block's LDS): ask u3d_conv3d_wgrad_bf16_job_supported",
+                    job->N, job->C0 + job->C1, job->G);
+    }
     U3D_REQUIRE(x && dz && dw && N > 0 && D > 0 && H > 0 && W > 0, "u3d_conv3d_wgrad_bf16: bad argument");
     U3D_REQUIRE(u3d_conv3d_wgrad_bf16_supported(C, K), "u3d_conv3d_wgrad_bf16: needs Cin %% 32 == 0 and Cout %% 32 == 0 (got %d, %d)", C, K);
     U3D_REQUIRE((((uintptr_t)x | (uintptr_t)dz | (uintptr_t)affine) & 15) == 0, "u3d_conv3d_wgrad_bf16: 16-byte alignment");
@@ -2130,12 +2192,23 @@ static int conv3d_wgrad_bf16_impl(int device, u3d_stream_t stream, const float* 
     }
     U3D_LAUNCH_CHECK();
     if (direct) return 0;
+    u3d_gn_bwd_job_t jb = {};
+    size_t job_lds = 0;
+    if (job) {
+        jb = *job;
+        if (jb.reps_lo < 1) jb.reps_lo = 1;
+        if (jb.reps_hi < 1) jb.reps_hi = 1;
+        job_lds = wgrad_bf16_job_lds_bytes(jb.N, jb.C0 + jb.C1, jb.G);
+    }
+    const unsigned jx = job ? 1u : 0u;
     if (q.P * 32 >= 1024) {
-        hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)(q.P * 32)), dim3(256), 0, (hipStream_t)stream, workspace, q.S, C, K, dw);
+        hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)(q.P * 32) + jx), dim3(256), job_lds, (hipStream_t)stream, workspace, q.S, C,
+                           K, dw, (int)jx, jb);
     } else {
         long long rb = ((long long)C * K * 27 + 255) / 256;
         if (rb > 8192) rb = 8192;
-        hipLaunchKernelGGL(wgrad_bf16_reduce_flat_kernel, dim3((unsigned)rb), dim3(256), 0, (hipStream_t)stream, workspace, q.S, C, K, dw);
+        hipLaunchKernelGGL(wgrad_bf16_reduce_flat_kernel, dim3((unsigned)rb + jx), dim3(256), job_lds, (hipStream_t)stream, workspace, q.S, C, K,
+                           dw, (int)jx, jb);
     }
     U3D_LAUNCH_CHECK();
     return 0;

@@ -508,8 +508,17 @@ class ConvLayers:
         cx, dev, src, rec = c.cx, c.cx.dev, c.src, c.rec
         need = nat.get_lib().u3d_wgrad_bf16_workspace_floats(c.N, c.D, c.H, c.W, src.C, c.Cout)
         ws = cx.ensure_ws(need)
-        nat.call("u3d_conv3d_wgrad_bf16" + ("_b16" if c.b16 else ""), dev.index, _stream(dev), _p(src.t0), _p(rec.affine), _p(c.dz),
-                 _p(cx.gview(rec.idx_w)), c.N, c.D, c.H, c.W, src.C, c.Cout, _p(ws), ws.numel(), flops=c.flops)
+        dw = cx.gview(rec.idx_w)
+        job = c.job
+        # the GroupNorm-backward reduction of the layer's input rides in the launch that adds the splits — where there is one
+        if job is not None and nat.get_lib().u3d_conv3d_wgrad_bf16_job_supported(c.N, c.D, c.H, c.W, src.C, c.Cout, 1 if c.b16 else 0, _p(dw),
+                                                                                  job.N, job.C0 + job.C1, job.G) != 1:
+            job = None
+        nat.call("u3d_conv3d_wgrad_bf16" + ("_b16" if c.b16 else "") + "_job", dev.index, _stream(dev), _p(src.t0), _p(rec.affine), _p(c.dz),
+                 _p(dw), c.N, c.D, c.H, c.W, src.C, c.Cout, _p(ws), ws.numel(), ctypes.byref(job) if job is not None else None,
+                 flops=c.flops)
+        if job is not None:
+            c.job = None
 
     def _wgrad_subpixel(self, c: "_BwdCall"):
         # weight gradient in two channel slices of the same (Cout, Ctot, 27) buffer: upsampled channels from the 64

@@ -346,6 +346,11 @@ _PROTOS = {
     "u3d_conv3d_bf16_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "u3d_conv3d_bf16_tile_variant": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "u3d_conv3d_wgrad_bf16_b16_variant": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "u3d_conv3d_wgrad_bf16_job_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int]),
+    "u3d_conv3d_wgrad_bf16_job": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                          c_int, c_void_p, c_int64, POINTER(U3DGnBwdJob)]),
+    "u3d_conv3d_wgrad_bf16_b16_job": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                              c_int, c_void_p, c_int64, POINTER(U3DGnBwdJob)]),
     "u3d_conv3d_bf16_ex": (
         c_int,
         [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
@@ -443,7 +448,7 @@ def get_lib():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.u3d_version() < 127:
+        if lib.u3d_version() < 128:
             raise U3DError("libu3d_hip.so is older than the Python host code")
         for kv in os.environ.get("U3D_TUNE", "").split(","):  # A/B knobs of u3d_set_tuning, e.g. U3D_TUNE=8:256,9:1 (results never change)
             if ":" in kv:

@@ -36,7 +36,7 @@ def test_header_symbols_exported():
     lib = ctypes.CDLL(nat.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert nat.get_lib().u3d_version() == 127
+    assert nat.get_lib().u3d_version() == 128
 
 
 def test_host_only_entry_points():

@@ -546,15 +546,15 @@ def test_model_with_bf16_activation_storage_against_the_storage_emulation(net):
     finally:
         orc.BF16_OPERANDS = orc.BF16_STORAGE = False
     logits, loss, grads, names = _step(model, x, t)
-    b16 = {n for n in names if n.endswith("_b16") or n.endswith("_b16_ex")}
-    assert {"u3d_conv3d_bf16_ex_b16", "u3d_conv3d_wgrad_bf16_b16", "u3d_convtr3d_fwd_t8_b16", "u3d_convtr3d_dgrad_t8_b16_ex",
+    b16 = {n for n in names if n.endswith("_b16") or n.endswith("_b16_ex") or n.endswith("_b16_job")}
+    assert {"u3d_conv3d_bf16_ex_b16", "u3d_conv3d_wgrad_bf16_b16_job", "u3d_convtr3d_fwd_t8_b16", "u3d_convtr3d_dgrad_t8_b16_ex",
             "u3d_convtr3d_wgrad_t8_b16", "u3d_conv1x1_fwd_b16", "u3d_conv1x1_bwd_b16", "u3d_maxpool2_fwd_b16", "u3d_maxpool2_bwd_merge_b16",
             "u3d_nearest_add_fwd_t8_b16", "u3d_nearest_sum_bwd_t8_b16", "u3d_gn_bwd_apply_b16", "u3d_conv1x1_head_fwd_b16",
             "u3d_conv1x1_head_bwd_b16"} <= b16, names
     if net == "ResidualUNetSE3D":
         assert {"u3d_se_apply_fwd_b16", "u3d_se_bwd_reduce_b16", "u3d_se_bwd_apply_b16"} <= b16 and not ({"u3d_se_apply_fwd", "u3d_se_bwd_apply"} & names), names
     # nothing of the fp32-storage family may have run beside them
-    assert not ({"u3d_conv3d_bf16_ex", "u3d_conv3d_wgrad_bf16", "u3d_gn_bwd_apply", "u3d_gn_bwd_apply_add", "u3d_maxpool2_fwd",
+    assert not ({"u3d_conv3d_bf16_ex", "u3d_conv3d_wgrad_bf16", "u3d_conv3d_wgrad_bf16_job", "u3d_gn_bwd_apply", "u3d_gn_bwd_apply_add", "u3d_maxpool2_fwd",
                  "u3d_conv1x1_fwd", "u3d_conv3d", "u3d_conv3d_ex", "u3d_conv3d_wgrad"} & names), names
     keys = list(g32)
     cat = lambda d: torch.cat([d[k].flatten().double() for k in keys])  # noqa: E731

@@ -322,7 +322,7 @@ def test_model_bf16_against_bf16_operand_oracle_and_fp32_oracle(cfg, shape):
     finally:
         orc.BF16_OPERANDS = False
     logits, loss, grads, names = _step(model, x, target, loss_name)
-    assert "u3d_conv3d_bf16_ex" in names and "u3d_conv3d_wgrad_bf16" in names, names
+    assert "u3d_conv3d_bf16_ex" in names and "u3d_conv3d_wgrad_bf16_job" in names, names
     if cfg["name"] == "UNet3D":  # the decoders' concat was written out and no sub-pixel (fp32) kernel ran on it
         assert "u3d_nearest_cat_fwd" in names and not any(n.startswith("u3d_subpixel") for n in names), names
     keys = list(g32)

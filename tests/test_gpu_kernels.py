@@ -661,6 +661,54 @@ def test_wgrad_job_equals_wgrad_then_groupnorm_backward_finalize_bit_for_bit(N, 
     assert lib.u3d_conv3d_wgrad_job_supported(4, 1024, 8) == 0
 
 
+@pytest.mark.parametrize("N,C,K,D,H,W,G,b16", [(1, 64, 64, 8, 16, 16, 8, 0), (1, 64, 64, 8, 16, 16, 8, 1), (2, 32, 96, 5, 9, 7, 4, 0),
+                                               (1, 128, 128, 4, 8, 8, 8, 1), (1, 1024, 1024, 4, 4, 4, 8, 1), (1, 64, 128, 16, 32, 32, 8, 1),
+                                               (1, 256, 256, 8, 8, 8, 8, 1), (1, 256, 256, 4, 8, 8, 8, 0)])
+def test_bf16_wgrad_job_equals_wgrad_then_groupnorm_backward_finalize_bit_for_bit(N, C, K, D, H, W, G, b16):
+    """u3d_conv3d_wgrad_bf16_job / _b16_job (round 6): dw and the GroupNorm-backward tables of the layer's input from the extra block of
+    the split reduction are those of the plain entry point + u3d_gn_bwd_finalize, bit for bit — for the block-per-row and the flat reduce
+    kernel; a shape with ONE split (the main kernel writes dw, no reduce launch) says so and refuses a job"""
+    U, nat, VSrc, _p, _stream = _mods()
+    torch.manual_seed(C + K + b16)
+    dev = U.DEV
+    V = float(D * H * W)
+    dt = torch.bfloat16 if b16 else torch.float32
+    x = U.ndhwc(torch.randn(N, C, D, H, W)).to(dt)
+    dz = U.ndhwc(torch.randn(N, K, D, H, W)).to(dt)
+    aff = torch.randn(N, C, 2, device=dev)
+    gamma = torch.randn(C, device=dev)
+    mr = torch.rand(N, G, 2, device=dev) + 0.5
+    g0 = torch.randn(N, C, 2, dtype=torch.float64, device=dev) * 100
+    lib = nat.get_lib()
+    n = lib.u3d_wgrad_bf16_workspace_floats(N, D, H, W, C, K)
+    ws = torch.empty(n, device=dev)
+    sfx = "_b16" if b16 else ""
+    dw_plain = torch.empty((K, C, 27), device=dev)
+    nat.call("u3d_conv3d_wgrad_bf16" + sfx, 0, _stream(dev), _p(x), _p(aff), _p(dz), _p(dw_plain), N, D, H, W, C, K, _p(ws), n)
+    dgam0, dbet0, coef0 = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty((N, 3, C), device=dev)
+    nat.call("u3d_gn_bwd_finalize", 0, _stream(dev), _p(g0), _p(mr), _p(gamma), N, C, G, V, _p(dgam0), _p(dbet0), _p(coef0))
+    dw = torch.full((K, C, 27), 7.0, device=dev)
+    dgam, dbet, coef = torch.full((C,), 7.0, device=dev), torch.full((C,), 7.0, device=dev), torch.full((N, 3, C), 7.0, device=dev)
+    job = nat.U3DGnBwdJob()
+    job.gstats_lo, job.gstats_hi, job.C0, job.C1, job.hi_scale, job.coef_hi = _p(g0), None, C, 0, 1.0, None
+    job.mean_rstd, job.gamma, job.dgamma, job.dbeta, job.coef = _p(mr), _p(gamma), _p(dgam), _p(dbet), _p(coef)
+    job.count, job.N, job.G = V, N, G
+    ok = lib.u3d_conv3d_wgrad_bf16_job_supported(N, D, H, W, C, K, b16, _p(dw), N, C, G)
+    one_split = b16 == 1 and (C, K, D) in ((1024, 1024, 4), (128, 128, 4))  # one tile per (32 x 64)-channel pair
+    if one_split:
+        assert ok == 0  # conv3d_wgrad_b16v2_kernel writes dw itself: no reduce launch
+        with pytest.raises(nat.U3DError):
+            nat.call("u3d_conv3d_wgrad_bf16" + sfx + "_job", 0, _stream(dev), _p(x), _p(aff), _p(dz), _p(dw), N, D, H, W, C, K, _p(ws), n,
+                     ctypes.byref(job))
+        nat.call("u3d_conv3d_wgrad_bf16" + sfx + "_job", 0, _stream(dev), _p(x), _p(aff), _p(dz), _p(dw), N, D, H, W, C, K, _p(ws), n, None)
+        assert torch.equal(dw, dw_plain)
+        return
+    assert ok == 1
+    nat.call("u3d_conv3d_wgrad_bf16" + sfx + "_job", 0, _stream(dev), _p(x), _p(aff), _p(dz), _p(dw), N, D, H, W, C, K, _p(ws), n,
+             ctypes.byref(job))
+    assert torch.equal(dw, dw_plain) and torch.equal(dgam, dgam0) and torch.equal(dbet, dbet0) and torch.equal(coef, coef0)
+
+
 @pytest.mark.parametrize("N,Cin,Cout,D,H,W,reps", [(2, 32, 32, 8, 16, 16, 8), (1, 16, 64, 8, 16, 32, 4), (2, 32, 64, 9, 13, 11, 8)])
 def test_statistics_replica_rows_sum_to_the_plain_tables(N, Cin, Cout, D, H, W, reps):
     """u3d_conv3d_ex_reps (round 6): the persistent kernels' blocks spread the per-sample flush of their f64 sums over `reps` rows of the

@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--no-stats", action="store_true", help="forward without the output statistics (what the f64 atomics of the epilogue cost)")
     args = ap.parse_args()
     only = args.only.split(",")
+    if os.environ.get("U3D_LAYERS"):  # custom shapes: name:C0:C1:Cout:level;...
+        LAYERS[:] = [(a, int(b), int(c), int(d), int(e)) for a, b, c, d, e in (x.split(":") for x in os.environ["U3D_LAYERS"].split(";"))]
     N = args.batch
     D0, H0, W0 = (int(v) for v in args.patch.split(","))
     tot = {k: [0.0, 0.0] for k in only}

@@ -93,7 +93,8 @@ def main():
     fams = {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] and v["ms"] > 0 else None}
             for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
-    PEAK = {"u3d_conv3d_bf16_ex": 2500.0, "u3d_conv3d_wgrad_bf16": 2500.0}
+    PEAK = {"u3d_conv3d_bf16_ex": 2500.0, "u3d_conv3d_wgrad_bf16": 2500.0, "u3d_conv3d_wgrad_bf16_job": 2500.0, "u3d_conv3d_bf16_ex_b16": 2500.0,
+            "u3d_conv3d_wgrad_bf16_b16_job": 2500.0}
     for k, v in summ.items():
         if k in PEAK and v["flops"] and v["ms"] > 0:
             tf = v["flops"] / (v["ms"] * 1e-3) / 1e12
