@@ -543,7 +543,10 @@ int u3d_pack_weights_bf16(int device, u3d_stream_t stream, const float* w, int C
  * (u3d_packed_weight_bf16_elems elements), mode 0 / 1, cin_stride unused; total_blocks = the sum over the descriptors.
  * Modes 4 / 5 (round 5): the forward / data-gradient space-to-depth images of a ConvTranspose3d weight (Cin, Cout, 3,3,3) —
  * desc.Cin = Cin, desc.Cout = Cout, `packed` = u3d_convtr3d_t8_packed_elems(Cin, Cout, mode - 4) elements, bit for bit what
- * u3d_pack_convtr3d_t8 writes; needs Cin % 32 == 0 and Cout % 32 == 0 (u3d_pack_weights_bf16_blocks returns 0 otherwise). */
+ * u3d_pack_convtr3d_t8 writes; needs Cin % 32 == 0 and Cout % 32 == 0 (u3d_pack_weights_bf16_blocks returns 0 otherwise).
+ * Mode 6 (round 6): BOTH 3x3x3 images of one weight from ONE read of it (modes 0 and 1 each read the whole weight: a third of the
+ * launch's bytes) — `packed` receives the mode-0 image and, u3d_packed_weight_bf16_elems(Cin, Cout, 0) elements behind it, the mode-1
+ * image, bit for bit what the two modes write; needs Cin % 32 == 0 and Cout % 32 == 0 (blocks: (Cin / 32) * (Cout / 32) + 2). */
 long long u3d_pack_weights_bf16_blocks(int Cin, int Cout, int mode);
 int u3d_pack_weights_bf16_batch(int device, u3d_stream_t stream, const u3d_pack_desc_t* descs_device, int n, long long total_blocks);
 int u3d_conv3d_bf16(int device, u3d_stream_t stream, const float* x, const float* affine, const void* packed_w, float* out,

@@ -771,13 +771,89 @@ __device__ __forceinline__ int pk_t8_sidx(int tap, int pp, bool fwd) {  // 3x3x3
     }
     return sidx;
 }
+// Mode 6 (round 6): BOTH 3x3x3 images of a weight from ONE read of it.  Modes 0 and 1 each read the whole master weight (their cells are
+// different 16 x 32 cuts of it): 1.13 GB of reads + 0.57 GB of writes per config-4 step at 5.9 TB/s.  A block of mode 6 owns a (32 output
+// channels x 32 input channels) region — 32 contiguous runs of 864 floats — keeps it in LDS as bf16 (the same round-to-nearest-even
+// conversion the fragment writes of modes 0 / 1 apply, so the images are bit for bit theirs) and writes the 2 x 27 fragments of the forward
+// image (chunks 2*cib, 2*cib + 1 of n-tile cob) and the 2 x 27 of the data-gradient image (chunks 2*cob, 2*cob + 1 of n-tile cib, taps
+// flipped).  The data-gradient image starts u3d_packed_weight_bf16_elems(Cin, Cout, 0) elements behind desc.packed.
+constexpr int PK_RS6 = 868;  // bf16 elements per region row: 8-byte aligned rows, 434 words = 50 mod 64: 32 rows -> 32 distinct banks
+__device__ __forceinline__ void pack_weights_bf16_both(const u3d_pack_desc_t& ds, int b, float* tile_f) {
+    typedef __bf16 b16x4 __attribute__((ext_vector_type(4)));
+    __bf16* tile = reinterpret_cast<__bf16*>(tile_f);
+    const int t = threadIdx.x;
+    const int Cin = ds.Cin, Cout = ds.Cout;
+    const int nt0 = Cout >> 5, nt1 = Cin >> 5, nch0 = Cin >> 4, nch1 = Cout >> 4;
+    __bf16* out0 = reinterpret_cast<__bf16*>(ds.packed);
+    __bf16* out1 = out0 + ((size_t)nch0 * 27 + 6) * nt0 * 512;
+    const int regions = nt0 * nt1;
+    if (b >= regions) {  // two tail blocks: BDIST = 6 taps of zero fragments after the last chunk of each image
+        bf16x8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
+        const bool second = b > regions;
+        bf16x8* o8 = reinterpret_cast<bf16x8*>(second ? out1 + (size_t)nch1 * 27 * nt1 * 512 : out0 + (size_t)nch0 * 27 * nt0 * 512);
+        const int cnt = 6 * (second ? nt1 : nt0) * 64;
+        for (int i = t; i < cnt; i += 256) o8[i] = z;
+        return;
+    }
+    const int cob = b / nt1, cib = b - cob * nt1;
+    const float* base = ds.w + ((size_t)(cob * 32) * Cin + cib * 32) * 27;
+    const size_t run_stride = (size_t)Cin * 27;
+    // 6912 float4 of the region (32 runs of 216), 27 per thread, in two rounds of loads in flight
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        f32x4 v[14];
+#pragma unroll
+        for (int j = 0; j < 14; ++j) {
+            const int i = t + 256 * (14 * half + j);
+            v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < 6912) {
+                const int r = i / 216, o = i - r * 216;
+                v[j] = *reinterpret_cast<const f32x4*>(base + (size_t)r * run_stride + 4 * o);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 14; ++j) {
+            const int i = t + 256 * (14 * half + j);
+            if (i < 6912) {
+                const int r = i / 216, o = i - r * 216;
+                *reinterpret_cast<b16x4*>(tile + r * PK_RS6 + 4 * o) = b16x4{(__bf16)v[j][0], (__bf16)v[j][1], (__bf16)v[j][2], (__bf16)v[j][3]};
+            }
+        }
+    }
+    __syncthreads();
+    // forward image: lane l of fragment (chunk c2, tap) holds column co = l & 31 and k = input channels 16*c2 + 8*(l >> 5) + 0..7
+    for (int i = t; i < 2 * 27 * 64; i += 256) {
+        const int l = i & 63, tap = (i >> 6) % 27, c2 = i / (27 * 64);
+        const __bf16* src = tile + (l & 31) * PK_RS6 + (16 * c2 + 8 * (l >> 5)) * 27 + tap;
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = src[e * 27];
+        *reinterpret_cast<bf16x8*>(out0 + ((((size_t)(2 * cib + c2) * 27 + tap) * nt0 + cob) * 64 + l) * 8) = v;
+    }
+    // data-gradient image: column ci = l & 31, k = output channels 16*c2 + 8*(l >> 5) + 0..7, taps flipped
+    for (int i = t; i < 2 * 27 * 64; i += 256) {
+        const int l = i & 63, tap = (i >> 6) % 27, c2 = i / (27 * 64);
+        const __bf16* src = tile + (16 * c2 + 8 * (l >> 5)) * PK_RS6 + (l & 31) * 27 + (26 - tap);
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = src[e * PK_RS6];
+        *reinterpret_cast<bf16x8*>(out1 + ((((size_t)(2 * cob + c2) * 27 + tap) * nt1 + cib) * 64 + l) * 8) = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void pack_weights_bf16_batch_kernel(const u3d_pack_desc_t* __restrict__ descs, int n) {
-    __shared__ float tile[32 * PK_RS0];  // 13,856 floats (>= 16 * PK_RS1 = 13,840)
+    __shared__ __attribute__((aligned(16))) float tile[16 * PK_RS6];  // 13,888 floats (>= 32 * PK_RS0 = 13,856, 16 * PK_RS1 = 13,840; mode 6: 32 x 868 bf16)
     const int t = threadIdx.x;
     int d = 0;
     while (d + 1 < n && (long long)blockIdx.x >= descs[d + 1].first) ++d;
     const u3d_pack_desc_t ds = descs[d];
     const int Cin = ds.Cin, Cout = ds.Cout, mode = ds.mode;
+    if (mode == 6) {
+        pack_weights_bf16_both(ds, (int)((long long)blockIdx.x - ds.first), tile);
+        return;
+    }
     const bool t8 = mode >= 4;  // 4: T8 forward (Kc = Cl, Nc = 8 Cs), 5: T8 data gradient (Kc = 8 Cs, Nc = Cl)
     const int Kc = t8 ? (mode == 4 ? Cin : 8 * Cout) : (mode == 0 ? Cin : Cout), Nc = t8 ? (mode == 4 ? 8 * Cout : Cin) : (mode == 0 ? Cout : Cin);
     const int NTAPS = t8 ? 8 : 27;
@@ -875,6 +951,10 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_batch_kernel(const u3d_
 }  // namespace
 
 extern "C" long long u3d_pack_weights_bf16_blocks(int Cin, int Cout, int mode) {
+    if (mode == 6) {  // both 3x3x3 images from one read: (32 x 32)-channel regions + the two tails; 0 = not eligible
+        if (Cin <= 0 || Cout <= 0 || Cin % 32 != 0 || Cout % 32 != 0) return 0;
+        return (long long)(Cin / 32) * (Cout / 32) + 2;
+    }
     if (mode == 4 || mode == 5) {  // T8 images of a transposed-convolution weight (Cin = Cl, Cout = Cs); 0 = not batchable
         if (Cin <= 0 || Cout <= 0 || Cin % 32 != 0 || Cout % 32 != 0) return 0;
         return mode == 4 ? (long long)(Cin / 16) * (Cout / 32) + 1 : (long long)(Cout / 16) * (Cin / 32) + 1;  // source regions + tail

@@ -20,6 +20,7 @@ from ._native import U3DSrc
 from ._engine_base import *  # noqa: F401,F403  (explicit __all__: helpers, records, activation codes)
 
 
+_PACK_BOTH = os.environ.get("U3D_PACK_BOTH", "1") != "0"  # A/B: 0 = the forward and data-gradient bf16 images of a weight as two reads of it
 _PACK_ELEMENTWISE = os.environ.get("U3D_PACK_ELEMENTWISE", "0") == "1"  # A/B: every image through the thread-per-slot packer
 
 
@@ -183,6 +184,18 @@ class WeightImages:
                     stale.append((w, 4 + mode, 30 + mode))
         if not stale:
             return
+        # a 3x3x3 weight whose forward AND data-gradient image are stale (every training step) is read ONCE: mode 6 writes both images,
+        # the data-gradient one right behind the forward one in one buffer (round 6; the two modes read 1.13 GB per config-4 step)
+        if _PACK_BOTH:
+            both = {id(w) for w, mode, _ in stale if mode == 0} & {id(w) for w, mode, _ in stale if mode == 1}
+            merged = []
+            for w, mode, slot in stale:
+                if id(w) in both and mode in (0, 1) and lib.u3d_pack_weights_bf16_blocks(w.shape[1], w.shape[0], 6) > 0:
+                    if mode == 0:
+                        merged.append((w, 6, (20, 21)))
+                else:
+                    merged.append((w, mode, slot))
+            stale = merged
         key = tuple((id(w), mode, w.data_ptr()) for w, mode, _ in stale)
         tab = getattr(self, "_pack_tables_bf16", None)
         if tab is None:
@@ -192,9 +205,25 @@ class WeightImages:
             descs = (nat.U3DPackDesc * len(stale))()
             bufs, first = [], 0
             for i, (w, mode, slot) in enumerate(stale):
-                if mode >= 4:  # ConvTranspose3d weight (Cl, Cs, 3,3,3): desc.Cin = Cl, desc.Cout = Cs
+                if mode in (4, 5):  # ConvTranspose3d weight (Cl, Cs, 3,3,3): desc.Cin = Cl, desc.Cout = Cs
                     Cin, Cout = w.shape[0], w.shape[1]
                     n = lib.u3d_convtr3d_t8_packed_elems(Cin, Cout, mode - 4)
+                elif mode == 6:
+                    Cout, Cin = w.shape[0], w.shape[1]
+                    n0, n1 = lib.u3d_packed_weight_bf16_elems(Cin, Cout, 0), lib.u3d_packed_weight_bf16_elems(Cin, Cout, 1)
+                    h0, h1 = self._pack_cache.get((id(w), 20)), self._pack_cache.get((id(w), 21))
+                    if (h0 is not None and h1 is not None and h0[1].numel() == n0 and h1[1].numel() == n1 and h0[1].device == dev
+                            and h1[1].data_ptr() == h0[1].data_ptr() + 2 * n0
+                            and h0[1].untyped_storage().data_ptr() == h1[1].untyped_storage().data_ptr()):
+                        pair = (h0[1], h1[1])  # (the two views of last step's buffer)
+                    else:
+                        whole = _empty(n0 + n1, dtype=torch.bfloat16, device=dev)
+                        pair = (whole[:n0], whole[n0:])
+                    bufs.append(pair)
+                    descs[i].w, descs[i].packed, descs[i].first = w.data_ptr(), pair[0].data_ptr(), first
+                    descs[i].Cout, descs[i].Cin, descs[i].mode, descs[i].cin_stride = Cout, Cin, 6, 0
+                    first += lib.u3d_pack_weights_bf16_blocks(Cin, Cout, 6)
+                    continue
                 else:
                     Cout, Cin = w.shape[0], w.shape[1]
                     n = lib.u3d_packed_weight_bf16_elems(Cin, Cout, mode)
@@ -212,7 +241,11 @@ class WeightImages:
         table, bufs, total = ent
         nat.call("u3d_pack_weights_bf16_batch", dev.index, _stream(dev), _p(table), len(stale), total)
         for (w, mode, slot), buf in zip(stale, bufs):
-            self._pack_cache[(id(w), slot)] = (self._ver(w), buf)
+            if mode == 6:
+                self._pack_cache[(id(w), 20)] = (self._ver(w), buf[0])
+                self._pack_cache[(id(w), 21)] = (self._ver(w), buf[1])
+            else:
+                self._pack_cache[(id(w), slot)] = (self._ver(w), buf)
 
     def _repack_all(self, dev, modes, sub=()):
         """(Re)pack the images of ALL conv weights whose parameter changed since the last pack — one launch for the whole

@@ -215,6 +215,49 @@ def test_batched_bf16_weight_pack_equals_the_per_layer_pack():
         assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), (co, ci, mode)
 
 
+def test_both_images_from_one_read_equal_the_two_single_mode_packs():
+    """round 6: mode 6 of u3d_pack_weights_bf16_batch — the forward and the data-gradient image of a weight from ONE read of it — writes bit
+    for bit what modes 0 and 1 (u3d_pack_weights_bf16) write, the second image right behind the first, both prefetch tails zeroed; mixed in
+    one launch with single-mode descriptors; channel counts that are not multiples of 32 are not eligible"""
+    lib = nat.get_lib()
+    torch.manual_seed(13)
+    shapes = [(64, 32), (32, 64), (128, 128), (96, 160), (512, 256), (1024, 1024)]  # (Cout, Cin)
+    ws = [torch.randn(co, ci, 3, 3, 3, device=U.DEV) for co, ci in shapes]
+    extra = torch.randn(64, 64, 3, 3, 3, device=U.DEV)
+    descs = (nat.U3DPackDesc * (len(ws) + 1))()
+    outs, first = [], 0
+    for i, w in enumerate(ws):
+        co, ci = w.shape[:2]
+        n0, n1 = lib.u3d_packed_weight_bf16_elems(ci, co, 0), lib.u3d_packed_weight_bf16_elems(ci, co, 1)
+        buf = torch.full((n0 + n1 + 64,), float("nan"), dtype=torch.bfloat16, device=U.DEV)
+        outs.append((buf, n0, n1))
+        descs[i].w, descs[i].packed, descs[i].first = w.data_ptr(), buf.data_ptr(), first
+        descs[i].Cout, descs[i].Cin, descs[i].mode, descs[i].cin_stride = co, ci, 6, 0
+        assert lib.u3d_pack_weights_bf16_blocks(ci, co, 6) == (ci // 32) * (co // 32) + 2
+        first += lib.u3d_pack_weights_bf16_blocks(ci, co, 6)
+    nx = lib.u3d_packed_weight_bf16_elems(64, 64, 1)
+    bx = torch.full((nx,), float("nan"), dtype=torch.bfloat16, device=U.DEV)
+    i = len(ws)
+    descs[i].w, descs[i].packed, descs[i].first = extra.data_ptr(), bx.data_ptr(), first
+    descs[i].Cout, descs[i].Cin, descs[i].mode, descs[i].cin_stride = 64, 64, 1, 0
+    first += lib.u3d_pack_weights_bf16_blocks(64, 64, 1)
+    table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(U.DEV)
+    nat.call("u3d_pack_weights_bf16_batch", 0, _stream(U.DEV), _p(table), len(ws) + 1, first)
+    for w, (buf, n0, n1) in zip(ws, outs):
+        co, ci = w.shape[:2]
+        r0, r1 = torch.empty(n0, dtype=torch.bfloat16, device=U.DEV), torch.empty(n1, dtype=torch.bfloat16, device=U.DEV)
+        nat.call("u3d_pack_weights_bf16", 0, _stream(U.DEV), _p(w), co, ci, 0, _p(r0))
+        nat.call("u3d_pack_weights_bf16", 0, _stream(U.DEV), _p(w), co, ci, 1, _p(r1))
+        torch.cuda.synchronize()
+        assert torch.equal(buf[:n0].view(torch.int16), r0.view(torch.int16)), (co, ci, 0)
+        assert torch.equal(buf[n0:n0 + n1].view(torch.int16), r1.view(torch.int16)), (co, ci, 1)
+        assert bool(torch.isnan(buf[n0 + n1:].float()).all())  # nothing written past the second image
+    rx = torch.empty(nx, dtype=torch.bfloat16, device=U.DEV)
+    nat.call("u3d_pack_weights_bf16", 0, _stream(U.DEV), _p(extra), 64, 64, 1, _p(rx))
+    assert torch.equal(bx.view(torch.int16), rx.view(torch.int16))
+    assert lib.u3d_pack_weights_bf16_blocks(48, 64, 6) == 0 and lib.u3d_pack_weights_bf16_blocks(64, 16, 6) == 0
+
+
 def test_batched_pack_of_the_transposed_convolution_images_equals_the_per_weight_pack():
     """round 5: modes 4 / 5 of u3d_pack_weights_bf16_batch — the space-to-depth (T8) images of ConvTranspose3d weights (Cl, Cs, 3,3,3)
     ride in the model's one pack launch; bit for bit the images of u3d_pack_convtr3d_t8 (forward / data gradient), mixed with 3x3x3

@@ -1,2 +1,8 @@
-timeout 600 python -m pytest tests/test_gpu_kernels.py -x -q -k "bf16_wgrad_job or wgrad_job" 2>&1 | grep -E "passed|failed|Error|error" | tail -5
-timeout 1200 python -m pytest tests/test_gpu_configs.py tests/test_gpu_b16.py tests/test_gpu_res.py tests/test_gpu_bf16.py -q 2>&1 | grep -E "passed|failed|Error|error" | tail -8
+cd /tmp && export TMPDIR=/tmp; cd - >/dev/null
+for v in 0 1; do
+U3D_PACK_BOTH=$v timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/r06ab/pk$v -- python tools/model_bench.py --bf16 --act-bf16 --no-events --steps 5 --warmup 2 > /dev/null 2>&1
+db=$(find gpurun_out/r06ab/pk$v -name "*.db" | head -1)
+echo "== U3D_PACK_BOTH=$v"
+python tools/prof_summary.py stats "$db" 7 | grep -E "pack_weights|total kernel" | cut -c1-200
+rm -rf gpurun_out/r06ab/pk$v
+done
