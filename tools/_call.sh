@@ -1,16 +1,9 @@
-B="python bench.py --no-cpu-baseline --no-roofline --no-extras --steps 100 --warmup 10"
-L=pytorch-3dunet_amd/pytorch3dunet_amd/lib
-ms() { python -c "import sys,json; print('$1', json.loads([l for l in sys.stdin.read().strip().splitlines() if l.startswith('{')][-1])['ms_per_step'])"; }
-for i in 1 2 3 4; do
-$B 2>/dev/null | ms base
-U3D_LIB_PATH=$L/libu3d_hip_idx32.so $B 2>/dev/null | ms idx32
-done
-cd /tmp && export TMPDIR=/tmp; cd - >/dev/null
-for v in base idx32; do
-if [ $v = idx32 ]; then export U3D_LIB_PATH=$L/libu3d_hip_idx32.so; fi
-timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/r06ab/ix$v -- python bench.py --no-cpu-baseline --no-roofline --no-extras --steps 5 --warmup 3 > /dev/null 2>&1
-db=$(find gpurun_out/r06ab/ix$v -name "*.db" | head -1)
-echo "== $v"
-python tools/prof_summary.py stats "$db" 8 | grep -E "gn_bwd_apply|maxpool2_bwd_merge|total kernel" | cut -c1-160
-rm -rf gpurun_out/r06ab/ix$v
-done
+mkdir -p gpurun_out/r06e
+timeout 1200 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|rror" | tail -5 > gpurun_out/r06e/r06e_gputests.log
+cat gpurun_out/r06e/r06e_gputests.log
+U3D_PROFILES_CORE=1 bash tools/run_profiles.sh r06e
+bash tools/run_profiles_cfg4.sh r06e_cfg4 --act-bf16
+python tools/model_bench.py --bf16 --act-bf16 --no-events --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/r06e/cfg4_bare.jsonl
+python tools/model_bench.py --bf16 --act-bf16 --checkpoint --no-events --steps 20 --warmup 5 2>/dev/null | tail -1 >> gpurun_out/r06e/cfg4_bare.jsonl
+python tools/model_bench.py --bf16 --act-bf16 --checkpoint --checkpoint-levels 2 --no-events --steps 20 --warmup 5 2>/dev/null | tail -1 >> gpurun_out/r06e/cfg4_bare.jsonl
+cat gpurun_out/r06e/cfg4_bare.jsonl
