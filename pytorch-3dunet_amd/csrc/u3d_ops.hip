@@ -1700,7 +1700,9 @@ extern "C" int u3d_conv1x1_head_bwd_b16(int device, u3d_stream_t stream, const f
                 "u3d_conv1x1_head_bwd_b16: needs Cin %% 4 == 0, Cin <= 256, Cout <= %d (got %d, %d)", HEAD_VEC_MAXCO, Cin, Cout);
     const int rows = 256 / (Cin / 4);
     long long blocks = cdivll((long long)V, (long long)rows * 32);
-    if (blocks > 2048) blocks = 2048;
+    // (one accumulator row: every block ends with Cout * (Cin + 1) same-address f64 atomics of 19.5 ns — config 4's head by block count,
+    // rocprofv3: 2048: 119 us, 1024: 105, 768: 109, 512: 141; the fp32 entry point spreads them over replica rows instead)
+    if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(head_bwd_vec_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), (size_t)rows * (Cout + 1) * Cin * sizeof(float),
                        (hipStream_t)stream, dlogits, (const __bf16*)x, w, N, (long long)V, Cin, Cout, relu_mask, (__bf16*)dx, acc, 1);
