@@ -369,7 +369,8 @@ class ConvLayers:
         return ystats
 
     def _single_conv_fwd(self, sc, name, src: VSrc, st_in, pool: _StatPool, tape: Optional[Tape], want_stats=True,
-                         residual: Optional[torch.Tensor] = None, sub=(), y_out: Optional[torch.Tensor] = None, act=None):
+                         residual: Optional[torch.Tensor] = None, sub=(), y_out: Optional[torch.Tensor] = None, act=None,
+                         record_only: bool = False):
         """One SingleConv (buildingblocks.py:99-135) in any native order (parse_order): 'gcr' = GroupNorm -> Conv3d -> ReLU fully
         fused; other non-linearities / GroupNorm after the conv add one bandwidth pass (csrc/u3d_act.hip).  With `residual`:
         f(conv(GN(x)) + residual), the tail of ResNetBlock.forward (buildingblocks.py:277-288; `act` = the block's f)."""
@@ -419,6 +420,23 @@ class ConvLayers:
                          sub, b16, *(split[1:] if split is not None else (None, None)))
         family = self._fwd_family(call, residual)
         small = family == "small"
+        dmod = getattr(sc, "dropout", None) if spec.drop == "d" else (getattr(sc, "dropout2d", None) if spec.drop == "D" else None)
+        # record_only (recomputation under activation checkpointing, the block's LAST convolution): y_out still holds this layer's final
+        # output — the block output the forward pass kept — so only what backward needs beside it is rebuilt (the GroupNorm tables of
+        # the layer's input, above): no convolution launch, no in-place activation pass.  Not for post-norm orders (backward wants the
+        # pre-norm tensor z) and not under dropout (its mask belongs to the record).
+        if record_only and y_out is not None and not post and not (dmod is not None and dmod.training and dmod.p > 0.0):
+            if tape is not None:
+                nw = gn.weight if gn is not None else None
+                tape.convs.append(
+                    ConvRec(name, src, affine, mean_rstd, y, nw, conv.weight, G,
+                            self._pindex[id(gn.weight)] if gn is not None else -1,
+                            self._pindex[id(gn.bias)] if gn is not None else self._pindex[id(conv.bias)],
+                            self._pindex[id(conv.weight)], small,
+                            sub.get(id(conv.weight)) if (sub and src.t1 is not None and residual is None) else None,
+                            not post, None, spec.norm, bn_training, None, call.affine_lo, call.affine_hi)
+                )
+            return y, None
         ystats = getattr(self, self._FWD_KERNELS[family])(call)
         post_rec = None
         if post:
@@ -443,7 +461,6 @@ class ConvLayers:
             nat.call("u3d_act_fwd", dev.index, _stream(dev), _p(y), y.numel(), act, slope, _p(y))
             ystats = None
         drop_rec = None
-        dmod = getattr(sc, "dropout", None) if spec.drop == "d" else (getattr(sc, "dropout2d", None) if spec.drop == "D" else None)
         if dmod is not None and dmod.training and dmod.p > 0.0:
             # The MASK comes from torch's generator exactly as the reference draws it (F.dropout on an NCDHW tensor of this
             # shape / feature_dropout's (N,C,1,1,1) noise: same Philox consumption, same element order), applied natively.

@@ -19,7 +19,7 @@ from ._native import U3DSrc
 from ._engine_base import *  # noqa: F401,F403  (explicit __all__: helpers, records, activation codes)
 from ._engine_unet import UNet3DEngine
 
-
+_CKPT_RERUN_LAST = os.environ.get("U3D_CKPT_RERUN_LAST", "0") == "1"  # A/B: recomputation re-runs a block's last convolution too (rounds 4-5)
 
 
 class ResUNetEngine(UNet3DEngine):
@@ -115,9 +115,13 @@ class ResUNetEngine(UNet3DEngine):
         if st2 is None and not self.post_norm:  # conv2's epilogue sums do not describe its (LeakyReLU / ELU) output
             st2 = self._stats_of(src3, None, None, pool, dev)[0]
         se_mod = getattr(bm, "se_module", None)
+        # (recomputation under checkpointing: the block output is still alive in y_out — conv3 is NOT run again, only its record is
+        # rebuilt; U3D_CKPT_RERUN_LAST=1 re-runs it as rounds 4-5 did (A/B; bit-identical).  An SE block's backward needs conv3's own
+        # output, which the forward pass did not keep: re-run.)
+        skip3 = (getattr(self, "_in_recompute", False) and se_mod is None and y_out is not None and not _CKPT_RERUN_LAST)
         y, y_st = self._single_conv_fwd(bm.conv3, name + ".c3", src3, (st2, Cout, 1.0, None, 0, 0.0), pool, tape,
                                         want_stats=se_mod is not None, residual=r, y_out=y_out if se_mod is None else None,
-                                        act=(self.act, self.slope))
+                                        act=(self.act, self.slope), record_only=skip3)
         se = None
         out = y
         if se_mod is not None:
