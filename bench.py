@@ -217,9 +217,35 @@ def main():
               "u3d_conv3d_wgrad_strided": "u3d_conv3d_wgrad"}
     dominant = {"u3d_conv3d", "u3d_conv3d_ex", "u3d_conv3d_ex_reps"}
     calls_per_step, fam_calls = 32, {"u3d_conv3d": 128}
+    prof = None
+
+    def host_prep():
+        """Everything host-side that has to happen once before the clock starts: the timed region's HIP events and the collector pass.
+        It takes 0.1-0.3 s during which the GPU sits idle and drops to its idle clocks — so it runs after the FIRST warm-up step, and the
+        remaining warm-up steps bring the chip back to its working state before the barrier (with it between the last warm-up step and
+        the barrier, as until round 6, the first timed steps ran on ramping clocks: 20 timed steps read 0.07 ms per step more than 100,
+        same box, whatever --warmup was)."""
+        nonlocal prof
+        if not args.no_roofline and rank == 0:
+            # inside the timed region only the DOMINANT MFMA family is bracketed by HIP events (the `roofline` object describes that
+            # family); every other entry point is timed in a few extra steps after it
+            # (its events are created HERE, before the clock starts: first-time event creation is 0.1-0.2 ms of host time each)
+            bracket_all = os.environ.get("U3D_BENCH_BRACKET_ALL") == "1"
+            prof = nat.EventProfiler(flops_only=True, only=None if bracket_all else dominant,
+                                     prealloc=2 * args.steps * ((sum(fam_calls.values()) if bracket_all else calls_per_step) + 4))
+        # Python's cyclic collector: a full (generation 2) pass over this process's objects takes ~75 ms of HOST time, and whether one falls
+        # into the timed region depended on --steps / --warmup through the number of event objects allocated above (measured: 17.4 -> 24-28 ms
+        # per step at --steps 10 --warmup 1..3, the whole difference in the first timed step's enqueue).  Collect now and move everything
+        # alive into the permanent generation; the collector itself stays ON during the timed steps (their garbage is young and cheap).
+        import gc
+
+        gc.collect()
+        gc.freeze()
+
+    prep_early = os.environ.get("U3D_BENCH_PREP_LAST") != "1"  # (A/B: 1 = the preparation between the last warm-up step and the barrier)
     for w in range(args.warmup):
-        if w == args.warmup - 1 and not args.no_roofline and rank == 0:
-            # the last warm-up step finds the dominant MFMA family (HIP events around every call that declares FLOPs), so that the
+        if w == (0 if prep_early else args.warmup - 1) and not args.no_roofline and rank == 0:
+            # the first warm-up step finds the dominant MFMA family (HIP events around every call that declares FLOPs), so that the
             # TIMED region only brackets that family: an event pair costs ~2 us of device time, ~110 MFMA calls per step
             # would cost ~0.4 ms (2.5 %) of every timed step
             scout = nat.EventProfiler(flops_only=True)
@@ -237,29 +263,16 @@ def main():
                 calls_per_step = fam_calls[top]
         else:
             step()
+        if w == 0 and prep_early:
+            host_prep()
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    prof = None
-    if not args.no_roofline and rank == 0:
-        # inside the timed region only the DOMINANT MFMA family is bracketed by HIP events (the `roofline` object describes that
-        # family); every other entry point is timed in a few extra steps after it
-        # (its events are created HERE, before the clock starts: first-time event creation is 0.1-0.2 ms of host time each)
-        bracket_all = os.environ.get("U3D_BENCH_BRACKET_ALL") == "1"
-        prof = nat.EventProfiler(flops_only=True, only=None if bracket_all else dominant,
-                                 prealloc=2 * args.steps * ((sum(fam_calls.values()) if bracket_all else calls_per_step) + 4))
-        nat.profiler = prof
-    # Python's cyclic collector: a full (generation 2) pass over this process's objects takes ~75 ms of HOST time, and whether one falls
-    # into the timed region depended on --steps / --warmup through the number of event objects allocated above (measured: 17.4 -> 24-28 ms
-    # per step at --steps 10 --warmup 1..3, the whole difference in the first timed step's enqueue).  Collect now and move everything
-    # alive into the permanent generation; the collector itself stays ON during the timed steps (their garbage is young and cheap).
-    import gc
-
-    gc.collect()
-    gc.freeze()
+    if not prep_early or args.warmup == 0:
+        host_prep()
     barrier()
     t0 = time.perf_counter()
     host_marks = []
