@@ -16,6 +16,7 @@ Rank 0 prints ONE JSON line (contract in the task description) extended with
   "cpu_baseline": the CPU oracle (port of the reference path on ATen CPU operators) timed on this box's host cores
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -237,8 +238,6 @@ def main():
         # into the timed region depended on --steps / --warmup through the number of event objects allocated above (measured: 17.4 -> 24-28 ms
         # per step at --steps 10 --warmup 1..3, the whole difference in the first timed step's enqueue).  Collect now and move everything
         # alive into the permanent generation; the collector itself stays ON during the timed steps (their garbage is young and cheap).
-        import gc
-
         gc.collect()
         gc.freeze()
 
@@ -281,10 +280,16 @@ def main():
     # an average launch duration over the timed region, not every launch of it: every `bracket_every`-th timed step is bracketed
     # (steps 0, 10, 20, ..), the others run as a user's step does.  U3D_BENCH_BRACKET_EVERY=1: every step (the round-5 behaviour).
     bracket_every = max(1, int(os.environ.get("U3D_BENCH_BRACKET_EVERY", "10")))
-    n_bracketed = (args.steps + bracket_every - 1) // bracket_every
+    # (the bracketed steps are every/2, every/2 + every, ..: NOT the first timed step — right after the barrier the host has no lead over the
+    # GPU, the launches of that step arrive spaced out and its kernels run on a chip that has just idled: the family read 0.82 of peak there
+    # against 0.77-0.78 in steady-state steps and rocprofv3's 0.78-0.79; U3D_BENCH_BRACKET_PHASE)
+    bracket_phase = int(os.environ.get("U3D_BENCH_BRACKET_PHASE", str(bracket_every // 2))) % bracket_every
+    if args.steps <= bracket_phase:
+        bracket_phase = 0
+    n_bracketed = len([i for i in range(args.steps) if i % bracket_every == bracket_phase])
     for i_step in range(args.steps):
         if prof is not None:
-            nat.profiler = prof if i_step % bracket_every == 0 else None
+            nat.profiler = prof if i_step % bracket_every == bracket_phase else None
         loss = step()
         if os.environ.get("U3D_BENCH_HOST_TRACE") == "1":
             host_marks.append(time.perf_counter() - t0)  # (debugging aid: when each step's launches were all enqueued)
@@ -380,7 +385,7 @@ def main():
                 "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                 "frac_source": f"HIP events on the launching stream around every launch of the family in {n_bracketed} of the {args.steps} timed "
-                               f"steps of this run (every {bracket_every}th; an event pair costs ~7 us of stream time, which is inside `value`)",
+                               f"steps of this run (every {bracket_every}th, from timed step {bracket_phase} on; an event pair costs ~7 us of stream time, which is inside `value`)",
                 # (the same family by rocprofv3 kernel durations is in profiles/*_tables.md, generated from a profile of this command; it is
                 # not repeated here: a number read from a committed file would sit beside the live one as if it described HEAD — ADVICE r05)
                 # NOT the contract's peak: what a bare fp32-MFMA stream sustains on this box right now, by operand data
