@@ -1,1 +1,1 @@
-U3D_PROFILES_CORE=1 bash tools/run_profiles.sh r06f
+bash tools/run_profiles_cfg4.sh r06f_cfg4 --act-bf16
