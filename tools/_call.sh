@@ -1,3 +1,3 @@
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | cut -c1-300
-timeout 1200 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|rror" | tail -3 | tee gpurun_out/r06f_gputests.log
-python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 | cut -c1-260
+M="python tools/model_bench.py --name UNet3D --f-maps 32 --levels 4 --batch 1 --steps 15 --warmup 5 --no-events"
+for p in 80,170,170 80,168,168 64,128,128; do $M --patch $p 2>/dev/null | tail -1 | cut -c1-200; done
+for p in 112,234,234 112,232,232; do $M --patch $p --forward-only 2>/dev/null | tail -1 | cut -c1-200; done
