@@ -415,9 +415,9 @@ def main():
                 opt.step()                                     # :246
                 return val
 
-            for _ in range(2):
+            gc.collect()  # (before the warm-up steps, not between them and the clock: idle GPU time right before a timed region is paid
+            for _ in range(3):  # back as two steps on clocks ramping up from idle, profiles/r06f_step_family_times.txt)
                 step_ref_order()
-            gc.collect()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(args.steps):
@@ -467,9 +467,9 @@ def main():
                     opt2.step()
                     return loss2
 
-                for _ in range(args.warmup):
-                    step2()
                 gc.collect()
+                for _ in range(max(args.warmup, 3)):
+                    step2()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 for _ in range(args.steps):
