@@ -1,3 +1,8 @@
-M="python tools/model_bench.py --name UNet3D --f-maps 32 --levels 4 --batch 1 --steps 15 --warmup 5 --no-events"
-for p in 80,170,170 80,168,168 64,128,128; do $M --patch $p 2>/dev/null | tail -1 | cut -c1-200; done
-for p in 112,234,234 112,232,232; do $M --patch $p --forward-only 2>/dev/null | tail -1 | cut -c1-200; done
+python tools/_ab_reduce.py 2>&1 | tail -6
+timeout 900 python -m pytest tests/test_gpu_kernels.py -q -k "wgrad" 2>&1 | grep -E "passed|failed|rror" | tail -2
+ms() { python -c "import sys,json; print('$1', json.loads([l for l in sys.stdin.read().strip().splitlines() if l.startswith('{')][-1])['ms_per_step'])"; }
+B="python bench.py --no-cpu-baseline --no-roofline --no-extras --steps 100 --warmup 10"
+for i in 1 2 3; do
+U3D_TUNE=23:2 $B 2>/dev/null | ms "4-byte "
+$B 2>/dev/null | ms "16-byte"
+done
